@@ -1,0 +1,88 @@
+"""ctypes binding of the CPU oracle (oracle/libzkoracle.so).  TEST-ONLY: product code never imports this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_DIR = os.path.join(_HERE, "..", "oracle")
+_LIB = os.path.join(_ORACLE_DIR, "libzkoracle.so")
+
+u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR])
+
+
+def load():
+    if not os.path.exists(_LIB):
+        build()
+    lib = C.CDLL(_LIB)
+    sz, u32, u64, vp = C.c_size_t, C.c_uint32, C.c_uint64, C.c_void_p
+    sig = {
+        "zko_fp_mul": (u32, [u32, u32]), "zko_fp_encode": (u32, [u32]), "zko_fp_decode": (u32, [u32]),
+        "zko_fp_inv": (u32, [u32]), "zko_rou_fwd": (u32, [C.c_uint]), "zko_rou_rev": (u32, [C.c_uint]),
+        "zko_fp4_mul": (None, [u32p, u32p, u32p]), "zko_fp4_inv": (None, [u32p, u32p]),
+        "zko_poseidon2_mix": (None, [u32p]),
+        "zko_hash_elem_slice": (None, [u32p, sz, sz, u32p]), "zko_hash_pair": (None, [u32p, u32p, u32p]),
+        "zko_batch_interpolate_ntt": (None, [u32p, sz, sz]),
+        "zko_batch_expand_into_evaluate_ntt": (None, [u32p, sz, u32p, sz, sz, sz]),
+        "zko_batch_bit_reverse": (None, [u32p, sz, sz]), "zko_zk_shift": (None, [u32p, sz, sz]),
+        "zko_hash_rows": (None, [u32p, sz, u32p, sz]), "zko_hash_fold": (None, [u32p, sz, sz]),
+        "zko_batch_evaluate_any": (None, [u32p, sz, sz, u32p, u32p, sz, u32p]),
+        "zko_mix_poly_coeffs": (None, [u32p, u32p, u32p, u32p, u32p, sz, sz]),
+        "zko_eltwise_add_elem": (None, [u32p, u32p, u32p, sz]),
+        "zko_eltwise_sum_extelem": (None, [u32p, sz, u32p, sz]),
+        "zko_fri_fold": (None, [u32p, sz, u32p, u32p]),
+        "zko_gather_sample": (None, [u32p, u32p, sz, sz, sz]),
+        "zko_prefix_products": (None, [u32p, sz]),
+        "zko_poly_interpolate": (None, [u32p, u32p, u32p, sz]),
+        "zko_poly_eval": (None, [u32p, sz, u32p, u32p]),
+        "zko_poly_divide": (None, [u32p, sz, u32p, u32p]),
+        "zko_circuit_load": (C.c_char_p, [u32p, sz, C.POINTER(vp)]), "zko_circuit_free": (None, [vp]),
+        "zko_poly_ext": (None, [vp, u32p, u32p, C.POINTER(vp), u32p]),
+        "zko_eval_check": (None, [vp, u32p, C.POINTER(vp), C.POINTER(vp), u32p, C.c_uint]),
+        "zko_syn_cell": (u32, [u64, u32, u32, u32]),
+        "zko_syn_witgen": (None, [vp, C.c_uint, C.c_uint, u64, u64, u32p, u32p, u32p]),
+        "zko_syn_accum": (None, [vp, C.c_uint, C.c_uint, u64, u32p, u32p, u32p]),
+        "zko_prove_segment": (C.POINTER(u32), [vp, C.c_uint, C.c_uint, u64, u64, C.POINTER(sz), C.POINTER(C.c_char_p)]),
+        "zko_verify_segment": (C.c_char_p, [vp, u32p, sz]),
+        "zko_free": (None, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(lib, name)
+        f.restype, f.argtypes = res, args
+    return lib
+
+
+class OracleCircuit:
+    def __init__(self, lib, desc):
+        self.lib = lib
+        self.desc = np.ascontiguousarray(desc, dtype=np.uint32)
+        h = C.c_void_p()
+        err = lib.zko_circuit_load(self.desc, self.desc.size, C.byref(h))
+        if err:
+            raise RuntimeError(err.decode())
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.zko_circuit_free(self.h)
+            self.h = None
+
+    def prove(self, po2, zk_cycles=1994, seed=0x5EED0000, noise_seed=0x2E80):
+        n = C.c_size_t()
+        err = C.c_char_p()
+        p = self.lib.zko_prove_segment(self.h, po2, zk_cycles, seed, noise_seed, C.byref(n), C.byref(err))
+        if not p:
+            raise RuntimeError((err.value or b"?").decode())
+        seal = np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+        self.lib.zko_free(p)
+        return seal
+
+    def verify(self, seal):
+        seal = np.ascontiguousarray(seal, dtype=np.uint32)
+        err = self.lib.zko_verify_segment(self.h, seal, seal.size)
+        return None if not err else err.decode()

@@ -1,0 +1,99 @@
+"""SYN-AIR: the declared-synthetic stand-in circuit for the (un-obtainable) rv32im constraint system.
+
+The real rv32im-v2 constraint polynomial, tap set and witness generator are Zirgen-generated artefacts of
+risc0-circuit-rv32im 4.0.2 (/root/reference/Cargo.lock:5320) and are not available offline (SURVEY.md §7
+hard part 1).  SYN-AIR has the same *shape* — three register groups (accum, code, data), back-0/back-1 taps,
+degree-5 constraints gated by code selectors, an accum group that is a grand product over Fp4 driven by
+Fiat-Shamir `mix` globals — so every HAL op and the whole DEEP-ALI + FRI protocol is exercised, and a
+random trace is made satisfying by construction.  The witness definition lives in DESIGN.md §SYN-AIR and is
+implemented twice: oracle/circuit.c (CPU) and zeth_amd/csrc/witgen.hip (HIP).
+
+Columns (n rows, A = n - zk_cycles active rows):
+  code : c0 active, c1 first, c2 body (active & !first), c3 row index, c4 last (row A-1), c5.. public noise
+  data : triples (3j, 3j+1, 3j+2 = product) for j < T = (wd-2)//3; col wd-2 = d0*d1*d3*d4; col wd-1 = running
+         sum s: s[0] = d0[0], s[r] = s[r-1] + d0[r] + c3[r]*d1[r]
+  accum: k = wa/4 Fp4 columns, a_e[r] = prod_{r' <= r} (mix_e + d_{e mod wd}[r'])
+Globals: out = (s[A-1], 0, 0, 0); mix = k Fp4 challenges (4k words).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .desc import GLOBAL_MIX, GLOBAL_OUT, GROUP_ACCUM, GROUP_CODE, GROUP_DATA, P, CircuitBuilder
+
+NBETA = P - 11
+
+
+def build_syn_air(wc: int = 16, wd: int = 208, wa: int = 32) -> np.ndarray:
+    assert wc >= 5 and wd >= 8 and wa >= 4 and wa % 4 == 0
+    b = CircuitBuilder((wa, wc, wd), (4, wa))
+    code = lambda c, back=0: b.get(GROUP_CODE, c, back)
+    data = lambda c, back=0: b.get(GROUP_DATA, c, back)
+    acc = lambda c, back=0: b.get(GROUP_ACCUM, c, back)
+    one = b.const(1)
+    nbeta = b.const(NBETA)
+    active, first, body, rowidx, last = (code(i) for i in range(5))
+    T = (wd - 2) // 3
+    s_col = wd - 1
+
+    # (A) multiplicative triples + the degree-4 product, gated by `active` (max degree 5)
+    inner = b.true()
+    for j in range(T):
+        inner = b.and_eqz(inner, b.sub(b.mul(data(3 * j), data(3 * j + 1)), data(3 * j + 2)))
+    prod4 = b.mul(b.mul(data(0), data(1)), b.mul(data(3), data(4)))
+    inner = b.and_eqz(inner, b.sub(prod4, data(wd - 2)))
+    chain = b.and_cond(b.true(), active, inner)
+
+    def term(e):          # mix_e + d (as Fp4 components)
+        m = [b.get_global(GLOBAL_MIX, 4 * e + i) for i in range(4)]
+        return [b.add(m[0], data(e % wd)), m[1], m[2], m[3]]
+
+    def ext_mul(x, y):    # Fp4 product written out in Fp steps (x^4 = -11)
+        m = lambda i, j: b.mul(x[i], y[j])
+        c0 = b.add(m(0, 0), b.mul(nbeta, b.add(b.add(m(1, 3), m(2, 2)), m(3, 1))))
+        c1 = b.add(b.add(m(0, 1), m(1, 0)), b.mul(nbeta, b.add(m(2, 3), m(3, 2))))
+        c2 = b.add(b.add(b.add(m(0, 2), m(1, 1)), m(2, 0)), b.mul(nbeta, m(3, 3)))
+        c3 = b.add(b.add(m(0, 3), m(1, 2)), b.add(m(2, 1), m(3, 0)))
+        return [c0, c1, c2, c3]
+
+    # (first) s = d0 ; a_e = term_e
+    inner = b.and_eqz(b.true(), b.sub(data(s_col), data(0)))
+    for e in range(wa // 4):
+        t = term(e)
+        for i in range(4):
+            inner = b.and_eqz(inner, b.sub(acc(4 * e + i), t[i]))
+    chain = b.and_cond(chain, first, inner)
+
+    # (body) s = s@1 + d0 + row*d1 ; a_e = a_e@1 * term_e
+    rhs = b.add(b.add(data(s_col, 1), data(0)), b.mul(rowidx, data(1)))
+    inner = b.and_eqz(b.true(), b.sub(data(s_col), rhs))
+    for e in range(wa // 4):
+        prev = [acc(4 * e + i, 1) for i in range(4)]
+        pr = ext_mul(prev, term(e))
+        for i in range(4):
+            inner = b.and_eqz(inner, b.sub(acc(4 * e + i), pr[i]))
+    chain = b.and_cond(chain, body, inner)
+
+    # (last) s = out[0]
+    inner = b.and_eqz(b.true(), b.sub(data(s_col), b.get_global(GLOBAL_OUT, 0)))
+    chain = b.and_cond(chain, last, inner)
+
+    # selector sanity (ungated)
+    chain = b.and_eqz(chain, b.mul(active, b.sub(one, active)))
+    chain = b.and_eqz(chain, b.mul(first, b.sub(one, first)))
+    chain = b.and_eqz(chain, b.sub(b.sub(active, first), body))
+    return b.finish(chain)
+
+
+# named shapes
+def syn_a() -> np.ndarray:
+    """SYN-A: W_code 16, W_data 208, W_accum 32."""
+    return build_syn_air(16, 208, 32)
+
+
+def syn_tiny() -> np.ndarray:
+    return build_syn_air(6, 11, 4)
+
+
+def syn_small() -> np.ndarray:
+    return build_syn_air(8, 20, 8)
