@@ -1,0 +1,175 @@
+/*
+ * zkhal.h — C ABI of libzkhal_mi355x.so: an MI355X (gfx950) implementation of the operator set behind
+ * risc0_zkp::hal::{Hal, CircuitHal, Buffer}, plus the per-segment prover that drives it.
+ *
+ * What this replaces.  risc0/zeth reaches the prover through exactly one call,
+ *     default_prover().prove(env, elf)            /root/reference/crates/host/src/lib.rs:137
+ * (imports at lib.rs:26; segment size chosen at lib.rs:132-135; result checked by receipt.verify at
+ * /root/reference/crates/host/src/bin/cli.rs:103-107).  Below that call sits the un-vendored
+ * risc0-zkp 3.0.2 (/root/reference/Cargo.lock:5393): `prove::Prover<H: Hal>` issues every op declared
+ * here through `hal::Hal` (src/hal/mod.rs) — upstream backends: CpuHal (src/hal/cpu.rs), CudaHal
+ * (src/hal/cuda.rs + risc0-sys kernels).  Each entry point below names the trait method it stands in for.
+ * A Rust `impl Hal for HipHal` binds these 1:1 (INTEGRATION.md shows the extern block).
+ *
+ * Conventions (same as upstream's risc0-sys C exports):
+ *   - every function returns `const char*`: NULL on success, otherwise a heap error string that the
+ *     caller releases with zkh_free_error();
+ *   - element words are raw Montgomery-form BabyBear u32 exactly as upstream stores `Elem` in memory and in
+ *     seals; Elem = 1 word, ExtElem = 4 words (AoS), Digest = 8 words;
+ *   - matrices are column-major like upstream Buffer<T>: element (row r, column c) at c*rows + r;
+ *   - a zkh_ctx is one GPU + one HIP stream, driven by one host thread at a time (upstream HALs are driven
+ *     by a single prover thread).  Ops are enqueued in order on the ctx stream and are asynchronous;
+ *     zkh_read / zkh_sync are the only host-visible sync points;
+ *   - zkh_buf handles are reference counted views {allocation, word offset, word length}; slices share the
+ *     allocation.  Host pointers are borrowed for the duration of the call only.
+ *   - There is NO CPU fallback in this library: without a HIP device every call fails.
+ */
+#ifndef ZKHAL_H
+#define ZKHAL_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zkh_ctx zkh_ctx;
+typedef struct zkh_buf zkh_buf;
+typedef struct zkh_circuit zkh_circuit;
+typedef struct zkh_prover zkh_prover;
+
+/* protocol constants — risc0-zkp 3.0.2 src/lib.rs */
+#define ZKH_INV_RATE 4
+#define ZKH_QUERIES 50
+#define ZKH_FRI_FOLD 16
+#define ZKH_FRI_MIN_DEGREE 256
+#define ZKH_ZK_CYCLES 1994
+#define ZKH_CHECK_SIZE 16
+#define ZKH_EXT_SIZE 4
+#define ZKH_DIGEST_WORDS 8
+
+void zkh_free_error(const char* err);
+/* library/ABI version and the gfx arch the kernels were compiled for ("gfx950") */
+const char* zkh_version(void);
+
+/* ---- context: CudaHal::new / HalPair (hal/cuda.rs) ---- */
+/* hash_suite must be "poseidon2" (the suite zeth's default ProverOpts selects). */
+const char* zkh_ctx_create(int device_ordinal, const char* hash_suite, zkh_ctx** out);
+void zkh_ctx_destroy(zkh_ctx*);
+const char* zkh_sync(zkh_ctx*);
+/* raw hipStream_t of the context (for callers that interleave their own work) */
+void* zkh_ctx_stream(zkh_ctx*);
+/* Replace the Poseidon2 tables (canonical residues): rc[24*29], diag[24] — consts.rs as data. */
+const char* zkh_poseidon2_set_constants(zkh_ctx*, const uint32_t* rc, const uint32_t* diag);
+
+/* ---- Buffer<T>: alloc_* / copy_from_* / slice / view / get_at (hal/mod.rs trait Buffer) ---- */
+const char* zkh_alloc(zkh_ctx*, const char* name, size_t n_words, int zero, zkh_buf** out);
+const char* zkh_copy_from(zkh_ctx*, const char* name, const uint32_t* host, size_t n_words, zkh_buf** out);
+/* wrap device memory owned by the caller (e.g. a torch tensor's data_ptr); never freed by the library */
+const char* zkh_wrap(zkh_ctx*, void* device_ptr, size_t n_words, zkh_buf** out);
+const char* zkh_slice(zkh_buf*, size_t off_words, size_t n_words, zkh_buf** out);
+void zkh_retain(zkh_buf*);
+void zkh_release(zkh_buf*);
+size_t zkh_size(const zkh_buf*);
+void* zkh_device_ptr(const zkh_buf*);
+/* view(): synchronises the stream, then D2H */
+const char* zkh_read(zkh_ctx*, const zkh_buf*, uint32_t* host, size_t off_words, size_t n_words);
+/* view_mut()/copy: H2D ordered on the stream */
+const char* zkh_write(zkh_ctx*, zkh_buf*, const uint32_t* host, size_t off_words, size_t n_words);
+
+/* ---- trait Hal ops (hal/mod.rs); semantics = CpuHal (hal/cpu.rs) ---- */
+/* Hal::batch_interpolate_ntt(io, count): per column inverse NTT, natural in -> bit-reversed coeffs, * n^-1 */
+const char* zkh_batch_interpolate_ntt(zkh_ctx*, zkh_buf* io, size_t count);
+/* Hal::batch_expand_into_evaluate_ntt(out, in, count, expand_bits) */
+const char* zkh_batch_expand_into_evaluate_ntt(zkh_ctx*, zkh_buf* out, const zkh_buf* in, size_t count,
+                                               size_t expand_bits);
+/* Hal::batch_bit_reverse(io, count) */
+const char* zkh_batch_bit_reverse(zkh_ctx*, zkh_buf* io, size_t count);
+/* Hal::zk_shift(io, count): io[c][i] *= 3^bitrev(i) */
+const char* zkh_zk_shift(zkh_ctx*, zkh_buf* io, size_t count);
+/* Fused Prover::commit_group prefix: interpolate_ntt + zk_shift in one pass over HBM (same result as the
+ * two calls above in sequence). */
+const char* zkh_batch_interpolate_ntt_zk_shift(zkh_ctx*, zkh_buf* io, size_t count);
+/* Out-of-place variant that also absorbs commit_group's eltwise_copy_elem: out = iNTT(in) [* 3^bitrev(i)];
+ * `in` (the witness) is left untouched. */
+const char* zkh_batch_interpolate_ntt_from(zkh_ctx*, zkh_buf* out, const zkh_buf* in, size_t count, int zk_shift);
+/* Hal::hash_rows(output, matrix): rows = output digests; leaf r = Poseidon2 sponge over matrix[c*rows + r] */
+const char* zkh_hash_rows(zkh_ctx*, zkh_buf* out_digests, const zkh_buf* matrix);
+/* Hal::hash_fold(io, input_size, output_size): io[out+i] = H(io[in+2i], io[in+2i+1]) */
+const char* zkh_hash_fold(zkh_ctx*, zkh_buf* io_digests, size_t input_size, size_t output_size);
+/* Fused MerkleTreeProver::new tail: every hash_fold layer from `rows` leaves down to the root.
+ * nodes has 2*rows digests, leaves already at [rows, 2*rows). */
+const char* zkh_merkle_fold_all(zkh_ctx*, zkh_buf* nodes, size_t rows);
+/* Hal::batch_evaluate_any(coeffs, poly_count, which, xs, out): out[k] = sum_j coeffs[which[k]][j] xs[k]^j */
+const char* zkh_batch_evaluate_any(zkh_ctx*, const zkh_buf* coeffs, size_t poly_count, const zkh_buf* which,
+                                   const zkh_buf* xs, zkh_buf* out);
+/* Hal::mix_poly_coeffs(output, mix_start, mix, input, combos, input_size, count) */
+const char* zkh_mix_poly_coeffs(zkh_ctx*, zkh_buf* out, const uint32_t mix_start[4], const uint32_t mix[4],
+                                const zkh_buf* in, const zkh_buf* combos, size_t input_size, size_t count);
+/* Hal::combos_prepare: combos[combo_of_reg*cycles + i] -= mix^reg * coeff_u[...]  (flattened on the host into
+ * (position, value) pairs: combos[pos[k]] -= val[k]) */
+const char* zkh_combos_prepare(zkh_ctx*, zkh_buf* combos, const uint32_t* pos, const uint32_t* vals_ext,
+                               size_t n_entries);
+/* Hal::combos_divide: synthetic division of combo polynomial `combo` (cycles ExtElems at combos[combo*cycles..])
+ * by (x - pt) for every pt in pts; remainders (must be 0) are written to rem_out (n_pts ExtElems, device). */
+const char* zkh_combos_divide(zkh_ctx*, zkh_buf* combos, size_t combo, size_t cycles, const uint32_t* pts_ext,
+                              size_t n_pts, zkh_buf* rem_out);
+/* Hal::eltwise_add_elem / eltwise_copy_elem / eltwise_zeroize_elem / eltwise_sum_extelem */
+const char* zkh_eltwise_add_elem(zkh_ctx*, zkh_buf* out, const zkh_buf* a, const zkh_buf* b);
+const char* zkh_eltwise_copy_elem(zkh_ctx*, zkh_buf* out, const zkh_buf* in);
+const char* zkh_eltwise_zeroize_elem(zkh_ctx*, zkh_buf* io);   /* INVALID (0xffffffff) -> 0 */
+const char* zkh_eltwise_sum_extelem(zkh_ctx*, zkh_buf* out_elem, const zkh_buf* in_ext);
+/* Hal::fri_fold(output, input, mix) */
+const char* zkh_fri_fold(zkh_ctx*, zkh_buf* out, const zkh_buf* in, const uint32_t mix[4]);
+/* Hal::gather_sample(dst, src, idx, size, stride): dst[g] = src[g*stride + idx] */
+const char* zkh_gather_sample(zkh_ctx*, zkh_buf* dst, const zkh_buf* src, size_t idx, size_t size, size_t stride);
+/* Hal::scatter(into, index, offsets, values) */
+const char* zkh_scatter(zkh_ctx*, zkh_buf* into, const uint32_t* index, const uint32_t* offsets,
+                        const uint32_t* values, size_t n_idx, size_t n_val);
+/* Hal::prefix_products(io): io[i] *= io[i-1] over ExtElems */
+const char* zkh_prefix_products(zkh_ctx*, zkh_buf* io_ext);
+/* batched MerkleTreeProver::prove for many indices at once (query phase): for each idx writes
+ * (cols column words, then the path digests down to the top layer) consecutively into `out` (device).
+ * words per query = cols + 8*(log2(rows) - top_layer). */
+const char* zkh_merkle_open(zkh_ctx*, const zkh_buf* matrix, const zkh_buf* nodes, size_t rows, size_t cols,
+                            const uint32_t* idx, size_t n_idx, zkh_buf* out);
+
+/* ---- CircuitHal (risc0-circuit-rv32im 4.0.2 src/prove/hal/*; circuit is data: zeth_amd/circuits/desc.py) ---- */
+const char* zkh_circuit_load(zkh_ctx*, const uint32_t* desc, size_t n_words, zkh_circuit** out);
+void zkh_circuit_destroy(zkh_circuit*);
+/* 1 if a build-time generated straight-line eval_check kernel matches this desc, 0 if the on-device step
+ * interpreter will be used. */
+int zkh_circuit_has_compiled_kernel(const zkh_circuit*);
+/* CircuitHal::eval_check(check, groups, globals, poly_mix, po2, steps).  groups = evaluated accum, code, data
+ * (each W x 4n); globals = out, mix.  use_interpreter != 0 forces the generic interpreter kernel. */
+const char* zkh_eval_check(zkh_ctx*, const zkh_circuit*, zkh_buf* check, const zkh_buf* const* groups,
+                           const zkh_buf* const* globals, const uint32_t poly_mix[4], size_t po2,
+                           int use_interpreter);
+
+/* ---- SYN-AIR witness generation on device (stands in for risc0-circuit-rv32im witgen) ---- */
+const char* zkh_syn_witgen(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cycles, uint64_t seed,
+                           uint64_t noise_seed, zkh_buf* code, zkh_buf* data, uint32_t out_global[4]);
+const char* zkh_syn_accum(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cycles, uint64_t noise_seed,
+                          const zkh_buf* data, const uint32_t* mix_global, zkh_buf* accum);
+
+/* ---- segment prover: SegmentProver::prove_segment + risc0_zkp::prove::Prover ---- */
+const char* zkh_prover_create(zkh_ctx*, const zkh_circuit*, zkh_prover** out);
+void zkh_prover_destroy(zkh_prover*);
+/* Seal one segment whose code/data traces are already resident in HBM (W x 2^po2 each).  On success *seal is
+ * a malloc'd word array (release with zkh_free_seal). */
+const char* zkh_prove_segment(zkh_prover*, size_t po2, size_t zk_cycles, uint64_t noise_seed, const zkh_buf* code,
+                              const zkh_buf* data, const uint32_t out_global[4], uint32_t** seal,
+                              size_t* seal_words);
+void zkh_free_seal(uint32_t* seal);
+
+/* ---- profiling: per-kernel HIP-event timing on the ctx stream ---- */
+const char* zkh_prof_enable(zkh_ctx*, int on);
+/* writes up to cap records; returns count via *n.  Each record: name (<=47 chars), calls, total_ms */
+typedef struct { char name[48]; uint64_t calls; double total_ms; double alg_bytes; } zkh_prof_rec;
+const char* zkh_prof_get(zkh_ctx*, zkh_prof_rec* recs, size_t cap, size_t* n);
+const char* zkh_prof_reset(zkh_ctx*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,36 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+P = 2013265921
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure only)."""
+    import zko
+    return zko.load()
+
+
+@pytest.fixture(scope="session")
+def hal():
+    """The product HAL on cuda:0 — fails loudly (no fallback) if the HIP library or the GPU is missing."""
+    from zeth_amd.hal import HipHal
+    h = HipHal(0)
+    yield h
+    h.close()
+
+
+def rand_fp(rng, *shape):
+    """Uniform field elements in Montgomery form (every u32 < P is a valid Montgomery word)."""
+    return rng.integers(0, P, size=shape, dtype=np.uint64).astype(np.uint32)

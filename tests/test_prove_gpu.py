@@ -1,0 +1,110 @@
+"""Whole-seal parity: HIP prover (through the C ABI) vs the CPU oracle prover, byte for byte, plus the independent
+verifier restatement as the acceptance test (the analogue of cli.rs:103 `receipt.verify`)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import zko
+from conftest import rand_fp
+from zeth_amd.circuits import syn_air
+from zeth_amd.prover import Segment, SegmentProver
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {"tiny": syn_air.syn_tiny, "small": syn_air.syn_small, "syn_a": syn_air.syn_a}
+
+
+def _witness_parity(hal, oracle, desc, po2, zk):
+    circ = hal.load_circuit(desc)
+    oc = zko.OracleCircuit(oracle, desc)
+    wa, wc, wd = (int(x) for x in desc[3:6])
+    n = 1 << po2
+    code, data = hal.alloc_elem("code", wc * n), hal.alloc_elem("data", wd * n)
+    out = hal.syn_witgen(circ, po2, zk, 77, 99, code, data)
+    ocode, odata, oout = np.zeros(wc * n, np.uint32), np.zeros(wd * n, np.uint32), np.zeros(4, np.uint32)
+    oracle.zko_syn_witgen(oc.h, po2, zk, 77, 99, ocode, odata, oout)
+    assert np.array_equal(code.to_vec(), ocode)
+    assert np.array_equal(data.to_vec(), odata)
+    assert np.array_equal(out, oout)
+    mix = rand_fp(np.random.default_rng(1), wa)
+    accum = hal.alloc_elem("accum", wa * n)
+    hal.syn_accum(circ, po2, zk, 99, data, mix, accum)
+    oacc = np.zeros(wa * n, np.uint32)
+    oracle.zko_syn_accum(oc.h, po2, zk, 99, odata, mix, oacc)
+    assert np.array_equal(accum.to_vec(), oacc)
+    return circ, oc, (code, data, accum), (ocode, odata, oacc), (out, mix)
+
+
+@pytest.mark.parametrize("shape,po2,zk", [("tiny", 9, 100), ("small", 12, 1994)])
+def test_witgen_and_eval_check_parity(hal, oracle, shape, po2, zk):
+    desc = SHAPES[shape]()
+    circ, oc, (code, data, accum), (ocode, odata, oacc), (out, mix) = _witness_parity(hal, oracle, desc, po2, zk)
+    wa, wc, wd = (int(x) for x in desc[3:6])
+    n, dom = 1 << po2, 4 << po2
+    # evaluate every group on the 4n coset with both implementations, then eval_check
+    ev, oev = [], []
+    for buf, host, w in ((accum, oacc, wa), (code, ocode, wc), (data, odata, wd)):
+        co = hal.alloc_elem("co", w * n)
+        hal.batch_interpolate_ntt_from(co, buf, w, True)
+        e = hal.alloc_elem("ev", w * dom)
+        hal.batch_expand_into_evaluate_ntt(e, co, w, 2)
+        ev.append(e)
+        h = host.copy()
+        oracle.zko_batch_interpolate_ntt(h, h.size, w)
+        oracle.zko_zk_shift(h, h.size, w)
+        oe = np.zeros(w * dom, np.uint32)
+        oracle.zko_batch_expand_into_evaluate_ntt(oe, oe.size, h, h.size, w, 2)
+        oev.append(oe)
+        assert np.array_equal(e.to_vec(), oe)
+    poly_mix = rand_fp(np.random.default_rng(2), 4)
+    want = np.zeros(4 * dom, np.uint32)
+    gp = (C.c_void_p * 3)(*[a.ctypes.data for a in oev])
+    glp = (C.c_void_p * 2)(out.ctypes.data, mix.ctypes.data)
+    oracle.zko_eval_check(oc.h, want, gp, glp, poly_mix, po2)
+    g_out, g_mix = hal.copy_from("out", out), hal.copy_from("mix", mix)
+    for interp in (True, False):
+        check = hal.alloc_elem("check", 4 * dom)
+        circ.eval_check(check, ev, [g_out, g_mix], poly_mix, po2, use_interpreter=interp)
+        assert np.array_equal(check.to_vec(), want), f"eval_check mismatch (interpreter={interp})"
+    assert circ.has_compiled_kernel()
+
+
+@pytest.mark.parametrize("shape,po2,zk", [("tiny", 9, 100), ("tiny", 13, 1994), ("small", 12, 1994), ("small", 14, 1994)])
+def test_seal_bit_exact_vs_oracle(hal, oracle, shape, po2, zk):
+    desc = SHAPES[shape]()
+    prover = SegmentProver(hal, desc)
+    seg = Segment(index=0, po2=po2, seed=0x5EED0000 + po2, noise_seed=0x2E80, zk_cycles=zk)
+    receipt = prover.prove_segment(seg)
+    oc = zko.OracleCircuit(oracle, desc)
+    want = oc.prove(po2, zk, seg.seed, seg.noise_seed)
+    assert receipt.seal.size == want.size
+    assert np.array_equal(receipt.seal, want), "HIP seal differs from the CPU oracle seal"
+    assert oc.verify(receipt.seal) is None
+    bad = receipt.seal.copy()
+    bad[bad.size // 3] ^= 1
+    assert oc.verify(bad) is not None
+
+
+def test_seal_syn_a_po2_16_verifies(hal, oracle):
+    """SYN-A column counts at 1/16 of the BASELINE segment size: oracle verifier must accept; seal equality too."""
+    desc = syn_air.syn_a()
+    prover = SegmentProver(hal, desc)
+    seg = Segment(index=3, po2=16, seed=0x5EED0003)
+    receipt = prover.prove_segment(seg)
+    oc = zko.OracleCircuit(oracle, desc)
+    assert oc.verify(receipt.seal) is None
+    want = oc.prove(16, seg.zk_cycles, seg.seed, seg.noise_seed)
+    assert np.array_equal(receipt.seal, want)
+
+
+def test_seal_full_size_po2_20_verifies(hal, oracle):
+    """BASELINE config 2: one 2^20-cycle SYN-A segment sealed on the GPU; accepted by the independent verifier."""
+    desc = syn_air.syn_a()
+    prover = SegmentProver(hal, desc)
+    receipt = prover.prove_segment(Segment(index=0, po2=20))
+    oc = zko.OracleCircuit(oracle, desc)
+    assert oc.verify(receipt.seal) is None
+    # determinism: same witness + noise -> identical seal
+    again = prover.prove_segment(Segment(index=0, po2=20))
+    assert np.array_equal(receipt.seal, again.seal)

@@ -1,0 +1,79 @@
+"""Build libzkhal_mi355x.so (gfx950) in-tree with hipcc, and the CPU oracle with gcc.
+
+`python -m zeth_amd.build` or `__graft_entry__.build()`.  hipcc cross-compiles without a GPU.  The shared
+library lands next to this file (git-ignored, but shipped to the GPU box by gpurun).
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "libzkhal_mi355x.so")
+OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
+SOURCES = ["hal.hip", "ntt.hip", "hash.hip", "poly.hip", "circuit.hip", "prover.hip", "eval_check_gen.hip"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-unused-result"]
+
+
+def _deps_digest(src: str) -> str:
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, src)]
+    files += sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    files += [os.path.join(ROOT, "include", f) for f in sorted(os.listdir(os.path.join(ROOT, "include")))]
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def _compile(src: str, force: bool) -> str:
+    obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+    stamp = obj + ".sha"
+    digest = _deps_digest(src)
+    if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return obj
+    cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
+    with open(stamp, "w") as fh:
+        fh.write(digest)
+    return obj
+
+
+def generate_eval_check() -> None:
+    """Emit csrc/eval_check_gen.hip: straight-line eval_check kernels for the shipped circuits."""
+    from .circuits import codegen
+    codegen.write_generated(os.path.join(CSRC, "eval_check_gen.hip"))
+
+
+def build_oracle() -> None:
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    generate_eval_check()
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    newest = max(os.path.getmtime(o) for o in objs)
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    build_oracle()

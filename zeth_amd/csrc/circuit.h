@@ -1,0 +1,61 @@
+// circuit.h — host-side circuit description (TapSet + PolyExtStep list as data) shared by circuit.hip, the
+// generated eval_check kernels and the segment prover.  Mirrors risc0-zkp 3.0.2 src/taps.rs + src/adapter.rs
+// (un-vendored; /root/reference/Cargo.lock:5393); blob layout: zeth_amd/circuits/desc.py.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "common.h"
+
+namespace zkh {
+
+constexpr uint32_t DESC_MAGIC = 0x5a4b4331u;
+constexpr uint32_t DESC_HEADER = 16;
+enum : uint32_t { GROUP_ACCUM = 0, GROUP_CODE = 1, GROUP_DATA = 2 };
+enum : uint32_t { GLOBAL_OUT = 0, GLOBAL_MIX = 1 };
+enum : uint32_t { OP_CONST = 0, OP_CONST_EXT, OP_GET, OP_GET_GLOBAL, OP_ADD, OP_SUB, OP_MUL, OP_TRUE, OP_AND_EQZ, OP_AND_COND };
+
+struct Tap { uint32_t group, offset, back; };
+struct Step { uint32_t op, a, b, c, d; };
+struct Reg { uint32_t group, offset, tap_begin, size, combo_id; };
+
+// Arguments every eval_check kernel (generated or interpreted) receives.
+struct EvalCheckArgs {
+    uint32_t* check;                 // 4 planes x dom
+    const uint32_t* groups[3];       // evaluated accum, code, data (W x dom)
+    const uint32_t* globals[2];      // out, mix (device)
+    const uint32_t* mix_pows;        // poly_mix^e, e < n_mix_pows (ExtElem each, device)
+    uint32_t zinv[4];                // 1 / (3^n * i^(idx mod 4) - 1), Montgomery
+    uint32_t dom;                    // 4n
+};
+typedef void (*eval_check_launch_fn)(const EvalCheckArgs&, hipStream_t);
+struct CompiledEvalCheck { uint64_t desc_hash; const char* name; eval_check_launch_fn launch; uint32_t n_mix_pows; };
+// registry filled by the generated translation unit (eval_check_gen.hip)
+const CompiledEvalCheck* find_compiled_eval_check(uint64_t desc_hash);
+
+uint64_t desc_hash64(const uint32_t* words, size_t n);
+
+// device program for the generic interpreter (slots allocated on the host by liveness)
+struct InterpInsn { uint32_t op, dst, a, b, c, w; };   // w = index into mix_pows
+
+}  // namespace zkh
+
+struct zkh_circuit {
+    zkh_ctx* ctx;
+    std::vector<uint32_t> desc;
+    uint64_t hash;
+    uint32_t group_size[3];
+    uint32_t global_size[2];
+    uint32_t ret, kind;
+    std::vector<zkh::Tap> taps;
+    std::vector<std::vector<uint32_t>> combos;
+    std::vector<zkh::Step> steps;
+    std::vector<zkh::Reg> regs;
+    size_t tot_combo_backs;
+    const zkh::CompiledEvalCheck* compiled;
+    // interpreter program
+    std::vector<zkh::InterpInsn> prog;
+    uint32_t n_fp_slots, n_mix_slots, n_mix_pows, ret_slot;
+    uint32_t* d_prog;     // device copy of prog
+    uint32_t* d_taps;     // device copy of taps (group, offset, back)
+};

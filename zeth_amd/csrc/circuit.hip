@@ -1,0 +1,412 @@
+// circuit.hip — CircuitHal side: circuit description loader, eval_check (generated kernels + generic on-device
+// step interpreter) and the SYN-AIR witness generator.
+// Stands in for risc0-circuit-rv32im 4.0.2 src/prove/hal/{mod.rs,cuda.rs} + the Zirgen-generated eval_check /
+// witgen kernels of its -sys crate (un-vendored; /root/reference/Cargo.lock:5320), driven through
+// risc0_zkp::hal::CircuitHal (risc0-zkp 3.0.2 src/hal/mod.rs).  Reached from
+// /root/reference/crates/host/src/lib.rs:137.
+#include "circuit.h"
+
+#include <algorithm>
+
+using namespace zkh;
+
+namespace zkh {
+uint64_t desc_hash64(const uint32_t* w, size_t n) {   // FNV-1a over the words
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < n; i++) {
+        for (int b = 0; b < 4; b++) { h ^= (w[i] >> (8 * b)) & 0xff; h *= 0x100000001b3ull; }
+    }
+    return h;
+}
+const char* launch_ext_powers(zkh_ctx* c, uint32_t* out, const uint32_t start[4], const uint32_t base[4], uint32_t n);
+}  // namespace zkh
+
+namespace {
+
+constexpr uint32_t INTERP_THREADS = 128;
+constexpr uint32_t INSN_WORDS = 6;
+
+// ---- generic interpreter: one lane per domain point, value slots in LDS ([slot][lane]) ----
+__global__ __launch_bounds__(INTERP_THREADS) void k_eval_check_interp(EvalCheckArgs a, const uint32_t* __restrict__ prog,
+                                                                      uint32_t n_insn, const uint32_t* __restrict__ taps,
+                                                                      uint32_t n_fp_slots, uint32_t ret_slot) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* fps = lds;                                              // [n_fp_slots][THREADS]
+    uint4* mxs = (uint4*)(lds + (size_t)n_fp_slots * INTERP_THREADS); // [n_mix_slots][THREADS]
+    const uint32_t t = threadIdx.x;
+    const uint32_t idx = blockIdx.x * INTERP_THREADS + t;
+    if (idx >= a.dom) return;
+    const uint32_t mask = a.dom - 1;
+    for (uint32_t pc = 0; pc < n_insn; pc++) {
+        const uint32_t* in = prog + pc * INSN_WORDS;
+        const uint32_t op = in[0], dst = in[1], x = in[2], y = in[3], z = in[4], w = in[5];
+        switch (op) {
+        case OP_CONST: fps[dst * INTERP_THREADS + t] = x; break;
+        case OP_GET: {
+            const uint32_t g = taps[3 * x], off = taps[3 * x + 1], back = taps[3 * x + 2];
+            fps[dst * INTERP_THREADS + t] = a.groups[g][(size_t)off * a.dom + ((idx - 4 * back) & mask)];
+            break; }
+        case OP_GET_GLOBAL: fps[dst * INTERP_THREADS + t] = a.globals[x][y]; break;
+        case OP_ADD: fps[dst * INTERP_THREADS + t] = add_mod(fps[x * INTERP_THREADS + t], fps[y * INTERP_THREADS + t]); break;
+        case OP_SUB: fps[dst * INTERP_THREADS + t] = sub_mod(fps[x * INTERP_THREADS + t], fps[y * INTERP_THREADS + t]); break;
+        case OP_MUL: fps[dst * INTERP_THREADS + t] = mul_mod(fps[x * INTERP_THREADS + t], fps[y * INTERP_THREADS + t]); break;
+        case OP_TRUE: mxs[dst * INTERP_THREADS + t] = make_uint4(0, 0, 0, 0); break;
+        case OP_AND_EQZ: {   // tot = x.tot + mix^e(x) * v
+            const uint4 xt = mxs[x * INTERP_THREADS + t];
+            const uint4 pw = ((const uint4*)a.mix_pows)[w];
+            const uint32_t v = fps[y * INTERP_THREADS + t];
+            mxs[dst * INTERP_THREADS + t] = make_uint4(add_mod(xt.x, mul_mod(pw.x, v)), add_mod(xt.y, mul_mod(pw.y, v)),
+                                                       add_mod(xt.z, mul_mod(pw.z, v)), add_mod(xt.w, mul_mod(pw.w, v)));
+            break; }
+        case OP_AND_COND: {  // tot = x.tot + cond * y.tot * mix^e(x)
+            const uint4 xt = mxs[x * INTERP_THREADS + t], yt = mxs[z * INTERP_THREADS + t];
+            const uint4 pw = ((const uint4*)a.mix_pows)[w];
+            const uint32_t cnd = fps[y * INTERP_THREADS + t];
+            const Fp4 r = Fp4(Fp::raw(xt.x), Fp::raw(xt.y), Fp::raw(xt.z), Fp::raw(xt.w)) +
+                          (Fp4(Fp::raw(yt.x), Fp::raw(yt.y), Fp::raw(yt.z), Fp::raw(yt.w)) * Fp::raw(cnd)) *
+                              Fp4(Fp::raw(pw.x), Fp::raw(pw.y), Fp::raw(pw.z), Fp::raw(pw.w));
+            mxs[dst * INTERP_THREADS + t] = make_uint4(r.c[0].v, r.c[1].v, r.c[2].v, r.c[3].v);
+            break; }
+        }
+    }
+    const uint4 tot = mxs[ret_slot * INTERP_THREADS + t];
+    const uint32_t zi = a.zinv[idx & 3];
+    a.check[idx] = mul_mod(tot.x, zi);
+    a.check[(size_t)a.dom + idx] = mul_mod(tot.y, zi);
+    a.check[2 * (size_t)a.dom + idx] = mul_mod(tot.z, zi);
+    a.check[3 * (size_t)a.dom + idx] = mul_mod(tot.w, zi);
+}
+
+// ---- SYN-AIR witness (CPU twin: oracle/circuit.c) ----
+__device__ __forceinline__ uint32_t syn_cell(uint64_t seed, uint32_t group, uint32_t col, uint32_t row) {
+    uint64_t z = seed ^ ((uint64_t)(group + 1) * 0x9E3779B97F4A7C15ull);
+    z += (uint64_t)col * 0xBF58476D1CE4E5B9ull;
+    z += (uint64_t)row * 0x94D049BB133111EBull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return mul_mod(R2, (uint32_t)(z >> 32) % P);
+}
+__global__ void k_syn_code(uint32_t* code, uint32_t wc, uint32_t n, uint32_t A, uint64_t seed) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y;
+    if (r >= n) return;
+    uint32_t v;
+    switch (col) {
+    case 0: v = r < A ? R1 : 0; break;
+    case 1: v = r == 0 ? R1 : 0; break;
+    case 2: v = (r > 0 && r < A) ? R1 : 0; break;
+    case 3: v = mul_mod(R2, r); break;
+    case 4: v = r == A - 1 ? R1 : 0; break;
+    default: v = syn_cell(seed, GROUP_CODE, col, r);
+    }
+    code[(size_t)col * n + r] = v;
+}
+// one lane per row: free cells, products, and the running-sum increment (scanned afterwards)
+__global__ void k_syn_data(uint32_t* data, uint32_t wd, uint32_t n, uint32_t A, uint64_t seed, uint64_t noise_seed) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t T = (wd - 2) / 3;
+    if (r >= A) {
+        for (uint32_t c = 0; c < wd; c++) data[(size_t)c * n + r] = syn_cell(noise_seed, GROUP_DATA, c, r);
+        return;
+    }
+    uint32_t d0 = 0, d1 = 0, d3 = 0, d4 = 0;
+    for (uint32_t j = 0; j < T; j++) {
+        const uint32_t x = syn_cell(seed, GROUP_DATA, 3 * j, r), y = syn_cell(seed, GROUP_DATA, 3 * j + 1, r);
+        const uint32_t pr = mul_mod(x, y);
+        data[(size_t)(3 * j) * n + r] = x; data[(size_t)(3 * j + 1) * n + r] = y; data[(size_t)(3 * j + 2) * n + r] = pr;
+        if (j == 0) { d0 = x; d1 = y; }
+        if (j == 1) { d3 = x; d4 = y; }
+    }
+    for (uint32_t c = 3 * T; c < wd - 2; c++) data[(size_t)c * n + r] = syn_cell(seed, GROUP_DATA, c, r);
+    data[(size_t)(wd - 2) * n + r] = mul_mod(mul_mod(d0, d1), mul_mod(d3, d4));
+    // increment of the running sum; row 0 starts the sum at d0
+    const uint32_t inc = r == 0 ? d0 : add_mod(d0, mul_mod(mul_mod(R2, r), d1));
+    data[(size_t)(wd - 1) * n + r] = inc;
+}
+// inclusive prefix sum (mod P) of the first A words of a column; single workgroup, chunked (witgen, untimed)
+__global__ __launch_bounds__(1024) void k_prefix_sum_fp(uint32_t* col, uint32_t A, uint32_t* last_out) {
+    __shared__ uint32_t buf[2][1024];
+    __shared__ uint32_t carry_s;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < A; base += 1024) {
+        const uint32_t i = base + t;
+        buf[0][t] = i < A ? col[i] : 0;
+        __syncthreads();
+        int cur = 0;
+        for (uint32_t d = 1; d < 1024; d <<= 1) {
+            uint32_t v = buf[cur][t];
+            if (t >= d) v = add_mod(v, buf[cur][t - d]);
+            buf[cur ^ 1][t] = v;
+            cur ^= 1;
+            __syncthreads();
+        }
+        const uint32_t v = add_mod(buf[cur][t], carry_s);
+        if (i < A) col[i] = v;
+        __syncthreads();
+        if (t == 1023) carry_s = v;
+        __syncthreads();
+    }
+    if (t == 0 && last_out) *last_out = carry_s;   // prefix through the last chunk = s[A-1]
+}
+// accum: terms[e][r] = mix_e + d_{e mod wd}[r] (active rows) or 1 (noise rows), AoS ExtElems
+__global__ void k_syn_accum_terms(uint32_t* terms, const uint32_t* data, const uint32_t* mix, uint32_t wd, uint32_t n, uint32_t A) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, e = blockIdx.y;
+    if (r >= n) return;
+    uint4 v;
+    if (r < A) {
+        const uint4 m = ((const uint4*)mix)[e];
+        v = make_uint4(add_mod(m.x, data[(size_t)(e % wd) * n + r]), m.y, m.z, m.w);
+    } else {
+        v = make_uint4(R1, 0, 0, 0);
+    }
+    ((uint4*)terms)[(size_t)e * n + r] = v;
+}
+__global__ void k_syn_accum_store(uint32_t* accum, const uint32_t* prods, uint32_t n, uint32_t A, uint64_t noise_seed) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, e = blockIdx.y;
+    if (r >= n) return;
+    uint32_t v[4];
+    if (r < A) {
+        const uint4 p = ((const uint4*)prods)[(size_t)e * n + r];
+        v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w;
+    } else {
+        for (int i = 0; i < 4; i++) v[i] = syn_cell(noise_seed, GROUP_ACCUM, 4 * e + i, r);
+    }
+    for (int i = 0; i < 4; i++) accum[(size_t)(4 * e + i) * n + r] = v[i];
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" const char* zkh_circuit_load(zkh_ctx* ctx, const uint32_t* d, size_t words, zkh_circuit** out) {
+    ZKH_REQUIRE(words >= DESC_HEADER && d[0] == DESC_MAGIC && d[1] == 1 && d[2] == 3 && d[6] == 2, "circuit desc: bad header");
+    zkh_circuit* c = new zkh_circuit();
+    c->ctx = ctx;
+    c->desc.assign(d, d + words);
+    c->hash = desc_hash64(d, words);
+    for (int g = 0; g < 3; g++) c->group_size[g] = d[3 + g];
+    c->global_size[0] = d[7]; c->global_size[1] = d[8];
+    const uint32_t n_taps = d[9], n_combos = d[10], n_steps = d[11];
+    c->ret = d[12]; c->kind = d[13];
+    size_t pos = DESC_HEADER;
+    auto fail = [&](const char* msg) { delete c; return make_err("circuit desc: %s", msg); };
+    if (pos + 3ull * n_taps > words) return fail("truncated taps");
+    for (uint32_t i = 0; i < n_taps; i++, pos += 3) {
+        Tap t{d[pos], d[pos + 1], d[pos + 2]};
+        if (t.group > 2 || t.offset >= c->group_size[t.group]) return fail("tap out of range");
+        c->taps.push_back(t);
+    }
+    c->tot_combo_backs = 0;
+    for (uint32_t i = 0; i < n_combos; i++) {
+        if (pos >= words || pos + 1 + d[pos] > words) return fail("truncated combos");
+        uint32_t cnt = d[pos++];
+        c->combos.emplace_back(d + pos, d + pos + cnt);
+        pos += cnt; c->tot_combo_backs += cnt;
+    }
+    if (pos + 5ull * n_steps > words) return fail("truncated steps");
+    for (uint32_t i = 0; i < n_steps; i++, pos += 5) c->steps.push_back(Step{d[pos], d[pos + 1], d[pos + 2], d[pos + 3], d[pos + 4]});
+    // registers
+    for (size_t i = 0; i < c->taps.size();) {
+        size_t j = i;
+        while (j < c->taps.size() && c->taps[j].group == c->taps[i].group && c->taps[j].offset == c->taps[i].offset) j++;
+        Reg r{c->taps[i].group, c->taps[i].offset, (uint32_t)i, (uint32_t)(j - i), 0xffffffffu};
+        for (size_t k = 0; k < c->combos.size(); k++) {
+            if (c->combos[k].size() != r.size) continue;
+            bool same = true;
+            for (uint32_t m = 0; m < r.size; m++) same &= c->combos[k][m] == c->taps[i + m].back;
+            if (same) { r.combo_id = (uint32_t)k; break; }
+        }
+        if (r.combo_id == 0xffffffffu) return fail("register without combo");
+        c->regs.push_back(r);
+        i = j;
+    }
+    for (int g = 0; g < 3; g++) {
+        size_t cnt = 0;
+        for (auto& r : c->regs) cnt += r.group == (uint32_t)g;
+        if (cnt != c->group_size[g]) return fail("every column of a group needs a register");
+    }
+    // ---- analyse the step list: static mix exponents, liveness, slot allocation ----
+    std::vector<uint32_t> fp_of_step, mix_exp;      // per mix var: exponent of poly_mix held in `mul`
+    std::vector<int> fp_last, mix_last;              // last step that reads var
+    struct V { bool is_mix; uint32_t id; };
+    std::vector<V> def(c->steps.size());
+    uint32_t nf = 0, nm = 0;
+    for (size_t i = 0; i < c->steps.size(); i++) {
+        const Step& s = c->steps[i];
+        if (s.op >= OP_TRUE) { def[i] = {true, nm++}; } else { def[i] = {false, nf++}; }
+    }
+    fp_last.assign(nf, -1); mix_last.assign(nm, -1); mix_exp.assign(nm, 0);
+    uint32_t max_pow = 0;
+    {
+        uint32_t cf = 0, cm = 0;
+        for (size_t i = 0; i < c->steps.size(); i++) {
+            const Step& s = c->steps[i];
+            auto usef = [&](uint32_t v) -> bool { if (v >= cf) return false; fp_last[v] = (int)i; return true; };
+            auto usem = [&](uint32_t v) -> bool { if (v >= cm) return false; mix_last[v] = (int)i; return true; };
+            bool ok = true;
+            switch (s.op) {
+            case OP_CONST: case OP_GET_GLOBAL: break;
+            case OP_GET: ok = s.a < c->taps.size(); break;
+            case OP_CONST_EXT: return fail("ConstExt is not supported on the device path");
+            case OP_ADD: case OP_SUB: case OP_MUL: ok = usef(s.a) && usef(s.b); break;
+            case OP_TRUE: mix_exp[cm] = 0; break;
+            case OP_AND_EQZ: ok = usem(s.a) && usef(s.b); if (ok) { mix_exp[cm] = mix_exp[s.a] + 1; max_pow = std::max(max_pow, mix_exp[s.a]); } break;
+            case OP_AND_COND: ok = usem(s.a) && usef(s.b) && usem(s.c);
+                if (ok) { mix_exp[cm] = mix_exp[s.a] + mix_exp[s.c]; max_pow = std::max(max_pow, mix_exp[s.a]); } break;
+            default: ok = false;
+            }
+            if (!ok) return fail("step operand out of range");
+            if (s.op == OP_GET_GLOBAL && (s.a > 1 || s.b >= c->global_size[s.a])) return fail("global out of range");
+            if (s.op >= OP_TRUE) cm++; else cf++;
+        }
+        if (c->ret >= nm) return fail("ret out of range");
+        mix_last[c->ret] = (int)c->steps.size();
+    }
+    c->n_mix_pows = max_pow + 1;
+    {
+        std::vector<uint32_t> fp_slot(nf, 0), mix_slot(nm, 0), free_f, free_m;
+        uint32_t nfs = 0, nms = 0, cf = 0, cm = 0;
+        // vars whose last use is step i are released after step i
+        std::vector<std::vector<uint32_t>> rel_f(c->steps.size() + 1), rel_m(c->steps.size() + 1);
+        for (uint32_t v = 0; v < nf; v++) if (fp_last[v] >= 0) rel_f[fp_last[v]].push_back(v);
+        for (uint32_t v = 0; v < nm; v++) if (mix_last[v] >= 0 && mix_last[v] < (int)c->steps.size()) rel_m[mix_last[v]].push_back(v);
+        for (size_t i = 0; i < c->steps.size(); i++) {
+            const Step& s = c->steps[i];
+            const bool is_mix = s.op >= OP_TRUE;
+            const bool dead = is_mix ? (mix_last[cm] < 0) : (fp_last[cf] < 0);
+            if (!dead) {
+                InterpInsn in{s.op, 0, 0, 0, 0, 0};
+                if (is_mix) { if (free_m.empty()) in.dst = nms++; else { in.dst = free_m.back(); free_m.pop_back(); } mix_slot[cm] = in.dst; }
+                else { if (free_f.empty()) in.dst = nfs++; else { in.dst = free_f.back(); free_f.pop_back(); } fp_slot[cf] = in.dst; }
+                switch (s.op) {
+                case OP_CONST: in.a = fp_encode(s.a).v; break;
+                case OP_GET: in.a = s.a; break;
+                case OP_GET_GLOBAL: in.a = s.a; in.b = s.b; break;
+                case OP_ADD: case OP_SUB: case OP_MUL: in.a = fp_slot[s.a]; in.b = fp_slot[s.b]; break;
+                case OP_TRUE: break;
+                case OP_AND_EQZ: in.a = mix_slot[s.a]; in.b = fp_slot[s.b]; in.w = mix_exp[s.a]; break;
+                case OP_AND_COND: in.a = mix_slot[s.a]; in.b = fp_slot[s.b]; in.c = mix_slot[s.c]; in.w = mix_exp[s.a]; break;
+                }
+                c->prog.push_back(in);
+            }
+            // NOTE: a destination slot may not alias a source released by the same step: release AFTER allocating
+            for (uint32_t v : rel_f[i]) free_f.push_back(fp_slot[v]);
+            for (uint32_t v : rel_m[i]) free_m.push_back(mix_slot[v]);
+            if (is_mix) cm++; else cf++;
+        }
+        c->n_fp_slots = nfs ? nfs : 1; c->n_mix_slots = nms ? nms : 1;
+        c->ret_slot = mix_slot[c->ret];
+    }
+    const size_t lds = ((size_t)c->n_fp_slots * 4 + (size_t)c->n_mix_slots * 16) * INTERP_THREADS;
+    if (lds > 160 * 1024) return fail("constraint program needs more live values than the interpreter's LDS holds");
+    c->compiled = find_compiled_eval_check(c->hash);
+    c->d_prog = nullptr; c->d_taps = nullptr;
+    {
+        static_assert(sizeof(InterpInsn) == INSN_WORDS * 4, "insn layout");
+        hipError_t e = hipMalloc((void**)&c->d_prog, c->prog.size() * sizeof(InterpInsn) + 4);
+        if (e == hipSuccess) e = hipMemcpy(c->d_prog, c->prog.data(), c->prog.size() * sizeof(InterpInsn), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void**)&c->d_taps, c->taps.size() * sizeof(Tap) + 4);
+        if (e == hipSuccess) e = hipMemcpy(c->d_taps, c->taps.data(), c->taps.size() * sizeof(Tap), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { const char* m = hipGetErrorString(e); return fail(m); }
+    }
+    *out = c;
+    return nullptr;
+}
+extern "C" void zkh_circuit_destroy(zkh_circuit* c) {
+    if (!c) return;
+    if (c->d_prog) (void)hipFree(c->d_prog);
+    if (c->d_taps) (void)hipFree(c->d_taps);
+    delete c;
+}
+extern "C" int zkh_circuit_has_compiled_kernel(const zkh_circuit* c) { return c->compiled != nullptr; }
+
+extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_buf* check, const zkh_buf* const* groups,
+                                      const zkh_buf* const* globals, const uint32_t poly_mix[4], size_t po2, int use_interpreter) {
+    const size_t n = (size_t)1 << po2, dom = n * ZKH_INV_RATE;
+    ZKH_REQUIRE(po2 + 2 <= (size_t)MAX_LOG_N, "eval_check: po2 %zu too large", po2);
+    ZKH_REQUIRE(check->len == ZKH_EXT_SIZE * dom, "eval_check: check buffer must hold 4 x 4n words");
+    for (int g = 0; g < 3; g++)
+        ZKH_REQUIRE(groups[g]->len == (size_t)c->group_size[g] * dom, "eval_check: group %d has %zu words, expected %zu", g,
+                    groups[g]->len, (size_t)c->group_size[g] * dom);
+    for (int g = 0; g < 2; g++) ZKH_REQUIRE(globals[g]->len >= c->global_size[g], "eval_check: global %d too small", g);
+    EvalCheckArgs a{};
+    a.check = check->ptr();
+    for (int g = 0; g < 3; g++) a.groups[g] = groups[g]->ptr();
+    for (int g = 0; g < 2; g++) a.globals[g] = globals[g]->ptr();
+    a.dom = (uint32_t)dom;
+    // (3 w^idx)^n = 3^n * i^(idx mod 4), i = ROU_FWD[2]
+    const Fp three_n = fp_pow(fp_encode(3), n), i4 = Fp::raw(ctx->rou_fwd[2]);
+    Fp cur = Fp::one();
+    for (int k = 0; k < 4; k++) { a.zinv[k] = fp_inv(three_n * cur - Fp::one()).v; cur = cur * i4; }
+    zkh_buf* pows = nullptr;
+    ZKH_TRY(new_buf(ctx, 4 * (size_t)c->n_mix_pows, false, &pows));
+    const uint32_t one[4] = {R1, 0, 0, 0};
+    ZKH_TRY(launch_ext_powers(ctx, pows->ptr(), one, poly_mix, c->n_mix_pows));
+    a.mix_pows = pows->ptr();
+    size_t total_w = 0;
+    for (int g = 0; g < 3; g++) total_w += c->group_size[g];
+    if (c->compiled && !use_interpreter) {
+        ProfScope prof(ctx, "eval_check", 4.0 * total_w * dom + 16.0 * dom);
+        c->compiled->launch(a, ctx->stream);
+    } else {
+        const size_t lds = ((size_t)c->n_fp_slots * 4 + (size_t)c->n_mix_slots * 16) * INTERP_THREADS;
+        ProfScope prof(ctx, "eval_check_interp", 4.0 * total_w * dom + 16.0 * dom);
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)k_eval_check_interp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        k_eval_check_interp<<<(unsigned)((dom + INTERP_THREADS - 1) / INTERP_THREADS), INTERP_THREADS, lds, ctx->stream>>>(
+            a, c->d_prog, (uint32_t)c->prog.size(), c->d_taps, c->n_fp_slots, c->ret_slot);
+    }
+    zkh_release(pows);
+    return last_launch_error("eval_check");
+}
+
+// ---- SYN-AIR witness ----
+extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t po2, size_t zk_cycles, uint64_t seed,
+                                      uint64_t noise_seed, zkh_buf* code, zkh_buf* data, uint32_t out_global[4]) {
+    ZKH_REQUIRE(c->kind == 1, "syn_witgen: circuit is not SYN-AIR");
+    const size_t n = (size_t)1 << po2;
+    ZKH_REQUIRE(n > zk_cycles + 1, "syn_witgen: po2 too small for zk_cycles");
+    const uint32_t wc = c->group_size[GROUP_CODE], wd = c->group_size[GROUP_DATA], A = (uint32_t)(n - zk_cycles);
+    ZKH_REQUIRE(code->len == (size_t)wc * n && data->len == (size_t)wd * n, "syn_witgen: buffer shape mismatch");
+    zkh_buf* last = nullptr;
+    ZKH_TRY(new_buf(ctx, 1, false, &last));
+    const unsigned bx = (unsigned)((n + 255) / 256);
+    k_syn_code<<<dim3(bx, wc), 256, 0, ctx->stream>>>(code->ptr(), wc, (uint32_t)n, A, seed);
+    k_syn_data<<<bx, 256, 0, ctx->stream>>>(data->ptr(), wd, (uint32_t)n, A, seed, noise_seed);
+    k_prefix_sum_fp<<<1, 1024, 0, ctx->stream>>>(data->ptr() + (size_t)(wd - 1) * n, A, last->ptr());
+    ZKH_TRY(last_launch_error("syn_witgen"));
+    out_global[1] = out_global[2] = out_global[3] = 0;
+    const char* err = zkh_read(ctx, last, out_global, 0, 1);
+    zkh_release(last);
+    return err;
+}
+extern "C" const char* zkh_syn_accum(zkh_ctx* ctx, const zkh_circuit* c, size_t po2, size_t zk_cycles, uint64_t noise_seed,
+                                     const zkh_buf* data, const uint32_t* mix_global, zkh_buf* accum) {
+    ZKH_REQUIRE(c->kind == 1, "syn_accum: circuit is not SYN-AIR");
+    const size_t n = (size_t)1 << po2;
+    const uint32_t wa = c->group_size[GROUP_ACCUM], wd = c->group_size[GROUP_DATA], A = (uint32_t)(n - zk_cycles), k = wa / 4;
+    ZKH_REQUIRE(accum->len == (size_t)wa * n && data->len == (size_t)wd * n, "syn_accum: buffer shape mismatch");
+    zkh_buf *mix = nullptr, *terms = nullptr;
+    ZKH_TRY(zkh_copy_from(ctx, "mix", mix_global, wa, &mix));
+    ZKH_TRY(new_buf(ctx, 4 * (size_t)k * n, false, &terms));
+    const unsigned bx = (unsigned)((n + 255) / 256);
+    {
+        ProfScope prof(ctx, "syn_accum_terms", (4.0 + 16.0) * k * n);
+        k_syn_accum_terms<<<dim3(bx, k), 256, 0, ctx->stream>>>(terms->ptr(), data->ptr(), mix->ptr(), wd, (uint32_t)n, A);
+    }
+    for (uint32_t e = 0; e < k; e++) {
+        zkh_buf* col = nullptr;
+        ZKH_TRY(zkh_slice(terms, 4 * (size_t)e * n, 4 * n, &col));
+        const char* err = zkh_prefix_products(ctx, col);
+        zkh_release(col);
+        ZKH_TRY(err);
+    }
+    {
+        ProfScope prof(ctx, "syn_accum_store", (16.0 + 16.0) * k * n);
+        k_syn_accum_store<<<dim3(bx, k), 256, 0, ctx->stream>>>(accum->ptr(), terms->ptr(), (uint32_t)n, A, noise_seed);
+    }
+    zkh_release(mix); zkh_release(terms);
+    return last_launch_error("syn_accum");
+}

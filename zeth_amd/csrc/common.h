@@ -1,0 +1,124 @@
+// common.h — internal structures of libzkhal_mi355x: context, buffers, stream-ordered pool, launch + profiling.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/zkhal.h"
+#include "fp.h"
+
+namespace zkh {
+
+// Error strings follow risc0-sys's convention: NULL = ok, heap string otherwise.
+inline const char* make_err(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return strdup(buf);
+}
+#define ZKH_HIP(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) return zkh::make_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+#define ZKH_TRY(expr)                    \
+    do {                                 \
+        const char* _err = (expr);       \
+        if (_err) return _err;           \
+    } while (0)
+#define ZKH_REQUIRE(cond, ...)                         \
+    do {                                               \
+        if (!(cond)) return zkh::make_err(__VA_ARGS__); \
+    } while (0)
+
+constexpr int TW_BITS = 12;                 // two-level twiddle tables: w_{2^24}^(hi*4096 + lo)
+constexpr int TW_SIZE = 1 << TW_BITS;
+constexpr int MAX_LOG_N = 2 * TW_BITS;      // largest NTT / coset-shift domain supported (2^24)
+constexpr int LDS_TW_LOG = 12;              // in-tile twiddles: w_{2^12}^j, j < 2^11
+
+struct DeviceTables {
+    // Poseidon2 (Montgomery form)
+    uint32_t* rc;        // 24*29
+    uint32_t* diag;      // 24
+    // twiddles, Montgomery form
+    uint32_t* tw_fwd_lo; uint32_t* tw_fwd_hi;   // w^lo, w^(hi*4096), w = ROU_FWD[24]
+    uint32_t* tw_rev_lo; uint32_t* tw_rev_hi;   // same for ROU_REV[24]
+    uint32_t* tile_fwd;  uint32_t* tile_rev;    // ROU_FWD[12]^j / ROU_REV[12]^j, j < 2048
+    uint32_t* shift_lo;  uint32_t* shift_hi;    // 3^lo, 3^(hi*4096)
+};
+
+struct ProfAgg { uint64_t calls = 0; double ms = 0; double bytes = 0; };
+struct ProfPending { std::string name; hipEvent_t a, b; double bytes; };
+
+}  // namespace zkh
+
+struct zkh_alloc_t {
+    void* ptr;
+    size_t bytes;
+    int refs;
+    bool owned;
+    zkh_ctx* ctx;
+};
+
+struct zkh_buf {
+    zkh_alloc_t* a;
+    size_t off, len;   // words
+    int refs;
+    uint32_t* ptr() const { return (uint32_t*)a->ptr + off; }
+};
+
+struct zkh_ctx {
+    int device;
+    hipStream_t stream;
+    zkh::DeviceTables tab;
+    uint32_t rou_fwd[28], rou_rev[28];          // host copies (Montgomery)
+    uint32_t h_rc[24 * 29], h_diag[24];         // host copies of the Poseidon2 tables (Montgomery)
+    std::multimap<size_t, void*> pool;          // stream-ordered free list (single in-order stream)
+    size_t pool_bytes = 0, live_bytes = 0, peak_bytes = 0;
+    bool prof = false;
+    std::vector<zkh::ProfPending> pending;
+    std::map<std::string, zkh::ProfAgg> agg;
+    std::vector<hipEvent_t> event_pool;
+    uint32_t* pinned = nullptr;                  // host staging
+    size_t pinned_words = 0;
+};
+
+namespace zkh {
+
+const char* pool_alloc(zkh_ctx* c, size_t bytes, void** out);
+void pool_free(zkh_ctx* c, void* p, size_t bytes);
+const char* new_buf(zkh_ctx* c, size_t n_words, bool zero, zkh_buf** out);
+void prof_begin(zkh_ctx* c, const char* name, double bytes);
+void prof_end(zkh_ctx* c);
+const char* ensure_pinned(zkh_ctx* c, size_t words);
+
+// Launch helper: optional HIP-event bracket on the ctx stream (what bench.py's roofline uses).
+struct ProfScope {
+    zkh_ctx* c;
+    ProfScope(zkh_ctx* ctx, const char* name, double bytes) : c(ctx) { if (c->prof) prof_begin(c, name, bytes); }
+    ~ProfScope() { if (c->prof) prof_end(c); }
+};
+
+inline const char* last_launch_error(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return make_err("launch %s: %s", what, hipGetErrorString(e));
+    return nullptr;
+}
+
+// XCD-aware block remap: hardware places block b on XCD b % 8; make consecutive logical tiles share an XCD
+// (and its L2) by giving XCD x the x-th contiguous slice of the tile range.  Bijective for any nblocks.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nblocks) {
+    const uint32_t xcd = b & 7u, q = nblocks >> 3, r = nblocks & 7u, idx = b >> 3;
+    const uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+}  // namespace zkh

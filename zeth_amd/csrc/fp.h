@@ -1,0 +1,145 @@
+// fp.h — BabyBear (P = 15*2^27 + 1) Montgomery arithmetic and the x^4 + 11 extension, host + gfx950 device.
+// Stands in for risc0-core 3.0.0 src/field/baby_bear.rs (un-vendored; /root/reference/Cargo.lock:5338):
+// Elem = u32 Montgomery word (< P), ExtElem = 4 Elems.  Reached from
+// /root/reference/crates/host/src/lib.rs:137 via risc0_zkp::hal::Hal.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ZKH_HD __host__ __device__ __forceinline__
+#else
+#define ZKH_HD inline
+#endif
+
+namespace zkh {
+
+constexpr uint32_t P = 2013265921u;        // 0x78000001
+constexpr uint32_t PINV = 0x88000001u;     // P^-1 mod 2^32
+constexpr uint32_t NEG_PINV = 0x77ffffffu; // -P^-1 mod 2^32
+constexpr uint32_t R1 = 268435454u;        // 2^32 mod P  (Montgomery 1)
+constexpr uint32_t R2 = 1172168163u;       // 2^64 mod P
+constexpr uint32_t INVALID = 0xffffffffu;
+
+struct Fp {
+    uint32_t v;   // Montgomery form, < P
+    ZKH_HD Fp() : v(0) {}
+    ZKH_HD explicit constexpr Fp(uint32_t raw, int) : v(raw) {}
+    static ZKH_HD Fp raw(uint32_t r) { return Fp(r, 0); }
+    static ZKH_HD Fp one() { return Fp(R1, 0); }
+    static ZKH_HD Fp zero() { return Fp(0, 0); }
+};
+
+// a + b mod P without a branch: min(s, s - P) under unsigned wrap.
+ZKH_HD uint32_t add_mod(uint32_t a, uint32_t b) {
+    uint32_t s = a + b, t = s - P;
+    return t < s ? t : s;
+}
+ZKH_HD uint32_t sub_mod(uint32_t a, uint32_t b) {
+    uint32_t s = a - b, t = s + P;
+    return t < s ? t : s;
+}
+// Montgomery reduction of a 64-bit product T < P * 2^32:  (T - (T*P^-1 mod 2^32) * P) / 2^32, in [0, P).
+ZKH_HD uint32_t mont_reduce(uint64_t t) {
+    uint32_t m = (uint32_t)t * PINV;
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t u = __umulhi(m, P);
+#else
+    uint32_t u = (uint32_t)(((uint64_t)m * P) >> 32);
+#endif
+    uint32_t hi = (uint32_t)(t >> 32);
+    uint32_t r = hi - u, r2 = r + P;
+    return r2 < r ? r2 : r;    // borrow <=> r wrapped <=> r + P wraps back below
+}
+ZKH_HD uint32_t mul_mod(uint32_t a, uint32_t b) { return mont_reduce((uint64_t)a * b); }
+
+ZKH_HD Fp operator+(Fp a, Fp b) { return Fp::raw(add_mod(a.v, b.v)); }
+ZKH_HD Fp operator-(Fp a, Fp b) { return Fp::raw(sub_mod(a.v, b.v)); }
+ZKH_HD Fp operator*(Fp a, Fp b) { return Fp::raw(mul_mod(a.v, b.v)); }
+ZKH_HD Fp operator-(Fp a) { return Fp::raw(a.v ? P - a.v : 0); }
+ZKH_HD bool operator==(Fp a, Fp b) { return a.v == b.v; }
+ZKH_HD Fp& operator+=(Fp& a, Fp b) { a = a + b; return a; }
+ZKH_HD Fp& operator-=(Fp& a, Fp b) { a = a - b; return a; }
+ZKH_HD Fp& operator*=(Fp& a, Fp b) { a = a * b; return a; }
+
+ZKH_HD Fp fp_encode(uint32_t x) { return Fp::raw(mul_mod(R2, x % P)); }
+ZKH_HD uint32_t fp_decode(Fp a) { return mul_mod(1u, a.v); }
+ZKH_HD Fp fp_pow(Fp a, uint64_t e) {
+    Fp r = Fp::one();
+    while (e) { if (e & 1) r = r * a; a = a * a; e >>= 1; }
+    return r;
+}
+ZKH_HD Fp fp_inv(Fp a) { return fp_pow(a, P - 2); }
+
+constexpr uint32_t NBETA_CANON = P - 11;     // x^4 = -11
+// Montgomery forms of 11 and -11 (computed once on host and checked in tests): 11 * 2^32 mod P
+constexpr uint32_t BETA_M = (uint32_t)((11ull << 32) % P);
+constexpr uint32_t NBETA_M = P - BETA_M;
+
+struct Fp4 {
+    Fp c[4];
+    ZKH_HD Fp4() {}
+    ZKH_HD Fp4(Fp a, Fp b, Fp d, Fp e) { c[0] = a; c[1] = b; c[2] = d; c[3] = e; }
+    ZKH_HD explicit Fp4(Fp a) { c[0] = a; c[1] = c[2] = c[3] = Fp::zero(); }
+    static ZKH_HD Fp4 zero() { return Fp4(Fp::zero()); }
+    static ZKH_HD Fp4 one() { return Fp4(Fp::one()); }
+};
+ZKH_HD Fp4 operator+(Fp4 a, Fp4 b) { return Fp4(a.c[0] + b.c[0], a.c[1] + b.c[1], a.c[2] + b.c[2], a.c[3] + b.c[3]); }
+ZKH_HD Fp4 operator-(Fp4 a, Fp4 b) { return Fp4(a.c[0] - b.c[0], a.c[1] - b.c[1], a.c[2] - b.c[2], a.c[3] - b.c[3]); }
+ZKH_HD Fp4 operator*(Fp4 a, Fp b) { return Fp4(a.c[0] * b, a.c[1] * b, a.c[2] * b, a.c[3] * b); }
+ZKH_HD bool operator==(Fp4 a, Fp4 b) { return a.c[0] == b.c[0] && a.c[1] == b.c[1] && a.c[2] == b.c[2] && a.c[3] == b.c[3]; }
+
+// Schoolbook product mod x^4 + 11 with lazy accumulation: 64-bit partial products (each < P^2) are summed in a
+// v_mad_u64_u32 chain and reduced ONCE per output coefficient (7 reductions + 19 wide multiplies instead of
+// 19 full Montgomery products).  Up to 4 products fit: 4*P^2 < 2^64 and 4*P^2 < 2*P*2^32, so one conditional
+// subtraction of P from the high word brings the sum under the P*2^32 bound mont_reduce needs.
+ZKH_HD uint32_t mont_reduce_wide(uint64_t t) {   // any t < 2*P*2^32
+    uint32_t hi = (uint32_t)(t >> 32), hi2 = hi - P;
+    hi = hi2 < hi ? hi2 : hi;
+    return mont_reduce(((uint64_t)hi << 32) | (uint32_t)t);
+}
+ZKH_HD Fp4 operator*(Fp4 a, Fp4 b) {
+    const uint64_t a0 = a.c[0].v, a1 = a.c[1].v, a2 = a.c[2].v, a3 = a.c[3].v;
+    const uint64_t b0 = b.c[0].v, b1 = b.c[1].v, b2 = b.c[2].v, b3 = b.c[3].v;
+    const uint64_t h0 = mont_reduce_wide(a1 * b3 + a2 * b2 + a3 * b1);   // x^4 coefficient
+    const uint64_t h1 = mont_reduce_wide(a2 * b3 + a3 * b2);             // x^5
+    const uint64_t h2 = mont_reduce(a3 * b3);                            // x^6
+    Fp4 r;
+    r.c[0] = Fp::raw(mont_reduce_wide(a0 * b0 + NBETA_M * h0));
+    r.c[1] = Fp::raw(mont_reduce_wide(a0 * b1 + a1 * b0 + NBETA_M * h1));
+    r.c[2] = Fp::raw(mont_reduce_wide(a0 * b2 + a1 * b1 + a2 * b0 + NBETA_M * h2));
+    r.c[3] = Fp::raw(mont_reduce_wide(a0 * b3 + a1 * b2 + a2 * b1 + a3 * b0));
+    return r;
+}
+ZKH_HD Fp4& operator+=(Fp4& a, Fp4 b) { a = a + b; return a; }
+ZKH_HD Fp4& operator*=(Fp4& a, Fp4 b) { a = a * b; return a; }
+ZKH_HD Fp4 fp4_pow(Fp4 a, uint64_t e) {
+    Fp4 r = Fp4::one();
+    while (e) { if (e & 1) r = r * a; a = a * a; e >>= 1; }
+    return r;
+}
+// Inverse through the norm tower: a(x) a(-x) = b0 + b2 x^2, (b0 + b2 x^2)(b0 - b2 x^2) = b0^2 + 11 b2^2 in Fp.
+ZKH_HD Fp4 fp4_inv(Fp4 a) {
+    const Fp beta = Fp::raw(BETA_M);
+    Fp a0 = a.c[0], a1 = a.c[1], a2 = a.c[2], a3 = a.c[3];
+    Fp b0 = a0 * a0 + beta * ((a1 + a1) * a3 - a2 * a2);
+    Fp b2 = (a0 + a0) * a2 - a1 * a1 + beta * (a3 * a3);
+    Fp ic = fp_inv(b0 * b0 + beta * (b2 * b2));
+    b0 = b0 * ic; b2 = b2 * ic;
+    return Fp4(a0, -a1, a2, -a3) * Fp4(b0, Fp::zero(), -b2, Fp::zero());
+}
+
+ZKH_HD uint32_t bitrev32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(x);
+#else
+    x = ((x & 0xaaaaaaaau) >> 1) | ((x & 0x55555555u) << 1);
+    x = ((x & 0xccccccccu) >> 2) | ((x & 0x33333333u) << 2);
+    x = ((x & 0xf0f0f0f0u) >> 4) | ((x & 0x0f0f0f0fu) << 4);
+    x = ((x & 0xff00ff00u) >> 8) | ((x & 0x00ff00ffu) << 8);
+    return (x >> 16) | (x << 16);
+#endif
+}
+ZKH_HD uint32_t log2_ceil(uint64_t x) { uint32_t r = 0; while ((1ull << r) < x) r++; return r; }
+
+}  // namespace zkh

@@ -1,0 +1,408 @@
+// hal.hip — context, Buffer<T> plumbing, stream-ordered pool, profiling, and the small element-wise Hal ops.
+// Stands in for risc0-zkp 3.0.2 src/hal/{mod.rs,cuda.rs} (un-vendored; /root/reference/Cargo.lock:5393),
+// reached from /root/reference/crates/host/src/lib.rs:137.
+#include "common.h"
+#include "../../include/zkh_poseidon2_consts.h"
+
+using namespace zkh;
+
+extern "C" void zkh_free_error(const char* e) { free((void*)e); }
+extern "C" const char* zkh_version(void) { return "zkhal-mi355x 0.1.0 (gfx950)"; }
+
+namespace zkh {
+
+const char* pool_alloc(zkh_ctx* c, size_t bytes, void** out) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    auto it = c->pool.find(bytes);
+    if (it != c->pool.end()) {
+        *out = it->second;
+        c->pool.erase(it);
+        c->pool_bytes -= bytes;
+    } else {
+        hipError_t e = hipMalloc(out, bytes);
+        if (e != hipSuccess) {
+            // release the cached blocks and retry once
+            (void)hipStreamSynchronize(c->stream);
+            for (auto& kv : c->pool) (void)hipFree(kv.second);
+            c->pool.clear(); c->pool_bytes = 0;
+            e = hipMalloc(out, bytes);
+            if (e != hipSuccess) return make_err("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        }
+    }
+    c->live_bytes += bytes;
+    if (c->live_bytes > c->peak_bytes) c->peak_bytes = c->live_bytes;
+    return nullptr;
+}
+void pool_free(zkh_ctx* c, void* p, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    c->live_bytes -= bytes;
+    // all work is in-order on one stream, so a block may be handed out again without a sync
+    c->pool.emplace(bytes, p);
+    c->pool_bytes += bytes;
+}
+const char* new_buf(zkh_ctx* c, size_t n_words, bool zero, zkh_buf** out) {
+    void* p = nullptr;
+    ZKH_TRY(pool_alloc(c, n_words * 4, &p));
+    if (zero && n_words) {
+        hipError_t e = hipMemsetAsync(p, 0, n_words * 4, c->stream);
+        if (e != hipSuccess) return make_err("hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    zkh_alloc_t* a = new zkh_alloc_t{p, n_words * 4, 1, true, c};
+    *out = new zkh_buf{a, 0, n_words, 1};
+    return nullptr;
+}
+const char* ensure_pinned(zkh_ctx* c, size_t words) {
+    if (c->pinned_words >= words) return nullptr;
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    size_t w = words < 65536 ? 65536 : words;
+    ZKH_HIP(hipHostMalloc((void**)&c->pinned, w * 4, hipHostMallocDefault));
+    c->pinned_words = w;
+    return nullptr;
+}
+static hipEvent_t get_event(zkh_ctx* c) {
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void prof_begin(zkh_ctx* c, const char* name, double bytes) {
+    ProfPending p{name, get_event(c), get_event(c), bytes};
+    (void)hipEventRecord(p.a, c->stream);
+    c->pending.push_back(p);
+}
+void prof_end(zkh_ctx* c) { (void)hipEventRecord(c->pending.back().b, c->stream); }
+static void prof_flush(zkh_ctx* c) {
+    if (c->pending.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->pending) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, p.a, p.b);
+        auto& g = c->agg[p.name];
+        g.calls++; g.ms += ms; g.bytes += p.bytes;
+        c->event_pool.push_back(p.a); c->event_pool.push_back(p.b);
+    }
+    c->pending.clear();
+}
+
+static const char* upload(uint32_t** dst, const std::vector<uint32_t>& v) {
+    ZKH_HIP(hipMalloc((void**)dst, v.size() * 4));
+    ZKH_HIP(hipMemcpy(*dst, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    return nullptr;
+}
+static std::vector<uint32_t> powers(Fp base, size_t n) {
+    std::vector<uint32_t> v(n);
+    Fp cur = Fp::one();
+    for (size_t i = 0; i < n; i++) { v[i] = cur.v; cur = cur * base; }
+    return v;
+}
+
+}  // namespace zkh
+
+extern "C" const char* zkh_poseidon2_set_constants(zkh_ctx* c, const uint32_t* rc, const uint32_t* diag) {
+    std::vector<uint32_t> r(24 * 29), d(24);
+    for (int i = 0; i < 24 * 29; i++) r[i] = fp_encode(rc[i]).v;
+    for (int i = 0; i < 24; i++) d[i] = fp_encode(diag[i]).v;
+    memcpy(c->h_rc, r.data(), sizeof c->h_rc);
+    memcpy(c->h_diag, d.data(), sizeof c->h_diag);
+    ZKH_HIP(hipStreamSynchronize(c->stream));
+    ZKH_HIP(hipMemcpy(c->tab.rc, r.data(), r.size() * 4, hipMemcpyHostToDevice));
+    ZKH_HIP(hipMemcpy(c->tab.diag, d.data(), d.size() * 4, hipMemcpyHostToDevice));
+    return nullptr;
+}
+
+extern "C" const char* zkh_ctx_create(int device, const char* suite, zkh_ctx** out) {
+    ZKH_REQUIRE(suite && strcmp(suite, "poseidon2") == 0, "unsupported hash suite '%s' (only poseidon2)", suite ? suite : "(null)");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    ZKH_REQUIRE(e == hipSuccess && ndev > 0, "no HIP device available (%s): libzkhal_mi355x has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    ZKH_REQUIRE(device >= 0 && device < ndev, "device ordinal %d out of range (%d devices)", device, ndev);
+    ZKH_HIP(hipSetDevice(device));
+    zkh_ctx* c = new zkh_ctx();
+    c->device = device;
+    ZKH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    Fp g = fp_encode(137);
+    for (int k = 0; k <= 27; k++) {
+        Fp w = fp_pow(g, 1ull << (27 - k));
+        c->rou_fwd[k] = w.v;
+        c->rou_rev[k] = fp_inv(w).v;
+    }
+    Fp wf = Fp::raw(c->rou_fwd[MAX_LOG_N]), wr = Fp::raw(c->rou_rev[MAX_LOG_N]);
+    ZKH_TRY(upload(&c->tab.tw_fwd_lo, powers(wf, TW_SIZE)));
+    ZKH_TRY(upload(&c->tab.tw_fwd_hi, powers(fp_pow(wf, TW_SIZE), TW_SIZE)));
+    ZKH_TRY(upload(&c->tab.tw_rev_lo, powers(wr, TW_SIZE)));
+    ZKH_TRY(upload(&c->tab.tw_rev_hi, powers(fp_pow(wr, TW_SIZE), TW_SIZE)));
+    ZKH_TRY(upload(&c->tab.tile_fwd, powers(Fp::raw(c->rou_fwd[LDS_TW_LOG]), 1 << (LDS_TW_LOG - 1))));
+    ZKH_TRY(upload(&c->tab.tile_rev, powers(Fp::raw(c->rou_rev[LDS_TW_LOG]), 1 << (LDS_TW_LOG - 1))));
+    Fp three = fp_encode(3);
+    ZKH_TRY(upload(&c->tab.shift_lo, powers(three, TW_SIZE)));
+    ZKH_TRY(upload(&c->tab.shift_hi, powers(fp_pow(three, TW_SIZE), TW_SIZE)));
+    ZKH_TRY(upload(&c->tab.rc, std::vector<uint32_t>(24 * 29)));
+    ZKH_TRY(upload(&c->tab.diag, std::vector<uint32_t>(24)));
+    ZKH_TRY(zkh_poseidon2_set_constants(c, ZKH_P2_ROUND_CONSTANTS, ZKH_P2_M_INT_DIAG));
+    *out = c;
+    return nullptr;
+}
+extern "C" void zkh_ctx_destroy(zkh_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->pool) (void)hipFree(kv.second);
+    uint32_t* t[] = {c->tab.rc, c->tab.diag, c->tab.tw_fwd_lo, c->tab.tw_fwd_hi, c->tab.tw_rev_lo, c->tab.tw_rev_hi,
+                     c->tab.tile_fwd, c->tab.tile_rev, c->tab.shift_lo, c->tab.shift_hi};
+    for (auto p : t) (void)hipFree(p);
+    for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+extern "C" const char* zkh_sync(zkh_ctx* c) { ZKH_HIP(hipStreamSynchronize(c->stream)); return nullptr; }
+extern "C" void* zkh_ctx_stream(zkh_ctx* c) { return (void*)c->stream; }
+
+// ---- buffers ----
+extern "C" const char* zkh_alloc(zkh_ctx* c, const char*, size_t n, int zero, zkh_buf** out) {
+    return new_buf(c, n, zero != 0, out);
+}
+extern "C" const char* zkh_copy_from(zkh_ctx* c, const char*, const uint32_t* host, size_t n, zkh_buf** out) {
+    ZKH_TRY(new_buf(c, n, false, out));
+    if (n) ZKH_HIP(hipMemcpyAsync((*out)->ptr(), host, n * 4, hipMemcpyHostToDevice, c->stream));
+    // the host pointer is only borrowed for the call: make sure the copy has consumed it
+    ZKH_HIP(hipStreamSynchronize(c->stream));
+    return nullptr;
+}
+extern "C" const char* zkh_wrap(zkh_ctx* c, void* dptr, size_t n, zkh_buf** out) {
+    zkh_alloc_t* a = new zkh_alloc_t{dptr, n * 4, 1, false, c};
+    *out = new zkh_buf{a, 0, n, 1};
+    return nullptr;
+}
+extern "C" const char* zkh_slice(zkh_buf* b, size_t off, size_t n, zkh_buf** out) {
+    ZKH_REQUIRE(off + n <= b->len, "slice [%zu, %zu) out of range (size %zu)", off, off + n, b->len);
+    b->a->refs++;
+    *out = new zkh_buf{b->a, b->off + off, n, 1};
+    return nullptr;
+}
+extern "C" void zkh_retain(zkh_buf* b) { b->refs++; }
+extern "C" void zkh_release(zkh_buf* b) {
+    if (!b || --b->refs > 0) return;
+    zkh_alloc_t* a = b->a;
+    if (--a->refs == 0) {
+        if (a->owned) pool_free(a->ctx, a->ptr, a->bytes);
+        delete a;
+    }
+    delete b;
+}
+extern "C" size_t zkh_size(const zkh_buf* b) { return b->len; }
+extern "C" void* zkh_device_ptr(const zkh_buf* b) { return (void*)b->ptr(); }
+extern "C" const char* zkh_read(zkh_ctx* c, const zkh_buf* b, uint32_t* host, size_t off, size_t n) {
+    ZKH_REQUIRE(off + n <= b->len, "read [%zu, %zu) out of range (size %zu)", off, off + n, b->len);
+    if (n) ZKH_HIP(hipMemcpyAsync(host, b->ptr() + off, n * 4, hipMemcpyDeviceToHost, c->stream));
+    ZKH_HIP(hipStreamSynchronize(c->stream));
+    return nullptr;
+}
+extern "C" const char* zkh_write(zkh_ctx* c, zkh_buf* b, const uint32_t* host, size_t off, size_t n) {
+    ZKH_REQUIRE(off + n <= b->len, "write [%zu, %zu) out of range (size %zu)", off, off + n, b->len);
+    if (n) ZKH_HIP(hipMemcpyAsync(b->ptr() + off, host, n * 4, hipMemcpyHostToDevice, c->stream));
+    ZKH_HIP(hipStreamSynchronize(c->stream));
+    return nullptr;
+}
+
+// ---- profiling ----
+extern "C" const char* zkh_prof_enable(zkh_ctx* c, int on) { prof_flush(c); c->prof = on != 0; return nullptr; }
+extern "C" const char* zkh_prof_reset(zkh_ctx* c) { prof_flush(c); c->agg.clear(); return nullptr; }
+extern "C" const char* zkh_prof_get(zkh_ctx* c, zkh_prof_rec* recs, size_t cap, size_t* n) {
+    prof_flush(c);
+    size_t i = 0;
+    for (auto& kv : c->agg) {
+        if (i >= cap) break;
+        memset(&recs[i], 0, sizeof recs[i]);
+        strncpy(recs[i].name, kv.first.c_str(), sizeof(recs[i].name) - 1);
+        recs[i].calls = kv.second.calls; recs[i].total_ms = kv.second.ms; recs[i].alg_bytes = kv.second.bytes;
+        i++;
+    }
+    *n = i;
+    return nullptr;
+}
+
+// =====================================================================================================
+// element-wise / gather ops.  All HBM-bound: one pass, lanes on consecutive words.
+// =====================================================================================================
+namespace {
+
+constexpr int TB = 256;
+inline unsigned blocks_for(size_t n, int per_block = TB) { return (unsigned)((n + per_block - 1) / per_block); }
+
+__global__ void k_add(uint32_t* out, const uint32_t* a, const uint32_t* b, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = add_mod(a[i], b[i]);
+}
+__global__ void k_copy(uint32_t* out, const uint32_t* in, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+__global__ void k_zeroize(uint32_t* io, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && io[i] == INVALID) io[i] = 0;
+}
+// in: k ExtElems (AoS) per idx at in[(j*count + idx)*4 ..]; out: 4 planes of count
+__global__ void k_sum_ext(uint32_t* out, const uint4* in, size_t count, size_t k) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (size_t j = 0; j < k; j++) {
+        uint4 v = in[j * count + idx];
+        s0 = add_mod(s0, v.x); s1 = add_mod(s1, v.y); s2 = add_mod(s2, v.z); s3 = add_mod(s3, v.w);
+    }
+    out[idx] = s0; out[count + idx] = s1; out[2 * count + idx] = s2; out[3 * count + idx] = s3;
+}
+// fri_fold: in = 4 planes x (16*count), out = 4 planes x count; slice order bit-reversed (cpu.rs fri_fold)
+__global__ void k_fri_fold(uint32_t* out, const uint32_t* in, size_t count, Fp4 mix) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    Fp4 tot = Fp4::zero(), cur = Fp4::one();
+#pragma unroll
+    for (unsigned i = 0; i < 16; i++) {
+        unsigned r = __brev(i) >> 28;
+        Fp4 f;
+#pragma unroll
+        for (int p = 0; p < 4; p++) f.c[p] = Fp::raw(in[(size_t)p * count * 16 + r * count + idx]);
+        tot = tot + cur * f;
+        cur = cur * mix;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; p++) out[p * count + idx] = tot.c[p].v;
+}
+__global__ void k_gather(uint32_t* dst, const uint32_t* src, size_t idx, size_t size, size_t stride) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < size) dst[g] = src[g * stride + idx];
+}
+__global__ void k_scatter(uint32_t* into, const uint32_t* index, const uint32_t* values, size_t n) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) into[index[j]] = values[j];
+}
+__global__ void k_combos_prepare(uint4* combos, const uint32_t* pos, const uint4* vals, size_t n) {
+    size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint4 c = combos[pos[k]], v = vals[k];
+    c.x = sub_mod(c.x, v.x); c.y = sub_mod(c.y, v.y); c.z = sub_mod(c.z, v.z); c.w = sub_mod(c.w, v.w);
+    combos[pos[k]] = c;
+}
+// Merkle opening for many query indices: block q handles idx[q]; first the column words then the sibling path.
+__global__ void k_merkle_open(uint32_t* out, const uint32_t* matrix, const uint32_t* nodes, const uint32_t* idxs,
+                              size_t rows, size_t cols, size_t top_size, size_t words_per_query) {
+    const uint32_t q = blockIdx.x;
+    const size_t idx = idxs[q];
+    uint32_t* o = out + (size_t)q * words_per_query;
+    for (size_t c = threadIdx.x; c < cols; c += blockDim.x) o[c] = matrix[c * rows + idx];
+    o += cols;
+    // path: level t (t = 0..) sibling of (idx + rows) >> t, while node index >= 2*top_size
+    size_t node = idx + rows;
+    unsigned levels = 0;
+    for (size_t j = node; j >= 2 * top_size; j >>= 1) levels++;
+    for (unsigned w = threadIdx.x; w < levels * 8; w += blockDim.x) {
+        unsigned lvl = w >> 3;
+        size_t sib = (node >> lvl) ^ 1;
+        o[w] = nodes[sib * 8 + (w & 7)];
+    }
+}
+
+}  // namespace
+
+extern "C" const char* zkh_eltwise_add_elem(zkh_ctx* c, zkh_buf* out, const zkh_buf* a, const zkh_buf* b) {
+    ZKH_REQUIRE(out->len == a->len && a->len == b->len, "eltwise_add_elem: size mismatch");
+    if (!out->len) return nullptr;
+    ProfScope ps(c, "eltwise_add_elem", 12.0 * out->len);
+    k_add<<<blocks_for(out->len), TB, 0, c->stream>>>(out->ptr(), a->ptr(), b->ptr(), out->len);
+    return last_launch_error("eltwise_add_elem");
+}
+extern "C" const char* zkh_eltwise_copy_elem(zkh_ctx* c, zkh_buf* out, const zkh_buf* in) {
+    ZKH_REQUIRE(out->len == in->len, "eltwise_copy_elem: size mismatch");
+    if (!out->len) return nullptr;
+    ProfScope ps(c, "eltwise_copy_elem", 8.0 * out->len);
+    k_copy<<<blocks_for(out->len), TB, 0, c->stream>>>(out->ptr(), in->ptr(), out->len);
+    return last_launch_error("eltwise_copy_elem");
+}
+extern "C" const char* zkh_eltwise_zeroize_elem(zkh_ctx* c, zkh_buf* io) {
+    if (!io->len) return nullptr;
+    ProfScope ps(c, "eltwise_zeroize_elem", 8.0 * io->len);
+    k_zeroize<<<blocks_for(io->len), TB, 0, c->stream>>>(io->ptr(), io->len);
+    return last_launch_error("eltwise_zeroize_elem");
+}
+extern "C" const char* zkh_eltwise_sum_extelem(zkh_ctx* c, zkh_buf* out, const zkh_buf* in) {
+    ZKH_REQUIRE(out->len % 4 == 0 && in->len % 4 == 0, "eltwise_sum_extelem: sizes must be multiples of 4");
+    size_t count = out->len / 4;
+    ZKH_REQUIRE(count && (in->len / 4) % count == 0, "eltwise_sum_extelem: input not a multiple of output");
+    size_t k = in->len / 4 / count;
+    ProfScope ps(c, "eltwise_sum_extelem", 4.0 * (in->len + out->len));
+    k_sum_ext<<<blocks_for(count), TB, 0, c->stream>>>(out->ptr(), (const uint4*)in->ptr(), count, k);
+    return last_launch_error("eltwise_sum_extelem");
+}
+extern "C" const char* zkh_fri_fold(zkh_ctx* c, zkh_buf* out, const zkh_buf* in, const uint32_t mix[4]) {
+    ZKH_REQUIRE(out->len % 4 == 0 && in->len == out->len * 16, "fri_fold: input must be 16x output");
+    size_t count = out->len / 4;
+    Fp4 m(Fp::raw(mix[0]), Fp::raw(mix[1]), Fp::raw(mix[2]), Fp::raw(mix[3]));
+    ProfScope ps(c, "fri_fold", 4.0 * (in->len + out->len));
+    k_fri_fold<<<blocks_for(count), TB, 0, c->stream>>>(out->ptr(), in->ptr(), count, m);
+    return last_launch_error("fri_fold");
+}
+extern "C" const char* zkh_gather_sample(zkh_ctx* c, zkh_buf* dst, const zkh_buf* src, size_t idx, size_t size,
+                                         size_t stride) {
+    ZKH_REQUIRE(dst->len >= size && (size == 0 || (size - 1) * stride + idx < src->len), "gather_sample: out of range");
+    if (!size) return nullptr;
+    ProfScope ps(c, "gather_sample", 8.0 * size);
+    k_gather<<<blocks_for(size), TB, 0, c->stream>>>(dst->ptr(), src->ptr(), idx, size, stride);
+    return last_launch_error("gather_sample");
+}
+extern "C" const char* zkh_scatter(zkh_ctx* c, zkh_buf* into, const uint32_t* index, const uint32_t* offsets,
+                                   const uint32_t* values, size_t n_idx, size_t n_val) {
+    // cpu.rs scatter walks offsets[i]..offsets[i+1] per cycle; the union of those ranges is [offsets[0], offsets[n_idx])
+    (void)n_idx;
+    if (!n_val) return nullptr;
+    for (size_t j = 0; j < n_val; j++) ZKH_REQUIRE(index[j] < into->len, "scatter: index %u out of range", index[j]);
+    (void)offsets;
+    zkh_buf *di = nullptr, *dv = nullptr;
+    ZKH_TRY(zkh_copy_from(c, "scatter_index", index, n_val, &di));
+    ZKH_TRY(zkh_copy_from(c, "scatter_values", values, n_val, &dv));
+    {
+        ProfScope ps(c, "scatter", 12.0 * n_val);
+        k_scatter<<<blocks_for(n_val), TB, 0, c->stream>>>(into->ptr(), di->ptr(), dv->ptr(), n_val);
+    }
+    zkh_release(di); zkh_release(dv);
+    return last_launch_error("scatter");
+}
+extern "C" const char* zkh_combos_prepare(zkh_ctx* c, zkh_buf* combos, const uint32_t* pos, const uint32_t* vals,
+                                          size_t n) {
+    if (!n) return nullptr;
+    for (size_t k = 0; k < n; k++) ZKH_REQUIRE((size_t)pos[k] * 4 + 4 <= combos->len, "combos_prepare: position out of range");
+    zkh_buf *dp = nullptr, *dv = nullptr;
+    ZKH_TRY(zkh_copy_from(c, "prep_pos", pos, n, &dp));
+    ZKH_TRY(zkh_copy_from(c, "prep_val", vals, 4 * n, &dv));
+    {
+        ProfScope ps(c, "combos_prepare", 36.0 * n);
+        k_combos_prepare<<<blocks_for(n), TB, 0, c->stream>>>((uint4*)combos->ptr(), dp->ptr(), (const uint4*)dv->ptr(), n);
+    }
+    zkh_release(dp); zkh_release(dv);
+    return last_launch_error("combos_prepare");
+}
+extern "C" const char* zkh_merkle_open(zkh_ctx* c, const zkh_buf* matrix, const zkh_buf* nodes, size_t rows, size_t cols,
+                                       const uint32_t* idx, size_t n_idx, zkh_buf* out) {
+    ZKH_REQUIRE(matrix->len == rows * cols && nodes->len == rows * 16, "merkle_open: shape mismatch");
+    unsigned layers = log2_ceil(rows), top_layer = 0;
+    for (unsigned i = 1; i < layers; i++) { if ((1u << i) > ZKH_QUERIES) break; top_layer = i; }
+    size_t top_size = (size_t)1 << top_layer;
+    size_t wpq = cols + 8 * (size_t)(layers - top_layer);
+    ZKH_REQUIRE(out->len >= wpq * n_idx, "merkle_open: output too small (%zu < %zu)", out->len, wpq * n_idx);
+    for (size_t i = 0; i < n_idx; i++) ZKH_REQUIRE(idx[i] < rows, "merkle_open: index out of range");
+    if (!n_idx) return nullptr;
+    zkh_buf* di = nullptr;
+    ZKH_TRY(zkh_copy_from(c, "open_idx", idx, n_idx, &di));
+    {
+        ProfScope ps(c, "merkle_open", 8.0 * wpq * n_idx);
+        k_merkle_open<<<(unsigned)n_idx, TB, 0, c->stream>>>(out->ptr(), matrix->ptr(), nodes->ptr(), di->ptr(), rows, cols,
+                                                            top_size, wpq);
+    }
+    zkh_release(di);
+    return last_launch_error("merkle_open");
+}

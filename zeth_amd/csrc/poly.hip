@@ -1,0 +1,282 @@
+// poly.hip — polynomial-side Hal ops on gfx950: batch_evaluate_any, mix_poly_coeffs, combos_divide,
+// prefix_products (risc0-zkp 3.0.2 src/hal/mod.rs, semantics src/hal/cpu.rs + src/core/poly.rs; un-vendored:
+// /root/reference/Cargo.lock:5393).  Issued by Prover::finalize (src/prove/prover.rs), reached from
+// /root/reference/crates/host/src/lib.rs:137.
+//
+// All of these stream W x n (or combos x n) words once: HBM-bound.  The two linear recurrences (synthetic
+// division, running product) are done as three-level 256-wide block scans (up-sweep of block totals, down-sweep
+// with carries) instead of upstream's chunked sequential loops.
+#include "common.h"
+
+using namespace zkh;
+
+namespace {
+
+constexpr int TB = 256;
+
+__device__ __forceinline__ Fp4 ld_ext(const uint32_t* p) {
+    const uint4 v = *(const uint4*)p;
+    return Fp4(Fp::raw(v.x), Fp::raw(v.y), Fp::raw(v.z), Fp::raw(v.w));
+}
+__device__ __forceinline__ void st_ext(uint32_t* p, Fp4 v) { *(uint4*)p = make_uint4(v.c[0].v, v.c[1].v, v.c[2].v, v.c[3].v); }
+
+// out[i] = start * base^i, i < n   (small tables: mix powers, x^t, ...)
+__global__ void k_ext_powers(uint32_t* out, Fp4 start, Fp4 base, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) st_ext(out + 4 * i, start * fp4_pow(base, i));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// batch_evaluate_any.  Block (chunk, k): partial[k][chunk] = sum_{j in chunk} coeffs[which[k]][j] * x_k^j.
+// Lane t owns coefficients j = chunk*CH + i*256 + t (coalesced); term = c * X^i (X = x^256, table in LDS),
+// the lane total is multiplied once by x^t and the block total once by x^(chunk*CH).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int EV_PER = 64, EV_CH = TB * EV_PER;
+__global__ __launch_bounds__(TB) void k_eval_partial(uint32_t* __restrict__ partial, const uint32_t* __restrict__ coeffs,
+                                                     size_t po, const uint32_t* __restrict__ which,
+                                                     const uint32_t* __restrict__ xs, uint32_t n_chunks) {
+    __shared__ uint4 xt[TB];        // x^t
+    __shared__ uint4 xp[EV_PER];    // X^i
+    __shared__ uint4 red[TB];
+    const uint32_t k = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
+    const Fp4 x = ld_ext(xs + 4 * k);
+    // doubling: tab[s + i] = tab[i] * x^s
+    if (t == 0) { st_ext((uint32_t*)&xt[0], Fp4::one()); }
+    __syncthreads();
+    Fp4 xs_pow = x;    // x^s
+    for (uint32_t s = 1; s < TB; s <<= 1) {
+        if (t < s) st_ext((uint32_t*)&xt[s + t], ld_ext((const uint32_t*)&xt[t]) * xs_pow);
+        xs_pow = xs_pow * xs_pow;
+        __syncthreads();
+    }
+    const Fp4 X = xs_pow;            // x^256
+    if (t == 0) st_ext((uint32_t*)&xp[0], Fp4::one());
+    __syncthreads();
+    Fp4 Xs = X;
+    for (uint32_t s = 1; s < EV_PER; s <<= 1) {
+        if (t < s) st_ext((uint32_t*)&xp[s + t], ld_ext((const uint32_t*)&xp[t]) * Xs);
+        Xs = Xs * Xs;
+        __syncthreads();
+    }
+    const uint32_t* c = coeffs + (size_t)which[k] * po;
+    const size_t j0 = (size_t)chunk * EV_CH + t;
+    Fp4 acc = Fp4::zero();
+#pragma unroll 4
+    for (int i = 0; i < EV_PER; i++) {
+        const size_t j = j0 + (size_t)i * TB;
+        if (j < po) acc = acc + ld_ext((const uint32_t*)&xp[i]) * Fp::raw(c[j]);
+    }
+    acc = acc * ld_ext((const uint32_t*)&xt[t]);
+    st_ext((uint32_t*)&red[t], acc);
+    __syncthreads();
+    for (uint32_t s = TB / 2; s >= 1; s >>= 1) {
+        if (t < s) st_ext((uint32_t*)&red[t], ld_ext((const uint32_t*)&red[t]) + ld_ext((const uint32_t*)&red[t + s]));
+        __syncthreads();
+    }
+    if (t == 0) {
+        // x^(chunk*CH) = (X^EV_PER)^chunk
+        const Fp4 base = fp4_pow(Xs, chunk);   // Xs == X^EV_PER after the loop
+        st_ext(partial + 4 * ((size_t)k * n_chunks + chunk), ld_ext((const uint32_t*)&red[0]) * base);
+    }
+}
+__global__ void k_eval_final(uint32_t* out, const uint32_t* partial, uint32_t n_chunks, uint32_t n_eval) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_eval) return;
+    Fp4 acc = Fp4::zero();
+    for (uint32_t c = 0; c < n_chunks; c++) acc = acc + ld_ext(partial + 4 * ((size_t)k * n_chunks + c));
+    st_ext(out + 4 * k, acc);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// mix_poly_coeffs: out[combos[c]][idx] += (mix_start * mix^c) * in[c][idx].  One lane per idx, columns streamed
+// with lanes on consecutive words; the running combo accumulator is flushed whenever the (wave-uniform)
+// combo id changes.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TB) void k_mix_poly_coeffs(uint32_t* __restrict__ out, const uint32_t* __restrict__ in,
+                                                        const uint32_t* __restrict__ combos, const uint32_t* __restrict__ pw,
+                                                        uint32_t input_size, size_t count) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    Fp4 acc = Fp4::zero();
+    uint32_t cur_combo = combos[0];
+    for (uint32_t c = 0; c < input_size; c++) {
+        const uint32_t cb = combos[c];
+        if (cb != cur_combo) {
+            uint32_t* o = out + 4 * ((size_t)cur_combo * count + idx);
+            st_ext(o, ld_ext(o) + acc);
+            acc = Fp4::zero();
+            cur_combo = cb;
+        }
+        acc = acc + ld_ext(pw + 4 * c) * Fp::raw(in[(size_t)c * count + idx]);
+    }
+    uint32_t* o = out + 4 * ((size_t)cur_combo * count + idx);
+    st_ext(o, ld_ext(o) + acc);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Weighted suffix scan over blocks of 256 ExtElems:
+//     S[t] = sum_{t' >= t} v[t'] * w^(t'-t)  +  w^(256-t) * carry          (carry = S of the next block's start)
+// TOTAL_ONLY: write S[0] per block (up-sweep).  Otherwise write S shifted by `shift` positions
+// (shift = 1 turns suffix sums into synthetic-division quotients: q_i = S_{i+1}).
+// ---------------------------------------------------------------------------------------------------------
+template <bool TOTAL_ONLY>
+__global__ __launch_bounds__(TB) void k_suffix_scan(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, size_t n,
+                                                    Fp4 w, const uint32_t* __restrict__ carries /* per block b: S of block b+1 start; may be null */,
+                                                    size_t n_carries, uint32_t shift, uint32_t* __restrict__ rem_out) {
+    __shared__ uint4 buf[2][TB + 1];
+    const uint32_t t = threadIdx.x;
+    const size_t b = blockIdx.x, i = b * TB + t;
+    Fp4 v = i < n ? ld_ext(in + 4 * i) : Fp4::zero();
+    Fp4 carry = Fp4::zero();
+    if (carries && b + 1 < n_carries) carry = ld_ext(carries + 4 * (b + 1));
+    st_ext((uint32_t*)&buf[0][t], v);
+    if (t == 0) st_ext((uint32_t*)&buf[0][TB], carry);
+    __syncthreads();
+    int cur = 0;
+    Fp4 wd = w;
+    for (uint32_t d = 1; d <= TB; d <<= 1) {       // 9 steps cover offsets up to 256 (the carry slot)
+        // each slot t in [0, 256]: S_t += w^d * S_{t+d}
+        for (uint32_t s = t; s <= TB; s += TB) {
+            Fp4 a = ld_ext((const uint32_t*)&buf[cur][s]);
+            if (s + d <= TB) a = a + ld_ext((const uint32_t*)&buf[cur][s + d]) * wd;
+            st_ext((uint32_t*)&buf[cur ^ 1][s], a);
+        }
+        wd = wd * wd;
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (TOTAL_ONLY) {
+        if (t == 0) st_ext(out + 4 * b, ld_ext((const uint32_t*)&buf[cur][0]));
+    } else {
+        if (i < n) st_ext(out + 4 * i, ld_ext((const uint32_t*)&buf[cur][t + shift]));
+        if (rem_out && i == 0) st_ext(rem_out, ld_ext((const uint32_t*)&buf[cur][0]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// prefix_products: inclusive running product over ExtElems, same three-level structure (prefix direction).
+// ---------------------------------------------------------------------------------------------------------
+template <bool TOTAL_ONLY>
+__global__ __launch_bounds__(TB) void k_prefix_prod(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, size_t n,
+                                                    const uint32_t* __restrict__ carries /* per block b: product of everything before block b */) {
+    __shared__ uint4 buf[2][TB];
+    const uint32_t t = threadIdx.x;
+    const size_t b = blockIdx.x, i = b * TB + t;
+    Fp4 v = i < n ? ld_ext(in + 4 * i) : Fp4::one();
+    if (carries && t == 0 && b > 0) v = v * ld_ext(carries + 4 * (b - 1));
+    st_ext((uint32_t*)&buf[0][t], v);
+    __syncthreads();
+    int cur = 0;
+    for (uint32_t d = 1; d < TB; d <<= 1) {
+        Fp4 a = ld_ext((const uint32_t*)&buf[cur][t]);
+        if (t >= d) a = a * ld_ext((const uint32_t*)&buf[cur][t - d]);
+        st_ext((uint32_t*)&buf[cur ^ 1][t], a);
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (TOTAL_ONLY) {
+        if (t == TB - 1) st_ext(out + 4 * b, ld_ext((const uint32_t*)&buf[cur][t]));
+    } else if (i < n) {
+        st_ext(out + 4 * i, ld_ext((const uint32_t*)&buf[cur][t]));
+    }
+}
+
+inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
+inline Fp4 to_fp4(const uint32_t* w) { return Fp4(Fp::raw(w[0]), Fp::raw(w[1]), Fp::raw(w[2]), Fp::raw(w[3])); }
+
+}  // namespace
+
+namespace zkh {
+const char* launch_ext_powers(zkh_ctx* c, uint32_t* out, const uint32_t start[4], const uint32_t base[4], uint32_t n) {
+    if (!n) return nullptr;
+    k_ext_powers<<<(unsigned)ceil_div(n, TB), TB, 0, c->stream>>>(out, to_fp4(start), to_fp4(base), n);
+    return last_launch_error("ext_powers");
+}
+}  // namespace zkh
+
+extern "C" const char* zkh_batch_evaluate_any(zkh_ctx* c, const zkh_buf* coeffs, size_t poly_count, const zkh_buf* which,
+                                              const zkh_buf* xs, zkh_buf* out) {
+    ZKH_REQUIRE(poly_count && coeffs->len % poly_count == 0, "batch_evaluate_any: coeffs size not a multiple of poly_count");
+    const size_t n_eval = which->len;
+    ZKH_REQUIRE(xs->len == 4 * n_eval && out->len == 4 * n_eval, "batch_evaluate_any: which/xs/out size mismatch");
+    if (!n_eval) return nullptr;
+    ZKH_REQUIRE(n_eval <= 65535, "batch_evaluate_any: too many evaluation points");
+    const size_t po = coeffs->len / poly_count;
+    const uint32_t n_chunks = (uint32_t)ceil_div(po, EV_CH);
+    zkh_buf* partial = nullptr;
+    ZKH_TRY(new_buf(c, 4 * n_eval * n_chunks, false, &partial));
+    {
+        ProfScope prof(c, "batch_evaluate_any", 4.0 * po * n_eval);
+        k_eval_partial<<<dim3(n_chunks, (unsigned)n_eval), TB, 0, c->stream>>>(partial->ptr(), coeffs->ptr(), po, which->ptr(),
+                                                                              xs->ptr(), n_chunks);
+        k_eval_final<<<(unsigned)ceil_div(n_eval, TB), TB, 0, c->stream>>>(out->ptr(), partial->ptr(), n_chunks, (uint32_t)n_eval);
+    }
+    zkh_release(partial);
+    return last_launch_error("batch_evaluate_any");
+}
+
+extern "C" const char* zkh_mix_poly_coeffs(zkh_ctx* c, zkh_buf* out, const uint32_t mix_start[4], const uint32_t mix[4],
+                                           const zkh_buf* in, const zkh_buf* combos, size_t input_size, size_t count) {
+    ZKH_REQUIRE(in->len == input_size * count && combos->len >= input_size, "mix_poly_coeffs: input shape mismatch");
+    ZKH_REQUIRE(out->len % (4 * count) == 0, "mix_poly_coeffs: output is not a whole number of ExtElem columns");
+    if (!input_size || !count) return nullptr;
+    zkh_buf* pw = nullptr;
+    ZKH_TRY(new_buf(c, 4 * input_size, false, &pw));
+    {
+        ProfScope prof(c, "mix_poly_coeffs", 4.0 * in->len + 32.0 * count * 2);
+        k_ext_powers<<<(unsigned)ceil_div(input_size, TB), TB, 0, c->stream>>>(pw->ptr(), to_fp4(mix_start), to_fp4(mix), (uint32_t)input_size);
+        k_mix_poly_coeffs<<<(unsigned)ceil_div(count, TB), TB, 0, c->stream>>>(out->ptr(), in->ptr(), combos->ptr(), pw->ptr(),
+                                                                              (uint32_t)input_size, count);
+    }
+    zkh_release(pw);
+    return last_launch_error("mix_poly_coeffs");
+}
+
+extern "C" const char* zkh_combos_divide(zkh_ctx* c, zkh_buf* combos, size_t combo, size_t cycles, const uint32_t* pts,
+                                         size_t n_pts, zkh_buf* rem_out) {
+    ZKH_REQUIRE((combo + 1) * cycles * 4 <= combos->len, "combos_divide: combo %zu out of range", combo);
+    ZKH_REQUIRE(rem_out->len >= 4 * n_pts, "combos_divide: remainder buffer too small");
+    ZKH_REQUIRE(cycles <= ((size_t)1 << 24), "combos_divide: polynomial too long");
+    uint32_t* poly = combos->ptr() + 4 * combo * cycles;
+    const size_t n0 = cycles, n1 = ceil_div(n0, TB), n2 = ceil_div(n1, TB);
+    zkh_buf *t0 = nullptr, *t1 = nullptr, *s2 = nullptr;
+    ZKH_TRY(new_buf(c, 4 * n1, false, &t0));    // level-0 block totals, then S at level-0 block starts
+    ZKH_TRY(new_buf(c, 4 * n2, false, &t1));    // level-1 block totals, then S at level-1 block starts
+    ZKH_TRY(new_buf(c, 4 * TB, false, &s2));
+    for (size_t k = 0; k < n_pts; k++) {
+        const Fp4 z = to_fp4(pts + 4 * k), z256 = fp4_pow(z, TB), z64k = fp4_pow(z256, TB);
+        ProfScope prof(c, "combos_divide", 32.0 * cycles);
+        // up-sweep
+        k_suffix_scan<true><<<(unsigned)n1, TB, 0, c->stream>>>(t0->ptr(), poly, n0, z, nullptr, 0, 0, nullptr);
+        k_suffix_scan<true><<<(unsigned)n2, TB, 0, c->stream>>>(t1->ptr(), t0->ptr(), n1, z256, nullptr, 0, 0, nullptr);
+        // top level (n2 <= 256): S at level-1 block starts
+        k_suffix_scan<false><<<1, TB, 0, c->stream>>>(t1->ptr(), t1->ptr(), n2, z64k, nullptr, 0, 0, nullptr);
+        // down-sweep: S at level-0 block starts, then the quotient itself (shift 1), remainder = S_0
+        k_suffix_scan<false><<<(unsigned)n2, TB, 0, c->stream>>>(t0->ptr(), t0->ptr(), n1, z256, t1->ptr(), n2, 0, nullptr);
+        k_suffix_scan<false><<<(unsigned)n1, TB, 0, c->stream>>>(poly, poly, n0, z, t0->ptr(), n1, 1, rem_out->ptr() + 4 * k);
+        ZKH_TRY(last_launch_error("combos_divide"));
+    }
+    zkh_release(t0); zkh_release(t1); zkh_release(s2);
+    return nullptr;
+}
+
+extern "C" const char* zkh_prefix_products(zkh_ctx* c, zkh_buf* io) {
+    ZKH_REQUIRE(io->len % 4 == 0, "prefix_products: not an ExtElem buffer");
+    const size_t n0 = io->len / 4;
+    if (n0 <= 1) return nullptr;
+    ZKH_REQUIRE(n0 <= ((size_t)1 << 24), "prefix_products: buffer too long");
+    const size_t n1 = ceil_div(n0, TB), n2 = ceil_div(n1, TB);
+    zkh_buf *t0 = nullptr, *t1 = nullptr;
+    ZKH_TRY(new_buf(c, 4 * n1, false, &t0));
+    ZKH_TRY(new_buf(c, 4 * n2, false, &t1));
+    {
+        ProfScope prof(c, "prefix_products", 32.0 * n0);
+        k_prefix_prod<true><<<(unsigned)n1, TB, 0, c->stream>>>(t0->ptr(), io->ptr(), n0, nullptr);
+        k_prefix_prod<true><<<(unsigned)n2, TB, 0, c->stream>>>(t1->ptr(), t0->ptr(), n1, nullptr);
+        k_prefix_prod<false><<<1, TB, 0, c->stream>>>(t1->ptr(), t1->ptr(), n2, nullptr);                 // inclusive over level-1 totals
+        k_prefix_prod<false><<<(unsigned)n2, TB, 0, c->stream>>>(t0->ptr(), t0->ptr(), n1, t1->ptr());    // inclusive over level-0 totals
+        k_prefix_prod<false><<<(unsigned)n1, TB, 0, c->stream>>>(io->ptr(), io->ptr(), n0, t0->ptr());
+    }
+    zkh_release(t0); zkh_release(t1);
+    return last_launch_error("prefix_products");
+}

@@ -1,0 +1,340 @@
+"""Python mirror of `risc0_zkp::hal::{Hal, CircuitHal, Buffer}` over libzkhal_mi355x.so (ctypes, no torch types).
+
+Method names and argument meaning follow the upstream trait (risc0-zkp 3.0.2 src/hal/mod.rs, un-vendored:
+/root/reference/Cargo.lock:5393) so that tests read like upstream's cpu-vs-gpu HAL parity tests.  The product
+path is the HIP library ONLY: importing this module without the built .so, or creating a HipHal without a
+GPU, raises — there is no CPU fallback here (the CPU oracle lives in oracle/ and is test-only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzkhal_mi355x.so")
+
+INV_RATE, QUERIES, FRI_FOLD, FRI_MIN_DEGREE, ZK_CYCLES, CHECK_SIZE, EXT_SIZE, DIGEST_WORDS = 4, 50, 16, 256, 1994, 16, 4, 8
+
+# every symbol include/zkhal.h declares: (restype, argtypes)
+_sz, _u32, _u64, _vp, _i = C.c_size_t, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int
+_u32p = C.POINTER(C.c_uint32)
+_err = C.c_void_p    # heap error string (freed with zkh_free_error)
+
+
+class ProfRec(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("calls", C.c_uint64), ("total_ms", C.c_double), ("alg_bytes", C.c_double)]
+
+
+ABI = {
+    "zkh_free_error": (None, [_vp]),
+    "zkh_version": (C.c_char_p, []),
+    "zkh_ctx_create": (_err, [_i, C.c_char_p, C.POINTER(_vp)]),
+    "zkh_ctx_destroy": (None, [_vp]),
+    "zkh_sync": (_err, [_vp]),
+    "zkh_ctx_stream": (_vp, [_vp]),
+    "zkh_poseidon2_set_constants": (_err, [_vp, _u32p, _u32p]),
+    "zkh_alloc": (_err, [_vp, C.c_char_p, _sz, _i, C.POINTER(_vp)]),
+    "zkh_copy_from": (_err, [_vp, C.c_char_p, _u32p, _sz, C.POINTER(_vp)]),
+    "zkh_wrap": (_err, [_vp, _vp, _sz, C.POINTER(_vp)]),
+    "zkh_slice": (_err, [_vp, _sz, _sz, C.POINTER(_vp)]),
+    "zkh_retain": (None, [_vp]),
+    "zkh_release": (None, [_vp]),
+    "zkh_size": (_sz, [_vp]),
+    "zkh_device_ptr": (_vp, [_vp]),
+    "zkh_read": (_err, [_vp, _vp, _u32p, _sz, _sz]),
+    "zkh_write": (_err, [_vp, _vp, _u32p, _sz, _sz]),
+    "zkh_batch_interpolate_ntt": (_err, [_vp, _vp, _sz]),
+    "zkh_batch_expand_into_evaluate_ntt": (_err, [_vp, _vp, _vp, _sz, _sz]),
+    "zkh_batch_bit_reverse": (_err, [_vp, _vp, _sz]),
+    "zkh_zk_shift": (_err, [_vp, _vp, _sz]),
+    "zkh_batch_interpolate_ntt_zk_shift": (_err, [_vp, _vp, _sz]),
+    "zkh_batch_interpolate_ntt_from": (_err, [_vp, _vp, _vp, _sz, _i]),
+    "zkh_hash_rows": (_err, [_vp, _vp, _vp]),
+    "zkh_hash_fold": (_err, [_vp, _vp, _sz, _sz]),
+    "zkh_merkle_fold_all": (_err, [_vp, _vp, _sz]),
+    "zkh_batch_evaluate_any": (_err, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "zkh_mix_poly_coeffs": (_err, [_vp, _vp, _u32p, _u32p, _vp, _vp, _sz, _sz]),
+    "zkh_combos_prepare": (_err, [_vp, _vp, _u32p, _u32p, _sz]),
+    "zkh_combos_divide": (_err, [_vp, _vp, _sz, _sz, _u32p, _sz, _vp]),
+    "zkh_eltwise_add_elem": (_err, [_vp, _vp, _vp, _vp]),
+    "zkh_eltwise_copy_elem": (_err, [_vp, _vp, _vp]),
+    "zkh_eltwise_zeroize_elem": (_err, [_vp, _vp]),
+    "zkh_eltwise_sum_extelem": (_err, [_vp, _vp, _vp]),
+    "zkh_fri_fold": (_err, [_vp, _vp, _vp, _u32p]),
+    "zkh_gather_sample": (_err, [_vp, _vp, _vp, _sz, _sz, _sz]),
+    "zkh_scatter": (_err, [_vp, _vp, _u32p, _u32p, _u32p, _sz, _sz]),
+    "zkh_prefix_products": (_err, [_vp, _vp]),
+    "zkh_merkle_open": (_err, [_vp, _vp, _vp, _sz, _sz, _u32p, _sz, _vp]),
+    "zkh_circuit_load": (_err, [_vp, _u32p, _sz, C.POINTER(_vp)]),
+    "zkh_circuit_destroy": (None, [_vp]),
+    "zkh_circuit_has_compiled_kernel": (_i, [_vp]),
+    "zkh_eval_check": (_err, [_vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _u32p, _sz, _i]),
+    "zkh_syn_witgen": (_err, [_vp, _vp, _sz, _sz, _u64, _u64, _vp, _vp, _u32p]),
+    "zkh_syn_accum": (_err, [_vp, _vp, _sz, _sz, _u64, _vp, _u32p, _vp]),
+    "zkh_prover_create": (_err, [_vp, _vp, C.POINTER(_vp)]),
+    "zkh_prover_destroy": (None, [_vp]),
+    "zkh_prove_segment": (_err, [_vp, _sz, _sz, _u64, _vp, _vp, _u32p, C.POINTER(_u32p), C.POINTER(_sz)]),
+    "zkh_free_seal": (None, [_u32p]),
+    "zkh_prof_enable": (_err, [_vp, _i]),
+    "zkh_prof_get": (_err, [_vp, C.POINTER(ProfRec), _sz, C.POINTER(_sz)]),
+    "zkh_prof_reset": (_err, [_vp]),
+}
+
+_lib = None
+
+
+class HalError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen libzkhal_mi355x.so and bind every symbol of include/zkhal.h (fails loudly if anything is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HalError(f"{LIB_PATH} is missing: run `python -m zeth_amd.build` (no CPU fallback exists)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in ABI.items():
+        fn = getattr(lib, name)      # AttributeError if the library does not export it
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _check(err):
+    if err:
+        lib = load_library()
+        msg = C.cast(err, C.c_char_p).value.decode(errors="replace")
+        lib.zkh_free_error(err)
+        raise HalError(msg)
+
+
+def _u32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(_u32p)
+
+
+class Buffer:
+    """`hal::Buffer<T>`: size / slice / to_vec (view) / get_at."""
+
+    def __init__(self, hal: "HipHal", handle):
+        self.hal, self.h = hal, handle
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h and _lib is not None and getattr(self.hal, "ctx", None):
+            _lib.zkh_release(h)      # (a context that is already closed has freed its pool)
+
+    def size(self) -> int:
+        return _lib.zkh_size(self.h)
+
+    def slice(self, offset: int, size: int) -> "Buffer":
+        out = _vp()
+        _check(_lib.zkh_slice(self.h, offset, size, C.byref(out)))
+        return Buffer(self.hal, out)
+
+    def to_vec(self) -> np.ndarray:
+        out = np.empty(self.size(), dtype=np.uint32)
+        _check(_lib.zkh_read(self.hal.ctx, self.h, _ptr(out), 0, out.size))
+        return out
+
+    def get_at(self, idx: int) -> int:
+        out = np.empty(1, dtype=np.uint32)
+        _check(_lib.zkh_read(self.hal.ctx, self.h, _ptr(out), idx, 1))
+        return int(out[0])
+
+    def write(self, host, offset: int = 0) -> None:
+        a = _u32(host)
+        _check(_lib.zkh_write(self.hal.ctx, self.h, _ptr(a), offset, a.size))
+
+    def device_ptr(self) -> int:
+        return _lib.zkh_device_ptr(self.h)
+
+
+class Circuit:
+    """A loaded circuit description (TapSet + PolyExtStep list) — the `CircuitHal` side."""
+
+    def __init__(self, hal: "HipHal", desc):
+        self.hal = hal
+        self.desc = _u32(desc)
+        h = _vp()
+        _check(_lib.zkh_circuit_load(hal.ctx, _ptr(self.desc), self.desc.size, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h and _lib is not None:
+            _lib.zkh_circuit_destroy(h)
+
+    def has_compiled_kernel(self) -> bool:
+        return bool(_lib.zkh_circuit_has_compiled_kernel(self.h))
+
+    def eval_check(self, check: Buffer, groups: Sequence[Buffer], globals_: Sequence[Buffer], poly_mix, po2: int,
+                   use_interpreter: bool = False) -> None:
+        g = (_vp * 3)(*[b.h for b in groups])
+        gl = (_vp * 2)(*[b.h for b in globals_])
+        pm = _u32(poly_mix)
+        _check(_lib.zkh_eval_check(self.hal.ctx, self.h, check.h, g, gl, _ptr(pm), po2, int(use_interpreter)))
+
+
+class HipHal:
+    """`impl Hal for HipHal` — one MI355X, one HIP stream, one driving thread."""
+
+    def __init__(self, device: int = 0, hash_suite: str = "poseidon2"):
+        load_library()
+        ctx = _vp()
+        _check(_lib.zkh_ctx_create(device, hash_suite.encode(), C.byref(ctx)))
+        self.ctx = ctx
+        self.device = device
+
+    def close(self):
+        ctx, self.ctx = getattr(self, "ctx", None), None
+        if ctx and _lib is not None:
+            _lib.zkh_ctx_destroy(ctx)
+
+    def __del__(self):
+        # buffers hold a reference to the hal, so the context outlives them
+        self.close()
+
+    def sync(self) -> None:
+        _check(_lib.zkh_sync(self.ctx))
+
+    # ---- allocation (alloc_elem / alloc_extelem / alloc_digest / alloc_u32 / copy_from_*) ----
+    def alloc(self, name: str, n_words: int, zero: bool = False) -> Buffer:
+        out = _vp()
+        _check(_lib.zkh_alloc(self.ctx, name.encode(), n_words, int(zero), C.byref(out)))
+        return Buffer(self, out)
+
+    def alloc_elem(self, name: str, size: int) -> Buffer:
+        return self.alloc(name, size)
+
+    def alloc_extelem(self, name: str, size: int) -> Buffer:
+        return self.alloc(name, size * EXT_SIZE)
+
+    def alloc_digest(self, name: str, size: int) -> Buffer:
+        return self.alloc(name, size * DIGEST_WORDS)
+
+    def copy_from(self, name: str, host) -> Buffer:
+        a = _u32(host).reshape(-1)
+        out = _vp()
+        _check(_lib.zkh_copy_from(self.ctx, name.encode(), _ptr(a), a.size, C.byref(out)))
+        return Buffer(self, out)
+
+    copy_from_elem = copy_from_extelem = copy_from_u32 = copy_from_digest = copy_from
+
+    def wrap(self, device_ptr: int, n_words: int) -> Buffer:
+        out = _vp()
+        _check(_lib.zkh_wrap(self.ctx, device_ptr, n_words, C.byref(out)))
+        return Buffer(self, out)
+
+    # ---- trait Hal ----
+    def batch_interpolate_ntt(self, io: Buffer, count: int) -> None:
+        _check(_lib.zkh_batch_interpolate_ntt(self.ctx, io.h, count))
+
+    def batch_expand_into_evaluate_ntt(self, out: Buffer, inp: Buffer, count: int, expand_bits: int) -> None:
+        _check(_lib.zkh_batch_expand_into_evaluate_ntt(self.ctx, out.h, inp.h, count, expand_bits))
+
+    def batch_bit_reverse(self, io: Buffer, count: int) -> None:
+        _check(_lib.zkh_batch_bit_reverse(self.ctx, io.h, count))
+
+    def zk_shift(self, io: Buffer, count: int) -> None:
+        _check(_lib.zkh_zk_shift(self.ctx, io.h, count))
+
+    def batch_interpolate_ntt_zk_shift(self, io: Buffer, count: int) -> None:
+        _check(_lib.zkh_batch_interpolate_ntt_zk_shift(self.ctx, io.h, count))
+
+    def batch_interpolate_ntt_from(self, out: Buffer, inp: Buffer, count: int, zk_shift: bool) -> None:
+        _check(_lib.zkh_batch_interpolate_ntt_from(self.ctx, out.h, inp.h, count, int(zk_shift)))
+
+    def hash_rows(self, output: Buffer, matrix: Buffer) -> None:
+        _check(_lib.zkh_hash_rows(self.ctx, output.h, matrix.h))
+
+    def hash_fold(self, io: Buffer, input_size: int, output_size: int) -> None:
+        _check(_lib.zkh_hash_fold(self.ctx, io.h, input_size, output_size))
+
+    def merkle_fold_all(self, nodes: Buffer, rows: int) -> None:
+        _check(_lib.zkh_merkle_fold_all(self.ctx, nodes.h, rows))
+
+    def batch_evaluate_any(self, coeffs: Buffer, poly_count: int, which: Buffer, xs: Buffer, out: Buffer) -> None:
+        _check(_lib.zkh_batch_evaluate_any(self.ctx, coeffs.h, poly_count, which.h, xs.h, out.h))
+
+    def mix_poly_coeffs(self, output: Buffer, mix_start, mix, inp: Buffer, combos: Buffer, input_size: int, count: int) -> None:
+        ms, m = _u32(mix_start), _u32(mix)
+        _check(_lib.zkh_mix_poly_coeffs(self.ctx, output.h, _ptr(ms), _ptr(m), inp.h, combos.h, input_size, count))
+
+    def combos_prepare(self, combos: Buffer, pos, vals_ext) -> None:
+        p, v = _u32(pos), _u32(vals_ext).reshape(-1)
+        _check(_lib.zkh_combos_prepare(self.ctx, combos.h, _ptr(p), _ptr(v), p.size))
+
+    def combos_divide(self, combos: Buffer, combo: int, cycles: int, pts_ext, rem_out: Buffer) -> None:
+        p = _u32(pts_ext).reshape(-1)
+        _check(_lib.zkh_combos_divide(self.ctx, combos.h, combo, cycles, _ptr(p), p.size // 4, rem_out.h))
+
+    def eltwise_add_elem(self, out: Buffer, a: Buffer, b: Buffer) -> None:
+        _check(_lib.zkh_eltwise_add_elem(self.ctx, out.h, a.h, b.h))
+
+    def eltwise_copy_elem(self, out: Buffer, inp: Buffer) -> None:
+        _check(_lib.zkh_eltwise_copy_elem(self.ctx, out.h, inp.h))
+
+    def eltwise_zeroize_elem(self, io: Buffer) -> None:
+        _check(_lib.zkh_eltwise_zeroize_elem(self.ctx, io.h))
+
+    def eltwise_sum_extelem(self, out: Buffer, inp: Buffer) -> None:
+        _check(_lib.zkh_eltwise_sum_extelem(self.ctx, out.h, inp.h))
+
+    def fri_fold(self, out: Buffer, inp: Buffer, mix) -> None:
+        m = _u32(mix)
+        _check(_lib.zkh_fri_fold(self.ctx, out.h, inp.h, _ptr(m)))
+
+    def gather_sample(self, dst: Buffer, src: Buffer, idx: int, size: int, stride: int) -> None:
+        _check(_lib.zkh_gather_sample(self.ctx, dst.h, src.h, idx, size, stride))
+
+    def scatter(self, into: Buffer, index, offsets, values) -> None:
+        i, o, v = _u32(index), _u32(offsets), _u32(values)
+        _check(_lib.zkh_scatter(self.ctx, into.h, _ptr(i), _ptr(o), _ptr(v), o.size - 1, v.size))
+
+    def prefix_products(self, io: Buffer) -> None:
+        _check(_lib.zkh_prefix_products(self.ctx, io.h))
+
+    def merkle_open(self, matrix: Buffer, nodes: Buffer, rows: int, cols: int, idx, out: Buffer) -> None:
+        i = _u32(idx)
+        _check(_lib.zkh_merkle_open(self.ctx, matrix.h, nodes.h, rows, cols, _ptr(i), i.size, out.h))
+
+    def poseidon2_set_constants(self, rc, diag) -> None:
+        r, d = _u32(rc), _u32(diag)
+        assert r.size == 24 * 29 and d.size == 24
+        _check(_lib.zkh_poseidon2_set_constants(self.ctx, _ptr(r), _ptr(d)))
+
+    # ---- circuit + SYN witness ----
+    def load_circuit(self, desc) -> Circuit:
+        return Circuit(self, desc)
+
+    def syn_witgen(self, circuit: Circuit, po2: int, zk_cycles: int, seed: int, noise_seed: int, code: Buffer, data: Buffer) -> np.ndarray:
+        out = np.zeros(4, dtype=np.uint32)
+        _check(_lib.zkh_syn_witgen(self.ctx, circuit.h, po2, zk_cycles, seed, noise_seed, code.h, data.h, _ptr(out)))
+        return out
+
+    def syn_accum(self, circuit: Circuit, po2: int, zk_cycles: int, noise_seed: int, data: Buffer, mix_global, accum: Buffer) -> None:
+        m = _u32(mix_global)
+        _check(_lib.zkh_syn_accum(self.ctx, circuit.h, po2, zk_cycles, noise_seed, data.h, _ptr(m), accum.h))
+
+    # ---- profiling ----
+    def prof_enable(self, on: bool = True) -> None:
+        _check(_lib.zkh_prof_enable(self.ctx, int(on)))
+
+    def prof_reset(self) -> None:
+        _check(_lib.zkh_prof_reset(self.ctx))
+
+    def prof_get(self) -> List[dict]:
+        recs = (ProfRec * 128)()
+        n = _sz()
+        _check(_lib.zkh_prof_get(self.ctx, recs, 128, C.byref(n)))
+        return [{"name": recs[i].name.decode(), "calls": int(recs[i].calls), "total_ms": float(recs[i].total_ms),
+                 "alg_bytes": float(recs[i].alg_bytes)} for i in range(n.value)]

@@ -1,0 +1,90 @@
+"""Block-level orchestration: the mirror of `BlockProcessor::prove` (/root/reference/crates/host/src/lib.rs:123-143).
+
+Upstream proves the segments of one block in a plain loop (`ProverImpl::prove_session`, risc0-zkvm 3.0.3,
+un-vendored: /root/reference/Cargo.lock:5418) and concatenates the `SegmentReceipt`s into a
+`CompositeReceipt`; `receipt.verify(image_id)` then checks every segment
+(/root/reference/crates/host/src/bin/cli.rs:103).  Segments are independent, so with G GPUs (one process per
+GPU, `torch.distributed` ranks) segment i goes to rank i mod G and NO data-path collective is needed; the
+receipts (~0.25 MB each) are gathered on rank 0 over the control plane (gloo / RCCL object gather).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+from .prover import Segment, SegmentReceipt
+
+
+def partition_round_robin(n_segments: int, world_size: int, rank: int) -> List[int]:
+    """Segment indices owned by `rank`: i with i % world_size == rank (BASELINE.json north_star)."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError(f"bad rank {rank} / world_size {world_size}")
+    return list(range(rank, n_segments, world_size))
+
+
+def session_segments(total_cycles: int, segment_po2: int = 20, base_seed: int = 0x5EED0000) -> List[Segment]:
+    """Split a session of `total_cycles` into 2^po2-cycle segments; the tail segment gets the smallest po2 >= 13
+    that holds the remainder (upstream pads the last segment to a power of two, MIN_CYCLES_PO2 = 13)."""
+    if total_cycles <= 0:
+        raise ValueError("total_cycles must be positive")
+    seg_cycles = 1 << segment_po2
+    segs: List[Segment] = []
+    full, rem = divmod(total_cycles, seg_cycles)
+    for i in range(full):
+        segs.append(Segment(index=i, po2=segment_po2, seed=base_seed + i))
+    if rem:
+        po2 = 13
+        while (1 << po2) < rem:
+            po2 += 1
+        segs.append(Segment(index=full, po2=min(po2, segment_po2), seed=base_seed + full))
+    return segs
+
+
+@dataclass
+class CompositeReceipt:
+    """`CompositeReceipt{segments[]}` analogue: ordered by segment index."""
+    segments: List[SegmentReceipt]
+
+    def verify_integrity(self) -> None:
+        idx = [s.index for s in self.segments]
+        if idx != list(range(len(idx))):
+            raise ValueError(f"composite receipt has missing or unordered segments: {idx}")
+
+
+class BlockProcessor:
+    """Proves the segment list of one block on this rank's GPU and (optionally) gathers across ranks."""
+
+    def __init__(self, prove_segment: Callable[[Segment], SegmentReceipt], rank: int = 0, world_size: int = 1,
+                 gather: Optional[Callable[[List[SegmentReceipt]], Optional[List[List[SegmentReceipt]]]]] = None):
+        self.prove_segment = prove_segment
+        self.rank, self.world_size = rank, world_size
+        self.gather = gather
+
+    def prove_local(self, segments: Sequence[Segment]) -> List[SegmentReceipt]:
+        mine = partition_round_robin(len(segments), self.world_size, self.rank)
+        return [self.prove_segment(segments[i]) for i in mine]
+
+    def prove(self, segments: Sequence[Segment]) -> Optional[CompositeReceipt]:
+        local = self.prove_local(segments)
+        if self.world_size == 1 or self.gather is None:
+            rec = CompositeReceipt(sorted(local, key=lambda r: r.index))
+            rec.verify_integrity()
+            return rec
+        parts = self.gather(local)
+        if parts is None:           # non-root rank
+            return None
+        rec = CompositeReceipt(sorted((r for p in parts for r in p), key=lambda r: r.index))
+        rec.verify_integrity()
+        return rec
+
+
+def torch_gather(rank: int, world_size: int):
+    """Control-plane gather of receipts to rank 0 with torch.distributed (gloo on CPU, RCCL on GPU)."""
+    import torch.distributed as dist
+
+    def _g(local: List[SegmentReceipt]):
+        out = [None] * world_size if rank == 0 else None
+        dist.gather_object(local, out, dst=0)
+        return out
+
+    return _g
