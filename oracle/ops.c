@@ -238,3 +238,10 @@ void zko_poly_interpolate(uint32_t* out, const uint32_t* xs, const uint32_t* fx,
     }
     free(ft); free(fr);
 }
+
+#ifdef _OPENMP
+#include <omp.h>
+int zko_num_threads(void) { return omp_get_max_threads(); }
+#else
+int zko_num_threads(void) { return 1; }
+#endif

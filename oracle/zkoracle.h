@@ -118,6 +118,7 @@ uint32_t* zko_prove_segment(const zko_circuit*, unsigned po2, unsigned zk_cycles
 /* restates risc0_zkp::verify::verify. NULL on success, static error string otherwise */
 const char* zko_verify_segment(const zko_circuit*, const uint32_t* seal, size_t seal_words);
 void zko_free(void*);
+int zko_num_threads(void);   /* OpenMP threads the oracle will use */
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,7 @@ def load():
         "zko_prove_segment": (C.POINTER(u32), [vp, C.c_uint, C.c_uint, u64, u64, C.POINTER(sz), C.POINTER(C.c_char_p)]),
         "zko_verify_segment": (C.c_char_p, [vp, u32p, sz]),
         "zko_free": (None, [vp]),
+        "zko_num_threads": (C.c_int, []),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
