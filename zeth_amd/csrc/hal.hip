@@ -136,6 +136,15 @@ extern "C" const char* zkh_ctx_create(int device, const char* suite, zkh_ctx** o
     ZKH_TRY(upload(&c->tab.tw_rev_hi, powers(fp_pow(wr, TW_SIZE), TW_SIZE)));
     ZKH_TRY(upload(&c->tab.tile_fwd, powers(Fp::raw(c->rou_fwd[LDS_TW_LOG]), 1 << (LDS_TW_LOG - 1))));
     ZKH_TRY(upload(&c->tab.tile_rev, powers(Fp::raw(c->rou_rev[LDS_TW_LOG]), 1 << (LDS_TW_LOG - 1))));
+    {
+        std::vector<uint32_t> lf(1 << LDS_TW_LOG, R1), lr(1 << LDS_TW_LOG, R1);
+        for (int j = 1; j <= LDS_TW_LOG; j++) {
+            auto pf = powers(Fp::raw(c->rou_fwd[j]), (size_t)1 << (j - 1)), pr = powers(Fp::raw(c->rou_rev[j]), (size_t)1 << (j - 1));
+            for (size_t e = 0; e < pf.size(); e++) { lf[((size_t)1 << (j - 1)) + e] = pf[e]; lr[((size_t)1 << (j - 1)) + e] = pr[e]; }
+        }
+        ZKH_TRY(upload(&c->tab.layer_fwd, lf));
+        ZKH_TRY(upload(&c->tab.layer_rev, lr));
+    }
     Fp three = fp_encode(3);
     ZKH_TRY(upload(&c->tab.shift_lo, powers(three, TW_SIZE)));
     ZKH_TRY(upload(&c->tab.shift_hi, powers(fp_pow(three, TW_SIZE), TW_SIZE)));
@@ -151,7 +160,7 @@ extern "C" void zkh_ctx_destroy(zkh_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->pool) (void)hipFree(kv.second);
     uint32_t* t[] = {c->tab.rc, c->tab.diag, c->tab.tw_fwd_lo, c->tab.tw_fwd_hi, c->tab.tw_rev_lo, c->tab.tw_rev_hi,
-                     c->tab.tile_fwd, c->tab.tile_rev, c->tab.shift_lo, c->tab.shift_hi};
+                     c->tab.tile_fwd, c->tab.tile_rev, c->tab.shift_lo, c->tab.shift_hi, c->tab.layer_fwd, c->tab.layer_rev};
     for (auto p : t) (void)hipFree(p);
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto ev : c->event_pool) (void)hipEventDestroy(ev);

@@ -32,6 +32,7 @@ struct PassParams {
     uint32_t scale;          // inverse last pass: multiply by n^-1 (Montgomery word) ...
     uint32_t zk_shift;       // ... and by 3^bitrev(i)
     const uint32_t* tile_tw; // w_{2^12}^j
+    const uint32_t* layer_tw; // per-layer tables: [2^(j-1) + e] = w_j^e
     const uint32_t* tw_lo;   // w_{2^24}^lo
     const uint32_t* tw_hi;   // w_{2^24}^(4096 hi)
     const uint32_t* sh_lo;
@@ -175,6 +176,238 @@ __global__ void k_bit_reverse_small(uint32_t* io, uint32_t log_n, size_t count) 
     }
 }
 
+
+// =====================================================================================================
+// Register-radix fast paths (the shapes a po2 >= 16 seal actually uses).  Each lane keeps 16 elements in
+// VGPRs and runs 4 radix-2 layers there; LDS is only the exchange medium between rounds (2 exchanges per
+// 4096-point tile instead of 12 read-modify-write sweeps), twiddles come from per-layer tables so that
+// consecutive lanes read consecutive words.
+// =====================================================================================================
+template <int LOGR, bool INVERSE, bool BASE0, int J_LO>
+__device__ __forceinline__ void radix_layers(uint32_t (&v)[1 << LOGR], const uint32_t* __restrict__ ltab,
+                                             const uint32_t base_low, const int first_b) {
+    constexpr int N = 1 << LOGR;
+    if (INVERSE) {
+#pragma unroll
+        for (int b = LOGR - 1; b >= 0; b--) {
+            const uint32_t* tw = ltab + (1u << (J_LO + b - 1));
+#pragma unroll
+            for (int kk = 0; kk < (1 << b); kk++) {
+                const bool unit = BASE0 && kk == 0;
+                const uint32_t w = unit ? 0u : tw[base_low + ((uint32_t)kk << (J_LO - 1))];
+#pragma unroll
+                for (int hi = 0; hi < (N >> (b + 1)); hi++) {
+                    const int k = (hi << (b + 1)) | kk;
+                    const uint32_t x = v[k], y = v[k + (1 << b)];
+                    v[k] = add_mod(x, y);
+                    const uint32_t d = sub_mod(x, y);
+                    v[k + (1 << b)] = unit ? d : mul_mod(d, w);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < LOGR; b++) {
+            if (b < first_b) continue;
+            const uint32_t* tw = ltab + (1u << (J_LO + b - 1));
+#pragma unroll
+            for (int kk = 0; kk < (1 << b); kk++) {
+                const bool unit = BASE0 && kk == 0;
+                const uint32_t w = unit ? 0u : tw[base_low + ((uint32_t)kk << (J_LO - 1))];
+#pragma unroll
+                for (int hi = 0; hi < (N >> (b + 1)); hi++) {
+                    const int k = (hi << (b + 1)) | kk;
+                    const uint32_t x = v[k], y = unit ? v[k + (1 << b)] : mul_mod(v[k + (1 << b)], w);
+                    v[k] = add_mod(x, y);
+                    v[k + (1 << b)] = sub_mod(x, y);
+                }
+            }
+        }
+    }
+}
+
+// Lowest pass, index bits [0, 12): one workgroup = 4096 contiguous words of one column.
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void k_ntt_low12(PassParams p) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4096];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = xcd_remap(blockIdx.x, p.tiles_per_col);
+    const size_t base = (size_t)tile << 12;
+    const uint32_t* in = p.in + (size_t)blockIdx.y * p.in_col_stride;
+    uint32_t* out = p.out + (size_t)blockIdx.y * p.out_col_stride;
+    const uint32_t* __restrict__ ltab = p.layer_tw;
+    const uint32_t hi = tid >> 4, low = tid & 15;
+    uint32_t v[16];
+    if (INVERSE) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = in[base + k * 256 + tid];
+        radix_layers<4, true, false, 9>(v, ltab, tid, 0);                       // layers 12..9
+#pragma unroll
+        for (int k = 0; k < 16; k++) lds[k * 256 + tid] = v[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = lds[hi * 256 + k * 16 + low];
+        radix_layers<4, true, false, 5>(v, ltab, low, 0);                       // layers 8..5
+#pragma unroll
+        for (int k = 0; k < 16; k++) lds[hi * 256 + k * 16 + low] = v[k];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 w = ((const uint4*)lds)[tid * 4 + q];
+            v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
+        }
+        radix_layers<4, true, true, 1>(v, ltab, 0, 0);                          // layers 4..1
+        const size_t pos0 = base + (size_t)tid * 16;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            uint32_t x = v[k];
+            if (p.scale) x = mul_mod(x, p.scale);
+            if (p.zk_shift) {
+                const uint32_t ex = __brev((uint32_t)(pos0 + k)) >> (32 - p.log_n);
+                x = mul_mod(x, mul_mod(p.sh_lo[ex & (TW_SIZE - 1)], p.sh_hi[ex >> TW_BITS]));
+            }
+            v[k] = x;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) ((uint4*)(out + pos0))[q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    } else {
+        const size_t pos0 = base + (size_t)tid * 16;
+        if (p.expand_bits == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint4 w = ((const uint4*)(in + pos0))[q];
+                v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = in[(pos0 + k) >> p.expand_bits];
+        }
+        radix_layers<4, false, true, 1>(v, ltab, 0, (int)p.expand_bits);        // layers 1..4 (first expand_bits skipped)
+#pragma unroll
+        for (int q = 0; q < 4; q++) ((uint4*)lds)[tid * 4 + q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = lds[hi * 256 + k * 16 + low];
+        radix_layers<4, false, false, 5>(v, ltab, low, 0);                      // layers 5..8
+#pragma unroll
+        for (int k = 0; k < 16; k++) lds[hi * 256 + k * 16 + low] = v[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = lds[k * 256 + tid];
+        radix_layers<4, false, false, 9>(v, ltab, tid, 0);                      // layers 9..12
+#pragma unroll
+        for (int k = 0; k < 16; k++) out[base + k * 256 + tid] = v[k];
+    }
+}
+
+// Strided pass, index bits [L, L+RH) with RH in {8, 10}: tile = 2^RH rows x 16 consecutive words, one lane per
+// (row group, column), 16 rows per lane.  Inverse: first pass (reads the witness, DIF, post-twiddle).  Forward:
+// last pass (pre-twiddle, DIT, in place).
+template <int RH, bool INVERSE>
+__global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];     // [2^RH][16]
+    const uint32_t tid = threadIdx.x, t = tid & 15, g = tid >> 4;
+    const uint32_t tile_id = xcd_remap(blockIdx.x, p.tiles_per_col);
+    const uint32_t lt_bits = p.L - 4;
+    const uint32_t a = tile_id >> lt_bits, lt = tile_id & ((1u << lt_bits) - 1);
+    const size_t base = ((size_t)a << (p.L + RH)) + ((size_t)lt << 4) + t;
+    const uint32_t lcol = (lt << 4) + t;
+    const uint32_t tw_shift = MAX_LOG_N - (p.L + RH);
+    const uint32_t* in = p.in + (size_t)blockIdx.y * p.in_col_stride;
+    uint32_t* out = p.out + (size_t)blockIdx.y * p.out_col_stride;
+    const uint32_t* __restrict__ ltab = p.layer_tw;
+    auto twid = [&](uint32_t m) -> uint32_t {
+        const uint32_t r = __brev(m) >> (32 - RH);
+        const uint32_t ex = (lcol * r) << tw_shift;
+        return mul_mod(p.tw_lo[ex & (TW_SIZE - 1)], p.tw_hi[ex >> TW_BITS]);
+    };
+    uint32_t v[16];
+    if (RH == 10) {
+        const uint32_t hi = g >> 2, low = g & 3;
+        if (INVERSE) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = in[base + ((size_t)(k * 64 + g) << p.L)];
+            radix_layers<4, true, false, 7>(v, ltab, g, 0);                     // sub-layers 10..7
+#pragma unroll
+            for (int k = 0; k < 16; k++) lds[(k * 64 + g) * 16 + t] = v[k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = lds[(hi * 64 + k * 4 + low) * 16 + t];
+            radix_layers<4, true, false, 3>(v, ltab, low, 0);                   // 6..3
+#pragma unroll
+            for (int k = 0; k < 16; k++) lds[(hi * 64 + k * 4 + low) * 16 + t] = v[k];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                uint32_t u[4];
+                const uint32_t m0 = (g * 4 + i) * 4;
+#pragma unroll
+                for (int k = 0; k < 4; k++) u[k] = lds[(m0 + k) * 16 + t];
+                radix_layers<2, true, true, 1>(u, ltab, 0, 0);                  // 2..1
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    uint32_t x = mul_mod(u[k], twid(m0 + k));
+                    if (p.scale) x = mul_mod(x, p.scale);
+                    out[base + ((size_t)(m0 + k) << p.L)] = x;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                uint32_t u[4];
+                const uint32_t m0 = (g * 4 + i) * 4;
+#pragma unroll
+                for (int k = 0; k < 4; k++) u[k] = mul_mod(in[base + ((size_t)(m0 + k) << p.L)], twid(m0 + k));
+                radix_layers<2, false, true, 1>(u, ltab, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 4; k++) lds[(m0 + k) * 16 + t] = u[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = lds[(hi * 64 + k * 4 + low) * 16 + t];
+            radix_layers<4, false, false, 3>(v, ltab, low, 0);
+#pragma unroll
+            for (int k = 0; k < 16; k++) lds[(hi * 64 + k * 4 + low) * 16 + t] = v[k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = lds[(k * 64 + g) * 16 + t];
+            radix_layers<4, false, false, 7>(v, ltab, g, 0);
+#pragma unroll
+            for (int k = 0; k < 16; k++) out[base + ((size_t)(k * 64 + g) << p.L)] = v[k];
+        }
+    } else {   // RH == 8: 256 rows, g < 16
+        if (INVERSE) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = in[base + ((size_t)(k * 16 + g) << p.L)];
+            radix_layers<4, true, false, 5>(v, ltab, g, 0);                     // 8..5
+#pragma unroll
+            for (int k = 0; k < 16; k++) lds[(k * 16 + g) * 16 + t] = v[k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = lds[(g * 16 + k) * 16 + t];
+            radix_layers<4, true, true, 1>(v, ltab, 0, 0);                      // 4..1
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                uint32_t x = mul_mod(v[k], twid(g * 16 + k));
+                if (p.scale) x = mul_mod(x, p.scale);
+                out[base + ((size_t)(g * 16 + k) << p.L)] = x;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = mul_mod(in[base + ((size_t)(g * 16 + k) << p.L)], twid(g * 16 + k));
+            radix_layers<4, false, true, 1>(v, ltab, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 16; k++) lds[(g * 16 + k) * 16 + t] = v[k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = lds[(k * 16 + g) * 16 + t];
+            radix_layers<4, false, false, 5>(v, ltab, g, 0);
+#pragma unroll
+            for (int k = 0; k < 16; k++) out[base + ((size_t)(k * 16 + g) << p.L)] = v[k];
+        }
+    }
+}
+
 struct Pass { uint32_t L, R; };
 // Cut log_n index bits into HBM passes of <= 12 bits.  The lowest pass works on contiguous runs (cheapest), the
 // strided passes above it are kept <= 10 bits so a 2^R x 16-word tile stays <= 64 KiB.
@@ -182,7 +415,8 @@ std::vector<Pass> plan_passes(uint32_t log_n) {
     std::vector<Pass> v;
     if (log_n <= 12) { v.push_back({0, log_n}); return v; }
     if (log_n <= 22) {
-        uint32_t low = (log_n + 1) / 2;
+        // >= 2^18: a full 4096-word contiguous low pass + a 2^6..2^10-row strided pass (register-radix kernels)
+        uint32_t low = log_n >= 18 ? 12 : (log_n + 1) / 2;
         if (log_n - low > 10) low = log_n - 10;
         v.push_back({0, low});
         v.push_back({low, log_n - low});
@@ -221,6 +455,7 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
         p.scale = (inverse && last) ? ninv.v : 0;
         p.zk_shift = (inverse && last && zk) ? 1 : 0;
         p.tile_tw = inverse ? c->tab.tile_rev : c->tab.tile_fwd;
+        p.layer_tw = inverse ? c->tab.layer_rev : c->tab.layer_fwd;
         p.tw_lo = inverse ? c->tab.tw_rev_lo : c->tab.tw_fwd_lo;
         p.tw_hi = inverse ? c->tab.tw_rev_hi : c->tab.tw_fwd_hi;
         p.sh_lo = c->tab.shift_lo; p.sh_hi = c->tab.shift_hi;
@@ -228,7 +463,23 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
         const size_t lds = ((size_t)4 << (p.R + p.log_t));
         dim3 grid(p.tiles_per_col, (unsigned)count);
         ProfScope prof(c, name, 8.0 * n * count);
-        if (inverse) k_ntt_pass<true><<<grid, NTT_THREADS, lds, c->stream>>>(p);
+        const bool scale_here = p.scale != 0;
+        if (ps.L == 0 && ps.R == 12 && p.expand_bits <= 4) {
+            if (inverse) k_ntt_low12<true><<<grid, 256, 0, c->stream>>>(p);
+            else k_ntt_low12<false><<<grid, 256, 0, c->stream>>>(p);
+        } else if (ps.L >= 4 && p.log_t == 4 && ps.R == 10 && !(scale_here && p.zk_shift)) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)k_ntt_high<10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+                (void)hipFuncSetAttribute((const void*)k_ntt_high<10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+                attr_set = true;
+            }
+            if (inverse) k_ntt_high<10, true><<<grid, 1024, lds, c->stream>>>(p);
+            else k_ntt_high<10, false><<<grid, 1024, lds, c->stream>>>(p);
+        } else if (ps.L >= 4 && p.log_t == 4 && ps.R == 8 && !(scale_here && p.zk_shift)) {
+            if (inverse) k_ntt_high<8, true><<<grid, 256, lds, c->stream>>>(p);
+            else k_ntt_high<8, false><<<grid, 256, lds, c->stream>>>(p);
+        } else if (inverse) k_ntt_pass<true><<<grid, NTT_THREADS, lds, c->stream>>>(p);
         else k_ntt_pass<false><<<grid, NTT_THREADS, lds, c->stream>>>(p);
         ZKH_TRY(last_launch_error(name));
     }
