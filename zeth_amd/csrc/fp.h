@@ -30,14 +30,20 @@ struct Fp {
     static ZKH_HD Fp zero() { return Fp(0, 0); }
 };
 
-// a + b mod P without a branch: min(s, s - P) under unsigned wrap.
-ZKH_HD uint32_t add_mod(uint32_t a, uint32_t b) {
-    uint32_t s = a + b, t = s - P;
-    return t < s ? t : s;
+// Conditional corrections are written with the overflow builtins so that hipcc emits v_sub(rev)_co_u32 + v_cndmask_b32.
+// Measured on gfx950 (tools/ubench_valu.hip, profiles/ubench_valu_r01.txt): v_add/v_sub/v_and/v_xor/v_ashrrev issue at
+// ~64 T lane-ops/s, while v_min_u32, v_add3, every 32-bit multiply, v_mad_u64_u32 and all fp64 ops issue at ~37 T/s; a
+// sub_co + cndmask pair costs ~2.1 add-slots against ~2.7 for sub + min.
+ZKH_HD uint32_t reduce_once(uint32_t s) {     // s in [0, 2P) -> [0, P)
+    uint32_t t;
+    const bool borrow = __builtin_usub_overflow(s, P, &t);
+    return borrow ? s : t;
 }
+ZKH_HD uint32_t add_mod(uint32_t a, uint32_t b) { return reduce_once(a + b); }
 ZKH_HD uint32_t sub_mod(uint32_t a, uint32_t b) {
-    uint32_t s = a - b, t = s + P;
-    return t < s ? t : s;
+    uint32_t t;
+    const bool borrow = __builtin_usub_overflow(a, b, &t);
+    return borrow ? t + P : t;
 }
 // Montgomery reduction of a 64-bit product T < P * 2^32:  (T - (T*P^-1 mod 2^32) * P) / 2^32, in [0, P).
 ZKH_HD uint32_t mont_reduce(uint64_t t) {
@@ -47,10 +53,24 @@ ZKH_HD uint32_t mont_reduce(uint64_t t) {
 #else
     uint32_t u = (uint32_t)(((uint64_t)m * P) >> 32);
 #endif
-    uint32_t hi = (uint32_t)(t >> 32);
-    uint32_t r = hi - u, r2 = r + P;
-    return r2 < r ? r2 : r;    // borrow <=> r wrapped <=> r + P wraps back below
+    return sub_mod((uint32_t)(t >> 32), u);
 }
+// Signed Montgomery product (Seiler): for |a|, |b| < P the result is in (-P, P) and congruent to a*b*2^-32 with NO
+// correction step, so chains of products (the x^7 s-box) only canonicalise once at the end.
+ZKH_HD int32_t smont(int32_t a, int32_t b) {
+    const int64_t t = (int64_t)a * b;
+    const int32_t m = (int32_t)((uint32_t)t * PINV);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int32_t u = __mulhi(m, (int32_t)P);
+    uint32_t hi = (uint32_t)((uint64_t)t >> 32);
+    asm("" : "+v"(hi));          // keep hipcc from widening hi - u back into a 64-bit subtract
+#else
+    const int32_t u = (int32_t)(((int64_t)m * (int64_t)P) >> 32);
+    uint32_t hi = (uint32_t)((uint64_t)t >> 32);
+#endif
+    return (int32_t)(hi - (uint32_t)u);
+}
+ZKH_HD uint32_t canon(int32_t x) { return (uint32_t)x + (P & (uint32_t)(x >> 31)); }   // (-P, P) -> [0, P)
 ZKH_HD uint32_t mul_mod(uint32_t a, uint32_t b) { return mont_reduce((uint64_t)a * b); }
 
 ZKH_HD Fp operator+(Fp a, Fp b) { return Fp::raw(add_mod(a.v, b.v)); }
@@ -94,8 +114,7 @@ ZKH_HD bool operator==(Fp4 a, Fp4 b) { return a.c[0] == b.c[0] && a.c[1] == b.c[
 // 19 full Montgomery products).  Up to 4 products fit: 4*P^2 < 2^64 and 4*P^2 < 2*P*2^32, so one conditional
 // subtraction of P from the high word brings the sum under the P*2^32 bound mont_reduce needs.
 ZKH_HD uint32_t mont_reduce_wide(uint64_t t) {   // any t < 2*P*2^32
-    uint32_t hi = (uint32_t)(t >> 32), hi2 = hi - P;
-    hi = hi2 < hi ? hi2 : hi;
+    const uint32_t hi = reduce_once((uint32_t)(t >> 32));
     return mont_reduce(((uint64_t)hi << 32) | (uint32_t)t);
 }
 ZKH_HD Fp4 operator*(Fp4 a, Fp4 b) {

@@ -10,9 +10,11 @@ namespace zkh {
 
 constexpr int CELLS = 24, RATE = 16, OUT = 8, HALF_FULL = 4, PARTIAL = 21;
 
+// x^7 with four signed Montgomery products (no per-product correction) and one canonicalisation.
 ZKH_HD uint32_t sbox7(uint32_t x) {
-    const uint32_t x2 = mul_mod(x, x), x3 = mul_mod(x2, x), x4 = mul_mod(x2, x2);
-    return mul_mod(x3, x4);
+    const int32_t sx = (int32_t)x;
+    const int32_t x2 = smont(sx, sx), x3 = smont(x2, sx), x4 = smont(x2, x2);
+    return canon(smont(x3, x4));
 }
 // 4x4 block [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] with 8 additions (Poseidon2 paper, appendix B)
 ZKH_HD void m4(uint32_t& x0, uint32_t& x1, uint32_t& x2, uint32_t& x3) {
