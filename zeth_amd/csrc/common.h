@@ -101,10 +101,17 @@ void prof_begin(zkh_ctx* c, const char* name, double bytes);
 void prof_end(zkh_ctx* c);
 const char* ensure_pinned(zkh_ctx* c, size_t words);
 
+// The HIP "current device" is per host thread: every entry point binds the calling thread to the context's GPU
+// (several host threads may each drive their own context on the same or on different GPUs).
+inline void bind_thread(const zkh_ctx* c) {
+    static thread_local int bound = -1;
+    if (bound != c->device) { (void)hipSetDevice(c->device); bound = c->device; }
+}
+
 // Launch helper: optional HIP-event bracket on the ctx stream (what bench.py's roofline uses).
 struct ProfScope {
     zkh_ctx* c;
-    ProfScope(zkh_ctx* ctx, const char* name, double bytes) : c(ctx) { if (c->prof) prof_begin(c, name, bytes); }
+    ProfScope(zkh_ctx* ctx, const char* name, double bytes) : c(ctx) { bind_thread(c); if (c->prof) prof_begin(c, name, bytes); }
     ~ProfScope() { if (c->prof) prof_end(c); }
 };
 

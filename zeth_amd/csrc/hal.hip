@@ -43,6 +43,7 @@ void pool_free(zkh_ctx* c, void* p, size_t bytes) {
     c->pool_bytes += bytes;
 }
 const char* new_buf(zkh_ctx* c, size_t n_words, bool zero, zkh_buf** out) {
+    bind_thread(c);
     void* p = nullptr;
     ZKH_TRY(pool_alloc(c, n_words * 4, &p));
     if (zero && n_words) {
@@ -102,7 +103,7 @@ static std::vector<uint32_t> powers(Fp base, size_t n) {
 
 extern "C" const char* zkh_poseidon2_set_constants(zkh_ctx* c, const uint32_t* rc, const uint32_t* diag) {
     std::vector<uint32_t> r(24 * 29), d(24);
-    for (int i = 0; i < 24 * 29; i++) r[i] = fp_encode(rc[i]).v;
+    for (int i = 0; i < 24 * 29; i++) r[i] = fp_encode(rc[i]).v - P;   // stored as rc - P: see poseidon2.h sbox7_rc
     for (int i = 0; i < 24; i++) d[i] = fp_encode(diag[i]).v;
     memcpy(c->h_rc, r.data(), sizeof c->h_rc);
     memcpy(c->h_diag, d.data(), sizeof c->h_diag);
@@ -168,7 +169,7 @@ extern "C" void zkh_ctx_destroy(zkh_ctx* c) {
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
-extern "C" const char* zkh_sync(zkh_ctx* c) { ZKH_HIP(hipStreamSynchronize(c->stream)); return nullptr; }
+extern "C" const char* zkh_sync(zkh_ctx* c) { bind_thread(c); ZKH_HIP(hipStreamSynchronize(c->stream)); return nullptr; }
 extern "C" void* zkh_ctx_stream(zkh_ctx* c) { return (void*)c->stream; }
 
 // ---- buffers ----
@@ -206,12 +207,14 @@ extern "C" void zkh_release(zkh_buf* b) {
 extern "C" size_t zkh_size(const zkh_buf* b) { return b->len; }
 extern "C" void* zkh_device_ptr(const zkh_buf* b) { return (void*)b->ptr(); }
 extern "C" const char* zkh_read(zkh_ctx* c, const zkh_buf* b, uint32_t* host, size_t off, size_t n) {
+    bind_thread(c);
     ZKH_REQUIRE(off + n <= b->len, "read [%zu, %zu) out of range (size %zu)", off, off + n, b->len);
     if (n) ZKH_HIP(hipMemcpyAsync(host, b->ptr() + off, n * 4, hipMemcpyDeviceToHost, c->stream));
     ZKH_HIP(hipStreamSynchronize(c->stream));
     return nullptr;
 }
 extern "C" const char* zkh_write(zkh_ctx* c, zkh_buf* b, const uint32_t* host, size_t off, size_t n) {
+    bind_thread(c);
     ZKH_REQUIRE(off + n <= b->len, "write [%zu, %zu) out of range (size %zu)", off, off + n, b->len);
     if (n) ZKH_HIP(hipMemcpyAsync(b->ptr() + off, host, n * 4, hipMemcpyHostToDevice, c->stream));
     ZKH_HIP(hipStreamSynchronize(c->stream));
