@@ -64,7 +64,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--po2", type=int, default=PO2)
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("ZKH_INFLIGHT", "2")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("ZKH_INFLIGHT", "3")),
                     help="segments sealed concurrently per GPU (one host thread + HIP stream each); 1 = strictly serial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events (no roofline object)")
@@ -81,8 +81,14 @@ def main() -> None:
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # control plane only (barrier + MAX of the elapsed time): RCCL by default, gloo on request (e.g. when several
+        # ranks are made to share one GPU for a dry run)
+        backend = os.environ.get("ZKH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from zeth_amd.circuits import syn_air
     from zeth_amd.circuits.desc import Circuit
@@ -90,6 +96,8 @@ def main() -> None:
     from zeth_amd.host import partition_round_robin
     from zeth_amd.prover import Segment, SegmentProver
 
+    # one GPU per rank; ZKH_SHARE_GPUS=1 lets ranks wrap around the visible devices (dry runs on a 1-GPU box)
+    device = local_rank % torch.cuda.device_count() if os.environ.get("ZKH_SHARE_GPUS") else local_rank
     desc = syn_air.syn_a()
     circ = Circuit.parse(desc)
     wa, wc, wd = circ.group_sizes
@@ -106,7 +114,7 @@ def main() -> None:
 
     class Worker:
         def __init__(self, w):
-            self.hal = HipHal(local_rank)            # raises if the HIP library / GPU is missing: no fallback
+            self.hal = HipHal(device)                # raises if the HIP library / GPU is missing: no fallback
             self.prover = SegmentProver(self.hal, desc)
             self.steps = [i for i in range(args.steps) if i % inflight == w]
             ring = max(1, min(len(self.steps) + args.warmup, 2))
@@ -157,7 +165,7 @@ def main() -> None:
         if wk.err is not None:
             raise wk.err
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{device}" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = []
