@@ -39,6 +39,7 @@ inline const char* make_err(const char* fmt, ...) {
         if (!(cond)) return zkh::make_err(__VA_ARGS__); \
     } while (0)
 
+constexpr int ZKH_P2_PTAB = 74;             // d, d^2, d^3 (24 each), sum d_i (i>=1), 23 — see poseidon2.h
 constexpr int TW_BITS = 12;                 // two-level twiddle tables: w_{2^24}^(hi*4096 + lo)
 constexpr int TW_SIZE = 1 << TW_BITS;
 constexpr int MAX_LOG_N = 2 * TW_BITS;      // largest NTT / coset-shift domain supported (2^24)
@@ -47,7 +48,7 @@ constexpr int LDS_TW_LOG = 12;              // in-tile twiddles: w_{2^12}^j, j <
 struct DeviceTables {
     // Poseidon2 (Montgomery form)
     uint32_t* rc;        // 24*29
-    uint32_t* diag;      // 24
+    uint32_t* diag;      // ZKH_P2_PTAB words: partial-round table
     // twiddles, Montgomery form
     uint32_t* tw_fwd_lo; uint32_t* tw_fwd_hi;   // w^lo, w^(hi*4096), w = ROU_FWD[24]
     uint32_t* tw_rev_lo; uint32_t* tw_rev_hi;   // same for ROU_REV[24]
@@ -81,7 +82,7 @@ struct zkh_ctx {
     hipStream_t stream;
     zkh::DeviceTables tab;
     uint32_t rou_fwd[28], rou_rev[28];          // host copies (Montgomery)
-    uint32_t h_rc[24 * 29], h_diag[24];         // host copies of the Poseidon2 tables (Montgomery)
+    uint32_t h_rc[24 * 29], h_diag[zkh::ZKH_P2_PTAB]; // host copies of the Poseidon2 tables (rc - P; partial-round table)
     std::multimap<size_t, void*> pool;          // stream-ordered free list (single in-order stream)
     size_t pool_bytes = 0, live_bytes = 0, peak_bytes = 0;
     bool prof = false;

@@ -102,9 +102,17 @@ static std::vector<uint32_t> powers(Fp base, size_t n) {
 }  // namespace zkh
 
 extern "C" const char* zkh_poseidon2_set_constants(zkh_ctx* c, const uint32_t* rc, const uint32_t* diag) {
-    std::vector<uint32_t> r(24 * 29), d(24);
+    std::vector<uint32_t> r(24 * 29), d(ZKH_P2_PTAB);
     for (int i = 0; i < 24 * 29; i++) r[i] = fp_encode(rc[i]).v - P;   // stored as rc - P: see poseidon2.h sbox7_rc
-    for (int i = 0; i < 24; i++) d[i] = fp_encode(diag[i]).v;
+    {   // partial-round table: d, d^2, d^3, c1 = sum_{i>=1} d_i, 23  (poseidon2.h)
+        Fp c1 = Fp::zero();
+        for (int i = 0; i < 24; i++) {
+            const Fp di = fp_encode(diag[i]);
+            d[i] = di.v; d[24 + i] = (di * di).v; d[48 + i] = (di * di * di).v;
+            if (i >= 1) c1 = c1 + di;
+        }
+        d[72] = c1.v; d[73] = fp_encode(23).v;
+    }
     memcpy(c->h_rc, r.data(), sizeof c->h_rc);
     memcpy(c->h_diag, d.data(), sizeof c->h_diag);
     ZKH_HIP(hipStreamSynchronize(c->stream));
@@ -150,7 +158,7 @@ extern "C" const char* zkh_ctx_create(int device, const char* suite, zkh_ctx** o
     ZKH_TRY(upload(&c->tab.shift_lo, powers(three, TW_SIZE)));
     ZKH_TRY(upload(&c->tab.shift_hi, powers(fp_pow(three, TW_SIZE), TW_SIZE)));
     ZKH_TRY(upload(&c->tab.rc, std::vector<uint32_t>(24 * 29)));
-    ZKH_TRY(upload(&c->tab.diag, std::vector<uint32_t>(24)));
+    ZKH_TRY(upload(&c->tab.diag, std::vector<uint32_t>(ZKH_P2_PTAB)));
     ZKH_TRY(zkh_poseidon2_set_constants(c, ZKH_P2_ROUND_CONSTANTS, ZKH_P2_M_INT_DIAG));
     *out = c;
     return nullptr;

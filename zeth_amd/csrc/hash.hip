@@ -16,7 +16,7 @@ using namespace zkh;
 namespace {
 
 // Hal::hash_rows — one lane per leaf.
-__global__ __launch_bounds__(256) void k_hash_rows(uint32_t* __restrict__ out, const uint32_t* __restrict__ matrix,
+__global__ __launch_bounds__(256, 5) void k_hash_rows(uint32_t* __restrict__ out, const uint32_t* __restrict__ matrix,
                                                    size_t rows, uint32_t cols, const uint32_t* __restrict__ rc,
                                                    const uint32_t* __restrict__ diag) {
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -26,19 +26,12 @@ __global__ __launch_bounds__(256) void k_hash_rows(uint32_t* __restrict__ out, c
     for (int i = 0; i < CELLS; i++) s[i] = 0;
     const uint32_t* src = matrix + r;
     const uint32_t full = cols / RATE, tail = cols % RATE;
-    uint32_t nxt[RATE];
-    if (full) {
-#pragma unroll
-        for (int i = 0; i < RATE; i++) nxt[i] = src[(size_t)i * rows];
-    }
+    // No register double-buffer for the next 16 columns: the grouped partial rounds need the VGPRs, and with >= 5
+    // waves per SIMD the loads of one wave hide under the permutations of the others.
     for (uint32_t b = 0; b < full; b++) {
+        const uint32_t* bsrc = src + (size_t)b * RATE * rows;
 #pragma unroll
-        for (int i = 0; i < RATE; i++) s[i] = nxt[i];
-        if (b + 1 < full) {
-            const uint32_t* nsrc = src + (size_t)(b + 1) * RATE * rows;
-#pragma unroll
-            for (int i = 0; i < RATE; i++) nxt[i] = nsrc[(size_t)i * rows];
-        }
+        for (int i = 0; i < RATE; i++) s[i] = bsrc[(size_t)i * rows];
         poseidon2_mix(s, rc, diag);
     }
     if (tail || cols == 0) {
@@ -53,7 +46,7 @@ __global__ __launch_bounds__(256) void k_hash_rows(uint32_t* __restrict__ out, c
 }
 
 // Hal::hash_fold — one lane per parent: io[out+i] = H(io[in+2i] || io[in+2i+1])
-__global__ __launch_bounds__(256) void k_hash_fold(uint32_t* __restrict__ io, size_t input_size, size_t output_size,
+__global__ __launch_bounds__(256, 5) void k_hash_fold(uint32_t* __restrict__ io, size_t input_size, size_t output_size,
                                                    const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= output_size) return;

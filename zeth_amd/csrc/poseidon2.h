@@ -47,7 +47,7 @@ ZKH_HD void m_ext(uint32_t (&s)[CELLS]) {
         s[i + 2] = add_mod(s[i + 2], c2); s[i + 3] = add_mod(s[i + 3], c3);
     }
 }
-// rc: round constants stored as rc - P (two's complement words); diag: Montgomery form.
+// rc: round constants stored as rc - P (two's complement words); diag: the 74-word partial-round table (see below).
 ZKH_HD void poseidon2_mix(uint32_t (&s)[CELLS], const uint32_t* __restrict__ rc,
                                               const uint32_t* __restrict__ diag) {
     m_ext(s);
@@ -58,19 +58,52 @@ ZKH_HD void poseidon2_mix(uint32_t (&s)[CELLS], const uint32_t* __restrict__ rc,
         for (int i = 0; i < CELLS; i++) s[i] = sbox7_rc(s[i], rc[round * CELLS + i]);
         m_ext(s);
     }
+    // ---- 21 partial rounds, three at a time ----
+    // Only cell 0 meets the s-box; cells 1..23 evolve linearly (s_i <- S + d_i s_i with S the round's state sum), so
+    // three rounds collapse to  s_i <- S2 + d_i S1 + d_i^2 S0 + d_i^3 s_i  (ONE reduction for three products instead
+    // of three).  The sums the cell-0 chain needs in between come from weighted sums taken once per group:
+    //   A = sum s_i, D1 = sum d_i s_i, D2 = sum d_i^2 s_i  (i >= 1);  A' = 23 S0 + D1;  A'' = 23 S1 + c1 S0 + D2.
+    // Exact field identities: the result equals 21 literal rounds (tests compare against the literal oracle).
+    // pc layout: [0,24) d, [24,48) d^2, [48,72) d^3, [72] c1 = sum_{i>=1} d_i, [73] 23 — all Montgomery form.
+    const uint32_t* __restrict__ pc = diag;
 #pragma unroll 1
-    for (int r = 0; r < PARTIAL; r++, round++) {
-        s[0] = sbox7_rc(s[0], rc[round * CELLS]);
-        // tree-shaped sum keeps the dependency chain short
-        uint32_t p[12];
+    for (int grp = 0; grp < PARTIAL / 3; grp++, round += 3) {
+        uint32_t q[12];
 #pragma unroll
-        for (int i = 0; i < 12; i++) p[i] = add_mod(s[2 * i], s[2 * i + 1]);
+        for (int i = 0; i < 11; i++) q[i] = add_mod(s[2 * i + 1], s[2 * i + 2]);
+        q[11] = s[23];
 #pragma unroll
-        for (int i = 0; i < 6; i++) p[i] = add_mod(p[2 * i], p[2 * i + 1]);
-        const uint32_t sum = add_mod(add_mod(add_mod(p[0], p[1]), add_mod(p[2], p[3])), add_mod(p[4], p[5]));
+        for (int i = 0; i < 6; i++) q[i] = add_mod(q[2 * i], q[2 * i + 1]);
+        const uint32_t A = add_mod(add_mod(add_mod(q[0], q[1]), add_mod(q[2], q[3])), add_mod(q[4], q[5]));
+        uint32_t D1 = 0, D2 = 0;
 #pragma unroll
-        for (int i = 0; i < CELLS; i++)   // sum + diag*s in ONE reduction: (sum * 2^32 + diag*s) * 2^-32
-            s[i] = mont_reduce_wide(((uint64_t)sum << 32) + (uint64_t)diag[i] * s[i]);
+        for (int i0 = 1; i0 < CELLS; i0 += 4) {             // groups of <= 4 products per 64-bit accumulator
+            uint64_t a1 = 0, a2 = 0;
+#pragma unroll
+            for (int i = i0; i < i0 + 4 && i < CELLS; i++) {
+                a1 += (uint64_t)pc[i] * s[i];
+                a2 += (uint64_t)pc[CELLS + i] * s[i];
+            }
+            const uint32_t r1 = mont_reduce_wide(a1), r2 = mont_reduce_wide(a2);
+            D1 = i0 == 1 ? r1 : add_mod(D1, r1);
+            D2 = i0 == 1 ? r2 : add_mod(D2, r2);
+        }
+        const uint32_t d0 = pc[0], c1 = pc[3 * CELLS], m23 = pc[3 * CELLS + 1];
+        const uint32_t z0 = sbox7_rc(s[0], rc[round * CELLS]);
+        const uint32_t S0 = add_mod(z0, A);
+        const uint32_t s0a = mont_reduce_wide(((uint64_t)S0 << 32) + (uint64_t)d0 * z0);
+        const uint32_t z1 = sbox7_rc(s0a, rc[(round + 1) * CELLS]);
+        const uint32_t S1 = add_mod(z1, add_mod(mul_mod(m23, S0), D1));
+        const uint32_t s0b = mont_reduce_wide(((uint64_t)S1 << 32) + (uint64_t)d0 * z1);
+        const uint32_t z2 = sbox7_rc(s0b, rc[(round + 2) * CELLS]);
+        const uint32_t A2 = add_mod(mont_reduce_wide((uint64_t)m23 * S1 + (uint64_t)c1 * S0), D2);
+        const uint32_t S2 = add_mod(z2, A2);
+        s[0] = mont_reduce_wide(((uint64_t)S2 << 32) + (uint64_t)d0 * z2);
+#pragma unroll
+        for (int i = 1; i < CELLS; i++) {
+            const uint32_t t = mont_reduce_wide((uint64_t)pc[i] * S1 + (uint64_t)pc[CELLS + i] * S0 + (uint64_t)pc[2 * CELLS + i] * s[i]);
+            s[i] = add_mod(S2, t);
+        }
     }
 #pragma unroll 1
     for (int r = 0; r < HALF_FULL; r++, round++) {
