@@ -63,38 +63,71 @@ __global__ __launch_bounds__(256, 5) void k_hash_fold(uint32_t* __restrict__ io,
     o[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
-// Top of the tree in ONE launch: a single workgroup folds layers width..1 through LDS (the last ~10 layers are
-// latency-bound: one launch instead of ten).  nodes[width, 2*width) is the input layer.
-constexpr int TOP_LOG = 9, TOP_W = 1 << TOP_LOG;
-__global__ __launch_bounds__(256) void k_fold_top(uint32_t* __restrict__ nodes, uint32_t width, const uint32_t* __restrict__ rc,
-                                                  const uint32_t* __restrict__ diag) {
-    __shared__ uint32_t layer[TOP_W * 8];
-    for (uint32_t w = threadIdx.x; w < width * 8; w += blockDim.x) layer[w] = nodes[(size_t)width * 8 + w];
+// ---------------------------------------------------------------------------------------------------------
+// Wavefront-cooperative permutation for the narrow layers of a tree.  With one lane per permutation a layer
+// cannot finish faster than one serial permutation (~36k VALU cycles, ~20-30 us) however few parents it has, and
+// a 2^22-leaf tree has 16 such layers.  Here EIGHT lanes share one permutation: lane j < 6 owns state cells
+// 4j..4j+3 (one M4 block), the column sums of M_ext and the partial-round state sum are 3-step DPP butterflies
+// (quad_perm xor 1, xor 2, row_half_mirror) that never touch LDS, round constants sit in LDS (one ds_read_b128 per
+// full round).  ~3.5x lower latency per layer; used only where the layer is too narrow to fill the chip.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t dpp_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t dpp_half_mirror(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true); }
+// sum over the 8 lanes of a group (lanes 6, 7 hold zeros), result in every lane
+__device__ __forceinline__ uint32_t group_sum(uint32_t v) {
+    v = add_mod(v, dpp_xor1(v));
+    v = add_mod(v, dpp_xor2(v));
+    return add_mod(v, dpp_half_mirror(v));
+}
+__device__ __forceinline__ void wide_m_ext(uint32_t (&c)[4]) {
+    m4(c[0], c[1], c[2], c[3]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) c[k] = add_mod(c[k], group_sum(c[k]));
+}
+constexpr int WIDE_LOG = 15;      // layers with <= 2^15 parents use the 8-lane kernel
+__global__ __launch_bounds__(256) void k_hash_fold_wide(uint32_t* __restrict__ io, size_t input_size, size_t output_size,
+                                                        const uint32_t* __restrict__ rc, const uint32_t* __restrict__ pc) {
+    __shared__ __attribute__((aligned(16))) uint32_t rcs[ROUNDS_TOTAL * CELLS + 8];
+    for (uint32_t w = threadIdx.x; w < ROUNDS_TOTAL * CELLS; w += blockDim.x) rcs[w] = rc[w];
     __syncthreads();
-    for (uint32_t cur = width >> 1; cur >= 1; cur >>= 1) {
-        uint32_t res[OUT];
-        // cur <= 256 parents: one lane each
-        const bool active = threadIdx.x < cur;
-        if (active) {
-            uint32_t s[CELLS];
-#pragma unroll
-            for (int k = 0; k < RATE; k++) s[k] = layer[threadIdx.x * 16 + k];
-#pragma unroll
-            for (int k = RATE; k < CELLS; k++) s[k] = 0;
-            poseidon2_mix(s, rc, diag);
-#pragma unroll
-            for (int k = 0; k < OUT; k++) res[k] = s[k];
-        }
-        __syncthreads();
-        if (active) {
-#pragma unroll
-            for (int k = 0; k < OUT; k++) {
-                layer[threadIdx.x * 8 + k] = res[k];
-                nodes[((size_t)cur + threadIdx.x) * 8 + k] = res[k];
-            }
-        }
-        __syncthreads();
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, j = gid & 7;
+    const bool owner = j < 6;                                   // lanes 6, 7 carry zeros
+    size_t parent = gid >> 3;
+    const bool live = parent < output_size;
+    if (!live) parent = output_size - 1;                        // keep the whole wave in the butterflies
+    uint32_t c[4] = {0, 0, 0, 0};
+    if (j < 4) {
+        const uint4 v = *(const uint4*)(io + (input_size + 2 * parent) * 8 + 4 * j);
+        c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
     }
+    const uint32_t jj = owner ? j : 5;
+    uint32_t d[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) d[k] = pc[4 * jj + k];
+    auto full_round = [&](int round) {
+        const uint4 r = *(const uint4*)(rcs + round * CELLS + 4 * jj);
+        c[0] = sbox7_rc(c[0], r.x); c[1] = sbox7_rc(c[1], r.y); c[2] = sbox7_rc(c[2], r.z); c[3] = sbox7_rc(c[3], r.w);
+        if (!owner) { c[0] = c[1] = c[2] = c[3] = 0; }
+        wide_m_ext(c);
+        if (!owner) { c[0] = c[1] = c[2] = c[3] = 0; }
+    };
+    wide_m_ext(c);
+    if (!owner) { c[0] = c[1] = c[2] = c[3] = 0; }
+    int round = 0;
+#pragma unroll
+    for (int r = 0; r < HALF_FULL; r++, round++) full_round(round);
+#pragma unroll 3
+    for (int r = 0; r < PARTIAL; r++, round++) {
+        const uint32_t z = sbox7_rc(c[0], rcs[round * CELLS]);
+        c[0] = j == 0 ? z : c[0];
+        const uint32_t sum = group_sum(add_mod(add_mod(c[0], c[1]), add_mod(c[2], c[3])));
+#pragma unroll
+        for (int k = 0; k < 4; k++) c[k] = owner ? mont_reduce_wide(((uint64_t)sum << 32) + (uint64_t)d[k] * c[k]) : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < HALF_FULL; r++, round++) full_round(round);
+    if (live && j < 2) *(uint4*)(io + (output_size + parent) * 8 + 4 * j) = make_uint4(c[0], c[1], c[2], c[3]);
 }
 
 }  // namespace
@@ -120,15 +153,15 @@ extern "C" const char* zkh_hash_fold(zkh_ctx* c, zkh_buf* io, size_t input_size,
 }
 extern "C" const char* zkh_merkle_fold_all(zkh_ctx* c, zkh_buf* nodes, size_t rows) {
     ZKH_REQUIRE(nodes->len == rows * 16 && rows && (rows & (rows - 1)) == 0, "merkle_fold_all: nodes must hold 2*rows digests");
-    size_t layer = rows;                       // current input layer width
-    while (layer > (size_t)TOP_W) {
-        ZKH_TRY(zkh_hash_fold(c, nodes, layer, layer / 2));
-        layer /= 2;
-    }
-    if (layer >= 2) {
-        ProfScope prof(c, "hash_fold_top", 96.0 * layer);
-        k_fold_top<<<1, 256, 0, c->stream>>>(nodes->ptr(), (uint32_t)layer, c->tab.rc, c->tab.diag);
-        ZKH_TRY(last_launch_error("hash_fold_top"));
+    for (size_t layer = rows; layer >= 2; layer /= 2) {       // layer = current input width, layer/2 parents
+        const size_t parents = layer / 2;
+        if (parents > ((size_t)1 << WIDE_LOG)) {
+            ZKH_TRY(zkh_hash_fold(c, nodes, layer, parents));
+        } else {
+            ProfScope prof(c, "hash_fold_wide", 96.0 * parents);
+            k_hash_fold_wide<<<(unsigned)((parents * 8 + 255) / 256), 256, 0, c->stream>>>(nodes->ptr(), layer, parents, c->tab.rc, c->tab.diag);
+            ZKH_TRY(last_launch_error("hash_fold_wide"));
+        }
     }
     return nullptr;
 }

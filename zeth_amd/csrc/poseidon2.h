@@ -8,7 +8,7 @@
 
 namespace zkh {
 
-constexpr int CELLS = 24, RATE = 16, OUT = 8, HALF_FULL = 4, PARTIAL = 21;
+constexpr int CELLS = 24, RATE = 16, OUT = 8, HALF_FULL = 4, PARTIAL = 21, ROUNDS_TOTAL = 2 * HALF_FULL + PARTIAL;
 
 // (x + rc)^7.  The round-constant tables hold rc - P (in [-P, 0)), so x + rcs is already a valid signed operand in
 // [-P, P): one plain add instead of a modular add.  Four signed Montgomery products (no per-product correction) and
