@@ -38,6 +38,7 @@ struct PassParams {
     const uint32_t* sh_lo;
     const uint32_t* sh_hi;
     uint32_t tiles_per_col;
+    uint32_t shift16[16];    // inverse last pass: n^-1 * 3^(bitrev4(k) << (log_n - 4)), k < 16 (Montgomery; 0 = unused)
 };
 
 // global index of tile element (m, t):  a*2^(L+R) + m*2^L + l0 + t
@@ -258,15 +259,16 @@ __global__ __launch_bounds__(256) void k_ntt_low12(PassParams p) {
         }
         radix_layers<4, true, true, 1>(v, ltab, 0, 0);                          // layers 4..1
         const size_t pos0 = base + (size_t)tid * 16;
+        if (p.zk_shift) {
+            // 3^bitrev(pos0 + k) = 3^bitrev(pos0) * 3^(bitrev4(k) << (log_n - 4)): one two-level lookup per lane, the 16
+            // k-dependent factors (already times n^-1) are kernel arguments
+            const uint32_t ex = __brev((uint32_t)pos0) >> (32 - p.log_n);
+            const uint32_t b = mul_mod(p.sh_lo[ex & (TW_SIZE - 1)], p.sh_hi[ex >> TW_BITS]);
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            uint32_t x = v[k];
-            if (p.scale) x = mul_mod(x, p.scale);
-            if (p.zk_shift) {
-                const uint32_t ex = __brev((uint32_t)(pos0 + k)) >> (32 - p.log_n);
-                x = mul_mod(x, mul_mod(p.sh_lo[ex & (TW_SIZE - 1)], p.sh_hi[ex >> TW_BITS]));
-            }
-            v[k] = x;
+            for (int k = 0; k < 16; k++) v[k] = mul_mod(mul_mod(v[k], b), p.shift16[k]);
+        } else if (p.scale) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = mul_mod(v[k], p.scale);
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) ((uint4*)(out + pos0))[q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
@@ -316,11 +318,30 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
     const uint32_t* in = p.in + (size_t)blockIdx.y * p.in_col_stride;
     uint32_t* out = p.out + (size_t)blockIdx.y * p.out_col_stride;
     const uint32_t* __restrict__ ltab = p.layer_tw;
-    auto twid = [&](uint32_t m) -> uint32_t {
-        const uint32_t r = __brev(m) >> (32 - RH);
-        const uint32_t ex = (lcol * r) << tw_shift;
+    auto root = [&](uint32_t e) -> uint32_t {                  // w_{L+RH}^e, e < 2^(L+RH)
+        const uint32_t ex = e << tw_shift;
         return mul_mod(p.tw_lo[ex & (TW_SIZE - 1)], p.tw_hi[ex >> TW_BITS]);
     };
+    // Four-step twiddles w^(lcol * bitrev(m)) of this lane's 16 rows, factored so that only 3 (RH = 10) or 2 (RH = 8)
+    // table gathers are needed instead of 16: bitrev splits over the bit fields of m.
+    uint32_t tw[16];
+    if (RH == 10) {         // m = g*16 + i*4 + k: bitrev10(m) = br2(k)*256 + br2(i)*64 + br6(g);  slot = 4*i + k
+        const uint32_t w0 = root(lcol * (__brev(g) >> 26)), u1 = root(lcol * 64u), v1 = root(lcol * 256u);
+        const uint32_t u2 = mul_mod(u1, u1), u3 = mul_mod(u2, u1), v2 = mul_mod(v1, v1), v3 = mul_mod(v2, v1);
+        const uint32_t wi[4] = {w0, mul_mod(w0, u2), mul_mod(w0, u1), mul_mod(w0, u3)};      // U^br2(i)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            tw[4 * i] = wi[i]; tw[4 * i + 1] = mul_mod(wi[i], v2); tw[4 * i + 2] = mul_mod(wi[i], v1); tw[4 * i + 3] = mul_mod(wi[i], v3);
+        }
+    } else {                // m = g*16 + k: bitrev8(m) = br4(k)*16 + br4(g);  slot = k
+        const uint32_t w0 = root(lcol * (__brev(g) >> 28)), q1 = root(lcol * 16u);
+        uint32_t qp[16];
+        qp[0] = w0;
+#pragma unroll
+        for (int e = 1; e < 16; e++) qp[e] = mul_mod(qp[e - 1], q1);     // w0 * Q^e
+#pragma unroll
+        for (int k = 0; k < 16; k++) tw[k] = qp[__builtin_bitreverse8((unsigned char)k) >> 4];
+    }
     uint32_t v[16];
     if (RH == 10) {
         const uint32_t hi = g >> 2, low = g & 3;
@@ -346,7 +367,7 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
                 radix_layers<2, true, true, 1>(u, ltab, 0, 0);                  // 2..1
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    uint32_t x = mul_mod(u[k], twid(m0 + k));
+                    uint32_t x = mul_mod(u[k], tw[4 * i + k]);
                     if (p.scale) x = mul_mod(x, p.scale);
                     out[base + ((size_t)(m0 + k) << p.L)] = x;
                 }
@@ -357,7 +378,7 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
                 uint32_t u[4];
                 const uint32_t m0 = (g * 4 + i) * 4;
 #pragma unroll
-                for (int k = 0; k < 4; k++) u[k] = mul_mod(in[base + ((size_t)(m0 + k) << p.L)], twid(m0 + k));
+                for (int k = 0; k < 4; k++) u[k] = mul_mod(in[base + ((size_t)(m0 + k) << p.L)], tw[4 * i + k]);
                 radix_layers<2, false, true, 1>(u, ltab, 0, 0);
 #pragma unroll
                 for (int k = 0; k < 4; k++) lds[(m0 + k) * 16 + t] = u[k];
@@ -388,13 +409,13 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
             radix_layers<4, true, true, 1>(v, ltab, 0, 0);                      // 4..1
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                uint32_t x = mul_mod(v[k], twid(g * 16 + k));
+                uint32_t x = mul_mod(v[k], tw[k]);
                 if (p.scale) x = mul_mod(x, p.scale);
                 out[base + ((size_t)(g * 16 + k) << p.L)] = x;
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = mul_mod(in[base + ((size_t)(g * 16 + k) << p.L)], twid(g * 16 + k));
+            for (int k = 0; k < 16; k++) v[k] = mul_mod(in[base + ((size_t)(g * 16 + k) << p.L)], tw[k]);
             radix_layers<4, false, true, 1>(v, ltab, 0, 0);
 #pragma unroll
             for (int k = 0; k < 16; k++) lds[(g * 16 + k) * 16 + t] = v[k];
@@ -459,6 +480,11 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
         p.tw_lo = inverse ? c->tab.tw_rev_lo : c->tab.tw_fwd_lo;
         p.tw_hi = inverse ? c->tab.tw_rev_hi : c->tab.tw_fwd_hi;
         p.sh_lo = c->tab.shift_lo; p.sh_hi = c->tab.shift_hi;
+        if (p.zk_shift && log_n >= 4) {
+            const Fp three = fp_encode(3);
+            for (uint32_t k = 0; k < 16; k++)
+                p.shift16[k] = (ninv * fp_pow(three, (uint64_t)(bitrev32(k) >> 28) << (log_n - 4))).v;
+        }
         p.tiles_per_col = (uint32_t)(n >> (p.R + p.log_t));
         const size_t lds = ((size_t)4 << (p.R + p.log_t));
         dim3 grid(p.tiles_per_col, (unsigned)count);
