@@ -1,0 +1,171 @@
+"""Runtime behaviour of the C-ABI library on the GPU: constant-table swap, several contexts driven from host threads,
+caller-owned device memory (torch), profiling records, size limits, full-size properties."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import zko
+from conftest import P, rand_fp
+from zeth_amd.circuits import syn_air
+from zeth_amd.hal import HalError, HipHal
+from zeth_amd.prover import Segment, SegmentProver
+
+pytestmark = pytest.mark.gpu
+
+
+def test_poseidon2_constants_are_data(oracle):
+    """consts.rs is data: swapping the tables on both sides keeps HIP == oracle (and changes the digests)."""
+    rng = np.random.default_rng(42)
+    rc = rng.integers(0, P, size=24 * 29, dtype=np.uint64).astype(np.uint32)
+    diag = rng.integers(1, P, size=24, dtype=np.uint64).astype(np.uint32)
+    m = rand_fp(rng, 64 * 37)
+    base = np.zeros(64 * 8, np.uint32)
+    oracle.zko_hash_rows(base, 64, m, m.size)
+    hal = HipHal(0)
+    try:
+        hal.poseidon2_set_constants(rc, diag)
+        oracle.zko_poseidon2_set_constants(rc, diag)
+        want = np.zeros(64 * 8, np.uint32)
+        oracle.zko_hash_rows(want, 64, m, m.size)
+        out = hal.alloc_digest("o", 64)
+        hal.hash_rows(out, hal.copy_from("m", m))
+        assert np.array_equal(out.to_vec(), want)
+        assert not np.array_equal(want, base)
+        # 2->1 compression through both fold kernels (one lane per parent, and the 8-lane cooperative one)
+        nodes = np.zeros(128 * 8, np.uint32)
+        nodes[64 * 8:] = want
+        wn = nodes.copy()
+        layer = 64
+        while layer > 1:
+            oracle.zko_hash_fold(wn, layer, layer // 2)
+            layer //= 2
+        nb = hal.copy_from("n", nodes)
+        hal.merkle_fold_all(nb, 64)
+        assert np.array_equal(nb.to_vec()[8:], wn[8:])
+    finally:
+        # restore the shipped tables in the oracle (process-global there)
+        import re
+        txt = open(zko._ORACLE_DIR + "/../include/zkh_poseidon2_consts.h").read()
+        nums = [int(x, 16) for x in re.findall(r"0x([0-9a-f]{8})u", txt)]
+        oracle.zko_poseidon2_set_constants(np.array(nums[24:], np.uint32), np.array(nums[:24], np.uint32))
+        hal.close()
+
+
+def test_two_contexts_from_two_threads_give_identical_seals(oracle):
+    desc = syn_air.syn_small()
+    out = [None, None]
+
+    def work(k):
+        hal = HipHal(0)
+        prover = SegmentProver(hal, desc)
+        out[k] = [prover.prove_segment(Segment(index=i, po2=13, seed=900 + i)).seal for i in range(3)]
+        del prover
+        hal.close()
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    oc = zko.OracleCircuit(oracle, desc)
+    for i in range(3):
+        assert np.array_equal(out[0][i], out[1][i])
+        assert np.array_equal(out[0][i], oc.prove(13, 1994, 900 + i, 0x2E80))
+
+
+def test_wrap_torch_memory_and_stream(hal, oracle):
+    """The boundary takes plain device pointers: a torch tensor's storage can be used in place (no torch types in the ABI)."""
+    import torch
+    rng = np.random.default_rng(4)
+    x = rand_fp(rng, 2 << 12)
+    t32 = torch.from_numpy(x.view(np.int32).copy()).to("cuda:0")
+    torch.cuda.synchronize()
+    buf = hal.wrap(t32.data_ptr(), x.size)
+    assert buf.size() == x.size and buf.device_ptr() == t32.data_ptr()
+    hal.batch_interpolate_ntt(buf, 2)
+    hal.sync()
+    want = x.copy()
+    oracle.zko_batch_interpolate_ntt(want, want.size, 2)
+    assert np.array_equal(t32.cpu().numpy().view(np.uint32), want)
+    del buf            # never frees caller-owned memory
+    assert int(t32[0].item()) == int(want.view(np.int32)[0])
+
+
+def test_profiling_records(hal):
+    hal.prof_reset()
+    hal.prof_enable(True)
+    a = hal.copy_from("a", rand_fp(np.random.default_rng(0), 1 << 16))
+    hal.batch_interpolate_ntt(a, 1)
+    hal.batch_bit_reverse(a, 1)
+    recs = {r["name"]: r for r in hal.prof_get()}
+    hal.prof_enable(False)
+    assert recs["batch_interpolate_ntt"]["calls"] == 2           # two HBM passes for 2^16
+    assert recs["batch_bit_reverse"]["calls"] == 1 and recs["batch_bit_reverse"]["total_ms"] > 0
+    assert recs["batch_interpolate_ntt"]["alg_bytes"] == 2 * 8.0 * (1 << 16)
+
+
+def test_size_limits(hal):
+    with pytest.raises(HalError, match="exceeds"):
+        hal.batch_interpolate_ntt(hal.alloc_elem("big", 1 << 25), 1)
+    a = hal.alloc_elem("z", 0)
+    assert a.size() == 0
+
+
+@pytest.mark.parametrize("log_n", [22, 24])
+def test_ntt_roundtrip_max_sizes(hal, log_n):
+    """interpolate then evaluate (expand 0) is the identity at the largest domains (2^22 = po2-20 domain, 2^24 = limit)."""
+    rng = np.random.default_rng(log_n)
+    x = rand_fp(rng, 1 << log_n)
+    buf = hal.copy_from("io", x)
+    hal.batch_interpolate_ntt(buf, 1)
+    out = hal.alloc_elem("out", 1 << log_n)
+    hal.batch_expand_into_evaluate_ntt(out, buf, 1, 0)
+    assert np.array_equal(out.to_vec(), x)
+    # and the coset shift composes: shift then bit-reverse twice is the shift
+    hal.zk_shift(buf, 1)
+    y = buf.to_vec()
+    hal.batch_bit_reverse(buf, 1)
+    hal.batch_bit_reverse(buf, 1)
+    assert np.array_equal(buf.to_vec(), y)
+
+
+def test_merkle_root_matches_independent_path_check(hal, oracle):
+    """Full-size property: for a 2^22-leaf tree, an opened path recomputed with the oracle's hash_pair reaches the root."""
+    rng = np.random.default_rng(77)
+    rows, cols = 1 << 22, 3
+    mat = hal.copy_from("m", rand_fp(rng, rows * cols))
+    nodes = hal.alloc_digest("n", 2 * rows)
+    hal.hash_rows(nodes.slice(rows * 8, rows * 8), mat)
+    hal.merkle_fold_all(nodes, rows)
+    root = nodes.slice(8, 8).to_vec()
+    top = nodes.slice(32 * 8, 32 * 8).to_vec().reshape(32, 8)
+    idx = np.array([0, 1, rows - 1, 123456, 4000000], np.uint32)
+    wpq = cols + 8 * (22 - 5)
+    out = hal.alloc("o", wpq * idx.size)
+    hal.merkle_open(mat, nodes, rows, cols, idx, out)
+    got = out.to_vec().reshape(idx.size, wpq)
+    for q, i in enumerate(idx):
+        cur = np.zeros(8, np.uint32)
+        oracle.zko_hash_elem_slice(np.ascontiguousarray(got[q, :cols]), cols, 1, cur)
+        j = int(i) + rows
+        for lvl in range(17):
+            sib = np.ascontiguousarray(got[q, cols + 8 * lvl: cols + 8 * lvl + 8])
+            nxt = np.zeros(8, np.uint32)
+            if j & 1:
+                oracle.zko_hash_pair(sib, cur, nxt)
+            else:
+                oracle.zko_hash_pair(cur, sib, nxt)
+            cur, j = nxt, j // 2
+        assert np.array_equal(cur, top[j - 32])
+    # the top layer folds to the root
+    layer = [top[k] for k in range(32)]
+    while len(layer) > 1:
+        nxt = []
+        for k in range(0, len(layer), 2):
+            o = np.zeros(8, np.uint32)
+            oracle.zko_hash_pair(np.ascontiguousarray(layer[k]), np.ascontiguousarray(layer[k + 1]), o)
+            nxt.append(o)
+        layer = nxt
+    assert np.array_equal(layer[0], root)

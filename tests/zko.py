@@ -26,6 +26,7 @@ def load():
         "zko_fp_inv": (u32, [u32]), "zko_rou_fwd": (u32, [C.c_uint]), "zko_rou_rev": (u32, [C.c_uint]),
         "zko_fp4_mul": (None, [u32p, u32p, u32p]), "zko_fp4_inv": (None, [u32p, u32p]),
         "zko_poseidon2_mix": (None, [u32p]),
+        "zko_poseidon2_set_constants": (None, [u32p, u32p]),
         "zko_hash_elem_slice": (None, [u32p, sz, sz, u32p]), "zko_hash_pair": (None, [u32p, u32p, u32p]),
         "zko_batch_interpolate_ntt": (None, [u32p, sz, sz]),
         "zko_batch_expand_into_evaluate_ntt": (None, [u32p, sz, u32p, sz, sz, sz]),
