@@ -202,11 +202,36 @@ def main() -> None:
             per_launch_ms = dom["total_ms"] / dom["calls"]
             per_launch_bytes = dom["alg_bytes"] / dom["calls"]
             ach = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+            # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
+            # FETCH doubled per the gfx950 correction; tools/pmc_summary.py) — bench.py cannot run rocprof on itself
+            traffic = None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+                kname = {"hash_rows": "k_hash_rows", "hash_fold": "k_hash_fold", "eval_check": "k_eval_check_syn_a"}.get(dom["name"])
+                if kname in tj and args.po2 == PO2:
+                    traffic = (tj[kname]["fetch_x2_bytes"] + tj[kname]["write_bytes"]) / tj[kname]["launches"]
+            except Exception:
+                traffic = None
             line["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                "frac": ach / HBM_PEAK_GBPS, "traffic": None, "avg_launch_ms": per_launch_ms,
+                                "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "avg_launch_ms": per_launch_ms,
                                 "alg_bytes_per_launch": per_launch_bytes, "share_of_kernel_time": dom["total_ms"] / tot_ms,
+                                "launches_overlap": inflight > 1,
                                 "note": "dominant kernel is integer-VALU-bound by construction (Poseidon2: ~21 Montgomery "
-                                        "products per absorbed byte); HBM fraction is reported as the contract asks"}
+                                        "products per absorbed byte); HBM fraction is reported as the contract asks; with "
+                                        "inflight_per_gpu > 1 kernels of different seals overlap, so per-launch durations include "
+                                        "time shared with other streams"}
+            if dom["name"] == "hash_rows":
+                # VALU view of the same kernel: permutations per launch x modelled issue cycles per 64-lane permutation
+                # (8 full rounds x 2560 + 7 partial groups x 2030 + 1024 cycles) against 1024 SIMDs at 2.4 GHz
+                perms = sum(-(-w // 16) for w in (wc, wd, wa, 16)) * 4 * n          # leaves of the 3 trace trees + check tree
+                deg = n
+                while deg > 256:                                                   # FRI rounds: 4*deg/16 rows of 64 words
+                    perms += 4 * (4 * deg // 16)
+                    deg //= 16
+                cyc = 8 * 2560 + 7 * 2030 + 1024
+                per_seal_ms = dom["total_ms"] / args.steps
+                line["roofline"]["valu"] = {"permutations_per_seal": perms, "model_cycles_per_wave_permutation": cyc,
+                                            "issue_utilisation_at_2p4GHz": (perms / 64.0) * cyc / (1024 * 2.4e9 * per_seal_ms * 1e-3)}
             line["kernels"] = [{"name": p["name"], "calls_per_seal": p["calls"] / args.steps,
                                 "ms_per_seal": p["total_ms"] / args.steps,
                                 "alg_GBps": (p["alg_bytes"] / (p["total_ms"] * 1e-3) / 1e9) if p["total_ms"] > 0 else 0.0}

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes per kernel (KB units -> bytes), largest launch per kernel.
 
-usage: python tools/pmc_summary.py <fetch_dir> <write_dir>   (each holds *_counter_collection.csv)
+usage: python tools/pmc_summary.py <fetch_dir> <write_dir> [traffic.json]   (each dir holds *_counter_collection.csv)
 FETCH_SIZE on gfx950 reports half of the bytes of a wide (16 B/lane) coalesced stream (MI355X_MICROARCH.md §HBM); both
 the raw number and the x2-corrected one are printed.  WRITE_SIZE is uncalibrated (raw).
 """
@@ -26,6 +26,10 @@ def load(d):
 
 
 fetch, write = load(sys.argv[1]), load(sys.argv[2])
+if len(sys.argv) > 3:      # machine-readable copy for bench.py's roofline.traffic
+    import json
+    json.dump({k: {"launches": len(fetch[k]), "fetch_x2_bytes": 2 * sum(fetch[k]), "write_bytes": sum(write.get(k, [0.0]))}
+               for k in fetch}, open(sys.argv[3], "w"), indent=1)
 print(f"{'kernel':34s} {'launches':>8s} {'max FETCH raw GB':>17s} {'x2 GB':>8s} {'max WRITE GB':>13s} {'sum FETCH x2 GB':>16s} {'sum WRITE GB':>13s}")
 for k in sorted(fetch, key=lambda k: -sum(fetch[k])):
     w = write.get(k, [0.0])

@@ -91,6 +91,7 @@ struct zkh_ctx {
     std::vector<hipEvent_t> event_pool;
     uint32_t* pinned = nullptr;                  // host staging
     size_t pinned_words = 0;
+    size_t stage_next = 0, stage_used = 0;       // pinned staging ring for small uploads (hal.hip h2d)
 };
 
 namespace zkh {

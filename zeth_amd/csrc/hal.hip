@@ -177,19 +177,40 @@ extern "C" void zkh_ctx_destroy(zkh_ctx* c) {
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
-extern "C" const char* zkh_sync(zkh_ctx* c) { bind_thread(c); ZKH_HIP(hipStreamSynchronize(c->stream)); return nullptr; }
+extern "C" const char* zkh_sync(zkh_ctx* c) { bind_thread(c); ZKH_HIP(hipStreamSynchronize(c->stream)); c->stage_used = 0; return nullptr; }
 extern "C" void* zkh_ctx_stream(zkh_ctx* c) { return (void*)c->stream; }
 
 // ---- buffers ----
 extern "C" const char* zkh_alloc(zkh_ctx* c, const char*, size_t n, int zero, zkh_buf** out) {
     return new_buf(c, n, zero != 0, out);
 }
+// Small host->device uploads (indices, challenges, tables: a few KB) go through a ring of pinned staging slots so that
+// the borrowed host pointer is consumed by a memcpy and NO stream synchronisation is needed; a slot is only reused after
+// the stream has been synchronised at least once since it was filled (every zkh_read does that).
+namespace zkh {
+constexpr size_t STAGE_SLOT_WORDS = 16384, STAGE_SLOTS = 64;      // 64 x 64 KiB pinned
+const char* h2d(zkh_ctx* c, uint32_t* dst, const uint32_t* host, size_t n) {
+    if (!n) return nullptr;
+    bind_thread(c);
+    if (n <= STAGE_SLOT_WORDS) {
+        ZKH_TRY(ensure_pinned(c, STAGE_SLOT_WORDS * STAGE_SLOTS));
+        if (c->stage_used == STAGE_SLOTS) { ZKH_HIP(hipStreamSynchronize(c->stream)); c->stage_used = 0; }
+        uint32_t* slot = c->pinned + (size_t)c->stage_next * STAGE_SLOT_WORDS;
+        memcpy(slot, host, n * 4);
+        ZKH_HIP(hipMemcpyAsync(dst, slot, n * 4, hipMemcpyHostToDevice, c->stream));
+        c->stage_next = (c->stage_next + 1) % STAGE_SLOTS;
+        c->stage_used++;
+        return nullptr;
+    }
+    ZKH_HIP(hipMemcpyAsync(dst, host, n * 4, hipMemcpyHostToDevice, c->stream));
+    ZKH_HIP(hipStreamSynchronize(c->stream));      // the host pointer is only borrowed for the call
+    c->stage_used = 0;
+    return nullptr;
+}
+}  // namespace zkh
 extern "C" const char* zkh_copy_from(zkh_ctx* c, const char*, const uint32_t* host, size_t n, zkh_buf** out) {
     ZKH_TRY(new_buf(c, n, false, out));
-    if (n) ZKH_HIP(hipMemcpyAsync((*out)->ptr(), host, n * 4, hipMemcpyHostToDevice, c->stream));
-    // the host pointer is only borrowed for the call: make sure the copy has consumed it
-    ZKH_HIP(hipStreamSynchronize(c->stream));
-    return nullptr;
+    return h2d(c, (*out)->ptr(), host, n);
 }
 extern "C" const char* zkh_wrap(zkh_ctx* c, void* dptr, size_t n, zkh_buf** out) {
     zkh_alloc_t* a = new zkh_alloc_t{dptr, n * 4, 1, false, c};
@@ -219,14 +240,13 @@ extern "C" const char* zkh_read(zkh_ctx* c, const zkh_buf* b, uint32_t* host, si
     ZKH_REQUIRE(off + n <= b->len, "read [%zu, %zu) out of range (size %zu)", off, off + n, b->len);
     if (n) ZKH_HIP(hipMemcpyAsync(host, b->ptr() + off, n * 4, hipMemcpyDeviceToHost, c->stream));
     ZKH_HIP(hipStreamSynchronize(c->stream));
+    c->stage_used = 0;
     return nullptr;
 }
 extern "C" const char* zkh_write(zkh_ctx* c, zkh_buf* b, const uint32_t* host, size_t off, size_t n) {
     bind_thread(c);
     ZKH_REQUIRE(off + n <= b->len, "write [%zu, %zu) out of range (size %zu)", off, off + n, b->len);
-    if (n) ZKH_HIP(hipMemcpyAsync(b->ptr() + off, host, n * 4, hipMemcpyHostToDevice, c->stream));
-    ZKH_HIP(hipStreamSynchronize(c->stream));
-    return nullptr;
+    return h2d(c, b->ptr() + off, host, n);
 }
 
 // ---- profiling ----
