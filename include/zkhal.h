@@ -103,6 +103,12 @@ const char* zkh_merkle_fold_all(zkh_ctx*, zkh_buf* nodes, size_t rows);
 /* Hal::batch_evaluate_any(coeffs, poly_count, which, xs, out): out[k] = sum_j coeffs[which[k]][j] xs[k]^j */
 const char* zkh_batch_evaluate_any(zkh_ctx*, const zkh_buf* coeffs, size_t poly_count, const zkh_buf* which,
                                    const zkh_buf* xs, zkh_buf* out);
+/* Same, for coefficient columns still in the bit-reversed order batch_interpolate_ntt produced (position p holds
+ * coefficient bitrev(p)); column length a power of two >= 2^14.  Lets PolyGroup::new skip its W x n batch_bit_reverse. */
+const char* zkh_batch_evaluate_any_bitrev(zkh_ctx*, const zkh_buf* coeffs, size_t poly_count, const zkh_buf* which,
+                                          const zkh_buf* xs, zkh_buf* out);
+/* batch_bit_reverse for ExtElem (AoS) columns: used on the few combo polynomials instead of on every coefficient column */
+const char* zkh_batch_bit_reverse_extelem(zkh_ctx*, zkh_buf* io_ext, size_t count);
 /* Hal::mix_poly_coeffs(output, mix_start, mix, input, combos, input_size, count) */
 const char* zkh_mix_poly_coeffs(zkh_ctx*, zkh_buf* out, const uint32_t mix_start[4], const uint32_t mix[4],
                                 const zkh_buf* in, const zkh_buf* combos, size_t input_size, size_t count);

@@ -266,3 +266,37 @@ def test_merkle_open(hal, oracle):
             j //= 2
             k += 1
         assert k == 7
+
+
+@pytest.mark.parametrize("log_n,polys,evals", [(14, 3, 4), (16, 2, 5), (20, 2, 3)])
+def test_batch_evaluate_any_bitrev(hal, oracle, log_n, polys, evals):
+    """Coefficients left in the iNTT's bit-reversed order give the same evaluations as natural order + evaluate_any."""
+    rng = np.random.default_rng(log_n)
+    po = 1 << log_n
+    nat = rand_fp(rng, po * polys)
+    br = nat.copy()
+    oracle.zko_batch_bit_reverse(br, br.size, polys)
+    which = rng.integers(0, polys, size=evals).astype(np.uint32)
+    xs = rand_fp(rng, 4 * evals)
+    want = np.zeros(4 * evals, dtype=np.uint32)
+    oracle.zko_batch_evaluate_any(nat, nat.size, polys, which, xs, evals, want)
+    out = hal.alloc_extelem("out", evals)
+    hal.batch_evaluate_any_bitrev(hal.copy_from("c", br), polys, hal.copy_from("w", which), hal.copy_from("x", xs), out)
+    eq(out.to_vec(), want)
+    from zeth_amd.hal import HalError
+    with pytest.raises(HalError, match="2\\^14"):
+        hal.batch_evaluate_any_bitrev(hal.copy_from("c", br[:1 << 10]), 1, hal.copy_from("w", which[:1] * 0), hal.copy_from("x", xs[:4]),
+                                      hal.alloc_extelem("o", 1))
+
+
+@pytest.mark.parametrize("log_n,count", [(1, 2), (8, 3), (15, 2)])
+def test_batch_bit_reverse_extelem(hal, log_n, count):
+    rng = np.random.default_rng(log_n)
+    n = 1 << log_n
+    x = rand_fp(rng, 4 * n * count)
+    buf = hal.copy_from("io", x)
+    hal.batch_bit_reverse_extelem(buf, count)
+    got = buf.to_vec().reshape(count, n, 4)
+    src = x.reshape(count, n, 4)
+    rev = np.array([int(format(i, f"0{log_n}b")[::-1], 2) for i in range(n)])
+    eq(got, src[:, rev, :])

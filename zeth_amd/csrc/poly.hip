@@ -32,31 +32,62 @@ __global__ void k_ext_powers(uint32_t* out, Fp4 start, Fp4 base, uint32_t n) {
 // the lane total is multiplied once by x^t and the block total once by x^(chunk*CH).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int EV_PER = 64, EV_CH = TB * EV_PER;
+// BITREV: the column holds its coefficients in the bit-reversed order batch_interpolate_ntt leaves them in (position p
+// holds coefficient bitrev_k(p)); x^bitrev(p) still factors over the bit fields of p = chunk*CH + i*256 + t, so only the
+// three power tables change and PolyGroup never has to bit-reverse W x n coefficient words.
+template <bool BITREV>
 __global__ __launch_bounds__(TB) void k_eval_partial(uint32_t* __restrict__ partial, const uint32_t* __restrict__ coeffs,
                                                      size_t po, const uint32_t* __restrict__ which,
-                                                     const uint32_t* __restrict__ xs, uint32_t n_chunks) {
-    __shared__ uint4 xt[TB];        // x^t
-    __shared__ uint4 xp[EV_PER];    // X^i
+                                                     const uint32_t* __restrict__ xs, uint32_t n_chunks, uint32_t log_n) {
+    __shared__ uint4 xt[TB];        // x^t            | x^(bitrev8(t) << (k-8))
+    __shared__ uint4 xp[EV_PER];    // X^i, X = x^256 | x^(bitrev6(i) << (k-14))
     __shared__ uint4 red[TB];
+    __shared__ uint4 sq[32];        // BITREV: x^(2^m)
     const uint32_t k = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
     const Fp4 x = ld_ext(xs + 4 * k);
-    // doubling: tab[s + i] = tab[i] * x^s
-    if (t == 0) { st_ext((uint32_t*)&xt[0], Fp4::one()); }
-    __syncthreads();
-    Fp4 xs_pow = x;    // x^s
-    for (uint32_t s = 1; s < TB; s <<= 1) {
-        if (t < s) st_ext((uint32_t*)&xt[s + t], ld_ext((const uint32_t*)&xt[t]) * xs_pow);
-        xs_pow = xs_pow * xs_pow;
+    Fp4 chunk_pow;
+    if (BITREV) {
+        if (t == 0) {
+            Fp4 y = x;
+            for (uint32_t m = 0; m < log_n; m++) { st_ext((uint32_t*)&sq[m], y); y = y * y; }
+            st_ext((uint32_t*)&xt[0], Fp4::one());
+            st_ext((uint32_t*)&xp[0], Fp4::one());
+        }
         __syncthreads();
-    }
-    const Fp4 X = xs_pow;            // x^256
-    if (t == 0) st_ext((uint32_t*)&xp[0], Fp4::one());
-    __syncthreads();
-    Fp4 Xs = X;
-    for (uint32_t s = 1; s < EV_PER; s <<= 1) {
-        if (t < s) st_ext((uint32_t*)&xp[s + t], ld_ext((const uint32_t*)&xp[t]) * Xs);
-        Xs = Xs * Xs;
+        for (uint32_t b = 0; b < 8; b++) {                    // position bit b of t  ->  exponent bit k-1-b
+            const uint32_t s = 1u << b;
+            if (t < s) st_ext((uint32_t*)&xt[s + t], ld_ext((const uint32_t*)&xt[t]) * ld_ext((const uint32_t*)&sq[log_n - 1 - b]));
+            __syncthreads();
+        }
+        for (uint32_t b = 0; b < 6; b++) {                    // position bit 8+b  ->  exponent bit k-9-b
+            const uint32_t s = 1u << b;
+            if (t < s) st_ext((uint32_t*)&xp[s + t], ld_ext((const uint32_t*)&xp[t]) * ld_ext((const uint32_t*)&sq[log_n - 9 - b]));
+            __syncthreads();
+        }
+        chunk_pow = Fp4::one();
+        if (t == 0)
+            for (uint32_t c = 0; c + 14 < log_n; c++)          // position bit 14+c -> exponent bit k-15-c
+                if ((chunk >> c) & 1) chunk_pow = chunk_pow * ld_ext((const uint32_t*)&sq[log_n - 15 - c]);
+    } else {
+        // doubling: tab[s + i] = tab[i] * x^s
+        if (t == 0) { st_ext((uint32_t*)&xt[0], Fp4::one()); }
         __syncthreads();
+        Fp4 xs_pow = x;    // x^s
+        for (uint32_t s = 1; s < TB; s <<= 1) {
+            if (t < s) st_ext((uint32_t*)&xt[s + t], ld_ext((const uint32_t*)&xt[t]) * xs_pow);
+            xs_pow = xs_pow * xs_pow;
+            __syncthreads();
+        }
+        const Fp4 X = xs_pow;            // x^256
+        if (t == 0) st_ext((uint32_t*)&xp[0], Fp4::one());
+        __syncthreads();
+        Fp4 Xs = X;
+        for (uint32_t s = 1; s < EV_PER; s <<= 1) {
+            if (t < s) st_ext((uint32_t*)&xp[s + t], ld_ext((const uint32_t*)&xp[t]) * Xs);
+            Xs = Xs * Xs;
+            __syncthreads();
+        }
+        chunk_pow = t == 0 ? fp4_pow(Xs, chunk) : Fp4::one();   // x^(chunk*CH) = (X^EV_PER)^chunk
     }
     const uint32_t* c = coeffs + (size_t)which[k] * po;
     const size_t j0 = (size_t)chunk * EV_CH + t;
@@ -73,10 +104,19 @@ __global__ __launch_bounds__(TB) void k_eval_partial(uint32_t* __restrict__ part
         if (t < s) st_ext((uint32_t*)&red[t], ld_ext((const uint32_t*)&red[t]) + ld_ext((const uint32_t*)&red[t + s]));
         __syncthreads();
     }
-    if (t == 0) {
-        // x^(chunk*CH) = (X^EV_PER)^chunk
-        const Fp4 base = fp4_pow(Xs, chunk);   // Xs == X^EV_PER after the loop
-        st_ext(partial + 4 * ((size_t)k * n_chunks + chunk), ld_ext((const uint32_t*)&red[0]) * base);
+    if (t == 0) st_ext(partial + 4 * ((size_t)k * n_chunks + chunk), ld_ext((const uint32_t*)&red[0]) * chunk_pow);
+}
+// in-place bit reversal of `count` polynomials of n ExtElems (AoS)
+__global__ void k_bit_reverse_ext(uint4* io, uint32_t log_n, size_t total) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const size_t n = (size_t)1 << log_n;
+    const uint32_t i = (uint32_t)(g & (n - 1));
+    const uint32_t r = log_n ? __brev(i) >> (32 - log_n) : 0;
+    if (i < r) {
+        uint4* col = io + (g - i);
+        const uint4 a = col[i], b = col[r];
+        col[i] = b; col[r] = a;
     }
 }
 __global__ void k_eval_final(uint32_t* out, const uint32_t* partial, uint32_t n_chunks, uint32_t n_eval) {
@@ -194,27 +234,50 @@ const char* launch_ext_powers(zkh_ctx* c, uint32_t* out, const uint32_t start[4]
 }
 }  // namespace zkh
 
-extern "C" const char* zkh_batch_evaluate_any(zkh_ctx* c, const zkh_buf* coeffs, size_t poly_count, const zkh_buf* which,
-                                              const zkh_buf* xs, zkh_buf* out) {
+static const char* evaluate_any_impl(zkh_ctx* c, const zkh_buf* coeffs, size_t poly_count, const zkh_buf* which,
+                                     const zkh_buf* xs, zkh_buf* out, bool bitrev) {
     ZKH_REQUIRE(poly_count && coeffs->len % poly_count == 0, "batch_evaluate_any: coeffs size not a multiple of poly_count");
     const size_t n_eval = which->len;
     ZKH_REQUIRE(xs->len == 4 * n_eval && out->len == 4 * n_eval, "batch_evaluate_any: which/xs/out size mismatch");
     if (!n_eval) return nullptr;
     ZKH_REQUIRE(n_eval <= 65535, "batch_evaluate_any: too many evaluation points");
     const size_t po = coeffs->len / poly_count;
+    const uint32_t log_n = log2_ceil(po);
+    if (bitrev) ZKH_REQUIRE(((size_t)1 << log_n) == po && log_n >= 14 && log_n <= 31,
+                            "batch_evaluate_any_bitrev: column length must be a power of two >= 2^14");
     const uint32_t n_chunks = (uint32_t)ceil_div(po, EV_CH);
     zkh_buf* partial = nullptr;
     ZKH_TRY(new_buf(c, 4 * n_eval * n_chunks, false, &partial));
     {
         ProfScope prof(c, "batch_evaluate_any", 4.0 * po * n_eval);
-        k_eval_partial<<<dim3(n_chunks, (unsigned)n_eval), TB, 0, c->stream>>>(partial->ptr(), coeffs->ptr(), po, which->ptr(),
-                                                                              xs->ptr(), n_chunks);
+        if (bitrev)
+            k_eval_partial<true><<<dim3(n_chunks, (unsigned)n_eval), TB, 0, c->stream>>>(partial->ptr(), coeffs->ptr(), po, which->ptr(),
+                                                                                      xs->ptr(), n_chunks, log_n);
+        else
+            k_eval_partial<false><<<dim3(n_chunks, (unsigned)n_eval), TB, 0, c->stream>>>(partial->ptr(), coeffs->ptr(), po, which->ptr(),
+                                                                                       xs->ptr(), n_chunks, log_n);
         k_eval_final<<<(unsigned)ceil_div(n_eval, TB), TB, 0, c->stream>>>(out->ptr(), partial->ptr(), n_chunks, (uint32_t)n_eval);
     }
     zkh_release(partial);
     return last_launch_error("batch_evaluate_any");
 }
-
+extern "C" const char* zkh_batch_evaluate_any(zkh_ctx* c, const zkh_buf* coeffs, size_t poly_count, const zkh_buf* which,
+                                              const zkh_buf* xs, zkh_buf* out) {
+    return evaluate_any_impl(c, coeffs, poly_count, which, xs, out, false);
+}
+extern "C" const char* zkh_batch_evaluate_any_bitrev(zkh_ctx* c, const zkh_buf* coeffs, size_t poly_count, const zkh_buf* which,
+                                                     const zkh_buf* xs, zkh_buf* out) {
+    return evaluate_any_impl(c, coeffs, poly_count, which, xs, out, true);
+}
+extern "C" const char* zkh_batch_bit_reverse_extelem(zkh_ctx* c, zkh_buf* io, size_t count) {
+    ZKH_REQUIRE(count && io->len % (4 * count) == 0, "batch_bit_reverse_extelem: size not a multiple of count ExtElem columns");
+    const size_t n = io->len / 4 / count;
+    const uint32_t log_n = log2_ceil(n);
+    ZKH_REQUIRE(((size_t)1 << log_n) == n, "batch_bit_reverse_extelem: column length %zu is not a power of two", n);
+    ProfScope prof(c, "batch_bit_reverse_extelem", 8.0 * io->len);
+    k_bit_reverse_ext<<<(unsigned)ceil_div(n * count, TB), TB, 0, c->stream>>>((uint4*)io->ptr(), log_n, n * count);
+    return last_launch_error("batch_bit_reverse_extelem");
+}
 extern "C" const char* zkh_mix_poly_coeffs(zkh_ctx* c, zkh_buf* out, const uint32_t mix_start[4], const uint32_t mix[4],
                                            const zkh_buf* in, const zkh_buf* combos, size_t input_size, size_t count) {
     ZKH_REQUIRE(in->len == input_size * count && combos->len >= input_size, "mix_poly_coeffs: input shape mismatch");

@@ -125,6 +125,7 @@ struct Merkle {
 struct PolyGroup {
     Buf coeffs, evaluated;
     size_t count = 0, n = 0;
+    bool bitrev = false;         // coeffs left in the iNTT's bit-reversed order (n >= 2^14): consumers index accordingly
     Merkle merkle;
     // takes ownership of bit-reversed coefficient columns
     const char* build(zkh_ctx* c, Buf&& co, size_t count_, size_t n_) {
@@ -132,7 +133,11 @@ struct PolyGroup {
         const size_t dom = n * ZKH_INV_RATE;
         ZKH_TRY(zkh_alloc(c, "evaluated", count * dom, 0, evaluated.out()));
         ZKH_TRY(zkh_batch_expand_into_evaluate_ntt(c, evaluated, coeffs, count, 2));
-        ZKH_TRY(zkh_batch_bit_reverse(c, coeffs, count));
+        // upstream bit-reverses the coefficients here for batch_evaluate_any / mix_poly_coeffs; both are order-agnostic
+        // once they know the layout, so for n >= 2^14 the W x n words stay put and only the few combo polynomials are
+        // bit-reversed later (zkh_batch_bit_reverse_extelem)
+        bitrev = n >= ((size_t)1 << 14);
+        if (!bitrev) ZKH_TRY(zkh_batch_bit_reverse(c, coeffs, count));
         return merkle.build(c, evaluated, dom, count);
     }
 };
@@ -267,7 +272,8 @@ extern "C" const char* zkh_prove_segment(zkh_prover* pr, size_t po2, size_t zk_c
             ZKH_TRY(zkh_copy_from(c, "which", which.data(), which.size(), dw.out()));
             ZKH_TRY(zkh_copy_from(c, "xs", (const uint32_t*)&all_xs[pos], 4 * which.size(), dx.out()));
             ZKH_TRY(zkh_alloc(c, "out", 4 * which.size(), 0, dout.out()));
-            ZKH_TRY(zkh_batch_evaluate_any(c, groups[g].coeffs, groups[g].count, dw, dx, dout));
+            if (groups[g].bitrev) ZKH_TRY(zkh_batch_evaluate_any_bitrev(c, groups[g].coeffs, groups[g].count, dw, dx, dout));
+            else ZKH_TRY(zkh_batch_evaluate_any(c, groups[g].coeffs, groups[g].count, dw, dx, dout));
             ZKH_TRY(zkh_read(c, dout, (uint32_t*)&eval_u[pos], 0, 4 * which.size()));
             pos += which.size();
         }
@@ -288,7 +294,8 @@ extern "C" const char* zkh_prove_segment(zkh_prover* pr, size_t po2, size_t zk_c
         ZKH_TRY(zkh_copy_from(c, "which", which, ZKH_CHECK_SIZE, dw.out()));
         ZKH_TRY(zkh_copy_from(c, "xs", (const uint32_t*)xs, 4 * ZKH_CHECK_SIZE, dx.out()));
         ZKH_TRY(zkh_alloc(c, "out", 4 * ZKH_CHECK_SIZE, 0, dout.out()));
-        ZKH_TRY(zkh_batch_evaluate_any(c, check_group.coeffs, ZKH_CHECK_SIZE, dw, dx, dout));
+        if (check_group.bitrev) ZKH_TRY(zkh_batch_evaluate_any_bitrev(c, check_group.coeffs, ZKH_CHECK_SIZE, dw, dx, dout));
+        else ZKH_TRY(zkh_batch_evaluate_any(c, check_group.coeffs, ZKH_CHECK_SIZE, dw, dx, dout));
         ZKH_TRY(zkh_read(c, dout, (uint32_t*)&coeff_u[pos], 0, 4 * ZKH_CHECK_SIZE));
     }
     iop.write((const uint32_t*)coeff_u.data(), 4 * n_u);
@@ -319,6 +326,7 @@ extern "C" const char* zkh_prove_segment(zkh_prover* pr, size_t po2, size_t zk_c
         ZKH_TRY(zkh_mix_poly_coeffs(c, combos, (const uint32_t*)&cur_mix, (const uint32_t*)&mix, check_group.coeffs, dw,
                                     ZKH_CHECK_SIZE, n));
     }
+    if (check_group.bitrev) ZKH_TRY(zkh_batch_bit_reverse_extelem(c, combos, combo_count + 1));   // combos -> natural order
     // combos_prepare: subtract the interpolated U polynomials (aggregated per position on the host)
     {
         std::map<uint32_t, Fp4> sub;

@@ -56,6 +56,8 @@ ABI = {
     "zkh_hash_fold": (_err, [_vp, _vp, _sz, _sz]),
     "zkh_merkle_fold_all": (_err, [_vp, _vp, _sz]),
     "zkh_batch_evaluate_any": (_err, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "zkh_batch_evaluate_any_bitrev": (_err, [_vp, _vp, _sz, _vp, _vp, _vp]),
+    "zkh_batch_bit_reverse_extelem": (_err, [_vp, _vp, _sz]),
     "zkh_mix_poly_coeffs": (_err, [_vp, _vp, _u32p, _u32p, _vp, _vp, _sz, _sz]),
     "zkh_combos_prepare": (_err, [_vp, _vp, _u32p, _u32p, _sz]),
     "zkh_combos_divide": (_err, [_vp, _vp, _sz, _sz, _u32p, _sz, _vp]),
@@ -264,6 +266,12 @@ class HipHal:
 
     def batch_evaluate_any(self, coeffs: Buffer, poly_count: int, which: Buffer, xs: Buffer, out: Buffer) -> None:
         _check(_lib.zkh_batch_evaluate_any(self.ctx, coeffs.h, poly_count, which.h, xs.h, out.h))
+
+    def batch_evaluate_any_bitrev(self, coeffs: Buffer, poly_count: int, which: Buffer, xs: Buffer, out: Buffer) -> None:
+        _check(_lib.zkh_batch_evaluate_any_bitrev(self.ctx, coeffs.h, poly_count, which.h, xs.h, out.h))
+
+    def batch_bit_reverse_extelem(self, io: Buffer, count: int) -> None:
+        _check(_lib.zkh_batch_bit_reverse_extelem(self.ctx, io.h, count))
 
     def mix_poly_coeffs(self, output: Buffer, mix_start, mix, inp: Buffer, combos: Buffer, input_size: int, count: int) -> None:
         ms, m = _u32(mix_start), _u32(mix)
