@@ -16,7 +16,7 @@ using namespace zkh;
 namespace {
 
 // Hal::hash_rows — one lane per leaf.
-__global__ __launch_bounds__(256, 5) void k_hash_rows(uint32_t* __restrict__ out, const uint32_t* __restrict__ matrix,
+__global__ __launch_bounds__(256, 4) void k_hash_rows(uint32_t* __restrict__ out, const uint32_t* __restrict__ matrix,
                                                    size_t rows, uint32_t cols, const uint32_t* __restrict__ rc,
                                                    const uint32_t* __restrict__ diag) {
     const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256, 5) void k_hash_rows(uint32_t* __restrict__ out
 }
 
 // Hal::hash_fold — one lane per parent: io[out+i] = H(io[in+2i] || io[in+2i+1])
-__global__ __launch_bounds__(256, 5) void k_hash_fold(uint32_t* __restrict__ io, size_t input_size, size_t output_size,
+__global__ __launch_bounds__(256) void k_hash_fold(uint32_t* __restrict__ io, size_t input_size, size_t output_size,
                                                    const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= output_size) return;
