@@ -96,6 +96,35 @@ def emit_kernel(name: str, desc: np.ndarray) -> Tuple[str, int, int]:
     w("    const uint32_t mask = a.dom - 1;")
     w("    const size_t dom = a.dom;")
     w("    const uint4* __restrict__ pw = (const uint4*)a.mix_pows;")
+    # how often each live mix var is consumed (a var consumed once by an AndEqz can stay a lazy 64-bit sum)
+    m_uses: Dict[int, int] = {}
+    for i, (op, x, y, z, d) in enumerate(c.steps):
+        k, vid = kinds[i]
+        if k == "m" and used_m[vid]:
+            if op == OP_AND_EQZ:
+                m_uses[x] = m_uses.get(x, 0) + 1
+            elif op == OP_AND_COND:
+                m_uses[x] = m_uses.get(x, 0) + 1
+                m_uses[z] = m_uses.get(z, 0) + 1
+    m_uses[c.ret] = m_uses.get(c.ret, 0) + 1
+    lazy: Dict[int, Tuple] = {}          # vid -> (base vid or None, [(step index of the power load, fp var)])
+    materialised = set()
+    zero_vars = set()
+
+    def materialise(vid: int) -> None:
+        if vid in materialised:
+            return
+        base, pend = lazy.pop(vid)
+        materialised.add(vid)
+        for kk, comp in enumerate("xyzw"):
+            prods = " + ".join(f"(uint64_t)p{si}.{comp} * f{fv}" for si, fv in pend)
+            if base is not None and len(pend) <= 2:
+                w(f"    const uint32_t m{vid}_{kk} = mont_reduce_wide(((uint64_t)m{base}_{kk} << 32) + {prods});")
+            elif base is not None:
+                w(f"    const uint32_t m{vid}_{kk} = add_mod(m{base}_{kk}, mont_reduce_wide({prods}));")
+            else:
+                w(f"    const uint32_t m{vid}_{kk} = mont_reduce_wide({prods});")
+
     for i, (op, x, y, z, d) in enumerate(c.steps):
         k, vid = kinds[i]
         if k == "f":
@@ -123,19 +152,34 @@ def emit_kernel(name: str, desc: np.ndarray) -> Tuple[str, int, int]:
                 continue
             m = f"m{vid}"
             if op == OP_TRUE:
+                zero_vars.add(vid)
+                materialised.add(vid)
                 w(f"    const uint32_t {m}_0 = 0, {m}_1 = 0, {m}_2 = 0, {m}_3 = 0;")
             elif op == OP_AND_EQZ:
+                # tot = x.tot + mix^e(x) * v.  Products are accumulated as 64-bit sums (v_mad_u64_u32 chains) and
+                # reduced once per <= 4 terms (4 P^2 < 2 P 2^32, the bound of mont_reduce_wide) instead of once each.
                 e = mix_exp[x]
                 w(f"    const uint4 p{i} = pw[{e}];")
-                for kk, comp in enumerate("xyzw"):
-                    w(f"    const uint32_t {m}_{kk} = add_mod(m{x}_{kk}, mul_mod(p{i}.{comp}, f{y}));")
+                if x in lazy and m_uses[x] == 1:
+                    base, pend = lazy.pop(x)
+                else:
+                    materialise(x)
+                    base, pend = (None if x in zero_vars else x), []
+                pend = pend + [(i, y)]
+                lazy[vid] = (base, pend)
+                if len(pend) == 4 or m_uses[vid] != 1 or vid == c.ret:
+                    materialise(vid)
             elif op == OP_AND_COND:
                 e = mix_exp[x]
+                materialise(x)
+                materialise(z)
+                materialised.add(vid)
                 w(f"    const uint4 p{i} = pw[{e}];")
                 w(f"    const Fp4 t{i} = (Fp4(Fp::raw(m{z}_0), Fp::raw(m{z}_1), Fp::raw(m{z}_2), Fp::raw(m{z}_3)) * Fp::raw(f{y})) *"
                   f" Fp4(Fp::raw(p{i}.x), Fp::raw(p{i}.y), Fp::raw(p{i}.z), Fp::raw(p{i}.w));")
                 for kk in range(4):
                     w(f"    const uint32_t {m}_{kk} = add_mod(m{x}_{kk}, t{i}.c[{kk}].v);")
+    materialise(c.ret)
     r = f"m{c.ret}"
     w("    const uint32_t zi = a.zinv[idx & 3];")
     for kk in range(4):
