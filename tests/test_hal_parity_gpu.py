@@ -18,7 +18,7 @@ def eq(a, b):
         raise AssertionError(f"{bad.size} mismatches, first at {bad[:5]}: {a.reshape(-1)[bad[:5]]} vs {b.reshape(-1)[bad[:5]]}")
 
 
-@pytest.mark.parametrize("log_n,count", [(3, 1), (8, 3), (12, 2), (13, 5), (16, 2), (20, 1), (21, 1)])
+@pytest.mark.parametrize("log_n,count", [(3, 1), (8, 3), (12, 2), (13, 5), (16, 2), (17, 3), (18, 2), (19, 1), (20, 1), (21, 1), (22, 1), (23, 1)])
 def test_batch_interpolate_ntt(hal, oracle, log_n, count):
     rng = np.random.default_rng(log_n * 100 + count)
     n = 1 << log_n
@@ -42,7 +42,7 @@ def test_batch_interpolate_ntt(hal, oracle, log_n, count):
     eq(buf.to_vec(), want)
 
 
-@pytest.mark.parametrize("log_n,count,bits", [(4, 2, 2), (10, 3, 2), (14, 4, 2), (15, 2, 0), (18, 3, 2), (22, 1, 2), (12, 2, 1)])
+@pytest.mark.parametrize("log_n,count,bits", [(4, 2, 2), (10, 3, 2), (14, 4, 2), (15, 2, 0), (18, 3, 2), (20, 2, 2), (22, 1, 2), (12, 2, 1), (24, 1, 2), (13, 1, 3)])
 def test_batch_expand_into_evaluate_ntt(hal, oracle, log_n, count, bits):
     rng = np.random.default_rng(log_n * 7 + count)
     n_out = 1 << log_n
