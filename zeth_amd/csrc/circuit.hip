@@ -124,7 +124,25 @@ __global__ void k_syn_data(uint32_t* data, uint32_t wd, uint32_t n, uint32_t A, 
     const uint32_t inc = r == 0 ? d0 : add_mod(d0, mul_mod(mul_mod(R2, r), d1));
     data[(size_t)(wd - 1) * n + r] = inc;
 }
-// inclusive prefix sum (mod P) of the first A words of a column; single workgroup, chunked (witgen, untimed)
+// inclusive prefix sum (mod P) of the first A words of a column, three-level: per-1024-chunk scans + chunk totals,
+// scan of the totals (one workgroup), carry add.  (witgen, reported separately from the seal)
+__global__ __launch_bounds__(1024) void k_prefix_sum_chunks(uint32_t* col, uint32_t A, uint32_t* totals) {
+    __shared__ uint32_t buf[2][1024];
+    const uint32_t t = threadIdx.x, i = blockIdx.x * 1024 + t;
+    buf[0][t] = i < A ? col[i] : 0;
+    __syncthreads();
+    int cur = 0;
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t v = buf[cur][t];
+        if (t >= d) v = add_mod(v, buf[cur][t - d]);
+        buf[cur ^ 1][t] = v;
+        cur ^= 1;
+        __syncthreads();
+    }
+    if (i < A) col[i] = buf[cur][t];
+    if (t == 1023 && totals) totals[blockIdx.x] = buf[cur][t];
+}
+// single workgroup over the (<= 2^14) chunk totals; also emits the grand total = s[A-1]
 __global__ __launch_bounds__(1024) void k_prefix_sum_fp(uint32_t* col, uint32_t A, uint32_t* last_out) {
     __shared__ uint32_t buf[2][1024];
     __shared__ uint32_t carry_s;
@@ -149,7 +167,12 @@ __global__ __launch_bounds__(1024) void k_prefix_sum_fp(uint32_t* col, uint32_t 
         if (t == 1023) carry_s = v;
         __syncthreads();
     }
-    if (t == 0 && last_out) *last_out = carry_s;   // prefix through the last chunk = s[A-1]
+    if (t == 0 && last_out) *last_out = carry_s;   // prefix through the last chunk
+}
+__global__ __launch_bounds__(1024) void k_prefix_sum_carry(uint32_t* col, uint32_t A, const uint32_t* totals_scan) {
+    const uint32_t i = blockIdx.x * 1024 + threadIdx.x;
+    if (blockIdx.x == 0 || i >= A) return;
+    col[i] = add_mod(col[i], totals_scan[blockIdx.x - 1]);
 }
 // accum: terms[e][r] = mix_e + d_{e mod wd}[r] (active rows) or 1 (noise rows), AoS ExtElems
 __global__ void k_syn_accum_terms(uint32_t* terms, const uint32_t* data, const uint32_t* mix, uint32_t wd, uint32_t n, uint32_t A) {
@@ -375,7 +398,16 @@ extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t
     const unsigned bx = (unsigned)((n + 255) / 256);
     k_syn_code<<<dim3(bx, wc), 256, 0, ctx->stream>>>(code->ptr(), wc, (uint32_t)n, A, seed);
     k_syn_data<<<bx, 256, 0, ctx->stream>>>(data->ptr(), wd, (uint32_t)n, A, seed, noise_seed);
-    k_prefix_sum_fp<<<1, 1024, 0, ctx->stream>>>(data->ptr() + (size_t)(wd - 1) * n, A, last->ptr());
+    {
+        const unsigned chunks = (A + 1023) / 1024;
+        zkh_buf* totals = nullptr;
+        ZKH_TRY(new_buf(ctx, chunks, false, &totals));
+        uint32_t* scol = data->ptr() + (size_t)(wd - 1) * n;
+        k_prefix_sum_chunks<<<chunks, 1024, 0, ctx->stream>>>(scol, A, totals->ptr());
+        k_prefix_sum_fp<<<1, 1024, 0, ctx->stream>>>(totals->ptr(), chunks, last->ptr());
+        k_prefix_sum_carry<<<chunks, 1024, 0, ctx->stream>>>(scol, A, totals->ptr());
+        zkh_release(totals);
+    }
     ZKH_TRY(last_launch_error("syn_witgen"));
     out_global[1] = out_global[2] = out_global[3] = 0;
     const char* err = zkh_read(ctx, last, out_global, 0, 1);
