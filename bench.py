@@ -142,6 +142,17 @@ def main() -> None:
             except Exception as e:                   # surfaced after join
                 self.err = e
 
+    def device_sync():
+        """Both sides of the timed region: every library stream, then torch's device-wide synchronize (torch is only
+        plumbing here; if its own HIP initialisation is unavailable the library's syncs already cover all our work)."""
+        for wk in workers:
+            wk.hal.sync()
+        try:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except (RuntimeError, AssertionError):
+            pass
+
     workers = [Worker(w) for w in range(inflight)]
     for wk in workers:
         for i in range(args.warmup):
@@ -151,7 +162,7 @@ def main() -> None:
         for wk in workers:
             wk.hal.prof_reset()
             wk.hal.prof_enable(True)
-    torch.cuda.synchronize()
+    device_sync()
     if distributed:
         dist.barrier()
     t0 = time.perf_counter()
@@ -160,7 +171,7 @@ def main() -> None:
         th.start()
     for th in threads:
         th.join()
-    torch.cuda.synchronize()
+    device_sync()
     if distributed:
         dist.barrier()
     dt = time.perf_counter() - t0

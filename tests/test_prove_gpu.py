@@ -108,3 +108,23 @@ def test_seal_full_size_po2_20_verifies(hal, oracle):
     # determinism: same witness + noise -> identical seal
     again = prover.prove_segment(Segment(index=0, po2=20))
     assert np.array_equal(receipt.seal, again.seal)
+
+
+@pytest.mark.parametrize("po2", [21, 22])
+def test_seal_maximum_sizes_verify(hal, oracle, po2):
+    """Largest supported segments (po2 22 -> 2^24 evaluation domain, three-pass NTTs): the verifier must accept."""
+    desc = syn_air.syn_small()
+    prover = SegmentProver(hal, desc)
+    receipt = prover.prove_segment(Segment(index=0, po2=po2, seed=0xABC0 + po2))
+    oc = zko.OracleCircuit(oracle, desc)
+    assert oc.verify(receipt.seal) is None
+    assert int(receipt.seal[4]) == po2
+
+
+def test_po2_beyond_limit_is_an_error(hal):
+    from zeth_amd.hal import HalError
+    prover = SegmentProver(hal, syn_air.syn_tiny())
+    with pytest.raises(HalError, match="too large|too small"):
+        prover.prove_segment(Segment(index=0, po2=23))
+    with pytest.raises(HalError, match="too small"):
+        prover.prove_segment(Segment(index=0, po2=10))          # n <= zk_cycles

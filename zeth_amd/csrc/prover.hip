@@ -91,7 +91,7 @@ struct Merkle {
     size_t rows = 0, cols = 0, layers = 0, top_layer = 0, top_size = 0;
     std::vector<uint32_t> top;   // nodes[1 .. 2*top_size) as words; root = top[0..8)
 
-    const char* build(zkh_ctx* c, zkh_buf* mat, size_t rows_, size_t cols_) {
+    const char* enqueue(zkh_ctx* c, zkh_buf* mat, size_t rows_, size_t cols_) {
         rows = rows_; cols = cols_; matrix = mat;
         layers = log2_ceil(rows); top_layer = 0;
         for (size_t i = 1; i < layers; i++) { if (((size_t)1 << i) > ZKH_QUERIES) break; top_layer = i; }
@@ -100,9 +100,12 @@ struct Merkle {
         Buf leaves;
         ZKH_TRY(zkh_slice(nodes, rows * 8, rows * 8, leaves.out()));
         ZKH_TRY(zkh_hash_rows(c, leaves, mat));
-        ZKH_TRY(zkh_merkle_fold_all(c, nodes, rows));
+        return zkh_merkle_fold_all(c, nodes, rows);
+    }
+    // one D2H: root + everything down to the top layer (the only host-visible sync of a commit)
+    const char* fetch_top(zkh_ctx* c) {
         top.resize((2 * top_size - 1) * 8);
-        return zkh_read(c, nodes, top.data(), 8, top.size());     // one D2H: root + everything down to the top layer
+        return zkh_read(c, nodes, top.data(), 8, top.size());
     }
     const uint32_t* root() const { return top.data(); }
     void commit(Iop& iop) const {
@@ -111,12 +114,13 @@ struct Merkle {
     }
     size_t words_per_query() const { return cols + 8 * (layers - top_layer); }
     // open all query rows at once: result[q] = column words ++ path digests
-    const char* open(zkh_ctx* c, const std::vector<uint32_t>& idx, std::vector<uint32_t>& result) const {
-        const size_t wpq = words_per_query();
-        Buf out;
-        ZKH_TRY(zkh_alloc(c, "open", wpq * idx.size(), 0, out.out()));
-        ZKH_TRY(zkh_merkle_open(c, matrix, nodes, rows, cols, idx.data(), idx.size(), out));
-        result.resize(wpq * idx.size());
+    // (enqueue and fetch are split so that every tree's gather is in flight before the first read-back)
+    const char* open_enqueue(zkh_ctx* c, const std::vector<uint32_t>& idx, Buf& out) const {
+        ZKH_TRY(zkh_alloc(c, "open", words_per_query() * idx.size(), 0, out.out()));
+        return zkh_merkle_open(c, matrix, nodes, rows, cols, idx.data(), idx.size(), out);
+    }
+    const char* open_fetch(zkh_ctx* c, const Buf& out, size_t n_idx, std::vector<uint32_t>& result) const {
+        result.resize(words_per_query() * n_idx);
         return zkh_read(c, out, result.data(), 0, result.size());
     }
 };
@@ -127,8 +131,8 @@ struct PolyGroup {
     size_t count = 0, n = 0;
     bool bitrev = false;         // coeffs left in the iNTT's bit-reversed order (n >= 2^14): consumers index accordingly
     Merkle merkle;
-    // takes ownership of bit-reversed coefficient columns
-    const char* build(zkh_ctx* c, Buf&& co, size_t count_, size_t n_) {
+    // takes ownership of bit-reversed coefficient columns; `enqueue` only queues GPU work, `merkle.fetch_top` syncs
+    const char* enqueue(zkh_ctx* c, Buf&& co, size_t count_, size_t n_) {
         coeffs = std::move(co); count = count_; n = n_;
         const size_t dom = n * ZKH_INV_RATE;
         ZKH_TRY(zkh_alloc(c, "evaluated", count * dom, 0, evaluated.out()));
@@ -138,7 +142,11 @@ struct PolyGroup {
         // bit-reversed later (zkh_batch_bit_reverse_extelem)
         bitrev = n >= ((size_t)1 << 14);
         if (!bitrev) ZKH_TRY(zkh_batch_bit_reverse(c, coeffs, count));
-        return merkle.build(c, evaluated, dom, count);
+        return merkle.enqueue(c, evaluated, dom, count);
+    }
+    const char* build(zkh_ctx* c, Buf&& co, size_t count_, size_t n_) {
+        ZKH_TRY(enqueue(c, std::move(co), count_, n_));
+        return merkle.fetch_top(c);
     }
 };
 
@@ -189,14 +197,21 @@ extern "C" const char* zkh_prover_create(zkh_ctx* ctx, const zkh_circuit* circui
 extern "C" void zkh_prover_destroy(zkh_prover* p) { delete p; }
 extern "C" void zkh_free_seal(uint32_t* s) { free(s); }
 
-static const char* commit_group(zkh_ctx* c, Iop& iop, PolyGroup& pg, const zkh_buf* trace, size_t count, size_t n) {
+static const char* commit_group_enqueue(zkh_ctx* c, PolyGroup& pg, const zkh_buf* trace, size_t count, size_t n) {
     ZKH_REQUIRE(trace->len == count * n, "commit_group: trace has %zu words, expected %zu x %zu", trace->len, count, n);
     Buf coeffs;
     ZKH_TRY(zkh_alloc(c, "coeffs", count * n, 0, coeffs.out()));
     ZKH_TRY(zkh_batch_interpolate_ntt_from(c, coeffs, trace, count, 1));
-    ZKH_TRY(pg.build(c, std::move(coeffs), count, n));
+    return pg.enqueue(c, std::move(coeffs), count, n);
+}
+static const char* commit_group_finish(zkh_ctx* c, Iop& iop, PolyGroup& pg) {
+    ZKH_TRY(pg.merkle.fetch_top(c));
     pg.merkle.commit(iop);
     return nullptr;
+}
+static const char* commit_group(zkh_ctx* c, Iop& iop, PolyGroup& pg, const zkh_buf* trace, size_t count, size_t n) {
+    ZKH_TRY(commit_group_enqueue(c, pg, trace, count, n));
+    return commit_group_finish(c, iop, pg);
 }
 
 extern "C" const char* zkh_prove_segment(zkh_prover* pr, size_t po2, size_t zk_cycles, uint64_t noise_seed, const zkh_buf* code,
@@ -225,8 +240,12 @@ extern "C" const char* zkh_prove_segment(zkh_prover* pr, size_t po2, size_t zk_c
     }
     // ---- commit code, data ----
     PolyGroup groups[3];
-    ZKH_TRY(commit_group(c, iop, groups[GROUP_CODE], code, wc, n));
-    ZKH_TRY(commit_group(c, iop, groups[GROUP_DATA], data, wd, n));
+    // neither commitment depends on a challenge, so both groups are queued before the first root is read back; the
+    // transcript still absorbs them in upstream's order (code, then data)
+    ZKH_TRY(commit_group_enqueue(c, groups[GROUP_CODE], code, wc, n));
+    ZKH_TRY(commit_group_enqueue(c, groups[GROUP_DATA], data, wd, n));
+    ZKH_TRY(commit_group_finish(c, iop, groups[GROUP_CODE]));
+    ZKH_TRY(commit_group_finish(c, iop, groups[GROUP_DATA]));
     // ---- accum: mix challenges -> accum witness -> commit ----
     std::vector<uint32_t> mix_global(cir->global_size[GLOBAL_MIX] ? cir->global_size[GLOBAL_MIX] : 1);
     for (size_t i = 0; i < cir->global_size[GLOBAL_MIX]; i++) mix_global[i] = iop.rng.random_elem();
@@ -258,8 +277,14 @@ extern "C" const char* zkh_prove_segment(zkh_prover* pr, size_t po2, size_t zk_c
     const Fp back_one = Fp::raw(c->rou_rev[po2]);
     const size_t n_taps = cir->taps.size();
     std::vector<Fp4> all_xs(n_taps), eval_u(n_taps);
+    const size_t n_u = n_taps + ZKH_CHECK_SIZE;
+    std::vector<Fp4> coeff_u(n_u);
+    const Fp4 z_pow = fp4_pow(z, ZKH_EXT_SIZE);
     {
-        size_t pos = 0;
+        // all four evaluations (three trace groups at z*w^-back, the check group at z^4) are enqueued before the first
+        // read-back, so the stream never idles on a host round trip between them
+        Buf dout[4];
+        size_t counts[4] = {0, 0, 0, 0}, pos = 0;
         for (uint32_t g = 0; g < 3; g++) {
             std::vector<uint32_t> which;
             for (size_t t = 0; t < n_taps; t++) {
@@ -267,36 +292,38 @@ extern "C" const char* zkh_prove_segment(zkh_prover* pr, size_t po2, size_t zk_c
                 which.push_back(cir->taps[t].offset);
                 all_xs[pos + which.size() - 1] = z * fp_pow(back_one, cir->taps[t].back);
             }
+            counts[g] = which.size();
             if (which.empty()) continue;
-            Buf dw, dx, dout;
+            Buf dw, dx;
             ZKH_TRY(zkh_copy_from(c, "which", which.data(), which.size(), dw.out()));
             ZKH_TRY(zkh_copy_from(c, "xs", (const uint32_t*)&all_xs[pos], 4 * which.size(), dx.out()));
-            ZKH_TRY(zkh_alloc(c, "out", 4 * which.size(), 0, dout.out()));
-            if (groups[g].bitrev) ZKH_TRY(zkh_batch_evaluate_any_bitrev(c, groups[g].coeffs, groups[g].count, dw, dx, dout));
-            else ZKH_TRY(zkh_batch_evaluate_any(c, groups[g].coeffs, groups[g].count, dw, dx, dout));
-            ZKH_TRY(zkh_read(c, dout, (uint32_t*)&eval_u[pos], 0, 4 * which.size()));
+            ZKH_TRY(zkh_alloc(c, "out", 4 * which.size(), 0, dout[g].out()));
+            if (groups[g].bitrev) ZKH_TRY(zkh_batch_evaluate_any_bitrev(c, groups[g].coeffs, groups[g].count, dw, dx, dout[g]));
+            else ZKH_TRY(zkh_batch_evaluate_any(c, groups[g].coeffs, groups[g].count, dw, dx, dout[g]));
             pos += which.size();
         }
-    }
-    const size_t n_u = n_taps + ZKH_CHECK_SIZE;
-    std::vector<Fp4> coeff_u(n_u);
-    const Fp4 z_pow = fp4_pow(z, ZKH_EXT_SIZE);
-    {
-        size_t pos = 0;
+        {
+            uint32_t which[ZKH_CHECK_SIZE];
+            Fp4 xs[ZKH_CHECK_SIZE];
+            for (int i = 0; i < ZKH_CHECK_SIZE; i++) { which[i] = i; xs[i] = z_pow; }
+            Buf dw, dx;
+            ZKH_TRY(zkh_copy_from(c, "which", which, ZKH_CHECK_SIZE, dw.out()));
+            ZKH_TRY(zkh_copy_from(c, "xs", (const uint32_t*)xs, 4 * ZKH_CHECK_SIZE, dx.out()));
+            ZKH_TRY(zkh_alloc(c, "out", 4 * ZKH_CHECK_SIZE, 0, dout[3].out()));
+            if (check_group.bitrev) ZKH_TRY(zkh_batch_evaluate_any_bitrev(c, check_group.coeffs, ZKH_CHECK_SIZE, dw, dx, dout[3]));
+            else ZKH_TRY(zkh_batch_evaluate_any(c, check_group.coeffs, ZKH_CHECK_SIZE, dw, dx, dout[3]));
+        }
+        pos = 0;
+        for (uint32_t g = 0; g < 3; g++) {
+            if (counts[g]) ZKH_TRY(zkh_read(c, dout[g], (uint32_t*)&eval_u[pos], 0, 4 * counts[g]));
+            pos += counts[g];
+        }
+        ZKH_TRY(zkh_read(c, dout[3], (uint32_t*)&coeff_u[n_taps], 0, 4 * ZKH_CHECK_SIZE));
+        pos = 0;
         for (const Reg& r : cir->regs) {
             poly_interpolate(&coeff_u[pos], &all_xs[pos], &eval_u[pos], r.size);
             pos += r.size;
         }
-        uint32_t which[ZKH_CHECK_SIZE];
-        Fp4 xs[ZKH_CHECK_SIZE];
-        for (int i = 0; i < ZKH_CHECK_SIZE; i++) { which[i] = i; xs[i] = z_pow; }
-        Buf dw, dx, dout;
-        ZKH_TRY(zkh_copy_from(c, "which", which, ZKH_CHECK_SIZE, dw.out()));
-        ZKH_TRY(zkh_copy_from(c, "xs", (const uint32_t*)xs, 4 * ZKH_CHECK_SIZE, dx.out()));
-        ZKH_TRY(zkh_alloc(c, "out", 4 * ZKH_CHECK_SIZE, 0, dout.out()));
-        if (check_group.bitrev) ZKH_TRY(zkh_batch_evaluate_any_bitrev(c, check_group.coeffs, ZKH_CHECK_SIZE, dw, dx, dout));
-        else ZKH_TRY(zkh_batch_evaluate_any(c, check_group.coeffs, ZKH_CHECK_SIZE, dw, dx, dout));
-        ZKH_TRY(zkh_read(c, dout, (uint32_t*)&coeff_u[pos], 0, 4 * ZKH_CHECK_SIZE));
     }
     iop.write((const uint32_t*)coeff_u.data(), 4 * n_u);
     {
@@ -384,7 +411,8 @@ extern "C" const char* zkh_prove_segment(zkh_prover* pr, size_t po2, size_t zk_c
             r->domain = size * ZKH_INV_RATE;
             ZKH_TRY(zkh_alloc(c, "evaluated", r->domain * ZKH_EXT_SIZE, 0, r->evaluated.out()));
             ZKH_TRY(zkh_batch_expand_into_evaluate_ntt(c, r->evaluated, cur, ZKH_EXT_SIZE, 2));
-            ZKH_TRY(r->merkle.build(c, r->evaluated, r->domain / ZKH_FRI_FOLD, ZKH_FRI_FOLD * ZKH_EXT_SIZE));
+            ZKH_TRY(r->merkle.enqueue(c, r->evaluated, r->domain / ZKH_FRI_FOLD, ZKH_FRI_FOLD * ZKH_EXT_SIZE));
+            ZKH_TRY(r->merkle.fetch_top(c));
             r->merkle.commit(iop);
             const Fp4 fold_mix = iop.rng.random_ext();
             ZKH_TRY(zkh_alloc(c, "out_coeffs", size / ZKH_FRI_FOLD * ZKH_EXT_SIZE, 0, r->coeffs.out()));
@@ -410,12 +438,15 @@ extern "C" const char* zkh_prove_segment(zkh_prover* pr, size_t po2, size_t zk_c
         for (int q = 0; q < ZKH_QUERIES; q++) pos0[q] = iop.rng.random_bits(log2_ceil(orig_domain)) % (uint32_t)orig_domain;
         std::vector<std::vector<uint32_t>> opened(4 + rounds.size());
         const Merkle* trees[4] = {&groups[0].merkle, &groups[1].merkle, &groups[2].merkle, &check_group.merkle};
-        for (int t = 0; t < 4; t++) ZKH_TRY(trees[t]->open(c, pos0, opened[t]));
+        std::vector<Buf> dev(4 + rounds.size());
+        for (int t = 0; t < 4; t++) ZKH_TRY(trees[t]->open_enqueue(c, pos0, dev[t]));
         std::vector<uint32_t> pos = pos0;
         for (size_t r = 0; r < rounds.size(); r++) {
             for (auto& p : pos) p %= (uint32_t)(rounds[r]->domain / ZKH_FRI_FOLD);
-            ZKH_TRY(rounds[r]->merkle.open(c, pos, opened[4 + r]));
+            ZKH_TRY(rounds[r]->merkle.open_enqueue(c, pos, dev[4 + r]));
         }
+        for (int t = 0; t < 4; t++) ZKH_TRY(trees[t]->open_fetch(c, dev[t], ZKH_QUERIES, opened[t]));
+        for (size_t r = 0; r < rounds.size(); r++) ZKH_TRY(rounds[r]->merkle.open_fetch(c, dev[4 + r], ZKH_QUERIES, opened[4 + r]));
         for (int q = 0; q < ZKH_QUERIES; q++) {
             for (int t = 0; t < 4; t++) {
                 const size_t w = trees[t]->words_per_query();
