@@ -168,6 +168,12 @@ const char* zkh_prove_segment(zkh_prover*, size_t po2, size_t zk_cycles, uint64_
                               size_t* seal_words);
 void zkh_free_seal(uint32_t* seal);
 
+/* ---- verifier: risc0_zkp::verify::verify — what `receipt.verify(image_id)` (cli.rs:103) runs per segment ----
+ * Pure host code, no GPU needed: the circuit may be loaded with ctx == NULL (zkh_circuit_load(NULL, ...)).
+ * rc / diag: canonical Poseidon2 tables (24*29 / 24 words) or NULL for the shipped ones.  NULL = seal accepted. */
+const char* zkh_verify_segment(const zkh_circuit*, const uint32_t* seal, size_t seal_words, const uint32_t* rc,
+                               const uint32_t* diag);
+
 /* ---- profiling: per-kernel HIP-event timing on the ctx stream ---- */
 const char* zkh_prof_enable(zkh_ctx*, int on);
 /* writes up to cap records; returns count via *n.  Each record: name (<=47 chars), calls, total_ms */

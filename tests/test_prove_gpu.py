@@ -128,3 +128,22 @@ def test_po2_beyond_limit_is_an_error(hal):
         prover.prove_segment(Segment(index=0, po2=23))
     with pytest.raises(HalError, match="too small"):
         prover.prove_segment(Segment(index=0, po2=10))          # n <= zk_cycles
+
+
+def test_block_of_segments_prove_then_verify(hal, oracle):
+    """The reference's flow for one block (lib.rs:123-143 then cli.rs:103): split the session into segments (short tail),
+    seal each on the GPU, assemble the composite in index order, verify with the PRODUCT's host verifier (and the oracle's)."""
+    from zeth_amd.hal import HalError
+    from zeth_amd.host import BlockProcessor, session_segments
+    desc = syn_air.syn_small()
+    prover = SegmentProver(hal, desc)
+    segs = session_segments(3 * (1 << 15) + 9000, segment_po2=15)       # three full 2^15 segments + a 2^14 tail
+    assert [s.po2 for s in segs] == [15, 15, 15, 14]
+    receipt = BlockProcessor(prover.prove_segment).prove(segs)
+    receipt.verify(desc)
+    oc = zko.OracleCircuit(oracle, desc)
+    for r in receipt.segments:
+        assert oc.verify(r.seal) is None
+    receipt.segments[2].seal[1000] ^= 4
+    with pytest.raises(HalError, match="verify_segment"):
+        receipt.verify(desc)

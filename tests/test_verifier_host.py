@@ -1,0 +1,76 @@
+"""The product's host-side verifier (zkh_verify_segment: the analogue of `receipt.verify`, cli.rs:103) needs no GPU.
+It must accept what the oracle's prover produces, agree with the oracle's independent verifier on every tampered seal,
+and fail with error strings (risc0-sys convention), never crash, on malformed input."""
+import numpy as np
+import pytest
+
+import zko
+from zeth_amd.circuits import syn_air
+from zeth_amd.hal import HalError, HostCircuit
+
+
+@pytest.mark.parametrize("shape,po2,zk", [("syn_tiny", 9, 100), ("syn_tiny", 12, 1994), ("syn_small", 13, 1994)])
+def test_accepts_oracle_seals(oracle, shape, po2, zk):
+    desc = getattr(syn_air, shape)()
+    seal = zko.OracleCircuit(oracle, desc).prove(po2, zk, 7, 9)
+    HostCircuit(desc).verify_segment(seal)
+
+
+def test_agrees_with_oracle_verifier_on_tampering(oracle):
+    desc = syn_air.syn_tiny()
+    oc = zko.OracleCircuit(oracle, desc)
+    hc = HostCircuit(desc)
+    seal = oc.prove(10, 300)
+    hc.verify_segment(seal)
+    rng = np.random.default_rng(1)
+    for pos in [0, 3, 4, 5, 200, 300, 1100, seal.size // 2, seal.size - 1, *rng.integers(0, seal.size, size=40)]:
+        bad = seal.copy()
+        bad[pos] ^= 1 << int(rng.integers(0, 31))
+        assert oc.verify(bad) is not None
+        with pytest.raises(HalError, match="verify_segment"):
+            hc.verify_segment(bad)
+    for cut in (1, 8, 100, seal.size - 4):
+        with pytest.raises(HalError, match="truncated|trailing|mismatch|range|po2"):
+            hc.verify_segment(seal[:-cut])
+    with pytest.raises(HalError, match="trailing"):
+        hc.verify_segment(np.concatenate([seal, np.zeros(3, np.uint32)]))
+    with pytest.raises(HalError):
+        HostCircuit(syn_air.syn_small()).verify_segment(seal)        # wrong circuit
+    with pytest.raises(HalError, match="po2|truncated"):
+        hc.verify_segment(np.zeros(5, np.uint32))
+
+
+def test_constraint_violation_is_rejected(oracle):
+    """Same scenario as the oracle test: a circuit whose selector constraint is violated by the witness."""
+    from zeth_amd.circuits.desc import Circuit
+    desc = syn_air.syn_tiny().copy()
+    c = Circuit.parse(desc)
+    pos = 16 + 3 * len(c.taps) + sum(1 + len(cb) for cb in c.combos)
+    desc[pos + 1] = 2
+    seal = zko.OracleCircuit(oracle, desc).prove(9, 100)
+    with pytest.raises(HalError, match="constraint check failed"):
+        HostCircuit(desc).verify_segment(seal)
+
+
+def test_custom_poseidon2_tables(oracle):
+    """The verifier takes the hash tables as data too."""
+    import re, os
+    desc = syn_air.syn_tiny()
+    rng = np.random.default_rng(5)
+    P = 2013265921
+    rc = rng.integers(0, P, size=24 * 29, dtype=np.uint64).astype(np.uint32)
+    diag = rng.integers(1, P, size=24, dtype=np.uint64).astype(np.uint32)
+    oc = zko.OracleCircuit(oracle, desc)
+    base = oc.prove(9, 100)
+    try:
+        oracle.zko_poseidon2_set_constants(rc, diag)
+        seal = oc.prove(9, 100)
+        assert not np.array_equal(seal[5:40], base[5:40])
+        hc = HostCircuit(desc)
+        hc.verify_segment(seal, rc, diag)
+        with pytest.raises(HalError):
+            hc.verify_segment(seal)                     # shipped tables: different transcript
+    finally:
+        txt = open(os.path.join(os.path.dirname(__file__), "..", "include", "zkh_poseidon2_consts.h")).read()
+        nums = [int(x, 16) for x in re.findall(r"0x([0-9a-f]{8})u", txt)]
+        oracle.zko_poseidon2_set_constants(np.array(nums[24:], np.uint32), np.array(nums[:24], np.uint32))

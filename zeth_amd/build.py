@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libzkhal_mi355x.so")
 OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
-SOURCES = ["hal.hip", "ntt.hip", "hash.hip", "poly.hip", "circuit.hip", "prover.hip", "eval_check_gen.hip"]
+SOURCES = ["hal.hip", "ntt.hip", "hash.hip", "poly.hip", "circuit.hip", "prover.hip", "verifier.hip", "eval_check_gen.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-unused-result"]
 

@@ -326,7 +326,8 @@ extern "C" const char* zkh_circuit_load(zkh_ctx* ctx, const uint32_t* d, size_t 
     if (lds > 160 * 1024) return fail("constraint program needs more live values than the interpreter's LDS holds");
     c->compiled = find_compiled_eval_check(c->hash);
     c->d_prog = nullptr; c->d_taps = nullptr;
-    {
+    if (ctx) {       // ctx == NULL: host-only circuit (enough for zkh_verify_segment, which needs no GPU)
+        bind_thread(ctx);
         static_assert(sizeof(InterpInsn) == INSN_WORDS * 4, "insn layout");
         hipError_t e = hipMalloc((void**)&c->d_prog, c->prog.size() * sizeof(InterpInsn) + 4);
         if (e == hipSuccess) e = hipMemcpy(c->d_prog, c->prog.data(), c->prog.size() * sizeof(InterpInsn), hipMemcpyHostToDevice);
@@ -347,6 +348,7 @@ extern "C" int zkh_circuit_has_compiled_kernel(const zkh_circuit* c) { return c-
 
 extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_buf* check, const zkh_buf* const* groups,
                                       const zkh_buf* const* globals, const uint32_t poly_mix[4], size_t po2, int use_interpreter) {
+    ZKH_REQUIRE(c->ctx == ctx && c->d_prog, "eval_check: circuit was not loaded on this context");
     const size_t n = (size_t)1 << po2, dom = n * ZKH_INV_RATE;
     ZKH_REQUIRE(po2 + 2 <= (size_t)MAX_LOG_N, "eval_check: po2 %zu too large", po2);
     ZKH_REQUIRE(check->len == ZKH_EXT_SIZE * dom, "eval_check: check buffer must hold 4 x 4n words");

@@ -1,0 +1,323 @@
+// verifier.hip — host-side STARK verifier for segment seals: what `receipt.verify(image_id)` runs per segment
+// (/root/reference/crates/host/src/bin/cli.rs:103) after `default_prover().prove` returned
+// (/root/reference/crates/host/src/lib.rs:137).  Follows risc0-zkp 3.0.2 src/verify/{mod.rs, merkle.rs, fri.rs,
+// read_iop.rs} (un-vendored: /root/reference/Cargo.lock:5393).  Pure host code (upstream verifies on the CPU too): it
+// needs no GPU and no zkh_ctx, only a circuit description and the Poseidon2 tables.
+#include <memory>
+
+#include "../../include/zkh_poseidon2_consts.h"
+#include "circuit.h"
+#include "poseidon2.h"
+
+using namespace zkh;
+
+namespace {
+
+struct Tables { uint32_t rc[24 * 29]; uint32_t pc[ZKH_P2_PTAB]; };
+void make_tables(Tables& t, const uint32_t* rc, const uint32_t* diag) {
+    for (int i = 0; i < 24 * 29; i++) t.rc[i] = fp_encode(rc[i]).v - P;
+    Fp c1 = Fp::zero();
+    for (int i = 0; i < 24; i++) {
+        const Fp d = fp_encode(diag[i]);
+        t.pc[i] = d.v; t.pc[24 + i] = (d * d).v; t.pc[48 + i] = (d * d * d).v;
+        if (i) c1 = c1 + d;
+    }
+    t.pc[72] = c1.v; t.pc[73] = fp_encode(23).v;
+}
+struct Digest {
+    uint32_t w[8];
+    bool operator==(const Digest& o) const { return memcmp(w, o.w, 32) == 0; }
+};
+struct Hasher {
+    const Tables* t;
+    void mix(uint32_t (&s)[CELLS]) const { poseidon2_mix(s, t->rc, t->pc); }
+    Digest elems(const uint32_t* in, size_t n) const {
+        uint32_t s[CELLS] = {0};
+        size_t fill = 0;
+        for (size_t i = 0; i < n; i++) {
+            s[fill++] = in[i];
+            if (fill == RATE) { mix(s); fill = 0; }
+        }
+        if (fill || !n) {
+            for (size_t i = fill; i < RATE; i++) s[i] = 0;
+            mix(s);
+        }
+        Digest d;
+        memcpy(d.w, s, 32);
+        return d;
+    }
+    Digest pair(const Digest& a, const Digest& b) const {
+        uint32_t both[16];
+        memcpy(both, a.w, 32); memcpy(both + 8, b.w, 32);
+        return elems(both, 16);
+    }
+};
+// ReadIOP: the seal plus the verifier's copy of the Fiat-Shamir sponge
+struct ReadIop {
+    const uint32_t* w; size_t n, pos = 0;
+    const Hasher* h;
+    uint32_t cells[CELLS] = {0};
+    uint32_t used = 0;
+    bool short_read = false;
+    const uint32_t* read(size_t k) {
+        if (pos + k > n) { short_read = true; return nullptr; }
+        const uint32_t* p = w + pos;
+        pos += k;
+        return p;
+    }
+    void commit(const Digest& d) {
+        if (used) { h->mix(cells); used = 0; }
+        for (int i = 0; i < OUT; i++) cells[i] = add_mod(cells[i], d.w[i]);
+        h->mix(cells);
+    }
+    uint32_t elem() {
+        if (used == RATE) { h->mix(cells); used = 0; }
+        return cells[used++];
+    }
+    Fp4 ext() { Fp4 r; for (int i = 0; i < 4; i++) r.c[i] = Fp::raw(elem()); return r; }
+    uint32_t bits(unsigned b) {
+        uint32_t v = fp_decode(Fp::raw(elem()));
+        for (int i = 0; i < 3; i++) { const uint32_t nv = fp_decode(Fp::raw(elem())); if (!v) v = nv; }
+        return v & (b >= 32 ? 0xffffffffu : (1u << b) - 1);
+    }
+};
+bool reduced(const uint32_t* p, size_t n) { for (size_t i = 0; i < n; i++) if (p[i] >= P) return false; return true; }
+
+// MerkleTreeVerifier
+struct TreeVerifier {
+    size_t rows = 0, cols = 0, top_size = 1;
+    std::vector<Digest> top;      // index 1 .. 2*top_size-1
+    const char* init(ReadIop& io, size_t rows_, size_t cols_) {
+        rows = rows_; cols = cols_;
+        const size_t layers = log2_ceil(rows);
+        size_t top_layer = 0;
+        for (size_t i = 1; i < layers; i++) { if (((size_t)1 << i) > ZKH_QUERIES) break; top_layer = i; }
+        top_size = (size_t)1 << top_layer;
+        const uint32_t* p = io.read(8 * top_size);
+        if (!p) return "seal truncated (tree top)";
+        top.assign(2 * top_size, Digest{});
+        memcpy(top[top_size].w, p, 32 * top_size);
+        for (size_t i = top_size; i-- > 1;) top[i] = io.h->pair(top[2 * i], top[2 * i + 1]);
+        io.commit(top[1]);
+        return nullptr;
+    }
+    const char* open(ReadIop& io, size_t idx, const uint32_t** col) const {
+        if (idx >= rows) return "query index out of range";
+        const uint32_t* c = io.read(cols);
+        if (!c) return "seal truncated (opened column)";
+        if (!reduced(c, cols)) return "opened column holds an unreduced element";
+        Digest cur = io.h->elems(c, cols);
+        size_t j = idx + rows;
+        while (j >= 2 * top_size) {
+            const uint32_t* o = io.read(8);
+            if (!o) return "seal truncated (authentication path)";
+            Digest sib;
+            memcpy(sib.w, o, 32);
+            cur = (j & 1) ? io.h->pair(sib, cur) : io.h->pair(cur, sib);
+            j >>= 1;
+        }
+        if (!(cur == top[j])) return "authentication path does not reach the committed top layer";
+        *col = c;
+        return nullptr;
+    }
+};
+
+Fp4 horner(const Fp4* co, size_t n, Fp4 x) {
+    Fp4 acc = Fp4::zero();
+    for (size_t i = n; i-- > 0;) acc = acc * x + co[i];
+    return acc;
+}
+// PolyExtStepDef::step over ExtElem (adapter.rs)
+Fp4 poly_ext(const zkh_circuit* c, Fp4 poly_mix, const std::vector<Fp4>& u, const uint32_t* const* globals) {
+    struct Mix { Fp4 tot, mul; };
+    std::vector<Fp4> fv; std::vector<Mix> mv;
+    fv.reserve(c->steps.size()); mv.reserve(c->steps.size());
+    for (const Step& s : c->steps) {
+        switch (s.op) {
+        case OP_CONST: fv.push_back(Fp4(fp_encode(s.a))); break;
+        case OP_CONST_EXT: fv.push_back(Fp4(fp_encode(s.a), fp_encode(s.b), fp_encode(s.c), fp_encode(s.d))); break;
+        case OP_GET: fv.push_back(u[s.a]); break;
+        case OP_GET_GLOBAL: fv.push_back(Fp4(Fp::raw(globals[s.a][s.b]))); break;
+        case OP_ADD: fv.push_back(fv[s.a] + fv[s.b]); break;
+        case OP_SUB: fv.push_back(fv[s.a] - fv[s.b]); break;
+        case OP_MUL: fv.push_back(fv[s.a] * fv[s.b]); break;
+        case OP_TRUE: mv.push_back({Fp4::zero(), Fp4::one()}); break;
+        case OP_AND_EQZ: { const Mix x = mv[s.a]; mv.push_back({x.tot + x.mul * fv[s.b], x.mul * poly_mix}); break; }
+        case OP_AND_COND: { const Mix x = mv[s.a], y = mv[s.c]; mv.push_back({x.tot + fv[s.b] * y.tot * x.mul, x.mul * y.mul}); break; }
+        }
+    }
+    return mv[c->ret].tot;
+}
+// verify/fri.rs fold_eval: 16 evaluations on a coset -> the folded polynomial's value
+Fp4 fold_eval(Fp4 (&v)[16], Fp4 mix, Fp inv_wk, const uint32_t (&rou_rev)[28]) {
+    for (int N = 4; N >= 1; N--) {                        // interpolate_ntt over ExtElem values
+        const int len = 1 << N, half = len >> 1;
+        const Fp step = Fp::raw(rou_rev[N]);
+        for (int s = 0; s < 16; s += len) {
+            Fp cur = Fp::one();
+            for (int i = 0; i < half; i++) {
+                const Fp4 a = v[s + i], b = v[s + i + half];
+                v[s + i] = a + b;
+                v[s + i + half] = (a - b) * cur;
+                cur = cur * step;
+            }
+        }
+    }
+    const Fp norm = fp_inv(fp_encode(16));
+    Fp4 tot = Fp4::zero(), mx = Fp4::one();
+    Fp mw = Fp::one();
+    for (int i = 0; i < 16; i++) {                        // coefficient i sits at bit-reversed position
+        const Fp4 ci = v[bitrev32((uint32_t)i) >> 28] * norm;
+        tot = tot + ci * mw * mx;
+        mx = mx * mix; mw = mw * inv_wk;
+    }
+    return tot;
+}
+
+}  // namespace
+
+extern "C" const char* zkh_verify_segment(const zkh_circuit* c, const uint32_t* seal, size_t seal_words,
+                                          const uint32_t* rc_canonical, const uint32_t* diag_canonical) {
+    ZKH_REQUIRE(c && seal, "verify_segment: null argument");
+    std::unique_ptr<Tables> tab(new Tables);
+    make_tables(*tab, rc_canonical ? rc_canonical : ZKH_P2_ROUND_CONSTANTS, diag_canonical ? diag_canonical : ZKH_P2_M_INT_DIAG);
+    Hasher hasher{tab.get()};
+    ReadIop io{seal, seal_words, 0, &hasher};
+    uint32_t rou_fwd[28], rou_rev[28];
+    {
+        const Fp g = fp_encode(137);
+        for (int k = 0; k <= 27; k++) { const Fp w = fp_pow(g, 1ull << (27 - k)); rou_fwd[k] = w.v; rou_rev[k] = fp_inv(w).v; }
+    }
+#define VFAIL(msg) return make_err("verify_segment: %s", msg)
+    // header
+    const uint32_t* out_global = io.read(4);
+    const uint32_t* ppo2 = io.read(1);
+    if (!out_global || !ppo2) VFAIL("seal truncated (header)");
+    const uint32_t po2 = *ppo2;
+    if (po2 < 1 || po2 + 2 > 27) VFAIL("bad po2");
+    if (!reduced(out_global, 4)) VFAIL("unreduced output global");
+    {
+        uint32_t hdr[5];
+        memcpy(hdr, out_global, 16);
+        hdr[4] = fp_encode(po2).v;
+        io.commit(hasher.elems(hdr, 5));
+    }
+    const size_t size = (size_t)1 << po2, domain = size * ZKH_INV_RATE;
+    TreeVerifier tg[3], tcheck;
+    const char* e;
+    if ((e = tg[GROUP_CODE].init(io, domain, c->group_size[GROUP_CODE]))) VFAIL(e);
+    if ((e = tg[GROUP_DATA].init(io, domain, c->group_size[GROUP_DATA]))) VFAIL(e);
+    std::vector<uint32_t> mix_global(c->global_size[GLOBAL_MIX] + 1);
+    for (uint32_t i = 0; i < c->global_size[GLOBAL_MIX]; i++) mix_global[i] = io.elem();
+    if ((e = tg[GROUP_ACCUM].init(io, domain, c->group_size[GROUP_ACCUM]))) VFAIL(e);
+    const Fp4 poly_mix = io.ext();
+    if ((e = tcheck.init(io, domain, ZKH_CHECK_SIZE))) VFAIL(e);
+    const Fp4 z = io.ext();
+    const Fp back_one = Fp::raw(rou_rev[po2]);
+    const size_t n_taps = c->taps.size(), n_u = n_taps + ZKH_CHECK_SIZE;
+    const uint32_t* cu = io.read(4 * n_u);
+    if (!cu) VFAIL("seal truncated (coeff_u)");
+    if (!reduced(cu, 4 * n_u)) VFAIL("unreduced coeff_u");
+    const Fp4* coeff_u = (const Fp4*)cu;
+    io.commit(hasher.elems(cu, 4 * n_u));
+    // U polynomials back to evaluations at z * w^-back, then the constraint polynomial at z against check(z)
+    std::vector<Fp4> eval_u(n_taps);
+    {
+        size_t pos = 0;
+        for (const Reg& r : c->regs) {
+            for (uint32_t i = 0; i < r.size; i++)
+                eval_u[pos + i] = horner(coeff_u + pos, r.size, z * fp_pow(back_one, c->taps[r.tap_begin + i].back));
+            pos += r.size;
+        }
+    }
+    {
+        const uint32_t* globals[2] = {out_global, mix_global.data()};
+        const Fp4 result = poly_ext(c, poly_mix, eval_u, globals);
+        static const int remap[4] = {0, 2, 1, 3};
+        Fp4 check = Fp4::zero();
+        for (int i = 0; i < 4; i++) {
+            const Fp4 zi = fp4_pow(z, i);
+            for (int k = 0; k < 4; k++) {
+                Fp4 basis = Fp4::zero();
+                basis.c[k] = Fp::one();
+                check = check + coeff_u[n_taps + remap[i] + 4 * k] * zi * basis;
+            }
+        }
+        check = check * (fp4_pow(z * fp_encode(3), size) - Fp4::one());
+        if (!(check == result)) VFAIL("constraint check failed: check(z) * Z(z) != constraints(z)");
+    }
+    const Fp4 mix = io.ext();
+    const size_t combo_count = c->combos.size();
+    std::vector<size_t> combo_begin(combo_count + 1, 0);
+    for (size_t i = 0; i < combo_count; i++) combo_begin[i + 1] = combo_begin[i] + c->combos[i].size();
+    std::vector<Fp4> combo_u(c->tot_combo_backs + 1, Fp4::zero()), mix_pows(c->regs.size() + ZKH_CHECK_SIZE);
+    {
+        Fp4 cur = Fp4::one();
+        size_t pos = 0;
+        for (size_t r = 0; r < c->regs.size(); r++) {
+            const Reg& reg = c->regs[r];
+            for (uint32_t i = 0; i < reg.size; i++) combo_u[combo_begin[reg.combo_id] + i] += cur * coeff_u[pos + i];
+            mix_pows[r] = cur;
+            cur = cur * mix; pos += reg.size;
+        }
+        for (int i = 0; i < ZKH_CHECK_SIZE; i++) {
+            combo_u[c->tot_combo_backs] += cur * coeff_u[pos++];
+            mix_pows[c->regs.size() + i] = cur;
+            cur = cur * mix;
+        }
+    }
+    // FRI
+    struct Round { size_t domain; TreeVerifier tree; Fp4 mix; };
+    std::vector<std::unique_ptr<Round>> rounds;
+    size_t degree = size, dom = domain;
+    while (degree > ZKH_FRI_MIN_DEGREE) {
+        std::unique_ptr<Round> r(new Round{dom, {}, Fp4::zero()});
+        if ((e = r->tree.init(io, dom / ZKH_FRI_FOLD, ZKH_FRI_FOLD * ZKH_EXT_SIZE))) VFAIL(e);
+        r->mix = io.ext();
+        rounds.push_back(std::move(r));
+        dom /= ZKH_FRI_FOLD; degree /= ZKH_FRI_FOLD;
+    }
+    const uint32_t* fin = io.read(ZKH_EXT_SIZE * degree);
+    if (!fin) VFAIL("seal truncated (final coefficients)");
+    if (!reduced(fin, ZKH_EXT_SIZE * degree)) VFAIL("unreduced final coefficients");
+    io.commit(hasher.elems(fin, ZKH_EXT_SIZE * degree));
+    std::vector<Fp4> final_poly(degree);
+    for (size_t i = 0; i < degree; i++) for (int j = 0; j < 4; j++) final_poly[i].c[j] = Fp::raw(fin[j * degree + i]);
+    const Fp gen_final = Fp::raw(rou_fwd[log2_ceil(dom)]), gen0 = Fp::raw(rou_fwd[log2_ceil(domain)]);
+    std::vector<Fp4> tot(combo_count + 1);
+    for (int q = 0; q < ZKH_QUERIES; q++) {
+        size_t pos = io.bits(log2_ceil(domain)) % domain;
+        const Fp4 x(fp_pow(gen0, pos));
+        const uint32_t* rows[3];
+        const uint32_t* check_row;
+        for (int g = 0; g < 3; g++) if ((e = tg[g].open(io, pos, &rows[g]))) VFAIL(e);
+        if ((e = tcheck.open(io, pos, &check_row))) VFAIL(e);
+        for (auto& t : tot) t = Fp4::zero();
+        for (size_t r = 0; r < c->regs.size(); r++) {
+            const Reg& reg = c->regs[r];
+            tot[reg.combo_id] += mix_pows[r] * Fp::raw(rows[reg.group][reg.offset]);
+        }
+        for (int i = 0; i < ZKH_CHECK_SIZE; i++) tot[combo_count] += mix_pows[c->regs.size() + i] * Fp::raw(check_row[i]);
+        Fp4 goal = Fp4::zero();
+        for (size_t i = 0; i < combo_count; i++) {
+            Fp4 divisor = Fp4::one();
+            for (uint32_t b : c->combos[i]) divisor = divisor * (x - z * fp_pow(back_one, b));
+            goal += (tot[i] - horner(&combo_u[combo_begin[i]], c->combos[i].size(), x)) * fp4_inv(divisor);
+        }
+        goal += (tot[combo_count] - combo_u[c->tot_combo_backs]) * fp4_inv(x - fp4_pow(z, ZKH_INV_RATE));
+        for (auto& r : rounds) {
+            const size_t per = r->domain / ZKH_FRI_FOLD, quot = pos / per, group = pos % per;
+            const uint32_t* data;
+            if ((e = r->tree.open(io, group, &data))) VFAIL(e);
+            Fp4 v[16];
+            for (int i = 0; i < 16; i++) for (int j = 0; j < 4; j++) v[i].c[j] = Fp::raw(data[j * 16 + i]);
+            if (!(v[quot] == goal)) VFAIL("FRI: opened value does not match the running goal");
+            goal = fold_eval(v, r->mix, fp_pow(Fp::raw(rou_rev[log2_ceil(r->domain)]), group), rou_rev);
+            pos = group;
+        }
+        if (!(horner(final_poly.data(), degree, Fp4(fp_pow(gen_final, pos))) == goal)) VFAIL("FRI: final polynomial mismatch");
+    }
+    if (io.pos != io.n) VFAIL("seal has trailing words");
+#undef VFAIL
+    return nullptr;
+}

@@ -80,6 +80,7 @@ ABI = {
     "zkh_prover_destroy": (None, [_vp]),
     "zkh_prove_segment": (_err, [_vp, _sz, _sz, _u64, _vp, _vp, _u32p, C.POINTER(_u32p), C.POINTER(_sz)]),
     "zkh_free_seal": (None, [_u32p]),
+    "zkh_verify_segment": (_err, [_vp, _u32p, _sz, _u32p, _u32p]),
     "zkh_prof_enable": (_err, [_vp, _i]),
     "zkh_prof_get": (_err, [_vp, C.POINTER(ProfRec), _sz, C.POINTER(_sz)]),
     "zkh_prof_reset": (_err, [_vp]),
@@ -184,6 +185,29 @@ class Circuit:
         gl = (_vp * 2)(*[b.h for b in globals_])
         pm = _u32(poly_mix)
         _check(_lib.zkh_eval_check(self.hal.ctx, self.h, check.h, g, gl, _ptr(pm), po2, int(use_interpreter)))
+
+
+class HostCircuit:
+    """A circuit description loaded WITHOUT a GPU context: enough for `verify_segment` (upstream verifies on the CPU)."""
+
+    def __init__(self, desc):
+        load_library()
+        self.desc = _u32(desc)
+        h = _vp()
+        _check(_lib.zkh_circuit_load(None, _ptr(self.desc), self.desc.size, C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h and _lib is not None:
+            _lib.zkh_circuit_destroy(h)
+
+    def verify_segment(self, seal, rc=None, diag=None) -> None:
+        """`Receipt::verify` for one segment seal: raises HalError (VerificationError analogue) if rejected."""
+        s = _u32(seal)
+        r = _ptr(_u32(rc)) if rc is not None else None
+        d = _ptr(_u32(diag)) if diag is not None else None
+        _check(_lib.zkh_verify_segment(self.h, _ptr(s), s.size, r, d))
 
 
 class HipHal:

@@ -50,6 +50,12 @@ class CompositeReceipt:
         if idx != list(range(len(idx))):
             raise ValueError(f"composite receipt has missing or unordered segments: {idx}")
 
+    def verify(self, circuit_desc) -> None:
+        """`receipt.verify(image_id)` analogue: structural integrity + every segment seal through the host verifier."""
+        self.verify_integrity()
+        for s in self.segments:
+            s.verify(circuit_desc)
+
 
 class BlockProcessor:
     """Proves the segment list of one block on this rank's GPU and (optionally) gathers across ranks."""

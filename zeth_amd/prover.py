@@ -43,6 +43,14 @@ class SegmentReceipt:
     def seal_bytes(self) -> bytes:
         return np.asarray(self.seal, dtype="<u4").tobytes()
 
+    def verify(self, circuit_desc) -> None:
+        """`Receipt::verify` for this segment (/root/reference/crates/host/src/bin/cli.rs:103): host-side, no GPU needed.
+        Raises `zeth_amd.hal.HalError` (the VerificationError analogue) if the seal is rejected."""
+        hc = _hal.HostCircuit(circuit_desc)
+        hc.verify_segment(self.seal)
+        if int(self.seal[4]) != self.po2:
+            raise _hal.HalError("receipt metadata does not match the seal (po2)")
+
 
 class SegmentProver:
     """`SegmentProverImpl<H, C>` analogue bound to one HipHal (one GPU)."""
