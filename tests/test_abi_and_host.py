@@ -117,3 +117,19 @@ def test_block_processor_assembles_in_index_order():
     assert [r.index for r in bp.prove(segs).segments] == [0, 1, 2, 3, 4]
     with pytest.raises(ValueError):
         CompositeReceipt([parts[0][0], parts[0][1]]).verify_integrity()
+
+
+def test_dev_mode_plumbing(monkeypatch):
+    """BASELINE config 1: RISC0_DEV_MODE=1 'prove' = segment scheduling + fake receipts, no GPU."""
+    from zeth_amd.hal import HalError
+    from zeth_amd.host import DevModeProver, dev_mode_enabled
+    monkeypatch.setenv("RISC0_DEV_MODE", "1")
+    assert dev_mode_enabled()
+    segs = session_segments(7 * (1 << 20) + 1, 20)
+    rec = BlockProcessor(DevModeProver().prove_segment).prove(segs)
+    assert [r.index for r in rec.segments] == list(range(8)) and rec.segments[-1].po2 == 13
+    assert all(r.hashfn == "fake" and r.seal.size == 0 for r in rec.segments)
+    with pytest.raises((HalError, IndexError)):
+        rec.verify(syn_air.syn_tiny())                  # fake receipts never verify
+    monkeypatch.delenv("RISC0_DEV_MODE")
+    assert not dev_mode_enabled()

@@ -84,6 +84,21 @@ class BlockProcessor:
         return rec
 
 
+class DevModeProver:
+    """`RISC0_DEV_MODE=1` analogue (BASELINE config 1; /root/reference/README.md:104-109, CI at
+    /root/reference/.github/workflows/main.yml:51-54): no proving, a fake receipt per segment that only carries the
+    claim metadata.  Plumbing for schedulers and tests — it never touches a GPU and its receipts never verify."""
+
+    def prove_segment(self, seg: Segment) -> SegmentReceipt:
+        import numpy as np
+        return SegmentReceipt(seal=np.zeros(0, dtype=np.uint32), index=seg.index, po2=seg.po2, hashfn="fake")
+
+
+def dev_mode_enabled() -> bool:
+    import os
+    return os.environ.get("RISC0_DEV_MODE", "").lower() in ("1", "true", "yes")
+
+
 def torch_gather(rank: int, world_size: int):
     """Control-plane gather of receipts to rank 0 with torch.distributed (gloo on CPU, RCCL on GPU)."""
     import torch.distributed as dist
