@@ -45,30 +45,21 @@ ZKH_HD uint32_t sub_mod(uint32_t a, uint32_t b) {
     const bool borrow = __builtin_usub_overflow(a, b, &t);
     return borrow ? t + P : t;
 }
-// Montgomery reduction of a 64-bit product T < P * 2^32:  (T - (T*P^-1 mod 2^32) * P) / 2^32, in [0, P).
+// Montgomery reduction of a 64-bit product T < P * 2^32:  (T + m*P) / 2^32 with m = -T * P^-1 mod 2^32 makes the low word
+// cancel, so ONE 64-bit multiply-add (v_mad_u64_u32 m, P, T) yields the quotient in its high register: two multiplies
+// and one multiply-add per product instead of three multiplies and a subtract.  T + m*P < 2P * 2^32 < 2^64.
 ZKH_HD uint32_t mont_reduce(uint64_t t) {
-    uint32_t m = (uint32_t)t * PINV;
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t u = __umulhi(m, P);
-#else
-    uint32_t u = (uint32_t)(((uint64_t)m * P) >> 32);
-#endif
-    return sub_mod((uint32_t)(t >> 32), u);
+    const uint32_t m = (uint32_t)t * NEG_PINV;
+    const uint64_t s = t + (uint64_t)m * P;
+    return reduce_once((uint32_t)(s >> 32));
 }
 // Signed Montgomery product (Seiler): for |a|, |b| < P the result is in (-P, P) and congruent to a*b*2^-32 with NO
-// correction step, so chains of products (the x^7 s-box) only canonicalise once at the end.
+// correction step, so chains of products (the x^7 s-box) only canonicalise once at the end.  |t + m*P| < 2^63.
 ZKH_HD int32_t smont(int32_t a, int32_t b) {
     const int64_t t = (int64_t)a * b;
-    const int32_t m = (int32_t)((uint32_t)t * PINV);
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int32_t u = __mulhi(m, (int32_t)P);
-    uint32_t hi = (uint32_t)((uint64_t)t >> 32);
-    asm("" : "+v"(hi));          // keep hipcc from widening hi - u back into a 64-bit subtract
-#else
-    const int32_t u = (int32_t)(((int64_t)m * (int64_t)P) >> 32);
-    uint32_t hi = (uint32_t)((uint64_t)t >> 32);
-#endif
-    return (int32_t)(hi - (uint32_t)u);
+    const int32_t m = (int32_t)((uint32_t)t * NEG_PINV);
+    const int64_t s = t + (int64_t)m * (int64_t)P;      // low 32 bits are zero
+    return (int32_t)(s >> 32);
 }
 ZKH_HD uint32_t canon(int32_t x) { return (uint32_t)x + (P & (uint32_t)(x >> 31)); }   // (-P, P) -> [0, P)
 ZKH_HD uint32_t mul_mod(uint32_t a, uint32_t b) { return mont_reduce((uint64_t)a * b); }

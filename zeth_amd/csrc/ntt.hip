@@ -85,7 +85,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassParams p) {
                 const uint32_t x = tile[i0], y = tile[i1];
                 const uint32_t w = p.tile_tw[low << (LDS_TW_LOG - j)];
                 tile[i0] = add_mod(x, y);
-                tile[i1] = mul_mod(sub_mod(x, y), w);
+                tile[i1] = mul_mod(x - y + P, w);          // lazy difference in (0, 2P): valid Montgomery operand
             }
             __syncthreads();
         }
@@ -201,8 +201,9 @@ __device__ __forceinline__ void radix_layers(uint32_t (&v)[1 << LOGR], const uin
                     const int k = (hi << (b + 1)) | kk;
                     const uint32_t x = v[k], y = v[k + (1 << b)];
                     v[k] = add_mod(x, y);
-                    const uint32_t d = sub_mod(x, y);
-                    v[k + (1 << b)] = unit ? d : mul_mod(d, w);
+                    // the difference feeds a Montgomery product, which accepts a lazy operand: x - y + P in (0, 2P)
+                    // (2 P^2 < P 2^32) costs two plain adds instead of a modular subtract
+                    v[k + (1 << b)] = unit ? sub_mod(x, y) : mul_mod(x - y + P, w);
                 }
             }
         }
