@@ -81,14 +81,21 @@ def main() -> None:
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # control plane only (barrier + MAX of the elapsed time): RCCL by default, gloo on request (e.g. when several
-        # ranks are made to share one GPU for a dry run)
-        backend = os.environ.get("ZKH_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        # Control plane only — the path has no exchange step (segments are independent).  Barrier and MAX-of-elapsed go
+        # over gloo (CPU tensors) so the timing protocol never depends on torch's own HIP state; RCCL is brought up next
+        # to it and exercised once before the timed region (one all_reduce over xGMI), which proves the one-rank-per-GPU
+        # RCCL world is healthy without putting a collective on the data path.  ZKH_DIST_BACKEND=gloo for CPU-only dry runs.
+        backend = os.environ.get("ZKH_DIST_BACKEND", "cpu:gloo,cuda:nccl")
+        if "nccl" in backend:
+            try:
+                torch.cuda.set_device(local_rank)
+            except (RuntimeError, AssertionError):
+                backend = "gloo"
+        dist.init_process_group(backend)
+        ctrl_dev = "cpu" if "gloo" in backend else f"cuda:{local_rank}"
+
+        def barrier():
+            dist.all_reduce(torch.zeros(1, device=ctrl_dev))
 
     from zeth_amd.circuits import syn_air
     from zeth_amd.circuits.desc import Circuit
@@ -162,9 +169,18 @@ def main() -> None:
         for wk in workers:
             wk.hal.prof_reset()
             wk.hal.prof_enable(True)
+    rccl = None
+    if distributed and "nccl" in backend:
+        try:
+            probe = torch.ones(1, device=f"cuda:{device}")
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            rccl = "ok" if int(probe.item()) == world else "wrong sum"
+        except Exception as e:                       # control plane stays on gloo; the seals never needed RCCL
+            rccl = f"unavailable ({type(e).__name__})"
     device_sync()
     if distributed:
-        dist.barrier()
+        barrier()
     t0 = time.perf_counter()
     threads = [threading.Thread(target=wk.run) for wk in workers]
     for th in threads:
@@ -173,13 +189,13 @@ def main() -> None:
         th.join()
     device_sync()
     if distributed:
-        dist.barrier()
+        barrier()
     dt = time.perf_counter() - t0
     for wk in workers:
         if wk.err is not None:
             raise wk.err
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{device}" if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([dt], dtype=torch.float64, device=ctrl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = []
@@ -203,6 +219,7 @@ def main() -> None:
                                    f"(W_code {wc}, W_data {wd}, W_accum {wa}, check 16; {len(circ.taps)} taps), poseidon2, "
                                    "witness resident in HBM", "po2": args.po2,
                        "parallelism": f"segments round-robin over {world} GPU(s), no collectives; {inflight} segment(s) in flight per GPU",
+                       "rccl_probe": rccl,
                        "inflight_per_gpu": inflight,
                        "seal_words": int(last.seal.size) if last is not None else 0},
             "seal_wall_clock_s": dt / args.steps * inflight,

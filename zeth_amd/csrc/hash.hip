@@ -5,9 +5,10 @@
 //
 // This is 31-bit modular integer work: no MFMA.  One lane owns one sponge; the 24-word state lives in VGPRs for
 // the whole permutation (all cell loops are fully unrolled, round constants arrive through scalar loads), rows
-// are read column-major so a wave's 64 lanes read 64 consecutive words per column, and the next 16 column
-// words are fetched while the current block is permuted.  VALU-bound by construction (~1356 Montgomery products
-// per 64 absorbed bytes); the HBM side only has to keep up with 16*W*n bytes per tree.
+// are read column-major so a wave's 64 lanes read 64 consecutive words per column; four resident workgroups per CU
+// hide the column loads behind other waves' permutations (no software prefetch: it only cost VGPRs).  VALU-bound
+// by construction (~1356 Montgomery products per 64 absorbed bytes); the HBM side only has to keep up with
+// 16*W*n bytes per tree.
 #include "common.h"
 #include "poseidon2.h"
 

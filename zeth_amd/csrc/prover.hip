@@ -6,7 +6,7 @@
 //
 // Differences from upstream that change no result:
 //   * commit_group's copy + iNTT + zk_shift are one out-of-place transform (zkh_batch_interpolate_ntt_from);
-//   * the Merkle tree is folded by zkh_merkle_fold_all (one launch for the top 9 layers);
+//   * the Merkle tree is folded by zkh_merkle_fold_all (lane-per-parent kernel for wide layers, 8-lane cooperative kernel below 2^15 parents);
 //   * the 50 query indices only depend on the Fiat-Shamir state after the last commit, so they are drawn first and
 //     each tree is opened for all of them with ONE gather kernel + ONE D2H instead of 50 x (gather + view).
 #include <memory>
