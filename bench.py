@@ -81,11 +81,11 @@ def main() -> None:
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # Control plane only — the path has no exchange step (segments are independent).  Barrier and MAX-of-elapsed go
-        # over gloo (CPU tensors) so the timing protocol never depends on torch's own HIP state; RCCL is brought up next
-        # to it and exercised once before the timed region (one all_reduce over xGMI), which proves the one-rank-per-GPU
-        # RCCL world is healthy without putting a collective on the data path.  ZKH_DIST_BACKEND=gloo for CPU-only dry runs.
-        backend = os.environ.get("ZKH_DIST_BACKEND", "cpu:gloo,cuda:nccl")
+        # Control plane only — the path has no exchange step (segments are independent), so there is no collective on
+        # the data path and none is invented: barrier and MAX-of-elapsed go over gloo on CPU tensors, which keeps the
+        # timing protocol independent of torch's own HIP state.  ZKH_DIST_BACKEND=cpu:gloo,cuda:nccl additionally
+        # brings RCCL up next to it and runs one all_reduce over xGMI before the timed region (health probe only).
+        backend = os.environ.get("ZKH_DIST_BACKEND", "gloo")
         if "nccl" in backend:
             try:
                 torch.cuda.set_device(local_rank)
@@ -123,8 +123,9 @@ def main() -> None:
         def __init__(self, w):
             self.hal = HipHal(device)                # raises if the HIP library / GPU is missing: no fallback
             self.prover = SegmentProver(self.hal, desc)
-            self.steps = [i for i in range(args.steps) if i % inflight == w]
-            ring = max(1, min(len(self.steps) + args.warmup, 2))
+            self.sealed = 0
+            self.seal_s = []
+            ring = max(1, min(-(-args.steps // inflight) + args.warmup, 2))
             self.wit = []
             self.witgen_s = []
             for j in range(ring):                    # witnesses resident in HBM before the clock starts
@@ -139,12 +140,17 @@ def main() -> None:
 
         def seal(self, i):
             seg, code, data, out = self.wit[i % len(self.wit)]
-            self.last = self.prover.seal(seg, code, data, out)
+            t_s = time.perf_counter()
+            self.last = self.prover.seal(seg, code, data, out)   # returns with the seal words on the host
+            self.seal_s.append(time.perf_counter() - t_s)
 
         def run(self):
+            # the K timed steps are handed out through a shared work index (work stealing), so K need
+            # not be a multiple of the number of seals in flight
             try:
-                for k in range(len(self.steps)):
-                    self.seal(args.warmup + k)
+                while next_step() is not None:
+                    self.seal(args.warmup + self.sealed)
+                    self.sealed += 1
                 self.hal.sync()
             except Exception as e:                   # surfaced after join
                 self.err = e
@@ -159,6 +165,16 @@ def main() -> None:
                 torch.cuda.synchronize()
         except (RuntimeError, AssertionError):
             pass
+
+    work_lock, work_next = threading.Lock(), [0]
+
+    def next_step():
+        with work_lock:
+            k = work_next[0]
+            if k >= args.steps:
+                return None
+            work_next[0] = k + 1
+            return k
 
     workers = [Worker(w) for w in range(inflight)]
     for wk in workers:
@@ -181,6 +197,8 @@ def main() -> None:
     device_sync()
     if distributed:
         barrier()
+    for wk in workers:
+        wk.seal_s.clear()
     t0 = time.perf_counter()
     threads = [threading.Thread(target=wk.run) for wk in workers]
     for th in threads:
@@ -222,7 +240,9 @@ def main() -> None:
                        "rccl_probe": rccl,
                        "inflight_per_gpu": inflight,
                        "seal_words": int(last.seal.size) if last is not None else 0},
-            "seal_wall_clock_s": dt / args.steps * inflight,
+            # wall-clock of one seal call (enqueue .. seal words on the host), mean over the timed seals of this rank;
+            # with several seals in flight each one shares the GPU, so this is latency under load, not 1/value
+            "seal_wall_clock_s": sum(t for wk in workers for t in wk.seal_s) / max(1, sum(len(wk.seal_s) for wk in workers)),
             # reported separately: synthetic witness generation on the device, outside the timed region
             "witgen_ms_per_segment": 1e3 * min(t for wk in workers for t in wk.witgen_s[1:] or wk.witgen_s),
         }

@@ -135,7 +135,7 @@ def main() -> None:
             combos = hal.copy_from("combos", (np.arange(w, dtype=np.uint32) % ncombo))
             out = hal.alloc_extelem("m6o", ncombo * n)
             ms, mx = rand_fp(rng, 4), rand_fp(rng, 4)
-            dt = timed(hal, lambda: hal.mix_poly_coeffs(out, ms, mx, coeffs, combos, n, w), args.reps)
+            dt = timed(hal, lambda: hal.mix_poly_coeffs(out, ms, mx, coeffs, combos, w, n), args.reps)
             line("M6", "mix_poly_coeffs", f"{w} x 2^{args.po2} -> {ncombo} combos", dt, 4 * w * n + 32 * ncombo * n)
             del out, combos
         if want("M7"):
