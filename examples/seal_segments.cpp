@@ -1,0 +1,164 @@
+// seal_segments — a host driver written against include/zkhal.h only (plain C ABI: no HIP, torch or Python in this
+// translation unit; it is compiled with g++).  It is the per-session loop that risc0-zkvm 3.0.3's
+// ProverImpl::prove_session runs and that zeth reaches from /root/reference/crates/host/src/lib.rs:137
+// (`default_prover().prove(env, elf)`): every segment of a session is sealed independently, here spread over G devices
+// with K seals in flight per device through one shared work index (segment i -> next free lane, no
+// exchange between devices), and every seal is then checked by the host verifier, the analogue of
+// `receipt.verify(image_id)` at /root/reference/crates/host/src/bin/cli.rs:103.
+//
+//   seal_segments --desc syn_a.desc [--po2 20] [--segments 8] [--devices 1] [--inflight 3] [--no-verify]
+//
+// The circuit description blob is what zeth_amd/circuits/desc.py serialises (`python -m zeth_amd.circuits.syn_air syn_a syn_a.desc`).
+// Witnesses are the declared-synthetic SYN-AIR traces generated on the device (zkh_syn_witgen); with the real rv32im
+// circuit the two trace buffers would come from the executor's preflight instead.
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "zkhal.h"
+
+namespace {
+
+struct Options {
+    std::string desc_path;
+    size_t po2 = 20, segments = 8, devices = 1, inflight = 3;
+    bool verify = true;
+};
+
+struct Receipt {
+    std::vector<uint32_t> seal;
+    double seal_s = 0;
+    int device = -1;
+};
+
+std::mutex g_err_lock;
+std::string g_first_error;
+
+bool failed(const char* err, const char* what) {
+    if (!err) return false;
+    {
+        std::lock_guard<std::mutex> lk(g_err_lock);
+        if (g_first_error.empty()) g_first_error = std::string(what) + ": " + err;
+    }
+    zkh_free_error(err);
+    return true;
+}
+
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// One lane = one context (device + stream) + circuit + prover; lanes of all devices pull from one work index.
+void lane(int device, const std::vector<uint32_t>& desc, const Options& opt, std::atomic<size_t>& next,
+          std::vector<Receipt>& receipts) {
+    zkh_ctx* ctx = nullptr;
+    zkh_circuit* circuit = nullptr;
+    zkh_prover* prover = nullptr;
+    zkh_buf *code = nullptr, *data = nullptr;
+    do {
+        if (failed(zkh_ctx_create(device, "poseidon2", &ctx), "zkh_ctx_create")) break;
+        if (failed(zkh_circuit_load(ctx, desc.data(), desc.size(), &circuit), "zkh_circuit_load")) break;
+        if (failed(zkh_prover_create(ctx, circuit, &prover), "zkh_prover_create")) break;
+        const size_t n = (size_t)1 << opt.po2;
+        const size_t w_code = desc[4], w_data = desc[5];          // header: magic, version, 3, W_accum, W_code, W_data
+        if (failed(zkh_alloc(ctx, "code", w_code * n, 0, &code), "zkh_alloc(code)")) break;
+        if (failed(zkh_alloc(ctx, "data", w_data * n, 0, &data), "zkh_alloc(data)")) break;
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= opt.segments) break;
+            uint32_t out_global[4];
+            if (failed(zkh_syn_witgen(ctx, circuit, opt.po2, ZKH_ZK_CYCLES, 0x5EED0000ull + i, 0x2E80, code, data, out_global),
+                       "zkh_syn_witgen"))
+                break;
+            uint32_t* seal = nullptr;
+            size_t words = 0;
+            const double t0 = now_s();
+            if (failed(zkh_prove_segment(prover, opt.po2, ZKH_ZK_CYCLES, 0x2E80, code, data, out_global, &seal, &words),
+                       "zkh_prove_segment"))
+                break;
+            receipts[i].seal_s = now_s() - t0;
+            receipts[i].seal.assign(seal, seal + words);
+            receipts[i].device = device;
+            zkh_free_seal(seal);
+        }
+    } while (false);
+    if (code) zkh_release(code);
+    if (data) zkh_release(data);
+    if (prover) zkh_prover_destroy(prover);
+    if (circuit) zkh_circuit_destroy(circuit);
+    if (ctx) zkh_ctx_destroy(ctx);
+}
+
+bool parse(int argc, char** argv, Options& o) {
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto val = [&](size_t& dst) { if (i + 1 < argc) dst = strtoull(argv[++i], nullptr, 10); };
+        if (a == "--desc" && i + 1 < argc) o.desc_path = argv[++i];
+        else if (a == "--po2") val(o.po2);
+        else if (a == "--segments") val(o.segments);
+        else if (a == "--devices") val(o.devices);
+        else if (a == "--inflight") val(o.inflight);
+        else if (a == "--no-verify") o.verify = false;
+        else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return false; }
+    }
+    return !o.desc_path.empty() && o.devices >= 1 && o.inflight >= 1 && o.segments >= 1;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    Options opt;
+    if (!parse(argc, argv, opt)) {
+        fprintf(stderr, "usage: %s --desc FILE [--po2 N] [--segments S] [--devices G] [--inflight K] [--no-verify]\n", argv[0]);
+        return 2;
+    }
+    FILE* f = fopen(opt.desc_path.c_str(), "rb");
+    if (!f) { perror(opt.desc_path.c_str()); return 2; }
+    std::vector<uint32_t> desc;
+    uint32_t word;
+    while (fread(&word, 4, 1, f) == 1) desc.push_back(word);
+    fclose(f);
+    if (desc.size() < 16) { fprintf(stderr, "%s: not a circuit description\n", opt.desc_path.c_str()); return 2; }
+
+    std::vector<Receipt> receipts(opt.segments);
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> lanes;
+    const double t0 = now_s();
+    for (size_t d = 0; d < opt.devices; d++)
+        for (size_t k = 0; k < opt.inflight; k++) lanes.emplace_back(lane, (int)d, std::cref(desc), std::cref(opt), std::ref(next), std::ref(receipts));
+    for (auto& t : lanes) t.join();
+    const double dt = now_s() - t0;
+    if (!g_first_error.empty()) { fprintf(stderr, "error: %s\n", g_first_error.c_str()); return 1; }
+
+    // composite receipt = the seals in segment order; verify each one on the host (no GPU involved)
+    size_t verified = 0, total_words = 0;
+    double seal_sum = 0;
+    if (opt.verify) {
+        zkh_circuit* host_circuit = nullptr;
+        if (failed(zkh_circuit_load(nullptr, desc.data(), desc.size(), &host_circuit), "zkh_circuit_load(host)")) {
+            fprintf(stderr, "error: %s\n", g_first_error.c_str());
+            return 1;
+        }
+        for (size_t i = 0; i < receipts.size(); i++) {
+            const char* err = zkh_verify_segment(host_circuit, receipts[i].seal.data(), receipts[i].seal.size(), nullptr, nullptr);
+            if (err) { fprintf(stderr, "segment %zu: seal REJECTED: %s\n", i, err); zkh_free_error(err); return 1; }
+            verified++;
+        }
+        zkh_circuit_destroy(host_circuit);
+    }
+    for (const auto& r : receipts) { total_words += r.seal.size(); seal_sum += r.seal_s; }
+    // wall clock here includes context creation, circuit load and witness generation: a session, not the bench metric
+    printf("{\"driver\": \"seal_segments\", \"library\": \"%s\", \"po2\": %zu, \"segments\": %zu, \"devices\": %zu, \"inflight\": %zu, "
+           "\"session_wall_s\": %.4f, \"segments_per_s_incl_setup\": %.3f, \"mean_seal_call_s\": %.4f, \"seal_words_total\": %zu, "
+           "\"verified\": %zu}\n",
+           zkh_version(), opt.po2, opt.segments, opt.devices, opt.inflight, dt, opt.segments / dt, seal_sum / opt.segments,
+           total_words, verified);
+    return 0;
+}

@@ -140,12 +140,19 @@ const char* zkh_prefix_products(zkh_ctx*, zkh_buf* io_ext);
 const char* zkh_merkle_open(zkh_ctx*, const zkh_buf* matrix, const zkh_buf* nodes, size_t rows, size_t cols,
                             const uint32_t* idx, size_t n_idx, zkh_buf* out);
 
-/* ---- CircuitHal (risc0-circuit-rv32im 4.0.2 src/prove/hal/*; circuit is data: zeth_amd/circuits/desc.py) ---- */
+/* ---- CircuitHal (risc0-circuit-rv32im 4.0.2 src/prove/hal/; circuit is data: zeth_amd/circuits/desc.py) ---- */
 const char* zkh_circuit_load(zkh_ctx*, const uint32_t* desc, size_t n_words, zkh_circuit** out);
 void zkh_circuit_destroy(zkh_circuit*);
-/* 1 if a build-time generated straight-line eval_check kernel matches this desc, 0 if the on-device step
- * interpreter will be used. */
+/* 2 if a code object was attached at run time (below), 1 if a build-time generated straight-line eval_check
+ * kernel matches this desc, 0 if the on-device step interpreter will be used. */
 int zkh_circuit_has_compiled_kernel(const zkh_circuit*);
+/* Attach a gfx950 code object (ELF or clang offload bundle, borrowed for the call) that holds
+ *   extern "C" __global__ void <kernel_name>(zkh::EvalCheckArgs)        -- csrc/circuit.h
+ * generated for this circuit's PolyExtStep list; zkh_eval_check then launches it instead of the interpreter.
+ * Replaces upstream's per-circuit machine-generated eval_check kernel (risc0-circuit-rv32im-sys 4.0.2
+ * kernels/…/eval_check.cu, un-vendored: /root/reference/Cargo.lock:5320) for circuits that arrive as data.
+ * Not thread-safe against a concurrent zkh_eval_check on the same circuit. */
+const char* zkh_circuit_attach_code_object(zkh_circuit*, const void* image, size_t len, const char* kernel_name);
 /* CircuitHal::eval_check(check, groups, globals, poly_mix, po2, steps).  groups = evaluated accum, code, data
  * (each W x 4n); globals = out, mix.  use_interpreter != 0 forces the generic interpreter kernel. */
 const char* zkh_eval_check(zkh_ctx*, const zkh_circuit*, zkh_buf* check, const zkh_buf* const* groups,

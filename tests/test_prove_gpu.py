@@ -147,3 +147,60 @@ def test_block_of_segments_prove_then_verify(hal, oracle):
     receipt.segments[2].seal[1000] ^= 4
     with pytest.raises(HalError, match="verify_segment"):
         receipt.verify(desc)
+
+
+def test_load_time_compiled_eval_check_matches_oracle_and_interpreter(hal, oracle, tmp_path, monkeypatch):
+    """A circuit shape with no built-in kernel gets its eval_check kernel generated + compiled when the blob is loaded
+    (circuits/jit.py -> zkh_circuit_attach_code_object); results must equal the oracle's and the interpreter's, and a
+    whole seal through that kernel must equal the oracle prover's seal byte for byte."""
+    monkeypatch.setenv("ZKH_JIT_CACHE", str(tmp_path))
+    desc = syn_air.build_syn_air(7, 17, 8)              # not one of the shipped shapes
+    po2, zk = 10, 300
+    plain = hal.load_circuit(desc, jit=False)
+    assert plain.kernel_kind() == "interpreter"
+    circ, oc, (code, data, accum), (ocode, odata, oacc), (out, mix) = _witness_parity(hal, oracle, desc, po2, zk)
+    assert circ.kernel_kind() == "attached"             # load_circuit compiled it (hipcc is part of the image)
+    assert any(f.name.endswith(".hsaco") for f in tmp_path.iterdir())
+    wa, wc, wd = (int(x) for x in desc[3:6])
+    n, dom = 1 << po2, 4 << po2
+    ev, oev = [], []
+    for buf, host, w in ((accum, oacc, wa), (code, ocode, wc), (data, odata, wd)):
+        co = hal.alloc_elem("co", w * n)
+        hal.batch_interpolate_ntt_from(co, buf, w, True)
+        e = hal.alloc_elem("ev", w * dom)
+        hal.batch_expand_into_evaluate_ntt(e, co, w, 2)
+        ev.append(e)
+        oev.append(e.to_vec())
+    poly_mix = rand_fp(np.random.default_rng(5), 4)
+    want = np.zeros(4 * dom, np.uint32)
+    gp = (C.c_void_p * 3)(*[a.ctypes.data for a in oev])
+    glp = (C.c_void_p * 2)(out.ctypes.data, mix.ctypes.data)
+    oracle.zko_eval_check(oc.h, want, gp, glp, poly_mix, po2)
+    g_out, g_mix = hal.copy_from("out", out), hal.copy_from("mix", mix)
+    for interp in (False, True):
+        check = hal.alloc_elem("check", 4 * dom)
+        circ.eval_check(check, ev, [g_out, g_mix], poly_mix, po2, use_interpreter=interp)
+        assert np.array_equal(check.to_vec(), want), f"eval_check mismatch (interpreter={interp})"
+    # attaching over a built-in kernel is allowed too and must not change results
+    small = hal.load_circuit(syn_air.syn_small(), jit=True)
+    assert small.kernel_kind() == "attached"
+    prover = SegmentProver(hal, desc)
+    assert prover.circuit.kernel_kind() == "attached"
+    seg = Segment(index=0, po2=po2, seed=0x5EED0000 + 3, noise_seed=0x2E80, zk_cycles=zk)
+    receipt = prover.prove_segment(seg)
+    want_seal = oc.prove(po2, zk, seg.seed, seg.noise_seed)
+    assert np.array_equal(receipt.seal, want_seal)
+    oc.verify(receipt.seal)
+
+
+def test_attach_rejects_garbage(hal):
+    from zeth_amd.hal import HalError
+    circ = hal.load_circuit(syn_air.syn_tiny(), jit=False)
+    with pytest.raises(HalError, match="not an ELF"):
+        circ.attach_code_object(b"\0" * 256, "k")
+    from zeth_amd.circuits import jit
+    image, name = jit.compile_code_object(syn_air.syn_tiny())
+    with pytest.raises(HalError, match="no kernel"):
+        circ.attach_code_object(image, "k_does_not_exist")
+    circ.attach_code_object(image, name)
+    assert circ.kernel_kind() == "attached"

@@ -54,6 +54,21 @@ def generate_eval_check() -> None:
     codegen.write_generated(os.path.join(CSRC, "eval_check_gen.hip"))
 
 
+def build_examples() -> str:
+    """examples/seal_segments: a plain g++ consumer of include/zkhal.h (no HIP headers, no Python)."""
+    src = os.path.join(ROOT, "examples", "seal_segments.cpp")
+    out = os.path.join(ROOT, "examples", "seal_segments")
+    deps = [src, os.path.join(ROOT, "include", "zkhal.h"), LIB]
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", out, "-L", HERE,
+           "-lzkhal_mi355x", "-Wl,-rpath,$ORIGIN/../zeth_amd", "-Wl,-rpath-link,/opt/rocm/lib", "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"g++ failed for examples/seal_segments.cpp:\n{r.stderr[-4000:]}")
+    return out
+
+
 def build_oracle() -> None:
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
 
@@ -69,6 +84,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+    build_examples()
     if verbose:
         print("built", LIB)
     return LIB

@@ -84,13 +84,16 @@ def analyse(c: Circuit):
     return kinds, mix_exp, used_f, used_m, max_pow + 1
 
 
-def emit_kernel(name: str, desc: np.ndarray) -> Tuple[str, int, int]:
+def emit_kernel(name: str, desc: np.ndarray, standalone: bool = False) -> Tuple[str, int, int]:
+    """HIP source of `k_eval_check_<name>` for this desc.  standalone=True: an `extern "C"` kernel with no host-side
+    launcher, for a code object that is attached at run time (circuits/jit.py)."""
     c = Circuit.parse(desc)
     kinds, mix_exp, used_f, used_m, n_pows = analyse(c)
     L: List[str] = []
     w = L.append
     w(f"// {name}: groups (accum, code, data) = {c.group_sizes}, {len(c.taps)} taps, {len(c.steps)} steps")
-    w(f"__global__ __launch_bounds__(256) void k_eval_check_{name}(EvalCheckArgs a) {{")
+    linkage = 'extern "C" ' if standalone else ""
+    w(f"{linkage}__global__ __launch_bounds__(256) void k_eval_check_{name}(EvalCheckArgs a) {{")
     w("    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;")
     w("    if (idx >= a.dom) return;")
     w("    const uint32_t mask = a.dom - 1;")
@@ -186,9 +189,10 @@ def emit_kernel(name: str, desc: np.ndarray) -> Tuple[str, int, int]:
         off = "" if kk == 0 else f"{kk} * dom + "
         w(f"    a.check[{off}idx] = mul_mod({r}_{kk}, zi);")
     w("}")
-    w(f"static void launch_{name}(const EvalCheckArgs& a, hipStream_t s) {{")
-    w(f"    k_eval_check_{name}<<<(a.dom + 255u) / 256u, 256, 0, s>>>(a);")
-    w("}")
+    if not standalone:
+        w(f"static void launch_{name}(const EvalCheckArgs& a, hipStream_t s) {{")
+        w(f"    k_eval_check_{name}<<<(a.dom + 255u) / 256u, 256, 0, s>>>(a);")
+        w("}")
     return "\n".join(L), desc_hash64(desc), n_pows
 
 

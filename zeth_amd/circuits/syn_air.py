@@ -97,3 +97,11 @@ def syn_tiny() -> np.ndarray:
 
 def syn_small() -> np.ndarray:
     return build_syn_air(8, 20, 8)
+
+
+if __name__ == "__main__":      # python -m zeth_amd.circuits.syn_air syn_a out.desc  (blob for non-Python hosts)
+    import sys
+    shape, path = sys.argv[1], sys.argv[2]
+    blob = {"syn_a": syn_a, "syn_tiny": syn_tiny, "syn_small": syn_small}[shape]()
+    np.asarray(blob, dtype="<u4").tofile(path)
+    print(f"{path}: {blob.size} words")

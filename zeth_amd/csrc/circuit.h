@@ -53,6 +53,10 @@ struct zkh_circuit {
     std::vector<zkh::Reg> regs;
     size_t tot_combo_backs;
     const zkh::CompiledEvalCheck* compiled;
+    // code object attached at run time (zkh_circuit_attach_code_object): eval_check kernel generated for THIS desc
+    hipModule_t jit_module;
+    hipFunction_t jit_kernel;
+    bool interp_ok;       // the step interpreter's live values fit its LDS
     // interpreter program
     std::vector<zkh::InterpInsn> prog;
     uint32_t n_fp_slots, n_mix_slots, n_mix_pows, ret_slot;

@@ -323,8 +323,10 @@ extern "C" const char* zkh_circuit_load(zkh_ctx* ctx, const uint32_t* d, size_t 
         c->ret_slot = mix_slot[c->ret];
     }
     const size_t lds = ((size_t)c->n_fp_slots * 4 + (size_t)c->n_mix_slots * 16) * INTERP_THREADS;
-    if (lds > 160 * 1024) return fail("constraint program needs more live values than the interpreter's LDS holds");
+    // a step list too large for the interpreter still loads: it then needs a compiled kernel (built in, or attached)
+    c->interp_ok = lds <= 160 * 1024;
     c->compiled = find_compiled_eval_check(c->hash);
+    c->jit_module = nullptr; c->jit_kernel = nullptr;
     c->d_prog = nullptr; c->d_taps = nullptr;
     if (ctx) {       // ctx == NULL: host-only circuit (enough for zkh_verify_segment, which needs no GPU)
         bind_thread(ctx);
@@ -342,9 +344,31 @@ extern "C" void zkh_circuit_destroy(zkh_circuit* c) {
     if (!c) return;
     if (c->d_prog) (void)hipFree(c->d_prog);
     if (c->d_taps) (void)hipFree(c->d_taps);
+    if (c->jit_module) (void)hipModuleUnload(c->jit_module);
     delete c;
 }
-extern "C" int zkh_circuit_has_compiled_kernel(const zkh_circuit* c) { return c->compiled != nullptr; }
+extern "C" int zkh_circuit_has_compiled_kernel(const zkh_circuit* c) { return c->jit_kernel ? 2 : (c->compiled != nullptr ? 1 : 0); }
+
+// Attach a gfx950 code object holding `extern "C" __global__ void <kernel_name>(EvalCheckArgs)` generated for this
+// circuit's step list (zeth_amd/circuits/jit.py produces it with the same generator the build uses).  Upstream ships
+// one machine-generated kernel per circuit; a circuit that arrives as data gets the same treatment at load time.
+extern "C" const char* zkh_circuit_attach_code_object(zkh_circuit* c, const void* image, size_t len, const char* kernel_name) {
+    ZKH_REQUIRE(c && c->ctx, "attach_code_object: circuit was loaded without a device context");
+    ZKH_REQUIRE(image && len >= 64 && kernel_name, "attach_code_object: empty code object");
+    ZKH_REQUIRE(memcmp(image, "\x7f" "ELF", 4) == 0 || memcmp(image, "__CLANG_OFFLOAD_BUNDLE__", 24) == 0,
+                "attach_code_object: not an ELF code object or offload bundle");
+    bind_thread(c->ctx);
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    hipError_t e = hipModuleLoadData(&mod, image);
+    // a failed module call leaves its code in the thread's last-error slot; clear it so the next launch check is clean
+    if (e != hipSuccess) { (void)hipGetLastError(); return make_err("attach_code_object: hipModuleLoadData: %s", hipGetErrorString(e)); }
+    e = hipModuleGetFunction(&fn, mod, kernel_name);
+    if (e != hipSuccess) { (void)hipGetLastError(); (void)hipModuleUnload(mod); return make_err("attach_code_object: no kernel '%s': %s", kernel_name, hipGetErrorString(e)); }
+    if (c->jit_module) (void)hipModuleUnload(c->jit_module);
+    c->jit_module = mod; c->jit_kernel = fn;
+    return nullptr;
+}
 
 extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_buf* check, const zkh_buf* const* groups,
                                       const zkh_buf* const* globals, const uint32_t poly_mix[4], size_t po2, int use_interpreter) {
@@ -372,10 +396,21 @@ extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_bu
     a.mix_pows = pows->ptr();
     size_t total_w = 0;
     for (int g = 0; g < 3; g++) total_w += c->group_size[g];
-    if (c->compiled && !use_interpreter) {
+    if (c->jit_kernel && !use_interpreter) {
+        ProfScope prof(ctx, "eval_check", 4.0 * total_w * dom + 16.0 * dom);
+        size_t arg_size = sizeof(a);
+        void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size, HIP_LAUNCH_PARAM_END};
+        const hipError_t e = hipModuleLaunchKernel(c->jit_kernel, (unsigned)((dom + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream,
+                                                   nullptr, config);
+        if (e != hipSuccess) { zkh_release(pows); return make_err("eval_check: launching the attached kernel: %s", hipGetErrorString(e)); }
+    } else if (c->compiled && !use_interpreter) {
         ProfScope prof(ctx, "eval_check", 4.0 * total_w * dom + 16.0 * dom);
         c->compiled->launch(a, ctx->stream);
     } else {
+        if (!c->interp_ok) {
+            zkh_release(pows);
+            return make_err("eval_check: the step list has more live values than the interpreter's LDS holds and no compiled kernel is attached");
+        }
         const size_t lds = ((size_t)c->n_fp_slots * 4 + (size_t)c->n_mix_slots * 16) * INTERP_THREADS;
         ProfScope prof(ctx, "eval_check_interp", 4.0 * total_w * dom + 16.0 * dom);
         if (lds > 64 * 1024)

@@ -73,6 +73,7 @@ ABI = {
     "zkh_circuit_load": (_err, [_vp, _u32p, _sz, C.POINTER(_vp)]),
     "zkh_circuit_destroy": (None, [_vp]),
     "zkh_circuit_has_compiled_kernel": (_i, [_vp]),
+    "zkh_circuit_attach_code_object": (_err, [_vp, C.c_char_p, _sz, C.c_char_p]),
     "zkh_eval_check": (_err, [_vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _u32p, _sz, _i]),
     "zkh_syn_witgen": (_err, [_vp, _vp, _sz, _sz, _u64, _u64, _vp, _vp, _u32p]),
     "zkh_syn_accum": (_err, [_vp, _vp, _sz, _sz, _u64, _vp, _u32p, _vp]),
@@ -178,6 +179,19 @@ class Circuit:
 
     def has_compiled_kernel(self) -> bool:
         return bool(_lib.zkh_circuit_has_compiled_kernel(self.h))
+
+    def kernel_kind(self) -> str:
+        """'attached' (code object compiled at load time), 'builtin' (generated at build time) or 'interpreter'."""
+        return ("interpreter", "builtin", "attached")[_lib.zkh_circuit_has_compiled_kernel(self.h)]
+
+    def attach_code_object(self, image: bytes, kernel_name: str) -> None:
+        _check(_lib.zkh_circuit_attach_code_object(self.h, image, len(image), kernel_name.encode()))
+
+    def jit(self, use_cache: bool = True) -> None:
+        """Generate + compile (hipcc --genco, disk-cached) + attach the straight-line eval_check kernel for this desc."""
+        from .circuits import jit as _jit
+        image, name = _jit.compile_code_object(self.desc, use_cache=use_cache)
+        self.attach_code_object(image, name)
 
     def eval_check(self, check: Buffer, groups: Sequence[Buffer], globals_: Sequence[Buffer], poly_mix, po2: int,
                    use_interpreter: bool = False) -> None:
@@ -345,8 +359,16 @@ class HipHal:
         _check(_lib.zkh_poseidon2_set_constants(self.ctx, _ptr(r), _ptr(d)))
 
     # ---- circuit + SYN witness ----
-    def load_circuit(self, desc) -> Circuit:
-        return Circuit(self, desc)
+    def load_circuit(self, desc, jit: Optional[bool] = None) -> Circuit:
+        """CircuitHal for a description blob.  jit=None (default): a desc without a built-in eval_check kernel gets one
+        compiled at load time when hipcc is on the machine, and runs on the step interpreter otherwise; jit=True:
+        always compile (raises if that is impossible); jit=False: never."""
+        c = Circuit(self, desc)
+        if jit or (jit is None and not c.has_compiled_kernel()):
+            from .circuits import jit as _jit
+            if jit or _jit.hipcc_path() is not None:
+                c.jit()
+        return c
 
     def syn_witgen(self, circuit: Circuit, po2: int, zk_cycles: int, seed: int, noise_seed: int, code: Buffer, data: Buffer) -> np.ndarray:
         out = np.zeros(4, dtype=np.uint32)
