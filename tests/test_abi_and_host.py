@@ -171,3 +171,24 @@ def test_header_is_plain_c_and_example_driver_builds(tmp_path):
     exe = build.build_examples()
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 2 and "usage:" in r.stderr
+
+
+def test_join_schedule_shape_and_placement():
+    """ceil(log2 S) dependent levels, S/2^l-way parallel, a join runs where its left child was produced."""
+    from zeth_amd.host import join_schedule
+    assert join_schedule(1, 4) == []
+    lv = join_schedule(1024, 8)
+    assert [len(x) for x in lv] == [512, 256, 128, 64, 32, 16, 8, 4, 2, 1]
+    assert sorted({t.device for t in lv[0]}) == [0, 2, 4, 6]          # leaf 2k lives on rank 2k mod 8
+    assert [sorted({t.device for t in x}) for x in lv[-3:]] == [[0], [0], [0]]
+    lv = join_schedule(5, 2)                                           # odd node carried up
+    assert [len(x) for x in lv] == [2, 1, 1]
+    assert [(t.left, t.right) for t in lv[0]] == [(0, 1), (2, 3)]
+    assert (lv[2][0].left, lv[2][0].right) == (0, 1)
+    for S in range(1, 40):
+        for G in (1, 3, 8):
+            lv = join_schedule(S, G)
+            assert sum(len(x) for x in lv) == S - 1                     # a binary tree over S leaves has S-1 joins
+            assert len(lv) == (S - 1).bit_length()
+    with pytest.raises(ValueError):
+        join_schedule(0, 1)

@@ -204,3 +204,28 @@ def test_attach_rejects_garbage(hal):
         circ.attach_code_object(image, "k_does_not_exist")
     circ.attach_code_object(image, name)
     assert circ.kernel_kind() == "attached"
+
+
+def test_join_tree_to_one_succinct_receipt(hal):
+    """BASELINE config 5 restated synthetically: 5 leaf segments -> 4 SYN-J joins in 3 dependent levels -> one root; every
+    seal (leaves with one circuit, joins with another, both on the same HAL) is accepted by the host verifier."""
+    from zeth_amd.host import join_seed, prove_succinct
+    leaf_desc, join_desc = syn_air.syn_small(), syn_air.build_syn_air(8, 32, 8)
+    leaf_prover, join_prover = SegmentProver(hal, leaf_desc), SegmentProver(hal, join_desc)
+    leaves = [leaf_prover.prove_segment(Segment(index=i, po2=11, seed=0x5EED0000 + i, zk_cycles=500)) for i in range(5)]
+    calls = []
+
+    def prove_join(seg):
+        calls.append(seg)
+        return join_prover.prove_segment(Segment(index=seg.index, po2=seg.po2, seed=seg.seed, zk_cycles=500))
+
+    rec = prove_succinct(leaves, prove_join, join_po2=10)
+    assert [len(lvl) for lvl in rec.joins] == [2, 1, 1] and len(calls) == 4
+    assert calls[0].seed == join_seed(leaves[0], leaves[1]) and calls[1].seed == join_seed(leaves[2], leaves[3])
+    assert calls[2].seed == join_seed(rec.joins[0][0], rec.joins[0][1])
+    assert calls[3].seed == join_seed(rec.joins[1][0], leaves[4])          # the odd leaf is carried up two levels
+    assert rec.root is rec.joins[2][0]
+    rec.verify(leaf_desc, join_desc)
+    rec.joins[1][0].seal[100] ^= 1
+    with pytest.raises(Exception):
+        rec.verify(leaf_desc, join_desc)

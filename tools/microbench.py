@@ -132,7 +132,8 @@ def main() -> None:
         coeffs = upload(hal, rng, "m6", w * n)
         if want("M6"):
             ncombo = 12
-            combos = hal.copy_from("combos", (np.arange(w, dtype=np.uint32) % ncombo))
+            # columns of one combo are adjacent, as a TapSet lays registers out (the accumulator is flushed on a change)
+            combos = hal.copy_from("combos", (np.arange(w, dtype=np.uint32) * ncombo // w))
             out = hal.alloc_extelem("m6o", ncombo * n)
             ms, mx = rand_fp(rng, 4), rand_fp(rng, 4)
             dt = timed(hal, lambda: hal.mix_poly_coeffs(out, ms, mx, coeffs, combos, w, n), args.reps)

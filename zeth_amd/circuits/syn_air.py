@@ -99,9 +99,14 @@ def syn_small() -> np.ndarray:
     return build_syn_air(8, 20, 8)
 
 
+def syn_join() -> np.ndarray:
+    """SYN-J: recursion-like widths (W ~ 16/128/16), declared synthetic."""
+    return build_syn_air(16, 128, 16)
+
+
 if __name__ == "__main__":      # python -m zeth_amd.circuits.syn_air syn_a out.desc  (blob for non-Python hosts)
     import sys
     shape, path = sys.argv[1], sys.argv[2]
-    blob = {"syn_a": syn_a, "syn_tiny": syn_tiny, "syn_small": syn_small}[shape]()
+    blob = {"syn_a": syn_a, "syn_tiny": syn_tiny, "syn_small": syn_small, "syn_join": syn_join}[shape]()
     np.asarray(blob, dtype="<u4").tofile(path)
     print(f"{path}: {blob.size} words")
