@@ -55,13 +55,39 @@ ZKH_HD uint32_t mont_reduce(uint64_t t) {
 }
 // Signed Montgomery product (Seiler): for |a|, |b| < P the result is in (-P, P) and congruent to a*b*2^-32 with NO
 // correction step, so chains of products (the x^7 s-box) only canonicalise once at the end.  |t + m*P| < 2^63.
+// acc + a*b as an exact (wrapping) 64-bit sum of a signed 32x32 product.  On the device it is pinned to ONE
+// v_mad_i64_i32: left to itself hipcc hoists the sign extensions of loop-invariant operands and then expands the
+// product as a generic 64x64 multiply (v_mad_u64_u32 + 2 v_mul_lo_u32 + v_add3_u32).  `_k`: b is wave-uniform (SGPR).
+ZKH_HD int64_t mad_i64(int32_t a, int32_t b, int64_t acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t d; uint64_t carry;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(acc));
+    return d;
+#else
+    return (int64_t)((uint64_t)acc + (uint64_t)((int64_t)a * b));
+#endif
+}
+ZKH_HD int64_t mad_i64_k(int32_t a, int32_t b_uniform, int64_t acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t d; uint64_t carry;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "s"(b_uniform), "v"(acc));
+    return d;
+#else
+    return (int64_t)((uint64_t)acc + (uint64_t)((int64_t)a * b_uniform));
+#endif
+}
+ZKH_HD int32_t smont_reduce(int64_t t) {                // any exact signed sum with |t| < P*2^31  ->  t*2^-32 in (-P, P)
+    const int32_t m = (int32_t)((uint32_t)t * NEG_PINV);
+    return (int32_t)(mad_i64_k(m, (int32_t)P, t) >> 32); // t + m*P: low 32 bits are zero
+}
 ZKH_HD int32_t smont(int32_t a, int32_t b) {
     const int64_t t = (int64_t)a * b;
     const int32_t m = (int32_t)((uint32_t)t * NEG_PINV);
     const int64_t s = t + (int64_t)m * (int64_t)P;      // low 32 bits are zero
     return (int32_t)(s >> 32);
 }
-ZKH_HD uint32_t canon(int32_t x) { return (uint32_t)x + (P & (uint32_t)(x >> 31)); }   // (-P, P) -> [0, P)
+ZKH_HD uint32_t canon(int32_t x) { return (uint32_t)x + (P & (uint32_t)(x >> 31)); }   // [-P, P) -> [0, P)
+ZKH_HD int32_t center(uint32_t x) { return (int32_t)(x - (x > (P - 1) / 2 ? P : 0u)); }  // [0, P) -> [-(P-1)/2, (P-1)/2]
 ZKH_HD uint32_t mul_mod(uint32_t a, uint32_t b) { return mont_reduce((uint64_t)a * b); }
 
 ZKH_HD Fp operator+(Fp a, Fp b) { return Fp::raw(add_mod(a.v, b.v)); }

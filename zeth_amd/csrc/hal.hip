@@ -2,6 +2,7 @@
 // Stands in for risc0-zkp 3.0.2 src/hal/{mod.rs,cuda.rs} (un-vendored; /root/reference/Cargo.lock:5393),
 // reached from /root/reference/crates/host/src/lib.rs:137.
 #include "common.h"
+#include "poseidon2.h"
 #include "../../include/zkh_poseidon2_consts.h"
 
 using namespace zkh;
@@ -104,15 +105,7 @@ static std::vector<uint32_t> powers(Fp base, size_t n) {
 extern "C" const char* zkh_poseidon2_set_constants(zkh_ctx* c, const uint32_t* rc, const uint32_t* diag) {
     std::vector<uint32_t> r(24 * 29), d(ZKH_P2_PTAB);
     for (int i = 0; i < 24 * 29; i++) r[i] = fp_encode(rc[i]).v - P;   // stored as rc - P: see poseidon2.h sbox7_rc
-    {   // partial-round table: d, d^2, d^3, c1 = sum_{i>=1} d_i, 23  (poseidon2.h)
-        Fp c1 = Fp::zero();
-        for (int i = 0; i < 24; i++) {
-            const Fp di = fp_encode(diag[i]);
-            d[i] = di.v; d[24 + i] = (di * di).v; d[48 + i] = (di * di * di).v;
-            if (i >= 1) c1 = c1 + di;
-        }
-        d[72] = c1.v; d[73] = fp_encode(23).v;
-    }
+    poseidon2_partial_table(d.data(), diag);
     memcpy(c->h_rc, r.data(), sizeof c->h_rc);
     memcpy(c->h_diag, d.data(), sizeof c->h_diag);
     ZKH_HIP(hipStreamSynchronize(c->stream));

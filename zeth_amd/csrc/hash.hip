@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256, 4) void k_hash_rows(uint32_t* __restrict__ out
 }
 
 // Hal::hash_fold — one lane per parent: io[out+i] = H(io[in+2i] || io[in+2i+1])
-__global__ __launch_bounds__(256) void k_hash_fold(uint32_t* __restrict__ io, size_t input_size, size_t output_size,
+__global__ __launch_bounds__(256, 4) void k_hash_fold(uint32_t* __restrict__ io, size_t input_size, size_t output_size,
                                                    const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= output_size) return;

@@ -9,6 +9,9 @@
 namespace zkh {
 
 constexpr int CELLS = 24, RATE = 16, OUT = 8, HALF_FULL = 4, PARTIAL = 21, ROUNDS_TOTAL = 2 * HALF_FULL + PARTIAL;
+// Partial-round table (Montgomery form): [0,24) d, [24,48) d^2, [48,72) d^3, [72] c1 = sum_{i>=1} d_i, [73] 23,
+// then the three rows again as centred two's-complement words in [74, 146).
+constexpr int P2_TAB_SIGNED = 74, P2_TAB_WORDS = P2_TAB_SIGNED + 3 * CELLS;
 
 // (x + rc)^7.  The round-constant tables hold rc - P (in [-P, 0)), so x + rcs is already a valid signed operand in
 // [-P, P): one plain add instead of a modular add.  Four signed Montgomery products (no per-product correction) and
@@ -47,7 +50,18 @@ ZKH_HD void m_ext(uint32_t (&s)[CELLS]) {
         s[i + 2] = add_mod(s[i + 2], c2); s[i + 3] = add_mod(s[i + 3], c3);
     }
 }
-// rc: round constants stored as rc - P (two's complement words); diag: the 74-word partial-round table (see below).
+// Build the partial-round table from the canonical internal diagonal (consts.rs M_INT_DIAG as data).
+inline void poseidon2_partial_table(uint32_t* t, const uint32_t* diag_canonical) {
+    Fp c1 = Fp::zero();
+    for (int i = 0; i < CELLS; i++) {
+        const Fp d = fp_encode(diag_canonical[i]);
+        t[i] = d.v; t[CELLS + i] = (d * d).v; t[2 * CELLS + i] = (d * d * d).v;
+        if (i) c1 = c1 + d;
+    }
+    t[3 * CELLS] = c1.v; t[3 * CELLS + 1] = fp_encode(23).v;
+    for (int i = 0; i < 3 * CELLS; i++) t[P2_TAB_SIGNED + i] = (uint32_t)center(t[i]);
+}
+// rc: round constants stored as rc - P (two's complement words); diag: the partial-round table above.
 ZKH_HD void poseidon2_mix(uint32_t (&s)[CELLS], const uint32_t* __restrict__ rc,
                                               const uint32_t* __restrict__ diag) {
     m_ext(s);
@@ -63,28 +77,35 @@ ZKH_HD void poseidon2_mix(uint32_t (&s)[CELLS], const uint32_t* __restrict__ rc,
     // three rounds collapse to  s_i <- S2 + d_i S1 + d_i^2 S0 + d_i^3 s_i  (ONE reduction for three products instead
     // of three).  The sums the cell-0 chain needs in between come from weighted sums taken once per group:
     //   A = sum s_i, D1 = sum d_i s_i, D2 = sum d_i^2 s_i  (i >= 1);  A' = 23 S0 + D1;  A'' = 23 S1 + c1 S0 + D2.
-    // Exact field identities: the result equals 21 literal rounds (tests compare against the literal oracle).
-    // pc layout: [0,24) d, [24,48) d^2, [48,72) d^3, [72] c1 = sum_{i>=1} d_i, [73] 23 — all Montgomery form.
-    const uint32_t* __restrict__ pc = diag;
+    // Inside this section cells 1..23 are SIGNED representatives in [-P, P) and the table rows used with them are
+    // centred (|d^k| <= (P-1)/2), which makes the per-cell update one signed reduction with no correction
+    // (|d^3 s + d^2 S0 + d S1| <= (P-1)P/2 + 2 ((P-1)/2)^2 < P 2^31 with S0, S1 centred) plus one sign-selected add
+    // of S2 or S2 - P; sums of signed products start from the bias P 2^32 (= 0 mod P), which keeps the accumulator a
+    // valid unsigned operand of mont_reduce_wide.  Exact field identities throughout: the result equals 21 literal
+    // rounds (tests compare against the literal oracle).
+    const uint32_t* __restrict__ pc = diag;                                   // unsigned rows + c1 + 23
+    const int32_t* __restrict__ pcs = (const int32_t*)(diag + P2_TAB_SIGNED); // centred d, d^2, d^3
+    constexpr int64_t BIAS = (int64_t)((uint64_t)P << 32);                    // = 0 mod P; sums wrap as unsigned
+    constexpr int32_t R1S = (int32_t)R1;                                      // 2^32 mod P = 268435454 < 2^28
 #pragma unroll 1
     for (int grp = 0; grp < PARTIAL / 3; grp++, round += 3) {
-        uint32_t q[12];
+        // A: 12 + 11 terms s_i * R (|sum| <= 12 P 2^28 = 0.75 P 2^32 < bias), reduced back by the Montgomery step
+        int64_t ta = BIAS, tb = BIAS;
 #pragma unroll
-        for (int i = 0; i < 11; i++) q[i] = add_mod(s[2 * i + 1], s[2 * i + 2]);
-        q[11] = s[23];
+        for (int i = 1; i <= 12; i++) ta = mad_i64_k((int32_t)s[i], R1S, ta);
 #pragma unroll
-        for (int i = 0; i < 6; i++) q[i] = add_mod(q[2 * i], q[2 * i + 1]);
-        const uint32_t A = add_mod(add_mod(add_mod(q[0], q[1]), add_mod(q[2], q[3])), add_mod(q[4], q[5]));
+        for (int i = 13; i < CELLS; i++) tb = mad_i64_k((int32_t)s[i], R1S, tb);
+        const uint32_t A = add_mod(mont_reduce_wide((uint64_t)ta), mont_reduce_wide((uint64_t)tb));
         uint32_t D1 = 0, D2 = 0;
 #pragma unroll
-        for (int i0 = 1; i0 < CELLS; i0 += 4) {             // groups of <= 4 products per 64-bit accumulator
-            uint64_t a1 = 0, a2 = 0;
+        for (int i0 = 1; i0 < CELLS; i0 += 4) {             // <= 4 signed products (|sum| <= 2 P^2 < bias) per accumulator
+            int64_t a1 = BIAS, a2 = BIAS;
 #pragma unroll
             for (int i = i0; i < i0 + 4 && i < CELLS; i++) {
-                a1 += (uint64_t)pc[i] * s[i];
-                a2 += (uint64_t)pc[CELLS + i] * s[i];
+                a1 = mad_i64_k((int32_t)s[i], pcs[i], a1);
+                a2 = mad_i64_k((int32_t)s[i], pcs[CELLS + i], a2);
             }
-            const uint32_t r1 = mont_reduce_wide(a1), r2 = mont_reduce_wide(a2);
+            const uint32_t r1 = mont_reduce_wide((uint64_t)a1), r2 = mont_reduce_wide((uint64_t)a2);
             D1 = i0 == 1 ? r1 : add_mod(D1, r1);
             D2 = i0 == 1 ? r2 : add_mod(D2, r2);
         }
@@ -99,12 +120,20 @@ ZKH_HD void poseidon2_mix(uint32_t (&s)[CELLS], const uint32_t* __restrict__ rc,
         const uint32_t A2 = add_mod(mont_reduce_wide((uint64_t)m23 * S1 + (uint64_t)c1 * S0), D2);
         const uint32_t S2 = add_mod(z2, A2);
         s[0] = mont_reduce_wide(((uint64_t)S2 << 32) + (uint64_t)d0 * z2);
+        const int32_t S0c = center(S0), S1c = center(S1);
+        const uint32_t S2mP = S2 - P;
 #pragma unroll
         for (int i = 1; i < CELLS; i++) {
-            const uint32_t t = mont_reduce_wide((uint64_t)pc[i] * S1 + (uint64_t)pc[CELLS + i] * S0 + (uint64_t)pc[2 * CELLS + i] * s[i]);
-            s[i] = add_mod(S2, t);
+            int32_t r = smont_reduce(mad_i64_k((int32_t)s[i], pcs[2 * CELLS + i],
+                                               mad_i64_k(S0c, pcs[CELLS + i], mad_i64_k(S1c, pcs[i], 0))));   // in (-P, P)
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm("" : "+v"(r));              // keep the sign test a 32-bit compare (hipcc would test the 64-bit sum)
+#endif
+            s[i] = (uint32_t)r + (r < 0 ? S2 : S2mP);                                          // in [-P, P)
         }
     }
+#pragma unroll
+    for (int i = 1; i < CELLS; i++) s[i] = canon((int32_t)s[i]);
 #pragma unroll 1
     for (int r = 0; r < HALF_FULL; r++, round++) {
 #pragma unroll

@@ -16,13 +16,7 @@ namespace {
 struct Tables { uint32_t rc[24 * 29]; uint32_t pc[ZKH_P2_PTAB]; };
 void make_tables(Tables& t, const uint32_t* rc, const uint32_t* diag) {
     for (int i = 0; i < 24 * 29; i++) t.rc[i] = fp_encode(rc[i]).v - P;
-    Fp c1 = Fp::zero();
-    for (int i = 0; i < 24; i++) {
-        const Fp d = fp_encode(diag[i]);
-        t.pc[i] = d.v; t.pc[24 + i] = (d * d).v; t.pc[48 + i] = (d * d * d).v;
-        if (i) c1 = c1 + d;
-    }
-    t.pc[72] = c1.v; t.pc[73] = fp_encode(23).v;
+    poseidon2_partial_table(t.pc, diag);
 }
 struct Digest {
     uint32_t w[8];
