@@ -275,13 +275,13 @@ def main() -> None:
                                         "time shared with other streams"}
             if dom["name"] == "hash_rows":
                 # VALU view of the same kernel: permutations per launch x modelled issue cycles per 64-lane permutation
-                # (8 full rounds x 2368 + 7 partial groups x 1926 + 1024 cycles) against 1024 SIMDs at 2.4 GHz
+                # (8 full rounds x 2368 + 7 partial groups x 1576 + 1024 + 138 cycles) against 1024 SIMDs at 2.4 GHz
                 perms = sum(-(-w // 16) for w in (wc, wd, wa, 16)) * 4 * n          # leaves of the 3 trace trees + check tree
                 deg = n
                 while deg > 256:                                                   # FRI rounds: 4*deg/16 rows of 64 words
                     perms += 4 * (4 * deg // 16)
                     deg //= 16
-                cyc = 8 * 2368 + 7 * 1926 + 1024
+                cyc = 8 * 2368 + 7 * 1576 + 1024 + 138
                 per_seal_ms = dom["total_ms"] / args.steps
                 line["roofline"]["valu"] = {"permutations_per_seal": perms, "model_cycles_per_wave_permutation": cyc,
                                             "issue_utilisation_at_2p4GHz": (perms / 64.0) * cyc / (1024 * 2.4e9 * per_seal_ms * 1e-3)}

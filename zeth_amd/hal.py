@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzkhal_mi355x.so")
+LIB_PATH = os.environ.get("ZKH_LIBRARY") or os.path.join(_HERE, "libzkhal_mi355x.so")   # override: another build of the same ABI
 
 INV_RATE, QUERIES, FRI_FOLD, FRI_MIN_DEGREE, ZK_CYCLES, CHECK_SIZE, EXT_SIZE, DIGEST_WORDS = 4, 50, 16, 256, 1994, 16, 4, 8
 
