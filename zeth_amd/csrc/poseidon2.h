@@ -96,29 +96,37 @@ ZKH_HD void poseidon2_mix(uint32_t (&s)[CELLS], const uint32_t* __restrict__ rc,
 #pragma unroll
         for (int i = 13; i < CELLS; i++) tb = mad_i64_k((int32_t)s[i], R1S, tb);
         const uint32_t A = add_mod(mont_reduce_wide((uint64_t)ta), mont_reduce_wide((uint64_t)tb));
-        uint32_t D1 = 0, D2 = 0;
+        // D1 = sum d_i s_i, D2 = sum d_i^2 s_i as six partial residues each (<= 4 signed products per accumulator,
+        // |sum| <= 2 P^2 < bias).  The partials are never added up on their own: they enter the 64-bit sums that
+        // produce S1 and S2 as r*R terms (r R < P 2^28), so S1 and S2 cost one reduction each.
+        uint32_t r1[6], r2[6];
 #pragma unroll
-        for (int i0 = 1; i0 < CELLS; i0 += 4) {             // <= 4 signed products (|sum| <= 2 P^2 < bias) per accumulator
+        for (int c = 0; c < 6; c++) {
             int64_t a1 = BIAS, a2 = BIAS;
 #pragma unroll
-            for (int i = i0; i < i0 + 4 && i < CELLS; i++) {
+            for (int i = 1 + 4 * c; i < 5 + 4 * c && i < CELLS; i++) {
                 a1 = mad_i64_k((int32_t)s[i], pcs[i], a1);
                 a2 = mad_i64_k((int32_t)s[i], pcs[CELLS + i], a2);
             }
-            const uint32_t r1 = mont_reduce_wide((uint64_t)a1), r2 = mont_reduce_wide((uint64_t)a2);
-            D1 = i0 == 1 ? r1 : add_mod(D1, r1);
-            D2 = i0 == 1 ? r2 : add_mod(D2, r2);
+            r1[c] = mont_reduce_wide((uint64_t)a1); r2[c] = mont_reduce_wide((uint64_t)a2);
         }
         const uint32_t d0 = pc[0], c1 = pc[3 * CELLS], m23 = pc[3 * CELLS + 1];
         const uint32_t z0 = sbox7_rc(s[0], rc[round * CELLS]);
         const uint32_t S0 = add_mod(z0, A);
         const uint32_t s0a = mont_reduce_wide(((uint64_t)S0 << 32) + (uint64_t)d0 * z0);
         const uint32_t z1 = sbox7_rc(s0a, rc[(round + 1) * CELLS]);
-        const uint32_t S1 = add_mod(z1, add_mod(mul_mod(m23, S0), D1));
+        // S1 = z1 + 23 S0 + D1:  z1 R + m23 S0 + sum r1 R  <  P^2 + 7 P 2^28  <  P 2^32
+        uint64_t t1 = (uint64_t)m23 * S0 + (uint64_t)z1 * R1;
+#pragma unroll
+        for (int c = 0; c < 6; c++) t1 += (uint64_t)r1[c] * R1;
+        const uint32_t S1 = mont_reduce(t1);
         const uint32_t s0b = mont_reduce_wide(((uint64_t)S1 << 32) + (uint64_t)d0 * z1);
         const uint32_t z2 = sbox7_rc(s0b, rc[(round + 2) * CELLS]);
-        const uint32_t A2 = add_mod(mont_reduce_wide((uint64_t)m23 * S1 + (uint64_t)c1 * S0), D2);
-        const uint32_t S2 = add_mod(z2, A2);
+        // S2 = z2 + 23 S1 + c1 S0 + D2:  < 2 P^2 + 7 P 2^28  <  2 P 2^32
+        uint64_t t2 = (uint64_t)m23 * S1 + (uint64_t)c1 * S0 + (uint64_t)z2 * R1;
+#pragma unroll
+        for (int c = 0; c < 6; c++) t2 += (uint64_t)r2[c] * R1;
+        const uint32_t S2 = mont_reduce_wide(t2);
         s[0] = mont_reduce_wide(((uint64_t)S2 << 32) + (uint64_t)d0 * z2);
         const int32_t S0c = center(S0), S1c = center(S1);
         const uint32_t S2mP = S2 - P;
