@@ -42,7 +42,8 @@ def test_batch_interpolate_ntt(hal, oracle, log_n, count):
     eq(buf.to_vec(), want)
 
 
-@pytest.mark.parametrize("log_n,count,bits", [(4, 2, 2), (10, 3, 2), (14, 4, 2), (15, 2, 0), (18, 3, 2), (20, 2, 2), (22, 1, 2), (12, 2, 1), (24, 1, 2), (13, 1, 3)])
+@pytest.mark.parametrize("log_n,count,bits", [(4, 2, 2), (10, 3, 2), (14, 4, 2), (15, 2, 0), (18, 3, 2), (20, 2, 2), (22, 1, 2), (12, 2, 1), (24, 1, 2), (13, 1, 3),
+                                              (20, 2, 0), (20, 1, 3), (22, 1, 4), (22, 1, 1), (21, 1, 2), (19, 2, 2)])
 def test_batch_expand_into_evaluate_ntt(hal, oracle, log_n, count, bits):
     rng = np.random.default_rng(log_n * 7 + count)
     n_out = 1 << log_n
@@ -52,6 +53,23 @@ def test_batch_expand_into_evaluate_ntt(hal, oracle, log_n, count, bits):
     oracle.zko_batch_expand_into_evaluate_ntt(want, want.size, x, x.size, count, bits)
     out = hal.alloc_elem("out", count * n_out)
     hal.batch_expand_into_evaluate_ntt(out, hal.copy_from("in", x), count, bits)
+    eq(out.to_vec(), want)
+
+
+@pytest.mark.parametrize("log_n,bits", [(20, 2), (22, 2), (20, 0)])
+def test_expand_ntt_extreme_inputs(hal, oracle, log_n, bits):
+    """The 2^20 / 2^22 forward transforms run lazy signed butterflies (values in (-P, P), |x + w y| < P 2^31): drive
+    them with all-(P-1), all-zero and alternating columns, where every intermediate sits at the edge of its range."""
+    n_out = 1 << log_n
+    n_in = n_out >> bits
+    cols = [np.full(n_in, P - 1, np.uint32), np.zeros(n_in, np.uint32),
+            np.where(np.arange(n_in) % 2 == 0, P - 1, 0).astype(np.uint32),
+            np.where(np.arange(n_in) % 3 == 0, 1, P - 1).astype(np.uint32)]
+    x = np.concatenate(cols)
+    want = np.zeros(len(cols) * n_out, dtype=np.uint32)
+    oracle.zko_batch_expand_into_evaluate_ntt(want, want.size, x, x.size, len(cols), bits)
+    out = hal.alloc_elem("out", len(cols) * n_out)
+    hal.batch_expand_into_evaluate_ntt(out, hal.copy_from("in", x), len(cols), bits)
     eq(out.to_vec(), want)
 
 

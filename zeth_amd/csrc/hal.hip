@@ -146,6 +146,8 @@ extern "C" const char* zkh_ctx_create(int device, const char* suite, zkh_ctx** o
         }
         ZKH_TRY(upload(&c->tab.layer_fwd, lf));
         ZKH_TRY(upload(&c->tab.layer_rev, lr));
+        for (auto& w : lf) w = mont_reduce((uint64_t)w);          // word / R: the plain residue
+        ZKH_TRY(upload(&c->tab.layer_fwd_plain, lf));
     }
     Fp three = fp_encode(3);
     ZKH_TRY(upload(&c->tab.shift_lo, powers(three, TW_SIZE)));
@@ -162,7 +164,7 @@ extern "C" void zkh_ctx_destroy(zkh_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->pool) (void)hipFree(kv.second);
     uint32_t* t[] = {c->tab.rc, c->tab.diag, c->tab.tw_fwd_lo, c->tab.tw_fwd_hi, c->tab.tw_rev_lo, c->tab.tw_rev_hi,
-                     c->tab.tile_fwd, c->tab.tile_rev, c->tab.shift_lo, c->tab.shift_hi, c->tab.layer_fwd, c->tab.layer_rev};
+                     c->tab.tile_fwd, c->tab.tile_rev, c->tab.shift_lo, c->tab.shift_hi, c->tab.layer_fwd, c->tab.layer_rev, c->tab.layer_fwd_plain};
     for (auto p : t) (void)hipFree(p);
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto ev : c->event_pool) (void)hipEventDestroy(ev);

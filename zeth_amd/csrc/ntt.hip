@@ -38,6 +38,8 @@ struct PassParams {
     const uint32_t* sh_lo;
     const uint32_t* sh_hi;
     uint32_t tiles_per_col;
+    uint32_t lazy;           // forward register-radix pair (low12 + high<8|10>): see radix_layers<..., LAZY>
+    uint32_t lazy_comp;      // R^(number of lazy layers) as a Montgomery word: folded into the four-step twiddle
     uint32_t shift16[16];    // inverse last pass: n^-1 * 3^(bitrev4(k) << (log_n - 4)), k < 16 (Montgomery; 0 = unused)
 };
 
@@ -184,11 +186,38 @@ __global__ void k_bit_reverse_small(uint32_t* io, uint32_t log_n, size_t count) 
 // 4096-point tile instead of 12 read-modify-write sweeps), twiddles come from per-layer tables so that
 // consecutive lanes read consecutive words.
 // =====================================================================================================
-template <int LOGR, bool INVERSE, bool BASE0, int J_LO>
+//
+// LAZY (forward only): values are SIGNED representatives in (-P, P) and every layer divides by R = 2^32:
+//   a = (x + w y) / R,  b = (x - w y) / R   as   smont_reduce(sext(x) +- w*y)   (|x + w y| <= P + P^2 < P 2^31),
+// with w read from the PLAIN (non-Montgomery) twiddle table, so that x and the product pick up the same factor 1/R,
+// i.e. one sign extension, two v_mad_i64_i32 and two uncorrected reductions per butterfly (11.9 add-slots instead of
+// 14.1 for product + modular add + modular subtract).  The accumulated R^-layers is cancelled by one constant folded
+// into the four-step twiddle of the strided pass, whose outputs are canonicalised once.  Exact field arithmetic:
+// results are identical to the plain path.
+template <int LOGR, bool INVERSE, bool BASE0, int J_LO, bool LAZY = false>
 __device__ __forceinline__ void radix_layers(uint32_t (&v)[1 << LOGR], const uint32_t* __restrict__ ltab,
                                              const uint32_t base_low, const int first_b) {
     constexpr int N = 1 << LOGR;
-    if (INVERSE) {
+    if (!INVERSE && LAZY) {
+#pragma unroll
+        for (int b = 0; b < LOGR; b++) {
+            if (b < first_b) continue;
+            const uint32_t* tw = ltab + (1u << (J_LO + b - 1));
+#pragma unroll
+            for (int kk = 0; kk < (1 << b); kk++) {
+                const bool unit = BASE0 && kk == 0;
+                const int32_t w = (int32_t)(unit ? 1u : tw[base_low + ((uint32_t)kk << (J_LO - 1))]), nw = -w;   // plain residue
+#pragma unroll
+                for (int hi = 0; hi < (N >> (b + 1)); hi++) {
+                    const int k = (hi << (b + 1)) | kk;
+                    const int64_t x = (int64_t)(int32_t)v[k];
+                    const int32_t y = (int32_t)v[k + (1 << b)];
+                    v[k] = (uint32_t)smont_reduce(mad_i64(y, w, x));
+                    v[k + (1 << b)] = (uint32_t)smont_reduce(mad_i64(y, nw, x));
+                }
+            }
+        }
+    } else if (INVERSE) {
 #pragma unroll
         for (int b = LOGR - 1; b >= 0; b--) {
             const uint32_t* tw = ltab + (1u << (J_LO + b - 1));
@@ -229,7 +258,7 @@ __device__ __forceinline__ void radix_layers(uint32_t (&v)[1 << LOGR], const uin
 }
 
 // Lowest pass, index bits [0, 12): one workgroup = 4096 contiguous words of one column.
-template <bool INVERSE>
+template <bool INVERSE, bool LAZY = false>
 __global__ __launch_bounds__(256) void k_ntt_low12(PassParams p) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[4096];
     const uint32_t tid = threadIdx.x;
@@ -285,19 +314,19 @@ __global__ __launch_bounds__(256) void k_ntt_low12(PassParams p) {
 #pragma unroll
             for (int k = 0; k < 16; k++) v[k] = in[(pos0 + k) >> p.expand_bits];
         }
-        radix_layers<4, false, true, 1>(v, ltab, 0, (int)p.expand_bits);        // layers 1..4 (first expand_bits skipped)
+        radix_layers<4, false, true, 1, LAZY>(v, ltab, 0, (int)p.expand_bits);  // layers 1..4 (first expand_bits skipped)
 #pragma unroll
         for (int q = 0; q < 4; q++) ((uint4*)lds)[tid * 4 + q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 16; k++) v[k] = lds[hi * 256 + k * 16 + low];
-        radix_layers<4, false, false, 5>(v, ltab, low, 0);                      // layers 5..8
+        radix_layers<4, false, false, 5, LAZY>(v, ltab, low, 0);                // layers 5..8
 #pragma unroll
         for (int k = 0; k < 16; k++) lds[hi * 256 + k * 16 + low] = v[k];
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 16; k++) v[k] = lds[k * 256 + tid];
-        radix_layers<4, false, false, 9>(v, ltab, tid, 0);                      // layers 9..12
+        radix_layers<4, false, false, 9, LAZY>(v, ltab, tid, 0);                // layers 9..12 (LAZY: signed words scaled by R^-(12 - expand_bits))
 #pragma unroll
         for (int k = 0; k < 16; k++) out[base + k * 256 + tid] = v[k];
     }
@@ -306,7 +335,7 @@ __global__ __launch_bounds__(256) void k_ntt_low12(PassParams p) {
 // Strided pass, index bits [L, L+RH) with RH in {8, 10}: tile = 2^RH rows x 16 consecutive words, one lane per
 // (row group, column), 16 rows per lane.  Inverse: first pass (reads the witness, DIF, post-twiddle).  Forward:
 // last pass (pre-twiddle, DIT, in place).
-template <int RH, bool INVERSE>
+template <int RH, bool INVERSE, bool LAZY = false>
 __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];     // [2^RH][16]
     const uint32_t tid = threadIdx.x, t = tid & 15, g = tid >> 4;
@@ -327,7 +356,9 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
     // table gathers are needed instead of 16: bitrev splits over the bit fields of m.
     uint32_t tw[16];
     if (RH == 10) {         // m = g*16 + i*4 + k: bitrev10(m) = br2(k)*256 + br2(i)*64 + br6(g);  slot = 4*i + k
-        const uint32_t w0 = root(lcol * (__brev(g) >> 26)), u1 = root(lcol * 64u), v1 = root(lcol * 256u);
+        uint32_t w0 = root(lcol * (__brev(g) >> 26));
+        if (LAZY) w0 = mul_mod(w0, p.lazy_comp);                // cancels the R^-layers of both lazy passes
+        const uint32_t u1 = root(lcol * 64u), v1 = root(lcol * 256u);
         const uint32_t u2 = mul_mod(u1, u1), u3 = mul_mod(u2, u1), v2 = mul_mod(v1, v1), v3 = mul_mod(v2, v1);
         const uint32_t wi[4] = {w0, mul_mod(w0, u2), mul_mod(w0, u1), mul_mod(w0, u3)};      // U^br2(i)
 #pragma unroll
@@ -335,7 +366,9 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
             tw[4 * i] = wi[i]; tw[4 * i + 1] = mul_mod(wi[i], v2); tw[4 * i + 2] = mul_mod(wi[i], v1); tw[4 * i + 3] = mul_mod(wi[i], v3);
         }
     } else {                // m = g*16 + k: bitrev8(m) = br4(k)*16 + br4(g);  slot = k
-        const uint32_t w0 = root(lcol * (__brev(g) >> 28)), q1 = root(lcol * 16u);
+        uint32_t w0 = root(lcol * (__brev(g) >> 28));
+        if (LAZY) w0 = mul_mod(w0, p.lazy_comp);
+        const uint32_t q1 = root(lcol * 16u);
         uint32_t qp[16];
         qp[0] = w0;
 #pragma unroll
@@ -379,23 +412,26 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
                 uint32_t u[4];
                 const uint32_t m0 = (g * 4 + i) * 4;
 #pragma unroll
-                for (int k = 0; k < 4; k++) u[k] = mul_mod(in[base + ((size_t)(m0 + k) << p.L)], tw[4 * i + k]);
-                radix_layers<2, false, true, 1>(u, ltab, 0, 0);
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t x = in[base + ((size_t)(m0 + k) << p.L)];
+                    u[k] = LAZY ? (uint32_t)smont((int32_t)x, (int32_t)tw[4 * i + k]) : mul_mod(x, tw[4 * i + k]);
+                }
+                radix_layers<2, false, true, 1, LAZY>(u, ltab, 0, 0);
 #pragma unroll
                 for (int k = 0; k < 4; k++) lds[(m0 + k) * 16 + t] = u[k];
             }
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < 16; k++) v[k] = lds[(hi * 64 + k * 4 + low) * 16 + t];
-            radix_layers<4, false, false, 3>(v, ltab, low, 0);
+            radix_layers<4, false, false, 3, LAZY>(v, ltab, low, 0);
 #pragma unroll
             for (int k = 0; k < 16; k++) lds[(hi * 64 + k * 4 + low) * 16 + t] = v[k];
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < 16; k++) v[k] = lds[(k * 64 + g) * 16 + t];
-            radix_layers<4, false, false, 7>(v, ltab, g, 0);
+            radix_layers<4, false, false, 7, LAZY>(v, ltab, g, 0);
 #pragma unroll
-            for (int k = 0; k < 16; k++) out[base + ((size_t)(k * 64 + g) << p.L)] = v[k];
+            for (int k = 0; k < 16; k++) out[base + ((size_t)(k * 64 + g) << p.L)] = LAZY ? canon((int32_t)v[k]) : v[k];
         }
     } else {   // RH == 8: 256 rows, g < 16
         if (INVERSE) {
@@ -416,16 +452,19 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = mul_mod(in[base + ((size_t)(g * 16 + k) << p.L)], tw[k]);
-            radix_layers<4, false, true, 1>(v, ltab, 0, 0);
+            for (int k = 0; k < 16; k++) {
+                const uint32_t x = in[base + ((size_t)(g * 16 + k) << p.L)];
+                v[k] = LAZY ? (uint32_t)smont((int32_t)x, (int32_t)tw[k]) : mul_mod(x, tw[k]);
+            }
+            radix_layers<4, false, true, 1, LAZY>(v, ltab, 0, 0);
 #pragma unroll
             for (int k = 0; k < 16; k++) lds[(g * 16 + k) * 16 + t] = v[k];
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < 16; k++) v[k] = lds[(k * 16 + g) * 16 + t];
-            radix_layers<4, false, false, 5>(v, ltab, g, 0);
+            radix_layers<4, false, false, 5, LAZY>(v, ltab, g, 0);
 #pragma unroll
-            for (int k = 0; k < 16; k++) out[base + ((size_t)(k * 16 + g) << p.L)] = v[k];
+            for (int k = 0; k < 16; k++) out[base + ((size_t)(k * 16 + g) << p.L)] = LAZY ? canon((int32_t)v[k]) : v[k];
         }
     }
 }
@@ -459,6 +498,11 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
     const size_t n = (size_t)1 << log_n;
     Fp ninv = fp_inv(fp_encode((uint32_t)(n % P)));
     const size_t npass = passes.size();
+    // forward transforms whose two passes are both register-radix kernels (2^20 and 2^22: what po2-18/20 seals
+    // expand into) run the lazy signed butterflies; the constant R^(layers run) rides on the four-step twiddle
+    static const bool no_lazy = getenv("ZKH_NTT_NO_LAZY") != nullptr;     // A/B switch for debugging
+    const bool lazy = !no_lazy && !inverse && npass == 2 && passes[0].R == 12 && (passes[1].R == 8 || passes[1].R == 10) && expand_bits <= 4;
+    const uint32_t lazy_comp = lazy ? fp_pow(Fp::raw(R2), 12 - expand_bits + passes[1].R).v : 0;
     for (size_t pi = 0; pi < npass; pi++) {
         // inverse: high bits first; forward: low bits first
         const Pass ps = inverse ? passes[npass - 1 - pi] : passes[pi];
@@ -476,8 +520,9 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
         p.twiddle = ps.L != 0;
         p.scale = (inverse && last) ? ninv.v : 0;
         p.zk_shift = (inverse && last && zk) ? 1 : 0;
+        p.lazy = lazy; p.lazy_comp = lazy_comp;
         p.tile_tw = inverse ? c->tab.tile_rev : c->tab.tile_fwd;
-        p.layer_tw = inverse ? c->tab.layer_rev : c->tab.layer_fwd;
+        p.layer_tw = inverse ? c->tab.layer_rev : (lazy ? c->tab.layer_fwd_plain : c->tab.layer_fwd);
         p.tw_lo = inverse ? c->tab.tw_rev_lo : c->tab.tw_fwd_lo;
         p.tw_hi = inverse ? c->tab.tw_rev_hi : c->tab.tw_fwd_hi;
         p.sh_lo = c->tab.shift_lo; p.sh_hi = c->tab.shift_hi;
@@ -493,18 +538,22 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
         const bool scale_here = p.scale != 0;
         if (ps.L == 0 && ps.R == 12 && p.expand_bits <= 4) {
             if (inverse) k_ntt_low12<true><<<grid, 256, 0, c->stream>>>(p);
+            else if (lazy) k_ntt_low12<false, true><<<grid, 256, 0, c->stream>>>(p);
             else k_ntt_low12<false><<<grid, 256, 0, c->stream>>>(p);
         } else if (ps.L >= 4 && p.log_t == 4 && ps.R == 10 && !(scale_here && p.zk_shift)) {
             static bool attr_set = false;
             if (!attr_set) {
                 (void)hipFuncSetAttribute((const void*)k_ntt_high<10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
                 (void)hipFuncSetAttribute((const void*)k_ntt_high<10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+                (void)hipFuncSetAttribute((const void*)k_ntt_high<10, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
                 attr_set = true;
             }
             if (inverse) k_ntt_high<10, true><<<grid, 1024, lds, c->stream>>>(p);
+            else if (lazy) k_ntt_high<10, false, true><<<grid, 1024, lds, c->stream>>>(p);
             else k_ntt_high<10, false><<<grid, 1024, lds, c->stream>>>(p);
         } else if (ps.L >= 4 && p.log_t == 4 && ps.R == 8 && !(scale_here && p.zk_shift)) {
             if (inverse) k_ntt_high<8, true><<<grid, 256, lds, c->stream>>>(p);
+            else if (lazy) k_ntt_high<8, false, true><<<grid, 256, lds, c->stream>>>(p);
             else k_ntt_high<8, false><<<grid, 256, lds, c->stream>>>(p);
         } else if (inverse) k_ntt_pass<true><<<grid, NTT_THREADS, lds, c->stream>>>(p);
         else k_ntt_pass<false><<<grid, NTT_THREADS, lds, c->stream>>>(p);
