@@ -19,6 +19,9 @@ OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
 SOURCES = ["hal.hip", "ntt.hip", "hash.hip", "poly.hip", "circuit.hip", "prover.hip", "verifier.hip", "eval_check_gen.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-unused-result"]
+# hash.hip: the unrolled Poseidon2 source order already interleaves 24 independent cells; LLVM's machine scheduler
+# re-interleaves it up to the register budget (128 VGPRs + scratch instead of 63) and measures 2 % slower on MI355X.
+EXTRA_FLAGS = {"hash.hip": ["-mllvm", "-enable-misched=0"]}
 
 
 def _deps_digest(src: str) -> str:
@@ -29,7 +32,7 @@ def _deps_digest(src: str) -> str:
     for f in files:
         with open(f, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + EXTRA_FLAGS.get(src, [])).encode())
     return h.hexdigest()
 
 
@@ -39,7 +42,7 @@ def _compile(src: str, force: bool) -> str:
     digest = _deps_digest(src)
     if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == digest:
         return obj
-    cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [HIPCC, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")

@@ -17,7 +17,8 @@ using namespace zkh;
 namespace {
 
 // Hal::hash_rows — one lane per leaf.
-// (2, 3 or 4 resident workgroups per CU measure the same 13.3 ms on the SYN-A data group: pure VALU issue)
+// (register budgets for 2, 3 or 4 workgroups per CU compile to the same speed; capping residency at 2 or 3 workgroups
+// with LDS padding is 5 % slower alone and 5 % slower with three seals in flight: no SMT-style gain from leaving room)
 __global__ __launch_bounds__(256, 4) void k_hash_rows(uint32_t* __restrict__ out, const uint32_t* __restrict__ matrix,
                                                    size_t rows, uint32_t cols, const uint32_t* __restrict__ rc,
                                                    const uint32_t* __restrict__ diag) {
