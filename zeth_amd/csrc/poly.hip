@@ -91,11 +91,21 @@ __global__ __launch_bounds__(TB) void k_eval_partial(uint32_t* __restrict__ part
     }
     const uint32_t* c = coeffs + (size_t)which[k] * po;
     const size_t j0 = (size_t)chunk * EV_CH + t;
+    // Fp x Fp4 multiply-accumulate, lazily: four products per 64-bit accumulator (4 P^2 < 2 P 2^32), then ONE reduction
+    // and one modular add per component instead of four of each.
     Fp4 acc = Fp4::zero();
-#pragma unroll 4
-    for (int i = 0; i < EV_PER; i++) {
-        const size_t j = j0 + (size_t)i * TB;
-        if (j < po) acc = acc + ld_ext((const uint32_t*)&xp[i]) * Fp::raw(c[j]);
+#pragma unroll 2
+    for (int i = 0; i < EV_PER; i += 4) {
+        uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const size_t j = j0 + (size_t)(i + u) * TB;
+            const uint64_t cj = j < po ? c[j] : 0u;
+            const uint4 pw = xp[i + u];
+            a0 += cj * pw.x; a1 += cj * pw.y; a2 += cj * pw.z; a3 += cj * pw.w;
+        }
+        acc.c[0] = Fp::raw(add_mod(acc.c[0].v, mont_reduce_wide(a0))); acc.c[1] = Fp::raw(add_mod(acc.c[1].v, mont_reduce_wide(a1)));
+        acc.c[2] = Fp::raw(add_mod(acc.c[2].v, mont_reduce_wide(a2))); acc.c[3] = Fp::raw(add_mod(acc.c[3].v, mont_reduce_wide(a3)));
     }
     acc = acc * ld_ext((const uint32_t*)&xt[t]);
     st_ext((uint32_t*)&red[t], acc);
@@ -137,18 +147,31 @@ __global__ __launch_bounds__(TB) void k_mix_poly_coeffs(uint32_t* __restrict__ o
                                                         uint32_t input_size, size_t count) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= count) return;
+    // lazy Fp x Fp4 multiply-accumulate: up to four products per 64-bit accumulator, one reduction per component
     Fp4 acc = Fp4::zero();
+    uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    uint32_t pending = 0;
+    auto fold = [&]() {
+        acc.c[0] = Fp::raw(add_mod(acc.c[0].v, mont_reduce_wide(a0))); acc.c[1] = Fp::raw(add_mod(acc.c[1].v, mont_reduce_wide(a1)));
+        acc.c[2] = Fp::raw(add_mod(acc.c[2].v, mont_reduce_wide(a2))); acc.c[3] = Fp::raw(add_mod(acc.c[3].v, mont_reduce_wide(a3)));
+        a0 = a1 = a2 = a3 = 0; pending = 0;
+    };
     uint32_t cur_combo = combos[0];
     for (uint32_t c = 0; c < input_size; c++) {
-        const uint32_t cb = combos[c];
+        const uint32_t cb = combos[c];                       // wave-uniform: every lane walks the same columns
         if (cb != cur_combo) {
+            fold();
             uint32_t* o = out + 4 * ((size_t)cur_combo * count + idx);
             st_ext(o, ld_ext(o) + acc);
             acc = Fp4::zero();
             cur_combo = cb;
         }
-        acc = acc + ld_ext(pw + 4 * c) * Fp::raw(in[(size_t)c * count + idx]);
+        const uint64_t v = in[(size_t)c * count + idx];
+        const uint4 m = *(const uint4*)(pw + 4 * c);
+        a0 += v * m.x; a1 += v * m.y; a2 += v * m.z; a3 += v * m.w;
+        if (++pending == 4) fold();
     }
+    fold();
     uint32_t* o = out + 4 * ((size_t)cur_combo * count + idx);
     st_ext(o, ld_ext(o) + acc);
 }
