@@ -88,13 +88,10 @@ __device__ __forceinline__ void wide_m_ext(uint32_t (&c)[4]) {
 #pragma unroll
     for (int k = 0; k < 4; k++) c[k] = add_mod(c[k], group_sum(c[k]));
 }
-constexpr int WIDE_LOG = 15;      // layers with <= 2^15 parents use the 8-lane kernel
-__global__ __launch_bounds__(256) void k_hash_fold_wide(uint32_t* __restrict__ io, size_t input_size, size_t output_size,
-                                                        const uint32_t* __restrict__ rc, const uint32_t* __restrict__ pc) {
-    __shared__ __attribute__((aligned(16))) uint32_t rcs[ROUNDS_TOTAL * CELLS + 8];
-    for (uint32_t w = threadIdx.x; w < ROUNDS_TOTAL * CELLS; w += blockDim.x) rcs[w] = rc[w];
-    __syncthreads();
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, j = gid & 7;
+// one 8-lane group folds one parent: io[out + parent] = H(io[in + 2 parent] || io[in + 2 parent + 1]); rcs = rc in LDS
+__device__ __forceinline__ void wide_fold_one(uint32_t* __restrict__ io, size_t input_size, size_t output_size, uint32_t gid,
+                                              const uint32_t* rcs, const uint32_t* __restrict__ pc) {
+    const uint32_t j = gid & 7;
     const bool owner = j < 6;                                   // lanes 6, 7 carry zeros
     size_t parent = gid >> 3;
     const bool live = parent < output_size;
@@ -132,6 +129,29 @@ __global__ __launch_bounds__(256) void k_hash_fold_wide(uint32_t* __restrict__ i
     for (int r = 0; r < HALF_FULL; r++, round++) full_round(round);
     if (live && j < 2) *(uint4*)(io + (output_size + parent) * 8 + 4 * j) = make_uint4(c[0], c[1], c[2], c[3]);
 }
+constexpr int WIDE_LOG = 15;      // layers with <= 2^15 parents use the 8-lane kernel
+constexpr int TAIL_LOG = 7;       // ... and the last 8 layers (<= 2^7 parents) are ONE launch of one 1024-lane workgroup
+__global__ __launch_bounds__(256) void k_hash_fold_wide(uint32_t* __restrict__ io, size_t input_size, size_t output_size,
+                                                        const uint32_t* __restrict__ rc, const uint32_t* __restrict__ pc) {
+    __shared__ __attribute__((aligned(16))) uint32_t rcs[ROUNDS_TOTAL * CELLS + 8];
+    for (uint32_t w = threadIdx.x; w < ROUNDS_TOTAL * CELLS; w += blockDim.x) rcs[w] = rc[w];
+    __syncthreads();
+    wide_fold_one(io, input_size, output_size, blockIdx.x * blockDim.x + threadIdx.x, rcs, pc);
+}
+// Tree top: parents = first_parents, first_parents / 2, ..., 1 inside one workgroup (each layer reads what the previous
+// one wrote: __syncthreads orders the global writes of a workgroup for its own later reads).
+__global__ __launch_bounds__(8 << TAIL_LOG) void k_hash_fold_tail(uint32_t* __restrict__ io, size_t first_parents,
+                                                                  const uint32_t* __restrict__ rc, const uint32_t* __restrict__ pc) {
+    __shared__ __attribute__((aligned(16))) uint32_t rcs[ROUNDS_TOTAL * CELLS + 8];
+    for (uint32_t w = threadIdx.x; w < ROUNDS_TOTAL * CELLS; w += blockDim.x) rcs[w] = rc[w];
+    __syncthreads();
+    for (size_t parents = first_parents; parents >= 1; parents >>= 1) {
+        if ((threadIdx.x >> 6) * 8 < parents)                    // wave-uniform: waves with no live group skip the layer
+            wide_fold_one(io, 2 * parents, parents, threadIdx.x, rcs, pc);
+        __threadfence_block();
+        __syncthreads();
+    }
+}
 
 }  // namespace
 
@@ -160,6 +180,11 @@ extern "C" const char* zkh_merkle_fold_all(zkh_ctx* c, zkh_buf* nodes, size_t ro
         const size_t parents = layer / 2;
         if (parents > ((size_t)1 << WIDE_LOG)) {
             ZKH_TRY(zkh_hash_fold(c, nodes, layer, parents));
+        } else if (parents <= ((size_t)1 << TAIL_LOG)) {
+            ProfScope prof(c, "hash_fold_tail", 96.0 * (2 * parents - 1));
+            k_hash_fold_tail<<<1, 8 << TAIL_LOG, 0, c->stream>>>(nodes->ptr(), parents, c->tab.rc, c->tab.diag);
+            ZKH_TRY(last_launch_error("hash_fold_tail"));
+            break;
         } else {
             ProfScope prof(c, "hash_fold_wide", 96.0 * parents);
             k_hash_fold_wide<<<(unsigned)((parents * 8 + 255) / 256), 256, 0, c->stream>>>(nodes->ptr(), layer, parents, c->tab.rc, c->tab.diag);
