@@ -129,14 +129,29 @@ __device__ __forceinline__ void wide_fold_one(uint32_t* __restrict__ io, size_t 
     for (int r = 0; r < HALF_FULL; r++, round++) full_round(round);
     if (live && j < 2) *(uint4*)(io + (output_size + parent) * 8 + 4 * j) = make_uint4(c[0], c[1], c[2], c[3]);
 }
-constexpr int WIDE_LOG = 15;      // layers with <= 2^15 parents use the 8-lane kernel
-constexpr int TAIL_LOG = 7;       // ... and the last 8 layers (<= 2^7 parents) are ONE launch of one 1024-lane workgroup
-__global__ __launch_bounds__(256) void k_hash_fold_wide(uint32_t* __restrict__ io, size_t input_size, size_t output_size,
-                                                        const uint32_t* __restrict__ rc, const uint32_t* __restrict__ pc) {
+constexpr int WIDE_LOG = 15;      // layers with <= 2^15 parents use the 8-lane permutation
+constexpr int TAIL_LOG = 7;       // a 1024-lane workgroup = 2^7 eight-lane groups; the last 8 layers (<= 2^7 parents) are one launch
+// Middle of the tree: workgroup b owns the 128 consecutive parents [128 b, 128 b + 128) of the layer with `first_parents`
+// parents and the `levels` - 1 layers above them (64, 32, ... parents of its own subtree), so the layers with
+// 2^15 .. 2^8 parents are ONE launch.  Each level still costs one 8-lane permutation of latency; what disappears is the
+// launch round trip between them.
+__global__ __launch_bounds__(8 << TAIL_LOG) void k_hash_fold_subtree(uint32_t* __restrict__ io, size_t first_parents, uint32_t levels,
+                                                                     const uint32_t* __restrict__ rc, const uint32_t* __restrict__ pc) {
     __shared__ __attribute__((aligned(16))) uint32_t rcs[ROUNDS_TOTAL * CELLS + 8];
     for (uint32_t w = threadIdx.x; w < ROUNDS_TOTAL * CELLS; w += blockDim.x) rcs[w] = rc[w];
     __syncthreads();
-    wide_fold_one(io, input_size, output_size, blockIdx.x * blockDim.x + threadIdx.x, rcs, pc);
+    for (uint32_t l = 0; l < levels; l++) {
+        const size_t parents = first_parents >> l;
+        const uint32_t local = (1u << TAIL_LOG) >> l;           // parents of this level inside the workgroup
+        if ((threadIdx.x >> 6) * 8 < local) {                   // wave-uniform
+            // lanes beyond `local` groups alias the last parent of the level (no write): live == false there
+            const uint32_t grp = threadIdx.x >> 3;
+            const uint32_t gid = grp < local ? (uint32_t)((blockIdx.x * local + grp) * 8 + (threadIdx.x & 7)) : 0xffffffffu;
+            wide_fold_one(io, 2 * parents, parents, gid, rcs, pc);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 // Tree top: parents = first_parents, first_parents / 2, ..., 1 inside one workgroup (each layer reads what the previous
 // one wrote: __syncthreads orders the global writes of a workgroup for its own later reads).
@@ -180,15 +195,19 @@ extern "C" const char* zkh_merkle_fold_all(zkh_ctx* c, zkh_buf* nodes, size_t ro
         const size_t parents = layer / 2;
         if (parents > ((size_t)1 << WIDE_LOG)) {
             ZKH_TRY(zkh_hash_fold(c, nodes, layer, parents));
-        } else if (parents <= ((size_t)1 << TAIL_LOG)) {
+        } else if (parents > ((size_t)1 << TAIL_LOG)) {
+            uint32_t levels = 0;
+            while ((parents >> levels) > ((size_t)1 << TAIL_LOG)) levels++;      // down to the layer with 2^(TAIL_LOG+1) parents
+            ProfScope prof(c, "hash_fold_wide", 96.0 * (2 * parents - (parents >> (levels - 1))));
+            k_hash_fold_subtree<<<(unsigned)(parents >> TAIL_LOG), 8 << TAIL_LOG, 0, c->stream>>>(nodes->ptr(), parents, levels, c->tab.rc,
+                                                                                                   c->tab.diag);
+            ZKH_TRY(last_launch_error("hash_fold_wide"));
+            layer >>= (levels - 1);                              // the loop's own /2 steps over the last fused level
+        } else {
             ProfScope prof(c, "hash_fold_tail", 96.0 * (2 * parents - 1));
             k_hash_fold_tail<<<1, 8 << TAIL_LOG, 0, c->stream>>>(nodes->ptr(), parents, c->tab.rc, c->tab.diag);
             ZKH_TRY(last_launch_error("hash_fold_tail"));
             break;
-        } else {
-            ProfScope prof(c, "hash_fold_wide", 96.0 * parents);
-            k_hash_fold_wide<<<(unsigned)((parents * 8 + 255) / 256), 256, 0, c->stream>>>(nodes->ptr(), layer, parents, c->tab.rc, c->tab.diag);
-            ZKH_TRY(last_launch_error("hash_fold_wide"));
         }
     }
     return nullptr;
