@@ -58,7 +58,7 @@ static void m_int(fp* c) {
     for (int i = 0; i < CELLS; i++) c[i] = fp_add(sum, fp_mul(g_diag[i], c[i]));
 }
 
-void zko_poseidon2_mix(uint32_t* c) {
+void zko_poseidon2_mix(uint32_t c[24]) {
     ensure_init();
     int round = 0;
     m_ext(c);
