@@ -57,6 +57,12 @@ const char* zkh_version(void);
 const char* zkh_ctx_create(int device_ordinal, const char* hash_suite, zkh_ctx** out);
 void zkh_ctx_destroy(zkh_ctx*);
 const char* zkh_sync(zkh_ctx*);
+/* Device memory of this context: bytes held by live buffers, bytes cached by the stream-ordered free list (blocks are
+ * recycled by exact size, so a host that proves many segment sizes accumulates cache), and the live high-water mark.
+ * zkh_ctx_trim drains the stream and returns the cached blocks to the driver; allocation does the same on its own
+ * before reporting out-of-memory. */
+void zkh_ctx_memory(const zkh_ctx*, size_t* live_bytes, size_t* cached_bytes, size_t* peak_live_bytes);
+const char* zkh_ctx_trim(zkh_ctx*);
 /* raw hipStream_t of the context (for callers that interleave their own work) */
 void* zkh_ctx_stream(zkh_ctx*);
 /* Replace the Poseidon2 tables (canonical residues): rc[24*29], diag[24] — consts.rs as data. */

@@ -190,3 +190,28 @@ def test_cpp_host_driver_seals_and_verifies(tmp_path):
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["verified"] == 4 and out["segments"] == 4 and out["seal_words_total"] > 4 * 1000
+
+
+def test_pool_accounting_and_trim(oracle):
+    """The free list recycles blocks by size: repeated seals of one shape do not grow memory, trim() returns the cache to
+    the driver, and the next seal is still byte-identical."""
+    from zeth_amd.hal import HipHal
+    from zeth_amd.circuits import syn_air
+    from zeth_amd.prover import Segment, SegmentProver
+    h = HipHal(0)
+    pr = SegmentProver(h, syn_air.syn_small())
+    seg = Segment(index=0, po2=13, seed=11)
+    code, data, out = pr.witgen(seg)
+    first = pr.seal(seg, code, data, out).seal
+    m1 = h.memory()
+    for _ in range(5):
+        assert np.array_equal(pr.seal(seg, code, data, out).seal, first)
+    m2 = h.memory()
+    assert m2["live"] == m1["live"] and m2["cached"] == m1["cached"] and m2["peak"] == m1["peak"]
+    assert m1["cached"] > 0 and m1["peak"] >= m1["live"] > 0
+    h.trim()
+    m3 = h.memory()
+    assert m3["cached"] == 0 and m3["live"] == m1["live"]
+    assert np.array_equal(pr.seal(seg, code, data, out).seal, first)
+    del pr, code, data
+    h.close()

@@ -158,6 +158,18 @@ extern "C" const char* zkh_ctx_create(int device, const char* suite, zkh_ctx** o
     *out = c;
     return nullptr;
 }
+extern "C" const char* zkh_ctx_trim(zkh_ctx* c) {
+    bind_thread(c);
+    ZKH_HIP(hipStreamSynchronize(c->stream));           // cached blocks may still be read by queued work
+    for (auto& kv : c->pool) (void)hipFree(kv.second);
+    c->pool.clear(); c->pool_bytes = 0;
+    return nullptr;
+}
+extern "C" void zkh_ctx_memory(const zkh_ctx* c, size_t* live, size_t* cached, size_t* peak) {
+    if (live) *live = c->live_bytes;
+    if (cached) *cached = c->pool_bytes;
+    if (peak) *peak = c->peak_bytes;
+}
 extern "C" void zkh_ctx_destroy(zkh_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);

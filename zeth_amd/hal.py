@@ -34,6 +34,8 @@ ABI = {
     "zkh_ctx_create": (_err, [_i, C.c_char_p, C.POINTER(_vp)]),
     "zkh_ctx_destroy": (None, [_vp]),
     "zkh_sync": (_err, [_vp]),
+    "zkh_ctx_memory": (None, [_vp, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
+    "zkh_ctx_trim": (_err, [_vp]),
     "zkh_ctx_stream": (_vp, [_vp]),
     "zkh_poseidon2_set_constants": (_err, [_vp, _u32p, _u32p]),
     "zkh_alloc": (_err, [_vp, C.c_char_p, _sz, _i, C.POINTER(_vp)]),
@@ -242,6 +244,16 @@ class HipHal:
     def __del__(self):
         # buffers hold a reference to the hal, so the context outlives them
         self.close()
+
+    def memory(self) -> dict:
+        """Bytes of device memory: held by live buffers, cached by the free list, live high-water mark."""
+        live, cached, peak = _sz(), _sz(), _sz()
+        _lib.zkh_ctx_memory(self.ctx, C.byref(live), C.byref(cached), C.byref(peak))
+        return {"live": live.value, "cached": cached.value, "peak": peak.value}
+
+    def trim(self) -> None:
+        """Drain the stream and hand the cached blocks back to the driver."""
+        _check(_lib.zkh_ctx_trim(self.ctx))
 
     def sync(self) -> None:
         _check(_lib.zkh_sync(self.ctx))
