@@ -8,7 +8,7 @@ the declared-synthetic stand-in for the un-obtainable rv32im circuit — DESIGN.
 list is partitioned round-robin (segment i -> rank i mod N, one process per GPU, no data-path collective), so
 per-GPU work is fixed as N grows: "scaling": "weak", value = N*K segments / max-over-ranks time.
 
-    python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus 1 --steps 30 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 """
@@ -61,8 +61,8 @@ def cpu_baseline(desc) -> dict:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30, help="timed seals per GPU (30 x ~32 ms: about a second of GPU time)")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed seals per lane before the clock starts (also ramps the clocks)")
     ap.add_argument("--po2", type=int, default=PO2)
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("ZKH_INFLIGHT", "3")),
                     help="segments sealed concurrently per GPU (one host thread + HIP stream each); 1 = strictly serial")
