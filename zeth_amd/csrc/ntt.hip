@@ -310,6 +310,11 @@ __global__ __launch_bounds__(256) void k_ntt_low12(PassParams p) {
                 const uint4 w = ((const uint4*)(in + pos0))[q];
                 v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
             }
+        } else if (p.expand_bits == 2) {
+            // 16 outputs of a lane replicate 4 consecutive inputs: one 16-byte load instead of 16 (4x redundant) dword loads
+            const uint4 w = *(const uint4*)(in + (pos0 >> 2));
+            v[0] = v[1] = v[2] = v[3] = w.x; v[4] = v[5] = v[6] = v[7] = w.y;
+            v[8] = v[9] = v[10] = v[11] = w.z; v[12] = v[13] = v[14] = v[15] = w.w;
         } else {
 #pragma unroll
             for (int k = 0; k < 16; k++) v[k] = in[(pos0 + k) >> p.expand_bits];
