@@ -225,6 +225,18 @@ def main() -> None:
                 m["calls"] += p["calls"]; m["total_ms"] += p["total_ms"]; m["alg_bytes"] += p["alg_bytes"]
             wk.hal.prof_enable(False)
         prof = list(merged.values())
+    # With several seals in flight the HIP-event brackets of one stream include time its kernels spent sharing the GPU
+    # with the other streams.  One more seal, alone on the GPU and outside the timed region, gives the unshared
+    # per-kernel durations next to them (and names the kernel that really dominates the work).
+    seal_times = [t for wk in workers for t in wk.seal_s]
+    ref = []
+    if prof and inflight > 1 and rank == 0:
+        w0 = workers[0]
+        w0.hal.prof_reset(); w0.hal.prof_enable(True)
+        w0.seal(args.warmup)
+        w0.hal.sync()
+        ref = w0.hal.prof_get()
+        w0.hal.prof_enable(False)
     last = next((wk.last for wk in workers if wk.last is not None), None)
 
     if rank == 0:
@@ -242,7 +254,7 @@ def main() -> None:
                        "seal_words": int(last.seal.size) if last is not None else 0},
             # wall-clock of one seal call (enqueue .. seal words on the host), mean over the timed seals of this rank;
             # with several seals in flight each one shares the GPU, so this is latency under load, not 1/value
-            "seal_wall_clock_s": sum(t for wk in workers for t in wk.seal_s) / max(1, sum(len(wk.seal_s) for wk in workers)),
+            "seal_wall_clock_s": sum(seal_times) / max(1, len(seal_times)),
             # reported separately: synthetic witness generation on the device, outside the timed region
             "witgen_ms_per_segment": 1e3 * min(t for wk in workers for t in wk.witgen_s[1:] or wk.witgen_s),
         }
@@ -251,8 +263,11 @@ def main() -> None:
                                  "unit": "GB/s", "frac": alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS}
         if prof:
             tot_ms = sum(p["total_ms"] for p in prof)
-            dom = max(prof, key=lambda p: p["total_ms"])
+            unshared = {p["name"]: p for p in (ref or prof)}
+            dom_name = max(unshared.values(), key=lambda p: p["total_ms"])["name"]
+            dom = next(p for p in prof if p["name"] == dom_name)
             per_launch_ms = dom["total_ms"] / dom["calls"]
+            per_launch_ms_unshared = unshared[dom_name]["total_ms"] / unshared[dom_name]["calls"]
             per_launch_bytes = dom["alg_bytes"] / dom["calls"]
             ach = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
             # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
@@ -267,12 +282,16 @@ def main() -> None:
                 traffic = None
             line["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "avg_launch_ms": per_launch_ms,
-                                "alg_bytes_per_launch": per_launch_bytes, "share_of_kernel_time": dom["total_ms"] / tot_ms,
+                                "avg_launch_ms_unshared": per_launch_ms_unshared,
+                                "achieved_unshared": per_launch_bytes / (per_launch_ms_unshared * 1e-3) / 1e9,
+                                "alg_bytes_per_launch": per_launch_bytes,
+                                "share_of_kernel_time": unshared[dom_name]["total_ms"] / sum(p["total_ms"] for p in unshared.values()),
                                 "launches_overlap": inflight > 1,
                                 "note": "dominant kernel is integer-VALU-bound by construction (Poseidon2: ~21 Montgomery "
                                         "products per absorbed byte); HBM fraction is reported as the contract asks; with "
-                                        "inflight_per_gpu > 1 kernels of different seals overlap, so per-launch durations include "
-                                        "time shared with other streams"}
+                                        "inflight_per_gpu > 1 kernels of different seals overlap, so avg_launch_ms (timed region) "
+                                        "includes time shared with other streams; *_unshared comes from one extra seal run "
+                                        "alone after the timed region"}
             if dom["name"] == "hash_rows":
                 # VALU view of the same kernel: permutations per launch x modelled issue cycles per 64-lane permutation
                 # (8 full rounds x 2368 + 7 partial groups x 1576 + 1024 + 138 cycles) against 1024 SIMDs at 2.4 GHz
@@ -282,13 +301,15 @@ def main() -> None:
                     perms += 4 * (4 * deg // 16)
                     deg //= 16
                 cyc = 8 * 2368 + 7 * 1576 + 1024 + 138
-                per_seal_ms = dom["total_ms"] / args.steps
+                per_seal_ms = unshared[dom_name]["total_ms"] / (1 if ref else args.steps)
                 line["roofline"]["valu"] = {"permutations_per_seal": perms, "model_cycles_per_wave_permutation": cyc,
                                             "issue_utilisation_at_2p4GHz": (perms / 64.0) * cyc / (1024 * 2.4e9 * per_seal_ms * 1e-3)}
-            line["kernels"] = [{"name": p["name"], "calls_per_seal": p["calls"] / args.steps,
-                                "ms_per_seal": p["total_ms"] / args.steps,
+            div = 1 if ref else args.steps
+            line["kernels"] = [{"name": p["name"], "calls_per_seal": p["calls"] / div,
+                                "ms_per_seal": p["total_ms"] / div,          # unshared (one seal alone on the GPU)
+                                "ms_per_seal_timed_region": next((q["total_ms"] / args.steps for q in prof if q["name"] == p["name"]), None),
                                 "alg_GBps": (p["alg_bytes"] / (p["total_ms"] * 1e-3) / 1e9) if p["total_ms"] > 0 else 0.0}
-                               for p in sorted(prof, key=lambda p: -p["total_ms"])]
+                               for p in sorted(unshared.values(), key=lambda p: -p["total_ms"])]
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(desc)
