@@ -1,6 +1,10 @@
 import os
 import sys
 
+# The oracle's OpenMP loops are sized for a handful of cores; on a 128-core GPU host the fork/join cost of tiny
+# parallel regions dominates the small test shapes (minutes instead of seconds).  Must be set before libgomp starts.
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+
 import numpy as np
 import pytest
 

@@ -229,3 +229,18 @@ def test_join_tree_to_one_succinct_receipt(hal):
     rec.joins[1][0].seal[100] ^= 1
     with pytest.raises(Exception):
         rec.verify(leaf_desc, join_desc)
+
+
+def test_wide_circuit_seal_bit_exact(hal, oracle, tmp_path, monkeypatch):
+    """A circuit four times wider than SYN-A (W_code 16, W_data 800, W_accum 64: 945 taps, 2615 steps) goes through the
+    same path end to end — eval_check compiled at load time — and its seal equals the oracle prover's byte for byte."""
+    monkeypatch.setenv("ZKH_JIT_CACHE", str(tmp_path))
+    desc = syn_air.build_syn_air(16, 800, 64)
+    prover = SegmentProver(hal, desc)
+    assert prover.circuit.kernel_kind() == "attached"
+    seg = Segment(index=0, po2=11, seed=0x5EED0000 + 99, noise_seed=0x2E80, zk_cycles=700)
+    receipt = prover.prove_segment(seg)
+    oc = zko.OracleCircuit(oracle, desc)
+    want = oc.prove(11, 700, seg.seed, seg.noise_seed)
+    assert np.array_equal(receipt.seal, want)
+    receipt.verify(desc)
