@@ -48,12 +48,25 @@ def cpu_baseline(desc) -> dict:
     import zko                                     # test infrastructure; used here ONLY as the reported CPU baseline
     lib = zko.load()
     oc = zko.OracleCircuit(lib, desc)
+    # the oracle's OpenMP loops stop scaling long before a two-socket host is full (fork/join + memory bound): scan a
+    # few thread counts on a small segment and quote the baseline at the fastest one
+    avail = int(lib.zko_num_threads())
+    best, best_dt = avail, None
+    for t in sorted({c for c in (8, 16, 32, 64, avail) if c <= avail}):
+        lib.zko_set_num_threads(t)
+        t0 = time.perf_counter()
+        oc.prove(CPU_SAMPLE_PO2 - 2, 1994, 0x5EED0000, 0x2E80)
+        d = time.perf_counter() - t0
+        if best_dt is None or d < best_dt:
+            best, best_dt = t, d
+    lib.zko_set_num_threads(best)
     t0 = time.perf_counter()
     seal = oc.prove(CPU_SAMPLE_PO2, 1994, 0x5EED0000, 0x2E80)
     dt = time.perf_counter() - t0
     scale = 1 << (PO2 - CPU_SAMPLE_PO2)
-    return {"value": 1.0 / (dt * scale), "unit": "segments/s", "cores": int(lib.zko_num_threads()), "kind": "port",
-            "sample": f"one SYN-A segment seal at po2={CPU_SAMPLE_PO2} ({dt:.2f} s wall, OpenMP oracle incl. witgen), "
+    return {"value": 1.0 / (dt * scale), "unit": "segments/s", "cores": best, "cores_available": avail, "kind": "port",
+            "sample": f"one SYN-A segment seal at po2={CPU_SAMPLE_PO2} ({dt:.2f} s wall, OpenMP oracle incl. witgen, at the fastest of "
+                      f"8/16/32/64/{avail} threads = {best}), "
                       f"scaled x1/{scale} to the po2={PO2} unit (work is ~linear in n)",
             "seal_words": int(seal.size)}
 

@@ -242,6 +242,8 @@ void zko_poly_interpolate(uint32_t* out, const uint32_t* xs, const uint32_t* fx,
 #ifdef _OPENMP
 #include <omp.h>
 int zko_num_threads(void) { return omp_get_max_threads(); }
+void zko_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 #else
 int zko_num_threads(void) { return 1; }
+void zko_set_num_threads(int n) { (void)n; }
 #endif

@@ -119,6 +119,7 @@ uint32_t* zko_prove_segment(const zko_circuit*, unsigned po2, unsigned zk_cycles
 const char* zko_verify_segment(const zko_circuit*, const uint32_t* seal, size_t seal_words);
 void zko_free(void*);
 int zko_num_threads(void);   /* OpenMP threads the oracle will use */
+void zko_set_num_threads(int n);   /* the loops stop scaling well before a 2-socket host is full: let the caller pick */
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,7 @@ def load():
         "zko_verify_segment": (C.c_char_p, [vp, u32p, sz]),
         "zko_free": (None, [vp]),
         "zko_num_threads": (C.c_int, []),
+        "zko_set_num_threads": (None, [C.c_int]),
     }
     for name, (res, args) in sig.items():
         f = getattr(lib, name)
