@@ -21,14 +21,16 @@ ZKH_HD uint32_t sbox7_rc(uint32_t x, uint32_t rcs) {
     const int32_t x2 = smont(sx, sx), x3 = smont(x2, sx), x4 = smont(x2, x2);
     return canon(smont(x3, x4));
 }
-// 2x mod P as x + x (v_add_u32 is full rate on gfx950, v_lshlrev_b32 is not); the empty asm keeps hipcc from
-// canonicalising the add back into a shift.
+// 2x mod P as x + x: v_add_u32 is full rate on gfx950 and v_lshlrev_b32 is not, but hipcc canonicalises x + x into
+// the shift, and hiding x behind an empty asm costs a register copy (36 v_mov per round) — so the add is spelled out.
 ZKH_HD uint32_t dbl_mod(uint32_t x) {
-    uint32_t y = x;
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm("" : "+v"(y));
+    uint32_t d;
+    asm("v_add_u32_e32 %0, %1, %1" : "=v"(d) : "v"(x));
+    return reduce_once(d);
+#else
+    return reduce_once(x + x);
 #endif
-    return reduce_once(x + y);
 }
 // 4x4 block [[5,7,1,3],[4,6,1,1],[1,3,5,7],[1,1,4,6]] with 8 additions (Poseidon2 paper, appendix B)
 ZKH_HD void m4(uint32_t& x0, uint32_t& x1, uint32_t& x2, uint32_t& x3) {
