@@ -104,11 +104,22 @@ def main() -> None:
                 torch.cuda.set_device(local_rank)
             except (RuntimeError, AssertionError):
                 backend = "gloo"
-        dist.init_process_group(backend)
         ctrl_dev = "cpu" if "gloo" in backend else f"cuda:{local_rank}"
 
         def barrier():
             dist.all_reduce(torch.zeros(1, device=ctrl_dev))
+
+        # gloo announces its connections on stdout; keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend)
+            barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     from zeth_amd.circuits import syn_air
     from zeth_amd.circuits.desc import Circuit
