@@ -125,3 +125,24 @@ def test_fuzz_scans_and_fold(hal, oracle, seed):
     outf = hal.alloc_elem("o", 4 * count)
     hal.fri_fold(outf, hal.copy_from("i", inp), mixv)
     eq(outf.to_vec(), wantf)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_whole_seals(hal, oracle, seed, tmp_path, monkeypatch):
+    """Random circuit widths, segment sizes and padding lengths: the HIP prover's seal equals the oracle prover's byte
+    for byte (eval_check compiled at load time for each shape), and the host verifier accepts it."""
+    import zko
+    from zeth_amd.circuits import syn_air
+    from zeth_amd.prover import Segment, SegmentProver
+    monkeypatch.setenv("ZKH_JIT_CACHE", str(tmp_path))
+    rng = np.random.default_rng(5000 + seed)
+    wc, wd, wa = int(rng.integers(5, 20)), int(rng.integers(8, 120)), 4 * int(rng.integers(1, 6))
+    po2 = int(rng.integers(9, 14))
+    zk = int(rng.integers(50, min(1994, (1 << po2) - 64)))
+    desc = syn_air.build_syn_air(wc, wd, wa)
+    prover = SegmentProver(hal, desc)
+    seg = Segment(index=seed, po2=po2, seed=int(rng.integers(1, 1 << 40)), noise_seed=int(rng.integers(1, 1 << 40)), zk_cycles=zk)
+    receipt = prover.prove_segment(seg)
+    want = zko.OracleCircuit(oracle, desc).prove(po2, zk, seg.seed, seg.noise_seed)
+    assert np.array_equal(receipt.seal, want), f"shape ({wc},{wd},{wa}) po2 {po2} zk {zk}"
+    receipt.verify(desc)
