@@ -253,6 +253,7 @@ def main() -> None:
     # with the other streams.  One more seal, alone on the GPU and outside the timed region, gives the unshared
     # per-kernel durations next to them (and names the kernel that really dominates the work).
     seal_times = [t for wk in workers for t in wk.seal_s]
+    unloaded_seal_s = None
     ref = []
     if prof and inflight > 1 and rank == 0:
         w0 = workers[0]
@@ -261,6 +262,7 @@ def main() -> None:
         w0.hal.sync()
         ref = w0.hal.prof_get()
         w0.hal.prof_enable(False)
+        unloaded_seal_s = w0.seal_s[-1]              # one seal alone on the GPU: the single-segment latency
     last = next((wk.last for wk in workers if wk.last is not None), None)
 
     if rank == 0:
@@ -279,6 +281,8 @@ def main() -> None:
             # wall-clock of one seal call (enqueue .. seal words on the host), mean over the timed seals of this rank;
             # with several seals in flight each one shares the GPU, so this is latency under load, not 1/value
             "seal_wall_clock_s": sum(seal_times) / max(1, len(seal_times)),
+            # ... and of one seal with the GPU to itself (inflight 1: the same thing as seal_wall_clock_s)
+            "seal_wall_clock_unloaded_s": unloaded_seal_s if unloaded_seal_s is not None else sum(seal_times) / max(1, len(seal_times)),
             # reported separately: synthetic witness generation on the device, outside the timed region
             "witgen_ms_per_segment": 1e3 * min(t for wk in workers for t in wk.witgen_s[1:] or wk.witgen_s),
         }
