@@ -480,18 +480,21 @@ struct Pass { uint32_t L, R; };
 std::vector<Pass> plan_passes(uint32_t log_n) {
     std::vector<Pass> v;
     if (log_n <= 12) { v.push_back({0, log_n}); return v; }
-    if (log_n <= 22) {
-        // >= 2^18: a full 4096-word contiguous low pass + a 2^6..2^10-row strided pass (register-radix kernels)
-        uint32_t low = log_n >= 18 ? 12 : (log_n + 1) / 2;
-        if (log_n - low > 10) low = log_n - 10;
+    if (log_n < 18) {                       // two balanced LDS passes
+        const uint32_t low = (log_n + 1) / 2;
         v.push_back({0, low});
         v.push_back({low, log_n - low});
         return v;
     }
-    const uint32_t rem = log_n - 12, r1 = (rem + 1) / 2;
+    // >= 2^18: the contiguous 4096-word register-radix pass, then strided passes.  2^8 and 2^10 rows have
+    // register-radix kernels; what is left over (1..3 bits at 2^21, 2^23, 2^24) goes to a last light pass of the
+    // generic kernel over wide tiles instead of a 9..12-layer LDS sweep (2^21: 0.94 ms vs 1.40 for 64 columns).
+    const uint32_t rem = log_n - 12;
     v.push_back({0, 12});
-    v.push_back({12, r1});
-    v.push_back({12 + r1, rem - r1});
+    if (rem == 8 || rem == 10 || rem <= 7) v.push_back({12, rem});
+    else if (rem == 9) { v.push_back({12, 8}); v.push_back({20, 1}); }
+    else if (rem == 11) { v.push_back({12, 8}); v.push_back({20, 3}); }
+    else { v.push_back({12, 10}); v.push_back({22, rem - 10}); }
     return v;
 }
 
@@ -517,7 +520,11 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
         p.in_col_stride = first ? in_col_stride : out_col_stride;
         p.out = out; p.out_col_stride = out_col_stride;
         p.log_n = log_n; p.L = ps.L; p.R = ps.R;
+        // tile width: 16 words for the register-radix strided kernels; the generic kernel takes as wide a run as a
+        // 4096-element tile allows (a 1..3-bit top pass then moves 2..8 KiB contiguous runs)
+        const bool reg_high = ps.L >= 4 && (ps.R == 8 || ps.R == 10);
         p.log_t = ps.L == 0 ? 0 : (ps.L < 4 ? ps.L : 4);
+        if (!reg_high && ps.L > 4 && ps.R < 8) p.log_t = ps.L < 12 - ps.R ? ps.L : 12 - ps.R;
         // keep the tile <= 64 KiB
         while (p.R + p.log_t > 14 && p.log_t > 0) p.log_t--;
         p.expand_bits = (!inverse && first) ? expand_bits : 0;
