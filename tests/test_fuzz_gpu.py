@@ -146,3 +146,17 @@ def test_fuzz_whole_seals(hal, oracle, seed, tmp_path, monkeypatch):
     want = zko.OracleCircuit(oracle, desc).prove(po2, zk, seg.seed, seg.noise_seed)
     assert np.array_equal(receipt.seal, want), f"shape ({wc},{wd},{wa}) po2 {po2} zk {zk}"
     receipt.verify(desc)
+
+
+@pytest.mark.parametrize("po2,zk", [(7, 40), (8, 60), (8, 200)])
+def test_smallest_segments(hal, oracle, po2, zk):
+    """Below FRI_MIN_DEGREE * 2 there is no FRI folding round at all (the final coefficients are sent directly)."""
+    import zko
+    from zeth_amd.circuits import syn_air
+    from zeth_amd.prover import Segment, SegmentProver
+    desc = syn_air.syn_tiny()
+    seg = Segment(index=0, po2=po2, seed=3, noise_seed=4, zk_cycles=zk)
+    receipt = SegmentProver(hal, desc).prove_segment(seg)
+    want = zko.OracleCircuit(oracle, desc).prove(po2, zk, 3, 4)
+    assert np.array_equal(receipt.seal, want)
+    receipt.verify(desc)
