@@ -17,6 +17,11 @@ P = 2013265921
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built artefacts: build them once (hipcc cross-compiles gfx950 without a GPU)
+    from zeth_amd import build as _build
+    if not os.path.exists(_build.LIB) or not os.path.exists(os.path.join(ROOT, "oracle", "libzkoracle.so")):
+        _build.build()
+        _build.build_oracle()
 
 
 @pytest.fixture(scope="session")
