@@ -6,7 +6,7 @@
 // exchange between devices), and every seal is then checked by the host verifier, the analogue of
 // `receipt.verify(image_id)` at /root/reference/crates/host/src/bin/cli.rs:103.
 //
-//   seal_segments --desc syn_a.desc [--po2 20] [--segments 8] [--devices 1] [--inflight 3] [--no-verify]
+//   seal_segments --desc syn_a.desc [--po2 20] [--segments 8] [--devices 1] [--inflight 3] [--no-verify] [--noise-seed N]
 //
 // The circuit description blob is what zeth_amd/circuits/desc.py serialises (`python -m zeth_amd.circuits.syn_air syn_a syn_a.desc`).
 // Witnesses are the declared-synthetic SYN-AIR traces generated on the device (zkh_syn_witgen); with the real rv32im
@@ -22,6 +22,8 @@
 #include <thread>
 #include <vector>
 
+#include <sys/random.h>
+
 #include "zkhal.h"
 
 namespace {
@@ -30,7 +32,16 @@ struct Options {
     std::string desc_path;
     size_t po2 = 20, segments = 8, devices = 1, inflight = 3;
     bool verify = true;
+    bool fixed_noise = false;        // --noise-seed: reproducible seals (tests); default: fresh OS randomness per segment
+    uint64_t noise_seed = 0;
 };
+
+// The zero-knowledge blinding rows must be unpredictable: upstream fills them from an OS RNG.
+uint64_t fresh_noise_seed() {
+    uint64_t v = 0;
+    if (getrandom(&v, sizeof v, 0) != (ssize_t)sizeof v) { perror("getrandom"); abort(); }
+    return v;
+}
 
 struct Receipt {
     std::vector<uint32_t> seal;
@@ -56,6 +67,10 @@ double now_s() {
 }
 
 // One lane = one context (device + stream) + circuit + prover; lanes of all devices pull from one work index.
+std::mutex g_root_lock;
+bool g_have_root = false;
+uint32_t g_control_root[8];
+
 void lane(int device, const std::vector<uint32_t>& desc, const Options& opt, std::atomic<size_t>& next,
           std::vector<Receipt>& receipts) {
     zkh_ctx* ctx = nullptr;
@@ -70,17 +85,27 @@ void lane(int device, const std::vector<uint32_t>& desc, const Options& opt, std
         const size_t w_code = desc[4], w_data = desc[5];          // header: magic, version, 3, W_accum, W_code, W_data
         if (failed(zkh_alloc(ctx, "code", w_code * n, 0, &code), "zkh_alloc(code)")) break;
         if (failed(zkh_alloc(ctx, "data", w_data * n, 0, &data), "zkh_alloc(data)")) break;
+        {   // the control root of (circuit, po2): computed once per session, checked by the verifier for every seal
+            std::lock_guard<std::mutex> lk(g_root_lock);
+            if (!g_have_root) {
+                if (failed(zkh_syn_control_root(prover, opt.po2, ZKH_ZK_CYCLES, g_control_root), "zkh_syn_control_root")) break;
+                g_have_root = true;
+            }
+        }
+        const size_t out_size = desc[7];
+        std::vector<uint32_t> out_global(out_size), pub(out_size > 4 ? out_size - 4 : 0, 0u);
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= opt.segments) break;
-            uint32_t out_global[4];
-            if (failed(zkh_syn_witgen(ctx, circuit, opt.po2, ZKH_ZK_CYCLES, 0x5EED0000ull + i, 0x2E80, code, data, out_global),
+            const uint64_t noise = opt.fixed_noise ? opt.noise_seed : fresh_noise_seed();
+            if (failed(zkh_syn_witgen(ctx, circuit, opt.po2, ZKH_ZK_CYCLES, 0x5EED0000ull + i, noise, pub.empty() ? nullptr : pub.data(),
+                                      code, data, out_global.data()),
                        "zkh_syn_witgen"))
                 break;
             uint32_t* seal = nullptr;
             size_t words = 0;
             const double t0 = now_s();
-            if (failed(zkh_prove_segment(prover, opt.po2, ZKH_ZK_CYCLES, 0x2E80, code, data, out_global, &seal, &words),
+            if (failed(zkh_prove_segment(prover, opt.po2, ZKH_ZK_CYCLES, noise, code, data, out_global.data(), &seal, &words),
                        "zkh_prove_segment"))
                 break;
             receipts[i].seal_s = now_s() - t0;
@@ -106,6 +131,7 @@ bool parse(int argc, char** argv, Options& o) {
         else if (a == "--devices") val(o.devices);
         else if (a == "--inflight") val(o.inflight);
         else if (a == "--no-verify") o.verify = false;
+        else if (a == "--noise-seed" && i + 1 < argc) { o.noise_seed = strtoull(argv[++i], nullptr, 0); o.fixed_noise = true; }
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return false; }
     }
     return !o.desc_path.empty() && o.devices >= 1 && o.inflight >= 1 && o.segments >= 1;
@@ -116,7 +142,7 @@ bool parse(int argc, char** argv, Options& o) {
 int main(int argc, char** argv) {
     Options opt;
     if (!parse(argc, argv, opt)) {
-        fprintf(stderr, "usage: %s --desc FILE [--po2 N] [--segments S] [--devices G] [--inflight K] [--no-verify]\n", argv[0]);
+        fprintf(stderr, "usage: %s --desc FILE [--po2 N] [--segments S] [--devices G] [--inflight K] [--no-verify] [--noise-seed N]\n", argv[0]);
         return 2;
     }
     FILE* f = fopen(opt.desc_path.c_str(), "rb");
@@ -147,7 +173,7 @@ int main(int argc, char** argv) {
             return 1;
         }
         for (size_t i = 0; i < receipts.size(); i++) {
-            const char* err = zkh_verify_segment(host_circuit, receipts[i].seal.data(), receipts[i].seal.size(), nullptr, nullptr);
+            const char* err = zkh_verify_segment(host_circuit, receipts[i].seal.data(), receipts[i].seal.size(), g_control_root, nullptr, nullptr);
             if (err) { fprintf(stderr, "segment %zu: seal REJECTED: %s\n", i, err); zkh_free_error(err); return 1; }
             verified++;
         }

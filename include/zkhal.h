@@ -49,7 +49,8 @@ typedef struct zkh_prover zkh_prover;
 #define ZKH_DIGEST_WORDS 8
 
 void zkh_free_error(const char* err);
-/* library/ABI version and the gfx arch the kernels were compiled for ("gfx950") */
+/* library/ABI version, the gfx arch the kernels were compiled for ("gfx950"), and whether the shipped Poseidon2 tables
+ * are the upstream ones or the declared placeholder ("poseidon2_consts=placeholder": digests cannot match upstream's) */
 const char* zkh_version(void);
 
 /* ---- context: CudaHal::new / HalPair (hal/cuda.rs) ---- */
@@ -82,6 +83,13 @@ void* zkh_device_ptr(const zkh_buf*);
 const char* zkh_read(zkh_ctx*, const zkh_buf*, uint32_t* host, size_t off_words, size_t n_words);
 /* view_mut()/copy: H2D ordered on the stream */
 const char* zkh_write(zkh_ctx*, zkh_buf*, const uint32_t* host, size_t off_words, size_t n_words);
+/* Witness ingress for hosts that run preflight + witgen on the CPU (upstream: SegmentProver steps 1-2 before
+ * Prover::commit_group; 0.94 GB of code + data per po2-20 SYN-A segment): pinned host memory the caller fills in place,
+ * and an upload that is only ENQUEUED on the context's stream (no host sync; the block must not be rewritten before the
+ * next zkh_sync / zkh_read of this context).  The DMA overlaps kernels of other contexts on the same GPU. */
+const char* zkh_host_alloc(zkh_ctx*, size_t n_words, uint32_t** host);
+void zkh_host_free(zkh_ctx*, uint32_t* host);
+const char* zkh_write_async(zkh_ctx*, zkh_buf*, const uint32_t* pinned_host, size_t off_words, size_t n_words);
 
 /* ---- trait Hal ops (hal/mod.rs); semantics = CpuHal (hal/cpu.rs) ---- */
 /* Hal::batch_interpolate_ntt(io, count): per column inverse NTT, natural in -> bit-reversed coeffs, * n^-1 */
@@ -160,32 +168,60 @@ int zkh_circuit_has_compiled_kernel(const zkh_circuit*);
  * Not thread-safe against a concurrent zkh_eval_check on the same circuit. */
 const char* zkh_circuit_attach_code_object(zkh_circuit*, const void* image, size_t len, const char* kernel_name);
 /* CircuitHal::eval_check(check, groups, globals, poly_mix, po2, steps).  groups = evaluated accum, code, data
- * (each W x 4n); globals = out, mix.  use_interpreter != 0 forces the generic interpreter kernel. */
-const char* zkh_eval_check(zkh_ctx*, const zkh_circuit*, zkh_buf* check, const zkh_buf* const* groups,
-                           const zkh_buf* const* globals, const uint32_t poly_mix[4], size_t po2,
-                           int use_interpreter);
+ * (each W x 4n; n_groups must be 3); globals = out, mix (n_globals must be 2); steps = 2^po2 like upstream.
+ * use_interpreter != 0 forces the generic interpreter kernel. */
+const char* zkh_eval_check(zkh_ctx*, const zkh_circuit*, zkh_buf* check, const zkh_buf* const* groups, size_t n_groups,
+                           const zkh_buf* const* globals, size_t n_globals, const uint32_t poly_mix[4], size_t po2,
+                           size_t steps, int use_interpreter);
 
 /* ---- SYN-AIR witness generation on device (stands in for risc0-circuit-rv32im witgen) ---- */
+/* code group only: a function of (circuit, po2, zk_cycles) — what the control root commits to */
+const char* zkh_syn_code(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cycles, zkh_buf* code);
+/* pub: OUTPUT_SIZE - 4 public input words (Montgomery; NULL if the circuit has none); out_global: OUTPUT_SIZE words */
 const char* zkh_syn_witgen(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cycles, uint64_t seed,
-                           uint64_t noise_seed, zkh_buf* code, zkh_buf* data, uint32_t out_global[4]);
+                           uint64_t noise_seed, const uint32_t* pub, zkh_buf* code, zkh_buf* data, uint32_t* out_global);
 const char* zkh_syn_accum(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cycles, uint64_t noise_seed,
                           const zkh_buf* data, const uint32_t* mix_global, zkh_buf* accum);
 
 /* ---- segment prover: SegmentProver::prove_segment + risc0_zkp::prove::Prover ---- */
 const char* zkh_prover_create(zkh_ctx*, const zkh_circuit*, zkh_prover** out);
 void zkh_prover_destroy(zkh_prover*);
-/* Seal one segment whose code/data traces are already resident in HBM (W x 2^po2 each).  On success *seal is
- * a malloc'd word array (release with zkh_free_seal). */
+/* Seal one segment of a SYN-AIR-family circuit (kind 1: the accum witness generator is zkh_syn_accum) whose code/data
+ * traces are already resident in HBM (W x 2^po2 each); out_global has OUTPUT_SIZE words.  On success *seal is a
+ * malloc'd word array (release with zkh_free_seal). */
 const char* zkh_prove_segment(zkh_prover*, size_t po2, size_t zk_cycles, uint64_t noise_seed, const zkh_buf* code,
-                              const zkh_buf* data, const uint32_t out_global[4], uint32_t** seal,
+                              const zkh_buf* data, const uint32_t* out_global, uint32_t** seal,
                               size_t* seal_words);
 void zkh_free_seal(uint32_t* seal);
+/* The same seal in the two halves upstream's SegmentProver drives `Prover` in, for ANY circuit and for traces the caller
+ * produced itself (uploaded with zkh_copy_from / zkh_write_async):
+ *   zkh_prove_begin : header, Prover::commit_group(code), commit_group(data); returns the accum mix challenges
+ *                     (global_size[mix] words into mix_global, may be NULL) drawn from the transcript;
+ *   (caller)        : fills the accum trace (W_accum x 2^po2) from data + mix — CircuitHal::accumulate, circuit-specific;
+ *   zkh_prove_finish: commit_group(accum) + Prover::finalize (eval_check, DEEP, FRI, queries).  Consumes the job whether
+ *                     or not it succeeds; zkh_prove_abort drops a job that will not be finished. */
+typedef struct zkh_seal_job zkh_seal_job;
+const char* zkh_prove_begin(zkh_prover*, size_t po2, const zkh_buf* code, const zkh_buf* data, const uint32_t* out_global,
+                            zkh_seal_job** job, uint32_t* mix_global);
+const char* zkh_prove_finish(zkh_seal_job*, const zkh_buf* accum, uint32_t** seal, size_t* seal_words);
+void zkh_prove_abort(zkh_seal_job*);
+/* Control root = Merkle root of the committed code group (the control-ID analogue: risc0-zkp verify/mod.rs check_code).
+ * zkh_code_root commits a caller-supplied code trace; zkh_syn_control_root generates SYN-AIR's for (po2, zk_cycles). */
+const char* zkh_code_root(zkh_prover*, const zkh_buf* code, size_t po2, uint32_t root[8]);
+const char* zkh_syn_control_root(zkh_prover*, size_t po2, size_t zk_cycles, uint32_t root[8]);
 
 /* ---- verifier: risc0_zkp::verify::verify — what `receipt.verify(image_id)` (cli.rs:103) runs per segment ----
  * Pure host code, no GPU needed: the circuit may be loaded with ctx == NULL (zkh_circuit_load(NULL, ...)).
- * rc / diag: canonical Poseidon2 tables (24*29 / 24 words) or NULL for the shipped ones.  NULL = seal accepted. */
-const char* zkh_verify_segment(const zkh_circuit*, const uint32_t* seal, size_t seal_words, const uint32_t* rc,
-                               const uint32_t* diag);
+ * control_root: the expected code commitment for (circuit, po2) — REQUIRED (check_code: a seal whose code group is
+ * anything else, e.g. all-zero selectors, is rejected).  rc / diag: canonical Poseidon2 tables (24*29 / 24 words) or
+ * NULL for the shipped ones.  NULL = seal accepted. */
+const char* zkh_verify_segment(const zkh_circuit*, const uint32_t* seal, size_t seal_words, const uint32_t control_root[8],
+                               const uint32_t* rc, const uint32_t* diag);
+
+/* Claim digest of a sealed segment = Poseidon2(out globals, po2, control root): what a join receipt commits to for each
+ * of its two children (zeth_amd/host.py; upstream: ReceiptClaim digests inside risc0-zkvm's lift/join).  Host only. */
+const char* zkh_receipt_claim(const zkh_circuit*, const uint32_t* seal, size_t seal_words, const uint32_t control_root[8],
+                              const uint32_t* rc, const uint32_t* diag, uint32_t claim[8]);
 
 /* ---- profiling: per-kernel HIP-event timing on the ctx stream ---- */
 const char* zkh_prof_enable(zkh_ctx*, int on);

@@ -76,10 +76,8 @@ size_t zko_circuit_tap_count(const zko_circuit* c) { return c->n_taps; }
 
 /* adapter.rs PolyExtStepDef::step — evaluated over ExtElem (the verifier's view). */
 typedef struct { fp4 tot, mul; } mix_state;
-void zko_poly_ext(const zko_circuit* c, const uint32_t poly_mix[4], const uint32_t* u, const uint32_t* const* globals,
-                  uint32_t out[4]) {
-    fp4* fpv = (fp4*)malloc(sizeof(fp4) * (c->n_steps + 1));
-    mix_state* mv = (mix_state*)malloc(sizeof(mix_state) * (c->n_steps + 1));
+static void poly_ext_buf(const zko_circuit* c, const uint32_t poly_mix[4], const uint32_t* u, const uint32_t* const* globals,
+                         uint32_t out[4], fp4* fpv, mix_state* mv) {
     size_t nf = 0, nm = 0;
     fp4 pm = ld4(poly_mix);
     for (size_t i = 0; i < c->n_steps; i++) {
@@ -106,6 +104,12 @@ void zko_poly_ext(const zko_circuit* c, const uint32_t poly_mix[4], const uint32
         }
     }
     st4(out, mv[c->ret].tot);
+}
+void zko_poly_ext(const zko_circuit* c, const uint32_t poly_mix[4], const uint32_t* u, const uint32_t* const* globals,
+                  uint32_t out[4]) {
+    fp4* fpv = (fp4*)malloc(sizeof(fp4) * (c->n_steps + 1));
+    mix_state* mv = (mix_state*)malloc(sizeof(mix_state) * (c->n_steps + 1));
+    poly_ext_buf(c, poly_mix, u, globals, out, fpv, mv);
     free(fpv); free(mv);
 }
 
@@ -118,6 +122,8 @@ void zko_eval_check(const zko_circuit* c, uint32_t* check, const uint32_t* const
 #pragma omp parallel
     {
         uint32_t* u = (uint32_t*)malloc(16 * c->n_taps);
+        fp4* fpv = (fp4*)malloc(sizeof(fp4) * (c->n_steps + 1));          /* per-thread scratch of the step interpreter */
+        mix_state* mv = (mix_state*)malloc(sizeof(mix_state) * (c->n_steps + 1));
 #pragma omp for schedule(static)
         for (size_t idx = 0; idx < dom; idx++) {
             for (size_t t = 0; t < c->n_taps; t++) {
@@ -127,13 +133,13 @@ void zko_eval_check(const zko_circuit* c, uint32_t* check, const uint32_t* const
                 st4(u + 4 * t, v);
             }
             uint32_t tot[4];
-            zko_poly_ext(c, poly_mix, u, globals, tot);
+            poly_ext_buf(c, poly_mix, u, globals, tot, fpv, mv);
             fp x = fp_pow(w, idx);
             fp y = fp_pow(fp_mul(three, x), n);
             fp4 r = fp4_mul_fp(ld4(tot), fp_inv(fp_sub(y, one)));
             for (int p = 0; p < 4; p++) check[(size_t)p * dom + idx] = r.c[p];
         }
-        free(u);
+        free(u); free(fpv); free(mv);
     }
 }
 
@@ -148,10 +154,11 @@ uint32_t zko_syn_cell(uint64_t seed, uint32_t group, uint32_t col, uint32_t row)
     return fp_from_u32((uint32_t)(z >> 32) % FP_P);
 }
 
-void zko_syn_witgen(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t seed, uint64_t noise_seed,
-                    uint32_t* code, uint32_t* data, uint32_t* out_global) {
+/* The code group depends only on (circuit, po2, zk_cycles) — like upstream, where it is the program's control
+ * columns and its Merkle root is the control ID the verifier checks (verify/mod.rs check_code). */
+void zko_syn_code(const zko_circuit* c, unsigned po2, unsigned zk, uint32_t* code) {
     size_t n = (size_t)1 << po2, A = n - zk;
-    size_t wc = c->group_size[ZKC_GROUP_CODE], wd = c->group_size[ZKC_GROUP_DATA];
+    size_t wc = c->group_size[ZKC_GROUP_CODE];
     fp one = fp_from_u32(1);
     for (size_t col = 0; col < wc; col++)
         for (size_t r = 0; r < n; r++) {
@@ -162,14 +169,24 @@ void zko_syn_witgen(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t se
             case 2: v = (r > 0 && r < A) ? one : 0; break;
             case 3: v = fp_from_u32((uint32_t)r); break;
             case 4: v = r == A - 1 ? one : 0; break;
-            default: v = zko_syn_cell(seed, ZKC_GROUP_CODE, (uint32_t)col, (uint32_t)r);
+            default: v = zko_syn_cell(ZKO_SYN_CODE_SEED, ZKC_GROUP_CODE, (uint32_t)col, (uint32_t)r);
             }
             code[col * n + r] = v;
         }
+}
+
+void zko_syn_witgen(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t seed, uint64_t noise_seed,
+                    const uint32_t* pub, uint32_t* code, uint32_t* data, uint32_t* out_global) {
+    size_t n = (size_t)1 << po2, A = n - zk;
+    size_t wd = c->group_size[ZKC_GROUP_DATA];
+    size_t n_pub = c->global_size[ZKC_GLOBAL_OUT] - 4;
+    zko_syn_code(c, po2, zk, code);
     size_t T = (wd - 2) / 3;
     for (size_t col = 0; col < wd; col++)
         for (size_t r = 0; r < n; r++)
             data[col * n + r] = zko_syn_cell(r < A ? seed : noise_seed, ZKC_GROUP_DATA, (uint32_t)col, (uint32_t)r);
+    /* public inputs: word k sits in row 0 of data column 3k (the x cell of triple k) and is bound to out[4 + k] */
+    for (size_t k = 0; k < n_pub; k++) data[(3 * k) * n] = pub[k];
     fp s = 0;
     for (size_t r = 0; r < A; r++) {
         for (size_t j = 0; j < T; j++)
@@ -180,6 +197,7 @@ void zko_syn_witgen(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t se
         data[(wd - 1) * n + r] = s;
     }
     out_global[0] = s; out_global[1] = out_global[2] = out_global[3] = 0;
+    for (size_t k = 0; k < n_pub; k++) out_global[4 + k] = pub[k];
 }
 
 void zko_syn_accum(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t noise_seed, const uint32_t* data,

@@ -20,6 +20,13 @@
 static inline fp4 ld4(const uint32_t* p) { fp4 r; memcpy(&r, p, 16); return r; }
 static inline void st4(uint32_t* p, fp4 v) { memcpy(p, &v, 16); }
 
+/* Stage hook (tests/golden/make_golden_large.py): lets the checker hash every intermediate buffer of a seal, so that the
+ * HIP path can be compared op by op at the BASELINE shape without keeping gigabytes of fixtures. */
+static zko_stage_hook g_hook = NULL;
+void zko_set_stage_hook(zko_stage_hook h) { g_hook = h; }
+static void stage(const char* name, const uint32_t* p, size_t words) { if (g_hook) g_hook(name, p, words); }
+static const char* GROUP_NAME[3] = {"accum", "code", "data"};
+
 /* ---- WriteIOP ---- */
 typedef struct { uint32_t* w; size_t n, cap; zko_rng rng; } iop_t;
 static void iop_write(iop_t* io, const uint32_t* p, size_t n) {
@@ -66,6 +73,13 @@ static void polygroup_new(polygroup_t* pg, uint32_t* coeffs, size_t count, size_
     zko_batch_bit_reverse(coeffs, count * n, count);
     merkle_build(&pg->merkle, pg->evaluated, dom, count);
 }
+static void polygroup_stage(const polygroup_t* pg, const char* group) {
+    char nm[64];
+    size_t dom = pg->n * ZKO_INV_RATE;
+    snprintf(nm, sizeof nm, "coeffs.%s", group); stage(nm, pg->coeffs, pg->count * pg->n);      /* natural order */
+    snprintf(nm, sizeof nm, "evaluated.%s", group); stage(nm, pg->evaluated, pg->count * dom);
+    snprintf(nm, sizeof nm, "nodes.%s", group); stage(nm, pg->merkle.nodes + 8, (2 * dom - 1) * 8);  /* root .. leaves */
+}
 static void polygroup_free(polygroup_t* pg) { free(pg->coeffs); free(pg->evaluated); free(pg->merkle.nodes); }
 /* Prover::commit_group: takes ownership of a copy of the trace columns */
 static void commit_group(polygroup_t* pg, iop_t* io, const uint32_t* trace, size_t count, size_t n) {
@@ -94,8 +108,19 @@ static void fri_round_new(fri_round_t* r, iop_t* io, const uint32_t* coeffs, siz
     zko_fri_fold(r->coeffs, r->coeffs_size, coeffs, fold_mix);
 }
 
+void zko_control_root(const zko_circuit* c, unsigned po2, unsigned zk, uint32_t root[8]) {
+    size_t n = (size_t)1 << po2, wc = c->group_size[ZKC_GROUP_CODE];
+    uint32_t* code = (uint32_t*)malloc(4 * wc * n);
+    zko_syn_code(c, po2, zk, code);
+    iop_t io; memset(&io, 0, sizeof io); zko_rng_init(&io.rng);
+    polygroup_t pg;
+    commit_group(&pg, &io, code, wc, n);
+    memcpy(root, pg.merkle.nodes + 8, 32);
+    polygroup_free(&pg); free(code); free(io.w);
+}
+
 uint32_t* zko_prove_segment(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t seed, uint64_t noise_seed,
-                            size_t* seal_words, const char** err) {
+                            const uint32_t* pub, size_t* seal_words, const char** err) {
     *err = NULL;
     size_t n = (size_t)1 << po2, dom = n * ZKO_INV_RATE;
     size_t wa = c->group_size[0], wc = c->group_size[1], wd = c->group_size[2];
@@ -105,27 +130,33 @@ uint32_t* zko_prove_segment(const zko_circuit* c, unsigned po2, unsigned zk, uin
     /* witgen (SegmentProver step 2) */
     uint32_t* code = (uint32_t*)malloc(4 * wc * n);
     uint32_t* data = (uint32_t*)malloc(4 * wd * n);
-    uint32_t out_global[4];
-    zko_syn_witgen(c, po2, zk, seed, noise_seed, code, data, out_global);
+    size_t out_size = c->global_size[ZKC_GLOBAL_OUT];
+    uint32_t* out_global = (uint32_t*)malloc(4 * (out_size + 1));
+    zko_syn_witgen(c, po2, zk, seed, noise_seed, pub, code, data, out_global);
+    stage("trace.code", code, wc * n); stage("trace.data", data, wd * n);
 
-    /* step 3: header — out globals + po2, committed */
+    /* step 3: header — out globals + po2 as field elements (write_field_elem_slice), committed */
     {
-        uint32_t hdr[5]; memcpy(hdr, out_global, 16); hdr[4] = fp_from_u32(po2);
-        iop_write(&io, out_global, 4);
-        uint32_t p = po2; iop_write(&io, &p, 1);
-        uint32_t dg[8]; zko_hash_elem_slice(hdr, 5, 1, dg);
+        out_global[out_size] = fp_from_u32(po2);
+        iop_write(&io, out_global, out_size + 1);
+        uint32_t dg[8]; zko_hash_elem_slice(out_global, out_size + 1, 1, dg);
         iop_commit(&io, dg);
     }
     /* step 4: commit code, data */
     polygroup_t groups[3];
     commit_group(&groups[ZKC_GROUP_CODE], &io, code, wc, n);
     commit_group(&groups[ZKC_GROUP_DATA], &io, data, wd, n);
+    polygroup_stage(&groups[ZKC_GROUP_CODE], GROUP_NAME[ZKC_GROUP_CODE]);
+    polygroup_stage(&groups[ZKC_GROUP_DATA], GROUP_NAME[ZKC_GROUP_DATA]);
     /* step 5: accum mix + accum */
     uint32_t* mix_global = (uint32_t*)malloc(4 * (wa ? wa : 1));
     for (size_t i = 0; i < c->global_size[ZKC_GLOBAL_MIX]; i++) mix_global[i] = zko_rng_random_elem(&io.rng);
     uint32_t* accum = (uint32_t*)malloc(4 * wa * n);
     zko_syn_accum(c, po2, zk, noise_seed, data, mix_global, accum);
+    stage("global.mix", mix_global, c->global_size[ZKC_GLOBAL_MIX]);
+    stage("trace.accum", accum, wa * n);
     commit_group(&groups[ZKC_GROUP_ACCUM], &io, accum, wa, n);
+    polygroup_stage(&groups[ZKC_GROUP_ACCUM], GROUP_NAME[ZKC_GROUP_ACCUM]);
     free(code); free(data); free(accum);
 
     /* step 6: finalize */
@@ -133,11 +164,14 @@ uint32_t* zko_prove_segment(const zko_circuit* c, unsigned po2, unsigned zk, uin
     uint32_t* check = (uint32_t*)calloc(EXT_SIZE * dom, 4);
     const uint32_t* gev[3] = {groups[0].evaluated, groups[1].evaluated, groups[2].evaluated};
     const uint32_t* globals[2] = {out_global, mix_global};
+    stage("poly_mix", poly_mix, 4);
     zko_eval_check(c, check, gev, globals, poly_mix, po2);
+    stage("check.evaluated", check, EXT_SIZE * dom);
     zko_batch_interpolate_ntt(check, EXT_SIZE * dom, EXT_SIZE);
     polygroup_t check_group;
     polygroup_new(&check_group, check, ZKO_CHECK_SIZE, n);   /* 4 polys of 4n reinterpreted as 16 of n */
     merkle_commit(&check_group.merkle, &io);
+    polygroup_stage(&check_group, "check");
 
     uint32_t zw[4]; zko_rng_random_ext_elem(&io.rng, zw);
     fp4 z = ld4(zw);
@@ -177,6 +211,8 @@ uint32_t* zko_prove_segment(const zko_circuit* c, unsigned po2, unsigned zk, uin
         zko_batch_evaluate_any(check_group.coeffs, ZKO_CHECK_SIZE * n, ZKO_CHECK_SIZE, which, (const uint32_t*)xs,
                                ZKO_CHECK_SIZE, (uint32_t*)(coeff_u + pos));
     }
+    stage("z", zw, 4);
+    stage("coeff_u", (const uint32_t*)coeff_u, 4 * n_u);
     iop_write(&io, (const uint32_t*)coeff_u, 4 * n_u);
     {
         uint32_t dg[8]; zko_hash_elem_slice((const uint32_t*)coeff_u, 4 * n_u, 1, dg);   /* hash_ext_elem_slice */
@@ -202,6 +238,8 @@ uint32_t* zko_prove_segment(const zko_circuit* c, unsigned po2, unsigned zk, uin
         for (int i = 0; i < ZKO_CHECK_SIZE; i++) which[i] = (uint32_t)combo_count;
         zko_mix_poly_coeffs(combos, (const uint32_t*)&cur_mix, mixw, check_group.coeffs, which, ZKO_CHECK_SIZE, n);
     }
+    stage("mix", mixw, 4);
+    stage("combos.mixed", combos, n * (combo_count + 1) * 4);
     /* combos_prepare: subtract the U polys; combos_divide: divide by prod (x - z*back_one^back) */
     {
         size_t cur_pos = 0; fp4 cur = fp4_one();
@@ -235,7 +273,9 @@ uint32_t* zko_prove_segment(const zko_circuit* c, unsigned po2, unsigned zk, uin
     }
     uint32_t* final_coeffs = (uint32_t*)malloc(4 * n * EXT_SIZE);
     zko_eltwise_sum_extelem(final_coeffs, n * EXT_SIZE, combos, n * (combo_count + 1));
+    stage("combos.divided", combos, n * (combo_count + 1) * 4);
     zko_batch_bit_reverse(final_coeffs, n * EXT_SIZE, EXT_SIZE);
+    stage("final_coeffs", final_coeffs, n * EXT_SIZE);
     free(combos);
 
     /* fri_prove */
@@ -267,7 +307,7 @@ uint32_t* zko_prove_segment(const zko_circuit* c, unsigned po2, unsigned zk, uin
         }
         for (size_t r = 0; r < n_rounds; r++) { free(rounds[r].coeffs); free(rounds[r].evaluated); free(rounds[r].merkle.nodes); }
     }
-    free(final_coeffs); free(all_xs); free(eval_u); free(coeff_u); free(mix_global);
+    free(final_coeffs); free(all_xs); free(eval_u); free(coeff_u); free(mix_global); free(out_global);
     for (int g = 0; g < 3; g++) polygroup_free(&groups[g]);
     polygroup_free(&check_group);
     *seal_words = io.n;

@@ -102,7 +102,8 @@ typedef struct { size_t domain; mverif_t merkle; fp4 mix; } vround_t;
 
 #define FAIL(msg) do { ret = (msg); goto done; } while (0)
 
-const char* zko_verify_segment(const zko_circuit* c, const uint32_t* seal, size_t seal_words) {
+const char* zko_verify_segment(const zko_circuit* c, const uint32_t* seal, size_t seal_words,
+                               const uint32_t control_root[8]) {
     const char* ret = NULL;
     riop_t io; memset(&io, 0, sizeof io); io.w = seal; io.n = seal_words; zko_rng_init(&io.rng);
     mverif_t mg[3], mcheck; memset(mg, 0, sizeof mg); memset(&mcheck, 0, sizeof mcheck);
@@ -111,19 +112,22 @@ const char* zko_verify_segment(const zko_circuit* c, const uint32_t* seal, size_
     uint32_t* mix_global = NULL;
 
     /* header */
-    const uint32_t* out_global = riop_read(&io, 4);
-    const uint32_t* ppo2 = riop_read(&io, 1);
+    if (!control_root) return "no control root given (check_code needs the expected code commitment)";
+    size_t out_size = c->global_size[ZKC_GLOBAL_OUT];
+    if (out_size + 1 > 256) return "output global too large";
+    const uint32_t* out_global = riop_read(&io, out_size + 1);     /* out words, then po2 as an Elem */
     if (io.bad) return "seal truncated (header)";
-    unsigned po2 = ppo2[0];
+    if (!elems_reduced(out_global, out_size + 1)) return "unreduced output";
+    unsigned po2 = fp_to_u32(out_global[out_size]);
     if (po2 > 24 || po2 < 1) return "bad po2";
-    if (!elems_reduced(out_global, 4)) return "unreduced output";
     {
-        uint32_t hdr[5]; memcpy(hdr, out_global, 16); hdr[4] = fp_from_u32(po2);
-        uint32_t dg[8]; zko_hash_elem_slice(hdr, 5, 1, dg); zko_rng_mix(&io.rng, dg);
+        uint32_t dg[8]; zko_hash_elem_slice(out_global, out_size + 1, 1, dg); zko_rng_mix(&io.rng, dg);
     }
     size_t size = (size_t)1 << po2, domain = ZKO_INV_RATE * size;
     const char* e;
     if ((e = mverif_new(&mg[ZKC_GROUP_CODE], &io, domain, c->group_size[ZKC_GROUP_CODE]))) FAIL(e);
+    /* check_code: the code commitment must be the one registered for (circuit, po2) */
+    if (memcmp(mg[ZKC_GROUP_CODE].top + 8, control_root, 32) != 0) FAIL("code root does not match the control root");
     if ((e = mverif_new(&mg[ZKC_GROUP_DATA], &io, domain, c->group_size[ZKC_GROUP_DATA]))) FAIL(e);
     mix_global = (uint32_t*)malloc(4 * (c->global_size[ZKC_GLOBAL_MIX] + 1));
     for (size_t i = 0; i < c->global_size[ZKC_GLOBAL_MIX]; i++) mix_global[i] = zko_rng_random_elem(&io.rng);

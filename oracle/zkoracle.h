@@ -104,9 +104,13 @@ void zko_eval_check(const zko_circuit*, uint32_t* check, const uint32_t* const* 
 
 /* ---- SYN-AIR witness (definition in DESIGN.md §SYN-AIR; mirrored by the HIP witgen kernels) ---- */
 uint32_t zko_syn_cell(uint64_t seed, uint32_t group, uint32_t col, uint32_t row);
-/* fills code (wc x n) and data (wd x n), out global (4 words) */
+#define ZKO_SYN_CODE_SEED 0xC0DEC0DE5EEDull
+/* code group (wc x n): a function of (circuit, po2, zk_cycles) only — its Merkle root is the control root */
+void zko_syn_code(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint32_t* code);
+/* fills code (wc x n) and data (wd x n), out global (OUTPUT_SIZE = 4 + n_pub words: s,0,0,0, pub...);
+ * pub = n_pub public input words (Montgomery), may be NULL when n_pub == 0 */
 void zko_syn_witgen(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t seed, uint64_t noise_seed,
-                    uint32_t* code, uint32_t* data, uint32_t* out_global);
+                    const uint32_t* pub, uint32_t* code, uint32_t* data, uint32_t* out_global);
 /* fills accum (wa x n) given data and the mix global (wa words) */
 void zko_syn_accum(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t noise_seed,
                    const uint32_t* data, const uint32_t* mix_global, uint32_t* accum);
@@ -114,9 +118,16 @@ void zko_syn_accum(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_
 /* ---- whole seal: restates SegmentProver::prove + risc0_zkp::prove::Prover ---- */
 /* returns malloc'd seal words (caller frees with zko_free); NULL + *err on failure */
 uint32_t* zko_prove_segment(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t seed,
-                            uint64_t noise_seed, size_t* seal_words, const char** err);
-/* restates risc0_zkp::verify::verify. NULL on success, static error string otherwise */
-const char* zko_verify_segment(const zko_circuit*, const uint32_t* seal, size_t seal_words);
+                            uint64_t noise_seed, const uint32_t* pub, size_t* seal_words, const char** err);
+/* Merkle root of the committed code group for (circuit, po2, zk_cycles): the control-ID analogue */
+void zko_control_root(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint32_t root[8]);
+/* restates risc0_zkp::verify::verify (incl. check_code: the code root must equal control_root).
+ * NULL on success, static error string otherwise */
+const char* zko_verify_segment(const zko_circuit*, const uint32_t* seal, size_t seal_words,
+                               const uint32_t control_root[8]);
+/* called by zko_prove_segment with every intermediate buffer of the seal (name, words) when set; NULL disables */
+typedef void (*zko_stage_hook)(const char* name, const uint32_t* data, size_t words);
+void zko_set_stage_hook(zko_stage_hook hook);
 void zko_free(void*);
 int zko_num_threads(void);   /* OpenMP threads the oracle will use */
 void zko_set_num_threads(int n);   /* the loops stop scaling well before a 2-socket host is full: let the caller pick */

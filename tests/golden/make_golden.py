@@ -23,8 +23,9 @@ for shape, po2, zk, seed, noise in [("syn_tiny", 9, 100, 0x5EED0000, 0x2E80), ("
                                     ("syn_small", 12, 1994, 0x5EED0002, 0x2E81), ("syn_a", 13, 1994, 0x5EED0003, 0x2E80)]:
     oc = zko.OracleCircuit(lib, getattr(syn_air, shape)())
     seal = oc.prove(po2, zk, seed, noise)
-    assert oc.verify(seal) is None
+    assert oc.verify(seal, zk_cycles=zk) is None
     seals.append({"shape": shape, "po2": po2, "zk_cycles": zk, "seed": seed, "noise_seed": noise, "words": int(seal.size),
+                  "control_root": [int(x) for x in oc.control_root(po2, zk)],
                   "sha256": hashlib.sha256(seal.astype("<u4").tobytes()).hexdigest(), "head": [int(x) for x in seal[:8]]})
 with open(os.path.join(HERE, "seal_digests.json"), "w") as fh:
     json.dump({"generator": "tests/golden/make_golden.py (CPU oracle)", "seals": seals}, fh, indent=1)

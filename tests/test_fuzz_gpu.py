@@ -145,7 +145,7 @@ def test_fuzz_whole_seals(hal, oracle, seed, tmp_path, monkeypatch):
     receipt = prover.prove_segment(seg)
     want = zko.OracleCircuit(oracle, desc).prove(po2, zk, seg.seed, seg.noise_seed)
     assert np.array_equal(receipt.seal, want), f"shape ({wc},{wd},{wa}) po2 {po2} zk {zk}"
-    receipt.verify(desc)
+    receipt.verify(desc, prover.control_root(po2, zk))
 
 
 @pytest.mark.parametrize("po2,zk", [(7, 40), (8, 60), (8, 200)])
@@ -156,7 +156,10 @@ def test_smallest_segments(hal, oracle, po2, zk):
     from zeth_amd.prover import Segment, SegmentProver
     desc = syn_air.syn_tiny()
     seg = Segment(index=0, po2=po2, seed=3, noise_seed=4, zk_cycles=zk)
-    receipt = SegmentProver(hal, desc).prove_segment(seg)
-    want = zko.OracleCircuit(oracle, desc).prove(po2, zk, 3, 4)
+    prover = SegmentProver(hal, desc)
+    receipt = prover.prove_segment(seg)
+    oc = zko.OracleCircuit(oracle, desc)
+    want = oc.prove(po2, zk, 3, 4)
     assert np.array_equal(receipt.seal, want)
-    receipt.verify(desc)
+    assert np.array_equal(prover.control_root(po2, zk), oc.control_root(po2, zk))
+    receipt.verify(desc, prover.control_root(po2, zk))

@@ -35,6 +35,7 @@ def test_golden_seal_digests(hal):
         seal = prover.prove_segment(seg).seal
         assert seal.size == g["words"] and seal[:8].tolist() == g["head"]
         assert hashlib.sha256(seal.astype("<u4").tobytes()).hexdigest() == g["sha256"]
+        assert prover.control_root(g["po2"], g["zk_cycles"]).tolist() == g["control_root"]
 
 
 def test_error_behaviour(hal):

@@ -1,6 +1,8 @@
 """N > 1 path on CPU: world_size-2 gloo processes partition a segment list round-robin, each "seals" its share with
 the CPU oracle standing in for the GPU (test-only), receipts are gathered on rank 0 with no data-path collective,
-and the composite equals the single-rank result bit for bit."""
+and the composite equals the single-rank result bit for bit.  The same two ranks then run the distributed join
+executor (BASELINE config 5): right children cross the control plane, the root lands on rank 0, and the succinct
+receipt verifies — including every join's commitment to the claims of its children."""
 import os
 import socket
 import sys
@@ -12,6 +14,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LEAF_PO2, JOIN_PO2, ZK, N_LEAVES = 9, 9, 100, 5
 
 
 def _free_port():
@@ -22,51 +25,100 @@ def _free_port():
     return p
 
 
+def _descs():
+    from zeth_amd.circuits import syn_air
+    return syn_air.syn_tiny(), syn_air.build_syn_air(6, 50, 4, n_pub=16)
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import zko
-    from zeth_amd.circuits import syn_air
-    from zeth_amd.host import BlockProcessor, torch_gather
+    from zeth_amd.host import BlockProcessor, JoinExecutor, receipt_claim, torch_gather
     from zeth_amd.prover import Segment, SegmentReceipt
-    oc = zko.OracleCircuit(zko.load(), syn_air.syn_tiny())
+    leaf_desc, join_desc = _descs()
+    lib = zko.load()
+    oc, ocj = zko.OracleCircuit(lib, leaf_desc), zko.OracleCircuit(lib, join_desc)
 
     def prove(seg):
         return SegmentReceipt(seal=oc.prove(seg.po2, seg.zk_cycles, seg.seed, seg.noise_seed), index=seg.index, po2=seg.po2)
 
-    segs = [Segment(index=i, po2=9, seed=100 + i, zk_cycles=100) for i in range(5)]
+    segs = [Segment(index=i, po2=LEAF_PO2, seed=100 + i, noise_seed=0x2E80, zk_cycles=ZK) for i in range(N_LEAVES)]
     bp = BlockProcessor(prove, rank=rank, world_size=world, gather=torch_gather(rank, world))
     # timing protocol of bench.py: barrier, work, barrier, MAX over ranks
     dist.barrier()
+    local = bp.prove_local(segs)
     rec = bp.prove(segs)
     dist.barrier()
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+
+    # ---- distributed join tree over the same leaves ----
+    leaf_root, join_root = oc.control_root(LEAF_PO2, ZK), ocj.control_root(JOIN_PO2, ZK)
+
+    def claim_of(r, is_leaf):
+        return receipt_claim(r, leaf_desc if is_leaf else join_desc, leaf_root if is_leaf else join_root)
+
+    def prove_join(seg):
+        seal = ocj.prove(seg.po2, ZK, seg.seed, 0x2E81, pub=np.array(seg.pub, np.uint32))
+        return SegmentReceipt(seal=seal, index=seg.index, po2=seg.po2)
+
+    ex = JoinExecutor(prove_join, claim_of, rank, world, join_po2=JOIN_PO2)
+    done, root = ex.run(N_LEAVES, {r.index: r for r in local})
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object({k: v.seal.tobytes() for k, v in done.items()}, gathered, dst=0)
     if rank == 0:
-        q.put(([r.index for r in rec.segments], [r.seal.tobytes() for r in rec.segments], float(t.item())))
+        q.put(([r.index for r in rec.segments], [r.seal.tobytes() for r in rec.segments], float(t.item()),
+               gathered, root.seal.tobytes() if root is not None else None))
     else:
-        assert rec is None
+        assert rec is None and root is None
     dist.destroy_process_group()
 
 
-def test_world_size_2_round_robin_matches_single_rank():
+def test_world_size_2_round_robin_and_distributed_joins():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import zko
-    from zeth_amd.circuits import syn_air
+    from zeth_amd.host import SuccinctReceipt, join_schedule, prove_succinct, receipt_claim
+    from zeth_amd.prover import SegmentReceipt
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    idx, seals, tmax = q.get(timeout=240)
+    idx, seals, tmax, gathered, root_bytes = q.get(timeout=400)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert idx == [0, 1, 2, 3, 4] and tmax == 2.0
-    oc = zko.OracleCircuit(zko.load(), syn_air.syn_tiny())
+    assert idx == list(range(N_LEAVES)) and tmax == 2.0
+    leaf_desc, join_desc = _descs()
+    lib = zko.load()
+    oc, ocj = zko.OracleCircuit(lib, leaf_desc), zko.OracleCircuit(lib, join_desc)
+    leaves = []
     for i, s in enumerate(seals):
-        want = oc.prove(9, 100, 100 + i, 0x2E80)
+        want = oc.prove(LEAF_PO2, ZK, 100 + i, 0x2E80)
         assert s == want.tobytes()
+        leaves.append(SegmentReceipt(seal=want, index=i, po2=LEAF_PO2))
+    # which rank ran which join: the one holding the left child; together the two ranks ran every join exactly once
+    sched = join_schedule(N_LEAVES, 2)
+    for r, part in enumerate(gathered):
+        assert set(part) == {(t.level, t.index) for lvl in sched for t in lvl if t.device == r}
+    assert sum(len(p) for p in gathered) == N_LEAVES - 1
+    # the distributed tree equals the single-rank tree bit for bit, and verifies
+    leaf_root, join_root = oc.control_root(LEAF_PO2, ZK), ocj.control_root(JOIN_PO2, ZK)
+
+    def claim_of(r, is_leaf):
+        return receipt_claim(r, leaf_desc if is_leaf else join_desc, leaf_root if is_leaf else join_root)
+
+    def prove_join(seg):
+        return SegmentReceipt(seal=ocj.prove(seg.po2, ZK, seg.seed, 0x2E81, pub=np.array(seg.pub, np.uint32)), index=seg.index, po2=seg.po2)
+
+    single = prove_succinct(leaves, prove_join, claim_of, join_po2=JOIN_PO2)
+    merged = {k: v for part in gathered for k, v in part.items()}
+    for lvl, tasks in zip(single.joins, join_schedule(N_LEAVES, 1)):
+        for j, t in zip(lvl, tasks):
+            assert merged[(t.level, t.index)] == j.seal.tobytes()
+    assert root_bytes == single.root.seal.tobytes()
+    single.verify(leaf_desc, join_desc, leaf_root, join_root)

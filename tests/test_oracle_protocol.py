@@ -19,11 +19,11 @@ def test_prove_verify_roundtrip(oracle, shape, po2, zk):
     desc = getattr(syn_air, shape)()
     oc = zko.OracleCircuit(oracle, desc)
     seal = oc.prove(po2, zk)
-    assert oc.verify(seal) is None
+    assert oc.verify(seal, zk_cycles=zk) is None
     c = Circuit.parse(desc)
     # seal layout: header, 4 group tops, coeff_u, FRI tops + final coeffs, 50 queries
     n = 1 << po2
-    assert seal[4] == po2
+    assert oracle.zko_fp_decode(int(seal[4])) == po2          # po2 travels as an Elem (Montgomery word), like upstream
     rounds, deg = 0, n
     while deg > 256:
         rounds, deg = rounds + 1, deg // 16
@@ -44,17 +44,17 @@ def test_verifier_rejects_tampering(oracle):
     desc = syn_air.syn_tiny()
     oc = zko.OracleCircuit(oracle, desc)
     seal = oc.prove(10, 300)
-    assert oc.verify(seal) is None
+    assert oc.verify(seal, zk_cycles=300) is None
     rng = np.random.default_rng(0)
     for pos in [0, 4, 5, 300, seal.size // 2, seal.size - 1, *rng.integers(0, seal.size, size=12)]:
         bad = seal.copy()
         bad[pos] ^= 1
-        assert oc.verify(bad) is not None, f"tampered word {pos} accepted"
-    assert oc.verify(seal[:-1]) is not None
-    assert oc.verify(np.concatenate([seal, [0]]).astype(np.uint32)) is not None
+        assert oc.verify(bad, zk_cycles=300) is not None, f"tampered word {pos} accepted"
+    assert oc.verify(seal[:-1], zk_cycles=300) is not None
+    assert oc.verify(np.concatenate([seal, [0]]).astype(np.uint32), zk_cycles=300) is not None
     # a seal for a different witness does not verify against ... itself it does; but cross-circuit it must not
     oc2 = zko.OracleCircuit(oracle, syn_air.syn_small())
-    assert oc2.verify(seal) is not None
+    assert oc2.verify(seal, zk_cycles=300) is not None
 
 
 def test_unsatisfied_witness_is_rejected_by_the_verifier(oracle):
@@ -67,7 +67,7 @@ def test_unsatisfied_witness_is_rejected_by_the_verifier(oracle):
     desc[pos + 1] = 2                                          # now active*(2-active) != 0 on active rows
     oc = zko.OracleCircuit(oracle, desc)
     seal = oc.prove(9, 100)
-    err = oc.verify(seal)
+    err = oc.verify(seal, zk_cycles=100)
     assert err is not None and "constraint check failed" in err
 
 

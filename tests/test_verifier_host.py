@@ -12,8 +12,9 @@ from zeth_amd.hal import HalError, HostCircuit
 @pytest.mark.parametrize("shape,po2,zk", [("syn_tiny", 9, 100), ("syn_tiny", 12, 1994), ("syn_small", 13, 1994)])
 def test_accepts_oracle_seals(oracle, shape, po2, zk):
     desc = getattr(syn_air, shape)()
-    seal = zko.OracleCircuit(oracle, desc).prove(po2, zk, 7, 9)
-    HostCircuit(desc).verify_segment(seal)
+    oc = zko.OracleCircuit(oracle, desc)
+    seal = oc.prove(po2, zk, 7, 9)
+    HostCircuit(desc).verify_segment(seal, oc.control_root(po2, zk))
 
 
 def test_agrees_with_oracle_verifier_on_tampering(oracle):
@@ -21,23 +22,24 @@ def test_agrees_with_oracle_verifier_on_tampering(oracle):
     oc = zko.OracleCircuit(oracle, desc)
     hc = HostCircuit(desc)
     seal = oc.prove(10, 300)
-    hc.verify_segment(seal)
+    root = oc.control_root(10, 300)
+    hc.verify_segment(seal, root)
     rng = np.random.default_rng(1)
     for pos in [0, 3, 4, 5, 200, 300, 1100, seal.size // 2, seal.size - 1, *rng.integers(0, seal.size, size=40)]:
         bad = seal.copy()
         bad[pos] ^= 1 << int(rng.integers(0, 31))
-        assert oc.verify(bad) is not None
+        assert oc.verify(bad, root) is not None
         with pytest.raises(HalError, match="verify_segment"):
-            hc.verify_segment(bad)
+            hc.verify_segment(bad, root)
     for cut in (1, 8, 100, seal.size - 4):
         with pytest.raises(HalError, match="truncated|trailing|mismatch|range|po2"):
-            hc.verify_segment(seal[:-cut])
+            hc.verify_segment(seal[:-cut], root)
     with pytest.raises(HalError, match="trailing"):
-        hc.verify_segment(np.concatenate([seal, np.zeros(3, np.uint32)]))
+        hc.verify_segment(np.concatenate([seal, np.zeros(3, np.uint32)]), root)
     with pytest.raises(HalError):
-        HostCircuit(syn_air.syn_small()).verify_segment(seal)        # wrong circuit
+        HostCircuit(syn_air.syn_small()).verify_segment(seal, root)        # wrong circuit
     with pytest.raises(HalError, match="po2|truncated"):
-        hc.verify_segment(np.zeros(5, np.uint32))
+        hc.verify_segment(np.zeros(5, np.uint32), root)
 
 
 def test_constraint_violation_is_rejected(oracle):
@@ -47,9 +49,10 @@ def test_constraint_violation_is_rejected(oracle):
     c = Circuit.parse(desc)
     pos = 16 + 3 * len(c.taps) + sum(1 + len(cb) for cb in c.combos)
     desc[pos + 1] = 2
-    seal = zko.OracleCircuit(oracle, desc).prove(9, 100)
+    oc = zko.OracleCircuit(oracle, desc)
+    seal = oc.prove(9, 100)
     with pytest.raises(HalError, match="constraint check failed"):
-        HostCircuit(desc).verify_segment(seal)
+        HostCircuit(desc).verify_segment(seal, oc.control_root(9, 100))
 
 
 def test_custom_poseidon2_tables(oracle):
@@ -67,9 +70,11 @@ def test_custom_poseidon2_tables(oracle):
         seal = oc.prove(9, 100)
         assert not np.array_equal(seal[5:40], base[5:40])
         hc = HostCircuit(desc)
-        hc.verify_segment(seal, rc, diag)
+        root = np.zeros(8, np.uint32)
+        oracle.zko_control_root(oc.h, 9, 100, root)          # under the custom tables (not the cached one)
+        hc.verify_segment(seal, root, rc, diag)
         with pytest.raises(HalError):
-            hc.verify_segment(seal)                     # shipped tables: different transcript
+            hc.verify_segment(seal, root)               # shipped tables: different transcript
     finally:
         txt = open(os.path.join(os.path.dirname(__file__), "..", "include", "zkh_poseidon2_consts.h")).read()
         nums = [int(x, 16) for x in re.findall(r"0x([0-9a-f]{8})u", txt)]

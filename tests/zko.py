@@ -46,10 +46,12 @@ def load():
         "zko_poly_ext": (None, [vp, u32p, u32p, C.POINTER(vp), u32p]),
         "zko_eval_check": (None, [vp, u32p, C.POINTER(vp), C.POINTER(vp), u32p, C.c_uint]),
         "zko_syn_cell": (u32, [u64, u32, u32, u32]),
-        "zko_syn_witgen": (None, [vp, C.c_uint, C.c_uint, u64, u64, u32p, u32p, u32p]),
+        "zko_syn_code": (None, [vp, C.c_uint, C.c_uint, u32p]),
+        "zko_syn_witgen": (None, [vp, C.c_uint, C.c_uint, u64, u64, C.c_void_p, u32p, u32p, u32p]),
         "zko_syn_accum": (None, [vp, C.c_uint, C.c_uint, u64, u32p, u32p, u32p]),
-        "zko_prove_segment": (C.POINTER(u32), [vp, C.c_uint, C.c_uint, u64, u64, C.POINTER(sz), C.POINTER(C.c_char_p)]),
-        "zko_verify_segment": (C.c_char_p, [vp, u32p, sz]),
+        "zko_prove_segment": (C.POINTER(u32), [vp, C.c_uint, C.c_uint, u64, u64, C.c_void_p, C.POINTER(sz), C.POINTER(C.c_char_p)]),
+        "zko_control_root": (None, [vp, C.c_uint, C.c_uint, u32p]),
+        "zko_verify_segment": (C.c_char_p, [vp, u32p, sz, C.c_void_p]),
         "zko_free": (None, [vp]),
         "zko_num_threads": (C.c_int, []),
         "zko_set_num_threads": (None, [C.c_int]),
@@ -75,17 +77,56 @@ class OracleCircuit:
             self.lib.zko_circuit_free(self.h)
             self.h = None
 
-    def prove(self, po2, zk_cycles=1994, seed=0x5EED0000, noise_seed=0x2E80):
+    @property
+    def out_size(self):
+        return int(self.desc[7])
+
+    def witgen(self, po2, zk_cycles=1994, seed=0x5EED0000, noise_seed=0x2E80, pub=None):
+        """-> (code, data, out_global) host arrays, the oracle's SYN witness."""
+        wa, wc, wd = (int(x) for x in self.desc[3:6])
+        n = 1 << po2
+        code, data, out = np.zeros(wc * n, np.uint32), np.zeros(wd * n, np.uint32), np.zeros(self.out_size, np.uint32)
+        self.lib.zko_syn_witgen(self.h, po2, zk_cycles, seed, noise_seed, self._pub(pub), code, data, out)
+        return code, data, out
+
+    def _pub(self, pub):
+        n_pub = self.out_size - 4
+        if n_pub == 0:
+            return None
+        self._pub_arr = np.ascontiguousarray(pub, dtype=np.uint32)
+        assert self._pub_arr.size == n_pub, f"circuit takes {n_pub} public input words"
+        return self._pub_arr.ctypes.data
+
+    def control_root(self, po2, zk_cycles=1994):
+        key = (po2, zk_cycles)
+        cache = self.__dict__.setdefault("_roots", {})
+        if key not in cache:
+            root = np.zeros(8, np.uint32)
+            self.lib.zko_control_root(self.h, po2, zk_cycles, root)
+            cache[key] = root
+        return cache[key]
+
+    def prove(self, po2, zk_cycles=1994, seed=0x5EED0000, noise_seed=0x2E80, pub=None):
         n = C.c_size_t()
         err = C.c_char_p()
-        p = self.lib.zko_prove_segment(self.h, po2, zk_cycles, seed, noise_seed, C.byref(n), C.byref(err))
+        p = self.lib.zko_prove_segment(self.h, po2, zk_cycles, seed, noise_seed, self._pub(pub), C.byref(n), C.byref(err))
         if not p:
             raise RuntimeError((err.value or b"?").decode())
         seal = np.ctypeslib.as_array(p, shape=(n.value,)).copy()
         self.lib.zko_free(p)
         return seal
 
-    def verify(self, seal):
+    def verify(self, seal, control_root=None, zk_cycles=1994):
+        """None if accepted.  control_root defaults to the oracle's own root for the po2 in the seal header (the test
+        passes an explicit one when it wants to check the binding itself)."""
         seal = np.ascontiguousarray(seal, dtype=np.uint32)
-        err = self.lib.zko_verify_segment(self.h, seal, seal.size)
+        if control_root is None:
+            po2 = 0
+            if seal.size > self.out_size:
+                po2 = int(self.lib.zko_fp_decode(int(seal[self.out_size])))
+            if not 1 <= po2 <= 22:
+                return "bad po2"
+            control_root = self.control_root(po2, zk_cycles)
+        cr = np.ascontiguousarray(control_root, dtype=np.uint32)
+        err = self.lib.zko_verify_segment(self.h, seal, seal.size, cr.ctypes.data)
         return None if not err else err.decode()

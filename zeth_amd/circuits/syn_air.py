@@ -13,7 +13,12 @@ Columns (n rows, A = n - zk_cycles active rows):
   data : triples (3j, 3j+1, 3j+2 = product) for j < T = (wd-2)//3; col wd-2 = d0*d1*d3*d4; col wd-1 = running
          sum s: s[0] = d0[0], s[r] = s[r-1] + d0[r] + c3[r]*d1[r]
   accum: k = wa/4 Fp4 columns, a_e[r] = prod_{r' <= r} (mix_e + d_{e mod wd}[r'])
-Globals: out = (s[A-1], 0, 0, 0); mix = k Fp4 challenges (4k words).
+Globals: out = (s[A-1], 0, 0, 0, pub_0 .. pub_{n_pub-1}); mix = k Fp4 challenges (4k words).
+Public inputs (n_pub > 0, used by the join circuit SYN-J): word k is placed in row 0 of data column 3k (the x cell of
+triple k; column 0 also feeds the running sum, so out[0] depends on pub_0) and bound to out[4 + k] by a `first`-gated
+constraint — the verifier, which reads `out` from the seal header, thereby learns which inputs the witness used.
+The code group depends only on (shape, po2, zk_cycles): its committed Merkle root is the control root (the control-ID
+analogue) that the verifier compares against.
 """
 from __future__ import annotations
 
@@ -24,9 +29,10 @@ from .desc import GLOBAL_MIX, GLOBAL_OUT, GROUP_ACCUM, GROUP_CODE, GROUP_DATA, P
 NBETA = P - 11
 
 
-def build_syn_air(wc: int = 16, wd: int = 208, wa: int = 32) -> np.ndarray:
+def build_syn_air(wc: int = 16, wd: int = 208, wa: int = 32, n_pub: int = 0) -> np.ndarray:
     assert wc >= 5 and wd >= 8 and wa >= 4 and wa % 4 == 0
-    b = CircuitBuilder((wa, wc, wd), (4, wa))
+    assert 0 <= n_pub <= (wd - 2) // 3, "one triple per public input word"
+    b = CircuitBuilder((wa, wc, wd), (4 + n_pub, wa))
     code = lambda c, back=0: b.get(GROUP_CODE, c, back)
     data = lambda c, back=0: b.get(GROUP_DATA, c, back)
     acc = lambda c, back=0: b.get(GROUP_ACCUM, c, back)
@@ -62,6 +68,9 @@ def build_syn_air(wc: int = 16, wd: int = 208, wa: int = 32) -> np.ndarray:
         t = term(e)
         for i in range(4):
             inner = b.and_eqz(inner, b.sub(acc(4 * e + i), t[i]))
+    # (first) public inputs: d_{3k}[0] = out[4 + k]
+    for k in range(n_pub):
+        inner = b.and_eqz(inner, b.sub(data(3 * k), b.get_global(GLOBAL_OUT, 4 + k)))
     chain = b.and_cond(chain, first, inner)
 
     # (body) s = s@1 + d0 + row*d1 ; a_e = a_e@1 * term_e
@@ -99,14 +108,26 @@ def syn_small() -> np.ndarray:
     return build_syn_air(8, 20, 8)
 
 
+JOIN_PUB_WORDS = 16      # two child claim digests (8 words each)
+
+
 def syn_join() -> np.ndarray:
-    """SYN-J: recursion-like widths (W ~ 16/128/16), declared synthetic."""
-    return build_syn_air(16, 128, 16)
+    """SYN-J: recursion-like widths (W ~ 16/128/16) with 16 public input words = the claim
+    digests of the two receipts a join combines, bound to its `out` globals by constraints.  Declared synthetic: the real
+    join additionally VERIFIES its children in-circuit (risc0-circuit-recursion 4.0.2, un-vendored)."""
+    return build_syn_air(16, 128, 16, n_pub=JOIN_PUB_WORDS)
+
+
+def syn_keccak() -> np.ndarray:
+    """SYN-K: a third circuit through the same HAL with keccak-coprocessor-like proportions — very wide data group,
+    narrow code/accum (risc0-circuit-keccak 4.0.2 is un-vendored: /root/reference/Cargo.lock:5289; zeth's guest reaches it
+    through the patched tiny-keccak, /root/reference/guests/stateless-client/Cargo.toml:39).  Declared synthetic."""
+    return build_syn_air(8, 880, 8)
 
 
 if __name__ == "__main__":      # python -m zeth_amd.circuits.syn_air syn_a out.desc  (blob for non-Python hosts)
     import sys
     shape, path = sys.argv[1], sys.argv[2]
-    blob = {"syn_a": syn_a, "syn_tiny": syn_tiny, "syn_small": syn_small, "syn_join": syn_join}[shape]()
+    blob = {"syn_a": syn_a, "syn_tiny": syn_tiny, "syn_small": syn_small, "syn_join": syn_join, "syn_keccak": syn_keccak}[shape]()
     np.asarray(blob, dtype="<u4").tofile(path)
     print(f"{path}: {blob.size} words")

@@ -87,6 +87,9 @@ __device__ __forceinline__ uint32_t syn_cell(uint64_t seed, uint32_t group, uint
     z ^= z >> 31;
     return mul_mod(R2, (uint32_t)(z >> 32) % P);
 }
+// The code group is a function of (circuit, po2, zk_cycles) only, like upstream's control columns: its Merkle root is the
+// control root the verifier checks.
+constexpr uint64_t SYN_CODE_SEED = 0xC0DEC0DE5EEDull;
 __global__ void k_syn_code(uint32_t* code, uint32_t wc, uint32_t n, uint32_t A, uint64_t seed) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y;
     if (r >= n) return;
@@ -102,7 +105,9 @@ __global__ void k_syn_code(uint32_t* code, uint32_t wc, uint32_t n, uint32_t A, 
     code[(size_t)col * n + r] = v;
 }
 // one lane per row: free cells, products, and the running-sum increment (scanned afterwards)
-__global__ void k_syn_data(uint32_t* data, uint32_t wd, uint32_t n, uint32_t A, uint64_t seed, uint64_t noise_seed) {
+// pub: n_pub public input words; word k replaces the x cell of triple k in row 0 (bound to out[4 + k] by a constraint)
+__global__ void k_syn_data(uint32_t* data, uint32_t wd, uint32_t n, uint32_t A, uint64_t seed, uint64_t noise_seed,
+                           const uint32_t* __restrict__ pub, uint32_t n_pub) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const uint32_t T = (wd - 2) / 3;
@@ -112,7 +117,9 @@ __global__ void k_syn_data(uint32_t* data, uint32_t wd, uint32_t n, uint32_t A, 
     }
     uint32_t d0 = 0, d1 = 0, d3 = 0, d4 = 0;
     for (uint32_t j = 0; j < T; j++) {
-        const uint32_t x = syn_cell(seed, GROUP_DATA, 3 * j, r), y = syn_cell(seed, GROUP_DATA, 3 * j + 1, r);
+        uint32_t x = syn_cell(seed, GROUP_DATA, 3 * j, r);
+        if (r == 0 && j < n_pub) x = pub[j];
+        const uint32_t y = syn_cell(seed, GROUP_DATA, 3 * j + 1, r);
         const uint32_t pr = mul_mod(x, y);
         data[(size_t)(3 * j) * n + r] = x; data[(size_t)(3 * j + 1) * n + r] = y; data[(size_t)(3 * j + 2) * n + r] = pr;
         if (j == 0) { d0 = x; d1 = y; }
@@ -342,6 +349,7 @@ extern "C" const char* zkh_circuit_load(zkh_ctx* ctx, const uint32_t* d, size_t 
 }
 extern "C" void zkh_circuit_destroy(zkh_circuit* c) {
     if (!c) return;
+    if (c->ctx) bind_thread(c->ctx);
     if (c->d_prog) (void)hipFree(c->d_prog);
     if (c->d_taps) (void)hipFree(c->d_taps);
     if (c->jit_module) (void)hipModuleUnload(c->jit_module);
@@ -370,10 +378,14 @@ extern "C" const char* zkh_circuit_attach_code_object(zkh_circuit* c, const void
     return nullptr;
 }
 
-extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_buf* check, const zkh_buf* const* groups,
-                                      const zkh_buf* const* globals, const uint32_t poly_mix[4], size_t po2, int use_interpreter) {
+extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_buf* check, const zkh_buf* const* groups, size_t n_groups,
+                                      const zkh_buf* const* globals, size_t n_globals, const uint32_t poly_mix[4], size_t po2,
+                                      size_t steps, int use_interpreter) {
     ZKH_REQUIRE(c->ctx == ctx && c->d_prog, "eval_check: circuit was not loaded on this context");
+    ZKH_REQUIRE(n_groups == 3 && n_globals == 2, "eval_check: expected 3 register groups (accum, code, data) and 2 global groups (out, mix), got %zu / %zu",
+                n_groups, n_globals);
     const size_t n = (size_t)1 << po2, dom = n * ZKH_INV_RATE;
+    ZKH_REQUIRE(steps == n, "eval_check: steps %zu != 2^po2 = %zu", steps, n);
     ZKH_REQUIRE(po2 + 2 <= (size_t)MAX_LOG_N, "eval_check: po2 %zu too large", po2);
     ZKH_REQUIRE(check->len == ZKH_EXT_SIZE * dom, "eval_check: check buffer must hold 4 x 4n words");
     for (int g = 0; g < 3; g++)
@@ -423,18 +435,33 @@ extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_bu
 }
 
 // ---- SYN-AIR witness ----
+extern "C" const char* zkh_syn_code(zkh_ctx* ctx, const zkh_circuit* c, size_t po2, size_t zk_cycles, zkh_buf* code) {
+    ZKH_REQUIRE(c->kind == 1, "syn_code: circuit is not SYN-AIR");
+    const size_t n = (size_t)1 << po2;
+    ZKH_REQUIRE(n > zk_cycles + 1, "syn_code: po2 too small for zk_cycles");
+    const uint32_t wc = c->group_size[GROUP_CODE], A = (uint32_t)(n - zk_cycles);
+    ZKH_REQUIRE(code->len == (size_t)wc * n, "syn_code: buffer shape mismatch");
+    ProfScope prof(ctx, "syn_code", 4.0 * wc * n);
+    k_syn_code<<<dim3((unsigned)((n + 255) / 256), wc), 256, 0, ctx->stream>>>(code->ptr(), wc, (uint32_t)n, A, SYN_CODE_SEED);
+    return last_launch_error("syn_code");
+}
 extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t po2, size_t zk_cycles, uint64_t seed,
-                                      uint64_t noise_seed, zkh_buf* code, zkh_buf* data, uint32_t out_global[4]) {
+                                      uint64_t noise_seed, const uint32_t* pub, zkh_buf* code, zkh_buf* data, uint32_t* out_global) {
     ZKH_REQUIRE(c->kind == 1, "syn_witgen: circuit is not SYN-AIR");
     const size_t n = (size_t)1 << po2;
     ZKH_REQUIRE(n > zk_cycles + 1, "syn_witgen: po2 too small for zk_cycles");
     const uint32_t wc = c->group_size[GROUP_CODE], wd = c->group_size[GROUP_DATA], A = (uint32_t)(n - zk_cycles);
+    const uint32_t n_pub = c->global_size[GLOBAL_OUT] - 4;
     ZKH_REQUIRE(code->len == (size_t)wc * n && data->len == (size_t)wd * n, "syn_witgen: buffer shape mismatch");
-    zkh_buf* last = nullptr;
+    ZKH_REQUIRE(n_pub == 0 || pub, "syn_witgen: the circuit has %u public input words but none were given", n_pub);
+    for (uint32_t k = 0; k < n_pub; k++) ZKH_REQUIRE(pub[k] < P, "syn_witgen: public input %u is not a reduced element", k);
+    ZKH_TRY(zkh_syn_code(ctx, c, po2, zk_cycles, code));
+    zkh_buf *last = nullptr, *dpub = nullptr;
     ZKH_TRY(new_buf(ctx, 1, false, &last));
+    if (n_pub) ZKH_TRY(zkh_copy_from(ctx, "pub", pub, n_pub, &dpub));
     const unsigned bx = (unsigned)((n + 255) / 256);
-    k_syn_code<<<dim3(bx, wc), 256, 0, ctx->stream>>>(code->ptr(), wc, (uint32_t)n, A, seed);
-    k_syn_data<<<bx, 256, 0, ctx->stream>>>(data->ptr(), wd, (uint32_t)n, A, seed, noise_seed);
+    k_syn_data<<<bx, 256, 0, ctx->stream>>>(data->ptr(), wd, (uint32_t)n, A, seed, noise_seed, dpub ? dpub->ptr() : nullptr, n_pub);
+    if (dpub) zkh_release(dpub);
     {
         const unsigned chunks = (A + 1023) / 1024;
         zkh_buf* totals = nullptr;
@@ -447,6 +474,7 @@ extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t
     }
     ZKH_TRY(last_launch_error("syn_witgen"));
     out_global[1] = out_global[2] = out_global[3] = 0;
+    for (uint32_t k = 0; k < n_pub; k++) out_global[4 + k] = pub[k];
     const char* err = zkh_read(ctx, last, out_global, 0, 1);
     zkh_release(last);
     return err;

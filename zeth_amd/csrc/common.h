@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -63,18 +64,22 @@ struct ProfPending { std::string name; hipEvent_t a, b; double bytes; };
 
 }  // namespace zkh
 
+// Reference counts are atomic so that handles may be retained / released from any host thread; everything that touches
+// the context itself (pool, stream, staging ring) stays single-threaded per context, as include/zkhal.h states.
 struct zkh_alloc_t {
     void* ptr;
     size_t bytes;
-    int refs;
+    std::atomic<int> refs;
     bool owned;
     zkh_ctx* ctx;
+    zkh_alloc_t(void* p, size_t b, int r, bool o, zkh_ctx* c) : ptr(p), bytes(b), refs(r), owned(o), ctx(c) {}
 };
 
 struct zkh_buf {
     zkh_alloc_t* a;
     size_t off, len;   // words
-    int refs;
+    std::atomic<int> refs;
+    zkh_buf(zkh_alloc_t* al, size_t o, size_t l, int r) : a(al), off(o), len(l), refs(r) {}
     uint32_t* ptr() const { return (uint32_t*)a->ptr + off; }
 };
 
@@ -93,6 +98,7 @@ struct zkh_ctx {
     uint32_t* pinned = nullptr;                  // host staging
     size_t pinned_words = 0;
     size_t stage_next = 0, stage_used = 0;       // pinned staging ring for small uploads (hal.hip h2d)
+    std::map<void*, size_t> host_blocks;         // pinned host memory handed to the caller (zkh_host_alloc): ptr -> bytes
 };
 
 namespace zkh {
@@ -105,11 +111,11 @@ void prof_end(zkh_ctx* c);
 const char* ensure_pinned(zkh_ctx* c, size_t words);
 
 // The HIP "current device" is per host thread: every entry point binds the calling thread to the context's GPU
-// (several host threads may each drive their own context on the same or on different GPUs).
-inline void bind_thread(const zkh_ctx* c) {
-    static thread_local int bound = -1;
-    if (bound != c->device) { (void)hipSetDevice(c->device); bound = c->device; }
-}
+// (several host threads may each drive their own context on the same or on different GPUs).  No caching: other code
+// on this thread (a torch synchronize, the embedding host) may have selected another device since the last call.
+inline void bind_thread(const zkh_ctx* c) { (void)hipSetDevice(c->device); }
+// per-device kernel attributes (dynamic LDS sizes); set when a context is created on the device (ntt.hip)
+const char* ntt_device_init(zkh_ctx* c);
 
 // Launch helper: optional HIP-event bracket on the ctx stream (what bench.py's roofline uses).
 struct ProfScope {

@@ -8,7 +8,13 @@
 using namespace zkh;
 
 extern "C" void zkh_free_error(const char* e) { free((void*)e); }
-extern "C" const char* zkh_version(void) { return "zkhal-mi355x 0.1.0 (gfx950)"; }
+// The version string names the two data items that are known placeholders: nobody should mistake a
+// digest produced with them for an upstream-compatible one.
+#if ZKH_P2_CONSTS_ARE_PLACEHOLDER
+extern "C" const char* zkh_version(void) { return "zkhal-mi355x 0.2.0 (gfx950; poseidon2_consts=placeholder)"; }
+#else
+extern "C" const char* zkh_version(void) { return "zkhal-mi355x 0.2.0 (gfx950; poseidon2_consts=upstream)"; }
+#endif
 
 namespace zkh {
 
@@ -51,8 +57,8 @@ const char* new_buf(zkh_ctx* c, size_t n_words, bool zero, zkh_buf** out) {
         hipError_t e = hipMemsetAsync(p, 0, n_words * 4, c->stream);
         if (e != hipSuccess) return make_err("hipMemsetAsync: %s", hipGetErrorString(e));
     }
-    zkh_alloc_t* a = new zkh_alloc_t{p, n_words * 4, 1, true, c};
-    *out = new zkh_buf{a, 0, n_words, 1};
+    zkh_alloc_t* a = new zkh_alloc_t(p, n_words * 4, 1, true, c);
+    *out = new zkh_buf(a, 0, n_words, 1);
     return nullptr;
 }
 const char* ensure_pinned(zkh_ctx* c, size_t words) {
@@ -103,6 +109,7 @@ static std::vector<uint32_t> powers(Fp base, size_t n) {
 }  // namespace zkh
 
 extern "C" const char* zkh_poseidon2_set_constants(zkh_ctx* c, const uint32_t* rc, const uint32_t* diag) {
+    bind_thread(c);
     std::vector<uint32_t> r(24 * 29), d(ZKH_P2_PTAB);
     for (int i = 0; i < 24 * 29; i++) r[i] = fp_encode(rc[i]).v - P;   // stored as rc - P: see poseidon2.h sbox7_rc
     poseidon2_partial_table(d.data(), diag);
@@ -155,6 +162,7 @@ extern "C" const char* zkh_ctx_create(int device, const char* suite, zkh_ctx** o
     ZKH_TRY(upload(&c->tab.rc, std::vector<uint32_t>(24 * 29)));
     ZKH_TRY(upload(&c->tab.diag, std::vector<uint32_t>(ZKH_P2_PTAB)));
     ZKH_TRY(zkh_poseidon2_set_constants(c, ZKH_P2_ROUND_CONSTANTS, ZKH_P2_M_INT_DIAG));
+    ZKH_TRY(ntt_device_init(c));
     *out = c;
     return nullptr;
 }
@@ -181,6 +189,7 @@ extern "C" void zkh_ctx_destroy(zkh_ctx* c) {
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    for (auto& kv : c->host_blocks) (void)hipHostFree(kv.first);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -220,21 +229,21 @@ extern "C" const char* zkh_copy_from(zkh_ctx* c, const char*, const uint32_t* ho
     return h2d(c, (*out)->ptr(), host, n);
 }
 extern "C" const char* zkh_wrap(zkh_ctx* c, void* dptr, size_t n, zkh_buf** out) {
-    zkh_alloc_t* a = new zkh_alloc_t{dptr, n * 4, 1, false, c};
-    *out = new zkh_buf{a, 0, n, 1};
+    zkh_alloc_t* a = new zkh_alloc_t(dptr, n * 4, 1, false, c);
+    *out = new zkh_buf(a, 0, n, 1);
     return nullptr;
 }
 extern "C" const char* zkh_slice(zkh_buf* b, size_t off, size_t n, zkh_buf** out) {
     ZKH_REQUIRE(off + n <= b->len, "slice [%zu, %zu) out of range (size %zu)", off, off + n, b->len);
-    b->a->refs++;
-    *out = new zkh_buf{b->a, b->off + off, n, 1};
+    b->a->refs.fetch_add(1, std::memory_order_relaxed);
+    *out = new zkh_buf(b->a, b->off + off, n, 1);
     return nullptr;
 }
-extern "C" void zkh_retain(zkh_buf* b) { b->refs++; }
+extern "C" void zkh_retain(zkh_buf* b) { b->refs.fetch_add(1, std::memory_order_relaxed); }
 extern "C" void zkh_release(zkh_buf* b) {
-    if (!b || --b->refs > 0) return;
+    if (!b || b->refs.fetch_sub(1, std::memory_order_acq_rel) > 1) return;
     zkh_alloc_t* a = b->a;
-    if (--a->refs == 0) {
+    if (a->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) {
         if (a->owned) pool_free(a->ctx, a->ptr, a->bytes);
         delete a;
     }
@@ -254,6 +263,45 @@ extern "C" const char* zkh_write(zkh_ctx* c, zkh_buf* b, const uint32_t* host, s
     bind_thread(c);
     ZKH_REQUIRE(off + n <= b->len, "write [%zu, %zu) out of range (size %zu)", off, off + n, b->len);
     return h2d(c, b->ptr() + off, host, n);
+}
+
+// ---- witness ingress: pinned host memory + asynchronous upload ----
+// A host that produces the witness on the CPU (upstream: preflight + witgen) writes it straight
+// into pinned memory and enqueues the upload; the copy is a DMA on this context's stream, so it overlaps the kernels of the
+// OTHER contexts sealing on the same GPU (bench.py keeps three seals in flight) and returns without a host sync.
+extern "C" const char* zkh_host_alloc(zkh_ctx* c, size_t n_words, uint32_t** host) {
+    ZKH_REQUIRE(c && host && n_words, "host_alloc: bad argument");
+    bind_thread(c);
+    void* p = nullptr;
+    ZKH_HIP(hipHostMalloc(&p, n_words * 4, hipHostMallocDefault));
+    c->host_blocks[p] = n_words * 4;
+    *host = (uint32_t*)p;
+    return nullptr;
+}
+extern "C" void zkh_host_free(zkh_ctx* c, uint32_t* host) {
+    if (!c || !host) return;
+    auto it = c->host_blocks.find((void*)host);
+    if (it == c->host_blocks.end()) return;
+    bind_thread(c);
+    (void)hipStreamSynchronize(c->stream);           // an upload from this block may still be in flight
+    (void)hipHostFree(it->first);
+    c->host_blocks.erase(it);
+}
+extern "C" const char* zkh_write_async(zkh_ctx* c, zkh_buf* b, const uint32_t* pinned_host, size_t off, size_t n) {
+    bind_thread(c);
+    ZKH_REQUIRE(off + n <= b->len, "write_async [%zu, %zu) out of range (size %zu)", off, off + n, b->len);
+    // the source must lie inside a block from zkh_host_alloc: only then is the copy a true asynchronous DMA, and only then
+    // does the library know the memory stays mapped until zkh_host_free (which drains the stream first)
+    auto it = c->host_blocks.upper_bound((void*)pinned_host);
+    bool inside = false;
+    if (it != c->host_blocks.begin()) {
+        --it;
+        const char* base = (const char*)it->first;
+        inside = (const char*)pinned_host >= base && (const char*)(pinned_host + n) <= base + it->second;
+    }
+    ZKH_REQUIRE(inside, "write_async: the source is not inside a zkh_host_alloc block of this context");
+    if (n) ZKH_HIP(hipMemcpyAsync(b->ptr() + off, pinned_host, n * 4, hipMemcpyHostToDevice, c->stream));
+    return nullptr;
 }
 
 // ---- profiling ----

@@ -553,13 +553,6 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
             else if (lazy) k_ntt_low12<false, true><<<grid, 256, 0, c->stream>>>(p);
             else k_ntt_low12<false><<<grid, 256, 0, c->stream>>>(p);
         } else if (ps.L >= 4 && p.log_t == 4 && ps.R == 10 && !(scale_here && p.zk_shift)) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute((const void*)k_ntt_high<10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-                (void)hipFuncSetAttribute((const void*)k_ntt_high<10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-                (void)hipFuncSetAttribute((const void*)k_ntt_high<10, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-                attr_set = true;
-            }
             if (inverse) k_ntt_high<10, true><<<grid, 1024, lds, c->stream>>>(p);
             else if (lazy) k_ntt_high<10, false, true><<<grid, 1024, lds, c->stream>>>(p);
             else k_ntt_high<10, false><<<grid, 1024, lds, c->stream>>>(p);
@@ -575,6 +568,16 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
 }
 
 }  // namespace
+
+// Dynamic-LDS limits are per (function, device): set them for the device of every context that is created, and fail the
+// context creation if the device refuses (hal.hip calls this from zkh_ctx_create).
+const char* zkh::ntt_device_init(zkh_ctx* c) {
+    bind_thread(c);
+    ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high<10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high<10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high<10, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    return nullptr;
+}
 
 static const char* interpolate_impl(zkh_ctx* c, zkh_buf* io, size_t count, bool zk, const char* name) {
     ZKH_REQUIRE(count && io->len % count == 0, "%s: size %zu not a multiple of count %zu", name, io->len, count);

@@ -214,59 +214,126 @@ static const char* commit_group(zkh_ctx* c, Iop& iop, PolyGroup& pg, const zkh_b
     return commit_group_finish(c, iop, pg);
 }
 
-extern "C" const char* zkh_prove_segment(zkh_prover* pr, size_t po2, size_t zk_cycles, uint64_t noise_seed, const zkh_buf* code,
-                                         const zkh_buf* data, const uint32_t out_global[4], uint32_t** seal, size_t* seal_words) {
+// An in-progress seal: everything Prover::commit_group has produced so far.  Upstream's SegmentProver drives
+// `Prover` in exactly these two halves — commit code and data, draw the accum mix from the transcript, let the
+// circuit's accum witness generator run (CircuitHal::accumulate, circuit-specific), then commit accum and finalize.
+struct zkh_seal_job {
+    zkh_prover* pr;
+    size_t po2;
+    Iop iop;
+    PolyGroup groups[3];
+    std::vector<uint32_t> out_global, mix_global;
+};
+
+extern "C" void zkh_prove_abort(zkh_seal_job* job) { delete job; }
+
+extern "C" const char* zkh_prove_begin(zkh_prover* pr, size_t po2, const zkh_buf* code, const zkh_buf* data,
+                                       const uint32_t* out_global, zkh_seal_job** out_job, uint32_t* mix_out) {
+    ZKH_REQUIRE(pr && code && data && out_global && out_job, "prove_begin: null argument");
     zkh_ctx* c = pr->ctx;
     const zkh_circuit* cir = pr->circuit;
-    ZKH_REQUIRE(po2 + 2 <= (size_t)MAX_LOG_N, "prove_segment: po2 %zu too large (max %d)", po2, MAX_LOG_N - 2);
-    ZKH_REQUIRE(cir->global_size[GLOBAL_OUT] == 4, "prove_segment: OUTPUT_SIZE must be 4");
-    const size_t n = (size_t)1 << po2, dom = n * ZKH_INV_RATE;
-    ZKH_REQUIRE(n > zk_cycles + 1, "prove_segment: po2 too small for zk_cycles");
-    const size_t wa = cir->group_size[GROUP_ACCUM], wc = cir->group_size[GROUP_CODE], wd = cir->group_size[GROUP_DATA];
-    Iop iop;
+    ZKH_REQUIRE(po2 >= 1 && po2 + 2 <= (size_t)MAX_LOG_N, "prove_begin: po2 %zu too large (max %d)", po2, MAX_LOG_N - 2);
+    const size_t n = (size_t)1 << po2;
+    const size_t wc = cir->group_size[GROUP_CODE], wd = cir->group_size[GROUP_DATA];
+    const size_t out_size = cir->global_size[GLOBAL_OUT];
+    std::unique_ptr<zkh_seal_job> job(new zkh_seal_job());
+    job->pr = pr; job->po2 = po2;
+    Iop& iop = job->iop;
     iop.rng.h = &pr->hash;
-
-    // ---- header: out globals + po2, bound into the transcript ----
+    // ---- header: out globals + po2, both as field elements (write_field_elem_slice), bound into the transcript ----
+    job->out_global.assign(out_global, out_global + out_size);
+    for (size_t i = 0; i < out_size; i++) ZKH_REQUIRE(out_global[i] < P, "prove_begin: output global %zu is not a reduced element", i);
     {
-        uint32_t hdr[5];
-        memcpy(hdr, out_global, 16);
-        hdr[4] = fp_encode((uint32_t)po2).v;
-        iop.write(out_global, 4);
-        const uint32_t p = (uint32_t)po2;
-        iop.write(&p, 1);
+        std::vector<uint32_t> hdr(job->out_global);
+        hdr.push_back(fp_encode((uint32_t)po2).v);
+        iop.write(hdr.data(), hdr.size());
         uint32_t dg[8];
-        pr->hash.hash_elems(hdr, 5, dg);
+        pr->hash.hash_elems(hdr.data(), hdr.size(), dg);
         iop.commit(dg);
     }
-    // ---- commit code, data ----
-    PolyGroup groups[3];
-    // neither commitment depends on a challenge, so both groups are queued before the first root is read back; the
-    // transcript still absorbs them in upstream's order (code, then data)
-    ZKH_TRY(commit_group_enqueue(c, groups[GROUP_CODE], code, wc, n));
-    ZKH_TRY(commit_group_enqueue(c, groups[GROUP_DATA], data, wd, n));
-    ZKH_TRY(commit_group_finish(c, iop, groups[GROUP_CODE]));
-    ZKH_TRY(commit_group_finish(c, iop, groups[GROUP_DATA]));
-    // ---- accum: mix challenges -> accum witness -> commit ----
-    std::vector<uint32_t> mix_global(cir->global_size[GLOBAL_MIX] ? cir->global_size[GLOBAL_MIX] : 1);
-    for (size_t i = 0; i < cir->global_size[GLOBAL_MIX]; i++) mix_global[i] = iop.rng.random_elem();
-    {
-        ZKH_REQUIRE(cir->kind == 1, "prove_segment: no accum witness generator for circuit kind %u", cir->kind);
-        Buf accum;
-        ZKH_TRY(zkh_alloc(c, "accum", wa * n, 0, accum.out()));
-        ZKH_TRY(zkh_syn_accum(c, cir, po2, zk_cycles, noise_seed, data, mix_global.data(), accum));
-        ZKH_TRY(commit_group(c, iop, groups[GROUP_ACCUM], accum, wa, n));
-    }
+    // ---- commit code, data: neither commitment depends on a challenge, so both groups are queued before the first
+    // root is read back; the transcript still absorbs them in upstream's order (code, then data)
+    ZKH_TRY(commit_group_enqueue(c, job->groups[GROUP_CODE], code, wc, n));
+    ZKH_TRY(commit_group_enqueue(c, job->groups[GROUP_DATA], data, wd, n));
+    ZKH_TRY(commit_group_finish(c, iop, job->groups[GROUP_CODE]));
+    ZKH_TRY(commit_group_finish(c, iop, job->groups[GROUP_DATA]));
+    // ---- accum mix challenges ----
+    job->mix_global.resize(cir->global_size[GLOBAL_MIX] ? cir->global_size[GLOBAL_MIX] : 1);
+    for (size_t i = 0; i < cir->global_size[GLOBAL_MIX]; i++) job->mix_global[i] = iop.rng.random_elem();
+    if (mix_out) memcpy(mix_out, job->mix_global.data(), 4 * cir->global_size[GLOBAL_MIX]);
+    *out_job = job.release();
+    return nullptr;
+}
+
+static const char* prove_finish_impl(zkh_seal_job* job, const zkh_buf* accum, uint32_t** seal, size_t* seal_words);
+
+extern "C" const char* zkh_prove_finish(zkh_seal_job* job_raw, const zkh_buf* accum, uint32_t** seal, size_t* seal_words) {
+    ZKH_REQUIRE(job_raw && accum && seal && seal_words, "prove_finish: null argument");
+    std::unique_ptr<zkh_seal_job> job(job_raw);      // consumed whether or not the seal succeeds
+    return prove_finish_impl(job.get(), accum, seal, seal_words);
+}
+
+// SegmentProver::prove for the SYN-AIR family (kind 1), whose accum witness generator lives in this library.
+extern "C" const char* zkh_prove_segment(zkh_prover* pr, size_t po2, size_t zk_cycles, uint64_t noise_seed, const zkh_buf* code,
+                                         const zkh_buf* data, const uint32_t* out_global, uint32_t** seal, size_t* seal_words) {
+    zkh_ctx* c = pr->ctx;
+    const zkh_circuit* cir = pr->circuit;
+    ZKH_REQUIRE(cir->kind == 1, "prove_segment: no built-in accum witness generator for circuit kind %u (use zkh_prove_begin / zkh_prove_finish)", cir->kind);
+    ZKH_REQUIRE(po2 + 2 <= (size_t)MAX_LOG_N, "prove_segment: po2 %zu too large (max %d)", po2, MAX_LOG_N - 2);
+    const size_t n = (size_t)1 << po2;
+    ZKH_REQUIRE(n > zk_cycles + 1, "prove_segment: po2 too small for zk_cycles");
+    zkh_seal_job* job_raw = nullptr;
+    ZKH_TRY(zkh_prove_begin(pr, po2, code, data, out_global, &job_raw, nullptr));
+    std::unique_ptr<zkh_seal_job> job(job_raw);
+    Buf accum;
+    ZKH_TRY(zkh_alloc(c, "accum", (size_t)cir->group_size[GROUP_ACCUM] * n, 0, accum.out()));
+    ZKH_TRY(zkh_syn_accum(c, cir, po2, zk_cycles, noise_seed, data, job->mix_global.data(), accum));
+    return prove_finish_impl(job.get(), accum, seal, seal_words);
+}
+
+// Merkle root of the committed code group — the control-ID analogue that zkh_verify_segment checks (verify/mod.rs
+// check_code).  Same commit_group as the seal's, so the root equals what a seal of this code trace carries.
+extern "C" const char* zkh_code_root(zkh_prover* pr, const zkh_buf* code, size_t po2, uint32_t root[8]) {
+    ZKH_REQUIRE(pr && code && root, "code_root: null argument");
+    ZKH_REQUIRE(po2 >= 1 && po2 + 2 <= (size_t)MAX_LOG_N, "code_root: po2 %zu out of range", po2);
+    PolyGroup pg;
+    ZKH_TRY(commit_group_enqueue(pr->ctx, pg, code, pr->circuit->group_size[GROUP_CODE], (size_t)1 << po2));
+    ZKH_TRY(pg.merkle.fetch_top(pr->ctx));
+    memcpy(root, pg.merkle.root(), 32);
+    return nullptr;
+}
+extern "C" const char* zkh_syn_control_root(zkh_prover* pr, size_t po2, size_t zk_cycles, uint32_t root[8]) {
+    ZKH_REQUIRE(pr && root, "syn_control_root: null argument");
+    ZKH_REQUIRE(po2 >= 1 && po2 + 2 <= (size_t)MAX_LOG_N && ((size_t)1 << po2) > zk_cycles + 1, "syn_control_root: po2 %zu out of range", po2);
+    Buf code;
+    ZKH_TRY(zkh_alloc(pr->ctx, "code", (size_t)pr->circuit->group_size[GROUP_CODE] << po2, 0, code.out()));
+    ZKH_TRY(zkh_syn_code(pr->ctx, pr->circuit, po2, zk_cycles, code));
+    return zkh_code_root(pr, code, po2, root);
+}
+
+static const char* prove_finish_impl(zkh_seal_job* job, const zkh_buf* accum_trace, uint32_t** seal, size_t* seal_words) {
+    zkh_prover* pr = job->pr;
+    zkh_ctx* c = pr->ctx;
+    const zkh_circuit* cir = pr->circuit;
+    const size_t po2 = job->po2;
+    const size_t n = (size_t)1 << po2, dom = n * ZKH_INV_RATE;
+    const size_t wa = cir->group_size[GROUP_ACCUM];
+    Iop& iop = job->iop;
+    PolyGroup* groups = job->groups;
+    const std::vector<uint32_t>& mix_global = job->mix_global;
+    const uint32_t* out_global = job->out_global.data();
+    ZKH_TRY(commit_group(c, iop, groups[GROUP_ACCUM], accum_trace, wa, n));
     // ---- finalize: constraint polynomial ----
     const Fp4 poly_mix = iop.rng.random_ext();
     PolyGroup check_group;
     {
         Buf check, g_out, g_mix;
         ZKH_TRY(zkh_alloc(c, "check_poly", ZKH_EXT_SIZE * dom, 0, check.out()));
-        ZKH_TRY(zkh_copy_from(c, "out", out_global, 4, g_out.out()));
+        ZKH_TRY(zkh_copy_from(c, "out", out_global, job->out_global.size(), g_out.out()));
         ZKH_TRY(zkh_copy_from(c, "mix", mix_global.data(), mix_global.size(), g_mix.out()));
         const zkh_buf* gev[3] = {groups[0].evaluated, groups[1].evaluated, groups[2].evaluated};
         const zkh_buf* globals[2] = {g_out, g_mix};
-        ZKH_TRY(zkh_eval_check(c, cir, check, gev, globals, (const uint32_t*)&poly_mix, po2, 0));
+        ZKH_TRY(zkh_eval_check(c, cir, check, gev, 3, globals, 2, (const uint32_t*)&poly_mix, po2, n, 0));
         ZKH_TRY(zkh_batch_interpolate_ntt(c, check, ZKH_EXT_SIZE));
         // 4 polys of degree 4n reinterpreted as 16 of degree n (bit-reversed layout makes them contiguous quarters)
         ZKH_TRY(check_group.build(c, std::move(check), ZKH_CHECK_SIZE, n));

@@ -170,9 +170,30 @@ Fp4 fold_eval(Fp4 (&v)[16], Fp4 mix, Fp inv_wk, const uint32_t (&rou_rev)[28]) {
 
 }  // namespace
 
-extern "C" const char* zkh_verify_segment(const zkh_circuit* c, const uint32_t* seal, size_t seal_words,
+// Claim digest of a sealed segment: Poseidon2 over (out globals, po2 as an Elem, control root).  A join's public inputs are
+// the claims of the two receipts it combines (host.py SuccinctReceipt); upstream's ReceiptClaim digests play this role.
+extern "C" const char* zkh_receipt_claim(const zkh_circuit* c, const uint32_t* seal, size_t seal_words, const uint32_t* control_root,
+                                         const uint32_t* rc_canonical, const uint32_t* diag_canonical, uint32_t claim[8]) {
+    ZKH_REQUIRE(c && seal && control_root && claim, "receipt_claim: null argument");
+    const size_t out_size = c->global_size[GLOBAL_OUT];
+    ZKH_REQUIRE(seal_words > out_size, "receipt_claim: seal truncated (header)");
+    std::unique_ptr<Tables> tab(new Tables);
+    make_tables(*tab, rc_canonical ? rc_canonical : ZKH_P2_ROUND_CONSTANTS, diag_canonical ? diag_canonical : ZKH_P2_M_INT_DIAG);
+    Hasher hasher{tab.get()};
+    std::vector<uint32_t> in(seal, seal + out_size + 1);
+    in.insert(in.end(), control_root, control_root + 8);
+    ZKH_REQUIRE(reduced(in.data(), in.size()), "receipt_claim: unreduced header or control root word");
+    const Digest d = hasher.elems(in.data(), in.size());
+    memcpy(claim, d.w, 32);
+    return nullptr;
+}
+
+extern "C" const char* zkh_verify_segment(const zkh_circuit* c, const uint32_t* seal, size_t seal_words, const uint32_t* control_root,
                                           const uint32_t* rc_canonical, const uint32_t* diag_canonical) {
     ZKH_REQUIRE(c && seal, "verify_segment: null argument");
+    // verify/mod.rs check_code: without the expected code commitment a prover may commit ANY code trace (e.g. all-zero
+    // selectors, which switch every gated constraint off) and "prove" an arbitrary output
+    ZKH_REQUIRE(control_root, "verify_segment: no control root given (the expected code commitment for this circuit and po2)");
     std::unique_ptr<Tables> tab(new Tables);
     make_tables(*tab, rc_canonical ? rc_canonical : ZKH_P2_ROUND_CONSTANTS, diag_canonical ? diag_canonical : ZKH_P2_M_INT_DIAG);
     Hasher hasher{tab.get()};
@@ -184,22 +205,18 @@ extern "C" const char* zkh_verify_segment(const zkh_circuit* c, const uint32_t* 
     }
 #define VFAIL(msg) return make_err("verify_segment: %s", msg)
     // header
-    const uint32_t* out_global = io.read(4);
-    const uint32_t* ppo2 = io.read(1);
-    if (!out_global || !ppo2) VFAIL("seal truncated (header)");
-    const uint32_t po2 = *ppo2;
-    if (po2 < 1 || po2 + 2 > 27) VFAIL("bad po2");
-    if (!reduced(out_global, 4)) VFAIL("unreduced output global");
-    {
-        uint32_t hdr[5];
-        memcpy(hdr, out_global, 16);
-        hdr[4] = fp_encode(po2).v;
-        io.commit(hasher.elems(hdr, 5));
-    }
+    const size_t out_size = c->global_size[GLOBAL_OUT];
+    const uint32_t* out_global = io.read(out_size + 1);            // out words, then po2 as an Elem
+    if (!out_global) VFAIL("seal truncated (header)");
+    if (!reduced(out_global, out_size + 1)) VFAIL("unreduced output global");
+    const uint32_t po2 = fp_decode(Fp::raw(out_global[out_size]));
+    if (po2 < 1 || po2 + 2 > (uint32_t)MAX_LOG_N) VFAIL("bad po2");
+    io.commit(hasher.elems(out_global, out_size + 1));
     const size_t size = (size_t)1 << po2, domain = size * ZKH_INV_RATE;
     TreeVerifier tg[3], tcheck;
     const char* e;
     if ((e = tg[GROUP_CODE].init(io, domain, c->group_size[GROUP_CODE]))) VFAIL(e);
+    if (memcmp(tg[GROUP_CODE].top[1].w, control_root, 32) != 0) VFAIL("code root does not match the control root");
     if ((e = tg[GROUP_DATA].init(io, domain, c->group_size[GROUP_DATA]))) VFAIL(e);
     std::vector<uint32_t> mix_global(c->global_size[GLOBAL_MIX] + 1);
     for (uint32_t i = 0; i < c->global_size[GLOBAL_MIX]; i++) mix_global[i] = io.elem();

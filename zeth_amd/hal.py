@@ -17,6 +17,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ZKH_LIBRARY") or os.path.join(_HERE, "libzkhal_mi355x.so")   # override: another build of the same ABI
 
 INV_RATE, QUERIES, FRI_FOLD, FRI_MIN_DEGREE, ZK_CYCLES, CHECK_SIZE, EXT_SIZE, DIGEST_WORDS = 4, 50, 16, 256, 1994, 16, 4, 8
+P = 2013265921                      # BabyBear
+_RINV = pow(1 << 32, -1, P)
+
+
+def fp_decode(word: int) -> int:
+    """Montgomery word -> canonical residue (seal words are raw Montgomery `Elem`s, like upstream's)."""
+    return (int(word) * _RINV) % P
+
+
+def fp_encode(x: int) -> int:
+    return ((int(x) % P) << 32) % P
 
 # every symbol include/zkhal.h declares: (restype, argtypes)
 _sz, _u32, _u64, _vp, _i = C.c_size_t, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int
@@ -48,6 +59,9 @@ ABI = {
     "zkh_device_ptr": (_vp, [_vp]),
     "zkh_read": (_err, [_vp, _vp, _u32p, _sz, _sz]),
     "zkh_write": (_err, [_vp, _vp, _u32p, _sz, _sz]),
+    "zkh_host_alloc": (_err, [_vp, _sz, C.POINTER(_u32p)]),
+    "zkh_host_free": (None, [_vp, _u32p]),
+    "zkh_write_async": (_err, [_vp, _vp, _u32p, _sz, _sz]),
     "zkh_batch_interpolate_ntt": (_err, [_vp, _vp, _sz]),
     "zkh_batch_expand_into_evaluate_ntt": (_err, [_vp, _vp, _vp, _sz, _sz]),
     "zkh_batch_bit_reverse": (_err, [_vp, _vp, _sz]),
@@ -76,14 +90,21 @@ ABI = {
     "zkh_circuit_destroy": (None, [_vp]),
     "zkh_circuit_has_compiled_kernel": (_i, [_vp]),
     "zkh_circuit_attach_code_object": (_err, [_vp, C.c_char_p, _sz, C.c_char_p]),
-    "zkh_eval_check": (_err, [_vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_vp), _u32p, _sz, _i]),
-    "zkh_syn_witgen": (_err, [_vp, _vp, _sz, _sz, _u64, _u64, _vp, _vp, _u32p]),
+    "zkh_eval_check": (_err, [_vp, _vp, _vp, C.POINTER(_vp), _sz, C.POINTER(_vp), _sz, _u32p, _sz, _sz, _i]),
+    "zkh_syn_code": (_err, [_vp, _vp, _sz, _sz, _vp]),
+    "zkh_syn_witgen": (_err, [_vp, _vp, _sz, _sz, _u64, _u64, _u32p, _vp, _vp, _u32p]),
     "zkh_syn_accum": (_err, [_vp, _vp, _sz, _sz, _u64, _vp, _u32p, _vp]),
     "zkh_prover_create": (_err, [_vp, _vp, C.POINTER(_vp)]),
     "zkh_prover_destroy": (None, [_vp]),
     "zkh_prove_segment": (_err, [_vp, _sz, _sz, _u64, _vp, _vp, _u32p, C.POINTER(_u32p), C.POINTER(_sz)]),
     "zkh_free_seal": (None, [_u32p]),
-    "zkh_verify_segment": (_err, [_vp, _u32p, _sz, _u32p, _u32p]),
+    "zkh_prove_begin": (_err, [_vp, _sz, _vp, _vp, _u32p, C.POINTER(_vp), _u32p]),
+    "zkh_prove_finish": (_err, [_vp, _vp, C.POINTER(_u32p), C.POINTER(_sz)]),
+    "zkh_prove_abort": (None, [_vp]),
+    "zkh_code_root": (_err, [_vp, _vp, _sz, _u32p]),
+    "zkh_syn_control_root": (_err, [_vp, _sz, _sz, _u32p]),
+    "zkh_verify_segment": (_err, [_vp, _u32p, _sz, _u32p, _u32p, _u32p]),
+    "zkh_receipt_claim": (_err, [_vp, _u32p, _sz, _u32p, _u32p, _u32p, _u32p]),
     "zkh_prof_enable": (_err, [_vp, _i]),
     "zkh_prof_get": (_err, [_vp, C.POINTER(ProfRec), _sz, C.POINTER(_sz)]),
     "zkh_prof_reset": (_err, [_vp]),
@@ -197,10 +218,11 @@ class Circuit:
 
     def eval_check(self, check: Buffer, groups: Sequence[Buffer], globals_: Sequence[Buffer], poly_mix, po2: int,
                    use_interpreter: bool = False) -> None:
-        g = (_vp * 3)(*[b.h for b in groups])
-        gl = (_vp * 2)(*[b.h for b in globals_])
+        g = (_vp * len(groups))(*[b.h for b in groups])
+        gl = (_vp * len(globals_))(*[b.h for b in globals_])
         pm = _u32(poly_mix)
-        _check(_lib.zkh_eval_check(self.hal.ctx, self.h, check.h, g, gl, _ptr(pm), po2, int(use_interpreter)))
+        _check(_lib.zkh_eval_check(self.hal.ctx, self.h, check.h, g, len(groups), gl, len(globals_), _ptr(pm), po2,
+                                   1 << po2, int(use_interpreter)))
 
 
 class HostCircuit:
@@ -218,12 +240,26 @@ class HostCircuit:
         if h and _lib is not None:
             _lib.zkh_circuit_destroy(h)
 
-    def verify_segment(self, seal, rc=None, diag=None) -> None:
-        """`Receipt::verify` for one segment seal: raises HalError (VerificationError analogue) if rejected."""
+    def verify_segment(self, seal, control_root, rc=None, diag=None) -> None:
+        """`Receipt::verify` for one segment seal: raises HalError (VerificationError analogue) if rejected.
+        `control_root` (8 words) is the expected code commitment for (circuit, po2): required, like upstream's control ID."""
         s = _u32(seal)
+        cr = _u32(control_root) if control_root is not None else None
+        if cr is not None and cr.size != 8:
+            raise HalError("verify_segment: control root must be 8 words")
         r = _ptr(_u32(rc)) if rc is not None else None
         d = _ptr(_u32(diag)) if diag is not None else None
-        _check(_lib.zkh_verify_segment(self.h, _ptr(s), s.size, r, d))
+        _check(_lib.zkh_verify_segment(self.h, _ptr(s), s.size, _ptr(cr) if cr is not None else None, r, d))
+
+
+    def receipt_claim(self, seal, control_root, rc=None, diag=None) -> np.ndarray:
+        """Claim digest (8 words) of a sealed segment: Poseidon2(out globals, po2, control root)."""
+        s, cr = _u32(seal), _u32(control_root)
+        out = np.zeros(8, dtype=np.uint32)
+        r = _ptr(_u32(rc)) if rc is not None else None
+        d = _ptr(_u32(diag)) if diag is not None else None
+        _check(_lib.zkh_receipt_claim(self.h, _ptr(s), s.size, _ptr(cr), r, d, _ptr(out)))
+        return out
 
 
 class HipHal:
@@ -235,6 +271,10 @@ class HipHal:
         _check(_lib.zkh_ctx_create(device, hash_suite.encode(), C.byref(ctx)))
         self.ctx = ctx
         self.device = device
+
+    @staticmethod
+    def version() -> str:
+        return load_library().zkh_version().decode()
 
     def close(self):
         ctx, self.ctx = getattr(self, "ctx", None), None
@@ -280,6 +320,19 @@ class HipHal:
         return Buffer(self, out)
 
     copy_from_elem = copy_from_extelem = copy_from_u32 = copy_from_digest = copy_from
+
+    def host_alloc(self, n_words: int) -> np.ndarray:
+        """Pinned host memory (a numpy view) for witnesses produced on the CPU; release with host_free."""
+        p = _u32p()
+        _check(_lib.zkh_host_alloc(self.ctx, n_words, C.byref(p)))
+        return np.ctypeslib.as_array(p, shape=(n_words,))
+
+    def host_free(self, arr: np.ndarray) -> None:
+        _lib.zkh_host_free(self.ctx, arr.ctypes.data_as(_u32p))
+
+    def write_async(self, buf: Buffer, pinned: np.ndarray, offset: int = 0) -> None:
+        """Enqueue H2D from a host_alloc block on the context's stream (no host sync)."""
+        _check(_lib.zkh_write_async(self.ctx, buf.h, pinned.ctypes.data_as(_u32p), offset, pinned.size))
 
     def wrap(self, device_ptr: int, n_words: int) -> Buffer:
         out = _vp()
@@ -382,9 +435,19 @@ class HipHal:
                 c.jit()
         return c
 
-    def syn_witgen(self, circuit: Circuit, po2: int, zk_cycles: int, seed: int, noise_seed: int, code: Buffer, data: Buffer) -> np.ndarray:
-        out = np.zeros(4, dtype=np.uint32)
-        _check(_lib.zkh_syn_witgen(self.ctx, circuit.h, po2, zk_cycles, seed, noise_seed, code.h, data.h, _ptr(out)))
+    def syn_code(self, circuit: Circuit, po2: int, zk_cycles: int, code: Buffer) -> None:
+        _check(_lib.zkh_syn_code(self.ctx, circuit.h, po2, zk_cycles, code.h))
+
+    def syn_witgen(self, circuit: Circuit, po2: int, zk_cycles: int, seed: int, noise_seed: int, code: Buffer, data: Buffer,
+                   pub=None) -> np.ndarray:
+        """-> out globals (OUTPUT_SIZE words: s, 0, 0, 0, then the public input words `pub`)."""
+        out_size = int(circuit.desc[7])
+        out = np.zeros(out_size, dtype=np.uint32)
+        p = _u32(pub) if pub is not None else np.zeros(0, np.uint32)
+        if p.size != out_size - 4:
+            raise HalError(f"syn_witgen: circuit takes {out_size - 4} public input words, got {p.size}")
+        _check(_lib.zkh_syn_witgen(self.ctx, circuit.h, po2, zk_cycles, seed & (2**64 - 1), noise_seed & (2**64 - 1),
+                                   _ptr(p) if p.size else None, code.h, data.h, _ptr(out)))
         return out
 
     def syn_accum(self, circuit: Circuit, po2: int, zk_cycles: int, noise_seed: int, data: Buffer, mix_global, accum: Buffer) -> None:

@@ -9,7 +9,7 @@ receipts (~0.25 MB each) are gathered on rank 0 over the control plane (gloo / R
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 from typing import Callable, List, Optional, Sequence
 
 from .prover import Segment, SegmentReceipt
@@ -40,21 +40,37 @@ def session_segments(total_cycles: int, segment_po2: int = 20, base_seed: int = 
     return segs
 
 
+def _root_for(control_root, po2: int):
+    """control_root argument of the verify methods: None (shipped table), one root, {po2: root} or callable(po2)."""
+    if control_root is None or hasattr(control_root, "shape") or isinstance(control_root, (list, tuple)):
+        return control_root
+    if isinstance(control_root, dict):
+        return control_root.get(po2)
+    return control_root(po2)
+
+
 @dataclass
 class CompositeReceipt:
-    """`CompositeReceipt{segments[]}` analogue: ordered by segment index."""
+    """`CompositeReceipt{segments[], assumption_receipts[]}` analogue: segments ordered by index; `assumptions` holds
+    the coprocessor proofs the guest requested (keccak batches, `prove_keccak` upstream) — each verified with its own circuit."""
     segments: List[SegmentReceipt]
+    assumptions: List[SegmentReceipt] = field(default_factory=list)
 
     def verify_integrity(self) -> None:
         idx = [s.index for s in self.segments]
         if idx != list(range(len(idx))):
             raise ValueError(f"composite receipt has missing or unordered segments: {idx}")
 
-    def verify(self, circuit_desc) -> None:
-        """`receipt.verify(image_id)` analogue: structural integrity + every segment seal through the host verifier."""
+    def verify(self, circuit_desc, control_root=None, assumption_desc=None, assumption_control_root=None) -> None:
+        """`receipt.verify(image_id)` analogue: structural integrity + every segment seal through the host verifier
+        against the expected control root (None: the shipped table; or {po2: root} / callable for other sizes)."""
         self.verify_integrity()
         for s in self.segments:
-            s.verify(circuit_desc)
+            s.verify(circuit_desc, _root_for(control_root, s.po2))
+        if self.assumptions and assumption_desc is None:
+            raise ValueError("composite receipt carries assumption receipts but no circuit was given for them")
+        for a in self.assumptions:
+            a.verify(assumption_desc, _root_for(assumption_control_root, a.po2))
 
 
 class BlockProcessor:
@@ -115,7 +131,10 @@ def torch_gather(rank: int, world_size: int):
 # Config 5 of BASELINE.json (lift/join to one succinct receipt), restated synthetically: the
 # recursion circuit (risc0-circuit-recursion 4.0.2, un-vendored: /root/reference/Cargo.lock:5305) is unobtainable, so
 # a "join" here is one seal of the declared-synthetic SYN-J shape (W_code 16, W_data 128, W_accum 16, po2 18 by
-# default) whose witness seed is bound to the two child seals.  Same HAL ops, different circuit, tree-shaped schedule.
+# default) that takes the CLAIM DIGESTS of its two children as public inputs: they sit in its witness, are bound to
+# its `out` globals by constraints, and the verifier of a succinct receipt checks every join's `out` against the claims
+# of the receipts below it.  (The real join additionally verifies the child seals in-circuit; that is what lets
+# upstream drop the tree and keep only the root.)  Same HAL ops, different circuit, tree-shaped schedule.
 # ---------------------------------------------------------------------------------------------------------------
 JOIN_PO2 = 18
 
@@ -127,6 +146,7 @@ class JoinTask:
     left: int           # node index in the level below
     right: int
     device: int         # rank that runs it: the one that produced `left`
+    right_owner: int    # rank that holds the right child (its receipt crosses the control plane when != device)
 
 
 def join_schedule(n_leaves: int, world_size: int) -> List[List[JoinTask]]:
@@ -140,7 +160,7 @@ def join_schedule(n_leaves: int, world_size: int) -> List[List[JoinTask]]:
     level = 0
     while len(owners) > 1:
         level += 1
-        tasks = [JoinTask(level, k, 2 * k, 2 * k + 1, owners[2 * k]) for k in range(len(owners) // 2)]
+        tasks = [JoinTask(level, k, 2 * k, 2 * k + 1, owners[2 * k], owners[2 * k + 1]) for k in range(len(owners) // 2)]
         nxt = [t.device for t in tasks]
         if len(owners) % 2:
             nxt.append(owners[-1])
@@ -149,43 +169,124 @@ def join_schedule(n_leaves: int, world_size: int) -> List[List[JoinTask]]:
     return levels
 
 
-def join_seed(left: SegmentReceipt, right: SegmentReceipt) -> int:
-    """64-bit witness seed of a join, bound to both child seals (stand-in for the recursion circuit reading them)."""
+def receipt_claim(receipt: SegmentReceipt, circuit_desc, control_root) -> "np.ndarray":
+    """Claim digest of a receipt: Poseidon2 over (out globals, po2, control root) — what a parent join commits to."""
+    from . import hal as _hal
+    return _hal.HostCircuit(circuit_desc).receipt_claim(receipt.seal, control_root)
+
+
+def join_segment(task: JoinTask, left_claim, right_claim, join_po2: int = JOIN_PO2, noise_seed: Optional[int] = None) -> Segment:
+    """The SYN-J segment of one join: public inputs = the two child claims; witness seed derived from them."""
     import hashlib
-    h = hashlib.sha256(left.seal_bytes() + right.seal_bytes()).digest()
-    return int.from_bytes(h[:8], "little")
-
-
-def prove_succinct(leaves: Sequence[SegmentReceipt], prove_join: Callable[[Segment], SegmentReceipt],
-                   join_po2: int = JOIN_PO2) -> "SuccinctReceipt":
-    """Single-rank driver of the join tree (every rank of `join_schedule` collapses onto the caller)."""
-    nodes = list(leaves)
-    joins: List[List[SegmentReceipt]] = []
-    for tasks in join_schedule(len(nodes), 1):
-        done = [prove_join(Segment(index=t.index, po2=join_po2, seed=join_seed(nodes[t.left], nodes[t.right])))
-                for t in tasks]
-        nxt = list(done)
-        if len(nodes) % 2:
-            nxt.append(nodes[-1])
-        joins.append(done)
-        nodes = nxt
-    return SuccinctReceipt(root=nodes[0], joins=joins, leaves=list(leaves))
+    import numpy as np
+    pub = np.concatenate([np.asarray(left_claim, dtype=np.uint32), np.asarray(right_claim, dtype=np.uint32)])
+    seed = int.from_bytes(hashlib.sha256(pub.astype("<u4").tobytes()).digest()[:8], "little")
+    kw = {} if noise_seed is None else {"noise_seed": noise_seed}
+    return Segment(index=task.index, po2=join_po2, seed=seed, pub=tuple(int(x) for x in pub), **kw)
 
 
 @dataclass
 class SuccinctReceipt:
+    """Root join receipt + the tree below it (kept because the synthetic join does not verify its children in-circuit)."""
     root: SegmentReceipt
     joins: List[List[SegmentReceipt]]
     leaves: List[SegmentReceipt]
 
-    def verify(self, segment_desc, join_desc) -> None:
-        """Every leaf seal and every join seal is accepted by the host verifier, and the tree has the scheduled shape.
-        (The synthetic join does not constrain its children — that is what the real recursion circuit adds.)"""
+    def verify(self, segment_desc, join_desc, leaf_root=None, join_root=None) -> None:
+        """Every leaf and join seal is accepted by the host verifier against its control root, the tree has the scheduled
+        shape, and every join's public outputs equal the claim digests of the two receipts it combines."""
+        import numpy as np
         shape = [len(t) for t in join_schedule(len(self.leaves), 1)]
         if [len(lvl) for lvl in self.joins] != shape:
             raise ValueError(f"join tree has levels {[len(lvl) for lvl in self.joins]}, expected {shape}")
+        from .prover import shipped_control_root
+        def root_of(desc, given, po2):
+            r = _root_for(given, po2)
+            return shipped_control_root(desc, po2) if r is None else r
         for s in self.leaves:
-            s.verify(segment_desc)
-        for lvl in self.joins:
-            for j in lvl:
-                j.verify(join_desc)
+            s.verify(segment_desc, root_of(segment_desc, leaf_root, s.po2))
+        nodes = [(s, receipt_claim(s, segment_desc, root_of(segment_desc, leaf_root, s.po2))) for s in self.leaves]
+        for lvl, tasks in zip(self.joins, join_schedule(len(self.leaves), 1)):
+            nxt = []
+            for j, t in zip(lvl, tasks):
+                jr = root_of(join_desc, join_root, j.po2)
+                j.verify(join_desc, jr)
+                want = np.concatenate([nodes[t.left][1], nodes[t.right][1]])
+                if not np.array_equal(np.asarray(j.seal[4:4 + want.size], dtype=np.uint32), want):
+                    raise ValueError(f"join (level {t.level}, index {t.index}) does not commit to the claims of its children")
+                nxt.append((j, receipt_claim(j, join_desc, jr)))
+            if len(nodes) % 2:
+                nxt.append(nodes[-1])
+            nodes = nxt
+        if nodes[0][0] is not self.root and len(self.leaves) > 1:
+            raise ValueError("root is not the top join")
+
+
+class JoinExecutor:
+    """Runs `join_schedule` on this rank (BASELINE config 5, `ProverImpl::{lift, join}` upstream).  World size 1: every
+    task is local.  World size G: a task runs on `task.device`; when the right child lives elsewhere its receipt is
+    sent over the control plane (torch.distributed point-to-point objects on gloo — ~0.25 MB, no data-path collective).
+
+    `claim_of(receipt, is_leaf) -> 8 words`, `prove_join(Segment) -> SegmentReceipt` are supplied by the caller (on a GPU
+    rank: SegmentProver bound to the SYN-J circuit)."""
+
+    def __init__(self, prove_join: Callable[[Segment], SegmentReceipt], claim_of: Callable[[SegmentReceipt, bool], "np.ndarray"],
+                 rank: int = 0, world_size: int = 1, join_po2: int = JOIN_PO2, noise_seed: Optional[int] = None,
+                 send=None, recv=None):
+        self.prove_join, self.claim_of = prove_join, claim_of
+        self.rank, self.world_size, self.join_po2, self.noise_seed = rank, world_size, join_po2, noise_seed
+        self._send, self._recv = send, recv
+        if world_size > 1 and (send is None or recv is None):
+            import torch.distributed as dist
+
+            def _s(obj, dst):
+                dist.send_object_list([obj], dst=dst)
+
+            def _r(src):
+                buf = [None]
+                dist.recv_object_list(buf, src=src)
+                return buf[0]
+            self._send, self._recv = _s, _r
+
+    def run(self, n_leaves: int, local_leaves: dict):
+        """local_leaves: {leaf index: SegmentReceipt} for the leaves this rank produced (index mod G == rank).
+        -> (joins_done_here: {(level, index): SegmentReceipt}, root receipt or None when it lives on another rank)."""
+        nodes = {i: (r, True) for i, r in local_leaves.items()}          # node index in the current level -> (receipt, is_leaf)
+        n_nodes = n_leaves
+        done = {}
+        for tasks in join_schedule(n_leaves, self.world_size):
+            # exchange step of the level, in task order on every rank (pairs up sends and receives without deadlock)
+            right = {}
+            for t in tasks:
+                if t.right_owner == t.device:
+                    continue
+                if self.rank == t.right_owner:
+                    self._send(nodes[t.right], t.device)
+                elif self.rank == t.device:
+                    right[t.index] = self._recv(t.right_owner)
+            nxt = {}
+            for t in tasks:
+                if t.device != self.rank:
+                    continue
+                l_rec, l_leaf = nodes[t.left]
+                r_rec, r_leaf = right[t.index] if t.index in right else nodes[t.right]
+                seg = join_segment(t, self.claim_of(l_rec, l_leaf), self.claim_of(r_rec, r_leaf), self.join_po2, self.noise_seed)
+                j = self.prove_join(seg)
+                done[(t.level, t.index)] = j
+                nxt[t.index] = (j, False)
+            if n_nodes % 2 and (n_nodes - 1) in nodes:                    # the unpaired last node is carried up where it lives
+                nxt[n_nodes // 2] = nodes[n_nodes - 1]
+            nodes, n_nodes = nxt, (n_nodes + 1) // 2
+        root = nodes.get(0, (None, False))[0] if n_nodes == 1 else None
+        return done, root
+
+
+def prove_succinct(leaves: Sequence[SegmentReceipt], prove_join: Callable[[Segment], SegmentReceipt],
+                   claim_of: Callable[[SegmentReceipt, bool], "np.ndarray"], join_po2: int = JOIN_PO2,
+                   noise_seed: Optional[int] = None) -> "SuccinctReceipt":
+    """Single-rank driver of the join tree (every rank of `join_schedule` collapses onto the caller)."""
+    ex = JoinExecutor(prove_join, claim_of, 0, 1, join_po2, noise_seed)
+    done, root = ex.run(len(leaves), dict(enumerate(leaves)))
+    sched = join_schedule(len(leaves), 1)
+    joins = [[done[(t.level, t.index)] for t in tasks] for tasks in sched]
+    return SuccinctReceipt(root=root if root is not None else leaves[0], joins=joins, leaves=list(leaves))
