@@ -1,23 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — segments/sec for sealing 2^20-cycle zkVM segments on N MI355X (BASELINE.json metric).
 
-One "step" = one segment seal (commit code/data, accum, eval_check, DEEP, FRI,
-queries) on a witness that is already resident in HBM when the timed region starts.  Workload at every N is
-BASELINE.json configs[1] per GPU: one 2^20-cycle SYN-A segment (W_code 16, W_data 208, W_accum 32; SYN-AIR is
-the declared-synthetic stand-in for the un-obtainable rv32im circuit — DESIGN.md).  With N GPUs the segment
-list is partitioned round-robin (segment i -> rank i mod N, one process per GPU, no data-path collective), so
-per-GPU work is fixed as N grows: "scaling": "weak", value = N*K segments / max-over-ranks time.
+One "step" = one segment seal (commit code/data, accum, eval_check, DEEP, FRI, queries).
+Configs (SURVEY.md §8d restatements of BASELINE.json's configs):
 
-    python bench.py --gpus 1 --steps 30 --warmup 2
+  --config segment  (default; BASELINE config 2)  every step seals one 2^po2-cycle segment whose witness is already
+                    resident in HBM when the clock starts; N GPUs = N ranks each doing K steps ("scaling": "weak").
+  --config block    (configs 3/4)  one block = S DISTINCT segments (seeds base+i, the last one a po2-18 tail), handed out
+                    round-robin over the ranks and through a shared work index inside a rank; witness generation runs
+                    inside the clock (reported separately), every seal is verified on the host after the clock stops;
+                    value = S / wall ("scaling": "strong").
+  --config succinct (config 5)  S leaf segments + the binary SYN-J join tree down to one root receipt; joins run on the
+                    rank that holds the left child, right children cross the gloo control plane.
+
+  --circuit syn_heavy  seals with the realistically heavy constraint system instead of SYN-A.
+  --ingress host       additionally times the PCIe-inclusive path: traces uploaded from pinned host memory every step.
+
+    python bench.py                         # N=1, K=30, W=2
+    python bench.py --gpus 8                # self-launching: spawns 8 ranks (gloo control plane, one GPU each)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W          # the driver's launch shape works too
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -25,7 +37,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
 PO2 = 20
-CPU_SAMPLE_PO2 = 17             # bounded CPU-baseline sample: one SYN-A segment at 2^17 cycles (1/8 of the unit)
+TAIL_PO2 = 18                   # the short last segment of a block
+CPU_SAMPLE_PO2 = 17             # bounded CPU-baseline sample: one segment at 2^17 cycles (1/8 of the unit)
+BASE_SEED = 0x5EED0000
+BENCH_NOISE = 0x2E80            # fixed blinding seed: bench seals must be reproducible run to run (product default: OS RNG)
 
 
 def seal_algorithmic_bytes(wa: int, wc: int, wd: int, n_taps: int, n_combos: int, n: int) -> float:
@@ -42,7 +57,7 @@ def seal_algorithmic_bytes(wa: int, wc: int, wd: int, n_taps: int, n_combos: int
     return float(commit + eval_check + check_group + deep + mix + combos + fri)
 
 
-def cpu_baseline(desc) -> dict:
+def cpu_baseline(desc, circuit_name: str) -> dict:
     """The CPU oracle (a from-spec port of the reference CPU prover's algorithm) on this host's cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import zko                                     # test infrastructure; used here ONLY as the reported CPU baseline
@@ -55,20 +70,42 @@ def cpu_baseline(desc) -> dict:
     for t in sorted({c for c in (8, 16, 32, 64, avail) if c <= avail}):
         lib.zko_set_num_threads(t)
         t0 = time.perf_counter()
-        oc.prove(CPU_SAMPLE_PO2 - 2, 1994, 0x5EED0000, 0x2E80)
+        oc.prove(CPU_SAMPLE_PO2 - 2, 1994, BASE_SEED, BENCH_NOISE)
         d = time.perf_counter() - t0
         if best_dt is None or d < best_dt:
             best, best_dt = t, d
     lib.zko_set_num_threads(best)
     t0 = time.perf_counter()
-    seal = oc.prove(CPU_SAMPLE_PO2, 1994, 0x5EED0000, 0x2E80)
+    seal = oc.prove(CPU_SAMPLE_PO2, 1994, BASE_SEED, BENCH_NOISE)
     dt = time.perf_counter() - t0
     scale = 1 << (PO2 - CPU_SAMPLE_PO2)
     return {"value": 1.0 / (dt * scale), "unit": "segments/s", "cores": best, "cores_available": avail, "kind": "port",
-            "sample": f"one SYN-A segment seal at po2={CPU_SAMPLE_PO2} ({dt:.2f} s wall, OpenMP oracle incl. witgen, at the fastest of "
+            "sample": f"one {circuit_name} segment seal at po2={CPU_SAMPLE_PO2} ({dt:.2f} s wall, OpenMP oracle incl. witgen, at the fastest of "
                       f"8/16/32/64/{avail} threads = {best}), "
                       f"scaled x1/{scale} to the po2={PO2} unit (work is ~linear in n)",
+            "note": "an extrapolated sample of a literal, untuned port (the reference CPU prover cannot be built here); "
+                    "reported as the contract asks, never a target and never a quotable speed-up",
             "seal_words": int(seal.size)}
+
+
+def self_launch(args, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks ourselves (one process per GPU, gloo control
+    plane over 127.0.0.1), pass rank 0's stdout (the ONE JSON line) through, fail if any rank fails."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), ZKH_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def main() -> None:
@@ -77,20 +114,29 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=30, help="timed seals per GPU (30 x ~32 ms: about a second of GPU time)")
     ap.add_argument("--warmup", type=int, default=2, help="untimed seals per lane before the clock starts (also ramps the clocks)")
     ap.add_argument("--po2", type=int, default=PO2)
+    ap.add_argument("--config", choices=("segment", "block", "succinct"), default="segment")
+    ap.add_argument("--circuit", choices=("syn_a", "syn_heavy"), default="syn_a")
+    ap.add_argument("--segments", type=int, default=None, help="block / succinct: number of segments S (default 256 / 1024)")
+    ap.add_argument("--join-po2", type=int, default=18)
+    ap.add_argument("--ingress", choices=("device", "host"), default="device")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("ZKH_INFLIGHT", "3")),
                     help="segments sealed concurrently per GPU (one host thread + HIP stream each); 1 = strictly serial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events (no roofline object)")
+    ap.add_argument("--no-verify", action="store_true", help="block / succinct: skip the host verification after the clock stops")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     distributed = world > 1
+    backend = "gloo"
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -120,66 +166,37 @@ def main() -> None:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
+    else:
+        def barrier():
+            pass
 
     from zeth_amd.circuits import syn_air
     from zeth_amd.circuits.desc import Circuit
     from zeth_amd.hal import HipHal
-    from zeth_amd.host import partition_round_robin
+    from zeth_amd.host import JoinExecutor, partition_round_robin, receipt_claim
     from zeth_amd.prover import Segment, SegmentProver
 
     # one GPU per rank; ZKH_SHARE_GPUS=1 lets ranks wrap around the visible devices (dry runs on a 1-GPU box)
-    device = local_rank % torch.cuda.device_count() if os.environ.get("ZKH_SHARE_GPUS") else local_rank
-    desc = syn_air.syn_a()
+    device = local_rank
+    if os.environ.get("ZKH_SHARE_GPUS"):
+        try:
+            device = local_rank % max(1, torch.cuda.device_count())
+        except (RuntimeError, AssertionError):
+            device = 0
+    if args.circuit == "syn_heavy":
+        from zeth_amd.circuits import syn_heavy
+        desc = syn_heavy.syn_heavy()
+    else:
+        desc = syn_air.syn_a()
+    join_desc = syn_air.syn_join()
     circ = Circuit.parse(desc)
     wa, wc, wd = circ.group_sizes
-    import threading
     n = 1 << args.po2
     inflight = max(1, min(args.inflight, args.steps))
+    workload = (f"{args.circuit.upper().replace('_', '-')} circuit (W_code {wc}, W_data {wd}, W_accum {wa}, check 16; {len(circ.taps)} taps, "
+                f"{len(circ.steps)} constraint steps), poseidon2")
 
-    # segment list of the "block": (warmup + steps) * world segments, partitioned round-robin over ranks; inside a
-    # rank, `inflight` host threads (one HipHal context = one HIP stream each) seal different segments concurrently so
-    # that the latency-bound phases of one seal (Merkle tree tops, scans, Fiat-Shamir round trips) overlap another's
-    # throughput-bound phases.  Segments stay independent: no data is shared between the threads.
-    total = (args.warmup + args.steps) * world
-    mine = partition_round_robin(total, world, rank)
-
-    class Worker:
-        def __init__(self, w):
-            self.hal = HipHal(device)                # raises if the HIP library / GPU is missing: no fallback
-            self.prover = SegmentProver(self.hal, desc)
-            self.sealed = 0
-            self.seal_s = []
-            ring = max(1, min(-(-args.steps // inflight) + args.warmup, 2))
-            self.wit = []
-            self.witgen_s = []
-            for j in range(ring):                    # witnesses resident in HBM before the clock starts
-                idx = mine[(w + j * inflight) % len(mine)]
-                seg = Segment(index=idx, po2=args.po2, seed=0x5EED0000 + idx)
-                t_w = time.perf_counter()
-                self.wit.append((seg, *self.prover.witgen(seg)))
-                self.hal.sync()
-                self.witgen_s.append(time.perf_counter() - t_w)
-            self.last = None
-            self.err = None
-
-        def seal(self, i):
-            seg, code, data, out = self.wit[i % len(self.wit)]
-            t_s = time.perf_counter()
-            self.last = self.prover.seal(seg, code, data, out)   # returns with the seal words on the host
-            self.seal_s.append(time.perf_counter() - t_s)
-
-        def run(self):
-            # the K timed steps are handed out through a shared work index (work stealing), so K need
-            # not be a multiple of the number of seals in flight
-            try:
-                while next_step() is not None:
-                    self.seal(args.warmup + self.sealed)
-                    self.sealed += 1
-                self.hal.sync()
-            except Exception as e:                   # surfaced after join
-                self.err = e
-
-    def device_sync():
+    def device_sync(workers):
         """Both sides of the timed region: every library stream, then torch's device-wide synchronize (torch is only
         plumbing here; if its own HIP initialisation is unavailable the library's syncs already cover all our work)."""
         for wk in workers:
@@ -190,162 +207,432 @@ def main() -> None:
         except (RuntimeError, AssertionError):
             pass
 
-    work_lock, work_next = threading.Lock(), [0]
+    class Lane:
+        """One seal in flight: a context (HIP stream) + circuit + prover, driven by one host thread."""
 
-    def next_step():
-        with work_lock:
-            k = work_next[0]
-            if k >= args.steps:
-                return None
-            work_next[0] = k + 1
-            return k
+        def __init__(self, with_join=False):
+            self.hal = HipHal(device)                # raises if the HIP library / GPU is missing: no fallback
+            self.prover = SegmentProver(self.hal, desc)
+            self.join_prover = SegmentProver(self.hal, join_desc) if with_join else None
+            self.seal_s, self.witgen_s, self.err = [], [], None
+            self.last = None
 
-    workers = [Worker(w) for w in range(inflight)]
-    for wk in workers:
-        for i in range(args.warmup):
-            wk.seal(i)
-        wk.hal.sync()
-    if not args.no_prof:
-        for wk in workers:
-            wk.hal.prof_reset()
-            wk.hal.prof_enable(True)
-    rccl = None
-    if distributed and "nccl" in backend:
-        try:
-            probe = torch.ones(1, device=f"cuda:{device}")
-            dist.all_reduce(probe)
-            torch.cuda.synchronize()
-            rccl = "ok" if int(probe.item()) == world else "wrong sum"
-        except Exception as e:                       # control plane stays on gloo; the seals never needed RCCL
-            rccl = f"unavailable ({type(e).__name__})"
-    device_sync()
-    if distributed:
-        barrier()
-    for wk in workers:
-        wk.seal_s.clear()
-    t0 = time.perf_counter()
-    threads = [threading.Thread(target=wk.run) for wk in workers]
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    device_sync()
-    if distributed:
-        barrier()
-    dt = time.perf_counter() - t0
-    for wk in workers:
-        if wk.err is not None:
-            raise wk.err
-    if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=ctrl_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    prof = []
-    if not args.no_prof:
+    def run_lanes(lanes, fn):
+        threads = [threading.Thread(target=fn, args=(ln,)) for ln in lanes]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        for ln in lanes:
+            if ln.err is not None:
+                raise ln.err
+
+    def merged_prof(lanes):
         merged = {}
-        for wk in workers:
-            for p in wk.hal.prof_get():
+        for ln in lanes:
+            for p in ln.hal.prof_get():
                 m = merged.setdefault(p["name"], {"name": p["name"], "calls": 0, "total_ms": 0.0, "alg_bytes": 0.0})
                 m["calls"] += p["calls"]; m["total_ms"] += p["total_ms"]; m["alg_bytes"] += p["alg_bytes"]
-            wk.hal.prof_enable(False)
-        prof = list(merged.values())
-    # With several seals in flight the HIP-event brackets of one stream include time its kernels spent sharing the GPU
-    # with the other streams.  One more seal, alone on the GPU and outside the timed region, gives the unshared
-    # per-kernel durations next to them (and names the kernel that really dominates the work).
-    seal_times = [t for wk in workers for t in wk.seal_s]
-    unloaded_seal_s = None
-    ref = []
-    if prof and inflight > 1 and rank == 0:
-        w0 = workers[0]
-        w0.hal.prof_reset(); w0.hal.prof_enable(True)
-        w0.seal(args.warmup)
-        w0.hal.sync()
-        ref = w0.hal.prof_get()
-        w0.hal.prof_enable(False)
-        unloaded_seal_s = w0.seal_s[-1]              # one seal alone on the GPU: the single-segment latency
-    last = next((wk.last for wk in workers if wk.last is not None), None)
+        return list(merged.values())
 
-    if rank == 0:
-        value = world * args.steps / dt
-        line = {
-            "metric": "segments/sec", "value": value, "unit": "segments/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"single 2^{args.po2}-cycle segment seal per step per GPU, SYN-A circuit "
-                                   f"(W_code {wc}, W_data {wd}, W_accum {wa}, check 16; {len(circ.taps)} taps), poseidon2, "
-                                   "witness resident in HBM", "po2": args.po2,
-                       "parallelism": f"segments round-robin over {world} GPU(s), no collectives; {inflight} segment(s) in flight per GPU",
-                       "rccl_probe": rccl,
-                       "inflight_per_gpu": inflight,
-                       "seal_words": int(last.seal.size) if last is not None else 0},
-            # wall-clock of one seal call (enqueue .. seal words on the host), mean over the timed seals of this rank;
-            # with several seals in flight each one shares the GPU, so this is latency under load, not 1/value
-            "seal_wall_clock_s": sum(seal_times) / max(1, len(seal_times)),
-            # ... and of one seal with the GPU to itself (inflight 1: the same thing as seal_wall_clock_s)
-            "seal_wall_clock_unloaded_s": unloaded_seal_s if unloaded_seal_s is not None else sum(seal_times) / max(1, len(seal_times)),
-            # reported separately: synthetic witness generation on the device, outside the timed region
-            "witgen_ms_per_segment": 1e3 * min(t for wk in workers for t in wk.witgen_s[1:] or wk.witgen_s),
-        }
-        alg = seal_algorithmic_bytes(wa, wc, wd, len(circ.taps), len(circ.combos), n)
-        line["seal_roofline"] = {"alg_bytes": alg, "achieved": alg / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBPS,
-                                 "unit": "GB/s", "frac": alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS}
-        if prof:
-            tot_ms = sum(p["total_ms"] for p in prof)
-            unshared = {p["name"]: p for p in (ref or prof)}
-            dom_name = max(unshared.values(), key=lambda p: p["total_ms"])["name"]
-            dom = next(p for p in prof if p["name"] == dom_name)
-            per_launch_ms = dom["total_ms"] / dom["calls"]
-            per_launch_ms_unshared = unshared[dom_name]["total_ms"] / unshared[dom_name]["calls"]
-            per_launch_bytes = dom["alg_bytes"] / dom["calls"]
-            ach = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
-            # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
-            # FETCH doubled per the gfx950 correction; tools/pmc_summary.py) — bench.py cannot run rocprof on itself
-            traffic = None
+    line = None
+    # =====================================================================================================
+    if args.config == "segment":
+        # segment list of the "block": (warmup + steps) * world segments, partitioned round-robin over ranks; inside a
+        # rank, `inflight` host threads (one HipHal context = one HIP stream each) seal different segments concurrently so
+        # that the latency-bound phases of one seal (Merkle tree tops, scans, Fiat-Shamir round trips) overlap another's
+        # throughput-bound phases.  Segments stay independent: no data is shared between the threads.
+        total = (args.warmup + args.steps) * world
+        mine = partition_round_robin(total, world, rank)
+        lanes = [Lane() for _ in range(inflight)]
+        for w, ln in enumerate(lanes):
+            ring = max(1, min(-(-args.steps // inflight) + args.warmup, 2))
+            ln.wit = []
+            for j in range(ring):                    # witnesses resident in HBM before the clock starts
+                idx = mine[(w + j * inflight) % len(mine)]
+                seg = Segment(index=idx, po2=args.po2, seed=BASE_SEED + idx, noise_seed=BENCH_NOISE)
+                t_w = time.perf_counter()
+                ln.wit.append((seg, *ln.prover.witgen(seg)))
+                ln.hal.sync()
+                ln.witgen_s.append(time.perf_counter() - t_w)
+
+        def seal_one(ln, i):
+            seg, code, data, out = ln.wit[i % len(ln.wit)]
+            t_s = time.perf_counter()
+            ln.last = ln.prover.seal(seg, code, data, out)   # returns with the seal words on the host
+            ln.seal_s.append(time.perf_counter() - t_s)
+
+        work_lock, work_next = threading.Lock(), [0]
+
+        def next_step(limit):
+            with work_lock:
+                k = work_next[0]
+                if k >= limit:
+                    return None
+                work_next[0] = k + 1
+                return k
+
+        def timed(ln):
+            # the K timed steps are handed out through a shared work index (SURVEY.md §8e: work stealing), so K need
+            # not be a multiple of the number of seals in flight
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-                kname = {"hash_rows": "k_hash_rows", "hash_fold": "k_hash_fold", "eval_check": "k_eval_check_syn_a"}.get(dom["name"])
-                if kname in tj and args.po2 == PO2:
-                    traffic = (tj[kname]["fetch_x2_bytes"] + tj[kname]["write_bytes"]) / tj[kname]["launches"]
-            except Exception:
-                traffic = None
-            line["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "avg_launch_ms": per_launch_ms,
-                                "avg_launch_ms_unshared": per_launch_ms_unshared,
-                                "achieved_unshared": per_launch_bytes / (per_launch_ms_unshared * 1e-3) / 1e9,
-                                "alg_bytes_per_launch": per_launch_bytes,
-                                "share_of_kernel_time": unshared[dom_name]["total_ms"] / sum(p["total_ms"] for p in unshared.values()),
-                                "launches_overlap": inflight > 1,
-                                "note": "dominant kernel is integer-VALU-bound by construction (Poseidon2: ~21 Montgomery "
-                                        "products per absorbed byte); HBM fraction is reported as the contract asks; with "
-                                        "inflight_per_gpu > 1 kernels of different seals overlap, so avg_launch_ms (timed region) "
-                                        "includes time shared with other streams; *_unshared comes from one extra seal run "
-                                        "alone after the timed region"}
-            if dom["name"] == "hash_rows":
-                # VALU view of the same kernel: permutations per launch x modelled issue cycles per 64-lane permutation
-                # (8 full rounds x 2368 + 7 partial groups x 1576 + 1024 + 138 cycles) against 1024 SIMDs at 2.4 GHz
-                perms = sum(-(-w // 16) for w in (wc, wd, wa, 16)) * 4 * n          # leaves of the 3 trace trees + check tree
-                deg = n
-                while deg > 256:                                                   # FRI rounds: 4*deg/16 rows of 64 words
-                    perms += 4 * (4 * deg // 16)
-                    deg //= 16
-                cyc = 8 * 2368 + 7 * 1576 + 1024 + 138
-                per_seal_ms = unshared[dom_name]["total_ms"] / (1 if ref else args.steps)
-                line["roofline"]["valu"] = {"permutations_per_seal": perms, "model_cycles_per_wave_permutation": cyc,
-                                            "issue_utilisation_at_2p4GHz": (perms / 64.0) * cyc / (1024 * 2.4e9 * per_seal_ms * 1e-3)}
-            div = 1 if ref else args.steps
-            line["kernels"] = [{"name": p["name"], "calls_per_seal": p["calls"] / div,
-                                "ms_per_seal": p["total_ms"] / div,          # unshared (one seal alone on the GPU)
-                                "ms_per_seal_timed_region": next((q["total_ms"] / args.steps for q in prof if q["name"] == p["name"]), None),
-                                "alg_GBps": (p["alg_bytes"] / (p["total_ms"] * 1e-3) / 1e9) if p["total_ms"] > 0 else 0.0}
-                               for p in sorted(unshared.values(), key=lambda p: -p["total_ms"])]
-        if world == 1 and not args.no_cpu_baseline:
+                done = 0
+                while next_step(args.steps) is not None:
+                    seal_one(ln, args.warmup + done)
+                    done += 1
+                ln.hal.sync()
+            except Exception as e:                   # surfaced after join
+                ln.err = e
+
+        for ln in lanes:
+            for i in range(args.warmup):
+                seal_one(ln, i)
+            ln.hal.sync()
+        if not args.no_prof:
+            for ln in lanes:
+                ln.hal.prof_reset()
+                ln.hal.prof_enable(True)
+        rccl = None
+        if distributed and "nccl" in backend:
             try:
-                line["cpu_baseline"] = cpu_baseline(desc)
-            except Exception as e:       # the baseline is a reported number, never a dependency of the product path
-                line["cpu_baseline"] = {"error": repr(e)}
+                probe = torch.ones(1, device=f"cuda:{device}")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                rccl = "ok" if int(probe.item()) == world else "wrong sum"
+            except Exception as e:                       # control plane stays on gloo; the seals never needed RCCL
+                rccl = f"unavailable ({type(e).__name__})"
+        device_sync(lanes)
+        barrier()
+        for ln in lanes:
+            ln.seal_s.clear()
+        t0 = time.perf_counter()
+        run_lanes(lanes, timed)
+        device_sync(lanes)
+        barrier()
+        dt = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([dt], dtype=torch.float64, device=ctrl_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        prof = []
+        if not args.no_prof:
+            prof = merged_prof(lanes)
+            for ln in lanes:
+                ln.hal.prof_enable(False)
+        # With several seals in flight the HIP-event brackets of one stream include time its kernels spent sharing the GPU
+        # with the other streams.  One more seal, alone on the GPU and outside the timed region, gives the unshared
+        # per-kernel durations next to them (and names the kernel that really dominates the work).
+        seal_times = [t for ln in lanes for t in ln.seal_s]
+        unloaded_seal_s = None
+        ref = []
+        if prof and rank == 0:
+            w0 = lanes[0]
+            w0.hal.prof_reset(); w0.hal.prof_enable(True)
+            seal_one(w0, args.warmup)
+            w0.hal.sync()
+            ref = w0.hal.prof_get()
+            w0.hal.prof_enable(False)
+            unloaded_seal_s = w0.seal_s[-1]              # one seal alone on the GPU: the single-segment latency
+        # PCIe-inclusive variant: the same K steps, but every step uploads its code + data traces from pinned host memory
+        pcie = None
+        if args.ingress == "host":
+            for ln in lanes:
+                seg, code, data, out = ln.wit[0]
+                ln.host = (ln.hal.host_alloc(code.size()), ln.hal.host_alloc(data.size()))
+                ln.host[0][:] = code.to_vec()
+                ln.host[1][:] = data.to_vec()
+
+            def host_step(ln):
+                seg, _, _, out = ln.wit[0]
+                ln.last = ln.prover.seal_host_witness(seg, ln.host[0], ln.host[1], out)
+
+            def timed_host(ln):
+                try:
+                    while next_step(args.steps) is not None:
+                        host_step(ln)
+                    ln.hal.sync()
+                except Exception as e:
+                    ln.err = e
+
+            for ln in lanes:
+                host_step(ln)
+            device_sync(lanes)
+            barrier()
+            work_next[0] = 0
+            t1 = time.perf_counter()
+            run_lanes(lanes, timed_host)
+            device_sync(lanes)
+            barrier()
+            dth = time.perf_counter() - t1
+            if distributed:
+                t = torch.tensor([dth], dtype=torch.float64, device=ctrl_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dth = float(t.item())
+            up_bytes = 4.0 * (lanes[0].host[0].size + lanes[0].host[1].size)
+            pcie = {"segments_per_s": world * args.steps / dth, "ms_per_step": 1e3 * dth / args.steps,
+                    "upload_bytes_per_segment": up_bytes, "upload_GBps_sustained": up_bytes * args.steps / dth / 1e9,
+                    "note": "code + data traces uploaded from pinned host memory (zkh_write_async) inside every step, "
+                            "sealed through zkh_prove_begin / zkh_prove_finish; uploads of one lane overlap the kernels of the others"}
+            for ln in lanes:
+                for h in ln.host:
+                    ln.hal.host_free(h)
+        last = next((ln.last for ln in lanes if ln.last is not None), None)
+        if rank == 0:
+            value = world * args.steps / dt
+            line = {
+                "metric": "segments/sec", "value": value, "unit": "segments/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                "config": {"workload": f"single 2^{args.po2}-cycle segment seal per step per GPU, {workload}, witness resident in HBM",
+                           "po2": args.po2, "circuit": args.circuit,
+                           "parallelism": f"segments round-robin over {world} GPU(s), no collectives; {inflight} segment(s) in flight per GPU",
+                           "rccl_probe": rccl, "inflight_per_gpu": inflight,
+                           "seal_words": int(last.seal.size) if last is not None else 0,
+                           "library": HipHal.version(),
+                           "poseidon2_consts": "placeholder" if "placeholder" in HipHal.version() else "upstream"},
+                # wall-clock of one seal call (enqueue .. seal words on the host), mean over the timed seals of this rank;
+                # with several seals in flight each one shares the GPU, so this is latency under load, not 1/value
+                "seal_wall_clock_s": sum(seal_times) / max(1, len(seal_times)),
+                # ... and of one seal with the GPU to itself (inflight 1: the same thing as seal_wall_clock_s)
+                "seal_wall_clock_unloaded_s": unloaded_seal_s if unloaded_seal_s is not None else sum(seal_times) / max(1, len(seal_times)),
+                # reported separately (SURVEY.md §8d): synthetic witness generation on the device, outside the timed region
+                "witgen_ms_per_segment": 1e3 * min(t for ln in lanes for t in ln.witgen_s[1:] or ln.witgen_s),
+            }
+            if pcie is not None:
+                line["pcie_inclusive"] = pcie
+            alg = seal_algorithmic_bytes(wa, wc, wd, len(circ.taps), len(circ.combos), n)
+            line["seal_roofline"] = {"alg_bytes": alg, "achieved": alg / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBPS,
+                                     "unit": "GB/s", "frac": alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS}
+            if prof:
+                add_roofline(line, prof, ref, args, inflight, (wa, wc, wd), n)
+            if world == 1 and not args.no_cpu_baseline:
+                try:
+                    line["cpu_baseline"] = cpu_baseline(desc, args.circuit)
+                except Exception as e:       # the baseline is a reported number, never a dependency of the product path
+                    line["cpu_baseline"] = {"error": repr(e)}
+    # =====================================================================================================
+    else:
+        S = args.segments or (256 if args.config == "block" else 1024)
+        succinct = args.config == "succinct"
+        segs = [Segment(index=i, po2=args.po2 if i + 1 < S or S == 1 else min(args.po2, TAIL_PO2), seed=BASE_SEED + i,
+                        noise_seed=BENCH_NOISE) for i in range(S)]
+        mine = partition_round_robin(S, world, rank)
+        lanes = [Lane(with_join=succinct) for _ in range(inflight)]
+        # warm-up: one full-size seal per lane (clocks, pools, code objects), plus the control roots the verifier needs
+        for ln in lanes:
+            for _ in range(max(1, args.warmup)):
+                ln.prover.prove_segment(Segment(index=0, po2=args.po2, seed=1, noise_seed=BENCH_NOISE))
+            if succinct:
+                ln.join_prover.prove_segment(Segment(index=0, po2=args.join_po2, seed=1, noise_seed=BENCH_NOISE,
+                                                     pub=tuple([0] * 16)))
+            ln.hal.sync()
+        roots = {p: lanes[0].prover.control_root(p) for p in sorted({s.po2 for s in segs})}
+        join_root = lanes[0].join_prover.control_root(args.join_po2) if succinct else None
+        receipts = {}
+        lock, nxt = threading.Lock(), [0]
+
+        def take():
+            with lock:
+                k = nxt[0]
+                if k >= len(mine):
+                    return None
+                nxt[0] = k + 1
+                return mine[k]
+
+        def seal_leaves(ln):
+            try:
+                while True:
+                    i = take()
+                    if i is None:
+                        break
+                    t_w = time.perf_counter()
+                    code, data, out = ln.prover.witgen(segs[i])      # inside the clock, reported separately
+                    t_s = time.perf_counter()
+                    rec = ln.prover.seal(segs[i], code, data, out)
+                    t_e = time.perf_counter()
+                    ln.witgen_s.append(t_s - t_w); ln.seal_s.append(t_e - t_s)
+                    with lock:
+                        receipts[i] = rec
+                ln.hal.sync()
+            except Exception as e:
+                ln.err = e
+
+        device_sync(lanes)
+        barrier()
+        t0 = time.perf_counter()
+        run_lanes(lanes, seal_leaves)
+        device_sync(lanes)
+        t_leaves = time.perf_counter() - t0
+        joins_done, root = {}, None
+        if succinct:
+            # join tree: tasks of one level are independent -> spread over the lanes of this rank
+            def claim_of(r, is_leaf):
+                return receipt_claim(r, desc if is_leaf else join_desc, roots[r.po2] if is_leaf else join_root)
+
+            jlock = threading.Lock()
+
+            def prove_joins_parallel(tasks_segs):
+                """prove a list of join Segments on this rank's lanes concurrently -> receipts in the same order"""
+                out = [None] * len(tasks_segs)
+                pos = [0]
+
+                def work(ln):
+                    try:
+                        while True:
+                            with jlock:
+                                k = pos[0]
+                                if k >= len(tasks_segs):
+                                    return
+                                pos[0] = k + 1
+                            out[k] = ln.join_prover.prove_segment(tasks_segs[k])
+                    except Exception as e:
+                        ln.err = e
+                run_lanes(lanes, work)
+                return out
+
+            class BatchedExecutor(JoinExecutor):
+                """JoinExecutor whose per-level local joins run concurrently on the lanes (same schedule, same results)."""
+                def run(self, n_leaves, local_leaves):
+                    from zeth_amd.host import join_schedule, join_segment
+                    nodes = {i: (r, True) for i, r in local_leaves.items()}
+                    n_nodes, done = n_leaves, {}
+                    for tasks in join_schedule(n_leaves, self.world_size):
+                        right = {}
+                        for t in tasks:
+                            if t.right_owner == t.device:
+                                continue
+                            if self.rank == t.right_owner:
+                                self._send(nodes[t.right], t.device)
+                            elif self.rank == t.device:
+                                right[t.index] = self._recv(t.right_owner)
+                        local = [t for t in tasks if t.device == self.rank]
+                        jsegs = []
+                        for t in local:
+                            l_rec, l_leaf = nodes[t.left]
+                            r_rec, r_leaf = right[t.index] if t.index in right else nodes[t.right]
+                            jsegs.append(join_segment(t, self.claim_of(l_rec, l_leaf), self.claim_of(r_rec, r_leaf), self.join_po2, self.noise_seed))
+                        recs = prove_joins_parallel(jsegs)
+                        nxt2 = {}
+                        for t, j in zip(local, recs):
+                            done[(t.level, t.index)] = j
+                            nxt2[t.index] = (j, False)
+                        if n_nodes % 2 and (n_nodes - 1) in nodes:
+                            nxt2[n_nodes // 2] = nodes[n_nodes - 1]
+                        nodes, n_nodes = nxt2, (n_nodes + 1) // 2
+                    return done, (nodes.get(0, (None, False))[0] if n_nodes == 1 else None)
+
+            ex = BatchedExecutor(None, claim_of, rank, world, join_po2=args.join_po2, noise_seed=BENCH_NOISE)
+            joins_done, root = ex.run(S, {i: receipts[i] for i in mine})
+            device_sync(lanes)
+        barrier()
+        dt = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([dt, t_leaves], dtype=torch.float64, device=ctrl_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt, t_leaves = float(t[0].item()), float(t[1].item())
+        # ---- after the clock: verify every seal this rank produced (cli.rs:103 analogue) ----
+        verified = 0
+        t_v = time.perf_counter()
+        if not args.no_verify:
+            for i in mine:
+                receipts[i].verify(desc, roots[segs[i].po2])
+                verified += 1
+            for j in joins_done.values():
+                j.verify(join_desc, join_root)
+                verified += 1
+        verify_s = time.perf_counter() - t_v
+        counts = torch.tensor([float(verified), float(len(joins_done))], dtype=torch.float64)
+        if distributed:
+            dist.all_reduce(counts)
+        if rank == 0:
+            n_joins = int(counts[1].item())
+            line = {
+                "metric": "segments/sec", "value": S / dt, "unit": "segments/s", "n_gpus": world, "steps": S,
+                "warmup": max(1, args.warmup), "ms_per_step": 1e3 * dt / S, "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                "config": {"workload": (f"{'block + join tree to one succinct receipt' if succinct else 'one block'}: {S} distinct "
+                                        f"2^{args.po2}-cycle segments (last one 2^{segs[-1].po2}), {workload}; witness generation inside the clock"
+                                        + (f"; {n_joins} SYN-J joins at po2 {args.join_po2}" if succinct else "")),
+                           "po2": args.po2, "circuit": args.circuit, "segments": S,
+                           "parallelism": f"segments round-robin over {world} GPU(s) + shared work index inside a rank, no data-path collective; "
+                                          f"{inflight} seal(s) in flight per GPU" + ("; joins on the rank of their left child, right child over gloo" if succinct else ""),
+                           "inflight_per_gpu": inflight, "library": HipHal.version(),
+                           "poseidon2_consts": "placeholder" if "placeholder" in HipHal.version() else "upstream"},
+                "block_wall_clock_s": dt, "leaf_phase_s": t_leaves, "join_phase_s": dt - t_leaves if succinct else None,
+                "witgen_ms_per_segment": 1e3 * sum(t for ln in lanes for t in ln.witgen_s) / max(1, sum(len(ln.witgen_s) for ln in lanes)),
+                "seal_call_ms_mean": 1e3 * sum(t for ln in lanes for t in ln.seal_s) / max(1, sum(len(ln.seal_s) for ln in lanes)),
+                "verified_after_clock": int(counts[0].item()), "verify_s_rank0": verify_s,
+                "root_receipt_words": int(root.seal.size) if root is not None else None,
+            }
+    if rank == 0 and line is not None:
         print(json.dumps(line))
     if distributed:
         dist.destroy_process_group()
+
+
+def add_roofline(line, prof, ref, args, inflight, widths, n):
+    """roofline{} for the dominant kernel + the per-kernel table, from the HIP-event brackets of the timed region (prof)
+    and of one extra seal that ran alone on the GPU (ref)."""
+    wa, wc, wd = widths
+    unshared = {p["name"]: p for p in (ref or prof)}
+    dom_name = max(unshared.values(), key=lambda p: p["total_ms"])["name"]
+    dom = next(p for p in prof if p["name"] == dom_name)
+    per_launch_ms = dom["total_ms"] / dom["calls"]
+    per_launch_ms_unshared = unshared[dom_name]["total_ms"] / unshared[dom_name]["calls"]
+    per_launch_bytes = dom["alg_bytes"] / dom["calls"]
+    ach = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
+    # FETCH doubled per the gfx950 correction; tools/pmc_summary.py) — bench.py cannot run rocprof on itself
+    traffic, traffic_source = None, None
+    for fn in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            kname = {"hash_rows": "k_hash_rows", "hash_fold": "k_hash_fold", "eval_check": "k_eval_check_syn_a"}.get(dom["name"])
+            if kname in tj and args.po2 == PO2 and args.circuit == "syn_a":
+                traffic = (tj[kname]["fetch_x2_bytes"] + tj[kname]["write_bytes"]) / tj[kname]["launches"]
+                traffic_source = f"profiles/{fn} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, not measured in this run)"
+                break
+        except Exception:
+            continue
+    line["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                        "avg_launch_ms": per_launch_ms,
+                        "avg_launch_ms_unshared": per_launch_ms_unshared,
+                        "achieved_unshared": per_launch_bytes / (per_launch_ms_unshared * 1e-3) / 1e9,
+                        "alg_bytes_per_launch": per_launch_bytes,
+                        "share_of_kernel_time": unshared[dom_name]["total_ms"] / sum(p["total_ms"] for p in unshared.values()),
+                        "launches_overlap": inflight > 1,
+                        "note": "dominant kernel is integer-VALU-bound by construction (Poseidon2: ~21 Montgomery "
+                                "products per absorbed byte); HBM fraction is reported as the contract asks; with "
+                                "inflight_per_gpu > 1 kernels of different seals overlap, so avg_launch_ms (timed region) "
+                                "includes time shared with other streams; *_unshared comes from one extra seal run "
+                                "alone after the timed region"}
+    if dom["name"] == "hash_rows":
+        # VALU view of the same kernel: permutations per launch x modelled issue cycles per 64-lane permutation
+        # (DESIGN.md §4: 8 full rounds x 2368 + 7 partial groups x 1576 + 1024 + 138 cycles) against 1024 SIMDs at 2.4 GHz
+        perms = sum(-(-w // 16) for w in (wc, wd, wa, 16)) * 4 * n          # leaves of the 3 trace trees + check tree
+        deg = n
+        while deg > 256:                                                   # FRI rounds: 4*deg/16 rows of 64 words
+            perms += 4 * (4 * deg // 16)
+            deg //= 16
+        cyc = 8 * 2368 + 7 * 1576 + 1024 + 138
+        per_seal_ms = unshared[dom_name]["total_ms"] / (1 if ref else args.steps)
+        line["roofline"]["valu"] = {"permutations_per_seal": perms, "model_cycles_per_wave_permutation": cyc,
+                                    "issue_utilisation_at_2p4GHz": (perms / 64.0) * cyc / (1024 * 2.4e9 * per_seal_ms * 1e-3)}
+    div = 1 if ref else args.steps
+    line["kernels"] = [{"name": p["name"], "calls_per_seal": p["calls"] / div,
+                        "ms_per_seal": p["total_ms"] / div,          # unshared (one seal alone on the GPU)
+                        "ms_per_seal_timed_region": next((q["total_ms"] / args.steps for q in prof if q["name"] == p["name"]), None),
+                        # §8d algorithmic bytes (operands once in, once out) / time; 0 for the later passes of a multi-pass op
+                        "alg_GBps": (p["alg_bytes"] / (p["total_ms"] * 1e-3) / 1e9) if p["total_ms"] > 0 else 0.0}
+                       for p in sorted(unshared.values(), key=lambda p: -p["total_ms"])]
+    # per Hal op (NTT records are "<op>:<kernel>" per pass): op totals with §8d bytes over the sum of the passes
+    ops = {}
+    for p in unshared.values():
+        o = ops.setdefault(p["name"].split(":")[0], {"ms": 0.0, "bytes": 0.0})
+        o["ms"] += p["total_ms"] / div; o["bytes"] += p["alg_bytes"] / div
+    line["ops"] = [{"op": k, "ms_per_seal": v["ms"], "alg_GBps": v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0}
+                   for k, v in sorted(ops.items(), key=lambda kv: -kv[1]["ms"])]
 
 
 if __name__ == "__main__":

@@ -167,6 +167,13 @@ int zkh_circuit_has_compiled_kernel(const zkh_circuit*);
  * kernels/…/eval_check.cu, un-vendored: /root/reference/Cargo.lock:5320) for circuits that arrive as data.
  * Not thread-safe against a concurrent zkh_eval_check on the same circuit. */
 const char* zkh_circuit_attach_code_object(zkh_circuit*, const void* image, size_t len, const char* kernel_name);
+/* A constraint system of realistic size is generated as n_parts kernels over disjoint constraint ranges (upstream splits
+ * its generated eval_check over many translation units for the same reason); each part arrives as its own code object.
+ * zkh_eval_check uses them once all n_parts are attached: part 0 writes `check`, the others add their share. */
+const char* zkh_circuit_attach_code_object_part(zkh_circuit*, const void* image, size_t len, const char* kernel_name,
+                                                size_t part, size_t n_parts);
+/* number of kernels zkh_eval_check will launch for this circuit (0: step interpreter) */
+size_t zkh_circuit_compiled_parts(const zkh_circuit*);
 /* CircuitHal::eval_check(check, groups, globals, poly_mix, po2, steps).  groups = evaluated accum, code, data
  * (each W x 4n; n_groups must be 3); globals = out, mix (n_globals must be 2); steps = 2^po2 like upstream.
  * use_interpreter != 0 forces the generic interpreter kernel. */

@@ -192,3 +192,58 @@ def test_join_schedule_shape_and_placement():
             assert len(lv) == (S - 1).bit_length()
     with pytest.raises(ValueError):
         join_schedule(0, 1)
+
+
+def test_codegen_value_numbering_windows_and_splitting():
+    """circuits/codegen.py on a constraint system of realistic shape: structurally identical sub-expressions collapse,
+    the leaves are cut into parts that cover every constraint exactly once, every part is a self-contained kernel."""
+    from zeth_amd.circuits import syn_heavy
+    desc = syn_heavy.syn_heavy_small()
+    c = Circuit.parse(desc)
+    plan = codegen.Plan.build(c)
+    arith = sum(1 for s in c.steps if s[0] in (4, 5, 6))
+    assert plan.n_unique < 0.85 * arith                      # Z_j and the shared terms are re-emitted by the circuit
+    assert any(plan.ext)                                     # ConstExt operands make some values Fp4-typed
+    weights = plan.leaf_weights()
+    assert len(weights) == plan.n_leaves[c.ret] == sum(1 for s in c.steps if s[0] == OP_AND_EQZ)
+    cuts = codegen.split_points(weights)
+    assert len(cuts) >= 2 and cuts[0][0] == 0 and cuts[-1][1] == len(weights)
+    assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+    parts, h, n_pows = codegen.emit_parts("t", desc, standalone=True)
+    assert [k for k, _ in parts] == codegen.part_kernel_names("t", len(cuts))
+    assert n_pows == plan.n_pows and h == codegen.desc_hash64(desc)
+    for k, src in parts:
+        assert f'extern "C" __global__ __launch_bounds__(256) void {k}(EvalCheckArgs a)' in src
+        assert "a.accumulate" in src and "tap_load(" in src and "volatile" not in src
+    # a small circuit stays one kernel with the historical name
+    one, _, _ = codegen.emit_parts("syn_tiny", syn_air.syn_tiny())
+    assert [k for k, _ in one] == ["k_eval_check_syn_tiny"]
+    # the full SYN-HEAVY: ~54 k steps, ~1.1 k taps, 7 tap combos, > 8 kernels
+    big = Circuit.parse(syn_heavy.syn_heavy())
+    assert len(big.steps) > 50000 and len(big.taps) > 1000 and len(big.combos) == 7
+
+
+def test_multi_part_jit_cross_compiles_with_verified_cache(tmp_path, monkeypatch):
+    from zeth_amd.circuits import jit, syn_heavy
+    if jit.hipcc_path() is None:
+        pytest.skip("hipcc not installed")
+    monkeypatch.setenv("ZKH_JIT_CACHE", str(tmp_path))
+    desc = syn_heavy.syn_heavy_small()
+    objs = jit.compile_code_objects(desc)
+    assert len(objs) >= 2 and all(img[:4] == b"\x7fELF" or img.startswith(b"__CLANG_OFFLOAD_BUNDLE__") for img, _ in objs)
+    files = sorted(f.name for f in tmp_path.iterdir())
+    assert sum(f.endswith(".hsaco") for f in files) == len(objs) == sum(f.endswith(".sha256") for f in files)
+    assert (os.stat(tmp_path).st_mode & 0o022) == 0
+    # a tampered cache entry is not used: it is recompiled (and with no compiler available, that fails loudly)
+    victim = next(f for f in tmp_path.iterdir() if f.name.endswith(".hsaco"))
+    victim.write_bytes(victim.read_bytes()[:-8] + b"tampered")
+    monkeypatch.setenv("HIPCC", "/nonexistent/hipcc")
+    with pytest.raises(jit.JitError):
+        jit.compile_code_objects(desc)
+    # `python -m zeth_amd.circuits.jit` writes code objects + a manifest for hosts that attach them through the C ABI
+    monkeypatch.delenv("HIPCC")
+    out = tmp_path / "objs"
+    assert jit.main(["jit", "syn_tiny", str(out)]) == 0
+    import json
+    man = json.load(open(out / "manifest.json"))
+    assert man["arch"] == "gfx950" and len(man["parts"]) == 1 and (out / man["parts"][0]["file"]).exists()

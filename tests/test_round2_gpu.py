@@ -323,3 +323,109 @@ def test_version_names_the_placeholder_tables():
     from zeth_amd import hal as zhal
     v = zhal.load_library().zkh_version().decode()
     assert "gfx950" in v and "poseidon2_consts=placeholder" in v
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SYN-HEAVY: a constraint system of realistic weight (value numbering, windows, split kernels, ConstExt, nested AndCond)
+# ---------------------------------------------------------------------------------------------------------------
+def _evaluated_groups(hal, oracle, prover, oc, seg):
+    """Witness + accum + the three evaluated groups on the device, and the same on the host (oracle)."""
+    import ctypes as C
+    desc = prover.circuit.desc
+    wa, wc, wd = (int(x) for x in desc[3:6])
+    n, dom = 1 << seg.po2, 4 << seg.po2
+    code, data, out = prover.witgen(seg)
+    ocode, odata, oout = oc.witgen(seg.po2, seg.zk_cycles, seg.seed, seg.noise_seed)
+    assert np.array_equal(code.to_vec(), ocode) and np.array_equal(data.to_vec(), odata) and np.array_equal(out, oout)
+    mix = np.random.default_rng(1).integers(0, 2013265921, size=wa, dtype=np.uint64).astype(np.uint32)
+    accum = hal.alloc_elem("accum", wa * n)
+    hal.syn_accum(prover.circuit, seg.po2, seg.zk_cycles, seg.noise_seed, data, mix, accum)
+    ev, oev = [], []
+    for buf, w in ((accum, wa), (code, wc), (data, wd)):
+        co = hal.alloc_elem("co", w * n)
+        hal.batch_interpolate_ntt_from(co, buf, w, True)
+        e = hal.alloc_elem("ev", w * dom)
+        hal.batch_expand_into_evaluate_ntt(e, co, w, 2)
+        ev.append(e)
+        oev.append(e.to_vec())               # the NTTs have their own parity tests: feed both sides the same evaluations
+    return ev, oev, out, mix
+
+
+def test_syn_heavy_eval_check_generated_interpreted_and_oracle_agree(hal, oracle, tmp_path, monkeypatch):
+    """ConstExt operands, AndCond inside AndCond, thousands of constraints with shared sub-expressions: the generated
+    kernels (value numbering + windows, TWO parts accumulated into `check`, compiled at load time), the on-device step
+    interpreter (taps / constants as operands, Fp4-typed slots) and the oracle's literal interpreter give identical words."""
+    import ctypes as C
+    from zeth_amd.circuits import syn_heavy
+    monkeypatch.setenv("ZKH_JIT_CACHE", str(tmp_path))
+    desc = syn_heavy.syn_heavy_small()
+    prover = SegmentProver(hal, desc)
+    assert prover.circuit.kernel_kind() == "attached" and prover.circuit.compiled_parts() >= 2
+    oc = zko.OracleCircuit(oracle, desc)
+    seg = Segment(index=0, po2=10, seed=11, noise_seed=12, zk_cycles=300)
+    ev, oev, out, mix = _evaluated_groups(hal, oracle, prover, oc, seg)
+    dom = 4 << seg.po2
+    poly_mix = np.random.default_rng(2).integers(0, 2013265921, size=4, dtype=np.uint64).astype(np.uint32)
+    want = np.zeros(4 * dom, np.uint32)
+    gp = (C.c_void_p * 3)(*[a.ctypes.data for a in oev])
+    glp = (C.c_void_p * 2)(out.ctypes.data, mix.ctypes.data)
+    oracle.zko_eval_check(oc.h, want, gp, glp, poly_mix, seg.po2)
+    g_out, g_mix = hal.copy_from("out", out), hal.copy_from("mix", mix)
+    for interp in (False, True):
+        check = hal.alloc_elem("check", 4 * dom)
+        prover.circuit.eval_check(check, ev, [g_out, g_mix], poly_mix, seg.po2, use_interpreter=interp)
+        assert np.array_equal(check.to_vec(), want), f"eval_check mismatch (interpreter={interp})"
+
+
+@pytest.mark.parametrize("po2,zk", [(9, 100), (13, 1994)])
+def test_syn_heavy_small_seal_bit_exact(hal, oracle, po2, zk, tmp_path, monkeypatch):
+    from zeth_amd.circuits import syn_heavy
+    monkeypatch.setenv("ZKH_JIT_CACHE", str(tmp_path))
+    desc = syn_heavy.syn_heavy_small()
+    prover = SegmentProver(hal, desc)
+    seg = Segment(index=0, po2=po2, seed=21 + po2, noise_seed=22, zk_cycles=zk)
+    receipt = prover.prove_segment(seg)
+    oc = zko.OracleCircuit(oracle, desc)
+    want = oc.prove(po2, zk, seg.seed, seg.noise_seed)
+    assert np.array_equal(receipt.seal, want)
+    receipt.verify(desc, prover.control_root(po2, zk))
+
+
+def test_syn_heavy_full_circuit_seal_bit_exact_and_po2_20_verifies(hal, oracle):
+    """The bench's `--circuit syn_heavy` (54 k steps, 1061 taps, 17 built-in kernels): byte-identical to the oracle at
+    po2 13, and a 2^20-cycle seal is accepted by the product's verifier and by the oracle's."""
+    from zeth_amd.circuits import syn_heavy
+    desc = syn_heavy.syn_heavy()
+    prover = SegmentProver(hal, desc)
+    assert prover.circuit.kernel_kind() == "builtin" and prover.circuit.compiled_parts() >= 8
+    oc = zko.OracleCircuit(oracle, desc)
+    seg = Segment(index=0, po2=13, seed=31, noise_seed=32)
+    receipt = prover.prove_segment(seg)
+    assert np.array_equal(receipt.seal, oc.prove(13, 1994, seg.seed, seg.noise_seed))
+    big = prover.prove_segment(Segment(index=1, po2=20, seed=33, noise_seed=34))
+    big.verify(desc, prover.control_root(20))
+    assert oc.verify(big.seal, prover.control_root(20)) is None
+
+
+@pytest.mark.parametrize("bitrev", [False, True])
+def test_batch_evaluate_any_runs_of_equal_columns(hal, oracle, bitrev):
+    """Taps of one register = consecutive entries with the same `which`: one block streams the column once for up to 8
+    points.  Runs of every length around that limit, interleaved with singletons, against the oracle."""
+    rng = np.random.default_rng(77)
+    po2, count = 14, 12
+    n = 1 << po2
+    coeffs = rng.integers(0, 2013265921, size=count * n, dtype=np.uint64).astype(np.uint32)
+    which = []
+    for col, run in zip([3, 0, 7, 7, 1, 11, 5, 2, 9, 4, 4, 6], [1, 5, 8, 9, 2, 17, 1, 3, 16, 7, 1, 24]):
+        which += [col] * run
+    which = np.array(which, dtype=np.uint32)
+    xs = rng.integers(0, 2013265921, size=4 * which.size, dtype=np.uint64).astype(np.uint32)
+    want = np.zeros(4 * which.size, np.uint32)
+    oracle.zko_batch_evaluate_any(coeffs, coeffs.size, count, which, xs, which.size, want)
+    dev = coeffs.copy()
+    if bitrev:
+        oracle.zko_batch_bit_reverse(dev, dev.size, count)       # the layout batch_interpolate_ntt leaves behind
+    out = hal.alloc_elem("out", 4 * which.size)
+    fn = hal.batch_evaluate_any_bitrev if bitrev else hal.batch_evaluate_any
+    fn(hal.copy_from("c", dev), count, hal.copy_from("w", which), hal.copy_from("x", xs), out)
+    assert np.array_equal(out.to_vec(), want)

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libzkhal_mi355x.so")
 OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
-SOURCES = ["hal.hip", "ntt.hip", "hash.hip", "poly.hip", "circuit.hip", "prover.hip", "verifier.hip", "eval_check_gen.hip"]
+SOURCES = ["hal.hip", "ntt.hip", "hash.hip", "poly.hip", "circuit.hip", "prover.hip", "verifier.hip"]   # + generated eval_check units
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-unused-result"]
 # hash.hip: the unrolled Poseidon2 source order already interleaves 24 independent cells; LLVM's machine scheduler
@@ -51,10 +51,11 @@ def _compile(src: str, force: bool) -> str:
     return obj
 
 
-def generate_eval_check() -> None:
-    """Emit csrc/eval_check_gen.hip: straight-line eval_check kernels for the shipped circuits."""
+def generate_eval_check() -> list:
+    """Emit csrc/eval_check_gen*.hip: straight-line eval_check kernels for the shipped circuits (one translation unit per
+    part of a split constraint system, so that the parts compile in parallel).  Returns the generated file names."""
     from .circuits import codegen
-    codegen.write_generated(os.path.join(CSRC, "eval_check_gen.hip"))
+    return codegen.write_generated(CSRC)
 
 
 def build_examples() -> str:
@@ -78,9 +79,13 @@ def build_oracle() -> None:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
-    generate_eval_check()
-    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    sources = SOURCES + generate_eval_check()
+    wanted = {s.replace(".hip", ".o") for s in sources}
+    for f in os.listdir(OBJ_DIR):                       # objects of generated units that no longer exist
+        if f.startswith("eval_check_gen") and f.endswith(".o") and f not in wanted:
+            os.remove(os.path.join(OBJ_DIR, f))
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, len(sources))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), sources))
     newest = max(os.path.getmtime(o) for o in objs)
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]

@@ -1,22 +1,34 @@
 """eval_check code generator: circuit desc (PolyExtStep list) -> straight-line HIP for gfx950.
 
 Upstream ships machine-generated CUDA for `CircuitHal::eval_check` (Zirgen output inside
-risc0-circuit-rv32im-sys, un-vendored: /root/reference/Cargo.lock:5320).  Here the generator is part of the
-build: `zeth_amd.build` runs it for the shipped circuit shapes and compiles the result into
-libzkhal_mi355x.so; at run time `zkh_circuit_load` picks the kernel whose desc hash matches, and any other
-desc falls back to the on-device interpreter (circuit.hip).
+risc0-circuit-rv32im-sys, un-vendored: /root/reference/Cargo.lock:5320), split over many translation units because
+one domain point evaluates O(10^4 - 10^5) field operations.  Here the generator is part of the build:
+`zeth_amd.build` runs it for the shipped circuit shapes and compiles the result into libzkhal_mi355x.so; at run time
+`zkh_circuit_load` picks the kernels whose desc hash matches, a desc that is not shipped gets the same treatment at
+load time (circuits/jit.py), and the on-device interpreter (circuit.hip) is the cross-check / last resort.
 
-MI355X-first choices (all result-preserving — field arithmetic is exact):
-  * value registers are Fp (the prover evaluates on the base-field coset), only mix totals are Fp4;
-  * every MixState's `mul` is a *static* power of poly_mix (True = mix^0, AndEqz adds 1, AndCond adds the
-    inner exponent), so the per-step Fp4 x Fp4 product of the literal algorithm disappears: powers come from a
-    precomputed table through scalar loads, and AndEqz is 4 multiply-adds;
-  * one lane per domain point, every tap read is a coalesced column read;
-  * 1/((3x)^n - 1) takes only 4 values on the coset (3^n * i^(idx mod 4)): a 4-entry kernel argument.
+MI355X-first choices (all result-preserving — field arithmetic is exact, results equal the literal step interpreter):
+  * value registers are Fp (the prover evaluates on the base-field coset); a value is Fp4 only downstream of a
+    ConstExt; mix totals are Fp4;
+  * every MixState's `mul` is a *static* power of poly_mix (True = mix^0, AndEqz adds 1, AndCond adds the inner
+    exponent), so the per-step Fp4 x Fp4 product of the literal algorithm disappears: powers come from a precomputed
+    table through scalar loads, AndEqz is 4 multiply-adds into 64-bit accumulators reduced once per 4 constraints;
+  * VALUE NUMBERING: structurally identical sub-expressions (same op on the same canonical operands, commutative ops
+    normalised) are computed once inside a window of constraints;
+  * WINDOWS bound the register pressure: a window is a run of consecutive constraints whose distinct live values fit a
+    budget; it is a C++ block, taps are (re)loaded where they are used, and a compiler barrier between windows that
+    share taps keeps LLVM from hoisting hundreds of loads to the top of the kernel (= spills);
+  * SPLITTING: the constraint leaves (in depth-first order of the mix tree) are cut into parts of roughly equal weight;
+    each part is its own kernel (own translation unit when shipped, own code object when compiled at load time, all
+    compiled in parallel) that evaluates only its leaves — partial sums of an AndCond's inner chain are multiplied by
+    the condition in every part that holds some of its leaves (distributivity) — and ADDS its share into `check`;
+  * one lane per domain point, every tap read is a coalesced column read; 1/((3x)^n - 1) takes only 4 values on the
+    coset (3^n * i^(idx mod 4)): a 4-entry kernel argument.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Tuple
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 
@@ -25,6 +37,9 @@ from .desc import (OP_ADD, OP_AND_COND, OP_AND_EQZ, OP_CONST, OP_CONST_EXT, OP_G
                    OP_TRUE, Circuit, P)
 
 R2 = pow(2, 64, P)
+WINDOW_BUDGET = 56          # distinct values (taps + intermediates) a window may define
+PART_WEIGHT = 3200          # value steps per generated kernel (one kernel ~ one translation unit / code object)
+GENERATOR_VERSION = 2
 
 
 def desc_hash64(desc: np.ndarray) -> int:
@@ -41,7 +56,7 @@ def mont(x: int) -> int:
 
 
 def analyse(c: Circuit):
-    """-> (fp_of_step, mix_of_step, mix_exp, used_fp, used_mix, n_pows)"""
+    """-> (kinds, mix_exp, used_fp, used_mix, n_pows): static mix exponents and liveness of the step list."""
     mix_exp: List[int] = []
     nf = nm = 0
     kinds = []
@@ -84,153 +99,471 @@ def analyse(c: Circuit):
     return kinds, mix_exp, used_f, used_m, max_pow + 1
 
 
-def emit_kernel(name: str, desc: np.ndarray, standalone: bool = False) -> Tuple[str, int, int]:
-    """HIP source of `k_eval_check_<name>` for this desc.  standalone=True: an `extern "C"` kernel with no host-side
-    launcher, for a code object that is attached at run time (circuits/jit.py)."""
-    c = Circuit.parse(desc)
-    kinds, mix_exp, used_f, used_m, n_pows = analyse(c)
+# -------------------------------------------------------------------------------------------------------------------
+# Plan: value numbering + the mix tree in chain form
+# -------------------------------------------------------------------------------------------------------------------
+@dataclass
+class Plan:
+    c: Circuit
+    fp: List[Tuple[int, int, int, int, int]] = field(default_factory=list)     # per fp var: (op, a, b, c, d), operands canonical
+    canon: List[int] = field(default_factory=list)                             # fp var -> canonical fp var
+    ext: List[bool] = field(default_factory=list)                              # fp var is Fp4-valued
+    mix: List[Tuple] = field(default_factory=list)                             # per mix var: ('t',) | ('e', x, v) | ('c', x, cond, y)
+    mix_exp: List[int] = field(default_factory=list)
+    n_leaves: List[int] = field(default_factory=list)                          # AndEqz leaves below each mix var
+    cone_size: Dict[int, int] = field(default_factory=dict)
+    n_pows: int = 1
+    n_unique: int = 0                                                          # canonical value steps reachable from ret
+
+    @staticmethod
+    def build(c: Circuit) -> "Plan":
+        p = Plan(c)
+        table: Dict[Tuple, int] = {}
+        for op, a, b, cc, d in c.steps:
+            if op >= OP_TRUE:
+                if op == OP_TRUE:
+                    p.mix.append(("t",)); p.mix_exp.append(0); p.n_leaves.append(0)
+                elif op == OP_AND_EQZ:
+                    p.mix.append(("e", a, p.canon[b])); p.mix_exp.append(p.mix_exp[a] + 1); p.n_leaves.append(p.n_leaves[a] + 1)
+                else:
+                    p.mix.append(("c", a, p.canon[b], cc)); p.mix_exp.append(p.mix_exp[a] + p.mix_exp[cc])
+                    p.n_leaves.append(p.n_leaves[a] + p.n_leaves[cc])
+                continue
+            vid = len(p.fp)
+            if op in (OP_ADD, OP_SUB, OP_MUL):
+                x, y = p.canon[a], p.canon[b]
+                if op != OP_SUB and x > y:
+                    x, y = y, x                                  # commutative: one canonical operand order
+                key = (op, x, y)
+                is_ext = p.ext[x] or p.ext[y]
+                step = (op, x, y, 0, 0)
+            elif op == OP_CONST:
+                key, is_ext, step = (op, a % P), False, (op, a % P, 0, 0, 0)
+            elif op == OP_CONST_EXT:
+                key, is_ext, step = (op, a % P, b % P, cc % P, d % P), True, (op, a % P, b % P, cc % P, d % P)
+            elif op == OP_GET:
+                key, is_ext, step = (op, a), False, (op, a, 0, 0, 0)
+            elif op == OP_GET_GLOBAL:
+                key, is_ext, step = (op, a, b), False, (op, a, b, 0, 0)
+            else:
+                raise ValueError(f"unknown step op {op}")
+            rep = table.setdefault(key, vid)
+            p.fp.append(step); p.canon.append(rep); p.ext.append(is_ext)
+        # reachable canonical values + max power used
+        seen = set()
+        max_pow = 0
+        stack = [c.ret]
+        seen_m = set()
+        roots: List[int] = []
+        while stack:
+            m = stack.pop()
+            if m in seen_m:
+                continue
+            seen_m.add(m)
+            node = p.mix[m]
+            if node[0] == "e":
+                stack.append(node[1]); roots.append(node[2]); max_pow = max(max_pow, p.mix_exp[node[1]])
+            elif node[0] == "c":
+                stack.append(node[1]); stack.append(node[3]); roots.append(node[2]); max_pow = max(max_pow, p.mix_exp[node[1]])
+        p.n_pows = max_pow + 1
+        work = list(roots)
+        while work:
+            v = work.pop()
+            if v in seen:
+                continue
+            seen.add(v)
+            op, x, y, _, _ = p.fp[v]
+            if op in (OP_ADD, OP_SUB, OP_MUL):
+                work.append(x); work.append(y)
+        p.n_unique = sum(1 for v in seen if p.fp[v][0] in (OP_ADD, OP_SUB, OP_MUL))
+        return p
+
+    def chain(self, m: int) -> List[Tuple]:
+        """Items of the chain ending in mix var m, in evaluation order: ('e', value, exp) | ('c', cond, inner var, exp)."""
+        items = []
+        while self.mix[m][0] != "t":
+            node = self.mix[m]
+            if node[0] == "e":
+                items.append(("e", node[2], self.mix_exp[node[1]]))
+            else:
+                items.append(("c", node[2], node[3], self.mix_exp[node[1]]))
+            m = node[1]
+        items.reverse()
+        return items
+
+    def cone(self, v: int, have) -> List[int]:
+        """Canonical values needed to compute v that are not in `have`, in dependency order (operands first)."""
+        out: List[int] = []
+        mark = set()
+        stack = [(v, False)]
+        while stack:
+            x, done = stack.pop()
+            if done:
+                out.append(x)
+                continue
+            if x in have or x in mark:
+                continue
+            mark.add(x)
+            stack.append((x, True))
+            op, a, b, _, _ = self.fp[x]
+            if op in (OP_ADD, OP_SUB, OP_MUL):
+                stack.append((b, False)); stack.append((a, False))
+        return out
+
+    def leaf_weights(self) -> List[int]:
+        """Cost estimate per AndEqz leaf in depth-first order (arithmetic steps in its cone, no cross-leaf sharing)."""
+        w: List[int] = []
+
+        def walk(m: int):
+            for it in self.chain(m):
+                if it[0] == "e":
+                    w.append(4 + sum(1 for x in self.cone(it[1], set()) if self.fp[x][0] in (OP_ADD, OP_SUB, OP_MUL)))
+                else:
+                    walk(it[2])
+        walk(self.c.ret)
+        return w
+
+
+def split_points(weights: List[int], part_weight: int = PART_WEIGHT) -> List[Tuple[int, int]]:
+    """Cut the leaf sequence into contiguous [lo, hi) ranges of roughly part_weight each."""
+    total = sum(weights)
+    n_parts = max(1, -(-total // part_weight))
+    target = total / n_parts
+    cuts, acc, lo = [], 0.0, 0
+    for i, w in enumerate(weights):
+        acc += w
+        if acc >= target * (len(cuts) + 1) and len(cuts) + 1 < n_parts:
+            cuts.append((lo, i + 1)); lo = i + 1
+    cuts.append((lo, len(weights)))
+    return [c for c in cuts if c[1] > c[0]] or [(0, len(weights))]
+
+
+# -------------------------------------------------------------------------------------------------------------------
+# Emission of one part
+# -------------------------------------------------------------------------------------------------------------------
+class _Emitter:
+    def __init__(self, plan: Plan, lo: int, hi: int):
+        self.p, self.lo, self.hi = plan, lo, hi
+        self.lines: List[str] = []
+        self.scope: set = set()             # canonical values defined in the open window
+        self.loaded_before: set = set()     # taps loaded by earlier windows (barrier needed before re-loading them)
+        self.window_open = False
+        self.depth_used = 0
+        self.pend: Dict[int, int] = {}      # depth -> lazy products pending in s{d}_*
+        self.tzero: Dict[int, bool] = {}    # depth -> t{d}_* statically known to be zero
+        self.backs: set = set()
+        self.globals_used: set = set()
+        self.leaf = 0                       # depth-first index of the next leaf
+        self.n_windows = 0
+        self.window_backs: List[set] = []   # per window: the backs its loads use (-> which offsets get an opaque copy)
+
+    def w(self, s: str) -> None:
+        self.lines.append(s)
+
+    # ---- windows ----
+    def open_window(self, need_barrier: bool) -> None:
+        # Window-local copies of the lane's byte offsets and of the domain size, made opaque to the optimiser: tap loads and
+        # column-base computations of different windows then are different SSA values, so GVN cannot merge a tap that many
+        # windows read into one long-lived register (= hundreds of VGPRs / SGPR spills at realistic circuit sizes).  No
+        # memory clobber: the mix-power reads must stay provably invariant to remain scalar loads.
+        self.w("    {")
+        self.w(f"        OPAQUE_WINDOW_{self.n_windows}")
+        self.window_backs.append(set())
+        self.window_open = True
+        self.n_windows += 1
+
+    def close_window(self) -> None:
+        if self.window_open:
+            self.w("    }")
+            self.loaded_before |= {v for v in self.scope if self.p.fp[v][0] == OP_GET}
+            self.scope = set()
+            self.window_open = False
+
+    def ensure_values(self, roots: List[int]) -> None:
+        """Define every value the roots need inside the current window; start a new window first if the budget is exceeded."""
+        need: List[int] = []
+        have = set(self.scope)
+        for r in roots:
+            for x in self.p.cone(r, have):
+                need.append(x); have.add(x)
+        defs = [x for x in need if self.p.fp[x][0] not in (OP_CONST, OP_GET_GLOBAL)]
+        if self.window_open and len(self.scope) + len(defs) > WINDOW_BUDGET and self.scope:
+            self.close_window()
+            need, have = [], set()
+            for r in roots:
+                for x in self.p.cone(r, have):
+                    need.append(x); have.add(x)
+            defs = [x for x in need if self.p.fp[x][0] not in (OP_CONST, OP_GET_GLOBAL)]
+        if not self.window_open:
+            reload = any(self.p.fp[x][0] == OP_GET and x in self.loaded_before for x in defs)
+            self.open_window(reload)
+        for x in need:
+            self.define(x)
+
+    def ref(self, v: int) -> str:
+        op, a, b, _, _ = self.p.fp[v]
+        if op == OP_CONST:
+            return f"{mont(a)}u"
+        if op == OP_GET_GLOBAL:
+            self.globals_used.add((a, b))
+            return f"q{a}_{b}"
+        return f"v{v}"
+
+    def ext_ref(self, v: int) -> str:
+        """An Fp4 expression for value v (promoting Fp values)."""
+        if self.p.ext[v]:
+            return f"x{v}"
+        return f"Fp4(Fp::raw({self.ref(v)}))"
+
+    def define(self, v: int) -> None:
+        op, a, b, cc, d = self.p.fp[v]
+        if op in (OP_CONST, OP_GET_GLOBAL):
+            self.ref(v)
+            return
+        self.scope.add(v)
+        if op == OP_GET:
+            g, off, back = self.p.c.taps[a]
+            self.backs.add(back)
+            self.window_backs[-1].add(back)
+            self.w(f"        const uint32_t v{v} = tap_load(g{g}, (size_t){off} * dw, o{back});")
+        elif op == OP_CONST_EXT:
+            self.w(f"        const Fp4 x{v}(Fp::raw({mont(a)}u), Fp::raw({mont(b)}u), Fp::raw({mont(cc)}u), Fp::raw({mont(d)}u));")
+        elif self.p.ext[v]:
+            sym = {OP_ADD: "+", OP_SUB: "-", OP_MUL: "*"}[op]
+            if op == OP_MUL and not self.p.ext[a]:
+                self.w(f"        const Fp4 x{v} = x{b} * Fp::raw({self.ref(a)});")
+            elif op == OP_MUL and not self.p.ext[b]:
+                self.w(f"        const Fp4 x{v} = x{a} * Fp::raw({self.ref(b)});")
+            else:
+                self.w(f"        const Fp4 x{v} = {self.ext_ref(a)} {sym} {self.ext_ref(b)};")
+        else:
+            fn = {OP_ADD: "add_mod", OP_SUB: "sub_mod", OP_MUL: "mul_mod"}[op]
+            self.w(f"        const uint32_t v{v} = {fn}({self.ref(a)}, {self.ref(b)});")
+
+    # ---- accumulators ----
+    def use_depth(self, d: int) -> None:
+        self.depth_used = max(self.depth_used, d + 1)
+
+    def reset(self, d: int) -> None:
+        self.use_depth(d)
+        ind = "        " if self.window_open else "    "
+        self.w(f"{ind}t{d}_0 = t{d}_1 = t{d}_2 = t{d}_3 = 0; s{d}_0 = s{d}_1 = s{d}_2 = s{d}_3 = 0;")
+        self.pend[d], self.tzero[d] = 0, True
+
+    def flush(self, d: int) -> None:
+        if self.pend.get(d, 0) == 0:
+            return
+        ind = "        " if self.window_open else "    "
+        for k in range(4):
+            if self.tzero[d]:
+                self.w(f"{ind}t{d}_{k} = mont_reduce_wide(s{d}_{k}); s{d}_{k} = 0;")
+            else:
+                self.w(f"{ind}t{d}_{k} = add_mod(t{d}_{k}, mont_reduce_wide(s{d}_{k})); s{d}_{k} = 0;")
+        self.pend[d], self.tzero[d] = 0, False
+
+    def add_fp4(self, d: int, expr: str) -> None:
+        """t{d} += Fp4 expression (non-lazy path: ConstExt-valued constraints and AndCond contributions)."""
+        self.flush(d)
+        ind = "        " if self.window_open else "    "
+        self.w(f"{ind}{{ const Fp4 c_ = {expr};")
+        for k in range(4):
+            self.w(f"{ind}  t{d}_{k} = add_mod(t{d}_{k}, c_.c[{k}].v);")
+        self.w(f"{ind}}}")
+        self.tzero[d] = False
+
+    # ---- the mix tree ----
+    def emit_chain(self, m: int, d: int) -> bool:
+        """Accumulate into depth d the leaves of chain m that fall into [lo, hi).  Returns whether anything was emitted."""
+        any_emitted = False
+        for it in self.p.chain(m):
+            if it[0] == "e":
+                idx = self.leaf
+                self.leaf += 1
+                if not (self.lo <= idx < self.hi):
+                    continue
+                _, v, e = it
+                self.ensure_values([v])
+                any_emitted = True
+                if self.p.ext[v]:
+                    self.add_fp4(d, f"Fp4(Fp::raw(pw[{e}].x), Fp::raw(pw[{e}].y), Fp::raw(pw[{e}].z), Fp::raw(pw[{e}].w)) * x{v}")
+                    continue
+                # tot += mix^e * v: four 64-bit multiply-adds (scalar-loaded power words), ONE reduction per four constraints
+                # (4 P^2 < 2 P 2^32, the bound of mont_reduce_wide)
+                r = self.ref(v)
+                self.w(f"        {{ const uint4 p_ = pw[{e}]; s{d}_0 += (uint64_t)p_.x * {r}; s{d}_1 += (uint64_t)p_.y * {r}; "
+                       f"s{d}_2 += (uint64_t)p_.z * {r}; s{d}_3 += (uint64_t)p_.w * {r}; }}")
+                self.pend[d] = self.pend.get(d, 0) + 1
+                if self.pend[d] == 4:
+                    self.flush(d)
+            else:
+                _, cond, inner, e = it
+                first = self.leaf
+                n_in = self.p.n_leaves[inner]
+                if first + n_in <= self.lo or first >= self.hi or n_in == 0:
+                    self.leaf += n_in
+                    continue
+                self.reset(d + 1)
+                got = self.emit_chain(inner, d + 1)
+                if not got:
+                    continue
+                self.flush(d + 1)
+                self.ensure_values([cond])
+                any_emitted = True
+                tin = f"Fp4(Fp::raw(t{d + 1}_0), Fp::raw(t{d + 1}_1), Fp::raw(t{d + 1}_2), Fp::raw(t{d + 1}_3))"
+                prod = f"{tin} * {self.ext_ref(cond)}" if self.p.ext[cond] else f"{tin} * Fp::raw({self.ref(cond)})"
+                if e != 0:
+                    prod = f"({prod}) * Fp4(Fp::raw(pw[{e}].x), Fp::raw(pw[{e}].y), Fp::raw(pw[{e}].z), Fp::raw(pw[{e}].w))"
+                self.add_fp4(d, prod)
+        return any_emitted
+
+
+def emit_part(kernel: str, plan: Plan, lo: int, hi: int, standalone: bool, header: str) -> str:
+    em = _Emitter(plan, lo, hi)
+    em.use_depth(0)
+    em.pend[0], em.tzero[0] = 0, True
+    em.emit_chain(plan.c.ret, 0)
+    em.close_window()
+    em.flush(0)
+    body = []
+    for ln in em.lines:
+        if ln.startswith("        OPAQUE_WINDOW_"):
+            k = int(ln.rsplit("_", 1)[1])
+            bks = sorted(em.window_backs[k])
+            decl = " ".join(f"uint32_t o{bk} = b{bk};" for bk in bks)
+            outs = ", ".join([f'"+v"(o{bk})' for bk in bks] + ['"+s"(dw)'])
+            # not `volatile` (a volatile asm counts as a memory clobber and would turn the mix-power reads into vector loads);
+            # the window number in the text keeps identical-looking statements from being merged
+            body.append(f"        {decl} uint32_t dw = a.dom; asm(\"; window {k}\" : {outs});")
+        else:
+            body.append(ln)
     L: List[str] = []
     w = L.append
-    w(f"// {name}: groups (accum, code, data) = {c.group_sizes}, {len(c.taps)} taps, {len(c.steps)} steps")
+    w(header)
     linkage = 'extern "C" ' if standalone else ""
-    w(f"{linkage}__global__ __launch_bounds__(256) void k_eval_check_{name}(EvalCheckArgs a) {{")
+    w(f"{linkage}__global__ __launch_bounds__(256) void {kernel}(EvalCheckArgs a) {{")
     w("    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;")
     w("    if (idx >= a.dom) return;")
     w("    const uint32_t mask = a.dom - 1;")
     w("    const size_t dom = a.dom;")
     w("    const uint4* __restrict__ pw = (const uint4*)a.mix_pows;")
-    # how often each live mix var is consumed (a var consumed once by an AndEqz can stay a lazy 64-bit sum)
-    m_uses: Dict[int, int] = {}
-    for i, (op, x, y, z, d) in enumerate(c.steps):
-        k, vid = kinds[i]
-        if k == "m" and used_m[vid]:
-            if op == OP_AND_EQZ:
-                m_uses[x] = m_uses.get(x, 0) + 1
-            elif op == OP_AND_COND:
-                m_uses[x] = m_uses.get(x, 0) + 1
-                m_uses[z] = m_uses.get(z, 0) + 1
-    m_uses[c.ret] = m_uses.get(c.ret, 0) + 1
-    lazy: Dict[int, Tuple] = {}          # vid -> (base vid or None, [(step index of the power load, fp var)])
-    materialised = set()
-    zero_vars = set()
-
-    def materialise(vid: int) -> None:
-        if vid in materialised:
-            return
-        base, pend = lazy.pop(vid)
-        materialised.add(vid)
-        for kk, comp in enumerate("xyzw"):
-            prods = " + ".join(f"(uint64_t)p{si}.{comp} * f{fv}" for si, fv in pend)
-            if base is not None and len(pend) <= 2:
-                w(f"    const uint32_t m{vid}_{kk} = mont_reduce_wide(((uint64_t)m{base}_{kk} << 32) + {prods});")
-            elif base is not None:
-                w(f"    const uint32_t m{vid}_{kk} = add_mod(m{base}_{kk}, mont_reduce_wide({prods}));")
-            else:
-                w(f"    const uint32_t m{vid}_{kk} = mont_reduce_wide({prods});")
-
-    for i, (op, x, y, z, d) in enumerate(c.steps):
-        k, vid = kinds[i]
-        if k == "f":
-            if not used_f[vid]:
-                continue
-            v = f"f{vid}"
-            if op == OP_CONST:
-                w(f"    const uint32_t {v} = {mont(x)}u;")
-            elif op == OP_CONST_EXT:
-                raise ValueError("ConstExt is not supported on the device path")
-            elif op == OP_GET:
-                g, off, back = c.taps[x]
-                pos = "idx" if back == 0 else f"((idx - {4 * back}u) & mask)"
-                w(f"    const uint32_t {v} = a.groups[{g}][(size_t){off} * dom + {pos}];")
-            elif op == OP_GET_GLOBAL:
-                w(f"    const uint32_t {v} = a.globals[{x}][{y}];")
-            elif op == OP_ADD:
-                w(f"    const uint32_t {v} = add_mod(f{x}, f{y});")
-            elif op == OP_SUB:
-                w(f"    const uint32_t {v} = sub_mod(f{x}, f{y});")
-            elif op == OP_MUL:
-                w(f"    const uint32_t {v} = mul_mod(f{x}, f{y});")
-        else:
-            if not used_m[vid]:
-                continue
-            m = f"m{vid}"
-            if op == OP_TRUE:
-                zero_vars.add(vid)
-                materialised.add(vid)
-                w(f"    const uint32_t {m}_0 = 0, {m}_1 = 0, {m}_2 = 0, {m}_3 = 0;")
-            elif op == OP_AND_EQZ:
-                # tot = x.tot + mix^e(x) * v.  Products are accumulated as 64-bit sums (v_mad_u64_u32 chains) and
-                # reduced once per <= 4 terms (4 P^2 < 2 P 2^32, the bound of mont_reduce_wide) instead of once each.
-                e = mix_exp[x]
-                w(f"    const uint4 p{i} = pw[{e}];")
-                if x in lazy and m_uses[x] == 1:
-                    base, pend = lazy.pop(x)
-                else:
-                    materialise(x)
-                    base, pend = (None if x in zero_vars else x), []
-                pend = pend + [(i, y)]
-                lazy[vid] = (base, pend)
-                if len(pend) == 4 or m_uses[vid] != 1 or vid == c.ret:
-                    materialise(vid)
-            elif op == OP_AND_COND:
-                e = mix_exp[x]
-                materialise(x)
-                materialise(z)
-                materialised.add(vid)
-                w(f"    const uint4 p{i} = pw[{e}];")
-                w(f"    const Fp4 t{i} = (Fp4(Fp::raw(m{z}_0), Fp::raw(m{z}_1), Fp::raw(m{z}_2), Fp::raw(m{z}_3)) * Fp::raw(f{y})) *"
-                  f" Fp4(Fp::raw(p{i}.x), Fp::raw(p{i}.y), Fp::raw(p{i}.z), Fp::raw(p{i}.w));")
-                for kk in range(4):
-                    w(f"    const uint32_t {m}_{kk} = add_mod(m{x}_{kk}, t{i}.c[{kk}].v);")
-    materialise(c.ret)
-    r = f"m{c.ret}"
+    for g in range(3):
+        w(f"    const uint32_t* __restrict__ g{g} = a.groups[{g}];")
+    for bk in sorted(em.backs):               # byte offset of this lane's row at each back (32-bit: 4n words < 2^26)
+        w(f"    const uint32_t b{bk} = " + ("idx * 4u;" if bk == 0 else f"((idx - {4 * bk}u) & mask) * 4u;"))
+    for (x, y) in sorted(em.globals_used):
+        w(f"    const uint32_t q{x}_{y} = a.globals[{x}][{y}];")
+    for d in range(em.depth_used):
+        w(f"    uint32_t t{d}_0 = 0, t{d}_1 = 0, t{d}_2 = 0, t{d}_3 = 0; uint64_t s{d}_0 = 0, s{d}_1 = 0, s{d}_2 = 0, s{d}_3 = 0;")
+    L.extend(body)
     w("    const uint32_t zi = a.zinv[idx & 3];")
+    w("    if (a.accumulate) {")
     for kk in range(4):
         off = "" if kk == 0 else f"{kk} * dom + "
-        w(f"    a.check[{off}idx] = mul_mod({r}_{kk}, zi);")
+        w(f"        a.check[{off}idx] = add_mod(a.check[{off}idx], mul_mod(t0_{kk}, zi));")
+    w("    } else {")
+    for kk in range(4):
+        off = "" if kk == 0 else f"{kk} * dom + "
+        w(f"        a.check[{off}idx] = mul_mod(t0_{kk}, zi);")
+    w("    }")
     w("}")
     if not standalone:
-        w(f"static void launch_{name}(const EvalCheckArgs& a, hipStream_t s) {{")
-        w(f"    k_eval_check_{name}<<<(a.dom + 255u) / 256u, 256, 0, s>>>(a);")
+        w(f"void launch_{kernel}(const EvalCheckArgs& a, hipStream_t s) {{")
+        w(f"    {kernel}<<<(a.dom + 255u) / 256u, 256, 0, s>>>(a);")
         w("}")
-    return "\n".join(L), desc_hash64(desc), n_pows
+    return "\n".join(L)
 
 
+def part_kernel_names(name: str, n_parts: int) -> List[str]:
+    return [f"k_eval_check_{name}"] if n_parts == 1 else [f"k_eval_check_{name}_p{i:02d}" for i in range(n_parts)]
+
+
+def emit_parts(name: str, desc: np.ndarray, standalone: bool = False) -> Tuple[List[Tuple[str, str]], int, int]:
+    """-> ([(kernel name, HIP source of that kernel)], desc hash, number of mix powers the kernels read).
+    standalone=True: `extern "C"` kernels with no host-side launcher, for code objects attached at run time (circuits/jit.py)."""
+    c = Circuit.parse(desc)
+    plan = Plan.build(c)
+    cuts = split_points(plan.leaf_weights())
+    names = part_kernel_names(name, len(cuts))
+    out = []
+    for k, (lo, hi) in zip(names, cuts):
+        header = (f"// {name}: groups (accum, code, data) = {c.group_sizes}, {len(c.taps)} taps, {len(c.steps)} steps "
+                  f"({plan.n_unique} distinct arithmetic values after value numbering); constraints [{lo}, {hi}) of {plan.n_leaves[c.ret]}")
+        out.append((k, emit_part(k, plan, lo, hi, standalone, header)))
+    return out, desc_hash64(desc), plan.n_pows
+
+
+def emit_kernel(name: str, desc: np.ndarray, standalone: bool = False) -> Tuple[str, int, int]:
+    """All kernels of a circuit as one source text (small circuits: exactly one kernel `k_eval_check_<name>`)."""
+    parts, h, n_pows = emit_parts(name, desc, standalone)
+    return "\n\n".join(src for _, src in parts), h, n_pows
+
+
+# -------------------------------------------------------------------------------------------------------------------
+# Shipped circuits: kernels compiled into libzkhal_mi355x.so
+# -------------------------------------------------------------------------------------------------------------------
 SHIPPED: Dict[str, np.ndarray] = {}
 
 
 def shipped() -> Dict[str, np.ndarray]:
     if not SHIPPED:
+        from . import syn_heavy
         SHIPPED["syn_a"] = syn_air.syn_a()
         SHIPPED["syn_small"] = syn_air.syn_small()
         SHIPPED["syn_tiny"] = syn_air.syn_tiny()
+        SHIPPED["syn_join"] = syn_air.syn_join()
+        SHIPPED["syn_heavy"] = syn_heavy.syn_heavy()
     return SHIPPED
 
 
-def generate_source() -> str:
-    parts = ["// GENERATED by zeth_amd/circuits/codegen.py — do not edit.  Straight-line eval_check kernels (gfx950) for the",
-             "// shipped circuit descriptions; selected at run time by desc hash (circuit.hip).",
-             '#include "circuit.h"', "", "using namespace zkh;", "", "namespace {", ""]
-    table = []
+PREAMBLE = ["// GENERATED by zeth_amd/circuits/codegen.py — do not edit.  Straight-line eval_check kernels (gfx950) for the",
+            "// shipped circuit descriptions; selected at run time by desc hash (circuit.hip).",
+            '#include "circuit.h"', "", "using namespace zkh;", ""]
+
+
+def generate_sources() -> Dict[str, str]:
+    """-> {file name: source}: `eval_check_gen.hip` (registry + the single-kernel circuits) and one
+    `eval_check_gen_<circuit>_pNN.hip` per part of a split circuit, so that the build compiles the parts in parallel."""
+    files: Dict[str, str] = {}
+    main = list(PREAMBLE)
+    table, externs = [], []
     for name, desc in shipped().items():
-        src, h, n_pows = emit_kernel(name, desc)
-        parts.append(src)
-        parts.append("")
-        table.append(f'    {{0x{h:016x}ull, "{name}", launch_{name}, {n_pows}u}},')
-    parts += ["const CompiledEvalCheck k_table[] = {", *table, "};", "", "}  // namespace", "",
-              "namespace zkh {", "const CompiledEvalCheck* find_compiled_eval_check(uint64_t h) {",
-              "    for (const auto& e : k_table) if (e.desc_hash == h) return &e;", "    return nullptr;", "}",
-              "}  // namespace zkh", ""]
-    return "\n".join(parts)
+        parts, h, n_pows = emit_parts(name, desc)
+        launchers = []
+        if len(parts) == 1:
+            main += [parts[0][1], ""]
+            launchers.append(f"launch_{parts[0][0]}")
+        else:
+            for k, src in parts:
+                files[f"eval_check_gen_{name}_{k.rsplit('_', 1)[1]}.hip"] = "\n".join(PREAMBLE + [src, ""])
+                externs.append(f"void launch_{k}(const EvalCheckArgs&, hipStream_t);")
+                launchers.append(f"launch_{k}")
+        main.append(f"static const eval_check_launch_fn parts_{name}[] = {{{', '.join(launchers)}}};")
+        table.append(f'    {{0x{h:016x}ull, "{name}", parts_{name}, {len(launchers)}u, {n_pows}u}},')
+    # the extern declarations must precede the arrays that reference them
+    src = "\n".join(PREAMBLE + externs + [""] + main[len(PREAMBLE):] + ["", "static const CompiledEvalCheck k_table[] = {", *table, "};", "",
+                    "namespace zkh {", "const CompiledEvalCheck* find_compiled_eval_check(uint64_t h) {",
+                    "    for (const auto& e : k_table) if (e.desc_hash == h) return &e;", "    return nullptr;", "}",
+                    "}  // namespace zkh", ""])
+    files["eval_check_gen.hip"] = src
+    return files
 
 
-def write_generated(path: str) -> None:
-    src = generate_source()
-    try:
-        with open(path) as fh:
-            if fh.read() == src:
-                return
-    except FileNotFoundError:
-        pass
-    with open(path, "w") as fh:
-        fh.write(src)
+def write_generated(csrc_dir: str) -> List[str]:
+    """Write the generated translation units into csrc_dir (only files whose content changed are touched) and remove stale
+    generated files.  Returns the file names, `eval_check_gen.hip` first."""
+    import os
+    files = generate_sources()
+    for fn in os.listdir(csrc_dir):
+        if fn.startswith("eval_check_gen") and fn.endswith(".hip") and fn not in files:
+            os.remove(os.path.join(csrc_dir, fn))
+    for fn, src in files.items():
+        path = os.path.join(csrc_dir, fn)
+        try:
+            with open(path) as fh:
+                if fh.read() == src:
+                    continue
+        except FileNotFoundError:
+            pass
+        with open(path, "w") as fh:
+            fh.write(src)
+    return ["eval_check_gen.hip"] + sorted(f for f in files if f != "eval_check_gen.hip")

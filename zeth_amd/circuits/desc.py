@@ -94,6 +94,10 @@ class CircuitBuilder:
     def get_global(self, base: int, off: int) -> Fp:
         return self._fp(OP_GET_GLOBAL, base, off)
 
+    def const_ext(self, c0: int, c1: int, c2: int, c3: int) -> Fp:
+        """PolyExtStep::ConstExt: an extension-field constant (the value it flows into becomes Fp4-valued)."""
+        return self._fp(OP_CONST_EXT, c0 % P, c1 % P, c2 % P, c3 % P)
+
     def add(self, a: Fp, b: Fp) -> Fp:
         return self._fp(OP_ADD, a.idx, b.idx)
 

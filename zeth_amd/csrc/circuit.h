@@ -27,16 +27,27 @@ struct EvalCheckArgs {
     const uint32_t* mix_pows;        // poly_mix^e, e < n_mix_pows (ExtElem each, device)
     uint32_t zinv[4];                // 1 / (3^n * i^(idx mod 4) - 1), Montgomery
     uint32_t dom;                    // 4n
+    uint32_t accumulate;             // 0: check = part; 1: check += part (parts 1.. of a split constraint system)
 };
+// Tap read of a generated eval_check kernel: wave-uniform column base (SGPR pair) + 32-bit per-lane byte offset, which is
+// the addressing form global_load has natively (no 64-bit VGPR address per load).
+__device__ __forceinline__ uint32_t tap_load(const uint32_t* __restrict__ group, size_t column_words, uint32_t lane_byte_offset) {
+    return *(const uint32_t*)((const char*)(group + column_words) + lane_byte_offset);
+}
 typedef void (*eval_check_launch_fn)(const EvalCheckArgs&, hipStream_t);
-struct CompiledEvalCheck { uint64_t desc_hash; const char* name; eval_check_launch_fn launch; uint32_t n_mix_pows; };
+// A circuit's generated eval_check: n_parts kernels over disjoint constraint ranges, launched back to back on one stream;
+// part 0 writes `check`, the others add their share (circuits/codegen.py).
+struct CompiledEvalCheck { uint64_t desc_hash; const char* name; const eval_check_launch_fn* parts; uint32_t n_parts; uint32_t n_mix_pows; };
 // registry filled by the generated translation unit (eval_check_gen.hip)
 const CompiledEvalCheck* find_compiled_eval_check(uint64_t desc_hash);
 
 uint64_t desc_hash64(const uint32_t* words, size_t n);
 
-// device program for the generic interpreter (slots allocated on the host by liveness)
-struct InterpInsn { uint32_t op, dst, a, b, c, w; };   // w = index into mix_pows
+// device program for the generic interpreter (slots allocated on the host by liveness).  op = opcode | kind(a) << 8 |
+// kind(b) << 11 | (dst is Fp4) << 14; operand kinds: taps, constants and globals are operands, not slots, so a tap that
+// thousands of constraints read does not pin a slot for the whole program.
+struct InterpInsn { uint32_t op, dst, a, b, c, w; };   // w = index into mix_pows (ConstExt: 4th word)
+enum : uint32_t { OPK_FP = 0, OPK_EXT = 1, OPK_TAP = 2, OPK_CONST = 3, OPK_GLOBAL = 4 };
 
 }  // namespace zkh
 
@@ -53,13 +64,13 @@ struct zkh_circuit {
     std::vector<zkh::Reg> regs;
     size_t tot_combo_backs;
     const zkh::CompiledEvalCheck* compiled;
-    // code object attached at run time (zkh_circuit_attach_code_object): eval_check kernel generated for THIS desc
-    hipModule_t jit_module;
-    hipFunction_t jit_kernel;
+    // code objects attached at run time (zkh_circuit_attach_code_object[_part]): eval_check kernels generated for THIS desc
+    std::vector<hipModule_t> jit_modules;
+    std::vector<hipFunction_t> jit_kernels;      // one per part; all non-null once every part is attached
     bool interp_ok;       // the step interpreter's live values fit its LDS
     // interpreter program
     std::vector<zkh::InterpInsn> prog;
-    uint32_t n_fp_slots, n_mix_slots, n_mix_pows, ret_slot;
+    uint32_t n_fp_slots, n_mix_slots, n_mix_pows, ret_slot;   // n_mix_slots: 16-byte slots (mix totals and Fp4-valued values)
     uint32_t* d_prog;     // device copy of prog
     uint32_t* d_taps;     // device copy of taps (group, offset, back)
 };

@@ -27,6 +27,10 @@ constexpr uint32_t INTERP_THREADS = 128;
 constexpr uint32_t INSN_WORDS = 6;
 
 // ---- generic interpreter: one lane per domain point, value slots in LDS ([slot][lane]) ----
+// fp slots hold Fp values, wide slots (uint4) hold mix totals and the Fp4-valued values downstream of a ConstExt; taps,
+// constants and globals are instruction operands (re-read where they are used), not slots.
+__device__ __forceinline__ Fp4 u4_fp4(uint4 v) { return Fp4(Fp::raw(v.x), Fp::raw(v.y), Fp::raw(v.z), Fp::raw(v.w)); }
+__device__ __forceinline__ uint4 fp4_u4(Fp4 v) { return make_uint4(v.c[0].v, v.c[1].v, v.c[2].v, v.c[3].v); }
 __global__ __launch_bounds__(INTERP_THREADS) void k_eval_check_interp(EvalCheckArgs a, const uint32_t* __restrict__ prog,
                                                                       uint32_t n_insn, const uint32_t* __restrict__ taps,
                                                                       uint32_t n_fp_slots, uint32_t ret_slot) {
@@ -37,35 +41,53 @@ __global__ __launch_bounds__(INTERP_THREADS) void k_eval_check_interp(EvalCheckA
     const uint32_t idx = blockIdx.x * INTERP_THREADS + t;
     if (idx >= a.dom) return;
     const uint32_t mask = a.dom - 1;
+    auto fp_operand = [&](uint32_t kind, uint32_t x) -> uint32_t {
+        switch (kind) {
+        case OPK_FP: return fps[x * INTERP_THREADS + t];
+        case OPK_TAP: {
+            const uint32_t g = taps[3 * x], off = taps[3 * x + 1], back = taps[3 * x + 2];
+            return a.groups[g][(size_t)off * a.dom + ((idx - 4 * back) & mask)]; }
+        case OPK_CONST: return x;
+        default: return a.globals[x >> 16][x & 0xffffu];
+        }
+    };
+    auto ext_operand = [&](uint32_t kind, uint32_t x) -> Fp4 {
+        if (kind == OPK_EXT) return u4_fp4(mxs[x * INTERP_THREADS + t]);
+        return Fp4(Fp::raw(fp_operand(kind, x)));
+    };
     for (uint32_t pc = 0; pc < n_insn; pc++) {
         const uint32_t* in = prog + pc * INSN_WORDS;
-        const uint32_t op = in[0], dst = in[1], x = in[2], y = in[3], z = in[4], w = in[5];
+        const uint32_t opw = in[0], dst = in[1], x = in[2], y = in[3], z = in[4], w = in[5];
+        const uint32_t op = opw & 0xffu, ka = (opw >> 8) & 7u, kb = (opw >> 11) & 7u;
+        const bool dst_ext = (opw >> 14) & 1u;
         switch (op) {
-        case OP_CONST: fps[dst * INTERP_THREADS + t] = x; break;
-        case OP_GET: {
-            const uint32_t g = taps[3 * x], off = taps[3 * x + 1], back = taps[3 * x + 2];
-            fps[dst * INTERP_THREADS + t] = a.groups[g][(size_t)off * a.dom + ((idx - 4 * back) & mask)];
-            break; }
-        case OP_GET_GLOBAL: fps[dst * INTERP_THREADS + t] = a.globals[x][y]; break;
-        case OP_ADD: fps[dst * INTERP_THREADS + t] = add_mod(fps[x * INTERP_THREADS + t], fps[y * INTERP_THREADS + t]); break;
-        case OP_SUB: fps[dst * INTERP_THREADS + t] = sub_mod(fps[x * INTERP_THREADS + t], fps[y * INTERP_THREADS + t]); break;
-        case OP_MUL: fps[dst * INTERP_THREADS + t] = mul_mod(fps[x * INTERP_THREADS + t], fps[y * INTERP_THREADS + t]); break;
+        case OP_CONST_EXT: mxs[dst * INTERP_THREADS + t] = make_uint4(x, y, z, w); break;
+        case OP_ADD: case OP_SUB: case OP_MUL:
+            if (dst_ext) {
+                const Fp4 l = ext_operand(ka, x), r = ext_operand(kb, y);
+                mxs[dst * INTERP_THREADS + t] = fp4_u4(op == OP_ADD ? l + r : (op == OP_SUB ? l - r : l * r));
+            } else {
+                const uint32_t l = fp_operand(ka, x), r = fp_operand(kb, y);
+                fps[dst * INTERP_THREADS + t] = op == OP_ADD ? add_mod(l, r) : (op == OP_SUB ? sub_mod(l, r) : mul_mod(l, r));
+            }
+            break;
         case OP_TRUE: mxs[dst * INTERP_THREADS + t] = make_uint4(0, 0, 0, 0); break;
         case OP_AND_EQZ: {   // tot = x.tot + mix^e(x) * v
             const uint4 xt = mxs[x * INTERP_THREADS + t];
             const uint4 pw = ((const uint4*)a.mix_pows)[w];
-            const uint32_t v = fps[y * INTERP_THREADS + t];
-            mxs[dst * INTERP_THREADS + t] = make_uint4(add_mod(xt.x, mul_mod(pw.x, v)), add_mod(xt.y, mul_mod(pw.y, v)),
-                                                       add_mod(xt.z, mul_mod(pw.z, v)), add_mod(xt.w, mul_mod(pw.w, v)));
+            if (kb == OPK_EXT) {
+                mxs[dst * INTERP_THREADS + t] = fp4_u4(u4_fp4(xt) + u4_fp4(pw) * ext_operand(kb, y));
+            } else {
+                const uint32_t v = fp_operand(kb, y);
+                mxs[dst * INTERP_THREADS + t] = make_uint4(add_mod(xt.x, mul_mod(pw.x, v)), add_mod(xt.y, mul_mod(pw.y, v)),
+                                                           add_mod(xt.z, mul_mod(pw.z, v)), add_mod(xt.w, mul_mod(pw.w, v)));
+            }
             break; }
         case OP_AND_COND: {  // tot = x.tot + cond * y.tot * mix^e(x)
             const uint4 xt = mxs[x * INTERP_THREADS + t], yt = mxs[z * INTERP_THREADS + t];
             const uint4 pw = ((const uint4*)a.mix_pows)[w];
-            const uint32_t cnd = fps[y * INTERP_THREADS + t];
-            const Fp4 r = Fp4(Fp::raw(xt.x), Fp::raw(xt.y), Fp::raw(xt.z), Fp::raw(xt.w)) +
-                          (Fp4(Fp::raw(yt.x), Fp::raw(yt.y), Fp::raw(yt.z), Fp::raw(yt.w)) * Fp::raw(cnd)) *
-                              Fp4(Fp::raw(pw.x), Fp::raw(pw.y), Fp::raw(pw.z), Fp::raw(pw.w));
-            mxs[dst * INTERP_THREADS + t] = make_uint4(r.c[0].v, r.c[1].v, r.c[2].v, r.c[3].v);
+            const Fp4 inner = kb == OPK_EXT ? u4_fp4(yt) * ext_operand(kb, y) : u4_fp4(yt) * Fp::raw(fp_operand(kb, y));
+            mxs[dst * INTERP_THREADS + t] = fp4_u4(u4_fp4(xt) + inner * u4_fp4(pw));
             break; }
         }
     }
@@ -257,83 +279,96 @@ extern "C" const char* zkh_circuit_load(zkh_ctx* ctx, const uint32_t* d, size_t 
         for (auto& r : c->regs) cnt += r.group == (uint32_t)g;
         if (cnt != c->group_size[g]) return fail("every column of a group needs a register");
     }
-    // ---- analyse the step list: static mix exponents, liveness, slot allocation ----
-    std::vector<uint32_t> fp_of_step, mix_exp;      // per mix var: exponent of poly_mix held in `mul`
-    std::vector<int> fp_last, mix_last;              // last step that reads var
+    // ---- analyse the step list: value types, static mix exponents, liveness, slot allocation ----
+    const size_t n_steps_all = c->steps.size();
     struct V { bool is_mix; uint32_t id; };
-    std::vector<V> def(c->steps.size());
+    std::vector<V> def(n_steps_all);
     uint32_t nf = 0, nm = 0;
-    for (size_t i = 0; i < c->steps.size(); i++) {
-        const Step& s = c->steps[i];
-        if (s.op >= OP_TRUE) { def[i] = {true, nm++}; } else { def[i] = {false, nf++}; }
+    for (size_t i = 0; i < n_steps_all; i++) {
+        if (c->steps[i].op >= OP_TRUE) def[i] = {true, nm++}; else def[i] = {false, nf++};
     }
-    fp_last.assign(nf, -1); mix_last.assign(nm, -1); mix_exp.assign(nm, 0);
+    // per value var: Fp4-valued?  operand form (slot / tap / const / global)?
+    std::vector<uint8_t> f_ext(nf, 0), f_kind(nf, OPK_FP);
+    std::vector<uint32_t> f_imm(nf, 0), mix_exp(nm, 0);
+    std::vector<int> fp_last(nf, -1), mix_last(nm, -1);            // last step that reads var
     uint32_t max_pow = 0;
     {
         uint32_t cf = 0, cm = 0;
-        for (size_t i = 0; i < c->steps.size(); i++) {
+        for (size_t i = 0; i < n_steps_all; i++) {
             const Step& s = c->steps[i];
             auto usef = [&](uint32_t v) -> bool { if (v >= cf) return false; fp_last[v] = (int)i; return true; };
             auto usem = [&](uint32_t v) -> bool { if (v >= cm) return false; mix_last[v] = (int)i; return true; };
             bool ok = true;
             switch (s.op) {
-            case OP_CONST: case OP_GET_GLOBAL: break;
-            case OP_GET: ok = s.a < c->taps.size(); break;
-            case OP_CONST_EXT: return fail("ConstExt is not supported on the device path");
-            case OP_ADD: case OP_SUB: case OP_MUL: ok = usef(s.a) && usef(s.b); break;
+            case OP_CONST: f_kind[cf] = OPK_CONST; f_imm[cf] = fp_encode(s.a).v; break;
+            case OP_GET_GLOBAL:
+                ok = s.a <= 1 && s.b < c->global_size[s.a] && s.b < 65536;
+                f_kind[cf] = OPK_GLOBAL; f_imm[cf] = (s.a << 16) | s.b; break;
+            case OP_GET: ok = s.a < c->taps.size(); f_kind[cf] = OPK_TAP; f_imm[cf] = s.a; break;
+            case OP_CONST_EXT: f_ext[cf] = 1; f_kind[cf] = OPK_EXT; break;
+            case OP_ADD: case OP_SUB: case OP_MUL:
+                ok = usef(s.a) && usef(s.b);
+                if (ok) { f_ext[cf] = f_ext[s.a] | f_ext[s.b]; f_kind[cf] = f_ext[cf] ? OPK_EXT : OPK_FP; }
+                break;
             case OP_TRUE: mix_exp[cm] = 0; break;
             case OP_AND_EQZ: ok = usem(s.a) && usef(s.b); if (ok) { mix_exp[cm] = mix_exp[s.a] + 1; max_pow = std::max(max_pow, mix_exp[s.a]); } break;
             case OP_AND_COND: ok = usem(s.a) && usef(s.b) && usem(s.c);
                 if (ok) { mix_exp[cm] = mix_exp[s.a] + mix_exp[s.c]; max_pow = std::max(max_pow, mix_exp[s.a]); } break;
             default: ok = false;
             }
-            if (!ok) return fail("step operand out of range");
-            if (s.op == OP_GET_GLOBAL && (s.a > 1 || s.b >= c->global_size[s.a])) return fail("global out of range");
+            if (!ok) return fail(s.op == OP_GET_GLOBAL ? "global out of range" : "step operand out of range");
             if (s.op >= OP_TRUE) cm++; else cf++;
         }
         if (c->ret >= nm) return fail("ret out of range");
-        mix_last[c->ret] = (int)c->steps.size();
+        mix_last[c->ret] = (int)n_steps_all;
     }
     c->n_mix_pows = max_pow + 1;
     {
-        std::vector<uint32_t> fp_slot(nf, 0), mix_slot(nm, 0), free_f, free_m;
-        uint32_t nfs = 0, nms = 0, cf = 0, cm = 0;
-        // vars whose last use is step i are released after step i
-        std::vector<std::vector<uint32_t>> rel_f(c->steps.size() + 1), rel_m(c->steps.size() + 1);
-        for (uint32_t v = 0; v < nf; v++) if (fp_last[v] >= 0) rel_f[fp_last[v]].push_back(v);
-        for (uint32_t v = 0; v < nm; v++) if (mix_last[v] >= 0 && mix_last[v] < (int)c->steps.size()) rel_m[mix_last[v]].push_back(v);
-        for (size_t i = 0; i < c->steps.size(); i++) {
+        // slots: fp slots for Fp results of arithmetic; wide slots for mix totals and Fp4-valued values.  Dead steps are
+        // dropped (a value var is dead if nothing reads it; liveness is not transitive here, which only costs slots).
+        std::vector<uint32_t> fp_slot(nf, 0), mix_slot(nm, 0), free_f, free_w;
+        uint32_t nfs = 0, nws = 0, cf = 0, cm = 0;
+        std::vector<std::vector<uint32_t>> rel_f(n_steps_all + 1), rel_m(n_steps_all + 1);
+        for (uint32_t v = 0; v < nf; v++) if (fp_last[v] >= 0 && (f_kind[v] == OPK_FP || f_kind[v] == OPK_EXT)) rel_f[fp_last[v]].push_back(v);
+        for (uint32_t v = 0; v < nm; v++) if (mix_last[v] >= 0 && mix_last[v] < (int)n_steps_all) rel_m[mix_last[v]].push_back(v);
+        auto take = [](std::vector<uint32_t>& fl, uint32_t& n) { if (fl.empty()) return n++; uint32_t x = fl.back(); fl.pop_back(); return x; };
+        auto operand = [&](uint32_t v, uint32_t& kind) -> uint32_t {
+            kind = f_kind[v];
+            return (kind == OPK_FP || kind == OPK_EXT) ? fp_slot[v] : f_imm[v];
+        };
+        for (size_t i = 0; i < n_steps_all; i++) {
             const Step& s = c->steps[i];
             const bool is_mix = s.op >= OP_TRUE;
+            const bool inline_operand = !is_mix && (s.op == OP_CONST || s.op == OP_GET || s.op == OP_GET_GLOBAL);
             const bool dead = is_mix ? (mix_last[cm] < 0) : (fp_last[cf] < 0);
-            if (!dead) {
+            if (!dead && !inline_operand) {
                 InterpInsn in{s.op, 0, 0, 0, 0, 0};
-                if (is_mix) { if (free_m.empty()) in.dst = nms++; else { in.dst = free_m.back(); free_m.pop_back(); } mix_slot[cm] = in.dst; }
-                else { if (free_f.empty()) in.dst = nfs++; else { in.dst = free_f.back(); free_f.pop_back(); } fp_slot[cf] = in.dst; }
+                uint32_t ka = 0, kb = 0;
+                if (is_mix) { in.dst = take(free_w, nws); mix_slot[cm] = in.dst; }
+                else if (f_ext[cf]) { in.dst = take(free_w, nws); fp_slot[cf] = in.dst; in.op |= 1u << 14; }
+                else { in.dst = take(free_f, nfs); fp_slot[cf] = in.dst; }
                 switch (s.op) {
-                case OP_CONST: in.a = fp_encode(s.a).v; break;
-                case OP_GET: in.a = s.a; break;
-                case OP_GET_GLOBAL: in.a = s.a; in.b = s.b; break;
-                case OP_ADD: case OP_SUB: case OP_MUL: in.a = fp_slot[s.a]; in.b = fp_slot[s.b]; break;
+                case OP_CONST_EXT: in.a = fp_encode(s.a).v; in.b = fp_encode(s.b).v; in.c = fp_encode(s.c).v; in.w = fp_encode(s.d).v; break;
+                case OP_ADD: case OP_SUB: case OP_MUL: in.a = operand(s.a, ka); in.b = operand(s.b, kb); break;
                 case OP_TRUE: break;
-                case OP_AND_EQZ: in.a = mix_slot[s.a]; in.b = fp_slot[s.b]; in.w = mix_exp[s.a]; break;
-                case OP_AND_COND: in.a = mix_slot[s.a]; in.b = fp_slot[s.b]; in.c = mix_slot[s.c]; in.w = mix_exp[s.a]; break;
+                case OP_AND_EQZ: in.a = mix_slot[s.a]; in.b = operand(s.b, kb); in.w = mix_exp[s.a]; break;
+                case OP_AND_COND: in.a = mix_slot[s.a]; in.b = operand(s.b, kb); in.c = mix_slot[s.c]; in.w = mix_exp[s.a]; break;
                 }
+                in.op |= (ka << 8) | (kb << 11);
                 c->prog.push_back(in);
             }
             // NOTE: a destination slot may not alias a source released by the same step: release AFTER allocating
-            for (uint32_t v : rel_f[i]) free_f.push_back(fp_slot[v]);
-            for (uint32_t v : rel_m[i]) free_m.push_back(mix_slot[v]);
+            for (uint32_t v : rel_f[i]) (f_ext[v] ? free_w : free_f).push_back(fp_slot[v]);
+            for (uint32_t v : rel_m[i]) free_w.push_back(mix_slot[v]);
             if (is_mix) cm++; else cf++;
         }
-        c->n_fp_slots = nfs ? nfs : 1; c->n_mix_slots = nms ? nms : 1;
+        c->n_fp_slots = nfs ? nfs : 1; c->n_mix_slots = nws ? nws : 1;
         c->ret_slot = mix_slot[c->ret];
     }
     const size_t lds = ((size_t)c->n_fp_slots * 4 + (size_t)c->n_mix_slots * 16) * INTERP_THREADS;
     // a step list too large for the interpreter still loads: it then needs a compiled kernel (built in, or attached)
     c->interp_ok = lds <= 160 * 1024;
     c->compiled = find_compiled_eval_check(c->hash);
-    c->jit_module = nullptr; c->jit_kernel = nullptr;
     c->d_prog = nullptr; c->d_taps = nullptr;
     if (ctx) {       // ctx == NULL: host-only circuit (enough for zkh_verify_segment, which needs no GPU)
         bind_thread(ctx);
@@ -352,17 +387,27 @@ extern "C" void zkh_circuit_destroy(zkh_circuit* c) {
     if (c->ctx) bind_thread(c->ctx);
     if (c->d_prog) (void)hipFree(c->d_prog);
     if (c->d_taps) (void)hipFree(c->d_taps);
-    if (c->jit_module) (void)hipModuleUnload(c->jit_module);
+    for (hipModule_t m : c->jit_modules) if (m) (void)hipModuleUnload(m);
     delete c;
 }
-extern "C" int zkh_circuit_has_compiled_kernel(const zkh_circuit* c) { return c->jit_kernel ? 2 : (c->compiled != nullptr ? 1 : 0); }
+static bool jit_complete(const zkh_circuit* c) {
+    if (c->jit_kernels.empty()) return false;
+    for (hipFunction_t f : c->jit_kernels) if (!f) return false;
+    return true;
+}
+extern "C" int zkh_circuit_has_compiled_kernel(const zkh_circuit* c) { return jit_complete(c) ? 2 : (c->compiled != nullptr ? 1 : 0); }
+extern "C" size_t zkh_circuit_compiled_parts(const zkh_circuit* c) {
+    return jit_complete(c) ? c->jit_kernels.size() : (c->compiled ? c->compiled->n_parts : 0);
+}
 
 // Attach a gfx950 code object holding `extern "C" __global__ void <kernel_name>(EvalCheckArgs)` generated for this
 // circuit's step list (zeth_amd/circuits/jit.py produces it with the same generator the build uses).  Upstream ships
 // one machine-generated kernel per circuit; a circuit that arrives as data gets the same treatment at load time.
-extern "C" const char* zkh_circuit_attach_code_object(zkh_circuit* c, const void* image, size_t len, const char* kernel_name) {
+extern "C" const char* zkh_circuit_attach_code_object_part(zkh_circuit* c, const void* image, size_t len, const char* kernel_name,
+                                                           size_t part, size_t n_parts) {
     ZKH_REQUIRE(c && c->ctx, "attach_code_object: circuit was loaded without a device context");
     ZKH_REQUIRE(image && len >= 64 && kernel_name, "attach_code_object: empty code object");
+    ZKH_REQUIRE(n_parts >= 1 && n_parts <= 4096 && part < n_parts, "attach_code_object: part %zu of %zu", part, n_parts);
     ZKH_REQUIRE(memcmp(image, "\x7f" "ELF", 4) == 0 || memcmp(image, "__CLANG_OFFLOAD_BUNDLE__", 24) == 0,
                 "attach_code_object: not an ELF code object or offload bundle");
     bind_thread(c->ctx);
@@ -373,9 +418,17 @@ extern "C" const char* zkh_circuit_attach_code_object(zkh_circuit* c, const void
     if (e != hipSuccess) { (void)hipGetLastError(); return make_err("attach_code_object: hipModuleLoadData: %s", hipGetErrorString(e)); }
     e = hipModuleGetFunction(&fn, mod, kernel_name);
     if (e != hipSuccess) { (void)hipGetLastError(); (void)hipModuleUnload(mod); return make_err("attach_code_object: no kernel '%s': %s", kernel_name, hipGetErrorString(e)); }
-    if (c->jit_module) (void)hipModuleUnload(c->jit_module);
-    c->jit_module = mod; c->jit_kernel = fn;
+    if (c->jit_kernels.size() != n_parts) {          // a new set of parts replaces whatever was attached before
+        for (hipModule_t m : c->jit_modules) if (m) (void)hipModuleUnload(m);
+        c->jit_modules.assign(n_parts, nullptr);
+        c->jit_kernels.assign(n_parts, nullptr);
+    }
+    if (c->jit_modules[part]) (void)hipModuleUnload(c->jit_modules[part]);
+    c->jit_modules[part] = mod; c->jit_kernels[part] = fn;
     return nullptr;
+}
+extern "C" const char* zkh_circuit_attach_code_object(zkh_circuit* c, const void* image, size_t len, const char* kernel_name) {
+    return zkh_circuit_attach_code_object_part(c, image, len, kernel_name, 0, 1);
 }
 
 extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_buf* check, const zkh_buf* const* groups, size_t n_groups,
@@ -408,16 +461,22 @@ extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_bu
     a.mix_pows = pows->ptr();
     size_t total_w = 0;
     for (int g = 0; g < 3; g++) total_w += c->group_size[g];
-    if (c->jit_kernel && !use_interpreter) {
+    if (jit_complete(c) && !use_interpreter) {
         ProfScope prof(ctx, "eval_check", 4.0 * total_w * dom + 16.0 * dom);
-        size_t arg_size = sizeof(a);
-        void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size, HIP_LAUNCH_PARAM_END};
-        const hipError_t e = hipModuleLaunchKernel(c->jit_kernel, (unsigned)((dom + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream,
-                                                   nullptr, config);
-        if (e != hipSuccess) { zkh_release(pows); return make_err("eval_check: launching the attached kernel: %s", hipGetErrorString(e)); }
+        for (size_t part = 0; part < c->jit_kernels.size(); part++) {
+            a.accumulate = part != 0;
+            size_t arg_size = sizeof(a);
+            void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size, HIP_LAUNCH_PARAM_END};
+            const hipError_t e = hipModuleLaunchKernel(c->jit_kernels[part], (unsigned)((dom + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream,
+                                                       nullptr, config);
+            if (e != hipSuccess) { zkh_release(pows); return make_err("eval_check: launching attached kernel %zu: %s", part, hipGetErrorString(e)); }
+        }
     } else if (c->compiled && !use_interpreter) {
         ProfScope prof(ctx, "eval_check", 4.0 * total_w * dom + 16.0 * dom);
-        c->compiled->launch(a, ctx->stream);
+        for (uint32_t part = 0; part < c->compiled->n_parts; part++) {
+            a.accumulate = part != 0;
+            c->compiled->parts[part](a, ctx->stream);
+        }
     } else {
         if (!c->interp_ok) {
             zkh_release(pows);
@@ -425,8 +484,10 @@ extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_bu
         }
         const size_t lds = ((size_t)c->n_fp_slots * 4 + (size_t)c->n_mix_slots * 16) * INTERP_THREADS;
         ProfScope prof(ctx, "eval_check_interp", 4.0 * total_w * dom + 16.0 * dom);
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)k_eval_check_interp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 64 * 1024) {
+            const hipError_t e = hipFuncSetAttribute((const void*)k_eval_check_interp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { zkh_release(pows); return make_err("eval_check: %zu bytes of LDS for the interpreter: %s", lds, hipGetErrorString(e)); }
+        }
         k_eval_check_interp<<<(unsigned)((dom + INTERP_THREADS - 1) / INTERP_THREADS), INTERP_THREADS, lds, ctx->stream>>>(
             a, c->d_prog, (uint32_t)c->prog.size(), c->d_taps, c->n_fp_slots, c->ret_slot);
     }

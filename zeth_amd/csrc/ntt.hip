@@ -546,8 +546,16 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
         p.tiles_per_col = (uint32_t)(n >> (p.R + p.log_t));
         const size_t lds = ((size_t)4 << (p.R + p.log_t));
         dim3 grid(p.tiles_per_col, (unsigned)count);
-        ProfScope prof(c, name, 8.0 * n * count);
+        // algorithmic bytes in SURVEY.md §8d's sense (operands read once + written once, whatever the number of HBM passes):
+        // charged to the first pass, the other passes of the same transform add time only
+        const double alg_bytes = pi == 0 ? 4.0 * count * (double)(((size_t)1 << log_n) >> expand_bits) + 4.0 * count * (double)n : 0.0;
         const bool scale_here = p.scale != 0;
+        // profiler record = "<Hal op>:<kernel>", so both the op totals and the per-kernel (per-pass) times can be read off
+        const bool k_low = ps.L == 0 && ps.R == 12 && p.expand_bits <= 4;
+        const bool k_h10 = !k_low && ps.L >= 4 && p.log_t == 4 && ps.R == 10 && !(scale_here && p.zk_shift);
+        const bool k_h8 = !k_low && !k_h10 && ps.L >= 4 && p.log_t == 4 && ps.R == 8 && !(scale_here && p.zk_shift);
+        const std::string pname = std::string(name) + (k_low ? ":k_ntt_low12" : k_h10 ? ":k_ntt_high10" : k_h8 ? ":k_ntt_high8" : ":k_ntt_pass");
+        ProfScope prof(c, pname.c_str(), alg_bytes);
         if (ps.L == 0 && ps.R == 12 && p.expand_bits <= 4) {
             if (inverse) k_ntt_low12<true><<<grid, 256, 0, c->stream>>>(p);
             else if (lazy) k_ntt_low12<false, true><<<grid, 256, 0, c->stream>>>(p);

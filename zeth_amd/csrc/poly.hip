@@ -30,91 +30,137 @@ __global__ void k_ext_powers(uint32_t* out, Fp4 start, Fp4 base, uint32_t n) {
 // batch_evaluate_any.  Block (chunk, k): partial[k][chunk] = sum_{j in chunk} coeffs[which[k]][j] * x_k^j.
 // Lane t owns coefficients j = chunk*CH + i*256 + t (coalesced); term = c * X^i (X = x^256, table in LDS),
 // the lane total is multiplied once by x^t and the block total once by x^(chunk*CH).
+//
+// A real tap set evaluates the same column at several points (taps at backs 0..4 of one register): consecutive entries
+// with the same which[] form a run, and ONE block streams the column once for up to EV_MAXP points of the run (the other
+// blocks of the run exit at once), so DEEP evaluation reads W x n words instead of #taps x n.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int EV_PER = 64, EV_CH = TB * EV_PER;
+constexpr int EV_PER = 64, EV_CH = TB * EV_PER, EV_MAXP = 8, EV_SCAN = 256;
+
+template <int NP>
+__device__ __forceinline__ void ev_accumulate(Fp4 (&acc)[EV_MAXP], const uint32_t* __restrict__ c, size_t j0, size_t po,
+                                              const uint4 (*xp)[EV_PER]) {
+    // Fp x Fp4 multiply-accumulate, lazily: four products per 64-bit accumulator (4 P^2 < 2 P 2^32), then ONE reduction
+    // and one modular add per component instead of four of each.  The coefficient is loaded once for all NP points.
+#pragma unroll 2
+    for (int i = 0; i < EV_PER; i += 4) {
+        uint64_t a[NP][4];
+#pragma unroll
+        for (int p = 0; p < NP; p++) a[p][0] = a[p][1] = a[p][2] = a[p][3] = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const size_t j = j0 + (size_t)(i + u) * TB;
+            const uint64_t cj = j < po ? c[j] : 0u;
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                const uint4 pw = xp[p][i + u];
+                a[p][0] += cj * pw.x; a[p][1] += cj * pw.y; a[p][2] += cj * pw.z; a[p][3] += cj * pw.w;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc[p].c[q] = Fp::raw(add_mod(acc[p].c[q].v, mont_reduce_wide(a[p][q])));
+    }
+}
+
 // BITREV: the column holds its coefficients in the bit-reversed order batch_interpolate_ntt leaves them in (position p
 // holds coefficient bitrev_k(p)); x^bitrev(p) still factors over the bit fields of p = chunk*CH + i*256 + t, so only the
 // three power tables change and PolyGroup never has to bit-reverse W x n coefficient words.
 template <bool BITREV>
 __global__ __launch_bounds__(TB) void k_eval_partial(uint32_t* __restrict__ partial, const uint32_t* __restrict__ coeffs,
                                                      size_t po, const uint32_t* __restrict__ which,
-                                                     const uint32_t* __restrict__ xs, uint32_t n_chunks, uint32_t log_n) {
-    __shared__ uint4 xt[TB];        // x^t            | x^(bitrev8(t) << (k-8))
-    __shared__ uint4 xp[EV_PER];    // X^i, X = x^256 | x^(bitrev6(i) << (k-14))
-    __shared__ uint4 red[TB];
-    __shared__ uint4 sq[32];        // BITREV: x^(2^m)
-    const uint32_t k = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
-    const Fp4 x = ld_ext(xs + 4 * k);
-    Fp4 chunk_pow;
-    if (BITREV) {
-        if (t == 0) {
-            Fp4 y = x;
-            for (uint32_t m = 0; m < log_n; m++) { st_ext((uint32_t*)&sq[m], y); y = y * y; }
-            st_ext((uint32_t*)&xt[0], Fp4::one());
-            st_ext((uint32_t*)&xp[0], Fp4::one());
-        }
-        __syncthreads();
-        for (uint32_t b = 0; b < 8; b++) {                    // position bit b of t  ->  exponent bit k-1-b
-            const uint32_t s = 1u << b;
-            if (t < s) st_ext((uint32_t*)&xt[s + t], ld_ext((const uint32_t*)&xt[t]) * ld_ext((const uint32_t*)&sq[log_n - 1 - b]));
+                                                     const uint32_t* __restrict__ xs, uint32_t n_chunks, uint32_t log_n,
+                                                     uint32_t n_eval) {
+    extern __shared__ __attribute__((aligned(16))) uint4 ev_lds[];
+    // run of this block: leader = first entry of the run, or every EV_MAXP-th entry of a longer run
+    const uint32_t k0 = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
+    const uint32_t col = which[k0];
+    uint32_t start = k0;
+    for (uint32_t back = 0; back < EV_SCAN && start > 0 && which[start - 1] == col; back++) start--;
+    if ((k0 - start) % EV_MAXP != 0) return;                  // another block of the run covers this entry
+    uint32_t np = 1;
+    while (np < EV_MAXP && k0 + np < n_eval && which[k0 + np] == col) np++;
+    uint4 (*xt)[TB] = (uint4 (*)[TB])ev_lds;                        // [np][TB]      x^t  | x^(bitrev8(t) << (k-8))
+    uint4 (*xp)[EV_PER] = (uint4 (*)[EV_PER])(ev_lds + np * TB);    // [np][EV_PER]  X^i, X = x^256 | x^(bitrev6(i) << (k-14))
+    uint4* red = ev_lds + np * (TB + EV_PER);                       // [TB]
+    uint4* sq = red + TB;                                           // [32]  BITREV: x^(2^m)
+    Fp4 chunk_pow[EV_MAXP];
+    for (uint32_t p = 0; p < np; p++) {
+        const Fp4 x = ld_ext(xs + 4 * (k0 + p));
+        if (BITREV) {
+            __syncthreads();                                  // sq is reused by every point
+            if (t == 0) {
+                Fp4 y = x;
+                for (uint32_t m = 0; m < log_n; m++) { st_ext((uint32_t*)&sq[m], y); y = y * y; }
+                st_ext((uint32_t*)&xt[p][0], Fp4::one());
+                st_ext((uint32_t*)&xp[p][0], Fp4::one());
+            }
             __syncthreads();
-        }
-        for (uint32_t b = 0; b < 6; b++) {                    // position bit 8+b  ->  exponent bit k-9-b
-            const uint32_t s = 1u << b;
-            if (t < s) st_ext((uint32_t*)&xp[s + t], ld_ext((const uint32_t*)&xp[t]) * ld_ext((const uint32_t*)&sq[log_n - 9 - b]));
+            for (uint32_t b = 0; b < 8; b++) {                    // position bit b of t  ->  exponent bit k-1-b
+                const uint32_t s = 1u << b;
+                if (t < s) st_ext((uint32_t*)&xt[p][s + t], ld_ext((const uint32_t*)&xt[p][t]) * ld_ext((const uint32_t*)&sq[log_n - 1 - b]));
+                __syncthreads();
+            }
+            for (uint32_t b = 0; b < 6; b++) {                    // position bit 8+b  ->  exponent bit k-9-b
+                const uint32_t s = 1u << b;
+                if (t < s) st_ext((uint32_t*)&xp[p][s + t], ld_ext((const uint32_t*)&xp[p][t]) * ld_ext((const uint32_t*)&sq[log_n - 9 - b]));
+                __syncthreads();
+            }
+            chunk_pow[p] = Fp4::one();
+            if (t == 0)
+                for (uint32_t c = 0; c + 14 < log_n; c++)          // position bit 14+c -> exponent bit k-15-c
+                    if ((chunk >> c) & 1) chunk_pow[p] = chunk_pow[p] * ld_ext((const uint32_t*)&sq[log_n - 15 - c]);
+        } else {
+            // doubling: tab[s + i] = tab[i] * x^s
+            if (t == 0) { st_ext((uint32_t*)&xt[p][0], Fp4::one()); }
             __syncthreads();
-        }
-        chunk_pow = Fp4::one();
-        if (t == 0)
-            for (uint32_t c = 0; c + 14 < log_n; c++)          // position bit 14+c -> exponent bit k-15-c
-                if ((chunk >> c) & 1) chunk_pow = chunk_pow * ld_ext((const uint32_t*)&sq[log_n - 15 - c]);
-    } else {
-        // doubling: tab[s + i] = tab[i] * x^s
-        if (t == 0) { st_ext((uint32_t*)&xt[0], Fp4::one()); }
-        __syncthreads();
-        Fp4 xs_pow = x;    // x^s
-        for (uint32_t s = 1; s < TB; s <<= 1) {
-            if (t < s) st_ext((uint32_t*)&xt[s + t], ld_ext((const uint32_t*)&xt[t]) * xs_pow);
-            xs_pow = xs_pow * xs_pow;
+            Fp4 xs_pow = x;    // x^s
+            for (uint32_t s = 1; s < TB; s <<= 1) {
+                if (t < s) st_ext((uint32_t*)&xt[p][s + t], ld_ext((const uint32_t*)&xt[p][t]) * xs_pow);
+                xs_pow = xs_pow * xs_pow;
+                __syncthreads();
+            }
+            const Fp4 X = xs_pow;            // x^256
+            if (t == 0) st_ext((uint32_t*)&xp[p][0], Fp4::one());
             __syncthreads();
+            Fp4 Xs = X;
+            for (uint32_t s = 1; s < EV_PER; s <<= 1) {
+                if (t < s) st_ext((uint32_t*)&xp[p][s + t], ld_ext((const uint32_t*)&xp[p][t]) * Xs);
+                Xs = Xs * Xs;
+                __syncthreads();
+            }
+            chunk_pow[p] = t == 0 ? fp4_pow(Xs, chunk) : Fp4::one();   // x^(chunk*CH) = (X^EV_PER)^chunk
         }
-        const Fp4 X = xs_pow;            // x^256
-        if (t == 0) st_ext((uint32_t*)&xp[0], Fp4::one());
-        __syncthreads();
-        Fp4 Xs = X;
-        for (uint32_t s = 1; s < EV_PER; s <<= 1) {
-            if (t < s) st_ext((uint32_t*)&xp[s + t], ld_ext((const uint32_t*)&xp[t]) * Xs);
-            Xs = Xs * Xs;
-            __syncthreads();
-        }
-        chunk_pow = t == 0 ? fp4_pow(Xs, chunk) : Fp4::one();   // x^(chunk*CH) = (X^EV_PER)^chunk
     }
-    const uint32_t* c = coeffs + (size_t)which[k] * po;
-    const size_t j0 = (size_t)chunk * EV_CH + t;
-    // Fp x Fp4 multiply-accumulate, lazily: four products per 64-bit accumulator (4 P^2 < 2 P 2^32), then ONE reduction
-    // and one modular add per component instead of four of each.
-    Fp4 acc = Fp4::zero();
-#pragma unroll 2
-    for (int i = 0; i < EV_PER; i += 4) {
-        uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const size_t j = j0 + (size_t)(i + u) * TB;
-            const uint64_t cj = j < po ? c[j] : 0u;
-            const uint4 pw = xp[i + u];
-            a0 += cj * pw.x; a1 += cj * pw.y; a2 += cj * pw.z; a3 += cj * pw.w;
-        }
-        acc.c[0] = Fp::raw(add_mod(acc.c[0].v, mont_reduce_wide(a0))); acc.c[1] = Fp::raw(add_mod(acc.c[1].v, mont_reduce_wide(a1)));
-        acc.c[2] = Fp::raw(add_mod(acc.c[2].v, mont_reduce_wide(a2))); acc.c[3] = Fp::raw(add_mod(acc.c[3].v, mont_reduce_wide(a3)));
-    }
-    acc = acc * ld_ext((const uint32_t*)&xt[t]);
-    st_ext((uint32_t*)&red[t], acc);
     __syncthreads();
-    for (uint32_t s = TB / 2; s >= 1; s >>= 1) {
-        if (t < s) st_ext((uint32_t*)&red[t], ld_ext((const uint32_t*)&red[t]) + ld_ext((const uint32_t*)&red[t + s]));
+    const uint32_t* c = coeffs + (size_t)col * po;
+    const size_t j0 = (size_t)chunk * EV_CH + t;
+    Fp4 acc[EV_MAXP];
+#pragma unroll
+    for (int p = 0; p < EV_MAXP; p++) acc[p] = Fp4::zero();
+    switch (np) {
+    case 1: ev_accumulate<1>(acc, c, j0, po, xp); break;
+    case 2: ev_accumulate<2>(acc, c, j0, po, xp); break;
+    case 3: ev_accumulate<3>(acc, c, j0, po, xp); break;
+    case 4: ev_accumulate<4>(acc, c, j0, po, xp); break;
+    case 5: ev_accumulate<5>(acc, c, j0, po, xp); break;
+    case 6: ev_accumulate<6>(acc, c, j0, po, xp); break;
+    case 7: ev_accumulate<7>(acc, c, j0, po, xp); break;
+    default: ev_accumulate<8>(acc, c, j0, po, xp); break;
+    }
+#pragma unroll
+    for (int p = 0; p < EV_MAXP; p++) {
+        if ((uint32_t)p >= np) break;
+        st_ext((uint32_t*)&red[t], acc[p] * ld_ext((const uint32_t*)&xt[p][t]));
+        __syncthreads();
+        for (uint32_t s = TB / 2; s >= 1; s >>= 1) {
+            if (t < s) st_ext((uint32_t*)&red[t], ld_ext((const uint32_t*)&red[t]) + ld_ext((const uint32_t*)&red[t + s]));
+            __syncthreads();
+        }
+        if (t == 0) st_ext(partial + 4 * ((size_t)(k0 + p) * n_chunks + chunk), ld_ext((const uint32_t*)&red[0]) * chunk_pow[p]);
         __syncthreads();
     }
-    if (t == 0) st_ext(partial + 4 * ((size_t)k * n_chunks + chunk), ld_ext((const uint32_t*)&red[0]) * chunk_pow);
 }
 // in-place bit reversal of `count` polynomials of n ExtElems (AoS)
 __global__ void k_bit_reverse_ext(uint4* io, uint32_t log_n, size_t total) {
@@ -273,12 +319,14 @@ static const char* evaluate_any_impl(zkh_ctx* c, const zkh_buf* coeffs, size_t p
     ZKH_TRY(new_buf(c, 4 * n_eval * n_chunks, false, &partial));
     {
         ProfScope prof(c, "batch_evaluate_any", 4.0 * po * n_eval);
+        // LDS: worst-case run of EV_MAXP points (power tables per point) + the reduction buffer + the squarings
+        const size_t lds = ((size_t)EV_MAXP * (TB + EV_PER) + TB + 32) * sizeof(uint4);
         if (bitrev)
-            k_eval_partial<true><<<dim3(n_chunks, (unsigned)n_eval), TB, 0, c->stream>>>(partial->ptr(), coeffs->ptr(), po, which->ptr(),
-                                                                                      xs->ptr(), n_chunks, log_n);
+            k_eval_partial<true><<<dim3(n_chunks, (unsigned)n_eval), TB, lds, c->stream>>>(partial->ptr(), coeffs->ptr(), po, which->ptr(),
+                                                                                        xs->ptr(), n_chunks, log_n, (uint32_t)n_eval);
         else
-            k_eval_partial<false><<<dim3(n_chunks, (unsigned)n_eval), TB, 0, c->stream>>>(partial->ptr(), coeffs->ptr(), po, which->ptr(),
-                                                                                       xs->ptr(), n_chunks, log_n);
+            k_eval_partial<false><<<dim3(n_chunks, (unsigned)n_eval), TB, lds, c->stream>>>(partial->ptr(), coeffs->ptr(), po, which->ptr(),
+                                                                                         xs->ptr(), n_chunks, log_n, (uint32_t)n_eval);
         k_eval_final<<<(unsigned)ceil_div(n_eval, TB), TB, 0, c->stream>>>(out->ptr(), partial->ptr(), n_chunks, (uint32_t)n_eval);
     }
     zkh_release(partial);

@@ -90,6 +90,8 @@ ABI = {
     "zkh_circuit_destroy": (None, [_vp]),
     "zkh_circuit_has_compiled_kernel": (_i, [_vp]),
     "zkh_circuit_attach_code_object": (_err, [_vp, C.c_char_p, _sz, C.c_char_p]),
+    "zkh_circuit_attach_code_object_part": (_err, [_vp, C.c_char_p, _sz, C.c_char_p, _sz, _sz]),
+    "zkh_circuit_compiled_parts": (_sz, [_vp]),
     "zkh_eval_check": (_err, [_vp, _vp, _vp, C.POINTER(_vp), _sz, C.POINTER(_vp), _sz, _u32p, _sz, _sz, _i]),
     "zkh_syn_code": (_err, [_vp, _vp, _sz, _sz, _vp]),
     "zkh_syn_witgen": (_err, [_vp, _vp, _sz, _sz, _u64, _u64, _u32p, _vp, _vp, _u32p]),
@@ -207,14 +209,19 @@ class Circuit:
         """'attached' (code object compiled at load time), 'builtin' (generated at build time) or 'interpreter'."""
         return ("interpreter", "builtin", "attached")[_lib.zkh_circuit_has_compiled_kernel(self.h)]
 
-    def attach_code_object(self, image: bytes, kernel_name: str) -> None:
-        _check(_lib.zkh_circuit_attach_code_object(self.h, image, len(image), kernel_name.encode()))
+    def attach_code_object(self, image: bytes, kernel_name: str, part: int = 0, n_parts: int = 1) -> None:
+        _check(_lib.zkh_circuit_attach_code_object_part(self.h, image, len(image), kernel_name.encode(), part, n_parts))
+
+    def compiled_parts(self) -> int:
+        return int(_lib.zkh_circuit_compiled_parts(self.h))
 
     def jit(self, use_cache: bool = True) -> None:
-        """Generate + compile (hipcc --genco, disk-cached) + attach the straight-line eval_check kernel for this desc."""
+        """Generate + compile (hipcc --genco per part, in parallel, disk-cached) + attach the straight-line eval_check
+        kernels for this desc."""
         from .circuits import jit as _jit
-        image, name = _jit.compile_code_object(self.desc, use_cache=use_cache)
-        self.attach_code_object(image, name)
+        objs = _jit.compile_code_objects(self.desc, use_cache=use_cache)
+        for i, (image, name) in enumerate(objs):
+            self.attach_code_object(image, name, i, len(objs))
 
     def eval_check(self, check: Buffer, groups: Sequence[Buffer], globals_: Sequence[Buffer], poly_mix, po2: int,
                    use_interpreter: bool = False) -> None:
