@@ -134,6 +134,11 @@ const char* zkh_combos_prepare(zkh_ctx*, zkh_buf* combos, const uint32_t* pos, c
  * by (x - pt) for every pt in pts; remainders (must be 0) are written to rem_out (n_pts ExtElems, device). */
 const char* zkh_combos_divide(zkh_ctx*, zkh_buf* combos, size_t combo, size_t cycles, const uint32_t* pts_ext,
                               size_t n_pts, zkh_buf* rem_out);
+/* The same for every combo of the buffer in one call: combo i (i < n_combos) is divided by (x - pt) for each of its points
+ * pts_ext[4*pts_begin[i] .. 4*pts_begin[i+1]); remainders go to rem_out in point order.  The r-th divisions of all
+ * combos share their kernel launches (they are independent; only the divisions of one combo are sequential). */
+const char* zkh_combos_divide_all(zkh_ctx*, zkh_buf* combos, size_t cycles, size_t n_combos, const uint32_t* pts_ext,
+                                  const uint32_t* pts_begin, zkh_buf* rem_out);
 /* Hal::eltwise_add_elem / eltwise_copy_elem / eltwise_zeroize_elem / eltwise_sum_extelem */
 const char* zkh_eltwise_add_elem(zkh_ctx*, zkh_buf* out, const zkh_buf* a, const zkh_buf* b);
 const char* zkh_eltwise_copy_elem(zkh_ctx*, zkh_buf* out, const zkh_buf* in);

@@ -429,3 +429,27 @@ def test_batch_evaluate_any_runs_of_equal_columns(hal, oracle, bitrev):
     fn = hal.batch_evaluate_any_bitrev if bitrev else hal.batch_evaluate_any
     fn(hal.copy_from("c", dev), count, hal.copy_from("w", which), hal.copy_from("x", xs), out)
     assert np.array_equal(out.to_vec(), want)
+
+
+def test_combos_divide_all_matches_sequential_division(hal, oracle):
+    """Seven combo polynomials with 1..5 division points each (SYN-HEAVY's tap combos): the batched rounds give the same
+    quotients and remainders as dividing every polynomial by its points one after the other on the CPU."""
+    rng = np.random.default_rng(91)
+    cycles, counts = 1 << 13, [1, 2, 3, 4, 5, 3, 2, 1]
+    P = 2013265921
+    combos = rng.integers(0, P, size=4 * cycles * len(counts), dtype=np.uint64).astype(np.uint32)
+    pts = rng.integers(0, P, size=4 * sum(counts), dtype=np.uint64).astype(np.uint32)
+    begin = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint32)
+    want, want_rem = combos.copy(), np.zeros(4 * sum(counts), np.uint32)
+    for i, cnt in enumerate(counts):
+        poly = want[4 * cycles * i: 4 * cycles * (i + 1)]
+        for k in range(cnt):
+            j = int(begin[i]) + k
+            rem = np.zeros(4, np.uint32)
+            oracle.zko_poly_divide(poly, cycles, pts[4 * j: 4 * j + 4].copy(), rem)
+            want_rem[4 * j: 4 * j + 4] = rem
+    dev = hal.copy_from("combos", combos)
+    rem_out = hal.alloc("rem", 4 * sum(counts), zero=True)
+    hal.combos_divide_all(dev, cycles, pts, begin, rem_out)
+    assert np.array_equal(dev.to_vec(), want)
+    assert np.array_equal(rem_out.to_vec(), want_rem)

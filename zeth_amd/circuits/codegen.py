@@ -14,10 +14,12 @@ MI355X-first choices (all result-preserving — field arithmetic is exact, resul
     exponent), so the per-step Fp4 x Fp4 product of the literal algorithm disappears: powers come from a precomputed
     table through scalar loads, AndEqz is 4 multiply-adds into 64-bit accumulators reduced once per 4 constraints;
   * VALUE NUMBERING: structurally identical sub-expressions (same op on the same canonical operands, commutative ops
-    normalised) are computed once inside a window of constraints;
-  * WINDOWS bound the register pressure: a window is a run of consecutive constraints whose distinct live values fit a
-    budget; it is a C++ block, taps are (re)loaded where they are used, and a compiler barrier between windows that
-    share taps keeps LLVM from hoisting hundreds of loads to the top of the kernel (= spills);
+    normalised) get one canonical value;
+  * a software REGISTER CACHE bounds the register pressure: canonical values (taps and intermediates) are kept in an
+    LRU of REG_BUDGET C++ variables; what drops out is recomputed / re-loaded when a later constraint needs it, so the
+    taps a neighbourhood of constraints keeps reading stay in VGPRs and nothing else does.  Offset "epochs" (opaque
+    copies of the lane offsets every EPOCH_LOADS loads) stop LLVM's GVN from merging all loads of a tap into one
+    kernel-long live range, which is what turns a 50 k-step circuit into spills;
   * SPLITTING: the constraint leaves (in depth-first order of the mix tree) are cut into parts of roughly equal weight;
     each part is its own kernel (own translation unit when shipped, own code object when compiled at load time, all
     compiled in parallel) that evaluates only its leaves — partial sums of an AndCond's inner chain are multiplied by
@@ -27,6 +29,8 @@ MI355X-first choices (all result-preserving — field arithmetic is exact, resul
 """
 from __future__ import annotations
 
+import os
+from collections import OrderedDict
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -37,9 +41,10 @@ from .desc import (OP_ADD, OP_AND_COND, OP_AND_EQZ, OP_CONST, OP_CONST_EXT, OP_G
                    OP_TRUE, Circuit, P)
 
 R2 = pow(2, 64, P)
-WINDOW_BUDGET = 56          # distinct values (taps + intermediates) a window may define
-PART_WEIGHT = 3200          # value steps per generated kernel (one kernel ~ one translation unit / code object)
-GENERATOR_VERSION = 2
+REG_BUDGET = int(os.environ.get("ZKH_CODEGEN_REGS", "72"))      # values (taps + intermediates) the register cache of a kernel holds
+EPOCH_LOADS = int(os.environ.get("ZKH_CODEGEN_EPOCH", "48"))    # tap loads per offset epoch
+PART_WEIGHT = int(os.environ.get("ZKH_CODEGEN_PART", "3200"))   # value steps per generated kernel (~ one translation unit / code object)
+GENERATOR_VERSION = 3
 
 
 def desc_hash64(desc: np.ndarray) -> int:
@@ -242,64 +247,47 @@ def split_points(weights: List[int], part_weight: int = PART_WEIGHT) -> List[Tup
 # Emission of one part
 # -------------------------------------------------------------------------------------------------------------------
 class _Emitter:
+    """Straight-line code for the constraint leaves [lo, hi) of the mix tree.
+
+    Values live in a software-managed register cache: `cache` maps a canonical value to the C++ variable that currently
+    holds it, in LRU order, and is capped at REG_BUDGET entries.  A value that falls out of the cache is simply no longer
+    referenced (its live range ends at its last use); if a later constraint needs it again it is recomputed — a tap is
+    re-loaded — under a fresh variable name.  Taps that a neighbourhood of constraints keeps reading therefore stay in
+    registers, cold ones do not pin any, and the VGPR demand of the kernel is the budget plus a constant."""
+
     def __init__(self, plan: Plan, lo: int, hi: int):
         self.p, self.lo, self.hi = plan, lo, hi
         self.lines: List[str] = []
-        self.scope: set = set()             # canonical values defined in the open window
-        self.loaded_before: set = set()     # taps loaded by earlier windows (barrier needed before re-loading them)
-        self.window_open = False
+        self.cache: "OrderedDict[int, str]" = OrderedDict()
+        self.gen: Dict[int, int] = {}       # canonical value -> how often it has been (re)defined
+        self.pinned: set = set()
         self.depth_used = 0
         self.pend: Dict[int, int] = {}      # depth -> lazy products pending in s{d}_*
         self.tzero: Dict[int, bool] = {}    # depth -> t{d}_* statically known to be zero
-        self.backs: set = set()
         self.globals_used: set = set()
         self.leaf = 0                       # depth-first index of the next leaf
-        self.n_windows = 0
-        self.window_backs: List[set] = []   # per window: the backs its loads use (-> which offsets get an opaque copy)
+        self.epoch = -1
+        self.epoch_loads = EPOCH_LOADS      # forces an epoch before the first load
+        self.epoch_backs: List[set] = []
+        self.n_loads = 0
+        self.n_arith = 0
 
     def w(self, s: str) -> None:
         self.lines.append(s)
 
-    # ---- windows ----
-    def open_window(self, need_barrier: bool) -> None:
-        # Window-local copies of the lane's byte offsets and of the domain size, made opaque to the optimiser: tap loads and
-        # column-base computations of different windows then are different SSA values, so GVN cannot merge a tap that many
-        # windows read into one long-lived register (= hundreds of VGPRs / SGPR spills at realistic circuit sizes).  No
-        # memory clobber: the mix-power reads must stay provably invariant to remain scalar loads.
-        self.w("    {")
-        self.w(f"        OPAQUE_WINDOW_{self.n_windows}")
-        self.window_backs.append(set())
-        self.window_open = True
-        self.n_windows += 1
+    # ---- offset epochs ----
+    def new_epoch(self) -> None:
+        # Epoch-local copies of the lane's byte offsets and of the domain size, made opaque to the optimiser: tap loads and
+        # column-base computations of different epochs are different SSA values, so GVN cannot undo the cache policy by
+        # merging every load of a tap into one kernel-long live range (hundreds of VGPRs and SGPR spills at realistic circuit
+        # sizes).  Not `volatile` and no memory clobber: the mix-power reads must stay provably invariant to remain scalar
+        # loads; the epoch number in the asm text keeps identical-looking statements from being merged.
+        self.epoch += 1
+        self.epoch_backs.append(set())
+        self.epoch_loads = 0
+        self.w(f"    OPAQUE_EPOCH_{self.epoch}")
 
-    def close_window(self) -> None:
-        if self.window_open:
-            self.w("    }")
-            self.loaded_before |= {v for v in self.scope if self.p.fp[v][0] == OP_GET}
-            self.scope = set()
-            self.window_open = False
-
-    def ensure_values(self, roots: List[int]) -> None:
-        """Define every value the roots need inside the current window; start a new window first if the budget is exceeded."""
-        need: List[int] = []
-        have = set(self.scope)
-        for r in roots:
-            for x in self.p.cone(r, have):
-                need.append(x); have.add(x)
-        defs = [x for x in need if self.p.fp[x][0] not in (OP_CONST, OP_GET_GLOBAL)]
-        if self.window_open and len(self.scope) + len(defs) > WINDOW_BUDGET and self.scope:
-            self.close_window()
-            need, have = [], set()
-            for r in roots:
-                for x in self.p.cone(r, have):
-                    need.append(x); have.add(x)
-            defs = [x for x in need if self.p.fp[x][0] not in (OP_CONST, OP_GET_GLOBAL)]
-        if not self.window_open:
-            reload = any(self.p.fp[x][0] == OP_GET and x in self.loaded_before for x in defs)
-            self.open_window(reload)
-        for x in need:
-            self.define(x)
-
+    # ---- values ----
     def ref(self, v: int) -> str:
         op, a, b, _, _ = self.p.fp[v]
         if op == OP_CONST:
@@ -307,38 +295,88 @@ class _Emitter:
         if op == OP_GET_GLOBAL:
             self.globals_used.add((a, b))
             return f"q{a}_{b}"
-        return f"v{v}"
+        return self.cache[v]
 
     def ext_ref(self, v: int) -> str:
         """An Fp4 expression for value v (promoting Fp values)."""
         if self.p.ext[v]:
-            return f"x{v}"
+            return self.cache[v]
         return f"Fp4(Fp::raw({self.ref(v)}))"
+
+    def touch(self, v: int) -> None:
+        if v in self.cache:
+            self.cache.move_to_end(v)
+
+    def need(self, roots: List[int]) -> None:
+        """Make every root available in the cache (computing what is missing), pinned until release()."""
+        for r in roots:
+            if self.p.fp[r][0] in (OP_CONST, OP_GET_GLOBAL):
+                continue
+            missing = self.p.cone(r, self.cache)
+            # operands that are already cached must survive the evictions the new definitions cause
+            for x in missing:
+                op, a, b, _, _ = self.p.fp[x]
+                if op in (OP_ADD, OP_SUB, OP_MUL):
+                    for o in (a, b):
+                        if o in self.cache:
+                            self.pinned.add(o)
+            for x in missing:
+                self.define(x)
+                self.pinned.add(x)
+            self.pinned.add(r)
+            self.touch(r)
+
+    def release(self) -> None:
+        self.pinned.clear()
+        while len(self.cache) > REG_BUDGET:
+            self.cache.popitem(last=False)
+
+    def evict_for_one(self) -> None:
+        if len(self.cache) < REG_BUDGET:
+            return
+        for k in self.cache:                       # oldest first
+            if k not in self.pinned:
+                del self.cache[k]
+                return
 
     def define(self, v: int) -> None:
         op, a, b, cc, d = self.p.fp[v]
         if op in (OP_CONST, OP_GET_GLOBAL):
             self.ref(v)
             return
-        self.scope.add(v)
+        for o in ((a, b) if op in (OP_ADD, OP_SUB, OP_MUL) else ()):
+            self.touch(o)
+        g = self.gen.get(v, 0)
+        self.gen[v] = g + 1
+        self.evict_for_one()
         if op == OP_GET:
-            g, off, back = self.p.c.taps[a]
-            self.backs.add(back)
-            self.window_backs[-1].add(back)
-            self.w(f"        const uint32_t v{v} = tap_load(g{g}, (size_t){off} * dw, o{back});")
+            grp, off, back = self.p.c.taps[a]
+            if self.epoch_loads >= EPOCH_LOADS:
+                self.new_epoch()
+            self.epoch_backs[-1].add(back)
+            self.epoch_loads += 1
+            self.n_loads += 1
+            name = f"v{v}" + (f"_{g}" if g else "")
+            self.w(f"    const uint32_t {name} = tap_load(g{grp}, (size_t){off} * dw{self.epoch}, o{back}_{self.epoch});")
         elif op == OP_CONST_EXT:
-            self.w(f"        const Fp4 x{v}(Fp::raw({mont(a)}u), Fp::raw({mont(b)}u), Fp::raw({mont(cc)}u), Fp::raw({mont(d)}u));")
+            name = f"x{v}" + (f"_{g}" if g else "")
+            self.w(f"    const Fp4 {name}(Fp::raw({mont(a)}u), Fp::raw({mont(b)}u), Fp::raw({mont(cc)}u), Fp::raw({mont(d)}u));")
         elif self.p.ext[v]:
+            name = f"x{v}" + (f"_{g}" if g else "")
             sym = {OP_ADD: "+", OP_SUB: "-", OP_MUL: "*"}[op]
             if op == OP_MUL and not self.p.ext[a]:
-                self.w(f"        const Fp4 x{v} = x{b} * Fp::raw({self.ref(a)});")
+                self.w(f"    const Fp4 {name} = {self.cache[b]} * Fp::raw({self.ref(a)});")
             elif op == OP_MUL and not self.p.ext[b]:
-                self.w(f"        const Fp4 x{v} = x{a} * Fp::raw({self.ref(b)});")
+                self.w(f"    const Fp4 {name} = {self.cache[a]} * Fp::raw({self.ref(b)});")
             else:
-                self.w(f"        const Fp4 x{v} = {self.ext_ref(a)} {sym} {self.ext_ref(b)};")
+                self.w(f"    const Fp4 {name} = {self.ext_ref(a)} {sym} {self.ext_ref(b)};")
+            self.n_arith += 1
         else:
+            name = f"v{v}" + (f"_{g}" if g else "")
             fn = {OP_ADD: "add_mod", OP_SUB: "sub_mod", OP_MUL: "mul_mod"}[op]
-            self.w(f"        const uint32_t v{v} = {fn}({self.ref(a)}, {self.ref(b)});")
+            self.w(f"    const uint32_t {name} = {fn}({self.ref(a)}, {self.ref(b)});")
+            self.n_arith += 1
+        self.cache[v] = name
 
     # ---- accumulators ----
     def use_depth(self, d: int) -> None:
@@ -346,29 +384,26 @@ class _Emitter:
 
     def reset(self, d: int) -> None:
         self.use_depth(d)
-        ind = "        " if self.window_open else "    "
-        self.w(f"{ind}t{d}_0 = t{d}_1 = t{d}_2 = t{d}_3 = 0; s{d}_0 = s{d}_1 = s{d}_2 = s{d}_3 = 0;")
+        self.w(f"    t{d}_0 = t{d}_1 = t{d}_2 = t{d}_3 = 0; s{d}_0 = s{d}_1 = s{d}_2 = s{d}_3 = 0;")
         self.pend[d], self.tzero[d] = 0, True
 
     def flush(self, d: int) -> None:
         if self.pend.get(d, 0) == 0:
             return
-        ind = "        " if self.window_open else "    "
         for k in range(4):
             if self.tzero[d]:
-                self.w(f"{ind}t{d}_{k} = mont_reduce_wide(s{d}_{k}); s{d}_{k} = 0;")
+                self.w(f"    t{d}_{k} = mont_reduce_wide(s{d}_{k}); s{d}_{k} = 0;")
             else:
-                self.w(f"{ind}t{d}_{k} = add_mod(t{d}_{k}, mont_reduce_wide(s{d}_{k})); s{d}_{k} = 0;")
+                self.w(f"    t{d}_{k} = add_mod(t{d}_{k}, mont_reduce_wide(s{d}_{k})); s{d}_{k} = 0;")
         self.pend[d], self.tzero[d] = 0, False
 
     def add_fp4(self, d: int, expr: str) -> None:
         """t{d} += Fp4 expression (non-lazy path: ConstExt-valued constraints and AndCond contributions)."""
         self.flush(d)
-        ind = "        " if self.window_open else "    "
-        self.w(f"{ind}{{ const Fp4 c_ = {expr};")
+        self.w(f"    {{ const Fp4 c_ = {expr};")
         for k in range(4):
-            self.w(f"{ind}  t{d}_{k} = add_mod(t{d}_{k}, c_.c[{k}].v);")
-        self.w(f"{ind}}}")
+            self.w(f"      t{d}_{k} = add_mod(t{d}_{k}, c_.c[{k}].v);")
+        self.w("    }")
         self.tzero[d] = False
 
     # ---- the mix tree ----
@@ -382,16 +417,18 @@ class _Emitter:
                 if not (self.lo <= idx < self.hi):
                     continue
                 _, v, e = it
-                self.ensure_values([v])
+                self.need([v])
                 any_emitted = True
                 if self.p.ext[v]:
-                    self.add_fp4(d, f"Fp4(Fp::raw(pw[{e}].x), Fp::raw(pw[{e}].y), Fp::raw(pw[{e}].z), Fp::raw(pw[{e}].w)) * x{v}")
+                    self.add_fp4(d, f"Fp4(Fp::raw(pw[{e}].x), Fp::raw(pw[{e}].y), Fp::raw(pw[{e}].z), Fp::raw(pw[{e}].w)) * {self.cache[v]}")
+                    self.release()
                     continue
                 # tot += mix^e * v: four 64-bit multiply-adds (scalar-loaded power words), ONE reduction per four constraints
                 # (4 P^2 < 2 P 2^32, the bound of mont_reduce_wide)
                 r = self.ref(v)
-                self.w(f"        {{ const uint4 p_ = pw[{e}]; s{d}_0 += (uint64_t)p_.x * {r}; s{d}_1 += (uint64_t)p_.y * {r}; "
+                self.w(f"    {{ const uint4 p_ = pw[{e}]; s{d}_0 += (uint64_t)p_.x * {r}; s{d}_1 += (uint64_t)p_.y * {r}; "
                        f"s{d}_2 += (uint64_t)p_.z * {r}; s{d}_3 += (uint64_t)p_.w * {r}; }}")
+                self.release()
                 self.pend[d] = self.pend.get(d, 0) + 1
                 if self.pend[d] == 4:
                     self.flush(d)
@@ -407,13 +444,14 @@ class _Emitter:
                 if not got:
                     continue
                 self.flush(d + 1)
-                self.ensure_values([cond])
+                self.need([cond])
                 any_emitted = True
                 tin = f"Fp4(Fp::raw(t{d + 1}_0), Fp::raw(t{d + 1}_1), Fp::raw(t{d + 1}_2), Fp::raw(t{d + 1}_3))"
                 prod = f"{tin} * {self.ext_ref(cond)}" if self.p.ext[cond] else f"{tin} * Fp::raw({self.ref(cond)})"
                 if e != 0:
                     prod = f"({prod}) * Fp4(Fp::raw(pw[{e}].x), Fp::raw(pw[{e}].y), Fp::raw(pw[{e}].z), Fp::raw(pw[{e}].w))"
                 self.add_fp4(d, prod)
+                self.release()
         return any_emitted
 
 
@@ -422,23 +460,23 @@ def emit_part(kernel: str, plan: Plan, lo: int, hi: int, standalone: bool, heade
     em.use_depth(0)
     em.pend[0], em.tzero[0] = 0, True
     em.emit_chain(plan.c.ret, 0)
-    em.close_window()
     em.flush(0)
     body = []
+    backs_used = set()
     for ln in em.lines:
-        if ln.startswith("        OPAQUE_WINDOW_"):
+        if ln.startswith("    OPAQUE_EPOCH_"):
             k = int(ln.rsplit("_", 1)[1])
-            bks = sorted(em.window_backs[k])
-            decl = " ".join(f"uint32_t o{bk} = b{bk};" for bk in bks)
-            outs = ", ".join([f'"+v"(o{bk})' for bk in bks] + ['"+s"(dw)'])
-            # not `volatile` (a volatile asm counts as a memory clobber and would turn the mix-power reads into vector loads);
-            # the window number in the text keeps identical-looking statements from being merged
-            body.append(f"        {decl} uint32_t dw = a.dom; asm(\"; window {k}\" : {outs});")
+            bks = sorted(em.epoch_backs[k])
+            backs_used |= set(bks)
+            decl = " ".join(f"uint32_t o{bk}_{k} = b{bk};" for bk in bks)
+            outs = ", ".join([f'"+v"(o{bk}_{k})' for bk in bks] + [f'"+s"(dw{k})'])
+            body.append(f"    {decl} uint32_t dw{k} = a.dom; asm(\"; epoch {k}\" : {outs});")
         else:
             body.append(ln)
     L: List[str] = []
     w = L.append
     w(header)
+    w(f"//   {em.n_loads} tap loads, {em.n_arith} arithmetic steps emitted (register cache of {REG_BUDGET} values, offset epochs of {EPOCH_LOADS} loads)")
     linkage = 'extern "C" ' if standalone else ""
     w(f"{linkage}__global__ __launch_bounds__(256) void {kernel}(EvalCheckArgs a) {{")
     w("    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;")
@@ -448,7 +486,7 @@ def emit_part(kernel: str, plan: Plan, lo: int, hi: int, standalone: bool, heade
     w("    const uint4* __restrict__ pw = (const uint4*)a.mix_pows;")
     for g in range(3):
         w(f"    const uint32_t* __restrict__ g{g} = a.groups[{g}];")
-    for bk in sorted(em.backs):               # byte offset of this lane's row at each back (32-bit: 4n words < 2^26)
+    for bk in sorted(backs_used):               # byte offset of this lane's row at each back (32-bit: 4n words < 2^26)
         w(f"    const uint32_t b{bk} = " + ("idx * 4u;" if bk == 0 else f"((idx - {4 * bk}u) & mask) * 4u;"))
     for (x, y) in sorted(em.globals_used):
         w(f"    const uint32_t q{x}_{y} = a.globals[{x}][{y}];")

@@ -11,8 +11,9 @@ real thing has and SYN-A lacks:
     columns at {0,1,2}: 7 distinct back-sets = 7 tap combos for DEEP / FRI batching (SYN-A: 2);
   * ~50 k PolyExtSteps, degree 5: ~3 k constraints  active * Z_j * Q  where Z_j = d[3j] d[3j+1] - d[3j+2] vanishes on
     every active row by construction of the SYN witness and Q is a pseudo-random degree-2 expression (~12 steps) over
-    taps at backs 0..4 with sub-terms shared between constraints (the generator's value numbering finds them) —
-    the seal's check polynomial still depends on every coefficient of Q at the random point z;
+    taps at backs 0..4, drawn mostly from the ~30 registers of the constraint's own component (locality, as in a real
+    circuit) with sub-terms shared between constraints (the generator's value numbering finds them) — the seal's check
+    polynomial still depends on every coefficient of Q at the random point z;
   * nested conditionals (AndCond inside AndCond) and ConstExt operands (extension-field valued sub-expressions).
 
 Everything stays data: the same desc blob format, consumed by the oracle, the interpreter and the code generator.
@@ -62,13 +63,28 @@ def build_syn_heavy(wc: int = 16, wd: int = 208, wa: int = 32, per_triple: int =
     tap_pool += [(GROUP_ACCUM, c, bk) for c in range(wa) for bk in (0, 1, 2)]
     pool_pos = [0]
 
+    # Locality, as in a real circuit: the constraints of one component (here: one triple) read a small set of related
+    # registers over and over — LOCAL taps, handed out round-robin so that every (column, back) pair of the pool becomes a
+    # tap — and only now and then something from elsewhere in the trace.
+    local: list = []
+
+    def new_local_pool(size: int = 28):
+        local.clear()
+        for _ in range(size):
+            local.append(tap_pool[pool_pos[0] % len(tap_pool)])
+            pool_pos[0] += 1
+        local.append(tap_pool[rnd(len(tap_pool))])
+        local.append(tap_pool[rnd(len(tap_pool))])
+
+    next_pos = [0]
+
     def next_tap():
-        g, c, bk = tap_pool[pool_pos[0] % len(tap_pool)]
-        pool_pos[0] += 1
+        g, c, bk = local[next_pos[0] % len(local)]
+        next_pos[0] += 1
         return b.get(g, c, bk)
 
     def rand_tap():
-        g, c, bk = tap_pool[rnd(len(tap_pool))]
+        g, c, bk = tap_pool[rnd(len(tap_pool))] if rnd(16) == 0 else local[rnd(len(local))]
         return b.get(g, c, bk)
 
     def linear(k: int):
@@ -84,13 +100,14 @@ def build_syn_heavy(wc: int = 16, wd: int = 208, wa: int = 32, per_triple: int =
     for j in range(T):
         x, y, p = data(3 * j), data(3 * j + 1), data(3 * j + 2)
         inner = b.and_eqz(inner, b.sub(b.mul(x, y), p))
+        new_local_pool()
         # sub-terms shared by the constraints of this triple (re-emitted every time: the generator's CSE finds them)
-        shared = [(1 + rnd(1 << 12), rnd(len(tap_pool)), rnd(len(tap_pool))) for _ in range(6)]
+        shared = [(1 + rnd(1 << 12), rnd(len(local)), rnd(len(local))) for _ in range(6)]
 
         def shared_term(i):
             c, ta, tb = shared[i]
-            ga, ca, ba = tap_pool[ta]
-            gb, cb, bb = tap_pool[tb]
+            ga, ca, ba = local[ta]
+            gb, cb, bb = local[tb]
             return b.add(b.mul(b.const(c), b.get(ga, ca, ba)), b.get(gb, cb, bb))      # degree 1
 
         nested = b.true()

@@ -6,6 +6,8 @@
 // All of these stream W x n (or combos x n) words once: HBM-bound.  The two linear recurrences (synthetic
 // division, running product) are done as three-level 256-wide block scans (up-sweep of block totals, down-sweep
 // with carries) instead of upstream's chunked sequential loops.
+#include <algorithm>
+
 #include "common.h"
 
 using namespace zkh;
@@ -39,7 +41,7 @@ constexpr int EV_PER = 64, EV_CH = TB * EV_PER, EV_MAXP = 8, EV_SCAN = 256;
 
 template <int NP>
 __device__ __forceinline__ void ev_accumulate(Fp4 (&acc)[EV_MAXP], const uint32_t* __restrict__ c, size_t j0, size_t po,
-                                              const uint4 (*xp)[EV_PER]) {
+                                              uint4 (*xp)[EV_PER]) {
     // Fp x Fp4 multiply-accumulate, lazily: four products per 64-bit accumulator (4 P^2 < 2 P 2^32), then ONE reduction
     // and one modular add per component instead of four of each.  The coefficient is loaded once for all NP points.
 #pragma unroll 2
@@ -81,11 +83,13 @@ __global__ __launch_bounds__(TB) void k_eval_partial(uint32_t* __restrict__ part
     if ((k0 - start) % EV_MAXP != 0) return;                  // another block of the run covers this entry
     uint32_t np = 1;
     while (np < EV_MAXP && k0 + np < n_eval && which[k0 + np] == col) np++;
-    uint4 (*xt)[TB] = (uint4 (*)[TB])ev_lds;                        // [np][TB]      x^t  | x^(bitrev8(t) << (k-8))
-    uint4 (*xp)[EV_PER] = (uint4 (*)[EV_PER])(ev_lds + np * TB);    // [np][EV_PER]  X^i, X = x^256 | x^(bitrev6(i) << (k-14))
-    uint4* red = ev_lds + np * (TB + EV_PER);                       // [TB]
+    // LDS (9.7 KB + 1 KB per extra point, so that many blocks stay resident per CU): the per-point X^i tables used by the
+    // streaming loop, and ONE x^t table + reduction buffer reused point by point afterwards
+    uint4 (*xp)[EV_PER] = (uint4 (*)[EV_PER])ev_lds;                // [EV_MAXP][EV_PER]  X^i, X = x^256 | x^(bitrev6(i) << (k-14))
+    uint4* xt = ev_lds + EV_MAXP * EV_PER;                          // [TB]  x^t | x^(bitrev8(t) << (k-8))
+    uint4* red = xt + TB;                                           // [TB]
     uint4* sq = red + TB;                                           // [32]  BITREV: x^(2^m)
-    Fp4 chunk_pow[EV_MAXP];
+    // ---- X^i tables of every point ----
     for (uint32_t p = 0; p < np; p++) {
         const Fp4 x = ld_ext(xs + 4 * (k0 + p));
         if (BITREV) {
@@ -93,44 +97,23 @@ __global__ __launch_bounds__(TB) void k_eval_partial(uint32_t* __restrict__ part
             if (t == 0) {
                 Fp4 y = x;
                 for (uint32_t m = 0; m < log_n; m++) { st_ext((uint32_t*)&sq[m], y); y = y * y; }
-                st_ext((uint32_t*)&xt[p][0], Fp4::one());
                 st_ext((uint32_t*)&xp[p][0], Fp4::one());
             }
             __syncthreads();
-            for (uint32_t b = 0; b < 8; b++) {                    // position bit b of t  ->  exponent bit k-1-b
-                const uint32_t s = 1u << b;
-                if (t < s) st_ext((uint32_t*)&xt[p][s + t], ld_ext((const uint32_t*)&xt[p][t]) * ld_ext((const uint32_t*)&sq[log_n - 1 - b]));
-                __syncthreads();
-            }
             for (uint32_t b = 0; b < 6; b++) {                    // position bit 8+b  ->  exponent bit k-9-b
                 const uint32_t s = 1u << b;
                 if (t < s) st_ext((uint32_t*)&xp[p][s + t], ld_ext((const uint32_t*)&xp[p][t]) * ld_ext((const uint32_t*)&sq[log_n - 9 - b]));
                 __syncthreads();
             }
-            chunk_pow[p] = Fp4::one();
-            if (t == 0)
-                for (uint32_t c = 0; c + 14 < log_n; c++)          // position bit 14+c -> exponent bit k-15-c
-                    if ((chunk >> c) & 1) chunk_pow[p] = chunk_pow[p] * ld_ext((const uint32_t*)&sq[log_n - 15 - c]);
         } else {
-            // doubling: tab[s + i] = tab[i] * x^s
-            if (t == 0) { st_ext((uint32_t*)&xt[p][0], Fp4::one()); }
-            __syncthreads();
-            Fp4 xs_pow = x;    // x^s
-            for (uint32_t s = 1; s < TB; s <<= 1) {
-                if (t < s) st_ext((uint32_t*)&xt[p][s + t], ld_ext((const uint32_t*)&xt[p][t]) * xs_pow);
-                xs_pow = xs_pow * xs_pow;
-                __syncthreads();
-            }
-            const Fp4 X = xs_pow;            // x^256
             if (t == 0) st_ext((uint32_t*)&xp[p][0], Fp4::one());
             __syncthreads();
-            Fp4 Xs = X;
+            Fp4 Xs = fp4_pow(x, TB);                              // X = x^256
             for (uint32_t s = 1; s < EV_PER; s <<= 1) {
                 if (t < s) st_ext((uint32_t*)&xp[p][s + t], ld_ext((const uint32_t*)&xp[p][t]) * Xs);
                 Xs = Xs * Xs;
                 __syncthreads();
             }
-            chunk_pow[p] = t == 0 ? fp4_pow(Xs, chunk) : Fp4::one();   // x^(chunk*CH) = (X^EV_PER)^chunk
         }
     }
     __syncthreads();
@@ -149,17 +132,47 @@ __global__ __launch_bounds__(TB) void k_eval_partial(uint32_t* __restrict__ part
     case 7: ev_accumulate<7>(acc, c, j0, po, xp); break;
     default: ev_accumulate<8>(acc, c, j0, po, xp); break;
     }
+    // ---- per point: lane total * x^t, block reduction, * x^(chunk*CH) ----
 #pragma unroll
     for (int p = 0; p < EV_MAXP; p++) {
         if ((uint32_t)p >= np) break;
-        st_ext((uint32_t*)&red[t], acc[p] * ld_ext((const uint32_t*)&xt[p][t]));
+        const Fp4 x = ld_ext(xs + 4 * (k0 + p));
+        Fp4 chunk_pow = Fp4::one();
+        __syncthreads();                                      // xt / red / sq of the previous point are no longer read
+        if (BITREV) {
+            if (t == 0) {
+                Fp4 y = x;
+                for (uint32_t m = 0; m < log_n; m++) { st_ext((uint32_t*)&sq[m], y); y = y * y; }
+                st_ext((uint32_t*)&xt[0], Fp4::one());
+            }
+            __syncthreads();
+            for (uint32_t b = 0; b < 8; b++) {                    // position bit b of t  ->  exponent bit k-1-b
+                const uint32_t s = 1u << b;
+                if (t < s) st_ext((uint32_t*)&xt[s + t], ld_ext((const uint32_t*)&xt[t]) * ld_ext((const uint32_t*)&sq[log_n - 1 - b]));
+                __syncthreads();
+            }
+            if (t == 0)
+                for (uint32_t cb = 0; cb + 14 < log_n; cb++)       // position bit 14+c -> exponent bit k-15-c
+                    if ((chunk >> cb) & 1) chunk_pow = chunk_pow * ld_ext((const uint32_t*)&sq[log_n - 15 - cb]);
+        } else {
+            // doubling: tab[s + i] = tab[i] * x^s
+            if (t == 0) st_ext((uint32_t*)&xt[0], Fp4::one());
+            __syncthreads();
+            Fp4 xs_pow = x;    // x^s
+            for (uint32_t s = 1; s < TB; s <<= 1) {
+                if (t < s) st_ext((uint32_t*)&xt[s + t], ld_ext((const uint32_t*)&xt[t]) * xs_pow);
+                xs_pow = xs_pow * xs_pow;
+                __syncthreads();
+            }
+            if (t == 0) chunk_pow = fp4_pow(fp4_pow(xs_pow, EV_PER), chunk);   // x^(chunk*CH) = ((x^256)^EV_PER)^chunk
+        }
+        st_ext((uint32_t*)&red[t], acc[p] * ld_ext((const uint32_t*)&xt[t]));
         __syncthreads();
         for (uint32_t s = TB / 2; s >= 1; s >>= 1) {
             if (t < s) st_ext((uint32_t*)&red[t], ld_ext((const uint32_t*)&red[t]) + ld_ext((const uint32_t*)&red[t + s]));
             __syncthreads();
         }
-        if (t == 0) st_ext(partial + 4 * ((size_t)(k0 + p) * n_chunks + chunk), ld_ext((const uint32_t*)&red[0]) * chunk_pow[p]);
-        __syncthreads();
+        if (t == 0) st_ext(partial + 4 * ((size_t)(k0 + p) * n_chunks + chunk), ld_ext((const uint32_t*)&red[0]) * chunk_pow);
     }
 }
 // in-place bit reversal of `count` polynomials of n ExtElems (AoS)
@@ -228,12 +241,21 @@ __global__ __launch_bounds__(TB) void k_mix_poly_coeffs(uint32_t* __restrict__ o
 // TOTAL_ONLY: write S[0] per block (up-sweep).  Otherwise write S shifted by `shift` positions
 // (shift = 1 turns suffix sums into synthetic-division quotients: q_i = S_{i+1}).
 // ---------------------------------------------------------------------------------------------------------
+// blockIdx.y selects one of several independent polynomials handled by the same launch (combos_divide_all): polynomial y
+// lives at in/out + offs[y] words, its carries at carries + y * carry_stride words, its weight is ws[y] (Fp4, device).
 template <bool TOTAL_ONLY>
 __global__ __launch_bounds__(TB) void k_suffix_scan(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, size_t n,
-                                                    Fp4 w, const uint32_t* __restrict__ carries /* per block b: S of block b+1 start; may be null */,
-                                                    size_t n_carries, uint32_t shift, uint32_t* __restrict__ rem_out) {
+                                                    const uint32_t* __restrict__ ws /* per y: Fp4 weight of this level */,
+                                                    const uint32_t* __restrict__ carries /* per block b: S of block b+1 start; may be null */,
+                                                    size_t n_carries, uint32_t shift, uint32_t* __restrict__ rem_out,
+                                                    const uint32_t* __restrict__ in_offs, const uint32_t* __restrict__ out_offs,
+                                                    size_t carry_stride, const uint32_t* __restrict__ rem_idx) {
     __shared__ uint4 buf[2][TB + 1];
-    const uint32_t t = threadIdx.x;
+    const uint32_t t = threadIdx.x, y = blockIdx.y;
+    in += in_offs ? (size_t)in_offs[y] : 0;
+    out += out_offs ? (size_t)out_offs[y] : 0;
+    if (carries) carries += (size_t)y * carry_stride;
+    const Fp4 w = ld_ext(ws + 4 * y);
     const size_t b = blockIdx.x, i = b * TB + t;
     Fp4 v = i < n ? ld_ext(in + 4 * i) : Fp4::zero();
     Fp4 carry = Fp4::zero();
@@ -258,7 +280,7 @@ __global__ __launch_bounds__(TB) void k_suffix_scan(uint32_t* __restrict__ out, 
         if (t == 0) st_ext(out + 4 * b, ld_ext((const uint32_t*)&buf[cur][0]));
     } else {
         if (i < n) st_ext(out + 4 * i, ld_ext((const uint32_t*)&buf[cur][t + shift]));
-        if (rem_out && i == 0) st_ext(rem_out, ld_ext((const uint32_t*)&buf[cur][0]));
+        if (rem_out && i == 0) st_ext(rem_out + 4 * (rem_idx ? rem_idx[y] : 0), ld_ext((const uint32_t*)&buf[cur][0]));
     }
 }
 
@@ -318,9 +340,10 @@ static const char* evaluate_any_impl(zkh_ctx* c, const zkh_buf* coeffs, size_t p
     zkh_buf* partial = nullptr;
     ZKH_TRY(new_buf(c, 4 * n_eval * n_chunks, false, &partial));
     {
-        ProfScope prof(c, "batch_evaluate_any", 4.0 * po * n_eval);
-        // LDS: worst-case run of EV_MAXP points (power tables per point) + the reduction buffer + the squarings
-        const size_t lds = ((size_t)EV_MAXP * (TB + EV_PER) + TB + 32) * sizeof(uint4);
+        // §8d: each coefficient column is streamed once for all the points it is evaluated at
+        ProfScope prof(c, "batch_evaluate_any", 4.0 * po * (double)(n_eval < poly_count ? n_eval : poly_count));
+        // LDS: X^i tables for a full run of EV_MAXP points + one x^t table + the reduction buffer + the squarings (16.9 KB)
+        const size_t lds = ((size_t)EV_MAXP * EV_PER + 2 * TB + 32) * sizeof(uint4);
         if (bitrev)
             k_eval_partial<true><<<dim3(n_chunks, (unsigned)n_eval), TB, lds, c->stream>>>(partial->ptr(), coeffs->ptr(), po, which->ptr(),
                                                                                         xs->ptr(), n_chunks, log_n, (uint32_t)n_eval);
@@ -366,31 +389,84 @@ extern "C" const char* zkh_mix_poly_coeffs(zkh_ctx* c, zkh_buf* out, const uint3
     return last_launch_error("mix_poly_coeffs");
 }
 
+namespace zkh { const char* h2d(zkh_ctx* c, uint32_t* dst, const uint32_t* host, size_t n); }
+
+// One round of synthetic division for `ny` independent polynomials of `cycles` ExtElems each (polynomial y at
+// combos + poly_off[y] words, divided by (x - pts[y]); remainder to rem_out[rem_idx[y]]): the five scan launches of the
+// three-level weighted suffix scan, each covering all ny polynomials through blockIdx.y.
+static const char* divide_round(zkh_ctx* c, zkh_buf* combos, size_t cycles, size_t ny, const uint32_t* poly_off, const Fp4* pts,
+                                const uint32_t* rem_idx, zkh_buf* rem_out) {
+    const size_t n0 = cycles, n1 = ceil_div(n0, TB), n2 = ceil_div(n1, TB);
+    ZKH_REQUIRE(n2 <= TB, "combos_divide: polynomial too long");
+    zkh_buf *t0 = nullptr, *t1 = nullptr, *meta = nullptr;
+    ZKH_TRY(new_buf(c, 4 * n1 * ny, false, &t0));    // level-0 block totals, then S at level-0 block starts
+    ZKH_TRY(new_buf(c, 4 * n2 * ny, false, &t1));    // level-1 block totals, then S at level-1 block starts
+    // per-launch metadata: weights of the three levels (z, z^256, z^65536), polynomial offsets, per-y offsets into t0 / t1
+    std::vector<uint32_t> m(12 * ny + 4 * ny);
+    for (size_t y = 0; y < ny; y++) {
+        const Fp4 z = pts[y], z256 = fp4_pow(z, TB), z64k = fp4_pow(z256, TB);
+        memcpy(&m[4 * y], &z, 16); memcpy(&m[4 * ny + 4 * y], &z256, 16); memcpy(&m[8 * ny + 4 * y], &z64k, 16);
+        m[12 * ny + y] = poly_off[y];
+        m[13 * ny + y] = (uint32_t)(4 * n1 * y);
+        m[14 * ny + y] = (uint32_t)(4 * n2 * y);
+        m[15 * ny + y] = rem_idx[y];
+    }
+    ZKH_TRY(new_buf(c, m.size(), false, &meta));
+    ZKH_TRY(h2d(c, meta->ptr(), m.data(), m.size()));
+    const uint32_t *w0 = meta->ptr(), *w1 = w0 + 4 * ny, *w2 = w0 + 8 * ny, *poff = w0 + 12 * ny, *t0off = w0 + 13 * ny,
+                   *t1off = w0 + 14 * ny, *ridx = w0 + 15 * ny;
+    {
+        ProfScope prof(c, "combos_divide", 32.0 * cycles * ny);
+        // up-sweep
+        k_suffix_scan<true><<<dim3((unsigned)n1, (unsigned)ny), TB, 0, c->stream>>>(t0->ptr(), combos->ptr(), n0, w0, nullptr, 0, 0, nullptr, poff, t0off, 0, nullptr);
+        k_suffix_scan<true><<<dim3((unsigned)n2, (unsigned)ny), TB, 0, c->stream>>>(t1->ptr(), t0->ptr(), n1, w1, nullptr, 0, 0, nullptr, t0off, t1off, 0, nullptr);
+        // top level (n2 <= 256): S at level-1 block starts
+        k_suffix_scan<false><<<dim3(1, (unsigned)ny), TB, 0, c->stream>>>(t1->ptr(), t1->ptr(), n2, w2, nullptr, 0, 0, nullptr, t1off, t1off, 0, nullptr);
+        // down-sweep: S at level-0 block starts, then the quotient itself (shift 1), remainder = S_0
+        k_suffix_scan<false><<<dim3((unsigned)n2, (unsigned)ny), TB, 0, c->stream>>>(t0->ptr(), t0->ptr(), n1, w1, t1->ptr(), n2, 0, nullptr, t0off, t0off, 4 * n2, nullptr);
+        k_suffix_scan<false><<<dim3((unsigned)n1, (unsigned)ny), TB, 0, c->stream>>>(combos->ptr(), combos->ptr(), n0, w0, t0->ptr(), n1, 1, rem_out->ptr(), poff, poff, 4 * n1, ridx);
+    }
+    zkh_release(t0); zkh_release(t1); zkh_release(meta);
+    return last_launch_error("combos_divide");
+}
+
 extern "C" const char* zkh_combos_divide(zkh_ctx* c, zkh_buf* combos, size_t combo, size_t cycles, const uint32_t* pts,
                                          size_t n_pts, zkh_buf* rem_out) {
     ZKH_REQUIRE((combo + 1) * cycles * 4 <= combos->len, "combos_divide: combo %zu out of range", combo);
     ZKH_REQUIRE(rem_out->len >= 4 * n_pts, "combos_divide: remainder buffer too small");
-    ZKH_REQUIRE(cycles <= ((size_t)1 << 24), "combos_divide: polynomial too long");
-    uint32_t* poly = combos->ptr() + 4 * combo * cycles;
-    const size_t n0 = cycles, n1 = ceil_div(n0, TB), n2 = ceil_div(n1, TB);
-    zkh_buf *t0 = nullptr, *t1 = nullptr, *s2 = nullptr;
-    ZKH_TRY(new_buf(c, 4 * n1, false, &t0));    // level-0 block totals, then S at level-0 block starts
-    ZKH_TRY(new_buf(c, 4 * n2, false, &t1));    // level-1 block totals, then S at level-1 block starts
-    ZKH_TRY(new_buf(c, 4 * TB, false, &s2));
+    ZKH_REQUIRE(cycles <= ((size_t)1 << 24) && combos->len < ((size_t)1 << 32), "combos_divide: polynomial too long");
+    const uint32_t off = (uint32_t)(4 * combo * cycles);
     for (size_t k = 0; k < n_pts; k++) {
-        const Fp4 z = to_fp4(pts + 4 * k), z256 = fp4_pow(z, TB), z64k = fp4_pow(z256, TB);
-        ProfScope prof(c, "combos_divide", 32.0 * cycles);
-        // up-sweep
-        k_suffix_scan<true><<<(unsigned)n1, TB, 0, c->stream>>>(t0->ptr(), poly, n0, z, nullptr, 0, 0, nullptr);
-        k_suffix_scan<true><<<(unsigned)n2, TB, 0, c->stream>>>(t1->ptr(), t0->ptr(), n1, z256, nullptr, 0, 0, nullptr);
-        // top level (n2 <= 256): S at level-1 block starts
-        k_suffix_scan<false><<<1, TB, 0, c->stream>>>(t1->ptr(), t1->ptr(), n2, z64k, nullptr, 0, 0, nullptr);
-        // down-sweep: S at level-0 block starts, then the quotient itself (shift 1), remainder = S_0
-        k_suffix_scan<false><<<(unsigned)n2, TB, 0, c->stream>>>(t0->ptr(), t0->ptr(), n1, z256, t1->ptr(), n2, 0, nullptr);
-        k_suffix_scan<false><<<(unsigned)n1, TB, 0, c->stream>>>(poly, poly, n0, z, t0->ptr(), n1, 1, rem_out->ptr() + 4 * k);
-        ZKH_TRY(last_launch_error("combos_divide"));
+        const Fp4 z = to_fp4(pts + 4 * k);
+        const uint32_t ridx = (uint32_t)k;
+        ZKH_TRY(divide_round(c, combos, cycles, 1, &off, &z, &ridx, rem_out));
     }
-    zkh_release(t0); zkh_release(t1); zkh_release(s2);
+    return nullptr;
+}
+// Hal::combos_divide for the whole combo buffer at once: combo i is divided by (x - pt) for each of its points
+// pts[pts_begin[i] .. pts_begin[i+1]); remainders land in rem_out in the same order.  The divisions of one combo are
+// sequential, different combos are independent: round r divides, in ONE set of launches, every combo that has an r-th point.
+extern "C" const char* zkh_combos_divide_all(zkh_ctx* c, zkh_buf* combos, size_t cycles, size_t n_combos, const uint32_t* pts,
+                                             const uint32_t* pts_begin, zkh_buf* rem_out) {
+    ZKH_REQUIRE(n_combos * cycles * 4 <= combos->len, "combos_divide_all: %zu combos of %zu cycles exceed the buffer", n_combos, cycles);
+    ZKH_REQUIRE(cycles <= ((size_t)1 << 24) && combos->len < ((size_t)1 << 32), "combos_divide_all: polynomial too long");
+    ZKH_REQUIRE(rem_out->len >= 4 * (size_t)pts_begin[n_combos], "combos_divide_all: remainder buffer too small");
+    size_t max_pts = 0;
+    for (size_t i = 0; i < n_combos; i++) {
+        ZKH_REQUIRE(pts_begin[i + 1] >= pts_begin[i], "combos_divide_all: pts_begin must be non-decreasing");
+        max_pts = std::max(max_pts, (size_t)(pts_begin[i + 1] - pts_begin[i]));
+    }
+    for (size_t r = 0; r < max_pts; r++) {
+        std::vector<uint32_t> off, ridx;
+        std::vector<Fp4> zs;
+        for (size_t i = 0; i < n_combos; i++) {
+            if (pts_begin[i] + r >= pts_begin[i + 1]) continue;
+            off.push_back((uint32_t)(4 * i * cycles));
+            ridx.push_back((uint32_t)(pts_begin[i] + r));
+            zs.push_back(to_fp4(pts + 4 * (pts_begin[i] + r)));
+        }
+        ZKH_TRY(divide_round(c, combos, cycles, off.size(), off.data(), zs.data(), ridx.data(), rem_out));
+    }
     return nullptr;
 }
 

@@ -442,23 +442,20 @@ static const char* prove_finish_impl(zkh_seal_job* job, const zkh_buf* accum_tra
         for (auto& kv : sub) { pos.push_back(kv.first); vals.push_back(kv.second); }
         ZKH_TRY(zkh_combos_prepare(c, combos, pos.data(), (const uint32_t*)vals.data(), pos.size()));
     }
-    // combos_divide: by prod (x - z w^-back) per combo, the check combo by (x - z^4); remainders must vanish
+    // combos_divide: by prod (x - z w^-back) per combo, the check combo by (x - z^4); remainders must vanish.  One call:
+    // the r-th divisions of all combos share their launches.
     {
-        size_t n_div = 1;
-        for (auto& cb : cir->combos) n_div += cb.size();
-        Buf rems;
-        ZKH_TRY(zkh_alloc(c, "rems", 4 * n_div, 1, rems.out()));
-        size_t used = 0;
+        std::vector<Fp4> pts;
+        std::vector<uint32_t> begin(1, 0);
         for (size_t i = 0; i <= combo_count; i++) {
-            std::vector<Fp4> pts;
             if (i == combo_count) pts.push_back(z_pow);
             else for (uint32_t b : cir->combos[i]) pts.push_back(z * fp_pow(back_one, b));
-            Buf rslice;
-            ZKH_TRY(zkh_slice(rems, 4 * used, 4 * pts.size(), rslice.out()));
-            ZKH_TRY(zkh_combos_divide(c, combos, i, n, (const uint32_t*)pts.data(), pts.size(), rslice));
-            used += pts.size();
+            begin.push_back((uint32_t)pts.size());
         }
-        std::vector<uint32_t> r(4 * n_div);
+        Buf rems;
+        ZKH_TRY(zkh_alloc(c, "rems", 4 * pts.size(), 1, rems.out()));
+        ZKH_TRY(zkh_combos_divide_all(c, combos, n, combo_count + 1, (const uint32_t*)pts.data(), begin.data(), rems));
+        std::vector<uint32_t> r(4 * pts.size());
         ZKH_TRY(zkh_read(c, rems, r.data(), 0, r.size()));
         for (uint32_t w : r) ZKH_REQUIRE(w == 0, "prove_segment: DEEP quotient has a non-zero remainder (witness does not satisfy the constraints)");
     }

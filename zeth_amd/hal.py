@@ -77,6 +77,7 @@ ABI = {
     "zkh_mix_poly_coeffs": (_err, [_vp, _vp, _u32p, _u32p, _vp, _vp, _sz, _sz]),
     "zkh_combos_prepare": (_err, [_vp, _vp, _u32p, _u32p, _sz]),
     "zkh_combos_divide": (_err, [_vp, _vp, _sz, _sz, _u32p, _sz, _vp]),
+    "zkh_combos_divide_all": (_err, [_vp, _vp, _sz, _sz, _u32p, _u32p, _vp]),
     "zkh_eltwise_add_elem": (_err, [_vp, _vp, _vp, _vp]),
     "zkh_eltwise_copy_elem": (_err, [_vp, _vp, _vp]),
     "zkh_eltwise_zeroize_elem": (_err, [_vp, _vp]),
@@ -394,6 +395,10 @@ class HipHal:
     def combos_divide(self, combos: Buffer, combo: int, cycles: int, pts_ext, rem_out: Buffer) -> None:
         p = _u32(pts_ext).reshape(-1)
         _check(_lib.zkh_combos_divide(self.ctx, combos.h, combo, cycles, _ptr(p), p.size // 4, rem_out.h))
+
+    def combos_divide_all(self, combos: Buffer, cycles: int, pts_ext, pts_begin, rem_out: Buffer) -> None:
+        p, b = _u32(pts_ext).reshape(-1), _u32(pts_begin)
+        _check(_lib.zkh_combos_divide_all(self.ctx, combos.h, cycles, b.size - 1, _ptr(p), _ptr(b), rem_out.h))
 
     def eltwise_add_elem(self, out: Buffer, a: Buffer, b: Buffer) -> None:
         _check(_lib.zkh_eltwise_add_elem(self.ctx, out.h, a.h, b.h))
