@@ -235,6 +235,17 @@ const char* zkh_verify_segment(const zkh_circuit*, const uint32_t* seal, size_t 
 const char* zkh_receipt_claim(const zkh_circuit*, const uint32_t* seal, size_t seal_words, const uint32_t control_root[8],
                               const uint32_t* rc, const uint32_t* diag, uint32_t claim[8]);
 
+/* Receipt container: a versioned little-endian word envelope around a seal carrying what upstream's SegmentReceipt does
+ * (circuit hash, po2, hash function, segment index, control root, claim digest, seal, checksum; layout: csrc/verifier.hip).
+ * Stands in for the bincode `SegmentReceipt` inside `ProveInfo` (risc0-zkvm 3.0.3, decoded by zeth at
+ * /root/reference/crates/host/src/lib.rs:137).  Host only.  *blob is malloc'd: release with zkh_free_seal. */
+const char* zkh_receipt_encode(const zkh_circuit*, const uint32_t* seal, size_t seal_words, uint32_t segment_index,
+                               const uint32_t control_root[8], uint32_t** blob, size_t* blob_words);
+/* Parse + integrity-check (checksum, version, hash-suite, and with a circuit: desc hash, output size, po2, claim digest).
+ * info receives header words [0, 26); the seal sits at blob + *seal_offset (info[9] words).  Does NOT verify the seal. */
+const char* zkh_receipt_decode(const zkh_circuit*, const uint32_t* blob, size_t blob_words, uint32_t info[26],
+                               size_t* seal_offset);
+
 /* ---- profiling: per-kernel HIP-event timing on the ctx stream ---- */
 const char* zkh_prof_enable(zkh_ctx*, int on);
 /* writes up to cap records; returns count via *n.  Each record: name (<=47 chars), calls, total_ms */

@@ -247,3 +247,26 @@ def test_multi_part_jit_cross_compiles_with_verified_cache(tmp_path, monkeypatch
     import json
     man = json.load(open(out / "manifest.json"))
     assert man["arch"] == "gfx950" and len(man["parts"]) == 1 and (out / man["parts"][0]["file"]).exists()
+
+
+def test_cached_input_reader_feeds_the_segment_list(tmp_path):
+    """cli.rs:126-131 keeps `cache/input_<hash>.json`; the reader validates the shape and turns the block into a segment
+    list: from a measured cycle count when a dev-mode run left one, from the declared gas heuristic otherwise."""
+    import json
+    from zeth_amd.host import CYCLES_PER_GAS_ESTIMATE, list_cached_inputs, read_cached_input
+    h1, h2 = "0x" + "ab" * 32, "0x" + "cd" * 32
+    (tmp_path / f"input_{h1}.json").write_text(json.dumps({"block": {"header": {"gasUsed": hex(29_500_000)}, "body": {}}, "witness": {"state": []}}))
+    (tmp_path / f"input_{h2}.json").write_text(json.dumps({"block": {"header": {"gasUsed": "0x1c9c380"}}, "witness": {}}))
+    (tmp_path / f"input_{h2}.cycles.json").write_text(json.dumps({"total_cycles": 5 * (1 << 20) + 70000, "user_cycles": 5_000_000,
+                                                                 "paging_cycles": 300_000, "keccak_calls": 1234}))
+    (tmp_path / "input_0xbad.json").write_text(json.dumps([1, 2, 3]))
+    assert list_cached_inputs(str(tmp_path)) == sorted([h1, h2, "0xbad"])
+    a = read_cached_input(str(tmp_path), h1)
+    assert a.cycles_source == "gas-estimate" and a.total_cycles == int(29_500_000 * CYCLES_PER_GAS_ESTIMATE) and a.gas_used == 29_500_000
+    segs = a.segments(20)
+    assert len(segs) == -(-a.total_cycles // (1 << 20)) and all(s.po2 == 20 for s in segs[:-1])
+    b = read_cached_input(str(tmp_path), h2)
+    assert b.cycles_source == "sidecar" and b.keccak_calls == 1234
+    assert [s.po2 for s in b.segments(20)] == [20] * 5 + [17]
+    with pytest.raises(ValueError, match="StatelessInput"):
+        read_cached_input(str(tmp_path), "0xbad")

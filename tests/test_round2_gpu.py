@@ -453,34 +453,3 @@ def test_combos_divide_all_matches_sequential_division(hal, oracle):
     hal.combos_divide_all(dev, cycles, pts, begin, rem_out)
     assert np.array_equal(dev.to_vec(), want)
     assert np.array_equal(rem_out.to_vec(), want_rem)
-
-
-def test_wide_tile_forward_ntt_pass_matches_oracle():
-    """ZKH_NTT_WIDE=1 switches the forward 2^10-row strided pass to 128-byte runs (k_ntt_high10_wide); the switch is read
-    once per process, so the check runs in a child: expand-NTT 2^20 -> 2^22 (lazy) and a plain 2^22 transform vs the oracle."""
-    import subprocess
-    import sys
-    code = r"""
-import sys, numpy as np
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-import zko
-from zeth_amd.hal import HipHal
-lib, hal = zko.load(), HipHal(0)
-rng = np.random.default_rng(5)
-P = 2013265921
-for count, lin, bits in ((3, 20, 2), (2, 22, 0), (2, 18, 4)):
-    src = rng.integers(0, P, size=count << lin, dtype=np.uint64).astype(np.uint32)
-    want = np.zeros(count << (lin + bits), np.uint32)
-    lib.zko_batch_expand_into_evaluate_ntt(want, want.size, src, src.size, count, bits)
-    out = hal.alloc_elem("o", want.size)
-    hal.prof_reset(); hal.prof_enable(True)
-    hal.batch_expand_into_evaluate_ntt(out, hal.copy_from("i", src), count, bits)
-    names = [r["name"] for r in hal.prof_get()]
-    hal.prof_enable(False)
-    assert any(n.endswith("k_ntt_high10_wide") for n in names), names
-    assert np.array_equal(out.to_vec(), want), (count, lin, bits)
-print("wide ok")
-""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ZKH_NTT_WIDE="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "wide ok" in r.stdout, r.stdout + r.stderr

@@ -106,9 +106,10 @@ def test_profiling_records(hal):
     hal.prof_enable(False)
     # NTT records are per pass, "<Hal op>:<kernel>"; 2^16 = two generic LDS passes.  The §8d algorithmic bytes of the op
     # (operands once in, once out: 8 n) are charged once, to the first pass
-    assert recs["batch_interpolate_ntt:k_ntt_pass"]["calls"] == 2
+    ntt = [r for n, r in recs.items() if n.startswith("batch_interpolate_ntt:")]
+    assert sum(r["calls"] for r in ntt) == 2
     assert recs["batch_bit_reverse"]["calls"] == 1 and recs["batch_bit_reverse"]["total_ms"] > 0
-    assert recs["batch_interpolate_ntt:k_ntt_pass"]["alg_bytes"] == 8.0 * (1 << 16)
+    assert sum(r["alg_bytes"] for r in ntt) == 8.0 * (1 << 16)
 
 
 def test_size_limits(hal):

@@ -79,3 +79,39 @@ def test_custom_poseidon2_tables(oracle):
         txt = open(os.path.join(os.path.dirname(__file__), "..", "include", "zkh_poseidon2_consts.h")).read()
         nums = [int(x, 16) for x in re.findall(r"0x([0-9a-f]{8})u", txt)]
         oracle.zko_poseidon2_set_constants(np.array(nums[24:], np.uint32), np.array(nums[:24], np.uint32))
+
+
+def test_receipt_container_roundtrip_and_integrity(oracle):
+    """The versioned word container around a seal (zkh_receipt_encode / zkh_receipt_decode): round trip, then every kind of
+    damage is refused — flipped payload, truncated blob, wrong circuit, tampered envelope fields."""
+    from zeth_amd.prover import SegmentReceipt
+    desc = syn_air.syn_tiny()
+    oc = zko.OracleCircuit(oracle, desc)
+    seal, root = oc.prove(10, 300), oc.control_root(10, 300)
+    rec = SegmentReceipt(seal=seal, index=7, po2=10, output=seal[:4].copy())
+    blob = rec.to_words(desc, root)
+    assert blob[0] == 0x31524B5A and blob.size == seal.size + 28
+    back = SegmentReceipt.from_words(desc, blob)
+    assert back.index == 7 and back.po2 == 10 and np.array_equal(back.seal, seal) and np.array_equal(back.control_root, root)
+    back.verify(desc, root)
+    hc = HostCircuit(desc)
+    hdr, _ = hc.receipt_decode(blob)
+    assert np.array_equal(hdr["claim"], hc.receipt_claim(seal, root)) and hdr["placeholder_tables"]
+    for pos in (0, 4, 9, 12, 20, 26, 500, blob.size - 1):
+        bad = blob.copy()
+        bad[pos] ^= 1
+        with pytest.raises(HalError, match="receipt_decode"):
+            hc.receipt_decode(bad)
+    with pytest.raises(HalError, match="receipt_decode"):
+        hc.receipt_decode(blob[:-3])
+    with pytest.raises(HalError, match="another circuit"):
+        HostCircuit(syn_air.syn_small()).receipt_decode(blob)
+    # an envelope that lies about the control root is caught by the claim digest even when its checksum is recomputed
+    forged = blob.copy()
+    forged[10] ^= 1
+    h = 0xCBF29CE484222325
+    for b in forged[:-2].astype("<u4").tobytes():
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    forged[-2], forged[-1] = h & 0xFFFFFFFF, h >> 32
+    with pytest.raises(HalError, match="claim digest"):
+        hc.receipt_decode(forged)

@@ -41,7 +41,7 @@ from .desc import (OP_ADD, OP_AND_COND, OP_AND_EQZ, OP_CONST, OP_CONST_EXT, OP_G
                    OP_TRUE, Circuit, P)
 
 R2 = pow(2, 64, P)
-REG_BUDGET = int(os.environ.get("ZKH_CODEGEN_REGS", "72"))      # values (taps + intermediates) the register cache of a kernel holds
+REG_BUDGET = int(os.environ.get("ZKH_CODEGEN_REGS", "96"))      # values (taps + intermediates) the register cache of a kernel holds
 EPOCH_LOADS = int(os.environ.get("ZKH_CODEGEN_EPOCH", "48"))    # tap loads per offset epoch
 PART_WEIGHT = int(os.environ.get("ZKH_CODEGEN_PART", "3200"))   # value steps per generated kernel (~ one translation unit / code object)
 GENERATOR_VERSION = 3

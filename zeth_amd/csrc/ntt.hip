@@ -474,76 +474,6 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
     }
 }
 
-// Forward strided pass over 2^10 rows with 32-word (128-byte) runs: the 16-word tile above moves half cache lines and
-// relies on the L2 to pair them up; here every global access is a full line.  Tile = 2^10 x 32 words = 128 KiB of the
-// CU's 160 KiB LDS, 1024 lanes, each lane owning column t = tid & 31 of TWO row groups (g, g + 32) per radix round.
-// Same arithmetic as k_ntt_high<10, false, LAZY> (identical results), different data movement.
-template <bool LAZY>
-__global__ __launch_bounds__(1024) void k_ntt_high10_wide(PassParams p) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];     // [2^10][32]
-    const uint32_t tid = threadIdx.x, t = tid & 31, g0 = tid >> 5;     // g0 < 32
-    const uint32_t tile_id = xcd_remap(blockIdx.x, p.tiles_per_col);
-    const uint32_t lt_bits = p.L - 5;
-    const uint32_t a = tile_id >> lt_bits, lt = tile_id & ((1u << lt_bits) - 1);
-    const size_t base = ((size_t)a << (p.L + 10)) + ((size_t)lt << 5) + t;
-    const uint32_t lcol = (lt << 5) + t;
-    const uint32_t tw_shift = MAX_LOG_N - (p.L + 10);
-    const uint32_t* in = p.in + (size_t)blockIdx.y * p.in_col_stride;
-    uint32_t* out = p.out + (size_t)blockIdx.y * p.out_col_stride;
-    const uint32_t* __restrict__ ltab = p.layer_tw;
-    auto root = [&](uint32_t e) -> uint32_t {                  // w_{L+10}^e
-        const uint32_t ex = e << tw_shift;
-        return mul_mod(p.tw_lo[ex & (TW_SIZE - 1)], p.tw_hi[ex >> TW_BITS]);
-    };
-    const uint32_t u1 = root(lcol * 64u), v1 = root(lcol * 256u);
-    const uint32_t u2 = mul_mod(u1, u1), u3 = mul_mod(u2, u1), v2 = mul_mod(v1, v1), v3 = mul_mod(v2, v1);
-    // round 1: rows m = (g*4 + i)*4 + k, g in {g0, g0 + 32}: pre-twiddle + radix-4
-#pragma unroll 1
-    for (uint32_t half = 0; half < 2; half++) {
-        const uint32_t g = g0 + 32 * half;
-        uint32_t w0 = root(lcol * (__brev(g) >> 26));          // bitrev10(m) = br2(k)*256 + br2(i)*64 + br6(g)
-        if (LAZY) w0 = mul_mod(w0, p.lazy_comp);
-        const uint32_t wi[4] = {w0, mul_mod(w0, u2), mul_mod(w0, u1), mul_mod(w0, u3)};
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t tw[4] = {wi[i], mul_mod(wi[i], v2), mul_mod(wi[i], v1), mul_mod(wi[i], v3)};
-            uint32_t u[4];
-            const uint32_t m0 = (g * 4 + i) * 4;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t x = in[base + ((size_t)(m0 + k) << p.L)];
-                u[k] = LAZY ? (uint32_t)smont((int32_t)x, (int32_t)tw[k]) : mul_mod(x, tw[k]);
-            }
-            radix_layers<2, false, true, 1, LAZY>(u, ltab, 0, 0);
-#pragma unroll
-            for (int k = 0; k < 4; k++) lds[(m0 + k) * 32 + t] = u[k];
-        }
-    }
-    __syncthreads();
-    uint32_t v[16];
-    // round 2: rows hi*64 + k*4 + low (sub-layers 3..6)
-#pragma unroll 1
-    for (uint32_t half = 0; half < 2; half++) {
-        const uint32_t g = g0 + 32 * half, hi = g >> 2, low = g & 3;
-#pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = lds[(hi * 64 + k * 4 + low) * 32 + t];
-        radix_layers<4, false, false, 3, LAZY>(v, ltab, low, 0);
-#pragma unroll
-        for (int k = 0; k < 16; k++) lds[(hi * 64 + k * 4 + low) * 32 + t] = v[k];
-    }
-    __syncthreads();
-    // round 3: rows k*64 + g (sub-layers 7..10), straight to HBM
-#pragma unroll 1
-    for (uint32_t half = 0; half < 2; half++) {
-        const uint32_t g = g0 + 32 * half;
-#pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = lds[(k * 64 + g) * 32 + t];
-        radix_layers<4, false, false, 7, LAZY>(v, ltab, g, 0);
-#pragma unroll
-        for (int k = 0; k < 16; k++) out[base + ((size_t)(k * 64 + g) << p.L)] = LAZY ? canon((int32_t)v[k]) : v[k];
-    }
-}
-
 struct Pass { uint32_t L, R; };
 // Cut log_n index bits into HBM passes of <= 12 bits.  The lowest pass works on contiguous runs (cheapest), the
 // strided passes above it are kept <= 10 bits so a 2^R x 16-word tile stays <= 64 KiB.
@@ -579,7 +509,6 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
     // forward transforms whose two passes are both register-radix kernels (2^20 and 2^22: what po2-18/20 seals
     // expand into) run the lazy signed butterflies; the constant R^(layers run) rides on the four-step twiddle
     static const bool no_lazy = getenv("ZKH_NTT_NO_LAZY") != nullptr;     // A/B switch for debugging
-    static const bool wide10 = getenv("ZKH_NTT_WIDE") != nullptr;         // A/B switch: 128-byte runs in the forward 2^10-row pass
     const bool lazy = !no_lazy && !inverse && npass == 2 && passes[0].R == 12 && (passes[1].R == 8 || passes[1].R == 10) && expand_bits <= 4;
     const uint32_t lazy_comp = lazy ? fp_pow(Fp::raw(R2), 12 - expand_bits + passes[1].R).v : 0;
     for (size_t pi = 0; pi < npass; pi++) {
@@ -625,19 +554,12 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
         const bool k_low = ps.L == 0 && ps.R == 12 && p.expand_bits <= 4;
         const bool k_h10 = !k_low && ps.L >= 4 && p.log_t == 4 && ps.R == 10 && !(scale_here && p.zk_shift);
         const bool k_h8 = !k_low && !k_h10 && ps.L >= 4 && p.log_t == 4 && ps.R == 8 && !(scale_here && p.zk_shift);
-        const bool k_w10 = k_h10 && !inverse && wide10 && ps.L >= 5;
-        const std::string pname = std::string(name) + (k_low ? ":k_ntt_low12" : k_w10 ? ":k_ntt_high10_wide" : k_h10 ? ":k_ntt_high10" : k_h8 ? ":k_ntt_high8" : ":k_ntt_pass");
+        const std::string pname = std::string(name) + (k_low ? ":k_ntt_low12" : k_h10 ? ":k_ntt_high10" : k_h8 ? ":k_ntt_high8" : ":k_ntt_pass");
         ProfScope prof(c, pname.c_str(), alg_bytes);
         if (ps.L == 0 && ps.R == 12 && p.expand_bits <= 4) {
             if (inverse) k_ntt_low12<true><<<grid, 256, 0, c->stream>>>(p);
             else if (lazy) k_ntt_low12<false, true><<<grid, 256, 0, c->stream>>>(p);
             else k_ntt_low12<false><<<grid, 256, 0, c->stream>>>(p);
-        } else if (!inverse && wide10 && ps.L >= 5 && p.log_t == 4 && ps.R == 10) {
-            p.log_t = 5;
-            p.tiles_per_col = (uint32_t)(n >> 15);
-            dim3 wgrid(p.tiles_per_col, (unsigned)count);
-            if (lazy) k_ntt_high10_wide<true><<<wgrid, 1024, 128 * 1024, c->stream>>>(p);
-            else k_ntt_high10_wide<false><<<wgrid, 1024, 128 * 1024, c->stream>>>(p);
         } else if (ps.L >= 4 && p.log_t == 4 && ps.R == 10 && !(scale_here && p.zk_shift)) {
             if (inverse) k_ntt_high<10, true><<<grid, 1024, lds, c->stream>>>(p);
             else if (lazy) k_ntt_high<10, false, true><<<grid, 1024, lds, c->stream>>>(p);
@@ -662,8 +584,6 @@ const char* zkh::ntt_device_init(zkh_ctx* c) {
     ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high<10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high<10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high<10, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high10_wide<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high10_wide<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     return nullptr;
 }
 

@@ -35,34 +35,35 @@ __global__ void k_ext_powers(uint32_t* out, Fp4 start, Fp4 base, uint32_t n) {
 //
 // A real tap set evaluates the same column at several points (taps at backs 0..4 of one register): consecutive entries
 // with the same which[] form a run, and ONE block streams the column once for up to EV_MAXP points of the run (the other
-// blocks of the run exit at once), so DEEP evaluation reads W x n words instead of #taps x n.
+// blocks of the run exit at once), so DEEP evaluation reads W x n words instead of #taps x n.  (EV_MAXP is a register
+// budget: 8 accumulating points need 256 VGPRs = one wave per SIMD, which costs more bandwidth than the re-reads save.)
 // ---------------------------------------------------------------------------------------------------------
-constexpr int EV_PER = 64, EV_CH = TB * EV_PER, EV_MAXP = 8, EV_SCAN = 256;
+constexpr int EV_PER = 64, EV_CH = TB * EV_PER, EV_MAXP = 5, EV_SCAN = 256;   // 5 = the longest back-set of a register (backs 0..4)
 
 template <int NP>
 __device__ __forceinline__ void ev_accumulate(Fp4 (&acc)[EV_MAXP], const uint32_t* __restrict__ c, size_t j0, size_t po,
                                               uint4 (*xp)[EV_PER]) {
     // Fp x Fp4 multiply-accumulate, lazily: four products per 64-bit accumulator (4 P^2 < 2 P 2^32), then ONE reduction
-    // and one modular add per component instead of four of each.  The coefficient is loaded once for all NP points.
-#pragma unroll 2
+    // and one modular add per component instead of four of each.  Four coefficients are loaded once and then used for all
+    // NP points, one point at a time (only one point's 64-bit accumulators are live: the register budget stays small).
     for (int i = 0; i < EV_PER; i += 4) {
-        uint64_t a[NP][4];
-#pragma unroll
-        for (int p = 0; p < NP; p++) a[p][0] = a[p][1] = a[p][2] = a[p][3] = 0;
+        uint64_t cj[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const size_t j = j0 + (size_t)(i + u) * TB;
-            const uint64_t cj = j < po ? c[j] : 0u;
-#pragma unroll
-            for (int p = 0; p < NP; p++) {
-                const uint4 pw = xp[p][i + u];
-                a[p][0] += cj * pw.x; a[p][1] += cj * pw.y; a[p][2] += cj * pw.z; a[p][3] += cj * pw.w;
-            }
+            cj[u] = j < po ? c[j] : 0u;
         }
 #pragma unroll
-        for (int p = 0; p < NP; p++)
+        for (int p = 0; p < NP; p++) {
+            uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) acc[p].c[q] = Fp::raw(add_mod(acc[p].c[q].v, mont_reduce_wide(a[p][q])));
+            for (int u = 0; u < 4; u++) {
+                const uint4 pw = xp[p][i + u];
+                a0 += cj[u] * pw.x; a1 += cj[u] * pw.y; a2 += cj[u] * pw.z; a3 += cj[u] * pw.w;
+            }
+            acc[p].c[0] = Fp::raw(add_mod(acc[p].c[0].v, mont_reduce_wide(a0))); acc[p].c[1] = Fp::raw(add_mod(acc[p].c[1].v, mont_reduce_wide(a1)));
+            acc[p].c[2] = Fp::raw(add_mod(acc[p].c[2].v, mont_reduce_wide(a2))); acc[p].c[3] = Fp::raw(add_mod(acc[p].c[3].v, mont_reduce_wide(a3)));
+        }
     }
 }
 
@@ -127,10 +128,7 @@ __global__ __launch_bounds__(TB) void k_eval_partial(uint32_t* __restrict__ part
     case 2: ev_accumulate<2>(acc, c, j0, po, xp); break;
     case 3: ev_accumulate<3>(acc, c, j0, po, xp); break;
     case 4: ev_accumulate<4>(acc, c, j0, po, xp); break;
-    case 5: ev_accumulate<5>(acc, c, j0, po, xp); break;
-    case 6: ev_accumulate<6>(acc, c, j0, po, xp); break;
-    case 7: ev_accumulate<7>(acc, c, j0, po, xp); break;
-    default: ev_accumulate<8>(acc, c, j0, po, xp); break;
+    default: ev_accumulate<5>(acc, c, j0, po, xp); break;
     }
     // ---- per point: lane total * x^t, block reduction, * x^(chunk*CH) ----
 #pragma unroll

@@ -332,3 +332,74 @@ extern "C" const char* zkh_verify_segment(const zkh_circuit* c, const uint32_t* 
 #undef VFAIL
     return nullptr;
 }
+
+// =====================================================================================================
+// Receipt container — a versioned, self-describing envelope around a seal (row f3 groundwork).
+// Upstream ships `SegmentReceipt{seal, index, hashfn, claim, verifier_parameters}` bincode-encoded inside `ProveInfo`
+// (risc0-zkvm 3.0.3 src/receipt/segment.rs, un-vendored: /root/reference/Cargo.lock:5418; decoded by zeth at
+// /root/reference/crates/host/src/lib.rs:137, verified at cli.rs:103).  That exact encoding needs the Rust types; this
+// container carries the same fields in plain little-endian u32 words so that any host can store, ship and check a seal:
+//   [0] 'ZKR1'  [1] version  [2..4) circuit desc hash  [4] po2  [5] hashfn (1 = poseidon2)  [6] flags (bit 0: placeholder
+//   Poseidon2 tables)  [7] segment index  [8] OUTPUT_SIZE  [9] seal words  [10..18) control root  [18..26) claim digest
+//   [26 ..) seal words  [last 2] FNV-1a 64 of everything before.
+// =====================================================================================================
+namespace {
+constexpr uint32_t RECEIPT_MAGIC = 0x31524b5au;   // "ZKR1"
+constexpr size_t RECEIPT_HEADER = 26;
+}  // namespace
+
+extern "C" const char* zkh_receipt_encode(const zkh_circuit* c, const uint32_t* seal, size_t seal_words, uint32_t segment_index,
+                                          const uint32_t* control_root, uint32_t** blob, size_t* blob_words) {
+    ZKH_REQUIRE(c && seal && control_root && blob && blob_words, "receipt_encode: null argument");
+    const size_t out_size = c->global_size[GLOBAL_OUT];
+    ZKH_REQUIRE(seal_words > out_size && seal_words < ((size_t)1 << 31), "receipt_encode: implausible seal length %zu", seal_words);
+    const uint32_t po2_elem = seal[out_size];
+    ZKH_REQUIRE(po2_elem < P, "receipt_encode: seal header holds an unreduced po2");
+    std::vector<uint32_t> w(RECEIPT_HEADER + seal_words + 2);
+    w[0] = RECEIPT_MAGIC; w[1] = 1;
+    w[2] = (uint32_t)c->hash; w[3] = (uint32_t)(c->hash >> 32);
+    w[4] = fp_decode(Fp::raw(po2_elem)); w[5] = 1; w[6] = ZKH_P2_CONSTS_ARE_PLACEHOLDER ? 1u : 0u;
+    w[7] = segment_index; w[8] = (uint32_t)out_size; w[9] = (uint32_t)seal_words;
+    memcpy(&w[10], control_root, 32);
+    ZKH_TRY(zkh_receipt_claim(c, seal, seal_words, control_root, nullptr, nullptr, &w[18]));
+    memcpy(&w[RECEIPT_HEADER], seal, 4 * seal_words);
+    const uint64_t h = desc_hash64(w.data(), RECEIPT_HEADER + seal_words);
+    w[RECEIPT_HEADER + seal_words] = (uint32_t)h; w[RECEIPT_HEADER + seal_words + 1] = (uint32_t)(h >> 32);
+    *blob = (uint32_t*)malloc(w.size() * 4);
+    ZKH_REQUIRE(*blob, "receipt_encode: out of memory");
+    memcpy(*blob, w.data(), w.size() * 4);
+    *blob_words = w.size();
+    return nullptr;
+}
+
+// Parses and integrity-checks a container: on success `info` holds words [0, 26) of the header and *seal_offset the word
+// offset of the seal inside the blob.  With a circuit, the desc hash, OUTPUT_SIZE and the claim digest are checked too.
+// This does NOT verify the seal: pass blob + *seal_offset, info[9] and info + 10 (the control root THE VERIFIER expects, not
+// blindly the one in the envelope) to zkh_verify_segment.
+extern "C" const char* zkh_receipt_decode(const zkh_circuit* c, const uint32_t* blob, size_t blob_words, uint32_t info[26],
+                                          size_t* seal_offset) {
+    ZKH_REQUIRE(blob && info && seal_offset, "receipt_decode: null argument");
+    ZKH_REQUIRE(blob_words >= RECEIPT_HEADER + 2 && blob[0] == RECEIPT_MAGIC, "receipt_decode: not a receipt container");
+    ZKH_REQUIRE(blob[1] == 1, "receipt_decode: unsupported container version %u", blob[1]);
+    const size_t seal_words = blob[9];
+    ZKH_REQUIRE(blob_words == RECEIPT_HEADER + seal_words + 2, "receipt_decode: container is %zu words, header says %zu", blob_words,
+                RECEIPT_HEADER + seal_words + 2);
+    const uint64_t h = desc_hash64(blob, RECEIPT_HEADER + seal_words);
+    ZKH_REQUIRE(blob[blob_words - 2] == (uint32_t)h && blob[blob_words - 1] == (uint32_t)(h >> 32), "receipt_decode: checksum mismatch (corrupted container)");
+    ZKH_REQUIRE(blob[5] == 1, "receipt_decode: unknown hash function id %u", blob[5]);
+    ZKH_REQUIRE((blob[6] & 1u) == (ZKH_P2_CONSTS_ARE_PLACEHOLDER ? 1u : 0u),
+                "receipt_decode: the receipt was sealed with %s Poseidon2 tables, this library has the other set",
+                (blob[6] & 1u) ? "placeholder" : "upstream");
+    if (c) {
+        ZKH_REQUIRE(blob[2] == (uint32_t)c->hash && blob[3] == (uint32_t)(c->hash >> 32), "receipt_decode: receipt belongs to another circuit");
+        ZKH_REQUIRE(blob[8] == c->global_size[GLOBAL_OUT] && seal_words > blob[8], "receipt_decode: output size mismatch");
+        ZKH_REQUIRE(blob[RECEIPT_HEADER + blob[8]] < P && fp_decode(Fp::raw(blob[RECEIPT_HEADER + blob[8]])) == blob[4],
+                    "receipt_decode: header po2 does not match the seal");
+        uint32_t claim[8];
+        ZKH_TRY(zkh_receipt_claim(c, blob + RECEIPT_HEADER, seal_words, blob + 10, nullptr, nullptr, claim));
+        ZKH_REQUIRE(memcmp(claim, blob + 18, 32) == 0, "receipt_decode: claim digest does not match the seal header");
+    }
+    memcpy(info, blob, 4 * RECEIPT_HEADER);
+    *seal_offset = RECEIPT_HEADER;
+    return nullptr;
+}

@@ -108,6 +108,8 @@ ABI = {
     "zkh_syn_control_root": (_err, [_vp, _sz, _sz, _u32p]),
     "zkh_verify_segment": (_err, [_vp, _u32p, _sz, _u32p, _u32p, _u32p]),
     "zkh_receipt_claim": (_err, [_vp, _u32p, _sz, _u32p, _u32p, _u32p, _u32p]),
+    "zkh_receipt_encode": (_err, [_vp, _u32p, _sz, _u32, _u32p, C.POINTER(_u32p), C.POINTER(_sz)]),
+    "zkh_receipt_decode": (_err, [_vp, _u32p, _sz, _u32p, C.POINTER(_sz)]),
     "zkh_prof_enable": (_err, [_vp, _i]),
     "zkh_prof_get": (_err, [_vp, C.POINTER(ProfRec), _sz, C.POINTER(_sz)]),
     "zkh_prof_reset": (_err, [_vp]),
@@ -259,6 +261,26 @@ class HostCircuit:
         d = _ptr(_u32(diag)) if diag is not None else None
         _check(_lib.zkh_verify_segment(self.h, _ptr(s), s.size, _ptr(cr) if cr is not None else None, r, d))
 
+
+    def receipt_encode(self, seal, segment_index: int, control_root) -> np.ndarray:
+        """Seal -> receipt container words (zkh_receipt_encode)."""
+        s, cr = _u32(seal), _u32(control_root)
+        blob, n = _u32p(), _sz()
+        _check(_lib.zkh_receipt_encode(self.h, _ptr(s), s.size, segment_index, _ptr(cr), C.byref(blob), C.byref(n)))
+        out = np.ctypeslib.as_array(blob, shape=(n.value,)).copy()
+        _lib.zkh_free_seal(blob)
+        return out
+
+    def receipt_decode(self, blob):
+        """Container words -> (header dict, seal words); raises HalError on any integrity failure."""
+        b = _u32(blob)
+        info = np.zeros(26, dtype=np.uint32)
+        off = _sz()
+        _check(_lib.zkh_receipt_decode(self.h, _ptr(b), b.size, _ptr(info), C.byref(off)))
+        hdr = {"version": int(info[1]), "circuit_hash": int(info[2]) | (int(info[3]) << 32), "po2": int(info[4]),
+               "hashfn": "poseidon2", "placeholder_tables": bool(info[6] & 1), "index": int(info[7]), "out_size": int(info[8]),
+               "control_root": info[10:18].copy(), "claim": info[18:26].copy()}
+        return hdr, b[off.value: off.value + int(info[9])].copy()
 
     def receipt_claim(self, seal, control_root, rc=None, diag=None) -> np.ndarray:
         """Claim digest (8 words) of a sealed segment: Poseidon2(out globals, po2, control root)."""

@@ -40,6 +40,67 @@ def session_segments(total_cycles: int, segment_po2: int = 20, base_seed: int = 
     return segs
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Cached block inputs: /root/reference/crates/host/src/bin/cli.rs:113-145 (`get_cached_input`) keeps one
+# `cache/input_<blockhash>.json` per block = serde_json of `StatelessInput{block, witness}`; run-parallel.sh:93 iterates
+# over exactly those files.  The segment count of a block comes from EXECUTING the guest on that input (the "N total
+# cycles" line run-parallel.sh:67 scrapes), which needs the rv32im executor + guest ELF (not available offline), so this
+# reader is a stub: it validates the file shape, takes the cycle count from a sidecar written by a previous dev-mode run
+# (`input_<hash>.cycles.json`: the run-parallel.sh columns) when there is one, and otherwise falls back to a declared
+# estimate from the block's gas — enough to drive `session_segments` / the block bench with realistic segment counts.
+# ---------------------------------------------------------------------------------------------------------------
+CYCLES_PER_GAS_ESTIMATE = 9.0        # declared heuristic (order of magnitude of RISC Zero's published zeth runs); replace with measured data
+
+
+@dataclass
+class CachedInput:
+    block_hash: str
+    path: str
+    input_bytes: int
+    gas_used: Optional[int]
+    total_cycles: int
+    cycles_source: str              # "sidecar" (measured by a dev-mode run) | "gas-estimate" | "size-estimate"
+    keccak_calls: Optional[int] = None
+
+    def segments(self, segment_po2: int = 20, base_seed: int = 0x5EED0000) -> List[Segment]:
+        return session_segments(self.total_cycles, segment_po2, base_seed)
+
+
+def read_cached_input(cache_dir: str, block_hash: str) -> CachedInput:
+    """`cache/input_<hash>.json` -> CachedInput (see the banner above for what is real and what is estimated)."""
+    import json
+    import os
+    path = os.path.join(cache_dir, f"input_{block_hash}.json")
+    with open(path) as fh:
+        doc = json.load(fh)
+    if not isinstance(doc, dict) or "block" not in doc or "witness" not in doc:
+        raise ValueError(f"{path}: not a StatelessInput (expected an object with `block` and `witness`)")
+    header = doc["block"].get("header", {}) if isinstance(doc["block"], dict) else {}
+    gas = header.get("gasUsed", header.get("gas_used"))
+    if isinstance(gas, str):
+        gas = int(gas, 16) if gas.startswith("0x") else int(gas)
+    size = os.path.getsize(path)
+    side = os.path.join(cache_dir, f"input_{block_hash}.cycles.json")
+    keccak = None
+    if os.path.exists(side):
+        with open(side) as fh:
+            s = json.load(fh)
+        cycles, source, keccak = int(s["total_cycles"]), "sidecar", s.get("keccak_calls")
+    elif gas:
+        cycles, source = int(gas * CYCLES_PER_GAS_ESTIMATE), "gas-estimate"
+    else:
+        cycles, source = max(1 << 20, size * 64), "size-estimate"
+    return CachedInput(block_hash, path, size, gas, cycles, source, keccak)
+
+
+def list_cached_inputs(cache_dir: str) -> List[str]:
+    """Block hashes with a cached input, the `cache/input_0x*.json` glob of run-parallel.sh:93."""
+    import glob
+    import os
+    return sorted(os.path.basename(p)[len("input_"):-len(".json")] for p in glob.glob(os.path.join(cache_dir, "input_0x*.json"))
+                  if not p.endswith(".cycles.json"))
+
+
 def _root_for(control_root, po2: int):
     """control_root argument of the verify methods: None (shipped table), one root, {po2: root} or callable(po2)."""
     if control_root is None or hasattr(control_root, "shape") or isinstance(control_root, (list, tuple)):

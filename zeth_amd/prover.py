@@ -84,6 +84,17 @@ class SegmentReceipt:
     def seal_bytes(self) -> bytes:
         return np.asarray(self.seal, dtype="<u4").tobytes()
 
+    def to_words(self, circuit_desc, control_root) -> np.ndarray:
+        """Receipt container (zkh_receipt_encode): what gets stored / shipped instead of upstream's bincode SegmentReceipt."""
+        return _hal.HostCircuit(circuit_desc).receipt_encode(self.seal, self.index, control_root)
+
+    @staticmethod
+    def from_words(circuit_desc, blob) -> "SegmentReceipt":
+        """Parse + integrity-check a container.  The control root inside is informational: `verify` takes the expected one."""
+        hdr, seal = _hal.HostCircuit(circuit_desc).receipt_decode(blob)
+        return SegmentReceipt(seal=seal, index=hdr["index"], po2=hdr["po2"], output=seal[:hdr["out_size"]].copy(),
+                              control_root=hdr["control_root"])
+
     def verify(self, circuit_desc, control_root=None) -> None:
         """`Receipt::verify` for this segment (/root/reference/crates/host/src/bin/cli.rs:103): host-side, no GPU needed.
         `control_root`: the expected code commitment; None looks it up in the shipped table (zk_cycles = ZK_CYCLES).
@@ -112,6 +123,7 @@ class SegmentProver:
         _hal._check(_hal._lib.zkh_prover_create(hal.ctx, self.circuit.h, C.byref(h)))
         self.h = h
         self._roots: Dict[Tuple[int, int], np.ndarray] = {}
+        self._group_sizes = tuple(int(x) for x in self.circuit.desc[3:6])       # (accum, code, data): desc header words
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
@@ -119,8 +131,7 @@ class SegmentProver:
             _hal._lib.zkh_prover_destroy(h)
 
     def group_sizes(self):
-        from .circuits.desc import Circuit
-        return Circuit.parse(self.circuit.desc).group_sizes
+        return self._group_sizes
 
     def out_size(self) -> int:
         return int(self.circuit.desc[7])
