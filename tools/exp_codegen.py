@@ -3,7 +3,8 @@
 length, part weight).  Every variant is generated, cross-compiled (hipcc --genco, parts in parallel), attached and timed
 at po2 20 on the SYN-A-shaped evaluated groups; results are checked against the first variant (bit-exact).
 
-    python tools/exp_codegen.py [syn_heavy|syn_a] [regs,regs,...] > gpurun_out/exp_codegen.jsonl
+    python tools/exp_codegen.py syn_heavy REGS=72 REGS=96,SOP=0 REGS=128,EPOCH=96 > gpurun_out/exp_codegen.jsonl
+(every argument after the circuit is one variant: comma-separated ZKH_CODEGEN_<KNOB>=value assignments)
 """
 import importlib
 import json
@@ -19,8 +20,8 @@ sys.path.insert(0, ROOT)
 
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "syn_heavy"
-    regs_list = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "48,72,96,128").split(",")]
-    epochs = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "48").split(",")]
+    variants = sys.argv[2:] or ["REGS=72", "REGS=96", "REGS=128"]
+    knobs = ("REGS", "EPOCH", "PART", "SOP")
     po2 = int(os.environ.get("EXP_PO2", "20"))
     from zeth_amd.circuits import codegen, jit
     from zeth_amd.hal import HipHal
@@ -59,20 +60,24 @@ def main():
     base = timed()
     ref = check.to_vec()
     print(json.dumps({"variant": "built-in", "circuit": name, "parts": circ.compiled_parts(), "ms": round(base, 3)}), flush=True)
-    for regs in regs_list:
-        for ep in epochs:
-            os.environ["ZKH_CODEGEN_REGS"], os.environ["ZKH_CODEGEN_EPOCH"] = str(regs), str(ep)
-            importlib.reload(codegen)
-            importlib.reload(jit)
-            t0 = time.perf_counter()
-            objs = jit.compile_code_objects(desc, use_cache=False)
-            t_c = time.perf_counter() - t0
-            for i, (img, kn) in enumerate(objs):
-                circ.attach_code_object(img, kn, i, len(objs))
-            ms = timed()
-            same = bool(np.array_equal(check.to_vec(), ref))
-            print(json.dumps({"variant": f"regs={regs},epoch={ep}", "circuit": name, "parts": len(objs), "compile_s": round(t_c, 1),
-                              "ms": round(ms, 3), "bit_exact_vs_builtin": same}), flush=True)
+    for var in variants:
+        for k in knobs:
+            os.environ.pop("ZKH_CODEGEN_" + k, None)
+        for kv in var.split(","):
+            k, v = kv.split("=")
+            assert k in knobs, k
+            os.environ["ZKH_CODEGEN_" + k] = v
+        importlib.reload(codegen)
+        importlib.reload(jit)
+        t0 = time.perf_counter()
+        objs = jit.compile_code_objects(desc, use_cache=False)
+        t_c = time.perf_counter() - t0
+        for i, (img, kn) in enumerate(objs):
+            circ.attach_code_object(img, kn, i, len(objs))
+        ms = timed()
+        same = bool(np.array_equal(check.to_vec(), ref))
+        print(json.dumps({"variant": var, "circuit": name, "parts": len(objs), "compile_s": round(t_c, 1),
+                          "ms": round(ms, 3), "bit_exact_vs_builtin": same}), flush=True)
 
 
 if __name__ == "__main__":

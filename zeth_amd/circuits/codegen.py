@@ -41,6 +41,8 @@ from .desc import (OP_ADD, OP_AND_COND, OP_AND_EQZ, OP_CONST, OP_CONST_EXT, OP_G
                    OP_TRUE, Circuit, P)
 
 R2 = pow(2, 64, P)
+R1 = pow(2, 32, P)           # Montgomery one
+USE_SOP = os.environ.get("ZKH_CODEGEN_SOP", "1") != "0"     # sums of products as one 64-bit chain + one reduction
 REG_BUDGET = int(os.environ.get("ZKH_CODEGEN_REGS", "96"))      # values (taps + intermediates) the register cache of a kernel holds
 EPOCH_LOADS = int(os.environ.get("ZKH_CODEGEN_EPOCH", "48"))    # tap loads per offset epoch
 PART_WEIGHT = int(os.environ.get("ZKH_CODEGEN_PART", "3200"))   # value steps per generated kernel (~ one translation unit / code object)
@@ -119,6 +121,9 @@ class Plan:
     cone_size: Dict[int, int] = field(default_factory=dict)
     n_pows: int = 1
     n_unique: int = 0                                                          # canonical value steps reachable from ret
+    sop: Dict[int, List[Tuple]] = field(default_factory=dict)                  # root value -> [(sign, 'p', a, b) | (sign, 'v', x)]
+    absorbed: set = field(default_factory=set)                                 # values that only exist inside a root's sum of products
+    n_sop_terms: int = 0
 
     @staticmethod
     def build(c: Circuit) -> "Plan":
@@ -181,7 +186,75 @@ class Plan:
             if op in (OP_ADD, OP_SUB, OP_MUL):
                 work.append(x); work.append(y)
         p.n_unique = sum(1 for v in seen if p.fp[v][0] in (OP_ADD, OP_SUB, OP_MUL))
+        if USE_SOP:
+            p.find_sums_of_products(seen, roots)
         return p
+
+    def find_sums_of_products(self, reachable, mix_roots) -> None:
+        """Lazy arithmetic: an ADD/SUB tree whose inner nodes have no other consumer is one expression
+               v = sum_i (+-) a_i * b_i  +  sum_j (+-) x_j
+        and is evaluated as a 64-bit multiply-add chain with ONE Montgomery reduction (products as they are, plain terms as
+        x * R so that they pick up the same 2^-32) instead of a full modular multiply per product and a modular add per
+        node.  Exact: the 64-bit sum is the integer sum of the terms (bounded below 2 P 2^32, the domain of
+        mont_reduce_wide; negative terms enter as (P - a) * b), so the reduced value is the same field element."""
+        uses: Dict[int, int] = {}
+        for v in reachable:
+            op, a, b, _, _ = self.fp[v]
+            if op in (OP_ADD, OP_SUB, OP_MUL):
+                uses[a] = uses.get(a, 0) + 1
+                uses[b] = uses.get(b, 0) + 1
+        for r in mix_roots:
+            uses[r] = uses.get(r, 0) + 1
+        PROD, PLAIN, LIMIT = float(P) * P, float(P) * pow(2, 32, P), 1.72e19
+
+        def is_sum(v):
+            return self.fp[v][0] in (OP_ADD, OP_SUB) and not self.ext[v]
+
+        for r in sorted(reachable, reverse=True):
+            if not is_sum(r) or r in self.absorbed:
+                continue
+            terms: List[Tuple] = []
+            inner: List[int] = []
+            stack = [(r, 1)]
+            while stack:
+                v, sg = stack.pop()
+                op, a, b, _, _ = self.fp[v]
+                for child, csg in ((b, sg if op == OP_ADD else -sg), (a, sg)):      # a is pushed last: emitted first
+                    cop = self.fp[child][0]
+                    if uses.get(child, 0) == 1 and not self.ext[child] and child not in self.absorbed:
+                        if cop in (OP_ADD, OP_SUB):
+                            inner.append(child); stack.append((child, csg)); continue
+                        if cop == OP_MUL:
+                            inner.append(child); terms.append((csg, "p", self.fp[child][1], self.fp[child][2])); continue
+                    terms.append((csg, "v", child))
+            n_prod = sum(1 for t in terms if t[1] == "p")
+            n_plain = len(terms) - n_prod
+            n_add = sum(1 for v in inner if self.fp[v][0] in (OP_ADD, OP_SUB)) + 1
+            plain_cost = 16 * n_prod + 8 * n_add
+            n_red = 1
+            acc = 0.0
+            for t in terms:                                   # reductions needed to stay inside the 64-bit bound
+                wgt = PROD if t[1] == "p" else PLAIN
+                if acc + wgt > LIMIT:
+                    n_red += 1; acc = PLAIN
+                acc += wgt
+            neg = sum(1 for t in terms if t[0] < 0 and not (t[1] == "v" and self.fp[t[2]][0] == OP_CONST)
+                      and not (t[1] == "p" and OP_CONST in (self.fp[t[2]][0], self.fp[t[3]][0])))
+            sop_cost = 4 * len(terms) + 2 * neg + 20 * n_red
+            if n_prod + n_plain >= 3 and sop_cost + 4 <= plain_cost:
+                self.sop[r] = terms
+                self.absorbed.update(inner)
+                self.n_sop_terms += len(terms)
+
+    def deps(self, v: int) -> List[int]:
+        """Values that must be available to compute v (the leaves of its sum of products, or its two operands)."""
+        if v in self.sop:
+            out = []
+            for t in self.sop[v]:
+                out.extend(t[2:] if t[1] == "p" else (t[2],))
+            return out
+        op, a, b, _, _ = self.fp[v]
+        return [a, b] if op in (OP_ADD, OP_SUB, OP_MUL) else []
 
     def chain(self, m: int) -> List[Tuple]:
         """Items of the chain ending in mix var m, in evaluation order: ('e', value, exp) | ('c', cond, inner var, exp)."""
@@ -210,9 +283,8 @@ class Plan:
                 continue
             mark.add(x)
             stack.append((x, True))
-            op, a, b, _, _ = self.fp[x]
-            if op in (OP_ADD, OP_SUB, OP_MUL):
-                stack.append((b, False)); stack.append((a, False))
+            for o in reversed(self.deps(x)):
+                stack.append((o, False))
         return out
 
     def leaf_weights(self) -> List[int]:
@@ -315,11 +387,9 @@ class _Emitter:
             missing = self.p.cone(r, self.cache)
             # operands that are already cached must survive the evictions the new definitions cause
             for x in missing:
-                op, a, b, _, _ = self.p.fp[x]
-                if op in (OP_ADD, OP_SUB, OP_MUL):
-                    for o in (a, b):
-                        if o in self.cache:
-                            self.pinned.add(o)
+                for o in self.p.deps(x):
+                    if o in self.cache:
+                        self.pinned.add(o)
             for x in missing:
                 self.define(x)
                 self.pinned.add(x)
@@ -344,11 +414,14 @@ class _Emitter:
         if op in (OP_CONST, OP_GET_GLOBAL):
             self.ref(v)
             return
-        for o in ((a, b) if op in (OP_ADD, OP_SUB, OP_MUL) else ()):
+        for o in self.p.deps(v):
             self.touch(o)
         g = self.gen.get(v, 0)
         self.gen[v] = g + 1
         self.evict_for_one()
+        if v in self.p.sop:
+            self.define_sop(v, g)
+            return
         if op == OP_GET:
             grp, off, back = self.p.c.taps[a]
             if self.epoch_loads >= EPOCH_LOADS:
@@ -376,6 +449,45 @@ class _Emitter:
             fn = {OP_ADD: "add_mod", OP_SUB: "sub_mod", OP_MUL: "mul_mod"}[op]
             self.w(f"    const uint32_t {name} = {fn}({self.ref(a)}, {self.ref(b)});")
             self.n_arith += 1
+        self.cache[v] = name
+
+    def define_sop(self, v: int, g: int) -> None:
+        """v = sum of (+-) products and (+-) plain terms: 64-bit multiply-add chain, one reduction (see Plan.find_sums_of_products)."""
+        PROD, PLAIN, LIMIT = float(P) * P, float(P) * R1, 1.72e19
+        name = f"v{v}" + (f"_{g}" if g else "")
+        const_sum = 0                                  # constant plain terms fold into the accumulator's initial value
+        dyn: List[Tuple[float, str]] = []
+        for t in self.p.sop[v]:
+            sg = t[0]
+            if t[1] == "v":
+                x = t[2]
+                if self.p.fp[x][0] == OP_CONST:
+                    c = mont(self.p.fp[x][1])
+                    const_sum += (c if sg > 0 else (P - c) % P) * R1
+                else:
+                    r = self.ref(x)
+                    dyn.append((PLAIN, f"(uint64_t){r} * {R1}u" if sg > 0 else f"(uint64_t)({P}u - {r}) * {R1}u"))
+            else:
+                a, b = t[2], t[3]
+                if self.p.fp[a][0] == OP_CONST:
+                    a, b = b, a                        # constant (if any) second
+                if self.p.fp[b][0] == OP_CONST:
+                    c = mont(self.p.fp[b][1])
+                    dyn.append((PROD, f"(uint64_t){self.ref(a)} * {c if sg > 0 else (P - c) % P}u"))
+                else:
+                    ra, rb = self.ref(a), self.ref(b)
+                    dyn.append((PROD, f"(uint64_t){ra} * {rb}" if sg > 0 else f"(uint64_t)({P}u - {ra}) * {rb}"))
+        tmp = f"u{v}" + (f"_{g}" if g else "")
+        acc = float(const_sum)
+        self.w(f"    uint64_t {tmp} = {const_sum}ull;")
+        for wgt, expr in dyn:
+            if acc + wgt > LIMIT:                       # partial reduction; the partial result re-enters as a plain term
+                self.w(f"    {tmp} = (uint64_t)mont_reduce_wide({tmp}) * {R1}u;")
+                acc = PLAIN
+            self.w(f"    {tmp} += {expr};")
+            acc += wgt
+        self.w(f"    const uint32_t {name} = mont_reduce_wide({tmp});")
+        self.n_arith += 1
         self.cache[v] = name
 
     # ---- accumulators ----
