@@ -7,6 +7,7 @@
 // `receipt.verify(image_id)` at /root/reference/crates/host/src/bin/cli.rs:103.
 //
 //   seal_segments --desc syn_a.desc [--po2 20] [--segments 8] [--devices 1] [--inflight 3] [--no-verify] [--noise-seed N]
+//                 [--receipts-dir DIR]     (writes segment_<i>.zkr: the receipt container of zkh_receipt_encode)
 //
 // The circuit description blob is what zeth_amd/circuits/desc.py serialises (`python -m zeth_amd.circuits.syn_air syn_a syn_a.desc`).
 // Witnesses are the declared-synthetic SYN-AIR traces generated on the device (zkh_syn_witgen); with the real rv32im
@@ -32,6 +33,7 @@ struct Options {
     std::string desc_path;
     size_t po2 = 20, segments = 8, devices = 1, inflight = 3;
     bool verify = true;
+    std::string receipts_dir;        // --receipts-dir: one receipt container per segment
     bool fixed_noise = false;        // --noise-seed: reproducible seals (tests); default: fresh OS randomness per segment
     uint64_t noise_seed = 0;
 };
@@ -131,6 +133,7 @@ bool parse(int argc, char** argv, Options& o) {
         else if (a == "--devices") val(o.devices);
         else if (a == "--inflight") val(o.inflight);
         else if (a == "--no-verify") o.verify = false;
+        else if (a == "--receipts-dir" && i + 1 < argc) o.receipts_dir = argv[++i];
         else if (a == "--noise-seed" && i + 1 < argc) { o.noise_seed = strtoull(argv[++i], nullptr, 0); o.fixed_noise = true; }
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return false; }
     }
@@ -142,7 +145,7 @@ bool parse(int argc, char** argv, Options& o) {
 int main(int argc, char** argv) {
     Options opt;
     if (!parse(argc, argv, opt)) {
-        fprintf(stderr, "usage: %s --desc FILE [--po2 N] [--segments S] [--devices G] [--inflight K] [--no-verify] [--noise-seed N]\n", argv[0]);
+        fprintf(stderr, "usage: %s --desc FILE [--po2 N] [--segments S] [--devices G] [--inflight K] [--no-verify] [--noise-seed N] [--receipts-dir DIR]\n", argv[0]);
         return 2;
     }
     FILE* f = fopen(opt.desc_path.c_str(), "rb");
@@ -176,6 +179,23 @@ int main(int argc, char** argv) {
             const char* err = zkh_verify_segment(host_circuit, receipts[i].seal.data(), receipts[i].seal.size(), g_control_root, nullptr, nullptr);
             if (err) { fprintf(stderr, "segment %zu: seal REJECTED: %s\n", i, err); zkh_free_error(err); return 1; }
             verified++;
+            if (!opt.receipts_dir.empty()) {
+                // the envelope a host would store or ship instead of upstream's bincode SegmentReceipt; read back and re-checked
+                uint32_t* blob = nullptr;
+                size_t words = 0, off = 0;
+                uint32_t info[26];
+                if (failed(zkh_receipt_encode(host_circuit, receipts[i].seal.data(), receipts[i].seal.size(), (uint32_t)i, g_control_root, &blob, &words),
+                           "zkh_receipt_encode") ||
+                    failed(zkh_receipt_decode(host_circuit, blob, words, info, &off), "zkh_receipt_decode")) {
+                    fprintf(stderr, "error: %s\n", g_first_error.c_str());
+                    return 1;
+                }
+                const std::string path = opt.receipts_dir + "/segment_" + std::to_string(i) + ".zkr";
+                FILE* rf = fopen(path.c_str(), "wb");
+                if (!rf || fwrite(blob, 4, words, rf) != words) { perror(path.c_str()); return 1; }
+                fclose(rf);
+                zkh_free_seal(blob);
+            }
         }
         zkh_circuit_destroy(host_circuit);
     }

@@ -147,6 +147,14 @@ def main() -> None:
             dt = timed(hal, lambda: hal.batch_evaluate_any(coeffs, w, which, xs, out), args.reps)
             line("M7", "batch_evaluate_any", f"{k} taps over {w} x 2^{args.po2}", dt, 4 * k * n)
             del which, xs, out
+            # a real tap set: every column at backs 0..4 (runs of 5 equal `which`): the column is streamed once per run
+            k5 = 5 * w
+            which = hal.copy_from("which", np.repeat(np.arange(w, dtype=np.uint32), 5))
+            xs = hal.copy_from("xs", rand_fp(rng, 4 * k5))
+            out = hal.alloc_extelem("m7o", k5)
+            dt = timed(hal, lambda: hal.batch_evaluate_any(coeffs, w, which, xs, out), args.reps)
+            line("M7t", "batch_evaluate_any, 5 taps per column", f"{k5} taps over {w} x 2^{args.po2}", dt, 4 * w * n)
+            del which, xs, out
         del coeffs
 
     if want("M8"):
@@ -163,6 +171,17 @@ def main() -> None:
         dt = timed(hal, lambda: circ.eval_check(check, groups, globals_, mix, args.po2, use_interpreter=True), 1)
         line("M8i", "eval_check (SYN-A, step-list interpreter)", f"{sum(d.group_sizes)} cols x 2^{args.po2 + 2} points",
              dt, 4 * sum(d.group_sizes) * dom + 16 * dom)
+        # the same evaluated groups under the heavy constraint system (same widths): VALU-bound generated kernels
+        from zeth_amd.circuits import syn_heavy
+        hdesc = syn_heavy.syn_heavy()
+        hd = Desc.parse(hdesc)
+        hcirc = hal.load_circuit(hdesc)
+        dt = timed(hal, lambda: hcirc.eval_check(check, groups, globals_, mix, args.po2), args.reps)
+        line("M8h", f"eval_check (SYN-HEAVY: {len(hd.steps)} steps, {len(hd.taps)} taps, {hcirc.compiled_parts()} generated kernels)",
+             f"{sum(hd.group_sizes)} cols x 2^{args.po2 + 2} points", dt, 4 * sum(hd.group_sizes) * dom + 16 * dom)
+        dt = timed(hal, lambda: hcirc.eval_check(check, groups, globals_, mix, args.po2, use_interpreter=True), 1)
+        line("M8hi", "eval_check (SYN-HEAVY, step-list interpreter)", f"{sum(hd.group_sizes)} cols x 2^{args.po2 + 2} points",
+             dt, 4 * sum(hd.group_sizes) * dom + 16 * dom)
     hal.close()
 
 

@@ -29,6 +29,7 @@ MI355X-first choices (all result-preserving — field arithmetic is exact, resul
 """
 from __future__ import annotations
 
+import bisect
 import os
 from collections import OrderedDict
 from dataclasses import dataclass, field
@@ -327,9 +328,16 @@ class _Emitter:
     re-loaded — under a fresh variable name.  Taps that a neighbourhood of constraints keeps reading therefore stay in
     registers, cold ones do not pin any, and the VGPR demand of the kernel is the budget plus a constant."""
 
-    def __init__(self, plan: Plan, lo: int, hi: int):
+    def __init__(self, plan: Plan, lo: int, hi: int, future: Optional[Dict[int, List[int]]] = None):
         self.p, self.lo, self.hi = plan, lo, hi
         self.lines: List[str] = []
+        # `future` = for every canonical value the (sorted) request numbers at which some constraint of this part needs it,
+        # recorded by a dry run over the same leaves.  With it the cache evicts the value whose next use is FARTHEST away
+        # (Belady's rule: the code is generated offline, so the future is known) instead of the least recently used one.
+        self.future = future
+        self.dry = future is None
+        self.request = 0
+        self.requests: List[int] = []       # dry run: the root of every request, in order
         self.cache: "OrderedDict[int, str]" = OrderedDict()
         self.gen: Dict[int, int] = {}       # canonical value -> how often it has been (re)defined
         self.pinned: set = set()
@@ -361,6 +369,8 @@ class _Emitter:
 
     # ---- values ----
     def ref(self, v: int) -> str:
+        if self.dry:
+            return "0"
         op, a, b, _, _ = self.p.fp[v]
         if op == OP_CONST:
             return f"{mont(a)}u"
@@ -371,6 +381,8 @@ class _Emitter:
 
     def ext_ref(self, v: int) -> str:
         """An Fp4 expression for value v (promoting Fp values)."""
+        if self.dry:
+            return "0"
         if self.p.ext[v]:
             return self.cache[v]
         return f"Fp4(Fp::raw({self.ref(v)}))"
@@ -382,6 +394,10 @@ class _Emitter:
     def need(self, roots: List[int]) -> None:
         """Make every root available in the cache (computing what is missing), pinned until release()."""
         for r in roots:
+            self.request += 1
+            if self.dry:
+                self.requests.append(r)
+                continue
             if self.p.fp[r][0] in (OP_CONST, OP_GET_GLOBAL):
                 continue
             missing = self.p.cone(r, self.cache)
@@ -398,16 +414,45 @@ class _Emitter:
 
     def release(self) -> None:
         self.pinned.clear()
+        if self.dry:
+            return
+        self.request += 0
+        self.drop_dead()
         while len(self.cache) > REG_BUDGET:
-            self.cache.popitem(last=False)
+            self.evict_for_one_forced()
+
+    def evict_for_one_forced(self) -> None:
+        victim, far = None, -1
+        for k in self.cache:
+            nu = self.next_use(k)
+            if nu > far:
+                victim, far = k, nu
+        del self.cache[victim]
+
+    def next_use(self, v: int) -> int:
+        uses = self.future.get(v)
+        if not uses:
+            return 1 << 60
+        i = bisect.bisect_left(uses, self.request)      # the current request still counts as a use
+        return uses[i] if i < len(uses) else 1 << 60
 
     def evict_for_one(self) -> None:
         if len(self.cache) < REG_BUDGET:
             return
-        for k in self.cache:                       # oldest first
-            if k not in self.pinned:
-                del self.cache[k]
-                return
+        victim, far = None, -1
+        for k in self.cache:
+            if k in self.pinned:
+                continue
+            nu = self.next_use(k)
+            if nu > far:
+                victim, far = k, nu
+        if victim is not None:
+            del self.cache[victim]
+
+    def drop_dead(self) -> None:
+        """After a request: values that no later constraint of this part needs leave the cache at once."""
+        for k in [k for k in self.cache if k not in self.pinned and self.next_use(k) >= (1 << 60)]:
+            del self.cache[k]
 
     def define(self, v: int) -> None:
         op, a, b, cc, d = self.p.fp[v]
@@ -532,7 +577,7 @@ class _Emitter:
                 self.need([v])
                 any_emitted = True
                 if self.p.ext[v]:
-                    self.add_fp4(d, f"Fp4(Fp::raw(pw[{e}].x), Fp::raw(pw[{e}].y), Fp::raw(pw[{e}].z), Fp::raw(pw[{e}].w)) * {self.cache[v]}")
+                    self.add_fp4(d, f"Fp4(Fp::raw(pw[{e}].x), Fp::raw(pw[{e}].y), Fp::raw(pw[{e}].z), Fp::raw(pw[{e}].w)) * {self.ext_ref(v)}")
                     self.release()
                     continue
                 # tot += mix^e * v: four 64-bit multiply-adds (scalar-loaded power words), ONE reduction per four constraints
@@ -568,7 +613,21 @@ class _Emitter:
 
 
 def emit_part(kernel: str, plan: Plan, lo: int, hi: int, standalone: bool, header: str) -> str:
-    em = _Emitter(plan, lo, hi)
+    # dry run: which root is requested when -> for every value in those roots' cones, the requests that need it
+    dry = _Emitter(plan, lo, hi)
+    dry.use_depth(0)
+    dry.pend[0], dry.tzero[0] = 0, True
+    dry.emit_chain(plan.c.ret, 0)
+    future: Dict[int, List[int]] = {}
+    cone_cache: Dict[int, List[int]] = {}
+    for req, r in enumerate(dry.requests, start=1):
+        if r not in cone_cache:
+            cone_cache[r] = plan.cone(r, ())
+        for x in cone_cache[r]:
+            lst = future.setdefault(x, [])
+            if not lst or lst[-1] != req:
+                lst.append(req)
+    em = _Emitter(plan, lo, hi, future)
     em.use_depth(0)
     em.pend[0], em.tzero[0] = 0, True
     em.emit_chain(plan.c.ret, 0)
