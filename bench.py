@@ -38,7 +38,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
 PO2 = 20
 TAIL_PO2 = 18                   # the short last segment of a block
-CPU_SAMPLE_PO2 = 17             # bounded CPU-baseline sample: one segment at 2^17 cycles (1/8 of the unit)
+CPU_SAMPLE_PO2 = 17             # thread-count probe runs at 2^15 cycles; the timed sample is the largest po2 <= 20 that fits the budget
+CPU_SAMPLE_BUDGET_S = 30.0
 BASE_SEED = 0x5EED0000
 BENCH_NOISE = 0x2E80            # fixed blinding seed: bench seals must be reproducible run to run (product default: OS RNG)
 
@@ -58,7 +59,9 @@ def seal_algorithmic_bytes(wa: int, wc: int, wd: int, n_taps: int, n_combos: int
 
 
 def cpu_baseline(desc, circuit_name: str) -> dict:
-    """The CPU oracle (a from-spec port of the reference CPU prover's algorithm) on this host's cores."""
+    """The CPU oracle (a from-spec port of the reference CPU prover's algorithm) on this host's cores: about 10-30 s of CPU
+    work.  On a host where the whole unit fits that budget (the GPU box: one po2-20 seal in ~20 s at 32 threads) the unit
+    itself is timed; otherwise the largest power-of-two fraction of it that does, scaled linearly (work is ~linear in n)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import zko                                     # test infrastructure; used here ONLY as the reported CPU baseline
     lib = zko.load()
@@ -66,25 +69,29 @@ def cpu_baseline(desc, circuit_name: str) -> dict:
     # the oracle's OpenMP loops stop scaling long before a two-socket host is full (fork/join + memory bound): scan a
     # few thread counts on a small segment and quote the baseline at the fastest one
     avail = int(lib.zko_num_threads())
+    probe_po2 = CPU_SAMPLE_PO2 - 2
     best, best_dt = avail, None
     for t in sorted({c for c in (8, 16, 32, 64, avail) if c <= avail}):
         lib.zko_set_num_threads(t)
         t0 = time.perf_counter()
-        oc.prove(CPU_SAMPLE_PO2 - 2, 1994, BASE_SEED, BENCH_NOISE)
+        oc.prove(probe_po2, 1994, BASE_SEED, BENCH_NOISE)
         d = time.perf_counter() - t0
         if best_dt is None or d < best_dt:
             best, best_dt = t, d
     lib.zko_set_num_threads(best)
+    sample_po2 = probe_po2
+    while sample_po2 < PO2 and best_dt * (1 << (sample_po2 + 1 - probe_po2)) <= CPU_SAMPLE_BUDGET_S:
+        sample_po2 += 1
     t0 = time.perf_counter()
-    seal = oc.prove(CPU_SAMPLE_PO2, 1994, BASE_SEED, BENCH_NOISE)
+    seal = oc.prove(sample_po2, 1994, BASE_SEED, BENCH_NOISE)
     dt = time.perf_counter() - t0
-    scale = 1 << (PO2 - CPU_SAMPLE_PO2)
+    scale = 1 << (PO2 - sample_po2)
+    how = "the unit itself, no extrapolation" if scale == 1 else f"scaled x1/{scale} to the po2={PO2} unit (work is ~linear in n)"
     return {"value": 1.0 / (dt * scale), "unit": "segments/s", "cores": best, "cores_available": avail, "kind": "port",
-            "sample": f"one {circuit_name} segment seal at po2={CPU_SAMPLE_PO2} ({dt:.2f} s wall, OpenMP oracle incl. witgen, at the fastest of "
-                      f"8/16/32/64/{avail} threads = {best}), "
-                      f"scaled x1/{scale} to the po2={PO2} unit (work is ~linear in n)",
-            "note": "an extrapolated sample of a literal, untuned port (the reference CPU prover cannot be built here); "
-                    "reported as the contract asks, never a target and never a quotable speed-up",
+            "sample": f"one {circuit_name} segment seal at po2={sample_po2} ({dt:.2f} s wall, OpenMP oracle incl. witgen, at the fastest of "
+                      f"8/16/32/64/{avail} threads = {best}); {how}",
+            "note": "a literal, untuned port (the reference CPU prover cannot be built here); reported as the contract asks, "
+                    "never a target and never a quotable speed-up",
             "seal_words": int(seal.size)}
 
 

@@ -47,7 +47,8 @@ USE_SOP = os.environ.get("ZKH_CODEGEN_SOP", "1") != "0"     # sums of products a
 REG_BUDGET = int(os.environ.get("ZKH_CODEGEN_REGS", "96"))      # values (taps + intermediates) the register cache of a kernel holds
 EPOCH_LOADS = int(os.environ.get("ZKH_CODEGEN_EPOCH", "48"))    # tap loads per offset epoch
 PART_WEIGHT = int(os.environ.get("ZKH_CODEGEN_PART", "3200"))   # value steps per generated kernel (~ one translation unit / code object)
-GENERATOR_VERSION = 3
+PREFETCH = int(os.environ.get("ZKH_CODEGEN_PREFETCH", "0"))    # tap loads issued this many constraints ahead of their first use
+GENERATOR_VERSION = 4
 
 
 def desc_hash64(desc: np.ndarray) -> int:
@@ -338,6 +339,7 @@ class _Emitter:
         self.dry = future is None
         self.request = 0
         self.requests: List[int] = []       # dry run: the root of every request, in order
+        self.upcoming: List[int] = []       # real run: the dry run's request list (for prefetching)
         self.cache: "OrderedDict[int, str]" = OrderedDict()
         self.gen: Dict[int, int] = {}       # canonical value -> how often it has been (re)defined
         self.pinned: set = set()
@@ -398,6 +400,15 @@ class _Emitter:
             if self.dry:
                 self.requests.append(r)
                 continue
+            if PREFETCH and self.upcoming:
+                # software prefetch: the taps of the next constraints are loaded now, so their latency overlaps this
+                # constraint's arithmetic (their next use is near, so the eviction rule keeps them)
+                for nxt in self.upcoming[self.request: self.request + PREFETCH]:
+                    if self.p.fp[nxt][0] in (OP_CONST, OP_GET_GLOBAL):
+                        continue
+                    for x in self.p.cone(nxt, self.cache):
+                        if self.p.fp[x][0] == OP_GET and x not in self.cache:
+                            self.define(x)
             if self.p.fp[r][0] in (OP_CONST, OP_GET_GLOBAL):
                 continue
             missing = self.p.cone(r, self.cache)
@@ -628,6 +639,7 @@ def emit_part(kernel: str, plan: Plan, lo: int, hi: int, standalone: bool, heade
             if not lst or lst[-1] != req:
                 lst.append(req)
     em = _Emitter(plan, lo, hi, future)
+    em.upcoming = dry.requests
     em.use_depth(0)
     em.pend[0], em.tzero[0] = 0, True
     em.emit_chain(plan.c.ret, 0)

@@ -67,15 +67,72 @@ __device__ __forceinline__ void ev_accumulate(Fp4 (&acc)[EV_MAXP], const uint32_
     }
 }
 
+// Power tables of one evaluation point, built ONCE per point (not once per block: a 2^20-coefficient column is 64 blocks,
+// and the ~30 dependent Fp4 products + 14 barriers of the table build cost more than streaming a block's 64 KiB):
+//   [0, 256)    x^t            | BITREV: x^(bitrev8(t) << (k-8))
+//   [256, 320)  X^i, X = x^256 | BITREV: x^(bitrev6(i) << (k-14))
+//   [320, 352)  [320] = X^64   | BITREV: x^(2^m), m < k
 // BITREV: the column holds its coefficients in the bit-reversed order batch_interpolate_ntt leaves them in (position p
 // holds coefficient bitrev_k(p)); x^bitrev(p) still factors over the bit fields of p = chunk*CH + i*256 + t, so only the
-// three power tables change and PolyGroup never has to bit-reverse W x n coefficient words.
+// tables change and PolyGroup never has to bit-reverse W x n coefficient words.
+constexpr int EV_TAB = TB + EV_PER + 32;
+template <bool BITREV>
+__global__ __launch_bounds__(TB) void k_eval_tables(uint4* __restrict__ tab, const uint32_t* __restrict__ xs, uint32_t log_n) {
+    __shared__ uint4 xt[TB], xp[EV_PER], sq[32];
+    const uint32_t t = threadIdx.x;
+    const Fp4 x = ld_ext(xs + 4 * blockIdx.x);
+    if (t < 32) st_ext((uint32_t*)&sq[t], Fp4::zero());
+    __syncthreads();
+    if (BITREV) {
+        if (t == 0) {
+            Fp4 y = x;
+            for (uint32_t m = 0; m < log_n; m++) { st_ext((uint32_t*)&sq[m], y); y = y * y; }
+            st_ext((uint32_t*)&xt[0], Fp4::one());
+            st_ext((uint32_t*)&xp[0], Fp4::one());
+        }
+        __syncthreads();
+        for (uint32_t b = 0; b < 8; b++) {                    // position bit b of t  ->  exponent bit k-1-b
+            const uint32_t s = 1u << b;
+            if (t < s) st_ext((uint32_t*)&xt[s + t], ld_ext((const uint32_t*)&xt[t]) * ld_ext((const uint32_t*)&sq[log_n - 1 - b]));
+            __syncthreads();
+        }
+        for (uint32_t b = 0; b < 6; b++) {                    // position bit 8+b  ->  exponent bit k-9-b
+            const uint32_t s = 1u << b;
+            if (t < s) st_ext((uint32_t*)&xp[s + t], ld_ext((const uint32_t*)&xp[t]) * ld_ext((const uint32_t*)&sq[log_n - 9 - b]));
+            __syncthreads();
+        }
+    } else {
+        // doubling: tab[s + i] = tab[i] * x^s
+        if (t == 0) { st_ext((uint32_t*)&xt[0], Fp4::one()); st_ext((uint32_t*)&xp[0], Fp4::one()); }
+        __syncthreads();
+        Fp4 xs_pow = x;    // x^s
+        for (uint32_t s = 1; s < TB; s <<= 1) {
+            if (t < s) st_ext((uint32_t*)&xt[s + t], ld_ext((const uint32_t*)&xt[t]) * xs_pow);
+            xs_pow = xs_pow * xs_pow;
+            __syncthreads();
+        }
+        Fp4 Xs = xs_pow;   // X = x^256
+        for (uint32_t s = 1; s < EV_PER; s <<= 1) {
+            if (t < s) st_ext((uint32_t*)&xp[s + t], ld_ext((const uint32_t*)&xp[t]) * Xs);
+            Xs = Xs * Xs;
+            __syncthreads();
+        }
+        if (t == 0) st_ext((uint32_t*)&sq[0], Xs);            // X^64 = x^(chunk length)
+        __syncthreads();
+    }
+    uint4* out = tab + (size_t)blockIdx.x * EV_TAB;
+    out[t] = xt[t];
+    if (t < EV_PER) out[TB + t] = xp[t];
+    if (t < 32) out[TB + EV_PER + t] = sq[t];
+}
+
 template <bool BITREV>
 __global__ __launch_bounds__(TB) void k_eval_partial(uint32_t* __restrict__ partial, const uint32_t* __restrict__ coeffs,
                                                      size_t po, const uint32_t* __restrict__ which,
-                                                     const uint32_t* __restrict__ xs, uint32_t n_chunks, uint32_t log_n,
+                                                     const uint4* __restrict__ tab, uint32_t n_chunks, uint32_t log_n,
                                                      uint32_t n_eval) {
-    extern __shared__ __attribute__((aligned(16))) uint4 ev_lds[];
+    __shared__ uint4 xp[EV_MAXP][EV_PER];
+    __shared__ uint4 red[TB];
     // run of this block: leader = first entry of the run, or every EV_MAXP-th entry of a longer run
     const uint32_t k0 = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
     const uint32_t col = which[k0];
@@ -84,39 +141,7 @@ __global__ __launch_bounds__(TB) void k_eval_partial(uint32_t* __restrict__ part
     if ((k0 - start) % EV_MAXP != 0) return;                  // another block of the run covers this entry
     uint32_t np = 1;
     while (np < EV_MAXP && k0 + np < n_eval && which[k0 + np] == col) np++;
-    // LDS (9.7 KB + 1 KB per extra point, so that many blocks stay resident per CU): the per-point X^i tables used by the
-    // streaming loop, and ONE x^t table + reduction buffer reused point by point afterwards
-    uint4 (*xp)[EV_PER] = (uint4 (*)[EV_PER])ev_lds;                // [EV_MAXP][EV_PER]  X^i, X = x^256 | x^(bitrev6(i) << (k-14))
-    uint4* xt = ev_lds + EV_MAXP * EV_PER;                          // [TB]  x^t | x^(bitrev8(t) << (k-8))
-    uint4* red = xt + TB;                                           // [TB]
-    uint4* sq = red + TB;                                           // [32]  BITREV: x^(2^m)
-    // ---- X^i tables of every point ----
-    for (uint32_t p = 0; p < np; p++) {
-        const Fp4 x = ld_ext(xs + 4 * (k0 + p));
-        if (BITREV) {
-            __syncthreads();                                  // sq is reused by every point
-            if (t == 0) {
-                Fp4 y = x;
-                for (uint32_t m = 0; m < log_n; m++) { st_ext((uint32_t*)&sq[m], y); y = y * y; }
-                st_ext((uint32_t*)&xp[p][0], Fp4::one());
-            }
-            __syncthreads();
-            for (uint32_t b = 0; b < 6; b++) {                    // position bit 8+b  ->  exponent bit k-9-b
-                const uint32_t s = 1u << b;
-                if (t < s) st_ext((uint32_t*)&xp[p][s + t], ld_ext((const uint32_t*)&xp[p][t]) * ld_ext((const uint32_t*)&sq[log_n - 9 - b]));
-                __syncthreads();
-            }
-        } else {
-            if (t == 0) st_ext((uint32_t*)&xp[p][0], Fp4::one());
-            __syncthreads();
-            Fp4 Xs = fp4_pow(x, TB);                              // X = x^256
-            for (uint32_t s = 1; s < EV_PER; s <<= 1) {
-                if (t < s) st_ext((uint32_t*)&xp[p][s + t], ld_ext((const uint32_t*)&xp[p][t]) * Xs);
-                Xs = Xs * Xs;
-                __syncthreads();
-            }
-        }
-    }
+    for (uint32_t e = t; e < np * EV_PER; e += TB) xp[e / EV_PER][e % EV_PER] = tab[(size_t)(k0 + e / EV_PER) * EV_TAB + TB + e % EV_PER];
     __syncthreads();
     const uint32_t* c = coeffs + (size_t)col * po;
     const size_t j0 = (size_t)chunk * EV_CH + t;
@@ -134,43 +159,26 @@ __global__ __launch_bounds__(TB) void k_eval_partial(uint32_t* __restrict__ part
 #pragma unroll
     for (int p = 0; p < EV_MAXP; p++) {
         if ((uint32_t)p >= np) break;
-        const Fp4 x = ld_ext(xs + 4 * (k0 + p));
-        Fp4 chunk_pow = Fp4::one();
-        __syncthreads();                                      // xt / red / sq of the previous point are no longer read
-        if (BITREV) {
-            if (t == 0) {
-                Fp4 y = x;
-                for (uint32_t m = 0; m < log_n; m++) { st_ext((uint32_t*)&sq[m], y); y = y * y; }
-                st_ext((uint32_t*)&xt[0], Fp4::one());
-            }
-            __syncthreads();
-            for (uint32_t b = 0; b < 8; b++) {                    // position bit b of t  ->  exponent bit k-1-b
-                const uint32_t s = 1u << b;
-                if (t < s) st_ext((uint32_t*)&xt[s + t], ld_ext((const uint32_t*)&xt[t]) * ld_ext((const uint32_t*)&sq[log_n - 1 - b]));
-                __syncthreads();
-            }
-            if (t == 0)
-                for (uint32_t cb = 0; cb + 14 < log_n; cb++)       // position bit 14+c -> exponent bit k-15-c
-                    if ((chunk >> cb) & 1) chunk_pow = chunk_pow * ld_ext((const uint32_t*)&sq[log_n - 15 - cb]);
-        } else {
-            // doubling: tab[s + i] = tab[i] * x^s
-            if (t == 0) st_ext((uint32_t*)&xt[0], Fp4::one());
-            __syncthreads();
-            Fp4 xs_pow = x;    // x^s
-            for (uint32_t s = 1; s < TB; s <<= 1) {
-                if (t < s) st_ext((uint32_t*)&xt[s + t], ld_ext((const uint32_t*)&xt[t]) * xs_pow);
-                xs_pow = xs_pow * xs_pow;
-                __syncthreads();
-            }
-            if (t == 0) chunk_pow = fp4_pow(fp4_pow(xs_pow, EV_PER), chunk);   // x^(chunk*CH) = ((x^256)^EV_PER)^chunk
-        }
-        st_ext((uint32_t*)&red[t], acc[p] * ld_ext((const uint32_t*)&xt[t]));
+        const uint4* pt = tab + (size_t)(k0 + p) * EV_TAB;
+        const uint4 xtv = pt[t];
+        __syncthreads();                                      // red of the previous point is no longer read
+        st_ext((uint32_t*)&red[t], acc[p] * ld_ext((const uint32_t*)&xtv));
         __syncthreads();
         for (uint32_t s = TB / 2; s >= 1; s >>= 1) {
             if (t < s) st_ext((uint32_t*)&red[t], ld_ext((const uint32_t*)&red[t]) + ld_ext((const uint32_t*)&red[t + s]));
             __syncthreads();
         }
-        if (t == 0) st_ext(partial + 4 * ((size_t)(k0 + p) * n_chunks + chunk), ld_ext((const uint32_t*)&red[0]) * chunk_pow);
+        if (t == 0) {
+            Fp4 chunk_pow = Fp4::one();
+            if (BITREV) {
+                for (uint32_t cb = 0; cb + 14 < log_n; cb++)       // position bit 14+c -> exponent bit k-15-c
+                    if ((chunk >> cb) & 1) { const uint4 q = pt[TB + EV_PER + log_n - 15 - cb]; chunk_pow = chunk_pow * ld_ext((const uint32_t*)&q); }
+            } else {
+                const uint4 q = pt[TB + EV_PER];                  // X^64 = x^(chunk length)
+                chunk_pow = fp4_pow(ld_ext((const uint32_t*)&q), chunk);
+            }
+            st_ext(partial + 4 * ((size_t)(k0 + p) * n_chunks + chunk), ld_ext((const uint32_t*)&red[0]) * chunk_pow);
+        }
     }
 }
 // in-place bit reversal of `count` polynomials of n ExtElems (AoS)
@@ -335,21 +343,24 @@ static const char* evaluate_any_impl(zkh_ctx* c, const zkh_buf* coeffs, size_t p
     if (bitrev) ZKH_REQUIRE(((size_t)1 << log_n) == po && log_n >= 14 && log_n <= 31,
                             "batch_evaluate_any_bitrev: column length must be a power of two >= 2^14");
     const uint32_t n_chunks = (uint32_t)ceil_div(po, EV_CH);
-    zkh_buf* partial = nullptr;
+    zkh_buf *partial = nullptr, *tab = nullptr;
     ZKH_TRY(new_buf(c, 4 * n_eval * n_chunks, false, &partial));
+    ZKH_TRY(new_buf(c, 4 * n_eval * (size_t)EV_TAB, false, &tab));
     {
         // §8d: each coefficient column is streamed once for all the points it is evaluated at
         ProfScope prof(c, "batch_evaluate_any", 4.0 * po * (double)(n_eval < poly_count ? n_eval : poly_count));
-        // LDS: X^i tables for a full run of EV_MAXP points + one x^t table + the reduction buffer + the squarings (16.9 KB)
-        const size_t lds = ((size_t)EV_MAXP * EV_PER + 2 * TB + 32) * sizeof(uint4);
-        if (bitrev)
-            k_eval_partial<true><<<dim3(n_chunks, (unsigned)n_eval), TB, lds, c->stream>>>(partial->ptr(), coeffs->ptr(), po, which->ptr(),
-                                                                                        xs->ptr(), n_chunks, log_n, (uint32_t)n_eval);
-        else
-            k_eval_partial<false><<<dim3(n_chunks, (unsigned)n_eval), TB, lds, c->stream>>>(partial->ptr(), coeffs->ptr(), po, which->ptr(),
-                                                                                         xs->ptr(), n_chunks, log_n, (uint32_t)n_eval);
+        if (bitrev) {
+            k_eval_tables<true><<<(unsigned)n_eval, TB, 0, c->stream>>>((uint4*)tab->ptr(), xs->ptr(), log_n);
+            k_eval_partial<true><<<dim3(n_chunks, (unsigned)n_eval), TB, 0, c->stream>>>(partial->ptr(), coeffs->ptr(), po, which->ptr(),
+                                                                                      (const uint4*)tab->ptr(), n_chunks, log_n, (uint32_t)n_eval);
+        } else {
+            k_eval_tables<false><<<(unsigned)n_eval, TB, 0, c->stream>>>((uint4*)tab->ptr(), xs->ptr(), log_n);
+            k_eval_partial<false><<<dim3(n_chunks, (unsigned)n_eval), TB, 0, c->stream>>>(partial->ptr(), coeffs->ptr(), po, which->ptr(),
+                                                                                       (const uint4*)tab->ptr(), n_chunks, log_n, (uint32_t)n_eval);
+        }
         k_eval_final<<<(unsigned)ceil_div(n_eval, TB), TB, 0, c->stream>>>(out->ptr(), partial->ptr(), n_chunks, (uint32_t)n_eval);
     }
+    zkh_release(tab);
     zkh_release(partial);
     return last_launch_error("batch_evaluate_any");
 }
