@@ -212,7 +212,7 @@ def main() -> None:
             wk.hal.sync()
         try:
             if torch.cuda.is_available():
-                torch.cuda.synchronize()
+                torch.cuda.synchronize(device)       # this rank's GPU only (never touch another rank's device)
         except (RuntimeError, AssertionError):
             pass
 

@@ -47,7 +47,7 @@ USE_SOP = os.environ.get("ZKH_CODEGEN_SOP", "1") != "0"     # sums of products a
 REG_BUDGET = int(os.environ.get("ZKH_CODEGEN_REGS", "96"))      # values (taps + intermediates) the register cache of a kernel holds
 EPOCH_LOADS = int(os.environ.get("ZKH_CODEGEN_EPOCH", "48"))    # tap loads per offset epoch
 PART_WEIGHT = int(os.environ.get("ZKH_CODEGEN_PART", "3200"))   # value steps per generated kernel (~ one translation unit / code object)
-PREFETCH = int(os.environ.get("ZKH_CODEGEN_PREFETCH", "0"))    # tap loads issued this many constraints ahead of their first use
+PREFETCH = int(os.environ.get("ZKH_CODEGEN_PREFETCH", "4"))    # tap loads issued this many constraints ahead of their first use
 GENERATOR_VERSION = 4
 
 

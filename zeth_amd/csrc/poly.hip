@@ -318,6 +318,34 @@ __global__ __launch_bounds__(TB) void k_prefix_prod(uint32_t* __restrict__ out, 
     }
 }
 
+// combos_divide_all, partial-fraction form: combo polynomial y := sum_p A[p] * Q[p] over its points p (Q[p] = quotient of the
+// ORIGINAL polynomial by (x - z_p) alone, A[p] = 1 / prod_{j != p} (z_p - z_j)).  desc per combo: {first pair, count}.
+__global__ __launch_bounds__(TB) void k_combine_quotients(uint32_t* __restrict__ combos, const uint32_t* __restrict__ q, size_t cycles,
+                                                          const uint32_t* __restrict__ combo_off, const uint32_t* __restrict__ first_pair,
+                                                          const uint32_t* __restrict__ n_pairs, const uint32_t* __restrict__ weights) {
+    const size_t i = (size_t)blockIdx.x * TB + threadIdx.x;
+    const uint32_t y = blockIdx.y;
+    if (i >= cycles) return;
+    Fp4 acc = Fp4::zero();
+    const uint32_t p0 = first_pair[y], np = n_pairs[y];
+    for (uint32_t p = 0; p < np; p++) acc = acc + ld_ext(q + 4 * ((size_t)(p0 + p) * cycles + i)) * ld_ext(weights + 4 * (p0 + p));
+    st_ext(combos + combo_off[y] + 4 * i, acc);
+}
+// The remainders of dividing successively by (x - z_1), (x - z_2), ... are the Newton divided differences of the
+// polynomial's values at those points: r_1 = c(z_1), r_2 = (c(z_2) - c(z_1)) / (z_2 - z_1), ...  One lane per combo.
+__global__ void k_divided_differences(uint32_t* __restrict__ rem_out, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ pts,
+                                      const uint32_t* __restrict__ first_pair, const uint32_t* __restrict__ n_pairs, uint32_t n_combos) {
+    const uint32_t y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= n_combos) return;
+    const uint32_t p0 = first_pair[y], np = n_pairs[y];
+    Fp4 d[8];
+    for (uint32_t p = 0; p < np; p++) d[p] = ld_ext(vals + 4 * (p0 + p));
+    for (uint32_t lvl = 1; lvl < np; lvl++)
+        for (uint32_t p = np - 1; p >= lvl; p--)
+            d[p] = (d[p] - d[p - 1]) * fp4_inv(ld_ext(pts + 4 * (p0 + p)) - ld_ext(pts + 4 * (p0 + p - lvl)));
+    for (uint32_t p = 0; p < np; p++) st_ext(rem_out + 4 * (p0 + p), d[p]);
+}
+
 inline size_t ceil_div(size_t a, size_t b) { return (a + b - 1) / b; }
 inline Fp4 to_fp4(const uint32_t* w) { return Fp4(Fp::raw(w[0]), Fp::raw(w[1]), Fp::raw(w[2]), Fp::raw(w[3])); }
 
@@ -404,14 +432,14 @@ namespace zkh { const char* h2d(zkh_ctx* c, uint32_t* dst, const uint32_t* host,
 // combos + poly_off[y] words, divided by (x - pts[y]); remainder to rem_out[rem_idx[y]]): the five scan launches of the
 // three-level weighted suffix scan, each covering all ny polynomials through blockIdx.y.
 static const char* divide_round(zkh_ctx* c, zkh_buf* combos, size_t cycles, size_t ny, const uint32_t* poly_off, const Fp4* pts,
-                                const uint32_t* rem_idx, zkh_buf* rem_out) {
+                                const uint32_t* rem_idx, zkh_buf* rem_out, zkh_buf* quot_out = nullptr, const uint32_t* quot_off = nullptr) {
     const size_t n0 = cycles, n1 = ceil_div(n0, TB), n2 = ceil_div(n1, TB);
     ZKH_REQUIRE(n2 <= TB, "combos_divide: polynomial too long");
     zkh_buf *t0 = nullptr, *t1 = nullptr, *meta = nullptr;
     ZKH_TRY(new_buf(c, 4 * n1 * ny, false, &t0));    // level-0 block totals, then S at level-0 block starts
     ZKH_TRY(new_buf(c, 4 * n2 * ny, false, &t1));    // level-1 block totals, then S at level-1 block starts
     // per-launch metadata: weights of the three levels (z, z^256, z^65536), polynomial offsets, per-y offsets into t0 / t1
-    std::vector<uint32_t> m(12 * ny + 4 * ny);
+    std::vector<uint32_t> m(12 * ny + 5 * ny);
     for (size_t y = 0; y < ny; y++) {
         const Fp4 z = pts[y], z256 = fp4_pow(z, TB), z64k = fp4_pow(z256, TB);
         memcpy(&m[4 * y], &z, 16); memcpy(&m[4 * ny + 4 * y], &z256, 16); memcpy(&m[8 * ny + 4 * y], &z64k, 16);
@@ -419,11 +447,13 @@ static const char* divide_round(zkh_ctx* c, zkh_buf* combos, size_t cycles, size
         m[13 * ny + y] = (uint32_t)(4 * n1 * y);
         m[14 * ny + y] = (uint32_t)(4 * n2 * y);
         m[15 * ny + y] = rem_idx[y];
+        m[16 * ny + y] = quot_off ? quot_off[y] : poly_off[y];
     }
     ZKH_TRY(new_buf(c, m.size(), false, &meta));
     ZKH_TRY(h2d(c, meta->ptr(), m.data(), m.size()));
     const uint32_t *w0 = meta->ptr(), *w1 = w0 + 4 * ny, *w2 = w0 + 8 * ny, *poff = w0 + 12 * ny, *t0off = w0 + 13 * ny,
-                   *t1off = w0 + 14 * ny, *ridx = w0 + 15 * ny;
+                   *t1off = w0 + 14 * ny, *ridx = w0 + 15 * ny, *qoff = w0 + 16 * ny;
+    uint32_t* qbase = quot_out ? quot_out->ptr() : combos->ptr();      // where the quotients go (in place by default)
     {
         ProfScope prof(c, "combos_divide", 32.0 * cycles * ny);
         // up-sweep
@@ -433,7 +463,7 @@ static const char* divide_round(zkh_ctx* c, zkh_buf* combos, size_t cycles, size
         k_suffix_scan<false><<<dim3(1, (unsigned)ny), TB, 0, c->stream>>>(t1->ptr(), t1->ptr(), n2, w2, nullptr, 0, 0, nullptr, t1off, t1off, 0, nullptr);
         // down-sweep: S at level-0 block starts, then the quotient itself (shift 1), remainder = S_0
         k_suffix_scan<false><<<dim3((unsigned)n2, (unsigned)ny), TB, 0, c->stream>>>(t0->ptr(), t0->ptr(), n1, w1, t1->ptr(), n2, 0, nullptr, t0off, t0off, 4 * n2, nullptr);
-        k_suffix_scan<false><<<dim3((unsigned)n1, (unsigned)ny), TB, 0, c->stream>>>(combos->ptr(), combos->ptr(), n0, w0, t0->ptr(), n1, 1, rem_out->ptr(), poff, poff, 4 * n1, ridx);
+        k_suffix_scan<false><<<dim3((unsigned)n1, (unsigned)ny), TB, 0, c->stream>>>(qbase, combos->ptr(), n0, w0, t0->ptr(), n1, 1, rem_out->ptr(), poff, qoff, 4 * n1, ridx);
     }
     zkh_release(t0); zkh_release(t1); zkh_release(meta);
     return last_launch_error("combos_divide");
@@ -461,22 +491,68 @@ extern "C" const char* zkh_combos_divide_all(zkh_ctx* c, zkh_buf* combos, size_t
     ZKH_REQUIRE(cycles <= ((size_t)1 << 24) && combos->len < ((size_t)1 << 32), "combos_divide_all: polynomial too long");
     ZKH_REQUIRE(rem_out->len >= 4 * (size_t)pts_begin[n_combos], "combos_divide_all: remainder buffer too small");
     size_t max_pts = 0;
+    bool distinct = true;
     for (size_t i = 0; i < n_combos; i++) {
         ZKH_REQUIRE(pts_begin[i + 1] >= pts_begin[i], "combos_divide_all: pts_begin must be non-decreasing");
         max_pts = std::max(max_pts, (size_t)(pts_begin[i + 1] - pts_begin[i]));
+        for (uint32_t a = pts_begin[i]; a < pts_begin[i + 1]; a++)
+            for (uint32_t b = a + 1; b < pts_begin[i + 1]; b++) distinct &= memcmp(pts + 4 * a, pts + 4 * b, 16) != 0;
     }
-    for (size_t r = 0; r < max_pts; r++) {
-        std::vector<uint32_t> off, ridx;
-        std::vector<Fp4> zs;
-        for (size_t i = 0; i < n_combos; i++) {
-            if (pts_begin[i] + r >= pts_begin[i + 1]) continue;
-            off.push_back((uint32_t)(4 * i * cycles));
-            ridx.push_back((uint32_t)(pts_begin[i] + r));
-            zs.push_back(to_fp4(pts + 4 * (pts_begin[i] + r)));
+    const size_t n_pairs = pts_begin[n_combos];
+    if (!n_pairs) return nullptr;
+    if (!distinct || max_pts > 8 || n_pairs * cycles * 4 >= ((size_t)1 << 32)) {
+        // generic fallback: one round of launches per division step (round r divides every combo that has an r-th point)
+        for (size_t r = 0; r < max_pts; r++) {
+            std::vector<uint32_t> off, ridx;
+            std::vector<Fp4> zs;
+            for (size_t i = 0; i < n_combos; i++) {
+                if (pts_begin[i] + r >= pts_begin[i + 1]) continue;
+                off.push_back((uint32_t)(4 * i * cycles));
+                ridx.push_back((uint32_t)(pts_begin[i] + r));
+                zs.push_back(to_fp4(pts + 4 * (pts_begin[i] + r)));
+            }
+            ZKH_TRY(divide_round(c, combos, cycles, off.size(), off.data(), zs.data(), ridx.data(), rem_out));
         }
-        ZKH_TRY(divide_round(c, combos, cycles, off.size(), off.data(), zs.data(), ridx.data(), rem_out));
+        return nullptr;
     }
-    return nullptr;
+    // Partial fractions: floor(c / prod_p (x - z_p)) = sum_p A_p * floor(c / (x - z_p)),  A_p = 1 / prod_{j != p} (z_p - z_j)
+    // (the difference of the two sides is (c mod D - Lagrange interpolant of c at the z_p) / D = 0), so ALL single-point
+    // divisions of ALL combos are independent and share one set of five scan launches; a sixth kernel forms the weighted
+    // sums.  The sequential remainders upstream checks are the divided differences of c(z_p).
+    std::vector<uint32_t> poly_off(n_pairs), quot_off(n_pairs), ridx(n_pairs), meta(4 * n_combos + 4 * n_pairs + 4 * n_pairs);
+    std::vector<Fp4> zs(n_pairs);
+    uint32_t* m_off = meta.data();                // combo -> word offset of its polynomial
+    uint32_t* m_first = m_off + n_combos;         // combo -> first pair
+    uint32_t* m_cnt = m_first + n_combos;         // combo -> number of pairs
+    uint32_t* m_w = m_cnt + 2 * n_combos;         // pair -> A_p (Fp4)      (one spare block keeps the arrays 16-byte aligned)
+    uint32_t* m_pts = m_w + 4 * n_pairs;          // pair -> z_p (Fp4)
+    for (size_t i = 0; i < n_combos; i++) {
+        m_off[i] = (uint32_t)(4 * i * cycles); m_first[i] = pts_begin[i]; m_cnt[i] = pts_begin[i + 1] - pts_begin[i];
+        for (uint32_t p = pts_begin[i]; p < pts_begin[i + 1]; p++) {
+            poly_off[p] = (uint32_t)(4 * i * cycles); quot_off[p] = (uint32_t)(4 * (size_t)p * cycles); ridx[p] = p;
+            zs[p] = to_fp4(pts + 4 * p);
+            Fp4 den = Fp4::one();
+            for (uint32_t j = pts_begin[i]; j < pts_begin[i + 1]; j++) if (j != p) den = den * (zs[p] - to_fp4(pts + 4 * j));
+            const Fp4 w = fp4_inv(den);
+            memcpy(m_w + 4 * p, &w, 16); memcpy(m_pts + 4 * p, pts + 4 * p, 16);
+        }
+    }
+    zkh_buf *quot = nullptr, *vals = nullptr, *dmeta = nullptr;
+    ZKH_TRY(new_buf(c, 4 * n_pairs * cycles, false, &quot));
+    ZKH_TRY(new_buf(c, 4 * n_pairs, false, &vals));
+    ZKH_TRY(new_buf(c, meta.size(), false, &dmeta));
+    ZKH_TRY(h2d(c, dmeta->ptr(), meta.data(), meta.size()));
+    ZKH_TRY(divide_round(c, combos, cycles, n_pairs, poly_off.data(), zs.data(), ridx.data(), vals, quot, quot_off.data()));
+    {
+        ProfScope prof(c, "combos_divide", 16.0 * cycles * (n_pairs + n_combos));
+        const uint32_t* d = dmeta->ptr();
+        k_combine_quotients<<<dim3((unsigned)ceil_div(cycles, TB), (unsigned)n_combos), TB, 0, c->stream>>>(
+            combos->ptr(), quot->ptr(), cycles, d, d + n_combos, d + 2 * n_combos, d + 4 * n_combos);
+        k_divided_differences<<<(unsigned)ceil_div(n_combos, 64), 64, 0, c->stream>>>(rem_out->ptr(), vals->ptr(), d + 4 * n_combos + 4 * n_pairs,
+                                                                                      d + n_combos, d + 2 * n_combos, (uint32_t)n_combos);
+    }
+    zkh_release(quot); zkh_release(vals); zkh_release(dmeta);
+    return last_launch_error("combos_divide_all");
 }
 
 extern "C" const char* zkh_prefix_products(zkh_ctx* c, zkh_buf* io) {
