@@ -19,6 +19,7 @@ uint64_t desc_hash64(const uint32_t* w, size_t n) {   // FNV-1a over the words
     return h;
 }
 const char* launch_ext_powers(zkh_ctx* c, uint32_t* out, const uint32_t start[4], const uint32_t base[4], uint32_t n);
+const char* prefix_products_batched(zkh_ctx* c, uint32_t* io, size_t n0, size_t count, size_t col_stride);
 }  // namespace zkh
 
 namespace {
@@ -554,13 +555,7 @@ extern "C" const char* zkh_syn_accum(zkh_ctx* ctx, const zkh_circuit* c, size_t 
         ProfScope prof(ctx, "syn_accum_terms", (4.0 + 16.0) * k * n);
         k_syn_accum_terms<<<dim3(bx, k), 256, 0, ctx->stream>>>(terms->ptr(), data->ptr(), mix->ptr(), wd, (uint32_t)n, A);
     }
-    for (uint32_t e = 0; e < k; e++) {
-        zkh_buf* col = nullptr;
-        ZKH_TRY(zkh_slice(terms, 4 * (size_t)e * n, 4 * n, &col));
-        const char* err = zkh_prefix_products(ctx, col);
-        zkh_release(col);
-        ZKH_TRY(err);
-    }
+    ZKH_TRY(prefix_products_batched(ctx, terms->ptr(), n, k, 4 * n));      // all k running products in one set of launches
     {
         ProfScope prof(ctx, "syn_accum_store", (16.0 + 16.0) * k * n);
         k_syn_accum_store<<<dim3(bx, k), 256, 0, ctx->stream>>>(accum->ptr(), terms->ptr(), (uint32_t)n, A, noise_seed);

@@ -242,35 +242,61 @@ __global__ __launch_bounds__(TB) void k_mix_poly_coeffs(uint32_t* __restrict__ o
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Weighted suffix scan over blocks of 256 ExtElems:
-//     S[t] = sum_{t' >= t} v[t'] * w^(t'-t)  +  w^(256-t) * carry          (carry = S of the next block's start)
+// Weighted suffix scan over blocks of BL = 256 * E ExtElems:
+//     S[t] = sum_{t' >= t} v[t'] * w^(t'-t)  +  w^(BL-t) * carry          (carry = S of the next block's start)
 // TOTAL_ONLY: write S[0] per block (up-sweep).  Otherwise write S shifted by `shift` positions
 // (shift = 1 turns suffix sums into synthetic-division quotients: q_i = S_{i+1}).
-// ---------------------------------------------------------------------------------------------------------
+// Work-efficient form: a lane owns E consecutive elements — a sequential Horner run for its total (E-1 products), a
+// 256-wide log-step scan over the lane totals with weight w^E (9 products), the run again seeded with the carry
+// (E products): (2E + 8) / E Fp4 products per element (3 at E = 8) instead of the 9 of a plain log-step scan.  Loads and
+// stores stay lane-strided (coalesced); the blocked view goes through a padded LDS stage.
 // blockIdx.y selects one of several independent polynomials handled by the same launch (combos_divide_all): polynomial y
 // lives at in/out + offs[y] words, its carries at carries + y * carry_stride words, its weight is ws[y] (Fp4, device).
-template <bool TOTAL_ONLY>
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SC_E = 8;          // elements per lane of the level-0 scans (levels 1, 2 are tiny: E = 1)
+template <bool TOTAL_ONLY, int E>
 __global__ __launch_bounds__(TB) void k_suffix_scan(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, size_t n,
                                                     const uint32_t* __restrict__ ws /* per y: Fp4 weight of this level */,
                                                     const uint32_t* __restrict__ carries /* per block b: S of block b+1 start; may be null */,
                                                     size_t n_carries, uint32_t shift, uint32_t* __restrict__ rem_out,
                                                     const uint32_t* __restrict__ in_offs, const uint32_t* __restrict__ out_offs,
                                                     size_t carry_stride, const uint32_t* __restrict__ rem_idx) {
+    constexpr int BL = TB * E;
+    __shared__ uint4 stage[E > 1 ? BL + TB : 1];       // element j of the block at j + j / E (one pad slot per lane run)
     __shared__ uint4 buf[2][TB + 1];
     const uint32_t t = threadIdx.x, y = blockIdx.y;
     in += in_offs ? (size_t)in_offs[y] : 0;
     out += out_offs ? (size_t)out_offs[y] : 0;
     if (carries) carries += (size_t)y * carry_stride;
     const Fp4 w = ld_ext(ws + 4 * y);
-    const size_t b = blockIdx.x, i = b * TB + t;
-    Fp4 v = i < n ? ld_ext(in + 4 * i) : Fp4::zero();
+    const size_t b = blockIdx.x, base = b * BL;
+    Fp4 e[E];
+    if (E == 1) {
+        const size_t i = base + t;
+        e[0] = i < n ? ld_ext(in + 4 * i) : Fp4::zero();
+    } else {
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            const uint32_t j = k * TB + t;
+            const size_t gi = base + j;
+            st_ext((uint32_t*)&stage[j + j / E], gi < n ? ld_ext(in + 4 * gi) : Fp4::zero());
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < E; k++) e[k] = ld_ext((const uint32_t*)&stage[t * E + k + t]);
+    }
+    Fp4 tot = e[E - 1];
+#pragma unroll
+    for (int k = E - 2; k >= 0; k--) tot = e[k] + tot * w;
     Fp4 carry = Fp4::zero();
     if (carries && b + 1 < n_carries) carry = ld_ext(carries + 4 * (b + 1));
-    st_ext((uint32_t*)&buf[0][t], v);
+    st_ext((uint32_t*)&buf[0][t], tot);
     if (t == 0) st_ext((uint32_t*)&buf[0][TB], carry);
     __syncthreads();
     int cur = 0;
     Fp4 wd = w;
+#pragma unroll
+    for (int q = 1; q < E; q <<= 1) wd = wd * wd;         // w^E: weight between neighbouring lane totals
     for (uint32_t d = 1; d <= TB; d <<= 1) {       // 9 steps cover offsets up to 256 (the carry slot)
         // each slot t in [0, 256]: S_t += w^d * S_{t+d}
         for (uint32_t s = t; s <= TB; s += TB) {
@@ -284,24 +310,68 @@ __global__ __launch_bounds__(TB) void k_suffix_scan(uint32_t* __restrict__ out, 
     }
     if (TOTAL_ONLY) {
         if (t == 0) st_ext(out + 4 * b, ld_ext((const uint32_t*)&buf[cur][0]));
+        return;
+    }
+    // S at the start of the next lane's run (slot TB = the block's carry), then this lane's run seeded with it
+    Fp4 r[E + 1];
+    r[E] = ld_ext((const uint32_t*)&buf[cur][t + 1]);
+#pragma unroll
+    for (int k = E - 1; k >= 0; k--) r[k] = e[k] + r[k + 1] * w;
+    if (rem_out && b == 0 && t == 0) st_ext(rem_out + 4 * (rem_idx ? rem_idx[y] : 0), r[0]);
+    if (E == 1) {
+        const size_t i = base + t;
+        if (i < n) st_ext(out + 4 * i, shift ? r[1] : r[0]);
     } else {
-        if (i < n) st_ext(out + 4 * i, ld_ext((const uint32_t*)&buf[cur][t + shift]));
-        if (rem_out && i == 0) st_ext(rem_out + 4 * (rem_idx ? rem_idx[y] : 0), ld_ext((const uint32_t*)&buf[cur][0]));
+        __syncthreads();                                  // every lane has read its run from the stage
+#pragma unroll
+        for (int k = 0; k < E; k++) st_ext((uint32_t*)&stage[t * E + k + t], shift ? r[k + 1] : r[k]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            const uint32_t j = k * TB + t;
+            const size_t gi = base + j;
+            if (gi < n) st_ext(out + 4 * gi, ld_ext((const uint32_t*)&stage[j + j / E]));
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// prefix_products: inclusive running product over ExtElems, same three-level structure (prefix direction).
+// prefix_products: inclusive running product over ExtElems, same structure in the prefix direction (a lane's run,
+// a log-step scan over the lane totals, the run again seeded with the product of everything before it).
+// blockIdx.y = one of `count` independent columns at io + y * col_stride (carries at carries + y * carry_stride).
 // ---------------------------------------------------------------------------------------------------------
-template <bool TOTAL_ONLY>
+template <bool TOTAL_ONLY, int E>
 __global__ __launch_bounds__(TB) void k_prefix_prod(uint32_t* __restrict__ out, const uint32_t* __restrict__ in, size_t n,
-                                                    const uint32_t* __restrict__ carries /* per block b: product of everything before block b */) {
+                                                    const uint32_t* __restrict__ carries /* per block b: product of everything before block b at [b-1] */,
+                                                    size_t col_stride_in, size_t col_stride_out, size_t carry_stride) {
+    constexpr int BL = TB * E;
+    __shared__ uint4 stage[E > 1 ? BL + TB : 1];
     __shared__ uint4 buf[2][TB];
-    const uint32_t t = threadIdx.x;
-    const size_t b = blockIdx.x, i = b * TB + t;
-    Fp4 v = i < n ? ld_ext(in + 4 * i) : Fp4::one();
-    if (carries && t == 0 && b > 0) v = v * ld_ext(carries + 4 * (b - 1));
-    st_ext((uint32_t*)&buf[0][t], v);
+    const uint32_t t = threadIdx.x, y = blockIdx.y;
+    in += (size_t)y * col_stride_in;
+    out += (size_t)y * col_stride_out;
+    if (carries) carries += (size_t)y * carry_stride;
+    const size_t b = blockIdx.x, base = b * BL;
+    Fp4 e[E];
+    if (E == 1) {
+        const size_t i = base + t;
+        e[0] = i < n ? ld_ext(in + 4 * i) : Fp4::one();
+    } else {
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            const uint32_t j = k * TB + t;
+            const size_t gi = base + j;
+            st_ext((uint32_t*)&stage[j + j / E], gi < n ? ld_ext(in + 4 * gi) : Fp4::one());
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < E; k++) e[k] = ld_ext((const uint32_t*)&stage[t * E + k + t]);
+    }
+    if (carries && t == 0 && b > 0) e[0] = e[0] * ld_ext(carries + 4 * (b - 1));
+    Fp4 tot = e[0];
+#pragma unroll
+    for (int k = 1; k < E; k++) tot = tot * e[k];
+    st_ext((uint32_t*)&buf[0][t], tot);
     __syncthreads();
     int cur = 0;
     for (uint32_t d = 1; d < TB; d <<= 1) {
@@ -313,8 +383,23 @@ __global__ __launch_bounds__(TB) void k_prefix_prod(uint32_t* __restrict__ out, 
     }
     if (TOTAL_ONLY) {
         if (t == TB - 1) st_ext(out + 4 * b, ld_ext((const uint32_t*)&buf[cur][t]));
-    } else if (i < n) {
-        st_ext(out + 4 * i, ld_ext((const uint32_t*)&buf[cur][t]));
+        return;
+    }
+    Fp4 r = t > 0 ? ld_ext((const uint32_t*)&buf[cur][t - 1]) : Fp4::one();     // product of everything before this lane's run
+    if (E == 1) {
+        const size_t i = base + t;
+        if (i < n) st_ext(out + 4 * i, r * e[0]);
+    } else {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < E; k++) { r = r * e[k]; st_ext((uint32_t*)&stage[t * E + k + t], r); }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < E; k++) {
+            const uint32_t j = k * TB + t;
+            const size_t gi = base + j;
+            if (gi < n) st_ext(out + 4 * gi, ld_ext((const uint32_t*)&stage[j + j / E]));
+        }
     }
 }
 
@@ -433,7 +518,8 @@ namespace zkh { const char* h2d(zkh_ctx* c, uint32_t* dst, const uint32_t* host,
 // three-level weighted suffix scan, each covering all ny polynomials through blockIdx.y.
 static const char* divide_round(zkh_ctx* c, zkh_buf* combos, size_t cycles, size_t ny, const uint32_t* poly_off, const Fp4* pts,
                                 const uint32_t* rem_idx, zkh_buf* rem_out, zkh_buf* quot_out = nullptr, const uint32_t* quot_off = nullptr) {
-    const size_t n0 = cycles, n1 = ceil_div(n0, TB), n2 = ceil_div(n1, TB);
+    const size_t BL0 = (size_t)TB * SC_E;
+    const size_t n0 = cycles, n1 = ceil_div(n0, BL0), n2 = ceil_div(n1, TB);
     ZKH_REQUIRE(n2 <= TB, "combos_divide: polynomial too long");
     zkh_buf *t0 = nullptr, *t1 = nullptr, *meta = nullptr;
     ZKH_TRY(new_buf(c, 4 * n1 * ny, false, &t0));    // level-0 block totals, then S at level-0 block starts
@@ -441,7 +527,7 @@ static const char* divide_round(zkh_ctx* c, zkh_buf* combos, size_t cycles, size
     // per-launch metadata: weights of the three levels (z, z^256, z^65536), polynomial offsets, per-y offsets into t0 / t1
     std::vector<uint32_t> m(12 * ny + 5 * ny);
     for (size_t y = 0; y < ny; y++) {
-        const Fp4 z = pts[y], z256 = fp4_pow(z, TB), z64k = fp4_pow(z256, TB);
+        const Fp4 z = pts[y], z256 = fp4_pow(z, BL0), z64k = fp4_pow(z256, TB);      // weights of levels 0, 1, 2
         memcpy(&m[4 * y], &z, 16); memcpy(&m[4 * ny + 4 * y], &z256, 16); memcpy(&m[8 * ny + 4 * y], &z64k, 16);
         m[12 * ny + y] = poly_off[y];
         m[13 * ny + y] = (uint32_t)(4 * n1 * y);
@@ -457,13 +543,13 @@ static const char* divide_round(zkh_ctx* c, zkh_buf* combos, size_t cycles, size
     {
         ProfScope prof(c, "combos_divide", 32.0 * cycles * ny);
         // up-sweep
-        k_suffix_scan<true><<<dim3((unsigned)n1, (unsigned)ny), TB, 0, c->stream>>>(t0->ptr(), combos->ptr(), n0, w0, nullptr, 0, 0, nullptr, poff, t0off, 0, nullptr);
-        k_suffix_scan<true><<<dim3((unsigned)n2, (unsigned)ny), TB, 0, c->stream>>>(t1->ptr(), t0->ptr(), n1, w1, nullptr, 0, 0, nullptr, t0off, t1off, 0, nullptr);
+        k_suffix_scan<true, SC_E><<<dim3((unsigned)n1, (unsigned)ny), TB, 0, c->stream>>>(t0->ptr(), combos->ptr(), n0, w0, nullptr, 0, 0, nullptr, poff, t0off, 0, nullptr);
+        k_suffix_scan<true, 1><<<dim3((unsigned)n2, (unsigned)ny), TB, 0, c->stream>>>(t1->ptr(), t0->ptr(), n1, w1, nullptr, 0, 0, nullptr, t0off, t1off, 0, nullptr);
         // top level (n2 <= 256): S at level-1 block starts
-        k_suffix_scan<false><<<dim3(1, (unsigned)ny), TB, 0, c->stream>>>(t1->ptr(), t1->ptr(), n2, w2, nullptr, 0, 0, nullptr, t1off, t1off, 0, nullptr);
+        k_suffix_scan<false, 1><<<dim3(1, (unsigned)ny), TB, 0, c->stream>>>(t1->ptr(), t1->ptr(), n2, w2, nullptr, 0, 0, nullptr, t1off, t1off, 0, nullptr);
         // down-sweep: S at level-0 block starts, then the quotient itself (shift 1), remainder = S_0
-        k_suffix_scan<false><<<dim3((unsigned)n2, (unsigned)ny), TB, 0, c->stream>>>(t0->ptr(), t0->ptr(), n1, w1, t1->ptr(), n2, 0, nullptr, t0off, t0off, 4 * n2, nullptr);
-        k_suffix_scan<false><<<dim3((unsigned)n1, (unsigned)ny), TB, 0, c->stream>>>(qbase, combos->ptr(), n0, w0, t0->ptr(), n1, 1, rem_out->ptr(), poff, qoff, 4 * n1, ridx);
+        k_suffix_scan<false, 1><<<dim3((unsigned)n2, (unsigned)ny), TB, 0, c->stream>>>(t0->ptr(), t0->ptr(), n1, w1, t1->ptr(), n2, 0, nullptr, t0off, t0off, 4 * n2, nullptr);
+        k_suffix_scan<false, SC_E><<<dim3((unsigned)n1, (unsigned)ny), TB, 0, c->stream>>>(qbase, combos->ptr(), n0, w0, t0->ptr(), n1, 1, rem_out->ptr(), poff, qoff, 4 * n1, ridx);
     }
     zkh_release(t0); zkh_release(t1); zkh_release(meta);
     return last_launch_error("combos_divide");
@@ -555,23 +641,31 @@ extern "C" const char* zkh_combos_divide_all(zkh_ctx* c, zkh_buf* combos, size_t
     return last_launch_error("combos_divide_all");
 }
 
-extern "C" const char* zkh_prefix_products(zkh_ctx* c, zkh_buf* io) {
-    ZKH_REQUIRE(io->len % 4 == 0, "prefix_products: not an ExtElem buffer");
-    const size_t n0 = io->len / 4;
-    if (n0 <= 1) return nullptr;
-    ZKH_REQUIRE(n0 <= ((size_t)1 << 24), "prefix_products: buffer too long");
-    const size_t n1 = ceil_div(n0, TB), n2 = ceil_div(n1, TB);
+namespace zkh {
+// `count` independent running products over columns of n0 ExtElems at io + y * col_stride words (one set of launches)
+const char* prefix_products_batched(zkh_ctx* c, uint32_t* io, size_t n0, size_t count, size_t col_stride) {
+    if (n0 <= 1 || !count) return nullptr;
+    ZKH_REQUIRE(n0 <= ((size_t)1 << 24) && count <= 65535, "prefix_products: buffer too long");
+    const size_t n1 = ceil_div(n0, (size_t)TB * SC_E), n2 = ceil_div(n1, TB);
+    ZKH_REQUIRE(n2 <= TB, "prefix_products: buffer too long");
     zkh_buf *t0 = nullptr, *t1 = nullptr;
-    ZKH_TRY(new_buf(c, 4 * n1, false, &t0));
-    ZKH_TRY(new_buf(c, 4 * n2, false, &t1));
+    ZKH_TRY(new_buf(c, 4 * n1 * count, false, &t0));
+    ZKH_TRY(new_buf(c, 4 * n2 * count, false, &t1));
     {
-        ProfScope prof(c, "prefix_products", 32.0 * n0);
-        k_prefix_prod<true><<<(unsigned)n1, TB, 0, c->stream>>>(t0->ptr(), io->ptr(), n0, nullptr);
-        k_prefix_prod<true><<<(unsigned)n2, TB, 0, c->stream>>>(t1->ptr(), t0->ptr(), n1, nullptr);
-        k_prefix_prod<false><<<1, TB, 0, c->stream>>>(t1->ptr(), t1->ptr(), n2, nullptr);                 // inclusive over level-1 totals
-        k_prefix_prod<false><<<(unsigned)n2, TB, 0, c->stream>>>(t0->ptr(), t0->ptr(), n1, t1->ptr());    // inclusive over level-0 totals
-        k_prefix_prod<false><<<(unsigned)n1, TB, 0, c->stream>>>(io->ptr(), io->ptr(), n0, t0->ptr());
+        ProfScope prof(c, "prefix_products", 32.0 * n0 * count);
+        const unsigned ny = (unsigned)count;
+        k_prefix_prod<true, SC_E><<<dim3((unsigned)n1, ny), TB, 0, c->stream>>>(t0->ptr(), io, n0, nullptr, col_stride, 4 * n1, 0);
+        k_prefix_prod<true, 1><<<dim3((unsigned)n2, ny), TB, 0, c->stream>>>(t1->ptr(), t0->ptr(), n1, nullptr, 4 * n1, 4 * n2, 0);
+        k_prefix_prod<false, 1><<<dim3(1, ny), TB, 0, c->stream>>>(t1->ptr(), t1->ptr(), n2, nullptr, 4 * n2, 4 * n2, 0);                   // inclusive over level-1 totals
+        k_prefix_prod<false, 1><<<dim3((unsigned)n2, ny), TB, 0, c->stream>>>(t0->ptr(), t0->ptr(), n1, t1->ptr(), 4 * n1, 4 * n1, 4 * n2);  // inclusive over level-0 totals
+        k_prefix_prod<false, SC_E><<<dim3((unsigned)n1, ny), TB, 0, c->stream>>>(io, io, n0, t0->ptr(), col_stride, col_stride, 4 * n1);
     }
     zkh_release(t0); zkh_release(t1);
     return last_launch_error("prefix_products");
+}
+}  // namespace zkh
+
+extern "C" const char* zkh_prefix_products(zkh_ctx* c, zkh_buf* io) {
+    ZKH_REQUIRE(io->len % 4 == 0, "prefix_products: not an ExtElem buffer");
+    return prefix_products_batched(c, io->ptr(), io->len / 4, 1, 0);
 }
