@@ -1,0 +1,9 @@
+set -u
+O=gpurun_out/r2h; mkdir -p $O
+export TMPDIR=/tmp
+( time timeout 900 python -m pytest tests -m gpu -q --durations=5 ) > $O/pytest.log 2>&1
+echo "pytest rc=$?" >> $O/pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
+timeout 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+bash tools/collect_profiles.sh $O/prof > $O/collect.log 2>&1
+tail -3 $O/pytest.log; tail -2 $O/smoke.log; head -c 300 $O/bench_default.json

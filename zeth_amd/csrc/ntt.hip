@@ -347,11 +347,17 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
     const uint32_t tile_id = xcd_remap(blockIdx.x, p.tiles_per_col);
     const uint32_t lt_bits = p.L - 4;
     const uint32_t a = tile_id >> lt_bits, lt = tile_id & ((1u << lt_bits) - 1);
-    const size_t base = ((size_t)a << (p.L + RH)) + ((size_t)lt << 4) + t;
+    const size_t base = ((size_t)a << (p.L + RH)) + ((size_t)lt << 4);      // wave-uniform: first word of the tile
     const uint32_t lcol = (lt << 4) + t;
     const uint32_t tw_shift = MAX_LOG_N - (p.L + RH);
-    const uint32_t* in = p.in + (size_t)blockIdx.y * p.in_col_stride;
-    uint32_t* out = p.out + (size_t)blockIdx.y * p.out_col_stride;
+    // Tile accesses as uniform base (SGPR pair) + 32-bit per-lane byte offset — global_load's native addressing form; a
+    // 64-bit VGPR address per access costs three extra VALU instructions each, ~10 % of this VALU-bound kernel.
+    // (row < 2^RH, L <= 14: the offset stays below 2^RH+L+2 <= 2^26 bytes.)
+    const char* in = (const char*)(p.in + (size_t)blockIdx.y * p.in_col_stride + base);
+    char* out = (char*)(p.out + (size_t)blockIdx.y * p.out_col_stride + base);
+    const uint32_t tb = t * 4u;
+#define TILE_IN(row) (*(const uint32_t*)(in + ((((uint32_t)(row)) << (p.L + 2)) + tb)))
+#define TILE_OUT(row) (*(uint32_t*)(out + ((((uint32_t)(row)) << (p.L + 2)) + tb)))
     const uint32_t* __restrict__ ltab = p.layer_tw;
     auto root = [&](uint32_t e) -> uint32_t {                  // w_{L+RH}^e, e < 2^(L+RH)
         const uint32_t ex = e << tw_shift;
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
         const uint32_t hi = g >> 2, low = g & 3;
         if (INVERSE) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = in[base + ((size_t)(k * 64 + g) << p.L)];
+            for (int k = 0; k < 16; k++) v[k] = TILE_IN(k * 64 + g);
             radix_layers<4, true, false, 7>(v, ltab, g, 0);                     // sub-layers 10..7
 #pragma unroll
             for (int k = 0; k < 16; k++) lds[(k * 64 + g) * 16 + t] = v[k];
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
                 for (int k = 0; k < 4; k++) {
                     uint32_t x = mul_mod(u[k], tw[4 * i + k]);
                     if (p.scale) x = mul_mod(x, p.scale);
-                    out[base + ((size_t)(m0 + k) << p.L)] = x;
+                    TILE_OUT(m0 + k) = x;
                 }
             }
         } else {
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
                 const uint32_t m0 = (g * 4 + i) * 4;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const uint32_t x = in[base + ((size_t)(m0 + k) << p.L)];
+                    const uint32_t x = TILE_IN(m0 + k);
                     u[k] = LAZY ? (uint32_t)smont((int32_t)x, (int32_t)tw[4 * i + k]) : mul_mod(x, tw[4 * i + k]);
                 }
                 radix_layers<2, false, true, 1, LAZY>(u, ltab, 0, 0);
@@ -436,12 +442,12 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
             for (int k = 0; k < 16; k++) v[k] = lds[(k * 64 + g) * 16 + t];
             radix_layers<4, false, false, 7, LAZY>(v, ltab, g, 0);
 #pragma unroll
-            for (int k = 0; k < 16; k++) out[base + ((size_t)(k * 64 + g) << p.L)] = LAZY ? canon((int32_t)v[k]) : v[k];
+            for (int k = 0; k < 16; k++) TILE_OUT(k * 64 + g) = LAZY ? canon((int32_t)v[k]) : v[k];
         }
     } else {   // RH == 8: 256 rows, g < 16
         if (INVERSE) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = in[base + ((size_t)(k * 16 + g) << p.L)];
+            for (int k = 0; k < 16; k++) v[k] = TILE_IN(k * 16 + g);
             radix_layers<4, true, false, 5>(v, ltab, g, 0);                     // 8..5
 #pragma unroll
             for (int k = 0; k < 16; k++) lds[(k * 16 + g) * 16 + t] = v[k];
@@ -453,12 +459,12 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
             for (int k = 0; k < 16; k++) {
                 uint32_t x = mul_mod(v[k], tw[k]);
                 if (p.scale) x = mul_mod(x, p.scale);
-                out[base + ((size_t)(g * 16 + k) << p.L)] = x;
+                TILE_OUT(g * 16 + k) = x;
             }
         } else {
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                const uint32_t x = in[base + ((size_t)(g * 16 + k) << p.L)];
+                const uint32_t x = TILE_IN(g * 16 + k);
                 v[k] = LAZY ? (uint32_t)smont((int32_t)x, (int32_t)tw[k]) : mul_mod(x, tw[k]);
             }
             radix_layers<4, false, true, 1, LAZY>(v, ltab, 0, 0);
@@ -469,10 +475,12 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
             for (int k = 0; k < 16; k++) v[k] = lds[(k * 16 + g) * 16 + t];
             radix_layers<4, false, false, 5, LAZY>(v, ltab, g, 0);
 #pragma unroll
-            for (int k = 0; k < 16; k++) out[base + ((size_t)(k * 16 + g) << p.L)] = LAZY ? canon((int32_t)v[k]) : v[k];
+            for (int k = 0; k < 16; k++) TILE_OUT(k * 16 + g) = LAZY ? canon((int32_t)v[k]) : v[k];
         }
     }
 }
+#undef TILE_IN
+#undef TILE_OUT
 
 struct Pass { uint32_t L, R; };
 // Cut log_n index bits into HBM passes of <= 12 bits.  The lowest pass works on contiguous runs (cheapest), the
