@@ -24,6 +24,14 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", 
 EXTRA_FLAGS = {"hash.hip": ["-mllvm", "-enable-misched=0"]}
 
 
+def _extra(src: str) -> list:
+    """Per-file flags; the generated eval_check units share theirs with the load-time compiler (circuits/jit.py)."""
+    if src.startswith("eval_check_gen"):
+        from .circuits import codegen
+        return EXTRA_FLAGS.get(src, []) + codegen.KERNEL_FLAGS
+    return EXTRA_FLAGS.get(src, [])
+
+
 def _deps_digest(src: str) -> str:
     h = hashlib.sha256()
     files = [os.path.join(CSRC, src)]
@@ -32,7 +40,7 @@ def _deps_digest(src: str) -> str:
     for f in files:
         with open(f, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS + EXTRA_FLAGS.get(src, [])).encode())
+    h.update(" ".join(FLAGS + _extra(src)).encode())
     return h.hexdigest()
 
 
@@ -42,7 +50,7 @@ def _compile(src: str, force: bool) -> str:
     digest = _deps_digest(src)
     if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == digest:
         return obj
-    cmd = [HIPCC, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [HIPCC, *FLAGS, *_extra(src), "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")

@@ -48,6 +48,8 @@ REG_BUDGET = int(os.environ.get("ZKH_CODEGEN_REGS", "96"))      # values (taps +
 EPOCH_LOADS = int(os.environ.get("ZKH_CODEGEN_EPOCH", "48"))    # tap loads per offset epoch
 PART_WEIGHT = int(os.environ.get("ZKH_CODEGEN_PART", "3200"))   # value steps per generated kernel (~ one translation unit / code object)
 PREFETCH = int(os.environ.get("ZKH_CODEGEN_PREFETCH", "4"))    # tap loads issued this many constraints ahead of their first use
+# compile flags of the generated translation units (build.py and jit.py use the same list)
+KERNEL_FLAGS = [f for f in os.environ.get("ZKH_CODEGEN_FLAGS", "").split() if f]
 GENERATOR_VERSION = 4
 
 

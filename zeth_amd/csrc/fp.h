@@ -35,16 +35,29 @@ struct Fp {
 // ~64 T lane-ops/s, while v_min_u32, v_add3, every 32-bit multiply, v_mad_u64_u32 and all fp64 ops issue at ~37 T/s; a
 // sub_co + cndmask pair costs ~2.1 add-slots against ~2.7 for sub + min.
 // v_subrev_co_u32 + v_cndmask_b32: measured cheaper than v_sub_u32 + v_min_u32 (hash_rows 13.3 vs 13.8 ms)
+// ZKH_REDUCE_MIN (a per-translation-unit build option, used by the generated eval_check kernels): the correction as
+// v_sub + v_min_u32 instead of v_subrev_co + v_cndmask.  Same results; no VCC dependency, hence none of the s_nop hazard
+// fillers that make up ~20 % of the instruction stream of straight-line field arithmetic.
 ZKH_HD uint32_t reduce_once(uint32_t s) {     // s in [0, 2P) -> [0, P)
+#if defined(ZKH_REDUCE_MIN)
+    const uint32_t t = s - P;                 // wraps above s exactly when s < P
+    return t < s ? t : s;
+#else
     uint32_t t;
     const bool borrow = __builtin_usub_overflow(s, P, &t);
     return borrow ? s : t;
+#endif
 }
 ZKH_HD uint32_t add_mod(uint32_t a, uint32_t b) { return reduce_once(a + b); }
 ZKH_HD uint32_t sub_mod(uint32_t a, uint32_t b) {
+#if defined(ZKH_REDUCE_MIN)
+    const uint32_t t = a - b, u = t + P;      // a >= b: u = t + P > t;  a < b: t is huge and u wraps to a - b + P < t
+    return u < t ? u : t;
+#else
     uint32_t t;
     const bool borrow = __builtin_usub_overflow(a, b, &t);
     return borrow ? t + P : t;
+#endif
 }
 // Montgomery reduction of a 64-bit product T < P * 2^32:  (T + m*P) / 2^32 with m = -T * P^-1 mod 2^32 makes the low word
 // cancel, so ONE 64-bit multiply-add (v_mad_u64_u32 m, P, T) yields the quotient in its high register: two multiplies
