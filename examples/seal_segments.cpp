@@ -8,6 +8,9 @@
 //
 //   seal_segments --desc syn_a.desc [--po2 20] [--segments 8] [--devices 1] [--inflight 3] [--no-verify] [--noise-seed N]
 //                 [--receipts-dir DIR]     (writes segment_<i>.zkr: the receipt container of zkh_receipt_encode)
+//                 [--code-objects DIR]     (eval_check kernels of a circuit that is not built in: the .hsaco files +
+//                                           manifest.txt written by `python -m zeth_amd.circuits.jit circuit.desc DIR`,
+//                                           attached through zkh_circuit_attach_code_object_part — no Python at run time)
 //
 // The circuit description blob is what zeth_amd/circuits/desc.py serialises (`python -m zeth_amd.circuits.syn_air syn_a syn_a.desc`).
 // Witnesses are the declared-synthetic SYN-AIR traces generated on the device (zkh_syn_witgen); with the real rv32im
@@ -34,6 +37,7 @@ struct Options {
     size_t po2 = 20, segments = 8, devices = 1, inflight = 3;
     bool verify = true;
     std::string receipts_dir;        // --receipts-dir: one receipt container per segment
+    std::string code_objects_dir;    // --code-objects: generated eval_check kernels to attach after loading the circuit
     bool fixed_noise = false;        // --noise-seed: reproducible seals (tests); default: fresh OS randomness per segment
     uint64_t noise_seed = 0;
 };
@@ -69,6 +73,27 @@ double now_s() {
 }
 
 // One lane = one context (device + stream) + circuit + prover; lanes of all devices pull from one work index.
+// Attach the code objects listed in DIR/manifest.txt ("<part> <n_parts> <kernel> <file>" per line) to a loaded circuit.
+bool attach_code_objects(zkh_circuit* circuit, const std::string& dir) {
+    FILE* mf = fopen((dir + "/manifest.txt").c_str(), "r");
+    if (!mf) { failed(strdup("cannot open manifest.txt"), dir.c_str()); return false; }
+    unsigned part = 0, n_parts = 0;
+    char kernel[256], file[256];
+    bool ok = true;
+    while (ok && fscanf(mf, "%u %u %255s %255s", &part, &n_parts, kernel, file) == 4) {
+        FILE* f = fopen((dir + "/" + file).c_str(), "rb");
+        if (!f) { failed(strdup("cannot open code object"), file); ok = false; break; }
+        std::vector<char> image;
+        char buf[65536];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof buf, f)) > 0) image.insert(image.end(), buf, buf + got);
+        fclose(f);
+        ok = !failed(zkh_circuit_attach_code_object_part(circuit, image.data(), image.size(), kernel, part, n_parts), "zkh_circuit_attach_code_object_part");
+    }
+    fclose(mf);
+    return ok && zkh_circuit_compiled_parts(circuit) > 0;
+}
+
 std::mutex g_root_lock;
 bool g_have_root = false;
 uint32_t g_control_root[8];
@@ -82,6 +107,7 @@ void lane(int device, const std::vector<uint32_t>& desc, const Options& opt, std
     do {
         if (failed(zkh_ctx_create(device, "poseidon2", &ctx), "zkh_ctx_create")) break;
         if (failed(zkh_circuit_load(ctx, desc.data(), desc.size(), &circuit), "zkh_circuit_load")) break;
+        if (!opt.code_objects_dir.empty() && !attach_code_objects(circuit, opt.code_objects_dir)) break;
         if (failed(zkh_prover_create(ctx, circuit, &prover), "zkh_prover_create")) break;
         const size_t n = (size_t)1 << opt.po2;
         const size_t w_code = desc[4], w_data = desc[5];          // header: magic, version, 3, W_accum, W_code, W_data
@@ -134,6 +160,7 @@ bool parse(int argc, char** argv, Options& o) {
         else if (a == "--inflight") val(o.inflight);
         else if (a == "--no-verify") o.verify = false;
         else if (a == "--receipts-dir" && i + 1 < argc) o.receipts_dir = argv[++i];
+        else if (a == "--code-objects" && i + 1 < argc) o.code_objects_dir = argv[++i];
         else if (a == "--noise-seed" && i + 1 < argc) { o.noise_seed = strtoull(argv[++i], nullptr, 0); o.fixed_noise = true; }
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return false; }
     }
@@ -145,7 +172,7 @@ bool parse(int argc, char** argv, Options& o) {
 int main(int argc, char** argv) {
     Options opt;
     if (!parse(argc, argv, opt)) {
-        fprintf(stderr, "usage: %s --desc FILE [--po2 N] [--segments S] [--devices G] [--inflight K] [--no-verify] [--noise-seed N] [--receipts-dir DIR]\n", argv[0]);
+        fprintf(stderr, "usage: %s --desc FILE [--po2 N] [--segments S] [--devices G] [--inflight K] [--no-verify] [--noise-seed N] [--receipts-dir DIR] [--code-objects DIR]\n", argv[0]);
         return 2;
     }
     FILE* f = fopen(opt.desc_path.c_str(), "rb");

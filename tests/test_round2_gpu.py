@@ -453,3 +453,39 @@ def test_combos_divide_all_matches_sequential_division(hal, oracle):
     hal.combos_divide_all(dev, cycles, pts, begin, rem_out)
     assert np.array_equal(dev.to_vec(), want)
     assert np.array_equal(rem_out.to_vec(), want_rem)
+
+
+def test_cpp_host_attaches_code_objects_and_writes_receipts(tmp_path):
+    """A non-Python host with a circuit that is NOT built into the library: the generated eval_check kernels arrive as code
+    objects (`python -m zeth_amd.circuits.jit` wrote them + a manifest ahead of time), examples/seal_segments attaches them
+    through zkh_circuit_attach_code_object_part, seals, verifies against the control root and writes receipt containers,
+    which the Python side parses back and verifies again."""
+    import subprocess
+    from zeth_amd import build
+    from zeth_amd.circuits import jit, syn_heavy
+    from zeth_amd.prover import SegmentReceipt
+    desc = syn_heavy.syn_heavy_small()                      # two kernels, no built-in match
+    desc_path = tmp_path / "c.desc"
+    np.asarray(desc, dtype="<u4").tofile(desc_path)
+    objs = tmp_path / "objs"
+    assert jit.main(["jit", str(desc_path), str(objs)]) == 0
+    assert (objs / "manifest.txt").read_text().count("\n") >= 2
+    rdir = tmp_path / "receipts"
+    rdir.mkdir()
+    exe = build.build_examples()
+    r = subprocess.run([exe, "--desc", str(desc_path), "--po2", "13", "--segments", "3", "--inflight", "2", "--noise-seed", "7",
+                        "--code-objects", str(objs), "--receipts-dir", str(rdir)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["verified"] == 3
+    blobs = []
+    for i in range(3):
+        blobs.append(np.fromfile(rdir / f"segment_{i}.zkr", dtype="<u4"))
+        rec = SegmentReceipt.from_words(desc, blobs[-1])
+        assert rec.index == i and rec.po2 == 13
+        rec.verify(desc, rec.control_root)                  # the driver computed the root on the GPU; same circuit, same po2
+    # without the code objects the same host still works (step interpreter), and gives the same seal for the same noise
+    r2 = subprocess.run([exe, "--desc", str(desc_path), "--po2", "13", "--segments", "1", "--inflight", "1", "--noise-seed", "7",
+                         "--receipts-dir", str(rdir)], capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr
+    assert np.array_equal(np.fromfile(rdir / "segment_0.zkr", dtype="<u4"), blobs[0])

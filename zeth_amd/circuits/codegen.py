@@ -544,7 +544,8 @@ class _Emitter:
                 acc = PLAIN
             self.w(f"    {tmp} += {expr};")
             acc += wgt
-        self.w(f"    const uint32_t {name} = mont_reduce_wide({tmp});")
+        # below P 2^32 the plain reduction is enough (one correction instead of two)
+        self.w(f"    const uint32_t {name} = {'mont_reduce' if acc < float(P) * 4294967296.0 else 'mont_reduce_wide'}({tmp});")
         self.n_arith += 1
         self.cache[v] = name
 
@@ -560,11 +561,13 @@ class _Emitter:
     def flush(self, d: int) -> None:
         if self.pend.get(d, 0) == 0:
             return
+        # the running total re-enters the 64-bit sum as t * R (4 P^2 + P R < 2 P 2^32): one multiply-add and the reduction's
+        # two corrections instead of a reduction plus a modular add
         for k in range(4):
             if self.tzero[d]:
                 self.w(f"    t{d}_{k} = mont_reduce_wide(s{d}_{k}); s{d}_{k} = 0;")
             else:
-                self.w(f"    t{d}_{k} = add_mod(t{d}_{k}, mont_reduce_wide(s{d}_{k})); s{d}_{k} = 0;")
+                self.w(f"    t{d}_{k} = mont_reduce_wide(s{d}_{k} + (uint64_t)t{d}_{k} * {R1}u); s{d}_{k} = 0;")
         self.pend[d], self.tzero[d] = 0, False
 
     def add_fp4(self, d: int, expr: str) -> None:
