@@ -6,7 +6,7 @@ hard part 1).  SYN-AIR has the same *shape* — three register groups (accum, co
 degree-5 constraints gated by code selectors, an accum group that is a grand product over Fp4 driven by
 Fiat-Shamir `mix` globals — so every HAL op and the whole DEEP-ALI + FRI protocol is exercised, and a
 random trace is made satisfying by construction.  The witness definition lives in DESIGN.md §SYN-AIR and is
-implemented twice: oracle/circuit.c (CPU) and zeth_amd/csrc/witgen.hip (HIP).
+implemented twice: oracle/circuit.c (CPU) and zeth_amd/csrc/circuit.hip (HIP, `k_syn_*`).
 
 Columns (n rows, A = n - zk_cycles active rows):
   code : c0 active, c1 first, c2 body (active & !first), c3 row index, c4 last (row A-1), c5.. public noise

@@ -455,8 +455,8 @@ extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_bu
     const Fp three_n = fp_pow(fp_encode(3), n), i4 = Fp::raw(ctx->rou_fwd[2]);
     Fp cur = Fp::one();
     for (int k = 0; k < 4; k++) { a.zinv[k] = fp_inv(three_n * cur - Fp::one()).v; cur = cur * i4; }
-    zkh_buf* pows = nullptr;
-    ZKH_TRY(new_buf(ctx, 4 * (size_t)c->n_mix_pows, false, &pows));
+    Tmp pows;
+    ZKH_TRY(new_buf(ctx, 4 * (size_t)c->n_mix_pows, false, pows.out()));
     const uint32_t one[4] = {R1, 0, 0, 0};
     ZKH_TRY(launch_ext_powers(ctx, pows->ptr(), one, poly_mix, c->n_mix_pows));
     a.mix_pows = pows->ptr();
@@ -470,7 +470,7 @@ extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_bu
             void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size, HIP_LAUNCH_PARAM_END};
             const hipError_t e = hipModuleLaunchKernel(c->jit_kernels[part], (unsigned)((dom + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream,
                                                        nullptr, config);
-            if (e != hipSuccess) { zkh_release(pows); return make_err("eval_check: launching attached kernel %zu: %s", part, hipGetErrorString(e)); }
+            if (e != hipSuccess) return make_err("eval_check: launching attached kernel %zu: %s", part, hipGetErrorString(e));
         }
     } else if (c->compiled && !use_interpreter) {
         ProfScope prof(ctx, "eval_check", 4.0 * total_w * dom + 16.0 * dom);
@@ -479,20 +479,17 @@ extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_bu
             c->compiled->parts[part](a, ctx->stream);
         }
     } else {
-        if (!c->interp_ok) {
-            zkh_release(pows);
+        if (!c->interp_ok)
             return make_err("eval_check: the step list has more live values than the interpreter's LDS holds and no compiled kernel is attached");
-        }
         const size_t lds = ((size_t)c->n_fp_slots * 4 + (size_t)c->n_mix_slots * 16) * INTERP_THREADS;
         ProfScope prof(ctx, "eval_check_interp", 4.0 * total_w * dom + 16.0 * dom);
         if (lds > 64 * 1024) {
             const hipError_t e = hipFuncSetAttribute((const void*)k_eval_check_interp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) { zkh_release(pows); return make_err("eval_check: %zu bytes of LDS for the interpreter: %s", lds, hipGetErrorString(e)); }
+            if (e != hipSuccess) return make_err("eval_check: %zu bytes of LDS for the interpreter: %s", lds, hipGetErrorString(e));
         }
         k_eval_check_interp<<<(unsigned)((dom + INTERP_THREADS - 1) / INTERP_THREADS), INTERP_THREADS, lds, ctx->stream>>>(
             a, c->d_prog, (uint32_t)c->prog.size(), c->d_taps, c->n_fp_slots, c->ret_slot);
     }
-    zkh_release(pows);
     return last_launch_error("eval_check");
 }
 
@@ -518,28 +515,24 @@ extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t
     ZKH_REQUIRE(n_pub == 0 || pub, "syn_witgen: the circuit has %u public input words but none were given", n_pub);
     for (uint32_t k = 0; k < n_pub; k++) ZKH_REQUIRE(pub[k] < P, "syn_witgen: public input %u is not a reduced element", k);
     ZKH_TRY(zkh_syn_code(ctx, c, po2, zk_cycles, code));
-    zkh_buf *last = nullptr, *dpub = nullptr;
-    ZKH_TRY(new_buf(ctx, 1, false, &last));
-    if (n_pub) ZKH_TRY(zkh_copy_from(ctx, "pub", pub, n_pub, &dpub));
+    Tmp last, dpub;
+    ZKH_TRY(new_buf(ctx, 1, false, last.out()));
+    if (n_pub) ZKH_TRY(zkh_copy_from(ctx, "pub", pub, n_pub, dpub.out()));
     const unsigned bx = (unsigned)((n + 255) / 256);
     k_syn_data<<<bx, 256, 0, ctx->stream>>>(data->ptr(), wd, (uint32_t)n, A, seed, noise_seed, dpub ? dpub->ptr() : nullptr, n_pub);
-    if (dpub) zkh_release(dpub);
     {
         const unsigned chunks = (A + 1023) / 1024;
-        zkh_buf* totals = nullptr;
-        ZKH_TRY(new_buf(ctx, chunks, false, &totals));
+        Tmp totals;
+        ZKH_TRY(new_buf(ctx, chunks, false, totals.out()));
         uint32_t* scol = data->ptr() + (size_t)(wd - 1) * n;
         k_prefix_sum_chunks<<<chunks, 1024, 0, ctx->stream>>>(scol, A, totals->ptr());
         k_prefix_sum_fp<<<1, 1024, 0, ctx->stream>>>(totals->ptr(), chunks, last->ptr());
         k_prefix_sum_carry<<<chunks, 1024, 0, ctx->stream>>>(scol, A, totals->ptr());
-        zkh_release(totals);
     }
     ZKH_TRY(last_launch_error("syn_witgen"));
     out_global[1] = out_global[2] = out_global[3] = 0;
     for (uint32_t k = 0; k < n_pub; k++) out_global[4 + k] = pub[k];
-    const char* err = zkh_read(ctx, last, out_global, 0, 1);
-    zkh_release(last);
-    return err;
+    return zkh_read(ctx, last, out_global, 0, 1);
 }
 extern "C" const char* zkh_syn_accum(zkh_ctx* ctx, const zkh_circuit* c, size_t po2, size_t zk_cycles, uint64_t noise_seed,
                                      const zkh_buf* data, const uint32_t* mix_global, zkh_buf* accum) {
@@ -547,9 +540,9 @@ extern "C" const char* zkh_syn_accum(zkh_ctx* ctx, const zkh_circuit* c, size_t 
     const size_t n = (size_t)1 << po2;
     const uint32_t wa = c->group_size[GROUP_ACCUM], wd = c->group_size[GROUP_DATA], A = (uint32_t)(n - zk_cycles), k = wa / 4;
     ZKH_REQUIRE(accum->len == (size_t)wa * n && data->len == (size_t)wd * n, "syn_accum: buffer shape mismatch");
-    zkh_buf *mix = nullptr, *terms = nullptr;
-    ZKH_TRY(zkh_copy_from(ctx, "mix", mix_global, wa, &mix));
-    ZKH_TRY(new_buf(ctx, 4 * (size_t)k * n, false, &terms));
+    Tmp mix, terms;
+    ZKH_TRY(zkh_copy_from(ctx, "mix", mix_global, wa, mix.out()));
+    ZKH_TRY(new_buf(ctx, 4 * (size_t)k * n, false, terms.out()));
     const unsigned bx = (unsigned)((n + 255) / 256);
     {
         ProfScope prof(ctx, "syn_accum_terms", (4.0 + 16.0) * k * n);
@@ -560,6 +553,6 @@ extern "C" const char* zkh_syn_accum(zkh_ctx* ctx, const zkh_circuit* c, size_t 
         ProfScope prof(ctx, "syn_accum_store", (16.0 + 16.0) * k * n);
         k_syn_accum_store<<<dim3(bx, k), 256, 0, ctx->stream>>>(accum->ptr(), terms->ptr(), (uint32_t)n, A, noise_seed);
     }
-    zkh_release(mix); zkh_release(terms);
+
     return last_launch_error("syn_accum");
 }

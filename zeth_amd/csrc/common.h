@@ -117,6 +117,19 @@ inline void bind_thread(const zkh_ctx* c) { (void)hipSetDevice(c->device); }
 // per-device kernel attributes (dynamic LDS sizes); set when a context is created on the device (ntt.hip)
 const char* ntt_device_init(zkh_ctx* c);
 
+// Scoped temporary buffer of an op: released on every return path (ZKH_TRY / ZKH_REQUIRE leave early on errors).
+struct Tmp {
+    zkh_buf* b = nullptr;
+    Tmp() {}
+    Tmp(const Tmp&) = delete;
+    Tmp& operator=(const Tmp&) = delete;
+    ~Tmp() { if (b) zkh_release(b); }
+    zkh_buf** out() { if (b) { zkh_release(b); b = nullptr; } return &b; }
+    operator zkh_buf*() const { return b; }
+    zkh_buf* operator->() const { return b; }
+    explicit operator bool() const { return b != nullptr; }
+};
+
 // Launch helper: optional HIP-event bracket on the ctx stream (what bench.py's roofline uses).
 struct ProfScope {
     zkh_ctx* c;

@@ -457,28 +457,28 @@ extern "C" const char* zkh_scatter(zkh_ctx* c, zkh_buf* into, const uint32_t* in
     if (!n_val) return nullptr;
     for (size_t j = 0; j < n_val; j++) ZKH_REQUIRE(index[j] < into->len, "scatter: index %u out of range", index[j]);
     (void)offsets;
-    zkh_buf *di = nullptr, *dv = nullptr;
-    ZKH_TRY(zkh_copy_from(c, "scatter_index", index, n_val, &di));
-    ZKH_TRY(zkh_copy_from(c, "scatter_values", values, n_val, &dv));
+    Tmp di, dv;
+    ZKH_TRY(zkh_copy_from(c, "scatter_index", index, n_val, di.out()));
+    ZKH_TRY(zkh_copy_from(c, "scatter_values", values, n_val, dv.out()));
     {
         ProfScope ps(c, "scatter", 12.0 * n_val);
         k_scatter<<<blocks_for(n_val), TB, 0, c->stream>>>(into->ptr(), di->ptr(), dv->ptr(), n_val);
     }
-    zkh_release(di); zkh_release(dv);
+
     return last_launch_error("scatter");
 }
 extern "C" const char* zkh_combos_prepare(zkh_ctx* c, zkh_buf* combos, const uint32_t* pos, const uint32_t* vals,
                                           size_t n) {
     if (!n) return nullptr;
     for (size_t k = 0; k < n; k++) ZKH_REQUIRE((size_t)pos[k] * 4 + 4 <= combos->len, "combos_prepare: position out of range");
-    zkh_buf *dp = nullptr, *dv = nullptr;
-    ZKH_TRY(zkh_copy_from(c, "prep_pos", pos, n, &dp));
-    ZKH_TRY(zkh_copy_from(c, "prep_val", vals, 4 * n, &dv));
+    Tmp dp, dv;
+    ZKH_TRY(zkh_copy_from(c, "prep_pos", pos, n, dp.out()));
+    ZKH_TRY(zkh_copy_from(c, "prep_val", vals, 4 * n, dv.out()));
     {
         ProfScope ps(c, "combos_prepare", 36.0 * n);
         k_combos_prepare<<<blocks_for(n), TB, 0, c->stream>>>((uint4*)combos->ptr(), dp->ptr(), (const uint4*)dv->ptr(), n);
     }
-    zkh_release(dp); zkh_release(dv);
+
     return last_launch_error("combos_prepare");
 }
 extern "C" const char* zkh_merkle_open(zkh_ctx* c, const zkh_buf* matrix, const zkh_buf* nodes, size_t rows, size_t cols,
@@ -491,13 +491,13 @@ extern "C" const char* zkh_merkle_open(zkh_ctx* c, const zkh_buf* matrix, const 
     ZKH_REQUIRE(out->len >= wpq * n_idx, "merkle_open: output too small (%zu < %zu)", out->len, wpq * n_idx);
     for (size_t i = 0; i < n_idx; i++) ZKH_REQUIRE(idx[i] < rows, "merkle_open: index out of range");
     if (!n_idx) return nullptr;
-    zkh_buf* di = nullptr;
-    ZKH_TRY(zkh_copy_from(c, "open_idx", idx, n_idx, &di));
+    Tmp di;
+    ZKH_TRY(zkh_copy_from(c, "open_idx", idx, n_idx, di.out()));
     {
         ProfScope ps(c, "merkle_open", 8.0 * wpq * n_idx);
         k_merkle_open<<<(unsigned)n_idx, TB, 0, c->stream>>>(out->ptr(), matrix->ptr(), nodes->ptr(), di->ptr(), rows, cols,
                                                             top_size, wpq);
     }
-    zkh_release(di);
+
     return last_launch_error("merkle_open");
 }

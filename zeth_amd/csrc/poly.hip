@@ -456,9 +456,9 @@ static const char* evaluate_any_impl(zkh_ctx* c, const zkh_buf* coeffs, size_t p
     if (bitrev) ZKH_REQUIRE(((size_t)1 << log_n) == po && log_n >= 14 && log_n <= 31,
                             "batch_evaluate_any_bitrev: column length must be a power of two >= 2^14");
     const uint32_t n_chunks = (uint32_t)ceil_div(po, EV_CH);
-    zkh_buf *partial = nullptr, *tab = nullptr;
-    ZKH_TRY(new_buf(c, 4 * n_eval * n_chunks, false, &partial));
-    ZKH_TRY(new_buf(c, 4 * n_eval * (size_t)EV_TAB, false, &tab));
+    Tmp partial, tab;
+    ZKH_TRY(new_buf(c, 4 * n_eval * n_chunks, false, partial.out()));
+    ZKH_TRY(new_buf(c, 4 * n_eval * (size_t)EV_TAB, false, tab.out()));
     {
         // §8d: each coefficient column is streamed once for all the points it is evaluated at
         ProfScope prof(c, "batch_evaluate_any", 4.0 * po * (double)(n_eval < poly_count ? n_eval : poly_count));
@@ -473,8 +473,6 @@ static const char* evaluate_any_impl(zkh_ctx* c, const zkh_buf* coeffs, size_t p
         }
         k_eval_final<<<(unsigned)ceil_div(n_eval, TB), TB, 0, c->stream>>>(out->ptr(), partial->ptr(), n_chunks, (uint32_t)n_eval);
     }
-    zkh_release(tab);
-    zkh_release(partial);
     return last_launch_error("batch_evaluate_any");
 }
 extern "C" const char* zkh_batch_evaluate_any(zkh_ctx* c, const zkh_buf* coeffs, size_t poly_count, const zkh_buf* which,
@@ -499,15 +497,14 @@ extern "C" const char* zkh_mix_poly_coeffs(zkh_ctx* c, zkh_buf* out, const uint3
     ZKH_REQUIRE(in->len == input_size * count && combos->len >= input_size, "mix_poly_coeffs: input shape mismatch");
     ZKH_REQUIRE(out->len % (4 * count) == 0, "mix_poly_coeffs: output is not a whole number of ExtElem columns");
     if (!input_size || !count) return nullptr;
-    zkh_buf* pw = nullptr;
-    ZKH_TRY(new_buf(c, 4 * input_size, false, &pw));
+    Tmp pw;
+    ZKH_TRY(new_buf(c, 4 * input_size, false, pw.out()));
     {
         ProfScope prof(c, "mix_poly_coeffs", 4.0 * in->len + 32.0 * count * 2);
         k_ext_powers<<<(unsigned)ceil_div(input_size, TB), TB, 0, c->stream>>>(pw->ptr(), to_fp4(mix_start), to_fp4(mix), (uint32_t)input_size);
         k_mix_poly_coeffs<<<(unsigned)ceil_div(count, TB), TB, 0, c->stream>>>(out->ptr(), in->ptr(), combos->ptr(), pw->ptr(),
                                                                               (uint32_t)input_size, count);
     }
-    zkh_release(pw);
     return last_launch_error("mix_poly_coeffs");
 }
 
@@ -521,9 +518,9 @@ static const char* divide_round(zkh_ctx* c, zkh_buf* combos, size_t cycles, size
     const size_t BL0 = (size_t)TB * SC_E;
     const size_t n0 = cycles, n1 = ceil_div(n0, BL0), n2 = ceil_div(n1, TB);
     ZKH_REQUIRE(n2 <= TB, "combos_divide: polynomial too long");
-    zkh_buf *t0 = nullptr, *t1 = nullptr, *meta = nullptr;
-    ZKH_TRY(new_buf(c, 4 * n1 * ny, false, &t0));    // level-0 block totals, then S at level-0 block starts
-    ZKH_TRY(new_buf(c, 4 * n2 * ny, false, &t1));    // level-1 block totals, then S at level-1 block starts
+    Tmp t0, t1, meta;
+    ZKH_TRY(new_buf(c, 4 * n1 * ny, false, t0.out()));    // level-0 block totals, then S at level-0 block starts
+    ZKH_TRY(new_buf(c, 4 * n2 * ny, false, t1.out()));    // level-1 block totals, then S at level-1 block starts
     // per-launch metadata: weights of the three levels (z, z^256, z^65536), polynomial offsets, per-y offsets into t0 / t1
     std::vector<uint32_t> m(12 * ny + 5 * ny);
     for (size_t y = 0; y < ny; y++) {
@@ -535,7 +532,7 @@ static const char* divide_round(zkh_ctx* c, zkh_buf* combos, size_t cycles, size
         m[15 * ny + y] = rem_idx[y];
         m[16 * ny + y] = quot_off ? quot_off[y] : poly_off[y];
     }
-    ZKH_TRY(new_buf(c, m.size(), false, &meta));
+    ZKH_TRY(new_buf(c, m.size(), false, meta.out()));
     ZKH_TRY(h2d(c, meta->ptr(), m.data(), m.size()));
     const uint32_t *w0 = meta->ptr(), *w1 = w0 + 4 * ny, *w2 = w0 + 8 * ny, *poff = w0 + 12 * ny, *t0off = w0 + 13 * ny,
                    *t1off = w0 + 14 * ny, *ridx = w0 + 15 * ny, *qoff = w0 + 16 * ny;
@@ -551,7 +548,6 @@ static const char* divide_round(zkh_ctx* c, zkh_buf* combos, size_t cycles, size
         k_suffix_scan<false, 1><<<dim3((unsigned)n2, (unsigned)ny), TB, 0, c->stream>>>(t0->ptr(), t0->ptr(), n1, w1, t1->ptr(), n2, 0, nullptr, t0off, t0off, 4 * n2, nullptr);
         k_suffix_scan<false, SC_E><<<dim3((unsigned)n1, (unsigned)ny), TB, 0, c->stream>>>(qbase, combos->ptr(), n0, w0, t0->ptr(), n1, 1, rem_out->ptr(), poff, qoff, 4 * n1, ridx);
     }
-    zkh_release(t0); zkh_release(t1); zkh_release(meta);
     return last_launch_error("combos_divide");
 }
 
@@ -623,10 +619,10 @@ extern "C" const char* zkh_combos_divide_all(zkh_ctx* c, zkh_buf* combos, size_t
             memcpy(m_w + 4 * p, &w, 16); memcpy(m_pts + 4 * p, pts + 4 * p, 16);
         }
     }
-    zkh_buf *quot = nullptr, *vals = nullptr, *dmeta = nullptr;
-    ZKH_TRY(new_buf(c, 4 * n_pairs * cycles, false, &quot));
-    ZKH_TRY(new_buf(c, 4 * n_pairs, false, &vals));
-    ZKH_TRY(new_buf(c, meta.size(), false, &dmeta));
+    Tmp quot, vals, dmeta;
+    ZKH_TRY(new_buf(c, 4 * n_pairs * cycles, false, quot.out()));
+    ZKH_TRY(new_buf(c, 4 * n_pairs, false, vals.out()));
+    ZKH_TRY(new_buf(c, meta.size(), false, dmeta.out()));
     ZKH_TRY(h2d(c, dmeta->ptr(), meta.data(), meta.size()));
     ZKH_TRY(divide_round(c, combos, cycles, n_pairs, poly_off.data(), zs.data(), ridx.data(), vals, quot, quot_off.data()));
     {
@@ -637,7 +633,6 @@ extern "C" const char* zkh_combos_divide_all(zkh_ctx* c, zkh_buf* combos, size_t
         k_divided_differences<<<(unsigned)ceil_div(n_combos, 64), 64, 0, c->stream>>>(rem_out->ptr(), vals->ptr(), d + 4 * n_combos + 4 * n_pairs,
                                                                                       d + n_combos, d + 2 * n_combos, (uint32_t)n_combos);
     }
-    zkh_release(quot); zkh_release(vals); zkh_release(dmeta);
     return last_launch_error("combos_divide_all");
 }
 
@@ -648,9 +643,9 @@ const char* prefix_products_batched(zkh_ctx* c, uint32_t* io, size_t n0, size_t 
     ZKH_REQUIRE(n0 <= ((size_t)1 << 24) && count <= 65535, "prefix_products: buffer too long");
     const size_t n1 = ceil_div(n0, (size_t)TB * SC_E), n2 = ceil_div(n1, TB);
     ZKH_REQUIRE(n2 <= TB, "prefix_products: buffer too long");
-    zkh_buf *t0 = nullptr, *t1 = nullptr;
-    ZKH_TRY(new_buf(c, 4 * n1 * count, false, &t0));
-    ZKH_TRY(new_buf(c, 4 * n2 * count, false, &t1));
+    Tmp t0, t1;
+    ZKH_TRY(new_buf(c, 4 * n1 * count, false, t0.out()));
+    ZKH_TRY(new_buf(c, 4 * n2 * count, false, t1.out()));
     {
         ProfScope prof(c, "prefix_products", 32.0 * n0 * count);
         const unsigned ny = (unsigned)count;
@@ -660,7 +655,6 @@ const char* prefix_products_batched(zkh_ctx* c, uint32_t* io, size_t n0, size_t 
         k_prefix_prod<false, 1><<<dim3((unsigned)n2, ny), TB, 0, c->stream>>>(t0->ptr(), t0->ptr(), n1, t1->ptr(), 4 * n1, 4 * n1, 4 * n2);  // inclusive over level-0 totals
         k_prefix_prod<false, SC_E><<<dim3((unsigned)n1, ny), TB, 0, c->stream>>>(io, io, n0, t0->ptr(), col_stride, col_stride, 4 * n1);
     }
-    zkh_release(t0); zkh_release(t1);
     return last_launch_error("prefix_products");
 }
 }  // namespace zkh
