@@ -52,17 +52,27 @@ def stage_digests(lib, desc, po2, seed=SEED, noise=NOISE, zk=ZK):
 
 
 def main():
-    po2s = [int(a) for a in sys.argv[1:]] or [20]
+    """usage: make_golden_large.py [shape:po2 ...]   (default syn_a:20 syn_heavy:20; shapes: syn_a, syn_heavy)"""
+    from zeth_amd.circuits import syn_heavy
+    shapes = {"syn_a": syn_air.syn_a, "syn_heavy": syn_heavy.syn_heavy}
+    todo = [a.split(":") for a in sys.argv[1:]] or [["syn_a", "20"], ["syn_heavy", "20"]]
     lib = zko.load()
     path = os.path.join(HERE, "large_digests.json")
     out = {"generator": "tests/golden/make_golden_large.py (CPU oracle, stage hook)", "cases": []}
-    for po2 in po2s:
-        seal, stages, dt = stage_digests(lib, syn_air.syn_a(), po2)
-        out["cases"].append({"shape": "syn_a", "po2": po2, "zk_cycles": ZK, "seed": SEED, "noise_seed": NOISE,
+    try:                                      # keep the cases that are not being regenerated
+        with open(path) as fh:
+            keep = [c for c in json.load(fh)["cases"] if [c["shape"], str(c["po2"])] not in todo]
+        out["cases"].extend(keep)
+    except (OSError, ValueError, KeyError):
+        pass
+    for shape, po2 in todo:
+        po2 = int(po2)
+        seal, stages, dt = stage_digests(lib, shapes[shape](), po2)
+        out["cases"].append({"shape": shape, "po2": po2, "zk_cycles": ZK, "seed": SEED, "noise_seed": NOISE,
                              "oracle_seconds": round(dt, 1), "threads": int(lib.zko_num_threads()),
                              "seal_words": int(seal.size), "seal_sha256": hashlib.sha256(seal.astype("<u4").tobytes()).hexdigest(),
                              "seal_head": [int(x) for x in seal[:8]], "stages": stages})
-        print(f"po2 {po2}: {dt:.1f} s, {len(stages)} stages, seal {seal.size} words", flush=True)
+        print(f"{shape} po2 {po2}: {dt:.1f} s, {len(stages)} stages, seal {seal.size} words", flush=True)
     with open(path, "w") as fh:
         json.dump(out, fh, indent=1)
     print("wrote", path)

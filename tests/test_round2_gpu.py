@@ -51,11 +51,13 @@ def _commit_group_stagewise(hal, trace, w, n, stages, name):
 
 @pytest.mark.parametrize("case", _large_cases(), ids=lambda c: f"{c['shape']}-po2-{c['po2']}")
 def test_baseline_shape_stage_by_stage_and_whole_seal(hal, case):
-    """BASELINE config 2's exact shape.  The oracle sealed this segment once on the CPU (tests/golden/make_golden_large.py,
-    minutes) and recorded a SHA-256 of every intermediate buffer; here the same pipeline runs through the C ABI op by op:
+    """BASELINE config 2's exact shape, under SYN-A and under the heavy constraint system.  The oracle sealed each segment
+    once on the CPU (tests/golden/make_golden_large.py, minutes) and recorded a SHA-256 of every intermediate buffer; here the
+    same pipeline runs through the C ABI op by op:
     witgen, iNTT + zk_shift (208 x 2^20), expand-NTT (208 x 2^20 -> 2^22), hash_rows (208 cols x 2^22 rows), the full
     Merkle fold, accum, eval_check (2^22 points), the check group, mix_poly_coeffs — and finally the whole seal."""
-    desc = getattr(syn_air, case["shape"])()
+    from zeth_amd.circuits import syn_heavy
+    desc = {"syn_a": syn_air.syn_a, "syn_heavy": syn_heavy.syn_heavy}[case["shape"]]()
     po2, zk = case["po2"], case["zk_cycles"]
     st = case["stages"]
     n, dom = 1 << po2, 4 << po2
