@@ -270,3 +270,60 @@ def test_cached_input_reader_feeds_the_segment_list(tmp_path):
     assert [s.po2 for s in b.segments(20)] == [20] * 5 + [17]
     with pytest.raises(ValueError, match="StatelessInput"):
         read_cached_input(str(tmp_path), "0xbad")
+
+
+@pytest.mark.parametrize("world,n_leaves", [(2, 5), (3, 7), (4, 16), (8, 21), (8, 64), (5, 1), (8, 3)])
+def test_join_executor_any_world_size_matches_single_rank(world, n_leaves):
+    """The distributed join schedule for G ranks (threads + queues standing in for the gloo point-to-point transport, a
+    deterministic fake 'prover'): every join runs exactly once, on the rank that holds its left child; only right children
+    travel; the root lands on rank 0 and equals the single-rank tree — for world sizes up to the 8 GPUs of the north star."""
+    import hashlib
+    import queue
+    import threading
+    from zeth_amd.host import JoinExecutor, join_schedule
+
+    def fake_receipt(index, po2, payload: bytes):
+        words = np.frombuffer(hashlib.sha256(payload).digest(), dtype=np.uint32).copy()
+        return SegmentReceipt(seal=words, index=index, po2=po2)
+
+    def claim_of(rec, is_leaf):
+        return np.frombuffer(hashlib.sha256(rec.seal.tobytes() + bytes([is_leaf])).digest(), dtype=np.uint32)[:8].copy() % 2013265921
+
+    def prove_join(seg):
+        return fake_receipt(seg.index, seg.po2, np.asarray(seg.pub, np.uint32).tobytes() + seg.seed.to_bytes(8, "little"))
+
+    leaves = [fake_receipt(i, 20, b"leaf%d" % i) for i in range(n_leaves)]
+    single_done, single_root = JoinExecutor(prove_join, claim_of, 0, 1, noise_seed=1).run(n_leaves, dict(enumerate(leaves)))
+    chan = {(s, d): queue.Queue() for s in range(world) for d in range(world)}
+    sent = []
+    results = [None] * world
+
+    def rank_main(r):
+        def send(obj, dst):
+            sent.append((r, dst))
+            chan[(r, dst)].put(obj)
+
+        def recv(src):
+            return chan[(src, r)].get(timeout=30)
+        ex = JoinExecutor(prove_join, claim_of, r, world, noise_seed=1, send=send, recv=recv)
+        results[r] = ex.run(n_leaves, {i: leaves[i] for i in range(r, n_leaves, world)})
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=60)
+        assert not t.is_alive()
+    sched = join_schedule(n_leaves, world)
+    merged = {}
+    for r, (done, root) in enumerate(results):
+        assert set(done) == {(t.level, t.index) for lvl in sched for t in lvl if t.device == r}
+        merged.update(done)
+        assert (root is not None) == (r == 0)               # the root always lands where leaf 0 was produced
+    assert len(merged) == n_leaves - 1 == len(single_done)
+    for k, rec in single_done.items():
+        assert np.array_equal(merged[k].seal, rec.seal)
+    if n_leaves > 1:
+        assert np.array_equal(results[0][1].seal, single_root.seal)
+    # only right children whose owner differs from the join's rank were sent
+    assert len(sent) == sum(1 for lvl in sched for t in lvl if t.right_owner != t.device)
