@@ -655,19 +655,23 @@ def add_roofline(line, prof, ref, args, inflight, widths, n):
                 break
         except Exception:
             continue
-    line["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                        "avg_launch_ms": per_launch_ms,
-                        "avg_launch_ms_unshared": per_launch_ms_unshared,
-                        "achieved_unshared": per_launch_bytes / (per_launch_ms_unshared * 1e-3) / 1e9,
+    # Primary figures = the kernel's own launch duration (HIP-event brackets of one seal that ran ALONE right after the timed
+    # region: what `rocprofv3 --kernel-trace --stats` reports per dispatch, profiles/r02_kernel_stats*.csv).  With several
+    # seals in flight the brackets of the timed region also contain the time a launch spent queued behind the other streams'
+    # kernels; those are kept as *_timed_region.
+    ach_unshared = per_launch_bytes / (per_launch_ms_unshared * 1e-3) / 1e9
+    line["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": ach_unshared, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": ach_unshared / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                        "avg_launch_ms": per_launch_ms_unshared,
+                        "avg_launch_ms_timed_region": per_launch_ms, "achieved_timed_region": ach,
                         "alg_bytes_per_launch": per_launch_bytes,
                         "share_of_kernel_time": unshared[dom_name]["total_ms"] / sum(p["total_ms"] for p in unshared.values()),
                         "launches_overlap": inflight > 1,
                         "note": "dominant kernel is integer-VALU-bound by construction (Poseidon2: ~21 Montgomery "
-                                "products per absorbed byte); HBM fraction is reported as the contract asks; with "
-                                "inflight_per_gpu > 1 kernels of different seals overlap, so avg_launch_ms (timed region) "
-                                "includes time shared with other streams; *_unshared comes from one extra seal run "
-                                "alone after the timed region"}
+                                "products per absorbed byte); HBM fraction is reported as the contract asks; avg_launch_ms is the "
+                                "kernel's own duration (one seal alone on the GPU, measured live after the timed region); with "
+                                "inflight_per_gpu > 1 the HIP-event brackets of the timed region (*_timed_region) also include time "
+                                "queued behind other streams' kernels"}
     if dom["name"] == "hash_rows":
         # VALU view of the same kernel: permutations per launch x modelled issue cycles per 64-lane permutation
         # (8 full rounds x 2368 + 7 partial groups x 1576 + 1024 + 138 cycles) against 1024 SIMDs at 2.4 GHz
