@@ -40,7 +40,7 @@ inline const char* make_err(const char* fmt, ...) {
         if (!(cond)) return zkh::make_err(__VA_ARGS__); \
     } while (0)
 
-constexpr int ZKH_P2_PTAB = 146;            // partial-round table, layout in poseidon2.h (P2_TAB_WORDS)
+constexpr int ZKH_P2_PTAB = 414;            // partial-round table, layout in poseidon2.h (P2_TAB_WORDS)
 constexpr int TW_BITS = 12;                 // two-level twiddle tables: w_{2^24}^(hi*4096 + lo)
 constexpr int TW_SIZE = 1 << TW_BITS;
 constexpr int MAX_LOG_N = 2 * TW_BITS;      // largest NTT / coset-shift domain supported (2^24)

@@ -112,7 +112,7 @@ extern "C" const char* zkh_poseidon2_set_constants(zkh_ctx* c, const uint32_t* r
     bind_thread(c);
     std::vector<uint32_t> r(24 * 29), d(ZKH_P2_PTAB);
     for (int i = 0; i < 24 * 29; i++) r[i] = fp_encode(rc[i]).v - P;   // stored as rc - P: see poseidon2.h sbox7_rc
-    poseidon2_partial_table(d.data(), diag);
+    poseidon2_partial_table(d.data(), rc, diag);
     memcpy(c->h_rc, r.data(), sizeof c->h_rc);
     memcpy(c->h_diag, d.data(), sizeof c->h_diag);
     ZKH_HIP(hipStreamSynchronize(c->stream));

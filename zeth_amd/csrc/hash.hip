@@ -35,14 +35,18 @@ __global__ __launch_bounds__(256, 4) void k_hash_rows(uint32_t* __restrict__ out
         const uint32_t* bsrc = src + (size_t)b * RATE * rows;
 #pragma unroll
         for (int i = 0; i < RATE; i++) s[i] = bsrc[(size_t)i * rows];
-        poseidon2_mix(s, rc, diag);
+        poseidon2_mix_raw(s, rc, diag);
+#pragma unroll
+        for (int i = RATE; i < CELLS; i++) s[i] = p2_finish(s[i], diag);     // the capacity is all the next block keeps
     }
     if (tail || cols == 0) {
         const uint32_t* tsrc = src + (size_t)full * RATE * rows;
 #pragma unroll
         for (int i = 0; i < RATE; i++) s[i] = (uint32_t)i < tail ? tsrc[(size_t)i * rows] : 0u;
-        poseidon2_mix(s, rc, diag);
+        poseidon2_mix_raw(s, rc, diag);
     }
+#pragma unroll
+    for (int i = 0; i < OUT; i++) s[i] = p2_finish(s[i], diag);
     uint4* o = (uint4*)(out + r * 8);
     o[0] = make_uint4(s[0], s[1], s[2], s[3]);
     o[1] = make_uint4(s[4], s[5], s[6], s[7]);
@@ -60,7 +64,9 @@ __global__ __launch_bounds__(256, 4) void k_hash_fold(uint32_t* __restrict__ io,
     s[8] = c.x; s[9] = c.y; s[10] = c.z; s[11] = c.w; s[12] = d.x; s[13] = d.y; s[14] = d.z; s[15] = d.w;
 #pragma unroll
     for (int k = RATE; k < CELLS; k++) s[k] = 0;
-    poseidon2_mix(s, rc, diag);
+    poseidon2_mix_raw(s, rc, diag);
+#pragma unroll
+    for (int k = 0; k < OUT; k++) s[k] = p2_finish(s[k], diag);
     uint4* o = (uint4*)(io + (output_size + i) * 8);
     o[0] = make_uint4(s[0], s[1], s[2], s[3]);
     o[1] = make_uint4(s[4], s[5], s[6], s[7]);

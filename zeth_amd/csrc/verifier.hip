@@ -16,7 +16,7 @@ namespace {
 struct Tables { uint32_t rc[24 * 29]; uint32_t pc[ZKH_P2_PTAB]; };
 void make_tables(Tables& t, const uint32_t* rc, const uint32_t* diag) {
     for (int i = 0; i < 24 * 29; i++) t.rc[i] = fp_encode(rc[i]).v - P;
-    poseidon2_partial_table(t.pc, diag);
+    poseidon2_partial_table(t.pc, rc, diag);
 }
 struct Digest {
     uint32_t w[8];
