@@ -1,5 +1,5 @@
 set -u
-O=gpurun_out/r2n; mkdir -p $O
+O=gpurun_out/r2o; mkdir -p $O
 export TMPDIR=/tmp
 ( time timeout 600 python -m pytest tests -m gpu -q -x -k "hash or merkle or poseidon or seal or fold" ) > $O/pytest.log 2>&1
 echo "pytest rc=$?" >> $O/pytest.log

@@ -111,6 +111,17 @@ ZKH_HD void m_ext_f64(uint32_t (&s)[CELLS], double (&d)[CELLS]) {
         s[i] = (uint32_t)((uint64_t)mad_i64_k(m, (int32_t)P, t) >> 32);
     }
 }
+// t + (a mod P) for a 64-bit accumulator a = hi 2^32 + lo:  hi R + lo  (one multiply-add, one add)
+ZKH_HD uint64_t fold64(uint64_t a, uint64_t t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"((uint32_t)(a >> 32)), "s"(R1), "v"(t));
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %3" : "=v"(t), "=s"(carry) : "v"((uint32_t)a), "v"(d));
+    return t;
+#else
+    return t + (a >> 32) * R1 + (uint32_t)a;
+#endif
+}
 // (v + rcf)^7 / R^6 in (-P, P): v + rcf is a signed operand with |.| <= P + 64 (see above); no canonicalisation.
 ZKH_HD int32_t sbox7_lazy(uint32_t v, uint32_t rcf) {
     const int32_t sx = (int32_t)(v + rcf);
@@ -178,11 +189,11 @@ ZKH_HD void poseidon2_mix_raw(uint32_t (&s)[CELLS], const uint32_t* __restrict__
     // three rounds collapse to  s_i <- S2 + d_i S1 + d_i^2 S0 + d_i^3 s_i  (ONE reduction for three products instead
     // of three).  The sums the cell-0 chain needs in between come from weighted sums taken once per group:
     //   A = sum s_i, D1 = sum d_i s_i, D2 = sum d_i^2 s_i  (i >= 1);  A' = 23 S0 + D1;  A'' = 23 S1 + c1 S0 + D2.
-    // Inside this section cells 1..23 are SIGNED representatives in [-P, P) and the table rows used with them are
-    // centred (|d^k| <= (P-1)/2), which makes the per-cell update one signed reduction with no correction
-    // (|d^3 s + d^2 S0 + d S1| <= (P-1)P/2 + 2 ((P-1)/2)^2 < P 2^31 with S0, S1 centred) plus one sign-selected add
-    // of S2 or S2 - P; sums of signed products start from the bias P 2^32 (= 0 mod P), which keeps the accumulator a
-    // valid unsigned operand of mont_reduce_wide.  Group 0 reads cells at the entry scale: its rows for the terms in s_i
+    // Inside this section cells 1..23 are SIGNED representatives in (-P, P) and the table rows used with them are
+    // centred (|d^k| <= (P-1)/2), which makes the per-cell update one signed reduction with no correction and no
+    // separate add (bound at the update below); sums of signed products start from the bias P 2^32 (= 0 mod P), which
+    // keeps every accumulator an unsigned word pair.
+    // Group 0 reads cells at the entry scale: its rows for the terms in s_i
     // are d^k rho instead of d^k and its plain sum is multiplied by rho once (same bounds: |s_i| <= P/2 + 64 there).
     const uint32_t* __restrict__ pc = diag;                                   // unsigned rows + c1 + 23
     const int32_t* __restrict__ pcs = (const int32_t*)(diag + P2_TAB_SIGNED); // centred d, d^2, d^3
@@ -191,57 +202,56 @@ ZKH_HD void poseidon2_mix_raw(uint32_t (&s)[CELLS], const uint32_t* __restrict__
 #pragma unroll 1
     for (int grp = 0; grp < PARTIAL / 3; grp++, round += 3) {
         const int32_t* __restrict__ pcg = grp == 0 ? (const int32_t*)(diag + P2_TAB_GROUP0) : pcs;   // rows for terms in s_i
-        // A: 12 + 11 terms s_i * R (|sum| <= 12 P 2^28 = 0.75 P 2^32 < bias), reduced back by the Montgomery step
+        // A: 12 + 11 terms s_i * R (|sum| <= 12 P 2^28 = 0.75 P 2^32 < bias)
         int64_t ta = BIAS, tb = BIAS;
 #pragma unroll
         for (int i = 1; i <= 12; i++) ta = mad_i64_k((int32_t)s[i], R1S, ta);
 #pragma unroll
         for (int i = 13; i < CELLS; i++) tb = mad_i64_k((int32_t)s[i], R1S, tb);
-        uint32_t A = add_mod(mont_reduce_wide((uint64_t)ta), mont_reduce_wide((uint64_t)tb));
-        if (grp == 0) A = mul_mod(A, diag[P2_TAB_KAPPA + 1]);
-        // D1 = sum d_i s_i, D2 = sum d_i^2 s_i as six partial residues each (<= 4 signed products per accumulator,
-        // |sum| <= 2 P^2 < bias).  The partials are never added up on their own: they enter the 64-bit sums that
-        // produce S1 and S2 as r*R terms (r R < P 2^28), so S1 and S2 cost one reduction each.
-        uint32_t r1[6], r2[6];
+        // D1 = sum d_i s_i, D2 = sum d_i^2 s_i as six accumulators each (<= 4 signed products per accumulator,
+        // |sum| <= 2 P^2 < bias, so every accumulator is an unsigned word pair below 1.94 P 2^32).  None of these sums
+        // is reduced on its own: hi 2^32 + lo = hi R + lo (mod P) folds an accumulator into the 64-bit sum that
+        // produces the next state sum with one multiply-add and one add (fold64), so S0, S1 and S2 cost one reduction each.
+        uint64_t a1[6], a2[6];
 #pragma unroll
         for (int c = 0; c < 6; c++) {
-            int64_t a1 = BIAS, a2 = BIAS;
+            int64_t x1 = BIAS, x2 = BIAS;
 #pragma unroll
             for (int i = 1 + 4 * c; i < 5 + 4 * c && i < CELLS; i++) {
-                a1 = mad_i64_k((int32_t)s[i], pcg[i], a1);
-                a2 = mad_i64_k((int32_t)s[i], pcg[CELLS + i], a2);
+                x1 = mad_i64_k((int32_t)s[i], pcg[i], x1);
+                x2 = mad_i64_k((int32_t)s[i], pcg[CELLS + i], x2);
             }
-            r1[c] = mont_reduce_wide((uint64_t)a1); r2[c] = mont_reduce_wide((uint64_t)a2);
+            a1[c] = (uint64_t)x1; a2[c] = (uint64_t)x2;
         }
         const uint32_t d0 = pc[0], c1 = pc[3 * CELLS], m23 = pc[3 * CELLS + 1];
         const uint32_t z0 = sbox7_rc(s[0], rc[round * CELLS]);
-        const uint32_t S0 = add_mod(z0, A);
+        // S0 = z0 + A:  z0 R + 2 (1.75 P 2^28 + 2^32)  <  P 2^32
+        uint32_t S0 = mont_reduce(fold64((uint64_t)tb, fold64((uint64_t)ta, (uint64_t)z0 * R1)));
+        if (grp == 0)      // the cells came in at the entry scale: S0 = z0 + rho sum
+            S0 = add_mod(z0, mul_mod(add_mod(mont_reduce_wide((uint64_t)ta), mont_reduce_wide((uint64_t)tb)), diag[P2_TAB_KAPPA + 1]));
         const uint32_t s0a = mont_reduce_wide(((uint64_t)S0 << 32) + (uint64_t)d0 * z0);
         const uint32_t z1 = sbox7_rc(s0a, rc[(round + 1) * CELLS]);
-        // S1 = z1 + 23 S0 + D1:  z1 R + m23 S0 + sum r1 R  <  P^2 + 7 P 2^28  <  P 2^32
+        // S1 = z1 + 23 S0 + D1:  z1 R + m23 S0 + 6 (1.94 P 2^28 + 2^32)  <  (0.0625 + 0.47 + 0.73) P 2^32  <  2 P 2^32
         uint64_t t1 = (uint64_t)m23 * S0 + (uint64_t)z1 * R1;
 #pragma unroll
-        for (int c = 0; c < 6; c++) t1 += (uint64_t)r1[c] * R1;
-        const uint32_t S1 = mont_reduce(t1);
+        for (int c = 0; c < 6; c++) t1 = fold64(a1[c], t1);
+        const uint32_t S1 = mont_reduce_wide(t1);
         const uint32_t s0b = mont_reduce_wide(((uint64_t)S1 << 32) + (uint64_t)d0 * z1);
         const uint32_t z2 = sbox7_rc(s0b, rc[(round + 2) * CELLS]);
-        // S2 = z2 + 23 S1 + c1 S0 + D2:  < 2 P^2 + 7 P 2^28  <  2 P 2^32
+        // S2 = z2 + 23 S1 + c1 S0 + D2:  < (0.0625 + 0.47 + 0.47 + 0.73) P 2^32  <  2 P 2^32
         uint64_t t2 = (uint64_t)m23 * S1 + (uint64_t)c1 * S0 + (uint64_t)z2 * R1;
 #pragma unroll
-        for (int c = 0; c < 6; c++) t2 += (uint64_t)r2[c] * R1;
+        for (int c = 0; c < 6; c++) t2 = fold64(a2[c], t2);
         const uint32_t S2 = mont_reduce_wide(t2);
         s[0] = mont_reduce_wide(((uint64_t)S2 << 32) + (uint64_t)d0 * z2);
+        // cells 1..23: S2 rides in the accumulator as S2 R, so the signed reduction's output IS the new cell:
+        // |S2 R + d S1 + d^2 S0 + d^3 s| <= (P-1)/2 R + 2 ((P-1)/2)^2 + (P-1)(P-1)/2 = (P-1)(P + 2^27 - 2) < P 2^31.
         const int32_t S0c = center(S0), S1c = center(S1);
-        const uint32_t S2mP = S2 - P;
+        const int64_t acc0 = mad_i64_k(center(S2), R1S, 0);
 #pragma unroll
-        for (int i = 1; i < CELLS; i++) {
-            int32_t r = smont_reduce(mad_i64_k((int32_t)s[i], pcg[2 * CELLS + i],
-                                               mad_i64_k(S0c, pcs[CELLS + i], mad_i64_k(S1c, pcs[i], 0))));   // in (-P, P)
-#if defined(__HIP_DEVICE_COMPILE__)
-            asm("" : "+v"(r));              // keep the sign test a 32-bit compare (hipcc would test the 64-bit sum)
-#endif
-            s[i] = (uint32_t)r + (r < 0 ? S2 : S2mP);                                          // in [-P, P)
-        }
+        for (int i = 1; i < CELLS; i++)
+            s[i] = (uint32_t)smont_reduce(mad_i64_k((int32_t)s[i], pcg[2 * CELLS + i],
+                                                    mad_i64_k(S0c, pcs[CELLS + i], mad_i64_k(S1c, pcs[i], acc0))));   // in (-P, P)
     }
 #pragma unroll
     for (int i = 1; i < CELLS; i++) s[i] = canon((int32_t)s[i]);
