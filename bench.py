@@ -674,13 +674,14 @@ def add_roofline(line, prof, ref, args, inflight, widths, n):
                                 "queued behind other streams' kernels"}
     if dom["name"] == "hash_rows":
         # VALU view of the same kernel: permutations per launch x modelled issue cycles per 64-lane permutation
-        # (8 full rounds x 2368 + 7 partial groups x 1576 + 1024 + 138 cycles) against 1024 SIMDs at 2.4 GHz
+        # (8 full rounds x 1990 + 7 partial groups x 1259 + first M_ext 711 + scale fixes 480 cycles;
+        # 4 cycles per multiply / fp64 / select-class instruction, 2.46 per plain add-class one: tools/ubench_valu.hip) against 1024 SIMDs at 2.4 GHz
         perms = sum(-(-w // 16) for w in (wc, wd, wa, 16)) * 4 * n          # leaves of the 3 trace trees + check tree
         deg = n
         while deg > 256:                                                   # FRI rounds: 4*deg/16 rows of 64 words
             perms += 4 * (4 * deg // 16)
             deg //= 16
-        cyc = 8 * 2368 + 7 * 1576 + 1024 + 138
+        cyc = 8 * 1990 + 7 * 1259 + 711 + 480
         per_seal_ms = unshared[dom_name]["total_ms"] / (1 if ref else args.steps)
         line["roofline"]["valu"] = {"permutations_per_seal": perms, "model_cycles_per_wave_permutation": cyc,
                                     "issue_utilisation_at_2p4GHz": (perms / 64.0) * cyc / (1024 * 2.4e9 * per_seal_ms * 1e-3)}

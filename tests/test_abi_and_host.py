@@ -327,3 +327,14 @@ def test_join_executor_any_world_size_matches_single_rank(world, n_leaves):
         assert np.array_equal(results[0][1].seal, single_root.seal)
     # only right children whose owner differs from the join's rank were sent
     assert len(sent) == sum(1 for lvl in sched for t in lvl if t.right_owner != t.device)
+
+
+def test_poseidon2_fast_form_equals_literal_permutation_at_the_bounds(tmp_path):
+    """tests/cpp/poseidon2_bounds.cpp: the scaled / lazily reduced permutation the kernels run (same header, host build)
+    against a literal 29-round permutation, on edge-valued and random states, round constants and diagonals."""
+    import subprocess
+    exe = tmp_path / "poseidon2_bounds"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "zeth_amd", "csrc"), "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "poseidon2_bounds.cpp"), "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe), "150000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout

@@ -53,6 +53,51 @@ def test_poseidon2_constants_are_data(oracle):
         hal.close()
 
 
+def _restore_shipped_constants(oracle):
+    import re
+    txt = open(zko._ORACLE_DIR + "/../include/zkh_poseidon2_consts.h").read()
+    nums = [int(x, 16) for x in re.findall(r"0x([0-9a-f]{8})u", txt)]
+    oracle.zko_poseidon2_set_constants(np.array(nums[24:], np.uint32), np.array(nums[:24], np.uint32))
+
+
+@pytest.mark.parametrize("rc_fill,diag_fill", [(0, 1), (P - 1, P - 1), (P - 1, (P - 1) // 2), (1, (P + 1) // 2), ((P - 1) // 2, P - 2)])
+def test_poseidon2_edge_constants_and_edge_inputs(oracle, rc_fill, diag_fill):
+    """The kernels carry the sponge state in scaled, lazily reduced forms (poseidon2.h): tables and inputs at the edges
+    of those forms' operand bounds (0, P-1, the centring boundary) must still give the literal oracle's digests."""
+    rng = np.random.default_rng(rc_fill % 1000 + diag_fill % 977)
+    rc = np.full(24 * 29, rc_fill, np.uint32)
+    diag = np.full(24, diag_fill, np.uint32)
+    rows, cols = 256, 37
+    edge = np.array([0, 1, 268435454, P - 1, (P - 1) // 2, (P + 1) // 2, P - 2], np.uint32)   # every u32 < P is a Montgomery word
+    mats = [np.zeros(rows * cols, np.uint32), np.full(rows * cols, P - 1, np.uint32),
+            edge[rng.integers(0, edge.size, rows * cols)], rand_fp(rng, rows * cols)]
+    hal = HipHal(0)
+    try:
+        hal.poseidon2_set_constants(rc, diag)
+        oracle.zko_poseidon2_set_constants(rc, diag)
+        for m in mats:
+            want = np.zeros(rows * 8, np.uint32)
+            oracle.zko_hash_rows(want, rows, m, m.size)
+            out = hal.alloc_digest("o", rows)
+            hal.hash_rows(out, hal.copy_from("m", m))
+            assert np.array_equal(out.to_vec(), want)
+            nodes = np.zeros(2 * rows * 8, np.uint32)
+            nodes[rows * 8:] = want
+            wn = nodes.copy()
+            layer = rows
+            while layer > 1:
+                oracle.zko_hash_fold(wn, layer, layer // 2)
+                layer //= 2
+            nb = hal.copy_from("n", nodes)
+            hal.hash_fold(nb, rows, rows // 2)                   # the lane-per-parent kernel on the widest layer
+            assert np.array_equal(nb.to_vec()[rows // 2 * 8:rows * 8], wn[rows // 2 * 8:rows * 8])
+            hal.merkle_fold_all(nb, rows)
+            assert np.array_equal(nb.to_vec()[8:], wn[8:])
+    finally:
+        _restore_shipped_constants(oracle)
+        hal.close()
+
+
 def test_two_contexts_from_two_threads_give_identical_seals(oracle):
     desc = syn_air.syn_small()
     out = [None, None]

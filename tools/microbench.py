@@ -29,7 +29,7 @@ from zeth_amd.hal import HipHal  # noqa: E402
 P = 2013265921
 HBM_PEAK, HBM_COPY = 8.0e12, 6.29e12
 SIMDS, CLOCK = 256 * 4, 2.4e9                 # 256 CUs x 4 SIMDs, peak engine clock
-PERM_CYC = 8 * 2368 + 7 * 1576 + 1024 + 138   # issue cycles of one wave64 over 64 Poseidon2 permutations
+PERM_CYC = 8 * 1990 + 7 * 1259 + 711 + 480   # issue cycles of one wave64 over 64 Poseidon2 permutations
 BFLY_CYC = 34                                 # mul_mod 18 + add_mod 8 + sub_mod 8
 
 

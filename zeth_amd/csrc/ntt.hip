@@ -359,31 +359,36 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
 #define TILE_IN(row) (*(const uint32_t*)(in + ((((uint32_t)(row)) << (p.L + 2)) + tb)))
 #define TILE_OUT(row) (*(uint32_t*)(out + ((((uint32_t)(row)) << (p.L + 2)) + tb)))
     const uint32_t* __restrict__ ltab = p.layer_tw;
+    // twiddle products: the lazy forward pass only ever uses them as signed operands of smont, so they may stay signed
+    // representatives in (-P, P) themselves (3 instructions per product instead of 5)
+    auto tmul = [](uint32_t x, uint32_t y) -> uint32_t {
+        return (LAZY && !INVERSE) ? (uint32_t)smont((int32_t)x, (int32_t)y) : mul_mod(x, y);
+    };
     auto root = [&](uint32_t e) -> uint32_t {                  // w_{L+RH}^e, e < 2^(L+RH)
         const uint32_t ex = e << tw_shift;
-        return mul_mod(p.tw_lo[ex & (TW_SIZE - 1)], p.tw_hi[ex >> TW_BITS]);
+        return tmul(p.tw_lo[ex & (TW_SIZE - 1)], p.tw_hi[ex >> TW_BITS]);
     };
     // Four-step twiddles w^(lcol * bitrev(m)) of this lane's 16 rows, factored so that only 3 (RH = 10) or 2 (RH = 8)
     // table gathers are needed instead of 16: bitrev splits over the bit fields of m.
     uint32_t tw[16];
     if (RH == 10) {         // m = g*16 + i*4 + k: bitrev10(m) = br2(k)*256 + br2(i)*64 + br6(g);  slot = 4*i + k
         uint32_t w0 = root(lcol * (__brev(g) >> 26));
-        if (LAZY) w0 = mul_mod(w0, p.lazy_comp);                // cancels the R^-layers of both lazy passes
+        if (LAZY) w0 = tmul(w0, p.lazy_comp);                // cancels the R^-layers of both lazy passes
         const uint32_t u1 = root(lcol * 64u), v1 = root(lcol * 256u);
-        const uint32_t u2 = mul_mod(u1, u1), u3 = mul_mod(u2, u1), v2 = mul_mod(v1, v1), v3 = mul_mod(v2, v1);
-        const uint32_t wi[4] = {w0, mul_mod(w0, u2), mul_mod(w0, u1), mul_mod(w0, u3)};      // U^br2(i)
+        const uint32_t u2 = tmul(u1, u1), u3 = tmul(u2, u1), v2 = tmul(v1, v1), v3 = tmul(v2, v1);
+        const uint32_t wi[4] = {w0, tmul(w0, u2), tmul(w0, u1), tmul(w0, u3)};      // U^br2(i)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            tw[4 * i] = wi[i]; tw[4 * i + 1] = mul_mod(wi[i], v2); tw[4 * i + 2] = mul_mod(wi[i], v1); tw[4 * i + 3] = mul_mod(wi[i], v3);
+            tw[4 * i] = wi[i]; tw[4 * i + 1] = tmul(wi[i], v2); tw[4 * i + 2] = tmul(wi[i], v1); tw[4 * i + 3] = tmul(wi[i], v3);
         }
     } else {                // m = g*16 + k: bitrev8(m) = br4(k)*16 + br4(g);  slot = k
         uint32_t w0 = root(lcol * (__brev(g) >> 28));
-        if (LAZY) w0 = mul_mod(w0, p.lazy_comp);
+        if (LAZY) w0 = tmul(w0, p.lazy_comp);
         const uint32_t q1 = root(lcol * 16u);
         uint32_t qp[16];
         qp[0] = w0;
 #pragma unroll
-        for (int e = 1; e < 16; e++) qp[e] = mul_mod(qp[e - 1], q1);     // w0 * Q^e
+        for (int e = 1; e < 16; e++) qp[e] = tmul(qp[e - 1], q1);     // w0 * Q^e
 #pragma unroll
         for (int k = 0; k < 16; k++) tw[k] = qp[__builtin_bitreverse8((unsigned char)k) >> 4];
     }
