@@ -47,10 +47,11 @@ USE_SOP = os.environ.get("ZKH_CODEGEN_SOP", "1") != "0"     # sums of products a
 REG_BUDGET = int(os.environ.get("ZKH_CODEGEN_REGS", "96"))      # values (taps + intermediates) the register cache of a kernel holds
 EPOCH_LOADS = int(os.environ.get("ZKH_CODEGEN_EPOCH", "48"))    # tap loads per offset epoch
 PART_WEIGHT = int(os.environ.get("ZKH_CODEGEN_PART", "3200"))   # value steps per generated kernel (~ one translation unit / code object)
+USE_LAZY = int(os.environ.get("ZKH_CODEGEN_LAZY", "1"))
 PREFETCH = int(os.environ.get("ZKH_CODEGEN_PREFETCH", "4"))    # tap loads issued this many constraints ahead of their first use
 # compile flags of the generated translation units (build.py and jit.py use the same list)
 KERNEL_FLAGS = [f for f in os.environ.get("ZKH_CODEGEN_FLAGS", "").split() if f]
-GENERATOR_VERSION = 4
+GENERATOR_VERSION = 5
 
 
 def desc_hash64(desc: np.ndarray) -> int:
@@ -128,6 +129,7 @@ class Plan:
     sop: Dict[int, List[Tuple]] = field(default_factory=dict)                  # root value -> [(sign, 'p', a, b) | (sign, 'v', x)]
     absorbed: set = field(default_factory=set)                                 # values that only exist inside a root's sum of products
     n_sop_terms: int = 0
+    lazy: set = field(default_factory=set)                                     # values kept in [0, 2P): every consumer multiplies
 
     @staticmethod
     def build(c: Circuit) -> "Plan":
@@ -192,7 +194,62 @@ class Plan:
         p.n_unique = sum(1 for v in seen if p.fp[v][0] in (OP_ADD, OP_SUB, OP_MUL))
         if USE_SOP:
             p.find_sums_of_products(seen, roots)
+        if USE_LAZY:
+            p.find_lazy(seen)
         return p
+
+    def find_lazy(self, reachable) -> None:
+        """Which arithmetic values may skip their final conditional subtraction and live in [0, 2P).
+        A product a * b with a < 2P, b < P is below 2 P^2 < P 2^32, the domain of the Montgomery step, whose uncorrected
+        output is again below 2P; so a value whose every consumer MULTIPLIES it (a product, a term of a sum of products, a
+        constraint's mix-power accumulation, the base factor of an Fp4 * Fp product) never needs the canonical
+        representative, provided the other factor is canonical.  Operands of additions and subtractions must be canonical
+        (a + b < 2P has to fit 32 bits, a - b + P has to stay positive)."""
+        def arith(v):
+            return v in self.sop or (self.fp[v][0] in (OP_ADD, OP_SUB, OP_MUL) and not self.ext[v])
+        live = sorted(v for v in reachable if v not in self.absorbed)
+        need_c = set()
+        pairs: List[Tuple[int, int]] = []
+        for r in live:
+            if r in self.sop:
+                pairs.extend((t[2], t[3]) for t in self.sop[r] if t[1] == "p")
+                continue
+            op, a, b, _, _ = self.fp[r]
+            if op not in (OP_ADD, OP_SUB, OP_MUL):
+                continue
+            if self.ext[r]:
+                if op == OP_MUL and self.ext[a] != self.ext[b]:
+                    continue                                   # Fp4 * Fp: four products with a canonical component each
+                need_c.update(o for o in (a, b) if not self.ext[o])
+            elif op == OP_MUL:
+                pairs.append((a, b))
+            else:
+                need_c.update((a, b))
+        for a, b in pairs:
+            if a == b:
+                need_c.add(a)
+        # two lazy factors would reach 4 P^2: one of each pair pays.  Greedy vertex cover of the conflict graph, highest
+        # degree first — the common factor of many products (a selector, say) is the one to keep canonical.
+        adj: Dict[int, set] = {}
+        for a, b in pairs:
+            if a != b and arith(a) and arith(b) and a not in need_c and b not in need_c:
+                adj.setdefault(a, set()).add(b); adj.setdefault(b, set()).add(a)
+        import heapq
+        heap = [(-len(n), v) for v, n in adj.items()]
+        heapq.heapify(heap)
+        while heap:
+            negdeg, v = heapq.heappop(heap)
+            if v in need_c or not adj.get(v):
+                continue
+            if -negdeg != len(adj[v]):
+                heapq.heappush(heap, (-len(adj[v]), v))        # stale entry: re-queue with the current degree
+                continue
+            need_c.add(v)
+            for o in adj.pop(v):
+                adj[o].discard(v)
+                if adj[o]:
+                    heapq.heappush(heap, (-len(adj[o]), o))
+        self.lazy = {v for v in live if arith(v) and v not in need_c}
 
     def find_sums_of_products(self, reachable, mix_roots) -> None:
         """Lazy arithmetic: an ADD/SUB tree whose inner nodes have no other consumer is one expression
@@ -348,6 +405,7 @@ class _Emitter:
         self.depth_used = 0
         self.pend: Dict[int, int] = {}      # depth -> lazy products pending in s{d}_*
         self.tzero: Dict[int, bool] = {}    # depth -> t{d}_* statically known to be zero
+        self.folded: Dict[int, bool] = {}   # depth -> s{d}_* carries a folded (unreduced) part of the total
         self.globals_used: set = set()
         self.leaf = 0                       # depth-first index of the next leaf
         self.epoch = -1
@@ -499,22 +557,37 @@ class _Emitter:
                 self.w(f"    const Fp4 {name} = {self.cache[b]} * Fp::raw({self.ref(a)});")
             elif op == OP_MUL and not self.p.ext[b]:
                 self.w(f"    const Fp4 {name} = {self.cache[a]} * Fp::raw({self.ref(b)});")
+            elif op in (OP_ADD, OP_SUB) and not self.p.ext[b]:
+                self.w(f"    const Fp4 {name} = ext_{'add' if op == OP_ADD else 'sub'}_base({self.cache[a]}, {self.ref(b)});")
+            elif op == OP_ADD and not self.p.ext[a]:
+                self.w(f"    const Fp4 {name} = ext_add_base({self.cache[b]}, {self.ref(a)});")
             else:
                 self.w(f"    const Fp4 {name} = {self.ext_ref(a)} {sym} {self.ext_ref(b)};")
             self.n_arith += 1
         else:
             name = f"v{v}" + (f"_{g}" if g else "")
-            fn = {OP_ADD: "add_mod", OP_SUB: "sub_mod", OP_MUL: "mul_mod"}[op]
-            self.w(f"    const uint32_t {name} = {fn}({self.ref(a)}, {self.ref(b)});")
+            if v in self.p.lazy:                       # every consumer multiplies: [0, 2P) will do (Plan.find_lazy)
+                expr = {OP_ADD: f"{self.ref(a)} + {self.ref(b)}", OP_SUB: f"{self.ref(a)} - {self.ref(b)} + {P}u",
+                        OP_MUL: f"mul_lazy({self.ref(a)}, {self.ref(b)})"}[op]
+                self.w(f"    const uint32_t {name} = {expr};")
+            else:
+                fn = {OP_ADD: "add_mod", OP_SUB: "sub_mod", OP_MUL: "mul_mod"}[op]
+                self.w(f"    const uint32_t {name} = {fn}({self.ref(a)}, {self.ref(b)});")
             self.n_arith += 1
         self.cache[v] = name
 
     def define_sop(self, v: int, g: int) -> None:
-        """v = sum of (+-) products and (+-) plain terms: 64-bit multiply-add chain, one reduction (see Plan.find_sums_of_products)."""
-        PROD, PLAIN, LIMIT = float(P) * P, float(P) * R1, 1.72e19
+        """v = sum of (+-) products and (+-) plain terms: 64-bit multiply-add chain, one reduction (see Plan.find_sums_of_products).
+        A lazy operand (< 2P) doubles its term's bound and is negated as 2P - x."""
+        PROD, PLAIN, LIMIT = float(P) * P, float(P) * R1, 1.84e19
         name = f"v{v}" + (f"_{g}" if g else "")
+        lz = self.p.lazy
         const_sum = 0                                  # constant plain terms fold into the accumulator's initial value
         dyn: List[Tuple[float, str]] = []
+
+        def neg(x: int) -> str:
+            return f"({2 * P if x in lz else P}u - {self.ref(x)})"
+
         for t in self.p.sop[v]:
             sg = t[0]
             if t[1] == "v":
@@ -523,29 +596,34 @@ class _Emitter:
                     c = mont(self.p.fp[x][1])
                     const_sum += (c if sg > 0 else (P - c) % P) * R1
                 else:
-                    r = self.ref(x)
-                    dyn.append((PLAIN, f"(uint64_t){r} * {R1}u" if sg > 0 else f"(uint64_t)({P}u - {r}) * {R1}u"))
+                    dyn.append((PLAIN * (2 if x in lz else 1), f"(uint64_t){self.ref(x) if sg > 0 else neg(x)} * {R1}u"))
             else:
                 a, b = t[2], t[3]
                 if self.p.fp[a][0] == OP_CONST:
                     a, b = b, a                        # constant (if any) second
+                wgt = PROD * (2 if (a in lz or b in lz) else 1)
                 if self.p.fp[b][0] == OP_CONST:
                     c = mont(self.p.fp[b][1])
-                    dyn.append((PROD, f"(uint64_t){self.ref(a)} * {c if sg > 0 else (P - c) % P}u"))
+                    dyn.append((wgt, f"(uint64_t){self.ref(a)} * {c if sg > 0 else (P - c) % P}u"))
                 else:
-                    ra, rb = self.ref(a), self.ref(b)
-                    dyn.append((PROD, f"(uint64_t){ra} * {rb}" if sg > 0 else f"(uint64_t)({P}u - {ra}) * {rb}"))
+                    dyn.append((wgt, f"(uint64_t){self.ref(a) if sg > 0 else neg(a)} * {self.ref(b)}"))
         tmp = f"u{v}" + (f"_{g}" if g else "")
+        const_sum %= P                                 # only the residue matters to the Montgomery step
         acc = float(const_sum)
         self.w(f"    uint64_t {tmp} = {const_sum}ull;")
         for wgt, expr in dyn:
-            if acc + wgt > LIMIT:                       # partial reduction; the partial result re-enters as a plain term
-                self.w(f"    {tmp} = (uint64_t)mont_reduce_wide({tmp}) * {R1}u;")
-                acc = PLAIN
+            if acc + wgt > LIMIT:                       # out of room: hi 2^32 + lo = hi R + lo (mod P), below 2^60 + 2^32
+                self.w(f"    {tmp} = fold_acc({tmp});")
+                acc = 4294967296.0 * R1 + 4294967296.0
             self.w(f"    {tmp} += {expr};")
             acc += wgt
-        # below P 2^32 the plain reduction is enough (one correction instead of two)
-        self.w(f"    const uint32_t {name} = {'mont_reduce' if acc < float(P) * 4294967296.0 else 'mont_reduce_wide'}({tmp});")
+        # below P 2^32 the plain reduction is enough (one correction instead of two); a lazy root skips the last correction
+        wide = acc >= float(P) * 4294967296.0
+        if wide and acc >= 2.0 * float(P) * 4294967296.0:
+            self.w(f"    {tmp} = fold_acc({tmp});")
+            wide = False
+        fn = ("mont_reduce_wide" if wide else "mont_reduce") + ("_lazy" if v in lz else "")
+        self.w(f"    const uint32_t {name} = {fn}({tmp});")
         self.n_arith += 1
         self.cache[v] = name
 
@@ -556,19 +634,32 @@ class _Emitter:
     def reset(self, d: int) -> None:
         self.use_depth(d)
         self.w(f"    t{d}_0 = t{d}_1 = t{d}_2 = t{d}_3 = 0; s{d}_0 = s{d}_1 = s{d}_2 = s{d}_3 = 0;")
-        self.pend[d], self.tzero[d] = 0, True
+        self.pend[d], self.tzero[d], self.folded[d] = 0, True, False
+
+    def fold(self, d: int) -> None:
+        """Make room in the 64-bit constraint sums without reducing them: s = hi 2^32 + lo = hi R + lo (mod P), which is
+        below 2^60 + 2^32 and leaves room for four more products (4 P^2 + 2^60 + 2^32 < 2^64)."""
+        for k in range(4):
+            self.w(f"    s{d}_{k} = fold_acc(s{d}_{k});")
+        self.pend[d] = 0
+        self.folded[d] = True
 
     def flush(self, d: int) -> None:
-        if self.pend.get(d, 0) == 0:
+        """t{d} = everything accumulated at depth d so far, as canonical words (needed before an Fp4 contribution is
+        added, before the level is multiplied by its condition, and at the end of the kernel)."""
+        if self.pend.get(d, 0) == 0 and not self.folded.get(d, False):
             return
-        # the running total re-enters the 64-bit sum as t * R (4 P^2 + P R < 2 P 2^32): one multiply-add and the reduction's
-        # two corrections instead of a reduction plus a modular add
+        # The running total re-enters as t * R and the plain reduction wants the sum below P 2^32.  Two units of pending
+        # products alone qualify: (P-1)(2P-1) + (P-1) R = (P-1)(2^32 - 1); so does a folded part (< 2^60 + 2^32) with one
+        # unit on top; anything more is folded first.
+        if self.pend.get(d, 0) > 2 or (self.pend.get(d, 0) > 1 and self.folded.get(d, False)):
+            self.fold(d)
         for k in range(4):
             if self.tzero[d]:
-                self.w(f"    t{d}_{k} = mont_reduce_wide(s{d}_{k}); s{d}_{k} = 0;")
+                self.w(f"    t{d}_{k} = mont_reduce(s{d}_{k}); s{d}_{k} = 0;")
             else:
-                self.w(f"    t{d}_{k} = mont_reduce_wide(s{d}_{k} + (uint64_t)t{d}_{k} * {R1}u); s{d}_{k} = 0;")
-        self.pend[d], self.tzero[d] = 0, False
+                self.w(f"    t{d}_{k} = mont_reduce(s{d}_{k} + (uint64_t)t{d}_{k} * {R1}u); s{d}_{k} = 0;")
+        self.pend[d], self.tzero[d], self.folded[d] = 0, False, False
 
     def add_fp4(self, d: int, expr: str) -> None:
         """t{d} += Fp4 expression (non-lazy path: ConstExt-valued constraints and AndCond contributions)."""
@@ -593,18 +684,23 @@ class _Emitter:
                 self.need([v])
                 any_emitted = True
                 if self.p.ext[v]:
-                    self.add_fp4(d, f"Fp4(Fp::raw(pw[{e}].x), Fp::raw(pw[{e}].y), Fp::raw(pw[{e}].z), Fp::raw(pw[{e}].w)) * {self.ext_ref(v)}")
+                    # tot += mix^e * x for an Fp4 x: sixteen products straight into the unreduced sums (four units of room)
+                    if self.pend.get(d, 0) > 0:
+                        self.fold(d)
+                    self.w(f"    ext_accumulate(s{d}_0, s{d}_1, s{d}_2, s{d}_3, pw[{e}], {self.ext_ref(v)});")
                     self.release()
+                    self.pend[d] = 4
                     continue
-                # tot += mix^e * v: four 64-bit multiply-adds (scalar-loaded power words), ONE reduction per four constraints
-                # (4 P^2 < 2 P 2^32, the bound of mont_reduce_wide)
+                # tot += mix^e * v: four 64-bit multiply-adds (scalar-loaded power words); the sums are folded (not reduced)
+                # when four units of products are pending and reduced once where the total is needed
                 r = self.ref(v)
+                wgt = 2 if v in self.p.lazy else 1      # a lazy value (< 2P) makes a product below 2 P^2
+                if self.pend.get(d, 0) + wgt > 4:
+                    self.fold(d)
                 self.w(f"    {{ const uint4 p_ = pw[{e}]; s{d}_0 += (uint64_t)p_.x * {r}; s{d}_1 += (uint64_t)p_.y * {r}; "
                        f"s{d}_2 += (uint64_t)p_.z * {r}; s{d}_3 += (uint64_t)p_.w * {r}; }}")
                 self.release()
-                self.pend[d] = self.pend.get(d, 0) + 1
-                if self.pend[d] == 4:
-                    self.flush(d)
+                self.pend[d] = self.pend.get(d, 0) + wgt
             else:
                 _, cond, inner, e = it
                 first = self.leaf

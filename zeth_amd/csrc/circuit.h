@@ -34,6 +34,27 @@ struct EvalCheckArgs {
 __device__ __forceinline__ uint32_t tap_load(const uint32_t* __restrict__ group, size_t column_words, uint32_t lane_byte_offset) {
     return *(const uint32_t*)((const char*)(group + column_words) + lane_byte_offset);
 }
+// tot += p * x for an Fp4-valued constraint x and the mix power p, into the four unreduced 64-bit component sums of the
+// generated kernels: only the three overflow coefficients (x^4..x^6, which meet -11) are reduced; the sixteen products
+// land in the sums as they are (at most four per component: the caller accounts four units of room).
+__device__ __forceinline__ void ext_accumulate(uint64_t& s0, uint64_t& s1, uint64_t& s2, uint64_t& s3, const uint4 p, const zkh::Fp4& x) {
+    using namespace zkh;
+    const uint64_t x0 = x.c[0].v, x1 = x.c[1].v, x2 = x.c[2].v, x3 = x.c[3].v;
+    const uint64_t h0 = mont_reduce_wide(p.y * x3 + p.z * x2 + p.w * x1);
+    const uint64_t h1 = mont_reduce_wide(p.z * x3 + p.w * x2);
+    const uint64_t h2 = mont_reduce(p.w * x3);
+    s0 += p.x * x0 + NBETA_M * h0;
+    s1 += p.x * x1 + p.y * x0 + NBETA_M * h1;
+    s2 += p.x * x2 + p.y * x1 + p.z * x0 + NBETA_M * h2;
+    s3 += p.x * x3 + p.y * x2 + p.z * x1 + p.w * x0;
+}
+// x + v for an Fp4 x and a base-field v (only the constant coefficient moves)
+__device__ __forceinline__ zkh::Fp4 ext_add_base(const zkh::Fp4& x, uint32_t v) {
+    return zkh::Fp4(x.c[0] + zkh::Fp::raw(v), x.c[1], x.c[2], x.c[3]);
+}
+__device__ __forceinline__ zkh::Fp4 ext_sub_base(const zkh::Fp4& x, uint32_t v) {
+    return zkh::Fp4(x.c[0] - zkh::Fp::raw(v), x.c[1], x.c[2], x.c[3]);
+}
 typedef void (*eval_check_launch_fn)(const EvalCheckArgs&, hipStream_t);
 // A circuit's generated eval_check: n_parts kernels over disjoint constraint ranges, launched back to back on one stream;
 // part 0 writes `check`, the others add their share (circuits/codegen.py).

@@ -150,6 +150,21 @@ ZKH_HD uint32_t mont_reduce_wide(uint64_t t) {   // any t < 2*P*2^32
     const uint32_t hi = reduce_once((uint32_t)(t >> 32));
     return mont_reduce(((uint64_t)hi << 32) | (uint32_t)t);
 }
+// Lazy forms for straight-line generated code (circuits/codegen.py, Plan.find_lazy): a value whose every consumer is a
+// product may stay in [0, 2P).  With one factor below 2P and the other below P the product is below 2 P^2 < P 2^32, and
+// the Montgomery step's uncorrected output (T + m P) / 2^32 < 2P again fits the same form.
+ZKH_HD uint32_t mont_reduce_lazy(uint64_t t) {        // t < P 2^32  ->  [0, 2P)
+    const uint32_t m = (uint32_t)t * NEG_PINV;
+    return (uint32_t)((t + (uint64_t)m * P) >> 32);
+}
+ZKH_HD uint32_t mont_reduce_wide_lazy(uint64_t t) {   // t < 2 P 2^32  ->  [0, 2P)
+    const uint32_t hi = reduce_once((uint32_t)(t >> 32));
+    return mont_reduce_lazy(((uint64_t)hi << 32) | (uint32_t)t);
+}
+ZKH_HD uint32_t mul_lazy(uint32_t a, uint32_t b) { return mont_reduce_lazy((uint64_t)a * b); }   // a b < P 2^32
+// Room in a 64-bit sum of products without reducing it: hi 2^32 + lo = hi R + lo (mod P), below 2^60 + 2^32.
+ZKH_HD uint64_t fold_acc(uint64_t s) { return (s >> 32) * R1 + (uint32_t)s; }
+
 ZKH_HD Fp4 operator*(Fp4 a, Fp4 b) {
     const uint64_t a0 = a.c[0].v, a1 = a.c[1].v, a2 = a.c[2].v, a3 = a.c[3].v;
     const uint64_t b0 = b.c[0].v, b1 = b.c[1].v, b2 = b.c[2].v, b3 = b.c[3].v;
