@@ -5,6 +5,7 @@ with runs of 0 and P-1.  The seeds are fixed, so a failure reproduces."""
 import numpy as np
 import pytest
 
+import zko
 from conftest import P, rand_fp
 
 pytestmark = pytest.mark.gpu
@@ -163,3 +164,40 @@ def test_smallest_segments(hal, oracle, po2, zk):
     assert np.array_equal(receipt.seal, want)
     assert np.array_equal(prover.control_root(po2, zk), oc.control_root(po2, zk))
     receipt.verify(desc, prover.control_root(po2, zk))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_eval_check_random_circuits(hal, oracle, seed, tmp_path, monkeypatch):
+    """Random constraint systems (circuits/syn_random.py: squares, +/- chains, values used as factor and addend, Fp4
+    operands on either side, nested AndCond with base and Fp4 conditions) through all three evaluators: the kernels
+    generated and compiled at load time, the on-device step interpreter, the oracle's literal interpreter."""
+    import ctypes as C
+    from zeth_amd.circuits import syn_random
+    monkeypatch.setenv("ZKH_JIT_CACHE", str(tmp_path))
+    rng = np.random.default_rng(7000 + seed)
+    groups = [(4, 6, 12), (8, 5, 20), (4, 16, 33)][seed % 3]
+    desc = syn_random.random_circuit(seed, groups=groups, n_values=160 + 40 * (seed % 4), n_constraints=30 + 15 * (seed % 3),
+                                     max_back=1 + seed % 4)
+    circ = hal.load_circuit(desc, jit=True)
+    assert circ.kernel_kind() == "attached"
+    oc = zko.OracleCircuit(oracle, desc)
+    po2 = 5 + seed % 3
+    dom = 4 << po2
+    edge = np.array([0, 1, P - 1, (P - 1) // 2, (P + 1) // 2], np.uint32)
+    gs = []
+    for w in (int(x) for x in desc[3:6]):
+        g = rand_fp(rng, w * dom)
+        hit = rng.integers(0, 8, size=g.size) == 0              # edge words sprinkled over the evaluations
+        g[hit] = edge[rng.integers(0, edge.size, size=int(hit.sum()))]
+        gs.append(g)
+    out, mix, poly_mix = rand_fp(rng, 4), rand_fp(rng, int(desc[3])), rand_fp(rng, 4)
+    want = np.zeros(4 * dom, np.uint32)
+    gp = (C.c_void_p * 3)(*[a.ctypes.data for a in gs])
+    glp = (C.c_void_p * 2)(out.ctypes.data, mix.ctypes.data)
+    oracle.zko_eval_check(oc.h, want, gp, glp, poly_mix, po2)
+    dev = [hal.copy_from("g", g) for g in gs]
+    g_out, g_mix = hal.copy_from("out", out), hal.copy_from("mix", mix)
+    for interp in (False, True):
+        check = hal.alloc_elem("check", 4 * dom)
+        circ.eval_check(check, dev, [g_out, g_mix], poly_mix, po2, use_interpreter=interp)
+        assert np.array_equal(check.to_vec(), want), f"eval_check mismatch (seed={seed}, interpreter={interp})"
