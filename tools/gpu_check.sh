@@ -1,5 +1,7 @@
+# One GPU-box pass: the whole -m gpu suite, the per-op micro-benchmarks, the default bench line.
+#     gpurun --timeout 1800 -- 'bash tools/gpu_check.sh <name>'   -> gpurun_out/<name>/
 set -u
-O=gpurun_out/${1:-r2p}; mkdir -p $O
+O=gpurun_out/${1:-check}; mkdir -p $O
 export TMPDIR=/tmp
 ( time timeout 900 python -m pytest tests -m gpu -q -x ) > $O/pytest.log 2>&1
 echo "pytest rc=$?" >> $O/pytest.log

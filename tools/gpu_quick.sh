@@ -1,3 +1,4 @@
+# A filtered -m gpu run:  gpurun -- 'bash tools/gpu_quick.sh <name> -k "expr"'
 set -u
 O=gpurun_out/${1:-q}; mkdir -p $O; shift
 export TMPDIR=/tmp
