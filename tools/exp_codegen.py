@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "syn_heavy"
     variants = sys.argv[2:] or ["REGS=72", "REGS=96", "REGS=128"]
-    knobs = ("REGS", "EPOCH", "PART", "SOP", "PREFETCH", "FLAGS")
+    knobs = ("REGS", "EPOCH", "PART", "SOP", "PREFETCH", "LAZY", "FLAGS")
     po2 = int(os.environ.get("EXP_PO2", "20"))
     from zeth_amd.circuits import codegen, jit
     from zeth_amd.hal import HipHal

@@ -51,7 +51,7 @@ USE_LAZY = int(os.environ.get("ZKH_CODEGEN_LAZY", "1"))
 PREFETCH = int(os.environ.get("ZKH_CODEGEN_PREFETCH", "4"))    # tap loads issued this many constraints ahead of their first use
 # compile flags of the generated translation units (build.py and jit.py use the same list)
 KERNEL_FLAGS = [f for f in os.environ.get("ZKH_CODEGEN_FLAGS", "").split() if f]
-GENERATOR_VERSION = 5
+GENERATOR_VERSION = 6
 
 
 def desc_hash64(desc: np.ndarray) -> int:
@@ -753,8 +753,10 @@ def emit_part(kernel: str, plan: Plan, lo: int, hi: int, standalone: bool, heade
             bks = sorted(em.epoch_backs[k])
             backs_used |= set(bks)
             decl = " ".join(f"uint32_t o{bk}_{k} = b{bk};" for bk in bks)
-            outs = ", ".join([f'"+v"(o{bk}_{k})' for bk in bks] + [f'"+s"(dw{k})'])
-            body.append(f"    {decl} uint32_t dw{k} = a.dom; asm(\"; epoch {k}\" : {outs});")
+            outs = ", ".join(f'"+v"(o{bk}_{k})' for bk in bks)
+            # the domain size gets its own statement: sharing one with the lane offsets makes LLVM treat it as divergent,
+            # and every column base (col * dom) is then computed in the VALU and moved back with two v_readfirstlane
+            body.append(f"    {decl} uint32_t dw{k} = a.dom; asm(\"; epoch {k}\" : {outs}); asm(\"; epoch {k} dom\" : \"+s\"(dw{k}));")
         else:
             body.append(ln)
     L: List[str] = []
