@@ -212,8 +212,10 @@ __device__ __forceinline__ void radix_layers(uint32_t (&v)[1 << LOGR], const uin
                     const int k = (hi << (b + 1)) | kk;
                     const int64_t x = (int64_t)(int32_t)v[k];
                     const int32_t y = (int32_t)v[k + (1 << b)];
-                    v[k] = (uint32_t)smont_reduce(mad_i64(y, w, x));
-                    v[k + (1 << b)] = (uint32_t)smont_reduce(mad_i64(y, nw, x));
+                    // BASE0 call sites pass base_low = 0: the twiddle is wave-uniform and stays in an SGPR (the "v"
+                    // operand of mad_i64 would cost a v_mov per product)
+                    v[k] = (uint32_t)smont_reduce(BASE0 ? mad_i64_k(y, w, x) : mad_i64(y, w, x));
+                    v[k + (1 << b)] = (uint32_t)smont_reduce(BASE0 ? mad_i64_k(y, nw, x) : mad_i64(y, nw, x));
                 }
             }
         }
