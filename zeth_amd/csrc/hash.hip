@@ -8,7 +8,10 @@
 // are read column-major so a wave's 64 lanes read 64 consecutive words per column; four resident workgroups per CU
 // hide the column loads behind other waves' permutations (no software prefetch: it only cost VGPRs).  VALU-bound
 // by construction (~1356 Montgomery products per 64 absorbed bytes); the HBM side only has to keep up with
-// 16*W*n bytes per tree.
+// 16*W*n bytes per tree.  The permutation is poseidon2.h's lane-per-permutation form: signed Montgomery s-boxes with
+// no canonicalisation, M_ext on exact doubles (v_add_f64 / v_fma_f64 issue at the rate of a 32-bit multiply and have
+// the headroom a 31-bit prime denies a 32-bit word), partial rounds three at a time with unreduced weighted sums:
+// 6.4 k VALU instructions per 64 permutations.
 #include "common.h"
 #include "poseidon2.h"
 
