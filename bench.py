@@ -133,6 +133,7 @@ def main() -> None:
     ap.add_argument("--no-verify", action="store_true", help="block / succinct: skip the host verification after the clock stops")
     ap.add_argument("--no-heavy", action="store_true", help="segment config with SYN-A: skip the extra SYN-HEAVY measurement")
     ap.add_argument("--heavy-steps", type=int, default=9)
+    ap.add_argument("--no-resident", action="store_true", help="segment config: skip the extra measurement with the code group kept resident")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -389,52 +390,69 @@ def main() -> None:
         # constraint steps instead of ~1 k): SYN-A's eval_check is 4 % of a seal, upstream's is the largest kernel, so the
         # headline number above flatters the real workload and this one is reported next to it (same lanes, same resident
         # witnesses, a few steps).
-        heavy = None
-        if args.circuit == "syn_a" and not args.no_heavy and args.po2 >= 13:
-            from zeth_amd.circuits import syn_heavy
-            hdesc = syn_heavy.syn_heavy()
-            hsteps = max(inflight, min(args.heavy_steps, args.steps))
+        def timed_extra(make_prover, steps, with_prof):
+            """A few more timed steps of the same resident witnesses under another prover per lane -> (seconds, per-kernel times)."""
             for ln in lanes:
-                ln.heavy = SegmentProver(ln.hal, hdesc)
+                ln.extra = make_prover(ln)
 
-            def heavy_one(ln):
+            def one(ln):
                 seg, code, data, out = ln.wit[0]
-                ln.last_heavy = ln.heavy.seal(seg, code, data, out)
+                ln.last_extra = ln.extra.seal(seg, code, data, out)
 
-            def timed_heavy(ln):
+            def timed(ln):
                 try:
-                    while next_step(hsteps) is not None:
-                        heavy_one(ln)
+                    while next_step(steps) is not None:
+                        one(ln)
                     ln.hal.sync()
                 except Exception as e:
                     ln.err = e
 
             for ln in lanes:
-                heavy_one(ln)
-            if rank == 0 and not args.no_prof:
+                one(ln)
+            kprof = {}
+            if with_prof and rank == 0 and not args.no_prof:
                 lanes[0].hal.prof_reset(); lanes[0].hal.prof_enable(True)
-                heavy_one(lanes[0]); lanes[0].hal.sync()
-                hprof = {p["name"]: p for p in lanes[0].hal.prof_get()}
+                one(lanes[0]); lanes[0].hal.sync()
+                kprof = {p["name"]: p for p in lanes[0].hal.prof_get()}
                 lanes[0].hal.prof_enable(False)
-            else:
-                hprof = {}
             device_sync(lanes)
             barrier()
             work_next[0] = 0
             t2 = time.perf_counter()
-            run_lanes(lanes, timed_heavy)
+            run_lanes(lanes, timed)
             device_sync(lanes)
             barrier()
-            dth = time.perf_counter() - t2
+            dte = time.perf_counter() - t2
             if distributed:
-                t = torch.tensor([dth], dtype=torch.float64, device=ctrl_dev)
+                t = torch.tensor([dte], dtype=torch.float64, device=ctrl_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dth = float(t.item())
+                dte = float(t.item())
+            return dte, kprof
+
+        heavy = None
+        if args.circuit == "syn_a" and not args.no_heavy and args.po2 >= 13:
+            from zeth_amd.circuits import syn_heavy
+            hdesc = syn_heavy.syn_heavy()
+            hsteps = max(inflight, min(args.heavy_steps, args.steps))
+            dth, hprof = timed_extra(lambda ln: SegmentProver(ln.hal, hdesc), hsteps, True)
             hc = Circuit.parse(hdesc)
             heavy = {"segments_per_s": world * hsteps / dth, "ms_per_step": 1e3 * dth / hsteps, "steps": hsteps,
                      "workload": f"same step with the SYN-HEAVY constraint system ({len(hc.steps)} steps, {len(hc.taps)} taps, "
-                                 f"{len(hc.combos)} tap combos, degree 5, ConstExt, nested AndCond; {lanes[0].heavy.circuit.compiled_parts()} generated kernels)",
+                                 f"{len(hc.combos)} tap combos, degree 5, ConstExt, nested AndCond; {lanes[0].extra.circuit.compiled_parts()} generated kernels)",
                      "kernels_ms_per_seal_unshared": {k: round(v["total_ms"], 3) for k, v in sorted(hprof.items(), key=lambda kv: -kv[1]["total_ms"])[:6]}}
+        # The same step with the committed code (control) group of this segment size kept resident in HBM instead of being
+        # re-committed for every segment (zkh_prover_cache_code; the group is a function of (circuit, po2) alone, 0.6 GB at
+        # po2 20).  Upstream's SegmentProver recomputes it and so does `value`; this is what a deployment that keeps it gets.
+        resident = None
+        if not args.no_resident and args.po2 >= 13:
+            rsteps = max(inflight, min(args.heavy_steps, args.steps))
+            dtr, _ = timed_extra(lambda ln: SegmentProver(ln.hal, desc, resident_code_group=True), rsteps, False)
+            import numpy as np
+            same = all(np.array_equal(ln.last_extra.seal, ln.prover.seal(*ln.wit[0]).seal) for ln in lanes)   # same witness, recomputing prover
+            resident = {"segments_per_s": world * rsteps / dtr, "ms_per_step": 1e3 * dtr / rsteps, "steps": rsteps,
+                        "seals_identical_to_recomputing_prover": bool(same),
+                        "note": "NOT the headline: the code group's iNTT / expand-NTT / leaf hashing / Merkle fold are skipped because "
+                                "its committed form is resident (opt-in: SegmentProver(resident_code_group=True))"}
         last = next((ln.last for ln in lanes if ln.last is not None), None)
         if rank == 0:
             value = world * args.steps / dt
@@ -461,6 +479,8 @@ def main() -> None:
                 line["pcie_inclusive"] = pcie
             if heavy is not None:
                 line["syn_heavy"] = heavy
+            if resident is not None:
+                line["code_group_resident"] = resident
             alg = seal_algorithmic_bytes(wa, wc, wd, len(circ.taps), len(circ.combos), n)
             line["seal_roofline"] = {"alg_bytes": alg, "achieved": alg / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBPS,
                                      "unit": "GB/s", "frac": alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS}

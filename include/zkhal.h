@@ -213,6 +213,15 @@ void zkh_free_seal(uint32_t* seal);
  *   zkh_prove_finish: commit_group(accum) + Prover::finalize (eval_check, DEEP, FRI, queries).  Consumes the job whether
  *                     or not it succeeds; zkh_prove_abort drops a job that will not be finished. */
 typedef struct zkh_seal_job zkh_seal_job;
+/* The code (control) group is a function of (circuit, po2) alone — it is what the control ID commits to — yet upstream's
+ * SegmentProver re-commits it for every segment.  A prover that seals many segments of one size can keep that group's
+ * committed form (coefficients, 4n evaluations, Merkle nodes: 0.6 GB at po2 20, W_code 16) resident in HBM:
+ * zkh_prover_cache_code commits `code` once for this po2 (replacing an earlier entry); afterwards zkh_prove_begin /
+ * zkh_prove_segment accept code == NULL for that po2 and share the resident group read-only.  Seals are byte-identical
+ * to the ones made from the same code trace.  The caller vouches that the trace is the circuit's code trace for that
+ * size (the verifier still checks the root against the control root).  zkh_prover_drop_code_cache releases the entries. */
+const char* zkh_prover_cache_code(zkh_prover*, size_t po2, const zkh_buf* code);
+void zkh_prover_drop_code_cache(zkh_prover*);
 const char* zkh_prove_begin(zkh_prover*, size_t po2, const zkh_buf* code, const zkh_buf* data, const uint32_t* out_global,
                             zkh_seal_job** job, uint32_t* mix_global);
 const char* zkh_prove_finish(zkh_seal_job*, const zkh_buf* accum, uint32_t** seal, size_t* seal_words);

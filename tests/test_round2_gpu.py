@@ -491,3 +491,46 @@ def test_cpp_host_attaches_code_objects_and_writes_receipts(tmp_path):
                          "--receipts-dir", str(rdir)], capture_output=True, text=True, timeout=300)
     assert r2.returncode == 0, r2.stderr
     assert np.array_equal(np.fromfile(rdir / "segment_0.zkr", dtype="<u4"), blobs[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the code (control) group kept resident per segment size (zkh_prover_cache_code)
+# ---------------------------------------------------------------------------------------------------------------
+def test_resident_code_group_gives_byte_identical_seals(hal, oracle):
+    """The code group is a function of (circuit, po2, zk_cycles): a prover that keeps its committed form resident must
+    produce the seals a recomputing prover produces — across segments, sizes, a change of zk_cycles, and both entry points
+    (zkh_prove_segment and the zkh_prove_begin / zkh_prove_finish halves)."""
+    desc = syn_air.syn_small()
+    plain = SegmentProver(hal, desc)
+    resident = SegmentProver(hal, desc, resident_code_group=True)
+    oc = zko.OracleCircuit(oracle, desc)
+    cases = [(10, 100, 1), (10, 100, 2), (12, 200, 3), (10, 100, 4), (10, 300, 5), (12, 200, 6)]
+    for po2, zk, seed in cases:
+        seg = Segment(index=seed, po2=po2, seed=seed, noise_seed=77 + seed, zk_cycles=zk)
+        want = plain.prove_segment(seg).seal
+        code, data, out = resident.witgen(seg)
+        got = resident.seal(seg, code, data, out).seal
+        assert np.array_equal(got, want), f"resident code group changed the seal (po2={po2}, zk={zk}, seed={seed})"
+        got2 = resident.seal_with_accum(seg, code, data, out, resident.syn_accumulate(seg, data)).seal
+        assert np.array_equal(got2, want)
+        assert resident._resident[po2] == zk
+    assert np.array_equal(want, oc.prove(12, 200, 6, 77 + 6))       # and both equal the oracle's
+
+
+def test_prove_begin_without_code_needs_a_resident_group(hal):
+    import ctypes as C
+    from zeth_amd import hal as zhal
+    desc = syn_air.syn_small()
+    prover = SegmentProver(hal, desc)
+    seg = Segment(index=0, po2=9, seed=1, noise_seed=2, zk_cycles=100)
+    code, data, out = prover.witgen(seg)
+    job = C.c_void_p()
+    outp = out.ctypes.data_as(C.POINTER(C.c_uint32))
+    with pytest.raises(HalError, match="resident code group"):
+        zhal._check(zhal._lib.zkh_prove_begin(prover.h, 9, None, data.h, outp, C.byref(job), None))
+    zhal._check(zhal._lib.zkh_prover_cache_code(prover.h, 9, code.h))
+    zhal._check(zhal._lib.zkh_prove_begin(prover.h, 9, None, data.h, outp, C.byref(job), None))
+    zhal._lib.zkh_prove_abort(job)
+    zhal._lib.zkh_prover_drop_code_cache(prover.h)
+    with pytest.raises(HalError, match="resident code group"):
+        zhal._check(zhal._lib.zkh_prove_begin(prover.h, 9, None, data.h, outp, C.byref(job), None))

@@ -13,6 +13,7 @@
 
 #include "circuit.h"
 #include "poseidon2.h"
+#include <map>
 
 using namespace zkh;
 
@@ -148,6 +149,17 @@ struct PolyGroup {
         ZKH_TRY(enqueue(c, std::move(co), count_, n_));
         return merkle.fetch_top(c);
     }
+    // a second, read-only owner of a committed group (new handles on the same device allocations)
+    const char* share_from(const PolyGroup& s) {
+        count = s.count; n = s.n; bitrev = s.bitrev;
+        ZKH_TRY(zkh_slice(s.coeffs, 0, s.coeffs.b->len, coeffs.out()));
+        ZKH_TRY(zkh_slice(s.evaluated, 0, s.evaluated.b->len, evaluated.out()));
+        ZKH_TRY(zkh_slice(s.merkle.nodes, 0, s.merkle.nodes.b->len, merkle.nodes.out()));
+        merkle.matrix = evaluated;
+        merkle.rows = s.merkle.rows; merkle.cols = s.merkle.cols; merkle.layers = s.merkle.layers;
+        merkle.top_layer = s.merkle.top_layer; merkle.top_size = s.merkle.top_size; merkle.top = s.merkle.top;
+        return nullptr;
+    }
 };
 
 struct FriRound {
@@ -187,11 +199,12 @@ struct zkh_prover {
     zkh_ctx* ctx;
     const zkh_circuit* circuit;
     HostHash hash;
+    std::map<size_t, std::unique_ptr<PolyGroup>> code_cache;   // po2 -> the committed code group, resident (zkh_prover_cache_code)
 };
 
 extern "C" const char* zkh_prover_create(zkh_ctx* ctx, const zkh_circuit* circuit, zkh_prover** out) {
     ZKH_REQUIRE(ctx && circuit, "prover_create: null argument");
-    *out = new zkh_prover{ctx, circuit, HostHash{ctx->h_rc, ctx->h_diag}};
+    *out = new zkh_prover{ctx, circuit, HostHash{ctx->h_rc, ctx->h_diag}, {}};
     return nullptr;
 }
 extern "C" void zkh_prover_destroy(zkh_prover* p) { delete p; }
@@ -227,9 +240,21 @@ struct zkh_seal_job {
 
 extern "C" void zkh_prove_abort(zkh_seal_job* job) { delete job; }
 
+extern "C" const char* zkh_prover_cache_code(zkh_prover* pr, size_t po2, const zkh_buf* code) {
+    ZKH_REQUIRE(pr && code, "prover_cache_code: null argument");
+    ZKH_REQUIRE(po2 >= 1 && po2 + 2 <= (size_t)MAX_LOG_N, "prover_cache_code: po2 %zu out of range", po2);
+    std::unique_ptr<PolyGroup> pg(new PolyGroup());
+    ZKH_TRY(commit_group_enqueue(pr->ctx, *pg, code, pr->circuit->group_size[GROUP_CODE], (size_t)1 << po2));
+    ZKH_TRY(pg->merkle.fetch_top(pr->ctx));
+    pr->code_cache[po2] = std::move(pg);
+    return nullptr;
+}
+extern "C" void zkh_prover_drop_code_cache(zkh_prover* pr) { if (pr) pr->code_cache.clear(); }
+
 extern "C" const char* zkh_prove_begin(zkh_prover* pr, size_t po2, const zkh_buf* code, const zkh_buf* data,
                                        const uint32_t* out_global, zkh_seal_job** out_job, uint32_t* mix_out) {
-    ZKH_REQUIRE(pr && code && data && out_global && out_job, "prove_begin: null argument");
+    ZKH_REQUIRE(pr && data && out_global && out_job, "prove_begin: null argument");
+    ZKH_REQUIRE(code || pr->code_cache.count(po2), "prove_begin: no code trace and no resident code group for po2 %zu (zkh_prover_cache_code)", po2);
     zkh_ctx* c = pr->ctx;
     const zkh_circuit* cir = pr->circuit;
     ZKH_REQUIRE(po2 >= 1 && po2 + 2 <= (size_t)MAX_LOG_N, "prove_begin: po2 %zu too large (max %d)", po2, MAX_LOG_N - 2);
@@ -253,9 +278,11 @@ extern "C" const char* zkh_prove_begin(zkh_prover* pr, size_t po2, const zkh_buf
     }
     // ---- commit code, data: neither commitment depends on a challenge, so both groups are queued before the first
     // root is read back; the transcript still absorbs them in upstream's order (code, then data)
-    ZKH_TRY(commit_group_enqueue(c, job->groups[GROUP_CODE], code, wc, n));
+    if (code) ZKH_TRY(commit_group_enqueue(c, job->groups[GROUP_CODE], code, wc, n));
+    else ZKH_TRY(job->groups[GROUP_CODE].share_from(*pr->code_cache[po2]));      // resident: nothing to compute
     ZKH_TRY(commit_group_enqueue(c, job->groups[GROUP_DATA], data, wd, n));
-    ZKH_TRY(commit_group_finish(c, iop, job->groups[GROUP_CODE]));
+    if (code) ZKH_TRY(commit_group_finish(c, iop, job->groups[GROUP_CODE]));
+    else job->groups[GROUP_CODE].merkle.commit(iop);
     ZKH_TRY(commit_group_finish(c, iop, job->groups[GROUP_DATA]));
     // ---- accum mix challenges ----
     job->mix_global.resize(cir->global_size[GLOBAL_MIX] ? cir->global_size[GLOBAL_MIX] : 1);

@@ -99,6 +99,8 @@ ABI = {
     "zkh_syn_accum": (_err, [_vp, _vp, _sz, _sz, _u64, _vp, _u32p, _vp]),
     "zkh_prover_create": (_err, [_vp, _vp, C.POINTER(_vp)]),
     "zkh_prover_destroy": (None, [_vp]),
+    "zkh_prover_cache_code": (_err, [_vp, _sz, _vp]),
+    "zkh_prover_drop_code_cache": (None, [_vp]),
     "zkh_prove_segment": (_err, [_vp, _sz, _sz, _u64, _vp, _vp, _u32p, C.POINTER(_u32p), C.POINTER(_sz)]),
     "zkh_free_seal": (None, [_u32p]),
     "zkh_prove_begin": (_err, [_vp, _sz, _vp, _vp, _u32p, C.POINTER(_vp), _u32p]),

@@ -116,12 +116,17 @@ class SegmentReceipt:
 class SegmentProver:
     """`SegmentProverImpl<H, C>` analogue bound to one HipHal (one GPU)."""
 
-    def __init__(self, hal: "_hal.HipHal", circuit_desc=None):
+    def __init__(self, hal: "_hal.HipHal", circuit_desc=None, resident_code_group: bool = False):
+        """resident_code_group: keep the committed code (control) group of each segment size in HBM instead of re-committing
+        it for every segment (zkh_prover_cache_code): the group is a function of (circuit, po2, zk_cycles) alone.  Off by
+        default — upstream's SegmentProver recomputes it, and so does the benchmark's headline number."""
         self.hal = hal
         self.circuit = hal.load_circuit(syn_air.syn_a() if circuit_desc is None else circuit_desc)
         h = C.c_void_p()
         _hal._check(_hal._lib.zkh_prover_create(hal.ctx, self.circuit.h, C.byref(h)))
         self.h = h
+        self.resident_code_group = resident_code_group
+        self._resident: Dict[int, int] = {}                 # po2 -> zk_cycles of the resident code group
         self._roots: Dict[Tuple[int, int], np.ndarray] = {}
         self._group_sizes = tuple(int(x) for x in self.circuit.desc[3:6])       # (accum, code, data): desc header words
 
@@ -165,12 +170,21 @@ class SegmentProver:
         _hal._lib.zkh_free_seal(seal_p)
         return seal
 
+    def _code_handle(self, seg: Segment, code):
+        """The code operand of a seal: the trace, or NULL once this size's committed group is resident."""
+        if not self.resident_code_group:
+            return code.h
+        if self._resident.get(seg.po2) != seg.zk_cycles:
+            _hal._check(_hal._lib.zkh_prover_cache_code(self.h, seg.po2, code.h))
+            self._resident[seg.po2] = seg.zk_cycles
+        return None
+
     def seal(self, seg: Segment, code, data, out_global) -> SegmentReceipt:
         """Steps 3-7 of SURVEY.md §3.2 on traces already resident in HBM: the timed unit of work."""
         out = np.ascontiguousarray(out_global, dtype=np.uint32)
         seal_p = C.POINTER(C.c_uint32)()
         n = C.c_size_t()
-        _hal._check(_hal._lib.zkh_prove_segment(self.h, seg.po2, seg.zk_cycles, seg.noise_seed & (2**64 - 1), code.h, data.h,
+        _hal._check(_hal._lib.zkh_prove_segment(self.h, seg.po2, seg.zk_cycles, seg.noise_seed & (2**64 - 1), self._code_handle(seg, code), data.h,
                                                 out.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(seal_p), C.byref(n)))
         return SegmentReceipt(seal=self._take_seal(seal_p, n), index=seg.index, po2=seg.po2, output=out.copy())
 
@@ -182,7 +196,7 @@ class SegmentProver:
         wa = self.group_sizes()[0]
         job = C.c_void_p()
         mix = np.zeros(max(1, int(self.circuit.desc[8])), dtype=np.uint32)
-        _hal._check(_hal._lib.zkh_prove_begin(self.h, seg.po2, code.h, data.h, out.ctypes.data_as(C.POINTER(C.c_uint32)),
+        _hal._check(_hal._lib.zkh_prove_begin(self.h, seg.po2, self._code_handle(seg, code), data.h, out.ctypes.data_as(C.POINTER(C.c_uint32)),
                                               C.byref(job), mix.ctypes.data_as(C.POINTER(C.c_uint32))))
         try:
             accum = accumulate(mix[: int(self.circuit.desc[8])])
