@@ -7,6 +7,7 @@
 // `receipt.verify(image_id)` at /root/reference/crates/host/src/bin/cli.rs:103.
 //
 //   seal_segments --desc syn_a.desc [--po2 20] [--segments 8] [--devices 1] [--inflight 3] [--no-verify] [--noise-seed N]
+//                 [--resident-code-group]
 //                 [--receipts-dir DIR]     (writes segment_<i>.zkr: the receipt container of zkh_receipt_encode)
 //                 [--code-objects DIR]     (eval_check kernels of a circuit that is not built in: the .hsaco files +
 //                                           manifest.txt written by `python -m zeth_amd.circuits.jit circuit.desc DIR`,
@@ -39,6 +40,7 @@ struct Options {
     std::string receipts_dir;        // --receipts-dir: one receipt container per segment
     std::string code_objects_dir;    // --code-objects: generated eval_check kernels to attach after loading the circuit
     bool fixed_noise = false;        // --noise-seed: reproducible seals (tests); default: fresh OS randomness per segment
+    bool resident_code = false;      // --resident-code-group: commit the code group once per worker and keep it in HBM
     uint64_t noise_seed = 0;
 };
 
@@ -122,6 +124,7 @@ void lane(int device, const std::vector<uint32_t>& desc, const Options& opt, std
         }
         const size_t out_size = desc[7];
         std::vector<uint32_t> out_global(out_size), pub(out_size > 4 ? out_size - 4 : 0, 0u);
+        bool code_resident = false;
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= opt.segments) break;
@@ -132,8 +135,14 @@ void lane(int device, const std::vector<uint32_t>& desc, const Options& opt, std
                 break;
             uint32_t* seal = nullptr;
             size_t words = 0;
+            // the code trace of (circuit, po2) is the same for every segment: its committed form can stay resident
+            if (opt.resident_code && !code_resident) {
+                if (failed(zkh_prover_cache_code(prover, opt.po2, code), "zkh_prover_cache_code")) break;
+                code_resident = true;
+            }
             const double t0 = now_s();
-            if (failed(zkh_prove_segment(prover, opt.po2, ZKH_ZK_CYCLES, noise, code, data, out_global.data(), &seal, &words),
+            if (failed(zkh_prove_segment(prover, opt.po2, ZKH_ZK_CYCLES, noise, code_resident ? nullptr : code, data, out_global.data(),
+                                         &seal, &words),
                        "zkh_prove_segment"))
                 break;
             receipts[i].seal_s = now_s() - t0;
@@ -161,6 +170,7 @@ bool parse(int argc, char** argv, Options& o) {
         else if (a == "--no-verify") o.verify = false;
         else if (a == "--receipts-dir" && i + 1 < argc) o.receipts_dir = argv[++i];
         else if (a == "--code-objects" && i + 1 < argc) o.code_objects_dir = argv[++i];
+        else if (a == "--resident-code-group") o.resident_code = true;
         else if (a == "--noise-seed" && i + 1 < argc) { o.noise_seed = strtoull(argv[++i], nullptr, 0); o.fixed_noise = true; }
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return false; }
     }
@@ -172,7 +182,7 @@ bool parse(int argc, char** argv, Options& o) {
 int main(int argc, char** argv) {
     Options opt;
     if (!parse(argc, argv, opt)) {
-        fprintf(stderr, "usage: %s --desc FILE [--po2 N] [--segments S] [--devices G] [--inflight K] [--no-verify] [--noise-seed N] [--receipts-dir DIR] [--code-objects DIR]\n", argv[0]);
+        fprintf(stderr, "usage: %s --desc FILE [--po2 N] [--segments S] [--devices G] [--inflight K] [--no-verify] [--noise-seed N] [--receipts-dir DIR] [--code-objects DIR] [--resident-code-group]\n", argv[0]);
         return 2;
     }
     FILE* f = fopen(opt.desc_path.c_str(), "rb");

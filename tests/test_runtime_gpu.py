@@ -238,6 +238,19 @@ def test_cpp_host_driver_seals_and_verifies(tmp_path):
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["verified"] == 4 and out["segments"] == 4 and out["seal_words_total"] > 4 * 1000
+    # the same session with the code group committed once per worker and kept resident: the receipts are the same bytes
+    # (fixed noise seed), and the host verifier accepts every one against the control root
+    da, db = tmp_path / "a", tmp_path / "b"
+    for d, extra in ((da, []), (db, ["--resident-code-group"])):
+        os.makedirs(d)
+        r = subprocess.run([exe, "--desc", str(desc), "--po2", "11", "--segments", "5", "--inflight", "2", "--noise-seed", "99",
+                            "--receipts-dir", str(d), *extra], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert json.loads(r.stdout.strip().splitlines()[-1])["verified"] == 5
+    names = sorted(os.listdir(da))
+    assert len(names) == 5 and names == sorted(os.listdir(db))
+    for nm in names:
+        assert open(da / nm, "rb").read() == open(db / nm, "rb").read(), nm
 
 
 def test_pool_accounting_and_trim(oracle):
