@@ -197,7 +197,7 @@ const char* zkh_syn_accum(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cy
 
 /* ---- segment prover: SegmentProver::prove_segment + risc0_zkp::prove::Prover ---- */
 const char* zkh_prover_create(zkh_ctx*, const zkh_circuit*, zkh_prover** out);
-void zkh_prover_destroy(zkh_prover*);
+void zkh_prover_destroy(zkh_prover*);   /* before zkh_ctx_destroy: a prover may hold device buffers (zkh_prover_cache_code) */
 /* Seal one segment of a SYN-AIR-family circuit (kind 1: the accum witness generator is zkh_syn_accum) whose code/data
  * traces are already resident in HBM (W x 2^po2 each); out_global has OUTPUT_SIZE words.  On success *seal is a
  * malloc'd word array (release with zkh_free_seal). */

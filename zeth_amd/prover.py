@@ -132,7 +132,8 @@ class SegmentProver:
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
-        if h and _hal._lib is not None:
+        # a prover may hold device buffers (the resident code group): like Buffer, it is only released into a live context
+        if h and _hal._lib is not None and getattr(self.hal, "ctx", None):
             _hal._lib.zkh_prover_destroy(h)
 
     def group_sizes(self):
