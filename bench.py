@@ -16,6 +16,10 @@ Configs (SURVEY.md §8d restatements of BASELINE.json's configs):
   --circuit syn_heavy  seals with the realistically heavy constraint system instead of SYN-A.
   --ingress host       additionally times the PCIe-inclusive path: traces uploaded from pinned host memory every step.
 
+The default line also carries two secondary measurements of the same step, neither of which is `value`: `syn_heavy` (the
+heavy constraint system) and `code_group_resident` (the per-size code group kept in HBM instead of re-committed per
+segment: DESIGN.md §3); --no-heavy / --no-resident skip them.
+
     python bench.py                         # N=1, K=30, W=2
     python bench.py --gpus 8                # self-launching: spawns 8 ranks (gloo control plane, one GPU each)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
