@@ -51,7 +51,7 @@ USE_LAZY = int(os.environ.get("ZKH_CODEGEN_LAZY", "1"))
 PREFETCH = int(os.environ.get("ZKH_CODEGEN_PREFETCH", "4"))    # tap loads issued this many constraints ahead of their first use
 # compile flags of the generated translation units (build.py and jit.py use the same list)
 KERNEL_FLAGS = [f for f in os.environ.get("ZKH_CODEGEN_FLAGS", "").split() if f]
-GENERATOR_VERSION = 6
+GENERATOR_VERSION = 7
 
 
 def desc_hash64(desc: np.ndarray) -> int:
@@ -195,20 +195,24 @@ class Plan:
         if USE_SOP:
             p.find_sums_of_products(seen, roots)
         if USE_LAZY:
-            p.find_lazy(seen)
+            p.find_lazy(seen, roots)
         return p
 
-    def find_lazy(self, reachable) -> None:
+    def find_lazy(self, reachable, mix_ext=()) -> None:
         """Which arithmetic values may skip their final conditional subtraction and live in [0, 2P).
         A product a * b with a < 2P, b < P is below 2 P^2 < P 2^32, the domain of the Montgomery step, whose uncorrected
         output is again below 2P; so a value whose every consumer MULTIPLIES it (a product, a term of a sum of products, a
         constraint's mix-power accumulation, the base factor of an Fp4 * Fp product) never needs the canonical
         representative, provided the other factor is canonical.  Operands of additions and subtractions must be canonical
         (a + b < 2P has to fit 32 bits, a - b + P has to stay positive)."""
+        def ext_by_base(v):
+            """An Fp4 value computed as Fp4 * Fp: four base products, so its components can be lazy in the same way."""
+            return self.ext[v] and self.fp[v][0] == OP_MUL and self.ext[self.fp[v][1]] != self.ext[self.fp[v][2]]
+
         def arith(v):
-            return v in self.sop or (self.fp[v][0] in (OP_ADD, OP_SUB, OP_MUL) and not self.ext[v])
+            return v in self.sop or (self.fp[v][0] in (OP_ADD, OP_SUB, OP_MUL) and not self.ext[v]) or ext_by_base(v)
         live = sorted(v for v in reachable if v not in self.absorbed)
-        need_c = set()
+        need_c = set(v for v in mix_ext if self.ext[v])        # Fp4 constraints and Fp4 conditions are consumed whole
         pairs: List[Tuple[int, int]] = []
         for r in live:
             if r in self.sop:
@@ -219,8 +223,9 @@ class Plan:
                 continue
             if self.ext[r]:
                 if op == OP_MUL and self.ext[a] != self.ext[b]:
-                    continue                                   # Fp4 * Fp: four products with a canonical component each
-                need_c.update(o for o in (a, b) if not self.ext[o])
+                    pairs.append((a, b))                       # Fp4 * Fp: four products; one side canonical is enough
+                    continue
+                need_c.update((a, b))                          # Fp4 +- anything, Fp4 * Fp4: canonical components
             elif op == OP_MUL:
                 pairs.append((a, b))
             else:
@@ -554,9 +559,12 @@ class _Emitter:
             name = f"x{v}" + (f"_{g}" if g else "")
             sym = {OP_ADD: "+", OP_SUB: "-", OP_MUL: "*"}[op]
             if op == OP_MUL and not self.p.ext[a]:
-                self.w(f"    const Fp4 {name} = {self.cache[b]} * Fp::raw({self.ref(a)});")
-            elif op == OP_MUL and not self.p.ext[b]:
-                self.w(f"    const Fp4 {name} = {self.cache[a]} * Fp::raw({self.ref(b)});")
+                a, b = b, a                            # the Fp4 operand first
+            if op == OP_MUL and not self.p.ext[b]:
+                if v in self.p.lazy:                   # every consumer multiplies the components by a canonical factor
+                    self.w(f"    const Fp4 {name} = ext_mul_base_lazy({self.cache[a]}, {self.ref(b)});")
+                else:
+                    self.w(f"    const Fp4 {name} = {self.cache[a]} * Fp::raw({self.ref(b)});")
             elif op in (OP_ADD, OP_SUB) and not self.p.ext[b]:
                 self.w(f"    const Fp4 {name} = ext_{'add' if op == OP_ADD else 'sub'}_base({self.cache[a]}, {self.ref(b)});")
             elif op == OP_ADD and not self.p.ext[a]:

@@ -60,6 +60,12 @@ def random_circuit(seed: int, groups=(4, 6, 12), n_values: int = 220, n_constrai
             c = b.const_ext(*(int(rng.integers(0, P)) for _ in range(4)))
             x = pick(base)
             ext.append([b.mul(c, x), b.mul(x, c), b.add(c, x), b.add(x, c), b.sub(c, x), b.sub(x, c)][int(rng.integers(0, 6))])
+        elif k < 94:                                         # Fp4 * Fp * Fp ...: products whose only consumer multiplies again
+            x = ext[int(rng.integers(0, len(ext)))]
+            for _ in range(int(rng.integers(2, 5))):
+                y = pick(base)
+                x = b.mul(x, y) if rng.integers(0, 2) else b.mul(y, x)
+            ext.append(x)
         else:
             x = ext[int(rng.integers(0, len(ext)))]
             y = ext[int(rng.integers(0, len(ext)))] if rng.integers(0, 2) else pick(base)

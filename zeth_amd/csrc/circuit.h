@@ -48,6 +48,11 @@ __device__ __forceinline__ void ext_accumulate(uint64_t& s0, uint64_t& s1, uint6
     s2 += p.x * x2 + p.y * x1 + p.z * x0 + NBETA_M * h2;
     s3 += p.x * x3 + p.y * x2 + p.z * x1 + p.w * x0;
 }
+// x * v with lazy components (each in [0, 2P)): for an Fp4 whose every consumer multiplies it by a canonical base value
+__device__ __forceinline__ zkh::Fp4 ext_mul_base_lazy(const zkh::Fp4& x, uint32_t v) {
+    using namespace zkh;
+    return Fp4(Fp::raw(mul_lazy(x.c[0].v, v)), Fp::raw(mul_lazy(x.c[1].v, v)), Fp::raw(mul_lazy(x.c[2].v, v)), Fp::raw(mul_lazy(x.c[3].v, v)));
+}
 // x + v for an Fp4 x and a base-field v (only the constant coefficient moves)
 __device__ __forceinline__ zkh::Fp4 ext_add_base(const zkh::Fp4& x, uint32_t v) {
     return zkh::Fp4(x.c[0] + zkh::Fp::raw(v), x.c[1], x.c[2], x.c[3]);
