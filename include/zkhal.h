@@ -15,7 +15,8 @@
  *   - every function returns `const char*`: NULL on success, otherwise a heap error string that the
  *     caller releases with zkh_free_error();
  *   - element words are raw Montgomery-form BabyBear u32 exactly as upstream stores `Elem` in memory and in
- *     seals; Elem = 1 word, ExtElem = 4 words (AoS), Digest = 8 words;
+ *     seals; Elem = 1 word, ExtElem = 4 words (AoS), Digest = 8 words.  Every op expects REDUCED words (< P) and
+ *     produces reduced words; upstream's Elem::INVALID marker (0xffffffff) is not an input (upstream asserts on it);
  *   - matrices are column-major like upstream Buffer<T>: element (row r, column c) at c*rows + r;
  *   - a zkh_ctx is one GPU + one HIP stream, driven by one host thread at a time (upstream HALs are driven
  *     by a single prover thread).  Ops are enqueued in order on the ctx stream and are asynchronous;
