@@ -470,7 +470,7 @@ def main() -> None:
                            "rccl_probe": rccl, "inflight_per_gpu": inflight,
                            "seal_words": int(last.seal.size) if last is not None else 0,
                            "library": HipHal.version(),
-                           "poseidon2_consts": "placeholder" if "placeholder" in HipHal.version() else "upstream"},
+                           "poseidon2_consts": HipHal.version().split("poseidon2_consts=")[-1].rstrip(")")},
                 # wall-clock of one seal call (enqueue .. seal words on the host), mean over the timed seals of this rank;
                 # with several seals in flight each one shares the GPU, so this is latency under load, not 1/value
                 "seal_wall_clock_s": sum(seal_times) / max(1, len(seal_times)),
@@ -642,7 +642,7 @@ def main() -> None:
                            "parallelism": f"segments round-robin over {world} GPU(s) + shared work index inside a rank, no data-path collective; "
                                           f"{inflight} seal(s) in flight per GPU" + ("; joins on the rank of their left child, right child over gloo" if succinct else ""),
                            "inflight_per_gpu": inflight, "library": HipHal.version(),
-                           "poseidon2_consts": "placeholder" if "placeholder" in HipHal.version() else "upstream"},
+                           "poseidon2_consts": HipHal.version().split("poseidon2_consts=")[-1].rstrip(")")},
                 "block_wall_clock_s": dt, "leaf_phase_s": t_leaves, "join_phase_s": dt - t_leaves if succinct else None,
                 "witgen_ms_per_segment": 1e3 * sum(t for ln in lanes for t in ln.witgen_s) / max(1, sum(len(ln.witgen_s) for ln in lanes)),
                 "seal_call_ms_mean": 1e3 * sum(t for ln in lanes for t in ln.seal_s) / max(1, sum(len(ln.seal_s) for ln in lanes)),

@@ -50,8 +50,10 @@ typedef struct zkh_prover zkh_prover;
 #define ZKH_DIGEST_WORDS 8
 
 void zkh_free_error(const char* err);
-/* library/ABI version, the gfx arch the kernels were compiled for ("gfx950"), and whether the shipped Poseidon2 tables
- * are the upstream ones or the declared placeholder ("poseidon2_consts=placeholder": digests cannot match upstream's) */
+/* library/ABI version, the gfx arch the kernels were compiled for ("gfx950"), and where the shipped Poseidon2 tables come
+ * from: "poseidon2_consts=derived" (output of the published parameter-generation procedure, tools/gen_poseidon2_consts.py,
+ * which reproduces every value of the published instance on record; not yet compared with upstream's consts.rs itself),
+ * "=upstream" once that comparison has been made, "=placeholder" for filler tables (digests cannot match upstream's) */
 const char* zkh_version(void);
 
 /* ---- context: CudaHal::new / HalPair (hal/cuda.rs) ---- */
@@ -115,6 +117,11 @@ const char* zkh_hash_fold(zkh_ctx*, zkh_buf* io_digests, size_t input_size, size
 /* Fused MerkleTreeProver::new tail: every hash_fold layer from `rows` leaves down to the root.
  * nodes has 2*rows digests, leaves already at [rows, 2*rows). */
 const char* zkh_merkle_fold_all(zkh_ctx*, zkh_buf* nodes, size_t rows);
+/* The bare permutation (risc0_zkp::core::hash::poseidon2::poseidon2_mix): `count` states of 24 Montgomery words each,
+ * in place — on the device with the context's tables, or on the host (rc / diag canonical residues, NULL = the shipped
+ * tables).  What the published known-answer vector of the instance is checked against (tests/golden/poseidon2_kat.json). */
+const char* zkh_poseidon2_mix(zkh_ctx*, zkh_buf* states, size_t count);
+const char* zkh_poseidon2_mix_host(const uint32_t* rc, const uint32_t* diag, uint32_t* states, size_t count);
 /* Hal::batch_evaluate_any(coeffs, poly_count, which, xs, out): out[k] = sum_j coeffs[which[k]][j] xs[k]^j */
 const char* zkh_batch_evaluate_any(zkh_ctx*, const zkh_buf* coeffs, size_t poly_count, const zkh_buf* which,
                                    const zkh_buf* xs, zkh_buf* out);

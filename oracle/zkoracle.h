@@ -13,8 +13,10 @@
  * /root/reference/crates/chainspec/src/lib.rs:208-221), and no reference binary can be built here
  * (no cargo/rustc/r0vm).  Every function below restates the published upstream algorithm as
  * summarised in SURVEY.md Appendix A and cites the upstream file it follows; the pins we do have are
- * first-principles identities (tests/test_oracle_*.py) and an independent verifier restatement
- * (verifier.c) that must accept every seal.
+ * first-principles identities (tests/test_oracle_*.py), an independent verifier restatement
+ * (verifier.c) that must accept every seal, and Poseidon2 tables (include/zkh_poseidon2_consts.h) that are
+ * the output of the published parameter-generation procedure (tools/gen_poseidon2_consts.py), which
+ * reproduces every value of the published instance on record — derived, not yet diffed against consts.rs.
  *
  * All buffers are host arrays of raw Montgomery-form u32 words, column-major exactly like upstream
  * Buffer<T>: element (row r, column c) at c*rows + r.  ExtElem buffers are AoS (4 words per element)

@@ -318,3 +318,26 @@ def test_batch_bit_reverse_extelem(hal, log_n, count):
     src = x.reshape(count, n, 4)
     rev = np.array([int(format(i, f"0{log_n}b")[::-1], 2) for i in range(n)])
     eq(got, src[:, rev, :])
+
+
+def test_poseidon2_permutation_known_answer_and_oracle(hal, oracle):
+    """The bare permutation on the device: the published known-answer vector of the instance
+    (tests/golden/poseidon2_kat.json), and the oracle's literal permutation on random and edge-valued states."""
+    import json
+    import os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "poseidon2_kat.json")))
+    want = np.array([int(x, 16) for x in kat["output_hex"]], np.uint32)
+    rng = np.random.default_rng(24)
+    states = rand_fp(rng, 1000 * 24)
+    states[:24] = [oracle.zko_fp_encode(int(v)) for v in kat["input"]]
+    states[24:48] = 0
+    states[48:72] = P - 1
+    states[72:96] = np.array([0, 1, P - 1, (P - 1) // 2, (P + 1) // 2, 268435454] * 4, np.uint32)
+    ref = states.copy()
+    for k in range(1000):
+        oracle.zko_poseidon2_mix(ref[24 * k: 24 * k + 24])
+    buf = hal.copy_from("states", states)
+    hal.poseidon2_mix(buf)
+    got = buf.to_vec()
+    assert np.array_equal(got, ref)
+    assert np.array_equal(np.array([oracle.zko_fp_decode(int(v)) for v in got[:24]], np.uint32), want)

@@ -82,3 +82,21 @@ def test_golden_seal_digests(oracle):
         seal = oc.prove(g["po2"], g["zk_cycles"], g["seed"], g["noise_seed"])
         assert seal.size == g["words"]
         assert hashlib.sha256(seal.astype("<u4").tobytes()).hexdigest() == g["sha256"]
+
+
+def test_poseidon2_published_known_answer(oracle):
+    """tests/golden/poseidon2_kat.json: the published known-answer vector of this Poseidon2 instance (input 0..23), the one
+    upstream's own poseidon2 tests compare against.  The oracle's literal permutation and the product's host path (the same
+    header the kernels compile) must both reproduce it with the shipped tables."""
+    import ctypes as C
+    from zeth_amd import hal as zhal
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "poseidon2_kat.json")))
+    want = np.array([int(x, 16) for x in kat["output_hex"]], np.uint32)
+    enc = np.array([oracle.zko_fp_encode(int(v)) for v in kat["input"]], np.uint32)
+    st = enc.copy()
+    oracle.zko_poseidon2_mix(st)
+    assert np.array_equal(np.array([oracle.zko_fp_decode(int(v)) for v in st], np.uint32), want)
+    lib = zhal.load_library()
+    st2 = np.concatenate([enc, enc])                      # two states: both get permuted
+    zhal._check(lib.zkh_poseidon2_mix_host(None, None, st2.ctypes.data_as(C.POINTER(C.c_uint32)), 2))
+    assert np.array_equal(st2[:24], st) and np.array_equal(st2[24:], st)

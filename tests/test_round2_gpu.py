@@ -321,10 +321,10 @@ def test_contexts_on_every_visible_device_from_threads(oracle):
             assert np.array_equal(out[l][i], want[i]), f"device {l[0]} lane {l[1]} segment {i}"
 
 
-def test_version_names_the_placeholder_tables():
+def test_version_names_the_provenance_of_the_poseidon2_tables():
     from zeth_amd import hal as zhal
     v = zhal.load_library().zkh_version().decode()
-    assert "gfx950" in v and "poseidon2_consts=placeholder" in v
+    assert "gfx950" in v and "poseidon2_consts=derived" in v
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -96,7 +96,7 @@ def test_receipt_container_roundtrip_and_integrity(oracle):
     back.verify(desc, root)
     hc = HostCircuit(desc)
     hdr, _ = hc.receipt_decode(blob)
-    assert np.array_equal(hdr["claim"], hc.receipt_claim(seal, root)) and hdr["placeholder_tables"]
+    assert np.array_equal(hdr["claim"], hc.receipt_claim(seal, root)) and hdr["tables"] == "derived" and not hdr["placeholder_tables"]
     for pos in (0, 4, 9, 12, 20, 26, 500, blob.size - 1):
         bad = blob.copy()
         bad[pos] ^= 1

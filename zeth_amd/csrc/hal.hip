@@ -8,10 +8,13 @@
 using namespace zkh;
 
 extern "C" void zkh_free_error(const char* e) { free((void*)e); }
-// The version string names the two data items that are known placeholders: nobody should mistake a
-// digest produced with them for an upstream-compatible one.
+// The version string says where the Poseidon2 tables come from: "placeholder" (filler: digests cannot
+// match upstream's), "derived" (produced by the published parameter-generation procedure, tools/gen_poseidon2_consts.py;
+// not yet compared with upstream's consts.rs word for word) or "upstream".
 #if ZKH_P2_CONSTS_ARE_PLACEHOLDER
 extern "C" const char* zkh_version(void) { return "zkhal-mi355x 0.2.0 (gfx950; poseidon2_consts=placeholder)"; }
+#elif ZKH_P2_CONSTS_ARE_DERIVED
+extern "C" const char* zkh_version(void) { return "zkhal-mi355x 0.2.0 (gfx950; poseidon2_consts=derived)"; }
 #else
 extern "C" const char* zkh_version(void) { return "zkhal-mi355x 0.2.0 (gfx950; poseidon2_consts=upstream)"; }
 #endif

@@ -177,8 +177,29 @@ __global__ __launch_bounds__(8 << TAIL_LOG) void k_hash_fold_tail(uint32_t* __re
     }
 }
 
+// the bare permutation, one lane per state (24 words each)
+__global__ __launch_bounds__(256) void k_poseidon2_mix(uint32_t* __restrict__ io, size_t count, const uint32_t* __restrict__ rc,
+                                                       const uint32_t* __restrict__ diag) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint4* p = (uint4*)(io + i * CELLS);
+    uint32_t s[CELLS];
+#pragma unroll
+    for (int q = 0; q < CELLS / 4; q++) { const uint4 v = p[q]; s[4 * q] = v.x; s[4 * q + 1] = v.y; s[4 * q + 2] = v.z; s[4 * q + 3] = v.w; }
+    poseidon2_mix(s, rc, diag);
+#pragma unroll
+    for (int q = 0; q < CELLS / 4; q++) p[q] = make_uint4(s[4 * q], s[4 * q + 1], s[4 * q + 2], s[4 * q + 3]);
+}
+
 }  // namespace
 
+extern "C" const char* zkh_poseidon2_mix(zkh_ctx* c, zkh_buf* states, size_t count) {
+    ZKH_REQUIRE(states && states->len == count * CELLS, "poseidon2_mix: buffer is not count x 24 words");
+    if (!count) return nullptr;
+    bind_thread(c);
+    k_poseidon2_mix<<<(unsigned)((count + 255) / 256), 256, 0, c->stream>>>(states->ptr(), count, c->tab.rc, c->tab.diag);
+    return last_launch_error("poseidon2_mix");
+}
 extern "C" const char* zkh_hash_rows(zkh_ctx* c, zkh_buf* out, const zkh_buf* matrix) {
     ZKH_REQUIRE(out->len % 8 == 0 && out->len, "hash_rows: output is not a digest array");
     const size_t rows = out->len / 8;

@@ -172,6 +172,19 @@ Fp4 fold_eval(Fp4 (&v)[16], Fp4 mix, Fp inv_wk, const uint32_t (&rou_rev)[28]) {
 
 // Claim digest of a sealed segment: Poseidon2 over (out globals, po2 as an Elem, control root).  A join's public inputs are
 // the claims of the two receipts it combines (host.py SuccinctReceipt); upstream's ReceiptClaim digests play this role.
+extern "C" const char* zkh_poseidon2_mix_host(const uint32_t* rc, const uint32_t* diag, uint32_t* states, size_t count) {
+    ZKH_REQUIRE(states || !count, "poseidon2_mix_host: null states");
+    std::unique_ptr<Tables> tab(new Tables());
+    make_tables(*tab, rc ? rc : ZKH_P2_ROUND_CONSTANTS, diag ? diag : ZKH_P2_M_INT_DIAG);
+    for (size_t k = 0; k < count; k++) {
+        uint32_t s[CELLS];
+        for (int i = 0; i < CELLS; i++) { s[i] = states[k * CELLS + i]; ZKH_REQUIRE(s[i] < P, "poseidon2_mix_host: unreduced word"); }
+        poseidon2_mix(s, tab->rc, tab->pc);
+        memcpy(states + k * CELLS, s, sizeof s);
+    }
+    return nullptr;
+}
+
 extern "C" const char* zkh_receipt_claim(const zkh_circuit* c, const uint32_t* seal, size_t seal_words, const uint32_t* control_root,
                                          const uint32_t* rc_canonical, const uint32_t* diag_canonical, uint32_t claim[8]) {
     ZKH_REQUIRE(c && seal && control_root && claim, "receipt_claim: null argument");
@@ -340,11 +353,15 @@ extern "C" const char* zkh_verify_segment(const zkh_circuit* c, const uint32_t* 
 // /root/reference/crates/host/src/lib.rs:137, verified at cli.rs:103).  That exact encoding needs the Rust types; this
 // container carries the same fields in plain little-endian u32 words so that any host can store, ship and check a seal:
 //   [0] 'ZKR1'  [1] version  [2..4) circuit desc hash  [4] po2  [5] hashfn (1 = poseidon2)  [6] flags (bit 0: placeholder
-//   Poseidon2 tables)  [7] segment index  [8] OUTPUT_SIZE  [9] seal words  [10..18) control root  [18..26) claim digest
+//   Poseidon2 tables, bit 1: tables derived from the published procedure, not yet checked against upstream's)  [7] segment index  [8] OUTPUT_SIZE  [9] seal words  [10..18) control root  [18..26) claim digest
 //   [26 ..) seal words  [last 2] FNV-1a 64 of everything before.
 // =====================================================================================================
 namespace {
 constexpr uint32_t RECEIPT_MAGIC = 0x31524b5au;   // "ZKR1"
+#if !defined(ZKH_P2_CONSTS_ARE_DERIVED)
+#define ZKH_P2_CONSTS_ARE_DERIVED 0
+#endif
+constexpr uint32_t P2_TABLE_FLAGS = (ZKH_P2_CONSTS_ARE_PLACEHOLDER ? 1u : 0u) | (ZKH_P2_CONSTS_ARE_DERIVED ? 2u : 0u);
 constexpr size_t RECEIPT_HEADER = 26;
 }  // namespace
 
@@ -358,7 +375,7 @@ extern "C" const char* zkh_receipt_encode(const zkh_circuit* c, const uint32_t* 
     std::vector<uint32_t> w(RECEIPT_HEADER + seal_words + 2);
     w[0] = RECEIPT_MAGIC; w[1] = 1;
     w[2] = (uint32_t)c->hash; w[3] = (uint32_t)(c->hash >> 32);
-    w[4] = fp_decode(Fp::raw(po2_elem)); w[5] = 1; w[6] = ZKH_P2_CONSTS_ARE_PLACEHOLDER ? 1u : 0u;
+    w[4] = fp_decode(Fp::raw(po2_elem)); w[5] = 1; w[6] = P2_TABLE_FLAGS;
     w[7] = segment_index; w[8] = (uint32_t)out_size; w[9] = (uint32_t)seal_words;
     memcpy(&w[10], control_root, 32);
     ZKH_TRY(zkh_receipt_claim(c, seal, seal_words, control_root, nullptr, nullptr, &w[18]));
@@ -387,9 +404,9 @@ extern "C" const char* zkh_receipt_decode(const zkh_circuit* c, const uint32_t* 
     const uint64_t h = desc_hash64(blob, RECEIPT_HEADER + seal_words);
     ZKH_REQUIRE(blob[blob_words - 2] == (uint32_t)h && blob[blob_words - 1] == (uint32_t)(h >> 32), "receipt_decode: checksum mismatch (corrupted container)");
     ZKH_REQUIRE(blob[5] == 1, "receipt_decode: unknown hash function id %u", blob[5]);
-    ZKH_REQUIRE((blob[6] & 1u) == (ZKH_P2_CONSTS_ARE_PLACEHOLDER ? 1u : 0u),
-                "receipt_decode: the receipt was sealed with %s Poseidon2 tables, this library has the other set",
-                (blob[6] & 1u) ? "placeholder" : "upstream");
+    ZKH_REQUIRE((blob[6] & 3u) == P2_TABLE_FLAGS,
+                "receipt_decode: the receipt was sealed with %s Poseidon2 tables, this library has another set",
+                (blob[6] & 1u) ? "placeholder" : (blob[6] & 2u) ? "derived" : "upstream");
     if (c) {
         ZKH_REQUIRE(blob[2] == (uint32_t)c->hash && blob[3] == (uint32_t)(c->hash >> 32), "receipt_decode: receipt belongs to another circuit");
         ZKH_REQUIRE(blob[8] == c->global_size[GLOBAL_OUT] && seal_words > blob[8], "receipt_decode: output size mismatch");

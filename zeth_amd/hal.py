@@ -97,6 +97,8 @@ ABI = {
     "zkh_syn_code": (_err, [_vp, _vp, _sz, _sz, _vp]),
     "zkh_syn_witgen": (_err, [_vp, _vp, _sz, _sz, _u64, _u64, _u32p, _vp, _vp, _u32p]),
     "zkh_syn_accum": (_err, [_vp, _vp, _sz, _sz, _u64, _vp, _u32p, _vp]),
+    "zkh_poseidon2_mix": (_err, [_vp, _vp, _sz]),
+    "zkh_poseidon2_mix_host": (_err, [_u32p, _u32p, _u32p, _sz]),
     "zkh_prover_create": (_err, [_vp, _vp, C.POINTER(_vp)]),
     "zkh_prover_destroy": (None, [_vp]),
     "zkh_prover_cache_code": (_err, [_vp, _sz, _vp]),
@@ -280,7 +282,8 @@ class HostCircuit:
         off = _sz()
         _check(_lib.zkh_receipt_decode(self.h, _ptr(b), b.size, _ptr(info), C.byref(off)))
         hdr = {"version": int(info[1]), "circuit_hash": int(info[2]) | (int(info[3]) << 32), "po2": int(info[4]),
-               "hashfn": "poseidon2", "placeholder_tables": bool(info[6] & 1), "index": int(info[7]), "out_size": int(info[8]),
+               "hashfn": "poseidon2", "placeholder_tables": bool(info[6] & 1),
+               "tables": "placeholder" if info[6] & 1 else "derived" if info[6] & 2 else "upstream", "index": int(info[7]), "out_size": int(info[8]),
                "control_root": info[10:18].copy(), "claim": info[18:26].copy()}
         return hdr, b[off.value: off.value + int(info[9])].copy()
 
@@ -453,6 +456,10 @@ class HipHal:
     def merkle_open(self, matrix: Buffer, nodes: Buffer, rows: int, cols: int, idx, out: Buffer) -> None:
         i = _u32(idx)
         _check(_lib.zkh_merkle_open(self.ctx, matrix.h, nodes.h, rows, cols, _ptr(i), i.size, out.h))
+
+    def poseidon2_mix(self, states: "Buffer") -> None:
+        """The bare permutation on `states.size() // 24` states (24 Montgomery words each), in place."""
+        _check(_lib.zkh_poseidon2_mix(self.ctx, states.h, states.size() // 24))
 
     def poseidon2_set_constants(self, rc, diag) -> None:
         r, d = _u32(rc), _u32(diag)
