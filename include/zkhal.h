@@ -230,6 +230,9 @@ typedef struct zkh_seal_job zkh_seal_job;
  * size (the verifier still checks the root against the control root).  zkh_prover_drop_code_cache releases the entries. */
 const char* zkh_prover_cache_code(zkh_prover*, size_t po2, const zkh_buf* code);
 void zkh_prover_drop_code_cache(zkh_prover*);
+/* Root of the resident code group of this size.  The entry is keyed by po2 alone although a code trace also depends on
+ * zk_cycles: a host that changes zk_cycles must re-cache, and can compare this root with the control root it expects. */
+const char* zkh_prover_cached_code_root(zkh_prover*, size_t po2, uint32_t root[8]);
 const char* zkh_prove_begin(zkh_prover*, size_t po2, const zkh_buf* code, const zkh_buf* data, const uint32_t* out_global,
                             zkh_seal_job** job, uint32_t* mix_global);
 const char* zkh_prove_finish(zkh_seal_job*, const zkh_buf* accum, uint32_t** seal, size_t* seal_words);
@@ -259,6 +262,8 @@ const char* zkh_receipt_claim(const zkh_circuit*, const uint32_t* seal, size_t s
 const char* zkh_receipt_encode(const zkh_circuit*, const uint32_t* seal, size_t seal_words, uint32_t segment_index,
                                const uint32_t control_root[8], uint32_t** blob, size_t* blob_words);
 /* Parse + integrity-check (checksum, version, hash-suite, and with a circuit: desc hash, output size, po2, claim digest).
+ * The checksum is FNV-1a: it detects corruption, not forgery; with circuit == NULL only the envelope is checked and NOTHING
+ * is authenticated.  Authenticity comes from zkh_verify_segment on the seal against the EXPECTED control root, never from here.
  * info receives header words [0, 26); the seal sits at blob + *seal_offset (info[9] words).  Does NOT verify the seal. */
 const char* zkh_receipt_decode(const zkh_circuit*, const uint32_t* blob, size_t blob_words, uint32_t info[26],
                                size_t* seal_offset);

@@ -122,3 +122,16 @@ def test_world_size_2_round_robin_and_distributed_joins():
             assert merged[(t.level, t.index)] == j.seal.tobytes()
     assert root_bytes == single.root.seal.tobytes()
     single.verify(leaf_desc, join_desc, leaf_root, join_root)
+    # round-2 advisor finding: the stored root must be the top of the verified tree BY CONTENT ...
+    import copy
+    clone = copy.deepcopy(single)                       # different objects, same content (a container round trip)
+    clone.verify(leaf_desc, join_desc, leaf_root, join_root)
+    forged = SuccinctReceipt(root=leaves[0], joins=single.joins, leaves=single.leaves)
+    with pytest.raises(ValueError, match="root is not the top"):
+        forged.verify(leaf_desc, join_desc, leaf_root, join_root)
+    # ... for a one-leaf session too: the root is that leaf, and an arbitrary root next to a valid leaf is rejected
+    one = prove_succinct(leaves[:1], prove_join, claim_of, join_po2=JOIN_PO2)
+    one.verify(leaf_desc, join_desc, leaf_root, join_root)
+    bad = SuccinctReceipt(root=leaves[1], joins=[], leaves=leaves[:1])
+    with pytest.raises(ValueError, match="root is not the top"):
+        bad.verify(leaf_desc, join_desc, leaf_root, join_root)

@@ -124,6 +124,7 @@ extern "C" const char* zkh_poseidon2_set_constants(zkh_ctx* c, const uint32_t* r
     return nullptr;
 }
 
+static const char* ctx_init_tables(zkh_ctx* c);
 extern "C" const char* zkh_ctx_create(int device, const char* suite, zkh_ctx** out) {
     ZKH_REQUIRE(suite && strcmp(suite, "poseidon2") == 0, "unsupported hash suite '%s' (only poseidon2)", suite ? suite : "(null)");
     int ndev = 0;
@@ -134,7 +135,18 @@ extern "C" const char* zkh_ctx_create(int device, const char* suite, zkh_ctx** o
     ZKH_HIP(hipSetDevice(device));
     zkh_ctx* c = new zkh_ctx();
     c->device = device;
-    ZKH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); se != hipSuccess) {
+        delete c;
+        return make_err("hipStreamCreateWithFlags: %s", hipGetErrorString(se));
+    }
+    if (const char* err = ctx_init_tables(c)) {     // a half-built context (stream, tables, pool) is not leaked
+        zkh_ctx_destroy(c);
+        return err;
+    }
+    *out = c;
+    return nullptr;
+}
+static const char* ctx_init_tables(zkh_ctx* c) {
     Fp g = fp_encode(137);
     for (int k = 0; k <= 27; k++) {
         Fp w = fp_pow(g, 1ull << (27 - k));
@@ -166,7 +178,6 @@ extern "C" const char* zkh_ctx_create(int device, const char* suite, zkh_ctx** o
     ZKH_TRY(upload(&c->tab.diag, std::vector<uint32_t>(ZKH_P2_PTAB)));
     ZKH_TRY(zkh_poseidon2_set_constants(c, ZKH_P2_ROUND_CONSTANTS, ZKH_P2_M_INT_DIAG));
     ZKH_TRY(ntt_device_init(c));
-    *out = c;
     return nullptr;
 }
 extern "C" const char* zkh_ctx_trim(zkh_ctx* c) {
@@ -237,7 +248,7 @@ extern "C" const char* zkh_wrap(zkh_ctx* c, void* dptr, size_t n, zkh_buf** out)
     return nullptr;
 }
 extern "C" const char* zkh_slice(zkh_buf* b, size_t off, size_t n, zkh_buf** out) {
-    ZKH_REQUIRE(off + n <= b->len, "slice [%zu, %zu) out of range (size %zu)", off, off + n, b->len);
+    ZKH_REQUIRE(n <= b->len && off <= b->len - n, "slice [%zu, +%zu) out of range (size %zu)", off, n, b->len);   // no wrap-around
     b->a->refs.fetch_add(1, std::memory_order_relaxed);
     *out = new zkh_buf(b->a, b->off + off, n, 1);
     return nullptr;
@@ -256,7 +267,7 @@ extern "C" size_t zkh_size(const zkh_buf* b) { return b->len; }
 extern "C" void* zkh_device_ptr(const zkh_buf* b) { return (void*)b->ptr(); }
 extern "C" const char* zkh_read(zkh_ctx* c, const zkh_buf* b, uint32_t* host, size_t off, size_t n) {
     bind_thread(c);
-    ZKH_REQUIRE(off + n <= b->len, "read [%zu, %zu) out of range (size %zu)", off, off + n, b->len);
+    ZKH_REQUIRE(n <= b->len && off <= b->len - n, "read [%zu, +%zu) out of range (size %zu)", off, n, b->len);   // no wrap-around
     if (n) ZKH_HIP(hipMemcpyAsync(host, b->ptr() + off, n * 4, hipMemcpyDeviceToHost, c->stream));
     ZKH_HIP(hipStreamSynchronize(c->stream));
     c->stage_used = 0;
@@ -264,7 +275,7 @@ extern "C" const char* zkh_read(zkh_ctx* c, const zkh_buf* b, uint32_t* host, si
 }
 extern "C" const char* zkh_write(zkh_ctx* c, zkh_buf* b, const uint32_t* host, size_t off, size_t n) {
     bind_thread(c);
-    ZKH_REQUIRE(off + n <= b->len, "write [%zu, %zu) out of range (size %zu)", off, off + n, b->len);
+    ZKH_REQUIRE(n <= b->len && off <= b->len - n, "write [%zu, +%zu) out of range (size %zu)", off, n, b->len);   // no wrap-around
     return h2d(c, b->ptr() + off, host, n);
 }
 
@@ -292,7 +303,7 @@ extern "C" void zkh_host_free(zkh_ctx* c, uint32_t* host) {
 }
 extern "C" const char* zkh_write_async(zkh_ctx* c, zkh_buf* b, const uint32_t* pinned_host, size_t off, size_t n) {
     bind_thread(c);
-    ZKH_REQUIRE(off + n <= b->len, "write_async [%zu, %zu) out of range (size %zu)", off, off + n, b->len);
+    ZKH_REQUIRE(n <= b->len && off <= b->len - n, "write_async [%zu, +%zu) out of range (size %zu)", off, n, b->len);   // no wrap-around
     // the source must lie inside a block from zkh_host_alloc: only then is the copy a true asynchronous DMA, and only then
     // does the library know the memory stays mapped until zkh_host_free (which drains the stream first)
     auto it = c->host_blocks.upper_bound((void*)pinned_host);

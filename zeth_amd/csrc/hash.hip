@@ -17,6 +17,9 @@
 
 using namespace zkh;
 
+// common.h sizes the host / device / verifier copies of the partial-round table by hand; poseidon2.h lays the table out.
+static_assert(zkh::ZKH_P2_PTAB == zkh::P2_TAB_WORDS, "common.h ZKH_P2_PTAB must equal poseidon2.h P2_TAB_WORDS");
+
 namespace {
 
 // Hal::hash_rows — one lane per leaf.

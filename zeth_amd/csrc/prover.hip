@@ -243,6 +243,8 @@ extern "C" void zkh_prove_abort(zkh_seal_job* job) { delete job; }
 extern "C" const char* zkh_prover_cache_code(zkh_prover* pr, size_t po2, const zkh_buf* code) {
     ZKH_REQUIRE(pr && code, "prover_cache_code: null argument");
     ZKH_REQUIRE(po2 >= 1 && po2 + 2 <= (size_t)MAX_LOG_N, "prover_cache_code: po2 %zu out of range", po2);
+    ZKH_REQUIRE(code->len == ((size_t)pr->circuit->group_size[GROUP_CODE] << po2), "prover_cache_code: code trace has %zu words, expected %zu (W_code x 2^po2)",
+                code->len, (size_t)pr->circuit->group_size[GROUP_CODE] << po2);
     std::unique_ptr<PolyGroup> pg(new PolyGroup());
     ZKH_TRY(commit_group_enqueue(pr->ctx, *pg, code, pr->circuit->group_size[GROUP_CODE], (size_t)1 << po2));
     ZKH_TRY(pg->merkle.fetch_top(pr->ctx));
@@ -250,6 +252,15 @@ extern "C" const char* zkh_prover_cache_code(zkh_prover* pr, size_t po2, const z
     return nullptr;
 }
 extern "C" void zkh_prover_drop_code_cache(zkh_prover* pr) { if (pr) pr->code_cache.clear(); }
+// The resident entry is keyed by po2 alone, while a code trace also depends on zk_cycles: a caller that changes zk_cycles
+// must re-cache.  This getter lets it check what is resident against the control root it expects before sealing with it.
+extern "C" const char* zkh_prover_cached_code_root(zkh_prover* pr, size_t po2, uint32_t root[8]) {
+    ZKH_REQUIRE(pr && root, "prover_cached_code_root: null argument");
+    auto it = pr->code_cache.find(po2);
+    ZKH_REQUIRE(it != pr->code_cache.end(), "prover_cached_code_root: no resident code group for po2 %zu", po2);
+    memcpy(root, it->second->merkle.root(), 32);
+    return nullptr;
+}
 
 extern "C" const char* zkh_prove_begin(zkh_prover* pr, size_t po2, const zkh_buf* code, const zkh_buf* data,
                                        const uint32_t* out_global, zkh_seal_job** out_job, uint32_t* mix_out) {
@@ -303,6 +314,7 @@ extern "C" const char* zkh_prove_finish(zkh_seal_job* job_raw, const zkh_buf* ac
 // SegmentProver::prove for the SYN-AIR family (kind 1), whose accum witness generator lives in this library.
 extern "C" const char* zkh_prove_segment(zkh_prover* pr, size_t po2, size_t zk_cycles, uint64_t noise_seed, const zkh_buf* code,
                                          const zkh_buf* data, const uint32_t* out_global, uint32_t** seal, size_t* seal_words) {
+    ZKH_REQUIRE(pr && data && out_global && seal && seal_words, "prove_segment: null argument");
     zkh_ctx* c = pr->ctx;
     const zkh_circuit* cir = pr->circuit;
     ZKH_REQUIRE(cir->kind == 1, "prove_segment: no built-in accum witness generator for circuit kind %u (use zkh_prove_begin / zkh_prove_finish)", cir->kind);

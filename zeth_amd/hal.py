@@ -103,6 +103,7 @@ ABI = {
     "zkh_prover_destroy": (None, [_vp]),
     "zkh_prover_cache_code": (_err, [_vp, _sz, _vp]),
     "zkh_prover_drop_code_cache": (None, [_vp]),
+    "zkh_prover_cached_code_root": (_err, [_vp, _sz, _u32p]),
     "zkh_prove_segment": (_err, [_vp, _sz, _sz, _u64, _vp, _vp, _u32p, C.POINTER(_u32p), C.POINTER(_sz)]),
     "zkh_free_seal": (None, [_u32p]),
     "zkh_prove_begin": (_err, [_vp, _sz, _vp, _vp, _u32p, C.POINTER(_vp), _u32p]),
@@ -269,6 +270,8 @@ class HostCircuit:
     def receipt_encode(self, seal, segment_index: int, control_root) -> np.ndarray:
         """Seal -> receipt container words (zkh_receipt_encode)."""
         s, cr = _u32(seal), _u32(control_root)
+        if cr.size != 8:
+            raise HalError("receipt_encode: control root must be 8 words")
         blob, n = _u32p(), _sz()
         _check(_lib.zkh_receipt_encode(self.h, _ptr(s), s.size, segment_index, _ptr(cr), C.byref(blob), C.byref(n)))
         out = np.ctypeslib.as_array(blob, shape=(n.value,)).copy()
@@ -290,6 +293,8 @@ class HostCircuit:
     def receipt_claim(self, seal, control_root, rc=None, diag=None) -> np.ndarray:
         """Claim digest (8 words) of a sealed segment: Poseidon2(out globals, po2, control root)."""
         s, cr = _u32(seal), _u32(control_root)
+        if cr.size != 8:
+            raise HalError("receipt_claim: control root must be 8 words")
         out = np.zeros(8, dtype=np.uint32)
         r = _ptr(_u32(rc)) if rc is not None else None
         d = _ptr(_u32(diag)) if diag is not None else None

@@ -279,8 +279,12 @@ class SuccinctReceipt:
             if len(nodes) % 2:
                 nxt.append(nodes[-1])
             nodes = nxt
-        if nodes[0][0] is not self.root and len(self.leaves) > 1:
-            raise ValueError("root is not the top join")
+        # the stored root must BE the top of the tree that was just verified — compared by content (a receipt that went
+        # through a container round trip is a different object), for one-leaf sessions too (the root is then that leaf)
+        top = nodes[0][0]
+        if (self.root.index != top.index or self.root.po2 != top.po2
+                or not np.array_equal(np.asarray(self.root.seal, dtype=np.uint32), np.asarray(top.seal, dtype=np.uint32))):
+            raise ValueError("root is not the top of the verified tree")
 
 
 class JoinExecutor:
