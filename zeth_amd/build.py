@@ -14,11 +14,14 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
-LIB = os.path.join(HERE, "libzkhal_mi355x.so")
-OBJ_DIR = os.path.join(HERE, "csrc", "_obj")
+# experiment builds of the same ABI (tools/gpu_*.sh A/B runs; loaded through ZKH_LIBRARY): ZKH_BUILD_VARIANT=<name>
+# ZKH_BUILD_FLAGS="-D..." -> .variants/libzkhal_<name>.so with its own object directory
+VARIANT = os.environ.get("ZKH_BUILD_VARIANT", "")
+LIB = os.path.join(ROOT, ".variants", f"libzkhal_{VARIANT}.so") if VARIANT else os.path.join(HERE, "libzkhal_mi355x.so")
+OBJ_DIR = os.path.join(ROOT, ".variants", f"_obj_{VARIANT}") if VARIANT else os.path.join(HERE, "csrc", "_obj")
 SOURCES = ["hal.hip", "ntt.hip", "hash.hip", "poly.hip", "circuit.hip", "prover.hip", "verifier.hip"]   # + generated eval_check units
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-unused-result"] + os.environ.get("ZKH_BUILD_FLAGS", "").split()
 # hash.hip: the unrolled Poseidon2 source order already interleaves 24 independent cells; LLVM's machine scheduler
 # re-interleaves it up to the register budget (126 VGPRs instead of 86) for no measurable gain on MI355X (hash_rows
 # M3 9.55 vs 9.59 ms): the source order is kept for the smaller footprint.
@@ -101,7 +104,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
-    build_examples()
+    if not VARIANT:
+        build_examples()
     if verbose:
         print("built", LIB)
     return LIB

@@ -90,6 +90,15 @@ ZKH_HD int64_t mad_i64_k(int32_t a, int32_t b_uniform, int64_t acc) {
     return (int64_t)((uint64_t)acc + (uint64_t)((int64_t)a * b_uniform));
 #endif
 }
+ZKH_HD int64_t mul_i64(int32_t a, int32_t b) {           // exact signed 32x32 -> 64 product: v_mad_i64_i32 with a literal 0 addend
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t d; uint64_t carry;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "v"(b));
+    return d;
+#else
+    return (int64_t)a * b;
+#endif
+}
 ZKH_HD int32_t smont_reduce(int64_t t) {                // any exact signed sum with |t| < P*2^31  ->  t*2^-32 in (-P, P)
     const int32_t m = (int32_t)((uint32_t)t * NEG_PINV);
     return (int32_t)(mad_i64_k(m, (int32_t)P, t) >> 32); // t + m*P: low 32 bits are zero

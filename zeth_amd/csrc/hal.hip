@@ -200,6 +200,7 @@ extern "C" void zkh_ctx_destroy(zkh_ctx* c) {
     uint32_t* t[] = {c->tab.rc, c->tab.diag, c->tab.tw_fwd_lo, c->tab.tw_fwd_hi, c->tab.tw_rev_lo, c->tab.tw_rev_hi,
                      c->tab.tile_fwd, c->tab.tile_rev, c->tab.shift_lo, c->tab.shift_hi, c->tab.layer_fwd, c->tab.layer_rev, c->tab.layer_fwd_plain};
     for (auto p : t) (void)hipFree(p);
+    for (auto& kv : c->ntt_fwd_matrix) (void)hipFree(kv.second);
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
     if (c->pinned) (void)hipHostFree(c->pinned);
