@@ -138,6 +138,15 @@ const char* zkh_mix_poly_coeffs(zkh_ctx*, zkh_buf* out, const uint32_t mix_start
  * (position, value) pairs: combos[pos[k]] -= val[k]) */
 const char* zkh_combos_prepare(zkh_ctx*, zkh_buf* combos, const uint32_t* pos, const uint32_t* vals_ext,
                                size_t n_entries);
+/* Hal::combos_prepare with upstream's own argument list (combos, coeff_u, combo_count, cycles, regs_count, reg_sizes,
+ * reg_combo_ids, mix), all operands device buffers as in `impl Hal`, nothing read back:
+ *   cur = 1; for r < regs_count: combos[cycles*reg_combo_ids[r] + i] -= cur * coeff_u[pos + i] (i < reg_sizes[r]); cur *= mix; pos += reg_sizes[r];
+ *   then ZKH_CHECK_SIZE times: combos[cycles*combo_count] -= cur * coeff_u[pos]; pos += 1; cur *= mix.
+ * combos: (combo_count + 1) x cycles ExtElems; register sizes <= 32.  (zkh_combos_prepare above is the host-flattened form
+ * the in-library prover uses.) */
+const char* zkh_combos_prepare_regs(zkh_ctx*, zkh_buf* combos, const zkh_buf* coeff_u, size_t combo_count, size_t cycles,
+                                    size_t regs_count, const zkh_buf* reg_sizes, const zkh_buf* reg_combo_ids,
+                                    const uint32_t mix[4]);
 /* Hal::combos_divide: synthetic division of combo polynomial `combo` (cycles ExtElems at combos[combo*cycles..])
  * by (x - pt) for every pt in pts; remainders (must be 0) are written to rem_out (n_pts ExtElems, device). */
 const char* zkh_combos_divide(zkh_ctx*, zkh_buf* combos, size_t combo, size_t cycles, const uint32_t* pts_ext,

@@ -399,6 +399,38 @@ __global__ void k_combos_prepare(uint4* combos, const uint32_t* pos, const uint4
     c.x = sub_mod(c.x, v.x); c.y = sub_mod(c.y, v.y); c.z = sub_mod(c.z, v.z); c.w = sub_mod(c.w, v.w);
     combos[pos[k]] = c;
 }
+// Hal::combos_prepare with upstream's own argument list, entirely on the device (no host round trip, like CudaHal):
+//   cur = 1; for each register r: combos[cycles * combo_id[r] + i] -= cur * coeff_u[pos + i] (i < size[r]); cur *= mix; pos += size[r]
+//   then the CHECK_SIZE check columns: combos[cycles * combo_count] -= cur * coeff_u[pos]; pos += 1; cur *= mix.
+// One lane per TARGET position (combo c, offset i) walks the register list and sums its own contributions (several
+// registers hit the same position, so the walk is per target, not per register); exact field arithmetic, so the order of
+// the subtractions does not matter.  A few dozen lanes x regs_count Fp4 products: ~0.1 ms for a thousand registers.
+constexpr uint32_t PREP_MAX_REG_SIZE = 32;
+__global__ void k_combos_prepare_regs(uint4* combos, size_t combos_ext, const uint4* coeff_u, uint32_t combo_count, size_t cycles,
+                                      uint32_t regs_count, const uint32_t* reg_sizes, const uint32_t* reg_combo_ids, Fp4 mix) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t c = tid / PREP_MAX_REG_SIZE, i = tid % PREP_MAX_REG_SIZE;
+    if (c > combo_count || (c == combo_count && i != 0)) return;
+    Fp4 cur = Fp4::one(), acc = Fp4::zero();
+    size_t pos = 0;
+    bool any = false;
+    auto ld = [&](size_t k) { const uint4 v = coeff_u[k]; return Fp4(Fp::raw(v.x), Fp::raw(v.y), Fp::raw(v.z), Fp::raw(v.w)); };
+    for (uint32_t r = 0; r < regs_count; r++) {
+        const uint32_t sz = reg_sizes[r];
+        if (reg_combo_ids[r] == c && i < sz) { acc = acc + cur * ld(pos + i); any = true; }
+        cur = cur * mix;
+        pos += sz;
+    }
+    if (c == combo_count) {
+        for (int k = 0; k < ZKH_CHECK_SIZE; k++) { acc = acc + cur * ld(pos + k); cur = cur * mix; }
+        any = true;
+    }
+    const size_t at = cycles * c + i;
+    if (!any || at >= combos_ext) return;
+    uint4 v = combos[at];
+    v.x = sub_mod(v.x, acc.c[0].v); v.y = sub_mod(v.y, acc.c[1].v); v.z = sub_mod(v.z, acc.c[2].v); v.w = sub_mod(v.w, acc.c[3].v);
+    combos[at] = v;
+}
 // Merkle opening for many query indices: block q handles idx[q]; first the column words then the sibling path.
 __global__ void k_merkle_open(uint32_t* out, const uint32_t* matrix, const uint32_t* nodes, const uint32_t* idxs,
                               size_t rows, size_t cols, size_t top_size, size_t words_per_query) {
@@ -495,6 +527,22 @@ extern "C" const char* zkh_combos_prepare(zkh_ctx* c, zkh_buf* combos, const uin
     }
 
     return last_launch_error("combos_prepare");
+}
+extern "C" const char* zkh_combos_prepare_regs(zkh_ctx* c, zkh_buf* combos, const zkh_buf* coeff_u, size_t combo_count, size_t cycles,
+                                               size_t regs_count, const zkh_buf* reg_sizes, const zkh_buf* reg_combo_ids, const uint32_t mix[4]) {
+    ZKH_REQUIRE(c && combos && coeff_u && reg_sizes && reg_combo_ids && mix, "combos_prepare_regs: null argument");
+    ZKH_REQUIRE(combos->len == (combo_count + 1) * cycles * 4, "combos_prepare_regs: combos has %zu words, expected (combo_count + 1) x cycles ExtElems", combos->len);
+    ZKH_REQUIRE(reg_sizes->len == regs_count && reg_combo_ids->len == regs_count, "combos_prepare_regs: reg_sizes / reg_combo_ids must hold regs_count words");
+    ZKH_REQUIRE(coeff_u->len % 4 == 0 && coeff_u->len >= 4 * (regs_count + ZKH_CHECK_SIZE), "combos_prepare_regs: coeff_u too short");
+    ZKH_REQUIRE(cycles >= PREP_MAX_REG_SIZE, "combos_prepare_regs: cycles %zu below the largest supported register size", cycles);
+    for (int i = 0; i < 4; i++) ZKH_REQUIRE(mix[i] < P, "combos_prepare_regs: mix is not a reduced element");
+    const Fp4 m(Fp::raw(mix[0]), Fp::raw(mix[1]), Fp::raw(mix[2]), Fp::raw(mix[3]));
+    const size_t lanes = (combo_count + 1) * PREP_MAX_REG_SIZE;
+    ProfScope ps(c, "combos_prepare", 36.0 * (double)(coeff_u->len / 4));
+    k_combos_prepare_regs<<<(unsigned)((lanes + 63) / 64), 64, 0, c->stream>>>((uint4*)combos->ptr(), combos->len / 4, (const uint4*)coeff_u->ptr(),
+                                                                               (uint32_t)combo_count, cycles, (uint32_t)regs_count, reg_sizes->ptr(),
+                                                                               reg_combo_ids->ptr(), m);
+    return last_launch_error("combos_prepare_regs");
 }
 extern "C" const char* zkh_merkle_open(zkh_ctx* c, const zkh_buf* matrix, const zkh_buf* nodes, size_t rows, size_t cols,
                                        const uint32_t* idx, size_t n_idx, zkh_buf* out) {

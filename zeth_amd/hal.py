@@ -76,6 +76,7 @@ ABI = {
     "zkh_batch_bit_reverse_extelem": (_err, [_vp, _vp, _sz]),
     "zkh_mix_poly_coeffs": (_err, [_vp, _vp, _u32p, _u32p, _vp, _vp, _sz, _sz]),
     "zkh_combos_prepare": (_err, [_vp, _vp, _u32p, _u32p, _sz]),
+    "zkh_combos_prepare_regs": (_err, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp, _u32p]),
     "zkh_combos_divide": (_err, [_vp, _vp, _sz, _sz, _u32p, _sz, _vp]),
     "zkh_combos_divide_all": (_err, [_vp, _vp, _sz, _sz, _u32p, _u32p, _vp]),
     "zkh_eltwise_add_elem": (_err, [_vp, _vp, _vp, _vp]),
@@ -423,6 +424,13 @@ class HipHal:
     def combos_prepare(self, combos: Buffer, pos, vals_ext) -> None:
         p, v = _u32(pos), _u32(vals_ext).reshape(-1)
         _check(_lib.zkh_combos_prepare(self.ctx, combos.h, _ptr(p), _ptr(v), p.size))
+
+    def combos_prepare_regs(self, combos: Buffer, coeff_u: Buffer, combo_count: int, cycles: int, reg_sizes: Buffer,
+                            reg_combo_ids: Buffer, mix) -> None:
+        """`Hal::combos_prepare` with upstream's literal argument list (all operands on the device)."""
+        m = _u32(mix)
+        _check(_lib.zkh_combos_prepare_regs(self.ctx, combos.h, coeff_u.h, combo_count, cycles, reg_sizes.size(), reg_sizes.h,
+                                            reg_combo_ids.h, _ptr(m)))
 
     def combos_divide(self, combos: Buffer, combo: int, cycles: int, pts_ext, rem_out: Buffer) -> None:
         p = _u32(pts_ext).reshape(-1)
