@@ -216,7 +216,8 @@ extern "C" const char* zkh_verify_segment(const zkh_circuit* c, const uint32_t* 
         const Fp g = fp_encode(137);
         for (int k = 0; k <= 27; k++) { const Fp w = fp_pow(g, 1ull << (27 - k)); rou_fwd[k] = w.v; rou_rev[k] = fp_inv(w).v; }
     }
-#define VFAIL(msg) return make_err("verify_segment: %s", msg)
+// the position tells tools/check_upstream_seal.py which section of the seal layout the first disagreement is in
+#define VFAIL(msg) return make_err("verify_segment: %s (seal word %zu of %zu)", msg, io.pos, io.n)
     // header
     const size_t out_size = c->global_size[GLOBAL_OUT];
     const uint32_t* out_global = io.read(out_size + 1);            // out words, then po2 as an Elem
