@@ -203,7 +203,12 @@ const char* zkh_eval_check(zkh_ctx*, const zkh_circuit*, zkh_buf* check, const z
                            const zkh_buf* const* globals, size_t n_globals, const uint32_t poly_mix[4], size_t po2,
                            size_t steps, int use_interpreter);
 
-/* ---- SYN-AIR witness generation on device (stands in for risc0-circuit-rv32im witgen) ---- */
+/* ---- built-in witness generators on the device, by circuit kind (desc word 13) ----
+ *   kind 1 SYN-AIR   stands in for risc0-circuit-rv32im's witgen (declared synthetic)
+ *   kind 2 KECCAK-F  every 25 active rows are one real keccak-f[1600] permutation (zeth_amd/circuits/keccak_f.py; stands
+ *                    in for risc0-circuit-keccak 4.0.2, /root/reference/Cargo.lock:5289).  For this kind `pub` is the optional
+ *                    input state of the LAST permutation (25 lanes = 50 words, low word first; NULL = seeded like the others)
+ *                    and out_global receives its output state as 100 16-bit limbs (lane l, limb j at 4 l + j). */
 /* code group only: a function of (circuit, po2, zk_cycles) — what the control root commits to */
 const char* zkh_syn_code(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cycles, zkh_buf* code);
 /* pub: OUTPUT_SIZE - 4 public input words (Montgomery; NULL if the circuit has none); out_global: OUTPUT_SIZE words */

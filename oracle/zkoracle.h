@@ -117,6 +117,14 @@ void zko_syn_witgen(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64
 void zko_syn_accum(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t noise_seed,
                    const uint32_t* data, const uint32_t* mix_global, uint32_t* accum);
 
+/* ---- KECCAK-F witness (zeth_amd/circuits/keccak_f.py; circuit kind 2): every 25 active rows = one keccak-f[1600] ----
+ * zko_syn_code / zko_syn_witgen dispatch here for kind 2; `pub` is then the optional input state of the LAST permutation
+ * (50 words = 25 lanes, low word first; NULL = seeded like the others) and out_global its output state (100 16-bit limbs). */
+uint64_t zko_keccak_lane(uint64_t seed, uint64_t perm, uint32_t lane);
+void zko_keccak_code(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint32_t* code);
+void zko_keccak_witgen(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t seed, uint64_t noise_seed,
+                       const uint32_t* last_input, uint32_t* code, uint32_t* data, uint32_t* out_global);
+
 /* ---- whole seal: restates SegmentProver::prove + risc0_zkp::prove::Prover ---- */
 /* returns malloc'd seal words (caller frees with zko_free); NULL + *err on failure */
 uint32_t* zko_prove_segment(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t seed,

@@ -90,6 +90,12 @@ class OracleCircuit:
         return code, data, out
 
     def _pub(self, pub):
+        if int(self.desc[13]) == 2:                       # KECCAK-F: optional input state of the last permutation (50 words)
+            if pub is None:
+                return None
+            self._pub_arr = np.ascontiguousarray(pub, dtype=np.uint32)
+            assert self._pub_arr.size == 50, "KECCAK-F takes 25 lanes = 50 words"
+            return self._pub_arr.ctypes.data
         n_pub = self.out_size - 4
         if n_pub == 0:
             return None

@@ -844,6 +844,8 @@ def shipped() -> Dict[str, np.ndarray]:
         SHIPPED["syn_tiny"] = syn_air.syn_tiny()
         SHIPPED["syn_join"] = syn_air.syn_join()
         SHIPPED["syn_heavy"] = syn_heavy.syn_heavy()
+        from . import keccak_f
+        SHIPPED["keccak_f"] = keccak_f.keccak_f_circuit()
     return SHIPPED
 
 

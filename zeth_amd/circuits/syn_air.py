@@ -118,16 +118,9 @@ def syn_join() -> np.ndarray:
     return build_syn_air(16, 128, 16, n_pub=JOIN_PUB_WORDS)
 
 
-def syn_keccak() -> np.ndarray:
-    """SYN-K: a third circuit through the same HAL with keccak-coprocessor-like proportions — very wide data group,
-    narrow code/accum (risc0-circuit-keccak 4.0.2 is un-vendored: /root/reference/Cargo.lock:5289; zeth's guest reaches it
-    through the patched tiny-keccak, /root/reference/guests/stateless-client/Cargo.toml:39).  Declared synthetic."""
-    return build_syn_air(8, 880, 8)
-
-
 if __name__ == "__main__":      # python -m zeth_amd.circuits.syn_air syn_a out.desc  (blob for non-Python hosts)
     import sys
     shape, path = sys.argv[1], sys.argv[2]
-    blob = {"syn_a": syn_a, "syn_tiny": syn_tiny, "syn_small": syn_small, "syn_join": syn_join, "syn_keccak": syn_keccak}[shape]()
+    blob = {"syn_a": syn_a, "syn_tiny": syn_tiny, "syn_small": syn_small, "syn_join": syn_join}[shape]()
     np.asarray(blob, dtype="<u4").tofile(path)
     print(f"{path}: {blob.size} words")

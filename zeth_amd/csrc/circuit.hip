@@ -230,6 +230,97 @@ __global__ void k_syn_accum_store(uint32_t* accum, const uint32_t* prods, uint32
     for (int i = 0; i < 4; i++) accum[(size_t)(4 * e + i) * n + r] = v[i];
 }
 
+// ---- KECCAK-F witness (zeth_amd/circuits/keccak_f.py; CPU twin: oracle/keccak.c) ----
+// Stands in for risc0-circuit-keccak 4.0.2's witness generator (un-vendored: /root/reference/Cargo.lock:5289): every 25
+// active rows are one FIPS 202 keccak-f[1600] permutation.  Two phases so that the wide (3840-column) trace is written with
+// coalesced stores: (1) one lane per PERMUTATION runs the 24 rounds on 25 x u64 registers and leaves 60 packed lanes per
+// trace row (state, theta parities, rho/pi output) in a scratch buffer; (2) one lane per (row, column) expands a bit.
+constexpr uint32_t KF_ROUNDS = 24, KF_BLOCK = 25, KF_LANES = 60;
+struct KeccakTables { uint64_t rc[KF_ROUNDS]; uint8_t rho[25]; };      // rho[x + 5 y]
+__device__ __forceinline__ uint64_t rotl64(uint64_t v, uint32_t k) { k &= 63; return k ? (v << k) | (v >> (64 - k)) : v; }
+__device__ __forceinline__ uint64_t keccak_lane(uint64_t seed, uint64_t perm, uint32_t lane) {
+    uint64_t z = seed ^ 0x4B454343414B5F46ull;
+    z += perm * 0xBF58476D1CE4E5B9ull;
+    z += (uint64_t)(lane + 1) * 0x94D049BB133111EBull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+__global__ void k_keccak_code(uint32_t* code, uint32_t n, uint32_t A, uint32_t K, KeccakTables tb) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y;
+    if (r >= n) return;
+    const bool in_blocks = r < KF_BLOCK * K;
+    const uint32_t k = r % KF_BLOCK;
+    bool v;
+    switch (col) {
+    case 0: v = r < A; break;
+    case 1: v = r == 0; break;
+    case 2: v = r > 0 && r < A; break;
+    case 3: v = in_blocks && k < KF_ROUNDS; break;
+    case 4: v = in_blocks && k >= 1; break;
+    case 5: v = in_blocks && k == 0; break;
+    case 6: v = K > 0 && r == KF_BLOCK * K - 1; break;
+    default: {
+        const uint32_t pos = (1u << (col - 7)) - 1;                 // 0, 1, 3, 7, 15, 31, 63
+        v = in_blocks && k >= 1 && ((tb.rc[k - 1] >> pos) & 1);
+    }
+    }
+    code[(size_t)col * n + r] = v ? R1 : 0;
+}
+// rows: [K][25][60] packed lanes; last_input: 25 lanes for permutation K-1 (device, may be null)
+__global__ void k_keccak_perm(uint64_t* rows, uint32_t K, uint64_t seed, const uint64_t* __restrict__ last_input, KeccakTables tb) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= K) return;
+    uint64_t a[25];
+    for (uint32_t l = 0; l < 25; l++) a[l] = (last_input && p + 1 == K) ? last_input[l] : keccak_lane(seed, p, l);
+    uint64_t* row = rows + (size_t)p * KF_BLOCK * KF_LANES;
+    for (uint32_t r = 0; r < KF_ROUNDS; r++, row += KF_LANES) {
+        uint64_t c[5], d[5], b[25];
+        for (uint32_t x = 0; x < 5; x++) {
+            const uint64_t t = a[x] ^ a[x + 5] ^ a[x + 10];
+            row[25 + x] = t;
+            row[30 + x] = c[x] = t ^ a[x + 15] ^ a[x + 20];
+        }
+        for (uint32_t x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ rotl64(c[(x + 1) % 5], 1);
+        for (uint32_t x = 0; x < 5; x++)
+            for (uint32_t y = 0; y < 5; y++) {
+                row[x + 5 * y] = a[x + 5 * y];
+                b[y + 5 * ((2 * x + 3 * y) % 5)] = rotl64(a[x + 5 * y] ^ d[x], tb.rho[x + 5 * y]);
+            }
+        for (uint32_t i = 0; i < 25; i++) row[35 + i] = b[i];
+        for (uint32_t y = 0; y < 5; y++)
+            for (uint32_t x = 0; x < 5; x++) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+        a[0] ^= tb.rc[r];
+    }
+    for (uint32_t i = 0; i < KF_LANES; i++) row[i] = i < 25 ? a[i] : 0;         // row 24: the output state
+}
+__global__ void k_keccak_expand(uint32_t* data, const uint64_t* __restrict__ rows, uint32_t n, uint32_t A, uint32_t K, uint64_t noise_seed) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y;
+    if (r >= n) return;
+    uint32_t v = 0;
+    if (r >= A) v = syn_cell(noise_seed, GROUP_DATA, col, r);
+    else if (r < KF_BLOCK * K) v = ((rows[(size_t)r * KF_LANES + (col >> 6)] >> (col & 63)) & 1) ? R1 : 0;
+    data[(size_t)col * n + r] = v;
+}
+KeccakTables keccak_tables() {
+    KeccakTables tb{};
+    uint32_t x = 1, y = 0;
+    for (uint32_t t = 0; t < 24; t++) {
+        tb.rho[x + 5 * y] = (uint8_t)(((t + 1) * (t + 2) / 2) % 64);
+        const uint32_t nx = y, ny = (2 * x + 3 * y) % 5;
+        x = nx; y = ny;
+    }
+    uint32_t reg = 1;                                        // LFSR x^8 + x^6 + x^5 + x^4 + 1 (FIPS 202 algorithm 5)
+    for (uint32_t i = 0; i < KF_ROUNDS; i++)
+        for (uint32_t j = 0; j < 7; j++) {
+            if (reg & 1) tb.rc[i] |= 1ull << ((1u << j) - 1);
+            reg <<= 1;
+            if (reg & 0x100) reg ^= 0x171;
+        }
+    return tb;
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -494,22 +585,61 @@ extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_bu
 }
 
 // ---- SYN-AIR witness ----
+// ---- built-in witness generators: circuit kind 1 = SYN-AIR, kind 2 = KECCAK-F ----
+static const char* keccak_check_shape(const zkh_circuit* c) {
+    ZKH_REQUIRE(c->group_size[GROUP_CODE] == 14 && c->group_size[GROUP_DATA] == KF_LANES * 64 && c->group_size[GROUP_ACCUM] == 4 &&
+                c->global_size[GLOBAL_OUT] == 100, "keccak witgen: the circuit does not have KECCAK-F's shape (14 / 3840 / 4 columns, 100 outputs)");
+    return nullptr;
+}
 extern "C" const char* zkh_syn_code(zkh_ctx* ctx, const zkh_circuit* c, size_t po2, size_t zk_cycles, zkh_buf* code) {
-    ZKH_REQUIRE(c->kind == 1, "syn_code: circuit is not SYN-AIR");
+    ZKH_REQUIRE(c->kind == 1 || c->kind == 2, "syn_code: no built-in witness generator for circuit kind %u", c->kind);
     const size_t n = (size_t)1 << po2;
     ZKH_REQUIRE(n > zk_cycles + 1, "syn_code: po2 too small for zk_cycles");
     const uint32_t wc = c->group_size[GROUP_CODE], A = (uint32_t)(n - zk_cycles);
     ZKH_REQUIRE(code->len == (size_t)wc * n, "syn_code: buffer shape mismatch");
+    if (c->kind == 2) {
+        ZKH_TRY(keccak_check_shape(c));
+        ProfScope prof(ctx, "keccak_code", 4.0 * wc * n);
+        k_keccak_code<<<dim3((unsigned)((n + 255) / 256), wc), 256, 0, ctx->stream>>>(code->ptr(), (uint32_t)n, A, A / KF_BLOCK, keccak_tables());
+        return last_launch_error("keccak_code");
+    }
     ProfScope prof(ctx, "syn_code", 4.0 * wc * n);
     k_syn_code<<<dim3((unsigned)((n + 255) / 256), wc), 256, 0, ctx->stream>>>(code->ptr(), wc, (uint32_t)n, A, SYN_CODE_SEED);
     return last_launch_error("syn_code");
 }
 extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t po2, size_t zk_cycles, uint64_t seed,
                                       uint64_t noise_seed, const uint32_t* pub, zkh_buf* code, zkh_buf* data, uint32_t* out_global) {
-    ZKH_REQUIRE(c->kind == 1, "syn_witgen: circuit is not SYN-AIR");
+    ZKH_REQUIRE(c->kind == 1 || c->kind == 2, "syn_witgen: no built-in witness generator for circuit kind %u", c->kind);
     const size_t n = (size_t)1 << po2;
     ZKH_REQUIRE(n > zk_cycles + 1, "syn_witgen: po2 too small for zk_cycles");
     const uint32_t wc = c->group_size[GROUP_CODE], wd = c->group_size[GROUP_DATA], A = (uint32_t)(n - zk_cycles);
+    if (c->kind == 2) {
+        // KECCAK-F: `pub` = optional input state of the LAST permutation (25 lanes = 50 words, low word first); out_global =
+        // that permutation's output state as 100 16-bit limbs (what the `final` row's constraints bind)
+        ZKH_TRY(keccak_check_shape(c));
+        ZKH_REQUIRE(code->len == (size_t)wc * n && data->len == (size_t)wd * n, "keccak witgen: buffer shape mismatch");
+        const uint32_t K = A / KF_BLOCK;
+        ZKH_REQUIRE(K > 0, "keccak witgen: no room for a permutation (25 rows) in %u active rows", A);
+        ZKH_TRY(zkh_syn_code(ctx, c, po2, zk_cycles, code));
+        Tmp rows, din;
+        ZKH_TRY(new_buf(ctx, (size_t)K * KF_BLOCK * KF_LANES * 2, false, rows.out()));
+        if (pub) ZKH_TRY(zkh_copy_from(ctx, "keccak_input", pub, 50, din.out()));
+        const KeccakTables tb = keccak_tables();
+        {
+            ProfScope prof(ctx, "keccak_perm", 8.0 * K * KF_BLOCK * KF_LANES);
+            k_keccak_perm<<<(K + 63) / 64, 64, 0, ctx->stream>>>((uint64_t*)rows->ptr(), K, seed, din ? (const uint64_t*)din->ptr() : nullptr, tb);
+        }
+        {
+            ProfScope prof(ctx, "keccak_expand", 4.0 * wd * n);
+            k_keccak_expand<<<dim3((unsigned)((n + 255) / 256), wd), 256, 0, ctx->stream>>>(data->ptr(), (const uint64_t*)rows->ptr(), (uint32_t)n, A, K, noise_seed);
+        }
+        ZKH_TRY(last_launch_error("keccak_witgen"));
+        uint32_t fin[50];
+        ZKH_TRY(zkh_read(ctx, rows, fin, ((size_t)K * KF_BLOCK - 1) * KF_LANES * 2, 50));
+        for (uint32_t l = 0; l < 25; l++)
+            for (uint32_t j = 0; j < 4; j++) out_global[4 * l + j] = fp_encode((fin[2 * l + (j >> 1)] >> (16 * (j & 1))) & 0xffffu).v;
+        return nullptr;
+    }
     const uint32_t n_pub = c->global_size[GLOBAL_OUT] - 4;
     ZKH_REQUIRE(code->len == (size_t)wc * n && data->len == (size_t)wd * n, "syn_witgen: buffer shape mismatch");
     ZKH_REQUIRE(n_pub == 0 || pub, "syn_witgen: the circuit has %u public input words but none were given", n_pub);
@@ -536,7 +666,7 @@ extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t
 }
 extern "C" const char* zkh_syn_accum(zkh_ctx* ctx, const zkh_circuit* c, size_t po2, size_t zk_cycles, uint64_t noise_seed,
                                      const zkh_buf* data, const uint32_t* mix_global, zkh_buf* accum) {
-    ZKH_REQUIRE(c->kind == 1, "syn_accum: circuit is not SYN-AIR");
+    ZKH_REQUIRE(c->kind == 1 || c->kind == 2, "syn_accum: no built-in accum witness generator for circuit kind %u", c->kind);
     const size_t n = (size_t)1 << po2;
     const uint32_t wa = c->group_size[GROUP_ACCUM], wd = c->group_size[GROUP_DATA], A = (uint32_t)(n - zk_cycles), k = wa / 4;
     ZKH_REQUIRE(accum->len == (size_t)wa * n && data->len == (size_t)wd * n, "syn_accum: buffer shape mismatch");

@@ -496,11 +496,16 @@ class HipHal:
 
     def syn_witgen(self, circuit: Circuit, po2: int, zk_cycles: int, seed: int, noise_seed: int, code: Buffer, data: Buffer,
                    pub=None) -> np.ndarray:
-        """-> out globals (OUTPUT_SIZE words: s, 0, 0, 0, then the public input words `pub`)."""
+        """-> out globals.  SYN-AIR (kind 1): OUTPUT_SIZE words s, 0, 0, 0, then the public input words `pub`.
+        KECCAK-F (kind 2): `pub` = optional input state of the LAST permutation (25 lanes = 50 words, low word first);
+        out = that permutation's output state as 100 16-bit limbs."""
         out_size = int(circuit.desc[7])
         out = np.zeros(out_size, dtype=np.uint32)
         p = _u32(pub) if pub is not None else np.zeros(0, np.uint32)
-        if p.size != out_size - 4:
+        if int(circuit.desc[13]) == 2:
+            if p.size not in (0, 50):
+                raise HalError(f"syn_witgen: KECCAK-F takes an optional 50-word input state, got {p.size} words")
+        elif p.size != out_size - 4:
             raise HalError(f"syn_witgen: circuit takes {out_size - 4} public input words, got {p.size}")
         _check(_lib.zkh_syn_witgen(self.ctx, circuit.h, po2, zk_cycles, seed & (2**64 - 1), noise_seed & (2**64 - 1),
                                    _ptr(p) if p.size else None, code.h, data.h, _ptr(out)))
