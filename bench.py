@@ -10,7 +10,7 @@ Configs (SURVEY.md §8d restatements of BASELINE.json's configs):
                     round-robin over the ranks and through a shared work index inside a rank; witness generation runs
                     inside the clock (reported separately), every seal is verified on the host after the clock stops;
                     value = S / wall ("scaling": "strong").
-  --config succinct (config 5)  S leaf segments + the binary SYN-J join tree down to one root receipt; joins run on the
+  --config succinct (config 5)  S leaf segments + the binary P2-JOIN join tree (Poseidon2 in-circuit) down to one root receipt; joins run on the
                     rank that holds the left child, right children cross the gloo control plane.
 
   --circuit syn_heavy  seals with the realistically heavy constraint system instead of SYN-A.
@@ -192,7 +192,7 @@ def main() -> None:
     from zeth_amd.circuits import syn_air
     from zeth_amd.circuits.desc import Circuit
     from zeth_amd.hal import HipHal
-    from zeth_amd.host import JoinExecutor, partition_round_robin, receipt_claim
+    from zeth_amd.host import JoinExecutor, fold_claims, node_claim, partition_round_robin, receipt_claim
     from zeth_amd.prover import Segment, SegmentProver
 
     # one GPU per rank; ZKH_SHARE_GPUS=1 lets ranks wrap around the visible devices (dry runs on a 1-GPU box)
@@ -207,7 +207,8 @@ def main() -> None:
         desc = syn_heavy.syn_heavy()
     else:
         desc = syn_air.syn_a()
-    join_desc = syn_air.syn_join()
+    from zeth_amd.circuits import p2_join
+    join_desc = p2_join.p2_join_circuit()     # joins hash their children's claims in-circuit (Poseidon2 unrolled over trace rows)
     circ = Circuit.parse(desc)
     wa, wc, wd = circ.group_sizes
     n = 1 << args.po2
@@ -631,7 +632,7 @@ def main() -> None:
                 ln.prover.prove_segment(Segment(index=0, po2=args.po2, seed=1, noise_seed=BENCH_NOISE))
             if succinct:
                 ln.join_prover.prove_segment(Segment(index=0, po2=args.join_po2, seed=1, noise_seed=BENCH_NOISE,
-                                                     pub=tuple([0] * 16)))
+                                                     pub=tuple([1] * 16)))
             ln.hal.sync()
         roots = {p: lanes[0].prover.control_root(p) for p in sorted({s.po2 for s in segs})}
         join_root = lanes[0].join_prover.control_root(args.join_po2) if succinct else None
@@ -641,7 +642,7 @@ def main() -> None:
         if succinct:
             # join tree: tasks of one level are independent -> spread over the lanes of this rank
             def claim_of(r, is_leaf):
-                return receipt_claim(r, desc if is_leaf else join_desc, roots[r.po2] if is_leaf else join_root)
+                return node_claim(r, desc if is_leaf else join_desc, roots[r.po2] if is_leaf else join_root, is_leaf)
 
             jlock = threading.Lock()
 
@@ -715,6 +716,21 @@ def main() -> None:
                 j.verify(join_desc, join_root)
                 verified += 1
         verify_s = time.perf_counter() - t_v
+        # succinct: what a holder of the COMPACT receipt (root + leaves, joins dropped) checks — the claim tree over the leaf
+        # claims, recomputed on the host with hash_pair, must end in the root receipt's public output
+        follows = None
+        if succinct and not args.no_verify:
+            mine_claims = {i: receipt_claim(receipts[i], desc, roots[segs[i].po2]) for i in mine}
+            parts = [mine_claims]
+            if distributed:
+                parts = [None] * world if rank == 0 else None
+                dist.gather_object(mine_claims, parts, dst=0)
+            if rank == 0 and root is not None and S > 1:
+                import numpy as np
+                allc = {k: v for part in parts for k, v in part.items()}
+                follows = bool(np.array_equal(root.seal[:8], fold_claims([allc[i] for i in range(S)])))
+                if not follows:
+                    raise SystemExit("bench: the root receipt's output is not the claim tree of the leaves")
         counts = torch.tensor([float(verified), float(len(joins_done))], dtype=torch.float64, device=ctrl_dev)
         if distributed:
             dist.all_reduce(counts)
@@ -726,7 +742,7 @@ def main() -> None:
                 "vs_baseline": None, "dtype": "u32", "data": "synthetic",
                 "config": {"workload": (f"{'block + join tree to one succinct receipt' if succinct else 'one block'}: {S} distinct "
                                         f"2^{args.po2}-cycle segments (last one 2^{segs[-1].po2}), {workload}; witness generation inside the clock"
-                                        + (f"; {n_joins} SYN-J joins at po2 {args.join_po2}" if succinct else "")),
+                                        + (f"; {n_joins} P2-JOIN joins at po2 {args.join_po2} (parent claim = Poseidon2 hash_pair of the children's, proven in-circuit)" if succinct else "")),
                            "po2": args.po2, "circuit": args.circuit, "segments": S,
                            "parallelism": f"segments round-robin over {world} GPU(s) + shared work index inside a rank, no data-path collective; "
                                           f"{inflight} seal(s) in flight per GPU" + ("; joins on the rank of their left child, right child over gloo" if succinct else ""),
@@ -737,6 +753,7 @@ def main() -> None:
                 "seal_call_ms_mean": 1e3 * sum(seal_s) / max(1, len(seal_s)),
                 "verified_after_clock": int(counts[0].item()), "verify_s_rank0": verify_s,
                 "root_receipt_words": int(root.seal.size) if root is not None else None,
+                "succinct_root_follows_from_leaf_claims": follows,
             }
     if rank == 0 and line is not None:
         print(json.dumps(line))

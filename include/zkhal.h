@@ -208,7 +208,10 @@ const char* zkh_eval_check(zkh_ctx*, const zkh_circuit*, zkh_buf* check, const z
  *   kind 2 KECCAK-F  every 25 active rows are one real keccak-f[1600] permutation (zeth_amd/circuits/keccak_f.py; stands
  *                    in for risc0-circuit-keccak 4.0.2, /root/reference/Cargo.lock:5289).  For this kind `pub` is the optional
  *                    input state of the LAST permutation (25 lanes = 50 words, low word first; NULL = seeded like the others)
- *                    and out_global receives its output state as 100 16-bit limbs (lane l, limb j at 4 l + j). */
+ *                    and out_global receives its output state as 100 16-bit limbs (lane l, limb j at 4 l + j).
+ *   kind 3 P2-JOIN   every 31 active rows are one Poseidon2 permutation; block 0 = hash_pair(left, right) (zeth_amd/circuits/
+ *                    p2_join.py; stands in for the in-circuit hashing of risc0-circuit-recursion 4.0.2, Cargo.lock:5305).
+ *                    `pub` = the two child claims (16 words, required); out_global = parent (8) ‖ left (8) ‖ right (8). */
 /* code group only: a function of (circuit, po2, zk_cycles) — what the control root commits to */
 const char* zkh_syn_code(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cycles, zkh_buf* code);
 /* pub: OUTPUT_SIZE - 4 public input words (Montgomery; NULL if the circuit has none); out_global: OUTPUT_SIZE words */

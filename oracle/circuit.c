@@ -157,7 +157,8 @@ uint32_t zko_syn_cell(uint64_t seed, uint32_t group, uint32_t col, uint32_t row)
 /* The code group depends only on (circuit, po2, zk_cycles) — like upstream, where it is the program's control
  * columns and its Merkle root is the control ID the verifier checks (verify/mod.rs check_code). */
 void zko_syn_code(const zko_circuit* c, unsigned po2, unsigned zk, uint32_t* code) {
-    if (c->kind == 2) { zko_keccak_code(c, po2, zk, code); return; }       /* built-in witness generators: 1 SYN-AIR, 2 KECCAK-F */
+    if (c->kind == 2) { zko_keccak_code(c, po2, zk, code); return; }       /* built-in witness generators: 1 SYN-AIR, 2 KECCAK-F, 3 P2-JOIN */
+    if (c->kind == 3) { zko_p2join_code(c, po2, zk, code); return; }
     size_t n = (size_t)1 << po2, A = n - zk;
     size_t wc = c->group_size[ZKC_GROUP_CODE];
     fp one = fp_from_u32(1);
@@ -179,6 +180,7 @@ void zko_syn_code(const zko_circuit* c, unsigned po2, unsigned zk, uint32_t* cod
 void zko_syn_witgen(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t seed, uint64_t noise_seed,
                     const uint32_t* pub, uint32_t* code, uint32_t* data, uint32_t* out_global) {
     if (c->kind == 2) { zko_keccak_witgen(c, po2, zk, seed, noise_seed, pub, code, data, out_global); return; }
+    if (c->kind == 3) { zko_p2join_witgen(c, po2, zk, noise_seed, pub, code, data, out_global); return; }
     size_t n = (size_t)1 << po2, A = n - zk;
     size_t wd = c->group_size[ZKC_GROUP_DATA];
     size_t n_pub = c->global_size[ZKC_GLOBAL_OUT] - 4;

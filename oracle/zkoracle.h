@@ -125,6 +125,13 @@ void zko_keccak_code(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint3
 void zko_keccak_witgen(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t seed, uint64_t noise_seed,
                        const uint32_t* last_input, uint32_t* code, uint32_t* data, uint32_t* out_global);
 
+/* ---- P2-JOIN witness (zeth_amd/circuits/p2_join.py; circuit kind 3): every 31 active rows = one Poseidon2 permutation,
+ * block 0 = hash_pair(left, right).  zko_syn_code / zko_syn_witgen dispatch here for kind 3; `pub` = the two child claims
+ * (16 Montgomery words, required), out_global = parent (8) ‖ left (8) ‖ right (8); the seed is unused. */
+void zko_p2join_code(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint32_t* code);
+void zko_p2join_witgen(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t noise_seed, const uint32_t* children,
+                       uint32_t* code, uint32_t* data, uint32_t* out_global);
+
 /* ---- whole seal: restates SegmentProver::prove + risc0_zkp::prove::Prover ---- */
 /* returns malloc'd seal words (caller frees with zko_free); NULL + *err on failure */
 uint32_t* zko_prove_segment(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t seed,

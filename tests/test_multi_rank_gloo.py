@@ -26,8 +26,8 @@ def _free_port():
 
 
 def _descs():
-    from zeth_amd.circuits import syn_air
-    return syn_air.syn_tiny(), syn_air.build_syn_air(6, 50, 4, n_pub=16)
+    from zeth_amd.circuits import p2_join, syn_air
+    return syn_air.syn_tiny(), p2_join.p2_join_circuit()        # joins hash their children's claims in-circuit
 
 
 def _worker(rank, world, port, q):
@@ -36,7 +36,7 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import zko
-    from zeth_amd.host import BlockProcessor, JoinExecutor, receipt_claim, torch_gather
+    from zeth_amd.host import BlockProcessor, JoinExecutor, node_claim, torch_gather
     from zeth_amd.prover import Segment, SegmentReceipt
     leaf_desc, join_desc = _descs()
     lib = zko.load()
@@ -59,7 +59,7 @@ def _worker(rank, world, port, q):
     leaf_root, join_root = oc.control_root(LEAF_PO2, ZK), ocj.control_root(JOIN_PO2, ZK)
 
     def claim_of(r, is_leaf):
-        return receipt_claim(r, leaf_desc if is_leaf else join_desc, leaf_root if is_leaf else join_root)
+        return node_claim(r, leaf_desc if is_leaf else join_desc, leaf_root if is_leaf else join_root, is_leaf)
 
     def prove_join(seg):
         seal = ocj.prove(seg.po2, ZK, seg.seed, 0x2E81, pub=np.array(seg.pub, np.uint32))
@@ -80,7 +80,8 @@ def _worker(rank, world, port, q):
 def test_world_size_2_round_robin_and_distributed_joins():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import zko
-    from zeth_amd.host import SuccinctReceipt, join_schedule, prove_succinct, receipt_claim
+    from zeth_amd.hal import HalError
+    from zeth_amd.host import SuccinctReceipt, fold_claims, join_schedule, node_claim, prove_succinct, receipt_claim
     from zeth_amd.prover import SegmentReceipt
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -110,7 +111,7 @@ def test_world_size_2_round_robin_and_distributed_joins():
     leaf_root, join_root = oc.control_root(LEAF_PO2, ZK), ocj.control_root(JOIN_PO2, ZK)
 
     def claim_of(r, is_leaf):
-        return receipt_claim(r, leaf_desc if is_leaf else join_desc, leaf_root if is_leaf else join_root)
+        return node_claim(r, leaf_desc if is_leaf else join_desc, leaf_root if is_leaf else join_root, is_leaf)
 
     def prove_join(seg):
         return SegmentReceipt(seal=ocj.prove(seg.po2, ZK, seg.seed, 0x2E81, pub=np.array(seg.pub, np.uint32)), index=seg.index, po2=seg.po2)
@@ -122,16 +123,27 @@ def test_world_size_2_round_robin_and_distributed_joins():
             assert merged[(t.level, t.index)] == j.seal.tobytes()
     assert root_bytes == single.root.seal.tobytes()
     single.verify(leaf_desc, join_desc, leaf_root, join_root)
-    # round-2 advisor finding: the stored root must be the top of the verified tree BY CONTENT ...
+    # P2-JOIN joins constrain parent = hash_pair(left, right): the verifier needs ONLY the root receipt and the leaves —
+    # the joins below the root are dropped, the claim tree is recomputed on the host and compared with the root's output
+    compact = single.compact()
+    assert compact.joins == []
+    compact.verify(leaf_desc, join_desc, leaf_root, join_root)
+    claims = [receipt_claim(r, leaf_desc, leaf_root) for r in leaves]
+    assert np.array_equal(single.root.seal[:8], fold_claims(claims))
     import copy
-    clone = copy.deepcopy(single)                       # different objects, same content (a container round trip)
-    clone.verify(leaf_desc, join_desc, leaf_root, join_root)
-    forged = SuccinctReceipt(root=leaves[0], joins=single.joins, leaves=single.leaves)
-    with pytest.raises(ValueError, match="root is not the top"):
-        forged.verify(leaf_desc, join_desc, leaf_root, join_root)
-    # ... for a one-leaf session too: the root is that leaf, and an arbitrary root next to a valid leaf is rejected
+    copy.deepcopy(compact).verify(leaf_desc, join_desc, leaf_root, join_root)      # content, not object identity
+    # a root that is not a join proof / a root over OTHER leaves / a leaf swapped for another valid leaf: all rejected
+    with pytest.raises((ValueError, HalError)):
+        SuccinctReceipt(root=leaves[0], joins=[], leaves=leaves).verify(leaf_desc, join_desc, leaf_root, join_root)
+    fewer = prove_succinct(leaves[:4], prove_join, claim_of, join_po2=JOIN_PO2)
+    with pytest.raises(ValueError, match="claim tree"):
+        SuccinctReceipt(root=fewer.root, joins=[], leaves=leaves).verify(leaf_desc, join_desc, leaf_root, join_root)
+    swapped = [leaves[1], leaves[0]] + leaves[2:]
+    swapped = [SegmentReceipt(seal=r.seal, index=i, po2=r.po2) for i, r in enumerate(swapped)]
+    with pytest.raises(ValueError, match="claim tree"):
+        SuccinctReceipt(root=single.root, joins=[], leaves=swapped).verify(leaf_desc, join_desc, leaf_root, join_root)
+    # a one-leaf session: the root is that leaf, and an arbitrary root next to a valid leaf is rejected
     one = prove_succinct(leaves[:1], prove_join, claim_of, join_po2=JOIN_PO2)
     one.verify(leaf_desc, join_desc, leaf_root, join_root)
-    bad = SuccinctReceipt(root=leaves[1], joins=[], leaves=leaves[:1])
     with pytest.raises(ValueError, match="root is not the top"):
-        bad.verify(leaf_desc, join_desc, leaf_root, join_root)
+        SuccinctReceipt(root=leaves[1], joins=[], leaves=leaves[:1]).verify(leaf_desc, join_desc, leaf_root, join_root)

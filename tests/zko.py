@@ -96,7 +96,7 @@ class OracleCircuit:
             self._pub_arr = np.ascontiguousarray(pub, dtype=np.uint32)
             assert self._pub_arr.size == 50, "KECCAK-F takes 25 lanes = 50 words"
             return self._pub_arr.ctypes.data
-        n_pub = self.out_size - 4
+        n_pub = 16 if int(self.desc[13]) == 3 else self.out_size - 4          # P2-JOIN: the two child claims
         if n_pub == 0:
             return None
         self._pub_arr = np.ascontiguousarray(pub, dtype=np.uint32)

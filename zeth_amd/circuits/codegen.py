@@ -846,6 +846,8 @@ def shipped() -> Dict[str, np.ndarray]:
         SHIPPED["syn_heavy"] = syn_heavy.syn_heavy()
         from . import keccak_f
         SHIPPED["keccak_f"] = keccak_f.keccak_f_circuit()
+        from . import p2_join
+        SHIPPED["p2_join"] = p2_join.p2_join_circuit()
     return SHIPPED
 
 

@@ -5,6 +5,8 @@
 // risc0_zkp::hal::CircuitHal (risc0-zkp 3.0.2 src/hal/mod.rs).  Reached from
 // /root/reference/crates/host/src/lib.rs:137.
 #include "circuit.h"
+#include "poseidon2.h"
+#include "../../include/zkh_poseidon2_consts.h"
 
 #include <algorithm>
 
@@ -321,6 +323,99 @@ KeccakTables keccak_tables() {
     return tb;
 }
 
+
+// ---- P2-JOIN witness (zeth_amd/circuits/p2_join.py; CPU twin: oracle/p2join.c) ----
+// Every 31 active rows are one Poseidon2 permutation laid out round by round (S[24], Q[24] = (S + rc)^3); block 0 hashes the
+// two child claims into the parent claim, the other blocks hash (parent ‖ public sibling words).  Stands in for the in-circuit
+// hashing of risc0-circuit-recursion 4.0.2 (un-vendored: /root/reference/Cargo.lock:5305).  A literal round-by-round
+// permutation (the trace needs every intermediate state); tab = Montgomery words of rc[24 * 29] then diag[24].
+constexpr uint32_t PJ_T = 24, PJ_HALF = 4, PJ_RP = 21, PJ_ROUNDS = 29, PJ_BLOCK = 31;
+__device__ __forceinline__ bool pj_is_full(uint32_t rnd) { return rnd < PJ_HALF || rnd >= PJ_HALF + PJ_RP; }
+__device__ void pj_m_ext(uint32_t (&c)[PJ_T]) {
+    uint32_t sums[4] = {0, 0, 0, 0};
+    for (uint32_t b = 0; b < PJ_T; b += 4) {
+        m4(c[b], c[b + 1], c[b + 2], c[b + 3]);
+        for (uint32_t i = 0; i < 4; i++) sums[i] = add_mod(sums[i], c[b + i]);
+    }
+    for (uint32_t k = 0; k < PJ_T; k++) c[k] = add_mod(c[k], sums[k & 3]);
+}
+__global__ void k_p2join_code(uint32_t* code, uint32_t n, uint32_t A, uint32_t K, const uint32_t* __restrict__ tab) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y;
+    if (r >= n) return;
+    uint32_t v = 0;
+    const bool in_blocks = r < PJ_BLOCK * K;
+    const uint32_t k = r % PJ_BLOCK;
+    const bool round_row = in_blocks && k >= 1 && k <= PJ_ROUNDS;
+    const bool full = round_row && pj_is_full(k - 1), part = round_row && !pj_is_full(k - 1);
+    switch (col) {
+    case 0: v = r < A ? R1 : 0; break;
+    case 1: v = r == 0 ? R1 : 0; break;
+    case 2: v = (r > 0 && r < A) ? R1 : 0; break;
+    case 3: v = (in_blocks && r == 0) ? R1 : 0; break;
+    case 4: v = (in_blocks && k == 0 && r > 0) ? R1 : 0; break;
+    case 5: v = (in_blocks && k == 1) ? R1 : 0; break;
+    case 6: v = full ? R1 : 0; break;
+    case 7: v = part ? R1 : 0; break;
+    case 8: v = (in_blocks && k >= 2 && pj_is_full(k - 2)) ? R1 : 0; break;
+    case 9: v = (in_blocks && k >= 2 && !pj_is_full(k - 2)) ? R1 : 0; break;
+    case 10: v = (in_blocks && r == PJ_BLOCK - 1) ? R1 : 0; break;
+    default:
+        if (col < 35) { if (full || (part && col == 11)) v = tab[(k - 1) * PJ_T + (col - 11)]; }
+        else if (in_blocks && k == 0 && r > 0) v = syn_cell(SYN_CODE_SEED, GROUP_CODE, col, r);
+    }
+    code[(size_t)col * n + r] = v;
+}
+// one lane per block: p0 .. p0 + count; block 0 takes `children` (16 words) and leaves the parent in parent_out, blocks
+// p >= 1 read the parent (written by an earlier launch) and their sibling words from the code group
+__global__ void k_p2join_blocks(uint32_t* data, const uint32_t* __restrict__ code, uint32_t n, uint32_t p0, uint32_t count,
+                                const uint32_t* __restrict__ children, uint32_t* parent, const uint32_t* __restrict__ tab) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t p = p0 + i;
+    const size_t r0 = (size_t)PJ_BLOCK * p;
+    uint32_t s[PJ_T];
+    for (uint32_t j = 0; j < PJ_T; j++) s[j] = 0;
+    if (p == 0) { for (uint32_t j = 0; j < 16; j++) s[j] = children[j]; }
+    else {
+        for (uint32_t j = 0; j < 8; j++) { s[j] = parent[j]; s[8 + j] = code[(size_t)(35 + j) * n + r0]; }
+    }
+    for (uint32_t j = 0; j < PJ_T; j++) { data[(size_t)j * n + r0] = s[j]; data[(size_t)(PJ_T + j) * n + r0] = 0; }
+    pj_m_ext(s);
+    const uint32_t* diag = tab + PJ_T * PJ_ROUNDS;
+    for (uint32_t rnd = 0; rnd < PJ_ROUNDS; rnd++) {
+        const size_t r = r0 + 1 + rnd;
+        for (uint32_t j = 0; j < PJ_T; j++) data[(size_t)j * n + r] = s[j];
+        if (pj_is_full(rnd)) {
+            for (uint32_t j = 0; j < PJ_T; j++) {
+                const uint32_t u = add_mod(s[j], tab[rnd * PJ_T + j]);
+                const uint32_t q = mul_mod(mul_mod(u, u), u);
+                data[(size_t)(PJ_T + j) * n + r] = q;
+                s[j] = mul_mod(mul_mod(q, q), u);
+            }
+            pj_m_ext(s);
+        } else {
+            const uint32_t u = add_mod(s[0], tab[rnd * PJ_T]);
+            const uint32_t q = mul_mod(mul_mod(u, u), u);
+            data[(size_t)PJ_T * n + r] = q;
+            for (uint32_t j = 1; j < PJ_T; j++) data[(size_t)(PJ_T + j) * n + r] = 0;
+            const uint32_t x7 = mul_mod(mul_mod(q, q), u);
+            uint32_t tot = x7;
+            for (uint32_t j = 1; j < PJ_T; j++) tot = add_mod(tot, s[j]);
+            s[0] = add_mod(tot, mul_mod(diag[0], x7));
+            for (uint32_t j = 1; j < PJ_T; j++) s[j] = add_mod(tot, mul_mod(diag[j], s[j]));
+        }
+    }
+    const size_t rl = r0 + PJ_BLOCK - 1;
+    for (uint32_t j = 0; j < PJ_T; j++) { data[(size_t)j * n + rl] = s[j]; data[(size_t)(PJ_T + j) * n + rl] = 0; }
+    if (p == 0) for (uint32_t j = 0; j < 8; j++) parent[j] = s[j];
+}
+// rows past the last block: zero while active, blinding noise after
+__global__ void k_p2join_tail(uint32_t* data, uint32_t n, uint32_t A, uint32_t first_row, uint64_t noise_seed) {
+    const uint32_t r = first_row + blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y;
+    if (r >= n) return;
+    data[(size_t)col * n + r] = r < A ? 0u : syn_cell(noise_seed, GROUP_DATA, col, r);
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -591,8 +686,19 @@ static const char* keccak_check_shape(const zkh_circuit* c) {
                 c->global_size[GLOBAL_OUT] == 100, "keccak witgen: the circuit does not have KECCAK-F's shape (14 / 3840 / 4 columns, 100 outputs)");
     return nullptr;
 }
+static const char* p2join_tables(zkh_ctx* ctx, Tmp& tab) {          // Montgomery words of the SHIPPED tables: rc[24 * 29] then diag[24]
+    std::vector<uint32_t> t(PJ_T * PJ_ROUNDS + PJ_T);
+    for (uint32_t i = 0; i < PJ_T * PJ_ROUNDS; i++) t[i] = fp_encode(ZKH_P2_ROUND_CONSTANTS[i]).v;
+    for (uint32_t i = 0; i < PJ_T; i++) t[PJ_T * PJ_ROUNDS + i] = fp_encode(ZKH_P2_M_INT_DIAG[i]).v;
+    return zkh_copy_from(ctx, "p2join_tables", t.data(), t.size(), tab.out());
+}
+static const char* p2join_check_shape(const zkh_circuit* c) {
+    ZKH_REQUIRE(c->group_size[GROUP_CODE] == 43 && c->group_size[GROUP_DATA] == 2 * PJ_T && c->group_size[GROUP_ACCUM] == 4 &&
+                c->global_size[GLOBAL_OUT] == 24, "p2join witgen: the circuit does not have P2-JOIN's shape (43 / 48 / 4 columns, 24 outputs)");
+    return nullptr;
+}
 extern "C" const char* zkh_syn_code(zkh_ctx* ctx, const zkh_circuit* c, size_t po2, size_t zk_cycles, zkh_buf* code) {
-    ZKH_REQUIRE(c->kind == 1 || c->kind == 2, "syn_code: no built-in witness generator for circuit kind %u", c->kind);
+    ZKH_REQUIRE(c->kind >= 1 && c->kind <= 3, "syn_code: no built-in witness generator for circuit kind %u", c->kind);
     const size_t n = (size_t)1 << po2;
     ZKH_REQUIRE(n > zk_cycles + 1, "syn_code: po2 too small for zk_cycles");
     const uint32_t wc = c->group_size[GROUP_CODE], A = (uint32_t)(n - zk_cycles);
@@ -603,16 +709,48 @@ extern "C" const char* zkh_syn_code(zkh_ctx* ctx, const zkh_circuit* c, size_t p
         k_keccak_code<<<dim3((unsigned)((n + 255) / 256), wc), 256, 0, ctx->stream>>>(code->ptr(), (uint32_t)n, A, A / KF_BLOCK, keccak_tables());
         return last_launch_error("keccak_code");
     }
+    if (c->kind == 3) {
+        ZKH_TRY(p2join_check_shape(c));
+        Tmp tab;
+        ZKH_TRY(p2join_tables(ctx, tab));
+        ProfScope prof(ctx, "p2join_code", 4.0 * wc * n);
+        k_p2join_code<<<dim3((unsigned)((n + 255) / 256), wc), 256, 0, ctx->stream>>>(code->ptr(), (uint32_t)n, A, A / PJ_BLOCK, tab->ptr());
+        return last_launch_error("p2join_code");
+    }
     ProfScope prof(ctx, "syn_code", 4.0 * wc * n);
     k_syn_code<<<dim3((unsigned)((n + 255) / 256), wc), 256, 0, ctx->stream>>>(code->ptr(), wc, (uint32_t)n, A, SYN_CODE_SEED);
     return last_launch_error("syn_code");
 }
 extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t po2, size_t zk_cycles, uint64_t seed,
                                       uint64_t noise_seed, const uint32_t* pub, zkh_buf* code, zkh_buf* data, uint32_t* out_global) {
-    ZKH_REQUIRE(c->kind == 1 || c->kind == 2, "syn_witgen: no built-in witness generator for circuit kind %u", c->kind);
+    ZKH_REQUIRE(c->kind >= 1 && c->kind <= 3, "syn_witgen: no built-in witness generator for circuit kind %u", c->kind);
     const size_t n = (size_t)1 << po2;
     ZKH_REQUIRE(n > zk_cycles + 1, "syn_witgen: po2 too small for zk_cycles");
     const uint32_t wc = c->group_size[GROUP_CODE], wd = c->group_size[GROUP_DATA], A = (uint32_t)(n - zk_cycles);
+    if (c->kind == 3) {
+        // P2-JOIN: `pub` = the two child claims (16 Montgomery words, required); out_global = parent ‖ left ‖ right
+        ZKH_TRY(p2join_check_shape(c));
+        ZKH_REQUIRE(code->len == (size_t)wc * n && data->len == (size_t)wd * n, "p2join witgen: buffer shape mismatch");
+        ZKH_REQUIRE(pub, "p2join witgen: the two child claims (16 words) are required");
+        for (uint32_t k = 0; k < 16; k++) ZKH_REQUIRE(pub[k] < P, "p2join witgen: child claim word %u is not a reduced element", k);
+        const uint32_t K = A / PJ_BLOCK;
+        ZKH_REQUIRE(K > 0, "p2join witgen: no room for a permutation (31 rows) in %u active rows", A);
+        ZKH_TRY(zkh_syn_code(ctx, c, po2, zk_cycles, code));
+        Tmp tab, kids, parent;
+        ZKH_TRY(p2join_tables(ctx, tab));
+        ZKH_TRY(zkh_copy_from(ctx, "children", pub, 16, kids.out()));
+        ZKH_TRY(new_buf(ctx, 8, false, parent.out()));
+        {
+            ProfScope prof(ctx, "p2join_blocks", 4.0 * wd * n);
+            k_p2join_blocks<<<1, 64, 0, ctx->stream>>>(data->ptr(), code->ptr(), (uint32_t)n, 0, 1, kids->ptr(), parent->ptr(), tab->ptr());
+            if (K > 1) k_p2join_blocks<<<(K - 1 + 63) / 64, 64, 0, ctx->stream>>>(data->ptr(), code->ptr(), (uint32_t)n, 1, K - 1, kids->ptr(), parent->ptr(), tab->ptr());
+            const uint32_t first = PJ_BLOCK * K;
+            if (first < n) k_p2join_tail<<<dim3((unsigned)((n - first + 255) / 256), wd), 256, 0, ctx->stream>>>(data->ptr(), (uint32_t)n, A, first, noise_seed);
+        }
+        ZKH_TRY(last_launch_error("p2join_witgen"));
+        memcpy(out_global + 8, pub, 64);
+        return zkh_read(ctx, parent, out_global, 0, 8);
+    }
     if (c->kind == 2) {
         // KECCAK-F: `pub` = optional input state of the LAST permutation (25 lanes = 50 words, low word first); out_global =
         // that permutation's output state as 100 16-bit limbs (what the `final` row's constraints bind)
@@ -666,7 +804,7 @@ extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t
 }
 extern "C" const char* zkh_syn_accum(zkh_ctx* ctx, const zkh_circuit* c, size_t po2, size_t zk_cycles, uint64_t noise_seed,
                                      const zkh_buf* data, const uint32_t* mix_global, zkh_buf* accum) {
-    ZKH_REQUIRE(c->kind == 1 || c->kind == 2, "syn_accum: no built-in accum witness generator for circuit kind %u", c->kind);
+    ZKH_REQUIRE(c->kind >= 1 && c->kind <= 3, "syn_accum: no built-in accum witness generator for circuit kind %u", c->kind);
     const size_t n = (size_t)1 << po2;
     const uint32_t wa = c->group_size[GROUP_ACCUM], wd = c->group_size[GROUP_DATA], A = (uint32_t)(n - zk_cycles), k = wa / 4;
     ZKH_REQUIRE(accum->len == (size_t)wa * n && data->len == (size_t)wd * n, "syn_accum: buffer shape mismatch");

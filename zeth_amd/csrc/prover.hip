@@ -317,7 +317,7 @@ extern "C" const char* zkh_prove_segment(zkh_prover* pr, size_t po2, size_t zk_c
     ZKH_REQUIRE(pr && data && out_global && seal && seal_words, "prove_segment: null argument");
     zkh_ctx* c = pr->ctx;
     const zkh_circuit* cir = pr->circuit;
-    ZKH_REQUIRE(cir->kind == 1 || cir->kind == 2, "prove_segment: no built-in accum witness generator for circuit kind %u (use zkh_prove_begin / zkh_prove_finish)", cir->kind);
+    ZKH_REQUIRE(cir->kind >= 1 && cir->kind <= 3, "prove_segment: no built-in accum witness generator for circuit kind %u (use zkh_prove_begin / zkh_prove_finish)", cir->kind);
     ZKH_REQUIRE(po2 + 2 <= (size_t)MAX_LOG_N, "prove_segment: po2 %zu too large (max %d)", po2, MAX_LOG_N - 2);
     const size_t n = (size_t)1 << po2;
     ZKH_REQUIRE(n > zk_cycles + 1, "prove_segment: po2 too small for zk_cycles");

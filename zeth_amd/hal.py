@@ -505,6 +505,9 @@ class HipHal:
         if int(circuit.desc[13]) == 2:
             if p.size not in (0, 50):
                 raise HalError(f"syn_witgen: KECCAK-F takes an optional 50-word input state, got {p.size} words")
+        elif int(circuit.desc[13]) == 3:
+            if p.size != 16:
+                raise HalError(f"syn_witgen: P2-JOIN takes the two child claims (16 words), got {p.size}")
         elif p.size != out_size - 4:
             raise HalError(f"syn_witgen: circuit takes {out_size - 4} public input words, got {p.size}")
         _check(_lib.zkh_syn_witgen(self.ctx, circuit.h, po2, zk_cycles, seed & (2**64 - 1), noise_seed & (2**64 - 1),

@@ -246,27 +246,99 @@ def join_segment(task: JoinTask, left_claim, right_claim, join_po2: int = JOIN_P
     return Segment(index=task.index, po2=join_po2, seed=seed, pub=tuple(int(x) for x in pub), **kw)
 
 
+def hash_pair(left, right) -> "np.ndarray":
+    """Poseidon2 `hash_pair` of two 8-word digests on the host (the library's zkh_poseidon2_mix_host): what a Merkle node is,
+    and what a P2-JOIN join proves about its two children's claims."""
+    import ctypes as C
+    import numpy as np
+    from . import hal as _hal
+    _hal.load_library()
+    st = np.zeros(24, dtype=np.uint32)
+    st[:8], st[8:16] = np.asarray(left, dtype=np.uint32), np.asarray(right, dtype=np.uint32)
+    _hal._check(_hal._lib.zkh_poseidon2_mix_host(None, None, st.ctypes.data_as(C.POINTER(C.c_uint32)), 1))
+    return st[:8].copy()
+
+
+def _is_p2_join(join_desc) -> bool:
+    return int(join_desc[13]) == 3
+
+
+def node_claim(receipt: SegmentReceipt, circuit_desc, control_root, is_leaf: bool) -> "np.ndarray":
+    """Claim of a node of the join tree.  Leaves: `receipt_claim`.  P2-JOIN joins: the parent digest the circuit constrains to
+    hash_pair(left, right) — `out[0..8)`; SYN-J joins (round 2): `receipt_claim` of the join receipt."""
+    import numpy as np
+    if not is_leaf and _is_p2_join(circuit_desc):
+        return np.asarray(receipt.seal[:8], dtype=np.uint32).copy()
+    return receipt_claim(receipt, circuit_desc, control_root)
+
+
+def fold_claims(claims) -> "np.ndarray":
+    """Root of the claim tree over `claims` along `join_schedule` (an unpaired last node is carried up unchanged)."""
+    level = [c for c in claims]
+    while len(level) > 1:
+        nxt = [hash_pair(level[2 * k], level[2 * k + 1]) for k in range(len(level) // 2)]
+        if len(level) % 2:
+            nxt.append(level[-1])
+        level = nxt
+    return level[0]
+
+
 @dataclass
 class SuccinctReceipt:
-    """Root join receipt + the tree below it (kept because the synthetic join does not verify its children in-circuit)."""
+    """Root join receipt + the leaves (+ optionally the joins below the root).
+
+    With P2-JOIN joins (zeth_amd/circuits/p2_join.py) every join CONSTRAINS parent = hash_pair(claim_left, claim_right), so
+    the join tree is a Merkle tree of claims: `verify` needs only the root receipt and the leaf receipts — it recomputes the
+    claim tree on the host and compares its root with the root receipt's public output; the joins below the root can be
+    dropped (`compact`).  (The synthetic join does not verify the child SEALS in-circuit — upstream's does, which is what lets
+    it drop the leaves as well; declared.)  With the round-2 SYN-J joins the whole tree is kept and walked."""
     root: SegmentReceipt
     joins: List[List[SegmentReceipt]]
     leaves: List[SegmentReceipt]
 
+    def compact(self) -> "SuccinctReceipt":
+        return SuccinctReceipt(root=self.root, joins=[], leaves=self.leaves)
+
     def verify(self, segment_desc, join_desc, leaf_root=None, join_root=None) -> None:
-        """Every leaf and join seal is accepted by the host verifier against its control root, the tree has the scheduled
-        shape, and every join's public outputs equal the claim digests of the two receipts it combines."""
         import numpy as np
-        shape = [len(t) for t in join_schedule(len(self.leaves), 1)]
-        if [len(lvl) for lvl in self.joins] != shape:
-            raise ValueError(f"join tree has levels {[len(lvl) for lvl in self.joins]}, expected {shape}")
         from .prover import shipped_control_root
+
         def root_of(desc, given, po2):
             r = _root_for(given, po2)
             return shipped_control_root(desc, po2) if r is None else r
         for s in self.leaves:
             s.verify(segment_desc, root_of(segment_desc, leaf_root, s.po2))
-        nodes = [(s, receipt_claim(s, segment_desc, root_of(segment_desc, leaf_root, s.po2))) for s in self.leaves]
+        leaf_claims = [receipt_claim(s, segment_desc, root_of(segment_desc, leaf_root, s.po2)) for s in self.leaves]
+        if len(self.leaves) == 1:
+            top = self.leaves[0]
+            if (self.root.index != top.index or self.root.po2 != top.po2
+                    or not np.array_equal(np.asarray(self.root.seal, dtype=np.uint32), np.asarray(top.seal, dtype=np.uint32))):
+                raise ValueError("root is not the top of the verified tree")
+            return
+        if _is_p2_join(join_desc):
+            # the root seal is a valid P2-JOIN proof, and what it hashed is the top of the claim tree over the verified leaves
+            self.root.verify(join_desc, root_of(join_desc, join_root, self.root.po2))
+            level = leaf_claims
+            while len(level) > 2:
+                nxt = [hash_pair(level[2 * k], level[2 * k + 1]) for k in range(len(level) // 2)]
+                if len(level) % 2:
+                    nxt.append(level[-1])
+                level = nxt
+            out = np.asarray(self.root.seal[:24], dtype=np.uint32)
+            if not np.array_equal(out[8:16], level[0]) or not np.array_equal(out[16:24], level[1]):
+                raise ValueError("root join does not commit to the claim tree of these leaves")
+            if not np.array_equal(out[:8], hash_pair(level[0], level[1])):
+                raise ValueError("root join's parent claim is not hash_pair of its children")     # implied by the seal; cheap to restate
+            # joins that were kept are checked too (they are not needed)
+            for lvl in self.joins:
+                for j in lvl:
+                    j.verify(join_desc, root_of(join_desc, join_root, j.po2))
+            return
+        # ---- SYN-J joins (round 2): walk the whole tree ----
+        shape = [len(t) for t in join_schedule(len(self.leaves), 1)]
+        if [len(lvl) for lvl in self.joins] != shape:
+            raise ValueError(f"join tree has levels {[len(lvl) for lvl in self.joins]}, expected {shape}")
+        nodes = list(zip(self.leaves, leaf_claims))
         for lvl, tasks in zip(self.joins, join_schedule(len(self.leaves), 1)):
             nxt = []
             for j, t in zip(lvl, tasks):
@@ -280,7 +352,7 @@ class SuccinctReceipt:
                 nxt.append(nodes[-1])
             nodes = nxt
         # the stored root must BE the top of the tree that was just verified — compared by content (a receipt that went
-        # through a container round trip is a different object), for one-leaf sessions too (the root is then that leaf)
+        # through a container round trip is a different object)
         top = nodes[0][0]
         if (self.root.index != top.index or self.root.po2 != top.po2
                 or not np.array_equal(np.asarray(self.root.seal, dtype=np.uint32), np.asarray(top.seal, dtype=np.uint32))):
