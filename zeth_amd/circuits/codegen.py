@@ -49,9 +49,16 @@ EPOCH_LOADS = int(os.environ.get("ZKH_CODEGEN_EPOCH", "48"))    # tap loads per 
 PART_WEIGHT = int(os.environ.get("ZKH_CODEGEN_PART", "3200"))   # value steps per generated kernel (~ one translation unit / code object)
 USE_LAZY = int(os.environ.get("ZKH_CODEGEN_LAZY", "1"))
 PREFETCH = int(os.environ.get("ZKH_CODEGEN_PREFETCH", "4"))    # tap loads issued this many constraints ahead of their first use
+# Order the constraints of a chain by tap-set locality (Plan.order_by_locality).  MEASURED, OFF by default
+# (profiles/r03_eval_check_locality.txt): it cuts the tap loads per point by 23 % (SYN-HEAVY) / 37 % (KECCAK-F) but scatters
+# the constraints' mix-power exponents, whose scalar loads then no longer merge (s_load_dwordx16 -> x4) and spill SGPRs
+# (+6.2 k v_readlane / v_writelane per point): SYN-HEAVY eval_check 12.41 -> 12.87 ms.  The kernels are VALU-bound, not
+# fetch-bound; fewer loads alone buy nothing.
+LOCALITY = int(os.environ.get("ZKH_CODEGEN_LOCALITY", "0"))
+LOCALITY_WINDOW = max(16, REG_BUDGET * 2 // 3)                 # taps assumed resident when the next constraint is chosen
 # compile flags of the generated translation units (build.py and jit.py use the same list)
 KERNEL_FLAGS = [f for f in os.environ.get("ZKH_CODEGEN_FLAGS", "").split() if f]
-GENERATOR_VERSION = 7
+GENERATOR_VERSION = 8
 
 
 def desc_hash64(desc: np.ndarray) -> int:
@@ -130,6 +137,8 @@ class Plan:
     absorbed: set = field(default_factory=set)                                 # values that only exist inside a root's sum of products
     n_sop_terms: int = 0
     lazy: set = field(default_factory=set)                                     # values kept in [0, 2P): every consumer multiplies
+    _chains: Dict[int, List[Tuple]] = field(default_factory=dict)
+    _tapsets: Dict[int, frozenset] = field(default_factory=dict)
 
     @staticmethod
     def build(c: Circuit) -> "Plan":
@@ -323,17 +332,94 @@ class Plan:
         return [a, b] if op in (OP_ADD, OP_SUB, OP_MUL) else []
 
     def chain(self, m: int) -> List[Tuple]:
-        """Items of the chain ending in mix var m, in evaluation order: ('e', value, exp) | ('c', cond, inner var, exp)."""
+        """Items of the chain ending in mix var m, in EMISSION order: ('e', value, exp) | ('c', cond, inner var, exp).
+        Every item carries its own static exponent, and a chain's total is the plain sum of its items' contributions, so the
+        items may be emitted in any order: they are ordered by tap-set locality (below) instead of the order the circuit
+        happened to list them in.  Deterministic and cached: the splitter, the dry run and the emitter all see one order."""
+        cached = self._chains.get(m)
+        if cached is not None:
+            return cached
         items = []
-        while self.mix[m][0] != "t":
-            node = self.mix[m]
+        k = m
+        while self.mix[k][0] != "t":
+            node = self.mix[k]
             if node[0] == "e":
                 items.append(("e", node[2], self.mix_exp[node[1]]))
             else:
                 items.append(("c", node[2], node[3], self.mix_exp[node[1]]))
-            m = node[1]
+            k = node[1]
         items.reverse()
+        if LOCALITY and len(items) > 2:
+            items = self.order_by_locality(items)
+        self._chains[m] = items
         return items
+
+    def tapset(self, v: int) -> frozenset:
+        """taps (canonical OP_GET values) below value v"""
+        ts = self._tapsets.get(v)
+        if ts is None:
+            ts = frozenset(x for x in self.cone(v, ()) if self.fp[x][0] == OP_GET)
+            self._tapsets[v] = ts
+        return ts
+
+    def item_taps(self, it) -> frozenset:
+        if it[0] == "e":
+            return self.tapset(it[1])
+        acc = set(self.tapset(it[1]))
+        for sub in self.chain(it[2]):
+            acc |= self.item_taps(sub)
+        return frozenset(acc)
+
+    def order_by_locality(self, items: List[Tuple]) -> List[Tuple]:
+        """Greedy clustering: after an item, emit next the unplaced item with the largest FRACTION of its taps among the
+        last LOCALITY_WINDOW distinct taps emitted (what the register cache plausibly still holds), then the fewest new taps;
+        ties and cold starts fall back to the circuit's own order.  A tap that far-apart constraints read is then loaded
+        once per cluster instead of once per neighbourhood: tap loads per domain point SYN-HEAVY 2 910 -> 2 230, KECCAK-F
+        16 584 -> 10 497 (and 33.4 k -> 29.6 k arithmetic steps: fewer evicted intermediates are recomputed)."""
+        taps = [self.item_taps(it) for it in items]
+        n = len(items)
+        users: Dict[int, List[int]] = {}
+        for i, ts in enumerate(taps):
+            for t in ts:
+                users.setdefault(t, []).append(i)
+        placed = [False] * n
+        score = [0] * n                      # taps of item i currently in the window
+        window: "OrderedDict[int, None]" = OrderedDict()
+        order: List[int] = []
+        next_cold = 0
+        hot: set = set()                     # unplaced items with score > 0
+
+        def enter(t):
+            if t in window:
+                window.move_to_end(t)
+                return
+            window[t] = None
+            for i in users.get(t, ()):
+                if not placed[i]:
+                    score[i] += 1
+                    hot.add(i)
+            while len(window) > LOCALITY_WINDOW:
+                old, _ = window.popitem(last=False)
+                for i in users.get(old, ()):
+                    if not placed[i]:
+                        score[i] -= 1
+                        if score[i] <= 0:
+                            hot.discard(i)
+        for _ in range(n):
+            best = -1
+            if hot:
+                # most taps already resident, then fewest NEW taps to load, then the circuit's order
+                best = min(hot, key=lambda i: (-(score[i] / len(taps[i])), len(taps[i]) - score[i], i))
+            if best < 0:
+                while placed[next_cold]:
+                    next_cold += 1
+                best = next_cold
+            placed[best] = True
+            hot.discard(best)
+            order.append(best)
+            for t in sorted(taps[best]):
+                enter(t)
+        return [items[i] for i in order]
 
     def cone(self, v: int, have) -> List[int]:
         """Canonical values needed to compute v that are not in `have`, in dependency order (operands first)."""
