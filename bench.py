@@ -140,6 +140,7 @@ def main() -> None:
     ap.add_argument("--no-resident", action="store_true", help="segment config: skip the extra measurement with the code group kept resident")
     ap.add_argument("--no-block", action="store_true", help="segment config: skip the short block leg (S distinct segments, witgen in the clock, all verified)")
     ap.add_argument("--block-segments", type=int, default=64, help="segment config: segments of the short block leg (the last one a po2-18 tail)")
+    ap.add_argument("--no-succinct", action="store_true", help="segment config: skip the join tree over the block leg's receipts")
     ap.add_argument("--no-certify", action="store_true", help="segment config: do not verify the timed seals / compare with the golden digest after the clock")
     args = ap.parse_args()
 
@@ -572,6 +573,50 @@ def main() -> None:
                      "verify_s_rank0": verify_s,
                      "workload": f"{S} distinct 2^{args.po2}-cycle segments (last one 2^{bsegs[-1].po2}), round-robin over {world} GPU(s), "
                                  f"{inflight} in flight per GPU; `--config block` runs S = 256"}
+            # ... and, on one GPU, the join tree over that block's receipts down to ONE root receipt (BASELINE config 5 in
+            # small: P2-JOIN joins at po2 18 hash their children's claims in-circuit).  Per level the joins are independent and
+            # spread over the lanes.  Afterwards the compact receipt (root + leaves, joins dropped) is verified the way a
+            # holder would: root seal, then the claim tree recomputed on the host from the leaf claims.
+            if world == 1 and not args.no_succinct and S > 1:
+                from zeth_amd.host import SuccinctReceipt, join_schedule, join_segment
+                for ln in lanes:
+                    ln.join_prover = SegmentProver(ln.hal, join_desc)
+                    ln.join_prover.prove_segment(Segment(index=0, po2=args.join_po2, seed=1, noise_seed=BENCH_NOISE, pub=tuple([1] * 16)))
+                    ln.hal.sync()
+                jroot = lanes[0].join_prover.control_root(args.join_po2)
+                nodes = [(brec[i], receipt_claim(brec[i], desc, broots[bsegs[i].po2])) for i in range(S)]
+                n_joins = 0
+                device_sync(lanes)
+                t_j = time.perf_counter()
+                for tasks in join_schedule(S, 1):
+                    jsegs = [join_segment(t, nodes[t.left][1], nodes[t.right][1], args.join_po2, BENCH_NOISE) for t in tasks]
+                    out_recs = [None] * len(jsegs)
+                    pos, plock = [0], threading.Lock()
+
+                    def jwork(ln):
+                        try:
+                            while True:
+                                with plock:
+                                    k = pos[0]
+                                    if k >= len(jsegs):
+                                        return
+                                    pos[0] = k + 1
+                                out_recs[k] = ln.join_prover.prove_segment(jsegs[k])
+                        except Exception as e:
+                            ln.err = e
+                    run_lanes(lanes, jwork)
+                    nxt = [(r, node_claim(r, join_desc, jroot, False)) for r in out_recs]
+                    if len(nodes) % 2:
+                        nxt.append(nodes[-1])
+                    nodes, n_joins = nxt, n_joins + len(jsegs)
+                device_sync(lanes)
+                join_s = time.perf_counter() - t_j
+                SuccinctReceipt(root=nodes[0][0], joins=[], leaves=[brec[i] for i in range(S)]).verify(desc, join_desc, broots, jroot)
+                block["succinct"] = {"leaves": S, "joins": n_joins, "join_po2": args.join_po2, "join_tree_s": join_s,
+                                     "block_plus_joins_s": block["wall_clock_s"] + join_s,
+                                     "root_receipt_words": int(nodes[0][0].seal.size), "compact_receipt_verified": True,
+                                     "note": "P2-JOIN: parent claim = Poseidon2 hash_pair(children's claims) constrained in-circuit; the verifier "
+                                             "needs the root receipt + the leaves only (`--config succinct` runs S = 1024)"}
         last = next((ln.last for ln in lanes if ln.last is not None), None)
         if rank == 0:
             value = world * args.steps / dt
@@ -775,7 +820,7 @@ def add_roofline(line, prof, ref, args, inflight, widths, n):
     # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
     # FETCH doubled per the gfx950 correction; tools/pmc_summary.py) — bench.py cannot run rocprof on itself
     traffic, traffic_source = None, None
-    for fn in ("r02_traffic.json", "r01_traffic.json"):
+    for fn in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
             kname = {"hash_rows": "k_hash_rows", "hash_fold": "k_hash_fold", "eval_check": "k_eval_check_syn_a"}.get(dom["name"])
