@@ -14,10 +14,10 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nblocks) {
     return xcd * q + idx;
 }
 
-template <int RH, int LOGT, bool REMAP>
-__global__ __launch_bounds__(1024) void k_tile(uint32_t* io, uint32_t log_n, uint32_t lds_dummy) {
+template <int RH, int LOGT, bool REMAP, int THREADS = 1024>
+__global__ __launch_bounds__(THREADS) void k_tile(uint32_t* io, uint32_t log_n, uint32_t lds_dummy) {
     extern __shared__ uint32_t lds[];
-    constexpr int T = 1 << LOGT, GROUPS = 1024 >> LOGT, PER = (1 << RH) / GROUPS;
+    constexpr int T = 1 << LOGT, GROUPS = THREADS >> LOGT, PER = (1 << RH) / GROUPS;
     const uint32_t L = log_n - RH;
     const uint32_t tid = threadIdx.x, t = tid & (T - 1), g = tid >> LOGT;
     const uint32_t tiles = 1u << (L - LOGT);
@@ -39,16 +39,16 @@ __global__ void k_copy(uint4* io, size_t n4) {
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-template <int RH, int LOGT, bool REMAP>
+template <int RH, int LOGT, bool REMAP, int THREADS = 1024>
 void run(uint32_t* d, uint32_t log_n, uint32_t cols, size_t lds_bytes, const char* what) {
-    CK(hipFuncSetAttribute((const void*)k_tile<RH, LOGT, REMAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_tile<RH, LOGT, REMAP, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     dim3 grid(1u << (log_n - RH - LOGT), cols);
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    k_tile<RH, LOGT, REMAP><<<grid, 1024, lds_bytes>>>(d, log_n, 0);
+    k_tile<RH, LOGT, REMAP, THREADS><<<grid, THREADS, lds_bytes>>>(d, log_n, 0);
     CK(hipDeviceSynchronize());
     const int reps = 5;
     CK(hipEventRecord(a));
-    for (int i = 0; i < reps; i++) k_tile<RH, LOGT, REMAP><<<grid, 1024, lds_bytes>>>(d, log_n, 0);
+    for (int i = 0; i < reps; i++) k_tile<RH, LOGT, REMAP, THREADS><<<grid, THREADS, lds_bytes>>>(d, log_n, 0);
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= reps;
     const double bytes = 8.0 * cols * (double)((size_t)1 << log_n);
@@ -78,5 +78,8 @@ int main(int argc, char** argv) {
     run<7, 7, true>(d, log_n, cols, 64 << 10, "128 rows x 512 B");
     run<6, 8, true>(d, log_n, cols, 64 << 10, "64 rows x 1 KiB");
     run<8, 6, true>(d, log_n, cols, 0, "256 rows x 256 B, no LDS");
+    run<10, 3, true, 512>(d, log_n, cols, 32 << 10, "1024 rows x 32 B, 512 lanes, 32 KiB: four workgroups per CU");
+    run<10, 2, true, 256>(d, log_n, cols, 16 << 10, "1024 rows x 16 B, 256 lanes, 16 KiB: eight workgroups per CU");
+    run<10, 4, true, 512>(d, log_n, cols, 64 << 10, "1024 rows x 64 B, 512 lanes x 32 words");
     return 0;
 }

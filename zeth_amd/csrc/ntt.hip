@@ -345,10 +345,13 @@ __global__ __launch_bounds__(256) void k_ntt_low12(PassParams p) {
 // Strided pass, index bits [L, L+RH) with RH in {8, 10}: tile = 2^RH rows x 16 consecutive words, one lane per
 // (row group, column), 16 rows per lane.  Inverse: first pass (reads the witness, DIF, post-twiddle).  Forward:
 // last pass (pre-twiddle, DIT, in place).
-template <int RH, bool INVERSE, bool LAZY = false, bool MATRIX = false>
-__global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
+template <int RH, bool INVERSE, bool LAZY = false, bool MATRIX = false, int LT = 4>
+__global__ __launch_bounds__(1 << (RH - 4 + LT)) void k_ntt_high(PassParams p) {
+    // LT = log2 of the tile width in words: 4 (64-byte runs, 2^RH lanes) or 3 (32-byte runs, half the lanes and half the LDS per
+    // workgroup: twice as many independent workgroups per CU for the same waves)
+    constexpr uint32_t TW = 1u << LT;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];     // [2^RH][16]
-    const uint32_t tid = threadIdx.x, t = tid & 15, g = tid >> 4;
+    const uint32_t tid = threadIdx.x, t = tid & (TW - 1), g = tid >> LT;
     uint32_t tile_id, col;
     if (p.col_fast) {        // block b runs on XCD b % 8: that XCD owns a contiguous slice of tiles and walks the COLUMNS of a tile first
         const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, tl = slot / p.ncols;
@@ -358,10 +361,10 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
         tile_id = xcd_remap(blockIdx.x, p.tiles_per_col);
         col = blockIdx.y;
     }
-    const uint32_t lt_bits = p.L - 4;
+    const uint32_t lt_bits = p.L - LT;
     const uint32_t a = tile_id >> lt_bits, lt = tile_id & ((1u << lt_bits) - 1);
-    const size_t base = ((size_t)a << (p.L + RH)) + ((size_t)lt << 4);      // wave-uniform: first word of the tile
-    const uint32_t lcol = (lt << 4) + t;
+    const size_t base = ((size_t)a << (p.L + RH)) + ((size_t)lt << LT);      // wave-uniform: first word of the tile
+    const uint32_t lcol = (lt << LT) + t;
     const uint32_t tw_shift = MAX_LOG_N - (p.L + RH);
     // Tile accesses as uniform base (SGPR pair) + 32-bit per-lane byte offset — global_load's native addressing form; a
     // 64-bit VGPR address per access costs three extra VALU instructions each, ~10 % of this VALU-bound kernel.
@@ -417,20 +420,20 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
             for (int k = 0; k < 16; k++) v[k] = TILE_IN(k * 64 + g);
             radix_layers<4, true, false, 7>(v, ltab, g, 0);                     // sub-layers 10..7
 #pragma unroll
-            for (int k = 0; k < 16; k++) lds[(k * 64 + g) * 16 + t] = v[k];
+            for (int k = 0; k < 16; k++) lds[(k * 64 + g) * TW + t] = v[k];
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = lds[(hi * 64 + k * 4 + low) * 16 + t];
+            for (int k = 0; k < 16; k++) v[k] = lds[(hi * 64 + k * 4 + low) * TW + t];
             radix_layers<4, true, false, 3>(v, ltab, low, 0);                   // 6..3
 #pragma unroll
-            for (int k = 0; k < 16; k++) lds[(hi * 64 + k * 4 + low) * 16 + t] = v[k];
+            for (int k = 0; k < 16; k++) lds[(hi * 64 + k * 4 + low) * TW + t] = v[k];
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 uint32_t u[4];
                 const uint32_t m0 = (g * 4 + i) * 4;
 #pragma unroll
-                for (int k = 0; k < 4; k++) u[k] = lds[(m0 + k) * 16 + t];
+                for (int k = 0; k < 4; k++) u[k] = lds[(m0 + k) * TW + t];
                 radix_layers<2, true, true, 1>(u, ltab, 0, 0);                  // 2..1
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -465,17 +468,17 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
                     radix_layers<2, false, true, 1, LAZY>(u, ltab, 0, 0);
                 }
 #pragma unroll
-                for (int k = 0; k < 4; k++) lds[(m0 + k) * 16 + t] = u[k];
+                for (int k = 0; k < 4; k++) lds[(m0 + k) * TW + t] = u[k];
             }
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = lds[(hi * 64 + k * 4 + low) * 16 + t];
+            for (int k = 0; k < 16; k++) v[k] = lds[(hi * 64 + k * 4 + low) * TW + t];
             radix_layers<4, false, false, 3, LAZY>(v, ltab, low, 0);
 #pragma unroll
-            for (int k = 0; k < 16; k++) lds[(hi * 64 + k * 4 + low) * 16 + t] = v[k];
+            for (int k = 0; k < 16; k++) lds[(hi * 64 + k * 4 + low) * TW + t] = v[k];
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = lds[(k * 64 + g) * 16 + t];
+            for (int k = 0; k < 16; k++) v[k] = lds[(k * 64 + g) * TW + t];
             radix_layers<4, false, false, 7, LAZY>(v, ltab, g, 0);
 #pragma unroll
             for (int k = 0; k < 16; k++) TILE_OUT(k * 64 + g) = LAZY ? canon((int32_t)v[k]) : v[k];
@@ -486,10 +489,10 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
             for (int k = 0; k < 16; k++) v[k] = TILE_IN(k * 16 + g);
             radix_layers<4, true, false, 5>(v, ltab, g, 0);                     // 8..5
 #pragma unroll
-            for (int k = 0; k < 16; k++) lds[(k * 16 + g) * 16 + t] = v[k];
+            for (int k = 0; k < 16; k++) lds[(k * 16 + g) * TW + t] = v[k];
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = lds[(g * 16 + k) * 16 + t];
+            for (int k = 0; k < 16; k++) v[k] = lds[(g * 16 + k) * TW + t];
             radix_layers<4, true, true, 1>(v, ltab, 0, 0);                      // 4..1
 #pragma unroll
             for (int k = 0; k < 16; k++) {
@@ -509,10 +512,10 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
             }
             radix_layers<4, false, true, 1, LAZY>(v, ltab, 0, 1);
 #pragma unroll
-            for (int k = 0; k < 16; k++) lds[(g * 16 + k) * 16 + t] = v[k];
+            for (int k = 0; k < 16; k++) lds[(g * 16 + k) * TW + t] = v[k];
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = lds[(k * 16 + g) * 16 + t];
+            for (int k = 0; k < 16; k++) v[k] = lds[(k * 16 + g) * TW + t];
             radix_layers<4, false, false, 5, LAZY>(v, ltab, g, 0);
 #pragma unroll
             for (int k = 0; k < 16; k++) TILE_OUT(k * 16 + g) = canon((int32_t)v[k]);
@@ -524,10 +527,10 @@ __global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
             }
             radix_layers<4, false, true, 1, LAZY>(v, ltab, 0, 0);
 #pragma unroll
-            for (int k = 0; k < 16; k++) lds[(g * 16 + k) * 16 + t] = v[k];
+            for (int k = 0; k < 16; k++) lds[(g * 16 + k) * TW + t] = v[k];
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = lds[(k * 16 + g) * 16 + t];
+            for (int k = 0; k < 16; k++) v[k] = lds[(k * 16 + g) * TW + t];
             radix_layers<4, false, false, 5, LAZY>(v, ltab, g, 0);
 #pragma unroll
             for (int k = 0; k < 16; k++) TILE_OUT(k * 16 + g) = LAZY ? canon((int32_t)v[k]) : v[k];
@@ -627,6 +630,9 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
         // 4096-element tile allows (a 1..3-bit top pass then moves 2..8 KiB contiguous runs)
         const bool reg_high = ps.L >= 4 && (ps.R == 8 || ps.R == 10);
         p.log_t = ps.L == 0 ? 0 : (ps.L < 4 ? ps.L : 4);
+        static const bool narrow = getenv("ZKH_NTT_NARROW") != nullptr;        // A/B: 32-byte runs, 512-lane workgroups (profiles/r03_ntt_matrix.txt)
+        const bool narrow_here = narrow && lazy && reg_high && ps.R == 10 && !fwd_matrix;
+        if (narrow_here) p.log_t = 3;
         if (!reg_high && ps.L > 4 && ps.R < 8) p.log_t = ps.L < 12 - ps.R ? ps.L : 12 - ps.R;
         // keep the tile <= 64 KiB
         while (p.R + p.log_t > 14 && p.log_t > 0) p.log_t--;
@@ -663,7 +669,7 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
         const bool scale_here = p.scale != 0;
         // profiler record = "<Hal op>:<kernel>", so both the op totals and the per-kernel (per-pass) times can be read off
         const bool k_low = ps.L == 0 && ps.R == 12 && p.expand_bits <= 4;
-        const bool k_h10 = !k_low && ps.L >= 4 && p.log_t == 4 && ps.R == 10 && !(scale_here && p.zk_shift);
+        const bool k_h10 = !k_low && ps.L >= 4 && (p.log_t == 4 || narrow_here) && ps.R == 10 && !(scale_here && p.zk_shift);
         const bool k_h8 = !k_low && !k_h10 && ps.L >= 4 && p.log_t == 4 && ps.R == 8 && !(scale_here && p.zk_shift);
         const std::string pname = std::string(name) + (k_low ? ":k_ntt_low12" : k_h10 ? ":k_ntt_high10" : k_h8 ? ":k_ntt_high8" : ":k_ntt_pass");
         ProfScope prof(c, pname.c_str(), alg_bytes);
@@ -671,9 +677,10 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
             if (inverse) k_ntt_low12<true><<<grid, 256, 0, c->stream>>>(p);
             else if (lazy) k_ntt_low12<false, true><<<grid, 256, 0, c->stream>>>(p);
             else k_ntt_low12<false><<<grid, 256, 0, c->stream>>>(p);
-        } else if (ps.L >= 4 && p.log_t == 4 && ps.R == 10 && !(scale_here && p.zk_shift)) {
+        } else if (ps.L >= 4 && (p.log_t == 4 || narrow_here) && ps.R == 10 && !(scale_here && p.zk_shift)) {
             if (inverse) k_ntt_high<10, true><<<grid, 1024, lds, c->stream>>>(p);
             else if (lazy && p.tw_matrix) k_ntt_high<10, false, true, true><<<grid, 1024, lds, c->stream>>>(p);
+            else if (narrow_here) k_ntt_high<10, false, true, false, 3><<<grid, 512, lds, c->stream>>>(p);
             else if (lazy) k_ntt_high<10, false, true><<<grid, 1024, lds, c->stream>>>(p);
             else k_ntt_high<10, false><<<grid, 1024, lds, c->stream>>>(p);
         } else if (ps.L >= 4 && p.log_t == 4 && ps.R == 8 && !(scale_here && p.zk_shift)) {
