@@ -99,6 +99,52 @@ def cpu_baseline(desc, circuit_name: str) -> dict:
             "seal_words": int(seal.size)}
 
 
+def live_traffic(kernel: str, circuit: str, po2: int, budget_s: float = 150.0):
+    """HBM bytes per launch of `kernel`, measured NOW: two child runs of this script (one serial seal each, no extra legs)
+    under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` — separate passes, kernel trace only, as
+    /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes; FETCH_SIZE doubled per that guide's gfx950 correction.
+    -> (bytes per launch, launches, description) or None when rocprofv3 is unavailable / a pass fails / the budget runs out."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    t0 = time.perf_counter()
+    sums = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        left = budget_s - (time.perf_counter() - t0)
+        if left < 20:
+            return None
+        d = tempfile.mkdtemp(prefix="zkh_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "bench", "--",
+               sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--inflight", "1", "--po2", str(po2),
+               "--circuit", circuit, "--no-cpu-baseline", "--no-prof", "--no-heavy", "--no-resident", "--no-block", "--no-certify",
+               "--no-live-traffic"]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=left, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, check=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            vals = []
+            for r in csv.DictReader(open(files[0])):
+                m = re.search(r"(k_[A-Za-z0-9_]+)", r["Kernel_Name"])
+                if m and m.group(1) == kernel and r.get("Counter_Name", counter) == counter:
+                    vals.append(float(r["Counter_Value"]) * 1024.0)           # rocprofv3 reports KB
+            if not vals:
+                return None
+            sums[counter] = vals
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    n = len(sums["FETCH_SIZE"])
+    per_launch = (2.0 * sum(sums["FETCH_SIZE"]) + sum(sums["WRITE_SIZE"])) / n
+    return per_launch, n, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, kernel trace only) around "
+                           f"two child runs of this command with one serial seal each; FETCH x2 per the gfx950 correction; mean over {n} launches "
+                           f"({time.perf_counter() - t0:.0f} s)")
+
+
 def self_launch(args, argv) -> int:
     """`python bench.py --gpus N` without a launcher: spawn the N ranks ourselves (one process per GPU, gloo control
     plane over 127.0.0.1), pass rank 0's stdout (the ONE JSON line) through, fail if any rank fails."""
@@ -140,6 +186,7 @@ def main() -> None:
     ap.add_argument("--no-resident", action="store_true", help="segment config: skip the extra measurement with the code group kept resident")
     ap.add_argument("--no-block", action="store_true", help="segment config: skip the short block leg (S distinct segments, witgen in the clock, all verified)")
     ap.add_argument("--block-segments", type=int, default=64, help="segment config: segments of the short block leg (the last one a po2-18 tail)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC file instead of two rocprofv3 --pmc child runs")
     ap.add_argument("--no-succinct", action="store_true", help="segment config: skip the join tree over the block leg's receipts")
     ap.add_argument("--no-certify", action="store_true", help="segment config: do not verify the timed seals / compare with the golden digest after the clock")
     args = ap.parse_args()
@@ -820,7 +867,12 @@ def add_roofline(line, prof, ref, args, inflight, widths, n):
     # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
     # FETCH doubled per the gfx950 correction; tools/pmc_summary.py) — bench.py cannot run rocprof on itself
     traffic, traffic_source = None, None
-    for fn in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    kname = {"hash_rows": "k_hash_rows", "hash_fold": "k_hash_fold", "eval_check": "k_eval_check_syn_a"}.get(dom["name"])
+    if kname and not args.no_live_traffic and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        got = live_traffic(kname, args.circuit, args.po2)
+        if got is not None:
+            traffic, _, traffic_source = got
+    for fn in () if traffic is not None else ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
             kname = {"hash_rows": "k_hash_rows", "hash_fold": "k_hash_fold", "eval_check": "k_eval_check_syn_a"}.get(dom["name"])

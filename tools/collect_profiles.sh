@@ -6,8 +6,8 @@
 set -u
 OUT=$(realpath -m "${1:-gpurun_out/prof}"); mkdir -p "$OUT"
 ROOT=$PWD; export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 12 --warmup 2"
-SHORT="python $ROOT/bench.py --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-prof --no-heavy --no-resident"
+BENCH="python $ROOT/bench.py --steps 12 --warmup 2 --no-live-traffic"
+SHORT="python $ROOT/bench.py --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-prof --no-heavy --no-resident --no-block --no-certify --no-live-traffic"
 cd /tmp
 # ---- BASELINE config 2 (SYN-A): default (3 seals in flight), serial, PCIe-inclusive ----
 timeout 300 $BENCH --ingress host > "$OUT/bench.json" 2> "$OUT/bench.err"
@@ -19,9 +19,9 @@ timeout 300 $BENCH --circuit syn_heavy --inflight 1 --no-cpu-baseline > "$OUT/be
 timeout 600 python $ROOT/bench.py --config block --segments 256 --no-cpu-baseline > "$OUT/bench_block.json" 2>> "$OUT/bench.err"
 timeout 900 python $ROOT/bench.py --config succinct --segments 1024 --no-cpu-baseline > "$OUT/bench_succinct.json" 2>> "$OUT/bench.err"
 # ---- rocprofv3: kernel stats (default + serial + heavy serial), then counters, each on its own ----
-timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- $BENCH --no-cpu-baseline --no-heavy --no-resident > /dev/null 2>&1
-timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_serial" -o bench -- $BENCH --inflight 1 --no-cpu-baseline --no-heavy --no-resident > /dev/null 2>&1
-timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_heavy_serial" -o bench -- $BENCH --circuit syn_heavy --inflight 1 --no-cpu-baseline --no-resident > /dev/null 2>&1
+timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- $BENCH --no-cpu-baseline --no-heavy --no-resident --no-block > /dev/null 2>&1
+timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_serial" -o bench -- $BENCH --inflight 1 --no-cpu-baseline --no-heavy --no-resident --no-block > /dev/null 2>&1
+timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_heavy_serial" -o bench -- $BENCH --circuit syn_heavy --inflight 1 --no-cpu-baseline --no-resident --no-block > /dev/null 2>&1
 timeout 180 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o bench -- $SHORT > /dev/null 2>&1
 timeout 180 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -o bench -- $SHORT > /dev/null 2>&1
 timeout 180 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace \
