@@ -781,7 +781,7 @@ class _Emitter:
                     # tot += mix^e * x for an Fp4 x: sixteen products straight into the unreduced sums (four units of room)
                     if self.pend.get(d, 0) > 0:
                         self.fold(d)
-                    self.w(f"    ext_accumulate(s{d}_0, s{d}_1, s{d}_2, s{d}_3, pw[{e}], {self.ext_ref(v)});")
+                    self.w(f"    ext_accumulate(s{d}_0, s{d}_1, s{d}_2, s{d}_3, pwp[{e}], {self.ext_ref(v)});")
                     self.release()
                     self.pend[d] = 4
                     continue
@@ -791,7 +791,7 @@ class _Emitter:
                 wgt = 2 if v in self.p.lazy else 1      # a lazy value (< 2P) makes a product below 2 P^2
                 if self.pend.get(d, 0) + wgt > 4:
                     self.fold(d)
-                self.w(f"    {{ const uint4 p_ = pw[{e}]; s{d}_0 += (uint64_t)p_.x * {r}; s{d}_1 += (uint64_t)p_.y * {r}; "
+                self.w(f"    {{ const uint4 p_ = pwp[{e}]; s{d}_0 += (uint64_t)p_.x * {r}; s{d}_1 += (uint64_t)p_.y * {r}; "
                        f"s{d}_2 += (uint64_t)p_.z * {r}; s{d}_3 += (uint64_t)p_.w * {r}; }}")
                 self.release()
                 self.pend[d] = self.pend.get(d, 0) + wgt
@@ -812,7 +812,7 @@ class _Emitter:
                 tin = f"Fp4(Fp::raw(t{d + 1}_0), Fp::raw(t{d + 1}_1), Fp::raw(t{d + 1}_2), Fp::raw(t{d + 1}_3))"
                 prod = f"{tin} * {self.ext_ref(cond)}" if self.p.ext[cond] else f"{tin} * Fp::raw({self.ref(cond)})"
                 if e != 0:
-                    prod = f"({prod}) * Fp4(Fp::raw(pw[{e}].x), Fp::raw(pw[{e}].y), Fp::raw(pw[{e}].z), Fp::raw(pw[{e}].w))"
+                    prod = f"({prod}) * Fp4(Fp::raw(pwp[{e}].x), Fp::raw(pwp[{e}].y), Fp::raw(pwp[{e}].z), Fp::raw(pwp[{e}].w))"
                 self.add_fp4(d, prod)
                 self.release()
         return any_emitted
@@ -863,7 +863,7 @@ def emit_part(kernel: str, plan: Plan, lo: int, hi: int, standalone: bool, heade
     w("    if (idx >= a.dom) return;")
     w("    const uint32_t mask = a.dom - 1;")
     w("    const size_t dom = a.dom;")
-    w("    const uint4* __restrict__ pw = (const uint4*)a.mix_pows;")
+    w("    const uint4* __restrict__ pwp = (const uint4*)a.mix_pows;")
     for g in range(3):
         w(f"    const uint32_t* __restrict__ g{g} = a.groups[{g}];")
     for bk in sorted(backs_used):               # byte offset of this lane's row at each back (32-bit: 4n words < 2^26)
