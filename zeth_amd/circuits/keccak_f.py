@@ -227,3 +227,10 @@ def keccak_f_circuit() -> np.ndarray:
     if _cached is None:
         _cached = build_keccak_f()
     return _cached.copy()
+
+
+if __name__ == "__main__":      # python -m zeth_amd.circuits.keccak_f out.desc   (blob for non-Python hosts, e.g. examples/seal_segments)
+    import sys
+    blob = keccak_f_circuit()
+    np.asarray(blob, dtype="<u4").tofile(sys.argv[1])
+    print(f"{sys.argv[1]}: {blob.size} words")

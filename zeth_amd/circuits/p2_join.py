@@ -198,3 +198,10 @@ def p2_join_circuit() -> np.ndarray:
     if _cached is None:
         _cached = build_p2_join()
     return _cached.copy()
+
+
+if __name__ == "__main__":      # python -m zeth_amd.circuits.p2_join out.desc   (blob for non-Python hosts, e.g. examples/seal_segments)
+    import sys
+    blob = p2_join_circuit()
+    np.asarray(blob, dtype="<u4").tofile(sys.argv[1])
+    print(f"{sys.argv[1]}: {blob.size} words")
