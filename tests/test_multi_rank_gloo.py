@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: world_size-2 gloo processes partition a segment list round-robin, each "seals" its share with
+"""N > 1 path on CPU: world_size-2 and world_size-4 gloo processes partition a segment list round-robin, each "seals" its share with
 the CPU oracle standing in for the GPU (test-only), receipts are gathered on rank 0 with no data-path collective,
 and the composite equals the single-rank result bit for bit.  The same two ranks then run the distributed join
 executor (BASELINE config 5): right children cross the control plane, the root lands on rank 0, and the succinct
@@ -77,7 +77,8 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_world_size_2_round_robin_and_distributed_joins():
+@pytest.mark.parametrize("world", [2, 4])
+def test_round_robin_and_distributed_joins_over_gloo(world):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import zko
     from zeth_amd.hal import HalError
@@ -86,14 +87,14 @@ def test_world_size_2_round_robin_and_distributed_joins():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     idx, seals, tmax, gathered, root_bytes = q.get(timeout=400)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert idx == list(range(N_LEAVES)) and tmax == 2.0
+    assert idx == list(range(N_LEAVES)) and tmax == float(world)
     leaf_desc, join_desc = _descs()
     lib = zko.load()
     oc, ocj = zko.OracleCircuit(lib, leaf_desc), zko.OracleCircuit(lib, join_desc)
@@ -103,7 +104,8 @@ def test_world_size_2_round_robin_and_distributed_joins():
         assert s == want.tobytes()
         leaves.append(SegmentReceipt(seal=want, index=i, po2=LEAF_PO2))
     # which rank ran which join: the one holding the left child; together the two ranks ran every join exactly once
-    sched = join_schedule(N_LEAVES, 2)
+    sched = join_schedule(N_LEAVES, world)
+    assert any(t.right_owner != t.device for lvl in sched for t in lvl)          # some right child really crosses ranks
     for r, part in enumerate(gathered):
         assert set(part) == {(t.level, t.index) for lvl in sched for t in lvl if t.device == r}
     assert sum(len(p) for p in gathered) == N_LEAVES - 1
