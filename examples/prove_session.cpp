@@ -1,0 +1,81 @@
+// prove_session — `default_prover().prove(env, elf)` as ONE library call (plain C ABI, compiled with g++).
+//
+// zeth's whole prove path is that one call (/root/reference/crates/host/src/lib.rs:137); behind it risc0-zkvm 3.0.3's
+// ProverServer::prove_session seals the session's segments and (with ProverOpts::succinct) folds them to one receipt, and
+// /root/reference/crates/host/src/bin/cli.rs:103 verifies the result.  Here: zkh_session_create -> zkh_session_prove ->
+// zkh_session_verify (csrc/session.hip): the segment loop, the lanes, the join tree and the verification all run inside the
+// library; this file only builds the segment list and prints what came back.  (examples/seal_segments.cpp is the same session
+// written out against the low-level entry points.)
+//
+//   prove_session --desc syn_a.desc [--join-desc p2_join.desc] [--po2 20] [--tail-po2 18] [--segments 64] [--devices 1]
+//                 [--inflight 3] [--join-po2 18] [--noise-seed N]
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "zkhal.h"
+
+static bool read_words(const std::string& path, std::vector<uint32_t>& out) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) { perror(path.c_str()); return false; }
+    uint32_t w;
+    while (fread(&w, 4, 1, f) == 1) out.push_back(w);
+    fclose(f);
+    return out.size() >= 16;
+}
+
+int main(int argc, char** argv) {
+    std::string desc_path, join_path;
+    size_t po2 = 20, tail_po2 = 18, n = 64, devices = 1, inflight = 3, join_po2 = 18;
+    uint64_t noise = 0;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto num = [&](size_t& d) { if (i + 1 < argc) d = strtoull(argv[++i], nullptr, 10); };
+        if (a == "--desc" && i + 1 < argc) desc_path = argv[++i];
+        else if (a == "--join-desc" && i + 1 < argc) join_path = argv[++i];
+        else if (a == "--po2") num(po2);
+        else if (a == "--tail-po2") num(tail_po2);
+        else if (a == "--segments") num(n);
+        else if (a == "--devices") num(devices);
+        else if (a == "--inflight") num(inflight);
+        else if (a == "--join-po2") num(join_po2);
+        else if (a == "--noise-seed" && i + 1 < argc) noise = strtoull(argv[++i], nullptr, 0);
+        else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+    std::vector<uint32_t> desc, jdesc;
+    if (desc_path.empty() || !read_words(desc_path, desc) || (!join_path.empty() && !read_words(join_path, jdesc))) {
+        fprintf(stderr, "usage: %s --desc FILE [--join-desc FILE] [--po2 N] [--tail-po2 N] [--segments S] [--devices G] [--inflight K] [--join-po2 N] [--noise-seed N]\n", argv[0]);
+        return 2;
+    }
+    std::vector<int> devs(devices);
+    for (size_t d = 0; d < devices; d++) devs[d] = (int)d;
+    zkh_session* session = nullptr;
+    const char* err = zkh_session_create(devs.data(), devs.size(), inflight, desc.data(), desc.size(), jdesc.empty() ? nullptr : jdesc.data(), jdesc.size(), &session);
+    if (err) { fprintf(stderr, "zkh_session_create: %s\n", err); zkh_free_error(err); return 1; }
+    // the session's segment list: S distinct segments, the last one the short tail
+    std::vector<zkh_segment> segs(n);
+    for (size_t i = 0; i < n; i++) {
+        memset(&segs[i], 0, sizeof segs[i]);
+        segs[i].po2 = (uint32_t)((i + 1 == n && n > 1) ? (tail_po2 < po2 ? tail_po2 : po2) : po2);
+        segs[i].seed = 0x5EED0000ull + i;
+        segs[i].noise_seed = noise;                       // 0: fresh OS randomness per segment, like upstream
+    }
+    zkh_prove_info info;
+    err = zkh_session_prove(session, segs.data(), n, !jdesc.empty(), join_po2, noise, &info);
+    if (err) { fprintf(stderr, "zkh_session_prove: %s\n", err); zkh_free_error(err); return 1; }
+    err = zkh_session_verify(session, segs.data(), &info, join_po2);
+    if (err) { fprintf(stderr, "REJECTED: %s\n", err); zkh_free_error(err); return 1; }
+    size_t words = 0;
+    for (size_t i = 0; i < info.n_segments; i++) words += info.seal_words[i];
+    printf("{\"driver\": \"prove_session\", \"library\": \"%s\", \"segments\": %zu, \"po2\": %zu, \"tail_po2\": %u, \"lanes\": %zu, "
+           "\"wall_s\": %.4f, \"leaves_s\": %.4f, \"segments_per_s\": %.3f, \"witgen_ms_per_segment\": %.3f, \"joins\": %zu, \"join_tree_s\": %.4f, "
+           "\"root_receipt_words\": %zu, \"seal_words_total\": %zu, \"verified\": true}\n",
+           zkh_version(), n, po2, segs[n - 1].po2, zkh_session_lanes(session), info.wall_s, info.leaves_s, n / info.leaves_s,
+           1e3 * info.witgen_s_sum / n, info.n_joins, info.join_s, info.root_seal_words, words);
+    zkh_prove_info_free(&info);
+    zkh_session_destroy(session);
+    return 0;
+}

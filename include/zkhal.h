@@ -285,6 +285,54 @@ const char* zkh_receipt_encode(const zkh_circuit*, const uint32_t* seal, size_t 
 const char* zkh_receipt_decode(const zkh_circuit*, const uint32_t* blob, size_t blob_words, uint32_t info[26],
                                size_t* seal_offset);
 
+/* ---- session executor: ProverServer::prove_session / ProverImpl::{prove_segment, join} (risc0-zkvm 3.0.3, un-vendored:
+ * /root/reference/Cargo.lock:5418) — what default_prover().prove(env, elf) runs once the executor has cut the guest's run
+ * into segments (/root/reference/crates/host/src/lib.rs:137), as ONE call: every segment sealed on G devices x K lanes through
+ * one shared work index (segments are independent: no exchange between devices), receipts in index order, optionally folded
+ * through the P2-JOIN tree to one root receipt; zkh_session_verify is receipt.verify (cli.rs:103) for the result.
+ * A session owns its lanes (one zkh_ctx + circuit + prover each) and runs one zkh_session_prove at a time. ---- */
+typedef struct zkh_session zkh_session;
+typedef struct {
+    uint32_t po2;                 /* segment size 2^po2 cycles */
+    uint64_t seed;                /* built-in witness generators (circuit kind 1..3): witness seed */
+    uint64_t noise_seed;          /* blinding rows; 0 = fresh OS randomness per segment (the product default, like upstream) */
+    const uint32_t* pub;          /* public inputs of the built-in generators (see zkh_syn_witgen), may be NULL */
+    size_t n_pub;
+    /* caller-produced traces instead (CPU preflight + witgen, upstream's flow): W_code x 2^po2, W_data x 2^po2 words and
+     * OUTPUT_SIZE out globals; accum comes from the session's accumulate callback (built-in for kinds 1..3) */
+    const uint32_t* host_code;
+    const uint32_t* host_data;
+    const uint32_t* out_global;
+} zkh_segment;
+typedef struct {
+    size_t n_segments;
+    uint32_t** seals;             /* n_segments malloc'd seals in index order (the composite receipt) */
+    size_t* seal_words;
+    uint32_t* root_seal;          /* the root join receipt, or NULL (no join tree requested / one segment) */
+    size_t root_seal_words;
+    size_t n_joins;
+    double wall_s, leaves_s, join_s;            /* whole call, leaf phase, join tree */
+    double witgen_s_sum, seal_s_sum;            /* summed over segments (lane seconds) */
+} zkh_prove_info;
+/* CircuitHal::accumulate for circuits without a built-in accum generator: fill `accum` (W_accum x 2^po2) from data + mix */
+typedef const char* (*zkh_accumulate_fn)(void* user, zkh_ctx*, const zkh_circuit*, size_t po2, const zkh_buf* data,
+                                         const uint32_t* mix_global, zkh_buf* accum);
+/* devices[n_devices] x lanes_per_device lanes; join_desc: a P2-JOIN description (kind 3) or NULL */
+const char* zkh_session_create(const int* devices, size_t n_devices, size_t lanes_per_device, const uint32_t* desc,
+                               size_t desc_words, const uint32_t* join_desc, size_t join_desc_words, zkh_session** out);
+void zkh_session_destroy(zkh_session*);
+size_t zkh_session_lanes(const zkh_session*);
+/* the circuit handle of a lane (join != 0: its join circuit), e.g. to attach code objects before proving */
+zkh_circuit* zkh_session_circuit(zkh_session*, size_t lane, int join);
+void zkh_session_set_accumulate(zkh_session*, zkh_accumulate_fn fn, void* user);
+/* join_tree != 0: fold the receipts through the join tree (joins at 2^join_po2; join_noise_seed 0 = OS randomness) */
+const char* zkh_session_prove(zkh_session*, const zkh_segment* segs, size_t n, int join_tree, size_t join_po2,
+                              uint64_t join_noise_seed, zkh_prove_info* info);
+void zkh_prove_info_free(zkh_prove_info*);
+/* every leaf seal against the control root of its size; with a root receipt also the root seal and the claim tree
+ * (hash_pair over the leaf claims, recomputed on the host) against the root's public output */
+const char* zkh_session_verify(zkh_session*, const zkh_segment* segs, const zkh_prove_info* info, size_t join_po2);
+
 /* ---- profiling: per-kernel HIP-event timing on the ctx stream ---- */
 const char* zkh_prof_enable(zkh_ctx*, int on);
 /* writes up to cap records; returns count via *n.  Each record: name (<=47 chars), calls, total_ms */

@@ -78,3 +78,36 @@ def test_combos_prepare_with_upstreams_argument_list_equals_the_flattened_form(h
                        np.asarray([w for v in sub.values() for w in hop.e_words(v)], dtype=np.uint32))
     assert np.array_equal(a.to_vec(), b.to_vec())
     assert not np.array_equal(a.to_vec(), start)
+
+
+def test_native_session_executor_equals_the_python_orchestration(hal):
+    """zkh_session_prove (csrc/session.hip: C++ threads over lanes, one call per session) against the Python mirrors: the same
+    seals (fixed noise), the same root receipt as prove_succinct with the same join noise, zkh_session_verify accepts, and a
+    swapped leaf is rejected by the compact verification."""
+    from zeth_amd.circuits import p2_join
+    from zeth_amd.hal import HalError
+    from zeth_amd.host import Session, SuccinctReceipt, node_claim, prove_succinct
+    ldesc, jdesc = syn_air.syn_small(), p2_join.p2_join_circuit()
+    segs = [Segment(index=i, po2=12 if i < 4 else 13, seed=700 + i, noise_seed=0x51) for i in range(5)]
+    sess = Session(ldesc, devices=(0,), lanes_per_device=2, join_desc=jdesc)
+    comp, root, stats = sess.prove(segs, join_tree=True, join_po2=13, join_noise_seed=0x77, verify=True)
+    assert stats["n_joins"] == 4 and stats["verified"] and root is not None and stats["wall_s"] > 0
+    lp, jp = SegmentProver(hal, ldesc), SegmentProver(hal, jdesc)
+    want = [lp.prove_segment(s) for s in segs]
+    for a, b in zip(comp.segments, want):
+        assert np.array_equal(a.seal, b.seal)
+    roots = {p: lp.control_root(p) for p in (12, 13)}
+    jroot = jp.control_root(13)
+
+    def claim_of(r, is_leaf):
+        return node_claim(r, ldesc if is_leaf else jdesc, roots[r.po2] if is_leaf else jroot, is_leaf)
+    ref = prove_succinct(want, jp.prove_segment, claim_of, join_po2=13, noise_seed=0x77)
+    assert np.array_equal(root.seal, ref.root.seal)
+    SuccinctReceipt(root, [], comp.segments).verify(ldesc, jdesc, roots, jroot)
+    # a session without a join circuit refuses the join tree; a one-segment session has no root
+    plain = Session(ldesc, lanes_per_device=1)
+    with pytest.raises(HalError, match="without a join circuit"):
+        plain.prove(segs[:2], join_tree=True)
+    comp1, root1, _ = plain.prove(segs[:1], verify=True)
+    assert root1 is None and np.array_equal(comp1.segments[0].seal, want[0].seal)
+    sess.close(); plain.close()

@@ -259,6 +259,13 @@ def test_cpp_host_driver_seals_and_verifies(tmp_path):
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["verified"] == 7 and out["joins"] == 6 and out["compact_receipt_verified"] is True and out["root_receipt_words"] > 1000
+    # the same session as ONE library call (zkh_session_create / _prove / _verify): examples/prove_session
+    exe2 = os.path.join(os.path.dirname(exe), "prove_session")
+    r = subprocess.run([exe2, "--desc", str(desc), "--join-desc", str(jdesc), "--po2", "13", "--tail-po2", "12", "--segments", "6", "--inflight", "2",
+                        "--join-po2", "13"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["verified"] is True and out["segments"] == 6 and out["joins"] == 5 and out["tail_po2"] == 12 and out["lanes"] == 2
     for nm in names:
         assert open(da / nm, "rb").read() == open(db / nm, "rb").read(), nm
 

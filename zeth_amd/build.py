@@ -19,7 +19,7 @@ ROOT = os.path.dirname(HERE)
 VARIANT = os.environ.get("ZKH_BUILD_VARIANT", "")
 LIB = os.path.join(ROOT, ".variants", f"libzkhal_{VARIANT}.so") if VARIANT else os.path.join(HERE, "libzkhal_mi355x.so")
 OBJ_DIR = os.path.join(ROOT, ".variants", f"_obj_{VARIANT}") if VARIANT else os.path.join(HERE, "csrc", "_obj")
-SOURCES = ["hal.hip", "ntt.hip", "hash.hip", "poly.hip", "circuit.hip", "prover.hip", "verifier.hip"]   # + generated eval_check units
+SOURCES = ["hal.hip", "ntt.hip", "hash.hip", "poly.hip", "circuit.hip", "prover.hip", "verifier.hip", "session.hip"]   # + generated eval_check units
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-unused-result"] + os.environ.get("ZKH_BUILD_FLAGS", "").split()
 # hash.hip: the unrolled Poseidon2 source order already interleaves 24 independent cells; LLVM's machine scheduler
@@ -71,18 +71,23 @@ def generate_eval_check() -> list:
 
 
 def build_examples() -> str:
-    """examples/seal_segments: a plain g++ consumer of include/zkhal.h (no HIP headers, no Python)."""
-    src = os.path.join(ROOT, "examples", "seal_segments.cpp")
-    out = os.path.join(ROOT, "examples", "seal_segments")
-    deps = [src, os.path.join(ROOT, "include", "zkhal.h"), LIB]
-    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
-        return out
-    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", out, "-L", HERE,
-           "-lzkhal_mi355x", "-Wl,-rpath,$ORIGIN/../zeth_amd", "-Wl,-rpath-link,/opt/rocm/lib", "-lpthread"]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"g++ failed for examples/seal_segments.cpp:\n{r.stderr[-4000:]}")
-    return out
+    """examples/seal_segments (the session written out against the low-level entry points) and examples/prove_session (the
+    same session as one zkh_session_prove call): plain g++ consumers of include/zkhal.h (no HIP headers, no Python).
+    Returns the path of seal_segments."""
+    outs = []
+    for name in ("seal_segments", "prove_session"):
+        src = os.path.join(ROOT, "examples", name + ".cpp")
+        out = os.path.join(ROOT, "examples", name)
+        outs.append(out)
+        deps = [src, os.path.join(ROOT, "include", "zkhal.h"), LIB]
+        if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+            continue
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", out, "-L", HERE,
+               "-lzkhal_mi355x", "-Wl,-rpath,$ORIGIN/../zeth_amd", "-Wl,-rpath-link,/opt/rocm/lib", "-lpthread"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"g++ failed for examples/{name}.cpp:\n{r.stderr[-4000:]}")
+    return outs[0]
 
 
 def build_oracle() -> None:

@@ -1,0 +1,311 @@
+// session.hip — the session executor: every segment of a session sealed on G devices x K lanes, receipts in index order,
+// optionally folded through the P2-JOIN tree to one root receipt, and the verification of what comes out.
+//
+// Stands in for risc0-zkvm 3.0.3 `ProverServer::prove_session` / `ProverImpl::{prove_segment, lift, join}` (un-vendored:
+// /root/reference/Cargo.lock:5418) — what `default_prover().prove(env, elf)` (/root/reference/crates/host/src/lib.rs:137) runs
+// after the executor has cut the guest's execution into segments — and for `receipt.verify(image_id)`
+// (/root/reference/crates/host/src/bin/cli.rs:103).  Upstream proves the segments of a session in a plain loop on one
+// device; segments are independent, so here segment i goes to whichever lane is free next (one shared work
+// index over all lanes of all devices: round-robin with work stealing for the short tail), with NO exchange between devices.
+// Host code only (threads + the C ABI of this library); one lane = one zkh_ctx (device + stream) + circuit + prover.
+#include <atomic>
+#include <chrono>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <sys/random.h>
+
+#include "circuit.h"
+
+using namespace zkh;
+
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+uint64_t os_random64() {
+    uint64_t v = 0;
+    if (getrandom(&v, sizeof v, 0) != (ssize_t)sizeof v) v = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() * 0x9E3779B97F4A7C15ull;
+    return v ? v : 1;
+}
+
+struct Lane {
+    int device = 0;
+    zkh_ctx* ctx = nullptr;
+    zkh_circuit *circuit = nullptr, *join_circuit = nullptr;
+    zkh_prover *prover = nullptr, *join_prover = nullptr;
+    void close() {
+        if (join_prover) zkh_prover_destroy(join_prover);
+        if (prover) zkh_prover_destroy(prover);
+        if (join_circuit) zkh_circuit_destroy(join_circuit);
+        if (circuit) zkh_circuit_destroy(circuit);
+        if (ctx) zkh_ctx_destroy(ctx);
+        join_prover = prover = nullptr; join_circuit = circuit = nullptr; ctx = nullptr;
+    }
+};
+
+struct ErrorSlot {
+    std::mutex lock;
+    std::string first;
+    bool set(const char* err, const char* what) {          // takes ownership of err; returns true if there was an error
+        if (!err) return false;
+        {
+            std::lock_guard<std::mutex> lk(lock);
+            if (first.empty()) first = std::string(what) + ": " + err;
+        }
+        zkh_free_error(err);
+        return true;
+    }
+    bool any() { std::lock_guard<std::mutex> lk(lock); return !first.empty(); }
+};
+
+}  // namespace
+
+struct zkh_session {
+    std::vector<uint32_t> desc, join_desc;
+    std::vector<Lane> lanes;
+    zkh_accumulate_fn accumulate = nullptr;
+    void* accumulate_user = nullptr;
+    ~zkh_session() { for (auto& l : lanes) l.close(); }
+};
+
+extern "C" const char* zkh_session_create(const int* devices, size_t n_devices, size_t lanes_per_device, const uint32_t* desc, size_t desc_words,
+                                          const uint32_t* join_desc, size_t join_desc_words, zkh_session** out) {
+    ZKH_REQUIRE(devices && n_devices && lanes_per_device && desc && desc_words >= 16 && out, "session_create: bad argument");
+    ZKH_REQUIRE(!join_desc || (join_desc_words >= 16 && join_desc[13] == 3), "session_create: the join circuit must be a P2-JOIN description (kind 3)");
+    std::unique_ptr<zkh_session> s(new zkh_session());
+    s->desc.assign(desc, desc + desc_words);
+    if (join_desc) s->join_desc.assign(join_desc, join_desc + join_desc_words);
+    s->lanes.resize(n_devices * lanes_per_device);
+    for (size_t i = 0; i < s->lanes.size(); i++) {
+        Lane& l = s->lanes[i];
+        l.device = devices[i / lanes_per_device];
+        ZKH_TRY(zkh_ctx_create(l.device, "poseidon2", &l.ctx));
+        ZKH_TRY(zkh_circuit_load(l.ctx, s->desc.data(), s->desc.size(), &l.circuit));
+        ZKH_TRY(zkh_prover_create(l.ctx, l.circuit, &l.prover));
+        if (join_desc) {
+            ZKH_TRY(zkh_circuit_load(l.ctx, s->join_desc.data(), s->join_desc.size(), &l.join_circuit));
+            ZKH_TRY(zkh_prover_create(l.ctx, l.join_circuit, &l.join_prover));
+        }
+    }
+    *out = s.release();
+    return nullptr;
+}
+extern "C" void zkh_session_destroy(zkh_session* s) { delete s; }
+extern "C" size_t zkh_session_lanes(const zkh_session* s) { return s ? s->lanes.size() : 0; }
+extern "C" zkh_circuit* zkh_session_circuit(zkh_session* s, size_t lane, int join) {
+    if (!s || lane >= s->lanes.size()) return nullptr;
+    return join ? s->lanes[lane].join_circuit : s->lanes[lane].circuit;
+}
+extern "C" void zkh_session_set_accumulate(zkh_session* s, zkh_accumulate_fn fn, void* user) {
+    if (s) { s->accumulate = fn; s->accumulate_user = user; }
+}
+
+extern "C" void zkh_prove_info_free(zkh_prove_info* info) {
+    if (!info) return;
+    for (size_t i = 0; i < info->n_segments; i++) if (info->seals) zkh_free_seal(info->seals[i]);
+    free(info->seals); free(info->seal_words);
+    zkh_free_seal(info->root_seal);
+    memset(info, 0, sizeof *info);
+}
+
+// control root of the leaf circuit at one segment's size: generated for the built-in circuits, committed from the caller's
+// code trace otherwise (a deployment ships these per (circuit, po2): upstream's control IDs)
+static const char* leaf_control_root(zkh_session* s, const zkh_segment& seg, uint32_t root[8]) {
+    Lane& l = s->lanes[0];
+    if (l.circuit->kind >= 1 && l.circuit->kind <= 3) return zkh_syn_control_root(l.prover, seg.po2, ZKH_ZK_CYCLES, root);
+    ZKH_REQUIRE(seg.host_code, "session: circuit kind %u has no built-in code generator and the segment carries no code trace", l.circuit->kind);
+    Tmp code;
+    ZKH_TRY(zkh_copy_from(l.ctx, "code", seg.host_code, (size_t)l.circuit->group_size[GROUP_CODE] << seg.po2, code.out()));
+    return zkh_code_root(l.prover, code, seg.po2, root);
+}
+
+// one segment on one lane: built-in witness generator, or the caller's traces through prove_begin / accumulate / prove_finish
+static const char* seal_one(zkh_session* s, Lane& l, const zkh_segment& seg, uint32_t** seal, size_t* words, double* witgen_s) {
+    const zkh_circuit* cir = l.circuit;
+    const size_t n = (size_t)1 << seg.po2;
+    const uint64_t noise = seg.noise_seed ? seg.noise_seed : os_random64();
+    Tmp code, data;
+    ZKH_TRY(zkh_alloc(l.ctx, "code", (size_t)cir->group_size[GROUP_CODE] * n, 0, code.out()));
+    ZKH_TRY(zkh_alloc(l.ctx, "data", (size_t)cir->group_size[GROUP_DATA] * n, 0, data.out()));
+    std::vector<uint32_t> out_global(cir->global_size[GLOBAL_OUT]);
+    const double t0 = now_s();
+    if (seg.host_code || seg.host_data) {
+        ZKH_REQUIRE(seg.host_code && seg.host_data && seg.out_global, "session: a segment with host traces needs host_code, host_data and out_global");
+        ZKH_TRY(zkh_write(l.ctx, code, seg.host_code, 0, code->len));
+        ZKH_TRY(zkh_write(l.ctx, data, seg.host_data, 0, data->len));
+        out_global.assign(seg.out_global, seg.out_global + out_global.size());
+        *witgen_s = now_s() - t0;
+        zkh_seal_job* job = nullptr;
+        std::vector<uint32_t> mix(cir->global_size[GLOBAL_MIX] ? cir->global_size[GLOBAL_MIX] : 1);
+        ZKH_TRY(zkh_prove_begin(l.prover, seg.po2, code, data, out_global.data(), &job, mix.data()));
+        Tmp accum;
+        const char* err = zkh_alloc(l.ctx, "accum", (size_t)cir->group_size[GROUP_ACCUM] * n, 0, accum.out());
+        if (!err) {
+            if (s->accumulate) err = s->accumulate(s->accumulate_user, l.ctx, cir, seg.po2, data, mix.data(), accum);
+            else if (cir->kind >= 1 && cir->kind <= 3) err = zkh_syn_accum(l.ctx, cir, seg.po2, ZKH_ZK_CYCLES, noise, data, mix.data(), accum);
+            else err = make_err("session: circuit kind %u has no built-in accum witness generator and no accumulate callback was set", cir->kind);
+        }
+        if (err) { zkh_prove_abort(job); return err; }
+        return zkh_prove_finish(job, accum, seal, words);
+    }
+    ZKH_REQUIRE(cir->kind >= 1 && cir->kind <= 3, "session: circuit kind %u has no built-in witness generator: supply host traces", cir->kind);
+    ZKH_TRY(zkh_syn_witgen(l.ctx, cir, seg.po2, ZKH_ZK_CYCLES, seg.seed, noise, seg.n_pub ? seg.pub : nullptr, code, data, out_global.data()));
+    *witgen_s = now_s() - t0;
+    return zkh_prove_segment(l.prover, seg.po2, ZKH_ZK_CYCLES, noise, code, data, out_global.data(), seal, words);
+}
+
+extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs, size_t n, int join_tree, size_t join_po2, uint64_t join_noise_seed,
+                                         zkh_prove_info* info) {
+    ZKH_REQUIRE(s && segs && n && info, "session_prove: bad argument");
+    ZKH_REQUIRE(!join_tree || !s->join_desc.empty(), "session_prove: the session was created without a join circuit");
+    memset(info, 0, sizeof *info);
+    info->n_segments = n;
+    info->seals = (uint32_t**)calloc(n, sizeof(uint32_t*));
+    info->seal_words = (size_t*)calloc(n, sizeof(size_t));
+    ErrorSlot errs;
+    std::atomic<size_t> next{0};
+    std::mutex stat_lock;
+    const double t0 = now_s();
+    {
+        std::vector<std::thread> th;
+        for (auto& lane : s->lanes)
+            th.emplace_back([&, l = &lane] {
+                double wit = 0, seal_t = 0;
+                for (;;) {
+                    const size_t i = next.fetch_add(1);
+                    if (i >= n || errs.any()) break;
+                    double w = 0;
+                    const double ts = now_s();
+                    if (errs.set(seal_one(s, *l, segs[i], &info->seals[i], &info->seal_words[i], &w), "segment")) break;
+                    wit += w; seal_t += now_s() - ts - w;
+                }
+                (void)zkh_sync(l->ctx);
+                std::lock_guard<std::mutex> lk(stat_lock);
+                info->witgen_s_sum += wit; info->seal_s_sum += seal_t;
+            });
+        for (auto& t : th) t.join();
+    }
+    info->leaves_s = now_s() - t0;
+    // ---- the join tree: level l pairs nodes (2k, 2k+1) of level l-1, an unpaired last node is carried up; the joins of a
+    // level are independent and pulled from one index by the lanes.  A leaf's claim is zkh_receipt_claim (needs the leaf's
+    // control root: computed per size by the first lane), a join's claim is the parent digest it constrains (out[0..8)). ----
+    if (join_tree && n > 1 && !errs.any()) {
+        const double tj = now_s();
+        std::vector<std::vector<uint32_t>> claims(n, std::vector<uint32_t>(8));
+        std::vector<std::pair<uint32_t, std::vector<uint32_t>>> roots;          // (po2, control root) of the leaf circuit
+        for (size_t i = 0; i < n && !errs.any(); i++) {
+            const uint32_t po2 = segs[i].po2;
+            const std::vector<uint32_t>* root = nullptr;
+            for (auto& r : roots) if (r.first == po2) root = &r.second;
+            if (!root) {
+                std::vector<uint32_t> cr(8);
+                if (errs.set(leaf_control_root(s, segs[i], cr.data()), "control root")) break;
+                roots.emplace_back(po2, cr);
+                root = &roots.back().second;
+            }
+            errs.set(zkh_receipt_claim(s->lanes[0].circuit, info->seals[i], info->seal_words[i], root->data(), nullptr, nullptr, claims[i].data()), "receipt_claim");
+        }
+        while (claims.size() > 1 && !errs.any()) {
+            const size_t pairs = claims.size() / 2;
+            std::vector<std::vector<uint32_t>> up(pairs, std::vector<uint32_t>(8));
+            std::vector<uint32_t*> seals(pairs, nullptr);
+            std::vector<size_t> words(pairs, 0);
+            std::atomic<size_t> idx{0};
+            std::vector<std::thread> th;
+            for (auto& lane : s->lanes)
+                th.emplace_back([&, l = &lane] {
+                    const zkh_circuit* jc = l->join_circuit;
+                    const size_t jn = (size_t)1 << join_po2;
+                    Tmp code, data;
+                    if (errs.set(zkh_alloc(l->ctx, "code", (size_t)jc->group_size[GROUP_CODE] * jn, 0, code.out()), "join alloc") ||
+                        errs.set(zkh_alloc(l->ctx, "data", (size_t)jc->group_size[GROUP_DATA] * jn, 0, data.out()), "join alloc")) return;
+                    uint32_t pub[16], outg[24];
+                    for (;;) {
+                        const size_t k = idx.fetch_add(1);
+                        if (k >= pairs || errs.any()) break;
+                        memcpy(pub, claims[2 * k].data(), 32);
+                        memcpy(pub + 8, claims[2 * k + 1].data(), 32);
+                        const uint64_t noise = join_noise_seed ? join_noise_seed : os_random64();
+                        if (errs.set(zkh_syn_witgen(l->ctx, jc, join_po2, ZKH_ZK_CYCLES, 0, noise, pub, code, data, outg), "join witgen") ||
+                            errs.set(zkh_prove_segment(l->join_prover, join_po2, ZKH_ZK_CYCLES, noise, code, data, outg, &seals[k], &words[k]), "join seal")) break;
+                        memcpy(up[k].data(), seals[k], 32);
+                    }
+                    (void)zkh_sync(l->ctx);
+                });
+            for (auto& t : th) t.join();
+            if (!errs.any()) {
+                info->n_joins += pairs;
+                if (claims.size() == 2) { info->root_seal = seals[0]; info->root_seal_words = words[0]; seals[0] = nullptr; }
+            }
+            for (auto p : seals) zkh_free_seal(p);            // joins below the root are not kept: the verifier does not need them
+            if (claims.size() % 2) up.push_back(claims.back());
+            claims.swap(up);
+        }
+        info->join_s = now_s() - tj;
+    }
+    info->wall_s = now_s() - t0;
+    if (errs.any()) {
+        zkh_prove_info_free(info);
+        return make_err("session_prove: %s", errs.first.c_str());
+    }
+    return nullptr;
+}
+
+// receipt.verify for what zkh_session_prove returned: every leaf seal against the control root of its size, and — when a root
+// receipt is present — the root seal against the join circuit's control root plus the claim tree recomputed on the host.
+// Host arithmetic only, except that the control roots of the built-in circuits are computed on lane 0 (a deployment ships them).
+extern "C" const char* zkh_session_verify(zkh_session* s, const zkh_segment* segs, const zkh_prove_info* info, size_t join_po2) {
+    ZKH_REQUIRE(s && segs && info && info->n_segments, "session_verify: bad argument");
+    zkh_circuit* hc = nullptr;
+    ZKH_TRY(zkh_circuit_load(nullptr, s->desc.data(), s->desc.size(), &hc));
+    std::unique_ptr<zkh_circuit, void (*)(zkh_circuit*)> hold(hc, zkh_circuit_destroy);
+    std::vector<std::pair<uint32_t, std::vector<uint32_t>>> roots;
+    std::vector<std::vector<uint32_t>> claims(info->n_segments, std::vector<uint32_t>(8));
+    for (size_t i = 0; i < info->n_segments; i++) {
+        const uint32_t po2 = segs[i].po2;
+        const std::vector<uint32_t>* root = nullptr;
+        for (auto& r : roots) if (r.first == po2) root = &r.second;
+        if (!root) {
+            std::vector<uint32_t> cr(8);
+            ZKH_TRY(leaf_control_root(s, segs[i], cr.data()));
+            roots.emplace_back(po2, cr);
+            root = &roots.back().second;
+        }
+        if (const char* e = zkh_verify_segment(hc, info->seals[i], info->seal_words[i], root->data(), nullptr, nullptr)) {
+            const char* out = make_err("session_verify: segment %zu: %s", i, e);
+            zkh_free_error(e);
+            return out;
+        }
+        ZKH_TRY(zkh_receipt_claim(hc, info->seals[i], info->seal_words[i], root->data(), nullptr, nullptr, claims[i].data()));
+    }
+    if (!info->root_seal) return nullptr;
+    ZKH_REQUIRE(!s->join_desc.empty() && info->n_segments > 1, "session_verify: a root receipt without a join circuit");
+    zkh_circuit* jc = nullptr;
+    ZKH_TRY(zkh_circuit_load(nullptr, s->join_desc.data(), s->join_desc.size(), &jc));
+    std::unique_ptr<zkh_circuit, void (*)(zkh_circuit*)> jhold(jc, zkh_circuit_destroy);
+    uint32_t jroot[8];
+    ZKH_TRY(zkh_syn_control_root(s->lanes[0].join_prover, join_po2, ZKH_ZK_CYCLES, jroot));
+    if (const char* e = zkh_verify_segment(jc, info->root_seal, info->root_seal_words, jroot, nullptr, nullptr)) {
+        const char* out = make_err("session_verify: root receipt: %s", e);
+        zkh_free_error(e);
+        return out;
+    }
+    while (claims.size() > 2) {
+        std::vector<std::vector<uint32_t>> up(claims.size() / 2, std::vector<uint32_t>(8));
+        for (size_t k = 0; k < up.size(); k++) {
+            uint32_t st[24] = {0};
+            memcpy(st, claims[2 * k].data(), 32); memcpy(st + 8, claims[2 * k + 1].data(), 32);
+            ZKH_TRY(zkh_poseidon2_mix_host(nullptr, nullptr, st, 1));
+            memcpy(up[k].data(), st, 32);
+        }
+        if (claims.size() % 2) up.push_back(claims.back());
+        claims.swap(up);
+    }
+    ZKH_REQUIRE(info->root_seal_words > 24 && memcmp(info->root_seal + 8, claims[0].data(), 32) == 0 && memcmp(info->root_seal + 16, claims[1].data(), 32) == 0,
+                "session_verify: the root receipt does not commit to the claim tree of these segments");
+    return nullptr;
+}

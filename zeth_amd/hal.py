@@ -29,6 +29,19 @@ def fp_decode(word: int) -> int:
 def fp_encode(x: int) -> int:
     return ((int(x) % P) << 32) % P
 
+class SegmentSpec(C.Structure):
+    """`zkh_segment` (include/zkhal.h): one segment of a session."""
+    _fields_ = [("po2", C.c_uint32), ("seed", C.c_uint64), ("noise_seed", C.c_uint64), ("pub", C.POINTER(C.c_uint32)), ("n_pub", C.c_size_t),
+                ("host_code", C.POINTER(C.c_uint32)), ("host_data", C.POINTER(C.c_uint32)), ("out_global", C.POINTER(C.c_uint32))]
+
+
+class ProveInfo(C.Structure):
+    """`zkh_prove_info`: what zkh_session_prove returns."""
+    _fields_ = [("n_segments", C.c_size_t), ("seals", C.POINTER(C.POINTER(C.c_uint32))), ("seal_words", C.POINTER(C.c_size_t)),
+                ("root_seal", C.POINTER(C.c_uint32)), ("root_seal_words", C.c_size_t), ("n_joins", C.c_size_t),
+                ("wall_s", C.c_double), ("leaves_s", C.c_double), ("join_s", C.c_double), ("witgen_s_sum", C.c_double), ("seal_s_sum", C.c_double)]
+
+
 # every symbol include/zkhal.h declares: (restype, argtypes)
 _sz, _u32, _u64, _vp, _i = C.c_size_t, C.c_uint32, C.c_uint64, C.c_void_p, C.c_int
 _u32p = C.POINTER(C.c_uint32)
@@ -116,6 +129,14 @@ ABI = {
     "zkh_receipt_claim": (_err, [_vp, _u32p, _sz, _u32p, _u32p, _u32p, _u32p]),
     "zkh_receipt_encode": (_err, [_vp, _u32p, _sz, _u32, _u32p, C.POINTER(_u32p), C.POINTER(_sz)]),
     "zkh_receipt_decode": (_err, [_vp, _u32p, _sz, _u32p, C.POINTER(_sz)]),
+    "zkh_session_create": (_err, [C.POINTER(_i), _sz, _sz, _u32p, _sz, _u32p, _sz, C.POINTER(_vp)]),
+    "zkh_session_destroy": (None, [_vp]),
+    "zkh_session_lanes": (_sz, [_vp]),
+    "zkh_session_circuit": (_vp, [_vp, _sz, _i]),
+    "zkh_session_set_accumulate": (None, [_vp, _vp, _vp]),
+    "zkh_session_prove": (_err, [_vp, C.POINTER(SegmentSpec), _sz, _i, _sz, _u64, C.POINTER(ProveInfo)]),
+    "zkh_prove_info_free": (None, [C.POINTER(ProveInfo)]),
+    "zkh_session_verify": (_err, [_vp, C.POINTER(SegmentSpec), C.POINTER(ProveInfo), _sz]),
     "zkh_prof_enable": (_err, [_vp, _i]),
     "zkh_prof_get": (_err, [_vp, C.POINTER(ProfRec), _sz, C.POINTER(_sz)]),
     "zkh_prof_reset": (_err, [_vp]),

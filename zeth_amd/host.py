@@ -161,6 +161,75 @@ class BlockProcessor:
         return rec
 
 
+class Session:
+    """`ProverServer::prove_session` as ONE native call (zkh_session_*, csrc/session.hip): the segments of a session sealed on
+    `devices` x `lanes_per_device` lanes through one shared work index inside the library (C++ threads, no Python in the loop),
+    receipts in index order, optionally folded through the P2-JOIN tree to one root receipt.  What a Rust shim's
+    `Prover::prove` would call once per session (/root/reference/crates/host/src/lib.rs:137)."""
+
+    def __init__(self, circuit_desc, devices: Sequence[int] = (0,), lanes_per_device: int = 3, join_desc=None):
+        import ctypes as C
+        import numpy as np
+        from . import hal as _hal
+        _hal.load_library()
+        self._hal, self._C, self._np = _hal, C, np
+        self.desc = np.ascontiguousarray(circuit_desc, dtype=np.uint32)
+        self.join_desc = None if join_desc is None else np.ascontiguousarray(join_desc, dtype=np.uint32)
+        dev = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _hal._check(_hal._lib.zkh_session_create(dev, len(devices), lanes_per_device, _hal._ptr(self.desc), self.desc.size,
+                                                 _hal._ptr(self.join_desc) if self.join_desc is not None else None,
+                                                 0 if self.join_desc is None else self.join_desc.size, C.byref(h)))
+        self.h = h
+
+    def close(self) -> None:
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            self._hal._lib.zkh_session_destroy(h)
+
+    __del__ = close
+
+    def _specs(self, segments: Sequence[Segment]):
+        C, np = self._C, self._np
+        arr = (self._hal.SegmentSpec * len(segments))()
+        keep = []
+        for s, seg in zip(arr, segments):
+            s.po2, s.seed, s.noise_seed = seg.po2, seg.seed & (2**64 - 1), seg.noise_seed & (2**64 - 1)
+            if seg.pub:
+                p = np.asarray(seg.pub, dtype=np.uint32)
+                keep.append(p)
+                s.pub, s.n_pub = p.ctypes.data_as(C.POINTER(C.c_uint32)), p.size
+        return arr, keep
+
+    def prove(self, segments: Sequence[Segment], join_tree: bool = False, join_po2: int = 18, join_noise_seed: int = 0,
+              verify: bool = False):
+        """-> (CompositeReceipt, root SegmentReceipt or None, stats dict).  Segments use the protocol's ZK_CYCLES; noise_seed 0
+        = fresh OS randomness per segment.  verify=True additionally runs `receipt.verify` inside the library
+        (zkh_session_verify: every leaf seal against its control root and, with a join tree, the root seal + the claim tree
+        recomputed from the leaf claims) and raises HalError if anything is rejected."""
+        C, np = self._C, self._np
+        specs, keep = self._specs(segments)
+        info = self._hal.ProveInfo()
+        self._hal._check(self._hal._lib.zkh_session_prove(self.h, specs, len(segments), int(join_tree), join_po2, join_noise_seed, C.byref(info)))
+        try:
+            if verify:
+                self._hal._check(self._hal._lib.zkh_session_verify(self.h, specs, C.byref(info), join_po2))
+            out_size = int(self.desc[7])
+            recs = []
+            for i, seg in enumerate(segments):
+                seal = np.ctypeslib.as_array(info.seals[i], shape=(info.seal_words[i],)).copy()
+                recs.append(SegmentReceipt(seal=seal, index=seg.index, po2=seg.po2, output=seal[:out_size].copy()))
+            root = None
+            if info.root_seal:
+                rs = np.ctypeslib.as_array(info.root_seal, shape=(info.root_seal_words,)).copy()
+                root = SegmentReceipt(seal=rs, index=0, po2=join_po2, output=rs[:24].copy())
+            stats = {"wall_s": info.wall_s, "leaves_s": info.leaves_s, "join_s": info.join_s, "n_joins": int(info.n_joins),
+                     "witgen_s_sum": info.witgen_s_sum, "seal_s_sum": info.seal_s_sum, "verified": bool(verify)}
+            return CompositeReceipt(recs), root, stats
+        finally:
+            self._hal._lib.zkh_prove_info_free(C.byref(info))
+
+
 class DevModeProver:
     """`RISC0_DEV_MODE=1` analogue (BASELINE config 1; /root/reference/README.md:104-109, CI at
     /root/reference/.github/workflows/main.yml:51-54): no proving, a fake receipt per segment that only carries the
