@@ -556,94 +556,6 @@ __global__ void k_fwd_twiddle_matrix(int32_t* out, uint32_t L, uint32_t RH, uint
     out[i] = center(mul_mod(w, scale_word));                                          // w * R^K, plain, centred
 }
 
-// Persistent, software-pipelined form of the lazy forward strided pass (RH = 10, 64-byte runs): ONE 1024-lane workgroup per CU
-// walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and issues the 16 loads of the NEXT tile as soon as the current tile's
-// inputs have been consumed by the first butterfly round (same registers), so the next tile's HBM latency hides under the two
-// radix-16 rounds (~4.6 us) instead of opening every workgroup (the one-tile-per-workgroup kernel above moves its bytes in
-// 1.44 ms, issues its arithmetic in ~1.1-1.5 ms, and takes 2.16: profiles/r03_ntt_matrix.txt).
-//   * vmcnt retires in order: any vector load that is WAITED for inside the two radix-16 rounds would drain the prefetch with it.
-//     The in-tile twiddle table (4096 words) therefore lives in LDS for the lifetime of the workgroup (ds_read counts on lgkmcnt),
-//     and the six four-step table gathers of a tile are issued at the top of its iteration, where the tile's data is needed anyway.
-//   * `__syncthreads` waits for LDS traffic only (s_waitcnt lgkmcnt), so the prefetch and the previous tile's stores stay in
-//     flight across the two barriers of a tile; the data tile is double-buffered in LDS (2 x 64 KiB + 16 KiB of twiddles) so that
-//     the next tile's first exchange cannot overwrite what a slow wave still reads.
-// Same arithmetic, same results.
-__global__ __launch_bounds__(1024) void k_ntt_high10_fwd_persist(PassParams p) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_all[];     // [4096] twiddles, then [2][1024][16] data
-    const uint32_t tid = threadIdx.x, t = tid & 15, g = tid >> 4, hi = g >> 2, low = g & 3;
-    const uint32_t total = p.tiles_per_col * p.ncols;
-    const uint32_t lt_bits = p.L - 4, tw_shift = MAX_LOG_N - (p.L + 10), tb = t * 4u;
-#pragma unroll
-    for (int k = 0; k < 4; k++) lds_all[k * 1024 + tid] = p.layer_tw[k * 1024 + tid];
-    const uint32_t* ltab = lds_all;
-    uint32_t* data0 = lds_all + 4096;
-    auto tmul = [](uint32_t x, uint32_t y) -> uint32_t { return (uint32_t)smont((int32_t)x, (int32_t)y); };
-    auto root = [&](uint32_t e) -> uint32_t {
-        const uint32_t ex = e << tw_shift;
-        return tmul(p.tw_lo[ex & (TW_SIZE - 1)], p.tw_hi[ex >> TW_BITS]);
-    };
-    // item -> (column, tile): items of one sweep of the grid are the tiles of ONE column, XCD-remapped like the one-shot kernel
-    auto locate = [&](uint32_t item, uint32_t& col, uint32_t& lt, size_t& base) {
-        col = item / p.tiles_per_col;
-        const uint32_t tile_id = xcd_remap(item - col * p.tiles_per_col, p.tiles_per_col);
-        const uint32_t a = tile_id >> lt_bits;
-        lt = tile_id & ((1u << lt_bits) - 1);
-        base = ((size_t)a << (p.L + 10)) + ((size_t)lt << 4);
-    };
-    auto load_tile = [&](uint32_t (&dst)[16], uint32_t item) {
-        uint32_t col, lt; size_t base;
-        locate(item, col, lt, base);
-        const char* in = (const char*)(p.in + (size_t)col * p.in_col_stride + base);
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int k = 0; k < 4; k++) dst[4 * i + k] = *(const uint32_t*)(in + ((((g * 4 + i) * 4 + k)) << (p.L + 2)) + tb);
-    };
-    uint32_t item = blockIdx.x;
-    if (item >= total) return;
-    uint32_t x[16];                        // the current tile's inputs, then (same registers) the next tile's
-    load_tile(x, item);
-    __syncthreads();                       // the twiddle table is in LDS
-    uint32_t buf = 0;
-    for (; item < total; item += gridDim.x, buf ^= 1u) {
-        uint32_t* lds = data0 + buf * (1024u * 16u);
-        uint32_t col, lt; size_t base;
-        locate(item, col, lt, base);
-        char* out = (char*)(p.out + (size_t)col * p.out_col_stride + base);
-        const uint32_t lcol = (lt << 4) + t;
-        // four-step twiddles w^(lcol * bitrev10(m)) of this lane's 16 rows (m = g*16 + i*4 + k), factored as in k_ntt_high
-        const uint32_t w0 = tmul(root(lcol * (__brev(g) >> 26)), p.lazy_comp);
-        const uint32_t u1 = root(lcol * 64u), v1 = root(lcol * 256u);
-        const uint32_t u2 = tmul(u1, u1), u3 = tmul(u2, u1), v2 = tmul(v1, v1), v3 = tmul(v2, v1);
-        const uint32_t wi[4] = {w0, tmul(w0, u2), tmul(w0, u1), tmul(w0, u3)};
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t twk[4] = {wi[i], tmul(wi[i], v2), tmul(wi[i], v1), tmul(wi[i], v3)};
-            uint32_t u[4];
-            const uint32_t m0 = (g * 4 + i) * 4;
-#pragma unroll
-            for (int k = 0; k < 4; k++) u[k] = (uint32_t)smont((int32_t)x[4 * i + k], (int32_t)twk[k]);
-            radix_layers<2, false, true, 1, true>(u, ltab, 0, 0);
-#pragma unroll
-            for (int k = 0; k < 4; k++) lds[(m0 + k) * 16 + t] = u[k];
-        }
-        if (item + gridDim.x < total) load_tile(x, item + gridDim.x);       // wave-uniform; in flight across both radix-16 rounds
-        __syncthreads();
-        uint32_t v[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = lds[(hi * 64 + k * 4 + low) * 16 + t];
-        radix_layers<4, false, false, 3, true>(v, ltab, low, 0);
-#pragma unroll
-        for (int k = 0; k < 16; k++) lds[(hi * 64 + k * 4 + low) * 16 + t] = v[k];
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = lds[(k * 64 + g) * 16 + t];
-        radix_layers<4, false, false, 7, true>(v, ltab, g, 0);
-#pragma unroll
-        for (int k = 0; k < 16; k++) *(uint32_t*)(out + (((uint32_t)(k * 64 + g)) << (p.L + 2)) + tb) = canon((int32_t)v[k]);
-    }
-}
-
 struct Pass { uint32_t L, R; };
 // Cut log_n index bits into HBM passes of <= 12 bits.  The lowest pass works on contiguous runs (cheapest), the
 // strided passes above it are kept <= 10 bits so a 2^R x 16-word tile stays <= 64 KiB.
@@ -721,11 +633,6 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
         static const bool narrow = getenv("ZKH_NTT_NARROW") != nullptr;        // A/B: 32-byte runs, 512-lane workgroups (profiles/r03_ntt_matrix.txt)
         const bool narrow_here = narrow && lazy && reg_high && ps.R == 10 && !fwd_matrix;
         if (narrow_here) p.log_t = 3;
-        // A/B: the persistent, software-pipelined form of the same pass (one workgroup per CU, next tile prefetched)
-        static const int persist = getenv("ZKH_NTT_PERSIST") ? atoi(getenv("ZKH_NTT_PERSIST")) : 0;
-        const bool persist_here = persist > 0 && lazy && reg_high && ps.R == 10 && !fwd_matrix && !narrow_here;
-        const unsigned persist_grid = (unsigned)persist;
-        if (!reg_high && ps.L > 4 && ps.R < 8) p.log_t = ps.L < 12 - ps.R ? ps.L : 12 - ps.R;
         // keep the tile <= 64 KiB
         while (p.R + p.log_t > 14 && p.log_t > 0) p.log_t--;
         p.expand_bits = (!inverse && first) ? expand_bits : 0;
@@ -773,7 +680,6 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
             if (inverse) k_ntt_high<10, true><<<grid, 1024, lds, c->stream>>>(p);
             else if (lazy && p.tw_matrix) k_ntt_high<10, false, true, true><<<grid, 1024, lds, c->stream>>>(p);
             else if (narrow_here) k_ntt_high<10, false, true, false, 3><<<grid, 512, lds, c->stream>>>(p);
-            else if (persist_here) k_ntt_high10_fwd_persist<<<persist_grid, 1024, 2 * lds + 16384, c->stream>>>(p);
             else if (lazy) k_ntt_high<10, false, true><<<grid, 1024, lds, c->stream>>>(p);
             else k_ntt_high<10, false><<<grid, 1024, lds, c->stream>>>(p);
         } else if (ps.L >= 4 && p.log_t == 4 && ps.R == 8 && !(scale_here && p.zk_shift)) {
@@ -798,7 +704,6 @@ const char* zkh::ntt_device_init(zkh_ctx* c) {
     ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high<10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high<10, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high<10, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high10_fwd_persist, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 16384));
     return nullptr;
 }
 
