@@ -157,3 +157,20 @@ def test_keccak_eval_check_generated_kernels_equal_interpreter_and_oracle(hal, o
     glp = (C.c_void_p * 2)(out_g.ctypes.data, mix_g.ctypes.data)
     oracle.zko_eval_check(oc.h, want, gp, glp, pm, po2)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_smallest_segment_seeded_inputs_and_no_room_for_a_permutation(hal, oracle):
+    """Edge cases: po2 11 (54 active rows = 2 permutations, both seeded, 4 idle active rows) seals byte-identically; a segment
+    whose active rows cannot hold one permutation is refused loudly."""
+    from zeth_amd.hal import HalError
+    from zeth_amd.prover import Segment, SegmentProver
+    desc = K.keccak_f_circuit()
+    prover = SegmentProver(hal, desc)
+    seg = Segment(index=0, po2=11, seed=77, noise_seed=5)
+    rec = prover.prove_segment(seg)
+    oc = zko.OracleCircuit(oracle, desc)
+    assert np.array_equal(rec.seal, oc.prove(11, ZK, 77, 5))
+    rec.verify(desc, prover.control_root(11))
+    with pytest.raises(HalError, match="no room for a permutation"):
+        prover.witgen(Segment(index=0, po2=11, seed=1, noise_seed=5, zk_cycles=2030))      # 18 active rows < 25

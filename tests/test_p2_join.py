@@ -122,3 +122,17 @@ def test_succinct_receipt_needs_only_the_root_and_the_leaves(hal):
     forged.seal[9] = (int(forged.seal[9]) + 1) % J.P
     with pytest.raises((HalError, ValueError)):
         SuccinctReceipt(forged, [], leaves).verify(ldesc, jdesc, lroot, jroot)
+
+
+@pytest.mark.gpu
+def test_smallest_join_has_only_the_parent_block(hal, oracle):
+    """Edge case: po2 11 leaves 54 active rows = ONE block (the parent hash, no sibling blocks) + 23 idle rows."""
+    from zeth_amd.prover import Segment, SegmentProver
+    desc = J.p2_join_circuit()
+    prover = SegmentProver(hal, desc)
+    kids = _children(11)
+    rec = prover.prove_segment(Segment(index=0, po2=11, seed=0, noise_seed=9, pub=tuple(int(x) for x in kids)))
+    oc = zko.OracleCircuit(oracle, desc)
+    assert np.array_equal(rec.seal, oc.prove(11, ZK, 0, 9, pub=kids))
+    assert list(rec.seal[:8]) == J.hash_pair_words(kids[:8], kids[8:])
+    rec.verify(desc, prover.control_root(11))
