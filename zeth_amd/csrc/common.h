@@ -56,7 +56,6 @@ struct DeviceTables {
     uint32_t* tile_fwd;  uint32_t* tile_rev;    // ROU_FWD[12]^j / ROU_REV[12]^j, j < 2048
     uint32_t* layer_fwd; uint32_t* layer_rev;   // per-layer: [2^(j-1) + e] = ROU[j]^e, e < 2^(j-1), j <= 12 (4096 words)
     uint32_t* layer_fwd_plain;                  // layer_fwd out of Montgomery form (plain residues): lazy butterflies (ntt.hip)
-    uint32_t* layer_fwd_plain14;                // the same for layers 1..14 (16384 words): k_ntt_low14
     uint32_t* shift_lo;  uint32_t* shift_hi;    // 3^lo, 3^(hi*4096)
 };
 

@@ -170,12 +170,6 @@ static const char* ctx_init_tables(zkh_ctx* c) {
         ZKH_TRY(upload(&c->tab.layer_rev, lr));
         for (auto& w : lf) w = mont_reduce((uint64_t)w);          // word / R: the plain residue
         ZKH_TRY(upload(&c->tab.layer_fwd_plain, lf));
-        std::vector<uint32_t> l14(1 << 14, 1u);
-        for (int j = 1; j <= 14; j++) {
-            auto pf = powers(Fp::raw(c->rou_fwd[j]), (size_t)1 << (j - 1));
-            for (size_t e = 0; e < pf.size(); e++) l14[((size_t)1 << (j - 1)) + e] = mont_reduce((uint64_t)pf[e]);     // plain residues
-        }
-        ZKH_TRY(upload(&c->tab.layer_fwd_plain14, l14));
     }
     Fp three = fp_encode(3);
     ZKH_TRY(upload(&c->tab.shift_lo, powers(three, TW_SIZE)));
@@ -204,7 +198,7 @@ extern "C" void zkh_ctx_destroy(zkh_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->pool) (void)hipFree(kv.second);
     uint32_t* t[] = {c->tab.rc, c->tab.diag, c->tab.tw_fwd_lo, c->tab.tw_fwd_hi, c->tab.tw_rev_lo, c->tab.tw_rev_hi,
-                     c->tab.tile_fwd, c->tab.tile_rev, c->tab.shift_lo, c->tab.shift_hi, c->tab.layer_fwd, c->tab.layer_rev, c->tab.layer_fwd_plain, c->tab.layer_fwd_plain14};
+                     c->tab.tile_fwd, c->tab.tile_rev, c->tab.shift_lo, c->tab.shift_hi, c->tab.layer_fwd, c->tab.layer_rev, c->tab.layer_fwd_plain};
     for (auto p : t) (void)hipFree(p);
     for (auto& kv : c->ntt_fwd_matrix) (void)hipFree(kv.second);
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }

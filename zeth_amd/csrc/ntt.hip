@@ -556,68 +556,6 @@ __global__ void k_fwd_twiddle_matrix(int32_t* out, uint32_t L, uint32_t RH, uint
     out[i] = center(mul_mod(w, scale_word));                                          // w * R^K, plain, centred
 }
 
-// Lowest pass over index bits [0, 14) (forward, lazy): one 1024-lane workgroup = 16384 contiguous words of one column, four
-// register rounds (4 + 4 + 4 + 2 layers), three LDS exchanges.  With it a 2^22 transform splits 14 + 8 instead of 12 + 10: the
-// strided pass then runs in the 256-row shape (16 KiB of LDS, 256 lanes: many independent workgroups per CU), which moves its
-// bytes at 3.9 TB/s where the 1024-row shape reaches 3.1 (profiles/r03_sq_counters.txt).  p.layer_tw = plain table of layers 1..14.
-__global__ __launch_bounds__(1024) void k_ntt_low14(PassParams p) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];          // 16384 words
-    const uint32_t tid = threadIdx.x;
-    const uint32_t tile = xcd_remap(blockIdx.x, p.tiles_per_col);
-    const size_t base = (size_t)tile << 14;
-    const uint32_t* in = p.in + (size_t)blockIdx.y * p.in_col_stride;
-    uint32_t* out = p.out + (size_t)blockIdx.y * p.out_col_stride;
-    const uint32_t* __restrict__ ltab = p.layer_tw;
-    uint32_t v[16];
-    const size_t pos0 = base + (size_t)tid * 16;
-    if (p.expand_bits == 0) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint4 w = ((const uint4*)(in + pos0))[q];
-            v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w;
-        }
-    } else if (p.expand_bits == 2) {
-        const uint4 w = *(const uint4*)(in + (pos0 >> 2));
-        v[0] = v[1] = v[2] = v[3] = w.x; v[4] = v[5] = v[6] = v[7] = w.y;
-        v[8] = v[9] = v[10] = v[11] = w.z; v[12] = v[13] = v[14] = v[15] = w.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = in[(pos0 + k) >> p.expand_bits];
-    }
-    radix_layers<4, false, true, 1, true>(v, ltab, 0, (int)p.expand_bits);        // layers 1..4 (first expand_bits skipped)
-#pragma unroll
-    for (int q = 0; q < 4; q++) ((uint4*)lds)[tid * 4 + q] = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-    __syncthreads();
-    {
-        const uint32_t hi = tid >> 4, low = tid & 15;
-#pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = lds[hi * 256 + k * 16 + low];
-        radix_layers<4, false, false, 5, true>(v, ltab, low, 0);                  // layers 5..8
-#pragma unroll
-        for (int k = 0; k < 16; k++) lds[hi * 256 + k * 16 + low] = v[k];
-    }
-    __syncthreads();
-    {
-        const uint32_t hi = tid >> 8, low = tid & 255;
-#pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = lds[hi * 4096 + k * 256 + low];
-        radix_layers<4, false, false, 9, true>(v, ltab, low, 0);                  // layers 9..12
-#pragma unroll
-        for (int k = 0; k < 16; k++) lds[hi * 4096 + k * 256 + low] = v[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        uint32_t u[4];
-        const uint32_t low = j * 1024 + tid;                                        // position inside the 4096-word block
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) u[kk] = lds[kk * 4096 + low];
-        radix_layers<2, false, false, 13, true>(u, ltab, low, 0);                  // layers 13..14 (signed words scaled by R^-(14 - expand_bits))
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) out[base + kk * 4096 + low] = u[kk];
-    }
-}
-
 struct Pass { uint32_t L, R; };
 // Cut log_n index bits into HBM passes of <= 12 bits.  The lowest pass works on contiguous runs (cheapest), the
 // strided passes above it are kept <= 10 bits so a 2^R x 16-word tile stays <= 64 KiB.
@@ -647,16 +585,13 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
     ZKH_REQUIRE(log_n <= (uint32_t)MAX_LOG_N, "%s: transform size 2^%u exceeds the supported 2^%d", name, log_n, MAX_LOG_N);
     ZKH_REQUIRE(count <= 65535, "%s: too many columns (%zu)", name, count);
     std::vector<Pass> passes = plan_passes(log_n);
-    // A/B (profiles/r03_ntt_matrix.txt): forward 2^22 as 14 + 8 (k_ntt_low14 + the 256-row strided kernel) instead of 12 + 10
-    static const bool split148 = getenv("ZKH_NTT_SPLIT148") != nullptr;
-    if (split148 && !inverse && log_n == 22 && expand_bits <= 4) passes = {{0, 14}, {14, 8}};
     const size_t n = (size_t)1 << log_n;
     Fp ninv = fp_inv(fp_encode((uint32_t)(n % P)));
     const size_t npass = passes.size();
     // forward transforms whose two passes are both register-radix kernels (2^20 and 2^22: what po2-18/20 seals
     // expand into) run the lazy signed butterflies; the constant R^(layers run) rides on the four-step twiddle
     static const bool no_lazy = getenv("ZKH_NTT_NO_LAZY") != nullptr;     // A/B switch for debugging
-    const bool lazy = !no_lazy && !inverse && npass == 2 && (passes[0].R == 12 || passes[0].R == 14) && (passes[1].R == 8 || passes[1].R == 10) && expand_bits <= 4;
+    const bool lazy = !no_lazy && !inverse && npass == 2 && passes[0].R == 12 && (passes[1].R == 8 || passes[1].R == 10) && expand_bits <= 4;
     const uint32_t lazy_comp = lazy ? fp_pow(Fp::raw(R2), passes[0].R - expand_bits + passes[1].R).v : 0;
     // the strided pass of a lazy transform reads its four-step twiddles from a per-shape matrix (built once per context)
     // MEASURED AND REJECTED as the default (profiles/r03_ntt_matrix.txt): the matrix removes 15 % of the pass's VALU
@@ -732,17 +667,12 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
         const double alg_bytes = pi == 0 ? 4.0 * count * (double)(((size_t)1 << log_n) >> expand_bits) + 4.0 * count * (double)n : 0.0;
         const bool scale_here = p.scale != 0;
         // profiler record = "<Hal op>:<kernel>", so both the op totals and the per-kernel (per-pass) times can be read off
-        const bool k_low14 = lazy && ps.L == 0 && ps.R == 14;
         const bool k_low = ps.L == 0 && ps.R == 12 && p.expand_bits <= 4;
         const bool k_h10 = !k_low && ps.L >= 4 && (p.log_t == 4 || narrow_here) && ps.R == 10 && !(scale_here && p.zk_shift);
         const bool k_h8 = !k_low && !k_h10 && ps.L >= 4 && p.log_t == 4 && ps.R == 8 && !(scale_here && p.zk_shift);
-        const std::string pname = std::string(name) + (k_low14 ? ":k_ntt_low14" : k_low ? ":k_ntt_low12" : k_h10 ? ":k_ntt_high10" : k_h8 ? ":k_ntt_high8" : ":k_ntt_pass");
+        const std::string pname = std::string(name) + (k_low ? ":k_ntt_low12" : k_h10 ? ":k_ntt_high10" : k_h8 ? ":k_ntt_high8" : ":k_ntt_pass");
         ProfScope prof(c, pname.c_str(), alg_bytes);
-        if (k_low14) {
-            p.layer_tw = c->tab.layer_fwd_plain14;
-            p.tiles_per_col = (uint32_t)(n >> 14);
-            k_ntt_low14<<<dim3(p.tiles_per_col, (unsigned)count), 1024, 65536, c->stream>>>(p);
-        } else if (ps.L == 0 && ps.R == 12 && p.expand_bits <= 4) {
+        if (ps.L == 0 && ps.R == 12 && p.expand_bits <= 4) {
             if (inverse) k_ntt_low12<true><<<grid, 256, 0, c->stream>>>(p);
             else if (lazy) k_ntt_low12<false, true><<<grid, 256, 0, c->stream>>>(p);
             else k_ntt_low12<false><<<grid, 256, 0, c->stream>>>(p);
@@ -774,7 +704,6 @@ const char* zkh::ntt_device_init(zkh_ctx* c) {
     ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high<10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high<10, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high<10, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_low14, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     return nullptr;
 }
 
