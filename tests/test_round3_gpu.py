@@ -111,3 +111,23 @@ def test_native_session_executor_equals_the_python_orchestration(hal):
     comp1, root1, _ = plain.prove(segs[:1], verify=True)
     assert root1 is None and np.array_equal(comp1.segments[0].seal, want[0].seal)
     sess.close(); plain.close()
+
+
+def test_session_executor_seals_caller_produced_traces(hal):
+    """The session's other input: traces the CALLER produced (upstream's flow — CPU preflight + witgen — here read back from the
+    device generator), uploaded and sealed through prove_begin / accumulate / prove_finish inside the library.  Same traces, same
+    noise: the same seals as the built-in path."""
+    from zeth_amd.host import Session
+    desc = syn_air.syn_small()
+    prover = SegmentProver(hal, desc)
+    segs = [Segment(index=i, po2=12, seed=40 + i, noise_seed=0x99) for i in range(3)]
+    traces, want = [], []
+    for seg in segs:
+        code, data, out = prover.witgen(seg)
+        traces.append((code.to_vec(), data.to_vec(), out))
+        want.append(prover.seal(seg, code, data, out).seal)
+    sess = Session(desc, lanes_per_device=2)
+    comp, root, _ = sess.prove(segs, host_traces=[traces[0], None, traces[2]], verify=True)      # mixed: two uploaded, one generated
+    for got, w in zip(comp.segments, want):
+        assert np.array_equal(got.seal, w)
+    sess.close()

@@ -189,26 +189,33 @@ class Session:
 
     __del__ = close
 
-    def _specs(self, segments: Sequence[Segment]):
+    def _specs(self, segments: Sequence[Segment], host_traces=None):
         C, np = self._C, self._np
         arr = (self._hal.SegmentSpec * len(segments))()
         keep = []
-        for s, seg in zip(arr, segments):
+        u32p = C.POINTER(C.c_uint32)
+        for i, (s, seg) in enumerate(zip(arr, segments)):
             s.po2, s.seed, s.noise_seed = seg.po2, seg.seed & (2**64 - 1), seg.noise_seed & (2**64 - 1)
             if seg.pub:
                 p = np.asarray(seg.pub, dtype=np.uint32)
                 keep.append(p)
-                s.pub, s.n_pub = p.ctypes.data_as(C.POINTER(C.c_uint32)), p.size
+                s.pub, s.n_pub = p.ctypes.data_as(u32p), p.size
+            if host_traces is not None and host_traces[i] is not None:
+                code, data, out = (np.ascontiguousarray(a, dtype=np.uint32) for a in host_traces[i])
+                keep.extend((code, data, out))
+                s.host_code, s.host_data, s.out_global = code.ctypes.data_as(u32p), data.ctypes.data_as(u32p), out.ctypes.data_as(u32p)
         return arr, keep
 
     def prove(self, segments: Sequence[Segment], join_tree: bool = False, join_po2: int = 18, join_noise_seed: int = 0,
-              verify: bool = False):
+              verify: bool = False, host_traces=None):
         """-> (CompositeReceipt, root SegmentReceipt or None, stats dict).  Segments use the protocol's ZK_CYCLES; noise_seed 0
         = fresh OS randomness per segment.  verify=True additionally runs `receipt.verify` inside the library
         (zkh_session_verify: every leaf seal against its control root and, with a join tree, the root seal + the claim tree
-        recomputed from the leaf claims) and raises HalError if anything is rejected."""
+        recomputed from the leaf claims) and raises HalError if anything is rejected.
+        host_traces: per segment None or (code, data, out_global) host arrays produced by the caller (upstream's flow: CPU
+        preflight + witgen) — uploaded and sealed through zkh_prove_begin / accumulate / zkh_prove_finish inside the library."""
         C, np = self._C, self._np
-        specs, keep = self._specs(segments)
+        specs, keep = self._specs(segments, host_traces)
         info = self._hal.ProveInfo()
         self._hal._check(self._hal._lib.zkh_session_prove(self.h, specs, len(segments), int(join_tree), join_po2, join_noise_seed, C.byref(info)))
         try:
