@@ -136,3 +136,40 @@ def test_smallest_join_has_only_the_parent_block(hal, oracle):
     assert np.array_equal(rec.seal, oc.prove(11, ZK, 0, 9, pub=kids))
     assert list(rec.seal[:8]) == J.hash_pair_words(kids[:8], kids[8:])
     rec.verify(desc, prover.control_root(11))
+
+
+@pytest.mark.gpu
+def test_keccak_assumption_receipts_are_leaves_of_the_claim_tree(hal):
+    """A block whose guest called the keccak accelerator: its segment receipts AND the KECCAK-F receipt of the accelerator batch
+    fold into one root receipt (upstream resolves assumptions during lift / join); the compact receipt verifies each kind of
+    leaf with its own circuit and control root and follows the claim tree to the root."""
+    import hashlib
+    from zeth_amd.circuits import keccak_f, syn_air
+    from zeth_amd.hal import fp_decode
+    from zeth_amd.host import SuccinctReceipt, node_claim, prove_succinct, receipt_claim
+    from zeth_amd.prover import Segment, SegmentProver
+    ldesc, kdesc, jdesc = syn_air.syn_small(), keccak_f.keccak_f_circuit(), J.p2_join_circuit()
+    lp, kp, jp = SegmentProver(hal, ldesc), SegmentProver(hal, kdesc), SegmentProver(hal, jdesc)
+    segs = [lp.prove_segment(Segment(index=i, po2=13, seed=60 + i, noise_seed=2)) for i in range(3)]
+    msg = b"accelerator batch of block 19000000"
+    pub = tuple(w for lane in keccak_f.sha3_256_block(msg) for w in (lane & 0xFFFFFFFF, lane >> 32))
+    krec = kp.prove_segment(Segment(index=3, po2=13, seed=9, noise_seed=2, pub=pub))
+    lroot, kroot, jroot = lp.control_root(13), kp.control_root(13), jp.control_root(13)
+    leaves = segs + [krec]
+
+    def claim_of(r, is_leaf):
+        if not is_leaf:
+            return node_claim(r, jdesc, jroot, False)
+        return receipt_claim(r, kdesc, kroot) if r is krec else receipt_claim(r, ldesc, lroot)
+
+    rec = prove_succinct(leaves, jp.prove_segment, claim_of, join_po2=13, noise_seed=4)
+    small = SuccinctReceipt(rec.root, [], leaves, n_assumptions=1)
+    small.verify(ldesc, jdesc, lroot, jroot, assumption_desc=kdesc, assumption_root=kroot)
+    small.verify(ldesc, jdesc, assumption_desc=kdesc)                     # shipped control roots for all three circuits
+    limbs = [fp_decode(int(w)) for w in krec.seal[:100]]
+    assert keccak_f.digest_of_state([sum(limbs[4 * l + j] << (16 * j) for j in range(4)) for l in range(25)]) == hashlib.sha3_256(msg).digest()
+    with pytest.raises(ValueError, match="assumption"):
+        small.verify(ldesc, jdesc, lroot, jroot)
+    # the assumption leaf treated as a segment of the main circuit is rejected (wrong circuit)
+    with pytest.raises(Exception):
+        SuccinctReceipt(rec.root, [], leaves, n_assumptions=0).verify(ldesc, jdesc, lroot, jroot)

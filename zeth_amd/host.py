@@ -371,20 +371,30 @@ class SuccinctReceipt:
     root: SegmentReceipt
     joins: List[List[SegmentReceipt]]
     leaves: List[SegmentReceipt]
+    n_assumptions: int = 0          # the LAST n_assumptions leaves are coprocessor (keccak) receipts of another circuit
 
     def compact(self) -> "SuccinctReceipt":
-        return SuccinctReceipt(root=self.root, joins=[], leaves=self.leaves)
+        return SuccinctReceipt(root=self.root, joins=[], leaves=self.leaves, n_assumptions=self.n_assumptions)
 
-    def verify(self, segment_desc, join_desc, leaf_root=None, join_root=None) -> None:
+    def verify(self, segment_desc, join_desc, leaf_root=None, join_root=None, assumption_desc=None, assumption_root=None) -> None:
+        """leaf_root / join_root / assumption_root: the expected control roots (None = the shipped table, or {po2: root}).
+        With assumption leaves (upstream: the keccak receipts a succinct receipt `resolve`s; here they are further leaves of
+        the claim tree, verified with their own circuit) `assumption_desc` is required."""
         import numpy as np
         from .prover import shipped_control_root
 
         def root_of(desc, given, po2):
             r = _root_for(given, po2)
             return shipped_control_root(desc, po2) if r is None else r
-        for s in self.leaves:
-            s.verify(segment_desc, root_of(segment_desc, leaf_root, s.po2))
-        leaf_claims = [receipt_claim(s, segment_desc, root_of(segment_desc, leaf_root, s.po2)) for s in self.leaves]
+        if self.n_assumptions and assumption_desc is None:
+            raise ValueError("succinct receipt carries assumption leaves but no circuit was given for them")
+        n_seg = len(self.leaves) - self.n_assumptions
+        leaf_claims = []
+        for k, s in enumerate(self.leaves):
+            d, given = (segment_desc, leaf_root) if k < n_seg else (assumption_desc, assumption_root)
+            r = root_of(d, given, s.po2)
+            s.verify(d, r)
+            leaf_claims.append(receipt_claim(s, d, r))
         if len(self.leaves) == 1:
             top = self.leaves[0]
             if (self.root.index != top.index or self.root.po2 != top.po2
