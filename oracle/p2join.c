@@ -31,7 +31,7 @@ static void pj_m_ext(fp* c) {
 static int pj_is_full(unsigned rnd) { return rnd < PJ_HALF || rnd >= PJ_HALF + PJ_RP; }
 
 /* rows[k][0..24) = S, rows[k][24..48) = Q for k < 31; in: 24 Montgomery words */
-static void pj_rows(const fp in[PJ_T], fp rows[PJ_BLOCK][2 * PJ_T]) {
+void zko_p2_rows(const uint32_t in[PJ_T], uint32_t rows[PJ_BLOCK][2 * PJ_T]) {
     memset(rows, 0, sizeof(fp) * PJ_BLOCK * 2 * PJ_T);
     fp s[PJ_T];
     memcpy(rows[0], in, sizeof(fp) * PJ_T);
@@ -103,7 +103,7 @@ void zko_p2join_witgen(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t
             memcpy(in, parent, 32);
             for (int j = 0; j < 8; j++) in[8 + j] = code[(35 + j) * n + PJ_BLOCK * p];
         }
-        pj_rows(in, rows);
+        zko_p2_rows(in, rows);
         if (p == 0) memcpy(parent, rows[PJ_BLOCK - 1], 32);
         for (size_t k = 0; k < PJ_BLOCK; k++)
             for (size_t col = 0; col < 2 * PJ_T; col++) data[col * n + PJ_BLOCK * p + k] = rows[k][col];

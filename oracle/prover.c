@@ -119,20 +119,45 @@ void zko_control_root(const zko_circuit* c, unsigned po2, unsigned zk, uint32_t 
     polygroup_free(&pg); free(code); free(io.w);
 }
 
+/* Merkle root of a given code trace (wc x n): the control root of a circuit whose code group is a program (kind 4) */
+void zko_root_of_code(const zko_circuit* c, unsigned po2, const uint32_t* code, uint32_t root[8]) {
+    size_t n = (size_t)1 << po2, wc = c->group_size[ZKC_GROUP_CODE];
+    iop_t io; memset(&io, 0, sizeof io); zko_rng_init(&io.rng);
+    polygroup_t pg;
+    commit_group(&pg, &io, code, wc, n);
+    memcpy(root, pg.merkle.nodes + 8, 32);
+    polygroup_free(&pg); free(io.w);
+}
+
 uint32_t* zko_prove_segment(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t seed, uint64_t noise_seed,
                             const uint32_t* pub, size_t* seal_words, const char** err) {
     *err = NULL;
-    size_t n = (size_t)1 << po2, dom = n * ZKO_INV_RATE;
-    size_t wa = c->group_size[0], wc = c->group_size[1], wd = c->group_size[2];
+    size_t n = (size_t)1 << po2;
+    size_t wc = c->group_size[1], wd = c->group_size[2];
     if (n <= zk + 1) { *err = "po2 too small for zk_cycles"; return NULL; }
-    iop_t io; memset(&io, 0, sizeof io); zko_rng_init(&io.rng);
-
+    if (c->kind == 4) { *err = "the recursion circuit has no seed-driven witness generator: zko_rec_witgen + zko_prove_traces"; return NULL; }
     /* witgen (SegmentProver step 2) */
     uint32_t* code = (uint32_t*)malloc(4 * wc * n);
     uint32_t* data = (uint32_t*)malloc(4 * wd * n);
     size_t out_size = c->global_size[ZKC_GLOBAL_OUT];
     uint32_t* out_global = (uint32_t*)malloc(4 * (out_size + 1));
     zko_syn_witgen(c, po2, zk, seed, noise_seed, pub, code, data, out_global);
+    uint32_t* seal = zko_prove_traces(c, po2, zk, noise_seed, code, data, out_global, seal_words, err);
+    free(code); free(data); free(out_global);
+    return seal;
+}
+
+/* the seal of given code / data traces and out globals (the accum group is generated here, after the mix challenge) */
+uint32_t* zko_prove_traces(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t noise_seed, const uint32_t* code,
+                           const uint32_t* data, const uint32_t* out_words, size_t* seal_words, const char** err) {
+    *err = NULL;
+    size_t n = (size_t)1 << po2, dom = n * ZKO_INV_RATE;
+    size_t wa = c->group_size[0], wc = c->group_size[1], wd = c->group_size[2];
+    if (n <= zk + 1) { *err = "po2 too small for zk_cycles"; return NULL; }
+    iop_t io; memset(&io, 0, sizeof io); zko_rng_init(&io.rng);
+    size_t out_size = c->global_size[ZKC_GLOBAL_OUT];
+    uint32_t* out_global = (uint32_t*)malloc(4 * (out_size + 1));
+    memcpy(out_global, out_words, 4 * out_size);
     stage("trace.code", code, wc * n); stage("trace.data", data, wd * n);
 
     /* step 3: header — out globals + po2 as field elements (write_field_elem_slice), committed */
@@ -149,15 +174,16 @@ uint32_t* zko_prove_segment(const zko_circuit* c, unsigned po2, unsigned zk, uin
     polygroup_stage(&groups[ZKC_GROUP_CODE], GROUP_NAME[ZKC_GROUP_CODE]);
     polygroup_stage(&groups[ZKC_GROUP_DATA], GROUP_NAME[ZKC_GROUP_DATA]);
     /* step 5: accum mix + accum */
-    uint32_t* mix_global = (uint32_t*)malloc(4 * (wa ? wa : 1));
+    uint32_t* mix_global = (uint32_t*)malloc(4 * (wa + c->global_size[ZKC_GLOBAL_MIX] + 1));
     for (size_t i = 0; i < c->global_size[ZKC_GLOBAL_MIX]; i++) mix_global[i] = zko_rng_random_elem(&io.rng);
     uint32_t* accum = (uint32_t*)malloc(4 * wa * n);
-    zko_syn_accum(c, po2, zk, noise_seed, data, mix_global, accum);
+    if (c->kind == 4) zko_rec_accum(c, po2, zk, noise_seed, code, data, mix_global, accum);
+    else zko_syn_accum(c, po2, zk, noise_seed, data, mix_global, accum);
     stage("global.mix", mix_global, c->global_size[ZKC_GLOBAL_MIX]);
     stage("trace.accum", accum, wa * n);
     commit_group(&groups[ZKC_GROUP_ACCUM], &io, accum, wa, n);
     polygroup_stage(&groups[ZKC_GROUP_ACCUM], GROUP_NAME[ZKC_GROUP_ACCUM]);
-    free(code); free(data); free(accum);
+    free(accum);
 
     /* step 6: finalize */
     uint32_t poly_mix[4]; zko_rng_random_ext_elem(&io.rng, poly_mix);

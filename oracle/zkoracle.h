@@ -136,6 +136,27 @@ void zko_p2join_witgen(const zko_circuit*, unsigned po2, unsigned zk_cycles, uin
 /* returns malloc'd seal words (caller frees with zko_free); NULL + *err on failure */
 uint32_t* zko_prove_segment(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t seed,
                             uint64_t noise_seed, const uint32_t* pub, size_t* seal_words, const char** err);
+/* the same from given code (wc x n) and data (wd x n) traces and the out globals (OUTPUT_SIZE words) */
+uint32_t* zko_prove_traces(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t noise_seed, const uint32_t* code,
+                           const uint32_t* data, const uint32_t* out_words, size_t* seal_words, const char** err);
+void zko_root_of_code(const zko_circuit*, unsigned po2, const uint32_t* code, uint32_t root[8]);
+
+/* ---- RECURSION circuit (zeth_amd/circuits/recursion.py; circuit kind 4): the code group is a PROGRAM ---- */
+/* code (55 x n) of a program blob; NULL on success */
+const char* zko_rec_code(const uint32_t* prog, size_t prog_words, uint32_t* code);
+/* runs the program's witness schedule on `inputs` (raw Montgomery words: child seals ...), fills code (55 x n), data (72 x n)
+ * and out_global (16 words); a message if an assertion of the program fails (the inputs are not what the program verifies) */
+const char* zko_rec_witgen(const uint32_t* prog, size_t prog_words, const uint32_t* inputs, size_t n_inputs, uint64_t noise_seed,
+                           uint32_t* code, uint32_t* data, uint32_t* out_global);
+/* the copy argument's running products (12 x n) from code, data and the 20 mix words */
+void zko_rec_accum(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t noise_seed, const uint32_t* code,
+                   const uint32_t* data, const uint32_t* mix_global, uint32_t* accum);
+/* every constraint of the circuit's step list on rows [row_lo, row_hi) of a trace (groups[g]: W_g x n): first failing row or -1 */
+long zko_check_rows(const zko_circuit*, unsigned po2, const uint32_t* const* groups, const uint32_t* const* globals, size_t row_lo,
+                    size_t row_hi);
+/* one Poseidon2 permutation as the 31 trace rows of P2-JOIN / RECURSION: rows[k] = S[24] ‖ Q[24] */
+void zko_p2_rows(const uint32_t in[24], uint32_t rows[31][48]);
+
 /* Merkle root of the committed code group for (circuit, po2, zk_cycles): the control-ID analogue */
 void zko_control_root(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint32_t root[8]);
 /* restates risc0_zkp::verify::verify (incl. check_code: the code root must equal control_root).

@@ -53,6 +53,12 @@ def load():
         "zko_control_root": (None, [vp, C.c_uint, C.c_uint, u32p]),
         "zko_verify_segment": (C.c_char_p, [vp, u32p, sz, C.c_void_p]),
         "zko_free": (None, [vp]),
+        "zko_prove_traces": (C.POINTER(u32), [vp, C.c_uint, C.c_uint, u64, u32p, u32p, u32p, C.POINTER(sz), C.POINTER(C.c_char_p)]),
+        "zko_root_of_code": (None, [vp, C.c_uint, u32p, u32p]),
+        "zko_rec_code": (C.c_char_p, [u32p, sz, u32p]),
+        "zko_rec_witgen": (C.c_char_p, [u32p, sz, u32p, sz, u64, u32p, u32p, u32p]),
+        "zko_rec_accum": (None, [vp, C.c_uint, C.c_uint, u64, u32p, u32p, u32p, u32p]),
+        "zko_check_rows": (C.c_long, [vp, C.c_uint, C.POINTER(vp), C.POINTER(vp), sz, sz]),
         "zko_num_threads": (C.c_int, []),
         "zko_set_num_threads": (None, [C.c_int]),
     }
@@ -116,6 +122,48 @@ class OracleCircuit:
         n = C.c_size_t()
         err = C.c_char_p()
         p = self.lib.zko_prove_segment(self.h, po2, zk_cycles, seed, noise_seed, self._pub(pub), C.byref(n), C.byref(err))
+        if not p:
+            raise RuntimeError((err.value or b"?").decode())
+        seal = np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+        self.lib.zko_free(p)
+        return seal
+
+    # ---- RECURSION (kind 4): the code group is a program blob (zeth_amd/circuits/recursion.py Program.finish) ----
+    def rec_witgen(self, prog, inputs, noise_seed=0x2E80):
+        """-> (code, data, out_global); raises if the program's assertions fail on `inputs` (raw Montgomery words)"""
+        prog = np.ascontiguousarray(prog, dtype=np.uint32)
+        inputs = np.ascontiguousarray(inputs if len(inputs) else [0], dtype=np.uint32)
+        wa, wc, wd = (int(x) for x in self.desc[3:6])
+        n = 1 << int(prog[2])
+        code, data, out = np.zeros(wc * n, np.uint32), np.zeros(wd * n, np.uint32), np.zeros(self.out_size, np.uint32)
+        err = self.lib.zko_rec_witgen(prog, prog.size, inputs, inputs.size, noise_seed, code, data, out)
+        if err:
+            raise RuntimeError(err.decode())
+        return code, data, out
+
+    def rec_accum(self, po2, code, data, mix, zk_cycles=1994, noise_seed=0x2E80):
+        accum = np.zeros(int(self.desc[3]) << po2, np.uint32)
+        self.lib.zko_rec_accum(self.h, po2, zk_cycles, noise_seed, code, data, np.ascontiguousarray(mix, dtype=np.uint32), accum)
+        return accum
+
+    def check_rows(self, po2, accum, code, data, out, mix, lo=0, hi=None):
+        """first row of the trace on which some constraint of the step list does not vanish, or -1"""
+        arrs = [np.ascontiguousarray(a, dtype=np.uint32) for a in (accum, code, data, out, mix)]
+        groups = (C.c_void_p * 3)(*(a.ctypes.data for a in arrs[:3]))
+        globals_ = (C.c_void_p * 2)(*(a.ctypes.data for a in arrs[3:]))
+        return int(self.lib.zko_check_rows(self.h, po2, groups, globals_, lo, (1 << po2) if hi is None else hi))
+
+    def root_of_code(self, po2, code):
+        root = np.zeros(8, np.uint32)
+        self.lib.zko_root_of_code(self.h, po2, np.ascontiguousarray(code, dtype=np.uint32), root)
+        return root
+
+    def prove_traces(self, po2, code, data, out, zk_cycles=1994, noise_seed=0x2E80):
+        n = C.c_size_t()
+        err = C.c_char_p()
+        p = self.lib.zko_prove_traces(self.h, po2, zk_cycles, noise_seed, np.ascontiguousarray(code, dtype=np.uint32),
+                                      np.ascontiguousarray(data, dtype=np.uint32), np.ascontiguousarray(out, dtype=np.uint32),
+                                      C.byref(n), C.byref(err))
         if not p:
             raise RuntimeError((err.value or b"?").decode())
         seal = np.ctypeslib.as_array(p, shape=(n.value,)).copy()
