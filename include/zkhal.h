@@ -285,6 +285,30 @@ const char* zkh_receipt_encode(const zkh_circuit*, const uint32_t* seal, size_t 
 const char* zkh_receipt_decode(const zkh_circuit*, const uint32_t* blob, size_t blob_words, uint32_t info[26],
                                size_t* seal_offset);
 
+/* ---- RECURSION circuit (kind 4): lift / join as programs of an in-circuit STARK verifier ----
+ * Replaces risc0-circuit-recursion 4.0.2 src/prove/{mod.rs Prover::run, program.rs} + its witness generator (un-vendored:
+ * /root/reference/Cargo.lock:5305), reached from default_prover().prove (/root/reference/crates/host/src/lib.rs:137) once per
+ * lift and per join (BASELINE.json config 5).  The circuit: zeth_amd/circuits/recursion.py (six Fp4 wires + one gate per row,
+ * Poseidon2 blocks, a copy argument in the accum group); a PROGRAM = the code group, produced by
+ * zeth_amd/circuits/rec_verify.py (build_lift / build_join = this library's verifier restated gate by gate) as a u32 blob.
+ * zkh_rec_program_load validates the blob, sorts its witness schedule into dependency levels, uploads it, generates the code
+ * group and commits it (resident); `circuit` = the RECURSION description loaded on the same context.  zkh_rec_prove runs the
+ * program on `inputs` (raw Montgomery words: the child seal(s) and the program's other witness words), which FAILS unless every
+ * assertion of the in-circuit verifier holds, and seals the trace; out_global (16 words) = claim (8) ‖ allowed-programs root. */
+typedef struct zkh_rec_program zkh_rec_program;
+const char* zkh_rec_program_load(zkh_ctx*, const zkh_circuit* circuit, const uint32_t* blob, size_t words, zkh_rec_program** out);
+void zkh_rec_program_destroy(zkh_rec_program*);
+/* root: the program's control root (Merkle root of its code group); info: po2, zk_cycles, input words, permutations, gates,
+ * witness ops, dependency levels, variables */
+const char* zkh_rec_program_info(const zkh_rec_program*, uint32_t root[8], uint32_t info[8]);
+const char* zkh_rec_code(const zkh_rec_program*, zkh_buf* code /* 55 x 2^po2 */);
+const char* zkh_rec_witgen(const zkh_rec_program*, const uint32_t* inputs, size_t n_inputs, uint64_t noise_seed,
+                           zkh_buf* data /* 72 x 2^po2 */, uint32_t out_global[16]);
+const char* zkh_rec_accum(const zkh_rec_program*, uint64_t noise_seed, const zkh_buf* data, const uint32_t* mix_global /* 20 */,
+                          zkh_buf* accum /* 12 x 2^po2 */);
+const char* zkh_rec_prove(const zkh_rec_program*, const uint32_t* inputs, size_t n_inputs, uint64_t noise_seed,
+                          uint32_t out_global[16] /* may be NULL */, uint32_t** seal, size_t* seal_words);
+
 /* ---- session executor: ProverServer::prove_session / ProverImpl::{prove_segment, join} (risc0-zkvm 3.0.3, un-vendored:
  * /root/reference/Cargo.lock:5418) — what default_prover().prove(env, elf) runs once the executor has cut the guest's run
  * into segments (/root/reference/crates/host/src/lib.rs:137), as ONE call: every segment sealed on G devices x K lanes through

@@ -1,0 +1,173 @@
+"""RECURSION on the device: witness generator, copy argument and seal against the CPU oracle, bit for
+bit; then the real thing - segment seals lifted and joined into one receipt whose every node verified its children in-circuit."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+import zko
+from zeth_amd.circuits import rec_verify as V, recursion as R, syn_air
+from zeth_amd.circuits.desc import P
+
+pytestmark = pytest.mark.gpu
+RM = (1 << 32) % P
+RINV = pow(RM, -1, P)
+ZK = 1994
+
+
+def small_program():
+    pr = R.Program()
+    x, y = pr.input(0, 4), pr.input(4, 4)
+    s, m = pr.add(x, y), pr.mul(x, y)
+    iv = pr.inv(m)
+    pr.eq(pr.mul(m, iv), pr.const(1))
+    a, b, _, _ = pr.unpack(x)
+    bits = pr.bits31(a, 12)
+    sel = pr.mux(bits[0], s, m)
+    h = pr.p2([x, y, s, m, pr.zero(), pr.zero()])
+    h2 = pr.p2([h[0], h[1], sel, iv, h[4], h[5]])
+    pr.eq(pr.is_zero(b), pr.zero())
+    pk = pr.pack(2, x, y, s, m)
+    pr.public(h2[0], h2[1], pk, bits[12])
+    return pr
+
+
+def _device_traces(hal, prog, inputs, noise=0x2E80):
+    n = 1 << prog.po2
+    code, data, accum = hal.alloc_elem("code", R.WC * n), hal.alloc_elem("data", R.WD * n), hal.alloc_elem("accum", R.WA * n)
+    prog.code(code)
+    out = prog.witgen(inputs, data, noise)
+    return code, data, accum, out
+
+
+def test_small_program_traces_accum_and_seal_match_the_oracle(hal, oracle):
+    from zeth_amd.hal import HalError, HostCircuit, RecProgram
+    pr = small_program()
+    po2 = 12
+    blob = pr.finish(po2, ZK)
+    inputs = np.array([v * RM % P for v in (5, 6, 7, 8, 11, 12, 13, 14)], dtype=np.uint32)
+    oc = zko.OracleCircuit(oracle, R.recursion_circuit())
+    ocode, odata, oout = oc.rec_witgen(blob, inputs)
+    circuit = hal.load_circuit(R.recursion_circuit())
+    assert circuit.kernel_kind() == "builtin"
+    prog = RecProgram(hal, circuit, blob)
+    assert (prog.po2, prog.n_inputs, prog.n_p2) == (po2, 8, 2)
+    code, data, accum, out = _device_traces(hal, prog, inputs)
+    assert np.array_equal(code.to_vec(), ocode)
+    assert np.array_equal(data.to_vec(), odata)
+    assert np.array_equal(out, oout)
+    assert np.array_equal(prog.root, oc.root_of_code(po2, ocode))
+    mix = np.array([(i * 7919 + 13) * RM % P for i in range(20)], dtype=np.uint32)
+    prog.accum(data, mix, accum)
+    oaccum = oc.rec_accum(po2, ocode, odata, mix, ZK)
+    assert np.array_equal(accum.to_vec(), oaccum)
+    assert oc.check_rows(po2, oaccum, ocode, odata, oout, mix) == -1
+    seal, out2 = prog.prove(inputs, 0x2E80)
+    assert np.array_equal(out2, oout)
+    assert np.array_equal(seal, oc.prove_traces(po2, ocode, odata, oout, ZK, 0x2E80))          # byte-identical seals
+    HostCircuit(R.recursion_circuit()).verify_segment(seal, prog.root)
+    assert oc.verify(seal, prog.root) is None
+    # a witness that breaks an assertion of the program does not exist
+    bad = inputs.copy()
+    bad[1] = 0                                                      # b = 0: is_zero(b) == 0 fails
+    with pytest.raises(HalError, match="assertion of the program fails"):
+        prog.prove(bad)
+    with pytest.raises(HalError, match="input words"):
+        prog.prove(inputs[:7])
+
+
+def test_lift_of_a_small_segment_matches_the_oracle_and_rejects_forgeries(hal, oracle):
+    from zeth_amd.hal import HalError, HostCircuit, RecProgram
+    from zeth_amd.prover import Segment, SegmentProver
+    desc = syn_air.syn_tiny()
+    sp = SegmentProver(hal, desc)
+    cpo2 = 13                                                       # two FRI rounds
+    rcpt = sp.prove_segment(Segment(0, cpo2, seed=77, noise_seed=5))
+    croot = sp.control_root(cpo2)
+    pr = V.build_lift(desc, cpo2, [int(w) * RINV % P for w in croot])
+    po2 = pr.min_po2(ZK)
+    blob = pr.finish(po2, ZK)
+    A = np.arange(1, 9, dtype=np.uint32)
+    inputs = np.concatenate([rcpt.seal, A])
+    oc = zko.OracleCircuit(oracle, R.recursion_circuit())
+    ocode, odata, oout = oc.rec_witgen(blob, inputs)
+    circuit = hal.load_circuit(R.recursion_circuit())
+    prog = RecProgram(hal, circuit, blob)
+    code, data, accum, out = _device_traces(hal, prog, inputs)
+    assert np.array_equal(data.to_vec(), odata) and np.array_equal(code.to_vec(), ocode) and np.array_equal(out, oout)
+    # the lift's claim is the segment's claim digest (zkh_receipt_claim), its second half the allowed root it was handed
+    assert np.array_equal(out[:8], HostCircuit(desc).receipt_claim(rcpt.seal, croot)) and np.array_equal(out[8:], A)
+    seal, _ = prog.prove(inputs, 0x2E80)
+    assert np.array_equal(seal, oc.prove_traces(po2, ocode, odata, oout, ZK, 0x2E80))
+    HostCircuit(R.recursion_circuit()).verify_segment(seal, prog.root)
+    # every part of the child seal is checked in-circuit: header, a Merkle top, coeff_u, an opened row, a path, FRI, the final poly
+    n = rcpt.seal.size
+    for k in (0, 4, 5 + 8 * 3, n // 5, n // 3, n // 2, 2 * n // 3, n - 300, n - 1):
+        forged = inputs.copy()
+        forged[k] = (int(forged[k]) + 1) % P
+        with pytest.raises(HalError, match="assertion of the program fails"):
+            prog.prove(forged)
+    # a seal under another control root (another circuit's code) is not lifted by this program
+    other = V.build_lift(desc, cpo2, [(int(w) * RINV + 1) % P for w in croot])
+    with pytest.raises(HalError, match="assertion of the program fails"):
+        RecProgram(hal, circuit, other.finish(po2, ZK)).prove(inputs)
+
+
+def test_block_of_segments_folds_to_one_receipt_that_verified_every_child_in_circuit(hal):
+    """BASELINE.json config 5 at the BASELINE shape: po2-20 SYN-A segments + a po2-18 tail, lift each, join to one root."""
+    from zeth_amd import recursion as rec
+    from zeth_amd.hal import HalError, HostCircuit
+    from zeth_amd.prover import Segment, SegmentProver
+    desc = syn_air.syn_a()
+    sp = SegmentProver(hal, desc, resident_code_group=True)
+    segs = [Segment(i, 20 if i < 4 else 18, seed=0x5EED0000 + i, noise_seed=100 + i) for i in range(5)]
+    t0 = time.time()
+    leaves = [sp.prove_segment(s) for s in segs]
+    t_seg = time.time() - t0
+    roots = {20: sp.control_root(20), 18: sp.control_root(18)}
+    t0 = time.time()
+    rx = rec.Recursion(hal, desc, roots)
+    t_load = time.time() - t0
+    assert [k[0] for k in rx.kinds] == ["lift", "lift", "join", "join", "join", "join"]
+    assert {p.po2 for p in rx.programs[:2]} == {18} and {p.po2 for p in rx.programs[2:]} == {19}
+    hal.sync()
+    t0 = time.time()
+    lifted = [rx.lift(r, noise_seed=7) for r in leaves]
+    hal.sync()
+    t_lift = time.time() - t0
+    t0 = time.time()
+    root = rx.fold(lifted, noise_seed=9)
+    hal.sync()
+    t_join = time.time() - t0
+    claims = [HostCircuit(desc).receipt_claim(r.seal, roots[r.po2]) for r in leaves]
+    for l, c in zip(lifted, claims):
+        assert np.array_equal(l.claim, c) and np.array_equal(l.allowed, rx.allowed_root())
+    assert root.n_leaves == 5 and root.po2 == 19
+    root.verify(rx.allowed_roots(), claims)                         # ONE seal + the claim tree: nothing else is needed
+    with pytest.raises(HalError, match="claim tree"):
+        root.verify(rx.allowed_roots(), claims[::-1])
+    with pytest.raises(HalError, match="allowed set"):
+        root.verify(rx.allowed_roots()[:2], claims)
+    # a join refuses a child that is not a valid recursion seal, one that carries another allowed root, and one whose program
+    # is not in the allowed set
+    forged = rec.RecReceipt(lifted[0].seal.copy(), lifted[0].po2, lifted[0].program, lifted[0].control_root)
+    forged.seal[lifted[0].seal.size // 2] ^= 1
+    with pytest.raises(HalError, match="assertion of the program fails"):
+        rx.join(forged, lifted[1])
+    inputs = np.concatenate([leaves[0].seal, np.arange(8, dtype=np.uint32)])
+    stranger, _ = rx.programs[0].prove(inputs, 3)                    # a valid lift, but under A' != A
+    with pytest.raises(HalError, match="assertion of the program fails"):
+        rx.join(lifted[0], rec.RecReceipt(stranger, 18, 0, rx.programs[0].root))
+    wrong = rec.RecReceipt(lifted[1].seal, lifted[1].po2, 2, lifted[1].control_root)     # membership path of another program
+    with pytest.raises(HalError, match="assertion of the program fails"):
+        rx.join(lifted[0], wrong)
+    line = {"config": "succinct, recursive", "segments": 5, "segment_s": round(t_seg, 3), "program_load_s": round(t_load, 2),
+            "lift_s_each": round(t_lift / 5, 4), "join_s_each": round(t_join / 4, 4),
+            "programs": [{"kind": list(k), "po2": p.po2, "permutations": p.n_p2, "gates": p.n_gates, "levels": p.n_levels,
+                          "input_words": p.n_inputs} for k, p in zip(rx.kinds, rx.programs)]}
+    print("RECURSION " + json.dumps(line))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/recursion_test.json", "w") as fh:
+        json.dump(line, fh)

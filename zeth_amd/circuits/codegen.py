@@ -934,6 +934,8 @@ def shipped() -> Dict[str, np.ndarray]:
         SHIPPED["keccak_f"] = keccak_f.keccak_f_circuit()
         from . import p2_join
         SHIPPED["p2_join"] = p2_join.p2_join_circuit()
+        from . import recursion
+        SHIPPED["recursion"] = recursion.recursion_circuit()
     return SHIPPED
 
 

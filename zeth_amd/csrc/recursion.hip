@@ -1,0 +1,500 @@
+// recursion.hip — the RECURSION circuit on the device: program loader, witness generator, copy-argument accumulators and the
+// lift / join seal (BASELINE.json config 5).  Stands in for risc0-circuit-recursion 4.0.2
+// src/prove/{mod.rs, program.rs} + its witness generator (un-vendored: /root/reference/Cargo.lock:5305), which
+// risc0_zkvm::default_prover().prove (/root/reference/crates/host/src/lib.rs:137) runs once per lift and per join to turn
+// a block's segment receipts into one succinct receipt.  The circuit and the program format: zeth_amd/circuits/recursion.py;
+// the programs (the STARK verifier itself): zeth_amd/circuits/rec_verify.py; CPU twin: oracle/recursion.c.
+//
+// MI355X mapping.  A program is a DAG of ~2 x 10^5 field micro-ops and ~10^4 Poseidon2 permutations whose depth is only a
+// few hundred (50 queries x ~8 Merkle paths run side by side; the transcript sponge is the long chain).  At load time the
+// ops are sorted into dependency levels; a witness is one launch per level with one lane per op (ops of a level sorted by
+// opcode so that waves stay uniform; a permutation is one lane running the lazily reduced form of hash.hip), values in a
+// device array of Fp4.  The trace is then written by three coalesced kernels (wires; Poseidon2 blocks round by round;
+// blinding rows), the copy argument by one term kernel + the batched prefix product of poly.hip.  The code group depends on
+// the program only: it is committed once at load and stays resident (461 MB for a po2-19 program), as upstream keeps the
+// control columns of lift / join.
+#include <algorithm>
+#include <memory>
+
+#include "../../include/zkh_poseidon2_consts.h"
+#include "circuit.h"
+#include "poseidon2.h"
+
+using namespace zkh;
+
+namespace zkh {
+const char* prefix_products_batched(zkh_ctx* c, uint32_t* io, size_t n0, size_t count, size_t col_stride);
+}
+
+namespace {
+
+constexpr uint32_t RC_T = 24, RC_BLOCK = 31, RC_NW = 6, RC_WD = 72, RC_WA = 12, RC_WC = 55, RC_ROW = 13, RC_ROUNDS = 29;
+constexpr uint32_t RC_MAGIC = 0x5a4b5231u, RC_HEADER = 16, RC_OP_WORDS = 8;
+enum : uint32_t { RO_INPUT = 1, RO_GEN, RO_MUX, RO_PACK, RO_UNPACK, RO_INV, RO_BITS, RO_P2, RO_EQ, RO_ISZ };
+enum : uint32_t { RG_MUX = 1, RG_BOOL = 2, RG_EMB = 4, RG_PACK0 = 8, RG_PUB = 128 };
+
+__device__ __forceinline__ Fp4 ld(const uint4* val, uint32_t v) {
+    const uint4 x = val[v];
+    return Fp4(Fp::raw(x.x), Fp::raw(x.y), Fp::raw(x.z), Fp::raw(x.w));
+}
+__device__ __forceinline__ void st(uint4* val, uint32_t v, const Fp4& x) { val[v] = make_uint4(x.c[0].v, x.c[1].v, x.c[2].v, x.c[3].v); }
+__device__ __forceinline__ uint32_t comp(const uint4& x, uint32_t j) { return j == 0 ? x.x : j == 1 ? x.y : j == 2 ? x.z : x.w; }
+
+// one dependency level of the witness schedule: lane i executes op lo + i
+__global__ __launch_bounds__(64) void k_rec_level(const uint32_t* __restrict__ ops, uint32_t lo, uint32_t hi, uint4* val,
+                                                  const uint32_t* __restrict__ consts, const uint32_t* __restrict__ inputs, uint32_t* fail,
+                                                  const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
+    const uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    const uint32_t* o = ops + (size_t)RC_OP_WORDS * i;
+    const uint32_t op = o[0] & 0xff, aux = (o[0] >> 8) & 0xff, out = o[1];
+    switch (op) {
+    case RO_INPUT: {
+        uint32_t w[4] = {0, 0, 0, 0};
+        bool ok = true;
+        for (uint32_t t = 0; t < aux && t < 4; t++) { w[t] = inputs[o[2] + t]; ok &= w[t] < P; }
+        if (!ok) atomicMin(fail, o[7]);
+        val[out] = make_uint4(w[0], w[1], w[2], w[3]);
+        break;
+    }
+    case RO_GEN: {
+        const uint32_t* q = consts + o[5];
+        const Fp4 a = ld(val, o[2]), b = ld(val, o[3]), c = ld(val, o[4]);
+        Fp4 r = q[0] ? (a * b) * Fp::raw(q[0]) : Fp4::zero();
+        r = r + a * Fp::raw(q[1]) + b * Fp::raw(q[2]) + c * Fp::raw(q[3]);
+        r.c[0] = r.c[0] + Fp::raw(q[4]);
+        st(val, out, r);
+        break;
+    }
+    case RO_MUX: {
+        const Fp4 a = ld(val, o[2]), b = ld(val, o[3]), c = ld(val, o[4]);
+        st(val, out, b + (c - b) * a.c[0]);
+        break;
+    }
+    case RO_PACK: {
+        const uint32_t j = aux & 3;
+        val[out] = make_uint4(comp(val[o[2]], j), comp(val[o[3]], j), comp(val[o[4]], j), comp(val[o[5]], j));
+        break;
+    }
+    case RO_UNPACK: {
+        const uint4 x = val[o[2]];
+        val[out] = make_uint4(x.x, 0, 0, 0); val[out + 1] = make_uint4(x.y, 0, 0, 0);
+        val[out + 2] = make_uint4(x.z, 0, 0, 0); val[out + 3] = make_uint4(x.w, 0, 0, 0);
+        break;
+    }
+    case RO_INV: {
+        const Fp4 a = ld(val, o[2]);
+        if (!(a.c[0].v | a.c[1].v | a.c[2].v | a.c[3].v)) atomicMin(fail, o[7]);
+        else st(val, out, fp4_inv(a));
+        break;
+    }
+    case RO_ISZ: {
+        const uint32_t a = val[o[2]].x;
+        val[out] = make_uint4(a ? fp_inv(Fp::raw(a)).v : 0u, 0, 0, 0);
+        break;
+    }
+    case RO_BITS: {
+        const uint32_t x = fp_decode(Fp::raw(val[o[2]].x));
+        for (uint32_t t = 0; t < 31; t++) val[out + t] = make_uint4(((x >> t) & 1) ? R1 : 0u, 0, 0, 0);
+        break;
+    }
+    case RO_P2: {
+        uint32_t s[CELLS];
+        for (uint32_t w = 0; w < RC_NW; w++) { const uint4 x = val[o[2 + w]]; s[4 * w] = x.x; s[4 * w + 1] = x.y; s[4 * w + 2] = x.z; s[4 * w + 3] = x.w; }
+        poseidon2_mix(s, rc, diag);
+        for (uint32_t w = 0; w < RC_NW; w++) val[out + w] = make_uint4(s[4 * w], s[4 * w + 1], s[4 * w + 2], s[4 * w + 3]);
+        break;
+    }
+    case RO_EQ: {
+        const uint4 a = val[o[2]], b = val[o[3]];
+        if (a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w) atomicMin(fail, o[7]);
+        break;
+    }
+    default: atomicMin(fail, o[7]);
+    }
+}
+
+__device__ __forceinline__ uint32_t rc_cell(uint64_t seed, uint32_t group, uint32_t col, uint32_t row) {   // = syn_cell of circuit.hip
+    uint64_t z = seed ^ ((uint64_t)(group + 1) * 0x9E3779B97F4A7C15ull);
+    z += (uint64_t)col * 0xBF58476D1CE4E5B9ull;
+    z += (uint64_t)row * 0x94D049BB133111EBull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return mul_mod(R2, (uint32_t)(z >> 32) % P);
+}
+__device__ __forceinline__ bool rc_is_full(uint32_t rnd) { return rnd < 4 || rnd >= 25; }
+
+// wires: one lane per (row, wire); rows past A are blinding noise (all 72 data columns: blockIdx.y < 6 covers W, the rest below)
+__global__ void k_rec_fill_wires(uint32_t* data, const uint32_t* __restrict__ pos, const uint4* __restrict__ val, uint32_t n, uint32_t A,
+                                 uint64_t noise_seed) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+    if (r >= n) return;
+    uint4 x = make_uint4(0, 0, 0, 0);
+    if (r < A) {
+        const uint32_t v = pos[(size_t)r * RC_NW + w];
+        if (v) x = val[v - 1];
+    } else {
+        x = make_uint4(rc_cell(noise_seed, GROUP_DATA, 4 * w, r), rc_cell(noise_seed, GROUP_DATA, 4 * w + 1, r),
+                       rc_cell(noise_seed, GROUP_DATA, 4 * w + 2, r), rc_cell(noise_seed, GROUP_DATA, 4 * w + 3, r));
+    }
+    data[(size_t)(4 * w) * n + r] = x.x; data[(size_t)(4 * w + 1) * n + r] = x.y;
+    data[(size_t)(4 * w + 2) * n + r] = x.z; data[(size_t)(4 * w + 3) * n + r] = x.w;
+}
+// S / Q columns outside the blocks: zero while active, noise after
+__global__ void k_rec_fill_tail(uint32_t* data, uint32_t n, uint32_t A, uint32_t first_row, uint64_t noise_seed) {
+    const uint32_t r = first_row + blockIdx.x * blockDim.x + threadIdx.x, col = RC_T + blockIdx.y;
+    if (r >= n) return;
+    data[(size_t)col * n + r] = r < A ? 0u : rc_cell(noise_seed, GROUP_DATA, col, r);
+}
+__device__ void rc_m_ext(uint32_t (&c)[RC_T]) {
+    uint32_t sums[4] = {0, 0, 0, 0};
+    for (uint32_t b = 0; b < RC_T; b += 4) {
+        m4(c[b], c[b + 1], c[b + 2], c[b + 3]);
+        for (uint32_t i = 0; i < 4; i++) sums[i] = add_mod(sums[i], c[b + i]);
+    }
+    for (uint32_t k = 0; k < RC_T; k++) c[k] = add_mod(c[k], sums[k & 3]);
+}
+// one lane per 31-row block: the permutation of the block's input row, round by round (S, Q), and the output row's wires;
+// tab = Montgomery words of rc[24 * 29] then diag[24]
+__global__ void k_rec_blocks(uint32_t* data, uint32_t n, uint32_t K, const uint32_t* __restrict__ tab) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= K) return;
+    const size_t r0 = (size_t)RC_BLOCK * p;
+    uint32_t* S = data + (size_t)RC_T * n;
+    uint32_t* Q = data + (size_t)2 * RC_T * n;
+    uint32_t s[RC_T];
+    for (uint32_t j = 0; j < RC_T; j++) { s[j] = data[(size_t)j * n + r0]; S[(size_t)j * n + r0] = s[j]; Q[(size_t)j * n + r0] = 0; }
+    rc_m_ext(s);
+    const uint32_t* diag = tab + RC_T * RC_ROUNDS;
+    for (uint32_t rnd = 0; rnd < RC_ROUNDS; rnd++) {
+        const size_t r = r0 + 1 + rnd;
+        for (uint32_t j = 0; j < RC_T; j++) S[(size_t)j * n + r] = s[j];
+        if (rc_is_full(rnd)) {
+            for (uint32_t j = 0; j < RC_T; j++) {
+                const uint32_t u = add_mod(s[j], tab[rnd * RC_T + j]);
+                const uint32_t q = mul_mod(mul_mod(u, u), u);
+                Q[(size_t)j * n + r] = q;
+                s[j] = mul_mod(mul_mod(q, q), u);
+            }
+            rc_m_ext(s);
+        } else {
+            const uint32_t u = add_mod(s[0], tab[rnd * RC_T]);
+            const uint32_t q = mul_mod(mul_mod(u, u), u);
+            Q[r] = q;
+            for (uint32_t j = 1; j < RC_T; j++) Q[(size_t)j * n + r] = 0;
+            const uint32_t x7 = mul_mod(mul_mod(q, q), u);
+            uint32_t tot = x7;
+            for (uint32_t j = 1; j < RC_T; j++) tot = add_mod(tot, s[j]);
+            s[0] = add_mod(tot, mul_mod(diag[0], x7));
+            for (uint32_t j = 1; j < RC_T; j++) s[j] = add_mod(tot, mul_mod(diag[j], s[j]));
+        }
+    }
+    const size_t rl = r0 + RC_BLOCK - 1;
+    for (uint32_t j = 0; j < RC_T; j++) { S[(size_t)j * n + rl] = s[j]; Q[(size_t)j * n + rl] = 0; data[(size_t)j * n + rl] = s[j]; }
+}
+// the code group: one lane per (row, column)
+__global__ void k_rec_code(uint32_t* code, const uint32_t* __restrict__ table, uint32_t n, uint32_t A, uint32_t K, const uint32_t* __restrict__ tab) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y;
+    if (r >= n) return;
+    uint32_t v = 0;
+    if (r < A) {
+        const uint32_t* row = table + (size_t)r * RC_ROW;
+        const bool in_blocks = r < RC_BLOCK * K;
+        const uint32_t k = r % RC_BLOCK;
+        const bool round_row = in_blocks && k >= 1 && k <= RC_ROUNDS;
+        const bool full = round_row && rc_is_full(k - 1), part = round_row && !rc_is_full(k - 1);
+        if (col == 0) v = R1;
+        else if (col == 1) v = r == 0 ? R1 : 0;
+        else if (col == 2) v = r > 0 ? R1 : 0;
+        else if (col == 3) v = r == A - 1 ? R1 : 0;
+        else if (col == 4) v = mul_mod(R2, r);
+        else if (col < 11) v = mul_mod(R2, row[7 + (col - 5)]);
+        else if (col < 17) v = mul_mod(R2, row[col - 11]);
+        else if (col == 17) v = (row[6] & RG_MUX) ? R1 : 0;
+        else if (col == 18) v = (row[6] & RG_BOOL) ? R1 : 0;
+        else if (col == 19) v = (row[6] & RG_EMB) ? R1 : 0;
+        else if (col < 24) v = (row[6] & (RG_PACK0 << (col - 20))) ? R1 : 0;
+        else if (col == 24) v = (in_blocks && (k == 0 || k == RC_BLOCK - 1)) ? R1 : 0;
+        else if (col == 25) v = (row[6] & RG_PUB) ? R1 : 0;
+        else if (col == 26) v = (in_blocks && k == 1) ? R1 : 0;
+        else if (col == 27) v = full ? R1 : 0;
+        else if (col == 28) v = part ? R1 : 0;
+        else if (col == 29) v = (in_blocks && k >= 2 && rc_is_full(k - 2)) ? R1 : 0;
+        else if (col == 30) v = (in_blocks && k >= 2 && !rc_is_full(k - 2)) ? R1 : 0;
+        else if (full || (part && col == 31)) v = tab[(k - 1) * RC_T + (col - 31)];
+    }
+    code[(size_t)col * n + r] = v;
+}
+// copy argument: terms[k][r] = prod_{w in {2k, 2k+1}} F(id_w, W_w) / F(sigma_w, W_w)  (active rows) or 1; AoS ExtElems
+__global__ void k_rec_accum_terms(uint32_t* terms, const uint32_t* __restrict__ table, const uint32_t* __restrict__ data,
+                                  const uint32_t* __restrict__ mix, uint32_t n, uint32_t A) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (r >= n) return;
+    Fp4 t = Fp4::one();
+    if (r < A) {
+        Fp4 beta[4], gamma;
+        for (int i = 0; i < 4; i++) beta[i] = Fp4(Fp::raw(mix[4 * i]), Fp::raw(mix[4 * i + 1]), Fp::raw(mix[4 * i + 2]), Fp::raw(mix[4 * i + 3]));
+        gamma = Fp4(Fp::raw(mix[16]), Fp::raw(mix[17]), Fp::raw(mix[18]), Fp::raw(mix[19]));
+        Fp4 num = Fp4::one(), den = Fp4::one();
+        for (uint32_t w = 2 * k; w < 2 * k + 2; w++) {
+            Fp4 f = gamma;
+            for (int i = 0; i < 4; i++) f = f + beta[i] * Fp::raw(data[(size_t)(4 * w + i) * n + r]);
+            Fp4 fi = f, fs = f;
+            fi.c[0] = fi.c[0] + fp_encode(RC_NW * r + w);
+            fs.c[0] = fs.c[0] + fp_encode(table[(size_t)r * RC_ROW + 7 + w]);
+            num = num * fi; den = den * fs;
+        }
+        t = num * fp4_inv(den);
+    }
+    ((uint4*)terms)[(size_t)k * n + r] = make_uint4(t.c[0].v, t.c[1].v, t.c[2].v, t.c[3].v);
+}
+__global__ void k_rec_accum_store(uint32_t* accum, const uint32_t* prods, uint32_t n, uint32_t A, uint64_t noise_seed) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, e = blockIdx.y;
+    if (r >= n) return;
+    uint32_t v[4];
+    if (r < A) {
+        const uint4 p = ((const uint4*)prods)[(size_t)e * n + r];
+        v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w;
+    } else {
+        for (int i = 0; i < 4; i++) v[i] = rc_cell(noise_seed, GROUP_ACCUM, 4 * e + i, r);
+    }
+    for (int i = 0; i < 4; i++) accum[(size_t)(4 * e + i) * n + r] = v[i];
+}
+__global__ void k_rec_gather_pub(uint32_t* out, const uint32_t* __restrict__ data, uint32_t n, uint32_t row) {
+    const uint32_t i = threadIdx.x;
+    if (i < 16) out[i] = data[(size_t)i * n + row];
+}
+
+}  // namespace
+
+struct zkh_rec_program {
+    zkh_ctx* ctx = nullptr;
+    const zkh_circuit* circuit = nullptr;
+    zkh_prover* prover = nullptr;
+    uint32_t po2 = 0, zk = 0, A = 0, n_vars = 0, n_consts = 0, n_ops = 0, n_inputs = 0, n_p2 = 0, n_gates = 0, pub_row = 0xffffffffu;
+    zkh_buf *d_table = nullptr, *d_pos = nullptr, *d_consts = nullptr, *d_ops = nullptr, *d_tab = nullptr;
+    std::vector<uint32_t> level_ptr;
+    uint32_t root[8] = {0};
+    uint64_t hash = 0;
+};
+
+extern "C" void zkh_rec_program_destroy(zkh_rec_program* p) {
+    if (!p) return;
+    if (p->ctx) bind_thread(p->ctx);
+    if (p->prover) zkh_prover_destroy(p->prover);
+    for (zkh_buf* b : {p->d_table, p->d_pos, p->d_consts, p->d_ops, p->d_tab}) if (b) zkh_release(b);
+    delete p;
+}
+
+static const char* rec_check_shape(const zkh_circuit* c) {
+    ZKH_REQUIRE(c && c->kind == 4 && c->group_size[GROUP_CODE] == RC_WC && c->group_size[GROUP_DATA] == RC_WD && c->group_size[GROUP_ACCUM] == RC_WA &&
+                c->global_size[GLOBAL_OUT] == 16 && c->global_size[GLOBAL_MIX] == 20,
+                "recursion: the circuit does not have RECURSION's shape (kind 4: 55 / 72 / 12 columns, 16 outputs, 20 mix words)");
+    return nullptr;
+}
+
+extern "C" const char* zkh_rec_code(const zkh_rec_program* p, zkh_buf* code) {
+    ZKH_REQUIRE(p && code, "rec_code: null argument");
+    const size_t n = (size_t)1 << p->po2;
+    ZKH_REQUIRE(code->len == (size_t)RC_WC * n, "rec_code: buffer shape mismatch");
+    ProfScope prof(p->ctx, "rec_code", 4.0 * RC_WC * n);
+    k_rec_code<<<dim3((unsigned)((n + 255) / 256), RC_WC), 256, 0, p->ctx->stream>>>(code->ptr(), p->d_table->ptr(), (uint32_t)n, p->A,
+                                                                                   p->A / RC_BLOCK, p->d_tab->ptr());
+    return last_launch_error("rec_code");
+}
+
+// Loads a program blob (zeth_amd/circuits/recursion.py Program.finish): validates it, sorts the witness schedule into
+// dependency levels, uploads the tables, generates the code group and commits it (resident for every later seal).
+extern "C" const char* zkh_rec_program_load(zkh_ctx* ctx, const zkh_circuit* circuit, const uint32_t* b, size_t words, zkh_rec_program** out) {
+    ZKH_REQUIRE(ctx && circuit && b && out, "rec_program_load: null argument");
+    ZKH_REQUIRE(circuit->ctx == ctx, "rec_program_load: the circuit was not loaded on this context");
+    ZKH_TRY(rec_check_shape(circuit));
+    ZKH_REQUIRE(words >= RC_HEADER && b[0] == RC_MAGIC && b[1] == 1, "rec_program_load: bad header");
+    std::unique_ptr<zkh_rec_program, void (*)(zkh_rec_program*)> p(new zkh_rec_program(), zkh_rec_program_destroy);
+    p->ctx = ctx; p->circuit = circuit;
+    p->po2 = b[2]; p->zk = b[3]; p->A = b[4]; p->n_vars = b[5]; p->n_consts = b[6]; p->n_ops = b[7]; p->n_inputs = b[8]; p->n_p2 = b[9]; p->n_gates = b[10];
+    ZKH_REQUIRE(p->po2 >= 1 && p->po2 + 2 <= (uint32_t)MAX_LOG_N && (size_t)p->A + p->zk == (size_t)1 << p->po2 && p->A > 1, "rec_program_load: bad shape");
+    const size_t A = p->A, need = RC_HEADER + A * (RC_ROW + RC_NW) + p->n_consts + (size_t)RC_OP_WORDS * p->n_ops;
+    ZKH_REQUIRE(words == need, "rec_program_load: %zu words, the header describes %zu", words, need);
+    ZKH_REQUIRE(p->n_p2 <= A / RC_BLOCK, "rec_program_load: more permutations than blocks");
+    const uint32_t* table = b + RC_HEADER;
+    const uint32_t* pos = table + A * RC_ROW;
+    const uint32_t* consts = pos + A * RC_NW;
+    const uint32_t* ops = consts + p->n_consts;
+    for (size_t i = 0; i < A * RC_NW; i++) ZKH_REQUIRE(pos[i] <= p->n_vars, "rec_program_load: a position names an unknown variable");
+    for (size_t r = 0; r < A; r++) {
+        const uint32_t* row = table + r * RC_ROW;
+        for (int i = 0; i < 6; i++) ZKH_REQUIRE(row[i] < P, "rec_program_load: gate coefficient out of range");
+        for (int w = 0; w < 6; w++) ZKH_REQUIRE(row[7 + w] < A * RC_NW, "rec_program_load: sigma out of range");
+        if ((row[6] & RG_PUB) && p->pub_row == 0xffffffffu) p->pub_row = (uint32_t)r;
+    }
+    // dependency levels
+    std::vector<uint32_t> var_level(p->n_vars ? p->n_vars : 1, 0), op_level(p->n_ops, 0);
+    uint32_t n_levels = 0;
+    for (uint32_t i = 0; i < p->n_ops; i++) {
+        const uint32_t* o = ops + (size_t)RC_OP_WORDS * i;
+        const uint32_t op = o[0] & 0xff, out_v = o[1];
+        uint32_t n_in = 0, n_out = 1;
+        switch (op) {
+        case RO_INPUT: ZKH_REQUIRE((o[0] >> 8) >= 1 && (o[0] >> 8) <= 4 && (size_t)o[2] + (o[0] >> 8) <= p->n_inputs, "rec_program_load: op %u reads outside the inputs", i); break;
+        case RO_GEN: n_in = 3; ZKH_REQUIRE((size_t)o[5] + 5 <= p->n_consts, "rec_program_load: op %u: constant index out of range", i); break;
+        case RO_MUX: n_in = 3; break;
+        case RO_PACK: n_in = 4; break;
+        case RO_UNPACK: n_in = 1; n_out = 4; break;
+        case RO_INV: case RO_ISZ: n_in = 1; break;
+        case RO_BITS: n_in = 1; n_out = 31; break;
+        case RO_P2: n_in = 6; n_out = 6; break;
+        case RO_EQ: n_in = 2; n_out = 0; break;
+        default: return make_err("rec_program_load: op %u has unknown opcode %u", i, op);
+        }
+        ZKH_REQUIRE((size_t)out_v + n_out <= p->n_vars || n_out == 0, "rec_program_load: op %u writes an unknown variable", i);
+        uint32_t lvl = 0;
+        for (uint32_t k = 0; k < n_in; k++) {
+            const uint32_t v = o[2 + k];
+            ZKH_REQUIRE(v < p->n_vars, "rec_program_load: op %u reads an unknown variable", i);
+            if (op == RO_GEN && v == out_v) continue;                  // a constant: its (zero-weighted) operands name itself
+            lvl = std::max(lvl, var_level[v] + 1);
+        }
+        op_level[i] = lvl;
+        for (uint32_t k = 0; k < n_out; k++) var_level[out_v + k] = lvl;
+        n_levels = std::max(n_levels, lvl + 1);
+    }
+    std::vector<uint32_t> order(p->n_ops);
+    for (uint32_t i = 0; i < p->n_ops; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        if (op_level[x] != op_level[y]) return op_level[x] < op_level[y];
+        return (ops[(size_t)RC_OP_WORDS * x] & 0xff) < (ops[(size_t)RC_OP_WORDS * y] & 0xff);
+    });
+    std::vector<uint32_t> sorted((size_t)RC_OP_WORDS * p->n_ops + 1);
+    p->level_ptr.assign(n_levels + 1, 0);
+    for (uint32_t k = 0; k < p->n_ops; k++) {
+        const uint32_t* o = ops + (size_t)RC_OP_WORDS * order[k];
+        uint32_t* d = &sorted[(size_t)RC_OP_WORDS * k];
+        const uint32_t op = o[0] & 0xff;
+        memcpy(d, o, 4 * RC_OP_WORDS);
+        // free the last word for the op's original index + 1 (what a failed assertion reports): P2 moves its sixth input out
+        // of it first (no slot is spare there, so its index goes unreported - a permutation cannot fail)
+        if (op != RO_P2) d[7] = order[k] + 1;
+        p->level_ptr[op_level[order[k]] + 1] = k + 1;
+    }
+    for (uint32_t l = 1; l <= n_levels; l++) p->level_ptr[l] = std::max(p->level_ptr[l], p->level_ptr[l - 1]);
+    bind_thread(ctx);
+    std::vector<uint32_t> kk(p->n_consts ? p->n_consts : 1, 0), tab(RC_T * RC_ROUNDS + RC_T);
+    for (uint32_t i = 0; i < p->n_consts; i++) { ZKH_REQUIRE(consts[i] < P, "rec_program_load: constant out of range"); kk[i] = fp_encode(consts[i]).v; }
+    for (uint32_t i = 0; i < RC_T * RC_ROUNDS; i++) tab[i] = fp_encode(ZKH_P2_ROUND_CONSTANTS[i]).v;
+    for (uint32_t i = 0; i < RC_T; i++) tab[RC_T * RC_ROUNDS + i] = fp_encode(ZKH_P2_M_INT_DIAG[i]).v;
+    ZKH_TRY(zkh_copy_from(ctx, "rec_table", table, A * RC_ROW, &p->d_table));
+    ZKH_TRY(zkh_copy_from(ctx, "rec_pos", pos, A * RC_NW, &p->d_pos));
+    ZKH_TRY(zkh_copy_from(ctx, "rec_consts", kk.data(), kk.size(), &p->d_consts));
+    ZKH_TRY(zkh_copy_from(ctx, "rec_ops", sorted.data(), sorted.size(), &p->d_ops));
+    ZKH_TRY(zkh_copy_from(ctx, "rec_tab", tab.data(), tab.size(), &p->d_tab));
+    p->hash = desc_hash64(b, words);
+    // the code group: generated, committed, resident
+    ZKH_TRY(zkh_prover_create(ctx, circuit, &p->prover));
+    {
+        Tmp code;
+        ZKH_TRY(new_buf(ctx, (size_t)RC_WC << p->po2, false, code.out()));
+        ZKH_TRY(zkh_rec_code(p.get(), code.b));
+        ZKH_TRY(zkh_prover_cache_code(p->prover, p->po2, code.b));
+        ZKH_TRY(zkh_prover_cached_code_root(p->prover, p->po2, p->root));
+    }
+    *out = p.release();
+    return nullptr;
+}
+
+extern "C" const char* zkh_rec_program_info(const zkh_rec_program* p, uint32_t root[8], uint32_t info[8]) {
+    ZKH_REQUIRE(p, "rec_program_info: null program");
+    if (root) memcpy(root, p->root, 32);
+    if (info) {
+        info[0] = p->po2; info[1] = p->zk; info[2] = p->n_inputs; info[3] = p->n_p2; info[4] = p->n_gates; info[5] = p->n_ops;
+        info[6] = (uint32_t)(p->level_ptr.size() - 1); info[7] = p->n_vars;
+    }
+    return nullptr;
+}
+
+// The witness: runs the program on `inputs` (raw Montgomery words: the child seals and what else the program reads), fills
+// data (72 x n) and out_global (16 words).  An assertion of the program that fails - the inputs are not what the program
+// verifies - is an error naming the op, not a trace.
+extern "C" const char* zkh_rec_witgen(const zkh_rec_program* p, const uint32_t* inputs, size_t n_inputs, uint64_t noise_seed, zkh_buf* data,
+                                      uint32_t out_global[16]) {
+    ZKH_REQUIRE(p && data && out_global && (inputs || !p->n_inputs), "rec_witgen: null argument");
+    ZKH_REQUIRE(n_inputs == p->n_inputs, "rec_witgen: the program reads %u input words, %zu were given", p->n_inputs, n_inputs);
+    zkh_ctx* c = p->ctx;
+    const size_t n = (size_t)1 << p->po2;
+    ZKH_REQUIRE(data->len == (size_t)RC_WD * n, "rec_witgen: buffer shape mismatch");
+    Tmp val, din, fail, pub;
+    ZKH_TRY(new_buf(c, 4 * (size_t)(p->n_vars ? p->n_vars : 1), false, val.out()));
+    const uint32_t zero = 0, none = 0xffffffffu;
+    ZKH_TRY(zkh_copy_from(c, "rec_inputs", n_inputs ? inputs : &zero, n_inputs ? n_inputs : 1, din.out()));
+    ZKH_TRY(zkh_copy_from(c, "rec_fail", &none, 1, fail.out()));
+    {
+        ProfScope prof(c, "rec_exec", 16.0 * p->n_vars);
+        for (size_t l = 0; l + 1 < p->level_ptr.size(); l++) {
+            const uint32_t lo = p->level_ptr[l], hi = p->level_ptr[l + 1];
+            if (hi == lo) continue;
+            k_rec_level<<<(hi - lo + 63) / 64, 64, 0, c->stream>>>(p->d_ops->ptr(), lo, hi, (uint4*)val->ptr(), p->d_consts->ptr(), din->ptr(),
+                                                                  fail->ptr(), c->tab.rc, c->tab.diag);
+        }
+    }
+    ZKH_TRY(last_launch_error("rec_exec"));
+    const uint32_t A = p->A, K = A / RC_BLOCK;
+    {
+        ProfScope prof(c, "rec_fill", 4.0 * RC_WD * n);
+        const unsigned bx = (unsigned)((n + 255) / 256);
+        k_rec_fill_wires<<<dim3(bx, RC_NW), 256, 0, c->stream>>>(data->ptr(), p->d_pos->ptr(), (const uint4*)val->ptr(), (uint32_t)n, A, noise_seed);
+        k_rec_blocks<<<(K + 63) / 64, 64, 0, c->stream>>>(data->ptr(), (uint32_t)n, K, p->d_tab->ptr());
+        const uint32_t first = RC_BLOCK * K;
+        if (first < n) k_rec_fill_tail<<<dim3((unsigned)((n - first + 255) / 256), 2 * RC_T), 256, 0, c->stream>>>(data->ptr(), (uint32_t)n, A, first, noise_seed);
+    }
+    ZKH_TRY(last_launch_error("rec_fill"));
+    ZKH_TRY(new_buf(c, 16, true, pub.out()));
+    if (p->pub_row != 0xffffffffu) k_rec_gather_pub<<<1, 64, 0, c->stream>>>(pub->ptr(), data->ptr(), (uint32_t)n, p->pub_row);
+    uint32_t failed = none;
+    ZKH_TRY(zkh_read(c, fail, &failed, 0, 1));
+    ZKH_TRY(zkh_read(c, pub, out_global, 0, 16));
+    ZKH_REQUIRE(failed == none, "rec_witgen: op %u: an assertion of the program fails on these inputs (two wires that the program ties "
+                "together differ, an inverse of zero, or an unreduced input word): the input is not a valid seal", failed - 1);
+    return nullptr;
+}
+
+extern "C" const char* zkh_rec_accum(const zkh_rec_program* p, uint64_t noise_seed, const zkh_buf* data, const uint32_t* mix_global, zkh_buf* accum) {
+    ZKH_REQUIRE(p && data && mix_global && accum, "rec_accum: null argument");
+    zkh_ctx* c = p->ctx;
+    const size_t n = (size_t)1 << p->po2;
+    ZKH_REQUIRE(accum->len == (size_t)RC_WA * n && data->len == (size_t)RC_WD * n, "rec_accum: buffer shape mismatch");
+    Tmp mix, terms;
+    ZKH_TRY(zkh_copy_from(c, "mix", mix_global, 20, mix.out()));
+    ZKH_TRY(new_buf(c, 4 * (size_t)3 * n, false, terms.out()));
+    const unsigned bx = (unsigned)((n + 255) / 256);
+    {
+        ProfScope prof(c, "rec_accum_terms", (4.0 * RC_NW * 4 + 16.0 * 3) * n);
+        k_rec_accum_terms<<<dim3(bx, 3), 256, 0, c->stream>>>(terms->ptr(), p->d_table->ptr(), data->ptr(), mix->ptr(), (uint32_t)n, p->A);
+    }
+    ZKH_TRY(prefix_products_batched(c, terms->ptr(), n, 3, 4 * n));
+    {
+        ProfScope prof(c, "rec_accum_store", 32.0 * 3 * n);
+        k_rec_accum_store<<<dim3(bx, 3), 256, 0, c->stream>>>(accum->ptr(), terms->ptr(), (uint32_t)n, p->A, noise_seed);
+    }
+    return last_launch_error("rec_accum");
+}
+
+// One lift / join: witness, seal.  The code group is the resident one committed at load.
+extern "C" const char* zkh_rec_prove(const zkh_rec_program* p, const uint32_t* inputs, size_t n_inputs, uint64_t noise_seed,
+                                     uint32_t out_global[16], uint32_t** seal, size_t* seal_words) {
+    ZKH_REQUIRE(p && seal && seal_words, "rec_prove: null argument");
+    zkh_ctx* c = p->ctx;
+    const size_t n = (size_t)1 << p->po2;
+    Tmp data, accum;
+    uint32_t out[16];
+    ZKH_TRY(new_buf(c, (size_t)RC_WD * n, false, data.out()));
+    ZKH_TRY(zkh_rec_witgen(p, inputs, n_inputs, noise_seed, data.b, out));
+    if (out_global) memcpy(out_global, out, sizeof out);
+    zkh_seal_job* job = nullptr;
+    uint32_t mix[20];
+    ZKH_TRY(zkh_prove_begin(p->prover, p->po2, nullptr, data.b, out, &job, mix));
+    const char* e = new_buf(c, (size_t)RC_WA * n, false, accum.out());
+    if (!e) e = zkh_rec_accum(p, noise_seed, data.b, mix, accum.b);
+    if (e) { zkh_prove_abort(job); return e; }
+    return zkh_prove_finish(job, accum.b, seal, seal_words);
+}

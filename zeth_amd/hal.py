@@ -129,6 +129,13 @@ ABI = {
     "zkh_receipt_claim": (_err, [_vp, _u32p, _sz, _u32p, _u32p, _u32p, _u32p]),
     "zkh_receipt_encode": (_err, [_vp, _u32p, _sz, _u32, _u32p, C.POINTER(_u32p), C.POINTER(_sz)]),
     "zkh_receipt_decode": (_err, [_vp, _u32p, _sz, _u32p, C.POINTER(_sz)]),
+    "zkh_rec_program_load": (_err, [_vp, _vp, _u32p, _sz, C.POINTER(_vp)]),
+    "zkh_rec_program_destroy": (None, [_vp]),
+    "zkh_rec_program_info": (_err, [_vp, _u32p, _u32p]),
+    "zkh_rec_code": (_err, [_vp, _vp]),
+    "zkh_rec_witgen": (_err, [_vp, _u32p, _sz, _u64, _vp, _u32p]),
+    "zkh_rec_accum": (_err, [_vp, _u64, _vp, _u32p, _vp]),
+    "zkh_rec_prove": (_err, [_vp, _u32p, _sz, _u64, _u32p, C.POINTER(_u32p), C.POINTER(_sz)]),
     "zkh_session_create": (_err, [C.POINTER(_i), _sz, _sz, _u32p, _sz, _u32p, _sz, C.POINTER(_vp)]),
     "zkh_session_destroy": (None, [_vp]),
     "zkh_session_lanes": (_sz, [_vp]),
@@ -322,6 +329,50 @@ class HostCircuit:
         d = _ptr(_u32(diag)) if diag is not None else None
         _check(_lib.zkh_receipt_claim(self.h, _ptr(s), s.size, _ptr(cr), r, d, _ptr(out)))
         return out
+
+
+class RecProgram:
+    """A loaded RECURSION program (lift / join): zkh_rec_program_*.  `circuit` = the RECURSION description on the same HAL."""
+
+    def __init__(self, hal: "HipHal", circuit: Circuit, blob):
+        self.hal, self.circuit = hal, circuit
+        b = _u32(blob)
+        h = _vp()
+        _check(_lib.zkh_rec_program_load(hal.ctx, circuit.h, _ptr(b), b.size, C.byref(h)))
+        self.h = h
+        root, info = np.zeros(8, np.uint32), np.zeros(8, np.uint32)
+        _check(_lib.zkh_rec_program_info(h, _ptr(root), _ptr(info)))
+        self.root = root
+        self.po2, self.zk_cycles, self.n_inputs, self.n_p2, self.n_gates, self.n_ops, self.n_levels, self.n_vars = (int(x) for x in info)
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h and _lib is not None:
+            _lib.zkh_rec_program_destroy(h)
+
+    def code(self, code: Buffer) -> None:
+        _check(_lib.zkh_rec_code(self.h, code.h))
+
+    def witgen(self, inputs, data: Buffer, noise_seed: int = 0x2E80) -> np.ndarray:
+        i = _u32(inputs)
+        out = np.zeros(16, np.uint32)
+        _check(_lib.zkh_rec_witgen(self.h, _ptr(i), i.size, noise_seed, data.h, _ptr(out)))
+        return out
+
+    def accum(self, data: Buffer, mix_global, accum: Buffer, noise_seed: int = 0x2E80) -> None:
+        m = _u32(mix_global)
+        assert m.size == 20
+        _check(_lib.zkh_rec_accum(self.h, noise_seed, data.h, _ptr(m), accum.h))
+
+    def prove(self, inputs, noise_seed: int = 0x2E80):
+        """-> (seal words, out globals): the witness exists only if the program's in-circuit verifier accepts `inputs`"""
+        i = _u32(inputs)
+        out = np.zeros(16, np.uint32)
+        seal, n = _u32p(), _sz()
+        _check(_lib.zkh_rec_prove(self.h, _ptr(i), i.size, noise_seed, _ptr(out), C.byref(seal), C.byref(n)))
+        words = np.ctypeslib.as_array(seal, shape=(n.value,)).copy()
+        _lib.zkh_free_seal(seal)
+        return words, out
 
 
 class HipHal:

@@ -1,0 +1,151 @@
+"""lift / join: a block's segment receipts folded into ONE succinct receipt whose every node verified its children IN-CIRCUIT.
+
+Host-side mirror of what `default_prover().prove(env, elf)` (/root/reference/crates/host/src/lib.rs:137) does after the
+segments are sealed when `ProverOpts::succinct()` is in force (BASELINE.json config 5): risc0-zkvm 3.0.3
+`ProverServer::{lift, join}` -> risc0-circuit-recursion 4.0.2 `Prover::run` on the lift / join programs (both un-vendored:
+/root/reference/Cargo.lock:5418, :5305).  Here: the programs are built by circuits/rec_verify.py (this library's STARK verifier
+restated as a RECURSION program), loaded once per GPU lane (`hal.RecProgram`: code group resident), and run per receipt.
+
+    rec = Recursion(hal, segment_desc, segment_po2s=(20, 18))
+    root = rec.fold([rec.lift(r) for r in segment_receipts])
+    root.verify(rec.allowed_root(), claims)          # host: one seal, one membership, one claim tree
+
+A `RecReceipt` is a seal of the RECURSION circuit: out = claim (8 words) ‖ allowed-programs root A (8 words).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import hal as _hal
+from .circuits import rec_verify, recursion as rc
+from .circuits.desc import P
+from .host import fold_claims, hash_pair
+from .prover import SegmentReceipt
+
+R = (1 << 32) % P
+RINV = pow(R, -1, P)
+N_ALLOWED = 1 << rec_verify.ALLOWED_DEPTH
+
+
+def allowed_tree(roots: Sequence[np.ndarray]) -> List[List[np.ndarray]]:
+    """levels of the allowed-programs tree over `roots` (padded with zero digests to 8 leaves): [leaves, ..., [root]]"""
+    assert len(roots) <= N_ALLOWED
+    level = [np.asarray(r, dtype=np.uint32) for r in roots] + [np.zeros(8, np.uint32)] * (N_ALLOWED - len(roots))
+    levels = [level]
+    while len(level) > 1:
+        level = [hash_pair(level[2 * i], level[2 * i + 1]) for i in range(len(level) // 2)]
+        levels.append(level)
+    return levels
+
+
+def membership_words(levels, index: int) -> np.ndarray:
+    """the witness words `Verifier.allowed_member` reads: per level the direction bit, then the sibling digest"""
+    out = []
+    for lvl in levels[:-1]:
+        bit = index & 1
+        out.append(np.array([bit * R % P], dtype=np.uint32))
+        out.append(lvl[index ^ 1])
+        index >>= 1
+    return np.concatenate(out)
+
+
+@dataclass
+class RecReceipt:
+    """`SuccinctReceipt` analogue: one seal of the RECURSION circuit under program `program` (index into the allowed set)."""
+    seal: np.ndarray
+    po2: int
+    program: int
+    control_root: np.ndarray
+    n_leaves: int = 1
+
+    @property
+    def claim(self) -> np.ndarray:
+        return np.asarray(self.seal[:8], dtype=np.uint32)
+
+    @property
+    def allowed(self) -> np.ndarray:
+        return np.asarray(self.seal[8:16], dtype=np.uint32)
+
+    def verify(self, allowed_roots: Sequence[np.ndarray], leaf_claims: Optional[Sequence[np.ndarray]] = None) -> None:
+        """Host check of the whole tree below this receipt: ONE seal verification, the program's membership in the allowed
+        set, the allowed root the receipt carries, and (given the leaves' claims) the claim tree.  Raises HalError."""
+        roots = [np.asarray(r, dtype=np.uint32) for r in allowed_roots]
+        if not any(np.array_equal(self.control_root, r) for r in roots):
+            raise _hal.HalError("recursion receipt: its program is not in the allowed set")
+        _hal.HostCircuit(rc.recursion_circuit()).verify_segment(self.seal, self.control_root)
+        if not np.array_equal(self.allowed, allowed_tree(roots)[-1][0]):
+            raise _hal.HalError("recursion receipt: it was produced under another allowed-programs root")
+        if leaf_claims is not None and not np.array_equal(self.claim, fold_claims(list(leaf_claims))):
+            raise _hal.HalError("recursion receipt: its claim is not the root of the leaves' claim tree")
+
+
+class Recursion:
+    """The lift / join programs of one GPU lane for segments of `segment_desc` at the po2s in `segment_po2s`."""
+    LIFT_PO2, JOIN_PO2 = 18, 19          # what the programs need for po2 <= 20 segments of SYN-A's width (Program.min_po2)
+
+    def __init__(self, hal: "_hal.HipHal", segment_desc, segment_roots: Dict[int, np.ndarray], zk_cycles: int = _hal.ZK_CYCLES):
+        """segment_roots: {segment po2: control root of the segment circuit at that po2} - one lift program each."""
+        self.hal = hal
+        self.zk = zk_cycles
+        self.segment_desc = np.asarray(segment_desc, dtype=np.uint32)
+        self.circuit = hal.load_circuit(rc.recursion_circuit())
+        self.rdesc = rc.recursion_circuit()
+        self.programs: List[_hal.RecProgram] = []
+        self.kinds: List[Tuple] = []
+        for po2, root in sorted(segment_roots.items(), reverse=True):
+            pr = rec_verify.build_lift(self.segment_desc, po2, [int(w) * RINV % P for w in np.asarray(root, dtype=np.uint32)])
+            self._load(("lift", po2), pr)
+        # joins: every pair of child sizes that can meet (lifts and joins), until the set of sizes closes
+        sizes = sorted({p.po2 for p in self.programs})
+        done = set()
+        while True:
+            todo = [(a, b) for a in sizes for b in sizes if (a, b) not in done]
+            if not todo:
+                break
+            for a, b in todo:
+                done.add((a, b))
+                self._load(("join", a, b), rec_verify.build_join(self.rdesc, a, b))
+            sizes = sorted({p.po2 for p in self.programs})
+        assert len(self.programs) <= N_ALLOWED, f"{len(self.programs)} programs do not fit the allowed set"
+        self.levels = allowed_tree([p.root for p in self.programs])
+
+    def _load(self, kind: Tuple, pr: rc.Program) -> None:
+        blob = pr.finish(pr.min_po2(self.zk), self.zk)
+        self.programs.append(_hal.RecProgram(self.hal, self.circuit, blob))
+        self.kinds.append(kind)
+
+    def allowed_roots(self) -> List[np.ndarray]:
+        return [p.root for p in self.programs]
+
+    def allowed_root(self) -> np.ndarray:
+        return self.levels[-1][0]
+
+    def lift(self, receipt: SegmentReceipt, noise_seed: Optional[int] = None) -> RecReceipt:
+        i = self.kinds.index(("lift", receipt.po2))
+        inputs = np.concatenate([np.asarray(receipt.seal, dtype=np.uint32), self.allowed_root()])
+        seal, _ = self.programs[i].prove(inputs, _seed(noise_seed))
+        return RecReceipt(seal, self.programs[i].po2, i, self.programs[i].root)
+
+    def join(self, left: RecReceipt, right: RecReceipt, noise_seed: Optional[int] = None) -> RecReceipt:
+        i = self.kinds.index(("join", left.po2, right.po2))
+        inputs = np.concatenate([left.seal, membership_words(self.levels, left.program), right.seal, membership_words(self.levels, right.program)])
+        seal, _ = self.programs[i].prove(inputs, _seed(noise_seed))
+        return RecReceipt(seal, self.programs[i].po2, i, self.programs[i].root, left.n_leaves + right.n_leaves)
+
+    def fold(self, leaves: Sequence[RecReceipt], noise_seed: Optional[int] = None) -> RecReceipt:
+        """the join tree of host.join_schedule / fold_claims: pairs left to right, an unpaired last node moves up unchanged"""
+        level = list(leaves)
+        while len(level) > 1:
+            nxt = [self.join(level[2 * k], level[2 * k + 1], noise_seed) for k in range(len(level) // 2)]
+            if len(level) % 2:
+                nxt.append(level[-1])
+            level = nxt
+        return level[0]
+
+
+def _seed(noise_seed: Optional[int]) -> int:
+    from .prover import fresh_noise_seed
+    return fresh_noise_seed() if noise_seed is None else noise_seed
