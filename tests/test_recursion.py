@@ -1,0 +1,211 @@
+"""RECURSION on the CPU: the circuit's gates and copy argument, the program assembler against its plain
+Python semantics, and the in-circuit STARK verifier (lift) run on real seals of the CPU oracle - accepted, and refused as soon
+as one word of the seal is forged.  The device twin is compared with all of this bit for bit in test_recursion_gpu.py."""
+import numpy as np
+import pytest
+
+import zko
+from zeth_amd.circuits import rec_verify as V, recursion as R, syn_air
+from zeth_amd.circuits.desc import Circuit, P
+
+RM = (1 << 32) % P
+RINV = pow(RM, -1, P)
+MIX = np.array([(i * 7919 + 13) * RM % P for i in range(20)], dtype=np.uint32)
+
+
+def enc(vals):
+    return np.array([int(v) * RM % P for v in vals], dtype=np.uint32)
+
+
+def small_program():
+    pr = R.Program()
+    x, y = pr.input(0, 4), pr.input(4, 4)
+    s, m = pr.add(x, y), pr.mul(x, y)
+    iv = pr.inv(m)
+    pr.eq(pr.mul(m, iv), pr.const(1))
+    a, b, _, _ = pr.unpack(x)
+    bits = pr.bits31(a, 12)
+    sel = pr.mux(bits[0], s, m)
+    h = pr.p2([x, y, s, m, pr.zero(), pr.zero()])
+    h2 = pr.p2([h[0], h[1], sel, iv, h[4], h[5]])
+    pr.eq(pr.is_zero(b), pr.zero())
+    pk = pr.pack(2, x, y, s, m)
+    k = pr.const(3, 1, 4, 1)
+    pr.public(h2[0], h2[1], pk, pr.mul(k, bits[12]))
+    return pr, (h2[0], h2[1], pk)
+
+
+@pytest.fixture(scope="module")
+def rec(oracle):
+    return zko.OracleCircuit(oracle, R.recursion_circuit())
+
+
+def test_circuit_shape():
+    c = Circuit.parse(R.recursion_circuit())
+    assert c.kind == 4 and c.group_sizes == (R.WA, R.WC, R.WD) == (12, 55, 72) and c.global_sizes == (16, 20)
+    assert max(b for _, _, b in c.taps) == 1                       # only the previous row is ever read
+
+
+def test_program_semantics_trace_and_seal(rec):
+    pr, (h0, h1, pk) = small_program()
+    zk = 50
+    po2 = pr.min_po2(zk)
+    assert po2 == 7
+    blob = pr.finish(po2, zk)
+    words = [5, 6, 7, 8, 11, 12, 13, 14]
+    vals = R.run_program(pr, words)
+    code, data, out = rec.rec_witgen(blob, enc(words))
+    assert list(out[:12]) == list(enc([w for v in (vals[h0], vals[h1], vals[pk]) for w in v]))
+    # x = 5 + 6 X + 7 X^2 + 8 X^3: bits of 5, pack(2, ...) = the third components
+    assert vals[pk] == (7, 13, (7 + 13) % P, vals[pk][3])
+    accum = rec.rec_accum(po2, code, data, MIX, zk)
+    assert rec.check_rows(po2, accum, code, data, out, MIX) == -1
+    seal = rec.prove_traces(po2, code, data, out, zk)
+    root = rec.root_of_code(po2, code)
+    assert rec.verify(seal, root, zk) is None
+    forged = seal.copy()
+    forged[0] = (int(forged[0]) + 1) % P
+    assert rec.verify(forged, root, zk) is not None
+    # another program has another control root: the seal does not verify under it
+    pr2, _ = small_program()
+    pr2.add(pr2.const(1), pr2.const(2))
+    code2, _, _ = rec.rec_witgen(pr2.finish(po2, zk), enc(words))
+    assert rec.verify(seal, rec.root_of_code(po2, code2), zk) is not None
+
+
+def test_every_kind_of_gate_and_the_copy_argument_bind_the_trace(rec):
+    """flip one cell of a wire that a given constraint family reads: the row check must find it"""
+    pr, _ = small_program()
+    zk, po2 = 50, 7
+    blob = pr.finish(po2, zk)
+    n = 1 << po2
+    code, data, out = rec.rec_witgen(blob, enc([5, 6, 7, 8, 11, 12, 13, 14]))
+    cg = code.reshape(R.WC, n)
+
+    def broken(col, row):
+        d = data.copy()
+        d[col * n + row] = (int(d[col * n + row]) + 1) % P
+        accum = rec.rec_accum(po2, code, d, MIX, zk)
+        return rec.check_rows(po2, accum, code, d, out, MIX)
+    assert rec.check_rows(po2, rec.rec_accum(po2, code, data, MIX, zk), code, data, out, MIX) == -1
+    for name, sel_col, wire in (("GEN", R.C_QM, 3), ("MUX", R.C_MUX, 3), ("BOOL", R.C_BOOL, 0), ("PACK", R.C_PACK + 2, 3),
+                                ("EMB", R.C_EMB, 4), ("PUB", R.C_PUB, 1)):
+        rows = np.nonzero(cg[sel_col])[0]
+        assert rows.size, name
+        assert broken(4 * wire + 1, int(rows[0])) >= 0, name
+    # the copy argument alone: a wire nobody's gate reads, but which shares a variable with another position
+    r_in = 31                                                       # input row of the second permutation: its wire a is h[0]
+    assert broken(0, r_in) >= 0 and broken(R.D_S + 5, 3) >= 0 and broken(R.D_Q + 2, 33) >= 0
+    # the out globals are bound to the PUB row
+    o2 = out.copy()
+    o2[3] = (int(o2[3]) + 1) % P
+    assert rec.check_rows(po2, rec.rec_accum(po2, code, data, MIX, zk), code, data, o2, MIX) >= 0
+
+
+def test_witness_generator_refuses_what_the_program_forbids(rec):
+    pr, _ = small_program()
+    blob = pr.finish(7, 50)
+    with pytest.raises(RuntimeError, match="tie"):
+        rec.rec_witgen(blob, enc([5, 0, 7, 8, 11, 12, 13, 14]))              # is_zero(b) must be 0
+    with pytest.raises(RuntimeError, match="reduced"):
+        rec.rec_witgen(blob, np.array([P] * 8, dtype=np.uint32))
+    with pytest.raises(RuntimeError, match="more input"):
+        rec.rec_witgen(blob, enc([1, 2, 3]))
+    bad = blob.copy()
+    bad[0] ^= 1
+    with pytest.raises(RuntimeError, match="header"):
+        rec.rec_witgen(bad, enc([5, 6, 7, 8, 11, 12, 13, 14]))
+    with pytest.raises(AssertionError):
+        R.run_program(pr, [5, 0, 7, 8, 11, 12, 13, 14])
+
+
+def test_bits_are_canonical(rec):
+    """31 boolean wires summing to x do not pin x's bits unless the value is forced below P"""
+    for x in (0, 1, P - 1, (1 << 27) - 1, 15 << 27):
+        pr = R.Program()
+        v = pr.input(0, 1)
+        bits = pr.bits31(v)
+        pr.public(bits[0], bits[27], bits[30], v)
+        vals = R.run_program(pr, [x])
+        assert [vals[b][0] for b in bits] == [(x >> i) & 1 for i in range(31)]
+        code, data, out = rec.rec_witgen(pr.finish(8, 50), enc([x]))
+        assert rec.check_rows(8, rec.rec_accum(8, code, data, MIX, 50), code, data, out, MIX) == -1
+
+
+@pytest.mark.parametrize("cpo2", [8, 10])
+def test_lift_runs_the_verifier_in_circuit(oracle, rec, cpo2):
+    """a real seal (CPU oracle, SYN-tiny): the lift program's witness exists, satisfies every constraint, carries the
+    segment's claim; one forged word anywhere in the seal and no witness exists.  cpo2 10 has a FRI round, 8 has none."""
+    desc = syn_air.syn_tiny()
+    child = zko.OracleCircuit(oracle, desc)
+    czk = 50
+    seal = child.prove(cpo2, czk)
+    croot = child.control_root(cpo2, czk)
+    pr = V.build_lift(desc, cpo2, [int(w) * RINV % P for w in croot])
+    assert pr.n_inputs == seal.size + 8                             # the program reads exactly the seal, then A
+    po2 = pr.min_po2()
+    blob = pr.finish(po2)
+    A = np.arange(1, 9, dtype=np.uint32)
+    inputs = np.concatenate([seal, A])
+    code, data, out = rec.rec_witgen(blob, inputs)
+    claim_in = np.concatenate([seal[:5], croot])                    # out (4) ‖ po2 ‖ control root
+    want = np.zeros(8, np.uint32)
+    oracle.zko_hash_elem_slice(np.ascontiguousarray(claim_in), claim_in.size, 1, want)
+    assert np.array_equal(out[:8], want) and np.array_equal(out[8:], A)
+    accum = rec.rec_accum(po2, code, data, MIX)
+    assert rec.check_rows(po2, accum, code, data, out, MIX) == -1
+    rng = np.random.default_rng(cpo2)
+    for k in [0, 4, 5, seal.size - 1] + [int(x) for x in rng.integers(0, seal.size, 12)]:
+        forged = inputs.copy()
+        forged[k] = (int(forged[k]) + 1) % P
+        with pytest.raises(RuntimeError, match="tie|inverse"):
+            rec.rec_witgen(blob, forged)
+    # the same seal under a program that expects another control root
+    other = V.build_lift(desc, cpo2, [(int(w) * RINV + 1) % P for w in croot])
+    with pytest.raises(RuntimeError, match="tie"):
+        rec.rec_witgen(other.finish(po2), inputs)
+
+
+def test_join_program_shape():
+    """join(18, 18) and join(19, 19) fit po2 19: the recursion closes on itself"""
+    desc = R.recursion_circuit()
+    for a, b in ((18, 18), (19, 19)):
+        pr = V.build_join(desc, a, b)
+        assert pr.min_po2() == 19
+        c = Circuit.parse(desc)
+        assert pr.n_inputs > 2 * (16 + 1 + 4 * (len(c.taps) + 16)) and pr.pub is not None
+
+
+def test_join_verifies_two_lifts_in_circuit(oracle, rec):
+    """the whole recursion on the CPU: two SYN-tiny segment seals, lifted (sealed by the oracle), joined - the join's witness
+    exists, satisfies every constraint of the po2-19 trace, and carries hash_pair of the two claims; it does not exist for a
+    child under another allowed root or with a membership path for another program"""
+    from zeth_amd import recursion as host_rec
+    desc = syn_air.syn_tiny()
+    child = zko.OracleCircuit(oracle, desc)
+    cpo2, czk = 8, 50
+    croot = child.control_root(cpo2, czk)
+    lift = V.build_lift(desc, cpo2, [int(w) * RINV % P for w in croot])
+    lpo2 = lift.min_po2()
+    lblob = lift.finish(lpo2)
+    join = V.build_join(R.recursion_circuit(), lpo2, lpo2)
+    jpo2 = join.min_po2()
+    jblob = join.finish(jpo2)
+    lcode, jcode = np.zeros(R.WC << lpo2, np.uint32), np.zeros(R.WC << jpo2, np.uint32)
+    assert oracle.zko_rec_code(lblob, lblob.size, lcode) is None and oracle.zko_rec_code(jblob, jblob.size, jcode) is None
+    levels = host_rec.allowed_tree([rec.root_of_code(lpo2, lcode), rec.root_of_code(jpo2, jcode)])
+    A = levels[-1][0]
+
+    def lifted(seed, allowed):
+        code, data, out = rec.rec_witgen(lblob, np.concatenate([child.prove(cpo2, czk, seed=seed), allowed]))
+        return rec.prove_traces(lpo2, code, data, out)
+    left, right = lifted(100, A), lifted(101, A)
+    path = host_rec.membership_words(levels, 0)
+    code, data, out = rec.rec_witgen(jblob, np.concatenate([left, path, right, path]))
+    assert np.array_equal(out[:8], host_rec.hash_pair(left[:8], right[:8])) and np.array_equal(out[8:], A)
+    assert rec.check_rows(jpo2, rec.rec_accum(jpo2, code, data, MIX), code, data, out, MIX) == -1
+    stranger = lifted(101, np.arange(8, dtype=np.uint32))                       # a valid lift, handed another allowed root
+    with pytest.raises(RuntimeError, match="tie"):
+        rec.rec_witgen(jblob, np.concatenate([left, path, stranger, path]))
+    with pytest.raises(RuntimeError, match="tie"):
+        rec.rec_witgen(jblob, np.concatenate([left, path, right, host_rec.membership_words(levels, 1)]))
