@@ -187,6 +187,10 @@ def main() -> None:
     ap.add_argument("--no-block", action="store_true", help="segment config: skip the short block leg (S distinct segments, witgen in the clock, all verified)")
     ap.add_argument("--block-segments", type=int, default=64, help="segment config: segments of the short block leg (the last one a po2-18 tail)")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC file instead of two rocprofv3 --pmc child runs")
+    ap.add_argument("--join-circuit", choices=("recursion", "p2_join"), default="recursion",
+                    help="succinct config: joins that verify both child seals in-circuit (lift + join programs of the RECURSION circuit), "
+                         "or round 3's P2-JOIN joins (claims hashed in-circuit, child seals checked by the host verifier)")
+    ap.add_argument("--no-recursive", action="store_true", help="segment config: skip the lift / join fold of the block leg's receipts")
     ap.add_argument("--no-succinct", action="store_true", help="segment config: skip the join tree over the block leg's receipts")
     ap.add_argument("--no-certify", action="store_true", help="segment config: do not verify the timed seals / compare with the golden digest after the clock")
     args = ap.parse_args()
@@ -347,6 +351,69 @@ def main() -> None:
         run_lanes(lanes, seal_leaves)
         device_sync(lanes)
         return receipts, t0, wit_s, seal_s
+
+    def recursive_prepare(lanes, leaf_roots, warm):
+        """build the lift / join programs (host) and load them on every lane (code groups committed, resident), one warm
+        lift + join per lane: before any clock, as upstream ships lift / join as precompiled .zkr programs"""
+        from zeth_amd import recursion as zrec
+        t_b = time.perf_counter()
+        programs = zrec.build_programs(desc, leaf_roots)
+        build_s = time.perf_counter() - t_b
+        t_b = time.perf_counter()
+        for ln in lanes:
+            ln.rec = zrec.Recursion(ln.hal, programs)
+            w = ln.rec.lift(warm, BENCH_NOISE)
+            ln.rec.join(w, w, BENCH_NOISE)
+            ln.hal.sync()
+        return {"program_build_s": build_s, "program_load_s_all_lanes": time.perf_counter() - t_b}
+
+    def recursive_fold(lanes, leaves):
+        """lift every segment receipt of `leaves` (in order), then join level by level down to ONE receipt - each join runs the
+        STARK verifier on both children INSIDE its circuit (zeth_amd/recursion.py).  Lifts and the joins of a level are
+        independent: a shared work index spreads them over the lanes.  -> (root receipt, stats)"""
+        lock = threading.Lock()
+
+        def spread(jobs):
+            """jobs: callables taking a lane -> results in order"""
+            out, pos = [None] * len(jobs), [0]
+
+            def work(ln):
+                try:
+                    while True:
+                        with lock:
+                            k = pos[0]
+                            if k >= len(jobs):
+                                return
+                            pos[0] = k + 1
+                        out[k] = jobs[k](ln)
+                except Exception as e:
+                    ln.err = e
+            run_lanes(lanes, work)
+            return out
+        device_sync(lanes)
+        t0 = time.perf_counter()
+        level = spread([(lambda ln, r=r: ln.rec.lift(r, BENCH_NOISE)) for r in leaves])
+        device_sync(lanes)
+        lift_s = time.perf_counter() - t0
+        n_joins = 0
+        while len(level) > 1:
+            nxt = spread([(lambda ln, a=level[2 * k], b=level[2 * k + 1]: ln.rec.join(a, b, BENCH_NOISE)) for k in range(len(level) // 2)])
+            n_joins += len(nxt)
+            if len(level) % 2:
+                nxt.append(level[-1])
+            level = nxt
+        device_sync(lanes)
+        total_s = time.perf_counter() - t0
+        rx = lanes[0].rec
+        stats = {"lifts": len(leaves), "joins": n_joins, "lift_phase_s": lift_s, "join_phase_s": total_s - lift_s, "fold_s": total_s,
+                 "lift_ms_each": 1e3 * lift_s / max(1, len(leaves)), "join_ms_each": 1e3 * (total_s - lift_s) / max(1, n_joins),
+                 "programs": [{"kind": "-".join(str(x) for x in k), "po2": p.po2, "permutations": p.n_p2, "gates": p.n_gates,
+                               "levels": p.n_levels, "witness_words": p.n_inputs} for k, p in zip(rx.kinds, rx.programs)],
+                 "root_receipt_words": int(level[0].seal.size),
+                 "note": "every lift runs the STARK verifier on its segment seal and every join on both child seals INSIDE the RECURSION "
+                         "circuit (Fiat-Shamir sponge, all Merkle openings, constraint check at z, DEEP, FRI of 50 queries); the root "
+                         "receipt is checked below with ONE seal verification + the claim tree of the leaves"}
+        return level[0], stats
 
     line = None
     # =====================================================================================================
@@ -664,6 +731,16 @@ def main() -> None:
                                      "root_receipt_words": int(nodes[0][0].seal.size), "compact_receipt_verified": True,
                                      "note": "P2-JOIN: parent claim = Poseidon2 hash_pair(children's claims) constrained in-circuit; the verifier "
                                              "needs the root receipt + the leaves only (`--config succinct` runs S = 1024)"}
+            if world == 1 and not args.no_recursive and S > 1:
+                prep = recursive_prepare(lanes, broots, brec[0])
+                rroot, rstats = recursive_fold(lanes, [brec[i] for i in range(S)])
+                rstats.update(prep)
+                t_v = time.perf_counter()
+                rroot.verify(lanes[0].rec.allowed_roots(), [receipt_claim(brec[i], desc, broots[bsegs[i].po2]) for i in range(S)])
+                rstats["root_verify_s"] = time.perf_counter() - t_v
+                rstats["root_verified_against_leaf_claims"] = True
+                rstats["block_plus_fold_s"] = block["wall_clock_s"] + rstats["fold_s"]
+                block["recursive"] = rstats
         last = next((ln.last for ln in lanes if ln.last is not None), None)
         if rank == 0:
             value = world * args.steps / dt
@@ -715,23 +792,47 @@ def main() -> None:
     else:
         S = args.segments or (256 if args.config == "block" else 1024)
         succinct = args.config == "succinct"
+        recursive = succinct and args.join_circuit == "recursion"
         segs = block_segments(S)
         mine = partition_round_robin(S, world, rank)
-        lanes = [Lane(with_join=succinct) for _ in range(inflight)]
+        if recursive and world > 1:
+            # every rank folds a contiguous, aligned power-of-two range of leaves: its local root is a node of the global join
+            # tree, and rank 0 joins the `world` local roots (the top log2(world) levels)
+            per = S // world
+            if S % world or per & (per - 1) or world & (world - 1):
+                raise SystemExit("bench: --join-circuit recursion on N ranks needs N and S / N to be powers of two")
+            mine = list(range(rank * per, (rank + 1) * per))
+        lanes = [Lane(with_join=succinct and not recursive) for _ in range(inflight)]
         # warm-up: one full-size seal per lane (clocks, pools, code objects), plus the control roots the verifier needs
         for ln in lanes:
             for _ in range(max(1, args.warmup)):
                 ln.prover.prove_segment(Segment(index=0, po2=args.po2, seed=1, noise_seed=BENCH_NOISE))
-            if succinct:
+            if succinct and not recursive:
                 ln.join_prover.prove_segment(Segment(index=0, po2=args.join_po2, seed=1, noise_seed=BENCH_NOISE,
                                                      pub=tuple([1] * 16)))
             ln.hal.sync()
         roots = {p: lanes[0].prover.control_root(p) for p in sorted({s.po2 for s in segs})}
-        join_root = lanes[0].join_prover.control_root(args.join_po2) if succinct else None
+        join_root = lanes[0].join_prover.control_root(args.join_po2) if succinct and not recursive else None
+        rstats = None
+        if recursive:
+            rstats = recursive_prepare(lanes, roots, lanes[0].prover.prove_segment(Segment(index=0, po2=args.po2, seed=1, noise_seed=BENCH_NOISE)))
         receipts, t0, wit_s, seal_s = seal_block(lanes, segs, mine)
         t_leaves = time.perf_counter() - t0
         joins_done, root = {}, None
-        if succinct:
+        if recursive:
+            local_root, st = recursive_fold(lanes, [receipts[i] for i in mine])
+            rstats.update(st)
+            tops = [local_root]
+            if distributed:
+                tops = [None] * world if rank == 0 else None
+                dist.gather_object(local_root, tops, dst=0)
+            if rank == 0:
+                t_top = time.perf_counter()
+                root = lanes[0].rec.fold(tops, BENCH_NOISE)
+                lanes[0].hal.sync()
+                rstats["top_joins"] = len(tops) - 1
+                rstats["top_joins_s"] = time.perf_counter() - t_top
+        elif succinct:
             # join tree: tasks of one level are independent -> spread over the lanes of this rank
             def claim_of(r, is_leaf):
                 return node_claim(r, desc if is_leaf else join_desc, roots[r.po2] if is_leaf else join_root, is_leaf)
@@ -811,6 +912,11 @@ def main() -> None:
         # succinct: what a holder of the COMPACT receipt (root + leaves, joins dropped) checks — the claim tree over the leaf
         # claims, recomputed on the host with hash_pair, must end in the root receipt's public output
         follows = None
+        if recursive and not args.no_verify and rank == 0:
+            t_rv = time.perf_counter()
+            root.verify(lanes[0].rec.allowed_roots())            # ONE seal; the claim tree is checked against the leaves below
+            rstats["root_verify_s"] = time.perf_counter() - t_rv
+            verified += 1
         if succinct and not args.no_verify:
             mine_claims = {i: receipt_claim(receipts[i], desc, roots[segs[i].po2]) for i in mine}
             parts = [mine_claims]
@@ -834,10 +940,12 @@ def main() -> None:
                 "vs_baseline": None, "dtype": "u32", "data": "synthetic",
                 "config": {"workload": (f"{'block + join tree to one succinct receipt' if succinct else 'one block'}: {S} distinct "
                                         f"2^{args.po2}-cycle segments (last one 2^{segs[-1].po2}), {workload}; witness generation inside the clock"
-                                        + (f"; {n_joins} P2-JOIN joins at po2 {args.join_po2} (parent claim = Poseidon2 hash_pair of the children's, proven in-circuit)" if succinct else "")),
+                                        + (f"; {S} lifts + {S - 1} joins of the RECURSION circuit: every node runs the STARK verifier on its child seal(s) in-circuit" if recursive else
+                                           f"; {n_joins} P2-JOIN joins at po2 {args.join_po2} (parent claim = Poseidon2 hash_pair of the children's, proven in-circuit)" if succinct else "")),
                            "po2": args.po2, "circuit": args.circuit, "segments": S,
                            "parallelism": f"segments round-robin over {world} GPU(s) + shared work index inside a rank, no data-path collective; "
-                                          f"{inflight} seal(s) in flight per GPU" + ("; joins on the rank of their left child, right child over gloo" if succinct else ""),
+                                          f"{inflight} seal(s) in flight per GPU" + ("; every rank folds its own aligned range of leaves, rank 0 joins the local roots (gathered over gloo)" if recursive else
+                                                                                     "; joins on the rank of their left child, right child over gloo" if succinct else ""),
                            "inflight_per_gpu": inflight, "library": HipHal.version(),
                            "poseidon2_consts": HipHal.version().split("poseidon2_consts=")[-1].rstrip(")")},
                 "block_wall_clock_s": dt, "leaf_phase_s": t_leaves, "join_phase_s": dt - t_leaves if succinct else None,
@@ -847,6 +955,11 @@ def main() -> None:
                 "root_receipt_words": int(root.seal.size) if root is not None else None,
                 "succinct_root_follows_from_leaf_claims": follows,
             }
+            if recursive:
+                line["recursion"] = rstats
+                line["config"]["join_circuit"] = "recursion (lift + join programs, in-circuit verification of every child seal)"
+            elif succinct:
+                line["config"]["join_circuit"] = "p2_join"
     if rank == 0 and line is not None:
         print(json.dumps(line))
     if distributed:

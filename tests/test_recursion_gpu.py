@@ -128,7 +128,8 @@ def test_block_of_segments_folds_to_one_receipt_that_verified_every_child_in_cir
     t_seg = time.time() - t0
     roots = {20: sp.control_root(20), 18: sp.control_root(18)}
     t0 = time.time()
-    rx = rec.Recursion(hal, desc, roots)
+    programs = rec.build_programs(desc, roots)
+    rx = rec.Recursion(hal, programs)
     t_load = time.time() - t0
     assert [k[0] for k in rx.kinds] == ["lift", "lift", "join", "join", "join", "join"]
     assert {p.po2 for p in rx.programs[:2]} == {18} and {p.po2 for p in rx.programs[2:]} == {19}

@@ -6,9 +6,10 @@ segments are sealed when `ProverOpts::succinct()` is in force (BASELINE.json con
 /root/reference/Cargo.lock:5418, :5305).  Here: the programs are built by circuits/rec_verify.py (this library's STARK verifier
 restated as a RECURSION program), loaded once per GPU lane (`hal.RecProgram`: code group resident), and run per receipt.
 
-    rec = Recursion(hal, segment_desc, segment_po2s=(20, 18))
+    programs = build_programs(segment_desc, {20: root20, 18: root18})      # host only; [(kind, blob)]
+    rec = Recursion(hal, programs)                                          # per GPU lane
     root = rec.fold([rec.lift(r) for r in segment_receipts])
-    root.verify(rec.allowed_root(), claims)          # host: one seal, one membership, one claim tree
+    root.verify(rec.allowed_roots(), claims)         # host: one seal, one membership, one claim tree
 
 A `RecReceipt` is a seal of the RECURSION circuit: out = claim (8 words) ‖ allowed-programs root A (8 words).
 """
@@ -82,40 +83,42 @@ class RecReceipt:
             raise _hal.HalError("recursion receipt: its claim is not the root of the leaves' claim tree")
 
 
+def build_programs(segment_desc, segment_roots: Dict[int, np.ndarray], zk_cycles: int = _hal.ZK_CYCLES) -> List[Tuple[Tuple, np.ndarray]]:
+    """The program set of a block: one lift per segment size (`segment_roots`: {po2: control root of the segment circuit}),
+    then joins for every pair of child sizes that can meet, until the set of sizes closes (po2-20 / po2-18 SYN-A segments: two
+    lifts at po2 18, join(18,18) -> 19, join(18,19), join(19,18), join(19,19) -> 19).  Pure host work, no GPU: [(kind, blob)]."""
+    segment_desc = np.asarray(segment_desc, dtype=np.uint32)
+    rdesc = rc.recursion_circuit()
+    out: List[Tuple[Tuple, np.ndarray]] = []
+    sizes = set()
+
+    def add(kind, pr):
+        po2 = pr.min_po2(zk_cycles)
+        out.append((kind, pr.finish(po2, zk_cycles)))
+        sizes.add(po2)
+    for po2, root in sorted(segment_roots.items(), reverse=True):
+        add(("lift", po2), rec_verify.build_lift(segment_desc, po2, [int(w) * RINV % P for w in np.asarray(root, dtype=np.uint32)]))
+    done = set()
+    while True:
+        todo = [(a, b) for a in sorted(sizes) for b in sorted(sizes) if (a, b) not in done]
+        if not todo:
+            break
+        for a, b in todo:
+            done.add((a, b))
+            add(("join", a, b), rec_verify.build_join(rdesc, a, b))
+    assert len(out) <= N_ALLOWED, f"{len(out)} programs do not fit the allowed set"
+    return out
+
+
 class Recursion:
-    """The lift / join programs of one GPU lane for segments of `segment_desc` at the po2s in `segment_po2s`."""
-    LIFT_PO2, JOIN_PO2 = 18, 19          # what the programs need for po2 <= 20 segments of SYN-A's width (Program.min_po2)
+    """The lift / join programs of one GPU lane (one HipHal): loaded once, code groups resident."""
 
-    def __init__(self, hal: "_hal.HipHal", segment_desc, segment_roots: Dict[int, np.ndarray], zk_cycles: int = _hal.ZK_CYCLES):
-        """segment_roots: {segment po2: control root of the segment circuit at that po2} - one lift program each."""
+    def __init__(self, hal: "_hal.HipHal", programs: Sequence[Tuple[Tuple, np.ndarray]]):
         self.hal = hal
-        self.zk = zk_cycles
-        self.segment_desc = np.asarray(segment_desc, dtype=np.uint32)
         self.circuit = hal.load_circuit(rc.recursion_circuit())
-        self.rdesc = rc.recursion_circuit()
-        self.programs: List[_hal.RecProgram] = []
-        self.kinds: List[Tuple] = []
-        for po2, root in sorted(segment_roots.items(), reverse=True):
-            pr = rec_verify.build_lift(self.segment_desc, po2, [int(w) * RINV % P for w in np.asarray(root, dtype=np.uint32)])
-            self._load(("lift", po2), pr)
-        # joins: every pair of child sizes that can meet (lifts and joins), until the set of sizes closes
-        sizes = sorted({p.po2 for p in self.programs})
-        done = set()
-        while True:
-            todo = [(a, b) for a in sizes for b in sizes if (a, b) not in done]
-            if not todo:
-                break
-            for a, b in todo:
-                done.add((a, b))
-                self._load(("join", a, b), rec_verify.build_join(self.rdesc, a, b))
-            sizes = sorted({p.po2 for p in self.programs})
-        assert len(self.programs) <= N_ALLOWED, f"{len(self.programs)} programs do not fit the allowed set"
+        self.kinds = [k for k, _ in programs]
+        self.programs = [_hal.RecProgram(hal, self.circuit, blob) for _, blob in programs]
         self.levels = allowed_tree([p.root for p in self.programs])
-
-    def _load(self, kind: Tuple, pr: rc.Program) -> None:
-        blob = pr.finish(pr.min_po2(self.zk), self.zk)
-        self.programs.append(_hal.RecProgram(self.hal, self.circuit, blob))
-        self.kinds.append(kind)
 
     def allowed_roots(self) -> List[np.ndarray]:
         return [p.root for p in self.programs]
