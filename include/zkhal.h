@@ -301,7 +301,7 @@ void zkh_rec_program_destroy(zkh_rec_program*);
 /* root: the program's control root (Merkle root of its code group); info: po2, zk_cycles, input words, permutations, gates,
  * witness ops, dependency levels, variables */
 const char* zkh_rec_program_info(const zkh_rec_program*, uint32_t root[8], uint32_t info[8]);
-const char* zkh_rec_code(const zkh_rec_program*, zkh_buf* code /* 55 x 2^po2 */);
+const char* zkh_rec_code(const zkh_rec_program*, zkh_buf* code /* 57 x 2^po2 */);
 const char* zkh_rec_witgen(const zkh_rec_program*, const uint32_t* inputs, size_t n_inputs, uint64_t noise_seed,
                            zkh_buf* data /* 72 x 2^po2 */, uint32_t out_global[16]);
 const char* zkh_rec_accum(const zkh_rec_program*, uint64_t noise_seed, const zkh_buf* data, const uint32_t* mix_global /* 20 */,

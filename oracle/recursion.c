@@ -15,11 +15,11 @@
 static inline fp4 ld4(const uint32_t* p) { fp4 r; memcpy(&r, p, 16); return r; }
 
 #define RC_T 24
-#define RC_BLOCK 31
+#define RC_BLOCK 12
 #define RC_NW 6
 #define RC_WD 72
 #define RC_WA 12
-#define RC_WC 55
+#define RC_WC 57
 #define RC_ROW_WORDS 13
 #define RC_MAGIC 0x5a4b5231u
 enum { RO_INPUT = 1, RO_GEN, RO_MUX, RO_PACK, RO_UNPACK, RO_INV, RO_BITS, RO_P2, RO_EQ, RO_ISZ };
@@ -45,7 +45,54 @@ static const char* rec_parse(const uint32_t* b, size_t words, rec_prog* p) {
     return NULL;
 }
 
-static int rc_is_full(unsigned rnd) { return rnd < 4 || rnd >= 25; }
+static void rc_m_ext(fp* c) {
+    static const unsigned M4[4][4] = {{5, 7, 1, 3}, {4, 6, 1, 1}, {1, 3, 5, 7}, {1, 1, 4, 6}};
+    fp y[RC_T], sums[4] = {0, 0, 0, 0};
+    for (int b = 0; b < RC_T; b += 4)
+        for (int i = 0; i < 4; i++) {
+            fp e = 0;
+            for (int j = 0; j < 4; j++) e = fp_add(e, fp_mul(fp_from_u32(M4[i][j]), c[b + j]));
+            y[b + i] = e;
+            sums[i] = fp_add(sums[i], e);
+        }
+    for (int k = 0; k < RC_T; k++) c[k] = fp_add(y[k], sums[k & 3]);
+}
+/* one permutation as the 12 rows of a block (zeth_amd/circuits/recursion.py block_rows): rows[k] = S[24] ‖ Q[24] */
+void zko_rec_p2_rows(const uint32_t in[RC_T], uint32_t rows[RC_BLOCK][2 * RC_T]) {
+    memset(rows, 0, sizeof(fp) * RC_BLOCK * 2 * RC_T);
+    fp s[RC_T];
+    memcpy(rows[0], in, sizeof s);
+    memcpy(s, in, sizeof s);
+    rc_m_ext(s);
+    unsigned rnd = 0, k = 1;
+    for (int half = 0; half < 2; half++) {
+        for (int f = 0; f < 4; f++, rnd++, k++) {
+            fp* row = rows[k];
+            memcpy(row, s, sizeof s);
+            for (int j = 0; j < RC_T; j++) {
+                fp u = fp_add(s[j], fp_from_u32(ZKH_P2_ROUND_CONSTANTS[rnd * RC_T + j]));
+                fp q = fp_mul(fp_mul(u, u), u);
+                row[RC_T + j] = q;
+                s[j] = fp_mul(fp_mul(q, q), u);
+            }
+            rc_m_ext(s);
+        }
+        if (half) break;
+        for (unsigned m = 12; m >= 9; m -= 3, k++) {
+            fp* row = rows[k];
+            memcpy(row, s, sizeof s);
+            for (unsigned i = 0; i < m; i++, rnd++) {
+                fp u = fp_add(s[0], fp_from_u32(ZKH_P2_ROUND_CONSTANTS[rnd * RC_T]));
+                fp q = fp_mul(fp_mul(u, u), u), x7 = fp_mul(fp_mul(q, q), u), tot = x7;
+                row[RC_T + 2 * i] = q; row[RC_T + 2 * i + 1] = x7;
+                for (int j = 1; j < RC_T; j++) tot = fp_add(tot, s[j]);
+                s[0] = fp_add(tot, fp_mul(fp_from_u32(ZKH_P2_M_INT_DIAG[0]), x7));
+                for (int j = 1; j < RC_T; j++) s[j] = fp_add(tot, fp_mul(fp_from_u32(ZKH_P2_M_INT_DIAG[j]), s[j]));
+            }
+        }
+    }
+    memcpy(rows[RC_BLOCK - 1], s, sizeof s);
+}
 
 /* the code group: a function of the program alone (its Merkle root is the program's control root) */
 const char* zko_rec_code(const uint32_t* blob, size_t words, uint32_t* code) {
@@ -73,15 +120,18 @@ const char* zko_rec_code(const uint32_t* blob, size_t words, uint32_t* code) {
         code[25 * n + r] = (fl & RG_PUB) ? one : 0;
         if (r >= RC_BLOCK * K) continue;
         const unsigned k = (unsigned)(r % RC_BLOCK);
-        const int round_row = k >= 1 && k <= 29, full = round_row && rc_is_full(k - 1), part = round_row && !rc_is_full(k - 1);
+        const int full = (k >= 1 && k <= 4) || (k >= 7 && k <= 10);
+        const unsigned rnd = k <= 4 ? k - 1 : k == 5 ? 4 : k == 6 ? 16 : k + 18;      /* first round this row performs (k = 7: 25) */
         code[24 * n + r] = (k == 0 || k == RC_BLOCK - 1) ? one : 0;
         code[26 * n + r] = k == 1 ? one : 0;
         code[27 * n + r] = full ? one : 0;
-        code[28 * n + r] = part ? one : 0;
-        code[29 * n + r] = (k >= 2 && rc_is_full(k - 2)) ? one : 0;
-        code[30 * n + r] = (k >= 2 && !rc_is_full(k - 2)) ? one : 0;
-        if (full) for (int j = 0; j < RC_T; j++) code[(31 + j) * n + r] = fp_from_u32(ZKH_P2_ROUND_CONSTANTS[(k - 1) * RC_T + j]);
-        if (part) code[31 * n + r] = fp_from_u32(ZKH_P2_ROUND_CONSTANTS[(k - 1) * RC_T]);
+        code[28 * n + r] = k == 5 ? one : 0;
+        code[29 * n + r] = k == 6 ? one : 0;
+        code[30 * n + r] = ((k >= 2 && k <= 5) || (k >= 8 && k <= 11)) ? one : 0;      /* the previous row did a full round */
+        code[31 * n + r] = k == 6 ? one : 0;                                            /* ... the twelve partial rounds */
+        code[32 * n + r] = k == 7 ? one : 0;                                            /* ... the nine partial rounds */
+        if (full) for (int j = 0; j < RC_T; j++) code[(33 + j) * n + r] = fp_from_u32(ZKH_P2_ROUND_CONSTANTS[rnd * RC_T + j]);
+        if (k == 5 || k == 6) for (unsigned i = 0; i < (k == 5 ? 12u : 9u); i++) code[(33 + i) * n + r] = fp_from_u32(ZKH_P2_ROUND_CONSTANTS[(rnd + i) * RC_T]);
     }
     return NULL;
 }
@@ -182,7 +232,7 @@ const char* zko_rec_witgen(const uint32_t* blob, size_t words, const uint32_t* i
                 fp in[RC_T];
                 const size_t r0 = RC_BLOCK * b;
                 for (int j = 0; j < RC_T; j++) in[j] = data[(size_t)j * n + r0];
-                zko_p2_rows(in, rows);
+                zko_rec_p2_rows(in, rows);
                 for (size_t k = 0; k < RC_BLOCK; k++)
                     for (size_t col = 0; col < 2 * RC_T; col++) data[(RC_T + col) * n + r0 + k] = rows[k][col];
                 for (int j = 0; j < RC_T; j++) data[(size_t)j * n + r0 + RC_BLOCK - 1] = rows[RC_BLOCK - 1][j];

@@ -156,6 +156,8 @@ long zko_check_rows(const zko_circuit*, unsigned po2, const uint32_t* const* gro
                     size_t row_hi);
 /* one Poseidon2 permutation as the 31 trace rows of P2-JOIN / RECURSION: rows[k] = S[24] ‖ Q[24] */
 void zko_p2_rows(const uint32_t in[24], uint32_t rows[31][48]);
+/* ... and as the 12 rows of a RECURSION block (rows 5 and 6 hold twelve and nine partial rounds) */
+void zko_rec_p2_rows(const uint32_t in[24], uint32_t rows[12][48]);
 
 /* Merkle root of the committed code group for (circuit, po2, zk_cycles): the control-ID analogue */
 void zko_control_root(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint32_t root[8]);

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import zko
-from zeth_amd.circuits import rec_verify as V, recursion as R, syn_air
+from zeth_amd.circuits import p2_join, rec_verify as V, recursion as R, syn_air
 from zeth_amd.circuits.desc import Circuit, P
 
 RM = (1 << 32) % P
@@ -42,7 +42,7 @@ def rec(oracle):
 
 def test_circuit_shape():
     c = Circuit.parse(R.recursion_circuit())
-    assert c.kind == 4 and c.group_sizes == (R.WA, R.WC, R.WD) == (12, 55, 72) and c.global_sizes == (16, 20)
+    assert c.kind == 4 and c.group_sizes == (R.WA, R.WC, R.WD) == (12, 57, 72) and c.global_sizes == (16, 20)
     assert max(b for _, _, b in c.taps) == 1                       # only the previous row is ever read
 
 
@@ -50,7 +50,7 @@ def test_program_semantics_trace_and_seal(rec):
     pr, (h0, h1, pk) = small_program()
     zk = 50
     po2 = pr.min_po2(zk)
-    assert po2 == 7
+    assert po2 == 7 and R.block_rows(list(range(24)))[-1][0] == p2_join.permute(list(range(24)))
     blob = pr.finish(po2, zk)
     words = [5, 6, 7, 8, 11, 12, 13, 14]
     vals = R.run_program(pr, words)
@@ -94,8 +94,8 @@ def test_every_kind_of_gate_and_the_copy_argument_bind_the_trace(rec):
         assert rows.size, name
         assert broken(4 * wire + 1, int(rows[0])) >= 0, name
     # the copy argument alone: a wire nobody's gate reads, but which shares a variable with another position
-    r_in = 31                                                       # input row of the second permutation: its wire a is h[0]
-    assert broken(0, r_in) >= 0 and broken(R.D_S + 5, 3) >= 0 and broken(R.D_Q + 2, 33) >= 0
+    r_in = R.BLOCK                                                  # input row of the second permutation: its wire a is h[0]
+    assert broken(0, r_in) >= 0 and broken(R.D_S + 5, 3) >= 0 and broken(R.D_Q + 2, R.BLOCK + 2) >= 0 and broken(R.D_Q + 5, 5) >= 0 and broken(R.D_Q + 17, R.BLOCK + 6) >= 0
     # the out globals are bound to the PUB row
     o2 = out.copy()
     o2[3] = (int(o2[3]) + 1) % P
@@ -167,18 +167,19 @@ def test_lift_runs_the_verifier_in_circuit(oracle, rec, cpo2):
 
 
 def test_join_program_shape():
-    """join(18, 18) and join(19, 19) fit po2 19: the recursion closes on itself"""
+    """lifts of po2-20 segments fit po2 17, join(17, 17) and join(18, 18) fit po2 18: the recursion closes on itself"""
     desc = R.recursion_circuit()
-    for a, b in ((18, 18), (19, 19)):
+    assert V.build_lift(syn_air.syn_a(), 20, list(range(8))).min_po2() == 17
+    for a, b in ((17, 17), (18, 18)):
         pr = V.build_join(desc, a, b)
-        assert pr.min_po2() == 19
+        assert pr.min_po2() == 18
         c = Circuit.parse(desc)
         assert pr.n_inputs > 2 * (16 + 1 + 4 * (len(c.taps) + 16)) and pr.pub is not None
 
 
 def test_join_verifies_two_lifts_in_circuit(oracle, rec):
     """the whole recursion on the CPU: two SYN-tiny segment seals, lifted (sealed by the oracle), joined - the join's witness
-    exists, satisfies every constraint of the po2-19 trace, and carries hash_pair of the two claims; it does not exist for a
+    exists, satisfies every constraint of its trace, and carries hash_pair of the two claims; it does not exist for a
     child under another allowed root or with a membership path for another program"""
     from zeth_amd import recursion as host_rec
     desc = syn_air.syn_tiny()

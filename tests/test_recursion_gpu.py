@@ -132,7 +132,7 @@ def test_block_of_segments_folds_to_one_receipt_that_verified_every_child_in_cir
     rx = rec.Recursion(hal, programs)
     t_load = time.time() - t0
     assert [k[0] for k in rx.kinds] == ["lift", "lift", "join", "join", "join", "join"]
-    assert {p.po2 for p in rx.programs[:2]} == {18} and {p.po2 for p in rx.programs[2:]} == {19}
+    assert {p.po2 for p in rx.programs[:2]} == {17} and {p.po2 for p in rx.programs[2:]} == {18}
     hal.sync()
     t0 = time.time()
     lifted = [rx.lift(r, noise_seed=7) for r in leaves]
@@ -145,7 +145,7 @@ def test_block_of_segments_folds_to_one_receipt_that_verified_every_child_in_cir
     claims = [HostCircuit(desc).receipt_claim(r.seal, roots[r.po2]) for r in leaves]
     for l, c in zip(lifted, claims):
         assert np.array_equal(l.claim, c) and np.array_equal(l.allowed, rx.allowed_root())
-    assert root.n_leaves == 5 and root.po2 == 19
+    assert root.n_leaves == 5 and root.po2 == 18
     root.verify(rx.allowed_roots(), claims)                         # ONE seal + the claim tree: nothing else is needed
     with pytest.raises(HalError, match="claim tree"):
         root.verify(rx.allowed_roots(), claims[::-1])
@@ -160,7 +160,7 @@ def test_block_of_segments_folds_to_one_receipt_that_verified_every_child_in_cir
     inputs = np.concatenate([leaves[0].seal, np.arange(8, dtype=np.uint32)])
     stranger, _ = rx.programs[0].prove(inputs, 3)                    # a valid lift, but under A' != A
     with pytest.raises(HalError, match="assertion of the program fails"):
-        rx.join(lifted[0], rec.RecReceipt(stranger, 18, 0, rx.programs[0].root))
+        rx.join(lifted[0], rec.RecReceipt(stranger, 17, 0, rx.programs[0].root))
     wrong = rec.RecReceipt(lifted[1].seal, lifted[1].po2, 2, lifted[1].control_root)     # membership path of another program
     with pytest.raises(HalError, match="assertion of the program fails"):
         rx.join(lifted[0], wrong)

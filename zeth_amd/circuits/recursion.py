@@ -13,9 +13,12 @@ and `join` are programs that run the STARK verifier on one / two child seals.  T
         EMB    a, b, c, e are base-field elements (components 1..3 zero)
         PACKj  d = (a_j, b_j, c_j, e_j)                            (4 x 4 transposes: hash words <-> Fp4 values)
         PUB    (a b c d) = the 16 output globals
-  * every 31 rows are one Poseidon2 permutation laid out round by round exactly as in P2-JOIN (p2_join.py): S[24], Q[24];
-    its input row binds S to the row's six wires, its output row binds the wires to S.  The gates of the 29 rows between
-    are free for arithmetic, so hashing and arithmetic run side by side;
+  * every 12 rows are one Poseidon2 permutation: S[24], Q[24].  Row 0 holds the input state (bound to the row's six wires),
+    rows 1..4 and 7..10 one FULL round each (Q_j = (S_j + rc_j)^3, as in P2-JOIN), rows 5 and 6 TWELVE and NINE partial rounds:
+    a partial round touches one s-box, so its row stores (Q_i, X_i) = ((u_i)^3, (u_i)^7) per round in the Q columns and every
+    later state cell is a LINEAR form of (S, X_1 .. X_i) with constant coefficients (the powers of the internal matrix);
+    row 11 holds the output (bound to the wires).  All constraints have degree <= 3 (+ selector).  The gates of the 10 rows
+    between input and output are free for arithmetic, so hashing and arithmetic run side by side;
   * equal wires are tied by a PLONK-style COPY argument in the accum group: position (row, wire) has the id 6 row + wire,
     the code columns sigma_w hold the id of the next position of the same variable, and three running products
         Z_k(row) = Z_k(row - 1) * prod_{w in {2k, 2k+1}} F(id_w, W_w) / F(sigma_w, W_w),
@@ -24,9 +27,9 @@ and `join` are programs that run the STARK verifier on one / two child seals.  T
 The program (gate coefficients, sigma) is the code group, hence the control root identifies the program, as upstream.
 rec_verify.py compiles this repository's verifier (csrc/verifier.hip = risc0-zkp src/verify/mod.rs) into such programs.
 
-Columns:  data 72 = W[6][4] | S[24] | Q[24];  accum 12 = Z[3][4];  code 55:
+Columns:  data 72 = W[6][4] | S[24] | Q[24];  accum 12 = Z[3][4];  code 57:
    0 active 1 first 2 body 3 last   4 rowid   5..10 sigma[6]   11 qM 12 qA 13 qB 14 qC 15 qD 16 qK
-   17 qMux 18 qBool 19 qEmb 20..23 qP[4]   24 pio 25 pub   26 lin 27 fullr 28 partr 29 lf 30 lp   31..54 rc[24]
+   17 qMux 18 qBool 19 qEmb 20..23 qP[4]   24 pio 25 pub   26 lin 27 fullr 28 partA 29 partB 30 lf 31 lpA 32 lpB   33..56 rc[24]
 Globals: out = 16 words (program-defined: rec_verify puts claim (8) ‖ allowed-programs root (8));  mix = 20 words.
 """
 from __future__ import annotations
@@ -40,16 +43,68 @@ from . import p2_join
 from .desc import GLOBAL_MIX, GLOBAL_OUT, GROUP_ACCUM, GROUP_CODE, GROUP_DATA, P, CircuitBuilder
 
 KIND_RECURSION = 4
-T, BLOCK, NW = 24, 31, 6
-WD, WA, WC, OUT_WORDS, MIX_WORDS = 72, 12, 55, 16, 20
+T, BLOCK, NW = 24, 12, 6
+WD, WA, WC, OUT_WORDS, MIX_WORDS = 72, 12, 57, 16, 20
+PART_A, PART_B = 12, 9                 # partial rounds held by rows 5 and 6 of a block (rounds 4..15, 16..24)
 C_ACTIVE, C_FIRST, C_BODY, C_LAST, C_ROWID, C_SIGMA = 0, 1, 2, 3, 4, 5
 C_QM, C_QA, C_QB, C_QC, C_QD, C_QK = 11, 12, 13, 14, 15, 16
 C_MUX, C_BOOL, C_EMB, C_PACK, C_PIO, C_PUB = 17, 18, 19, 20, 24, 25
-C_LIN, C_FULLR, C_PARTR, C_LF, C_LP, C_RC = 26, 27, 28, 29, 30, 31
+C_LIN, C_FULLR, C_PARTA, C_PARTB, C_LF, C_LPA, C_LPB, C_RC = 26, 27, 28, 29, 30, 31, 32, 33
 D_S, D_Q = 24, 48
 NBETA = P - 11
 M4, DIAG, RC = p2_join.M4, p2_join.DIAG, p2_join.RC
 ZK_CYCLES = 1994
+
+
+def partial_forms(m: int):
+    """m consecutive partial rounds as linear algebra: with X_i = (s0 + rc_i)^7 of round i taken as a variable, every state
+    cell is a linear form over (S_0..S_23, X_1..X_m) with constant coefficients.  -> {'s0': [form of cell 0 BEFORE round i
+    (without rc)], 'out': [forms of the 24 cells after round m]}, a form = list of 24 + m canonical coefficients."""
+    nv = T + m
+    f = [[1 if v == j else 0 for v in range(nv)] for j in range(T)]
+    s0 = []
+    for i in range(m):
+        s0.append(list(f[0]))
+        x = [1 if v == T + i else 0 for v in range(nv)]
+        tot = [(x[v] + sum(f[j][v] for j in range(1, T))) % P for v in range(nv)]
+        f = [[(tot[v] + DIAG[0] * x[v]) % P for v in range(nv)]] + [[(tot[v] + DIAG[j] * f[j][v]) % P for v in range(nv)] for j in range(1, T)]
+    return {"s0": s0, "out": f}
+
+
+def block_rows(inp):
+    """One permutation as the 12 trace rows of a block, over canonical residues: [(S[24], Q[24])].  The plain-Python statement
+    of what oracle/recursion.c and csrc/recursion.hip write; rows[11][0] is the output."""
+    rows = [([x % P for x in inp], [0] * T)]
+    s = p2_join.m_ext(rows[0][0])
+    rnd = 0
+
+    def full(s, rnd):
+        rc = RC[rnd * T:(rnd + 1) * T]
+        q = [pow((s[i] + rc[i]) % P, 3, P) for i in range(T)]
+        return q, p2_join.m_ext([q[i] * q[i] % P * ((s[i] + rc[i]) % P) % P for i in range(T)])
+    for _ in range(4):
+        q, nxt = full(s, rnd)
+        rows.append((s, q))
+        s, rnd = nxt, rnd + 1
+    for m in (PART_A, PART_B):
+        q = [0] * T
+        s_in = s
+        for i in range(m):
+            u = (s[0] + RC[rnd * T]) % P
+            q[2 * i] = pow(u, 3, P)
+            x7 = q[2 * i] * q[2 * i] % P * u % P
+            q[2 * i + 1] = x7
+            tot = (x7 + sum(s[1:])) % P
+            s = [(tot + DIAG[0] * x7) % P] + [(tot + DIAG[j] * s[j]) % P for j in range(1, T)]
+            rnd += 1
+        rows.append((s_in, q))
+    for _ in range(4):
+        q, nxt = full(s, rnd)
+        rows.append((s, q))
+        s, rnd = nxt, rnd + 1
+    rows.append((s, [0] * T))
+    assert rnd == 29 and len(rows) == BLOCK
+    return rows
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -120,17 +175,32 @@ def build_recursion() -> np.ndarray:
     u = [b.add(S(j), code(C_RC + j)) for j in range(T)]
     cube = lambda x: b.mul(b.mul(x, x), x)
     chain = gated(chain, code(C_FULLR), [b.sub(Q(j), cube(u[j])) for j in range(T)])
-    chain = gated(chain, code(C_PARTR), [b.sub(Q(0), cube(u[0]))])
     prev = [S(j, 1) for j in range(T)]
     chain = gated(chain, code(C_LIN), [b.sub(S(k), e) for k, e in enumerate(lin_m_ext(prev))])
     x7 = [b.mul(b.mul(Q(j, 1), Q(j, 1)), b.add(S(j, 1), code(C_RC + j, 1))) for j in range(T)]
     chain = gated(chain, code(C_LF), [b.sub(S(k), e) for k, e in enumerate(lin_m_ext(x7))])
-    tot = x7[0]
-    for j in range(1, T):
-        tot = b.add(tot, prev[j])
-    diag = [b.const(d) for d in DIAG]
-    chain = gated(chain, code(C_LP), [b.sub(S(0), b.add(tot, b.mul(diag[0], x7[0])))]
-                  + [b.sub(S(j), b.add(tot, b.mul(diag[j], prev[j]))) for j in range(1, T)])
+    # partial rows: m rounds, (Q_i, X_i) in Q columns 2i, 2i + 1; states as linear forms over (S[24], X_1 .. X_m)
+    for m, sel_here, sel_next in ((PART_A, C_PARTA, C_LPA), (PART_B, C_PARTB, C_LPB)):
+        forms = partial_forms(m)
+        for back, sel in ((0, sel_here), (1, sel_next)):
+            var = [S(j, back) for j in range(T)] + [Q(2 * i + 1, back) for i in range(m)]
+
+            def lin_form(coeffs):
+                e = None
+                for v, cf in zip(var, coeffs):
+                    if cf:
+                        t = v if cf == 1 else b.mul(b.const(cf), v)
+                        e = t if e is None else b.add(e, t)
+                return e if e is not None else b.const(0)
+            if back == 0:
+                cons = []
+                for i in range(m):
+                    ui = b.add(lin_form(forms["s0"][i]), code(C_RC + i))
+                    qi, xi = Q(2 * i), Q(2 * i + 1)
+                    cons += [b.sub(qi, cube(ui)), b.sub(xi, b.mul(b.mul(qi, qi), ui))]
+                chain = gated(chain, code(sel), cons)
+            else:
+                chain = gated(chain, code(sel), [b.sub(S(j), lin_form(forms["out"][j])) for j in range(T)])
     # the copy argument
     beta = [[mixg(4 * i + c) for c in range(4)] for i in range(4)]
     gamma = [mixg(16 + c) for c in range(4)]

@@ -28,7 +28,7 @@ const char* prefix_products_batched(zkh_ctx* c, uint32_t* io, size_t n0, size_t 
 
 namespace {
 
-constexpr uint32_t RC_T = 24, RC_BLOCK = 31, RC_NW = 6, RC_WD = 72, RC_WA = 12, RC_WC = 55, RC_ROW = 13, RC_ROUNDS = 29;
+constexpr uint32_t RC_T = 24, RC_BLOCK = 12, RC_NW = 6, RC_WD = 72, RC_WA = 12, RC_WC = 57, RC_ROW = 13, RC_ROUNDS = 29;
 constexpr uint32_t RC_MAGIC = 0x5a4b5231u, RC_HEADER = 16, RC_OP_WORDS = 8;
 enum : uint32_t { RO_INPUT = 1, RO_GEN, RO_MUX, RO_PACK, RO_UNPACK, RO_INV, RO_BITS, RO_P2, RO_EQ, RO_ISZ };
 enum : uint32_t { RG_MUX = 1, RG_BOOL = 2, RG_EMB = 4, RG_PACK0 = 8, RG_PUB = 128 };
@@ -155,8 +155,9 @@ __device__ void rc_m_ext(uint32_t (&c)[RC_T]) {
     }
     for (uint32_t k = 0; k < RC_T; k++) c[k] = add_mod(c[k], sums[k & 3]);
 }
-// one lane per 31-row block: the permutation of the block's input row, round by round (S, Q), and the output row's wires;
-// tab = Montgomery words of rc[24 * 29] then diag[24]
+// one lane per 12-row block: the permutation of the block's input row (zeth_amd/circuits/recursion.py block_rows): rows 1..4 and
+// 7..10 one full round each (S, Q = cubes), rows 5 / 6 twelve / nine partial rounds ((Q_i, X_i) pairs in the Q columns), row 11
+// the output and the output row's wires; tab = Montgomery words of rc[24 * 29] then diag[24]
 __global__ void k_rec_blocks(uint32_t* data, uint32_t n, uint32_t K, const uint32_t* __restrict__ tab) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= K) return;
@@ -167,31 +168,35 @@ __global__ void k_rec_blocks(uint32_t* data, uint32_t n, uint32_t K, const uint3
     for (uint32_t j = 0; j < RC_T; j++) { s[j] = data[(size_t)j * n + r0]; S[(size_t)j * n + r0] = s[j]; Q[(size_t)j * n + r0] = 0; }
     rc_m_ext(s);
     const uint32_t* diag = tab + RC_T * RC_ROUNDS;
-    for (uint32_t rnd = 0; rnd < RC_ROUNDS; rnd++) {
-        const size_t r = r0 + 1 + rnd;
-        for (uint32_t j = 0; j < RC_T; j++) S[(size_t)j * n + r] = s[j];
-        if (rc_is_full(rnd)) {
+    uint32_t rnd = 0;
+    size_t r = r0 + 1;
+    for (uint32_t half = 0; half < 2; half++) {
+        for (uint32_t f = 0; f < 4; f++, rnd++, r++) {
             for (uint32_t j = 0; j < RC_T; j++) {
+                S[(size_t)j * n + r] = s[j];
                 const uint32_t u = add_mod(s[j], tab[rnd * RC_T + j]);
                 const uint32_t q = mul_mod(mul_mod(u, u), u);
                 Q[(size_t)j * n + r] = q;
                 s[j] = mul_mod(mul_mod(q, q), u);
             }
             rc_m_ext(s);
-        } else {
-            const uint32_t u = add_mod(s[0], tab[rnd * RC_T]);
-            const uint32_t q = mul_mod(mul_mod(u, u), u);
-            Q[r] = q;
-            for (uint32_t j = 1; j < RC_T; j++) Q[(size_t)j * n + r] = 0;
-            const uint32_t x7 = mul_mod(mul_mod(q, q), u);
-            uint32_t tot = x7;
-            for (uint32_t j = 1; j < RC_T; j++) tot = add_mod(tot, s[j]);
-            s[0] = add_mod(tot, mul_mod(diag[0], x7));
-            for (uint32_t j = 1; j < RC_T; j++) s[j] = add_mod(tot, mul_mod(diag[j], s[j]));
+        }
+        if (half) break;
+        for (uint32_t m = 12; m >= 9; m -= 3, r++) {
+            for (uint32_t j = 0; j < RC_T; j++) S[(size_t)j * n + r] = s[j];
+            for (uint32_t i = 0; i < m; i++, rnd++) {
+                const uint32_t u = add_mod(s[0], tab[rnd * RC_T]);
+                const uint32_t q = mul_mod(mul_mod(u, u), u), x7 = mul_mod(mul_mod(q, q), u);
+                Q[(size_t)(2 * i) * n + r] = q; Q[(size_t)(2 * i + 1) * n + r] = x7;
+                uint32_t tot = x7;
+                for (uint32_t j = 1; j < RC_T; j++) tot = add_mod(tot, s[j]);
+                s[0] = add_mod(tot, mul_mod(diag[0], x7));
+                for (uint32_t j = 1; j < RC_T; j++) s[j] = add_mod(tot, mul_mod(diag[j], s[j]));
+            }
+            for (uint32_t j = 2 * m; j < RC_T; j++) Q[(size_t)j * n + r] = 0;
         }
     }
-    const size_t rl = r0 + RC_BLOCK - 1;
-    for (uint32_t j = 0; j < RC_T; j++) { S[(size_t)j * n + rl] = s[j]; Q[(size_t)j * n + rl] = 0; data[(size_t)j * n + rl] = s[j]; }
+    for (uint32_t j = 0; j < RC_T; j++) { S[(size_t)j * n + r] = s[j]; Q[(size_t)j * n + r] = 0; data[(size_t)j * n + r] = s[j]; }
 }
 // the code group: one lane per (row, column)
 __global__ void k_rec_code(uint32_t* code, const uint32_t* __restrict__ table, uint32_t n, uint32_t A, uint32_t K, const uint32_t* __restrict__ tab) {
@@ -202,8 +207,8 @@ __global__ void k_rec_code(uint32_t* code, const uint32_t* __restrict__ table, u
         const uint32_t* row = table + (size_t)r * RC_ROW;
         const bool in_blocks = r < RC_BLOCK * K;
         const uint32_t k = r % RC_BLOCK;
-        const bool round_row = in_blocks && k >= 1 && k <= RC_ROUNDS;
-        const bool full = round_row && rc_is_full(k - 1), part = round_row && !rc_is_full(k - 1);
+        const bool full = in_blocks && ((k >= 1 && k <= 4) || (k >= 7 && k <= 10));
+        const uint32_t rnd = k <= 4 ? k - 1 : k == 5 ? 4 : k == 6 ? 16 : k + 18;         // first round this row performs
         if (col == 0) v = R1;
         else if (col == 1) v = r == 0 ? R1 : 0;
         else if (col == 2) v = r > 0 ? R1 : 0;
@@ -217,12 +222,16 @@ __global__ void k_rec_code(uint32_t* code, const uint32_t* __restrict__ table, u
         else if (col < 24) v = (row[6] & (RG_PACK0 << (col - 20))) ? R1 : 0;
         else if (col == 24) v = (in_blocks && (k == 0 || k == RC_BLOCK - 1)) ? R1 : 0;
         else if (col == 25) v = (row[6] & RG_PUB) ? R1 : 0;
-        else if (col == 26) v = (in_blocks && k == 1) ? R1 : 0;
+        else if (!in_blocks) v = 0;
+        else if (col == 26) v = k == 1 ? R1 : 0;
         else if (col == 27) v = full ? R1 : 0;
-        else if (col == 28) v = part ? R1 : 0;
-        else if (col == 29) v = (in_blocks && k >= 2 && rc_is_full(k - 2)) ? R1 : 0;
-        else if (col == 30) v = (in_blocks && k >= 2 && !rc_is_full(k - 2)) ? R1 : 0;
-        else if (full || (part && col == 31)) v = tab[(k - 1) * RC_T + (col - 31)];
+        else if (col == 28) v = k == 5 ? R1 : 0;
+        else if (col == 29) v = k == 6 ? R1 : 0;
+        else if (col == 30) v = ((k >= 2 && k <= 5) || (k >= 8 && k <= 11)) ? R1 : 0;
+        else if (col == 31) v = k == 6 ? R1 : 0;
+        else if (col == 32) v = k == 7 ? R1 : 0;
+        else if (full) v = tab[rnd * RC_T + (col - 33)];
+        else if ((k == 5 && col - 33 < 12) || (k == 6 && col - 33 < 9)) v = tab[(rnd + (col - 33)) * RC_T];
     }
     code[(size_t)col * n + r] = v;
 }
@@ -290,7 +299,7 @@ extern "C" void zkh_rec_program_destroy(zkh_rec_program* p) {
 static const char* rec_check_shape(const zkh_circuit* c) {
     ZKH_REQUIRE(c && c->kind == 4 && c->group_size[GROUP_CODE] == RC_WC && c->group_size[GROUP_DATA] == RC_WD && c->group_size[GROUP_ACCUM] == RC_WA &&
                 c->global_size[GLOBAL_OUT] == 16 && c->global_size[GLOBAL_MIX] == 20,
-                "recursion: the circuit does not have RECURSION's shape (kind 4: 55 / 72 / 12 columns, 16 outputs, 20 mix words)");
+                "recursion: the circuit does not have RECURSION's shape (kind 4: 57 / 72 / 12 columns, 16 outputs, 20 mix words)");
     return nullptr;
 }
 

@@ -347,7 +347,8 @@ class RecProgram:
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
-        if h and _lib is not None:
+        # a program holds device buffers and a prover (the resident code group): only released into a live context
+        if h and _lib is not None and getattr(self.hal, "ctx", None):
             _lib.zkh_rec_program_destroy(h)
 
     def code(self, code: Buffer) -> None:

@@ -86,7 +86,7 @@ class RecReceipt:
 def build_programs(segment_desc, segment_roots: Dict[int, np.ndarray], zk_cycles: int = _hal.ZK_CYCLES) -> List[Tuple[Tuple, np.ndarray]]:
     """The program set of a block: one lift per segment size (`segment_roots`: {po2: control root of the segment circuit}),
     then joins for every pair of child sizes that can meet, until the set of sizes closes (po2-20 / po2-18 SYN-A segments: two
-    lifts at po2 18, join(18,18) -> 19, join(18,19), join(19,18), join(19,19) -> 19).  Pure host work, no GPU: [(kind, blob)]."""
+    lifts at po2 17, join(17,17) -> 18, join(17,18), join(18,17), join(18,18) -> 18).  Pure host work, no GPU: [(kind, blob)]."""
     segment_desc = np.asarray(segment_desc, dtype=np.uint32)
     rdesc = rc.recursion_circuit()
     out: List[Tuple[Tuple, np.ndarray]] = []
