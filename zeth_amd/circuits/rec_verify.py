@@ -12,7 +12,7 @@ FRI fold of all 50 queries run INSIDE the circuit, on a child seal that enters a
 
 `A` is the Merkle root of the control roots of the allowed programs (upstream: the control-id allow list): a program cannot
 contain its own root, so membership is proven against a public root that every level hands down and the final verifier
-checks (host.py RecursiveReceipt).  claim(segment) is csrc/verifier.hip zkh_receipt_claim: Poseidon2 over (out globals, po2,
+checks (zeth_amd/recursion.py RecReceipt.verify).  claim(segment) is csrc/verifier.hip zkh_receipt_claim: Poseidon2 over (out globals, po2,
 control root).
 """
 from __future__ import annotations
@@ -442,3 +442,23 @@ def build_join(recursion_desc: np.ndarray, po2_left: int, po2_right: int) -> Pro
     parent = v.pair(claims[0], claims[1])
     pr.public(parent[0], parent[1], allowed[0], allowed[1])
     return pr
+
+
+if __name__ == "__main__":      # python -m zeth_amd.circuits.rec_verify out_dir [segment.desc po2:root_hex8 ...]
+    # writes the program set of a block (zeth_amd/recursion.py build_programs) as u32 blobs for non-Python hosts; without a
+    # segment description: SYN-A at po2 20 and 18 with the control roots shipped in circuits/control_roots.json
+    import os
+    import sys
+    from . import syn_air
+    from .. import recursion as host_rec
+    from ..prover import shipped_control_root
+    out_dir = sys.argv[1]
+    os.makedirs(out_dir, exist_ok=True)
+    desc = syn_air.syn_a()
+    roots = {po2: shipped_control_root(desc, po2) for po2 in (20, 18)}
+    if any(r is None for r in roots.values()):
+        raise SystemExit("no shipped control root for SYN-A at po2 20 / 18 (python -m zeth_amd.prover on a GPU box)")
+    for kind, blob in host_rec.build_programs(desc, roots):
+        path = os.path.join(out_dir, "-".join(str(x) for x in kind) + ".zkr1")
+        np.asarray(blob, dtype="<u4").tofile(path)
+        print(f"{path}: {blob.size} words, po2 {int(blob[2])}")
