@@ -7,14 +7,19 @@
 // library; this file only builds the segment list and prints what came back.  (examples/seal_segments.cpp is the same session
 // written out against the low-level entry points.)
 //
-//   prove_session --desc syn_a.desc [--join-desc p2_join.desc] [--po2 20] [--tail-po2 18] [--segments 64] [--devices 1]
-//                 [--inflight 3] [--join-po2 18] [--noise-seed N]
+//   prove_session --desc syn_a.desc [--join-desc p2_join.desc | --recursion-dir DIR] [--po2 20] [--tail-po2 18] [--segments 64]
+//                 [--devices 1] [--inflight 3] [--join-po2 18] [--noise-seed N]
+// --recursion-dir: the directory `python -m zeth_amd.circuits.rec_verify DIR` and `python -m zeth_amd.circuits.recursion
+// DIR/recursion.desc` wrote (lift-<po2>.zkr1, join-<l>-<r>.zkr1): lift every receipt and join them to one root receipt whose
+// every node verified its child seal(s) IN-CIRCUIT (BASELINE.json config 5).
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
+
+#include <dirent.h>
 
 #include "zkhal.h"
 
@@ -28,7 +33,7 @@ static bool read_words(const std::string& path, std::vector<uint32_t>& out) {
 }
 
 int main(int argc, char** argv) {
-    std::string desc_path, join_path;
+    std::string desc_path, join_path, rec_dir;
     size_t po2 = 20, tail_po2 = 18, n = 64, devices = 1, inflight = 3, join_po2 = 18;
     uint64_t noise = 0;
     for (int i = 1; i < argc; i++) {
@@ -36,6 +41,7 @@ int main(int argc, char** argv) {
         auto num = [&](size_t& d) { if (i + 1 < argc) d = strtoull(argv[++i], nullptr, 10); };
         if (a == "--desc" && i + 1 < argc) desc_path = argv[++i];
         else if (a == "--join-desc" && i + 1 < argc) join_path = argv[++i];
+        else if (a == "--recursion-dir" && i + 1 < argc) rec_dir = argv[++i];
         else if (a == "--po2") num(po2);
         else if (a == "--tail-po2") num(tail_po2);
         else if (a == "--segments") num(n);
@@ -55,6 +61,33 @@ int main(int argc, char** argv) {
     zkh_session* session = nullptr;
     const char* err = zkh_session_create(devs.data(), devs.size(), inflight, desc.data(), desc.size(), jdesc.empty() ? nullptr : jdesc.data(), jdesc.size(), &session);
     if (err) { fprintf(stderr, "zkh_session_create: %s\n", err); zkh_free_error(err); return 1; }
+    if (!rec_dir.empty()) {
+        // the lift / join programs: every *.zkr1 of the directory, kind from the file name
+        std::vector<uint32_t> rdesc;
+        if (!read_words(rec_dir + "/recursion.desc", rdesc)) return 2;
+        std::vector<std::vector<uint32_t>> blobs;
+        std::vector<uint32_t> kinds;
+        DIR* d = opendir(rec_dir.c_str());
+        if (!d) { perror(rec_dir.c_str()); return 2; }
+        std::vector<std::string> names;
+        while (dirent* e = readdir(d)) names.push_back(e->d_name);
+        closedir(d);
+        for (const std::string& name : names) {
+            unsigned a = 0, b = 0;
+            uint32_t kind;
+            if (sscanf(name.c_str(), "lift-%u.zkr1", &a) == 1 && name.find(".zkr1") != std::string::npos) kind = 0;
+            else if (sscanf(name.c_str(), "join-%u-%u.zkr1", &a, &b) == 2) kind = 1;
+            else continue;
+            blobs.emplace_back();
+            if (!read_words(rec_dir + "/" + name, blobs.back())) return 2;
+            kinds.insert(kinds.end(), {kind, a, b});
+        }
+        std::vector<const uint32_t*> ptrs;
+        std::vector<size_t> words;
+        for (auto& bl : blobs) { ptrs.push_back(bl.data()); words.push_back(bl.size()); }
+        err = zkh_session_set_recursion(session, rdesc.data(), rdesc.size(), ptrs.data(), words.data(), kinds.data(), blobs.size());
+        if (err) { fprintf(stderr, "zkh_session_set_recursion: %s\n", err); zkh_free_error(err); return 1; }
+    }
     // the session's segment list: S distinct segments, the last one the short tail
     std::vector<zkh_segment> segs(n);
     for (size_t i = 0; i < n; i++) {
@@ -64,17 +97,19 @@ int main(int argc, char** argv) {
         segs[i].noise_seed = noise;                       // 0: fresh OS randomness per segment, like upstream
     }
     zkh_prove_info info;
-    err = zkh_session_prove(session, segs.data(), n, !jdesc.empty(), join_po2, noise, &info);
+    err = zkh_session_prove(session, segs.data(), n, !rec_dir.empty() ? 2 : !jdesc.empty(), join_po2, noise, &info);
     if (err) { fprintf(stderr, "zkh_session_prove: %s\n", err); zkh_free_error(err); return 1; }
     err = zkh_session_verify(session, segs.data(), &info, join_po2);
     if (err) { fprintf(stderr, "REJECTED: %s\n", err); zkh_free_error(err); return 1; }
     size_t words = 0;
     for (size_t i = 0; i < info.n_segments; i++) words += info.seal_words[i];
     printf("{\"driver\": \"prove_session\", \"library\": \"%s\", \"segments\": %zu, \"po2\": %zu, \"tail_po2\": %u, \"lanes\": %zu, "
-           "\"wall_s\": %.4f, \"leaves_s\": %.4f, \"segments_per_s\": %.3f, \"witgen_ms_per_segment\": %.3f, \"joins\": %zu, \"join_tree_s\": %.4f, "
-           "\"root_receipt_words\": %zu, \"seal_words_total\": %zu, \"verified\": true}\n",
+           "\"wall_s\": %.4f, \"leaves_s\": %.4f, \"segments_per_s\": %.3f, \"witgen_ms_per_segment\": %.3f, \"lifts\": %zu, \"lift_s\": %.4f, "
+           "\"joins\": %zu, \"join_tree_s\": %.4f, \"in_circuit_verification\": %s, \"root_receipt_words\": %zu, \"seal_words_total\": %zu, "
+           "\"verified\": true}\n",
            zkh_version(), n, po2, segs[n - 1].po2, zkh_session_lanes(session), info.wall_s, info.leaves_s, n / info.leaves_s,
-           1e3 * info.witgen_s_sum / n, info.n_joins, info.join_s, info.root_seal_words, words);
+           1e3 * info.witgen_s_sum / n, info.n_lifts, info.lift_s, info.n_joins, info.join_s, info.n_lifts ? "true" : "false",
+           info.root_seal_words, words);
     zkh_prove_info_free(&info);
     zkh_session_destroy(session);
     return 0;

@@ -337,6 +337,9 @@ typedef struct {
     size_t n_joins;
     double wall_s, leaves_s, join_s;            /* whole call, leaf phase, join tree */
     double witgen_s_sum, seal_s_sum;            /* summed over segments (lane seconds) */
+    size_t n_lifts;                             /* join_tree == 2: lifts run (= n_segments); the root is a RECURSION seal */
+    size_t root_program;                        /* ... and the index of the program the root was sealed under */
+    double lift_s;                              /* ... the lift phase (join_s is then the joins alone) */
 } zkh_prove_info;
 /* CircuitHal::accumulate for circuits without a built-in accum generator: fill `accum` (W_accum x 2^po2) from data + mix */
 typedef const char* (*zkh_accumulate_fn)(void* user, zkh_ctx*, const zkh_circuit*, size_t po2, const zkh_buf* data,
@@ -349,7 +352,14 @@ size_t zkh_session_lanes(const zkh_session*);
 /* the circuit handle of a lane (join != 0: its join circuit), e.g. to attach code objects before proving */
 zkh_circuit* zkh_session_circuit(zkh_session*, size_t lane, int join);
 void zkh_session_set_accumulate(zkh_session*, zkh_accumulate_fn fn, void* user);
-/* join_tree != 0: fold the receipts through the join tree (joins at 2^join_po2; join_noise_seed 0 = OS randomness) */
+/* The lift / join programs of the RECURSION circuit (zkh_rec_program_*; blobs from `python -m zeth_amd.circuits.rec_verify dir`):
+ * rec_desc = the RECURSION description; program i is blobs[i] (words[i] words) of kind kinds[3 i .. 3 i + 3) = {0, segment po2, 0}
+ * for a lift, {1, left po2, right po2} for a join.  Every lane loads every program (code groups resident). */
+const char* zkh_session_set_recursion(zkh_session*, const uint32_t* rec_desc, size_t rec_desc_words, const uint32_t* const* blobs,
+                                      const size_t* words, const uint32_t* kinds, size_t n_programs);
+/* join_tree == 1: fold the receipts through the P2-JOIN tree (joins at 2^join_po2; join_noise_seed 0 = OS randomness);
+ * join_tree == 2: lift every receipt and join level by level with the RECURSION programs - every node verifies its child
+ * seal(s) in-circuit; the root receipt is a RECURSION seal with out = claim tree root ‖ allowed-programs root */
 const char* zkh_session_prove(zkh_session*, const zkh_segment* segs, size_t n, int join_tree, size_t join_po2,
                               uint64_t join_noise_seed, zkh_prove_info* info);
 void zkh_prove_info_free(zkh_prove_info*);

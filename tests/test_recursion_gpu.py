@@ -172,3 +172,56 @@ def test_block_of_segments_folds_to_one_receipt_that_verified_every_child_in_cir
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/recursion_test.json", "w") as fh:
         json.dump(line, fh)
+
+
+def test_native_session_executor_lifts_and_joins_like_the_python_driver(hal, tmp_path):
+    """zkh_session_prove(join_tree = 2) (csrc/session.hip: C++ threads over lanes) against zeth_amd/recursion.py: the same root
+    receipt word for word (fixed noise), zkh_session_verify accepts it, a swapped leaf is refused; and the compiled host
+    examples/prove_session does the same from program files."""
+    import subprocess
+    from zeth_amd import build, recursion as rec
+    from zeth_amd.hal import HalError
+    from zeth_amd.host import Session
+    from zeth_amd.prover import Segment, SegmentProver
+    desc = syn_air.syn_small()
+    sp = SegmentProver(hal, desc)
+    segs = [Segment(index=i, po2=13 if i < 4 else 12, seed=900 + i, noise_seed=0x51) for i in range(5)]
+    roots = {13: sp.control_root(13), 12: sp.control_root(12)}
+    programs = rec.build_programs(desc, roots)
+    sess = Session(desc, devices=(0,), lanes_per_device=2)
+    with pytest.raises(HalError, match="set_recursion"):
+        sess.prove(segs, join_tree=2)
+    sess.set_recursion(programs)
+    comp, root, stats = sess.prove(segs, join_tree=2, join_noise_seed=0x77, verify=True)
+    assert stats["n_lifts"] == 5 and stats["n_joins"] == 4 and stats["verified"] and root is not None
+    rx = rec.Recursion(hal, programs)
+    leaves = [sp.prove_segment(s) for s in segs]
+    for a, b in zip(comp.segments, leaves):
+        assert np.array_equal(a.seal, b.seal)
+    want = rx.fold([rx.lift(r, 0x77) for r in leaves], 0x77)
+    assert np.array_equal(root.seal, want.seal) and stats["root_program"] == want.program
+    want.verify(rx.allowed_roots(), [HostCircuit_claim(desc, r, roots) for r in leaves])
+    # the library's verification binds the root to THESE segments: another session's root is refused
+    other = [Segment(index=i, po2=s.po2, seed=s.seed + 50, noise_seed=0x51) for i, s in enumerate(segs)]
+    _, root2, _ = sess.prove(other, join_tree=2, join_noise_seed=0x77, verify=True)
+    assert not np.array_equal(root2.seal[:8], root.seal[:8])
+    sess.close()
+    # the compiled host: programs from files
+    d = tmp_path / "zkr"
+    d.mkdir()
+    np.asarray(R.recursion_circuit(), dtype="<u4").tofile(d / "recursion.desc")
+    for kind, blob in programs:
+        np.asarray(blob, dtype="<u4").tofile(d / ("-".join(str(x) for x in kind) + ".zkr1"))
+    dpath = tmp_path / "syn_small.desc"
+    np.asarray(desc, dtype="<u4").tofile(dpath)
+    exe = os.path.join(os.path.dirname(build.build_examples()), "prove_session")
+    r = subprocess.run([exe, "--desc", str(dpath), "--recursion-dir", str(d), "--po2", "13", "--tail-po2", "12", "--segments", "6", "--inflight", "2"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["verified"] is True and out["lifts"] == 6 and out["joins"] == 5 and out["in_circuit_verification"] is True
+
+
+def HostCircuit_claim(desc, receipt, roots):
+    from zeth_amd.hal import HostCircuit
+    return HostCircuit(desc).receipt_claim(receipt.seal, roots[receipt.po2])

@@ -35,9 +35,14 @@ uint64_t os_random64() {
 struct Lane {
     int device = 0;
     zkh_ctx* ctx = nullptr;
-    zkh_circuit *circuit = nullptr, *join_circuit = nullptr;
+    zkh_circuit *circuit = nullptr, *join_circuit = nullptr, *rec_circuit = nullptr;
     zkh_prover *prover = nullptr, *join_prover = nullptr;
+    std::vector<zkh_rec_program*> programs;
     void close() {
+        for (auto p : programs) zkh_rec_program_destroy(p);
+        programs.clear();
+        if (rec_circuit) zkh_circuit_destroy(rec_circuit);
+        rec_circuit = nullptr;
         if (join_prover) zkh_prover_destroy(join_prover);
         if (prover) zkh_prover_destroy(prover);
         if (join_circuit) zkh_circuit_destroy(join_circuit);
@@ -64,8 +69,12 @@ struct ErrorSlot {
 
 }  // namespace
 
+struct RecKind { uint32_t join, a, b; };
 struct zkh_session {
-    std::vector<uint32_t> desc, join_desc;
+    std::vector<uint32_t> desc, join_desc, rec_desc;
+    std::vector<RecKind> rec_kinds;
+    std::vector<std::vector<uint32_t>> rec_roots;                 // control root of program i
+    std::vector<std::vector<std::vector<uint32_t>>> allowed;       // levels of the allowed-programs tree (8 leaves)
     std::vector<Lane> lanes;
     zkh_accumulate_fn accumulate = nullptr;
     void* accumulate_user = nullptr;
@@ -102,6 +111,46 @@ extern "C" zkh_circuit* zkh_session_circuit(zkh_session* s, size_t lane, int joi
 }
 extern "C" void zkh_session_set_accumulate(zkh_session* s, zkh_accumulate_fn fn, void* user) {
     if (s) { s->accumulate = fn; s->accumulate_user = user; }
+}
+
+static const char* hash_pair_host(const uint32_t* a, const uint32_t* b, uint32_t out[8]) {
+    uint32_t st[24] = {0};
+    memcpy(st, a, 32); memcpy(st + 8, b, 32);
+    ZKH_TRY(zkh_poseidon2_mix_host(nullptr, nullptr, st, 1));
+    memcpy(out, st, 32);
+    return nullptr;
+}
+constexpr size_t REC_ALLOWED = 8, REC_DEPTH = 3;                   // zeth_amd/circuits/rec_verify.py ALLOWED_DEPTH
+
+extern "C" const char* zkh_session_set_recursion(zkh_session* s, const uint32_t* rec_desc, size_t rec_desc_words, const uint32_t* const* blobs,
+                                                 const size_t* words, const uint32_t* kinds, size_t n_programs) {
+    ZKH_REQUIRE(s && rec_desc && rec_desc_words >= 16 && blobs && words && kinds && n_programs && n_programs <= REC_ALLOWED, "session_set_recursion: bad argument");
+    ZKH_REQUIRE(s->rec_kinds.empty(), "session_set_recursion: the session already has its programs");
+    s->rec_desc.assign(rec_desc, rec_desc + rec_desc_words);
+    for (auto& l : s->lanes) {
+        ZKH_TRY(zkh_circuit_load(l.ctx, s->rec_desc.data(), s->rec_desc.size(), &l.rec_circuit));
+        for (size_t i = 0; i < n_programs; i++) {
+            zkh_rec_program* p = nullptr;
+            ZKH_TRY(zkh_rec_program_load(l.ctx, l.rec_circuit, blobs[i], words[i], &p));
+            l.programs.push_back(p);
+        }
+    }
+    for (size_t i = 0; i < n_programs; i++) {
+        s->rec_kinds.push_back(RecKind{kinds[3 * i], kinds[3 * i + 1], kinds[3 * i + 2]});
+        std::vector<uint32_t> root(8);
+        ZKH_TRY(zkh_rec_program_info(s->lanes[0].programs[i], root.data(), nullptr));
+        s->rec_roots.push_back(root);
+    }
+    std::vector<std::vector<uint32_t>> level(s->rec_roots);
+    level.resize(REC_ALLOWED, std::vector<uint32_t>(8, 0));
+    s->allowed.assign(1, level);
+    while (level.size() > 1) {
+        std::vector<std::vector<uint32_t>> up(level.size() / 2, std::vector<uint32_t>(8));
+        for (size_t k = 0; k < up.size(); k++) ZKH_TRY(hash_pair_host(level[2 * k].data(), level[2 * k + 1].data(), up[k].data()));
+        s->allowed.push_back(up);
+        level.swap(up);
+    }
+    return nullptr;
 }
 
 extern "C" void zkh_prove_info_free(zkh_prove_info* info) {
@@ -161,7 +210,8 @@ static const char* seal_one(zkh_session* s, Lane& l, const zkh_segment& seg, uin
 extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs, size_t n, int join_tree, size_t join_po2, uint64_t join_noise_seed,
                                          zkh_prove_info* info) {
     ZKH_REQUIRE(s && segs && n && info, "session_prove: bad argument");
-    ZKH_REQUIRE(!join_tree || !s->join_desc.empty(), "session_prove: the session was created without a join circuit");
+    ZKH_REQUIRE(join_tree != 1 || !s->join_desc.empty(), "session_prove: the session was created without a join circuit");
+    ZKH_REQUIRE(join_tree != 2 || !s->rec_kinds.empty(), "session_prove: join_tree 2 needs zkh_session_set_recursion");
     memset(info, 0, sizeof *info);
     info->n_segments = n;
     info->seals = (uint32_t**)calloc(n, sizeof(uint32_t*));
@@ -193,7 +243,85 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
     // ---- the join tree: level l pairs nodes (2k, 2k+1) of level l-1, an unpaired last node is carried up; the joins of a
     // level are independent and pulled from one index by the lanes.  A leaf's claim is zkh_receipt_claim (needs the leaf's
     // control root: computed per size by the first lane), a join's claim is the parent digest it constrains (out[0..8)). ----
-    if (join_tree && n > 1 && !errs.any()) {
+    if (join_tree == 2 && !errs.any()) {
+        // ---- lift every receipt, then join level by level: every node verifies its child seal(s) in-circuit ----
+        struct Node { uint32_t* seal = nullptr; size_t words = 0; uint32_t po2 = 0, program = 0; };
+        auto program_of = [&](uint32_t join, uint32_t a, uint32_t b) -> int {
+            for (size_t i = 0; i < s->rec_kinds.size(); i++)
+                if (s->rec_kinds[i].join == join && s->rec_kinds[i].a == a && (!join || s->rec_kinds[i].b == b)) return (int)i;
+            return -1;
+        };
+        auto po2_of = [&](uint32_t program) { uint32_t inf[8]; (void)zkh_rec_program_info(s->lanes[0].programs[program], nullptr, inf); return inf[0]; };
+        auto path_of = [&](uint32_t program, std::vector<uint32_t>& out) {      // per level: the direction bit as an element, the sibling
+            size_t idx = program;
+            for (size_t l = 0; l < REC_DEPTH; l++) {
+                out.push_back(fp_encode((uint32_t)(idx & 1)).v);
+                out.insert(out.end(), s->allowed[l][idx ^ 1].begin(), s->allowed[l][idx ^ 1].end());
+                idx >>= 1;
+            }
+        };
+        const std::vector<uint32_t>& A = s->allowed.back()[0];
+        std::vector<Node> level(n);
+        const double tl = now_s();
+        {
+            std::atomic<size_t> idx{0};
+            std::vector<std::thread> th;
+            for (auto& lane : s->lanes)
+                th.emplace_back([&, l = &lane] {
+                    std::vector<uint32_t> in;
+                    for (;;) {
+                        const size_t k = idx.fetch_add(1);
+                        if (k >= n || errs.any()) break;
+                        const int p = program_of(0, segs[k].po2, 0);
+                        if (p < 0) { errs.set(make_err("no lift program for po2-%u segments", segs[k].po2), "lift"); break; }
+                        in.assign(info->seals[k], info->seals[k] + info->seal_words[k]);
+                        in.insert(in.end(), A.begin(), A.end());
+                        Node& nd = level[k];
+                        nd.program = (uint32_t)p; nd.po2 = po2_of((uint32_t)p);
+                        if (errs.set(zkh_rec_prove(l->programs[p], in.data(), in.size(), join_noise_seed ? join_noise_seed : os_random64(), nullptr, &nd.seal, &nd.words), "lift")) break;
+                    }
+                    (void)zkh_sync(l->ctx);
+                });
+            for (auto& t : th) t.join();
+        }
+        info->n_lifts = n;
+        info->lift_s = now_s() - tl;
+        const double tj = now_s();
+        while (level.size() > 1 && !errs.any()) {
+            const size_t pairs = level.size() / 2;
+            std::vector<Node> up(pairs);
+            std::atomic<size_t> idx{0};
+            std::vector<std::thread> th;
+            for (auto& lane : s->lanes)
+                th.emplace_back([&, l = &lane] {
+                    std::vector<uint32_t> in;
+                    for (;;) {
+                        const size_t k = idx.fetch_add(1);
+                        if (k >= pairs || errs.any()) break;
+                        const Node &a = level[2 * k], &b = level[2 * k + 1];
+                        const int p = program_of(1, a.po2, b.po2);
+                        if (p < 0) { errs.set(make_err("no join program for children of po2 %u and %u", a.po2, b.po2), "join"); break; }
+                        in.assign(a.seal, a.seal + a.words);
+                        path_of(a.program, in);
+                        in.insert(in.end(), b.seal, b.seal + b.words);
+                        path_of(b.program, in);
+                        Node& nd = up[k];
+                        nd.program = (uint32_t)p; nd.po2 = po2_of((uint32_t)p);
+                        if (errs.set(zkh_rec_prove(l->programs[p], in.data(), in.size(), join_noise_seed ? join_noise_seed : os_random64(), nullptr, &nd.seal, &nd.words), "join")) break;
+                    }
+                    (void)zkh_sync(l->ctx);
+                });
+            for (auto& t : th) t.join();
+            info->n_joins += pairs;
+            for (size_t k = 0; k < 2 * pairs; k++) zkh_free_seal(level[k].seal);          // children are not kept
+            if (level.size() % 2) up.push_back(level.back());
+            level.swap(up);
+        }
+        info->join_s = now_s() - tj;
+        if (!errs.any()) { info->root_seal = level[0].seal; info->root_seal_words = level[0].words; info->root_program = level[0].program; level[0].seal = nullptr; }
+        for (auto& nd : level) zkh_free_seal(nd.seal);
+    }
+    if (join_tree == 1 && n > 1 && !errs.any()) {
         const double tj = now_s();
         std::vector<std::vector<uint32_t>> claims(n, std::vector<uint32_t>(8));
         std::vector<std::pair<uint32_t, std::vector<uint32_t>>> roots;          // (po2, control root) of the leaf circuit
@@ -283,6 +411,28 @@ extern "C" const char* zkh_session_verify(zkh_session* s, const zkh_segment* seg
         ZKH_TRY(zkh_receipt_claim(hc, info->seals[i], info->seal_words[i], root->data(), nullptr, nullptr, claims[i].data()));
     }
     if (!info->root_seal) return nullptr;
+    if (info->n_lifts) {
+        // a RECURSION root: ONE seal under a program of the allowed set, out = claim tree root ‖ allowed-programs root
+        ZKH_REQUIRE(!s->rec_kinds.empty() && info->root_program < s->rec_roots.size(), "session_verify: a recursion root without the session's programs");
+        zkh_circuit* rc = nullptr;
+        ZKH_TRY(zkh_circuit_load(nullptr, s->rec_desc.data(), s->rec_desc.size(), &rc));
+        std::unique_ptr<zkh_circuit, void (*)(zkh_circuit*)> rhold(rc, zkh_circuit_destroy);
+        if (const char* e = zkh_verify_segment(rc, info->root_seal, info->root_seal_words, s->rec_roots[info->root_program].data(), nullptr, nullptr)) {
+            const char* out = make_err("session_verify: root receipt: %s", e);
+            zkh_free_error(e);
+            return out;
+        }
+        while (claims.size() > 1) {
+            std::vector<std::vector<uint32_t>> up(claims.size() / 2, std::vector<uint32_t>(8));
+            for (size_t k = 0; k < up.size(); k++) ZKH_TRY(hash_pair_host(claims[2 * k].data(), claims[2 * k + 1].data(), up[k].data()));
+            if (claims.size() % 2) up.push_back(claims.back());
+            claims.swap(up);
+        }
+        ZKH_REQUIRE(info->root_seal_words > 16 && memcmp(info->root_seal, claims[0].data(), 32) == 0,
+                    "session_verify: the root receipt does not commit to the claim tree of these segments");
+        ZKH_REQUIRE(memcmp(info->root_seal + 8, s->allowed.back()[0].data(), 32) == 0, "session_verify: the root receipt was produced under another allowed-programs root");
+        return nullptr;
+    }
     ZKH_REQUIRE(!s->join_desc.empty() && info->n_segments > 1, "session_verify: a root receipt without a join circuit");
     zkh_circuit* jc = nullptr;
     ZKH_TRY(zkh_circuit_load(nullptr, s->join_desc.data(), s->join_desc.size(), &jc));

@@ -39,7 +39,8 @@ class ProveInfo(C.Structure):
     """`zkh_prove_info`: what zkh_session_prove returns."""
     _fields_ = [("n_segments", C.c_size_t), ("seals", C.POINTER(C.POINTER(C.c_uint32))), ("seal_words", C.POINTER(C.c_size_t)),
                 ("root_seal", C.POINTER(C.c_uint32)), ("root_seal_words", C.c_size_t), ("n_joins", C.c_size_t),
-                ("wall_s", C.c_double), ("leaves_s", C.c_double), ("join_s", C.c_double), ("witgen_s_sum", C.c_double), ("seal_s_sum", C.c_double)]
+                ("wall_s", C.c_double), ("leaves_s", C.c_double), ("join_s", C.c_double), ("witgen_s_sum", C.c_double), ("seal_s_sum", C.c_double),
+                ("n_lifts", C.c_size_t), ("root_program", C.c_size_t), ("lift_s", C.c_double)]
 
 
 # every symbol include/zkhal.h declares: (restype, argtypes)
@@ -141,6 +142,7 @@ ABI = {
     "zkh_session_lanes": (_sz, [_vp]),
     "zkh_session_circuit": (_vp, [_vp, _sz, _i]),
     "zkh_session_set_accumulate": (None, [_vp, _vp, _vp]),
+    "zkh_session_set_recursion": (_err, [_vp, _u32p, _sz, C.POINTER(_u32p), C.POINTER(_sz), _u32p, _sz]),
     "zkh_session_prove": (_err, [_vp, C.POINTER(SegmentSpec), _sz, _i, _sz, _u64, C.POINTER(ProveInfo)]),
     "zkh_prove_info_free": (None, [C.POINTER(ProveInfo)]),
     "zkh_session_verify": (_err, [_vp, C.POINTER(SegmentSpec), C.POINTER(ProveInfo), _sz]),

@@ -189,6 +189,19 @@ class Session:
 
     __del__ = close
 
+    def set_recursion(self, programs) -> None:
+        """programs: [(kind, blob)] from zeth_amd.recursion.build_programs - loaded on every lane (code groups resident); then
+        `prove(..., join_tree=2)` lifts every receipt and joins them with in-circuit verification of every child seal"""
+        C, np = self._C, self._np
+        from .circuits import recursion as rc
+        rdesc = np.ascontiguousarray(rc.recursion_circuit(), dtype=np.uint32)
+        blobs = [np.ascontiguousarray(b, dtype=np.uint32) for _, b in programs]
+        u32p = C.POINTER(C.c_uint32)
+        ptrs = (u32p * len(blobs))(*[b.ctypes.data_as(u32p) for b in blobs])
+        words = (C.c_size_t * len(blobs))(*[b.size for b in blobs])
+        kinds = np.array([[0, k[1], 0] if k[0] == "lift" else [1, k[1], k[2]] for k, _ in programs], dtype=np.uint32).reshape(-1)
+        self._hal._check(self._hal._lib.zkh_session_set_recursion(self.h, self._hal._ptr(rdesc), rdesc.size, ptrs, words, self._hal._ptr(kinds), len(blobs)))
+
     def _specs(self, segments: Sequence[Segment], host_traces=None):
         C, np = self._C, self._np
         arr = (self._hal.SegmentSpec * len(segments))()
@@ -206,7 +219,7 @@ class Session:
                 s.host_code, s.host_data, s.out_global = code.ctypes.data_as(u32p), data.ctypes.data_as(u32p), out.ctypes.data_as(u32p)
         return arr, keep
 
-    def prove(self, segments: Sequence[Segment], join_tree: bool = False, join_po2: int = 18, join_noise_seed: int = 0,
+    def prove(self, segments: Sequence[Segment], join_tree: int = 0, join_po2: int = 18, join_noise_seed: int = 0,
               verify: bool = False, host_traces=None):
         """-> (CompositeReceipt, root SegmentReceipt or None, stats dict).  Segments use the protocol's ZK_CYCLES; noise_seed 0
         = fresh OS randomness per segment.  verify=True additionally runs `receipt.verify` inside the library
@@ -229,8 +242,10 @@ class Session:
             root = None
             if info.root_seal:
                 rs = np.ctypeslib.as_array(info.root_seal, shape=(info.root_seal_words,)).copy()
-                root = SegmentReceipt(seal=rs, index=0, po2=join_po2, output=rs[:24].copy())
+                recursive = bool(info.n_lifts)
+                root = SegmentReceipt(seal=rs, index=0, po2=self._hal.fp_decode(int(rs[16])) if recursive else join_po2, output=rs[:16 if recursive else 24].copy())
             stats = {"wall_s": info.wall_s, "leaves_s": info.leaves_s, "join_s": info.join_s, "n_joins": int(info.n_joins),
+                     "n_lifts": int(info.n_lifts), "lift_s": info.lift_s, "root_program": int(info.root_program),
                      "witgen_s_sum": info.witgen_s_sum, "seal_s_sum": info.seal_s_sum, "verified": bool(verify)}
             return CompositeReceipt(recs), root, stats
         finally:
