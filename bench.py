@@ -798,10 +798,11 @@ def main() -> None:
         if recursive and world > 1:
             # every rank folds a contiguous, aligned power-of-two range of leaves: its local root is a node of the global join
             # tree, and rank 0 joins the `world` local roots (the top log2(world) levels)
-            per = S // world
-            if S % world or per & (per - 1) or world & (world - 1):
-                raise SystemExit("bench: --join-circuit recursion on N ranks needs N and S / N to be powers of two")
-            mine = list(range(rank * per, (rank + 1) * per))
+            from zeth_amd.recursion import aligned_range
+            try:
+                mine = list(aligned_range(S, world, rank))
+            except ValueError as e:
+                raise SystemExit(f"bench: --join-circuit recursion: {e}")
         lanes = [Lane(with_join=succinct and not recursive) for _ in range(inflight)]
         # warm-up: one full-size seal per lane (clocks, pools, code objects), plus the control roots the verifier needs
         for ln in lanes:

@@ -110,6 +110,17 @@ def build_programs(segment_desc, segment_roots: Dict[int, np.ndarray], zk_cycles
     return out
 
 
+def aligned_range(n_leaves: int, world_size: int, rank: int) -> range:
+    """The leaves rank `rank` folds when a block is spread over `world_size` GPUs: contiguous, aligned power-of-two ranges, so
+    that every rank's local root is a node of the global join tree (the tree of host.fold_claims) and rank 0 only joins the
+    `world_size` local roots - the one exchange of the path: world_size - 1 receipts (~210 KB each) gathered over the control
+    plane.  Needs world_size and n_leaves / world_size to be powers of two."""
+    per = n_leaves // world_size
+    if n_leaves % world_size or per & (per - 1) or world_size & (world_size - 1) or per == 0:
+        raise ValueError("the recursive fold on N ranks needs N and S / N to be powers of two")
+    return range(rank * per, (rank + 1) * per)
+
+
 class Recursion:
     """The lift / join programs of one GPU lane (one HipHal): loaded once, code groups resident."""
 
