@@ -225,3 +225,33 @@ def test_native_session_executor_lifts_and_joins_like_the_python_driver(hal, tmp
 def HostCircuit_claim(desc, receipt, roots):
     from zeth_amd.hal import HostCircuit
     return HostCircuit(desc).receipt_claim(receipt.seal, roots[receipt.po2])
+
+
+def test_a_keccak_assumption_receipt_is_lifted_too(hal):
+    """The lift program is built from a circuit DESCRIPTION: the same builder lifts a KECCAK-F receipt (3 840 columns, 43.8 k
+    constraint steps evaluated gate by gate in-circuit) - how upstream resolves a keccak assumption on the way to the succinct
+    receipt.  The lift's claim is the keccak receipt's claim digest, which binds the SHA-3 state it proves."""
+    import hashlib
+    from zeth_amd import recursion as rec
+    from zeth_amd.circuits import keccak_f
+    from zeth_amd.hal import HalError, HostCircuit, fp_decode
+    from zeth_amd.prover import Segment, SegmentProver
+    kdesc = keccak_f.keccak_f_circuit()
+    kp = SegmentProver(hal, kdesc)
+    msg = b"assumption: one accelerator batch"
+    pub = tuple(w for lane in keccak_f.sha3_256_block(msg) for w in (lane & 0xFFFFFFFF, lane >> 32))
+    krec = kp.prove_segment(Segment(index=0, po2=13, seed=0xCECC, noise_seed=3, pub=pub))
+    limbs = [fp_decode(int(w)) for w in krec.seal[:100]]
+    assert keccak_f.digest_of_state([sum(limbs[4 * l + j] << (16 * j) for j in range(4)) for l in range(25)]) == hashlib.sha3_256(msg).digest()
+    kroot = kp.control_root(13)
+    programs = [p for p in rec.build_programs(kdesc, {13: kroot}) if p[0][0] == "lift"]
+    rx = rec.Recursion(hal, programs)
+    lifted = rx.lift(krec, noise_seed=5)
+    assert np.array_equal(lifted.claim, HostCircuit(kdesc).receipt_claim(krec.seal, kroot))
+    lifted.verify(rx.allowed_roots())
+    forged = krec.seal.copy()
+    forged[7] = (int(forged[7]) + 1) % P                            # one limb of the proven state
+    from zeth_amd.prover import SegmentReceipt
+    with pytest.raises(HalError, match="assertion of the program fails"):
+        rx.lift(SegmentReceipt(seal=forged, index=0, po2=13))
+    print("KECCAK lift:", {"po2": lifted.po2, "permutations": rx.programs[0].n_p2, "gates": rx.programs[0].n_gates})
