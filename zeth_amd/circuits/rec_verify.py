@@ -90,6 +90,10 @@ class Verifier:
         """`count` words as packed wires (4 words each, the last zero padded)"""
         out = [self.pr.input(self.pos + 4 * i, min(4, count - 4 * i)) for i in range((count + 3) // 4)]
         self.pos += count
+        if count % 4:                          # the padding of a partial wire is part of what gets hashed: it must BE zero
+            u = self.pr.unpack(out[-1])
+            for k in range(count % 4, 4):
+                self.pr.eq(u[k], self.pr.zero())
         return out
 
     # ---- hashing
