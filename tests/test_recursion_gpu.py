@@ -211,7 +211,7 @@ def test_native_session_executor_lifts_and_joins_like_the_python_driver(hal, tmp
     d.mkdir()
     np.asarray(R.recursion_circuit(), dtype="<u4").tofile(d / "recursion.desc")
     for kind, blob in programs:
-        np.asarray(blob, dtype="<u4").tofile(d / ("-".join(str(x) for x in kind) + ".zkr1"))
+        np.asarray(blob, dtype="<u4").tofile(d / ("-".join(str(x) for x in kind[:3 if kind[0] == "join" else 2]) + ".zkr1"))
     dpath = tmp_path / "syn_small.desc"
     np.asarray(desc, dtype="<u4").tofile(dpath)
     exe = os.path.join(os.path.dirname(build.build_examples()), "prove_session")
@@ -255,3 +255,28 @@ def test_a_keccak_assumption_receipt_is_lifted_too(hal):
     with pytest.raises(HalError, match="assertion of the program fails"):
         rx.lift(SegmentReceipt(seal=forged, index=0, po2=13))
     print("KECCAK lift:", {"po2": lifted.po2, "permutations": rx.programs[0].n_p2, "gates": rx.programs[0].n_gates})
+
+
+def test_segments_and_a_keccak_assumption_fold_into_one_receipt(hal):
+    """upstream's flow for a block whose guest used the keccak accelerator: the segment receipts AND the keccak batch receipt
+    are lifted, then joined into one receipt - every node verified in-circuit, three circuits (SYN, KECCAK-F, RECURSION) and
+    three recursion sizes (17, 18, 19) in one allowed set"""
+    from zeth_amd import recursion as rec
+    from zeth_amd.circuits import keccak_f
+    from zeth_amd.hal import HostCircuit
+    from zeth_amd.prover import Segment, SegmentProver
+    sdesc, kdesc = syn_air.syn_small(), keccak_f.keccak_f_circuit()
+    sp, kp = SegmentProver(hal, sdesc), SegmentProver(hal, kdesc)
+    segs = [sp.prove_segment(Segment(index=i, po2=13, seed=60 + i, noise_seed=9)) for i in range(3)]
+    krec = kp.prove_segment(Segment(index=0, po2=13, seed=0xCECC, noise_seed=3))
+    sroot, kroot = sp.control_root(13), kp.control_root(13)
+    programs = rec.build_programs(sdesc, {13: sroot}, assumptions=[(kdesc, {13: kroot})])
+    rx = rec.Recursion(hal, programs)
+    sizes = sorted({p.po2 for p in rx.programs})
+    assert len(programs) <= 16 and len(sizes) == 3
+    leaves = [rx.lift(r, 5) for r in segs] + [rx.lift(krec, 5, family=1)]
+    root = rx.fold(leaves, 7)
+    claims = [HostCircuit(sdesc).receipt_claim(r.seal, sroot) for r in segs] + [HostCircuit(kdesc).receipt_claim(krec.seal, kroot)]
+    root.verify(rx.allowed_roots(), claims)
+    assert root.n_leaves == 4
+    print("RESOLVE", {"programs": len(programs), "sizes": sizes})

@@ -26,7 +26,7 @@ from .desc import (GLOBAL_MIX, GLOBAL_OUT, GROUP_ACCUM, GROUP_CODE, GROUP_DATA, 
 from .recursion import NW, Program
 
 QUERIES, INV_RATE, FRI_FOLD, FRI_MIN_DEGREE, CHECK_SIZE, EXT = 50, 4, 16, 256, 16, 4
-ALLOWED_DEPTH = 3                                         # the allowed-programs tree holds 8 control roots
+ALLOWED_DEPTH = 4                                         # the allowed-programs tree holds 16 control roots
 ROU_FWD = [pow(137, 1 << (27 - k), P) for k in range(28)]
 ROU_REV = [pow(w, P - 2, P) for w in ROU_FWD]
 
@@ -463,6 +463,6 @@ if __name__ == "__main__":      # python -m zeth_amd.circuits.rec_verify out_dir
     if any(r is None for r in roots.values()):
         raise SystemExit("no shipped control root for SYN-A at po2 20 / 18 (python -m zeth_amd.prover on a GPU box)")
     for kind, blob in host_rec.build_programs(desc, roots):
-        path = os.path.join(out_dir, "-".join(str(x) for x in kind) + ".zkr1")
+        path = os.path.join(out_dir, "-".join(str(x) for x in kind[:3 if kind[0] == "join" else 2]) + ".zkr1")
         np.asarray(blob, dtype="<u4").tofile(path)
         print(f"{path}: {blob.size} words, po2 {int(blob[2])}")

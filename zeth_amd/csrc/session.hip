@@ -120,7 +120,7 @@ static const char* hash_pair_host(const uint32_t* a, const uint32_t* b, uint32_t
     memcpy(out, st, 32);
     return nullptr;
 }
-constexpr size_t REC_ALLOWED = 8, REC_DEPTH = 3;                   // zeth_amd/circuits/rec_verify.py ALLOWED_DEPTH
+constexpr size_t REC_ALLOWED = 16, REC_DEPTH = 4;                   // zeth_amd/circuits/rec_verify.py ALLOWED_DEPTH
 
 extern "C" const char* zkh_session_set_recursion(zkh_session* s, const uint32_t* rec_desc, size_t rec_desc_words, const uint32_t* const* blobs,
                                                  const size_t* words, const uint32_t* kinds, size_t n_programs) {
@@ -248,7 +248,7 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
         struct Node { uint32_t* seal = nullptr; size_t words = 0; uint32_t po2 = 0, program = 0; };
         auto program_of = [&](uint32_t join, uint32_t a, uint32_t b) -> int {
             for (size_t i = 0; i < s->rec_kinds.size(); i++)
-                if (s->rec_kinds[i].join == join && s->rec_kinds[i].a == a && (!join || s->rec_kinds[i].b == b)) return (int)i;
+                if (s->rec_kinds[i].join == join && s->rec_kinds[i].a == a && s->rec_kinds[i].b == b) return (int)i;     // lifts: b = circuit family, 0 = the session's
             return -1;
         };
         auto po2_of = [&](uint32_t program) { uint32_t inf[8]; (void)zkh_rec_program_info(s->lanes[0].programs[program], nullptr, inf); return inf[0]; };

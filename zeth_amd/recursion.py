@@ -32,7 +32,7 @@ N_ALLOWED = 1 << rec_verify.ALLOWED_DEPTH
 
 
 def allowed_tree(roots: Sequence[np.ndarray]) -> List[List[np.ndarray]]:
-    """levels of the allowed-programs tree over `roots` (padded with zero digests to 8 leaves): [leaves, ..., [root]]"""
+    """levels of the allowed-programs tree over `roots` (padded with zero digests to 16 leaves): [leaves, ..., [root]]"""
     assert len(roots) <= N_ALLOWED
     level = [np.asarray(r, dtype=np.uint32) for r in roots] + [np.zeros(8, np.uint32)] * (N_ALLOWED - len(roots))
     levels = [level]
@@ -83,11 +83,14 @@ class RecReceipt:
             raise _hal.HalError("recursion receipt: its claim is not the root of the leaves' claim tree")
 
 
-def build_programs(segment_desc, segment_roots: Dict[int, np.ndarray], zk_cycles: int = _hal.ZK_CYCLES) -> List[Tuple[Tuple, np.ndarray]]:
-    """The program set of a block: one lift per segment size (`segment_roots`: {po2: control root of the segment circuit}),
-    then joins for every pair of child sizes that can meet, until the set of sizes closes (po2-20 / po2-18 SYN-A segments: two
-    lifts at po2 17, join(17,17) -> 18, join(17,18), join(18,17), join(18,18) -> 18).  Pure host work, no GPU: [(kind, blob)]."""
-    segment_desc = np.asarray(segment_desc, dtype=np.uint32)
+def build_programs(segment_desc, segment_roots: Optional[Dict[int, np.ndarray]] = None, zk_cycles: int = _hal.ZK_CYCLES,
+                   assumptions: Sequence[Tuple[np.ndarray, Dict[int, np.ndarray]]] = ()) -> List[Tuple[Tuple, np.ndarray]]:
+    """The program set of a block: one lift per segment size (`segment_roots`: {po2: control root of the segment circuit}) and
+    per size of every assumption circuit (`assumptions`: [(circuit description, {po2: control root})], e.g. KECCAK-F batches:
+    upstream lifts those receipts too and resolves them on the way to the succinct receipt), then joins for every pair of
+    child sizes that can meet, until the set of sizes closes (po2-20 / po2-18 SYN-A segments: two lifts at po2 17,
+    join(17,17) -> 18, join(17,18), join(18,17), join(18,18) -> 18).  Pure host work, no GPU: [(kind, blob)], kind =
+    ("lift", segment po2, family) with family 0 = the segment circuit, 1.. = the assumption circuits, or ("join", po2_l, po2_r)."""
     rdesc = rc.recursion_circuit()
     out: List[Tuple[Tuple, np.ndarray]] = []
     sizes = set()
@@ -96,8 +99,11 @@ def build_programs(segment_desc, segment_roots: Dict[int, np.ndarray], zk_cycles
         po2 = pr.min_po2(zk_cycles)
         out.append((kind, pr.finish(po2, zk_cycles)))
         sizes.add(po2)
-    for po2, root in sorted(segment_roots.items(), reverse=True):
-        add(("lift", po2), rec_verify.build_lift(segment_desc, po2, [int(w) * RINV % P for w in np.asarray(root, dtype=np.uint32)]))
+    families = [(segment_desc, segment_roots or {})] + list(assumptions)
+    for fam, (desc, roots) in enumerate(families):
+        desc = np.asarray(desc, dtype=np.uint32)
+        for po2, root in sorted(roots.items(), reverse=True):
+            add(("lift", po2, fam), rec_verify.build_lift(desc, po2, [int(w) * RINV % P for w in np.asarray(root, dtype=np.uint32)]))
     done = set()
     while True:
         todo = [(a, b) for a in sorted(sizes) for b in sorted(sizes) if (a, b) not in done]
@@ -137,8 +143,9 @@ class Recursion:
     def allowed_root(self) -> np.ndarray:
         return self.levels[-1][0]
 
-    def lift(self, receipt: SegmentReceipt, noise_seed: Optional[int] = None) -> RecReceipt:
-        i = self.kinds.index(("lift", receipt.po2))
+    def lift(self, receipt: SegmentReceipt, noise_seed: Optional[int] = None, family: int = 0) -> RecReceipt:
+        """family 0: a receipt of the segment circuit; 1..: of the corresponding assumption circuit of build_programs"""
+        i = self.kinds.index(("lift", receipt.po2, family))
         inputs = np.concatenate([np.asarray(receipt.seal, dtype=np.uint32), self.allowed_root()])
         seal, _ = self.programs[i].prove(inputs, _seed(noise_seed))
         return RecReceipt(seal, self.programs[i].po2, i, self.programs[i].root)
