@@ -21,8 +21,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .desc import (GLOBAL_MIX, GLOBAL_OUT, GROUP_ACCUM, GROUP_CODE, GROUP_DATA, OP_ADD, OP_AND_COND, OP_AND_EQZ, OP_CONST,
-                   OP_CONST_EXT, OP_GET, OP_GET_GLOBAL, OP_MUL, OP_SUB, OP_TRUE, Circuit, P)
+from .desc import (GLOBAL_OUT, GROUP_ACCUM, GROUP_CODE, GROUP_DATA, OP_ADD, OP_AND_COND, OP_AND_EQZ, OP_CONST, OP_CONST_EXT, OP_GET,
+                   OP_GET_GLOBAL, OP_MUL, OP_SUB, OP_TRUE, Circuit, P)
 from .recursion import NW, Program
 
 QUERIES, INV_RATE, FRI_FOLD, FRI_MIN_DEGREE, CHECK_SIZE, EXT = 50, 4, 16, 256, 16, 4

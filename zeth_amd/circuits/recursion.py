@@ -34,7 +34,7 @@ Globals: out = 16 words (program-defined: rec_verify puts claim (8) ‖ allowed-
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -367,8 +367,9 @@ class Program:
     def scale(self, a, k, plus=0):
         return self.gen(a, a, a, qA=k, qK=plus)
 
-    def lin(self, a, ka, b, kb, c=None, kc=0, k=0):
-        return self.gen(a, b, a if c is None else c, qA=ka, qB=kb, qC=kc if c is not None else 0, qK=k)
+    def lin(self, a, ka, b, kb, k=0):
+        """ka a + kb b + k"""
+        return self.gen(a, b, a, qA=ka, qB=kb, qK=k)
 
     def mux(self, bit: int, b: int, c: int) -> int:
         """bit ? c : b   (bit must be a BOOL wire)"""
@@ -378,15 +379,11 @@ class Program:
         return d
 
     def boolean(self, a: int) -> None:
+        """a is a BOOL wire: a_0 in {0, 1}, a_1 = a_2 = a_3 = 0 (the witness generator checks a*a = a, which says the same)"""
         self.gates.append(Gate([a, -1, -1, -1, -1, -1], flags=G_BOOL))
-        z = self.gen_free(a)
-        del z
-
-    def gen_free(self, a):          # witness-side check of a BOOL wire: a0 (a0 - 1) = 0 and embedded
         z = self.var()
         self._op(OP_GEN, z, a, a, a, self._kidx((1, P - 1, 0, 0, 0)))
         self.ops.append((OP_EQ, 0, z, self.zero(), 0, 0, 0, 0))
-        return z
 
     def pack(self, j: int, a: int, b: int, c: int, e: int, embedded: bool = False) -> int:
         """d = (a_j, b_j, c_j, e_j)"""
