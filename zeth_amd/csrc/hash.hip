@@ -14,6 +14,7 @@
 // 6.4 k VALU instructions per 64 permutations.
 #include "common.h"
 #include "poseidon2.h"
+#include "poseidon2_wide.h"
 
 using namespace zkh;
 
@@ -85,26 +86,12 @@ __global__ __launch_bounds__(256, 4) void k_hash_fold(uint32_t* __restrict__ io,
 // 4j..4j+3 (one M4 block), the column sums of M_ext and the partial-round state sum are 3-step DPP butterflies
 // (quad_perm xor 1, xor 2, row_half_mirror) that never touch LDS, round constants sit in LDS (one ds_read_b128 per
 // full round).  ~3.5x lower latency per layer; used only where the layer is too narrow to fill the chip.
+// (The permutation itself: poseidon2_wide.h.)
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }
-__device__ __forceinline__ uint32_t dpp_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true); }
-__device__ __forceinline__ uint32_t dpp_half_mirror(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true); }
-// sum over the 8 lanes of a group (lanes 6, 7 hold zeros), result in every lane
-__device__ __forceinline__ uint32_t group_sum(uint32_t v) {
-    v = add_mod(v, dpp_xor1(v));
-    v = add_mod(v, dpp_xor2(v));
-    return add_mod(v, dpp_half_mirror(v));
-}
-__device__ __forceinline__ void wide_m_ext(uint32_t (&c)[4]) {
-    m4(c[0], c[1], c[2], c[3]);
-#pragma unroll
-    for (int k = 0; k < 4; k++) c[k] = add_mod(c[k], group_sum(c[k]));
-}
 // one 8-lane group folds one parent: io[out + parent] = H(io[in + 2 parent] || io[in + 2 parent + 1]); rcs = rc in LDS
 __device__ __forceinline__ void wide_fold_one(uint32_t* __restrict__ io, size_t input_size, size_t output_size, uint32_t gid,
                                               const uint32_t* rcs, const uint32_t* __restrict__ pc) {
     const uint32_t j = gid & 7;
-    const bool owner = j < 6;                                   // lanes 6, 7 carry zeros
     size_t parent = gid >> 3;
     const bool live = parent < output_size;
     if (!live) parent = output_size - 1;                        // keep the whole wave in the butterflies
@@ -113,32 +100,7 @@ __device__ __forceinline__ void wide_fold_one(uint32_t* __restrict__ io, size_t 
         const uint4 v = *(const uint4*)(io + (input_size + 2 * parent) * 8 + 4 * j);
         c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w;
     }
-    const uint32_t jj = owner ? j : 5;
-    uint32_t d[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) d[k] = pc[4 * jj + k];
-    auto full_round = [&](int round) {
-        const uint4 r = *(const uint4*)(rcs + round * CELLS + 4 * jj);
-        c[0] = sbox7_rc(c[0], r.x); c[1] = sbox7_rc(c[1], r.y); c[2] = sbox7_rc(c[2], r.z); c[3] = sbox7_rc(c[3], r.w);
-        if (!owner) { c[0] = c[1] = c[2] = c[3] = 0; }
-        wide_m_ext(c);
-        if (!owner) { c[0] = c[1] = c[2] = c[3] = 0; }
-    };
-    wide_m_ext(c);
-    if (!owner) { c[0] = c[1] = c[2] = c[3] = 0; }
-    int round = 0;
-#pragma unroll
-    for (int r = 0; r < HALF_FULL; r++, round++) full_round(round);
-#pragma unroll 3
-    for (int r = 0; r < PARTIAL; r++, round++) {
-        const uint32_t z = sbox7_rc(c[0], rcs[round * CELLS]);
-        c[0] = j == 0 ? z : c[0];
-        const uint32_t sum = group_sum(add_mod(add_mod(c[0], c[1]), add_mod(c[2], c[3])));
-#pragma unroll
-        for (int k = 0; k < 4; k++) c[k] = owner ? mont_reduce_wide(((uint64_t)sum << 32) + (uint64_t)d[k] * c[k]) : 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < HALF_FULL; r++, round++) full_round(round);
+    wide_permute(c, j, rcs, pc);
     if (live && j < 2) *(uint4*)(io + (output_size + parent) * 8 + 4 * j) = make_uint4(c[0], c[1], c[2], c[3]);
 }
 constexpr int WIDE_LOG = 15;      // layers with <= 2^15 parents use the 8-lane permutation

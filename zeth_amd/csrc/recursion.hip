@@ -19,6 +19,7 @@
 #include "../../include/zkh_poseidon2_consts.h"
 #include "circuit.h"
 #include "poseidon2.h"
+#include "poseidon2_wide.h"
 
 using namespace zkh;
 
@@ -40,13 +41,10 @@ __device__ __forceinline__ Fp4 ld(const uint4* val, uint32_t v) {
 __device__ __forceinline__ void st(uint4* val, uint32_t v, const Fp4& x) { val[v] = make_uint4(x.c[0].v, x.c[1].v, x.c[2].v, x.c[3].v); }
 __device__ __forceinline__ uint32_t comp(const uint4& x, uint32_t j) { return j == 0 ? x.x : j == 1 ? x.y : j == 2 ? x.z : x.w; }
 
-// one dependency level of the witness schedule: lane i executes op lo + i
-__global__ __launch_bounds__(64) void k_rec_level(const uint32_t* __restrict__ ops, uint32_t lo, uint32_t hi, uint4* val,
-                                                  const uint32_t* __restrict__ consts, const uint32_t* __restrict__ inputs, uint32_t* fail,
-                                                  const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
-    const uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= hi) return;
-    const uint32_t* o = ops + (size_t)RC_OP_WORDS * i;
+// one op of the witness schedule (any but a cooperative permutation)
+__device__ __forceinline__ void rec_exec_op(const uint32_t* __restrict__ o, uint4* val, const uint32_t* __restrict__ consts,
+                                            const uint32_t* __restrict__ inputs, uint32_t* fail, const uint32_t* __restrict__ rc,
+                                            const uint32_t* __restrict__ diag) {
     const uint32_t op = o[0] & 0xff, aux = (o[0] >> 8) & 0xff, out = o[1];
     switch (op) {
     case RO_INPUT: {
@@ -98,7 +96,7 @@ __global__ __launch_bounds__(64) void k_rec_level(const uint32_t* __restrict__ o
         for (uint32_t t = 0; t < 31; t++) val[out + t] = make_uint4(((x >> t) & 1) ? R1 : 0u, 0, 0, 0);
         break;
     }
-    case RO_P2: {
+    case RO_P2: {                              // one lane, the lazily reduced form of hash.hip (levels wide enough to fill the chip)
         uint32_t s[CELLS];
         for (uint32_t w = 0; w < RC_NW; w++) { const uint4 x = val[o[2 + w]]; s[4 * w] = x.x; s[4 * w + 1] = x.y; s[4 * w + 2] = x.z; s[4 * w + 3] = x.w; }
         poseidon2_mix(s, rc, diag);
@@ -112,6 +110,61 @@ __global__ __launch_bounds__(64) void k_rec_level(const uint32_t* __restrict__ o
     }
     default: atomicMin(fail, o[7]);
     }
+}
+// a wide dependency level: lane i executes op lo + i
+__global__ __launch_bounds__(64) void k_rec_level(const uint32_t* __restrict__ ops, uint32_t lo, uint32_t hi, uint4* val,
+                                                  const uint32_t* __restrict__ consts, const uint32_t* __restrict__ inputs, uint32_t* fail,
+                                                  const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
+    const uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    rec_exec_op(ops + (size_t)RC_OP_WORDS * i, val, consts, inputs, fail, rc, diag);
+}
+// A RUN of narrow levels [l0, l1) in ONE workgroup of 1024 lanes: the level chain of a verifier (the transcript sponge, the
+// Horner and constraint chains) is hundreds of levels a few ops wide, and a launch per level costs ~10 us each.  Here a level is
+// a barrier; its permutations run on eight lanes each (poseidon2_wide.h: ~3.5 x lower latency than one lane), in whole waves
+// after the lanes of the other ops.  lv[l] = {lo, p2lo, p2hi, hi}: ops [lo, p2lo) and [p2hi, hi) are not permutations, [p2lo,
+// p2hi) are (ops of a level are sorted by opcode).  The host only puts a level in a run if its lanes fit: non-permutation ops
+// rounded up to a wave + 8 per permutation <= 1024.
+__global__ __launch_bounds__(1024) void k_rec_run(const uint32_t* __restrict__ ops, const uint4* __restrict__ lv, uint32_t l0, uint32_t l1,
+                                                  uint4* val, const uint32_t* __restrict__ consts, const uint32_t* __restrict__ inputs,
+                                                  uint32_t* fail, const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
+    __shared__ __attribute__((aligned(16))) uint32_t rcs[ROUNDS_TOTAL * CELLS + 8];
+    for (uint32_t w = threadIdx.x; w < ROUNDS_TOTAL * CELLS; w += blockDim.x) rcs[w] = rc[w];
+    __syncthreads();
+    const uint32_t t = threadIdx.x;
+    for (uint32_t l = l0; l < l1; l++) {
+        const uint4 r = lv[l];
+        const uint32_t n_a = r.y - r.x, n_other = n_a + (r.w - r.z), first_p2 = (n_other + 63) & ~63u, n_p2 = r.z - r.y;
+        if (t < n_other) {
+            const uint32_t i = t < n_a ? r.x + t : r.z + (t - n_a);
+            rec_exec_op(ops + (size_t)RC_OP_WORDS * i, val, consts, inputs, fail, rc, diag);
+        } else if (t >= first_p2 && ((t - first_p2) >> 6) * 8 < n_p2) {          // wave-uniform: waves with at least one permutation
+            const uint32_t g = (t - first_p2) >> 3, j = t & 7;
+            const bool live = g < n_p2;
+            const uint32_t* o = ops + (size_t)RC_OP_WORDS * (r.y + (live ? g : n_p2 - 1));
+            uint32_t c[4] = {0, 0, 0, 0};
+            if (j < 6) { const uint4 x = val[o[2 + j]]; c[0] = x.x; c[1] = x.y; c[2] = x.z; c[3] = x.w; }
+            wide_permute(c, j, rcs, diag);
+            if (live && j < 6) val[o[1] + j] = make_uint4(c[0], c[1], c[2], c[3]);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+// the permutations of a wide level, eight lanes each
+__global__ __launch_bounds__(256) void k_rec_p2_wide(const uint32_t* __restrict__ ops, uint32_t lo, uint32_t hi, uint4* val,
+                                                     const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
+    __shared__ __attribute__((aligned(16))) uint32_t rcs[ROUNDS_TOTAL * CELLS + 8];
+    for (uint32_t w = threadIdx.x; w < ROUNDS_TOTAL * CELLS; w += blockDim.x) rcs[w] = rc[w];
+    __syncthreads();
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, g = gid >> 3, j = gid & 7, n = hi - lo;
+    if ((gid >> 6) * 8 >= n) return;                                             // wave-uniform
+    const bool live = g < n;
+    const uint32_t* o = ops + (size_t)RC_OP_WORDS * (lo + (live ? g : n - 1));
+    uint32_t c[4] = {0, 0, 0, 0};
+    if (j < 6) { const uint4 x = val[o[2 + j]]; c[0] = x.x; c[1] = x.y; c[2] = x.z; c[3] = x.w; }
+    wide_permute(c, j, rcs, diag);
+    if (live && j < 6) val[o[1] + j] = make_uint4(c[0], c[1], c[2], c[3]);
 }
 
 __device__ __forceinline__ uint32_t rc_cell(uint64_t seed, uint32_t group, uint32_t col, uint32_t row) {   // = syn_cell of circuit.hip
@@ -284,6 +337,10 @@ struct zkh_rec_program {
     uint32_t po2 = 0, zk = 0, A = 0, n_vars = 0, n_consts = 0, n_ops = 0, n_inputs = 0, n_p2 = 0, n_gates = 0, pub_row = 0xffffffffu;
     zkh_buf *d_table = nullptr, *d_pos = nullptr, *d_consts = nullptr, *d_ops = nullptr, *d_tab = nullptr;
     std::vector<uint32_t> level_ptr;
+    std::vector<uint32_t> lv;                      // per level: lo, p2lo, p2hi, hi
+    struct Step { uint32_t l0, l1; bool run; };
+    std::vector<Step> plan;                        // runs of narrow levels (one launch) and single wide levels
+    zkh_buf* d_lv = nullptr;
     uint32_t root[8] = {0};
     uint64_t hash = 0;
 };
@@ -292,7 +349,7 @@ extern "C" void zkh_rec_program_destroy(zkh_rec_program* p) {
     if (!p) return;
     if (p->ctx) bind_thread(p->ctx);
     if (p->prover) zkh_prover_destroy(p->prover);
-    for (zkh_buf* b : {p->d_table, p->d_pos, p->d_consts, p->d_ops, p->d_tab}) if (b) zkh_release(b);
+    for (zkh_buf* b : {p->d_table, p->d_pos, p->d_consts, p->d_ops, p->d_tab, p->d_lv}) if (b) zkh_release(b);
     delete p;
 }
 
@@ -388,6 +445,20 @@ extern "C" const char* zkh_rec_program_load(zkh_ctx* ctx, const zkh_circuit* cir
         p->level_ptr[op_level[order[k]] + 1] = k + 1;
     }
     for (uint32_t l = 1; l <= n_levels; l++) p->level_ptr[l] = std::max(p->level_ptr[l], p->level_ptr[l - 1]);
+    // per level the range of its permutations (ops are sorted by opcode inside a level), and the launch plan
+    p->lv.assign(4 * (size_t)n_levels + 4, 0);
+    for (uint32_t l = 0; l < n_levels; l++) {
+        const uint32_t lo = p->level_ptr[l], hi = p->level_ptr[l + 1];
+        uint32_t a = lo, b = lo;
+        while (a < hi && (sorted[(size_t)RC_OP_WORDS * a] & 0xff) < RO_P2) a++;
+        b = a;
+        while (b < hi && (sorted[(size_t)RC_OP_WORDS * b] & 0xff) == RO_P2) b++;
+        p->lv[4 * l] = lo; p->lv[4 * l + 1] = a; p->lv[4 * l + 2] = b; p->lv[4 * l + 3] = hi;
+        const uint32_t lanes = (((a - lo) + (hi - b) + 63) & ~63u) + 8 * (b - a);
+        const bool narrow = lanes <= 1024;
+        if (narrow && !p->plan.empty() && p->plan.back().run) p->plan.back().l1 = l + 1;
+        else p->plan.push_back({l, l + 1, narrow});
+    }
     bind_thread(ctx);
     std::vector<uint32_t> kk(p->n_consts ? p->n_consts : 1, 0), tab(RC_T * RC_ROUNDS + RC_T);
     for (uint32_t i = 0; i < p->n_consts; i++) { ZKH_REQUIRE(consts[i] < P, "rec_program_load: constant out of range"); kk[i] = fp_encode(consts[i]).v; }
@@ -398,6 +469,7 @@ extern "C" const char* zkh_rec_program_load(zkh_ctx* ctx, const zkh_circuit* cir
     ZKH_TRY(zkh_copy_from(ctx, "rec_consts", kk.data(), kk.size(), &p->d_consts));
     ZKH_TRY(zkh_copy_from(ctx, "rec_ops", sorted.data(), sorted.size(), &p->d_ops));
     ZKH_TRY(zkh_copy_from(ctx, "rec_tab", tab.data(), tab.size(), &p->d_tab));
+    ZKH_TRY(zkh_copy_from(ctx, "rec_lv", p->lv.data(), p->lv.size(), &p->d_lv));
     p->hash = desc_hash64(b, words);
     // the code group: generated, committed, resident
     ZKH_TRY(zkh_prover_create(ctx, circuit, &p->prover));
@@ -417,7 +489,7 @@ extern "C" const char* zkh_rec_program_info(const zkh_rec_program* p, uint32_t r
     if (root) memcpy(root, p->root, 32);
     if (info) {
         info[0] = p->po2; info[1] = p->zk; info[2] = p->n_inputs; info[3] = p->n_p2; info[4] = p->n_gates; info[5] = p->n_ops;
-        info[6] = (uint32_t)(p->level_ptr.size() - 1); info[7] = p->n_vars;
+        info[6] = (uint32_t)(p->level_ptr.size() - 1); info[7] = p->n_vars;       // (launches per witness: plan.size() runs / wide levels)
     }
     return nullptr;
 }
@@ -439,11 +511,24 @@ extern "C" const char* zkh_rec_witgen(const zkh_rec_program* p, const uint32_t* 
     ZKH_TRY(zkh_copy_from(c, "rec_fail", &none, 1, fail.out()));
     {
         ProfScope prof(c, "rec_exec", 16.0 * p->n_vars);
-        for (size_t l = 0; l + 1 < p->level_ptr.size(); l++) {
-            const uint32_t lo = p->level_ptr[l], hi = p->level_ptr[l + 1];
-            if (hi == lo) continue;
-            k_rec_level<<<(hi - lo + 63) / 64, 64, 0, c->stream>>>(p->d_ops->ptr(), lo, hi, (uint4*)val->ptr(), p->d_consts->ptr(), din->ptr(),
-                                                                  fail->ptr(), c->tab.rc, c->tab.diag);
+        static const bool per_level = getenv("ZKH_REC_PER_LEVEL") != nullptr;       // A/B: one launch per level, one lane per op
+        uint4* v = (uint4*)val->ptr();
+        for (const auto& st : p->plan) {
+            if (st.run && !per_level) {
+                k_rec_run<<<1, 1024, 0, c->stream>>>(p->d_ops->ptr(), (const uint4*)p->d_lv->ptr(), st.l0, st.l1, v, p->d_consts->ptr(), din->ptr(),
+                                                     fail->ptr(), c->tab.rc, c->tab.diag);
+                continue;
+            }
+            for (uint32_t l = st.l0; l < st.l1; l++) {
+                const uint32_t lo = p->lv[4 * l], a = p->lv[4 * l + 1], b = p->lv[4 * l + 2], hi = p->lv[4 * l + 3];
+                if (per_level) {
+                    if (hi > lo) k_rec_level<<<(hi - lo + 63) / 64, 64, 0, c->stream>>>(p->d_ops->ptr(), lo, hi, v, p->d_consts->ptr(), din->ptr(), fail->ptr(), c->tab.rc, c->tab.diag);
+                    continue;
+                }
+                if (a > lo) k_rec_level<<<(a - lo + 63) / 64, 64, 0, c->stream>>>(p->d_ops->ptr(), lo, a, v, p->d_consts->ptr(), din->ptr(), fail->ptr(), c->tab.rc, c->tab.diag);
+                if (hi > b) k_rec_level<<<(hi - b + 63) / 64, 64, 0, c->stream>>>(p->d_ops->ptr(), b, hi, v, p->d_consts->ptr(), din->ptr(), fail->ptr(), c->tab.rc, c->tab.diag);
+                if (b > a) k_rec_p2_wide<<<(8 * (b - a) + 255) / 256, 256, 0, c->stream>>>(p->d_ops->ptr(), a, b, v, c->tab.rc, c->tab.diag);
+            }
         }
     }
     ZKH_TRY(last_launch_error("rec_exec"));
