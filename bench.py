@@ -193,6 +193,7 @@ def main() -> None:
     ap.add_argument("--fold-inflight", type=int, default=int(os.environ.get("ZKH_FOLD_INFLIGHT", "6")),
                     help="lifts / joins in flight per GPU: a lift's witness schedule is a chain of ~300 small launches (latency), so the fold "
                          "packs the GPU with more lanes than the seals need (measured: 3 -> 6 lanes, 5.1 -> 4.4 ms per join)")
+    ap.add_argument("--no-fused-lift", action="store_true", help="recursion: lift every segment on its own and join (three proofs per pair at the bottom level) instead of lift2")
     ap.add_argument("--no-recursive", action="store_true", help="segment config: skip the lift / join fold of the block leg's receipts")
     ap.add_argument("--no-succinct", action="store_true", help="segment config: skip the join tree over the block leg's receipts")
     ap.add_argument("--no-certify", action="store_true", help="segment config: do not verify the timed seals / compare with the golden digest after the clock")
@@ -399,9 +400,19 @@ def main() -> None:
             return out
         device_sync(lanes)
         t0 = time.perf_counter()
-        level = spread([(lambda ln, r=r: ln.rec.lift(r, BENCH_NOISE)) for r in leaves])
-        device_sync(lanes)
-        lift_s = time.perf_counter() - t0
+        # bottom level: lift + lift + join fused into one proof per pair of segments (lift2) where the program set has it
+        rx0 = lanes[0].rec
+        jobs, n_fused = [], 0
+        for k in range(len(leaves) // 2):
+            a, b = leaves[2 * k], leaves[2 * k + 1]
+            if not args.no_fused_lift and rx0.has_lift2(a, b):
+                jobs.append(lambda ln, a=a, b=b: ln.rec.lift2(a, b, BENCH_NOISE))
+                n_fused += 1
+            else:
+                jobs.append(lambda ln, a=a, b=b: ln.rec.join(ln.rec.lift(a, BENCH_NOISE), ln.rec.lift(b, BENCH_NOISE), BENCH_NOISE))
+        if len(leaves) % 2:
+            jobs.append(lambda ln, r=leaves[-1]: ln.rec.lift(r, BENCH_NOISE))
+        level = spread(jobs) if len(leaves) > 1 else spread([lambda ln, r=leaves[0]: ln.rec.lift(r, BENCH_NOISE)])
         n_joins = 0
         while len(level) > 1:
             nxt = spread([(lambda ln, a=level[2 * k], b=level[2 * k + 1]: ln.rec.join(a, b, BENCH_NOISE)) for k in range(len(level) // 2)])
@@ -412,8 +423,11 @@ def main() -> None:
         device_sync(lanes)
         total_s = time.perf_counter() - t0
         rx = lanes[0].rec
-        stats = {"lifts": len(leaves), "joins": n_joins, "lift_phase_s": lift_s, "join_phase_s": total_s - lift_s, "fold_s": total_s,
-                 "lift_ms_each": 1e3 * lift_s / max(1, len(leaves)), "join_ms_each": 1e3 * (total_s - lift_s) / max(1, n_joins),
+        n_unfused = len(leaves) // 2 - n_fused
+        stats = {"segments_lifted": len(leaves), "fused_lift2": n_fused, "lifts": 2 * n_unfused + len(leaves) % 2, "joins": n_joins + n_unfused,
+                 "proofs": n_fused + 3 * n_unfused + len(leaves) % 2 + n_joins,
+                 "bottom_level_s": lift_s, "join_phase_s": total_s - lift_s, "fold_s": total_s,
+                 "bottom_ms_per_segment": 1e3 * lift_s / max(1, len(leaves)), "join_ms_each": 1e3 * (total_s - lift_s) / max(1, n_joins),
                  "programs": [{"kind": "-".join(str(x) for x in k), "po2": p.po2, "permutations": p.n_p2, "gates": p.n_gates,
                                "levels": p.n_levels, "witness_words": p.n_inputs} for k, p in zip(rx.kinds, rx.programs)],
                  "root_receipt_words": int(level[0].seal.size),
@@ -952,7 +966,7 @@ def main() -> None:
                 "vs_baseline": None, "dtype": "u32", "data": "synthetic",
                 "config": {"workload": (f"{'block + join tree to one succinct receipt' if succinct else 'one block'}: {S} distinct "
                                         f"2^{args.po2}-cycle segments (last one 2^{segs[-1].po2}), {workload}; witness generation inside the clock"
-                                        + (f"; {S} lifts + {S - 1} joins of the RECURSION circuit: every node runs the STARK verifier on its child seal(s) in-circuit" if recursive else
+                                        + (f"; {rstats['proofs']} proofs of the RECURSION circuit ({rstats['fused_lift2']} lift2 = lift + lift + join fused, {rstats['lifts']} lifts, {rstats['joins']} joins): every node runs the STARK verifier on its child seal(s) in-circuit" if recursive else
                                            f"; {n_joins} P2-JOIN joins at po2 {args.join_po2} (parent claim = Poseidon2 hash_pair of the children's, proven in-circuit)" if succinct else "")),
                            "po2": args.po2, "circuit": args.circuit, "segments": S,
                            "parallelism": f"segments round-robin over {world} GPU(s) + shared work index inside a rank, no data-path collective; "

@@ -10,7 +10,7 @@
 //   prove_session --desc syn_a.desc [--join-desc p2_join.desc | --recursion-dir DIR] [--po2 20] [--tail-po2 18] [--segments 64]
 //                 [--devices 1] [--inflight 3] [--join-po2 18] [--noise-seed N]
 // --recursion-dir: the directory `python -m zeth_amd.circuits.rec_verify DIR` and `python -m zeth_amd.circuits.recursion
-// DIR/recursion.desc` wrote (lift-<po2>.zkr1, join-<l>-<r>.zkr1): lift every receipt and join them to one root receipt whose
+// DIR/recursion.desc` wrote (lift-<po2>.zkr1, lift2-<l>-<r>.zkr1, join-<l>-<r>.zkr1): lift the receipts (in pairs: lift2) and join them to one root receipt whose
 // every node verified its child seal(s) IN-CIRCUIT (BASELINE.json config 5).
 #include <cstdint>
 #include <cstdio>
@@ -75,7 +75,9 @@ int main(int argc, char** argv) {
         for (const std::string& name : names) {
             unsigned a = 0, b = 0;
             uint32_t kind;
-            if (sscanf(name.c_str(), "lift-%u.zkr1", &a) == 1 && name.find(".zkr1") != std::string::npos) kind = 0;
+            if (name.find(".zkr1") == std::string::npos) continue;
+            if (sscanf(name.c_str(), "lift2-%u-%u.zkr1", &a, &b) == 2) kind = 2;
+            else if (sscanf(name.c_str(), "lift-%u.zkr1", &a) == 1) { kind = 0; b = 0; }
             else if (sscanf(name.c_str(), "join-%u-%u.zkr1", &a, &b) == 2) kind = 1;
             else continue;
             blobs.emplace_back();

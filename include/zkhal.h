@@ -337,7 +337,7 @@ typedef struct {
     size_t n_joins;
     double wall_s, leaves_s, join_s;            /* whole call, leaf phase, join tree */
     double witgen_s_sum, seal_s_sum;            /* summed over segments (lane seconds) */
-    size_t n_lifts;                             /* join_tree == 2: lifts run (= n_segments); the root is a RECURSION seal */
+    size_t n_lifts;                             /* join_tree == 2: proofs of the bottom level (lifts, or lift2 per pair); the root is a RECURSION seal */
     size_t root_program;                        /* ... and the index of the program the root was sealed under */
     double lift_s;                              /* ... the lift phase (join_s is then the joins alone) */
 } zkh_prove_info;
@@ -353,8 +353,10 @@ size_t zkh_session_lanes(const zkh_session*);
 zkh_circuit* zkh_session_circuit(zkh_session*, size_t lane, int join);
 void zkh_session_set_accumulate(zkh_session*, zkh_accumulate_fn fn, void* user);
 /* The lift / join programs of the RECURSION circuit (zkh_rec_program_*; blobs from `python -m zeth_amd.circuits.rec_verify dir`):
- * rec_desc = the RECURSION description; program i is blobs[i] (words[i] words) of kind kinds[3 i .. 3 i + 3) = {0, segment po2, 0}
- * for a lift, {1, left po2, right po2} for a join.  Every lane loads every program (code groups resident). */
+ * rec_desc = the RECURSION description; program i is blobs[i] (words[i] words) of kind kinds[3 i .. 3 i + 3) = {0, segment po2,
+ * circuit family (0 = the session's)} for a lift, {1, left po2, right po2} for a join of two recursion seals, {2, left po2,
+ * right po2} for a lift2 (two SEGMENT seals verified by one program: lift + lift + join fused; used for the bottom level when
+ * every pair of the session has one).  Every lane loads every program (code groups resident). */
 const char* zkh_session_set_recursion(zkh_session*, const uint32_t* rec_desc, size_t rec_desc_words, const uint32_t* const* blobs,
                                       const size_t* words, const uint32_t* kinds, size_t n_programs);
 /* join_tree == 1: fold the receipts through the P2-JOIN tree (joins at 2^join_po2; join_noise_seed 0 = OS randomness);

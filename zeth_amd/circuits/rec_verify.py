@@ -7,6 +7,7 @@ FRI fold of all 50 queries run INSIDE the circuit, on a child seal that enters a
 `lift` / `join` programs (risc0-circuit-recursion 4.0.2 `.zkr`, un-vendored: /root/reference/Cargo.lock:5305) do:
 
   lift(circuit, po2):  verify one segment seal;  out = claim(segment) ‖ A
+  lift2(circuit, po2_l, po2_r):  verify two segment seals;  out = hash_pair(claim_l, claim_r) ‖ A   (lift + lift + join fused)
   join(po2_l, po2_r):  verify two recursion seals, require that both carry this A and that their programs' control roots are
                        members of the allowed set A;  out = hash_pair(claim_l, claim_r) ‖ A
 
@@ -409,19 +410,39 @@ class Verifier:
         pr.eq(cur[1], allowed[1])
 
 
-def build_lift(circuit_desc: np.ndarray, po2: int, control_root: Sequence[int]) -> Program:
-    """Inputs: the segment seal, then A (8 words).  control_root: canonical residues of the segment circuit's code root."""
-    c = Circuit.parse(circuit_desc)
-    pr = Program()
-    v = Verifier(pr)
+def _segment_claim(v: Verifier, c: Circuit, po2: int, control_root: Sequence[int]) -> List[int]:
+    """verify one segment seal (fresh transcript), pin its code root to `control_root`, -> its claim digest (2 wires)"""
+    pr = v.pr
+    v.io = Sponge(pr)
     s = v.verify_seal(c, po2)
     root_words = v.digest_words(s["code_root"])
     for w, k in zip(root_words, control_root):
         pr.eq(w, pr.const(int(k)))
-    head_words = s["out"] + [pr.const(po2)]
-    claim = v.elems(v.repack(head_words + root_words))
+    return v.elems(v.repack(s["out"] + [pr.const(po2)] + root_words))
+
+
+def build_lift(circuit_desc: np.ndarray, po2: int, control_root: Sequence[int]) -> Program:
+    """Inputs: the segment seal, then A (8 words).  control_root: canonical residues of the segment circuit's code root."""
+    pr = Program()
+    v = Verifier(pr)
+    claim = _segment_claim(v, Circuit.parse(circuit_desc), po2, control_root)
     allowed = v.read(8)
     pr.public(claim[0], claim[1], allowed[0], allowed[1])
+    return pr
+
+
+def build_lift2(circuit_desc: np.ndarray, po2_left: int, root_left: Sequence[int], po2_right: int, root_right: Sequence[int]) -> Program:
+    """lift + lift + join as ONE program: verify two SEGMENT seals, out = hash_pair(claim_l, claim_r) ‖ A.  The bottom level of
+    the join tree then costs one recursion proof per pair of segments instead of three (the statement is the same: the node
+    two lifts and a join would produce).  Inputs: left seal, right seal, A."""
+    c = Circuit.parse(circuit_desc)
+    pr = Program()
+    v = Verifier(pr)
+    left = _segment_claim(v, c, po2_left, root_left)
+    right = _segment_claim(v, c, po2_right, root_right)
+    parent = v.pair(left, right)
+    allowed = v.read(8)
+    pr.public(parent[0], parent[1], allowed[0], allowed[1])
     return pr
 
 
@@ -463,6 +484,6 @@ if __name__ == "__main__":      # python -m zeth_amd.circuits.rec_verify out_dir
     if any(r is None for r in roots.values()):
         raise SystemExit("no shipped control root for SYN-A at po2 20 / 18 (python -m zeth_amd.prover on a GPU box)")
     for kind, blob in host_rec.build_programs(desc, roots):
-        path = os.path.join(out_dir, "-".join(str(x) for x in kind[:3 if kind[0] == "join" else 2]) + ".zkr1")
+        path = os.path.join(out_dir, "-".join(str(x) for x in kind[:2 if kind[0] == "lift" else 3]) + ".zkr1")
         np.asarray(blob, dtype="<u4").tofile(path)
         print(f"{path}: {blob.size} words, po2 {int(blob[2])}")

@@ -261,9 +261,19 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
             }
         };
         const std::vector<uint32_t>& A = s->allowed.back()[0];
-        std::vector<Node> level(n);
+        // bottom level: a pair of segments is ONE proof where the program set has lift2(po2_l, po2_r) (lift + lift + join fused),
+        // else lift, lift (and the pair is joined with the level above); an unpaired last segment is lifted
+        const size_t n_pairs = n / 2;
+        std::vector<char> fused(n_pairs, 0);
+        size_t n_fused = 0;
+        for (size_t k = 0; k < n_pairs; k++)
+            if (program_of(2, segs[2 * k].po2, segs[2 * k + 1].po2) >= 0) { fused[k] = 1; n_fused++; }
+        const bool all_fused = n_fused == n_pairs && n > 1;
+        std::vector<Node> level(all_fused ? n_pairs + n % 2 : n);
         const double tl = now_s();
         {
+            // jobs: all pairs fused -> one job per pair (+ the odd tail); otherwise one lift per segment
+            const size_t n_jobs = level.size();
             std::atomic<size_t> idx{0};
             std::vector<std::thread> th;
             for (auto& lane : s->lanes)
@@ -271,10 +281,18 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
                     std::vector<uint32_t> in;
                     for (;;) {
                         const size_t k = idx.fetch_add(1);
-                        if (k >= n || errs.any()) break;
-                        const int p = program_of(0, segs[k].po2, 0);
-                        if (p < 0) { errs.set(make_err("no lift program for po2-%u segments", segs[k].po2), "lift"); break; }
-                        in.assign(info->seals[k], info->seals[k] + info->seal_words[k]);
+                        if (k >= n_jobs || errs.any()) break;
+                        int p;
+                        if (all_fused && k < n_pairs) {
+                            p = program_of(2, segs[2 * k].po2, segs[2 * k + 1].po2);
+                            in.assign(info->seals[2 * k], info->seals[2 * k] + info->seal_words[2 * k]);
+                            in.insert(in.end(), info->seals[2 * k + 1], info->seals[2 * k + 1] + info->seal_words[2 * k + 1]);
+                        } else {
+                            const size_t i = all_fused ? n - 1 : k;
+                            p = program_of(0, segs[i].po2, 0);
+                            if (p < 0) { errs.set(make_err("no lift program for po2-%u segments", segs[i].po2), "lift"); break; }
+                            in.assign(info->seals[i], info->seals[i] + info->seal_words[i]);
+                        }
                         in.insert(in.end(), A.begin(), A.end());
                         Node& nd = level[k];
                         nd.program = (uint32_t)p; nd.po2 = po2_of((uint32_t)p);
@@ -284,7 +302,8 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
                 });
             for (auto& t : th) t.join();
         }
-        info->n_lifts = n;
+        info->n_joins = 0;
+        info->n_lifts = all_fused ? n_pairs + n % 2 : n;      // proofs of the bottom level (lift2 counts once)
         info->lift_s = now_s() - tl;
         const double tj = now_s();
         while (level.size() > 1 && !errs.any()) {

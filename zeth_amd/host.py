@@ -199,7 +199,8 @@ class Session:
         u32p = C.POINTER(C.c_uint32)
         ptrs = (u32p * len(blobs))(*[b.ctypes.data_as(u32p) for b in blobs])
         words = (C.c_size_t * len(blobs))(*[b.size for b in blobs])
-        kinds = np.array([[0, k[1], k[2]] if k[0] == "lift" else [1, k[1], k[2]] for k, _ in programs], dtype=np.uint32).reshape(-1)
+        code = {"lift": 0, "join": 1, "lift2": 2}
+        kinds = np.array([[code[k[0]], k[1], k[2]] for k, _ in programs], dtype=np.uint32).reshape(-1)
         self._hal._check(self._hal._lib.zkh_session_set_recursion(self.h, self._hal._ptr(rdesc), rdesc.size, ptrs, words, self._hal._ptr(kinds), len(blobs)))
 
     def _specs(self, segments: Sequence[Segment], host_traces=None):

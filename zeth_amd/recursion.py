@@ -84,13 +84,14 @@ class RecReceipt:
 
 
 def build_programs(segment_desc, segment_roots: Optional[Dict[int, np.ndarray]] = None, zk_cycles: int = _hal.ZK_CYCLES,
-                   assumptions: Sequence[Tuple[np.ndarray, Dict[int, np.ndarray]]] = ()) -> List[Tuple[Tuple, np.ndarray]]:
+                   assumptions: Sequence[Tuple[np.ndarray, Dict[int, np.ndarray]]] = (), fused_pairs: bool = True) -> List[Tuple[Tuple, np.ndarray]]:
     """The program set of a block: one lift per segment size (`segment_roots`: {po2: control root of the segment circuit}) and
     per size of every assumption circuit (`assumptions`: [(circuit description, {po2: control root})], e.g. KECCAK-F batches:
     upstream lifts those receipts too and resolves them on the way to the succinct receipt), then joins for every pair of
     child sizes that can meet, until the set of sizes closes (po2-20 / po2-18 SYN-A segments: two lifts at po2 17,
     join(17,17) -> 18, join(17,18), join(18,17), join(18,18) -> 18).  Pure host work, no GPU: [(kind, blob)], kind =
-    ("lift", segment po2, family) with family 0 = the segment circuit, 1.. = the assumption circuits, or ("join", po2_l, po2_r)."""
+    ("lift", segment po2, family) with family 0 = the segment circuit, 1.. = the assumption circuits, ("lift2", po2_l, po2_r) =
+    lift + lift + join fused for a pair of segment receipts (fused_pairs), or ("join", po2_l, po2_r)."""
     rdesc = rc.recursion_circuit()
     out: List[Tuple[Tuple, np.ndarray]] = []
     sizes = set()
@@ -100,10 +101,18 @@ def build_programs(segment_desc, segment_roots: Optional[Dict[int, np.ndarray]] 
         out.append((kind, pr.finish(po2, zk_cycles)))
         sizes.add(po2)
     families = [(segment_desc, segment_roots or {})] + list(assumptions)
+    canon = lambda root: [int(w) * RINV % P for w in np.asarray(root, dtype=np.uint32)]
     for fam, (desc, roots) in enumerate(families):
         desc = np.asarray(desc, dtype=np.uint32)
         for po2, root in sorted(roots.items(), reverse=True):
-            add(("lift", po2, fam), rec_verify.build_lift(desc, po2, [int(w) * RINV % P for w in np.asarray(root, dtype=np.uint32)]))
+            add(("lift", po2, fam), rec_verify.build_lift(desc, po2, canon(root)))
+    if fused_pairs:
+        # lift + lift + join as one program for pairs of SEGMENT receipts (a block's segments come largest first, the short
+        # tail last: pairs (a, b) with a >= b)
+        po2s = sorted(segment_roots or {}, reverse=True)
+        for i, a in enumerate(po2s):
+            for b in po2s[i:]:
+                add(("lift2", a, b), rec_verify.build_lift2(np.asarray(segment_desc, dtype=np.uint32), a, canon(segment_roots[a]), b, canon(segment_roots[b])))
     done = set()
     while True:
         todo = [(a, b) for a in sorted(sizes) for b in sorted(sizes) if (a, b) not in done]
@@ -150,11 +159,32 @@ class Recursion:
         seal, _ = self.programs[i].prove(inputs, _seed(noise_seed))
         return RecReceipt(seal, self.programs[i].po2, i, self.programs[i].root)
 
+    def has_lift2(self, left: SegmentReceipt, right: SegmentReceipt) -> bool:
+        return ("lift2", left.po2, right.po2) in self.kinds
+
+    def lift2(self, left: SegmentReceipt, right: SegmentReceipt, noise_seed: Optional[int] = None) -> RecReceipt:
+        """the node lift(left), lift(right), join would produce, as one proof"""
+        i = self.kinds.index(("lift2", left.po2, right.po2))
+        inputs = np.concatenate([np.asarray(left.seal, dtype=np.uint32), np.asarray(right.seal, dtype=np.uint32), self.allowed_root()])
+        seal, _ = self.programs[i].prove(inputs, _seed(noise_seed))
+        return RecReceipt(seal, self.programs[i].po2, i, self.programs[i].root, 2)
+
     def join(self, left: RecReceipt, right: RecReceipt, noise_seed: Optional[int] = None) -> RecReceipt:
         i = self.kinds.index(("join", left.po2, right.po2))
         inputs = np.concatenate([left.seal, membership_words(self.levels, left.program), right.seal, membership_words(self.levels, right.program)])
         seal, _ = self.programs[i].prove(inputs, _seed(noise_seed))
         return RecReceipt(seal, self.programs[i].po2, i, self.programs[i].root, left.n_leaves + right.n_leaves)
+
+    def fold_segments(self, receipts: Sequence[SegmentReceipt], noise_seed: Optional[int] = None) -> RecReceipt:
+        """segment receipts -> one receipt: the bottom level pairs them with lift2 where the program set has it (else lift, lift,
+        join), an unpaired last receipt is lifted; the tree above is `fold`.  Same tree, same claims as lifting everything."""
+        level: List[RecReceipt] = []
+        for k in range(len(receipts) // 2):
+            a, b = receipts[2 * k], receipts[2 * k + 1]
+            level.append(self.lift2(a, b, noise_seed) if self.has_lift2(a, b) else self.join(self.lift(a, noise_seed), self.lift(b, noise_seed), noise_seed))
+        if len(receipts) % 2:
+            level.append(self.lift(receipts[-1], noise_seed))
+        return self.fold(level, noise_seed)
 
     def fold(self, leaves: Sequence[RecReceipt], noise_seed: Optional[int] = None) -> RecReceipt:
         """the join tree of host.join_schedule / fold_claims: pairs left to right, an unpaired last node moves up unchanged"""
