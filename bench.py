@@ -412,7 +412,9 @@ def main() -> None:
                 jobs.append(lambda ln, a=a, b=b: ln.rec.join(ln.rec.lift(a, BENCH_NOISE), ln.rec.lift(b, BENCH_NOISE), BENCH_NOISE))
         if len(leaves) % 2:
             jobs.append(lambda ln, r=leaves[-1]: ln.rec.lift(r, BENCH_NOISE))
-        level = spread(jobs) if len(leaves) > 1 else spread([lambda ln, r=leaves[0]: ln.rec.lift(r, BENCH_NOISE)])
+        level = spread(jobs)
+        device_sync(lanes)
+        lift_s = time.perf_counter() - t0
         n_joins = 0
         while len(level) > 1:
             nxt = spread([(lambda ln, a=level[2 * k], b=level[2 * k + 1]: ln.rec.join(a, b, BENCH_NOISE)) for k in range(len(level) // 2)])

@@ -289,7 +289,7 @@ def test_segments_and_a_keccak_assumption_fold_into_one_receipt(hal):
     segs = [sp.prove_segment(Segment(index=i, po2=13, seed=60 + i, noise_seed=9)) for i in range(3)]
     krec = kp.prove_segment(Segment(index=0, po2=13, seed=0xCECC, noise_seed=3))
     sroot, kroot = sp.control_root(13), kp.control_root(13)
-    programs = rec.build_programs(sdesc, {13: sroot}, assumptions=[(kdesc, {13: kroot})])
+    programs = rec.build_programs(sdesc, {13: sroot}, assumptions=[(kdesc, {13: kroot})], fused_pairs=False)
     rx = rec.Recursion(hal, programs)
     sizes = sorted({p.po2 for p in rx.programs})
     assert len(programs) <= 16 and len(sizes) >= 3
