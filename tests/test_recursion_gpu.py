@@ -109,6 +109,14 @@ def test_lift_of_a_small_segment_matches_the_oracle_and_rejects_forgeries(hal, o
         forged[k] = (int(forged[k]) + 1) % P
         with pytest.raises(HalError, match="assertion of the program fails"):
             prog.prove(forged)
+    # ... and 300 more words drawn at random: no word of a seal is left unbound by the in-circuit verifier
+    data_buf = hal.alloc_elem("data", R.WD << prog.po2)
+    rng = np.random.default_rng(7)
+    for k in rng.integers(0, n, 300):
+        forged = inputs.copy()
+        forged[k] = (int(forged[k]) + 1 + int(rng.integers(0, P - 1))) % P
+        with pytest.raises(HalError, match="assertion of the program fails"):
+            prog.witgen(forged, data_buf)
     # a seal under another control root (another circuit's code) is not lifted by this program
     other = V.build_lift(desc, cpo2, [(int(w) * RINV + 1) % P for w in croot])
     with pytest.raises(HalError, match="assertion of the program fails"):
