@@ -76,9 +76,12 @@ struct zkh_session {
     std::vector<std::vector<uint32_t>> rec_roots;                 // control root of program i
     std::vector<std::vector<std::vector<uint32_t>>> allowed;       // levels of the allowed-programs tree (8 leaves)
     std::vector<Lane> lanes;
+    std::vector<Lane> fold_lanes;        // extra contexts that only lift / join (zkh_session_set_recursion): the fold packs the GPU with more lanes than the seals need
+    std::vector<Lane*> rec_lanes;        // lanes + fold_lanes
+    size_t lanes_per_device = 0;
     zkh_accumulate_fn accumulate = nullptr;
     void* accumulate_user = nullptr;
-    ~zkh_session() { for (auto& l : lanes) l.close(); }
+    ~zkh_session() { for (auto& l : fold_lanes) l.close(); for (auto& l : lanes) l.close(); }
 };
 
 extern "C" const char* zkh_session_create(const int* devices, size_t n_devices, size_t lanes_per_device, const uint32_t* desc, size_t desc_words,
@@ -89,6 +92,7 @@ extern "C" const char* zkh_session_create(const int* devices, size_t n_devices, 
     s->desc.assign(desc, desc + desc_words);
     if (join_desc) s->join_desc.assign(join_desc, join_desc + join_desc_words);
     s->lanes.resize(n_devices * lanes_per_device);
+    s->lanes_per_device = lanes_per_device;
     for (size_t i = 0; i < s->lanes.size(); i++) {
         Lane& l = s->lanes[i];
         l.device = devices[i / lanes_per_device];
@@ -127,7 +131,23 @@ extern "C" const char* zkh_session_set_recursion(zkh_session* s, const uint32_t*
     ZKH_REQUIRE(s && rec_desc && rec_desc_words >= 16 && blobs && words && kinds && n_programs && n_programs <= REC_ALLOWED, "session_set_recursion: bad argument");
     ZKH_REQUIRE(s->rec_kinds.empty(), "session_set_recursion: the session already has its programs");
     s->rec_desc.assign(rec_desc, rec_desc + rec_desc_words);
-    for (auto& l : s->lanes) {
+    // a lift's / join's witness schedule is a chain of ~300 dependency levels (latency): the fold runs on ZKH_FOLD_LANES lanes
+    // per device (default 6: the measured knee, profiles/r03_recursion_fold_lanes.txt), the sealing lanes plus extra contexts
+    const char* env = getenv("ZKH_FOLD_LANES");
+    const size_t want = env ? (size_t)strtoul(env, nullptr, 10) : 6;
+    const size_t n_devices = s->lanes.size() / s->lanes_per_device;
+    if (want > s->lanes_per_device) {
+        s->fold_lanes.resize(n_devices * (want - s->lanes_per_device));
+        for (size_t i = 0; i < s->fold_lanes.size(); i++) {
+            Lane& l = s->fold_lanes[i];
+            l.device = s->lanes[(i / (want - s->lanes_per_device)) * s->lanes_per_device].device;
+            ZKH_TRY(zkh_ctx_create(l.device, "poseidon2", &l.ctx));
+        }
+    }
+    for (auto& l : s->lanes) s->rec_lanes.push_back(&l);
+    for (auto& l : s->fold_lanes) s->rec_lanes.push_back(&l);
+    for (Lane* lp : s->rec_lanes) {
+        Lane& l = *lp;
         ZKH_TRY(zkh_circuit_load(l.ctx, s->rec_desc.data(), s->rec_desc.size(), &l.rec_circuit));
         for (size_t i = 0; i < n_programs; i++) {
             zkh_rec_program* p = nullptr;
@@ -276,8 +296,8 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
             const size_t n_jobs = level.size();
             std::atomic<size_t> idx{0};
             std::vector<std::thread> th;
-            for (auto& lane : s->lanes)
-                th.emplace_back([&, l = &lane] {
+            for (Lane* lane : s->rec_lanes)
+                th.emplace_back([&, l = lane] {
                     std::vector<uint32_t> in;
                     for (;;) {
                         const size_t k = idx.fetch_add(1);
@@ -311,8 +331,8 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
             std::vector<Node> up(pairs);
             std::atomic<size_t> idx{0};
             std::vector<std::thread> th;
-            for (auto& lane : s->lanes)
-                th.emplace_back([&, l = &lane] {
+            for (Lane* lane : s->rec_lanes)
+                th.emplace_back([&, l = lane] {
                     std::vector<uint32_t> in;
                     for (;;) {
                         const size_t k = idx.fetch_add(1);
