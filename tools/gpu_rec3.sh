@@ -1,4 +1,4 @@
-# the native host (g++ only) running BASELINE config 5 with in-circuit verification, from program files; kernel stats of the fold
+# the native host (g++ only) running BASELINE config 5 with in-circuit verification, from program files
 set -u
 O=gpurun_out/rec; mkdir -p $O
 export TMPDIR=/tmp
@@ -8,8 +8,4 @@ python -m zeth_amd.circuits.recursion $D/recursion.desc >> $O/programs.txt 2>&1
 python -m zeth_amd.circuits.syn_air syn_a $D/syn_a.desc >> $O/programs.txt 2>&1
 export LD_LIBRARY_PATH=$PWD/zeth_amd:${LD_LIBRARY_PATH:-}
 timeout 900 examples/prove_session --desc $D/syn_a.desc --recursion-dir $D --segments ${1:-1024} > $O/prove_session_recursion.json 2> $O/prove_session_recursion.err
-cat $O/prove_session_recursion.json; tail -n 3 $O/prove_session_recursion.err
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/rec/prof_fold -o fold -- $OLDPWD/examples/prove_session --desc $D/syn_a.desc --recursion-dir $D --segments 64 --inflight 1 > /dev/null 2> $OLDPWD/gpurun_out/rec/prof.err; cd $OLDPWD
-find $O/prof_fold -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/fold_kernel_stats.csv
-head -25 $O/fold_kernel_stats.csv | cut -c1-150
-rm -rf $O/prof_fold
+echo "rc=$?"; cat $O/prove_session_recursion.json; tail -n 3 $O/prove_session_recursion.err
