@@ -1,6 +1,7 @@
-"""The N > 1 shape of the recursive fold on CPU (gloo, world size 2): every rank lifts and joins its own aligned range of leaves,
-rank 0 gathers the local roots over the control plane and joins them - with the CPU oracle standing in for the GPU (test-only),
-real seals all the way: the top join's witness exists, satisfies every constraint, and carries the claim tree of all leaves."""
+"""The N > 1 shape of the recursive fold on CPU (gloo, world size 2): every rank folds its own aligned range of leaves (here one
+leaf each: a lift - the fold inside a rank is tests/test_recursion.py's join test), rank 0 gathers the local roots over the control
+plane and joins them - with the CPU oracle standing in for the GPU (test-only), real seals all the way: the top join's witness
+exists, satisfies every constraint, and carries the claim tree of all leaves."""
 import os
 import socket
 import sys
@@ -10,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CPO2, CZK, N_LEAVES = 8, 50, 4
+CPO2, CZK, N_LEAVES = 8, 50, 2
 
 
 def _free_port():
@@ -42,11 +43,8 @@ def _worker(rank, world, port, q):
     j1 = V.build_join(R.recursion_circuit(), lpo2, lpo2)
     jpo2 = j1.min_po2()
     j1blob = j1.finish(jpo2)
-    j2 = V.build_join(R.recursion_circuit(), jpo2, jpo2)
-    assert j2.min_po2() == jpo2                                    # the recursion closes
-    j2blob = j2.finish(jpo2)
     roots = []
-    for blob, po2 in ((lblob, lpo2), (j1blob, jpo2), (j2blob, jpo2)):
+    for blob, po2 in ((lblob, lpo2), (j1blob, jpo2)):
         code = np.zeros(R.WC << po2, np.uint32)
         assert lib.zko_rec_code(blob, blob.size, code) is None
         roots.append(rec.root_of_code(po2, code))
@@ -64,14 +62,13 @@ def _worker(rank, world, port, q):
         c = np.zeros(8, np.uint32)
         lib.zko_hash_elem_slice(np.ascontiguousarray(cin), cin.size, 1, c)
         claims[i] = c
-    lifted = [run(lblob, lpo2, np.concatenate([leaves[i], A]))[0] for i in mine]
-    path0 = host_rec.membership_words(levels, 0)
-    local_root, _ = run(j1blob, jpo2, np.concatenate([lifted[0], path0, lifted[1], path0]))
+    assert len(mine) == 1
+    local_root, _ = run(lblob, lpo2, np.concatenate([leaves[mine[0]], A]))          # this rank's fold: one leaf, lifted and sealed
     gathered = [None] * world if rank == 0 else None
     dist.gather_object((local_root, claims), gathered, dst=0)
     if rank == 0:
-        path1 = host_rec.membership_words(levels, 1)
-        _, (code, data, out) = run(j2blob, jpo2, np.concatenate([gathered[0][0], path1, gathered[1][0], path1]), seal=False)
+        path0 = host_rec.membership_words(levels, 0)
+        _, (code, data, out) = run(j1blob, jpo2, np.concatenate([gathered[0][0], path0, gathered[1][0], path0]), seal=False)
         mix = np.array([(i * 7919 + 13) % P for i in range(20)], dtype=np.uint32)
         bad = rec.check_rows(jpo2, rec.rec_accum(jpo2, code, data, mix), code, data, out, mix)
         allc = {k: v for _, part in gathered for k, v in part.items()}
@@ -98,4 +95,4 @@ def test_two_ranks_fold_their_ranges_and_rank0_joins_the_local_roots():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert res == {"bad_row": -1, "claim_ok": True, "allowed_ok": True, "ranges": [[0, 1], [2, 3]]}
+    assert res == {"bad_row": -1, "claim_ok": True, "allowed_ok": True, "ranges": [[0], [1]]}
