@@ -951,7 +951,7 @@ def main() -> None:
             if distributed:
                 parts = [None] * world if rank == 0 else None
                 dist.gather_object(mine_claims, parts, dst=0)
-            if rank == 0 and root is not None and S > 1:
+            if rank == 0 and root is not None and (S > 1 or recursive):
                 import numpy as np
                 allc = {k: v for part in parts for k, v in part.items()}
                 follows = bool(np.array_equal(root.seal[:8], fold_claims([allc[i] for i in range(S)])))
