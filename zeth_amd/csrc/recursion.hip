@@ -41,7 +41,9 @@ __device__ __forceinline__ Fp4 ld(const uint4* val, uint32_t v) {
 __device__ __forceinline__ void st(uint4* val, uint32_t v, const Fp4& x) { val[v] = make_uint4(x.c[0].v, x.c[1].v, x.c[2].v, x.c[3].v); }
 __device__ __forceinline__ uint32_t comp(const uint4& x, uint32_t j) { return j == 0 ? x.x : j == 1 ? x.y : j == 2 ? x.z : x.w; }
 
-// one op of the witness schedule (any but a cooperative permutation)
+// one op of the witness schedule; WITH_P2: a permutation on ONE lane is among them (the wide-level kernel; the persistent runs
+// give permutations eight lanes and leave the single-lane form, with its ~90 live registers, out of their budget)
+template <bool WITH_P2>
 __device__ __forceinline__ void rec_exec_op(const uint32_t* __restrict__ o, uint4* val, const uint32_t* __restrict__ consts,
                                             const uint32_t* __restrict__ inputs, uint32_t* fail, const uint32_t* __restrict__ rc,
                                             const uint32_t* __restrict__ diag) {
@@ -96,13 +98,13 @@ __device__ __forceinline__ void rec_exec_op(const uint32_t* __restrict__ o, uint
         for (uint32_t t = 0; t < 31; t++) val[out + t] = make_uint4(((x >> t) & 1) ? R1 : 0u, 0, 0, 0);
         break;
     }
-    case RO_P2: {                              // one lane, the lazily reduced form of hash.hip (levels wide enough to fill the chip)
+    case RO_P2: if (WITH_P2) {                 // one lane, the lazily reduced form of hash.hip (levels wide enough to fill the chip)
         uint32_t s[CELLS];
         for (uint32_t w = 0; w < RC_NW; w++) { const uint4 x = val[o[2 + w]]; s[4 * w] = x.x; s[4 * w + 1] = x.y; s[4 * w + 2] = x.z; s[4 * w + 3] = x.w; }
         poseidon2_mix(s, rc, diag);
         for (uint32_t w = 0; w < RC_NW; w++) val[out + w] = make_uint4(s[4 * w], s[4 * w + 1], s[4 * w + 2], s[4 * w + 3]);
         break;
-    }
+    } else { atomicMin(fail, 1u); break; }
     case RO_EQ: {
         const uint4 a = val[o[2]], b = val[o[3]];
         if (a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w) atomicMin(fail, o[7]);
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(64) void k_rec_level(const uint32_t* __restrict__ o
                                                   const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
     const uint32_t i = lo + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= hi) return;
-    rec_exec_op(ops + (size_t)RC_OP_WORDS * i, val, consts, inputs, fail, rc, diag);
+    rec_exec_op<true>(ops + (size_t)RC_OP_WORDS * i, val, consts, inputs, fail, rc, diag);
 }
 // A RUN of narrow levels [l0, l1) in ONE workgroup of 1024 lanes: the level chain of a verifier (the transcript sponge, the
 // Horner and constraint chains) is hundreds of levels a few ops wide, and a launch per level costs ~10 us each.  Here a level is
@@ -132,23 +134,48 @@ __global__ __launch_bounds__(1024) void k_rec_run(const uint32_t* __restrict__ o
     for (uint32_t w = threadIdx.x; w < ROUNDS_TOTAL * CELLS; w += blockDim.x) rcs[w] = rc[w];
     __syncthreads();
     const uint32_t t = threadIdx.x;
-    for (uint32_t l = l0; l < l1; l++) {
-        const uint4 r = lv[l];
+    // what this lane does in a level: nothing, op `i` on its own, or lane `j` of the permutation `i`; the op record (two uint4)
+    // of the NEXT level is fetched while the current one executes - the schedule is static, only `val` carries dependencies
+    auto role = [&](const uint4 r, uint32_t& i, bool& p2, bool& live) -> bool {
         const uint32_t n_a = r.y - r.x, n_other = n_a + (r.w - r.z), first_p2 = (n_other + 63) & ~63u, n_p2 = r.z - r.y;
-        if (t < n_other) {
-            const uint32_t i = t < n_a ? r.x + t : r.z + (t - n_a);
-            rec_exec_op(ops + (size_t)RC_OP_WORDS * i, val, consts, inputs, fail, rc, diag);
-        } else if (t >= first_p2 && ((t - first_p2) >> 6) * 8 < n_p2) {          // wave-uniform: waves with at least one permutation
-            const uint32_t g = (t - first_p2) >> 3, j = t & 7;
-            const bool live = g < n_p2;
-            const uint32_t* o = ops + (size_t)RC_OP_WORDS * (r.y + (live ? g : n_p2 - 1));
-            uint32_t c[4] = {0, 0, 0, 0};
-            if (j < 6) { const uint4 x = val[o[2 + j]]; c[0] = x.x; c[1] = x.y; c[2] = x.z; c[3] = x.w; }
-            wide_permute(c, j, rcs, diag);
-            if (live && j < 6) val[o[1] + j] = make_uint4(c[0], c[1], c[2], c[3]);
+        p2 = false; live = true;
+        if (t < n_other) { i = t < n_a ? r.x + t : r.z + (t - n_a); return true; }
+        if (t >= first_p2 && ((t - first_p2) >> 6) * 8 < n_p2) {                 // wave-uniform: waves with at least one permutation
+            const uint32_t g = (t - first_p2) >> 3;
+            p2 = true; live = g < n_p2;
+            i = r.y + (live ? g : n_p2 - 1);
+            return true;
+        }
+        return false;
+    };
+    const uint4* ops4 = (const uint4*)ops;
+    uint32_t i = 0;
+    bool p2 = false, live = false;
+    bool busy = role(lv[l0], i, p2, live);
+    uint4 oa = make_uint4(0, 0, 0, 0), ob = oa;
+    if (busy) { oa = ops4[2 * (size_t)i]; ob = ops4[2 * (size_t)i + 1]; }
+    for (uint32_t l = l0; l < l1; l++) {
+        uint32_t ni = 0;
+        bool np2 = false, nlive = false, nbusy = false;
+        uint4 na = make_uint4(0, 0, 0, 0), nb = na;
+        if (l + 1 < l1) {
+            nbusy = role(lv[l + 1], ni, np2, nlive);
+            if (nbusy) { na = ops4[2 * (size_t)ni]; nb = ops4[2 * (size_t)ni + 1]; }
+        }
+        if (busy) {
+            const uint32_t o[RC_OP_WORDS] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
+            if (!p2) rec_exec_op<false>(o, val, consts, inputs, fail, rc, diag);
+            else {
+                const uint32_t j = t & 7;
+                uint32_t c[4] = {0, 0, 0, 0};
+                if (j < 6) { const uint4 x = val[o[2 + j]]; c[0] = x.x; c[1] = x.y; c[2] = x.z; c[3] = x.w; }
+                wide_permute(c, j, rcs, diag);
+                if (live && j < 6) val[o[1] + j] = make_uint4(c[0], c[1], c[2], c[3]);
+            }
         }
         __threadfence_block();
         __syncthreads();
+        busy = nbusy; i = ni; p2 = np2; live = nlive; oa = na; ob = nb;
     }
 }
 // the permutations of a wide level, eight lanes each
