@@ -294,7 +294,9 @@ const char* zkh_receipt_decode(const zkh_circuit*, const uint32_t* blob, size_t 
  * zkh_rec_program_load validates the blob, sorts its witness schedule into dependency levels, uploads it, generates the code
  * group and commits it (resident); `circuit` = the RECURSION description loaded on the same context.  zkh_rec_prove runs the
  * program on `inputs` (raw Montgomery words: the child seal(s) and the program's other witness words), which FAILS unless every
- * assertion of the in-circuit verifier holds, and seals the trace; out_global (16 words) = claim (8) ‖ allowed-programs root. */
+ * assertion of the in-circuit verifier holds, and seals the trace; out_global (16 words) = claim (8) ‖ allowed-programs root.
+ * A program handle owns its witness buffers and the hipGraph of its schedule: one zkh_rec_witgen / zkh_rec_prove at a time per
+ * handle (every lane loads its own). */
 typedef struct zkh_rec_program zkh_rec_program;
 const char* zkh_rec_program_load(zkh_ctx*, const zkh_circuit* circuit, const uint32_t* blob, size_t words, zkh_rec_program** out);
 void zkh_rec_program_destroy(zkh_rec_program*);

@@ -368,15 +368,23 @@ struct zkh_rec_program {
     struct Step { uint32_t l0, l1; bool run; };
     std::vector<Step> plan;                        // runs of narrow levels (one launch) and single wide levels
     zkh_buf* d_lv = nullptr;
+    // the witness schedule as a hipGraph: the launches of `plan` with this program's own value / input / failure buffers as
+    // constant arguments, instantiated once at load and replayed per witness (one graph launch instead of ~130 kernel launches)
+    zkh_buf *d_val = nullptr, *d_in = nullptr, *d_fail = nullptr;
+    hipGraphExec_t graph = nullptr;
     uint32_t root[8] = {0};
     uint64_t hash = 0;
 };
 
+// the launches of one witness schedule on the context's stream (directly, or while the stream is being captured into a graph)
+static void rec_enqueue_schedule(const zkh_rec_program* p, uint4* v, const uint32_t* din, uint32_t* fail, bool per_level);
+
 extern "C" void zkh_rec_program_destroy(zkh_rec_program* p) {
     if (!p) return;
     if (p->ctx) bind_thread(p->ctx);
+    if (p->graph) (void)hipGraphExecDestroy(p->graph);
     if (p->prover) zkh_prover_destroy(p->prover);
-    for (zkh_buf* b : {p->d_table, p->d_pos, p->d_consts, p->d_ops, p->d_tab, p->d_lv}) if (b) zkh_release(b);
+    for (zkh_buf* b : {p->d_table, p->d_pos, p->d_consts, p->d_ops, p->d_tab, p->d_lv, p->d_val, p->d_in, p->d_fail}) if (b) zkh_release(b);
     delete p;
 }
 
@@ -385,6 +393,27 @@ static const char* rec_check_shape(const zkh_circuit* c) {
                 c->global_size[GLOBAL_OUT] == 16 && c->global_size[GLOBAL_MIX] == 20,
                 "recursion: the circuit does not have RECURSION's shape (kind 4: 57 / 72 / 12 columns, 16 outputs, 20 mix words)");
     return nullptr;
+}
+
+static void rec_enqueue_schedule(const zkh_rec_program* p, uint4* v, const uint32_t* din, uint32_t* fail, bool per_level) {
+    zkh_ctx* c = p->ctx;
+    for (const auto& st : p->plan) {
+        if (st.run && !per_level) {
+            k_rec_run<<<1, 1024, 0, c->stream>>>(p->d_ops->ptr(), (const uint4*)p->d_lv->ptr(), st.l0, st.l1, v, p->d_consts->ptr(), din, fail,
+                                                 c->tab.rc, c->tab.diag);
+            continue;
+        }
+        for (uint32_t l = st.l0; l < st.l1; l++) {
+            const uint32_t lo = p->lv[4 * l], a = p->lv[4 * l + 1], b = p->lv[4 * l + 2], hi = p->lv[4 * l + 3];
+            if (per_level) {
+                if (hi > lo) k_rec_level<<<(hi - lo + 63) / 64, 64, 0, c->stream>>>(p->d_ops->ptr(), lo, hi, v, p->d_consts->ptr(), din, fail, c->tab.rc, c->tab.diag);
+                continue;
+            }
+            if (a > lo) k_rec_level<<<(a - lo + 63) / 64, 64, 0, c->stream>>>(p->d_ops->ptr(), lo, a, v, p->d_consts->ptr(), din, fail, c->tab.rc, c->tab.diag);
+            if (hi > b) k_rec_level<<<(hi - b + 63) / 64, 64, 0, c->stream>>>(p->d_ops->ptr(), b, hi, v, p->d_consts->ptr(), din, fail, c->tab.rc, c->tab.diag);
+            if (b > a) k_rec_p2_wide<<<(8 * (b - a) + 255) / 256, 256, 0, c->stream>>>(p->d_ops->ptr(), a, b, v, c->tab.rc, c->tab.diag);
+        }
+    }
 }
 
 extern "C" const char* zkh_rec_code(const zkh_rec_program* p, zkh_buf* code) {
@@ -497,6 +526,22 @@ extern "C" const char* zkh_rec_program_load(zkh_ctx* ctx, const zkh_circuit* cir
     ZKH_TRY(zkh_copy_from(ctx, "rec_ops", sorted.data(), sorted.size(), &p->d_ops));
     ZKH_TRY(zkh_copy_from(ctx, "rec_tab", tab.data(), tab.size(), &p->d_tab));
     ZKH_TRY(zkh_copy_from(ctx, "rec_lv", p->lv.data(), p->lv.size(), &p->d_lv));
+    ZKH_TRY(new_buf(ctx, 4 * (size_t)(p->n_vars ? p->n_vars : 1), false, &p->d_val));
+    ZKH_TRY(new_buf(ctx, p->n_inputs ? p->n_inputs : 1, true, &p->d_in));
+    ZKH_TRY(new_buf(ctx, 1, true, &p->d_fail));
+    if (!getenv("ZKH_REC_NO_GRAPH")) {
+        // capture the schedule once; a failed capture (or instantiate) leaves `graph` null and the launches direct
+        ZKH_HIP(hipStreamSynchronize(ctx->stream));
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            rec_enqueue_schedule(p.get(), (uint4*)p->d_val->ptr(), p->d_in->ptr(), p->d_fail->ptr(), false);
+            if (hipStreamEndCapture(ctx->stream, &g) == hipSuccess && g) {
+                if (hipGraphInstantiate(&p->graph, g, nullptr, nullptr, 0) != hipSuccess) p->graph = nullptr;
+                (void)hipGraphDestroy(g);
+            }
+        }
+        (void)hipGetLastError();
+    }
     p->hash = desc_hash64(b, words);
     // the code group: generated, committed, resident
     ZKH_TRY(zkh_prover_create(ctx, circuit, &p->prover));
@@ -531,31 +576,19 @@ extern "C" const char* zkh_rec_witgen(const zkh_rec_program* p, const uint32_t* 
     zkh_ctx* c = p->ctx;
     const size_t n = (size_t)1 << p->po2;
     ZKH_REQUIRE(data->len == (size_t)RC_WD * n, "rec_witgen: buffer shape mismatch");
-    Tmp val, din, fail, pub;
-    ZKH_TRY(new_buf(c, 4 * (size_t)(p->n_vars ? p->n_vars : 1), false, val.out()));
-    const uint32_t zero = 0, none = 0xffffffffu;
-    ZKH_TRY(zkh_copy_from(c, "rec_inputs", n_inputs ? inputs : &zero, n_inputs ? n_inputs : 1, din.out()));
-    ZKH_TRY(zkh_copy_from(c, "rec_fail", &none, 1, fail.out()));
+    Tmp pub;
+    zkh_buf *val = p->d_val, *fail = p->d_fail;
+    const uint32_t none = 0xffffffffu;
+    if (n_inputs) ZKH_TRY(zkh_write(c, p->d_in, inputs, 0, n_inputs));
+    ZKH_TRY(zkh_write(c, p->d_fail, &none, 0, 1));
     {
         ProfScope prof(c, "rec_exec", 16.0 * p->n_vars);
         static const bool per_level = getenv("ZKH_REC_PER_LEVEL") != nullptr;       // A/B: one launch per level, one lane per op
-        uint4* v = (uint4*)val->ptr();
-        for (const auto& st : p->plan) {
-            if (st.run && !per_level) {
-                k_rec_run<<<1, 1024, 0, c->stream>>>(p->d_ops->ptr(), (const uint4*)p->d_lv->ptr(), st.l0, st.l1, v, p->d_consts->ptr(), din->ptr(),
-                                                     fail->ptr(), c->tab.rc, c->tab.diag);
-                continue;
-            }
-            for (uint32_t l = st.l0; l < st.l1; l++) {
-                const uint32_t lo = p->lv[4 * l], a = p->lv[4 * l + 1], b = p->lv[4 * l + 2], hi = p->lv[4 * l + 3];
-                if (per_level) {
-                    if (hi > lo) k_rec_level<<<(hi - lo + 63) / 64, 64, 0, c->stream>>>(p->d_ops->ptr(), lo, hi, v, p->d_consts->ptr(), din->ptr(), fail->ptr(), c->tab.rc, c->tab.diag);
-                    continue;
-                }
-                if (a > lo) k_rec_level<<<(a - lo + 63) / 64, 64, 0, c->stream>>>(p->d_ops->ptr(), lo, a, v, p->d_consts->ptr(), din->ptr(), fail->ptr(), c->tab.rc, c->tab.diag);
-                if (hi > b) k_rec_level<<<(hi - b + 63) / 64, 64, 0, c->stream>>>(p->d_ops->ptr(), b, hi, v, p->d_consts->ptr(), din->ptr(), fail->ptr(), c->tab.rc, c->tab.diag);
-                if (b > a) k_rec_p2_wide<<<(8 * (b - a) + 255) / 256, 256, 0, c->stream>>>(p->d_ops->ptr(), a, b, v, c->tab.rc, c->tab.diag);
-            }
+        if (p->graph && !per_level) {
+            const hipError_t e = hipGraphLaunch(p->graph, c->stream);
+            if (e != hipSuccess) return make_err("rec_witgen: hipGraphLaunch: %s", hipGetErrorString(e));
+        } else {
+            rec_enqueue_schedule(p, (uint4*)p->d_val->ptr(), p->d_in->ptr(), p->d_fail->ptr(), per_level);
         }
     }
     ZKH_TRY(last_launch_error("rec_exec"));
