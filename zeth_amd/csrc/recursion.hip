@@ -556,6 +556,8 @@ extern "C" const char* zkh_rec_program_load(zkh_ctx* ctx, const zkh_circuit* cir
     return nullptr;
 }
 
+extern "C" int zkh_rec_program_has_graph(const zkh_rec_program* p) { return p && p->graph ? (int)p->plan.size() : 0; }
+
 extern "C" const char* zkh_rec_program_info(const zkh_rec_program* p, uint32_t root[8], uint32_t info[8]) {
     ZKH_REQUIRE(p, "rec_program_info: null program");
     if (root) memcpy(root, p->root, 32);

@@ -133,6 +133,7 @@ ABI = {
     "zkh_rec_program_load": (_err, [_vp, _vp, _u32p, _sz, C.POINTER(_vp)]),
     "zkh_rec_program_destroy": (None, [_vp]),
     "zkh_rec_program_info": (_err, [_vp, _u32p, _u32p]),
+    "zkh_rec_program_has_graph": (_i, [_vp]),
     "zkh_rec_code": (_err, [_vp, _vp]),
     "zkh_rec_witgen": (_err, [_vp, _u32p, _sz, _u64, _vp, _u32p]),
     "zkh_rec_accum": (_err, [_vp, _u64, _vp, _u32p, _vp]),
@@ -346,6 +347,7 @@ class RecProgram:
         _check(_lib.zkh_rec_program_info(h, _ptr(root), _ptr(info)))
         self.root = root
         self.po2, self.zk_cycles, self.n_inputs, self.n_p2, self.n_gates, self.n_ops, self.n_levels, self.n_vars = (int(x) for x in info)
+        self.graph_steps = int(_lib.zkh_rec_program_has_graph(h))       # > 0: the witness schedule is a hipGraph of that many plan steps
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
