@@ -186,6 +186,21 @@ def test_block_of_segments_folds_to_one_receipt_that_verified_every_child_in_cir
     wrong = rec.RecReceipt(lifted[1].seal, lifted[1].po2, 2, lifted[1].control_root)     # membership path of another program
     with pytest.raises(HalError, match="assertion of the program fails"):
         rx.join(lifted[0], wrong)
+    # the BASELINE shape against the oracle: the lift of a po2-20 SYN-A seal - the device's witness (72 x 2^17 words), its copy
+    # argument and its seal are the CPU oracle's, word for word
+    import zko
+    oc = zko.OracleCircuit(zko.load(), R.recursion_circuit())
+    blob20 = programs[0][1]
+    inputs = np.concatenate([leaves[0].seal, rx.allowed_root()])
+    ocode, odata, oout = oc.rec_witgen(blob20, inputs, noise_seed=7)
+    p20 = rx.programs[0]
+    n17 = 1 << p20.po2
+    data_buf, accum_buf = hal.alloc_elem("data", R.WD * n17), hal.alloc_elem("accum", R.WA * n17)
+    assert np.array_equal(p20.witgen(inputs, data_buf, 7), oout) and np.array_equal(data_buf.to_vec(), odata)
+    mix = np.array([(i * 104729 + 7) * RM % P for i in range(20)], dtype=np.uint32)
+    p20.accum(data_buf, mix, accum_buf, 7)
+    assert np.array_equal(accum_buf.to_vec(), oc.rec_accum(p20.po2, ocode, odata, mix, ZK, 7))
+    assert np.array_equal(lifted[0].seal, oc.prove_traces(p20.po2, ocode, odata, oout, ZK, 7))
     line = {"config": "succinct, recursive", "segments": 5, "segment_s": round(t_seg, 3), "program_load_s": round(t_load, 2),
             "lift_s_each": round(t_lift / 5, 4), "join_s_each": round(t_join / 4, 4), "fold_s_9_proofs": round(t_lift + t_join, 4),
             "fold_s_fused_5_proofs": round(t_fused, 4),
