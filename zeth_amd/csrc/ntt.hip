@@ -630,6 +630,9 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
         // 4096-element tile allows (a 1..3-bit top pass then moves 2..8 KiB contiguous runs)
         const bool reg_high = ps.L >= 4 && (ps.R == 8 || ps.R == 10);
         p.log_t = ps.L == 0 ? 0 : (ps.L < 4 ? ps.L : 4);
+        // the generic kernel on a strided pass: 4096-element tiles, i.e. runs of 2^(12 - R) consecutive words (a 1..3-bit top pass
+        // at 2^21 / 2^23 / 2^24 then streams 2..8 KiB runs; with 16-word runs it moved 64 elements per workgroup: 0.6 TB/s)
+        if (ps.L != 0 && !reg_high && ps.R < 12) p.log_t = std::max<uint32_t>(p.log_t, std::min<uint32_t>(ps.L, 12 - ps.R));
         static const bool narrow = getenv("ZKH_NTT_NARROW") != nullptr;        // A/B: 32-byte runs, 512-lane workgroups (profiles/r03_ntt_matrix.txt)
         const bool narrow_here = narrow && lazy && reg_high && ps.R == 10 && !fwd_matrix;
         if (narrow_here) p.log_t = 3;
