@@ -16,5 +16,6 @@ timeout 900 python bench.py --config succinct --no-fused-lift > $O/bench_succinc
 timeout 900 python bench.py --config succinct --join-circuit p2_join > $O/bench_succinct_p2join.json 2>> $O/bench_succinct_recursion.err
 ( cd /tmp && LD_LIBRARY_PATH=$OLDPWD/zeth_amd timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/prof_fold -o fold -- $OLDPWD/examples/prove_session --desc /tmp/syn_a.desc --recursion-dir $D --segments 64 --inflight 1 > /dev/null 2>&1 )
 find $O/prof_fold -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/fold_kernel_stats.csv; rm -rf $O/prof_fold
+bash tools/gpu_big.sh > $O/big.txt 2>&1; cp gpurun_out/big/bench_po2_21.json $O/bench_po2_21.json; cp gpurun_out/big/bench_po2_22.json $O/bench_po2_22.json
 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/bench_default.time; tail -1 $O/smoke.log > $O/smoke.txt
-tail -3 $O/pytest.log; cat $O/bench_default.time; cat $O/smoke.txt; cat $O/prove_session_recursion_1024.json; head -8 $O/fold_kernel_stats.csv | cut -c1-160; head -c 300 $O/bench_default.json; echo; head -c 200 $O/bench_8rank.json; echo; cat $O/prove_session_256.json
+tail -3 $O/pytest.log; cat $O/bench_default.time; grep -v amdgpu $O/big.txt; cat $O/smoke.txt; cat $O/prove_session_recursion_1024.json; head -8 $O/fold_kernel_stats.csv | cut -c1-160; head -c 300 $O/bench_default.json; echo; head -c 200 $O/bench_8rank.json; echo; cat $O/prove_session_256.json
