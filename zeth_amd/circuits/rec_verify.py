@@ -41,7 +41,8 @@ def bitrev4(i: int) -> int:
 
 
 class Sponge:
-    """ReadIop's copy of the Fiat-Shamir sponge (verify/read_iop.rs + poseidon2/rng.rs): 24 cells = 6 packed wires"""
+    """ReadIop's copy of the Fiat-Shamir sponge (csrc/verifier.hip:50-77 = risc0-zkp verify/read_iop.rs + poseidon2/rng.rs):
+    24 cells = 6 packed wires; commit adds a digest into cells 0..7 and mixes, elem squeezes the next rate cell"""
 
     def __init__(self, pr: Program):
         self.pr = pr
@@ -99,7 +100,8 @@ class Verifier:
 
     # ---- hashing
     def elems(self, wires: Sequence[int]) -> List[int]:
-        """hash_elem_slice over the words of the packed wires (whole sponge blocks of 4 wires; missing wires are zero)"""
+        """hash_elem_slice (csrc/verifier.hip:28-42) over the words of the packed wires: whole sponge blocks of 4 wires, the rate is
+        overwritten, the capacity carried; missing wires are zero"""
         pr, z = self.pr, self.pr.zero()
         cap = [z, z]
         blocks = max(1, (len(wires) + 3) // 4)
@@ -114,7 +116,7 @@ class Verifier:
         z = self.pr.zero()
         return self.pr.p2([a[0], a[1], b[0], b[1], z, z])[:2]
 
-    # ---- MerkleTreeVerifier
+    # ---- MerkleTreeVerifier (csrc/verifier.hip:81-117 = risc0-zkp verify/merkle.rs)
     def tree_init(self, rows: int, cols: int) -> dict:
         layers = log2_ceil(rows)
         top_layer = 0
@@ -170,7 +172,8 @@ class Verifier:
         return acc
 
     def poly_ext(self, c: Circuit, poly_mix: int, u: Sequence[int], out_words: Sequence[int], mix_words: Sequence[int]) -> int:
-        """PolyExtStepDef::step over ExtElem (adapter.rs): -> the constraint polynomial's value"""
+        """PolyExtStepDef::step over ExtElem (csrc/verifier.hip:125-144 = risc0-zkp adapter.rs): -> the constraint polynomial's value.
+        A MixState's `mul` is a static power of poly_mix, so only `tot` needs wires."""
         pr = self.pr
         fv: List[int] = []
         mv: List[Tuple[Optional[int], int]] = []                 # (tot wire or None for zero, static exponent of poly_mix)
@@ -213,7 +216,8 @@ class Verifier:
         return tot if tot is not None else pr.zero()
 
     def fold_eval(self, v: List[int], mxn: Sequence[int], inv_wk: int) -> int:
-        """verify/fri.rs fold_eval: 16 evaluations on a coset -> the folded polynomial's value.  mxn[i] = mix^i / 16."""
+        """fold_eval (csrc/verifier.hip:146-169 = risc0-zkp verify/fri.rs): 16 evaluations on a coset -> the folded polynomial's value:
+        a 16-point inverse NTT with constant twiddles, then sum_i c_bitrev(i) (inv_wk mix)^i / 16.  mxn[i] = mix^i / 16."""
         pr = self.pr
         v = list(v)
         for N in (4, 3, 2, 1):
@@ -235,7 +239,7 @@ class Verifier:
                 tot = pr.muladd(pr.mul(ci, mw), mxn[i], tot)
         return tot
 
-    # ---- verify/mod.rs
+    # ---- csrc/verifier.hip:204-347 zkh_verify_segment = risc0-zkp verify/mod.rs, statement by statement
     def verify_seal(self, c: Circuit, po2: int) -> dict:
         """-> {'out': embedded out-global wires, 'out_packed': header wires (out ‖ po2), 'code_root': 2 wires}"""
         pr, io = self.pr, self.io
