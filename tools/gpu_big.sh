@@ -2,7 +2,7 @@
 set -u
 O=gpurun_out/big; mkdir -p $O
 for p in 21 22; do
-  timeout 900 python bench.py --po2 $p --steps 6 --warmup 1 --inflight 2 --no-cpu-baseline --no-live-traffic --no-heavy --no-resident --no-block > $O/bench_po2_$p.json 2> $O/bench_po2_$p.err
+  timeout 900 python bench.py --po2 $p --steps 9 --warmup 1 --no-cpu-baseline --no-live-traffic --no-heavy --no-resident --no-block > $O/bench_po2_$p.json 2> $O/bench_po2_$p.err
   echo "po2 $p rc=$?"; python - <<P
 import json
 try:
