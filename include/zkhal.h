@@ -303,8 +303,9 @@ void zkh_rec_program_destroy(zkh_rec_program*);
 /* root: the program's control root (Merkle root of its code group); info: po2, zk_cycles, input words, permutations, gates,
  * witness ops, dependency levels, variables */
 const char* zkh_rec_program_info(const zkh_rec_program*, uint32_t root[8], uint32_t info[8]);
-/* > 0: the witness schedule is replayed as a hipGraph; the value is the number of steps of its launch plan (runs of narrow levels
- * in one persistent workgroup + single wide levels).  0: launched kernel by kernel (ZKH_REC_NO_GRAPH, or capture unavailable). */
+/* > 0: the witness schedule is replayed as a hipGraph (opt-in: ZKH_REC_GRAPH=1 when the program is loaded); the value is the
+ * number of steps of its launch plan (runs of narrow levels in one persistent workgroup + single wide levels).  0: the plan is
+ * launched kernel by kernel (the default: measured equal, and profilers cope with it). */
 int zkh_rec_program_has_graph(const zkh_rec_program*);
 const char* zkh_rec_code(const zkh_rec_program*, zkh_buf* code /* 57 x 2^po2 */);
 const char* zkh_rec_witgen(const zkh_rec_program*, const uint32_t* inputs, size_t n_inputs, uint64_t noise_seed,

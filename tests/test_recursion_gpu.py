@@ -54,7 +54,15 @@ def test_small_program_traces_accum_and_seal_match_the_oracle(hal, oracle):
     assert circuit.kernel_kind() == "builtin"
     prog = RecProgram(hal, circuit, blob)
     assert (prog.po2, prog.n_inputs, prog.n_p2) == (po2, 8, 2)
-    assert prog.graph_steps > 0 or os.environ.get("ZKH_REC_NO_GRAPH")          # the witness schedule is replayed as a hipGraph
+    assert prog.graph_steps == 0
+    os.environ["ZKH_REC_GRAPH"] = "1"                               # opt-in: the same schedule captured as a hipGraph and replayed
+    try:
+        gprog = RecProgram(hal, circuit, blob)
+    finally:
+        del os.environ["ZKH_REC_GRAPH"]
+    assert gprog.graph_steps > 0
+    gdata = hal.alloc_elem("gdata", R.WD << po2)
+    assert np.array_equal(gprog.witgen(inputs, gdata), oout) and np.array_equal(gdata.to_vec(), odata)
     code, data, accum, out = _device_traces(hal, prog, inputs)
     assert np.array_equal(code.to_vec(), ocode)
     assert np.array_equal(data.to_vec(), odata)

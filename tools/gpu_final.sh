@@ -14,7 +14,7 @@ LD_LIBRARY_PATH=$PWD/zeth_amd timeout 600 examples/prove_session --desc /tmp/syn
 timeout 900 python bench.py --config succinct > $O/bench_succinct_recursion.json 2> $O/bench_succinct_recursion.err; echo "bench_succinct rc=$?" >> $O/bench_default.time
 timeout 900 python bench.py --config succinct --no-fused-lift > $O/bench_succinct_recursion_unfused.json 2>> $O/bench_succinct_recursion.err
 timeout 900 python bench.py --config succinct --join-circuit p2_join > $O/bench_succinct_p2join.json 2>> $O/bench_succinct_recursion.err
-( cd /tmp && ZKH_REC_NO_GRAPH=1 LD_LIBRARY_PATH=$OLDPWD/zeth_amd timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/prof_fold -o fold -- $OLDPWD/examples/prove_session --desc /tmp/syn_a.desc --recursion-dir $D --segments 64 --inflight 1 > /dev/null 2>&1 )
+( cd /tmp && LD_LIBRARY_PATH=$OLDPWD/zeth_amd timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$O/prof_fold -o fold -- $OLDPWD/examples/prove_session --desc /tmp/syn_a.desc --recursion-dir $D --segments 64 --inflight 1 > /dev/null 2>&1 )
 find $O/prof_fold -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/fold_kernel_stats.csv; rm -rf $O/prof_fold
 bash tools/gpu_big.sh > $O/big.txt 2>&1; cp gpurun_out/big/bench_po2_21.json $O/bench_po2_21.json; cp gpurun_out/big/bench_po2_22.json $O/bench_po2_22.json
 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/bench_default.time; tail -1 $O/smoke.log > $O/smoke.txt
