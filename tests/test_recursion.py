@@ -210,3 +210,18 @@ def test_join_verifies_two_lifts_in_circuit(oracle, rec):
         rec.rec_witgen(jblob, np.concatenate([left, path, stranger, path]))
     with pytest.raises(RuntimeError, match="tie"):
         rec.rec_witgen(jblob, np.concatenate([left, path, right, host_rec.membership_words(levels, 1)]))
+
+
+def test_committed_digests_of_circuit_programs_and_oracle_witnesses():
+    """tests/golden/recursion_digests.json (make_golden_recursion.py): the circuit description, the assembler's blobs and the
+    oracle's witnesses / seal have not moved since the fixture was committed"""
+    import importlib.util
+    import json
+    import os
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden_recursion", os.path.join(g, "make_golden_recursion.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with open(os.path.join(g, "recursion_digests.json")) as fh:
+        want = json.load(fh)
+    assert mod.digests() == want
