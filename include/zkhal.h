@@ -290,7 +290,7 @@ const char* zkh_receipt_decode(const zkh_circuit*, const uint32_t* blob, size_t 
  * /root/reference/Cargo.lock:5305), reached from default_prover().prove (/root/reference/crates/host/src/lib.rs:137) once per
  * lift and per join (BASELINE.json config 5).  The circuit: zeth_amd/circuits/recursion.py (six Fp4 wires + one gate per row,
  * Poseidon2 blocks, a copy argument in the accum group); a PROGRAM = the code group, produced by
- * zeth_amd/circuits/rec_verify.py (build_lift / build_join = this library's verifier restated gate by gate) as a u32 blob.
+ * zeth_amd/circuits/rec_verify.py (build_lift / build_lift2 / build_join = this library's verifier restated gate by gate) as a u32 blob.
  * zkh_rec_program_load validates the blob, sorts its witness schedule into dependency levels, uploads it, generates the code
  * group and commits it (resident); `circuit` = the RECURSION description loaded on the same context.  zkh_rec_prove runs the
  * program on `inputs` (raw Montgomery words: the child seal(s) and the program's other witness words), which FAILS unless every
