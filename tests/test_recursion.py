@@ -225,3 +225,27 @@ def test_committed_digests_of_circuit_programs_and_oracle_witnesses():
     with open(os.path.join(g, "recursion_digests.json")) as fh:
         want = json.load(fh)
     assert mod.digests() == want
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_programs_python_semantics_c_interpreter_and_constraints_agree(rec, seed):
+    """seeded random programs over every gate kind: the plain-Python semantics, the C witness generator and the circuit's own
+    constraints (row check over the whole trace incl. the copy argument) agree; a random wire flipped afterwards is caught"""
+    from rec_programs import random_program
+    pr, words, pub = random_program(seed)
+    rng = np.random.default_rng(seed)
+    zk = 50
+    po2 = pr.min_po2(zk)
+    blob = pr.finish(po2, zk)
+    vals = R.run_program(pr, words)
+    code, data, out = rec.rec_witgen(blob, enc(words))
+    assert list(out) == list(enc([w for v in pub for w in vals[v]]))
+    accum = rec.rec_accum(po2, code, data, MIX, zk)
+    assert rec.check_rows(po2, accum, code, data, out, MIX) == -1
+    n = 1 << po2
+    used = np.nonzero(code.reshape(R.WC, n)[R.C_QD])[0]                     # rows whose gate writes wire d
+    r = int(used[int(rng.integers(0, used.size))])
+    d2 = data.copy()
+    col = 12 + int(rng.integers(0, 4))
+    d2[col * n + r] = (int(d2[col * n + r]) + 1 + int(rng.integers(0, P - 1))) % P
+    assert rec.check_rows(po2, rec.rec_accum(po2, code, d2, MIX, zk), code, d2, out, MIX) >= 0

@@ -87,6 +87,22 @@ def test_small_program_traces_accum_and_seal_match_the_oracle(hal, oracle):
         prog.prove(inputs[:7])
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_random_programs_device_witness_equals_the_oracles(hal, oracle, seed):
+    """seeded random programs over every gate kind (tests/rec_programs.py): whatever the dependency levels, the persistent
+    runs and the eight-lane permutations do, the device's trace and public output are the C interpreter's"""
+    from rec_programs import random_program
+    from zeth_amd.hal import RecProgram
+    pr, words, _ = random_program(seed)
+    blob = pr.finish(max(12, pr.min_po2(ZK)), ZK)
+    inputs = np.array([w * RM % P for w in words], dtype=np.uint32)
+    oc = zko.OracleCircuit(oracle, R.recursion_circuit())
+    ocode, odata, oout = oc.rec_witgen(blob, inputs)
+    prog = RecProgram(hal, hal.load_circuit(R.recursion_circuit()), blob)
+    code, data, accum, out = _device_traces(hal, prog, inputs)
+    assert np.array_equal(out, oout) and np.array_equal(data.to_vec(), odata) and np.array_equal(code.to_vec(), ocode)
+
+
 def test_lift_of_a_small_segment_matches_the_oracle_and_rejects_forgeries(hal, oracle):
     from zeth_amd.hal import HalError, HostCircuit, RecProgram
     from zeth_amd.prover import Segment, SegmentProver
