@@ -39,5 +39,5 @@ def random_program(seed: int):
             wires.append(pr.add(pr.mul(a, a), pr.const(1, 0, 0, 1)))
     pub = [wires[-1 - i] for i in range(4)]
     pr.public(*pub)
-    words = [int(x) for x in rng.integers(0, P, 4 * n_in)]
+    words = [int(x) for x in rng.integers(0, P, 4 * n_in)][:pr.n_inputs]      # exactly what the program reads
     return pr, words, pub
