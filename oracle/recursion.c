@@ -147,6 +147,7 @@ const char* zko_rec_witgen(const uint32_t* blob, size_t words, const uint32_t* i
     const char* e = rec_parse(blob, words, &p);
     if (e) return e;
     if (n_inputs < p.n_inputs) return "recursion witgen: the program reads more input words than were given";
+    if (n_inputs > p.n_inputs) return "recursion witgen: more input words than the program reads (a seal with trailing words is not a valid seal)";
     if ((e = zko_rec_code(blob, words, code))) return e;
     size_t n = (size_t)1 << p.po2, A = p.A, K = A / RC_BLOCK;
     fp4* val = (fp4*)calloc(p.n_vars ? p.n_vars : 1, sizeof(fp4));

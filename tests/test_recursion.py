@@ -111,6 +111,8 @@ def test_witness_generator_refuses_what_the_program_forbids(rec):
         rec.rec_witgen(blob, np.array([P] * 8, dtype=np.uint32))
     with pytest.raises(RuntimeError, match="more input"):
         rec.rec_witgen(blob, enc([1, 2, 3]))
+    with pytest.raises(RuntimeError, match="trailing"):
+        rec.rec_witgen(blob, enc([5, 6, 7, 8, 11, 12, 13, 14, 15]))
     bad = blob.copy()
     bad[0] ^= 1
     with pytest.raises(RuntimeError, match="header"):

@@ -132,7 +132,9 @@ class OracleCircuit:
     def rec_witgen(self, prog, inputs, noise_seed=0x2E80):
         """-> (code, data, out_global); raises if the program's assertions fail on `inputs` (raw Montgomery words)"""
         prog = np.ascontiguousarray(prog, dtype=np.uint32)
-        inputs = np.ascontiguousarray(inputs if len(inputs) else [0], dtype=np.uint32)
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint32)
+        if inputs.size == 0:
+            inputs = np.zeros(1, np.uint32)[:0]
         wa, wc, wd = (int(x) for x in self.desc[3:6])
         n = 1 << int(prog[2])
         code, data, out = np.zeros(wc * n, np.uint32), np.zeros(wd * n, np.uint32), np.zeros(self.out_size, np.uint32)
