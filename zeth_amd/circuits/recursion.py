@@ -484,7 +484,12 @@ class Program:
             pos[BLOCK * p] = ins
             pos[BLOCK * p + BLOCK - 1] = np.arange(out, out + NW)
         # copy classes -> sigma
-        roots = np.array([self.find(v) for v in range(self.n_vars)], dtype=np.int64) if self.n_vars else np.zeros(0, dtype=np.int64)
+        roots = np.array(self.parent, dtype=np.int64)                  # union-find resolved by pointer jumping (parents point downwards)
+        while True:
+            nxt = roots[roots]
+            if np.array_equal(nxt, roots):
+                break
+            roots = nxt
         flat = pos.reshape(-1)
         used = np.nonzero(flat >= 0)[0]
         cls = roots[flat[used]]
