@@ -207,6 +207,23 @@ def test_join_verifies_two_lifts_in_circuit(oracle, rec):
     code, data, out = rec.rec_witgen(jblob, np.concatenate([left, path, right, path]))
     assert np.array_equal(out[:8], host_rec.hash_pair(left[:8], right[:8])) and np.array_equal(out[8:], A)
     assert rec.check_rows(jpo2, rec.rec_accum(jpo2, code, data, MIX), code, data, out, MIX) == -1
+    # the product's host-side check of a recursion receipt (zeth_amd/recursion.py RecReceipt.verify: no GPU involved): the
+    # oracle-sealed lift verifies under the allowed set it was made for, with the claim of its segment - and only so
+    from zeth_amd.hal import HalError
+    roots = [rec.root_of_code(lpo2, lcode), rec.root_of_code(jpo2, jcode)]
+    receipt = host_rec.RecReceipt(left, lpo2, 0, roots[0])
+    claim_in = np.concatenate([child.prove(cpo2, czk, seed=100)[:5], croot])
+    claim = np.zeros(8, np.uint32)
+    oracle.zko_hash_elem_slice(np.ascontiguousarray(claim_in), claim_in.size, 1, claim)
+    receipt.verify(roots, [claim])
+    for bad_roots, bad_claims, what in ((roots[1:], [claim], "allowed set"), (roots[::-1], [claim], "allowed-programs root"),
+                                        (roots, [claim[::-1].copy()], "claim tree")):
+        with pytest.raises(HalError, match=what):
+            receipt.verify(bad_roots, bad_claims)
+    forged = host_rec.RecReceipt(left.copy(), lpo2, 0, roots[0])
+    forged.seal[left.size // 2] ^= 1
+    with pytest.raises(HalError):
+        forged.verify(roots, [claim])
     stranger = lifted(101, np.arange(8, dtype=np.uint32))                       # a valid lift, handed another allowed root
     with pytest.raises(RuntimeError, match="tie"):
         rec.rec_witgen(jblob, np.concatenate([left, path, stranger, path]))
