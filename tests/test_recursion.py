@@ -268,3 +268,19 @@ def test_random_programs_python_semantics_c_interpreter_and_constraints_agree(re
     col = 12 + int(rng.integers(0, 4))
     d2[col * n + r] = (int(d2[col * n + r]) + 1 + int(rng.integers(0, P - 1))) % P
     assert rec.check_rows(po2, rec.rec_accum(po2, code, d2, MIX, zk), code, d2, out, MIX) >= 0
+
+
+def test_program_set_of_a_block_closes_at_po2_18():
+    """build_programs (host only): a SYN-A block with po2-20 segments and a po2-18 tail needs 2 lifts, 3 fused lift2 and 4 joins;
+    lifts fit po2 17, everything above po2 18, and the set fits the allowed tree"""
+    from zeth_amd import recursion as host_rec
+    r = np.arange(8, dtype=np.uint32)
+    programs = host_rec.build_programs(syn_air.syn_a(), {20: r, 18: r + 1})
+    kinds = [k for k, _ in programs]
+    assert kinds == [("lift", 20, 0), ("lift", 18, 0), ("lift2", 20, 20), ("lift2", 20, 18), ("lift2", 18, 18),
+                     ("join", 17, 17), ("join", 17, 18), ("join", 18, 17), ("join", 18, 18)]
+    assert [int(b[2]) for _, b in programs] == [17, 17, 18, 18, 18, 18, 18, 18, 18] and len(programs) <= host_rec.N_ALLOWED
+    levels = host_rec.allowed_tree([np.full(8, i + 1, np.uint32) for i in range(len(programs))])
+    assert [len(lv) for lv in levels] == [16, 8, 4, 2, 1]
+    w = host_rec.membership_words(levels, 5)
+    assert w.size == 4 * 9 and [int(w[9 * i]) for i in range(4)] == [host_rec.R * b % P for b in (1, 0, 1, 0)]
