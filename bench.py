@@ -20,7 +20,7 @@ The default line also carries two secondary measurements of the same step, neith
 heavy constraint system) and `code_group_resident` (the per-size code group kept in HBM instead of re-committed per
 segment: DESIGN.md §3); --no-heavy / --no-resident skip them.
 
-    python bench.py                         # N=1, K=30, W=2
+    python bench.py                         # N=1, K=60, W=2
     python bench.py --gpus 8                # self-launching: spawns 8 ranks (gloo control plane, one GPU each)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W          # the driver's launch shape works too
@@ -62,17 +62,48 @@ def seal_algorithmic_bytes(wa: int, wc: int, wd: int, n_taps: int, n_combos: int
     return float(commit + eval_check + check_group + deep + mix + combos + fri)
 
 
+_CPU_WORKER = r"""
+import os, sys, time, json
+cpus = [int(c) for c in sys.argv[3].split(",")] if sys.argv[3] else []
+if cpus:
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        pass
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import zko                                   # test infrastructure; here ONLY as the reported CPU baseline
+from zeth_amd.circuits import syn_air, syn_heavy
+desc = syn_heavy.syn_heavy() if sys.argv[2] == "syn_heavy" else syn_air.syn_a()
+lib = zko.load()
+oc = zko.OracleCircuit(lib, desc)
+po2, seed, noise = int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+sys.stdout.write("ready\n"); sys.stdout.flush()
+sys.stdin.readline()                          # all workers start their seal together
+t0 = time.perf_counter()
+seal = oc.prove(po2, 1994, seed, noise)
+print(json.dumps({"s": time.perf_counter() - t0, "words": int(seal.size)})); sys.stdout.flush()
+"""
+
+
 def cpu_baseline(desc, circuit_name: str) -> dict:
-    """The CPU oracle (a from-spec port of the reference CPU prover's algorithm) on this host's cores: about 10-30 s of CPU
-    work.  On a host where the whole unit fits that budget (the GPU box: one po2-20 seal in ~20 s at 32 threads) the unit
-    itself is timed; otherwise the largest power-of-two fraction of it that does, scaled linearly (work is ~linear in n)."""
+    """The CPU oracle (a from-spec port of the reference CPU prover's algorithm) on this host's cores, two figures:
+    (1) ONE seal alone at the thread count where the oracle's OpenMP loops stop scaling (latency), and
+    (2) the WHOLE host: floor(cores / threads) independent seals at once, one process each, pinned to disjoint core blocks
+        (the reference proves segments independently, so a CPU-only deployment would fill its cores exactly like this) ->
+        aggregate segments/s = `value`, `cores` = all cores those processes used.
+    About 10-30 s of CPU work each.  On a host where the whole unit fits that budget (the GPU box: one po2-20 seal in ~20 s)
+    the unit itself is timed; otherwise the largest power-of-two fraction of it that does, scaled linearly (work ~ n)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import zko                                     # test infrastructure; used here ONLY as the reported CPU baseline
     lib = zko.load()
     oc = zko.OracleCircuit(lib, desc)
     # the oracle's OpenMP loops stop scaling long before a two-socket host is full (fork/join + memory bound): scan a
-    # few thread counts on a small segment and quote the baseline at the fastest one
-    avail = int(lib.zko_num_threads())
+    # few thread counts on a small segment and run every seal at the fastest one
+    try:
+        usable = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = list(range(os.cpu_count() or 1))
+    avail = min(int(lib.zko_num_threads()), len(usable))
     probe_po2 = CPU_SAMPLE_PO2 - 2
     best, best_dt = avail, None
     for t in sorted({c for c in (8, 16, 32, 64, avail) if c <= avail}):
@@ -82,6 +113,8 @@ def cpu_baseline(desc, circuit_name: str) -> dict:
         d = time.perf_counter() - t0
         if best_dt is None or d < best_dt:
             best, best_dt = t, d
+    if os.environ.get("ZKH_CPU_BASELINE_THREADS"):             # tests: force the per-process thread count
+        best = max(1, min(avail, int(os.environ["ZKH_CPU_BASELINE_THREADS"])))
     lib.zko_set_num_threads(best)
     sample_po2 = probe_po2
     while sample_po2 < PO2 and best_dt * (1 << (sample_po2 + 1 - probe_po2)) <= CPU_SAMPLE_BUDGET_S:
@@ -91,19 +124,61 @@ def cpu_baseline(desc, circuit_name: str) -> dict:
     dt = time.perf_counter() - t0
     scale = 1 << (PO2 - sample_po2)
     how = "the unit itself, no extrapolation" if scale == 1 else f"scaled x1/{scale} to the po2={PO2} unit (work is ~linear in n)"
-    return {"value": 1.0 / (dt * scale), "unit": "segments/s", "cores": best, "cores_available": avail, "kind": "port",
-            "sample": f"one {circuit_name} segment seal at po2={sample_po2} ({dt:.2f} s wall, OpenMP oracle incl. witgen, at the fastest of "
-                      f"8/16/32/64/{avail} threads = {best}); {how}",
-            "note": "a literal, untuned port (the reference CPU prover cannot be built here); reported as the contract asks, "
-                    "never a target and never a quotable speed-up",
-            "seal_words": int(seal.size)}
+    single = {"value": 1.0 / (dt * scale), "seal_s": dt * scale, "cores": best,
+              "sample": f"one {circuit_name} segment seal at po2={sample_po2} alone on the host ({dt:.2f} s wall, OpenMP oracle incl. witgen, at the "
+                        f"fastest of 8/16/32/64/{avail} threads = {best}); {how}"}
+    out = {"value": single["value"], "unit": "segments/s", "cores": best, "cores_available": avail, "kind": "port",
+           "sample": single["sample"], "single_seal": single,
+           "note": "a literal, untuned port (the reference CPU prover cannot be built here); reported as the contract asks, "
+                   "never a target and never a quotable speed-up",
+           "seal_words": int(seal.size)}
+    # ---- the whole host: P = floor(cores / best) processes, `best` threads each, disjoint core blocks, distinct segments ----
+    procs_n = max(1, avail // best)
+    try:
+        mem_avail = next(int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable:")) * 1024
+        per_proc = 10e9 * (1 << sample_po2) / (1 << 20)          # measured: 0.49 GB of RSS per 2^16 cycles (SYN-A), 8 GB at po2 20
+        procs_n = max(1, min(procs_n, int(0.8 * mem_avail / per_proc)))
+    except (OSError, StopIteration, ValueError):
+        pass
+    if procs_n > 1:
+        try:
+            workers = []
+            for k in range(procs_n):
+                block = usable[k * best:(k + 1) * best]
+                env = dict(os.environ, OMP_NUM_THREADS=str(best), OMP_PROC_BIND="false")
+                for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                    env.pop(var, None)
+                workers.append(subprocess.Popen([sys.executable, "-c", _CPU_WORKER, ROOT, circuit_name, ",".join(map(str, block)), str(sample_po2),
+                                                 str(BASE_SEED + k), str(BENCH_NOISE)], env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True))
+            for w in workers:
+                if w.stdout.readline().strip() != "ready":
+                    raise RuntimeError("a CPU baseline worker did not start")
+            t0 = time.perf_counter()
+            for w in workers:
+                w.stdin.write("go\n"); w.stdin.flush()
+            times = [json.loads(w.stdout.readline())["s"] for w in workers]
+            wall = time.perf_counter() - t0
+            for w in workers:
+                w.wait(timeout=60)
+            out.update(value=procs_n / (wall * scale), cores=procs_n * best,
+                       sample=f"{procs_n} independent {circuit_name} segment seals at po2={sample_po2} at once, one process x {best} OpenMP threads each on "
+                              f"disjoint core blocks ({wall:.2f} s wall for all, {min(times):.1f}-{max(times):.1f} s per seal under load; OpenMP oracle "
+                              f"incl. witgen): {procs_n * best} of {avail} cores; {how}; one seal alone: {dt * scale:.2f} s",
+                       full_host={"processes": procs_n, "threads_each": best, "wall_s": wall, "seal_s_under_load": times})
+        except Exception as e:           # the single-seal figure stands
+            out["full_host_error"] = repr(e)
+            for w in workers:
+                if w.poll() is None:
+                    w.kill()
+    return out
 
 
-def live_traffic(kernel: str, circuit: str, po2: int, budget_s: float = 150.0):
-    """HBM bytes per launch of `kernel`, measured NOW: two child runs of this script (one serial seal each, no extra legs)
-    under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` — separate passes, kernel trace only, as
-    /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes; FETCH_SIZE doubled per that guide's gfx950 correction.
-    -> (bytes per launch, launches, description) or None when rocprofv3 is unavailable / a pass fails / the budget runs out."""
+def live_traffic(kernels, circuit: str, po2: int, budget_s: float = 150.0, device: int = 0):
+    """HBM bytes per launch of the kernels whose names start with one of `kernels`, measured NOW: two child runs of this script
+    (one serial seal each, no extra legs, on `device` only) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` — separate
+    passes, kernel trace only, as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes; FETCH_SIZE doubled per that guide's
+    gfx950 correction.  -> (bytes per launch, launches, description) or None when rocprofv3 is unavailable / a pass fails / the
+    budget runs out."""
     import csv
     import glob
     import re
@@ -111,6 +186,14 @@ def live_traffic(kernel: str, circuit: str, po2: int, budget_s: float = 150.0):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None
+    if isinstance(kernels, str):
+        kernels = (kernels,)
+    env = dict(os.environ, TMPDIR="/tmp")
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "ZKH_BENCH_CHILD", "ZKH_SHARE_GPUS", "GROUP_RANK", "ROLE_RANK",
+                "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
+        env.pop(var, None)
+    visible = [v for v in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if v != ""]
+    env["HIP_VISIBLE_DEVICES"] = visible[device] if device < len(visible) else str(device)      # the child sees this rank's GPU as device 0
     t0 = time.perf_counter()
     sums = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -123,13 +206,13 @@ def live_traffic(kernel: str, circuit: str, po2: int, budget_s: float = 150.0):
                "--circuit", circuit, "--no-cpu-baseline", "--no-prof", "--no-heavy", "--no-resident", "--no-block", "--no-certify",
                "--no-live-traffic"]
         try:
-            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=left, stdout=subprocess.DEVNULL,
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=left, stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL, check=True)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             vals = []
             for r in csv.DictReader(open(files[0])):
                 m = re.search(r"(k_[A-Za-z0-9_]+)", r["Kernel_Name"])
-                if m and m.group(1) == kernel and r.get("Counter_Name", counter) == counter:
+                if m and any(m.group(1) == k or (k.endswith("_") and m.group(1).startswith(k)) for k in kernels) and r.get("Counter_Name", counter) == counter:
                     vals.append(float(r["Counter_Value"]) * 1024.0)           # rocprofv3 reports KB
             if not vals:
                 return None
@@ -168,7 +251,7 @@ def self_launch(args, argv) -> int:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30, help="timed seals per GPU (30 x ~32 ms: about a second of GPU time)")
+    ap.add_argument("--steps", type=int, default=60, help="timed seals per GPU (60 x ~23.5 ms: 1.4 s of GPU time; run-to-run spread +-0.2 %%)")
     ap.add_argument("--warmup", type=int, default=2, help="untimed seals per lane before the clock starts (also ramps the clocks)")
     ap.add_argument("--po2", type=int, default=PO2)
     ap.add_argument("--config", choices=("segment", "block", "succinct"), default="segment")
@@ -185,7 +268,9 @@ def main() -> None:
     ap.add_argument("--heavy-steps", type=int, default=9)
     ap.add_argument("--no-resident", action="store_true", help="segment config: skip the extra measurement with the code group kept resident")
     ap.add_argument("--no-block", action="store_true", help="segment config: skip the short block leg (S distinct segments, witgen in the clock, all verified)")
-    ap.add_argument("--block-segments", type=int, default=64, help="segment config: segments of the short block leg (the last one a po2-18 tail)")
+    ap.add_argument("--block-segments", type=int, default=None,
+                    help="segment config: segments of the block leg (the last one a po2-18 tail); default 64 on one GPU, 256 on N > 1 "
+                         "(the strong-scaling figure next to the weak-scaling `value`: BASELINE's metric is a block's wall-clock)")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC file instead of two rocprofv3 --pmc child runs")
     ap.add_argument("--join-circuit", choices=("recursion", "p2_join"), default="recursion",
                     help="succinct config: joins that verify both child seals in-circuit (lift + join programs of the RECURSION circuit), "
@@ -193,6 +278,13 @@ def main() -> None:
     ap.add_argument("--fold-inflight", type=int, default=int(os.environ.get("ZKH_FOLD_INFLIGHT", "6")),
                     help="lifts / joins in flight per GPU: a lift's witness schedule is a chain of ~300 small launches (latency), so the fold "
                          "packs the GPU with more lanes than the seals need (measured: 3 -> 6 lanes, 5.1 -> 4.4 ms per join)")
+    ap.add_argument("--executor", choices=("native", "python"), default="native",
+                    help="succinct config with --join-circuit recursion: the native session executor (zkh_session_prove: one pipeline) or round 3's "
+                         "Python-orchestrated two-phase fold")
+    ap.add_argument("--fold", choices=("streamed", "phased"), default="streamed",
+                    help="native executor: prove a lift2 / join the moment its children exist, concurrently with the sealing lanes (one pipeline), "
+                         "or seal everything first and fold afterwards (two phases)")
+    ap.add_argument("--recompute-code", action="store_true", help="block / succinct: re-commit the code group for every segment (upstream's SegmentProver) instead of keeping it resident")
     ap.add_argument("--no-fused-lift", action="store_true", help="recursion: lift every segment on its own and join (three proofs per pair at the bottom level) instead of lift2")
     ap.add_argument("--no-recursive", action="store_true", help="segment config: skip the lift / join fold of the block leg's receipts")
     ap.add_argument("--no-succinct", action="store_true", help="segment config: skip the join tree over the block leg's receipts")
@@ -258,6 +350,16 @@ def main() -> None:
             device = local_rank % max(1, torch.cuda.device_count())
         except (RuntimeError, AssertionError):
             device = 0
+    # host placement: this rank's threads (and the pinned blocks they allocate) next to its GPU's root port; the ranks whose
+    # GPUs share a NUMA node split that node's cores (csrc/topology.hip; ZKH_AFFINITY=off leaves the process alone)
+    placement = {"numa_node": -1, "cpus": 0}
+    try:
+        from zeth_amd import hal as _zhal
+        slot, share = (0, 1) if os.environ.get("ZKH_SHARE_GPUS") else _zhal.placement_slot(device, list(range(world)))
+        placement = _zhal.bind_to_device(device, slot, share)
+        placement.update(slot=slot, share=share, pci_bus_id=_zhal.device_numa_node(device)[1])
+    except Exception as e:                               # placement is an optimisation, never a dependency
+        placement["error"] = repr(e)
     if args.circuit == "syn_heavy":
         from zeth_amd.circuits import syn_heavy
         desc = syn_heavy.syn_heavy()
@@ -286,9 +388,9 @@ def main() -> None:
     class Lane:
         """One seal in flight: a context (HIP stream) + circuit + prover, driven by one host thread."""
 
-        def __init__(self, with_join=False):
+        def __init__(self, with_join=False, resident=False):
             self.hal = HipHal(device)                # raises if the HIP library / GPU is missing: no fallback
-            self.prover = SegmentProver(self.hal, desc)
+            self.prover = SegmentProver(self.hal, desc, resident_code_group=resident)
             self.join_prover = SegmentProver(self.hal, join_desc) if with_join else None
             self.seal_s, self.witgen_s, self.err = [], [], None
             self.last, self.sealed = None, []
@@ -316,7 +418,7 @@ def main() -> None:
         return [Segment(index=i, po2=args.po2 if i + 1 < S or S == 1 else min(args.po2, TAIL_PO2), seed=BASE_SEED + i,
                         noise_seed=BENCH_NOISE) for i in range(S)]
 
-    def seal_block(lanes, segs, mine):
+    def seal_block(lanes, segs, mine, prover_of=lambda ln: ln.prover):
         """Seal this rank's share `mine` of the block `segs` on the lanes (shared work index), witness generation inside the
         clock -> ({index: receipt}, wall seconds incl. both device syncs, witgen seconds[], seal-call seconds[])."""
         receipts, wit_s, seal_s = {}, [], []
@@ -337,10 +439,11 @@ def main() -> None:
                     if i is None:
                         break
                     t_w = time.perf_counter()
-                    code, data, out = ln.prover.witgen(segs[i])      # inside the clock, reported separately
+                    pv = prover_of(ln)
+                    code, data, out = pv.witgen(segs[i])             # inside the clock, reported separately
                     ln.hal.sync()                                    # so that t_s - t_w is the witness generator alone
                     t_s = time.perf_counter()
-                    rec = ln.prover.seal(segs[i], code, data, out)
+                    rec = pv.seal(segs[i], code, data, out)
                     t_e = time.perf_counter()
                     with lock:
                         receipts[i] = rec
@@ -439,6 +542,7 @@ def main() -> None:
         return level[0], stats
 
     line = None
+    after_group = []                  # rank 0: work for the line that runs once the process group is destroyed
     # =====================================================================================================
     if args.config == "segment":
         # segment list of the "block": (warmup + steps) * world segments, partitioned round-robin over ranks; inside a
@@ -561,14 +665,17 @@ def main() -> None:
         seal_times = [t for ln in lanes for t in ln.seal_s]
         unloaded_seal_s = None
         ref = []
-        if prof and rank == 0:
-            w0 = lanes[0]
-            w0.hal.prof_reset(); w0.hal.prof_enable(True)
-            seal_one(w0, args.warmup)
-            w0.hal.sync()
-            ref = w0.hal.prof_get()
-            w0.hal.prof_enable(False)
-            unloaded_seal_s = w0.seal_s[-1]              # one seal alone on the GPU: the single-segment latency
+        if prof:
+            barrier()                                    # every rank is past its certification: nothing else runs while rank 0 takes its reference seal
+            if rank == 0:
+                w0 = lanes[0]
+                w0.hal.prof_reset(); w0.hal.prof_enable(True)
+                seal_one(w0, args.warmup)
+                w0.hal.sync()
+                ref = w0.hal.prof_get()
+                w0.hal.prof_enable(False)
+                unloaded_seal_s = w0.seal_s[-1]          # one seal alone on the GPU: the single-segment latency
+            barrier()
         # PCIe-inclusive variant: the same K steps, but every step uploads its code + data traces from pinned host memory
         pcie = None
         if args.ingress == "host":
@@ -683,15 +790,33 @@ def main() -> None:
         # S DISTINCT segments, the last one a po2-18 tail, round-robin over the ranks, witness generation INSIDE the clock,
         # every seal verified on the host after the clock.  `--config block` is the full-size version (S = 256).
         block = None
+        if args.block_segments is None:
+            args.block_segments = 64 if world == 1 else 256
         if not args.no_block and args.po2 >= 13 and args.block_segments > 0:
             S = args.block_segments
             bsegs = block_segments(S)
             bmine = partition_round_robin(S, world, rank)
-            for ln in lanes:                                  # the tail's size once, outside the clock (pool blocks, code objects)
-                ln.prover.prove_segment(Segment(index=0, po2=bsegs[-1].po2, seed=1, noise_seed=BENCH_NOISE))
+            # The block leg keeps the committed code (control) group of each segment size RESIDENT per lane (it is a
+            # function of (circuit, po2) alone; seals are byte-identical) — what the session executor does by default.  Upstream's
+            # SegmentProver re-commits it per segment: that figure is reported next to it (`recompute_code_group`), and `value`
+            # above is measured that way too.
+            for ln in lanes:                                  # every size once, outside the clock (pool blocks, code objects, the resident groups)
+                ln.block_prover = ln.prover if args.recompute_code else SegmentProver(ln.hal, desc, resident_code_group=True)
+                for p2 in sorted({sg.po2 for sg in bsegs}):
+                    ln.block_prover.prove_segment(Segment(index=0, po2=p2, seed=1, noise_seed=BENCH_NOISE))
+                    ln.prover.prove_segment(Segment(index=0, po2=p2, seed=1, noise_seed=BENCH_NOISE))
                 ln.hal.sync()
             broots = {p: lanes[0].prover.control_root(p) for p in sorted({sg.po2 for sg in bsegs})}
-            brec, tb0, bwit, bseal = seal_block(lanes, bsegs, bmine)
+            recompute = None
+            if not args.recompute_code:
+                _, tr0, _, _ = seal_block(lanes, bsegs, bmine)
+                barrier()
+                trc = torch.tensor([time.perf_counter() - tr0], dtype=torch.float64, device=ctrl_dev)
+                if distributed:
+                    dist.all_reduce(trc, op=dist.ReduceOp.MAX)
+                recompute = {"wall_clock_s": float(trc.item()), "segments_per_s": S / float(trc.item()),
+                             "note": "the same block with the code group re-committed for every segment, as upstream's SegmentProver does"}
+            brec, tb0, bwit, bseal = seal_block(lanes, bsegs, bmine, prover_of=lambda ln: ln.block_prover)
             barrier()
             dtb = time.perf_counter() - tb0
             t_v = time.perf_counter()
@@ -706,6 +831,8 @@ def main() -> None:
                 tb[0] = mx[0]
             block = {"segments": S, "wall_clock_s": float(tb[0].item()), "segments_per_s": S / float(tb[0].item()),
                      "tail_po2": bsegs[-1].po2, "witgen_in_clock": True, "verified_after_clock": int(tb[1].item()),
+                     "code_group": "recomputed per segment" if args.recompute_code else "resident per lane and size (byte-identical seals)",
+                     "recompute_code_group": recompute,
                      "witgen_ms_per_segment": 1e3 * float(tb[2].item()) / max(1.0, float(tb[3].item())),
                      "verify_s_rank0": verify_s,
                      "workload": f"{S} distinct 2^{args.po2}-cycle segments (last one 2^{bsegs[-1].po2}), round-robin over {world} GPU(s), "
@@ -776,7 +903,7 @@ def main() -> None:
                 "config": {"workload": f"single 2^{args.po2}-cycle segment seal per step per GPU, {workload}, witness resident in HBM",
                            "po2": args.po2, "circuit": args.circuit,
                            "parallelism": f"segments round-robin over {world} GPU(s), no collectives; {inflight} segment(s) in flight per GPU",
-                           "rccl_probe": rccl, "inflight_per_gpu": inflight,
+                           "rccl_probe": rccl, "inflight_per_gpu": inflight, "host_placement_rank0": placement,
                            "seal_words": int(last.seal.size) if last is not None else 0,
                            "library": HipHal.version(),
                            "poseidon2_consts": HipHal.version().split("poseidon2_consts=")[-1].rstrip(")")},
@@ -797,6 +924,9 @@ def main() -> None:
                 line["certify"] = certify
             if block is not None:
                 line["block"] = block
+                # the strong-scaling figure (BASELINE's metric is a block's seal wall-clock): total work fixed at S segments
+                line["block_wall_clock_s"] = block["wall_clock_s"]
+                line["block_segments_per_s"] = block["segments_per_s"]
             if pcie is not None:
                 line["pcie_inclusive"] = pcie
             if heavy is not None:
@@ -806,13 +936,17 @@ def main() -> None:
             alg = seal_algorithmic_bytes(wa, wc, wd, len(circ.taps), len(circ.combos), n)
             line["seal_roofline"] = {"alg_bytes": alg, "achieved": alg / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBPS,
                                      "unit": "GB/s", "frac": alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS}
+            # roofline{} (its HBM traffic is measured by child runs under rocprofv3) and the CPU baseline are taken by rank 0 AFTER
+            # the process group is gone: the other ranks have nothing left to do, the host's cores and rank 0's GPU are idle
             if prof:
-                add_roofline(line, prof, ref, args, inflight, (wa, wc, wd), n)
-            if world == 1 and not args.no_cpu_baseline:
-                try:
-                    line["cpu_baseline"] = cpu_baseline(desc, args.circuit)
-                except Exception as e:       # the baseline is a reported number, never a dependency of the product path
-                    line["cpu_baseline"] = {"error": repr(e)}
+                after_group.append(lambda: add_roofline(line, prof, ref, args, inflight, (wa, wc, wd), n, device))
+            if not args.no_cpu_baseline:
+                def _cpu():
+                    try:
+                        line["cpu_baseline"] = cpu_baseline(desc, args.circuit)
+                    except Exception as e:       # the baseline is a reported number, never a dependency of the product path
+                        line["cpu_baseline"] = {"error": repr(e)}
+                after_group.append(_cpu)
     # =====================================================================================================
     else:
         S = args.segments or (256 if args.config == "block" else 1024)
@@ -828,195 +962,353 @@ def main() -> None:
                 mine = list(aligned_range(S, world, rank))
             except ValueError as e:
                 raise SystemExit(f"bench: --join-circuit recursion: {e}")
-        lanes = [Lane(with_join=succinct and not recursive) for _ in range(inflight)]
-        # warm-up: one full-size seal per lane (clocks, pools, code objects), plus the control roots the verifier needs
-        for ln in lanes:
+        if recursive and args.executor == "native":
+            # ---- config 5 as ONE native call per rank: zkh_session_prove(join_tree = 2) seals this rank's segments and folds them —
+            # by default as one pipeline (a lift2 / join is proven the moment its children exist, on the fold lanes while the sealing
+            # lanes are busy), with --fold phased as two phases.  No Python in the loop; this is what a Rust shim's Prover::prove
+            # would call once per session (/root/reference/crates/host/src/lib.rs:137). ----
+            import numpy as np
+            from zeth_amd import recursion as zrec
+            from zeth_amd.host import Session
+            os.environ["ZKH_FOLD_LANES"] = str(max(args.fold_inflight, inflight))
+            probe = Lane()                                     # control roots + (rank 0, N > 1) the top joins
+            probe.prover.prove_segment(Segment(index=0, po2=args.po2, seed=1, noise_seed=BENCH_NOISE))
+            roots = {p: probe.prover.control_root(p) for p in sorted({s.po2 for s in segs})}
+            t_b = time.perf_counter()
+            programs = zrec.build_programs(desc, roots, fused_pairs=not args.no_fused_lift)
+            build_s = time.perf_counter() - t_b
+            t_b = time.perf_counter()
+            sess = Session(desc, devices=(device,), lanes_per_device=inflight)
+            sess.set_recursion(programs)
+            sess.set_streamed_fold(args.fold == "streamed")
+            sess.set_resident_code(not args.recompute_code)
+            load_s = time.perf_counter() - t_b
+            # warm-up: a short session of the same shape (every segment size, every program kind, pools, clocks)
+            wsegs = [segs[0]] * (2 * max(args.fold_inflight, inflight)) + [segs[0], segs[-1]]
             for _ in range(max(1, args.warmup)):
-                ln.prover.prove_segment(Segment(index=0, po2=args.po2, seed=1, noise_seed=BENCH_NOISE))
-            if succinct and not recursive:
-                ln.join_prover.prove_segment(Segment(index=0, po2=args.join_po2, seed=1, noise_seed=BENCH_NOISE,
-                                                     pub=tuple([1] * 16)))
-            ln.hal.sync()
-        roots = {p: lanes[0].prover.control_root(p) for p in sorted({s.po2 for s in segs})}
-        join_root = lanes[0].join_prover.control_root(args.join_po2) if succinct and not recursive else None
-        rstats, rlanes = None, None
-        if recursive:
-            rlanes = fold_lanes(lanes)
-            rstats = recursive_prepare(rlanes, roots, lanes[0].prover.prove_segment(Segment(index=0, po2=args.po2, seed=1, noise_seed=BENCH_NOISE)))
-            rstats["in_flight"] = len(rlanes)
-        receipts, t0, wit_s, seal_s = seal_block(lanes, segs, mine)
-        t_leaves = time.perf_counter() - t0
-        joins_done, root = {}, None
-        if recursive:
-            local_root, st = recursive_fold(rlanes, [receipts[i] for i in mine])
-            rstats.update(st)
-            tops = [local_root]
+                sess.prove(wsegs, join_tree=2, join_noise_seed=BENCH_NOISE)
+            if distributed and rank == 0:
+                probe.rec = zrec.Recursion(probe.hal, programs)
+            device_sync([probe])
+            barrier()
+            t0 = time.perf_counter()
+            comp, local_root, st = sess.prove([segs[i] for i in mine], join_tree=2, join_noise_seed=BENCH_NOISE)
+            t_local = time.perf_counter() - t0
+            kinds = [k for k, _ in programs]
+            rp = st["root_program"]
+            local = zrec.RecReceipt(local_root.seal, local_root.po2, rp, None, len(mine))
+            tops, root = [local], local
+            top_s = 0.0
             if distributed:
                 tops = [None] * world if rank == 0 else None
-                dist.gather_object(local_root, tops, dst=0)
-            if rank == 0:
-                t_top = time.perf_counter()
-                root = lanes[0].rec.fold(tops, BENCH_NOISE)
-                lanes[0].hal.sync()
-                rstats["top_joins"] = len(tops) - 1
-                rstats["top_joins_s"] = time.perf_counter() - t_top
-        elif succinct:
-            # join tree: tasks of one level are independent -> spread over the lanes of this rank
-            def claim_of(r, is_leaf):
-                return node_claim(r, desc if is_leaf else join_desc, roots[r.po2] if is_leaf else join_root, is_leaf)
-
-            jlock = threading.Lock()
-
-            def prove_joins_parallel(tasks_segs):
-                """prove a list of join Segments on this rank's lanes concurrently -> receipts in the same order"""
-                out = [None] * len(tasks_segs)
-                pos = [0]
-
-                def work(ln):
-                    try:
-                        while True:
-                            with jlock:
-                                k = pos[0]
-                                if k >= len(tasks_segs):
-                                    return
-                                pos[0] = k + 1
-                            out[k] = ln.join_prover.prove_segment(tasks_segs[k])
-                    except Exception as e:
-                        ln.err = e
-                run_lanes(lanes, work)
-                return out
-
-            class BatchedExecutor(JoinExecutor):
-                """JoinExecutor whose per-level local joins run concurrently on the lanes (same schedule, same results)."""
-                def run(self, n_leaves, local_leaves):
-                    from zeth_amd.host import join_schedule, join_segment
-                    nodes = {i: (r, True) for i, r in local_leaves.items()}
-                    n_nodes, done = n_leaves, {}
-                    for tasks in join_schedule(n_leaves, self.world_size):
-                        right = {}
-                        for t in tasks:
-                            if t.right_owner == t.device:
-                                continue
-                            if self.rank == t.right_owner:
-                                self._send(nodes[t.right], t.device)
-                            elif self.rank == t.device:
-                                right[t.index] = self._recv(t.right_owner)
-                        local = [t for t in tasks if t.device == self.rank]
-                        jsegs = []
-                        for t in local:
-                            l_rec, l_leaf = nodes[t.left]
-                            r_rec, r_leaf = right[t.index] if t.index in right else nodes[t.right]
-                            jsegs.append(join_segment(t, self.claim_of(l_rec, l_leaf), self.claim_of(r_rec, r_leaf), self.join_po2, self.noise_seed))
-                        recs = prove_joins_parallel(jsegs)
-                        nxt2 = {}
-                        for t, j in zip(local, recs):
-                            done[(t.level, t.index)] = j
-                            nxt2[t.index] = (j, False)
-                        if n_nodes % 2 and (n_nodes - 1) in nodes:
-                            nxt2[n_nodes // 2] = nodes[n_nodes - 1]
-                        nodes, n_nodes = nxt2, (n_nodes + 1) // 2
-                    return done, (nodes.get(0, (None, False))[0] if n_nodes == 1 else None)
-
-            ex = BatchedExecutor(None, claim_of, rank, world, join_po2=args.join_po2, noise_seed=BENCH_NOISE)
-            joins_done, root = ex.run(S, {i: receipts[i] for i in mine})
-            device_sync(lanes)
-        barrier()
-        dt = time.perf_counter() - t0
-        if distributed:
-            t = torch.tensor([dt, t_leaves], dtype=torch.float64, device=ctrl_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt, t_leaves = float(t[0].item()), float(t[1].item())
-        # ---- after the clock: verify every seal this rank produced (cli.rs:103 analogue) ----
-        verified = 0
-        t_v = time.perf_counter()
-        if not args.no_verify:
-            for i in mine:
-                receipts[i].verify(desc, roots[segs[i].po2])
-                verified += 1
-            for j in joins_done.values():
-                j.verify(join_desc, join_root)
-                verified += 1
-        verify_s = time.perf_counter() - t_v
-        # succinct: what a holder of the COMPACT receipt (root + leaves, joins dropped) checks — the claim tree over the leaf
-        # claims, recomputed on the host with hash_pair, must end in the root receipt's public output
-        follows = None
-        if recursive and not args.no_verify and rank == 0:
-            t_rv = time.perf_counter()
-            root.verify(lanes[0].rec.allowed_roots())            # ONE seal; the claim tree is checked against the leaves below
-            rstats["root_verify_s"] = time.perf_counter() - t_rv
-            verified += 1
-        if succinct and not args.no_verify:
-            mine_claims = {i: receipt_claim(receipts[i], desc, roots[segs[i].po2]) for i in mine}
+                dist.gather_object(local, tops, dst=0)
+                if rank == 0:
+                    t_top = time.perf_counter()
+                    for t in tops:
+                        t.control_root = probe.rec.programs[t.program].root
+                    root = probe.rec.fold(tops, BENCH_NOISE)
+                    probe.hal.sync()
+                    top_s = time.perf_counter() - t_top
+            barrier()
+            dt = time.perf_counter() - t0
+            tt = torch.tensor([dt, st["leaves_s"], st["fold_tail_s"], st["fold_busy_s_sum"], float(st["n_retries"]), st["witgen_s_sum"], float(len(mine))],
+                              dtype=torch.float64, device=ctrl_dev)
+            if distributed:
+                mx = tt[:3].clone()
+                dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+                dist.all_reduce(tt)
+                tt[:3] = mx
+            dt, t_leaves, fold_tail = float(tt[0]), float(tt[1]), float(tt[2])
+            # ---- after the clock: every leaf seal through the host verifier, the root seal, and the claim tree ----
+            verified, follows = 0, None
+            t_v = time.perf_counter()
+            if not args.no_verify:
+                for r in comp.segments:
+                    r.verify(desc, roots[r.po2])
+                    verified += 1
+            verify_s = time.perf_counter() - t_v
+            mine_claims = {i: receipt_claim(r, desc, roots[r.po2]) for i, r in zip(mine, comp.segments)} if not args.no_verify else {}
             parts = [mine_claims]
             if distributed:
                 parts = [None] * world if rank == 0 else None
                 dist.gather_object(mine_claims, parts, dst=0)
-            if rank == 0 and root is not None and (S > 1 or recursive):
-                import numpy as np
-                allc = {k: v for part in parts for k, v in part.items()}
-                follows = bool(np.array_equal(root.seal[:8], fold_claims([allc[i] for i in range(S)])))
-                if not follows:
-                    raise SystemExit("bench: the root receipt's output is not the claim tree of the leaves")
-        counts = torch.tensor([float(verified), float(len(joins_done))], dtype=torch.float64, device=ctrl_dev)
-        if distributed:
-            dist.all_reduce(counts)
-        if rank == 0:
-            n_joins = int(counts[1].item())
-            line = {
-                "metric": "segments/sec", "value": S / dt, "unit": "segments/s", "n_gpus": world, "steps": S,
-                "warmup": max(1, args.warmup), "ms_per_step": 1e3 * dt / S, "higher_is_better": True, "scaling": "strong",
-                "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-                "config": {"workload": (f"{'block + join tree to one succinct receipt' if succinct else 'one block'}: {S} distinct "
-                                        f"2^{args.po2}-cycle segments (last one 2^{segs[-1].po2}), {workload}; witness generation inside the clock"
-                                        + (f"; {rstats['proofs']} proofs of the RECURSION circuit ({rstats['fused_lift2']} lift2 = lift + lift + join fused, {rstats['lifts']} lifts, {rstats['joins']} joins): every node runs the STARK verifier on its child seal(s) in-circuit" if recursive else
-                                           f"; {n_joins} P2-JOIN joins at po2 {args.join_po2} (parent claim = Poseidon2 hash_pair of the children's, proven in-circuit)" if succinct else "")),
-                           "po2": args.po2, "circuit": args.circuit, "segments": S,
-                           "parallelism": f"segments round-robin over {world} GPU(s) + shared work index inside a rank, no data-path collective; "
-                                          f"{inflight} seal(s) in flight per GPU" + ("; every rank folds its own aligned range of leaves, rank 0 joins the local roots (gathered over gloo)" if recursive else
-                                                                                     "; joins on the rank of their left child, right child over gloo" if succinct else ""),
-                           "inflight_per_gpu": inflight, "library": HipHal.version(),
-                           "poseidon2_consts": HipHal.version().split("poseidon2_consts=")[-1].rstrip(")")},
-                "block_wall_clock_s": dt, "leaf_phase_s": t_leaves, "join_phase_s": dt - t_leaves if succinct else None,
-                "witgen_ms_per_segment": 1e3 * sum(wit_s) / max(1, len(wit_s)),      # mean, in-clock (rank 0's segments)
-                "seal_call_ms_mean": 1e3 * sum(seal_s) / max(1, len(seal_s)),
-                "verified_after_clock": int(counts[0].item()), "verify_s_rank0": verify_s,
-                "root_receipt_words": int(root.seal.size) if root is not None else None,
-                "succinct_root_follows_from_leaf_claims": follows,
-            }
+            rstats = None
+            if rank == 0:
+                if not args.no_verify:
+                    if not distributed:
+                        probe.rec = zrec.Recursion(probe.hal, programs)       # only for the allowed set (host data), after the clock
+                        root.control_root = probe.rec.programs[root.program].root
+                    t_rv = time.perf_counter()
+                    root.verify(probe.rec.allowed_roots())                    # ONE seal; the claim tree is checked against the leaves below
+                    root_verify_s = time.perf_counter() - t_rv
+                    verified += 1
+                    allc = {k: v for part in parts for k, v in part.items()}
+                    follows = bool(np.array_equal(root.seal[:8], fold_claims([allc[i] for i in range(S)])))
+                    if not follows:
+                        raise SystemExit("bench: the root receipt's output is not the claim tree of the leaves")
+                else:
+                    root_verify_s = None
+                n_fused = sum(1 for k in range(len(mine) // 2) if ("lift2", segs[mine[2 * k]].po2, segs[mine[2 * k + 1]].po2) in kinds)
+                all_fused = n_fused == len(mine) // 2 and len(mine) > 1
+                rstats = {"executor": "native: one zkh_session_prove(join_tree = 2) call per rank (csrc/session.hip), no Python in the loop",
+                          "fold": args.fold, "streamed_fold": st["streamed_fold"], "code_group": "recomputed per segment" if args.recompute_code else "resident per lane and size",
+                          "bottom_level_proofs": st["n_lifts"] * world, "fused_lift2": (len(mine) // 2) * world if all_fused else 0,
+                          "joins": st["n_joins"] * world + (world - 1), "proofs": (st["n_lifts"] + st["n_joins"]) * world + (world - 1),
+                          "leaves_s": t_leaves, "fold_tail_s": fold_tail, "fold_busy_lane_s": float(tt[3]), "top_joins": world - 1, "top_joins_s": top_s,
+                          "segment_retries": int(tt[4]), "program_build_s": build_s, "program_load_s_all_lanes": load_s,
+                          "in_flight": {"sealing_lanes": inflight, "fold_lanes": max(args.fold_inflight, inflight)},
+                          "root_verify_s": root_verify_s,
+                          "note": "every lift2 runs the STARK verifier on two segment seals and every join on both child seals INSIDE the RECURSION "
+                                  "circuit; fold_tail_s = last segment sealed -> root receipt (the part of the fold the leaves did not hide)"}
+            cnt = torch.tensor([float(verified)], dtype=torch.float64, device=ctrl_dev)
+            if distributed:
+                dist.all_reduce(cnt)
+            if rank == 0:
+                line = {
+                    "metric": "segments/sec", "value": S / dt, "unit": "segments/s", "n_gpus": world, "steps": S,
+                    "warmup": max(1, args.warmup), "ms_per_step": 1e3 * dt / S, "higher_is_better": True, "scaling": "strong",
+                    "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                    "config": {"workload": (f"block + fold to ONE succinct receipt: {S} distinct 2^{args.po2}-cycle segments (last one 2^{segs[-1].po2}), {workload}; "
+                                            f"witness generation inside the clock; {rstats['proofs']} proofs of the RECURSION circuit, every node runs the STARK "
+                                            f"verifier on its child seal(s) in-circuit; fold {args.fold}"),
+                               "po2": args.po2, "circuit": args.circuit, "segments": S,
+                               "parallelism": (f"{world} GPU(s): every rank seals AND folds its own contiguous, aligned power-of-two range of segments "
+                                               f"(a deviation from round-robin, so that a rank's local root is a node of the global join tree), rank 0 joins "
+                                               f"the {world} local roots gathered over gloo; no data-path collective; {inflight} sealing + "
+                                               f"{max(args.fold_inflight, inflight) - inflight} fold-only lanes per GPU"),
+                               "inflight_per_gpu": inflight, "library": HipHal.version(), "host_placement_rank0": placement,
+                               "join_circuit": "recursion (lift2 + join programs, in-circuit verification of every child seal)",
+                               "poseidon2_consts": HipHal.version().split("poseidon2_consts=")[-1].rstrip(")")},
+                    "block_wall_clock_s": dt, "leaf_phase_s": t_leaves, "join_phase_s": dt - t_leaves,
+                    "witgen_ms_per_segment": 1e3 * float(tt[5]) / max(1.0, float(tt[6])),
+                    "verified_after_clock": int(cnt.item()), "verify_s_rank0": verify_s,
+                    "root_receipt_words": int(root.seal.size), "succinct_root_follows_from_leaf_claims": follows,
+                    "recursion": rstats,
+                }
+        else:
+            # block / succinct: the committed code group of each segment size stays resident per lane (what the session executor does
+            # by default; byte-identical seals); --recompute-code re-commits it per segment like upstream's SegmentProver
+            lanes = [Lane(with_join=succinct and not recursive, resident=not args.recompute_code) for _ in range(inflight)]
+            # warm-up: one seal of every size per lane (clocks, pools, code objects, resident groups), plus the control roots the verifier needs
+            for ln in lanes:
+                for _ in range(max(1, args.warmup)):
+                    for p2 in sorted({sg.po2 for sg in segs}, reverse=True):
+                        ln.prover.prove_segment(Segment(index=0, po2=p2, seed=1, noise_seed=BENCH_NOISE))
+                if succinct and not recursive:
+                    ln.join_prover.prove_segment(Segment(index=0, po2=args.join_po2, seed=1, noise_seed=BENCH_NOISE,
+                                                         pub=tuple([1] * 16)))
+                ln.hal.sync()
+            roots = {p: lanes[0].prover.control_root(p) for p in sorted({s.po2 for s in segs})}
+            join_root = lanes[0].join_prover.control_root(args.join_po2) if succinct and not recursive else None
+            rstats, rlanes = None, None
             if recursive:
-                line["recursion"] = rstats
-                line["config"]["join_circuit"] = "recursion (lift + join programs, in-circuit verification of every child seal)"
+                rlanes = fold_lanes(lanes)
+                rstats = recursive_prepare(rlanes, roots, lanes[0].prover.prove_segment(Segment(index=0, po2=args.po2, seed=1, noise_seed=BENCH_NOISE)))
+                rstats["in_flight"] = len(rlanes)
+            receipts, t0, wit_s, seal_s = seal_block(lanes, segs, mine)
+            t_leaves = time.perf_counter() - t0
+            joins_done, root = {}, None
+            if recursive:
+                local_root, st = recursive_fold(rlanes, [receipts[i] for i in mine])
+                rstats.update(st)
+                tops = [local_root]
+                if distributed:
+                    tops = [None] * world if rank == 0 else None
+                    dist.gather_object(local_root, tops, dst=0)
+                if rank == 0:
+                    t_top = time.perf_counter()
+                    root = lanes[0].rec.fold(tops, BENCH_NOISE)
+                    lanes[0].hal.sync()
+                    rstats["top_joins"] = len(tops) - 1
+                    rstats["top_joins_s"] = time.perf_counter() - t_top
             elif succinct:
-                line["config"]["join_circuit"] = "p2_join"
-    if rank == 0 and line is not None:
-        print(json.dumps(line))
+                # join tree: tasks of one level are independent -> spread over the lanes of this rank
+                def claim_of(r, is_leaf):
+                    return node_claim(r, desc if is_leaf else join_desc, roots[r.po2] if is_leaf else join_root, is_leaf)
+
+                jlock = threading.Lock()
+
+                def prove_joins_parallel(tasks_segs):
+                    """prove a list of join Segments on this rank's lanes concurrently -> receipts in the same order"""
+                    out = [None] * len(tasks_segs)
+                    pos = [0]
+
+                    def work(ln):
+                        try:
+                            while True:
+                                with jlock:
+                                    k = pos[0]
+                                    if k >= len(tasks_segs):
+                                        return
+                                    pos[0] = k + 1
+                                out[k] = ln.join_prover.prove_segment(tasks_segs[k])
+                        except Exception as e:
+                            ln.err = e
+                    run_lanes(lanes, work)
+                    return out
+
+                class BatchedExecutor(JoinExecutor):
+                    """JoinExecutor whose per-level local joins run concurrently on the lanes (same schedule, same results)."""
+                    def run(self, n_leaves, local_leaves):
+                        from zeth_amd.host import join_schedule, join_segment
+                        nodes = {i: (r, True) for i, r in local_leaves.items()}
+                        n_nodes, done = n_leaves, {}
+                        for tasks in join_schedule(n_leaves, self.world_size):
+                            right = {}
+                            for t in tasks:
+                                if t.right_owner == t.device:
+                                    continue
+                                if self.rank == t.right_owner:
+                                    self._send(nodes[t.right], t.device)
+                                elif self.rank == t.device:
+                                    right[t.index] = self._recv(t.right_owner)
+                            local = [t for t in tasks if t.device == self.rank]
+                            jsegs = []
+                            for t in local:
+                                l_rec, l_leaf = nodes[t.left]
+                                r_rec, r_leaf = right[t.index] if t.index in right else nodes[t.right]
+                                jsegs.append(join_segment(t, self.claim_of(l_rec, l_leaf), self.claim_of(r_rec, r_leaf), self.join_po2, self.noise_seed))
+                            recs = prove_joins_parallel(jsegs)
+                            nxt2 = {}
+                            for t, j in zip(local, recs):
+                                done[(t.level, t.index)] = j
+                                nxt2[t.index] = (j, False)
+                            if n_nodes % 2 and (n_nodes - 1) in nodes:
+                                nxt2[n_nodes // 2] = nodes[n_nodes - 1]
+                            nodes, n_nodes = nxt2, (n_nodes + 1) // 2
+                        return done, (nodes.get(0, (None, False))[0] if n_nodes == 1 else None)
+
+                ex = BatchedExecutor(None, claim_of, rank, world, join_po2=args.join_po2, noise_seed=BENCH_NOISE)
+                joins_done, root = ex.run(S, {i: receipts[i] for i in mine})
+                device_sync(lanes)
+            barrier()
+            dt = time.perf_counter() - t0
+            if distributed:
+                t = torch.tensor([dt, t_leaves], dtype=torch.float64, device=ctrl_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt, t_leaves = float(t[0].item()), float(t[1].item())
+            # ---- after the clock: verify every seal this rank produced (cli.rs:103 analogue) ----
+            verified = 0
+            t_v = time.perf_counter()
+            if not args.no_verify:
+                for i in mine:
+                    receipts[i].verify(desc, roots[segs[i].po2])
+                    verified += 1
+                for j in joins_done.values():
+                    j.verify(join_desc, join_root)
+                    verified += 1
+            verify_s = time.perf_counter() - t_v
+            # succinct: what a holder of the COMPACT receipt (root + leaves, joins dropped) checks — the claim tree over the leaf
+            # claims, recomputed on the host with hash_pair, must end in the root receipt's public output
+            follows = None
+            if recursive and not args.no_verify and rank == 0:
+                t_rv = time.perf_counter()
+                root.verify(lanes[0].rec.allowed_roots())            # ONE seal; the claim tree is checked against the leaves below
+                rstats["root_verify_s"] = time.perf_counter() - t_rv
+                verified += 1
+            if succinct and not args.no_verify:
+                mine_claims = {i: receipt_claim(receipts[i], desc, roots[segs[i].po2]) for i in mine}
+                parts = [mine_claims]
+                if distributed:
+                    parts = [None] * world if rank == 0 else None
+                    dist.gather_object(mine_claims, parts, dst=0)
+                if rank == 0 and root is not None and (S > 1 or recursive):
+                    import numpy as np
+                    allc = {k: v for part in parts for k, v in part.items()}
+                    follows = bool(np.array_equal(root.seal[:8], fold_claims([allc[i] for i in range(S)])))
+                    if not follows:
+                        raise SystemExit("bench: the root receipt's output is not the claim tree of the leaves")
+            counts = torch.tensor([float(verified), float(len(joins_done))], dtype=torch.float64, device=ctrl_dev)
+            if distributed:
+                dist.all_reduce(counts)
+            if rank == 0:
+                n_joins = int(counts[1].item())
+                line = {
+                    "metric": "segments/sec", "value": S / dt, "unit": "segments/s", "n_gpus": world, "steps": S,
+                    "warmup": max(1, args.warmup), "ms_per_step": 1e3 * dt / S, "higher_is_better": True, "scaling": "strong",
+                    "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                    "config": {"workload": (f"{'block + join tree to one succinct receipt' if succinct else 'one block'}: {S} distinct "
+                                            f"2^{args.po2}-cycle segments (last one 2^{segs[-1].po2}), {workload}; witness generation inside the clock"
+                                            + (f"; {rstats['proofs']} proofs of the RECURSION circuit ({rstats['fused_lift2']} lift2 = lift + lift + join fused, {rstats['lifts']} lifts, {rstats['joins']} joins): every node runs the STARK verifier on its child seal(s) in-circuit" if recursive else
+                                               f"; {n_joins} P2-JOIN joins at po2 {args.join_po2} (parent claim = Poseidon2 hash_pair of the children's, proven in-circuit)" if succinct else "")),
+                               "po2": args.po2, "circuit": args.circuit, "segments": S,
+                               "parallelism": f"segments round-robin over {world} GPU(s) + shared work index inside a rank, no data-path collective; "
+                                              f"{inflight} seal(s) in flight per GPU" + ("; every rank folds its own aligned range of leaves, rank 0 joins the local roots (gathered over gloo)" if recursive else
+                                                                                         "; joins on the rank of their left child, right child over gloo" if succinct else ""),
+                               "inflight_per_gpu": inflight, "library": HipHal.version(), "host_placement_rank0": placement,
+                               "code_group": "recomputed per segment" if args.recompute_code else "resident per lane and size (byte-identical seals)",
+                               "poseidon2_consts": HipHal.version().split("poseidon2_consts=")[-1].rstrip(")")},
+                    "block_wall_clock_s": dt, "leaf_phase_s": t_leaves, "join_phase_s": dt - t_leaves if succinct else None,
+                    "witgen_ms_per_segment": 1e3 * sum(wit_s) / max(1, len(wit_s)),      # mean, in-clock (rank 0's segments)
+                    "seal_call_ms_mean": 1e3 * sum(seal_s) / max(1, len(seal_s)),
+                    "verified_after_clock": int(counts[0].item()), "verify_s_rank0": verify_s,
+                    "root_receipt_words": int(root.seal.size) if root is not None else None,
+                    "succinct_root_follows_from_leaf_claims": follows,
+                }
+                if recursive:
+                    line["recursion"] = rstats
+                    line["config"]["join_circuit"] = "recursion (lift + join programs, in-circuit verification of every child seal)"
+                elif succinct:
+                    line["config"]["join_circuit"] = "p2_join"
     if distributed:
+        barrier()
         dist.destroy_process_group()
+    if rank == 0 and line is not None:
+        for fn in after_group:
+            fn()
+        print(json.dumps(line))
 
 
-def add_roofline(line, prof, ref, args, inflight, widths, n):
-    """roofline{} for the dominant kernel + the per-kernel table, from the HIP-event brackets of the timed region (prof)
+# kernels (rocprofv3 names) behind the ops whose HBM traffic bench.py can measure on itself
+TRAFFIC_KERNELS = {"hash_rows": ("k_hash_rows",), "hash_fold": ("k_hash_fold",), "eval_check": ("k_eval_check_",)}
+
+
+def by_op(records):
+    """HIP-event records -> per Hal op.  NTT records are "<op>:<kernel>" per pass and the op's §8d bytes are charged to exactly ONE
+    pass of every invocation, so: op time = sum over its passes, op bytes = sum, op invocations = calls of the passes that carry
+    bytes.  A sub-kernel bracket is never a roofline candidate on its own (its bytes live with the parent op)."""
+    ops = {}
+    for p in records:
+        o = ops.setdefault(p["name"].split(":")[0], {"name": p["name"].split(":")[0], "total_ms": 0.0, "alg_bytes": 0.0, "calls": 0, "launches": 0})
+        o["total_ms"] += p["total_ms"]; o["alg_bytes"] += p["alg_bytes"]; o["launches"] += p["calls"]
+        if p["alg_bytes"] > 0 or ":" not in p["name"]:
+            o["calls"] += p["calls"]
+    for o in ops.values():
+        o["calls"] = max(1, o["calls"])
+    return ops
+
+
+def add_roofline(line, prof, ref, args, inflight, widths, n, device=0):
+    """roofline{} for the dominant op + the per-kernel table, from the HIP-event brackets of the timed region (prof)
     and of one extra seal that ran alone on the GPU (ref)."""
     wa, wc, wd = widths
     unshared = {p["name"]: p for p in (ref or prof)}
-    dom_name = max(unshared.values(), key=lambda p: p["total_ms"])["name"]
-    dom = next(p for p in prof if p["name"] == dom_name)
+    ops_unshared, ops_timed = by_op(unshared.values()), by_op(prof)
+    # the dominant OP among those with algorithmic bytes (every Hal op has them; witness-generator brackets may not)
+    cands = [o for o in ops_unshared.values() if o["alg_bytes"] > 0 and o["name"] in ops_timed] or list(ops_unshared.values())
+    dom_u = max(cands, key=lambda o: o["total_ms"])
+    dom_name = dom_u["name"]
+    dom = ops_timed.get(dom_name, dom_u)
     per_launch_ms = dom["total_ms"] / dom["calls"]
-    per_launch_ms_unshared = unshared[dom_name]["total_ms"] / unshared[dom_name]["calls"]
-    per_launch_bytes = dom["alg_bytes"] / dom["calls"]
+    per_launch_ms_unshared = dom_u["total_ms"] / dom_u["calls"]
+    per_launch_bytes = dom_u["alg_bytes"] / dom_u["calls"]
     ach = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
-    # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
-    # FETCH doubled per the gfx950 correction; tools/pmc_summary.py) — bench.py cannot run rocprof on itself
+    # HBM bytes per launch: measured now (two child runs under rocprofv3 --pmc, separate passes) on this rank's GPU, else
+    # from the committed PMC passes of an earlier run of this command (tools/pmc_summary.py)
     traffic, traffic_source = None, None
-    kname = {"hash_rows": "k_hash_rows", "hash_fold": "k_hash_fold", "eval_check": "k_eval_check_syn_a"}.get(dom["name"])
-    if kname and not args.no_live_traffic and int(os.environ.get("WORLD_SIZE", "1")) == 1:
-        got = live_traffic(kname, args.circuit, args.po2)
+    knames = TRAFFIC_KERNELS.get(dom_name)
+    if knames and not args.no_live_traffic:
+        got = live_traffic(knames, args.circuit, args.po2, device=device)
         if got is not None:
-            traffic, _, traffic_source = got
-    for fn in () if traffic is not None else ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+            per_kernel_launch, n_launch, traffic_source = got
+            # an op invocation = dom_u["launches"] / dom_u["calls"] kernel launches (eval_check of a split circuit: one per part)
+            traffic = per_kernel_launch * dom_u["launches"] / dom_u["calls"]
+    for fn in () if traffic is not None else ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
-            kname = {"hash_rows": "k_hash_rows", "hash_fold": "k_hash_fold", "eval_check": "k_eval_check_syn_a"}.get(dom["name"])
+            kname = (knames or ("",))[0]
+            if kname == "k_eval_check_":
+                kname = "k_eval_check_" + args.circuit
             if kname in tj and args.po2 == PO2 and args.circuit == "syn_a":
                 traffic = (tj[kname]["fetch_x2_bytes"] + tj[kname]["write_bytes"]) / tj[kname]["launches"]
                 traffic_source = f"profiles/{fn} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, not measured in this run)"
@@ -1024,23 +1316,24 @@ def add_roofline(line, prof, ref, args, inflight, widths, n):
         except Exception:
             continue
     # Primary figures = the kernel's own launch duration (HIP-event brackets of one seal that ran ALONE right after the timed
-    # region: what `rocprofv3 --kernel-trace --stats` reports per dispatch, profiles/r02_kernel_stats*.csv).  With several
+    # region: what `rocprofv3 --kernel-trace --stats` reports per dispatch, profiles/r0N_kernel_stats*.csv).  With several
     # seals in flight the brackets of the timed region also contain the time a launch spent queued behind the other streams'
     # kernels; those are kept as *_timed_region.
     ach_unshared = per_launch_bytes / (per_launch_ms_unshared * 1e-3) / 1e9
-    line["roofline"] = {"bound": "hbm", "kernel": dom["name"], "achieved": ach_unshared, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+    line["roofline"] = {"bound": "hbm", "kernel": dom_name, "achieved": ach_unshared, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": ach_unshared / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                         "avg_launch_ms": per_launch_ms_unshared,
                         "avg_launch_ms_timed_region": per_launch_ms, "achieved_timed_region": ach,
                         "alg_bytes_per_launch": per_launch_bytes,
-                        "share_of_kernel_time": unshared[dom_name]["total_ms"] / sum(p["total_ms"] for p in unshared.values()),
+                        "share_of_kernel_time": dom_u["total_ms"] / sum(p["total_ms"] for p in unshared.values()),
                         "launches_overlap": inflight > 1,
+                        "measured_on": f"rank 0's GPU (device {device}), one seal alone after the timed region" if ref else "the timed region",
                         "note": "dominant kernel is integer-VALU-bound by construction (Poseidon2: ~21 Montgomery "
                                 "products per absorbed byte); HBM fraction is reported as the contract asks; avg_launch_ms is the "
                                 "kernel's own duration (one seal alone on the GPU, measured live after the timed region); with "
                                 "inflight_per_gpu > 1 the HIP-event brackets of the timed region (*_timed_region) also include time "
                                 "queued behind other streams' kernels"}
-    if dom["name"] == "hash_rows":
+    if dom_name == "hash_rows":
         # VALU view of the same kernel: permutations per launch x modelled issue cycles per 64-lane permutation
         # (8 full rounds x 1990 + 7 partial groups x 1259 + first M_ext 711 + scale fixes 480 cycles;
         # 4 cycles per multiply / fp64 / select-class instruction, 2.46 per plain add-class one: tools/ubench_valu.hip) against 1024 SIMDs at 2.4 GHz
@@ -1050,7 +1343,7 @@ def add_roofline(line, prof, ref, args, inflight, widths, n):
             perms += 4 * (4 * deg // 16)
             deg //= 16
         cyc = 8 * 1990 + 7 * 1259 + 711 + 480
-        per_seal_ms = unshared[dom_name]["total_ms"] / (1 if ref else args.steps)
+        per_seal_ms = dom_u["total_ms"] / (1 if ref else args.steps)
         line["roofline"]["valu"] = {"permutations_per_seal": perms, "model_cycles_per_wave_permutation": cyc,
                                     "issue_utilisation_at_2p4GHz": (perms / 64.0) * cyc / (1024 * 2.4e9 * per_seal_ms * 1e-3)}
     div = 1 if ref else args.steps
@@ -1061,12 +1354,9 @@ def add_roofline(line, prof, ref, args, inflight, widths, n):
                         "alg_GBps": (p["alg_bytes"] / (p["total_ms"] * 1e-3) / 1e9) if p["total_ms"] > 0 else 0.0}
                        for p in sorted(unshared.values(), key=lambda p: -p["total_ms"])]
     # per Hal op (NTT records are "<op>:<kernel>" per pass): op totals with §8d bytes over the sum of the passes
-    ops = {}
-    for p in unshared.values():
-        o = ops.setdefault(p["name"].split(":")[0], {"ms": 0.0, "bytes": 0.0})
-        o["ms"] += p["total_ms"] / div; o["bytes"] += p["alg_bytes"] / div
-    line["ops"] = [{"op": k, "ms_per_seal": v["ms"], "alg_GBps": v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0}
-                   for k, v in sorted(ops.items(), key=lambda kv: -kv[1]["ms"])]
+    line["ops"] = [{"op": o["name"], "ms_per_seal": o["total_ms"] / div,
+                    "alg_GBps": o["alg_bytes"] / (o["total_ms"] * 1e-3) / 1e9 if o["total_ms"] > 0 else 0.0}
+                   for o in sorted(ops_unshared.values(), key=lambda o: -o["total_ms"])]
 
 
 if __name__ == "__main__":

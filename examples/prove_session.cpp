@@ -8,7 +8,7 @@
 // written out against the low-level entry points.)
 //
 //   prove_session --desc syn_a.desc [--join-desc p2_join.desc | --recursion-dir DIR] [--po2 20] [--tail-po2 18] [--segments 64]
-//                 [--devices 1] [--inflight 3] [--join-po2 18] [--noise-seed N]
+//                 [--devices 1] [--inflight 3] [--join-po2 18] [--noise-seed N] [--two-phase] [--recompute-code]
 // --recursion-dir: the directory `python -m zeth_amd.circuits.rec_verify DIR` and `python -m zeth_amd.circuits.recursion
 // DIR/recursion.desc` wrote (lift-<po2>.zkr1, lift2-<l>-<r>.zkr1, join-<l>-<r>.zkr1): lift the receipts (in pairs: lift2) and join them to one root receipt whose
 // every node verified its child seal(s) IN-CIRCUIT (BASELINE.json config 5).
@@ -36,6 +36,7 @@ int main(int argc, char** argv) {
     std::string desc_path, join_path, rec_dir;
     size_t po2 = 20, tail_po2 = 18, n = 64, devices = 1, inflight = 3, join_po2 = 18;
     uint64_t noise = 0;
+    bool two_phase = false, recompute_code = false;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto num = [&](size_t& d) { if (i + 1 < argc) d = strtoull(argv[++i], nullptr, 10); };
@@ -49,6 +50,8 @@ int main(int argc, char** argv) {
         else if (a == "--inflight") num(inflight);
         else if (a == "--join-po2") num(join_po2);
         else if (a == "--noise-seed" && i + 1 < argc) noise = strtoull(argv[++i], nullptr, 0);
+        else if (a == "--two-phase") two_phase = true;          // seal everything, then fold (default: one pipeline)
+        else if (a == "--recompute-code") recompute_code = true; // re-commit the code group per segment, like upstream's SegmentProver
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     std::vector<uint32_t> desc, jdesc;
@@ -90,6 +93,8 @@ int main(int argc, char** argv) {
         err = zkh_session_set_recursion(session, rdesc.data(), rdesc.size(), ptrs.data(), words.data(), kinds.data(), blobs.size());
         if (err) { fprintf(stderr, "zkh_session_set_recursion: %s\n", err); zkh_free_error(err); return 1; }
     }
+    if (two_phase) zkh_session_set_streamed_fold(session, 0);
+    if (recompute_code) zkh_session_set_resident_code(session, 0);
     // the session's segment list: S distinct segments, the last one the short tail
     std::vector<zkh_segment> segs(n);
     for (size_t i = 0; i < n; i++) {
@@ -108,10 +113,10 @@ int main(int argc, char** argv) {
     printf("{\"driver\": \"prove_session\", \"library\": \"%s\", \"segments\": %zu, \"po2\": %zu, \"tail_po2\": %u, \"lanes\": %zu, "
            "\"wall_s\": %.4f, \"leaves_s\": %.4f, \"segments_per_s\": %.3f, \"witgen_ms_per_segment\": %.3f, \"lifts\": %zu, \"lift_s\": %.4f, "
            "\"joins\": %zu, \"join_tree_s\": %.4f, \"in_circuit_verification\": %s, \"root_receipt_words\": %zu, \"seal_words_total\": %zu, "
-           "\"verified\": true}\n",
+           "\"streamed_fold\": %s, \"fold_tail_s\": %.4f, \"fold_busy_lane_s\": %.3f, \"segment_retries\": %zu, \"verified\": true}\n",
            zkh_version(), n, po2, segs[n - 1].po2, zkh_session_lanes(session), info.wall_s, info.leaves_s, n / info.leaves_s,
            1e3 * info.witgen_s_sum / n, info.n_lifts, info.lift_s, info.n_joins, info.join_s, info.n_lifts ? "true" : "false",
-           info.root_seal_words, words);
+           info.root_seal_words, words, info.streamed ? "true" : "false", info.fold_tail_s, info.fold_busy_s_sum, info.n_retries);
     zkh_prove_info_free(&info);
     zkh_session_destroy(session);
     return 0;

@@ -117,6 +117,10 @@ const char* zkh_hash_fold(zkh_ctx*, zkh_buf* io_digests, size_t input_size, size
 /* Fused MerkleTreeProver::new tail: every hash_fold layer from `rows` leaves down to the root.
  * nodes has 2*rows digests, leaves already at [rows, 2*rows). */
 const char* zkh_merkle_fold_all(zkh_ctx*, zkh_buf* nodes, size_t rows);
+/* MerkleTreeProver::new as one call: nodes[rows .. 2 rows) = hash_rows(matrix), then every layer above down to the root at nodes[1].
+ * Wide trees hash two adjacent rows per lane and their parent in the same pass (the largest hash_fold layer is never a launch of
+ * its own); digests are identical to zkh_hash_rows + zkh_merkle_fold_all. */
+const char* zkh_merkle_build(zkh_ctx*, zkh_buf* nodes, const zkh_buf* matrix, size_t rows);
 /* The bare permutation (risc0_zkp::core::hash::poseidon2::poseidon2_mix): `count` states of 24 Montgomery words each,
  * in place — on the device with the context's tables, or on the host (rc / diag canonical residues, NULL = the shipped
  * tables).  What the published known-answer vector of the instance is checked against (tests/golden/poseidon2_kat.json). */
@@ -214,7 +218,8 @@ const char* zkh_eval_check(zkh_ctx*, const zkh_circuit*, zkh_buf* check, const z
  *                    `pub` = the two child claims (16 words, required); out_global = parent (8) ‖ left (8) ‖ right (8). */
 /* code group only: a function of (circuit, po2, zk_cycles) — what the control root commits to */
 const char* zkh_syn_code(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cycles, zkh_buf* code);
-/* pub: OUTPUT_SIZE - 4 public input words (Montgomery; NULL if the circuit has none); out_global: OUTPUT_SIZE words */
+/* pub: OUTPUT_SIZE - 4 public input words (Montgomery; NULL if the circuit has none); out_global: OUTPUT_SIZE words;
+ * code may be NULL for kinds 1 and 2 (the caller already holds this size's code group, e.g. resident in its prover) */
 const char* zkh_syn_witgen(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cycles, uint64_t seed,
                            uint64_t noise_seed, const uint32_t* pub, zkh_buf* code, zkh_buf* data, uint32_t* out_global);
 const char* zkh_syn_accum(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cycles, uint64_t noise_seed,
@@ -345,7 +350,12 @@ typedef struct {
     double witgen_s_sum, seal_s_sum;            /* summed over segments (lane seconds) */
     size_t n_lifts;                             /* join_tree == 2: proofs of the bottom level (lifts, or lift2 per pair); the root is a RECURSION seal */
     size_t root_program;                        /* ... and the index of the program the root was sealed under */
-    double lift_s;                              /* ... the lift phase (join_s is then the joins alone) */
+    double lift_s;                              /* ... the bottom level (join_s is then the joins alone) — with the streamed fold: what
+                                                 * each still took AFTER the last segment was sealed (most of it overlapped the leaves) */
+    size_t n_retries;                           /* segments handed to another lane after a failed attempt (ZKH_SEGMENT_RETRIES, default 1) */
+    double fold_tail_s;                         /* join_tree == 2: last segment sealed -> root receipt */
+    double fold_busy_s_sum;                     /* ... lane seconds spent inside lift / lift2 / join proofs */
+    int streamed;                               /* ... 1 = fold nodes were proven as soon as their children existed (the default) */
 } zkh_prove_info;
 /* CircuitHal::accumulate for circuits without a built-in accum generator: fill `accum` (W_accum x 2^po2) from data + mix */
 typedef const char* (*zkh_accumulate_fn)(void* user, zkh_ctx*, const zkh_circuit*, size_t po2, const zkh_buf* data,
@@ -358,6 +368,10 @@ size_t zkh_session_lanes(const zkh_session*);
 /* the circuit handle of a lane (join != 0: its join circuit), e.g. to attach code objects before proving */
 zkh_circuit* zkh_session_circuit(zkh_session*, size_t lane, int join);
 void zkh_session_set_accumulate(zkh_session*, zkh_accumulate_fn fn, void* user);
+/* Built-in circuits (kinds 1, 2): every lane commits the code (control) group of a segment size ONCE and keeps the committed form
+ * resident in HBM (zkh_prover_cache_code) — the default; seals are byte-identical.  on = 0: re-commit it per segment, as
+ * upstream's SegmentProver does. */
+void zkh_session_set_resident_code(zkh_session*, int on);
 /* The lift / join programs of the RECURSION circuit (zkh_rec_program_*; blobs from `python -m zeth_amd.circuits.rec_verify dir`):
  * rec_desc = the RECURSION description; program i is blobs[i] (words[i] words) of kind kinds[3 i .. 3 i + 3) = {0, segment po2,
  * circuit family (0 = the session's)} for a lift, {1, left po2, right po2} for a join of two recursion seals, {2, left po2,
@@ -365,6 +379,10 @@ void zkh_session_set_accumulate(zkh_session*, zkh_accumulate_fn fn, void* user);
  * every pair of the session has one).  Every lane loads every program (code groups resident). */
 const char* zkh_session_set_recursion(zkh_session*, const uint32_t* rec_desc, size_t rec_desc_words, const uint32_t* const* blobs,
                                       const size_t* words, const uint32_t* kinds, size_t n_programs);
+/* join_tree == 2 runs as ONE pipeline by default: a lift2 / join is proven the moment both children exist, on the fold lanes while
+ * the sealing lanes are still busy with segments, on every lane afterwards (upstream joins as receipts arrive too).  on = 0: two
+ * phases (seal everything, then fold).  Same tree, same receipts either way. */
+void zkh_session_set_streamed_fold(zkh_session*, int on);
 /* join_tree == 1: fold the receipts through the P2-JOIN tree (joins at 2^join_po2; join_noise_seed 0 = OS randomness);
  * join_tree == 2: lift every receipt and join level by level with the RECURSION programs - every node verifies its child
  * seal(s) in-circuit; the root receipt is a RECURSION seal with out = claim tree root ‖ allowed-programs root */
@@ -374,6 +392,21 @@ void zkh_prove_info_free(zkh_prove_info*);
 /* every leaf seal against the control root of its size; with a root receipt also the root seal and the claim tree
  * (hash_pair over the leaf claims, recomputed on the host) against the root's public output */
 const char* zkh_session_verify(zkh_session*, const zkh_segment* segs, const zkh_prove_info* info, size_t join_po2);
+
+/* ---- host placement (topology.hip): one process per GPU / one lane thread per context should run on the cores of the NUMA node
+ * the GPU's root port hangs off, and allocate its pinned witness blocks there (upstream leaves placement to the operator:
+ * /root/reference/run-parallel.sh:15 starts one prover per GPU and pins nothing).  Host only; sysfs + sched_setaffinity. ---- */
+/* "0-15,64-79" -> sorted CPU ids (cpus may be NULL to count); anything that is not a cpulist is an error */
+const char* zkh_parse_cpulist(const char* text, int* cpus, size_t cap, size_t* n);
+/* NUMA node of PCI function bdf ("0000:c1:00.0") and that node's CPUs, read under sysfs_root ("/sys"); *node = -1 and
+ * *n_cpus = 0 when the kernel reports none */
+const char* zkh_pci_numa_cpus(const char* sysfs_root, const char* bdf, int* node, int* cpus, size_t cap, size_t* n_cpus);
+/* NUMA node of a HIP device (-1 = unknown) and, optionally, its PCI bus id */
+const char* zkh_device_numa_node(int device, int* node, char pci_bus_id[32]);
+/* Bind the CALLING thread (and the threads it creates afterwards) to slice `slot` of `share` equal slices of the device's
+ * NUMA-node CPUs (share <= 1: the whole node) and make that node its preferred memory node.  ZKH_AFFINITY=off, or a host that
+ * reports no node: nothing is changed and *node = -1. */
+const char* zkh_bind_thread_to_device(int device, size_t slot, size_t share, int* node, size_t* n_cpus);
 
 /* ---- profiling: per-kernel HIP-event timing on the ctx stream ---- */
 const char* zkh_prof_enable(zkh_ctx*, int on);

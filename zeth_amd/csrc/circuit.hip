@@ -730,7 +730,7 @@ extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t
     if (c->kind == 3) {
         // P2-JOIN: `pub` = the two child claims (16 Montgomery words, required); out_global = parent ‖ left ‖ right
         ZKH_TRY(p2join_check_shape(c));
-        ZKH_REQUIRE(code->len == (size_t)wc * n && data->len == (size_t)wd * n, "p2join witgen: buffer shape mismatch");
+        ZKH_REQUIRE(code && code->len == (size_t)wc * n && data->len == (size_t)wd * n, "p2join witgen: buffer shape mismatch (the code group is an input of this generator)");
         ZKH_REQUIRE(pub, "p2join witgen: the two child claims (16 words) are required");
         for (uint32_t k = 0; k < 16; k++) ZKH_REQUIRE(pub[k] < P, "p2join witgen: child claim word %u is not a reduced element", k);
         const uint32_t K = A / PJ_BLOCK;
@@ -755,10 +755,10 @@ extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t
         // KECCAK-F: `pub` = optional input state of the LAST permutation (25 lanes = 50 words, low word first); out_global =
         // that permutation's output state as 100 16-bit limbs (what the `final` row's constraints bind)
         ZKH_TRY(keccak_check_shape(c));
-        ZKH_REQUIRE(code->len == (size_t)wc * n && data->len == (size_t)wd * n, "keccak witgen: buffer shape mismatch");
+        ZKH_REQUIRE((!code || code->len == (size_t)wc * n) && data->len == (size_t)wd * n, "keccak witgen: buffer shape mismatch");
         const uint32_t K = A / KF_BLOCK;
         ZKH_REQUIRE(K > 0, "keccak witgen: no room for a permutation (25 rows) in %u active rows", A);
-        ZKH_TRY(zkh_syn_code(ctx, c, po2, zk_cycles, code));
+        if (code) ZKH_TRY(zkh_syn_code(ctx, c, po2, zk_cycles, code));
         Tmp rows, din;
         ZKH_TRY(new_buf(ctx, (size_t)K * KF_BLOCK * KF_LANES * 2, false, rows.out()));
         if (pub) ZKH_TRY(zkh_copy_from(ctx, "keccak_input", pub, 50, din.out()));
@@ -779,10 +779,10 @@ extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t
         return nullptr;
     }
     const uint32_t n_pub = c->global_size[GLOBAL_OUT] - 4;
-    ZKH_REQUIRE(code->len == (size_t)wc * n && data->len == (size_t)wd * n, "syn_witgen: buffer shape mismatch");
+    ZKH_REQUIRE((!code || code->len == (size_t)wc * n) && data->len == (size_t)wd * n, "syn_witgen: buffer shape mismatch");
     ZKH_REQUIRE(n_pub == 0 || pub, "syn_witgen: the circuit has %u public input words but none were given", n_pub);
     for (uint32_t k = 0; k < n_pub; k++) ZKH_REQUIRE(pub[k] < P, "syn_witgen: public input %u is not a reduced element", k);
-    ZKH_TRY(zkh_syn_code(ctx, c, po2, zk_cycles, code));
+    if (code) ZKH_TRY(zkh_syn_code(ctx, c, po2, zk_cycles, code));       // NULL: the caller holds this size's code group already (resident)
     Tmp last, dpub;
     ZKH_TRY(new_buf(ctx, 1, false, last.out()));
     if (n_pub) ZKH_TRY(zkh_copy_from(ctx, "pub", pub, n_pub, dpub.out()));

@@ -8,8 +8,11 @@
 // device; segments are independent, so here segment i goes to whichever lane is free next (one shared work
 // index over all lanes of all devices: round-robin with work stealing for the short tail), with NO exchange between devices.
 // Host code only (threads + the C ABI of this library); one lane = one zkh_ctx (device + stream) + circuit + prover.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -26,10 +29,15 @@ namespace {
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-uint64_t os_random64() {
+// Blinding seeds come from the OS; if it cannot deliver, the seal must FAIL rather than run with a guessable seed
+// (predictable blinding rows would silently lose zero-knowledge).
+const char* os_random64(uint64_t* out) {
     uint64_t v = 0;
-    if (getrandom(&v, sizeof v, 0) != (ssize_t)sizeof v) v = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() * 0x9E3779B97F4A7C15ull;
-    return v ? v : 1;
+    for (int tries = 0; tries < 4 && !v; tries++)
+        if (getrandom(&v, sizeof v, 0) != (ssize_t)sizeof v) v = 0;
+    ZKH_REQUIRE(v != 0, "OS randomness (getrandom) is unavailable: refusing to seal with a predictable blinding seed");
+    *out = v;
+    return nullptr;
 }
 
 struct Lane {
@@ -38,6 +46,7 @@ struct Lane {
     zkh_circuit *circuit = nullptr, *join_circuit = nullptr, *rec_circuit = nullptr;
     zkh_prover *prover = nullptr, *join_prover = nullptr;
     std::vector<zkh_rec_program*> programs;
+    std::vector<uint32_t> resident_po2;       // sizes whose committed code group this lane's prover keeps in HBM
     void close() {
         for (auto p : programs) zkh_rec_program_destroy(p);
         programs.clear();
@@ -81,6 +90,8 @@ struct zkh_session {
     size_t lanes_per_device = 0;
     zkh_accumulate_fn accumulate = nullptr;
     void* accumulate_user = nullptr;
+    bool resident_code = true;           // built-in circuits: the committed code group of each size stays in HBM per lane
+    bool streamed_fold = true;           // join_tree 2: lift2 / join a node the moment its children exist, concurrently with the sealing lanes
     ~zkh_session() { for (auto& l : fold_lanes) l.close(); for (auto& l : lanes) l.close(); }
 };
 
@@ -113,6 +124,11 @@ extern "C" zkh_circuit* zkh_session_circuit(zkh_session* s, size_t lane, int joi
     if (!s || lane >= s->lanes.size()) return nullptr;
     return join ? s->lanes[lane].join_circuit : s->lanes[lane].circuit;
 }
+extern "C" void zkh_session_set_resident_code(zkh_session* s, int on) {
+    if (!s) return;
+    s->resident_code = on != 0;
+    if (!on) for (auto& l : s->lanes) { if (l.prover) zkh_prover_drop_code_cache(l.prover); l.resident_po2.clear(); }
+}
 extern "C" void zkh_session_set_accumulate(zkh_session* s, zkh_accumulate_fn fn, void* user) {
     if (s) { s->accumulate = fn; s->accumulate_user = user; }
 }
@@ -129,49 +145,73 @@ constexpr size_t REC_ALLOWED = 16, REC_DEPTH = 4;                   // zeth_amd/
 extern "C" const char* zkh_session_set_recursion(zkh_session* s, const uint32_t* rec_desc, size_t rec_desc_words, const uint32_t* const* blobs,
                                                  const size_t* words, const uint32_t* kinds, size_t n_programs) {
     ZKH_REQUIRE(s && rec_desc && rec_desc_words >= 16 && blobs && words && kinds && n_programs && n_programs <= REC_ALLOWED, "session_set_recursion: bad argument");
-    ZKH_REQUIRE(s->rec_kinds.empty(), "session_set_recursion: the session already has its programs");
-    s->rec_desc.assign(rec_desc, rec_desc + rec_desc_words);
+    ZKH_REQUIRE(s->rec_kinds.empty() && s->rec_lanes.empty() && s->fold_lanes.empty(), "session_set_recursion: the session already has its programs");
+    // Everything is built in locals and committed to the session only when every context, circuit and program has loaded: a
+    // failure half way leaves the session exactly as it was (no lane holds a program, no fold lane exists, a retry starts clean).
+    std::vector<Lane> fold_lanes;
+    struct Loaded { zkh_circuit* circuit = nullptr; std::vector<zkh_rec_program*> programs; };
+    std::vector<Loaded> loaded;
+    auto undo = [&] {
+        for (auto& ld : loaded) { for (auto p : ld.programs) zkh_rec_program_destroy(p); if (ld.circuit) zkh_circuit_destroy(ld.circuit); }
+        for (auto& l : fold_lanes) l.close();
+    };
+#define REC_TRY(expr) do { const char* _e = (expr); if (_e) { undo(); return _e; } } while (0)
     // a lift's / join's witness schedule is a chain of ~300 dependency levels (latency): the fold runs on ZKH_FOLD_LANES lanes
     // per device (default 6: the measured knee, profiles/r03_recursion_fold_lanes.txt), the sealing lanes plus extra contexts
     const char* env = getenv("ZKH_FOLD_LANES");
     const size_t want = env ? (size_t)strtoul(env, nullptr, 10) : 6;
     const size_t n_devices = s->lanes.size() / s->lanes_per_device;
     if (want > s->lanes_per_device) {
-        s->fold_lanes.resize(n_devices * (want - s->lanes_per_device));
-        for (size_t i = 0; i < s->fold_lanes.size(); i++) {
-            Lane& l = s->fold_lanes[i];
+        fold_lanes.resize(n_devices * (want - s->lanes_per_device));
+        for (size_t i = 0; i < fold_lanes.size(); i++) {
+            Lane& l = fold_lanes[i];
             l.device = s->lanes[(i / (want - s->lanes_per_device)) * s->lanes_per_device].device;
-            ZKH_TRY(zkh_ctx_create(l.device, "poseidon2", &l.ctx));
+            REC_TRY(zkh_ctx_create(l.device, "poseidon2", &l.ctx));
         }
     }
-    for (auto& l : s->lanes) s->rec_lanes.push_back(&l);
-    for (auto& l : s->fold_lanes) s->rec_lanes.push_back(&l);
-    for (Lane* lp : s->rec_lanes) {
-        Lane& l = *lp;
-        ZKH_TRY(zkh_circuit_load(l.ctx, s->rec_desc.data(), s->rec_desc.size(), &l.rec_circuit));
+    std::vector<Lane*> rec_lanes;
+    for (auto& l : s->lanes) rec_lanes.push_back(&l);
+    for (auto& l : fold_lanes) rec_lanes.push_back(&l);
+    loaded.resize(rec_lanes.size());
+    for (size_t k = 0; k < rec_lanes.size(); k++) {
+        REC_TRY(zkh_circuit_load(rec_lanes[k]->ctx, rec_desc, rec_desc_words, &loaded[k].circuit));
         for (size_t i = 0; i < n_programs; i++) {
             zkh_rec_program* p = nullptr;
-            ZKH_TRY(zkh_rec_program_load(l.ctx, l.rec_circuit, blobs[i], words[i], &p));
-            l.programs.push_back(p);
+            REC_TRY(zkh_rec_program_load(rec_lanes[k]->ctx, loaded[k].circuit, blobs[i], words[i], &p));
+            loaded[k].programs.push_back(p);
         }
     }
+    std::vector<RecKind> rec_kinds;
+    std::vector<std::vector<uint32_t>> rec_roots;
     for (size_t i = 0; i < n_programs; i++) {
-        s->rec_kinds.push_back(RecKind{kinds[3 * i], kinds[3 * i + 1], kinds[3 * i + 2]});
+        rec_kinds.push_back(RecKind{kinds[3 * i], kinds[3 * i + 1], kinds[3 * i + 2]});
         std::vector<uint32_t> root(8);
-        ZKH_TRY(zkh_rec_program_info(s->lanes[0].programs[i], root.data(), nullptr));
-        s->rec_roots.push_back(root);
+        REC_TRY(zkh_rec_program_info(loaded[0].programs[i], root.data(), nullptr));
+        rec_roots.push_back(root);
     }
-    std::vector<std::vector<uint32_t>> level(s->rec_roots);
+    std::vector<std::vector<uint32_t>> level(rec_roots);
     level.resize(REC_ALLOWED, std::vector<uint32_t>(8, 0));
-    s->allowed.assign(1, level);
+    std::vector<std::vector<std::vector<uint32_t>>> allowed(1, level);
     while (level.size() > 1) {
         std::vector<std::vector<uint32_t>> up(level.size() / 2, std::vector<uint32_t>(8));
-        for (size_t k = 0; k < up.size(); k++) ZKH_TRY(hash_pair_host(level[2 * k].data(), level[2 * k + 1].data(), up[k].data()));
-        s->allowed.push_back(up);
+        for (size_t k = 0; k < up.size(); k++) REC_TRY(hash_pair_host(level[2 * k].data(), level[2 * k + 1].data(), up[k].data()));
+        allowed.push_back(up);
         level.swap(up);
     }
+#undef REC_TRY
+    // ---- commit (nothing below can fail) ----
+    s->rec_desc.assign(rec_desc, rec_desc + rec_desc_words);
+    s->fold_lanes = std::move(fold_lanes);
+    s->rec_lanes.clear();
+    for (auto& l : s->lanes) s->rec_lanes.push_back(&l);
+    for (auto& l : s->fold_lanes) s->rec_lanes.push_back(&l);
+    for (size_t k = 0; k < s->rec_lanes.size(); k++) { s->rec_lanes[k]->rec_circuit = loaded[k].circuit; s->rec_lanes[k]->programs = std::move(loaded[k].programs); }
+    s->rec_kinds = std::move(rec_kinds);
+    s->rec_roots = std::move(rec_roots);
+    s->allowed = std::move(allowed);
     return nullptr;
 }
+extern "C" void zkh_session_set_streamed_fold(zkh_session* s, int on) { if (s) s->streamed_fold = on != 0; }
 
 extern "C" void zkh_prove_info_free(zkh_prove_info* info) {
     if (!info) return;
@@ -196,7 +236,8 @@ static const char* leaf_control_root(zkh_session* s, const zkh_segment& seg, uin
 static const char* seal_one(zkh_session* s, Lane& l, const zkh_segment& seg, uint32_t** seal, size_t* words, double* witgen_s) {
     const zkh_circuit* cir = l.circuit;
     const size_t n = (size_t)1 << seg.po2;
-    const uint64_t noise = seg.noise_seed ? seg.noise_seed : os_random64();
+    uint64_t noise = seg.noise_seed;
+    if (!noise) ZKH_TRY(os_random64(&noise));
     Tmp code, data;
     ZKH_TRY(zkh_alloc(l.ctx, "code", (size_t)cir->group_size[GROUP_CODE] * n, 0, code.out()));
     ZKH_TRY(zkh_alloc(l.ctx, "data", (size_t)cir->group_size[GROUP_DATA] * n, 0, data.out()));
@@ -222,6 +263,20 @@ static const char* seal_one(zkh_session* s, Lane& l, const zkh_segment& seg, uin
         return zkh_prove_finish(job, accum, seal, words);
     }
     ZKH_REQUIRE(cir->kind >= 1 && cir->kind <= 3, "session: circuit kind %u has no built-in witness generator: supply host traces", cir->kind);
+    // The code (control) group of a built-in circuit is a function of (circuit, po2) alone: commit it once per lane and size and
+    // keep the committed form in HBM (seals are byte-identical to the recomputing prover's).  Upstream's
+    // SegmentProver re-commits it per segment; zkh_session_set_resident_code(s, 0) does the same.
+    if (s->resident_code && cir->kind <= 2) {
+        if (std::find(l.resident_po2.begin(), l.resident_po2.end(), seg.po2) == l.resident_po2.end()) {
+            ZKH_TRY(zkh_syn_code(l.ctx, cir, seg.po2, ZKH_ZK_CYCLES, code));
+            ZKH_TRY(zkh_prover_cache_code(l.prover, seg.po2, code));
+            l.resident_po2.push_back(seg.po2);
+        }
+        code.out();                                                  // the trace itself is not needed again
+        ZKH_TRY(zkh_syn_witgen(l.ctx, cir, seg.po2, ZKH_ZK_CYCLES, seg.seed, noise, seg.n_pub ? seg.pub : nullptr, nullptr, data, out_global.data()));
+        *witgen_s = now_s() - t0;
+        return zkh_prove_segment(l.prover, seg.po2, ZKH_ZK_CYCLES, noise, nullptr, data, out_global.data(), seal, words);
+    }
     ZKH_TRY(zkh_syn_witgen(l.ctx, cir, seg.po2, ZKH_ZK_CYCLES, seg.seed, noise, seg.n_pub ? seg.pub : nullptr, code, data, out_global.data()));
     *witgen_s = now_s() - t0;
     return zkh_prove_segment(l.prover, seg.po2, ZKH_ZK_CYCLES, noise, code, data, out_global.data(), seal, words);
@@ -236,129 +291,240 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
     info->n_segments = n;
     info->seals = (uint32_t**)calloc(n, sizeof(uint32_t*));
     info->seal_words = (size_t*)calloc(n, sizeof(size_t));
+    if (!info->seals || !info->seal_words) {
+        free(info->seals); free(info->seal_words);
+        memset(info, 0, sizeof *info);
+        return make_err("session_prove: out of host memory for %zu receipts", n);
+    }
+    const bool fold = join_tree == 2;
+    const bool streamed = fold && s->streamed_fold;
+    info->streamed = streamed;
+    constexpr size_t NONE = (size_t)-1;
+
+    // ---- the fold plan (join_tree 2), fixed before anything runs: the bottom level turns segment receipts into recursion
+    // receipts — a pair of segments is ONE proof where the program set has lift2(po2_l, po2_r) for EVERY pair (lift + lift + join
+    // fused), else every segment is lifted on its own — and every level above pairs nodes (2k, 2k+1), an unpaired last node moves
+    // up unchanged (the tree of host.fold_claims).  A node's program follows from its children's sizes, so a missing program is
+    // reported here, not after the leaves are sealed. ----
+    struct PNode {
+        uint32_t kind = 0;                 // 0 lift(a), 2 lift2(a, b): a, b segment indices; 1 join(a, b): node ids
+        size_t a = 0, b = 0, parent = (size_t)-1;
+        uint32_t program = 0, po2 = 0;
+        int pending = 0;                   // children not yet available
+        uint32_t* seal = nullptr;
+        size_t words = 0;
+    };
+    std::vector<PNode> plan;
+    std::vector<size_t> owner(fold ? n : 0, NONE);         // the bottom node that consumes segment i
+    size_t root_node = NONE, n_bottom = 0;
+    auto program_of = [&](uint32_t join, uint32_t a, uint32_t b) -> int {
+        for (size_t i = 0; i < s->rec_kinds.size(); i++)
+            if (s->rec_kinds[i].join == join && s->rec_kinds[i].a == a && s->rec_kinds[i].b == b) return (int)i;     // lifts: b = circuit family, 0 = the session's
+        return -1;
+    };
+    auto po2_of = [&](uint32_t program) { uint32_t inf[8] = {0}; (void)zkh_rec_program_info(s->lanes[0].programs[program], nullptr, inf); return inf[0]; };
+    if (fold) {
+        const size_t n_pairs = n / 2;
+        bool all_fused = n > 1;
+        for (size_t k = 0; k < n_pairs && all_fused; k++) all_fused = program_of(2, segs[2 * k].po2, segs[2 * k + 1].po2) >= 0;
+        auto add_lift = [&](size_t i) -> const char* {
+            const int p = program_of(0, segs[i].po2, 0);
+            ZKH_REQUIRE(p >= 0, "session_prove: no lift program for po2-%u segments", segs[i].po2);
+            PNode nd; nd.kind = 0; nd.a = i; nd.program = (uint32_t)p; nd.po2 = po2_of((uint32_t)p); nd.pending = 1;
+            owner[i] = plan.size(); plan.push_back(nd);
+            return nullptr;
+        };
+        const char* perr = nullptr;
+        if (all_fused) {
+            for (size_t k = 0; k < n_pairs; k++) {
+                PNode nd; nd.kind = 2; nd.a = 2 * k; nd.b = 2 * k + 1; nd.pending = 2;
+                nd.program = (uint32_t)program_of(2, segs[2 * k].po2, segs[2 * k + 1].po2); nd.po2 = po2_of(nd.program);
+                owner[2 * k] = owner[2 * k + 1] = plan.size(); plan.push_back(nd);
+            }
+            if (n % 2) perr = add_lift(n - 1);
+        } else {
+            for (size_t i = 0; i < n && !perr; i++) perr = add_lift(i);
+        }
+        n_bottom = plan.size();
+        std::vector<size_t> cur(n_bottom);
+        for (size_t k = 0; k < n_bottom; k++) cur[k] = k;
+        while (cur.size() > 1 && !perr) {
+            std::vector<size_t> nxt;
+            for (size_t k = 0; k + 1 < cur.size(); k += 2) {
+                PNode nd; nd.kind = 1; nd.a = cur[k]; nd.b = cur[k + 1]; nd.pending = 2;
+                const int p = program_of(1, plan[nd.a].po2, plan[nd.b].po2);
+                if (p < 0) { perr = make_err("session_prove: no join program for children of po2 %u and %u", plan[nd.a].po2, plan[nd.b].po2); break; }
+                nd.program = (uint32_t)p; nd.po2 = po2_of(nd.program);
+                plan[nd.a].parent = plan[nd.b].parent = plan.size();
+                nxt.push_back(plan.size()); plan.push_back(nd);
+            }
+            if (cur.size() % 2) nxt.push_back(cur.back());
+            cur.swap(nxt);
+        }
+        if (perr) { zkh_prove_info_free(info); return perr; }
+        root_node = cur[0];
+    }
+    auto path_of = [&](uint32_t program, std::vector<uint32_t>& out) {      // per level: the direction bit as an element, the sibling
+        size_t idx = program;
+        for (size_t l = 0; l < REC_DEPTH; l++) {
+            out.push_back(fp_encode((uint32_t)(idx & 1)).v);
+            out.insert(out.end(), s->allowed[l][idx ^ 1].begin(), s->allowed[l][idx ^ 1].end());
+            idx >>= 1;
+        }
+    };
+
+    // ---- one scheduler for the whole call.  Sealing lanes pull segments from one index (round-robin with work stealing over all
+    // lanes of all devices; a segment whose seal fails is handed to ANOTHER lane before the session gives up: ZKH_SEGMENT_RETRIES,
+    // default 1).  With join_tree 2 a fold node becomes ready the moment its children exist and is proven by whichever lane is
+    // free — the fold-only lanes while segments are still being sealed (the witness schedule of a lift / join is a 300-level
+    // latency chain that fills the gaps the VALU-bound seals leave), every lane once the segments are done: upstream's
+    // join-as-you-go.  zkh_session_set_streamed_fold(s, 0) holds the fold back until the last segment is sealed (two phases). ----
     ErrorSlot errs;
-    std::atomic<size_t> next{0};
-    std::mutex stat_lock;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<size_t> ready;                                  // fold nodes whose children exist
+    struct Retry { size_t seg; const Lane* failed_on; double since; };
+    std::deque<Retry> retry;
+    std::vector<int> attempts(n, 0);
+    size_t next_seal = 0, seals_done = 0, seal_lanes_active = s->lanes.size();
+    bool root_done = !fold;
+    double t_leaves_done = 0, t_bottom_done = 0;
+    size_t bottom_done = 0;
+    const char* renv = getenv("ZKH_SEGMENT_RETRIES");
+    const int max_retries = renv ? atoi(renv) : 1;
+    const char* fenv = getenv("ZKH_FAULT_SEGMENT");            // fault injection (tests): the FIRST attempt at this segment fails
+    const long fault_seg = fenv ? atol(fenv) : -1;
+    const char* faenv = getenv("ZKH_FAULT_SEGMENT_ALWAYS");    // ... every attempt at this segment fails
+    const long fault_always = faenv ? atol(faenv) : -1;
     const double t0 = now_s();
+
+    auto finished = [&] { return errs.any() || (seals_done == n && root_done); };            // call with m held
+    auto child_done = [&](size_t node) {                                                       // call with m held
+        if (--plan[node].pending == 0) { ready.push_back(node); cv.notify_all(); }
+    };
+    auto run_node = [&](Lane* l, size_t id, std::vector<uint32_t>& in) -> const char* {
+        PNode& nd = plan[id];
+        in.clear();
+        const std::vector<uint32_t>& A = s->allowed.back()[0];
+        if (nd.kind == 1) {
+            const PNode &a = plan[nd.a], &b = plan[nd.b];
+            in.assign(a.seal, a.seal + a.words);
+            path_of(a.program, in);
+            in.insert(in.end(), b.seal, b.seal + b.words);
+            path_of(b.program, in);
+        } else {
+            in.assign(info->seals[nd.a], info->seals[nd.a] + info->seal_words[nd.a]);
+            if (nd.kind == 2) in.insert(in.end(), info->seals[nd.b], info->seals[nd.b] + info->seal_words[nd.b]);
+            in.insert(in.end(), A.begin(), A.end());
+        }
+        uint64_t noise = join_noise_seed;
+        if (!noise) ZKH_TRY(os_random64(&noise));
+        ZKH_TRY(zkh_rec_prove(l->programs[nd.program], in.data(), in.size(), noise, nullptr, &nd.seal, &nd.words));
+        if (nd.kind == 1) {                                    // children are not kept: the verifier needs the root only
+            zkh_free_seal(plan[nd.a].seal); zkh_free_seal(plan[nd.b].seal);
+            plan[nd.a].seal = plan[nd.b].seal = nullptr;
+        }
+        return nullptr;
+    };
+    double wit_sum = 0, seal_sum = 0, fold_busy = 0;
+    size_t n_retries = 0;
+    auto worker = [&](Lane* l, bool can_seal) {
+        if (!getenv("ZKH_SESSION_NO_AFFINITY")) { const char* e = zkh_bind_thread_to_device(l->device, 0, 1, nullptr, nullptr); if (e) zkh_free_error(e); }
+        std::vector<uint32_t> in;
+        double wit = 0, seal_t = 0, fold_t = 0;
+        int consecutive_failures = 0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            if (finished()) break;
+            // 1) a segment: retries first (never on the lane that just failed it, unless no other sealing lane is left or
+            //    nobody else picked it up within 50 ms), then the next index
+            size_t seg = NONE;
+            if (can_seal) {
+                for (auto it = retry.begin(); it != retry.end(); ++it)
+                    if (it->failed_on != l || seal_lanes_active <= 1 || now_s() - it->since > 0.05) { seg = it->seg; retry.erase(it); break; }
+                if (seg == NONE && next_seal < n) seg = next_seal++;
+            }
+            if (seg != NONE) {
+                lk.unlock();
+                double w = 0;
+                const double ts = now_s();
+                const char* err = nullptr;
+                if ((long)seg == fault_always || ((long)seg == fault_seg && attempts[seg] == 0)) err = make_err("injected fault (ZKH_FAULT_SEGMENT)");
+                else err = seal_one(s, *l, segs[seg], &info->seals[seg], &info->seal_words[seg], &w);
+                const double te = now_s();
+                lk.lock();
+                if (err) {
+                    if (attempts[seg]++ < max_retries) {       // hand it to another lane / device
+                        zkh_free_error(err);
+                        zkh_free_seal(info->seals[seg]); info->seals[seg] = nullptr; info->seal_words[seg] = 0;
+                        retry.push_back(Retry{seg, l, now_s()});
+                        n_retries++;
+                        cv.notify_all();
+                        if (++consecutive_failures >= 2 && seal_lanes_active > 1) { can_seal = false; seal_lanes_active--; }      // this lane stops taking segments
+                        continue;
+                    }
+                    char what[64];
+                    snprintf(what, sizeof what, "segment %zu (after %d attempt(s))", seg, attempts[seg]);
+                    errs.set(err, what);
+                    cv.notify_all();
+                    break;
+                }
+                consecutive_failures = 0;
+                wit += w; seal_t += te - ts - w;
+                if (++seals_done == n) { t_leaves_done = now_s(); cv.notify_all(); }
+                if (fold) child_done(owner[seg]);
+                continue;
+            }
+            // 2) a fold node (streamed: any time; two phases: once every segment is sealed)
+            if (fold && !ready.empty() && (streamed || seals_done == n)) {
+                const size_t id = ready.front();
+                ready.pop_front();
+                lk.unlock();
+                const double ts = now_s();
+                const char* err = run_node(l, id, in);
+                const double te = now_s();
+                lk.lock();
+                fold_t += te - ts;
+                if (err) { errs.set(err, plan[id].kind == 1 ? "join" : plan[id].kind == 2 ? "lift2" : "lift"); cv.notify_all(); break; }
+                if (id < n_bottom && ++bottom_done == n_bottom) t_bottom_done = now_s();
+                if (id == root_node) { root_done = true; cv.notify_all(); }
+                else if (plan[id].parent != NONE) child_done(plan[id].parent);
+                continue;
+            }
+            // 3) nothing to do right now (a retry entry held back for another lane wakes us after 20 ms)
+            if (can_seal && !retry.empty()) cv.wait_for(lk, std::chrono::milliseconds(20));
+            else cv.wait(lk);
+        }
+        if (can_seal) seal_lanes_active = seal_lanes_active ? seal_lanes_active - 1 : 0;
+        wit_sum += wit; seal_sum += seal_t; fold_busy += fold_t;
+        lk.unlock();
+        cv.notify_all();
+        (void)zkh_sync(l->ctx);
+    };
     {
         std::vector<std::thread> th;
-        for (auto& lane : s->lanes)
-            th.emplace_back([&, l = &lane] {
-                double wit = 0, seal_t = 0;
-                for (;;) {
-                    const size_t i = next.fetch_add(1);
-                    if (i >= n || errs.any()) break;
-                    double w = 0;
-                    const double ts = now_s();
-                    if (errs.set(seal_one(s, *l, segs[i], &info->seals[i], &info->seal_words[i], &w), "segment")) break;
-                    wit += w; seal_t += now_s() - ts - w;
-                }
-                (void)zkh_sync(l->ctx);
-                std::lock_guard<std::mutex> lk(stat_lock);
-                info->witgen_s_sum += wit; info->seal_s_sum += seal_t;
-            });
+        for (auto& lane : s->lanes) th.emplace_back(worker, &lane, true);
+        if (fold) for (auto& lane : s->fold_lanes) th.emplace_back(worker, &lane, false);
         for (auto& t : th) t.join();
     }
-    info->leaves_s = now_s() - t0;
-    // ---- the join tree: level l pairs nodes (2k, 2k+1) of level l-1, an unpaired last node is carried up; the joins of a
-    // level are independent and pulled from one index by the lanes.  A leaf's claim is zkh_receipt_claim (needs the leaf's
-    // control root: computed per size by the first lane), a join's claim is the parent digest it constrains (out[0..8)). ----
-    if (join_tree == 2 && !errs.any()) {
-        // ---- lift every receipt, then join level by level: every node verifies its child seal(s) in-circuit ----
-        struct Node { uint32_t* seal = nullptr; size_t words = 0; uint32_t po2 = 0, program = 0; };
-        auto program_of = [&](uint32_t join, uint32_t a, uint32_t b) -> int {
-            for (size_t i = 0; i < s->rec_kinds.size(); i++)
-                if (s->rec_kinds[i].join == join && s->rec_kinds[i].a == a && s->rec_kinds[i].b == b) return (int)i;     // lifts: b = circuit family, 0 = the session's
-            return -1;
-        };
-        auto po2_of = [&](uint32_t program) { uint32_t inf[8]; (void)zkh_rec_program_info(s->lanes[0].programs[program], nullptr, inf); return inf[0]; };
-        auto path_of = [&](uint32_t program, std::vector<uint32_t>& out) {      // per level: the direction bit as an element, the sibling
-            size_t idx = program;
-            for (size_t l = 0; l < REC_DEPTH; l++) {
-                out.push_back(fp_encode((uint32_t)(idx & 1)).v);
-                out.insert(out.end(), s->allowed[l][idx ^ 1].begin(), s->allowed[l][idx ^ 1].end());
-                idx >>= 1;
-            }
-        };
-        const std::vector<uint32_t>& A = s->allowed.back()[0];
-        // bottom level: a pair of segments is ONE proof where the program set has lift2(po2_l, po2_r) (lift + lift + join fused),
-        // else lift, lift (and the pair is joined with the level above); an unpaired last segment is lifted
-        const size_t n_pairs = n / 2;
-        std::vector<char> fused(n_pairs, 0);
-        size_t n_fused = 0;
-        for (size_t k = 0; k < n_pairs; k++)
-            if (program_of(2, segs[2 * k].po2, segs[2 * k + 1].po2) >= 0) { fused[k] = 1; n_fused++; }
-        const bool all_fused = n_fused == n_pairs && n > 1;
-        std::vector<Node> level(all_fused ? n_pairs + n % 2 : n);
-        const double tl = now_s();
-        {
-            // jobs: all pairs fused -> one job per pair (+ the odd tail); otherwise one lift per segment
-            const size_t n_jobs = level.size();
-            std::atomic<size_t> idx{0};
-            std::vector<std::thread> th;
-            for (Lane* lane : s->rec_lanes)
-                th.emplace_back([&, l = lane] {
-                    std::vector<uint32_t> in;
-                    for (;;) {
-                        const size_t k = idx.fetch_add(1);
-                        if (k >= n_jobs || errs.any()) break;
-                        int p;
-                        if (all_fused && k < n_pairs) {
-                            p = program_of(2, segs[2 * k].po2, segs[2 * k + 1].po2);
-                            in.assign(info->seals[2 * k], info->seals[2 * k] + info->seal_words[2 * k]);
-                            in.insert(in.end(), info->seals[2 * k + 1], info->seals[2 * k + 1] + info->seal_words[2 * k + 1]);
-                        } else {
-                            const size_t i = all_fused ? n - 1 : k;
-                            p = program_of(0, segs[i].po2, 0);
-                            if (p < 0) { errs.set(make_err("no lift program for po2-%u segments", segs[i].po2), "lift"); break; }
-                            in.assign(info->seals[i], info->seals[i] + info->seal_words[i]);
-                        }
-                        in.insert(in.end(), A.begin(), A.end());
-                        Node& nd = level[k];
-                        nd.program = (uint32_t)p; nd.po2 = po2_of((uint32_t)p);
-                        if (errs.set(zkh_rec_prove(l->programs[p], in.data(), in.size(), join_noise_seed ? join_noise_seed : os_random64(), nullptr, &nd.seal, &nd.words), "lift")) break;
-                    }
-                    (void)zkh_sync(l->ctx);
-                });
-            for (auto& t : th) t.join();
+    const double t_end = now_s();
+    info->witgen_s_sum = wit_sum; info->seal_s_sum = seal_sum; info->fold_busy_s_sum = fold_busy; info->n_retries = n_retries;
+    info->leaves_s = (t_leaves_done ? t_leaves_done : t_end) - t0;
+    if (fold) {
+        // bottom level = lifts (or lift2 per pair); with the streamed fold these overlap the leaf phase: lift_s / join_s are what the
+        // fold still took AFTER the last segment was sealed (bottom level, then joins); two phases: the two phases' durations
+        const double tb = std::max(t_bottom_done ? t_bottom_done : t_end, t0 + info->leaves_s);
+        info->n_lifts = n_bottom;
+        info->n_joins = plan.size() - n_bottom;
+        info->lift_s = tb - (t0 + info->leaves_s);
+        info->join_s = t_end - tb;
+        info->fold_tail_s = t_end - (t0 + info->leaves_s);
+        if (!errs.any()) {
+            PNode& r = plan[root_node];
+            info->root_seal = r.seal; info->root_seal_words = r.words; info->root_program = r.program;
+            r.seal = nullptr;
         }
-        info->n_joins = 0;
-        info->n_lifts = all_fused ? n_pairs + n % 2 : n;      // proofs of the bottom level (lift2 counts once)
-        info->lift_s = now_s() - tl;
-        const double tj = now_s();
-        while (level.size() > 1 && !errs.any()) {
-            const size_t pairs = level.size() / 2;
-            std::vector<Node> up(pairs);
-            std::atomic<size_t> idx{0};
-            std::vector<std::thread> th;
-            for (Lane* lane : s->rec_lanes)
-                th.emplace_back([&, l = lane] {
-                    std::vector<uint32_t> in;
-                    for (;;) {
-                        const size_t k = idx.fetch_add(1);
-                        if (k >= pairs || errs.any()) break;
-                        const Node &a = level[2 * k], &b = level[2 * k + 1];
-                        const int p = program_of(1, a.po2, b.po2);
-                        if (p < 0) { errs.set(make_err("no join program for children of po2 %u and %u", a.po2, b.po2), "join"); break; }
-                        in.assign(a.seal, a.seal + a.words);
-                        path_of(a.program, in);
-                        in.insert(in.end(), b.seal, b.seal + b.words);
-                        path_of(b.program, in);
-                        Node& nd = up[k];
-                        nd.program = (uint32_t)p; nd.po2 = po2_of((uint32_t)p);
-                        if (errs.set(zkh_rec_prove(l->programs[p], in.data(), in.size(), join_noise_seed ? join_noise_seed : os_random64(), nullptr, &nd.seal, &nd.words), "join")) break;
-                    }
-                    (void)zkh_sync(l->ctx);
-                });
-            for (auto& t : th) t.join();
-            info->n_joins += pairs;
-            for (size_t k = 0; k < 2 * pairs; k++) zkh_free_seal(level[k].seal);          // children are not kept
-            if (level.size() % 2) up.push_back(level.back());
-            level.swap(up);
-        }
-        info->join_s = now_s() - tj;
-        if (!errs.any()) { info->root_seal = level[0].seal; info->root_seal_words = level[0].words; info->root_program = level[0].program; level[0].seal = nullptr; }
-        for (auto& nd : level) zkh_free_seal(nd.seal);
+        for (auto& nd : plan) zkh_free_seal(nd.seal);
     }
     if (join_tree == 1 && n > 1 && !errs.any()) {
         const double tj = now_s();
@@ -396,7 +562,8 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
                         if (k >= pairs || errs.any()) break;
                         memcpy(pub, claims[2 * k].data(), 32);
                         memcpy(pub + 8, claims[2 * k + 1].data(), 32);
-                        const uint64_t noise = join_noise_seed ? join_noise_seed : os_random64();
+                        uint64_t noise = join_noise_seed;
+                        if (!noise && errs.set(os_random64(&noise), "join noise")) break;
                         if (errs.set(zkh_syn_witgen(l->ctx, jc, join_po2, ZKH_ZK_CYCLES, 0, noise, pub, code, data, outg), "join witgen") ||
                             errs.set(zkh_prove_segment(l->join_prover, join_po2, ZKH_ZK_CYCLES, noise, code, data, outg, &seals[k], &words[k]), "join seal")) break;
                         memcpy(up[k].data(), seals[k], 32);

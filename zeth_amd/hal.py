@@ -40,7 +40,8 @@ class ProveInfo(C.Structure):
     _fields_ = [("n_segments", C.c_size_t), ("seals", C.POINTER(C.POINTER(C.c_uint32))), ("seal_words", C.POINTER(C.c_size_t)),
                 ("root_seal", C.POINTER(C.c_uint32)), ("root_seal_words", C.c_size_t), ("n_joins", C.c_size_t),
                 ("wall_s", C.c_double), ("leaves_s", C.c_double), ("join_s", C.c_double), ("witgen_s_sum", C.c_double), ("seal_s_sum", C.c_double),
-                ("n_lifts", C.c_size_t), ("root_program", C.c_size_t), ("lift_s", C.c_double)]
+                ("n_lifts", C.c_size_t), ("root_program", C.c_size_t), ("lift_s", C.c_double),
+                ("n_retries", C.c_size_t), ("fold_tail_s", C.c_double), ("fold_busy_s_sum", C.c_double), ("streamed", C.c_int)]
 
 
 # every symbol include/zkhal.h declares: (restype, argtypes)
@@ -85,6 +86,7 @@ ABI = {
     "zkh_hash_rows": (_err, [_vp, _vp, _vp]),
     "zkh_hash_fold": (_err, [_vp, _vp, _sz, _sz]),
     "zkh_merkle_fold_all": (_err, [_vp, _vp, _sz]),
+    "zkh_merkle_build": (_err, [_vp, _vp, _vp, _sz]),
     "zkh_batch_evaluate_any": (_err, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "zkh_batch_evaluate_any_bitrev": (_err, [_vp, _vp, _sz, _vp, _vp, _vp]),
     "zkh_batch_bit_reverse_extelem": (_err, [_vp, _vp, _sz]),
@@ -143,10 +145,16 @@ ABI = {
     "zkh_session_lanes": (_sz, [_vp]),
     "zkh_session_circuit": (_vp, [_vp, _sz, _i]),
     "zkh_session_set_accumulate": (None, [_vp, _vp, _vp]),
+    "zkh_session_set_resident_code": (None, [_vp, _i]),
+    "zkh_session_set_streamed_fold": (None, [_vp, _i]),
     "zkh_session_set_recursion": (_err, [_vp, _u32p, _sz, C.POINTER(_u32p), C.POINTER(_sz), _u32p, _sz]),
     "zkh_session_prove": (_err, [_vp, C.POINTER(SegmentSpec), _sz, _i, _sz, _u64, C.POINTER(ProveInfo)]),
     "zkh_prove_info_free": (None, [C.POINTER(ProveInfo)]),
     "zkh_session_verify": (_err, [_vp, C.POINTER(SegmentSpec), C.POINTER(ProveInfo), _sz]),
+    "zkh_parse_cpulist": (_err, [C.c_char_p, C.POINTER(_i), _sz, C.POINTER(_sz)]),
+    "zkh_pci_numa_cpus": (_err, [C.c_char_p, C.c_char_p, C.POINTER(_i), C.POINTER(_i), _sz, C.POINTER(_sz)]),
+    "zkh_device_numa_node": (_err, [_i, C.POINTER(_i), C.c_char_p]),
+    "zkh_bind_thread_to_device": (_err, [_i, _sz, _sz, C.POINTER(_i), C.POINTER(_sz)]),
     "zkh_prof_enable": (_err, [_vp, _i]),
     "zkh_prof_get": (_err, [_vp, C.POINTER(ProfRec), _sz, C.POINTER(_sz)]),
     "zkh_prof_reset": (_err, [_vp]),
@@ -380,6 +388,53 @@ class RecProgram:
         return words, out
 
 
+# ---- host placement (csrc/topology.hip) ----
+def parse_cpulist(text: str) -> List[int]:
+    load_library()
+    n = _sz()
+    _check(_lib.zkh_parse_cpulist(text.encode(), None, 0, C.byref(n)))
+    cpus = (_i * max(1, n.value))()
+    _check(_lib.zkh_parse_cpulist(text.encode(), cpus, n.value, C.byref(n)))
+    return list(cpus[: n.value])
+
+
+def pci_numa_cpus(bdf: str, sysfs_root: str = "/sys"):
+    """-> (NUMA node of the PCI function or -1, the node's CPU ids)"""
+    load_library()
+    node, n = _i(-1), _sz()
+    cpus = (_i * 4096)()
+    _check(_lib.zkh_pci_numa_cpus(sysfs_root.encode(), bdf.encode(), C.byref(node), cpus, 4096, C.byref(n)))
+    return node.value, list(cpus[: min(n.value, 4096)])
+
+
+def device_numa_node(device: int):
+    """-> (NUMA node of the HIP device or -1, its PCI bus id)"""
+    load_library()
+    node = _i(-1)
+    bdf = C.create_string_buffer(32)
+    _check(_lib.zkh_device_numa_node(device, C.byref(node), bdf))
+    return node.value, bdf.value.decode()
+
+
+def bind_to_device(device: int, slot: int = 0, share: int = 1) -> dict:
+    """Bind the calling thread (threads created afterwards inherit it) to the cores next to `device`: slice `slot` of `share`
+    slices of its NUMA node when several ranks share the node.  -> {"numa_node": n or -1, "cpus": count}"""
+    load_library()
+    node, n = _i(-1), _sz()
+    _check(_lib.zkh_bind_thread_to_device(device, slot, share, C.byref(node), C.byref(n)))
+    return {"numa_node": node.value, "cpus": n.value}
+
+
+def placement_slot(device: int, devices: Sequence[int]):
+    """Which slice of its NUMA node the rank driving `device` takes when the ranks of `devices` share the host:
+    -> (slot, share) = (index of `device` among the devices on the same node, their number); (0, 1) if the node is unknown."""
+    mine = device_numa_node(device)[0]
+    if mine < 0:
+        return 0, 1
+    same = [d for d in devices if device_numa_node(d)[0] == mine]
+    return same.index(device), len(same)
+
+
 class HipHal:
     """`impl Hal for HipHal` — one MI355X, one HIP stream, one driving thread."""
 
@@ -485,6 +540,11 @@ class HipHal:
     def merkle_fold_all(self, nodes: Buffer, rows: int) -> None:
         _check(_lib.zkh_merkle_fold_all(self.ctx, nodes.h, rows))
 
+    def merkle_build(self, nodes: Buffer, matrix: Buffer, rows: int) -> None:
+        """`MerkleTreeProver::new`: leaves = hash_rows(matrix) at nodes[rows..2 rows), then every layer above (wide trees hash two
+        adjacent rows and their parent per lane in one pass)."""
+        _check(_lib.zkh_merkle_build(self.ctx, nodes.h, matrix.h, rows))
+
     def batch_evaluate_any(self, coeffs: Buffer, poly_count: int, which: Buffer, xs: Buffer, out: Buffer) -> None:
         _check(_lib.zkh_batch_evaluate_any(self.ctx, coeffs.h, poly_count, which.h, xs.h, out.h))
 
@@ -573,7 +633,8 @@ class HipHal:
 
     def syn_witgen(self, circuit: Circuit, po2: int, zk_cycles: int, seed: int, noise_seed: int, code: Buffer, data: Buffer,
                    pub=None) -> np.ndarray:
-        """-> out globals.  SYN-AIR (kind 1): OUTPUT_SIZE words s, 0, 0, 0, then the public input words `pub`.
+        """-> out globals.  `code` may be None for kinds 1 / 2 (the code group of this size is already held, e.g. resident).
+        SYN-AIR (kind 1): OUTPUT_SIZE words s, 0, 0, 0, then the public input words `pub`.
         KECCAK-F (kind 2): `pub` = optional input state of the LAST permutation (25 lanes = 50 words, low word first);
         out = that permutation's output state as 100 16-bit limbs."""
         out_size = int(circuit.desc[7])
@@ -588,7 +649,7 @@ class HipHal:
         elif p.size != out_size - 4:
             raise HalError(f"syn_witgen: circuit takes {out_size - 4} public input words, got {p.size}")
         _check(_lib.zkh_syn_witgen(self.ctx, circuit.h, po2, zk_cycles, seed & (2**64 - 1), noise_seed & (2**64 - 1),
-                                   _ptr(p) if p.size else None, code.h, data.h, _ptr(out)))
+                                   _ptr(p) if p.size else None, code.h if code is not None else None, data.h, _ptr(out)))
         return out
 
     def syn_accum(self, circuit: Circuit, po2: int, zk_cycles: int, noise_seed: int, data: Buffer, mix_global, accum: Buffer) -> None:

@@ -203,6 +203,16 @@ class Session:
         kinds = np.array([[code[k[0]], k[1], k[2]] for k, _ in programs], dtype=np.uint32).reshape(-1)
         self._hal._check(self._hal._lib.zkh_session_set_recursion(self.h, self._hal._ptr(rdesc), rdesc.size, ptrs, words, self._hal._ptr(kinds), len(blobs)))
 
+    def set_streamed_fold(self, on: bool) -> None:
+        """join_tree=2: prove a lift2 / join the moment its children exist, concurrently with the sealing lanes (default), or hold
+        the fold back until the last segment is sealed (two phases).  Same tree, same receipts."""
+        self._hal._lib.zkh_session_set_streamed_fold(self.h, int(on))
+
+    def set_resident_code(self, on: bool) -> None:
+        """built-in circuits: keep the committed code group of each segment size resident per lane (default) or re-commit it per
+        segment like upstream's SegmentProver.  Seals are byte-identical."""
+        self._hal._lib.zkh_session_set_resident_code(self.h, int(on))
+
     def _specs(self, segments: Sequence[Segment], host_traces=None):
         C, np = self._C, self._np
         arr = (self._hal.SegmentSpec * len(segments))()
@@ -247,7 +257,9 @@ class Session:
                 root = SegmentReceipt(seal=rs, index=0, po2=self._hal.fp_decode(int(rs[16])) if recursive else join_po2, output=rs[:16 if recursive else 24].copy())
             stats = {"wall_s": info.wall_s, "leaves_s": info.leaves_s, "join_s": info.join_s, "n_joins": int(info.n_joins),
                      "n_lifts": int(info.n_lifts), "lift_s": info.lift_s, "root_program": int(info.root_program),
-                     "witgen_s_sum": info.witgen_s_sum, "seal_s_sum": info.seal_s_sum, "verified": bool(verify)}
+                     "witgen_s_sum": info.witgen_s_sum, "seal_s_sum": info.seal_s_sum, "verified": bool(verify),
+                     "n_retries": int(info.n_retries), "fold_tail_s": info.fold_tail_s, "fold_busy_s_sum": info.fold_busy_s_sum,
+                     "streamed_fold": bool(info.streamed)}
             return CompositeReceipt(recs), root, stats
         finally:
             self._hal._lib.zkh_prove_info_free(C.byref(info))

@@ -160,7 +160,10 @@ class SegmentProver:
         """Witness generation (code + data traces resident in HBM) — reported separately from the seal."""
         wa, wc, wd = self.group_sizes()
         n = 1 << seg.po2
-        code = self.hal.alloc_elem("code", wc * n)
+        # with this size's committed code group resident the trace is not needed again (kinds 1 / 2: the data generator does
+        # not read it) -> code is None, and `seal` passes NULL
+        held = self.resident_code_group and self._resident.get(seg.po2) == seg.zk_cycles and int(self.circuit.desc[13]) in (1, 2)
+        code = None if held else self.hal.alloc_elem("code", wc * n)
         data = self.hal.alloc_elem("data", wd * n)
         out = self.hal.syn_witgen(self.circuit, seg.po2, seg.zk_cycles, seg.seed, seg.noise_seed, code, data,
                                   pub=np.asarray(seg.pub, dtype=np.uint32) if seg.pub else None)
@@ -176,6 +179,8 @@ class SegmentProver:
         if not self.resident_code_group:
             return code.h
         if self._resident.get(seg.po2) != seg.zk_cycles:
+            if code is None:
+                raise _hal.HalError("seal: no code trace and no resident code group of this size")
             _hal._check(_hal._lib.zkh_prover_cache_code(self.h, seg.po2, code.h))
             self._resident[seg.po2] = seg.zk_cycles
         return None
