@@ -117,9 +117,9 @@ const char* zkh_hash_fold(zkh_ctx*, zkh_buf* io_digests, size_t input_size, size
 /* Fused MerkleTreeProver::new tail: every hash_fold layer from `rows` leaves down to the root.
  * nodes has 2*rows digests, leaves already at [rows, 2*rows). */
 const char* zkh_merkle_fold_all(zkh_ctx*, zkh_buf* nodes, size_t rows);
-/* MerkleTreeProver::new as one call: nodes[rows .. 2 rows) = hash_rows(matrix), then every layer above down to the root at nodes[1].
- * Wide trees hash two adjacent rows per lane and their parent in the same pass (the largest hash_fold layer is never a launch of
- * its own); digests are identical to zkh_hash_rows + zkh_merkle_fold_all. */
+/* MerkleTreeProver::new as one call: nodes[rows .. 2 rows) = hash_rows(matrix), then every layer above down to the root at nodes[1];
+ * digests are identical to zkh_hash_rows + zkh_merkle_fold_all.  (ZKH_MERKLE_FUSED=1: wide trees hash two adjacent rows per lane
+ * and their parent in one pass — measured, not faster on MI355X, hence opt-in.) */
 const char* zkh_merkle_build(zkh_ctx*, zkh_buf* nodes, const zkh_buf* matrix, size_t rows);
 /* The bare permutation (risc0_zkp::core::hash::poseidon2::poseidon2_mix): `count` states of 24 Montgomery words each,
  * in place — on the device with the context's tables, or on the host (rc / diag canonical residues, NULL = the shipped

@@ -45,3 +45,66 @@ def test_bench_accepts_the_drivers_flags():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup", "--config", "--join-circuit", "--fold-inflight", "--no-fused-lift"):
         assert flag in out.stdout, flag
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_roofline_is_taken_per_op_and_never_from_a_byteless_sub_kernel_bracket():
+    """Round-3 verdict, weak 8: on a shared GPU a sub-kernel bracket of a multi-pass op (whose §8d bytes are charged to another
+    pass of the same op) out-timed everything and the line said frac 0.0 / alg_bytes 0.0.  The dominant entry is now an OP:
+    passes summed, bytes summed, invocations = calls of the byte-carrying passes."""
+    bench = _load_bench()
+    recs = [{"name": "hash_rows", "calls": 7, "total_ms": 14.0, "alg_bytes": 7 * 740e6},
+            {"name": "batch_expand_into_evaluate_ntt:k_ntt_high10", "calls": 5, "total_ms": 30.0, "alg_bytes": 0.0},      # queued behind other ranks
+            {"name": "batch_expand_into_evaluate_ntt:k_ntt_low12", "calls": 6, "total_ms": 2.0, "alg_bytes": 6 * 700e6},
+            {"name": "batch_expand_into_evaluate_ntt:k_ntt_pass", "calls": 3, "total_ms": 0.1, "alg_bytes": 3 * 1e5},
+            {"name": "syn_data", "calls": 1, "total_ms": 50.0, "alg_bytes": 0.0}]                                          # a bracket with no §8d bytes at all
+    ops = bench.by_op(recs)
+    ntt = ops["batch_expand_into_evaluate_ntt"]
+    assert ntt["calls"] == 9 and ntt["launches"] == 14 and abs(ntt["total_ms"] - 32.1) < 1e-9 and ntt["alg_bytes"] > 4e9
+
+    class A:
+        no_live_traffic, circuit, po2, steps = True, "syn_a", 20, 1
+    line = {}
+    bench.add_roofline(line, recs, recs, A, 3, (32, 16, 208), 1 << 20)
+    r = line["roofline"]
+    assert r["kernel"] == "batch_expand_into_evaluate_ntt" and r["frac"] > 0 and r["alg_bytes_per_launch"] > 0 and r["achieved"] > 0
+    assert abs(r["avg_launch_ms"] - 32.1 / 9) < 1e-9
+    # with hash_rows dominant the committed PMC file supplies the traffic when no live measurement is possible
+    recs[1]["total_ms"] = 3.0
+    recs[4]["total_ms"] = 0.5
+    line = {}
+    bench.add_roofline(line, recs, recs, A, 3, (32, 16, 208), 1 << 20)
+    r = line["roofline"]
+    assert r["kernel"] == "hash_rows" and r["traffic"] and r["traffic"] > 0 and abs(r["alg_bytes_per_launch"] - 740e6) < 1
+    assert [o["op"] for o in line["ops"]][:2] == ["hash_rows", "batch_expand_into_evaluate_ntt"]
+
+
+def test_host_placement_helpers_parse_sysfs(tmp_path):
+    """csrc/topology.hip without a GPU: cpulist parsing, PCI function -> NUMA node -> CPUs under a fake sysfs tree."""
+    from zeth_amd import hal
+    assert hal.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert hal.parse_cpulist("5") == [5] and hal.parse_cpulist("") == []
+    for bad in ("abc", "3-1", "1-", "0-3;5"):
+        try:
+            hal.parse_cpulist(bad)
+            raise AssertionError(bad)
+        except hal.HalError:
+            pass
+    dev = tmp_path / "bus" / "pci" / "devices" / "0000:c1:00.0"
+    dev.mkdir(parents=True)
+    (dev / "numa_node").write_text("1\n")
+    node = tmp_path / "devices" / "system" / "node" / "node1"
+    node.mkdir(parents=True)
+    (node / "cpulist").write_text("64-127,192-255\n")
+    n, cpus = hal.pci_numa_cpus("0000:C1:00.0", str(tmp_path))
+    assert n == 1 and len(cpus) == 128 and cpus[0] == 64 and cpus[-1] == 255
+    assert hal.pci_numa_cpus("0000:aa:00.0", str(tmp_path)) == (-1, [])         # unknown device
+    (dev / "numa_node").write_text("-1\n")
+    assert hal.pci_numa_cpus("0000:c1:00.0", str(tmp_path)) == (-1, [])         # the kernel reports no node

@@ -1,0 +1,96 @@
+#!/bin/bash
+# ONE runner for everything measured on the GPU box.  From the repo root:
+#     gpurun --timeout 900 -- 'bash tools/gpu.sh <recipe> [name]'        -> gpurun_out/<name>/...
+# Recipes (each step under its own `timeout`; counter passes never share a run with tracing domains):
+#   tests        the whole -m gpu suite + smoke()
+#   new [FILE]   one test file (default tests/test_round4_gpu.py), fail fast
+#   bench        the driver's command (python bench.py) + its 8-rank form on ONE GPU (ZKH_SHARE_GPUS=1)
+#   config5      BASELINE config 5 (S = 1024 -> one succinct receipt): streamed pipeline, two phases, and the g++ host
+#   ab VAR       A/B of one env switch of the library (e.g. ZKH_MERKLE_FUSED): bench with and without VAR=1, 3 repeats each
+#   profiles     everything profiles/ holds (tools/collect_profiles.sh)
+#   big          po2 21 / 22 segments
+#   soak         1000 distinct segments through the g++ driver
+#   roots        regenerate zeth_amd/circuits/control_roots.json
+#   power        rocm-smi clock / power while one kernel family loops
+# Summaries to keep are copied by hand from gpurun_out/<name>/ into profiles/ (tracked).
+set -u
+R=${1:?recipe}; shift
+export TMPDIR=/tmp
+line() { python - "$1" <<'PY'
+import json, sys
+try:
+    l = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    keys = ("value", "ms_per_step", "n_gpus", "steps", "timed_seals_verified", "block_wall_clock_s", "block_segments_per_s", "leaf_phase_s")
+    print(sys.argv[1].split("/")[-1], {k: (round(l[k], 3) if isinstance(l[k], float) else l[k]) for k in keys if k in l},
+          "roofline.frac", round(l.get("roofline", {}).get("frac", 0), 4), "cpu", round(l.get("cpu_baseline", {}).get("value", 0), 4))
+except Exception as e:
+    print(sys.argv[1], "no line:", e)
+PY
+}
+case $R in
+tests)
+  O=gpurun_out/${1:-tests}; mkdir -p $O
+  ( time timeout 1500 python -m pytest tests -m gpu -q -x ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+  python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log
+  tail -5 $O/pytest.log; tail -2 $O/smoke.log ;;
+new)
+  O=gpurun_out/new; mkdir -p $O
+  ( time timeout 900 python -m pytest ${1:-tests/test_round4_gpu.py} -m gpu -q -x ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+  tail -30 $O/pytest.log ;;
+bench)
+  O=gpurun_out/${1:-bench}; mkdir -p $O
+  ( time timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err ) 2> $O/bench_default.time; line $O/bench_default.json
+  ( time ZKH_SHARE_GPUS=1 timeout 900 python bench.py --gpus 8 --steps 6 --warmup 1 --no-heavy > $O/bench_8rank_one_gpu.json 2> $O/bench_8rank.err ) 2> $O/bench_8rank.time; line $O/bench_8rank_one_gpu.json
+  grep real $O/*.time; tail -3 $O/bench_default.err | grep -v amdgpu.ids ;;
+config5)
+  O=gpurun_out/${1:-config5}; mkdir -p $O
+  timeout 900 python bench.py --config succinct --no-cpu-baseline > $O/bench_succinct_streamed.json 2> $O/err.txt; line $O/bench_succinct_streamed.json
+  timeout 900 python bench.py --config succinct --fold phased --no-cpu-baseline > $O/bench_succinct_phased.json 2>> $O/err.txt; line $O/bench_succinct_phased.json
+  timeout 900 python bench.py --config succinct --fold phased --recompute-code --no-cpu-baseline > $O/bench_succinct_phased_recompute.json 2>> $O/err.txt; line $O/bench_succinct_phased_recompute.json
+  D=/tmp/zkr; mkdir -p $D; python -m zeth_amd.circuits.rec_verify $D > /dev/null; python -m zeth_amd.circuits.recursion $D/recursion.desc > /dev/null
+  python -m zeth_amd.circuits.syn_air syn_a /tmp/syn_a.desc > /dev/null
+  LD_LIBRARY_PATH=$PWD/zeth_amd timeout 600 examples/prove_session --desc /tmp/syn_a.desc --recursion-dir $D --segments 1024 --noise-seed 11904 > $O/prove_session_1024_streamed.json 2>> $O/err.txt
+  LD_LIBRARY_PATH=$PWD/zeth_amd timeout 600 examples/prove_session --desc /tmp/syn_a.desc --recursion-dir $D --segments 1024 --noise-seed 11904 --two-phase > $O/prove_session_1024_two_phase.json 2>> $O/err.txt
+  cat $O/prove_session_1024_*.json | cut -c1-700; grep -v amdgpu.ids $O/err.txt | tail -5 ;;
+ab)
+  V=${1:?env variable}; O=gpurun_out/ab_$V; mkdir -p $O
+  for i in 1 2 3; do
+    timeout 300 python bench.py --no-cpu-baseline --no-heavy --no-resident --no-block --no-live-traffic --no-certify > $O/off_$i.json 2>> $O/err.txt; line $O/off_$i.json
+    env $V=1 timeout 300 python bench.py --no-cpu-baseline --no-heavy --no-resident --no-block --no-live-traffic --no-certify > $O/on_$i.json 2>> $O/err.txt; line $O/on_$i.json
+  done
+  timeout 300 python bench.py --inflight 1 --steps 20 --no-cpu-baseline --no-heavy --no-resident --no-block --no-live-traffic --no-certify > $O/off_serial.json 2>> $O/err.txt
+  env $V=1 timeout 300 python bench.py --inflight 1 --steps 20 --no-cpu-baseline --no-heavy --no-resident --no-block --no-live-traffic --no-certify > $O/on_serial.json 2>> $O/err.txt
+  python - $O <<'PY'
+import json, sys
+for tag in ("off", "on"):
+    l = json.loads(open(f"{sys.argv[1]}/{tag}_serial.json").read().strip().splitlines()[-1])
+    print(tag, "serial", round(l["value"], 2), {o["op"]: round(o["ms_per_seal"], 3) for o in l["ops"][:6]})
+PY
+  ;;
+profiles) bash tools/collect_profiles.sh gpurun_out/${1:-prof} ;;
+big)
+  O=gpurun_out/${1:-big}; mkdir -p $O
+  for p in 21 22; do
+    timeout 900 python bench.py --po2 $p --steps 9 --warmup 1 --no-cpu-baseline --no-live-traffic --no-heavy --no-resident --no-block > $O/bench_po2_$p.json 2> $O/bench_po2_$p.err
+    line $O/bench_po2_$p.json
+  done ;;
+soak)
+  O=gpurun_out/${1:-soak}; mkdir -p $O
+  python -m zeth_amd.circuits.syn_air syn_a /tmp/syn_a.desc > /dev/null
+  ( time timeout 900 examples/seal_segments --desc /tmp/syn_a.desc --po2 20 --segments 1000 --inflight 3 ) > $O/soak.json 2> $O/soak.err
+  cut -c1-400 $O/soak.json; tail -4 $O/soak.err ;;
+roots)
+  O=gpurun_out/${1:-roots}; mkdir -p $O
+  timeout 600 python -m zeth_amd.prover > $O/regen.log 2>&1 && cp zeth_amd/circuits/control_roots.json $O/control_roots.json
+  tail -2 $O/regen.log ;;
+power)
+  O=gpurun_out/${1:-power}; mkdir -p $O
+  sample() { tag=$1; shift; ( timeout 240 "$@" > $O/run_$tag.txt 2>> $O/err.txt ) & pid=$!; : > $O/smi_$tag.txt
+    while kill -0 $pid 2>/dev/null; do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Package Power|sclk|mclk" | tr '\n' ' ' >> $O/smi_$tag.txt; echo >> $O/smi_$tag.txt; sleep 0.4; done; }
+  for m in M1 M2 M3 M4 M8; do sample $m python tools/microbench.py --only $m --reps 4000; done
+  sample bench python bench.py --steps 600 --warmup 2 --no-block --no-live-traffic --no-certify --no-cpu-baseline
+  for tag in M1 M2 M3 M4 M8 bench; do
+    echo "== $tag"; sed -E 's/.*sclk[^(]*\(([0-9]+)Mhz\).*Power \(W\): ([0-9.]+).*/\1 \2/' $O/smi_$tag.txt | awk '$2>600{n++; c[n]=$1; w[n]=$2} END{ if(!n){print "  none"; exit} asort(c); asort(w); printf "  n=%d sclk median %d MHz  power median %d W\n", n, c[int((n+1)/2)], w[int((n+1)/2)]}'
+  done ;;
+*) echo "unknown recipe $R"; exit 2 ;;
+esac

@@ -59,11 +59,10 @@ __global__ __launch_bounds__(256, 4) void k_hash_rows(uint32_t* __restrict__ out
     o[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
-// MerkleTreeProver::new for a wide tree: hash_rows AND the first hash_fold layer in one pass.  A lane owns the ADJACENT rows 2p and
+// (opt-in, see zkh_merkle_build) MerkleTreeProver::new for a wide tree: hash_rows AND the first hash_fold layer in one pass.  A lane owns the ADJACENT rows 2p and
 // 2p + 1 (column loads are 8 bytes per lane: a wave still reads 512 contiguous bytes per column) and runs their two sponges block
-// by block in alternation, then — with both digests in registers — their parent's permutation.  What that buys: the largest layer
-// of every tree (rows / 2 permutations) runs in the steady state of this kernel (constants hot, no launch, no 64-byte re-read of
-// the two digests) instead of as k_hash_fold's one-shot permutation per lane, which measured 1.3 x the cost per permutation.
+// by block in alternation, then — with both digests in registers — their parent's permutation: the largest layer of every tree
+// (rows / 2 permutations) runs in the steady state of this kernel (constants hot, no launch, no 64-byte re-read of the two digests).
 // One call site of the permutation (the turns of a pair are a runtime loop), so the code stays the size of k_hash_rows.
 __global__ __launch_bounds__(256, 4) void k_hash_rows_pair(uint32_t* __restrict__ nodes, const uint32_t* __restrict__ matrix, size_t rows,
                                                         uint32_t cols, const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
@@ -252,13 +251,16 @@ extern "C" const char* zkh_merkle_fold_all(zkh_ctx* c, zkh_buf* nodes, size_t ro
     ZKH_REQUIRE(nodes->len == rows * 16 && rows && (rows & (rows - 1)) == 0, "merkle_fold_all: nodes must hold 2*rows digests");
     return merkle_fold_from(c, nodes, rows);
 }
-// MerkleTreeProver::new: leaves = hash_rows(matrix), then every layer above.  Wide trees take the fused first pass
-// (k_hash_rows_pair: leaves + their parents); ZKH_MERKLE_UNFUSED=1 keeps the two separate ops (A/B runs).
+// MerkleTreeProver::new: leaves = hash_rows(matrix), then every layer above.  ZKH_MERKLE_FUSED=1 gives wide trees the fused
+// first pass (k_hash_rows_pair: leaves + their parents) — built for the round-3 verdict's item 6, measured, and NOT the default:
+// the 2^21-parent layers of a po2-20 seal cost 1.73 ms inside the fused kernel against 1.60 ms as k_hash_fold launches
+// (profiles/r04_merkle_fused_ab.txt: 17.81 vs 17.68 ms of Poseidon2 per seal, 42.3 vs 42.4 segments/s).  Per permutation
+// k_hash_fold (190 ps) was never slower than k_hash_rows (197 ps); the pair kernel's 127 VGPRs cost it one wave per SIMD.
 extern "C" const char* zkh_merkle_build(zkh_ctx* c, zkh_buf* nodes, const zkh_buf* matrix, size_t rows) {
     ZKH_REQUIRE(nodes && matrix && nodes->len == rows * 16 && rows && (rows & (rows - 1)) == 0, "merkle_build: nodes must hold 2*rows digests");
     ZKH_REQUIRE(matrix->len % rows == 0, "merkle_build: matrix size %zu not a multiple of rows %zu", matrix->len, rows);
-    static const bool unfused = getenv("ZKH_MERKLE_UNFUSED") != nullptr;
-    if (rows / 2 > ((size_t)1 << 15) && !unfused) {
+    static const bool fused = getenv("ZKH_MERKLE_FUSED") != nullptr;
+    if (rows / 2 > ((size_t)1 << 15) && fused) {
         const size_t cols = matrix->len / rows;
         {
             // §8d bytes, no credit for the fusion: hash_rows (matrix in, leaves out) + the first hash_fold layer (leaves in, parents out)

@@ -6,8 +6,8 @@
 //
 // Differences from upstream that change no result:
 //   * commit_group's copy + iNTT + zk_shift are one out-of-place transform (zkh_batch_interpolate_ntt_from);
-//   * the Merkle tree is built by zkh_merkle_build (wide trees: leaves AND their parents in one pass, two adjacent rows per lane; then a
-//     lane-per-parent kernel for wide layers, an 8-lane cooperative kernel below 2^15 parents);
+//   * the Merkle tree is built by zkh_merkle_build (hash_rows, then a lane-per-parent kernel for wide layers and an 8-lane cooperative
+//     kernel below 2^15 parents);
 //   * the 50 query indices only depend on the Fiat-Shamir state after the last commit, so they are drawn first and
 //     each tree is opened for all of them with ONE gather kernel + ONE D2H instead of 50 x (gather + view).
 #include <memory>
@@ -99,7 +99,7 @@ struct Merkle {
         for (size_t i = 1; i < layers; i++) { if (((size_t)1 << i) > ZKH_QUERIES) break; top_layer = i; }
         top_size = (size_t)1 << top_layer;
         ZKH_TRY(zkh_alloc(c, "nodes", rows * 2 * 8, 0, nodes.out()));
-        return zkh_merkle_build(c, nodes, mat, rows);         // hash_rows + every hash_fold layer (wide trees: leaves and their parents in one pass)
+        return zkh_merkle_build(c, nodes, mat, rows);         // hash_rows + every hash_fold layer
     }
     // one D2H: root + everything down to the top layer (the only host-visible sync of a commit)
     const char* fetch_top(zkh_ctx* c) {
