@@ -311,6 +311,8 @@ def main() -> None:
                          "or seal everything first and fold afterwards (two phases)")
     ap.add_argument("--recompute-code", action="store_true", help="block / succinct: re-commit the code group for every segment (upstream's SegmentProver) instead of keeping it resident")
     ap.add_argument("--no-fused-lift", action="store_true", help="recursion: lift every segment on its own and join (three proofs per pair at the bottom level) instead of lift2")
+    ap.add_argument("--no-preflight-leg", action="store_true", help="segment config: skip the block leg with the host-preflight witness pipeline")
+    ap.add_argument("--preflight-producers", type=int, default=2, help="host preflight threads per sealing lane")
     ap.add_argument("--no-recursive", action="store_true", help="segment config: skip the lift / join fold of the block leg's receipts")
     ap.add_argument("--no-succinct", action="store_true", help="segment config: skip the join tree over the block leg's receipts")
     ap.add_argument("--no-certify", action="store_true", help="segment config: do not verify the timed seals / compare with the golden digest after the clock")
@@ -866,6 +868,45 @@ def main() -> None:
                      "verify_s_rank0": verify_s,
                      "workload": f"{S} distinct 2^{args.po2}-cycle segments (last one 2^{bsegs[-1].po2}), round-robin over {world} GPU(s), "
                                  f"{inflight} in flight per GPU; `--config block` runs S = 256"}
+            # The same block with upstream's witness SHAPE: a sequential host preflight per segment replays the
+            # cycles on host threads that run AHEAD of the seals (2 per sealing lane), 16 bytes per cycle cross PCIe from pinned
+            # memory, the GPU row-fill kernel expands them (csrc/preflight.hip), and the preload is a zkh_scatter — through the native
+            # session executor (zkh_session_set_witness_source(1)).  The host CPU seconds per segment are the Amdahl term of the
+            # pipeline: with T producer threads it sustains min(GPU rate, T / preflight seconds).
+            if not args.no_preflight_leg and args.circuit == "syn_a":
+                from zeth_amd.host import Session
+                psess = Session(desc, devices=(device,), lanes_per_device=inflight)
+                psess.set_witness_source(1, args.preflight_producers)
+                psess.set_resident_code(not args.recompute_code)
+                pwarm = [bsegs[0]] * inflight + [bsegs[-1]]
+                psess.prove(pwarm)
+                device_sync(lanes)
+                barrier()
+                tp0 = time.perf_counter()
+                pcomp, _, pst = psess.prove([bsegs[i] for i in bmine])
+                barrier()
+                dtp = time.perf_counter() - tp0
+                for r in pcomp.segments:
+                    r.verify(desc, broots[r.po2])
+                tpv = torch.tensor([dtp, pst["preflight_cpu_s_sum"], pst["trace_bytes"], float(len(bmine)), pst["witgen_s_sum"]], dtype=torch.float64, device=ctrl_dev)
+                if distributed:
+                    mx = tpv[:1].clone()
+                    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+                    dist.all_reduce(tpv)
+                    tpv[0] = mx[0]
+                block["host_preflight_pipeline"] = {
+                    "segments": S, "wall_clock_s": float(tpv[0]), "segments_per_s": S / float(tpv[0]),
+                    "host_preflight_cpu_ms_per_segment": 1e3 * float(tpv[1]) / max(1.0, float(tpv[3])),
+                    "pcie_bytes_per_segment": float(tpv[2]) / max(1.0, float(tpv[3])),
+                    "full_trace_bytes_per_segment": 4.0 * (wc + wd) * n,
+                    "upload_and_row_fill_ms_per_segment": 1e3 * float(tpv[4]) / max(1.0, float(tpv[3])),
+                    "producer_threads_per_gpu": inflight * (args.preflight_producers or 2), "sealing_lanes_per_gpu": inflight,
+                    "verified_after_clock": int(tpv[3]),
+                    "note": "the preflight is a sequential per-cycle machine (SYN-VM: 8 registers, 64 instructions, 1 KiB words of RAM) on host "
+                            "threads; its 16-byte-per-cycle records are the ONLY witness input that crosses PCIe; the GPU expands them (one lane per "
+                            "cycle), scans the running sum and scatters the preloaded RAM image; a DIFFERENT witness than the closed-form "
+                            "generator's, same circuit, seals byte-identical to the CPU oracle's (tests/test_round4_gpu.py)"}
+                psess.close()
             # ... and, on one GPU, the join tree over that block's receipts down to ONE root receipt (BASELINE config 5 in
             # small: P2-JOIN joins at po2 18 hash their children's claims in-circuit).  Per level the joins are independent and
             # spread over the lanes.  Afterwards the compact receipt (root + leaves, joins dropped) is verified the way a

@@ -143,11 +143,12 @@ const char* zkh_mix_poly_coeffs(zkh_ctx*, zkh_buf* out, const uint32_t mix_start
 const char* zkh_combos_prepare(zkh_ctx*, zkh_buf* combos, const uint32_t* pos, const uint32_t* vals_ext,
                                size_t n_entries);
 /* Hal::combos_prepare with upstream's own argument list (combos, coeff_u, combo_count, cycles, regs_count, reg_sizes,
- * reg_combo_ids, mix), all operands device buffers as in `impl Hal`, nothing read back:
+ * reg_combo_ids, mix), all operands device buffers as in `impl Hal`:
  *   cur = 1; for r < regs_count: combos[cycles*reg_combo_ids[r] + i] -= cur * coeff_u[pos + i] (i < reg_sizes[r]); cur *= mix; pos += reg_sizes[r];
  *   then ZKH_CHECK_SIZE times: combos[cycles*combo_count] -= cur * coeff_u[pos]; pos += 1; cur *= mix.
- * combos: (combo_count + 1) x cycles ExtElems; register sizes <= 32.  (zkh_combos_prepare above is the host-flattened form
- * the in-library prover uses.) */
+ * combos: (combo_count + 1) x cycles ExtElems; registers of any size 1 .. cycles.  The register list is read back once and VALIDATED
+ * before the launch (sizes, combo ids, and that coeff_u holds sum(sizes) + ZKH_CHECK_SIZE coefficients): an inconsistent list is an
+ * error, never an out-of-bounds read.  (zkh_combos_prepare above is the host-flattened form the in-library prover uses.) */
 const char* zkh_combos_prepare_regs(zkh_ctx*, zkh_buf* combos, const zkh_buf* coeff_u, size_t combo_count, size_t cycles,
                                     size_t regs_count, const zkh_buf* reg_sizes, const zkh_buf* reg_combo_ids,
                                     const uint32_t mix[4]);
@@ -224,6 +225,21 @@ const char* zkh_syn_witgen(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_c
                            uint64_t noise_seed, const uint32_t* pub, zkh_buf* code, zkh_buf* data, uint32_t* out_global);
 const char* zkh_syn_accum(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cycles, uint64_t noise_seed,
                           const zkh_buf* data, const uint32_t* mix_global, zkh_buf* accum);
+
+/* ---- trace-driven witness (csrc/preflight.hip).  Upstream: the rv32im preflight replays a segment's cycles
+ * on one host thread into per-cycle records, witgen kernels fill the trace rows from them (one lane per cycle) and Hal::scatter
+ * places the preloaded memory image (risc0-circuit-rv32im 4.0.2 prove/witgen, un-vendored: /root/reference/Cargo.lock:5320; the
+ * guest input enters at /root/reference/crates/host/src/lib.rs:132-136).  Here the same pipeline for SYN-AIR circuits (kind 1,
+ * no public inputs) with a stand-in machine: zkh_syn_preflight is the SEQUENTIAL host producer — 4 words (16 bytes) per active
+ * cycle, all valid Elem words, plus the 1024-word RAM image before the first cycle — and zkh_syn_witgen_trace expands records
+ * that are already on the device (zkh_write_async from pinned memory: 16.7 MB per po2-20 segment instead of the 0.94 GB full
+ * trace) into the data group: one row-fill launch, the running-sum scan, the preload through zkh_scatter. ---- */
+size_t zkh_syn_preflight_ram_words(void);
+const char* zkh_syn_preflight(uint64_t seed, size_t po2, size_t zk_cycles, uint32_t* records, uint32_t* ram_image,
+                              double* cpu_seconds);
+const char* zkh_syn_witgen_trace(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cycles, uint64_t noise_seed,
+                                 const zkh_buf* records, const uint32_t* ram_image, zkh_buf* code, zkh_buf* data,
+                                 uint32_t* out_global);
 
 /* ---- segment prover: SegmentProver::prove_segment + risc0_zkp::prove::Prover ---- */
 const char* zkh_prover_create(zkh_ctx*, const zkh_circuit*, zkh_prover** out);
@@ -356,6 +372,8 @@ typedef struct {
     double fold_tail_s;                         /* join_tree == 2: last segment sealed -> root receipt */
     double fold_busy_s_sum;                     /* ... lane seconds spent inside lift / lift2 / join proofs */
     int streamed;                               /* ... 1 = fold nodes were proven as soon as their children existed (the default) */
+    double preflight_cpu_s_sum;                 /* witness source 1: host CPU seconds spent in the sequential preflight, summed over segments */
+    double trace_bytes;                         /* ... bytes that crossed PCIe as witness input (16 per cycle + the RAM image), summed */
 } zkh_prove_info;
 /* CircuitHal::accumulate for circuits without a built-in accum generator: fill `accum` (W_accum x 2^po2) from data + mix */
 typedef const char* (*zkh_accumulate_fn)(void* user, zkh_ctx*, const zkh_circuit*, size_t po2, const zkh_buf* data,
@@ -383,6 +401,11 @@ const char* zkh_session_set_recursion(zkh_session*, const uint32_t* rec_desc, si
  * the sealing lanes are still busy with segments, on every lane afterwards (upstream joins as receipts arrive too).  on = 0: two
  * phases (seal everything, then fold).  Same tree, same receipts either way. */
 void zkh_session_set_streamed_fold(zkh_session*, int on);
+/* Where a segment's witness comes from (SYN-AIR circuits without public inputs).  0 (default): the closed-form generator on the
+ * device (zkh_syn_witgen).  1: upstream's shape — a SEQUENTIAL host preflight per segment (zkh_syn_preflight) running ahead of the
+ * seals on `producers_per_lane` host threads per sealing lane (0 = 2), its compact records (16 bytes per cycle) uploaded from pinned
+ * memory and expanded on the GPU (zkh_syn_witgen_trace).  zkh_prove_info reports the host CPU seconds and the PCIe bytes. */
+const char* zkh_session_set_witness_source(zkh_session*, int source, size_t producers_per_lane);
 /* join_tree == 1: fold the receipts through the P2-JOIN tree (joins at 2^join_po2; join_noise_seed 0 = OS randomness);
  * join_tree == 2: lift every receipt and join level by level with the RECURSION programs - every node verifies its child
  * seal(s) in-circuit; the root receipt is a RECURSION seal with out = claim tree root ‖ allowed-programs root */

@@ -88,13 +88,15 @@ void zko_keccak_code(const zko_circuit* c, unsigned po2, unsigned zk, uint32_t* 
         code[4 * n + r] = (in_blocks && k >= 1) ? one : 0;
         code[5 * n + r] = (in_blocks && k == 0) ? one : 0;
         code[6 * n + r] = (K > 0 && r == KF_BLOCK * K - 1) ? one : 0;
+        if (wc > 14) code[14 * n + r] = (K > 0 && r == KF_BLOCK * (K - 1)) ? one : 0;       /* bind: row 0 of the last block */
         if (in_blocks && k >= 1)
             for (int j = 0; j < 7; j++) code[(7 + j) * n + r] = ((rc[k - 1] >> KF_RC_POS[j]) & 1) ? one : 0;
     }
 }
 
 /* last_input: 50 words (25 lanes, low word first) = the input state of the LAST permutation, or NULL (seeded like the
- * others).  out_global: 100 words, the output state of the last permutation as 16-bit limbs (lane l, limb j at 4 l + j). */
+ * others).  out_global: 200 words — the output state of the last permutation as 16-bit limbs (lane l, limb j at 4 l + j), then its
+ * input state at 100 + 4 l + j (the claim binds the PAIR: an output alone always has a preimage). */
 void zko_keccak_witgen(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t seed, uint64_t noise_seed,
                        const uint32_t* last_input, uint32_t* code, uint32_t* data, uint32_t* out_global) {
     size_t n = (size_t)1 << po2, A = n - zk, K = A / KF_BLOCK;
@@ -117,7 +119,10 @@ void zko_keccak_witgen(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t
                 data[col * n + KF_BLOCK * p + k] = ((rows[k][col >> 6] >> (col & 63)) & 1) ? one : 0;
         if (p + 1 == K)
             for (uint32_t l = 0; l < 25; l++)
-                for (uint32_t j = 0; j < 4; j++) out_global[4 * l + j] = fp_from_u32((uint32_t)((rows[KF_ROUNDS][l] >> (16 * j)) & 0xFFFF));
+                for (uint32_t j = 0; j < 4; j++) {
+                    out_global[4 * l + j] = fp_from_u32((uint32_t)((rows[KF_ROUNDS][l] >> (16 * j)) & 0xFFFF));
+                    if (c->global_size[ZKC_GLOBAL_OUT] >= 200) out_global[100 + 4 * l + j] = fp_from_u32((uint32_t)((in[l] >> (16 * j)) & 0xFFFF));
+                }
     }
     free(rows);
     for (size_t col = 0; col < wd; col++)

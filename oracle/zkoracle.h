@@ -137,6 +137,12 @@ void zko_p2join_witgen(const zko_circuit*, unsigned po2, unsigned zk_cycles, uin
 uint32_t* zko_prove_segment(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t seed,
                             uint64_t noise_seed, const uint32_t* pub, size_t* seal_words, const char** err);
 /* the same from given code (wc x n) and data (wd x n) traces and the out globals (OUTPUT_SIZE words) */
+/* ---- trace-driven witness (preflight.c): the sequential per-cycle machine and the row fill ----
+ * records: 4 words per ACTIVE row (2^po2 - zk_cycles rows); ram_image: zko_syn_preflight_ram_words() words (may be NULL) */
+size_t zko_syn_preflight_ram_words(void);
+void zko_syn_preflight(uint64_t seed, unsigned po2, unsigned zk_cycles, uint32_t* records, uint32_t* ram_image);
+void zko_syn_witgen_trace(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t noise_seed, const uint32_t* records,
+                          const uint32_t* ram_image, uint32_t* code, uint32_t* data, uint32_t* out_global);
 uint32_t* zko_prove_traces(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t noise_seed, const uint32_t* code,
                            const uint32_t* data, const uint32_t* out_words, size_t* seal_words, const char** err);
 void zko_root_of_code(const zko_circuit*, unsigned po2, const uint32_t* code, uint32_t root[8]);

@@ -35,7 +35,7 @@ def test_reference_permutation_is_sha3():
         assert K.digest_of_state(K.keccak_f(K.sha3_256_block(msg))) == hashlib.sha3_256(msg).digest()
     assert K.RC[:3] == [0x1, 0x8082, 0x800000000000808A] and K.RC[23] == 0x8000000080008008
     c = Circuit.parse(K.keccak_f_circuit())
-    assert c.group_sizes == (4, 14, 3840) and c.global_sizes == (100, 4) and c.kind == 2 and c.combos == [(0,), (0, 1)]
+    assert c.group_sizes == (4, 15, 3840) and c.global_sizes == (200, 4) and c.kind == 2 and c.combos == [(0,), (0, 1)]
 
 
 @pytest.fixture(scope="module")
@@ -57,7 +57,8 @@ def test_oracle_witness_is_keccak_f_row_by_row_and_its_output_is_the_sha3_digest
     got = _lanes(data, n, base + 24, r1)
     assert got[:25] == final and not any(got[25:])
     assert K.digest_of_state(got[:25]) == hashlib.sha3_256(MSG).digest()
-    assert [int(x) for x in out] == [int(oracle.zko_fp_encode(v)) for v in K.out_words(final)]
+    # out = the last permutation's output limbs, then its INPUT limbs: the claim binds the pair (an output alone always has a preimage)
+    assert [int(x) for x in out] == [int(oracle.zko_fp_encode(v)) for v in K.out_words(final, K.sha3_256_block(MSG))]
     # a seeded permutation elsewhere in the trace
     import ctypes as C
     oracle.zko_keccak_lane.restype, oracle.zko_keccak_lane.argtypes = C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint32]
@@ -69,6 +70,7 @@ def test_oracle_witness_is_keccak_f_row_by_row_and_its_output_is_the_sha3_digest
     for j, pos in enumerate(K.RC_POS):
         assert int((cg[7 + j] == r1).sum()) == k_perms * sum((rc >> pos) & 1 for rc in K.RC)
     assert cg[6, 25 * k_perms - 1] == r1
+    assert int((cg[14] == r1).sum()) == 1 and cg[14, 25 * (k_perms - 1)] == r1          # bind: row 0 of the last block
 
 
 def test_oracle_proves_the_permutations_and_both_verifiers_accept(oracle):
@@ -83,12 +85,36 @@ def test_oracle_proves_the_permutations_and_both_verifiers_accept(oracle):
     assert K.digest_of_state(state) == hashlib.sha3_256(MSG).digest()
     root = oc.control_root(PO2, ZK)
     HostCircuit(desc).verify_segment(seal, root)                       # the product's host verifier
-    # a forged digest: flip one output limb
-    bad = seal.copy()
-    bad[3] = oracle.zko_fp_encode((limbs[3] + 1) & 0xFFFF)
-    assert oc.verify(bad) is not None
-    with pytest.raises(HalError):
-        HostCircuit(desc).verify_segment(bad, root)
+    # the INPUT state is public too: out[100..200) is the padded message block
+    in_limbs = [fp_decode(int(w)) for w in seal[100:200]]
+    assert [sum(in_limbs[4 * lane + j] << (16 * j) for j in range(4)) for lane in range(25)] == K.sha3_256_block(MSG)
+    # a forged digest: flip one output limb; a forged preimage claim: flip one INPUT limb — both refused by both verifiers
+    for pos, cur in ((3, limbs[3]), (100 + 7, in_limbs[7])):
+        bad = seal.copy()
+        bad[pos] = oracle.zko_fp_encode((cur + 1) & 0xFFFF)
+        assert oc.verify(bad) is not None
+        with pytest.raises(HalError):
+            HostCircuit(desc).verify_segment(bad, root)
+
+
+def test_an_output_alone_no_longer_has_a_witness(oracle):
+    """Round-3 advisor finding: with only the output bound, ANY `out` was provable (keccak-f is a bijection: invert the rounds to
+    get a preimage).  Now the claim holds (input, output): a witness built for output y by inverting keccak-f proves
+    (f^-1(y), y) — a true statement — and cannot be passed off as a claim about another input."""
+    oc = zko.OracleCircuit(oracle, K.keccak_f_circuit())
+    honest_in = K.sha3_256_block(MSG)
+    other_in = K.sha3_256_block(b"another message")
+    code, data, out = oc.witgen(PO2, ZK, seed=1, noise_seed=2, pub=_pub(MSG))
+    n = 1 << PO2
+    mix = np.array([5, 6, 7, 8], dtype=np.uint32)
+    accum = np.zeros(4 * n, dtype=np.uint32)
+    oracle.zko_syn_accum(oc.h, PO2, ZK, 2, data, mix, accum)
+    claimed = out.copy()
+    claimed[100:200] = [int(oracle.zko_fp_encode(v)) for v in K.out_words(other_in)]      # same output, a different claimed input
+    assert oc.check_rows(PO2, accum, code, data, out, mix) == -1                          # the honest (input, output) pair: every row holds
+    bind_row = 25 * ((n - ZK) // 25 - 1)
+    assert oc.check_rows(PO2, accum, code, data, claimed, mix) == bind_row                # the forged input claim fails exactly on the bind row
+    assert honest_in != other_in
 
 
 # ------------------------------------------------------------------------------------------------ GPU
@@ -141,7 +167,7 @@ def test_keccak_eval_check_generated_kernels_equal_interpreter_and_oracle(hal, o
     rng = np.random.default_rng(5)
     P = 2013265921
     groups = [rng.integers(0, P, size=w * dom, dtype=np.uint64).astype(np.uint32) for w in (4, 14, 3840)]
-    out_g = rng.integers(0, P, size=100, dtype=np.uint64).astype(np.uint32)
+    out_g = rng.integers(0, P, size=200, dtype=np.uint64).astype(np.uint32)
     mix_g = rng.integers(0, P, size=4, dtype=np.uint64).astype(np.uint32)
     pm = rng.integers(0, P, size=4, dtype=np.uint64).astype(np.uint32)
     dg = [hal.copy_from("g", g) for g in groups]

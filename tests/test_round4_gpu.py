@@ -127,3 +127,116 @@ def test_host_placement_of_this_device():
         _, cpus = H.pci_numa_cpus(bdf)
         assert out["mask"] <= set(cpus) and out["r"]["cpus"] == len(out["mask"])
     assert H.placement_slot(0, [0]) == (0, 1)
+
+
+@pytest.mark.parametrize("shape,po2", [("syn_a", 13), ("wd21", 12), ("syn_small", 12)])
+def test_trace_driven_witness_equals_the_oracles(hal, oracle, shape, po2):
+    """Row f1: host preflight (sequential machine, 16 bytes per cycle) -> upload -> k_syn_rowfill + scan + the preload through
+    zkh_scatter gives the oracle's data group word for word (oracle/preflight.c), and the seal of those traces is the oracle's."""
+    import zko
+    from zeth_amd import hal as H
+    from zeth_amd.prover import Segment, SegmentProver
+    desc = {"syn_a": syn_air.syn_a, "syn_small": syn_air.syn_small, "wd21": lambda: syn_air.build_syn_air(8, 21, 8)}[shape]()
+    oc = zko.OracleCircuit(oracle, desc)
+    seed, noise = 0x5EED0000 + po2, 0x2E80
+    rec, ram, secs = H.syn_preflight(seed, po2)
+    orec, oram = oc.preflight(seed, po2)
+    assert np.array_equal(rec, orec) and np.array_equal(ram, oram) and secs > 0 and (rec < 2013265921).all()
+    sp = SegmentProver(hal, desc)
+    wa, wc, wd = sp.group_sizes()
+    n = 1 << po2
+    pinned = hal.host_alloc(rec.size)                        # the ingress path proper: pinned memory + an enqueued upload
+    pinned[:] = rec
+    drec = hal.alloc("records", rec.size)
+    hal.write_async(drec, pinned)
+    code, data = hal.alloc_elem("code", wc * n), hal.alloc_elem("data", wd * n)
+    out = hal.syn_witgen_trace(sp.circuit, po2, 1994, noise, drec, ram, code, data)
+    ocode, odata, oout = oc.witgen_trace(po2, rec, ram, noise)
+    assert np.array_equal(data.to_vec(), odata) and np.array_equal(code.to_vec(), ocode) and np.array_equal(out, oout)
+    T = (wd - 2) // 3
+    if wd - 2 > 3 * T:                                        # the preload landed: the first unconstrained column holds the RAM image
+        assert np.array_equal(odata[3 * T * n: 3 * T * n + 1024], ram)
+    seg = Segment(index=0, po2=po2, seed=seed, noise_seed=noise)
+    got = sp.seal(seg, code, data, out)
+    want = oc.prove_traces(po2, ocode, odata, oout, noise_seed=noise)
+    assert np.array_equal(got.seal, want)
+    got.verify(desc, sp.control_root(po2))
+    hal.sync()
+    hal.host_free(pinned)
+
+
+def test_session_with_host_preflight_pipeline(hal, oracle, monkeypatch):
+    """zkh_session_set_witness_source(1): producer threads replay every segment's cycles on the host ahead of the seals; receipts
+    equal the op-by-op path's and the oracle's, the host CPU time and the PCIe bytes are reported, a faulted segment is retried."""
+    import zko
+    from zeth_amd import hal as H
+    from zeth_amd.host import Session
+    from zeth_amd.prover import Segment, SegmentProver
+    desc = syn_air.syn_a()
+    oc = zko.OracleCircuit(oracle, desc)
+    segs = [Segment(index=i, po2=13 if i < 5 else 12, seed=1400 + i, noise_seed=0x53) for i in range(6)]
+    sess = Session(desc, devices=(0,), lanes_per_device=2)
+    sess.set_witness_source(1, 2)
+    comp, _, st = sess.prove(segs, verify=True)
+    words = sum(16 * ((1 << s.po2) - 1994) + 4 * 1024 + 16 for s in segs)
+    assert st["preflight_cpu_s_sum"] > 0 and st["trace_bytes"] == words and st["n_retries"] == 0
+    sp = SegmentProver(hal, desc)
+    for s, r in zip(segs, comp.segments):
+        rec, ram, _ = H.syn_preflight(s.seed, s.po2)
+        ocode, odata, oout = oc.witgen_trace(s.po2, rec, ram, s.noise_seed)
+        assert np.array_equal(r.seal, oc.prove_traces(s.po2, ocode, odata, oout, noise_seed=s.noise_seed))
+    monkeypatch.setenv("ZKH_FAULT_SEGMENT", "3")
+    comp2, _, st2 = sess.prove(segs, verify=True)
+    assert st2["n_retries"] == 1 and all(np.array_equal(a.seal, b.seal) for a, b in zip(comp.segments, comp2.segments))
+    monkeypatch.delenv("ZKH_FAULT_SEGMENT")
+    # back to the closed-form generator: different witnesses, hence different seals, same session
+    sess.set_witness_source(0)
+    comp3, _, st3 = sess.prove(segs, verify=True)
+    assert st3["trace_bytes"] == 0 and not np.array_equal(comp3.segments[0].seal, comp.segments[0].seal)
+    sess.close()
+
+
+def test_combos_prepare_regs_takes_any_register_size_and_refuses_inconsistent_lists(hal):
+    """Round-3 advisor finding: registers larger than 32 silently lost their terms and the sizes were never checked against coeff_u.
+    Now: any size up to `cycles` (against the host aggregation), and an inconsistent register list is an ERROR before the launch."""
+    import hal_only_prover as hop
+    from zeth_amd.hal import HalError
+    P = 2013265921
+    rng = np.random.default_rng(11)
+    cycles, combo_count = 128, 3
+    sizes = np.array([1, 40, 3, 97, 32, 33, 128, 2], dtype=np.uint32)
+    ids = rng.integers(0, combo_count, size=sizes.size).astype(np.uint32)
+    n_u = int(sizes.sum()) + hop.CHECK_SIZE
+    coeff_u = rng.integers(0, P, size=4 * n_u, dtype=np.uint64).astype(np.uint32)
+    start = rng.integers(0, P, size=4 * cycles * (combo_count + 1), dtype=np.uint64).astype(np.uint32)
+    mix = tuple(int(x) for x in rng.integers(1, P, size=4))
+    a = hal.copy_from("combos", start)
+    hal.combos_prepare_regs(a, hal.copy_from("cu", coeff_u), combo_count, cycles, hal.copy_from("s", sizes), hal.copy_from("i", ids), hop.e_words(mix))
+    sub, cur, pos = {}, (1, 0, 0, 0), 0
+    cu = [tuple(hop.dec(coeff_u[4 * k + i]) for i in range(4)) for k in range(n_u)]
+    for sz, cid in zip(sizes, ids):
+        for i in range(int(sz)):
+            key = cycles * int(cid) + i
+            sub[key] = hop.e_add(sub.get(key, (0, 0, 0, 0)), hop.e_mul(cur, cu[pos + i]))
+        cur = hop.e_mul(cur, mix)
+        pos += int(sz)
+    for _ in range(hop.CHECK_SIZE):
+        key = cycles * combo_count
+        sub[key] = hop.e_add(sub.get(key, (0, 0, 0, 0)), hop.e_mul(cur, cu[pos]))
+        pos += 1
+        cur = hop.e_mul(cur, mix)
+    b = hal.copy_from("combos", start)
+    hal.combos_prepare(b, np.asarray(list(sub), dtype=np.uint32), np.asarray([w for v in sub.values() for w in hop.e_words(v)], dtype=np.uint32))
+    assert np.array_equal(a.to_vec(), b.to_vec())
+
+    def call(sz, idv, cu_words):
+        hal.combos_prepare_regs(hal.copy_from("combos", start), hal.copy_from("cu", coeff_u[:cu_words]), combo_count, cycles,
+                                hal.copy_from("s", np.asarray(sz, dtype=np.uint32)), hal.copy_from("i", np.asarray(idv, dtype=np.uint32)), hop.e_words(mix))
+    with pytest.raises(HalError, match="add up to"):                  # sizes claim more U coefficients than coeff_u holds
+        call(sizes, ids, 4 * (n_u - 5))
+    with pytest.raises(HalError, match="has size"):                   # a register larger than the polynomial
+        call([cycles + 1] + list(sizes[1:]), ids, coeff_u.size)
+    with pytest.raises(HalError, match="has size"):
+        call([0] + list(sizes[1:]), ids, coeff_u.size)
+    with pytest.raises(HalError, match="names combo"):
+        call(sizes, [combo_count] + list(ids[1:]), coeff_u.size)

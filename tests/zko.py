@@ -59,6 +59,9 @@ def load():
         "zko_rec_witgen": (C.c_char_p, [u32p, sz, u32p, sz, u64, u32p, u32p, u32p]),
         "zko_rec_accum": (None, [vp, C.c_uint, C.c_uint, u64, u32p, u32p, u32p, u32p]),
         "zko_check_rows": (C.c_long, [vp, C.c_uint, C.POINTER(vp), C.POINTER(vp), sz, sz]),
+        "zko_syn_preflight_ram_words": (sz, []),
+        "zko_syn_preflight": (None, [u64, C.c_uint, C.c_uint, u32p, u32p]),
+        "zko_syn_witgen_trace": (None, [vp, C.c_uint, C.c_uint, u64, u32p, u32p, C.c_void_p, u32p, u32p]),
         "zko_num_threads": (C.c_int, []),
         "zko_set_num_threads": (None, [C.c_int]),
     }
@@ -93,6 +96,22 @@ class OracleCircuit:
         n = 1 << po2
         code, data, out = np.zeros(wc * n, np.uint32), np.zeros(wd * n, np.uint32), np.zeros(self.out_size, np.uint32)
         self.lib.zko_syn_witgen(self.h, po2, zk_cycles, seed, noise_seed, self._pub(pub), code, data, out)
+        return code, data, out
+
+    def preflight(self, seed, po2, zk_cycles=1994):
+        """-> (records: 4 words per active cycle, RAM image): the oracle's sequential machine (oracle/preflight.c)"""
+        A = (1 << po2) - zk_cycles
+        rec, ram = np.zeros(4 * A, np.uint32), np.zeros(int(self.lib.zko_syn_preflight_ram_words()), np.uint32)
+        self.lib.zko_syn_preflight(seed, po2, zk_cycles, rec, ram)
+        return rec, ram
+
+    def witgen_trace(self, po2, records, ram, noise_seed=0x2E80, zk_cycles=1994):
+        """records + RAM image -> (code, data, out_global): the oracle's row fill"""
+        wa, wc, wd = (int(x) for x in self.desc[3:6])
+        n = 1 << po2
+        code, data, out = np.zeros(wc * n, np.uint32), np.zeros(wd * n, np.uint32), np.zeros(self.out_size, np.uint32)
+        self.lib.zko_syn_witgen_trace(self.h, po2, zk_cycles, noise_seed, np.ascontiguousarray(records, dtype=np.uint32),
+                                      np.ascontiguousarray(ram, dtype=np.uint32), code.ctypes.data_as(C.c_void_p), data, out)
         return code, data, out
 
     def _pub(self, pub):

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(HERE)
 VARIANT = os.environ.get("ZKH_BUILD_VARIANT", "")
 LIB = os.path.join(ROOT, ".variants", f"libzkhal_{VARIANT}.so") if VARIANT else os.path.join(HERE, "libzkhal_mi355x.so")
 OBJ_DIR = os.path.join(ROOT, ".variants", f"_obj_{VARIANT}") if VARIANT else os.path.join(HERE, "csrc", "_obj")
-SOURCES = ["hal.hip", "ntt.hip", "hash.hip", "poly.hip", "circuit.hip", "prover.hip", "verifier.hip", "session.hip", "recursion.hip", "topology.hip"]   # + generated eval_check units
+SOURCES = ["hal.hip", "ntt.hip", "hash.hip", "poly.hip", "circuit.hip", "prover.hip", "verifier.hip", "session.hip", "recursion.hip", "topology.hip", "preflight.hip"]   # + generated eval_check units
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-Wno-unused-result"] + os.environ.get("ZKH_BUILD_FLAGS", "").split()
 # hash.hip: the unrolled Poseidon2 source order already interleaves 24 independent cells; LLVM's machine scheduler

@@ -16,16 +16,23 @@ Trace (n rows, A = n - zk_cycles active, K = A // 25 permutations, row r of perm
       C[x]     lanes 30..34                    T[x] ^ A[x,3] ^ A[x,4]                       (theta column parities)
       B[X, Y]  lanes 35..59                    rho / pi of theta's output: B[y, 2x+3y] = rotl(A[x,y] ^ D[x], r[x,y]),
                                                D[x] = C[x-1] ^ rotl(C[x+1], 1)
-  code (14 columns, a function of (po2, zk_cycles) alone -> control root):
+  code (15 columns, a function of (po2, zk_cycles) alone -> control root):
       0 active  1 first  2 body (the accum argument's selectors, as in SYN-AIR)
       3 round   (rows 0..23 of a block)        4 link  (rows 1..24: A follows from the previous row's B by chi + iota)
       5 input   (row 0 of a block: A is boolean)       6 final (row 24 of the LAST block: A is bound to `out`)
       7..13     the round constant of the PREVIOUS row's round at its 7 possible bit positions (0,1,3,7,15,31,63), on link rows
+      14 bind   (row 0 of the LAST block: that permutation's INPUT state is bound to `out` too)
   accum: one Fp4 running product of (mix + data column 0), the same argument (and kernel) as SYN-AIR's.
 Constraints (degree <= 5 with the selector): xor(a, b) = a + b - 2ab;
   round: T, C (3-way xors), B = xor(A', D) through the rho / pi wiring;
-  link : A = B@1 ^ (~B@1[x+1] & B@1[x+2])  [^ rc on lane 0];   input: a (1 - a) = 0;   final: 100 16-bit limbs = out.
-Globals: out = 100 words (lane l, limb j at 4 l + j), mix = 4 words.
+  link : A = B@1 ^ (~B@1[x+1] & B@1[x+2])  [^ rc on lane 0];   input: a (1 - a) = 0;   final: 100 16-bit limbs = out[0..100);
+  bind : the 100 16-bit limbs of the last permutation's input state = out[100..200).
+Globals: out = 200 words — the OUTPUT state of the last permutation (lane l, limb j at 4 l + j), then its INPUT state at 100 + 4 l + j —
+mix = 4 words.
+What a receipt says: "keccak-f(input) = output" for the (input, output) pair in `out`, i.e. in the claim.  Binding the output alone
+(as this circuit did before round 4) said nothing: keccak-f is a bijection, every output has a preimage, so any `out` was provable.
+The other K - 1 permutations of a segment are filler the claim does not mention (upstream's circuit folds all of them into a
+transcript digest; here one receipt = one (input, output) claim — declared).
 """
 from __future__ import annotations
 
@@ -35,7 +42,7 @@ from .desc import GLOBAL_MIX, GLOBAL_OUT, GROUP_ACCUM, GROUP_CODE, GROUP_DATA, P
 
 KIND_KECCAK_F = 2
 ROUNDS, BLOCK_ROWS = 24, 25
-WC, WD, WA, OUT_WORDS = 14, 60 * 64, 4, 100
+WC, WD, WA, OUT_WORDS = 15, 60 * 64, 4, 200
 LANE_A, LANE_T, LANE_C, LANE_B = 0, 25, 30, 35
 RC_POS = (0, 1, 3, 7, 15, 31, 63)
 NBETA = P - 11
@@ -119,9 +126,11 @@ def digest_of_state(state) -> bytes:
     return b"".join(int(v).to_bytes(8, "little") for v in state[:4])
 
 
-def out_words(state):
-    """The 100 `out` globals (canonical values) of a final state: lane l, 16-bit limb j at 4 l + j."""
-    return [(int(state[l]) >> (16 * j)) & 0xFFFF for l in range(25) for j in range(4)]
+def out_words(state, input_state=None):
+    """The `out` globals (canonical values): the final state's 100 16-bit limbs (lane l, limb j at 4 l + j), then — given the
+    last permutation's input state — its 100 limbs (the full 200-word `out` of the circuit)."""
+    limbs = lambda st: [(int(st[l]) >> (16 * j)) & 0xFFFF for l in range(25) for j in range(4)]
+    return limbs(state) + (limbs(input_state) if input_state is not None else [])
 
 
 def build_keccak_f() -> np.ndarray:
@@ -131,6 +140,7 @@ def build_keccak_f() -> np.ndarray:
     acc = lambda c, back=0: b.get(GROUP_ACCUM, c, back)
     one, two = b.const(1), b.const(2)
     active, first, body, rnd, link, inp, final = (code(i) for i in range(7))
+    bind = code(14)
     rcb = {pos: code(7 + j) for j, pos in enumerate(RC_POS)}
 
     def xor(p, q):                                   # p + q - 2 p q
@@ -191,6 +201,16 @@ def build_keccak_f() -> np.ndarray:
                 s = b.add(s, b.mul(pow2[i], bit(lane, 16 * j + i)))
             inner = b.and_eqz(inner, b.sub(s, b.get_global(GLOBAL_OUT, 4 * lane + j)))
     chain = b.and_cond(chain, final, inner)
+
+    # ---- bind row (row 0 of the last block): that permutation's INPUT state, as 16-bit limbs, is public too ----
+    inner = b.true()
+    for lane in range(25):
+        for j in range(4):
+            s = bit(lane, 16 * j)
+            for i in range(1, 16):
+                s = b.add(s, b.mul(pow2[i], bit(lane, 16 * j + i)))
+            inner = b.and_eqz(inner, b.sub(s, b.get_global(GLOBAL_OUT, 100 + 4 * lane + j)))
+    chain = b.and_cond(chain, bind, inner)
 
     # ---- accum: one Fp4 running product of (mix + data column 0), SYN-AIR's argument ----
     nbeta = b.const(NBETA)

@@ -68,6 +68,8 @@ struct CompiledEvalCheck { uint64_t desc_hash; const char* name; const eval_chec
 const CompiledEvalCheck* find_compiled_eval_check(uint64_t desc_hash);
 
 uint64_t desc_hash64(const uint32_t* words, size_t n);
+// inclusive prefix sum (mod P) of the first A words of a device column, in place; *last_out (device) = the grand total (circuit.hip)
+const char* prefix_sum_column(zkh_ctx* ctx, uint32_t* col, uint32_t A, uint32_t* last_out);
 
 // device program for the generic interpreter (slots allocated on the host by liveness).  op = opcode | kind(a) << 8 |
 // kind(b) << 11 | (dst is Fp4) << 14; operand kinds: taps, constants and globals are operands, not slots, so a tap that

@@ -263,6 +263,7 @@ __global__ void k_keccak_code(uint32_t* code, uint32_t n, uint32_t A, uint32_t K
     case 4: v = in_blocks && k >= 1; break;
     case 5: v = in_blocks && k == 0; break;
     case 6: v = K > 0 && r == KF_BLOCK * K - 1; break;
+    case 14: v = K > 0 && r == KF_BLOCK * (K - 1); break;          // bind: row 0 of the last block (its input state is public too)
     default: {
         const uint32_t pos = (1u << (col - 7)) - 1;                 // 0, 1, 3, 7, 15, 31, 63
         v = in_blocks && k >= 1 && ((tb.rc[k - 1] >> pos) & 1);
@@ -682,8 +683,8 @@ extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_bu
 // ---- SYN-AIR witness ----
 // ---- built-in witness generators: circuit kind 1 = SYN-AIR, kind 2 = KECCAK-F ----
 static const char* keccak_check_shape(const zkh_circuit* c) {
-    ZKH_REQUIRE(c->group_size[GROUP_CODE] == 14 && c->group_size[GROUP_DATA] == KF_LANES * 64 && c->group_size[GROUP_ACCUM] == 4 &&
-                c->global_size[GLOBAL_OUT] == 100, "keccak witgen: the circuit does not have KECCAK-F's shape (14 / 3840 / 4 columns, 100 outputs)");
+    ZKH_REQUIRE(c->group_size[GROUP_CODE] == 15 && c->group_size[GROUP_DATA] == KF_LANES * 64 && c->group_size[GROUP_ACCUM] == 4 &&
+                c->global_size[GLOBAL_OUT] == 200, "keccak witgen: the circuit does not have KECCAK-F's shape (15 / 3840 / 4 columns, 200 outputs)");
     return nullptr;
 }
 static const char* p2join_tables(zkh_ctx* ctx, Tmp& tab) {          // Montgomery words of the SHIPPED tables: rc[24 * 29] then diag[24]
@@ -696,6 +697,16 @@ static const char* p2join_check_shape(const zkh_circuit* c) {
     ZKH_REQUIRE(c->group_size[GROUP_CODE] == 43 && c->group_size[GROUP_DATA] == 2 * PJ_T && c->group_size[GROUP_ACCUM] == 4 &&
                 c->global_size[GLOBAL_OUT] == 24, "p2join witgen: the circuit does not have P2-JOIN's shape (43 / 48 / 4 columns, 24 outputs)");
     return nullptr;
+}
+// inclusive prefix sum (mod P) of the first A words of a device column, in place; *last_out = the grand total (device word)
+const char* zkh::prefix_sum_column(zkh_ctx* ctx, uint32_t* col, uint32_t A, uint32_t* last_out) {
+    const unsigned chunks = (A + 1023) / 1024;
+    Tmp totals;
+    ZKH_TRY(new_buf(ctx, chunks, false, totals.out()));
+    k_prefix_sum_chunks<<<chunks, 1024, 0, ctx->stream>>>(col, A, totals->ptr());
+    k_prefix_sum_fp<<<1, 1024, 0, ctx->stream>>>(totals->ptr(), chunks, last_out);
+    k_prefix_sum_carry<<<chunks, 1024, 0, ctx->stream>>>(col, A, totals->ptr());
+    return last_launch_error("prefix_sum_column");
 }
 extern "C" const char* zkh_syn_code(zkh_ctx* ctx, const zkh_circuit* c, size_t po2, size_t zk_cycles, zkh_buf* code) {
     ZKH_REQUIRE(c->kind >= 1 && c->kind <= 3, "syn_code: no built-in witness generator for circuit kind %u", c->kind);
@@ -753,7 +764,7 @@ extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t
     }
     if (c->kind == 2) {
         // KECCAK-F: `pub` = optional input state of the LAST permutation (25 lanes = 50 words, low word first); out_global =
-        // that permutation's output state as 100 16-bit limbs (what the `final` row's constraints bind)
+        // that permutation's output state as 100 16-bit limbs, then its input state as 100 more (what the `final` / `bind` rows' constraints bind)
         ZKH_TRY(keccak_check_shape(c));
         ZKH_REQUIRE((!code || code->len == (size_t)wc * n) && data->len == (size_t)wd * n, "keccak witgen: buffer shape mismatch");
         const uint32_t K = A / KF_BLOCK;
@@ -772,10 +783,15 @@ extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t
             k_keccak_expand<<<dim3((unsigned)((n + 255) / 256), wd), 256, 0, ctx->stream>>>(data->ptr(), (const uint64_t*)rows->ptr(), (uint32_t)n, A, K, noise_seed);
         }
         ZKH_TRY(last_launch_error("keccak_witgen"));
-        uint32_t fin[50];
+        // out = the last permutation's OUTPUT state, then its INPUT state (row 0 of the last block), as 16-bit limbs: the claim binds the pair
+        uint32_t fin[50], first[50];
         ZKH_TRY(zkh_read(ctx, rows, fin, ((size_t)K * KF_BLOCK - 1) * KF_LANES * 2, 50));
+        ZKH_TRY(zkh_read(ctx, rows, first, ((size_t)(K - 1) * KF_BLOCK) * KF_LANES * 2, 50));
         for (uint32_t l = 0; l < 25; l++)
-            for (uint32_t j = 0; j < 4; j++) out_global[4 * l + j] = fp_encode((fin[2 * l + (j >> 1)] >> (16 * (j & 1))) & 0xffffu).v;
+            for (uint32_t j = 0; j < 4; j++) {
+                out_global[4 * l + j] = fp_encode((fin[2 * l + (j >> 1)] >> (16 * (j & 1))) & 0xffffu).v;
+                out_global[100 + 4 * l + j] = fp_encode((first[2 * l + (j >> 1)] >> (16 * (j & 1))) & 0xffffu).v;
+            }
         return nullptr;
     }
     const uint32_t n_pub = c->global_size[GLOBAL_OUT] - 4;
@@ -788,15 +804,7 @@ extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t
     if (n_pub) ZKH_TRY(zkh_copy_from(ctx, "pub", pub, n_pub, dpub.out()));
     const unsigned bx = (unsigned)((n + 255) / 256);
     k_syn_data<<<bx, 256, 0, ctx->stream>>>(data->ptr(), wd, (uint32_t)n, A, seed, noise_seed, dpub ? dpub->ptr() : nullptr, n_pub);
-    {
-        const unsigned chunks = (A + 1023) / 1024;
-        Tmp totals;
-        ZKH_TRY(new_buf(ctx, chunks, false, totals.out()));
-        uint32_t* scol = data->ptr() + (size_t)(wd - 1) * n;
-        k_prefix_sum_chunks<<<chunks, 1024, 0, ctx->stream>>>(scol, A, totals->ptr());
-        k_prefix_sum_fp<<<1, 1024, 0, ctx->stream>>>(totals->ptr(), chunks, last->ptr());
-        k_prefix_sum_carry<<<chunks, 1024, 0, ctx->stream>>>(scol, A, totals->ptr());
-    }
+    ZKH_TRY(prefix_sum_column(ctx, data->ptr() + (size_t)(wd - 1) * n, A, last->ptr()));
     ZKH_TRY(last_launch_error("syn_witgen"));
     out_global[1] = out_global[2] = out_global[3] = 0;
     for (uint32_t k = 0; k < n_pub; k++) out_global[4 + k] = pub[k];

@@ -1,6 +1,8 @@
 // hal.hip — context, Buffer<T> plumbing, stream-ordered pool, profiling, and the small element-wise Hal ops.
 // Stands in for risc0-zkp 3.0.2 src/hal/{mod.rs,cuda.rs} (un-vendored; /root/reference/Cargo.lock:5393),
 // reached from /root/reference/crates/host/src/lib.rs:137.
+#include <algorithm>
+
 #include "common.h"
 #include "poseidon2.h"
 #include "../../include/zkh_poseidon2_consts.h"
@@ -405,31 +407,35 @@ __global__ void k_combos_prepare(uint4* combos, const uint32_t* pos, const uint4
 // One lane per TARGET position (combo c, offset i) walks the register list and sums its own contributions (several
 // registers hit the same position, so the walk is per target, not per register); exact field arithmetic, so the order of
 // the subtractions does not matter.  A few dozen lanes x regs_count Fp4 products: ~0.1 ms for a thousand registers.
-constexpr uint32_t PREP_MAX_REG_SIZE = 32;
+// Lane (c, i) owns the target offsets i, i + 32, i + 64, ... of combo c (registers of any size: `max_size` is the largest one, from the
+// host's validation of the register list, which also bounds every coeff_u index this kernel forms).
+constexpr uint32_t PREP_LANES_PER_COMBO = 32;
 __global__ void k_combos_prepare_regs(uint4* combos, size_t combos_ext, const uint4* coeff_u, uint32_t combo_count, size_t cycles,
-                                      uint32_t regs_count, const uint32_t* reg_sizes, const uint32_t* reg_combo_ids, Fp4 mix) {
+                                      uint32_t regs_count, const uint32_t* reg_sizes, const uint32_t* reg_combo_ids, Fp4 mix, uint32_t max_size) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t c = tid / PREP_MAX_REG_SIZE, i = tid % PREP_MAX_REG_SIZE;
-    if (c > combo_count || (c == combo_count && i != 0)) return;
-    Fp4 cur = Fp4::one(), acc = Fp4::zero();
-    size_t pos = 0;
-    bool any = false;
+    const uint32_t c = tid / PREP_LANES_PER_COMBO, i0 = tid % PREP_LANES_PER_COMBO;
+    if (c > combo_count || (c == combo_count && i0 != 0)) return;
     auto ld = [&](size_t k) { const uint4 v = coeff_u[k]; return Fp4(Fp::raw(v.x), Fp::raw(v.y), Fp::raw(v.z), Fp::raw(v.w)); };
-    for (uint32_t r = 0; r < regs_count; r++) {
-        const uint32_t sz = reg_sizes[r];
-        if (reg_combo_ids[r] == c && i < sz) { acc = acc + cur * ld(pos + i); any = true; }
-        cur = cur * mix;
-        pos += sz;
+    for (uint32_t i = i0; i < (c == combo_count ? 1u : max_size); i += PREP_LANES_PER_COMBO) {
+        Fp4 cur = Fp4::one(), acc = Fp4::zero();
+        size_t pos = 0;
+        bool any = false;
+        for (uint32_t r = 0; r < regs_count; r++) {
+            const uint32_t sz = reg_sizes[r];
+            if (reg_combo_ids[r] == c && i < sz) { acc = acc + cur * ld(pos + i); any = true; }
+            cur = cur * mix;
+            pos += sz;
+        }
+        if (c == combo_count) {
+            for (int k = 0; k < ZKH_CHECK_SIZE; k++) { acc = acc + cur * ld(pos + k); cur = cur * mix; }
+            any = true;
+        }
+        const size_t at = cycles * c + i;
+        if (!any || at >= combos_ext) continue;
+        uint4 v = combos[at];
+        v.x = sub_mod(v.x, acc.c[0].v); v.y = sub_mod(v.y, acc.c[1].v); v.z = sub_mod(v.z, acc.c[2].v); v.w = sub_mod(v.w, acc.c[3].v);
+        combos[at] = v;
     }
-    if (c == combo_count) {
-        for (int k = 0; k < ZKH_CHECK_SIZE; k++) { acc = acc + cur * ld(pos + k); cur = cur * mix; }
-        any = true;
-    }
-    const size_t at = cycles * c + i;
-    if (!any || at >= combos_ext) return;
-    uint4 v = combos[at];
-    v.x = sub_mod(v.x, acc.c[0].v); v.y = sub_mod(v.y, acc.c[1].v); v.z = sub_mod(v.z, acc.c[2].v); v.w = sub_mod(v.w, acc.c[3].v);
-    combos[at] = v;
 }
 // Merkle opening for many query indices: block q handles idx[q]; first the column words then the sibling path.
 __global__ void k_merkle_open(uint32_t* out, const uint32_t* matrix, const uint32_t* nodes, const uint32_t* idxs,
@@ -534,14 +540,32 @@ extern "C" const char* zkh_combos_prepare_regs(zkh_ctx* c, zkh_buf* combos, cons
     ZKH_REQUIRE(combos->len == (combo_count + 1) * cycles * 4, "combos_prepare_regs: combos has %zu words, expected (combo_count + 1) x cycles ExtElems", combos->len);
     ZKH_REQUIRE(reg_sizes->len == regs_count && reg_combo_ids->len == regs_count, "combos_prepare_regs: reg_sizes / reg_combo_ids must hold regs_count words");
     ZKH_REQUIRE(coeff_u->len % 4 == 0 && coeff_u->len >= 4 * (regs_count + ZKH_CHECK_SIZE), "combos_prepare_regs: coeff_u too short");
-    ZKH_REQUIRE(cycles >= PREP_MAX_REG_SIZE, "combos_prepare_regs: cycles %zu below the largest supported register size", cycles);
     for (int i = 0; i < 4; i++) ZKH_REQUIRE(mix[i] < P, "combos_prepare_regs: mix is not a reduced element");
+    // The register list is the caller's device data and this is a public entry point: read it back once (a few KB; the call is in
+    // the latency-bound DEEP phase anyway) and check everything the kernel will index with — every size, every combo id, and that
+    // the U coefficients the sizes add up to (plus the CHECK_SIZE of the check polynomial) are really there.
+    std::vector<uint32_t> h_sizes(regs_count), h_ids(regs_count);
+    if (regs_count) {
+        ZKH_TRY(zkh_read(c, reg_sizes, h_sizes.data(), 0, regs_count));
+        ZKH_TRY(zkh_read(c, reg_combo_ids, h_ids.data(), 0, regs_count));
+    }
+    size_t total = 0;
+    uint32_t max_size = 1;
+    for (size_t r = 0; r < regs_count; r++) {
+        ZKH_REQUIRE(h_sizes[r] >= 1 && h_sizes[r] <= cycles, "combos_prepare_regs: register %zu has size %u (must be 1 .. cycles = %zu)", r, h_sizes[r], cycles);
+        ZKH_REQUIRE(h_ids[r] < combo_count, "combos_prepare_regs: register %zu names combo %u of %zu", r, h_ids[r], combo_count);
+        total += h_sizes[r];
+        max_size = std::max(max_size, h_sizes[r]);
+    }
+    ZKH_REQUIRE(cycles >= ZKH_CHECK_SIZE && (total + ZKH_CHECK_SIZE) * 4 <= coeff_u->len,
+                "combos_prepare_regs: the register sizes add up to %zu U coefficients (+ %d of the check polynomial) but coeff_u holds %zu", total,
+                ZKH_CHECK_SIZE, coeff_u->len / 4);
     const Fp4 m(Fp::raw(mix[0]), Fp::raw(mix[1]), Fp::raw(mix[2]), Fp::raw(mix[3]));
-    const size_t lanes = (combo_count + 1) * PREP_MAX_REG_SIZE;
+    const size_t lanes = (combo_count + 1) * PREP_LANES_PER_COMBO;
     ProfScope ps(c, "combos_prepare", 36.0 * (double)(coeff_u->len / 4));
     k_combos_prepare_regs<<<(unsigned)((lanes + 63) / 64), 64, 0, c->stream>>>((uint4*)combos->ptr(), combos->len / 4, (const uint4*)coeff_u->ptr(),
                                                                                (uint32_t)combo_count, cycles, (uint32_t)regs_count, reg_sizes->ptr(),
-                                                                               reg_combo_ids->ptr(), m);
+                                                                               reg_combo_ids->ptr(), m, max_size);
     return last_launch_error("combos_prepare_regs");
 }
 extern "C" const char* zkh_merkle_open(zkh_ctx* c, const zkh_buf* matrix, const zkh_buf* nodes, size_t rows, size_t cols,

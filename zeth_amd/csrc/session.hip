@@ -47,7 +47,12 @@ struct Lane {
     zkh_prover *prover = nullptr, *join_prover = nullptr;
     std::vector<zkh_rec_program*> programs;
     std::vector<uint32_t> resident_po2;       // sizes whose committed code group this lane's prover keeps in HBM
+    // witness source 1 (host preflight): pinned record slots of this lane (zkh_host_alloc), 4 x 2^po2 words each, recycled
+    std::vector<uint32_t*> record_slots;
+    size_t record_slot_words = 0;
     void close() {
+        for (auto p : record_slots) if (ctx) zkh_host_free(ctx, p);
+        record_slots.clear(); record_slot_words = 0;
         for (auto p : programs) zkh_rec_program_destroy(p);
         programs.clear();
         if (rec_circuit) zkh_circuit_destroy(rec_circuit);
@@ -92,6 +97,8 @@ struct zkh_session {
     void* accumulate_user = nullptr;
     bool resident_code = true;           // built-in circuits: the committed code group of each size stays in HBM per lane
     bool streamed_fold = true;           // join_tree 2: lift2 / join a node the moment its children exist, concurrently with the sealing lanes
+    int witness_source = 0;              // 0: closed-form generators on the device; 1: sequential host preflight -> compact records -> row fill
+    size_t producers_per_lane = 2;       // ... host threads per sealing lane that run the preflight ahead of the seals
     ~zkh_session() { for (auto& l : fold_lanes) l.close(); for (auto& l : lanes) l.close(); }
 };
 
@@ -212,6 +219,14 @@ extern "C" const char* zkh_session_set_recursion(zkh_session* s, const uint32_t*
     return nullptr;
 }
 extern "C" void zkh_session_set_streamed_fold(zkh_session* s, int on) { if (s) s->streamed_fold = on != 0; }
+extern "C" const char* zkh_session_set_witness_source(zkh_session* s, int source, size_t producers_per_lane) {
+    ZKH_REQUIRE(s && (source == 0 || source == 1), "session_set_witness_source: source must be 0 (closed form on the device) or 1 (host preflight)");
+    ZKH_REQUIRE(source == 0 || (s->lanes[0].circuit->kind == 1 && s->lanes[0].circuit->global_size[GLOBAL_OUT] == 4),
+                "session_set_witness_source: the host preflight drives SYN-AIR circuits (kind 1) without public inputs only");
+    s->witness_source = source;
+    s->producers_per_lane = producers_per_lane ? producers_per_lane : 2;
+    return nullptr;
+}
 
 extern "C" void zkh_prove_info_free(zkh_prove_info* info) {
     if (!info) return;
@@ -233,7 +248,9 @@ static const char* leaf_control_root(zkh_session* s, const zkh_segment& seg, uin
 }
 
 // one segment on one lane: built-in witness generator, or the caller's traces through prove_begin / accumulate / prove_finish
-static const char* seal_one(zkh_session* s, Lane& l, const zkh_segment& seg, uint32_t** seal, size_t* words, double* witgen_s) {
+// records / ram: this segment's preflight output in pinned memory (witness source 1), or NULL: run the preflight here (a retry)
+static const char* seal_one(zkh_session* s, Lane& l, const zkh_segment& seg, uint32_t** seal, size_t* words, double* witgen_s,
+                            const uint32_t* records = nullptr, const uint32_t* ram = nullptr, double* preflight_cpu_s = nullptr, double* trace_bytes = nullptr) {
     const zkh_circuit* cir = l.circuit;
     const size_t n = (size_t)1 << seg.po2;
     uint64_t noise = seg.noise_seed;
@@ -273,13 +290,29 @@ static const char* seal_one(zkh_session* s, Lane& l, const zkh_segment& seg, uin
             l.resident_po2.push_back(seg.po2);
         }
         code.out();                                                  // the trace itself is not needed again
-        ZKH_TRY(zkh_syn_witgen(l.ctx, cir, seg.po2, ZKH_ZK_CYCLES, seg.seed, noise, seg.n_pub ? seg.pub : nullptr, nullptr, data, out_global.data()));
-        *witgen_s = now_s() - t0;
-        return zkh_prove_segment(l.prover, seg.po2, ZKH_ZK_CYCLES, noise, nullptr, data, out_global.data(), seal, words);
     }
-    ZKH_TRY(zkh_syn_witgen(l.ctx, cir, seg.po2, ZKH_ZK_CYCLES, seg.seed, noise, seg.n_pub ? seg.pub : nullptr, code, data, out_global.data()));
+    zkh_buf* code_arg = code ? (zkh_buf*)code : nullptr;
+    if (s->witness_source == 1 && cir->kind == 1) {
+        // trace-driven: the compact per-cycle records (16 bytes per cycle) go up from pinned memory, the row fill expands them
+        const size_t A = n - ZKH_ZK_CYCLES;
+        std::vector<uint32_t> inline_records, inline_ram;
+        if (!records) {                                               // no producer ran ahead for this one (a retry): preflight here
+            inline_records.resize(4 * A); inline_ram.resize(zkh_syn_preflight_ram_words());
+            double cpu = 0;
+            ZKH_TRY(zkh_syn_preflight(seg.seed, seg.po2, ZKH_ZK_CYCLES, inline_records.data(), inline_ram.data(), &cpu));
+            if (preflight_cpu_s) *preflight_cpu_s += cpu;
+        }
+        Tmp recs;
+        ZKH_TRY(zkh_alloc(l.ctx, "records", 4 * A, 0, recs.out()));
+        if (records) ZKH_TRY(zkh_write_async(l.ctx, recs, records, 0, 4 * A));
+        else ZKH_TRY(zkh_write(l.ctx, recs, inline_records.data(), 0, 4 * A));
+        if (trace_bytes) *trace_bytes += 16.0 * A + 4.0 * zkh_syn_preflight_ram_words() + 4.0 * out_global.size();
+        ZKH_TRY(zkh_syn_witgen_trace(l.ctx, cir, seg.po2, ZKH_ZK_CYCLES, noise, recs, records ? ram : inline_ram.data(), code_arg, data, out_global.data()));
+    } else {
+        ZKH_TRY(zkh_syn_witgen(l.ctx, cir, seg.po2, ZKH_ZK_CYCLES, seg.seed, noise, seg.n_pub ? seg.pub : nullptr, code_arg, data, out_global.data()));
+    }
     *witgen_s = now_s() - t0;
-    return zkh_prove_segment(l.prover, seg.po2, ZKH_ZK_CYCLES, noise, code, data, out_global.data(), seal, words);
+    return zkh_prove_segment(l.prover, seg.po2, ZKH_ZK_CYCLES, noise, code_arg, data, out_global.data(), seal, words);
 }
 
 extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs, size_t n, int join_tree, size_t join_po2, uint64_t join_noise_seed,
@@ -426,9 +459,68 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
         }
         return nullptr;
     };
-    double wit_sum = 0, seal_sum = 0, fold_busy = 0;
+    double wit_sum = 0, seal_sum = 0, fold_busy = 0, pre_cpu_sum = 0, trace_bytes_sum = 0;
     size_t n_retries = 0;
+    // ---- witness source 1: the sequential host preflight runs AHEAD of the seals.  Every sealing lane has its own producer threads
+    // (zkh_session_set_witness_source: default 2 — one preflight of a po2-20 segment is ~70 ms of one core, a lane seals one every
+    // ~70 ms) and a pool of pinned record slots (producers + 1): a producer takes the next segment index, replays its cycles into a
+    // free slot, and queues (segment, slot) for its lane, which uploads the 16 bytes per cycle and row-fills on the GPU.  The
+    // producers are what pull the work index; a lane seals what its producers hand it. ----
+    const bool use_pre = s->witness_source == 1 && s->lanes[0].circuit->kind == 1;
+    struct Ready { size_t seg; uint32_t* slot; };
+    struct LaneQ { std::deque<Ready> ready; std::vector<uint32_t*> free_slots; size_t producers_active = 0; bool accepting = true; };
+    std::vector<LaneQ> laneq(s->lanes.size());
+    const size_t ram_words = zkh_syn_preflight_ram_words();
+    if (use_pre) {
+        uint32_t max_po2 = 0;
+        for (size_t i = 0; i < n; i++) {
+            ZKH_REQUIRE(!segs[i].host_code && !segs[i].host_data && !segs[i].n_pub, "session_prove: witness source 1 takes segments described by their seed only");
+            max_po2 = std::max(max_po2, segs[i].po2);
+        }
+        const size_t slot_words = ((size_t)4 << max_po2) + ram_words;          // records, then the RAM image
+        for (size_t k = 0; k < s->lanes.size(); k++) {
+            Lane& l = s->lanes[k];
+            if (l.record_slot_words < slot_words) {                             // (main thread: nobody else touches the contexts yet)
+                for (auto p : l.record_slots) zkh_host_free(l.ctx, p);
+                l.record_slots.clear(); l.record_slot_words = 0;
+            }
+            while (l.record_slots.size() < s->producers_per_lane + 1) {
+                uint32_t* p = nullptr;
+                if (const char* e = zkh_host_alloc(l.ctx, slot_words, &p)) { zkh_prove_info_free(info); return e; }
+                l.record_slots.push_back(p);
+            }
+            l.record_slot_words = slot_words;
+            laneq[k].free_slots = l.record_slots;
+            laneq[k].producers_active = s->producers_per_lane;
+        }
+    }
+    auto producer = [&](size_t lane_idx) {
+        LaneQ& q = laneq[lane_idx];
+        const Lane& l = s->lanes[lane_idx];
+        if (!getenv("ZKH_SESSION_NO_AFFINITY")) { const char* e = zkh_bind_thread_to_device(l.device, 0, 1, nullptr, nullptr); if (e) zkh_free_error(e); }
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return errs.any() || !q.accepting || next_seal >= n || !q.free_slots.empty(); });
+            if (errs.any() || !q.accepting || next_seal >= n) break;
+            const size_t i = next_seal++;
+            uint32_t* slot = q.free_slots.back();
+            q.free_slots.pop_back();
+            lk.unlock();
+            double cpu = 0;
+            const char* err = zkh_syn_preflight(segs[i].seed, segs[i].po2, ZKH_ZK_CYCLES, slot, slot + ((size_t)4 << segs[i].po2), &cpu);
+            lk.lock();
+            pre_cpu_sum += cpu;
+            if (err) { errs.set(err, "preflight"); q.free_slots.push_back(slot); break; }
+            if (q.accepting) q.ready.push_back(Ready{i, slot});
+            else { q.free_slots.push_back(slot); retry.push_back(Retry{i, nullptr, 0}); }     // the lane stopped sealing meanwhile: anyone may take it
+            cv.notify_all();
+        }
+        q.producers_active--;
+        lk.unlock();
+        cv.notify_all();
+    };
     auto worker = [&](Lane* l, bool can_seal) {
+        const size_t lane_idx = can_seal ? (size_t)(l - s->lanes.data()) : 0;
         if (!getenv("ZKH_SESSION_NO_AFFINITY")) { const char* e = zkh_bind_thread_to_device(l->device, 0, 1, nullptr, nullptr); if (e) zkh_free_error(e); }
         std::vector<uint32_t> in;
         double wit = 0, seal_t = 0, fold_t = 0;
@@ -439,20 +531,26 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
             // 1) a segment: retries first (never on the lane that just failed it, unless no other sealing lane is left or
             //    nobody else picked it up within 50 ms), then the next index
             size_t seg = NONE;
+            uint32_t* slot = nullptr;
             if (can_seal) {
                 for (auto it = retry.begin(); it != retry.end(); ++it)
                     if (it->failed_on != l || seal_lanes_active <= 1 || now_s() - it->since > 0.05) { seg = it->seg; retry.erase(it); break; }
-                if (seg == NONE && next_seal < n) seg = next_seal++;
+                if (seg == NONE && use_pre) {
+                    LaneQ& q = laneq[lane_idx];
+                    if (!q.ready.empty()) { seg = q.ready.front().seg; slot = q.ready.front().slot; q.ready.pop_front(); }
+                } else if (seg == NONE && next_seal < n) seg = next_seal++;
             }
             if (seg != NONE) {
                 lk.unlock();
-                double w = 0;
+                double w = 0, pcpu = 0, tbytes = 0;
                 const double ts = now_s();
                 const char* err = nullptr;
                 if ((long)seg == fault_always || ((long)seg == fault_seg && attempts[seg] == 0)) err = make_err("injected fault (ZKH_FAULT_SEGMENT)");
-                else err = seal_one(s, *l, segs[seg], &info->seals[seg], &info->seal_words[seg], &w);
+                else err = seal_one(s, *l, segs[seg], &info->seals[seg], &info->seal_words[seg], &w, slot, slot ? slot + ((size_t)4 << segs[seg].po2) : nullptr, &pcpu, &tbytes);
                 const double te = now_s();
                 lk.lock();
+                pre_cpu_sum += pcpu; trace_bytes_sum += tbytes;
+                if (slot) { laneq[lane_idx].free_slots.push_back(slot); cv.notify_all(); }      // the upload is done: the seal ended with a host sync
                 if (err) {
                     if (attempts[seg]++ < max_retries) {       // hand it to another lane / device
                         zkh_free_error(err);
@@ -460,7 +558,15 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
                         retry.push_back(Retry{seg, l, now_s()});
                         n_retries++;
                         cv.notify_all();
-                        if (++consecutive_failures >= 2 && seal_lanes_active > 1) { can_seal = false; seal_lanes_active--; }      // this lane stops taking segments
+                        if (++consecutive_failures >= 2 && seal_lanes_active > 1) {      // this lane stops taking segments
+                            can_seal = false; seal_lanes_active--;
+                            if (use_pre) {                            // what its producers already prepared goes to the other lanes
+                                LaneQ& q = laneq[lane_idx];
+                                q.accepting = false;
+                                for (auto& r : q.ready) { q.free_slots.push_back(r.slot); retry.push_back(Retry{r.seg, nullptr, 0}); }
+                                q.ready.clear();
+                            }
+                        }
                         continue;
                     }
                     char what[64];
@@ -491,7 +597,8 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
                 else if (plan[id].parent != NONE) child_done(plan[id].parent);
                 continue;
             }
-            // 3) nothing to do right now (a retry entry held back for another lane wakes us after 20 ms)
+            // 3) nothing to do right now (a retry entry held back for another lane wakes us after 20 ms; producers, finished seals and
+            //    finished fold nodes notify)
             if (can_seal && !retry.empty()) cv.wait_for(lk, std::chrono::milliseconds(20));
             else cv.wait(lk);
         }
@@ -505,10 +612,12 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
         std::vector<std::thread> th;
         for (auto& lane : s->lanes) th.emplace_back(worker, &lane, true);
         if (fold) for (auto& lane : s->fold_lanes) th.emplace_back(worker, &lane, false);
+        if (use_pre) for (size_t k = 0; k < s->lanes.size(); k++) for (size_t p = 0; p < s->producers_per_lane; p++) th.emplace_back(producer, k);
         for (auto& t : th) t.join();
     }
     const double t_end = now_s();
     info->witgen_s_sum = wit_sum; info->seal_s_sum = seal_sum; info->fold_busy_s_sum = fold_busy; info->n_retries = n_retries;
+    info->preflight_cpu_s_sum = pre_cpu_sum; info->trace_bytes = trace_bytes_sum;
     info->leaves_s = (t_leaves_done ? t_leaves_done : t_end) - t0;
     if (fold) {
         // bottom level = lifts (or lift2 per pair); with the streamed fold these overlap the leaf phase: lift_s / join_s are what the

@@ -41,7 +41,8 @@ class ProveInfo(C.Structure):
                 ("root_seal", C.POINTER(C.c_uint32)), ("root_seal_words", C.c_size_t), ("n_joins", C.c_size_t),
                 ("wall_s", C.c_double), ("leaves_s", C.c_double), ("join_s", C.c_double), ("witgen_s_sum", C.c_double), ("seal_s_sum", C.c_double),
                 ("n_lifts", C.c_size_t), ("root_program", C.c_size_t), ("lift_s", C.c_double),
-                ("n_retries", C.c_size_t), ("fold_tail_s", C.c_double), ("fold_busy_s_sum", C.c_double), ("streamed", C.c_int)]
+                ("n_retries", C.c_size_t), ("fold_tail_s", C.c_double), ("fold_busy_s_sum", C.c_double), ("streamed", C.c_int),
+                ("preflight_cpu_s_sum", C.c_double), ("trace_bytes", C.c_double)]
 
 
 # every symbol include/zkhal.h declares: (restype, argtypes)
@@ -114,6 +115,9 @@ ABI = {
     "zkh_syn_code": (_err, [_vp, _vp, _sz, _sz, _vp]),
     "zkh_syn_witgen": (_err, [_vp, _vp, _sz, _sz, _u64, _u64, _u32p, _vp, _vp, _u32p]),
     "zkh_syn_accum": (_err, [_vp, _vp, _sz, _sz, _u64, _vp, _u32p, _vp]),
+    "zkh_syn_preflight_ram_words": (_sz, []),
+    "zkh_syn_preflight": (_err, [_u64, _sz, _sz, _u32p, _u32p, C.POINTER(C.c_double)]),
+    "zkh_syn_witgen_trace": (_err, [_vp, _vp, _sz, _sz, _u64, _vp, _u32p, _vp, _vp, _u32p]),
     "zkh_poseidon2_mix": (_err, [_vp, _vp, _sz]),
     "zkh_poseidon2_mix_host": (_err, [_u32p, _u32p, _u32p, _sz]),
     "zkh_prover_create": (_err, [_vp, _vp, C.POINTER(_vp)]),
@@ -147,6 +151,7 @@ ABI = {
     "zkh_session_set_accumulate": (None, [_vp, _vp, _vp]),
     "zkh_session_set_resident_code": (None, [_vp, _i]),
     "zkh_session_set_streamed_fold": (None, [_vp, _i]),
+    "zkh_session_set_witness_source": (_err, [_vp, _i, _sz]),
     "zkh_session_set_recursion": (_err, [_vp, _u32p, _sz, C.POINTER(_u32p), C.POINTER(_sz), _u32p, _sz]),
     "zkh_session_prove": (_err, [_vp, C.POINTER(SegmentSpec), _sz, _i, _sz, _u64, C.POINTER(ProveInfo)]),
     "zkh_prove_info_free": (None, [C.POINTER(ProveInfo)]),
@@ -386,6 +391,19 @@ class RecProgram:
         words = np.ctypeslib.as_array(seal, shape=(n.value,)).copy()
         _lib.zkh_free_seal(seal)
         return words, out
+
+
+def syn_preflight(seed: int, po2: int, zk_cycles: int = ZK_CYCLES, records: Optional[np.ndarray] = None):
+    """The sequential host machine (csrc/preflight.hip): -> (records: 4 words per active cycle, RAM image, CPU seconds).
+    `records` may be a pinned view from HipHal.host_alloc (filled in place)."""
+    load_library()
+    A = (1 << po2) - zk_cycles
+    rec = records if records is not None else np.empty(4 * A, dtype=np.uint32)
+    assert rec.size == 4 * A and rec.dtype == np.uint32
+    ram = np.empty(int(_lib.zkh_syn_preflight_ram_words()), dtype=np.uint32)
+    secs = C.c_double(0.0)
+    _check(_lib.zkh_syn_preflight(seed & (2**64 - 1), po2, zk_cycles, _ptr(rec), _ptr(ram), C.byref(secs)))
+    return rec, ram, secs.value
 
 
 # ---- host placement (csrc/topology.hip) ----
@@ -650,6 +668,15 @@ class HipHal:
             raise HalError(f"syn_witgen: circuit takes {out_size - 4} public input words, got {p.size}")
         _check(_lib.zkh_syn_witgen(self.ctx, circuit.h, po2, zk_cycles, seed & (2**64 - 1), noise_seed & (2**64 - 1),
                                    _ptr(p) if p.size else None, code.h if code is not None else None, data.h, _ptr(out)))
+        return out
+
+    def syn_witgen_trace(self, circuit: Circuit, po2: int, zk_cycles: int, noise_seed: int, records: Buffer, ram_image, code: Optional[Buffer],
+                         data: Buffer) -> np.ndarray:
+        """records (device, 4 words per active cycle) + the RAM image -> code (None: already held), data; returns the out globals"""
+        out = np.zeros(int(circuit.desc[7]), dtype=np.uint32)
+        ram = _u32(ram_image) if ram_image is not None else None
+        _check(_lib.zkh_syn_witgen_trace(self.ctx, circuit.h, po2, zk_cycles, noise_seed & (2**64 - 1), records.h, _ptr(ram) if ram is not None else None,
+                                         code.h if code is not None else None, data.h, _ptr(out)))
         return out
 
     def syn_accum(self, circuit: Circuit, po2: int, zk_cycles: int, noise_seed: int, data: Buffer, mix_global, accum: Buffer) -> None:

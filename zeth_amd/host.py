@@ -208,6 +208,12 @@ class Session:
         the fold back until the last segment is sealed (two phases).  Same tree, same receipts."""
         self._hal._lib.zkh_session_set_streamed_fold(self.h, int(on))
 
+    def set_witness_source(self, source: int, producers_per_lane: int = 0) -> None:
+        """0: closed-form witness generators on the device (default).  1: a sequential host preflight per segment runs ahead of the
+        seals on `producers_per_lane` host threads per lane (0 = 2); its compact per-cycle records (16 bytes per cycle) are uploaded
+        from pinned memory and expanded by the GPU row-fill kernel (csrc/preflight.hip) — upstream's preflight -> witgen shape."""
+        self._hal._check(self._hal._lib.zkh_session_set_witness_source(self.h, int(source), int(producers_per_lane)))
+
     def set_resident_code(self, on: bool) -> None:
         """built-in circuits: keep the committed code group of each segment size resident per lane (default) or re-commit it per
         segment like upstream's SegmentProver.  Seals are byte-identical."""
@@ -259,7 +265,7 @@ class Session:
                      "n_lifts": int(info.n_lifts), "lift_s": info.lift_s, "root_program": int(info.root_program),
                      "witgen_s_sum": info.witgen_s_sum, "seal_s_sum": info.seal_s_sum, "verified": bool(verify),
                      "n_retries": int(info.n_retries), "fold_tail_s": info.fold_tail_s, "fold_busy_s_sum": info.fold_busy_s_sum,
-                     "streamed_fold": bool(info.streamed)}
+                     "streamed_fold": bool(info.streamed), "preflight_cpu_s_sum": info.preflight_cpu_s_sum, "trace_bytes": info.trace_bytes}
             return CompositeReceipt(recs), root, stats
         finally:
             self._hal._lib.zkh_prove_info_free(C.byref(info))
