@@ -355,6 +355,8 @@ def test_poseidon2_tables_are_the_output_of_the_published_procedure():
     txt = open(os.path.join(ROOT, "include", "zkh_poseidon2_consts.h")).read()
     nums = [int(x, 16) for x in re.findall(r"0x([0-9a-f]{8})u", txt)]
     assert nums[:24] == diag and nums[24:] == rc
+    from zeth_amd.circuits import poseidon2_consts as pc          # the package's own copy (no dependency on include/ at import time)
+    assert pc.M_INT_DIAG == diag and pc.ROUND_CONSTANTS == rc
     assert "#define ZKH_P2_CONSTS_ARE_PLACEHOLDER 0" in txt and "#define ZKH_P2_CONSTS_ARE_DERIVED 1" in txt
     # the routines the acceptance test stands on
     assert gen.irreducible([11, 0, 0, 0, 1])                      # x^4 + 11: the prover's extension field

@@ -249,6 +249,21 @@ def main():
             f.write("    " + ", ".join("0x%08xu" % d for d in rc[i:i + 8]) + ",\n")
         f.write("};\n#endif\n")
     print("wrote", os.path.normpath(out))
+    # the same tables as a Python module INSIDE the package (circuits/p2_join.py, circuits/recursion.py put the constants into
+    # their code groups): an installed zeth_amd must not depend on the repository's include/ directory being next to it
+    py = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "zeth_amd", "circuits", "poseidon2_consts.py")
+    with open(py, "w") as f:
+        f.write('"""GENERATED by tools/gen_poseidon2_consts.py together with include/zkh_poseidon2_consts.h (same run, same values; a CPU test\n'
+                'compares the two word for word): Poseidon2 (BabyBear, t = 24, x^7, R_F = 8, R_P = 21) tables, canonical residues.\n'
+                'ROUND_CONSTANTS[round * 24 + cell]; partial rounds (4..24) only have cell 0.  Provenance: DERIVED (see the header)."""\n')
+        f.write("M_INT_DIAG = [\n")
+        for i in range(0, 24, 8):
+            f.write("    " + ", ".join("0x%08x" % d for d in diag[i:i + 8]) + ",\n")
+        f.write("]\nROUND_CONSTANTS = [\n")
+        for i in range(0, 24 * 29, 8):
+            f.write("    " + ", ".join("0x%08x" % d for d in rc[i:i + 8]) + ",\n")
+        f.write("]\n")
+    print("wrote", os.path.normpath(py))
 
 
 if __name__ == "__main__":

@@ -46,15 +46,10 @@ RINV = pow(R, -1, P)
 
 
 def shipped_tables():
-    """(rc[24 * 29], diag[24]) canonical residues from include/zkh_poseidon2_consts.h."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "include", "zkh_poseidon2_consts.h")
-    src = open(path).read()
-
-    def arr(name):
-        body = src[src.index(name):]
-        body = body[body.index("{") + 1:body.index("}")]
-        return [int(x.rstrip("u"), 16) for x in re.findall(r"0x[0-9a-fA-F]+u?", body)]
-    return arr("ZKH_P2_ROUND_CONSTANTS"), arr("ZKH_P2_M_INT_DIAG")
+    """(rc[24 * 29], diag[24]) canonical residues: circuits/poseidon2_consts.py, generated in the same run as
+    include/zkh_poseidon2_consts.h (tests/test_abi_and_host.py compares the two word for word)."""
+    from . import poseidon2_consts as pc
+    return list(pc.ROUND_CONSTANTS), list(pc.M_INT_DIAG)
 
 
 RC, DIAG = shipped_tables()

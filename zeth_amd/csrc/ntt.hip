@@ -600,8 +600,14 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
     // instructions (934 -> 796 per wave) but doubles its loads, and the pass is as much memory- as VALU-limited (2.16 -> 2.31 ms
     // for 208 x 2^22; walking the columns of a tile first so that the matrix tile stays in L2 makes every concurrent block
     // hit the same in-column offsets: 3.11 ms).  Kept behind ZKH_NTT_MATRIX=1 / ZKH_NTT_COLFAST=1 so the A/B can be re-run.
+    // The rejected variants are compiled only into experiment builds (ZKH_BUILD_FLAGS=-DZKH_NTT_EXPERIMENTS): the shipped library
+    // carries neither their template instantiations nor their switches; profiles/r03_ntt_matrix.txt and r03_ntt_ab*.jsonl are the record.
+#ifdef ZKH_NTT_EXPERIMENTS
     static const bool use_matrix = getenv("ZKH_NTT_MATRIX") != nullptr;
     static const bool no_colfast = getenv("ZKH_NTT_COLFAST") == nullptr;
+#else
+    constexpr bool use_matrix = false, no_colfast = true;
+#endif
     const int32_t* fwd_matrix = nullptr;
     if (lazy && use_matrix && (n >> (passes[1].R + 4)) % 8 == 0) {
         const uint32_t key = (log_n << 8) | expand_bits;
@@ -635,7 +641,11 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
         // the generic kernel on a strided pass: 4096-element tiles, i.e. runs of 2^(12 - R) consecutive words (a 1..3-bit top pass
         // at 2^21 / 2^23 / 2^24 then streams 2..8 KiB runs; with 16-word runs it moved 64 elements per workgroup: 0.6 TB/s)
         if (ps.L != 0 && !reg_high && ps.R < 12) p.log_t = std::max<uint32_t>(p.log_t, std::min<uint32_t>(ps.L, 12 - ps.R));
+#ifdef ZKH_NTT_EXPERIMENTS
         static const bool narrow = getenv("ZKH_NTT_NARROW") != nullptr;        // A/B: 32-byte runs, 512-lane workgroups (profiles/r03_ntt_matrix.txt)
+#else
+        constexpr bool narrow = false;
+#endif
         const bool narrow_here = narrow && lazy && reg_high && ps.R == 10 && !fwd_matrix;
         if (narrow_here) p.log_t = 3;
         // keep the tile <= 64 KiB
@@ -683,13 +693,17 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
             else k_ntt_low12<false><<<grid, 256, 0, c->stream>>>(p);
         } else if (ps.L >= 4 && (p.log_t == 4 || narrow_here) && ps.R == 10 && !(scale_here && p.zk_shift)) {
             if (inverse) k_ntt_high<10, true><<<grid, 1024, lds, c->stream>>>(p);
+#ifdef ZKH_NTT_EXPERIMENTS
             else if (lazy && p.tw_matrix) k_ntt_high<10, false, true, true><<<grid, 1024, lds, c->stream>>>(p);
             else if (narrow_here) k_ntt_high<10, false, true, false, 3><<<grid, 512, lds, c->stream>>>(p);
+#endif
             else if (lazy) k_ntt_high<10, false, true><<<grid, 1024, lds, c->stream>>>(p);
             else k_ntt_high<10, false><<<grid, 1024, lds, c->stream>>>(p);
         } else if (ps.L >= 4 && p.log_t == 4 && ps.R == 8 && !(scale_here && p.zk_shift)) {
             if (inverse) k_ntt_high<8, true><<<grid, 256, lds, c->stream>>>(p);
+#ifdef ZKH_NTT_EXPERIMENTS
             else if (lazy && p.tw_matrix) k_ntt_high<8, false, true, true><<<grid, 256, lds, c->stream>>>(p);
+#endif
             else if (lazy) k_ntt_high<8, false, true><<<grid, 256, lds, c->stream>>>(p);
             else k_ntt_high<8, false><<<grid, 256, lds, c->stream>>>(p);
         } else if (inverse) k_ntt_pass<true><<<grid, NTT_THREADS, lds, c->stream>>>(p);
@@ -708,7 +722,9 @@ const char* zkh::ntt_device_init(zkh_ctx* c) {
     ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high<10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high<10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high<10, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+#ifdef ZKH_NTT_EXPERIMENTS
     ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high<10, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+#endif
     return nullptr;
 }
 
