@@ -140,10 +140,10 @@ def cpu_baseline(desc, circuit_name: str, cpus=None) -> dict:
                    "never a target and never a quotable speed-up",
            "seal_words": int(seal.size)}
     # ---- the whole host: P = floor(cores / best) processes, `best` threads each, disjoint core blocks, distinct segments ----
-    # (a bounded sample: the seals of this leg are a quarter of the unit each — with every core busy the memory-bound oracle runs
-    # several times slower per seal than alone, and the whole command has to stay within minutes)
+    # (a bounded sample: the seals of this leg are 1/16 of the unit each — with every core busy the memory-bound oracle runs ~20 x
+    # slower per seal than alone, and the whole command has to stay within minutes)
     procs_n = max(1, avail // best)
-    full_po2 = max(probe_po2, sample_po2 - 2)
+    full_po2 = max(probe_po2, sample_po2 - 4)              # measured on the GPU box: 16 seals at once run ~20 x slower each than one alone
     full_scale = 1 << (PO2 - full_po2)
     try:
         mem_avail = next(int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable:")) * 1024
@@ -168,11 +168,11 @@ def cpu_baseline(desc, circuit_name: str, cpus=None) -> dict:
             for w in workers:
                 w.stdin.write("go\n"); w.stdin.flush()
             import select
-            times, deadline = [], time.perf_counter() + 4.0 * CPU_SAMPLE_BUDGET_S
+            times, deadline = [], time.perf_counter() + 3.0 * CPU_SAMPLE_BUDGET_S
             for w in workers:
                 left = deadline - time.perf_counter()
                 if left <= 0 or not select.select([w.stdout], [], [], left)[0]:
-                    raise TimeoutError(f"the full-host leg did not finish within {4.0 * CPU_SAMPLE_BUDGET_S:.0f} s")
+                    raise TimeoutError(f"the full-host leg did not finish within {3.0 * CPU_SAMPLE_BUDGET_S:.0f} s")
                 times.append(json.loads(w.stdout.readline())["s"])
             wall = time.perf_counter() - t0
             for w in workers:
@@ -874,12 +874,27 @@ def main() -> None:
             # session executor (zkh_session_set_witness_source(1)).  The host CPU seconds per segment are the Amdahl term of the
             # pipeline: with T producer threads it sustains min(GPU rate, T / preflight seconds).
             if not args.no_preflight_leg and args.circuit == "syn_a":
+                from zeth_amd.hal import HalError
                 from zeth_amd.host import Session
-                psess = Session(desc, devices=(device,), lanes_per_device=inflight)
-                psess.set_witness_source(1, args.preflight_producers)
-                psess.set_resident_code(not args.recompute_code)
-                pwarm = [bsegs[0]] * inflight + [bsegs[-1]]
-                psess.prove(pwarm)
+                for ln in lanes:                       # the session brings its own lanes: hand the cached pool blocks of this rank's back first
+                    ln.hal.trim()
+                psess, perr = None, None
+                try:
+                    psess = Session(desc, devices=(device,), lanes_per_device=inflight)
+                    psess.set_witness_source(1, args.preflight_producers)
+                    psess.set_resident_code(not args.recompute_code)
+                    psess.prove([bsegs[0]] * inflight + [bsegs[-1]])          # warm-up: every size once per lane
+                except HalError as e:                  # (ranks sharing ONE GPU in a dry run can run out of HBM here)
+                    perr = str(e)
+                okf = torch.tensor([0.0 if perr else 1.0], dtype=torch.float64, device=ctrl_dev)
+                if distributed:
+                    dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+                if okf.item() < 1.0:                   # every rank skips the leg together
+                    block["host_preflight_pipeline"] = {"error": perr or "another rank could not set the leg up"}
+                    if psess is not None:
+                        psess.close()
+                    psess = None
+            if not args.no_preflight_leg and args.circuit == "syn_a" and psess is not None:
                 device_sync(lanes)
                 barrier()
                 tp0 = time.perf_counter()
@@ -907,6 +922,7 @@ def main() -> None:
                             "cycle), scans the running sum and scatters the preloaded RAM image; a DIFFERENT witness than the closed-form "
                             "generator's, same circuit, seals byte-identical to the CPU oracle's (tests/test_round4_gpu.py)"}
                 psess.close()
+                del psess
             # ... and, on one GPU, the join tree over that block's receipts down to ONE root receipt (BASELINE config 5 in
             # small: P2-JOIN joins at po2 18 hash their children's claims in-circuit).  Per level the joins are independent and
             # spread over the lanes.  Afterwards the compact receipt (root + leaves, joins dropped) is verified the way a

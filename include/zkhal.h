@@ -231,7 +231,8 @@ const char* zkh_syn_accum(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cy
  * places the preloaded memory image (risc0-circuit-rv32im 4.0.2 prove/witgen, un-vendored: /root/reference/Cargo.lock:5320; the
  * guest input enters at /root/reference/crates/host/src/lib.rs:132-136).  Here the same pipeline for SYN-AIR circuits (kind 1,
  * no public inputs) with a stand-in machine: zkh_syn_preflight is the SEQUENTIAL host producer — 4 words (16 bytes) per active
- * cycle, all valid Elem words, plus the 1024-word RAM image before the first cycle — and zkh_syn_witgen_trace expands records
+ * cycle (value, operand, pc | op | rd | address, running state digest), all valid Elem words, plus the 1024-word RAM image before
+ * the first cycle — and zkh_syn_witgen_trace expands records
  * that are already on the device (zkh_write_async from pinned memory: 16.7 MB per po2-20 segment instead of the 0.94 GB full
  * trace) into the data group: one row-fill launch, the running-sum scan, the preload through zkh_scatter. ---- */
 size_t zkh_syn_preflight_ram_words(void);

@@ -9,7 +9,8 @@
  * one instruction per cycle (ADD, MUL, ADDI, LOAD, STORE, BNE over BabyBear residues).  It is inherently sequential — cycle r
  * needs the registers and memory cycle r - 1 left — which is the property of the real preflight that matters for the pipeline.
  * Per cycle it emits ONE 16-byte record: w0 = the value produced, w1 = operand b, w2 = pc | op << 8 | rd << 12 | addr << 16,
- * w3 = operand a.  All four words are < P, i.e. valid raw Elem words. */
+ * w3 = the machine's running state digest (16 dependent mixing rounds per cycle over value, address and pc) reduced mod P.
+ * All four words are < P, i.e. valid raw Elem words. */
 #include <string.h>
 
 #include "circuit.h"
@@ -45,6 +46,7 @@ void zko_syn_preflight(uint64_t seed, unsigned po2, unsigned zk, uint32_t* recor
     for (uint32_t k = 0; k < PF_REGS; k++) reg[k] = (uint32_t)(pf_next(&st) >> 32) % FP_P;
     if (ram_image) memcpy(ram_image, ram, sizeof ram);          /* the preload: RAM as it is BEFORE the first cycle */
     uint32_t pc = 0;
+    uint64_t h = st;
     for (size_t r = 0; r < A; r++) {
         const uint32_t op = prog[pc].op, rd = prog[pc].rd, a = reg[prog[pc].rs1], b = reg[prog[pc].rs2], imm = prog[pc].imm;
         uint32_t v = 0, addr = 0, next = (pc + 1) % PF_PROG;
@@ -56,7 +58,13 @@ void zko_syn_preflight(uint64_t seed, unsigned po2, unsigned zk, uint32_t* recor
         case 4: addr = (a ^ imm) & (PF_RAM - 1); ram[addr] = b; v = b; break;                  /* STORE */
         default: v = a != b; if (v) next = prog[pc].target; break;                             /* BNE  */
         }
-        records[4 * r] = v; records[4 * r + 1] = b; records[4 * r + 2] = pc | op << 8 | rd << 12 | addr << 16; records[4 * r + 3] = a;
+        /* the machine's running state digest: every cycle folds (value, address, pc) in through 16 dependent mixing rounds — the
+         * stand-in for the per-cycle bookkeeping of a real preflight (paging, memory-transaction log), and what makes a cycle cost
+         * tens of nanoseconds rather than one */
+        h ^= (uint64_t)v | (uint64_t)(addr << 8 | pc) << 32;
+        for (int k = 0; k < 16; k++) { h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; }
+        (void)a;
+        records[4 * r] = v; records[4 * r + 1] = b; records[4 * r + 2] = pc | op << 8 | rd << 12 | addr << 16; records[4 * r + 3] = (uint32_t)(h >> 33) % FP_P;
         pc = next;
     }
 }

@@ -166,7 +166,7 @@ def test_keccak_eval_check_generated_kernels_equal_interpreter_and_oracle(hal, o
     dom = 4 << po2
     rng = np.random.default_rng(5)
     P = 2013265921
-    groups = [rng.integers(0, P, size=w * dom, dtype=np.uint64).astype(np.uint32) for w in (4, 14, 3840)]
+    groups = [rng.integers(0, P, size=w * dom, dtype=np.uint64).astype(np.uint32) for w in (4, K.WC, 3840)]
     out_g = rng.integers(0, P, size=200, dtype=np.uint64).astype(np.uint32)
     mix_g = rng.integers(0, P, size=4, dtype=np.uint64).astype(np.uint32)
     pm = rng.integers(0, P, size=4, dtype=np.uint64).astype(np.uint32)

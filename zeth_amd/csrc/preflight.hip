@@ -92,6 +92,7 @@ extern "C" const char* zkh_syn_preflight(uint64_t seed, size_t po2, size_t zk_cy
     for (uint32_t k = 0; k < PF_REGS; k++) reg[k] = (uint32_t)(pf_next(st) >> 32) % P;
     if (ram_image) memcpy(ram_image, ram, sizeof ram);
     uint32_t pc = 0;
+    uint64_t h = st;
     for (size_t r = 0; r < A; r++) {
         const Ins& in = prog[pc];
         const uint32_t a = reg[in.rs1], b = reg[in.rs2];
@@ -104,8 +105,13 @@ extern "C" const char* zkh_syn_preflight(uint64_t seed, size_t po2, size_t zk_cy
         case 4: addr = (a ^ in.imm) & (PF_RAM - 1); ram[addr] = b; v = b; break;                            // STORE
         default: v = a != b; if (v) next = in.target; break;                                                 // BNE
         }
+        // the running state digest: (value, address, pc) folded in through 16 DEPENDENT mixing rounds per cycle — the stand-in for the
+        // per-cycle bookkeeping of a real preflight (paging, the memory-transaction log); it is what makes a cycle cost tens of
+        // nanoseconds of one core, i.e. what the pipeline has to hide
+        h ^= (uint64_t)v | (uint64_t)(addr << 8 | pc) << 32;
+        for (int k = 0; k < 16; k++) { h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; }
         uint32_t* rec = records + 4 * r;
-        rec[0] = v; rec[1] = b; rec[2] = pc | in.op << 8 | in.rd << 12 | addr << 16; rec[3] = a;
+        rec[0] = v; rec[1] = b; rec[2] = pc | in.op << 8 | in.rd << 12 | addr << 16; rec[3] = (uint32_t)(h >> 33) % P;
         pc = next;
     }
     if (cpu_seconds) *cpu_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
