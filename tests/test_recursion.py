@@ -284,3 +284,28 @@ def test_program_set_of_a_block_closes_at_po2_18():
     assert [len(lv) for lv in levels] == [16, 8, 4, 2, 1]
     w = host_rec.membership_words(levels, 5)
     assert w.size == 4 * 9 and [int(w[9 * i]) for i in range(4)] == [host_rec.R * b % P for b in (1, 0, 1, 0)]
+
+
+def test_shipped_program_manifest_is_what_the_builder_emits():
+    """examples/recursion_programs.manifest.json: the SHA-256 of every lift / lift2 / join program (and of the RECURSION circuit
+    description) a non-Python host loads for a SYN-A block (`python -m zeth_amd.circuits.rec_verify DIR`, control roots from
+    circuits/control_roots.json).  Rebuilding the set from the tree must give exactly these files: the g++ host
+    (examples/prove_session --recursion-dir) is reproducible from the repository alone."""
+    import hashlib
+    import json
+    import os
+    from zeth_amd import recursion as host_rec
+    from zeth_amd.prover import shipped_control_root
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    man = json.load(open(os.path.join(root, "examples", "recursion_programs.manifest.json")))
+    desc = syn_air.syn_a()
+    roots = {po2: shipped_control_root(desc, po2) for po2 in (20, 18)}
+    assert all(r is not None for r in roots.values())
+    assert {p: [int(w) for w in r] for p, r in roots.items()} == {int(k): v for k, v in man["segment_control_roots"].items()}
+    built = {}
+    for kind, blob in host_rec.build_programs(desc, roots):
+        name = "-".join(str(x) for x in kind[:2 if kind[0] == "lift" else 3]) + ".zkr1"
+        built[name] = {"words": int(blob.size), "po2": int(blob[2]), "sha256": hashlib.sha256(np.asarray(blob, dtype="<u4").tobytes()).hexdigest()}
+    rdesc = np.asarray(R.recursion_circuit(), dtype="<u4")
+    built["recursion.desc"] = {"words": int(rdesc.size), "sha256": hashlib.sha256(rdesc.tobytes()).hexdigest()}
+    assert built == man["files"]

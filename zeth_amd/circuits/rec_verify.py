@@ -487,7 +487,20 @@ if __name__ == "__main__":      # python -m zeth_amd.circuits.rec_verify out_dir
     roots = {po2: shipped_control_root(desc, po2) for po2 in (20, 18)}
     if any(r is None for r in roots.values()):
         raise SystemExit("no shipped control root for SYN-A at po2 20 / 18 (python -m zeth_amd.prover on a GPU box)")
+    import hashlib
+    import json
+    manifest = {}
     for kind, blob in host_rec.build_programs(desc, roots):
-        path = os.path.join(out_dir, "-".join(str(x) for x in kind[:2 if kind[0] == "lift" else 3]) + ".zkr1")
+        name = "-".join(str(x) for x in kind[:2 if kind[0] == "lift" else 3]) + ".zkr1"
+        path = os.path.join(out_dir, name)
         np.asarray(blob, dtype="<u4").tofile(path)
+        manifest[name] = {"words": int(blob.size), "po2": int(blob[2]), "sha256": hashlib.sha256(np.asarray(blob, dtype="<u4").tobytes()).hexdigest()}
         print(f"{path}: {blob.size} words, po2 {int(blob[2])}")
+    # the manifest a non-Python host checks its program files against (committed: examples/recursion_programs.manifest.json;
+    # tests/test_recursion.py rebuilds the set and compares) — upstream ships its lift / join programs as hashed .zkr files too
+    from . import recursion as rcirc
+    rdesc = np.asarray(rcirc.recursion_circuit(), dtype="<u4")
+    manifest["recursion.desc"] = {"words": int(rdesc.size), "sha256": hashlib.sha256(rdesc.tobytes()).hexdigest()}
+    with open(os.path.join(out_dir, "manifest.json"), "w") as fh:
+        json.dump({"generator": "python -m zeth_amd.circuits.rec_verify <dir> (SYN-A segments at po2 20 / 18, control roots from circuits/control_roots.json)",
+                   "segment_control_roots": {str(p): [int(w) for w in r] for p, r in roots.items()}, "files": manifest}, fh, indent=1)
