@@ -1,4 +1,4 @@
-"""The driver's contract for bench.py, checked on the committed line of the last GPU run (profiles/r03_bench_default.json): the
+"""The driver's contract for bench.py, checked on the committed lines of the last GPU runs (profiles/r04_*.json): the
 one JSON line carries BASELINE.json's metric with every field the contract names, a roofline object for the dominant kernel and
 a CPU baseline; and the command line still parses the driver's flags.  (No GPU: the line is a committed measurement.)"""
 import json
@@ -15,35 +15,68 @@ def _line(name):
 
 
 def test_default_line_has_every_contract_field():
-    l = _line("r03_bench_default.json")
+    l = _line("r04_bench_default.json")
     assert l["metric"] == "segments/sec" and l["unit"] == "segments/s" and l["higher_is_better"] is True
-    assert l["n_gpus"] == 1 and l["steps"] == 30 and l["warmup"] == 2 and l["scaling"] == "weak" and l["data"] == "synthetic"
+    assert l["n_gpus"] == 1 and l["steps"] == 60 and l["warmup"] == 2 and l["scaling"] == "weak" and l["data"] == "synthetic"
     assert l["vs_baseline"] is None and l["dtype"] == "u32"                      # BASELINE.md publishes no number for this metric
     assert abs(l["value"] - 1e3 / l["ms_per_step"]) / l["value"] < 1e-6 and "workload" in l["config"] and "model" not in l["config"]
+    assert l["steps"] * l["ms_per_step"] >= 1400.0                               # the timed region is at least 1.4 s
     r = l["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] > 0 and r["kernel"] == "hash_rows"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["kernel"] == "hash_rows"
+    assert 0.99 < r["traffic"] / r["alg_bytes_per_launch"] < 1.01 and "measured in this run" in r["traffic_source"]
     c = l["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "segments/s" and c["sample"]
+    # both CPU figures: one seal alone, and the whole host busy (>= 90 % of the cores)
+    assert c["single_seal"]["value"] > 0 and c["full_host"]["cores"] >= 0.9 * c["cores_available"] and c["full_host"]["value"] > 0
+    assert c["value"] == max(c["single_seal"]["value"], c["full_host"]["value"])
     # the line certifies its own work, and folds a block to one receipt both ways
-    assert l["timed_seals_verified"] == 30 and l["seal_matches_golden"] is True
+    assert l["timed_seals_verified"] == 60 and l["seal_matches_golden"] is True
     b = l["block"]
     assert b["verified_after_clock"] == b["segments"] == 64 and b["succinct"]["compact_receipt_verified"] is True
     assert b["recursive"]["root_verified_against_leaf_claims"] is True and b["recursive"]["proofs"] == 63
+    assert "resident" in b["code_group"] and b["recompute_code_group"]["segments_per_s"] > 0
+    assert l["block_wall_clock_s"] == b["wall_clock_s"] and l["block_segments_per_s"] == b["segments_per_s"]
+    # row f1: the host-preflight pipeline, with the Amdahl term and the PCIe bytes in the line
+    p = b["host_preflight_pipeline"]
+    assert p["segments_per_s"] >= 41.0 and p["verified_after_clock"] == 64 and p["host_preflight_cpu_ms_per_segment"] > 1.0
+    assert p["pcie_bytes_per_segment"] < 0.02 * p["full_trace_bytes_per_segment"]
+    assert "numa_node" in l["config"]["host_placement_rank0"]
 
 
-def test_config5_line_is_the_in_circuit_fold():
-    l = _line("r03_bench_succinct_recursion.json")
+def test_eight_rank_line_is_contract_complete():
+    """The driver's multi-GPU command, dry-run as 8 ranks on ONE GPU (ZKH_SHARE_GPUS=1): a SCALE line shaped like this must not
+    come back unmeasured — roofline with a non-zero fraction and measured traffic, a CPU baseline, the strong-scaling block leg."""
+    l = _line("r04_8rank_one_gpu.json")
+    assert l["n_gpus"] == 8 and l["scaling"] == "weak" and l["timed_seals_verified"] == 8 * l["steps"] and l["seal_matches_golden"] is True
+    r = l["roofline"]
+    assert r["frac"] > 0 and r["alg_bytes_per_launch"] > 0 and r["traffic"] is not None and r["traffic"] > 0 and r["kernel"] == "hash_rows"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = l["cpu_baseline"]
+    assert c["value"] > 0 and c["cores"] >= 1 and c["kind"] == "port" and c["sample"]
+    b = l["block"]
+    assert b["segments"] == 256 == b["verified_after_clock"] and l["block_wall_clock_s"] > 0 and l["block_segments_per_s"] > 0
+    assert b["host_preflight_pipeline"]["verified_after_clock"] == 256
+
+
+def test_config5_line_is_the_streamed_in_circuit_fold():
+    l = _line("r04_bench_succinct_streamed.json")
     r = l["recursion"]
     assert l["steps"] == 1024 and l["succinct_root_follows_from_leaf_claims"] is True and "recursion" in l["config"]["join_circuit"]
     assert r["fused_lift2"] == 512 and r["joins"] == 511 and r["proofs"] == 1023 and l["verified_after_clock"] >= 1025
-    assert abs(l["block_wall_clock_s"] - (l["leaf_phase_s"] + r["fold_s"])) < 0.5
+    assert r["streamed_fold"] is True and r["fold_tail_s"] < 0.5 and "native" in r["executor"]
+    two = _line("r04_bench_succinct_phased.json")
+    assert two["recursion"]["streamed_fold"] is False and two["recursion"]["fold_tail_s"] > 3.0
+    assert l["block_wall_clock_s"] < two["block_wall_clock_s"] < 27.8                   # round 3: 27.8 s
+    host = _line("r04_prove_session_recursion_1024_streamed.json")                       # the g++ host, no Python in the process
+    assert host["wall_s"] <= 26.0 and host["streamed_fold"] is True and host["verified"] is True and host["joins"] == 511
 
 
 def test_bench_accepts_the_drivers_flags():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0
-    for flag in ("--gpus", "--steps", "--warmup", "--config", "--join-circuit", "--fold-inflight", "--no-fused-lift"):
+    for flag in ("--gpus", "--steps", "--warmup", "--config", "--join-circuit", "--fold-inflight", "--no-fused-lift", "--fold", "--executor",
+                 "--recompute-code", "--no-preflight-leg"):
         assert flag in out.stdout, flag
 
 
