@@ -225,6 +225,12 @@ const char* zkh_syn_witgen(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_c
                            uint64_t noise_seed, const uint32_t* pub, zkh_buf* code, zkh_buf* data, uint32_t* out_global);
 const char* zkh_syn_accum(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cycles, uint64_t noise_seed,
                           const zkh_buf* data, const uint32_t* mix_global, zkh_buf* accum);
+/* Chained sessions (SYN-C: a kind-1 circuit with ONE public input = the segment's pre-state; out = (post, 0, 0, 0, pre)): what each
+ * of n segments (seed, po2) adds to the running state — its post-state when started from state 0 — in one launch.  The executor's
+ * part: with these a host fixes every segment's pre-state before any segment is proven (upstream's executor fixes
+ * ReceiptClaim.pre / .post the same way), which keeps the segments independent for the provers. */
+const char* zkh_syn_chain_contributions(zkh_ctx*, const zkh_circuit*, const uint64_t* seeds, const uint32_t* po2s, size_t n,
+                                        size_t zk_cycles, uint32_t* contributions);
 
 /* ---- trace-driven witness (csrc/preflight.hip).  Upstream: the rv32im preflight replays a segment's cycles
  * on one host thread into per-cycle records, witgen kernels fill the trace rows from them (one lane per cycle) and Hal::scatter
@@ -402,6 +408,11 @@ const char* zkh_session_set_recursion(zkh_session*, const uint32_t* rec_desc, si
  * the sealing lanes are still busy with segments, on every lane afterwards (upstream joins as receipts arrive too).  on = 0: two
  * phases (seal everything, then fold).  Same tree, same receipts either way. */
 void zkh_session_set_streamed_fold(zkh_session*, int on);
+/* Chained session (SYN-C circuits): zkh_session_prove runs the executor's pass first (zkh_syn_chain_contributions), gives segment i
+ * the pre-state initial + sum of the contributions of segments 0 .. i-1 as its public input (any `pub` of the caller is replaced),
+ * and zkh_session_verify additionally checks CONTINUITY on the seals: the first segment starts from initial_state (canonical
+ * residue), every segment's pre-state (out[4]) is its predecessor's post-state (out[0]) — `CompositeReceipt::verify_integrity`. */
+const char* zkh_session_set_chained(zkh_session*, int on, uint32_t initial_state);
 /* Where a segment's witness comes from (SYN-AIR circuits without public inputs).  0 (default): the closed-form generator on the
  * device (zkh_syn_witgen).  1: upstream's shape — a SEQUENTIAL host preflight per segment (zkh_syn_preflight) running ahead of the
  * seals on `producers_per_lane` host threads per sealing lane (0 = 2), its compact records (16 bytes per cycle) uploaded from pinned

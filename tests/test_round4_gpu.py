@@ -240,3 +240,40 @@ def test_combos_prepare_regs_takes_any_register_size_and_refuses_inconsistent_li
         call([0] + list(sizes[1:]), ids, coeff_u.size)
     with pytest.raises(HalError, match="names combo"):
         call(sizes, [combo_count] + list(ids[1:]), coeff_u.size)
+
+
+def test_chained_session_on_the_gpu(hal, oracle):
+    """Claim continuity through the native session executor: zkh_session_set_chained runs the executor's pass on the GPU (one launch:
+    every segment's contribution to the running state), proves each segment with its pre-state as public input, and
+    zkh_session_verify checks pre == prev.post on the seals.  Seals equal the oracle's for the same pre-states; the Python
+    CompositeReceipt check agrees; a session started from another state is a different, equally continuous session."""
+    import zko
+    from zeth_amd.circuits.syn_air import syn_chain_small
+    from zeth_amd.hal import P, fp_encode
+    from zeth_amd.host import Session, chain_segments
+    from zeth_amd.prover import Segment, SegmentProver
+    desc = syn_chain_small()
+    oc = zko.OracleCircuit(oracle, desc)
+    sp = SegmentProver(hal, desc)
+    segs = [Segment(index=i, po2=13 if i != 2 else 12, seed=1500 + i, noise_seed=0x54) for i in range(5)]
+    # the executor's pass: GPU contributions equal the oracle's
+    contrib = [sp.chain_contribution(s) for s in segs]
+    for s, c in zip(segs, contrib):
+        assert c == int(oc.witgen(s.po2, 1994, s.seed, s.noise_seed, pub=np.zeros(1, np.uint32))[2][0])
+    want = chain_segments(segs, lambda s: contrib[s.index], initial_state=7)
+    sess = Session(desc, devices=(0,), lanes_per_device=2)
+    sess.set_chained(True, 7)
+    comp, _, st = sess.prove(segs, verify=True)
+    roots = {p: sp.control_root(p) for p in (12, 13)}
+    comp.verify(desc, roots, chained=True, initial_state=7)
+    for s, r in zip(want, comp.segments):
+        assert int(r.seal[4]) == s.pub[0]
+        assert np.array_equal(r.seal, oc.prove(s.po2, 1994, s.seed, s.noise_seed, pub=np.asarray(s.pub, dtype=np.uint32)))
+    assert comp.final_state() == (fp_encode(7) + sum(contrib)) % P
+    with pytest.raises(ValueError, match="not continuous"):
+        comp.verify(desc, roots, chained=True, initial_state=0)
+    sess.set_chained(True, 0)
+    comp0, _, _ = sess.prove(segs, verify=True)
+    comp0.verify(desc, roots, chained=True, initial_state=0)
+    assert comp0.final_state() == sum(contrib) % P and not np.array_equal(comp0.segments[0].seal, comp.segments[0].seal)
+    sess.close()

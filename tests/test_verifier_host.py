@@ -115,3 +115,55 @@ def test_receipt_container_roundtrip_and_integrity(oracle):
     forged[-2], forged[-1] = h & 0xFFFFFFFF, h >> 32
     with pytest.raises(HalError, match="claim digest"):
         hc.receipt_decode(forged)
+
+
+def test_chained_session_is_continuous_and_tampering_breaks_the_chain(oracle):
+    """Claim continuity (SYN-C: SYN-A's family with the segment's pre-state as its one public input; out = (post, 0, 0, 0, pre)).
+    The executor's pass fixes every segment's pre-state, the segments are proven independently (here by the oracle), and
+    `CompositeReceipt.verify(chained=True)` — upstream's verify_integrity: pre == prev.post — accepts the session; a receipt
+    taken out, two receipts swapped, a receipt of another session spliced in, or a wrong initial state are refused."""
+    import zko
+    from dataclasses import replace
+    from zeth_amd.circuits import syn_air
+    from zeth_amd.hal import P, fp_encode
+    from zeth_amd.host import CompositeReceipt, chain_segments
+    from zeth_amd.prover import Segment, SegmentReceipt
+    desc = syn_air.syn_chain_small()
+    oc = zko.OracleCircuit(oracle, desc)
+    po2, zk = 12, 1994
+    root = oc.control_root(po2, zk)
+
+    def contribution(seg):
+        return int(oc.witgen(seg.po2, zk, seg.seed, seg.noise_seed, pub=np.zeros(1, np.uint32))[2][0])
+
+    def prove(seg):
+        seal = oc.prove(seg.po2, zk, seg.seed, seg.noise_seed, pub=np.asarray(seg.pub, dtype=np.uint32))
+        return SegmentReceipt(seal=seal, index=seg.index, po2=seg.po2, output=seal[:5].copy())
+    base = [Segment(index=i, po2=po2, seed=700 + i, noise_seed=0x61) for i in range(4)]
+    chained = chain_segments(base, contribution, initial_state=7)
+    assert chained[0].pub == (fp_encode(7),) and all(len(s.pub) == 1 for s in chained)
+    recs = [prove(s) for s in chained]
+    comp = CompositeReceipt(recs)
+    comp.verify(desc, root, chained=True, initial_state=7)
+    # the chain really is the running sum: post(i) = pre(i) + contribution(i), and the last post is the session's final state
+    for s, r in zip(chained, recs):
+        assert int(r.seal[4]) == s.pub[0] and int(r.seal[0]) == (s.pub[0] + contribution(s)) % P
+    assert comp.final_state() == int(recs[-1].seal[0])
+    with pytest.raises(ValueError, match="not continuous"):
+        comp.verify(desc, root, chained=True, initial_state=8)                      # wrong initial state
+    swapped = [replace(recs[0]), replace(recs[2], index=1), replace(recs[1], index=2), replace(recs[3])]
+    with pytest.raises(ValueError, match="not continuous"):
+        CompositeReceipt(swapped).verify(desc, root, chained=True, initial_state=7)
+    other = prove(chain_segments([Segment(index=0, po2=po2, seed=999, noise_seed=0x61)], contribution, initial_state=7)[0])
+    spliced = [recs[0], replace(other, index=1), recs[2], recs[3]]
+    with pytest.raises(ValueError, match="not continuous"):
+        CompositeReceipt(spliced).verify(desc, root, chained=True, initial_state=7)
+    with pytest.raises(ValueError, match="missing or unordered"):
+        CompositeReceipt([recs[0], recs[2], recs[3]]).verify(desc, root, chained=True, initial_state=7)
+    # without the chain check the same receipts are individually valid: continuity is a property of the SESSION
+    CompositeReceipt(swapped).verify(desc, root)
+    # and a forged pre-state inside a seal is refused by the seal verification itself (the state words are bound public inputs)
+    forged = recs[1].seal.copy()
+    forged[4] = recs[0].seal[4]
+    with pytest.raises(Exception):
+        SegmentReceipt(seal=forged, index=1, po2=po2, output=forged[:5].copy()).verify(desc, root)

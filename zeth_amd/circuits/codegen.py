@@ -929,6 +929,7 @@ def shipped() -> Dict[str, np.ndarray]:
         SHIPPED["syn_small"] = syn_air.syn_small()
         SHIPPED["syn_tiny"] = syn_air.syn_tiny()
         SHIPPED["syn_join"] = syn_air.syn_join()
+        SHIPPED["syn_chain"] = syn_air.syn_chain()
         SHIPPED["syn_heavy"] = syn_heavy.syn_heavy()
         from . import keccak_f
         SHIPPED["keccak_f"] = keccak_f.keccak_f_circuit()

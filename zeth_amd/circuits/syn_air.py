@@ -108,6 +108,22 @@ def syn_small() -> np.ndarray:
     return build_syn_air(8, 20, 8)
 
 
+def syn_chain() -> np.ndarray:
+    """SYN-C: SYN-A with ONE public input — the segment's PRE-STATE.  out = (post, 0, 0, 0, pre): `pre` sits in row 0 of data
+    column 0 and is bound to out[4] by the `first`-gated public-input constraint; the running sum starts there (s[0] = d0[0] =
+    pre) and ends in out[0] = post = pre + (the segment's own contribution).  Two consecutive segments of a session are
+    CONTINUOUS when post(i) = pre(i + 1): what upstream's `ReceiptClaim{pre, post}` carries and `CompositeReceipt::verify_integrity`
+    checks (risc0-zkvm 3.0.3, un-vendored; reached from /root/reference/crates/host/src/bin/cli.rs:103).  Same code group as
+    SYN-A (the control columns do not depend on the number of public inputs), hence the same control roots."""
+    return build_syn_air(16, 208, 32, n_pub=1)
+
+
+def syn_chain_small() -> np.ndarray:
+    """the same at SYN-small's widths (tests)"""
+    return build_syn_air(8, 20, 8, n_pub=1)
+
+
+CHAIN_PRE, CHAIN_POST = 4, 0      # positions of the pre / post state words in a SYN-C seal's `out` header
 JOIN_PUB_WORDS = 16      # two child claim digests (8 words each)
 
 
@@ -121,6 +137,6 @@ def syn_join() -> np.ndarray:
 if __name__ == "__main__":      # python -m zeth_amd.circuits.syn_air syn_a out.desc  (blob for non-Python hosts)
     import sys
     shape, path = sys.argv[1], sys.argv[2]
-    blob = {"syn_a": syn_a, "syn_tiny": syn_tiny, "syn_small": syn_small, "syn_join": syn_join}[shape]()
+    blob = {"syn_a": syn_a, "syn_tiny": syn_tiny, "syn_small": syn_small, "syn_join": syn_join, "syn_chain": syn_chain}[shape]()
     np.asarray(blob, dtype="<u4").tofile(path)
     print(f"{path}: {blob.size} words")

@@ -156,6 +156,27 @@ __global__ void k_syn_data(uint32_t* data, uint32_t wd, uint32_t n, uint32_t A, 
     const uint32_t inc = r == 0 ? d0 : add_mod(d0, mul_mod(mul_mod(R2, r), d1));
     data[(size_t)(wd - 1) * n + r] = inc;
 }
+// Chained sessions (SYN-C, circuits/syn_air.py syn_chain): what segment i adds to the running state = sum over its active rows
+// r >= 1 of d0[r] + r d1[r] (row 0 holds the pre-state itself).  One workgroup per segment; the executor's pass of a session.
+__global__ __launch_bounds__(1024) void k_syn_chain_contrib(uint32_t* out, const uint64_t* __restrict__ seeds, const uint32_t* __restrict__ po2s,
+                                                            uint32_t zk_cycles) {
+    __shared__ uint32_t part[1024];
+    const uint32_t i = blockIdx.x, t = threadIdx.x;
+    const uint64_t seed = seeds[i];
+    const uint32_t A = (1u << po2s[i]) - zk_cycles;
+    uint32_t acc = 0;
+    for (uint32_t r = 1 + t; r < A; r += 1024) {
+        const uint32_t d0 = syn_cell(seed, GROUP_DATA, 0, r), d1 = syn_cell(seed, GROUP_DATA, 1, r);
+        acc = add_mod(acc, add_mod(d0, mul_mod(mul_mod(R2, r), d1)));
+    }
+    part[t] = acc;
+    __syncthreads();
+    for (uint32_t d = 512; d >= 1; d >>= 1) {
+        if (t < d) part[t] = add_mod(part[t], part[t + d]);
+        __syncthreads();
+    }
+    if (t == 0) out[i] = part[0];
+}
 // inclusive prefix sum (mod P) of the first A words of a column, three-level: per-1024-chunk scans + chunk totals,
 // scan of the totals (one workgroup), carry add.  (witgen, reported separately from the seal)
 __global__ __launch_bounds__(1024) void k_prefix_sum_chunks(uint32_t* col, uint32_t A, uint32_t* totals) {
@@ -809,6 +830,20 @@ extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t
     out_global[1] = out_global[2] = out_global[3] = 0;
     for (uint32_t k = 0; k < n_pub; k++) out_global[4 + k] = pub[k];
     return zkh_read(ctx, last, out_global, 0, 1);
+}
+extern "C" const char* zkh_syn_chain_contributions(zkh_ctx* ctx, const zkh_circuit* c, const uint64_t* seeds, const uint32_t* po2s, size_t n,
+                                                   size_t zk_cycles, uint32_t* contributions) {
+    ZKH_REQUIRE(ctx && c && seeds && po2s && contributions, "syn_chain_contributions: null argument");
+    ZKH_REQUIRE(c->kind == 1 && c->global_size[GLOBAL_OUT] == 5, "syn_chain_contributions: the circuit is not a SYN-C circuit (kind 1 with one public input)");
+    if (!n) return nullptr;
+    for (size_t i = 0; i < n; i++) ZKH_REQUIRE(po2s[i] >= 1 && po2s[i] <= 24 && ((size_t)1 << po2s[i]) > zk_cycles + 1, "syn_chain_contributions: segment %zu: po2 out of range", i);
+    Tmp dseeds, dpo2, dout;
+    ZKH_TRY(zkh_copy_from(ctx, "chain_seeds", (const uint32_t*)seeds, 2 * n, dseeds.out()));
+    ZKH_TRY(zkh_copy_from(ctx, "chain_po2", po2s, n, dpo2.out()));
+    ZKH_TRY(new_buf(ctx, n, false, dout.out()));
+    k_syn_chain_contrib<<<(unsigned)n, 1024, 0, ctx->stream>>>(dout->ptr(), (const uint64_t*)dseeds->ptr(), dpo2->ptr(), (uint32_t)zk_cycles);
+    ZKH_TRY(last_launch_error("syn_chain_contrib"));
+    return zkh_read(ctx, dout, contributions, 0, n);
 }
 extern "C" const char* zkh_syn_accum(zkh_ctx* ctx, const zkh_circuit* c, size_t po2, size_t zk_cycles, uint64_t noise_seed,
                                      const zkh_buf* data, const uint32_t* mix_global, zkh_buf* accum) {

@@ -97,6 +97,8 @@ struct zkh_session {
     void* accumulate_user = nullptr;
     bool resident_code = true;           // built-in circuits: the committed code group of each size stays in HBM per lane
     bool streamed_fold = true;           // join_tree 2: lift2 / join a node the moment its children exist, concurrently with the sealing lanes
+    bool chained = false;                // SYN-C sessions: segment i's pre-state = initial + contributions of segments 0 .. i-1 (continuity)
+    uint32_t initial_state = 0;          // ... as a canonical residue
     int witness_source = 0;              // 0: closed-form generators on the device; 1: sequential host preflight -> compact records -> row fill
     size_t producers_per_lane = 2;       // ... host threads per sealing lane that run the preflight ahead of the seals
     ~zkh_session() { for (auto& l : fold_lanes) l.close(); for (auto& l : lanes) l.close(); }
@@ -219,6 +221,14 @@ extern "C" const char* zkh_session_set_recursion(zkh_session* s, const uint32_t*
     return nullptr;
 }
 extern "C" void zkh_session_set_streamed_fold(zkh_session* s, int on) { if (s) s->streamed_fold = on != 0; }
+extern "C" const char* zkh_session_set_chained(zkh_session* s, int on, uint32_t initial_state) {
+    ZKH_REQUIRE(s, "session_set_chained: null session");
+    ZKH_REQUIRE(!on || (s->lanes[0].circuit->kind == 1 && s->lanes[0].circuit->global_size[GLOBAL_OUT] == 5),
+                "session_set_chained: continuity needs a SYN-C circuit (kind 1 with one public input: the pre-state)");
+    ZKH_REQUIRE(initial_state < P, "session_set_chained: the initial state is not a reduced element");
+    s->chained = on != 0; s->initial_state = initial_state;
+    return nullptr;
+}
 extern "C" const char* zkh_session_set_witness_source(zkh_session* s, int source, size_t producers_per_lane) {
     ZKH_REQUIRE(s && (source == 0 || source == 1), "session_set_witness_source: source must be 0 (closed form on the device) or 1 (host preflight)");
     ZKH_REQUIRE(source == 0 || (s->lanes[0].circuit->kind == 1 && s->lanes[0].circuit->global_size[GLOBAL_OUT] == 4),
@@ -333,6 +343,28 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
     const bool streamed = fold && s->streamed_fold;
     info->streamed = streamed;
     constexpr size_t NONE = (size_t)-1;
+    // ---- chained session: the executor's pass.  Every segment's pre-state is fixed BEFORE any segment is proven (one launch over
+    // all segments), so the provers stay independent; the pre-state becomes the segment's public input ----
+    std::vector<zkh_segment> chained_segs;
+    std::vector<uint32_t> pre_states;
+    if (s->chained) {
+        std::vector<uint64_t> seeds(n);
+        std::vector<uint32_t> po2s(n), contrib(n);
+        for (size_t i = 0; i < n; i++) {
+            if (segs[i].host_code || segs[i].host_data) { zkh_prove_info_free(info); return make_err("session_prove: a chained session takes segments described by their seed"); }
+            seeds[i] = segs[i].seed; po2s[i] = segs[i].po2;
+        }
+        if (const char* e = zkh_syn_chain_contributions(s->lanes[0].ctx, s->lanes[0].circuit, seeds.data(), po2s.data(), n, ZKH_ZK_CYCLES, contrib.data())) {
+            zkh_prove_info_free(info);
+            return e;
+        }
+        pre_states.resize(n);
+        uint32_t state = fp_encode(s->initial_state).v;
+        for (size_t i = 0; i < n; i++) { pre_states[i] = state; state = add_mod(state, contrib[i]); }
+        chained_segs.assign(segs, segs + n);
+        for (size_t i = 0; i < n; i++) { chained_segs[i].pub = &pre_states[i]; chained_segs[i].n_pub = 1; }
+        segs = chained_segs.data();
+    }
 
     // ---- the fold plan (join_tree 2), fixed before anything runs: the bottom level turns segment receipts into recursion
     // receipts — a pair of segments is ONE proof where the program set has lift2(po2_l, po2_r) for EVERY pair (lift + lift + join
@@ -724,6 +756,13 @@ extern "C" const char* zkh_session_verify(zkh_session* s, const zkh_segment* seg
             return out;
         }
         ZKH_TRY(zkh_receipt_claim(hc, info->seals[i], info->seal_words[i], root->data(), nullptr, nullptr, claims[i].data()));
+    }
+    if (s->chained) {          // continuity (CompositeReceipt::verify_integrity): pre == prev.post, read from the verified seals' `out` words
+        uint32_t prev = fp_encode(s->initial_state).v;
+        for (size_t i = 0; i < info->n_segments; i++) {
+            ZKH_REQUIRE(info->seal_words[i] > 5 && info->seals[i][4] == prev, "session_verify: the session is not continuous: segment %zu does not start from its predecessor's post-state", i);
+            prev = info->seals[i][0];
+        }
     }
     if (!info->root_seal) return nullptr;
     if (info->n_lifts) {

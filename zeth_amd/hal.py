@@ -115,6 +115,7 @@ ABI = {
     "zkh_syn_code": (_err, [_vp, _vp, _sz, _sz, _vp]),
     "zkh_syn_witgen": (_err, [_vp, _vp, _sz, _sz, _u64, _u64, _u32p, _vp, _vp, _u32p]),
     "zkh_syn_accum": (_err, [_vp, _vp, _sz, _sz, _u64, _vp, _u32p, _vp]),
+    "zkh_syn_chain_contributions": (_err, [_vp, _vp, C.POINTER(_u64), _u32p, _sz, _sz, _u32p]),
     "zkh_syn_preflight_ram_words": (_sz, []),
     "zkh_syn_preflight": (_err, [_u64, _sz, _sz, _u32p, _u32p, C.POINTER(C.c_double)]),
     "zkh_syn_witgen_trace": (_err, [_vp, _vp, _sz, _sz, _u64, _vp, _u32p, _vp, _vp, _u32p]),
@@ -152,6 +153,7 @@ ABI = {
     "zkh_session_set_resident_code": (None, [_vp, _i]),
     "zkh_session_set_streamed_fold": (None, [_vp, _i]),
     "zkh_session_set_witness_source": (_err, [_vp, _i, _sz]),
+    "zkh_session_set_chained": (_err, [_vp, _i, _u32]),
     "zkh_session_set_recursion": (_err, [_vp, _u32p, _sz, C.POINTER(_u32p), C.POINTER(_sz), _u32p, _sz]),
     "zkh_session_prove": (_err, [_vp, C.POINTER(SegmentSpec), _sz, _i, _sz, _u64, C.POINTER(ProveInfo)]),
     "zkh_prove_info_free": (None, [C.POINTER(ProveInfo)]),

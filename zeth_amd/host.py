@@ -117,15 +117,34 @@ class CompositeReceipt:
     segments: List[SegmentReceipt]
     assumptions: List[SegmentReceipt] = field(default_factory=list)
 
-    def verify_integrity(self) -> None:
+    def verify_integrity(self, chained: bool = False, initial_state: int = 0) -> None:
+        """`CompositeReceipt::verify_integrity`: the segments are all there, in order — and, for a session of SYN-C segments
+        (`chained`, circuits/syn_air.py syn_chain: out = (post, 0, 0, 0, pre)), CONTINUOUS: the first segment starts from
+        `initial_state` and every segment's pre-state is its predecessor's post-state (upstream: `pre == prev.post` over
+        `ReceiptClaim`s).  The state words are read from the seals' `out` headers, which the seal verification binds."""
         idx = [s.index for s in self.segments]
         if idx != list(range(len(idx))):
             raise ValueError(f"composite receipt has missing or unordered segments: {idx}")
+        if chained:
+            from .circuits.syn_air import CHAIN_POST, CHAIN_PRE
+            from .hal import fp_encode
+            prev = fp_encode(initial_state)
+            for s in self.segments:
+                if int(s.seal[CHAIN_PRE]) != prev:
+                    raise ValueError(f"composite receipt is not continuous: segment {s.index} starts from state word {int(s.seal[CHAIN_PRE])}, "
+                                     f"its predecessor ended in {prev}")
+                prev = int(s.seal[CHAIN_POST])
 
-    def verify(self, circuit_desc, control_root=None, assumption_desc=None, assumption_control_root=None) -> None:
-        """`receipt.verify(image_id)` analogue: structural integrity + every segment seal through the host verifier
-        against the expected control root (None: the shipped table; or {po2: root} / callable for other sizes)."""
-        self.verify_integrity()
+    def final_state(self) -> int:
+        """post-state word of the last segment of a chained session (Montgomery form)"""
+        from .circuits.syn_air import CHAIN_POST
+        return int(self.segments[-1].seal[CHAIN_POST])
+
+    def verify(self, circuit_desc, control_root=None, assumption_desc=None, assumption_control_root=None, chained: bool = False,
+               initial_state: int = 0) -> None:
+        """`receipt.verify(image_id)` analogue: structural integrity (+ continuity of a chained session) + every segment seal through
+        the host verifier against the expected control root (None: the shipped table; or {po2: root} / callable for other sizes)."""
+        self.verify_integrity(chained, initial_state)
         for s in self.segments:
             s.verify(circuit_desc, _root_for(control_root, s.po2))
         if self.assumptions and assumption_desc is None:
@@ -159,6 +178,20 @@ class BlockProcessor:
         rec = CompositeReceipt(sorted((r for p in parts for r in p), key=lambda r: r.index))
         rec.verify_integrity()
         return rec
+
+
+def chain_segments(segments: Sequence[Segment], contribution: Callable[[Segment], int], initial_state: int = 0) -> List[Segment]:
+    """The executor's part of a chained session (SYN-C): give every segment its pre-state as its public input.
+    `contribution(seg)` = the Montgomery word the segment adds to the running state (its `post` when started from state 0:
+    `SegmentProver.chain_contribution` on the GPU, the oracle in tests); upstream's executor likewise fixes every segment's
+    pre / post `SystemState` before any segment is proven, which is what keeps the segments independent for the provers."""
+    from dataclasses import replace
+    from .hal import P, fp_encode
+    out, state = [], fp_encode(initial_state)
+    for seg in segments:
+        out.append(replace(seg, pub=(state,)))
+        state = (state + contribution(seg)) % P           # Montgomery words add like the elements they stand for
+    return out
 
 
 class Session:
@@ -213,6 +246,12 @@ class Session:
         seals on `producers_per_lane` host threads per lane (0 = 2); its compact per-cycle records (16 bytes per cycle) are uploaded
         from pinned memory and expanded by the GPU row-fill kernel (csrc/preflight.hip) — upstream's preflight -> witgen shape."""
         self._hal._check(self._hal._lib.zkh_session_set_witness_source(self.h, int(source), int(producers_per_lane)))
+
+    def set_chained(self, on: bool, initial_state: int = 0) -> None:
+        """SYN-C sessions: the library runs the executor's pass (every segment's pre-state = initial + the contributions of its
+        predecessors, one launch), proves the segments with those pre-states as public inputs, and `verify=True` additionally checks
+        continuity (pre == prev.post) on the seals."""
+        self._hal._check(self._hal._lib.zkh_session_set_chained(self.h, int(on), int(initial_state)))
 
     def set_resident_code(self, on: bool) -> None:
         """built-in circuits: keep the committed code group of each segment size resident per lane (default) or re-commit it per

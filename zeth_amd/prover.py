@@ -169,6 +169,15 @@ class SegmentProver:
                                   pub=np.asarray(seg.pub, dtype=np.uint32) if seg.pub else None)
         return code, data, out
 
+    def chain_contribution(self, seg: Segment) -> int:
+        """What a SYN-C segment adds to the running state: its post-state when started from state 0 (the witness generator run
+        with pre = 0; the executor's pass of a chained session, outside any proving clock)."""
+        seeds = (C.c_uint64 * 1)(seg.seed & (2**64 - 1))
+        po2s, out = np.array([seg.po2], dtype=np.uint32), np.zeros(1, dtype=np.uint32)
+        _hal._check(_hal._lib.zkh_syn_chain_contributions(self.hal.ctx, self.circuit.h, seeds, po2s.ctypes.data_as(C.POINTER(C.c_uint32)), 1, seg.zk_cycles,
+                                                          out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return int(out[0])
+
     def _take_seal(self, seal_p, n) -> np.ndarray:
         seal = np.ctypeslib.as_array(seal_p, shape=(n.value,)).copy()
         _hal._lib.zkh_free_seal(seal_p)
