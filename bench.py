@@ -309,6 +309,7 @@ def main() -> None:
     ap.add_argument("--fold", choices=("streamed", "phased"), default="streamed",
                     help="native executor: prove a lift2 / join the moment its children exist, concurrently with the sealing lanes (one pipeline), "
                          "or seal everything first and fold afterwards (two phases)")
+    ap.add_argument("--chained", action="store_true", help="block config: SYN-C segments whose pre-state is their predecessor's post-state (claim continuity), through the native session executor")
     ap.add_argument("--recompute-code", action="store_true", help="block / succinct: re-commit the code group for every segment (upstream's SegmentProver) instead of keeping it resident")
     ap.add_argument("--no-fused-lift", action="store_true", help="recursion: lift every segment on its own and join (three proofs per pair at the bottom level) instead of lift2")
     ap.add_argument("--no-preflight-leg", action="store_true", help="segment config: skip the block leg with the host-preflight witness pipeline")
@@ -1048,7 +1049,63 @@ def main() -> None:
                 mine = list(aligned_range(S, world, rank))
             except ValueError as e:
                 raise SystemExit(f"bench: --join-circuit recursion: {e}")
-        if recursive and args.executor == "native":
+        if args.config == "block" and args.chained:
+            # ---- a CHAINED block (claim continuity): SYN-C segments — SYN-A with the pre-state as public input, out =
+            # (post, 0, 0, 0, pre) — through the native session executor.  Rank 0 runs the executor's pass for the WHOLE block (one
+            # launch: every segment's contribution to the running state; before the clock, as upstream's executor runs before any
+            # proving), the pre-states travel with the segment list, every rank proves its round-robin share independently, and
+            # after the clock the gathered composite must pass pre == prev.post (`CompositeReceipt::verify_integrity`). ----
+            from zeth_amd.circuits import syn_air as _sa
+            from zeth_amd.host import CompositeReceipt, Session, chain_segments
+            cdesc = _sa.syn_chain()
+            cprobe = SegmentProver(HipHal(device), cdesc)
+            croots = {p: cprobe.control_root(p) for p in sorted({sg.po2 for sg in segs})}
+            box = [None]
+            t_e = time.perf_counter()
+            if rank == 0:
+                box[0] = chain_segments(segs, cprobe.chain_contribution, initial_state=1)
+            executor_s = time.perf_counter() - t_e
+            if distributed:
+                dist.broadcast_object_list(box, src=0)
+            csegs = box[0]
+            sess = Session(cdesc, devices=(device,), lanes_per_device=inflight)
+            sess.set_resident_code(not args.recompute_code)
+            sess.prove([csegs[0]] * inflight + [csegs[-1]])            # warm-up (the library treats `pub` as given: not chained mode)
+            device_sync([cprobe])
+            barrier()
+            t0 = time.perf_counter()
+            comp, _, st = sess.prove([csegs[i] for i in mine])
+            barrier()
+            dt = time.perf_counter() - t0
+            t_v = time.perf_counter()
+            for r in comp.segments:
+                r.verify(cdesc, croots[r.po2])
+            verify_s = time.perf_counter() - t_v
+            for r, i in zip(comp.segments, mine):
+                r.index = i
+            parts = [comp.segments]
+            if distributed:
+                parts = [None] * world if rank == 0 else None
+                dist.gather_object(comp.segments, parts, dst=0)
+                tm = torch.tensor([dt], dtype=torch.float64, device=ctrl_dev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                dt = float(tm.item())
+            if rank == 0:
+                whole = CompositeReceipt(sorted((r for part in parts for r in part), key=lambda r: r.index))
+                whole.verify_integrity(chained=True, initial_state=1)           # raises if the session is not continuous
+                line = {
+                    "metric": "segments/sec", "value": S / dt, "unit": "segments/s", "n_gpus": world, "steps": S, "warmup": 1,
+                    "ms_per_step": 1e3 * dt / S, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                    "config": {"workload": f"one CHAINED block: {S} distinct 2^{args.po2}-cycle SYN-C segments (last one 2^{segs[-1].po2}); every segment's "
+                                           f"pre-state is its predecessor's post-state (out = post, 0, 0, 0, pre), fixed by the executor's pass before the clock; "
+                                           f"witness generation inside the clock", "po2": args.po2, "circuit": "syn_chain", "segments": S,
+                               "parallelism": f"segments round-robin over {world} GPU(s), native session executor per rank, no data-path collective; {inflight} seal(s) in flight per GPU",
+                               "inflight_per_gpu": inflight, "library": HipHal.version(), "host_placement_rank0": placement},
+                    "block_wall_clock_s": dt, "verified_after_clock": len(whole.segments), "verify_s_rank0": verify_s,
+                    "continuity": {"checked": "pre == prev.post over all segments (CompositeReceipt.verify_integrity), first pre == the initial state",
+                                   "executor_pass_s": executor_s, "initial_state": 1, "final_state_word": whole.final_state()},
+                }
+        elif recursive and args.executor == "native":
             # ---- config 5 as ONE native call per rank: zkh_session_prove(join_tree = 2) seals this rank's segments and folds them —
             # by default as one pipeline (a lift2 / join is proven the moment its children exist, on the fold lanes while the sealing
             # lanes are busy), with --fold phased as two phases.  No Python in the loop; this is what a Rust shim's Prover::prove

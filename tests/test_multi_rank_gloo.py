@@ -149,3 +149,53 @@ def test_round_robin_and_distributed_joins_over_gloo(world):
     one.verify(leaf_desc, join_desc, leaf_root, join_root)
     with pytest.raises(ValueError, match="root is not the top"):
         SuccinctReceipt(root=leaves[1], joins=[], leaves=leaves[:1]).verify(leaf_desc, join_desc, leaf_root, join_root)
+
+
+def _chain_worker(rank, world, port, q):
+    """A CHAINED session over N ranks: the executor's pass runs once (rank 0) and fixes every segment's pre-state, the pre-states
+    travel with the segment list over the control plane, segment i is proven on rank i mod N (independent provers), rank 0 gathers."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import zko
+    from zeth_amd.circuits import syn_air
+    from zeth_amd.host import BlockProcessor, chain_segments, torch_gather
+    from zeth_amd.prover import Segment, SegmentReceipt
+    desc = syn_air.syn_chain_small()
+    oc = zko.OracleCircuit(zko.load(), desc)
+    po2, zk = 11, 1994
+    base = [Segment(index=i, po2=po2, seed=300 + i, noise_seed=0x62) for i in range(5)]
+    box = [None]
+    if rank == 0:            # the executor: one sequential pass that fixes pre / post of every segment
+        box[0] = chain_segments(base, lambda s: int(oc.witgen(s.po2, zk, s.seed, s.noise_seed, pub=np.zeros(1, np.uint32))[2][0]), initial_state=3)
+    dist.broadcast_object_list(box, src=0)
+    segs = box[0]
+
+    def prove(seg):
+        seal = oc.prove(seg.po2, zk, seg.seed, seg.noise_seed, pub=np.asarray(seg.pub, dtype=np.uint32))
+        return SegmentReceipt(seal=seal, index=seg.index, po2=seg.po2, output=seal[:5].copy())
+    rec = BlockProcessor(prove, rank=rank, world_size=world, gather=torch_gather(rank, world)).prove(segs)
+    if rank == 0:
+        root = oc.control_root(po2, zk)
+        rec.verify(desc, root, chained=True, initial_state=3)
+        q.put([r.seal.tobytes() for r in rec.segments])
+    dist.destroy_process_group()
+
+
+def test_chained_session_across_two_ranks_is_continuous():
+    """claim continuity does not serialise the provers: with the pre-states fixed by the executor's pass, two ranks prove their
+    round-robin shares independently and the gathered composite passes the pre == prev.post check"""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_chain_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    seals = q.get()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert len(seals) == 5 and len(set(seals)) == 5
+    words = [np.frombuffer(s, dtype=np.uint32) for s in seals]
+    assert all(int(words[i + 1][4]) == int(words[i][0]) for i in range(4))
