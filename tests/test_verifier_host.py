@@ -160,6 +160,18 @@ def test_chained_session_is_continuous_and_tampering_breaks_the_chain(oracle):
         CompositeReceipt(spliced).verify(desc, root, chained=True, initial_state=7)
     with pytest.raises(ValueError, match="missing or unordered"):
         CompositeReceipt([recs[0], recs[2], recs[3]]).verify(desc, root, chained=True, initial_state=7)
+    # the reference's flow (lib.rs:123-143 then cli.rs:103-107): prove -> (receipt, image id); receipt.verify(image_id); journal compare
+    from zeth_amd.hal import HalError, fp_decode
+    from zeth_amd.host import Receipt, image_id, prove_chained_block
+    receipt, iid = prove_chained_block(prove, contribution, desc, base, initial_state=7)
+    receipt.verify(iid, desc, initial_state=7, control_root=root)
+    assert receipt.journal == int(fp_decode(comp.final_state())).to_bytes(4, "little") and np.array_equal(iid, image_id(desc, 7))
+    with pytest.raises(HalError, match="image id"):
+        receipt.verify(image_id(desc, 8), desc, initial_state=7, control_root=root)           # another program / initial state
+    with pytest.raises(HalError, match="journal"):
+        Receipt(receipt.inner, b"\x00\x00\x00\x01").verify(iid, desc, initial_state=7, control_root=root)
+    with pytest.raises(ValueError, match="not continuous"):
+        Receipt(CompositeReceipt(swapped), receipt.journal).verify(iid, desc, initial_state=7, control_root=root)
     # without the chain check the same receipts are individually valid: continuity is a property of the SESSION
     CompositeReceipt(swapped).verify(desc, root)
     # and a forged pre-state inside a seal is refused by the seal verification itself (the state words are bound public inputs)

@@ -194,6 +194,52 @@ def chain_segments(segments: Sequence[Segment], contribution: Callable[[Segment]
     return out
 
 
+def image_id(circuit_desc, initial_state: int = 0) -> "np.ndarray":
+    """The 8-word identifier a verifier is handed for a chained session — the analogue of zeth's Image ID
+    (`compute_image_id(elf)`, /root/reference/crates/host/src/lib.rs:74-84: a digest of the guest program's initial memory image).
+    Here the "program" is the circuit description and the state every session starts from:
+    hash_pair(description hash ‖ 0.., initial state ‖ 0..) with the prover's own Poseidon2."""
+    import numpy as np
+    from .circuits.codegen import desc_hash64
+    from .hal import fp_encode
+    h = desc_hash64(np.asarray(circuit_desc, dtype=np.uint32))
+    left = np.array([fp_encode(h & 0x3FFFFFFF), fp_encode((h >> 30) & 0x3FFFFFFF), fp_encode(h >> 60), 0, 0, 0, 0, 0], dtype=np.uint32)
+    right = np.array([fp_encode(initial_state), 0, 0, 0, 0, 0, 0, 0], dtype=np.uint32)
+    return hash_pair(left, right)
+
+
+@dataclass
+class Receipt:
+    """`risc0_zkvm::Receipt{inner, journal}` analogue for a chained session: what `BlockProcessor::prove` returns next to the image
+    id (/root/reference/crates/host/src/lib.rs:123-143) and what the CLI then checks
+    (/root/reference/crates/host/src/bin/cli.rs:103-107): `receipt.verify(image_id)`, then the journal against the expected value.
+    The journal is the session's final state word (canonical, 4 bytes little-endian) — the public output the last segment binds."""
+    inner: CompositeReceipt
+    journal: bytes
+
+    def verify(self, expected_image_id, circuit_desc, initial_state: int = 0, control_root=None) -> None:
+        """Every segment seal against its control root, the session continuous from `initial_state`, the image id the caller
+        expected = the one (circuit, initial state) hash to, and the journal = the final state the last seal binds.  Raises."""
+        import numpy as np
+        from .hal import HalError, fp_decode
+        if not np.array_equal(np.asarray(expected_image_id, dtype=np.uint32), image_id(circuit_desc, initial_state)):
+            raise HalError("receipt.verify: the image id does not match this circuit and initial state")
+        self.inner.verify(circuit_desc, control_root, chained=True, initial_state=initial_state)
+        if self.journal != int(fp_decode(self.inner.final_state())).to_bytes(4, "little"):
+            raise HalError("receipt.verify: the journal is not the final state the last segment's seal binds")
+
+
+def prove_chained_block(prove_segment: Callable[[Segment], SegmentReceipt], contribution: Callable[[Segment], int], circuit_desc,
+                        segments: Sequence[Segment], initial_state: int = 0):
+    """`BlockProcessor::prove(input, po2) -> (Receipt, image id)` (/root/reference/crates/host/src/lib.rs:123-143) for a chained
+    session on this rank: the executor's pass (pre-states), the segment seals, the composite with its journal."""
+    from .hal import fp_decode
+    chained = chain_segments(segments, contribution, initial_state)
+    comp = CompositeReceipt([prove_segment(s) for s in chained])
+    comp.verify_integrity(chained=True, initial_state=initial_state)
+    return Receipt(comp, int(fp_decode(comp.final_state())).to_bytes(4, "little")), image_id(circuit_desc, initial_state)
+
+
 class Session:
     """`ProverServer::prove_session` as ONE native call (zkh_session_*, csrc/session.hip): the segments of a session sealed on
     `devices` x `lanes_per_device` lanes through one shared work index inside the library (C++ threads, no Python in the loop),
