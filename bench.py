@@ -1186,7 +1186,7 @@ def main() -> None:
                     root_verify_s = time.perf_counter() - t_rv
                     verified += 1
                     allc = {k: v for part in parts for k, v in part.items()}
-                    follows = bool(np.array_equal(root.seal[:8], fold_claims([allc[i] for i in range(S)])))
+                    follows = bool(np.array_equal(root.seal[:8], zrec.fold_leaf_claims([allc[i] for i in range(S)])))
                     if not follows:
                         raise SystemExit("bench: the root receipt's output is not the claim tree of the leaves")
                 else:
@@ -1358,7 +1358,11 @@ def main() -> None:
                 if rank == 0 and root is not None and (S > 1 or recursive):
                     import numpy as np
                     allc = {k: v for part in parts for k, v in part.items()}
-                    follows = bool(np.array_equal(root.seal[:8], fold_claims([allc[i] for i in range(S)])))
+                    if recursive:
+                        from zeth_amd.recursion import fold_leaf_claims
+                        follows = bool(np.array_equal(root.seal[:8], fold_leaf_claims([allc[i] for i in range(S)])))
+                    else:
+                        follows = bool(np.array_equal(root.seal[:8], fold_claims([allc[i] for i in range(S)])))
                     if not follows:
                         raise SystemExit("bench: the root receipt's output is not the claim tree of the leaves")
             counts = torch.tensor([float(verified), float(len(joins_done))], dtype=torch.float64, device=ctrl_dev)

@@ -153,7 +153,9 @@ def test_lift_runs_the_verifier_in_circuit(oracle, rec, cpo2):
     claim_in = np.concatenate([seal[:5], croot])                    # out (4) ‖ po2 ‖ control root
     want = np.zeros(8, np.uint32)
     oracle.zko_hash_elem_slice(np.ascontiguousarray(claim_in), claim_in.size, 1, want)
-    assert np.array_equal(out[:8], want) and np.array_equal(out[8:], A)
+    # what the lift publishes is claim' = hash_pair(receipt claim, (pre, post, 0..)): SYN-tiny has no state words, so (0, 0)
+    from zeth_amd import recursion as host_rec
+    assert np.array_equal(out[:8], host_rec.wrap_claim(want, 0, 0)) and np.array_equal(out[8:], A)
     accum = rec.rec_accum(po2, code, data, MIX)
     assert rec.check_rows(po2, accum, code, data, out, MIX) == -1
     rng = np.random.default_rng(cpo2)
@@ -204,17 +206,28 @@ def test_join_verifies_two_lifts_in_circuit(oracle, rec):
         return rec.prove_traces(lpo2, code, data, out)
     left, right = lifted(100, A), lifted(101, A)
     path = host_rec.membership_words(levels, 0)
-    code, data, out = rec.rec_witgen(jblob, np.concatenate([left, path, right, path]))
-    assert np.array_equal(out[:8], host_rec.hash_pair(left[:8], right[:8])) and np.array_equal(out[8:], A)
+
+    def leaf_claim(seed):
+        claim_in = np.concatenate([child.prove(cpo2, czk, seed=seed)[:5], croot])
+        c = np.zeros(8, np.uint32)
+        oracle.zko_hash_elem_slice(np.ascontiguousarray(claim_in), claim_in.size, 1, c)
+        return c
+    # a join reads, per child: seal, membership path, then the OPENING of the child's claim' (core, pre, post) - checked in-circuit
+    opening = lambda seed: np.concatenate([leaf_claim(seed), np.zeros(2, np.uint32)])
+    code, data, out = rec.rec_witgen(jblob, np.concatenate([left, path, opening(100), right, path, opening(101)]))
+    assert np.array_equal(out[:8], host_rec.wrap_claim(host_rec.hash_pair(left[:8], right[:8]), 0, 0)) and np.array_equal(out[8:], A)
+    assert np.array_equal(out[:8], host_rec.fold_leaf_claims([leaf_claim(100), leaf_claim(101)]))
+    with pytest.raises(RuntimeError, match="tie"):                              # an opening that is not the child's claim': no witness
+        rec.rec_witgen(jblob, np.concatenate([left, path, opening(101), right, path, opening(101)]))
+    with pytest.raises(RuntimeError, match="tie"):                              # a state range the child's claim' does not commit to
+        rec.rec_witgen(jblob, np.concatenate([left, path, leaf_claim(100), np.array([0, 5], np.uint32), right, path, opening(101)]))
     assert rec.check_rows(jpo2, rec.rec_accum(jpo2, code, data, MIX), code, data, out, MIX) == -1
     # the product's host-side check of a recursion receipt (zeth_amd/recursion.py RecReceipt.verify: no GPU involved): the
     # oracle-sealed lift verifies under the allowed set it was made for, with the claim of its segment - and only so
     from zeth_amd.hal import HalError
     roots = [rec.root_of_code(lpo2, lcode), rec.root_of_code(jpo2, jcode)]
     receipt = host_rec.RecReceipt(left, lpo2, 0, roots[0])
-    claim_in = np.concatenate([child.prove(cpo2, czk, seed=100)[:5], croot])
-    claim = np.zeros(8, np.uint32)
-    oracle.zko_hash_elem_slice(np.ascontiguousarray(claim_in), claim_in.size, 1, claim)
+    claim = leaf_claim(100)
     receipt.verify(roots, [claim])
     for bad_roots, bad_claims, what in ((roots[1:], [claim], "allowed set"), (roots[::-1], [claim], "allowed-programs root"),
                                         (roots, [claim[::-1].copy()], "claim tree")):
@@ -226,9 +239,9 @@ def test_join_verifies_two_lifts_in_circuit(oracle, rec):
         forged.verify(roots, [claim])
     stranger = lifted(101, np.arange(8, dtype=np.uint32))                       # a valid lift, handed another allowed root
     with pytest.raises(RuntimeError, match="tie"):
-        rec.rec_witgen(jblob, np.concatenate([left, path, stranger, path]))
+        rec.rec_witgen(jblob, np.concatenate([left, path, opening(100), stranger, path, opening(101)]))
     with pytest.raises(RuntimeError, match="tie"):
-        rec.rec_witgen(jblob, np.concatenate([left, path, right, host_rec.membership_words(levels, 1)]))
+        rec.rec_witgen(jblob, np.concatenate([left, path, opening(100), right, host_rec.membership_words(levels, 1), opening(101)]))
 
 
 def test_committed_digests_of_circuit_programs_and_oracle_witnesses():

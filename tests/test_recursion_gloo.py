@@ -68,11 +68,13 @@ def _worker(rank, world, port, q):
     dist.gather_object((local_root, claims), gathered, dst=0)
     if rank == 0:
         path0 = host_rec.membership_words(levels, 0)
-        _, (code, data, out) = run(j1blob, jpo2, np.concatenate([gathered[0][0], path0, gathered[1][0], path0]), seal=False)
+        allc = {k: v for _, part in gathered for k, v in part.items()}
+        opening = lambda i: np.concatenate([allc[i], np.zeros(2, np.uint32)])        # a lift's claim' opens to (receipt claim, pre 0, post 0)
+        _, (code, data, out) = run(j1blob, jpo2, np.concatenate([gathered[0][0], path0, opening(0), gathered[1][0], path0, opening(1)]), seal=False)
         mix = np.array([(i * 7919 + 13) % P for i in range(20)], dtype=np.uint32)
         bad = rec.check_rows(jpo2, rec.rec_accum(jpo2, code, data, mix), code, data, out, mix)
         allc = {k: v for _, part in gathered for k, v in part.items()}
-        want = host_rec.fold_claims([allc[i] for i in range(N_LEAVES)])
+        want = host_rec.fold_leaf_claims([allc[i] for i in range(N_LEAVES)])
         q.put({"bad_row": bad, "claim_ok": bool(np.array_equal(out[:8], want)), "allowed_ok": bool(np.array_equal(out[8:], A)),
                "ranges": [list(host_rec.aligned_range(N_LEAVES, world, r)) for r in range(world)]})
     dist.barrier()

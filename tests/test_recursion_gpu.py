@@ -176,8 +176,8 @@ def test_block_of_segments_folds_to_one_receipt_that_verified_every_child_in_cir
     hal.sync()
     t_join = time.time() - t0
     claims = [HostCircuit(desc).receipt_claim(r.seal, roots[r.po2]) for r in leaves]
-    for l, c in zip(lifted, claims):
-        assert np.array_equal(l.claim, c) and np.array_equal(l.allowed, rx.allowed_root())
+    for l, c in zip(lifted, claims):        # a lift publishes claim' = hash_pair(receipt claim, (pre, post, 0..)); SYN-A has no state: (0, 0)
+        assert np.array_equal(l.claim, rec.wrap_claim(c, 0, 0)) and np.array_equal(l.core, c) and np.array_equal(l.allowed, rx.allowed_root())
     assert root.n_leaves == 5 and root.po2 == 18
     root.verify(rx.allowed_roots(), claims)                         # ONE seal + the claim tree: nothing else is needed
     # the same tree with the bottom level fused: lift2 = lift + lift + join as one proof per pair of segments (5 proofs, not 9)
@@ -199,17 +199,24 @@ def test_block_of_segments_folds_to_one_receipt_that_verified_every_child_in_cir
         root.verify(rx.allowed_roots()[:2], claims)
     # a join refuses a child that is not a valid recursion seal, one that carries another allowed root, and one whose program
     # is not in the allowed set
-    forged = rec.RecReceipt(lifted[0].seal.copy(), lifted[0].po2, lifted[0].program, lifted[0].control_root)
+    forged = rec.RecReceipt(lifted[0].seal.copy(), lifted[0].po2, lifted[0].program, lifted[0].control_root, 1, lifted[0].core, 0, 0)
     forged.seal[lifted[0].seal.size // 2] ^= 1
     with pytest.raises(HalError, match="assertion of the program fails"):
         rx.join(forged, lifted[1])
     inputs = np.concatenate([leaves[0].seal, np.arange(8, dtype=np.uint32)])
     stranger, _ = rx.programs[0].prove(inputs, 3)                    # a valid lift, but under A' != A
     with pytest.raises(HalError, match="assertion of the program fails"):
-        rx.join(lifted[0], rec.RecReceipt(stranger, 17, 0, rx.programs[0].root))
-    wrong = rec.RecReceipt(lifted[1].seal, lifted[1].po2, 2, lifted[1].control_root)     # membership path of another program
+        rx.join(lifted[0], rec.RecReceipt(stranger, 17, 0, rx.programs[0].root, 1, lifted[0].core, 0, 0))
+    wrong = rec.RecReceipt(lifted[1].seal, lifted[1].po2, 2, lifted[1].control_root, 1, lifted[1].core, 0, 0)     # membership path of another program
     with pytest.raises(HalError, match="assertion of the program fails"):
         rx.join(lifted[0], wrong)
+    # ... and a child whose claim' is opened with another core or another state range (the opening is checked in-circuit)
+    lied = rec.RecReceipt(lifted[1].seal, lifted[1].po2, lifted[1].program, lifted[1].control_root, 1, lifted[0].core, 0, 0)
+    with pytest.raises(HalError, match="assertion of the program fails"):
+        rx.join(lifted[0], lied)
+    lied = rec.RecReceipt(lifted[1].seal, lifted[1].po2, lifted[1].program, lifted[1].control_root, 1, lifted[1].core, 0, 5)
+    with pytest.raises(HalError, match="assertion of the program fails"):
+        rx.join(lifted[0], lied)
     # the BASELINE shape against the oracle: the lift of a po2-20 SYN-A seal - the device's witness (72 x 2^17 words), its copy
     # argument and its seal are the CPU oracle's, word for word
     import zko
@@ -312,9 +319,9 @@ def test_a_keccak_assumption_receipt_is_lifted_too(hal):
     assert keccak_f.digest_of_state([sum(limbs[4 * l + j] << (16 * j) for j in range(4)) for l in range(25)]) == hashlib.sha3_256(msg).digest()
     kroot = kp.control_root(13)
     programs = [p for p in rec.build_programs(kdesc, {13: kroot}) if p[0][0] == "lift"]
-    rx = rec.Recursion(hal, programs)
+    rx = rec.Recursion(hal, programs, families=[(kdesc, {13: kroot})])
     lifted = rx.lift(krec, noise_seed=5)
-    assert np.array_equal(lifted.claim, HostCircuit(kdesc).receipt_claim(krec.seal, kroot))
+    assert np.array_equal(lifted.claim, rec.wrap_claim(HostCircuit(kdesc).receipt_claim(krec.seal, kroot), 0, 0))
     lifted.verify(rx.allowed_roots())
     forged = krec.seal.copy()
     forged[7] = (int(forged[7]) + 1) % P                            # one limb of the proven state

@@ -277,3 +277,46 @@ def test_chained_session_on_the_gpu(hal, oracle):
     comp0.verify(desc, roots, chained=True, initial_state=0)
     assert comp0.final_state() == sum(contrib) % P and not np.array_equal(comp0.segments[0].seal, comp.segments[0].seal)
     sess.close()
+
+
+def test_chained_session_folds_to_one_receipt_whose_joins_asserted_continuity(hal):
+    """Continuity IN-CIRCUIT: every recursion receipt publishes claim' = hash_pair(core, (pre, post, 0..)); lift2 and join open their
+    children's claim' and assert post(left) = pre(right).  A chained SYN-C session folds to one receipt natively and in the Python
+    driver (same root, word for word); the root follows from the leaves' (claim, pre, post); two segments that do NOT chain have no
+    lift2 witness, and a claim tree over a broken chain is refused on the host as well."""
+    from zeth_amd import recursion as rec
+    from zeth_amd.circuits.syn_air import syn_chain_small
+    from zeth_amd.hal import HalError, HostCircuit
+    from zeth_amd.host import Session, chain_segments
+    from zeth_amd.prover import Segment, SegmentProver
+    desc = syn_chain_small()
+    sp = SegmentProver(hal, desc)
+    base = [Segment(index=i, po2=13, seed=1600 + i, noise_seed=0x55) for i in range(4)]
+    roots = {13: sp.control_root(13)}
+    programs = rec.build_programs(desc, roots)
+    sess = Session(desc, devices=(0,), lanes_per_device=2)
+    sess.set_recursion(programs)
+    sess.set_chained(True, 9)
+    comp, root, st = sess.prove(base, join_tree=2, join_noise_seed=0x78, verify=True)          # zkh_session_verify: seals, chain, claim tree
+    assert st["n_lifts"] == 2 and st["n_joins"] == 1
+    comp.verify(desc, roots, chained=True, initial_state=9)
+    rx = rec.Recursion(hal, programs)
+    want = rx.fold_segments(comp.segments, 0x78)
+    assert np.array_equal(root.seal, want.seal)
+    leaves = [(HostCircuit(desc).receipt_claim(r.seal, roots[13]), int(r.seal[4]), int(r.seal[0])) for r in comp.segments]
+    want.verify(rx.allowed_roots(), leaves)
+    assert (want.pre, want.post) == (int(comp.segments[0].seal[4]), comp.final_state())
+    assert np.array_equal(want.claim, rec.fold_leaf_claims(leaves))
+    # a pair that does not chain: segment 2 after segment 0 — the fused lift has no witness; the host-side tree refuses too
+    with pytest.raises(HalError, match="assertion of the program fails"):
+        rx.lift2(comp.segments[0], comp.segments[2])
+    with pytest.raises(HalError, match="do not chain"):
+        rec.fold_leaf_claims([leaves[0], leaves[2], leaves[1], leaves[3]])
+    with pytest.raises(HalError):                                                              # plain claims (state 0, 0) are another tree
+        want.verify(rx.allowed_roots(), [l[0] for l in leaves])
+    # without the executor's pass (arbitrary public inputs) the session cannot be folded: its joins would not chain
+    sess.set_chained(False)
+    loose = [Segment(index=i, po2=13, seed=1600 + i, noise_seed=0x55, pub=(i + 1,)) for i in range(4)]
+    with pytest.raises(HalError, match="do not chain|assertion of the program fails"):
+        sess.prove(loose, join_tree=2, join_noise_seed=0x78)
+    sess.close()

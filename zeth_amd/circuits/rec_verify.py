@@ -414,62 +414,92 @@ class Verifier:
         pr.eq(cur[1], allowed[1])
 
 
-def _segment_claim(v: Verifier, c: Circuit, po2: int, control_root: Sequence[int]) -> List[int]:
-    """verify one segment seal (fresh transcript), pin its code root to `control_root`, -> its claim digest (2 wires)"""
+def chain_words(c: Circuit):
+    """(index of the pre-state, index of the post-state) in the `out` globals of a circuit whose segments chain (SYN-C: kind 1 with
+    one public input, out = (post, 0, 0, 0, pre)), or None for circuits without a state"""
+    return (4, 0) if c.kind == 1 and c.global_sizes[0] == 5 else None
+
+
+def _wrap(v: Verifier, core: Sequence[int], pre: int, post: int) -> List[int]:
+    """claim' = hash_pair(core, (pre, post, 0, 0, 0, 0, 0, 0)): the claim every recursion receipt publishes — its core claim (a
+    segment's receipt claim, or hash_pair of the two children's claim') bound to the state range [pre, post] it covers"""
+    pr, z = v.pr, v.pr.zero()
+    return v.pair(core, [pr.pack(0, pre, post, z, z, embedded=True), z])
+
+
+def _segment_claim(v: Verifier, c: Circuit, po2: int, control_root: Sequence[int]):
+    """verify one segment seal (fresh transcript), pin its code root to `control_root` -> (its claim digest: 2 wires, pre, post):
+    pre / post are the segment's state words (embedded wires of its `out` header; zero for circuits without a state)"""
     pr = v.pr
     v.io = Sponge(pr)
     s = v.verify_seal(c, po2)
     root_words = v.digest_words(s["code_root"])
     for w, k in zip(root_words, control_root):
         pr.eq(w, pr.const(int(k)))
-    return v.elems(v.repack(s["out"] + [pr.const(po2)] + root_words))
+    cw = chain_words(c)
+    pre, post = (s["out"][cw[0]], s["out"][cw[1]]) if cw else (pr.zero(), pr.zero())
+    return v.elems(v.repack(s["out"] + [pr.const(po2)] + root_words)), pre, post
 
 
 def build_lift(circuit_desc: np.ndarray, po2: int, control_root: Sequence[int]) -> Program:
-    """Inputs: the segment seal, then A (8 words).  control_root: canonical residues of the segment circuit's code root."""
+    """Inputs: the segment seal, then A (8 words).  control_root: canonical residues of the segment circuit's code root.
+    out = claim' ‖ A with claim' = hash_pair(receipt claim, (pre, post, 0..)): the segment's state words ride in the claim."""
     pr = Program()
     v = Verifier(pr)
-    claim = _segment_claim(v, Circuit.parse(circuit_desc), po2, control_root)
+    claim, pre, post = _segment_claim(v, Circuit.parse(circuit_desc), po2, control_root)
+    wrapped = _wrap(v, claim, pre, post)
     allowed = v.read(8)
-    pr.public(claim[0], claim[1], allowed[0], allowed[1])
+    pr.public(wrapped[0], wrapped[1], allowed[0], allowed[1])
     return pr
 
 
 def build_lift2(circuit_desc: np.ndarray, po2_left: int, root_left: Sequence[int], po2_right: int, root_right: Sequence[int]) -> Program:
-    """lift + lift + join as ONE program: verify two SEGMENT seals, out = hash_pair(claim_l, claim_r) ‖ A.  The bottom level of
-    the join tree then costs one recursion proof per pair of segments instead of three (the statement is the same: the node
-    two lifts and a join would produce).  Inputs: left seal, right seal, A."""
+    """lift + lift + join as ONE program: verify two SEGMENT seals, ASSERT post(left) = pre(right), out = claim' of the node two lifts
+    and a join would produce ‖ A.  The bottom level of the join tree then costs one recursion proof per pair of segments instead
+    of three.  Inputs: left seal, right seal, A."""
     c = Circuit.parse(circuit_desc)
     pr = Program()
     v = Verifier(pr)
-    left = _segment_claim(v, c, po2_left, root_left)
-    right = _segment_claim(v, c, po2_right, root_right)
-    parent = v.pair(left, right)
+    left, pre_l, post_l = _segment_claim(v, c, po2_left, root_left)
+    right, pre_r, post_r = _segment_claim(v, c, po2_right, root_right)
+    pr.eq(post_l, pre_r)                                          # continuity: the right segment starts where the left one ended
+    parent = v.pair(_wrap(v, left, pre_l, post_l), _wrap(v, right, pre_r, post_r))
+    wrapped = _wrap(v, parent, pre_l, post_r)
     allowed = v.read(8)
-    pr.public(parent[0], parent[1], allowed[0], allowed[1])
+    pr.public(wrapped[0], wrapped[1], allowed[0], allowed[1])
     return pr
 
 
 def build_join(recursion_desc: np.ndarray, po2_left: int, po2_right: int) -> Program:
-    """Inputs: left seal, its membership path (ALLOWED_DEPTH x (bit, 8 sibling words)), right seal, its path.
-    Each child's out is claim ‖ A; both A must be this program's A (= its own public output)."""
+    """Inputs per child: its seal, its membership path (ALLOWED_DEPTH x (bit, 8 sibling words)), then the OPENING of its claim':
+    core (8 words) and (pre, post).  Each child's out is claim' ‖ A; both A must be this program's A (= its own public output);
+    hash_pair(core, (pre, post, 0..)) must BE the child's claim'; and post(left) = pre(right) — upstream's join asserts the same
+    continuity between the two `ReceiptClaim`s it merges.  out = hash_pair(hash_pair(claim'_l, claim'_r), (pre_l, post_r, 0..)) ‖ A."""
     c = Circuit.parse(recursion_desc)
     pr = Program()
     v = Verifier(pr)
-    claims, allowed = [], None
+    claims, states, allowed = [], [], None
     for po2 in (po2_left, po2_right):
         v.io = Sponge(pr)
         s = v.verify_seal(c, po2)
-        out_packed = s["head"][:4]                               # out = 16 words: claim (2 wires) ‖ A (2 wires)
+        out_packed = s["head"][:4]                               # out = 16 words: claim' (2 wires) ‖ A (2 wires)
         if allowed is None:
             allowed = out_packed[2:4]
         else:
             pr.eq(out_packed[2], allowed[0])
             pr.eq(out_packed[3], allowed[1])
         v.allowed_member(s["code_root"], allowed)
+        core = v.read(8)
+        st = pr.unpack(v.read(2)[0])                             # (pre, post, 0, 0): the padding is constrained by read()
+        opened = _wrap(v, core, st[0], st[1])
+        pr.eq(opened[0], out_packed[0])
+        pr.eq(opened[1], out_packed[1])
         claims.append(out_packed[:2])
+        states.append((st[0], st[1]))
+    pr.eq(states[0][1], states[1][0])                             # continuity
     parent = v.pair(claims[0], claims[1])
-    pr.public(parent[0], parent[1], allowed[0], allowed[1])
+    wrapped = _wrap(v, parent, states[0][0], states[1][1])
+    pr.public(wrapped[0], wrapped[1], allowed[0], allowed[1])
     return pr
 
 

@@ -151,6 +151,31 @@ static const char* hash_pair_host(const uint32_t* a, const uint32_t* b, uint32_t
 }
 constexpr size_t REC_ALLOWED = 16, REC_DEPTH = 4;                   // zeth_amd/circuits/rec_verify.py ALLOWED_DEPTH
 
+// claim' = hash_pair(core, (pre, post, 0, 0, 0, 0, 0, 0)): what every recursion receipt publishes (circuits/rec_verify.py _wrap) — its
+// core claim bound to the state range [pre, post] it covers.  A join opens both children's claim' in-circuit and asserts
+// post(left) = pre(right); the opening (core, pre, post) travels next to a receipt as witness for its parent, never trusted.
+struct NodeClaim { uint32_t core[8] = {0}; uint32_t pre = 0, post = 0; };
+static const char* wrap_claim(const NodeClaim& c, uint32_t out[8]) {
+    const uint32_t st[8] = {c.pre, c.post, 0, 0, 0, 0, 0, 0};
+    return hash_pair_host(c.core, st, out);
+}
+// (receipt claim, pre, post) of a segment seal: SYN-C circuits (kind 1, five outputs) carry their state in out[4] / out[0]
+static const char* leaf_claim(const zkh_circuit* c, const uint32_t* seal, size_t words, const uint32_t* control_root, NodeClaim* out) {
+    ZKH_TRY(zkh_receipt_claim(c, seal, words, control_root, nullptr, nullptr, out->core));
+    const bool chained = c->kind == 1 && c->global_size[GLOBAL_OUT] == 5;
+    out->pre = chained ? seal[4] : 0; out->post = chained ? seal[0] : 0;
+    return nullptr;
+}
+// parent of two nodes: core = hash_pair(claim'_l, claim'_r), state range = [pre_l, post_r]; the children must chain
+static const char* parent_claim(const NodeClaim& l, const NodeClaim& r, NodeClaim* out) {
+    ZKH_REQUIRE(l.post == r.pre, "claim tree: two neighbouring nodes do not chain (post(l) != pre(r)): no join has a witness for them");
+    uint32_t cl[8], cr[8];
+    ZKH_TRY(wrap_claim(l, cl)); ZKH_TRY(wrap_claim(r, cr));
+    ZKH_TRY(hash_pair_host(cl, cr, out->core));
+    out->pre = l.pre; out->post = r.post;
+    return nullptr;
+}
+
 extern "C" const char* zkh_session_set_recursion(zkh_session* s, const uint32_t* rec_desc, size_t rec_desc_words, const uint32_t* const* blobs,
                                                  const size_t* words, const uint32_t* kinds, size_t n_programs) {
     ZKH_REQUIRE(s && rec_desc && rec_desc_words >= 16 && blobs && words && kinds && n_programs && n_programs <= REC_ALLOWED, "session_set_recursion: bad argument");
@@ -378,6 +403,7 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
         int pending = 0;                   // children not yet available
         uint32_t* seal = nullptr;
         size_t words = 0;
+        NodeClaim claim;                   // the opening of the claim' its seal publishes (set when the node is proven)
     };
     std::vector<PNode> plan;
     std::vector<size_t> owner(fold ? n : 0, NONE);         // the bottom node that consumes segment i
@@ -429,6 +455,19 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
         if (perr) { zkh_prove_info_free(info); return perr; }
         root_node = cur[0];
     }
+    // control root of the leaf circuit per segment size (the lifts' claims are computed against it): before any thread starts
+    std::vector<std::pair<uint32_t, std::vector<uint32_t>>> fold_leaf_roots;
+    auto leaf_root_of = [&](uint32_t po2) -> const uint32_t* {
+        for (auto& r : fold_leaf_roots) if (r.first == po2) return r.second.data();
+        return nullptr;
+    };
+    if (fold)
+        for (size_t i = 0; i < n; i++)
+            if (!leaf_root_of(segs[i].po2)) {
+                std::vector<uint32_t> cr(8);
+                if (const char* e = leaf_control_root(s, segs[i], cr.data())) { zkh_prove_info_free(info); return e; }
+                fold_leaf_roots.emplace_back(segs[i].po2, cr);
+            }
     auto path_of = [&](uint32_t program, std::vector<uint32_t>& out) {      // per level: the direction bit as an element, the sibling
         size_t idx = program;
         for (size_t l = 0; l < REC_DEPTH; l++) {
@@ -472,14 +511,28 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
         in.clear();
         const std::vector<uint32_t>& A = s->allowed.back()[0];
         if (nd.kind == 1) {
+            // per child: seal, membership path, then the opening of its claim' (core, pre, post) — all checked in-circuit
             const PNode &a = plan[nd.a], &b = plan[nd.b];
-            in.assign(a.seal, a.seal + a.words);
-            path_of(a.program, in);
-            in.insert(in.end(), b.seal, b.seal + b.words);
-            path_of(b.program, in);
+            for (const PNode* ch : {&a, &b}) {
+                in.insert(in.end(), ch->seal, ch->seal + ch->words);
+                path_of(ch->program, in);
+                in.insert(in.end(), ch->claim.core, ch->claim.core + 8);
+                in.push_back(ch->claim.pre); in.push_back(ch->claim.post);
+            }
+            ZKH_TRY(parent_claim(a.claim, b.claim, &nd.claim));
         } else {
+            const zkh_circuit* lc = s->lanes[0].circuit;
             in.assign(info->seals[nd.a], info->seals[nd.a] + info->seal_words[nd.a]);
-            if (nd.kind == 2) in.insert(in.end(), info->seals[nd.b], info->seals[nd.b] + info->seal_words[nd.b]);
+            NodeClaim ca;
+            ZKH_TRY(leaf_claim(lc, info->seals[nd.a], info->seal_words[nd.a], leaf_root_of(segs[nd.a].po2), &ca));
+            if (nd.kind == 2) {
+                in.insert(in.end(), info->seals[nd.b], info->seals[nd.b] + info->seal_words[nd.b]);
+                NodeClaim cb;
+                ZKH_TRY(leaf_claim(lc, info->seals[nd.b], info->seal_words[nd.b], leaf_root_of(segs[nd.b].po2), &cb));
+                ZKH_TRY(parent_claim(ca, cb, &nd.claim));
+            } else {
+                nd.claim = ca;
+            }
             in.insert(in.end(), A.begin(), A.end());
         }
         uint64_t noise = join_noise_seed;
@@ -776,13 +829,23 @@ extern "C" const char* zkh_session_verify(zkh_session* s, const zkh_segment* seg
             zkh_free_error(e);
             return out;
         }
-        while (claims.size() > 1) {
-            std::vector<std::vector<uint32_t>> up(claims.size() / 2, std::vector<uint32_t>(8));
-            for (size_t k = 0; k < up.size(); k++) ZKH_TRY(hash_pair_host(claims[2 * k].data(), claims[2 * k + 1].data(), up[k].data()));
-            if (claims.size() % 2) up.push_back(claims.back());
-            claims.swap(up);
+        // the claim tree over the leaves (receipt claim + state words of every VERIFIED segment seal), as the lift2 / join programs
+        // build it in-circuit: parent core = hash_pair(claim'_l, claim'_r), state range [pre_l, post_r], and neighbours must chain
+        std::vector<NodeClaim> nodes(info->n_segments);
+        for (size_t i = 0; i < info->n_segments; i++) {
+            memcpy(nodes[i].core, claims[i].data(), 32);
+            const bool chained = hc->kind == 1 && hc->global_size[GLOBAL_OUT] == 5;
+            nodes[i].pre = chained ? info->seals[i][4] : 0; nodes[i].post = chained ? info->seals[i][0] : 0;
         }
-        ZKH_REQUIRE(info->root_seal_words > 16 && memcmp(info->root_seal, claims[0].data(), 32) == 0,
+        while (nodes.size() > 1) {
+            std::vector<NodeClaim> up(nodes.size() / 2);
+            for (size_t k = 0; k < up.size(); k++) ZKH_TRY(parent_claim(nodes[2 * k], nodes[2 * k + 1], &up[k]));
+            if (nodes.size() % 2) up.push_back(nodes.back());
+            nodes.swap(up);
+        }
+        uint32_t want[8];
+        ZKH_TRY(wrap_claim(nodes[0], want));
+        ZKH_REQUIRE(info->root_seal_words > 16 && memcmp(info->root_seal, want, 32) == 0,
                     "session_verify: the root receipt does not commit to the claim tree of these segments");
         ZKH_REQUIRE(memcmp(info->root_seal + 8, s->allowed.back()[0].data(), 32) == 0, "session_verify: the root receipt was produced under another allowed-programs root");
         return nullptr;

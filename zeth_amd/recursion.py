@@ -23,7 +23,7 @@ import numpy as np
 from . import hal as _hal
 from .circuits import rec_verify, recursion as rc
 from .circuits.desc import P
-from .host import fold_claims, hash_pair
+from .host import fold_claims, hash_pair  # noqa: F401  (fold_claims: the P2-JOIN tree, re-exported for callers)
 from .prover import SegmentReceipt
 
 R = (1 << 32) % P
@@ -53,14 +53,58 @@ def membership_words(levels, index: int) -> np.ndarray:
     return np.concatenate(out)
 
 
+def state_digest(pre: int, post: int) -> np.ndarray:
+    """(pre, post, 0, 0, 0, 0, 0, 0): the second operand of a wrapped claim"""
+    return np.array([pre, post, 0, 0, 0, 0, 0, 0], dtype=np.uint32)
+
+
+def wrap_claim(core, pre: int, post: int) -> np.ndarray:
+    """claim' = hash_pair(core, (pre, post, 0..)) — what every recursion receipt publishes (circuits/rec_verify.py _wrap): its core
+    claim bound to the state range [pre, post] it covers (Montgomery words; 0, 0 for circuits without a state)"""
+    return hash_pair(core, state_digest(pre, post))
+
+
+def segment_state(desc, seal) -> Tuple[int, int]:
+    """(pre, post) state words of a segment seal: SYN-C circuits carry them in out[4] / out[0]; every other circuit has none"""
+    d = np.asarray(desc, dtype=np.uint32)
+    cw = rec_verify.chain_words(rec_verify.Circuit.parse(d))
+    return (int(seal[cw[0]]), int(seal[cw[1]])) if cw else (0, 0)
+
+
+def fold_leaf_claims(leaves) -> np.ndarray:
+    """The claim' a lift / lift2 / join tree ends in, recomputed on the host from the LEAVES: [(receipt claim, pre, post)] (a bare
+    8-word claim counts as state (0, 0)).  Node = (core, pre, post): a leaf's core is its receipt claim; a parent's core is
+    hash_pair(claim'_l, claim'_r) and its state range runs from the left child's pre to the right child's post; pairs left to
+    right, an unpaired last node moves up unchanged (the tree of host.join_schedule).  Raises if two neighbours do not chain —
+    the joins could not have been proven: every join asserts post(l) = pre(r) in-circuit."""
+    level = [(np.asarray(l[0], dtype=np.uint32), int(l[1]), int(l[2])) if isinstance(l, (tuple, list)) and len(l) == 3 and not np.isscalar(l[0])
+             else (np.asarray(l, dtype=np.uint32), 0, 0) for l in leaves]
+    while len(level) > 1:
+        nxt = []
+        for k in range(len(level) // 2):
+            (cl, pl, ql), (cr, pr_, qr) = level[2 * k], level[2 * k + 1]
+            if ql != pr_:
+                raise _hal.HalError("claim tree: two neighbouring nodes do not chain (post(l) != pre(r)): no join has a witness for them")
+            nxt.append((hash_pair(wrap_claim(cl, pl, ql), wrap_claim(cr, pr_, qr)), pl, qr))
+        if len(level) % 2:
+            nxt.append(level[-1])
+        level = nxt
+    return wrap_claim(*level[0])
+
+
 @dataclass
 class RecReceipt:
-    """`SuccinctReceipt` analogue: one seal of the RECURSION circuit under program `program` (index into the allowed set)."""
+    """`SuccinctReceipt` analogue: one seal of the RECURSION circuit under program `program` (index into the allowed set).
+    core / pre / post open the claim' the seal publishes (claim' = wrap_claim(core, pre, post)): a join needs them as witness for
+    its children and checks them in-circuit, so they are carried next to the seal, never trusted."""
     seal: np.ndarray
     po2: int
     program: int
     control_root: np.ndarray
     n_leaves: int = 1
+    core: Optional[np.ndarray] = None
+    pre: int = 0
+    post: int = 0
 
     @property
     def claim(self) -> np.ndarray:
@@ -72,15 +116,21 @@ class RecReceipt:
 
     def verify(self, allowed_roots: Sequence[np.ndarray], leaf_claims: Optional[Sequence[np.ndarray]] = None) -> None:
         """Host check of the whole tree below this receipt: ONE seal verification, the program's membership in the allowed
-        set, the allowed root the receipt carries, and (given the leaves' claims) the claim tree.  Raises HalError."""
+        set, the allowed root the receipt carries, and (given the leaves: receipt claims, or (claim, pre, post) for circuits with a
+        state) the claim tree — whose joins each asserted post(l) = pre(r) in-circuit.  Raises HalError."""
         roots = [np.asarray(r, dtype=np.uint32) for r in allowed_roots]
         if not any(np.array_equal(self.control_root, r) for r in roots):
             raise _hal.HalError("recursion receipt: its program is not in the allowed set")
         _hal.HostCircuit(rc.recursion_circuit()).verify_segment(self.seal, self.control_root)
         if not np.array_equal(self.allowed, allowed_tree(roots)[-1][0]):
             raise _hal.HalError("recursion receipt: it was produced under another allowed-programs root")
-        if leaf_claims is not None and not np.array_equal(self.claim, fold_claims(list(leaf_claims))):
+        if leaf_claims is not None and not np.array_equal(self.claim, fold_leaf_claims(list(leaf_claims))):
             raise _hal.HalError("recursion receipt: its claim is not the root of the leaves' claim tree")
+
+
+class ProgramSet(list):
+    """[(kind, blob)] + the leaf families [(circuit description, {po2: control root})] the lifts were built for"""
+    families: list = []
 
 
 def build_programs(segment_desc, segment_roots: Optional[Dict[int, np.ndarray]] = None, zk_cycles: int = _hal.ZK_CYCLES,
@@ -122,7 +172,9 @@ def build_programs(segment_desc, segment_roots: Optional[Dict[int, np.ndarray]] 
             done.add((a, b))
             add(("join", a, b), rec_verify.build_join(rdesc, a, b))
     assert len(out) <= N_ALLOWED, f"{len(out)} programs do not fit the allowed set"
-    return out
+    ps = ProgramSet(out)
+    ps.families = [(np.asarray(d, dtype=np.uint32), dict(r)) for d, r in families]
+    return ps
 
 
 def aligned_range(n_leaves: int, world_size: int, rank: int) -> range:
@@ -139,8 +191,12 @@ def aligned_range(n_leaves: int, world_size: int, rank: int) -> range:
 class Recursion:
     """The lift / join programs of one GPU lane (one HipHal): loaded once, code groups resident."""
 
-    def __init__(self, hal: "_hal.HipHal", programs: Sequence[Tuple[Tuple, np.ndarray]]):
+    def __init__(self, hal: "_hal.HipHal", programs: Sequence[Tuple[Tuple, np.ndarray]], families: Sequence = ()):
+        """families: [(circuit description, {po2: control root})] in build_programs' order (family 0 = the segment circuit) — what
+        lift / lift2 need to open a leaf's claim (receipt claim + state words); without it leaves are taken to have no state and
+        their claims must be supplied (`lift(..., claim=)`)."""
         self.hal = hal
+        self.families = list(families) or list(getattr(programs, "families", ()))
         self.circuit = hal.load_circuit(rc.recursion_circuit())
         self.kinds = [k for k, _ in programs]
         self.programs = [_hal.RecProgram(hal, self.circuit, blob) for _, blob in programs]
@@ -152,28 +208,47 @@ class Recursion:
     def allowed_root(self) -> np.ndarray:
         return self.levels[-1][0]
 
+    def _leaf(self, receipt: SegmentReceipt, family: int):
+        """(receipt claim, pre, post) of a leaf: what the lift proves about it"""
+        if family >= len(self.families):
+            raise _hal.HalError("Recursion: no circuit description / control roots for this leaf family (pass families= to Recursion)")
+        desc, roots = self.families[family]
+        claim = _hal.HostCircuit(desc).receipt_claim(receipt.seal, roots[receipt.po2])
+        pre, post = segment_state(desc, receipt.seal)
+        return claim, pre, post
+
     def lift(self, receipt: SegmentReceipt, noise_seed: Optional[int] = None, family: int = 0) -> RecReceipt:
         """family 0: a receipt of the segment circuit; 1..: of the corresponding assumption circuit of build_programs"""
         i = self.kinds.index(("lift", receipt.po2, family))
         inputs = np.concatenate([np.asarray(receipt.seal, dtype=np.uint32), self.allowed_root()])
         seal, _ = self.programs[i].prove(inputs, _seed(noise_seed))
-        return RecReceipt(seal, self.programs[i].po2, i, self.programs[i].root)
+        core, pre, post = self._leaf(receipt, family)
+        return RecReceipt(seal, self.programs[i].po2, i, self.programs[i].root, 1, core, pre, post)
 
     def has_lift2(self, left: SegmentReceipt, right: SegmentReceipt) -> bool:
         return ("lift2", left.po2, right.po2) in self.kinds
 
     def lift2(self, left: SegmentReceipt, right: SegmentReceipt, noise_seed: Optional[int] = None) -> RecReceipt:
-        """the node lift(left), lift(right), join would produce, as one proof"""
+        """the node lift(left), lift(right), join would produce, as one proof (the program asserts post(left) = pre(right))"""
         i = self.kinds.index(("lift2", left.po2, right.po2))
         inputs = np.concatenate([np.asarray(left.seal, dtype=np.uint32), np.asarray(right.seal, dtype=np.uint32), self.allowed_root()])
         seal, _ = self.programs[i].prove(inputs, _seed(noise_seed))
-        return RecReceipt(seal, self.programs[i].po2, i, self.programs[i].root, 2)
+        (cl, pl, ql), (cr, pr_, qr) = self._leaf(left, 0), self._leaf(right, 0)
+        core = hash_pair(wrap_claim(cl, pl, ql), wrap_claim(cr, pr_, qr))
+        return RecReceipt(seal, self.programs[i].po2, i, self.programs[i].root, 2, core, pl, qr)
 
     def join(self, left: RecReceipt, right: RecReceipt, noise_seed: Optional[int] = None) -> RecReceipt:
+        """inputs per child: seal, membership path, then the opening of its claim' (core, pre, post); the program checks the opening,
+        both memberships, and post(left) = pre(right)"""
         i = self.kinds.index(("join", left.po2, right.po2))
-        inputs = np.concatenate([left.seal, membership_words(self.levels, left.program), right.seal, membership_words(self.levels, right.program)])
-        seal, _ = self.programs[i].prove(inputs, _seed(noise_seed))
-        return RecReceipt(seal, self.programs[i].po2, i, self.programs[i].root, left.n_leaves + right.n_leaves)
+        parts = []
+        for ch in (left, right):
+            if ch.core is None:
+                raise _hal.HalError("join: a child receipt without the opening of its claim (core, pre, post)")
+            parts += [ch.seal, membership_words(self.levels, ch.program), np.asarray(ch.core, dtype=np.uint32), np.array([ch.pre, ch.post], dtype=np.uint32)]
+        seal, _ = self.programs[i].prove(np.concatenate(parts), _seed(noise_seed))
+        core = hash_pair(left.claim, right.claim)
+        return RecReceipt(seal, self.programs[i].po2, i, self.programs[i].root, left.n_leaves + right.n_leaves, core, left.pre, right.post)
 
     def fold_segments(self, receipts: Sequence[SegmentReceipt], noise_seed: Optional[int] = None) -> RecReceipt:
         """segment receipts -> one receipt: the bottom level pairs them with lift2 where the program set has it (else lift, lift,
