@@ -1139,7 +1139,7 @@ def main() -> None:
             t_local = time.perf_counter() - t0
             kinds = [k for k, _ in programs]
             rp = st["root_program"]
-            local = zrec.RecReceipt(local_root.seal, local_root.po2, rp, None, len(mine))
+            local = zrec.RecReceipt(local_root.seal, local_root.po2, rp, None, len(mine), st["root_core"], st["root_pre"], st["root_post"])
             tops, root = [local], local
             top_s = 0.0
             if distributed:

@@ -381,6 +381,8 @@ typedef struct {
     int streamed;                               /* ... 1 = fold nodes were proven as soon as their children existed (the default) */
     double preflight_cpu_s_sum;                 /* witness source 1: host CPU seconds spent in the sequential preflight, summed over segments */
     double trace_bytes;                         /* ... bytes that crossed PCIe as witness input (16 per cycle + the RAM image), summed */
+    uint32_t root_core[8];                      /* join_tree == 2: the OPENING of the claim' the root seal publishes (claim' = hash_pair(core, */
+    uint32_t root_pre, root_post;               /* (pre, post, 0..))): what a further join needs as witness for this receipt; never trusted */
 } zkh_prove_info;
 /* CircuitHal::accumulate for circuits without a built-in accum generator: fill `accum` (W_accum x 2^po2) from data + mix */
 typedef const char* (*zkh_accumulate_fn)(void* user, zkh_ctx*, const zkh_circuit*, size_t po2, const zkh_buf* data,

@@ -123,7 +123,8 @@ def test_lift_of_a_small_segment_matches_the_oracle_and_rejects_forgeries(hal, o
     code, data, accum, out = _device_traces(hal, prog, inputs)
     assert np.array_equal(data.to_vec(), odata) and np.array_equal(code.to_vec(), ocode) and np.array_equal(out, oout)
     # the lift's claim is the segment's claim digest (zkh_receipt_claim), its second half the allowed root it was handed
-    assert np.array_equal(out[:8], HostCircuit(desc).receipt_claim(rcpt.seal, croot)) and np.array_equal(out[8:], A)
+    from zeth_amd import recursion as host_rec
+    assert np.array_equal(out[:8], host_rec.wrap_claim(HostCircuit(desc).receipt_claim(rcpt.seal, croot), 0, 0)) and np.array_equal(out[8:], A)
     seal, _ = prog.prove(inputs, 0x2E80)
     assert np.array_equal(seal, oc.prove_traces(po2, ocode, odata, oout, ZK, 0x2E80))
     HostCircuit(R.recursion_circuit()).verify_segment(seal, prog.root)

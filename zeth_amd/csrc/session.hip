@@ -716,6 +716,7 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
         if (!errs.any()) {
             PNode& r = plan[root_node];
             info->root_seal = r.seal; info->root_seal_words = r.words; info->root_program = r.program;
+            memcpy(info->root_core, r.claim.core, 32); info->root_pre = r.claim.pre; info->root_post = r.claim.post;
             r.seal = nullptr;
         }
         for (auto& nd : plan) zkh_free_seal(nd.seal);

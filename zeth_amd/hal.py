@@ -42,7 +42,8 @@ class ProveInfo(C.Structure):
                 ("wall_s", C.c_double), ("leaves_s", C.c_double), ("join_s", C.c_double), ("witgen_s_sum", C.c_double), ("seal_s_sum", C.c_double),
                 ("n_lifts", C.c_size_t), ("root_program", C.c_size_t), ("lift_s", C.c_double),
                 ("n_retries", C.c_size_t), ("fold_tail_s", C.c_double), ("fold_busy_s_sum", C.c_double), ("streamed", C.c_int),
-                ("preflight_cpu_s_sum", C.c_double), ("trace_bytes", C.c_double)]
+                ("preflight_cpu_s_sum", C.c_double), ("trace_bytes", C.c_double),
+                ("root_core", C.c_uint32 * 8), ("root_pre", C.c_uint32), ("root_post", C.c_uint32)]
 
 
 # every symbol include/zkhal.h declares: (restype, argtypes)

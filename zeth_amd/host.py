@@ -350,7 +350,9 @@ class Session:
                      "n_lifts": int(info.n_lifts), "lift_s": info.lift_s, "root_program": int(info.root_program),
                      "witgen_s_sum": info.witgen_s_sum, "seal_s_sum": info.seal_s_sum, "verified": bool(verify),
                      "n_retries": int(info.n_retries), "fold_tail_s": info.fold_tail_s, "fold_busy_s_sum": info.fold_busy_s_sum,
-                     "streamed_fold": bool(info.streamed), "preflight_cpu_s_sum": info.preflight_cpu_s_sum, "trace_bytes": info.trace_bytes}
+                     "streamed_fold": bool(info.streamed), "preflight_cpu_s_sum": info.preflight_cpu_s_sum, "trace_bytes": info.trace_bytes,
+                     # join_tree = 2: the opening of the root's claim' (what a further join needs as witness for this receipt)
+                     "root_core": np.array(list(info.root_core), dtype=np.uint32), "root_pre": int(info.root_pre), "root_post": int(info.root_post)}
             return CompositeReceipt(recs), root, stats
         finally:
             self._hal._lib.zkh_prove_info_free(C.byref(info))
