@@ -689,6 +689,8 @@ def main() -> None:
             if distributed:
                 dist.all_reduce(cnt)
             certify = {"timed_seals_verified": int(cnt.item()), "seal_matches_golden": matches,
+                       "golden_is": "the SHA-256 of THIS repository's CPU oracle seal for the same seeds (tests/golden/large_digests.json): a regression pin "
+                                    "that ties the timed GPU seal to the oracle, not a vector held by the reference (it holds none for this path)",
                        "golden_seals_compared": len(zero) if golden is not None else 0,
                        "verify_ms_per_seal_host": 1e3 * (time.perf_counter() - t_v) / max(1, len(sealed))}
         # With several seals in flight the HIP-event brackets of one stream include time its kernels spent sharing the GPU

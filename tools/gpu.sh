@@ -5,6 +5,7 @@
 #   tests        the whole -m gpu suite + smoke()
 #   new [FILE]   one test file (default tests/test_round4_gpu.py), fail fast
 #   bench        the driver's command (python bench.py) + its 8-rank form on ONE GPU (ZKH_SHARE_GPUS=1)
+#   torchrun2    the driver's N > 1 launch shape (python -m torch.distributed.run ... bench.py --gpus 2) on ONE GPU
 #   succinct4    config 5's N-rank shape as 4 ranks on ONE GPU (native executor per rank + top joins on rank 0)
 #   config5      BASELINE config 5 (S = 1024 -> one succinct receipt): streamed pipeline, two phases, and the g++ host
 #   ab VAR       A/B of one env switch of the library (e.g. ZKH_MERKLE_FUSED): bench with and without VAR=1, 3 repeats each
@@ -68,6 +69,11 @@ for tag in ("off", "on"):
     print(tag, "serial", round(l["value"], 2), {o["op"]: round(o["ms_per_seal"], 3) for o in l["ops"][:6]})
 PY
   ;;
+torchrun2)
+  O=gpurun_out/${1:-torchrun2}; mkdir -p $O      # the driver's launch shape for N > 1 (torch.distributed.run), 2 ranks sharing the one GPU
+  ( time ZKH_SHARE_GPUS=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
+      bench.py --gpus 2 --steps 8 --warmup 2 > $O/bench_torchrun2.out 2> $O/err.txt; echo "rc=$?" ) 2> $O/time.txt
+  grep -c '^{"metric"' $O/bench_torchrun2.out; grep '^{"metric"' $O/bench_torchrun2.out | tail -1 > $O/bench_torchrun2.json; line $O/bench_torchrun2.json; grep real $O/time.txt ;;
 succinct4)
   O=gpurun_out/${1:-succinct4}; mkdir -p $O      # the N-rank shape of config 5 on ONE GPU: every rank seals + folds its aligned range natively, rank 0 joins the local roots
   ZKH_SHARE_GPUS=1 timeout 600 python bench.py --gpus 4 --config succinct --segments 32 --no-cpu-baseline > $O/bench_succinct_4rank_one_gpu.json 2> $O/err.txt; line $O/bench_succinct_4rank_one_gpu.json
