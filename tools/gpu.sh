@@ -5,8 +5,11 @@
 #   tests        the whole -m gpu suite + smoke()
 #   new [FILE]   one test file (default tests/test_round4_gpu.py), fail fast
 #   bench        the driver's command (python bench.py) + its 8-rank form on ONE GPU (ZKH_SHARE_GPUS=1)
+#   foldlanes    config 5 (g++ host, streamed) at 4 / 5 / 6 / 8 fold lanes per GPU
+#   inflight     the headline at 2 .. 6 seals in flight per GPU
 #   torchrun2    the driver's N > 1 launch shape (python -m torch.distributed.run ... bench.py --gpus 2) on ONE GPU
 #   succinct4    config 5's N-rank shape as 4 ranks on ONE GPU (native executor per rank + top joins on rank 0)
+#   chained      bench.py --config block --chained (S = 256 SYN-C segments, pre == prev.post checked after the clock)
 #   config5      BASELINE config 5 (S = 1024 -> one succinct receipt): streamed pipeline, two phases, and the g++ host
 #   ab VAR       A/B of one env switch of the library (e.g. ZKH_MERKLE_FUSED): bench with and without VAR=1, 3 repeats each
 #   profiles     everything profiles/ holds (tools/collect_profiles.sh)
@@ -44,6 +47,10 @@ bench)
   ( time timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err ) 2> $O/bench_default.time; line $O/bench_default.json
   ( time ZKH_SHARE_GPUS=1 timeout 900 python bench.py --gpus 8 --steps 6 --warmup 1 --no-heavy > $O/bench_8rank_one_gpu.json 2> $O/bench_8rank.err ) 2> $O/bench_8rank.time; line $O/bench_8rank_one_gpu.json
   grep real $O/*.time; tail -3 $O/bench_default.err | grep -v amdgpu.ids ;;
+chained)
+  O=gpurun_out/${1:-chained}; mkdir -p $O        # a chained block (claim continuity) and the same block with the host-preflight witness, full size
+  timeout 600 python bench.py --config block --chained --no-cpu-baseline > $O/bench_block_chained.json 2> $O/err.txt; line $O/bench_block_chained.json
+  grep -v amdgpu.ids $O/err.txt | tail -3 ;;
 config5)
   O=gpurun_out/${1:-config5}; mkdir -p $O
   timeout 900 python bench.py --config succinct --no-cpu-baseline > $O/bench_succinct_streamed.json 2> $O/err.txt; line $O/bench_succinct_streamed.json
@@ -69,6 +76,20 @@ for tag in ("off", "on"):
     print(tag, "serial", round(l["value"], 2), {o["op"]: round(o["ms_per_seal"], 3) for o in l["ops"][:6]})
 PY
   ;;
+foldlanes)
+  O=gpurun_out/${1:-foldlanes}; mkdir -p $O      # config 5 through the g++ host: fold lanes per GPU (the sealing lanes + fold-only contexts) with the streamed fold
+  D=/tmp/zkr; mkdir -p $D; python -m zeth_amd.circuits.rec_verify $D > /dev/null; python -m zeth_amd.circuits.recursion $D/recursion.desc > /dev/null
+  python -m zeth_amd.circuits.syn_air syn_a /tmp/syn_a.desc > /dev/null
+  for k in 6 4 5 8; do
+    LD_LIBRARY_PATH=$PWD/zeth_amd ZKH_FOLD_LANES=$k timeout 600 examples/prove_session --desc /tmp/syn_a.desc --recursion-dir $D --segments 1024 --noise-seed 11904 > $O/fold_lanes_$k.json 2>> $O/err.txt
+    echo -n "fold lanes $k: "; cut -c150-420 $O/fold_lanes_$k.json
+  done ;;
+inflight)
+  O=gpurun_out/${1:-inflight}; mkdir -p $O       # seals in flight per GPU: the headline at 2 / 3 / 4 / 5 / 6 lanes, twice each, interleaved
+  for rep in 1 2; do for k in 3 2 4 5 6; do
+    timeout 300 python bench.py --inflight $k --no-cpu-baseline --no-heavy --no-resident --no-block --no-live-traffic --no-certify --no-prof > $O/k${k}_$rep.json 2>> $O/err.txt
+    echo -n "inflight $k: "; line $O/k${k}_$rep.json
+  done; done ;;
 torchrun2)
   O=gpurun_out/${1:-torchrun2}; mkdir -p $O      # the driver's launch shape for N > 1 (torch.distributed.run), 2 ranks sharing the one GPU
   ( time ZKH_SHARE_GPUS=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
