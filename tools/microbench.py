@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-op micro-benchmarks M1..M8 of SURVEY.md §8d on one MI355X, through the C ABI (HipHal).
+"""Per-op micro-benchmarks M1..M8 of SURVEY.md §8d (+ M9: the trace-driven witness, row f1) on one MI355X, through the C ABI (HipHal).
 
 Each line of output is one JSON object: the op, its shape, the average wall time of one call (stream drained on both
 sides of `reps` back-to-back calls), its ALGORITHMIC bytes (SURVEY.md §8a "B_alg": inputs read once + outputs written
@@ -182,6 +182,29 @@ def main() -> None:
         dt = timed(hal, lambda: hcirc.eval_check(check, groups, globals_, mix, args.po2, use_interpreter=True), 1)
         line("M8hi", "eval_check (SYN-HEAVY, step-list interpreter)", f"{sum(hd.group_sizes)} cols x 2^{args.po2 + 2} points",
              dt, 4 * sum(hd.group_sizes) * dom + 16 * dom)
+    if want("M9"):
+        # row f1: the trace-driven witness — host preflight (sequential, one core), then upload + row fill + scan + scatter on the GPU
+        from zeth_amd import hal as H
+        desc = syn_air.syn_a()
+        d = Desc.parse(desc)
+        circ = hal.load_circuit(desc)
+        wa, wc, wd = d.group_sizes
+        A = n - 1994
+        pinned = hal.host_alloc(4 * A)
+        t0 = time.perf_counter()
+        _, ram, cpu_s = H.syn_preflight(0x5EED0000, args.po2, records=pinned)
+        line("M9p", "syn_preflight (host, one core: the sequential producer)", f"2^{args.po2} cycles -> {16 * A / 1e6:.1f} MB of records",
+             time.perf_counter() - t0, 16 * A)
+        drec, data = hal.alloc("records", 4 * A), hal.alloc_elem("data", wd * n)
+
+        def fill():
+            hal.write_async(drec, pinned)
+            hal.syn_witgen_trace(circ, args.po2, 1994, 0x2E80, drec, ram, None, data)
+        dt = timed(hal, fill, args.reps)
+        line("M9", "upload of the compact trace + k_syn_rowfill + running-sum scan + preload scatter", f"{wd} x 2^{args.po2} data group from 16-byte records",
+             dt, 16 * A + 4 * wd * n)
+        hal.sync()
+        hal.host_free(pinned)
     hal.close()
 
 
