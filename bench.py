@@ -373,11 +373,15 @@ def main() -> None:
 
     # one GPU per rank; ZKH_SHARE_GPUS=1 lets ranks wrap around the visible devices (dry runs on a 1-GPU box)
     device = local_rank
+    try:
+        visible = int(torch.cuda.device_count())
+    except (RuntimeError, AssertionError):
+        visible = 0
     if os.environ.get("ZKH_SHARE_GPUS"):
-        try:
-            device = local_rank % max(1, torch.cuda.device_count())
-        except (RuntimeError, AssertionError):
-            device = 0
+        device = local_rank % max(1, visible)
+    elif 0 < visible <= local_rank:
+        # a launcher that narrows HIP_VISIBLE_DEVICES per rank (every rank sees ITS GPU as device 0): follow it instead of failing
+        device = local_rank % visible
     # host placement: this rank's threads (and the pinned blocks they allocate) next to its GPU's root port; the ranks whose
     # GPUs share a NUMA node split that node's cores (csrc/topology.hip; ZKH_AFFINITY=off leaves the process alone)
     try:
@@ -387,7 +391,7 @@ def main() -> None:
     placement = {"numa_node": -1, "cpus": 0, "cpus_before": len(cpus_before or [])}
     try:
         from zeth_amd import hal as _zhal
-        slot, share = (0, 1) if os.environ.get("ZKH_SHARE_GPUS") else _zhal.placement_slot(device, list(range(world)))
+        slot, share = (0, 1) if os.environ.get("ZKH_SHARE_GPUS") or visible < world else _zhal.placement_slot(device, list(range(world)))
         placement = _zhal.bind_to_device(device, slot, share)
         placement.update(slot=slot, share=share, pci_bus_id=_zhal.device_numa_node(device)[1])
     except Exception as e:                               # placement is an optimisation, never a dependency
