@@ -320,3 +320,26 @@ def test_chained_session_folds_to_one_receipt_whose_joins_asserted_continuity(ha
     with pytest.raises(HalError, match="do not chain|assertion of the program fails"):
         sess.prove(loose, join_tree=2, join_noise_seed=0x78)
     sess.close()
+
+
+def test_session_over_a_device_list_with_streamed_fold(hal):
+    """The G devices x K lanes shape of the executor (here the device list names GPU 0 twice: two "devices" x 2 lanes + their
+    fold-only lanes): segments and fold nodes are pulled by lanes of both, receipts come back in index order and the root equals
+    the single-device session's word for word."""
+    from zeth_amd import recursion as rec
+    from zeth_amd.host import Session
+    from zeth_amd.prover import Segment, SegmentProver
+    desc = syn_air.syn_small()
+    sp = SegmentProver(hal, desc)
+    segs = [Segment(index=i, po2=13 if i != 5 else 12, seed=1700 + i, noise_seed=0x56) for i in range(9)]
+    programs = rec.build_programs(desc, {13: sp.control_root(13), 12: sp.control_root(12)})
+    roots = {}
+    for devices in ((0,), (0, 0)):
+        sess = Session(desc, devices=devices, lanes_per_device=2)
+        sess.set_recursion(programs)
+        comp, root, st = sess.prove(segs, join_tree=2, join_noise_seed=0x79, verify=True)
+        assert [r.index for r in comp.segments] == list(range(9)) and st["n_retries"] == 0
+        roots[devices] = (root.seal.copy(), [r.seal.copy() for r in comp.segments])
+        sess.close()
+    assert np.array_equal(roots[(0,)][0], roots[(0, 0)][0])
+    assert all(np.array_equal(a, b) for a, b in zip(roots[(0,)][1], roots[(0, 0)][1]))
