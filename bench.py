@@ -1409,6 +1409,30 @@ def main() -> None:
     if rank == 0 and line is not None:
         for fn in after_group:
             fn()
+        # the secondary measurements of this run once more, INSIDE `config` (a record that keeps only the contract's keys then still
+        # holds them): nothing here is `value`
+        also = {}
+        if isinstance(line.get("syn_heavy"), dict):
+            also["syn_heavy_segments_per_s"] = round(line["syn_heavy"]["segments_per_s"], 3)
+        if isinstance(line.get("code_group_resident"), dict):
+            also["code_group_resident_segments_per_s"] = round(line["code_group_resident"]["segments_per_s"], 3)
+        blk = line.get("block")
+        if isinstance(blk, dict):
+            also["block"] = {"segments": blk["segments"], "wall_clock_s": round(blk["wall_clock_s"], 4), "segments_per_s": round(blk["segments_per_s"], 3),
+                             "recompute_code_group_segments_per_s": round((blk.get("recompute_code_group") or {}).get("segments_per_s", 0.0), 3) or None}
+            pre = blk.get("host_preflight_pipeline")
+            if isinstance(pre, dict) and "segments_per_s" in pre:
+                also["host_preflight_pipeline"] = {"segments_per_s": round(pre["segments_per_s"], 3),
+                                                   "host_cpu_ms_per_segment": round(pre["host_preflight_cpu_ms_per_segment"], 2),
+                                                   "pcie_MB_per_segment": round(pre["pcie_bytes_per_segment"] / 1e6, 2)}
+            if isinstance(blk.get("recursive"), dict):
+                also["block_fold_to_one_receipt_s"] = round(blk["recursive"]["fold_s"], 4)
+        if isinstance(line.get("recursion"), dict):
+            also["fold"] = {k: line["recursion"].get(k) for k in ("fold", "proofs", "fold_tail_s", "leaves_s")}
+        if "seal_wall_clock_unloaded_s" in line:
+            also["seal_wall_clock_unloaded_s"] = round(line["seal_wall_clock_unloaded_s"], 5)
+        if also:
+            line["config"]["also_measured"] = also
         print(json.dumps(line))
 
 
