@@ -86,3 +86,41 @@ def test_check_upstream_receipt_tool(tmp_path):
     q.write_bytes(b"\x07\x00\x00\x00" + bytes(64))
     r = subprocess.run([sys.executable, tool, str(q)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "DECODE FAILED" in r.stdout and "variant index 7" in r.stdout
+
+
+def test_this_repositorys_receipts_travel_in_upstreams_containers(oracle):
+    """A composite of oracle-sealed segments -> bincode `Receipt{inner: Composite}` -> back: the seals verify again; a recursion
+    receipt -> `Receipt{inner: Succinct}` carries its control id and the membership path of its program as the inclusion proof."""
+    import zko
+    from zeth_amd import recursion as host_rec
+    from zeth_amd.circuits import syn_air
+    from zeth_amd.host import CompositeReceipt, hash_pair
+    from zeth_amd.prover import SegmentReceipt
+    desc = syn_air.syn_tiny()
+    oc = zko.OracleCircuit(oracle, desc)
+    po2, zk = 9, 100
+    root = oc.control_root(po2, zk)
+    recs = []
+    for i in range(3):
+        seal = oc.prove(po2, zk, 40 + i, 0x2E80)
+        recs.append(SegmentReceipt(seal=seal, index=i, po2=po2, output=seal[:4].copy()))
+    blob = CompositeReceipt(recs).to_upstream_bytes(desc, root, journal=b"\x01\x02\x03\x04")
+    val = rc.decode(rc.Receipt, blob)
+    assert val["journal"]["bytes"] == b"\x01\x02\x03\x04" and [s["hashfn"] for s in val["inner"][1]["segments"]] == ["poseidon2"] * 3
+    back = CompositeReceipt.from_upstream_bytes(blob, out_size=4)
+    assert [r.po2 for r in back.segments] == [po2] * 3
+    for a, b in zip(recs, back.segments):
+        assert np.array_equal(a.seal, b.seal) and a.index == b.index
+        assert oc.verify(b.seal, root) is None
+    # a recursion receipt as a SuccinctReceipt: the inclusion proof is the program's path in the allowed-programs tree
+    roots = [np.full(8, i + 1, np.uint32) for i in range(3)]
+    levels = host_rec.allowed_tree(roots)
+    fake = host_rec.RecReceipt(np.arange(40, dtype=np.uint32), 16, 2, roots[2])
+    sv = rc.decode(rc.Receipt, fake.to_upstream_bytes(levels))["inner"]
+    assert sv[0] == "Succinct" and sv[1]["control_id"] == [3] * 8 and sv[1]["control_inclusion_proof"]["index"] == 2
+    cur, idx = roots[2], 2
+    for d in sv[1]["control_inclusion_proof"]["digests"]:                       # the proof folds to the allowed root
+        d = np.asarray(d, dtype=np.uint32)
+        cur = hash_pair(d, cur) if idx & 1 else hash_pair(cur, d)
+        idx >>= 1
+    assert np.array_equal(cur, levels[-1][0]) and sv[1]["verifier_parameters"] == [int(w) for w in levels[-1][0]]

@@ -135,6 +135,31 @@ class CompositeReceipt:
                                      f"its predecessor ended in {prev}")
                 prev = int(s.seal[CHAIN_POST])
 
+    def to_upstream_bytes(self, circuit_desc, control_root=None, journal: bytes = b"") -> bytes:
+        """This composite in upstream's wire format: bincode `Receipt{inner: Composite{segments, ..}, journal, metadata}`
+        (receipt_codec.py: layouts RECALLED from risc0-zkvm 3.0.3).  Every segment carries its seal, index, hashfn and — in the
+        pruned `post` slot of a placeholder `ReceiptClaim` — its claim digest (these circuits have no rv32im SystemState)."""
+        from . import receipt_codec as rc
+        from .prover import shipped_control_root
+        root_of = lambda s: _root_for(control_root, s.po2) if control_root is not None else shipped_control_root(circuit_desc, s.po2)
+        segs = [(s.seal, s.index, receipt_claim(s, circuit_desc, root_of(s))) for s in self.segments]
+        return rc.composite_receipt_bytes(segs, journal=journal)
+
+    @staticmethod
+    def from_upstream_bytes(data: bytes, out_size: int) -> "CompositeReceipt":
+        """decode the bincode container back into segment receipts (seal, index; po2 from the seal header)"""
+        import numpy as np
+        from . import receipt_codec as rc
+        from .hal import fp_decode
+        val = rc.decode(rc.Receipt, data)
+        if val["inner"][0] != "Composite":
+            raise ValueError(f"not a composite receipt: {val['inner'][0]}")
+        segs = []
+        for s in val["inner"][1]["segments"]:
+            seal = np.asarray(s["seal"], dtype=np.uint32)
+            segs.append(SegmentReceipt(seal=seal, index=s["index"], po2=fp_decode(int(seal[out_size])), hashfn=s["hashfn"], output=seal[:out_size].copy()))
+        return CompositeReceipt(segs)
+
     def final_state(self) -> int:
         """post-state word of the last segment of a chained session (Montgomery form)"""
         from .circuits.syn_air import CHAIN_POST

@@ -114,6 +114,18 @@ class RecReceipt:
     def allowed(self) -> np.ndarray:
         return np.asarray(self.seal[8:16], dtype=np.uint32)
 
+    def to_upstream_bytes(self, allowed_levels, journal: bytes = b"") -> bytes:
+        """This receipt in upstream's wire format: bincode `Receipt{inner: Succinct{seal, control_id, claim, hashfn,
+        verifier_parameters, control_inclusion_proof}, ..}` (receipt_codec.py, RECALLED layouts): control_id = the program's control
+        root, the inclusion proof = its membership path in the allowed-programs tree (`allowed_tree` levels), the claim digest in
+        the placeholder claim's pruned `post` slot."""
+        from . import receipt_codec as rc
+        idx, digests = self.program, []
+        for lvl in allowed_levels[:-1]:
+            digests.append([int(w) for w in lvl[idx ^ 1]])
+            idx >>= 1
+        return rc.succinct_receipt_bytes(self.seal, self.control_root, self.claim, journal, self.program, digests, verifier_parameters=allowed_levels[-1][0])
+
     def verify(self, allowed_roots: Sequence[np.ndarray], leaf_claims: Optional[Sequence[np.ndarray]] = None) -> None:
         """Host check of the whole tree below this receipt: ONE seal verification, the program's membership in the allowed
         set, the allowed root the receipt carries, and (given the leaves: receipt claims, or (claim, pre, post) for circuits with a
