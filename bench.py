@@ -309,6 +309,9 @@ def main() -> None:
     ap.add_argument("--fold", choices=("streamed", "phased"), default="streamed",
                     help="native executor: prove a lift2 / join the moment its children exist, concurrently with the sealing lanes (one pipeline), "
                          "or seal everything first and fold afterwards (two phases)")
+    ap.add_argument("--witness", choices=("device", "preflight"), default="device",
+                    help="succinct config (native executor): where a segment's witness comes from - the closed-form generator on the device, or upstream's "
+                         "shape: a sequential host preflight per segment (producer threads), its compact records uploaded and row-filled on the GPU")
     ap.add_argument("--chained", action="store_true", help="block config: SYN-C segments whose pre-state is their predecessor's post-state (claim continuity), through the native session executor")
     ap.add_argument("--recompute-code", action="store_true", help="block / succinct: re-commit the code group for every segment (upstream's SegmentProver) instead of keeping it resident")
     ap.add_argument("--no-fused-lift", action="store_true", help="recursion: lift every segment on its own and join (three proofs per pair at the bottom level) instead of lift2")
@@ -1131,6 +1134,8 @@ def main() -> None:
             sess.set_recursion(programs)
             sess.set_streamed_fold(args.fold == "streamed")
             sess.set_resident_code(not args.recompute_code)
+            if args.witness == "preflight":                    # upstream's whole shape: host preflight -> row fill -> seal -> join-as-you-go
+                sess.set_witness_source(1, args.preflight_producers)
             load_s = time.perf_counter() - t_b
             # warm-up: a short session of the same shape (every segment size, every program kind, pools, clocks)
             wsegs = [segs[0]] * (2 * max(args.fold_inflight, inflight)) + [segs[0], segs[-1]]
@@ -1160,8 +1165,8 @@ def main() -> None:
                     top_s = time.perf_counter() - t_top
             barrier()
             dt = time.perf_counter() - t0
-            tt = torch.tensor([dt, st["leaves_s"], st["fold_tail_s"], st["fold_busy_s_sum"], float(st["n_retries"]), st["witgen_s_sum"], float(len(mine))],
-                              dtype=torch.float64, device=ctrl_dev)
+            tt = torch.tensor([dt, st["leaves_s"], st["fold_tail_s"], st["fold_busy_s_sum"], float(st["n_retries"]), st["witgen_s_sum"], float(len(mine)),
+                               st["preflight_cpu_s_sum"], st["trace_bytes"]], dtype=torch.float64, device=ctrl_dev)
             if distributed:
                 mx = tt[:3].clone()
                 dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -1200,6 +1205,10 @@ def main() -> None:
                 n_fused = sum(1 for k in range(len(mine) // 2) if ("lift2", segs[mine[2 * k]].po2, segs[mine[2 * k + 1]].po2) in kinds)
                 all_fused = n_fused == len(mine) // 2 and len(mine) > 1
                 rstats = {"executor": "native: one zkh_session_prove(join_tree = 2) call per rank (csrc/session.hip), no Python in the loop",
+                          "witness": ("host preflight: a sequential per-cycle machine on producer threads ahead of the seals, 16 bytes per cycle over PCIe, row fill "
+                                      "on the GPU" if args.witness == "preflight" else "closed-form generator on the device"),
+                          "host_preflight_cpu_ms_per_segment": 1e3 * float(tt[7]) / max(1.0, float(tt[6])) if args.witness == "preflight" else None,
+                          "pcie_bytes_per_segment": float(tt[8]) / max(1.0, float(tt[6])) if args.witness == "preflight" else None,
                           "fold": args.fold, "streamed_fold": st["streamed_fold"], "code_group": "recomputed per segment" if args.recompute_code else "resident per lane and size",
                           "bottom_level_proofs": st["n_lifts"] * world, "fused_lift2": (len(mine) // 2) * world if all_fused else 0,
                           "joins": st["n_joins"] * world + (world - 1), "proofs": (st["n_lifts"] + st["n_joins"]) * world + (world - 1),

@@ -50,6 +50,7 @@ bench)
 chained)
   O=gpurun_out/${1:-chained}; mkdir -p $O        # a chained block (claim continuity) and the same block with the host-preflight witness, full size
   timeout 600 python bench.py --config block --chained --no-cpu-baseline > $O/bench_block_chained.json 2> $O/err.txt; line $O/bench_block_chained.json
+  timeout 900 python bench.py --config succinct --witness preflight --no-cpu-baseline > $O/bench_succinct_preflight.json 2>> $O/err.txt; line $O/bench_succinct_preflight.json
   grep -v amdgpu.ids $O/err.txt | tail -3 ;;
 config5)
   O=gpurun_out/${1:-config5}; mkdir -p $O

@@ -794,22 +794,37 @@ extern "C" const char* zkh_session_verify(zkh_session* s, const zkh_segment* seg
     std::unique_ptr<zkh_circuit, void (*)(zkh_circuit*)> hold(hc, zkh_circuit_destroy);
     std::vector<std::pair<uint32_t, std::vector<uint32_t>>> roots;
     std::vector<std::vector<uint32_t>> claims(info->n_segments, std::vector<uint32_t>(8));
-    for (size_t i = 0; i < info->n_segments; i++) {
-        const uint32_t po2 = segs[i].po2;
-        const std::vector<uint32_t>* root = nullptr;
-        for (auto& r : roots) if (r.first == po2) root = &r.second;
-        if (!root) {
+    for (size_t i = 0; i < info->n_segments; i++) {          // the control root of every segment size first (lane 0's GPU for built-in circuits)
+        bool have = false;
+        for (auto& r : roots) have = have || r.first == segs[i].po2;
+        if (!have) {
             std::vector<uint32_t> cr(8);
             ZKH_TRY(leaf_control_root(s, segs[i], cr.data()));
-            roots.emplace_back(po2, cr);
-            root = &roots.back().second;
+            roots.emplace_back(segs[i].po2, cr);
         }
-        if (const char* e = zkh_verify_segment(hc, info->seals[i], info->seal_words[i], root->data(), nullptr, nullptr)) {
-            const char* out = make_err("session_verify: segment %zu: %s", i, e);
-            zkh_free_error(e);
-            return out;
-        }
-        ZKH_TRY(zkh_receipt_claim(hc, info->seals[i], info->seal_words[i], root->data(), nullptr, nullptr, claims[i].data()));
+    }
+    {
+        // the segment seals are independent and the verifier is pure host arithmetic on read-only data: spread them over host
+        // threads (upstream verifies them in a loop; 1024 seals x 7 ms is 7 s on one core)
+        ErrorSlot verrs;
+        std::atomic<size_t> next{0};
+        const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), (size_t)16, info->n_segments}));
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < n_threads; t++)
+            th.emplace_back([&] {
+                for (;;) {
+                    const size_t i = next.fetch_add(1);
+                    if (i >= info->n_segments || verrs.any()) return;
+                    const uint32_t* root = nullptr;
+                    for (auto& r : roots) if (r.first == segs[i].po2) root = r.second.data();
+                    char what[48];
+                    snprintf(what, sizeof what, "segment %zu", i);
+                    if (verrs.set(zkh_verify_segment(hc, info->seals[i], info->seal_words[i], root, nullptr, nullptr), what)) return;
+                    if (verrs.set(zkh_receipt_claim(hc, info->seals[i], info->seal_words[i], root, nullptr, nullptr, claims[i].data()), what)) return;
+                }
+            });
+        for (auto& t : th) t.join();
+        if (verrs.any()) return make_err("session_verify: %s", verrs.first.c_str());
     }
     if (s->chained) {          // continuity (CompositeReceipt::verify_integrity): pre == prev.post, read from the verified seals' `out` words
         uint32_t prev = fp_encode(s->initial_state).v;
