@@ -194,10 +194,11 @@ def test_join_schedule_shape_and_placement():
         join_schedule(0, 1)
 
 
-def test_codegen_value_numbering_windows_and_splitting():
+def test_codegen_value_numbering_windows_and_splitting(monkeypatch):
     """circuits/codegen.py on a constraint system of realistic shape: structurally identical sub-expressions collapse,
     the leaves are cut into parts that cover every constraint exactly once, every part is a self-contained kernel."""
     from zeth_amd.circuits import syn_heavy
+    monkeypatch.setenv("ZKH_CODEGEN_PART", "1600")           # the small circuit in several parts (the shipped weight keeps it whole)
     desc = syn_heavy.syn_heavy_small()
     c = Circuit.parse(desc)
     plan = codegen.Plan.build(c)
@@ -215,6 +216,12 @@ def test_codegen_value_numbering_windows_and_splitting():
     for k, src in parts:
         assert f'extern "C" __global__ __launch_bounds__(256) void {k}(EvalCheckArgs a)' in src
         assert "a.accumulate" in src and "tap_load(" in src and "volatile" not in src
+        # the part's own power table: slots 0, 1, 2, ... in the order the code reads them, exponents exported beside the kernel
+        import re
+        slots = [int(x) for x in re.findall(r"pwp\[(\d+)\]", src)]
+        assert sorted(set(slots)) == list(range(len(set(slots))))
+        exps = [int(x) for x in re.search(rf"{k}_exps\[\] = \{{([^}}]*)\}}", src).group(1).split(",")]
+        assert exps[0] == len(exps) - 1 == len(set(slots)) and all(e < n_pows for e in exps[1:])
     # a small circuit stays one kernel with the historical name
     one, _, _ = codegen.emit_parts("syn_tiny", syn_air.syn_tiny())
     assert [k for k, _ in one] == ["k_eval_check_syn_tiny"]
@@ -228,6 +235,7 @@ def test_multi_part_jit_cross_compiles_with_verified_cache(tmp_path, monkeypatch
     if jit.hipcc_path() is None:
         pytest.skip("hipcc not installed")
     monkeypatch.setenv("ZKH_JIT_CACHE", str(tmp_path))
+    monkeypatch.setenv("ZKH_CODEGEN_PART", "1600")
     desc = syn_heavy.syn_heavy_small()
     objs = jit.compile_code_objects(desc)
     assert len(objs) >= 2 and all(img[:4] == b"\x7fELF" or img.startswith(b"__CLANG_OFFLOAD_BUNDLE__") for img, _ in objs)

@@ -366,6 +366,7 @@ def test_syn_heavy_eval_check_generated_interpreted_and_oracle_agree(hal, oracle
     import ctypes as C
     from zeth_amd.circuits import syn_heavy
     monkeypatch.setenv("ZKH_JIT_CACHE", str(tmp_path))
+    monkeypatch.setenv("ZKH_CODEGEN_PART", "1600")          # several parts (the shipped weight keeps this small circuit whole)
     desc = syn_heavy.syn_heavy_small()
     prover = SegmentProver(hal, desc)
     assert prover.circuit.kernel_kind() == "attached" and prover.circuit.compiled_parts() >= 2
@@ -463,7 +464,7 @@ def test_combos_divide_all_matches_sequential_division(hal, oracle):
     assert np.array_equal(rem_out.to_vec(), want_rem)
 
 
-def test_cpp_host_attaches_code_objects_and_writes_receipts(tmp_path):
+def test_cpp_host_attaches_code_objects_and_writes_receipts(tmp_path, monkeypatch):
     """A non-Python host with a circuit that is NOT built into the library: the generated eval_check kernels arrive as code
     objects (`python -m zeth_amd.circuits.jit` wrote them + a manifest ahead of time), examples/seal_segments attaches them
     through zkh_circuit_attach_code_object_part, seals, verifies against the control root and writes receipt containers,
@@ -472,6 +473,7 @@ def test_cpp_host_attaches_code_objects_and_writes_receipts(tmp_path):
     from zeth_amd import build
     from zeth_amd.circuits import jit, syn_heavy
     from zeth_amd.prover import SegmentReceipt
+    monkeypatch.setenv("ZKH_CODEGEN_PART", "1600")
     desc = syn_heavy.syn_heavy_small()                      # two kernels, no built-in match
     desc_path = tmp_path / "c.desc"
     np.asarray(desc, dtype="<u4").tofile(desc_path)

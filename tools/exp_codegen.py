@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "syn_heavy"
     variants = sys.argv[2:] or ["REGS=72", "REGS=96", "REGS=128"]
-    knobs = ("REGS", "EPOCH", "PART", "SOP", "PREFETCH", "LAZY", "FLAGS")
+    knobs = ("REGS", "EPOCH", "PART", "SOP", "PREFETCH", "LAZY", "FLAGS", "GATHER", "LOCALITY", "LOCWIN")
     po2 = int(os.environ.get("EXP_PO2", "20"))
     from zeth_amd.circuits import codegen, jit
     from zeth_amd.hal import HipHal
@@ -48,7 +48,7 @@ def main():
     poly_mix = np.array([5, 6, 7, 8], dtype=np.uint32)
     check = hal.alloc_elem("check", 4 * dom)
 
-    def timed(reps=3):
+    def timed(reps=10):
         circ.eval_check(check, ev, [g_out, g_mix], poly_mix, po2)
         hal.sync()
         t0 = time.perf_counter()

@@ -46,19 +46,25 @@ R1 = pow(2, 32, P)           # Montgomery one
 USE_SOP = os.environ.get("ZKH_CODEGEN_SOP", "1") != "0"     # sums of products as one 64-bit chain + one reduction
 REG_BUDGET = int(os.environ.get("ZKH_CODEGEN_REGS", "96"))      # values (taps + intermediates) the register cache of a kernel holds
 EPOCH_LOADS = int(os.environ.get("ZKH_CODEGEN_EPOCH", "48"))    # tap loads per offset epoch
-PART_WEIGHT = int(os.environ.get("ZKH_CODEGEN_PART", "3200"))   # value steps per generated kernel (~ one translation unit / code object)
+PART_WEIGHT = int(os.environ.get("ZKH_CODEGEN_PART", "6400"))   # value steps per generated kernel (~ one translation unit / code object)
 USE_LAZY = int(os.environ.get("ZKH_CODEGEN_LAZY", "1"))
-PREFETCH = int(os.environ.get("ZKH_CODEGEN_PREFETCH", "4"))    # tap loads issued this many constraints ahead of their first use
-# Order the constraints of a chain by tap-set locality (Plan.order_by_locality).  MEASURED, OFF by default
-# (profiles/r03_eval_check_locality.txt): it cuts the tap loads per point by 23 % (SYN-HEAVY) / 37 % (KECCAK-F) but scatters
-# the constraints' mix-power exponents, whose scalar loads then no longer merge (s_load_dwordx16 -> x4) and spill SGPRs
-# (+6.2 k v_readlane / v_writelane per point): SYN-HEAVY eval_check 12.41 -> 12.87 ms.  The kernels are VALU-bound, not
-# fetch-bound; fewer loads alone buy nothing.
-LOCALITY = int(os.environ.get("ZKH_CODEGEN_LOCALITY", "0"))
-LOCALITY_WINDOW = max(16, REG_BUDGET * 2 // 3)                 # taps assumed resident when the next constraint is chosen
+PREFETCH = int(os.environ.get("ZKH_CODEGEN_PREFETCH", "8"))    # tap loads issued this many constraints ahead of their first use
+# Order the constraints of a chain by tap-set locality (Plan.order_by_locality): 23 % (SYN-HEAVY) / 37 % (KECCAK-F) fewer tap
+# loads per point.  On its own it LOST (round 3, profiles/r03_eval_check_locality.txt: 12.41 -> 12.87 ms): it scatters the
+# constraints' mix-power exponents, whose scalar loads then no longer merge (s_load_dwordx16 -> x4) and spill SGPRs (+6.2 k
+# v_readlane / v_writelane per point).  With GATHER (below) the powers are consecutive in ANY emission order and it pays
+# (round 4, profiles/r04_eval_check_gather.txt): SYN-HEAVY 13.8 -> 13.2 ms, KECCAK-F 1.29 -> 1.14 ms, bit-exact.
+LOCALITY = int(os.environ.get("ZKH_CODEGEN_LOCALITY", "1"))
+LOCALITY_WINDOW = int(os.environ.get("ZKH_CODEGEN_LOCWIN", "0")) or max(16, REG_BUDGET * 2 // 3)   # taps assumed resident when the next constraint is chosen
+# The mix powers a part reads, GATHERED into emission order (slot k of the part's table = the k-th power its code touches): the
+# scalar loads of consecutive constraints are consecutive again whatever order the constraints are emitted in, so they merge
+# (s_load_dwordx16: 587 -> 783 over SYN-HEAVY's 13 kernels) and no SGPR spills into VGPR lanes (v_readlane + v_writelane
+# 1 464 -> 0).  The kernel exports its exponent list (`exps_<kernel>` / `<kernel>_exps`, first word = count); circuit.hip computes
+# the per-call power table through it (mix^exps[i], ONE small launch, as before) and hands every part its own slice.
+GATHER = int(os.environ.get("ZKH_CODEGEN_GATHER", "1"))
 # compile flags of the generated translation units (build.py and jit.py use the same list)
 KERNEL_FLAGS = [f for f in os.environ.get("ZKH_CODEGEN_FLAGS", "").split() if f]
-GENERATOR_VERSION = 8
+GENERATOR_VERSION = 9
 
 
 def desc_hash64(desc: np.ndarray) -> int:
@@ -453,8 +459,11 @@ class Plan:
         return w
 
 
-def split_points(weights: List[int], part_weight: int = PART_WEIGHT) -> List[Tuple[int, int]]:
-    """Cut the leaf sequence into contiguous [lo, hi) ranges of roughly part_weight each."""
+def split_points(weights: List[int], part_weight: Optional[int] = None) -> List[Tuple[int, int]]:
+    """Cut the leaf sequence into contiguous [lo, hi) ranges of roughly part_weight each (default: ZKH_CODEGEN_PART as it is
+    NOW, else PART_WEIGHT — read at call time so that a test can ask for a multi-part split of a small circuit)."""
+    if part_weight is None:
+        part_weight = int(os.environ.get("ZKH_CODEGEN_PART", PART_WEIGHT))
     total = sum(weights)
     n_parts = max(1, -(-total // part_weight))
     target = total / n_parts
@@ -499,6 +508,7 @@ class _Emitter:
         self.folded: Dict[int, bool] = {}   # depth -> s{d}_* carries a folded (unreduced) part of the total
         self.globals_used: set = set()
         self.leaf = 0                       # depth-first index of the next leaf
+        self.pw_exps: List[int] = []        # GATHER: the exponent behind every slot of this part's power table, in emission order
         self.epoch = -1
         self.epoch_loads = EPOCH_LOADS      # forces an epoch before the first load
         self.epoch_backs: List[set] = []
@@ -721,6 +731,13 @@ class _Emitter:
         self.n_arith += 1
         self.cache[v] = name
 
+    def pw(self, e: int) -> int:
+        """Index of mix^e in the table this kernel reads: e itself, or (GATHER) the next slot of the part's own table."""
+        if not GATHER:
+            return e
+        self.pw_exps.append(e)
+        return len(self.pw_exps) - 1
+
     # ---- accumulators ----
     def use_depth(self, d: int) -> None:
         self.depth_used = max(self.depth_used, d + 1)
@@ -781,7 +798,7 @@ class _Emitter:
                     # tot += mix^e * x for an Fp4 x: sixteen products straight into the unreduced sums (four units of room)
                     if self.pend.get(d, 0) > 0:
                         self.fold(d)
-                    self.w(f"    ext_accumulate(s{d}_0, s{d}_1, s{d}_2, s{d}_3, pwp[{e}], {self.ext_ref(v)});")
+                    self.w(f"    ext_accumulate(s{d}_0, s{d}_1, s{d}_2, s{d}_3, pwp[{self.pw(e)}], {self.ext_ref(v)});")
                     self.release()
                     self.pend[d] = 4
                     continue
@@ -791,7 +808,7 @@ class _Emitter:
                 wgt = 2 if v in self.p.lazy else 1      # a lazy value (< 2P) makes a product below 2 P^2
                 if self.pend.get(d, 0) + wgt > 4:
                     self.fold(d)
-                self.w(f"    {{ const uint4 p_ = pwp[{e}]; s{d}_0 += (uint64_t)p_.x * {r}; s{d}_1 += (uint64_t)p_.y * {r}; "
+                self.w(f"    {{ const uint4 p_ = pwp[{self.pw(e)}]; s{d}_0 += (uint64_t)p_.x * {r}; s{d}_1 += (uint64_t)p_.y * {r}; "
                        f"s{d}_2 += (uint64_t)p_.z * {r}; s{d}_3 += (uint64_t)p_.w * {r}; }}")
                 self.release()
                 self.pend[d] = self.pend.get(d, 0) + wgt
@@ -812,7 +829,8 @@ class _Emitter:
                 tin = f"Fp4(Fp::raw(t{d + 1}_0), Fp::raw(t{d + 1}_1), Fp::raw(t{d + 1}_2), Fp::raw(t{d + 1}_3))"
                 prod = f"{tin} * {self.ext_ref(cond)}" if self.p.ext[cond] else f"{tin} * Fp::raw({self.ref(cond)})"
                 if e != 0:
-                    prod = f"({prod}) * Fp4(Fp::raw(pwp[{e}].x), Fp::raw(pwp[{e}].y), Fp::raw(pwp[{e}].z), Fp::raw(pwp[{e}].w))"
+                    k = self.pw(e)
+                    prod = f"({prod}) * Fp4(Fp::raw(pwp[{k}].x), Fp::raw(pwp[{k}].y), Fp::raw(pwp[{k}].z), Fp::raw(pwp[{k}].w))"
                 self.add_fp4(d, prod)
                 self.release()
         return any_emitted
@@ -888,6 +906,12 @@ def emit_part(kernel: str, plan: Plan, lo: int, hi: int, standalone: bool, heade
         w(f"void launch_{kernel}(const EvalCheckArgs& a, hipStream_t s) {{")
         w(f"    {kernel}<<<(a.dom + 255u) / 256u, 256, 0, s>>>(a);")
         w("}")
+    if GATHER:          # the exponent behind every slot of this part's power table (first word: how many)
+        words = ", ".join(str(x) for x in [len(em.pw_exps)] + em.pw_exps)
+        if standalone:
+            w(f'extern "C" __device__ __attribute__((used)) const uint32_t {kernel}_exps[] = {{{words}}};')
+        else:
+            w(f"extern const uint32_t exps_{kernel}[] = {{{words}}};")
     return "\n".join(L)
 
 
@@ -963,7 +987,13 @@ def generate_sources() -> Dict[str, str]:
                 externs.append(f"void launch_{k}(const EvalCheckArgs&, hipStream_t);")
                 launchers.append(f"launch_{k}")
         main.append(f"static const eval_check_launch_fn parts_{name}[] = {{{', '.join(launchers)}}};")
-        table.append(f'    {{0x{h:016x}ull, "{name}", parts_{name}, {len(launchers)}u, {n_pows}u}},')
+        gather = "nullptr"
+        if GATHER:
+            if len(parts) > 1:
+                externs.extend(f"extern const uint32_t exps_{k}[];" for k, _ in parts)
+            main.append(f"static const uint32_t* const gexps_{name}[] = {{{', '.join('exps_' + k for k, _ in parts)}}};")
+            gather = f"gexps_{name}"
+        table.append(f'    {{0x{h:016x}ull, "{name}", parts_{name}, {len(launchers)}u, {n_pows}u, {gather}}},')
     # the extern declarations must precede the arrays that reference them
     src = "\n".join(PREAMBLE + externs + [""] + main[len(PREAMBLE):] + ["", "static const CompiledEvalCheck k_table[] = {", *table, "};", "",
                     "namespace zkh {", "const CompiledEvalCheck* find_compiled_eval_check(uint64_t h) {",

@@ -63,7 +63,10 @@ __device__ __forceinline__ zkh::Fp4 ext_sub_base(const zkh::Fp4& x, uint32_t v) 
 typedef void (*eval_check_launch_fn)(const EvalCheckArgs&, hipStream_t);
 // A circuit's generated eval_check: n_parts kernels over disjoint constraint ranges, launched back to back on one stream;
 // part 0 writes `check`, the others add their share (circuits/codegen.py).
-struct CompiledEvalCheck { uint64_t desc_hash; const char* name; const eval_check_launch_fn* parts; uint32_t n_parts; uint32_t n_mix_pows; };
+// gather_exps (optional): per part, {count, exponent of slot 0, 1, ...} — the part reads its mix powers from a table of its own,
+// gathered into the order its code touches them (codegen.py GATHER); NULL: every part indexes the plain table mix^0, mix^1, ...
+struct CompiledEvalCheck { uint64_t desc_hash; const char* name; const eval_check_launch_fn* parts; uint32_t n_parts; uint32_t n_mix_pows;
+                           const uint32_t* const* gather_exps; };
 // registry filled by the generated translation unit (eval_check_gen.hip)
 const CompiledEvalCheck* find_compiled_eval_check(uint64_t desc_hash);
 
@@ -95,6 +98,11 @@ struct zkh_circuit {
     // code objects attached at run time (zkh_circuit_attach_code_object[_part]): eval_check kernels generated for THIS desc
     std::vector<hipModule_t> jit_modules;
     std::vector<hipFunction_t> jit_kernels;      // one per part; all non-null once every part is attached
+    // gathered power tables ([0] built-in kernels, [1] attached code objects): device exponent list of all parts back to back,
+    // and where each part's slots start (n_parts + 1 entries); empty = the parts index the plain table
+    uint32_t* d_gather[2];
+    std::vector<uint32_t> gather_off[2];
+    std::vector<std::vector<uint32_t>> jit_exps;   // per attached part: its exponent list ({} = none exported)
     bool interp_ok;       // the step interpreter's live values fit its LDS
     // interpreter program
     std::vector<zkh::InterpInsn> prog;

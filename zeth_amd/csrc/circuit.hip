@@ -21,6 +21,10 @@ uint64_t desc_hash64(const uint32_t* w, size_t n) {   // FNV-1a over the words
     return h;
 }
 const char* launch_ext_powers(zkh_ctx* c, uint32_t* out, const uint32_t start[4], const uint32_t base[4], uint32_t n);
+const char* launch_ext_powers_at(zkh_ctx* c, uint32_t* out, const uint32_t base[4], const uint32_t* d_exps, uint32_t n);
+}
+static const char* set_gather(zkh_circuit* c, int which, const std::vector<const uint32_t*>& lists);
+namespace zkh {
 const char* prefix_products_batched(zkh_ctx* c, uint32_t* io, size_t n0, size_t count, size_t col_stride);
 }  // namespace zkh
 
@@ -587,13 +591,40 @@ extern "C" const char* zkh_circuit_load(zkh_ctx* ctx, const uint32_t* d, size_t 
         if (e == hipSuccess) e = hipMalloc((void**)&c->d_taps, c->taps.size() * sizeof(Tap) + 4);
         if (e == hipSuccess) e = hipMemcpy(c->d_taps, c->taps.data(), c->taps.size() * sizeof(Tap), hipMemcpyHostToDevice);
         if (e != hipSuccess) { const char* m = hipGetErrorString(e); return fail(m); }
+        if (c->compiled && c->compiled->gather_exps) {
+            std::vector<const uint32_t*> lists(c->compiled->gather_exps, c->compiled->gather_exps + c->compiled->n_parts);
+            if (const char* err = set_gather(c, 0, lists)) { std::string m(err); zkh_free_error(err); return fail(m.c_str()); }
+        }
     }
     *out = c;
+    return nullptr;
+}
+// The parts' exported exponent lists ({count, e0, e1, ...} each) -> one device list + the parts' slot offsets.  All parts or none.
+static const char* set_gather(zkh_circuit* c, int which, const std::vector<const uint32_t*>& lists) {
+    if (c->d_gather[which]) { (void)hipFree(c->d_gather[which]); c->d_gather[which] = nullptr; }
+    c->gather_off[which].clear();
+    size_t exported = 0;
+    for (const uint32_t* l : lists) exported += l != nullptr;
+    if (!exported) return nullptr;
+    ZKH_REQUIRE(exported == lists.size(), "eval_check kernels: %zu of %zu parts export a gathered power table", exported, lists.size());
+    std::vector<uint32_t> all, off(1, 0);
+    for (const uint32_t* l : lists) {
+        for (uint32_t i = 0; i < l[0]; i++) {
+            ZKH_REQUIRE(l[1 + i] < c->n_mix_pows, "eval_check kernels: gathered mix power %u, the step list has %u", l[1 + i], c->n_mix_pows);
+            all.push_back(l[1 + i]);
+        }
+        off.push_back((uint32_t)all.size());
+    }
+    hipError_t e = hipMalloc((void**)&c->d_gather[which], all.size() * 4 + 4);
+    if (e == hipSuccess) e = hipMemcpy(c->d_gather[which], all.data(), all.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return make_err("eval_check kernels: gathered power table: %s", hipGetErrorString(e));
+    c->gather_off[which] = std::move(off);
     return nullptr;
 }
 extern "C" void zkh_circuit_destroy(zkh_circuit* c) {
     if (!c) return;
     if (c->ctx) bind_thread(c->ctx);
+    for (int w = 0; w < 2; w++) if (c->d_gather[w]) (void)hipFree(c->d_gather[w]);
     if (c->d_prog) (void)hipFree(c->d_prog);
     if (c->d_taps) (void)hipFree(c->d_taps);
     for (hipModule_t m : c->jit_modules) if (m) (void)hipModuleUnload(m);
@@ -627,13 +658,39 @@ extern "C" const char* zkh_circuit_attach_code_object_part(zkh_circuit* c, const
     if (e != hipSuccess) { (void)hipGetLastError(); return make_err("attach_code_object: hipModuleLoadData: %s", hipGetErrorString(e)); }
     e = hipModuleGetFunction(&fn, mod, kernel_name);
     if (e != hipSuccess) { (void)hipGetLastError(); (void)hipModuleUnload(mod); return make_err("attach_code_object: no kernel '%s': %s", kernel_name, hipGetErrorString(e)); }
+    // a kernel generated with a gathered power table exports `<kernel>_exps` = {count, exponent of slot 0, 1, ...}
+    std::vector<uint32_t> exps;
+    {
+        hipDeviceptr_t dptr = nullptr;
+        size_t bytes = 0;
+        const std::string sym = std::string(kernel_name) + "_exps";
+        if (hipModuleGetGlobal(&dptr, &bytes, mod, sym.c_str()) == hipSuccess && bytes >= 4 && bytes % 4 == 0) {
+            exps.resize(bytes / 4);
+            e = hipMemcpy(exps.data(), dptr, bytes, hipMemcpyDeviceToHost);
+            if (e != hipSuccess || exps[0] != exps.size() - 1) {
+                (void)hipGetLastError(); (void)hipModuleUnload(mod);
+                return make_err("attach_code_object: '%s' is malformed", sym.c_str());
+            }
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     if (c->jit_kernels.size() != n_parts) {          // a new set of parts replaces whatever was attached before
         for (hipModule_t m : c->jit_modules) if (m) (void)hipModuleUnload(m);
         c->jit_modules.assign(n_parts, nullptr);
         c->jit_kernels.assign(n_parts, nullptr);
+        c->jit_exps.assign(n_parts, {});
     }
     if (c->jit_modules[part]) (void)hipModuleUnload(c->jit_modules[part]);
-    c->jit_modules[part] = mod; c->jit_kernels[part] = fn;
+    c->jit_modules[part] = mod; c->jit_kernels[part] = fn; c->jit_exps[part] = std::move(exps);
+    if (jit_complete(c)) {
+        std::vector<const uint32_t*> lists;
+        for (const auto& l : c->jit_exps) lists.push_back(l.empty() ? nullptr : l.data());
+        if (const char* err = set_gather(c, 1, lists)) {      // a set that disagrees with itself is not launched
+            c->jit_kernels[part] = nullptr;
+            return err;
+        }
+    }
     return nullptr;
 }
 extern "C" const char* zkh_circuit_attach_code_object(zkh_circuit* c, const void* image, size_t len, const char* kernel_name) {
@@ -663,10 +720,19 @@ extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_bu
     const Fp three_n = fp_pow(fp_encode(3), n), i4 = Fp::raw(ctx->rou_fwd[2]);
     Fp cur = Fp::one();
     for (int k = 0; k < 4; k++) { a.zinv[k] = fp_inv(three_n * cur - Fp::one()).v; cur = cur * i4; }
+    // the mix powers: the plain table mix^0, mix^1, ... — or, for kernels generated that way, every part's own table, gathered
+    // into the order its code reads them (one launch either way)
+    const int which = jit_complete(c) ? 1 : 0;
+    const std::vector<uint32_t>* goff = (!use_interpreter && (which == 1 || c->compiled) && !c->gather_off[which].empty()) ? &c->gather_off[which] : nullptr;
     Tmp pows;
-    ZKH_TRY(new_buf(ctx, 4 * (size_t)c->n_mix_pows, false, pows.out()));
-    const uint32_t one[4] = {R1, 0, 0, 0};
-    ZKH_TRY(launch_ext_powers(ctx, pows->ptr(), one, poly_mix, c->n_mix_pows));
+    if (goff) {
+        ZKH_TRY(new_buf(ctx, 4 * (size_t)goff->back() + 4, false, pows.out()));
+        ZKH_TRY(launch_ext_powers_at(ctx, pows->ptr(), poly_mix, c->d_gather[which], goff->back()));
+    } else {
+        ZKH_TRY(new_buf(ctx, 4 * (size_t)c->n_mix_pows, false, pows.out()));
+        const uint32_t one[4] = {R1, 0, 0, 0};
+        ZKH_TRY(launch_ext_powers(ctx, pows->ptr(), one, poly_mix, c->n_mix_pows));
+    }
     a.mix_pows = pows->ptr();
     size_t total_w = 0;
     for (int g = 0; g < 3; g++) total_w += c->group_size[g];
@@ -674,6 +740,7 @@ extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_bu
         ProfScope prof(ctx, "eval_check", 4.0 * total_w * dom + 16.0 * dom);
         for (size_t part = 0; part < c->jit_kernels.size(); part++) {
             a.accumulate = part != 0;
+            if (goff) a.mix_pows = pows->ptr() + 4 * (size_t)(*goff)[part];
             size_t arg_size = sizeof(a);
             void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &arg_size, HIP_LAUNCH_PARAM_END};
             const hipError_t e = hipModuleLaunchKernel(c->jit_kernels[part], (unsigned)((dom + 255) / 256), 1, 1, 256, 1, 1, 0, ctx->stream,
@@ -684,6 +751,7 @@ extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_bu
         ProfScope prof(ctx, "eval_check", 4.0 * total_w * dom + 16.0 * dom);
         for (uint32_t part = 0; part < c->compiled->n_parts; part++) {
             a.accumulate = part != 0;
+            if (goff) a.mix_pows = pows->ptr() + 4 * (size_t)(*goff)[part];
             c->compiled->parts[part](a, ctx->stream);
         }
     } else {

@@ -28,6 +28,12 @@ __global__ void k_ext_powers(uint32_t* out, Fp4 start, Fp4 base, uint32_t n) {
     if (i < n) st_ext(out + 4 * i, start * fp4_pow(base, i));
 }
 
+// out[i] = base^exps[i], i < n   (eval_check's mix powers gathered into the order a generated kernel reads them)
+__global__ void k_ext_powers_at(uint32_t* out, Fp4 base, const uint32_t* __restrict__ exps, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) st_ext(out + 4 * i, fp4_pow(base, exps[i]));
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // batch_evaluate_any.  Block (chunk, k): partial[k][chunk] = sum_{j in chunk} coeffs[which[k]][j] * x_k^j.
 // Lane t owns coefficients j = chunk*CH + i*256 + t (coalesced); term = c * X^i (X = x^256, table in LDS),
@@ -441,6 +447,11 @@ const char* launch_ext_powers(zkh_ctx* c, uint32_t* out, const uint32_t start[4]
     if (!n) return nullptr;
     k_ext_powers<<<(unsigned)ceil_div(n, TB), TB, 0, c->stream>>>(out, to_fp4(start), to_fp4(base), n);
     return last_launch_error("ext_powers");
+}
+const char* launch_ext_powers_at(zkh_ctx* c, uint32_t* out, const uint32_t base[4], const uint32_t* d_exps, uint32_t n) {
+    if (!n) return nullptr;
+    k_ext_powers_at<<<(unsigned)ceil_div(n, TB), TB, 0, c->stream>>>(out, to_fp4(base), d_exps, n);
+    return last_launch_error("ext_powers_at");
 }
 }  // namespace zkh
 
