@@ -401,12 +401,12 @@ def test_syn_heavy_small_seal_bit_exact(hal, oracle, po2, zk, tmp_path, monkeypa
 
 
 def test_syn_heavy_full_circuit_seal_bit_exact_and_po2_20_verifies(hal, oracle):
-    """The bench's `--circuit syn_heavy` (54 k steps, 1061 taps, 17 built-in kernels): byte-identical to the oracle at
+    """The bench's `--circuit syn_heavy` (54 k steps, 1061 taps, 7 built-in kernels): byte-identical to the oracle at
     po2 13, and a 2^20-cycle seal is accepted by the product's verifier and by the oracle's."""
     from zeth_amd.circuits import syn_heavy
     desc = syn_heavy.syn_heavy()
     prover = SegmentProver(hal, desc)
-    assert prover.circuit.kernel_kind() == "builtin" and prover.circuit.compiled_parts() >= 8
+    assert prover.circuit.kernel_kind() == "builtin" and prover.circuit.compiled_parts() >= 4
     oc = zko.OracleCircuit(oracle, desc)
     seg = Segment(index=0, po2=13, seed=31, noise_seed=32)
     receipt = prover.prove_segment(seg)
