@@ -314,6 +314,7 @@ def main() -> None:
                          "shape: a sequential host preflight per segment (producer threads), its compact records uploaded and row-filled on the GPU")
     ap.add_argument("--chained", action="store_true", help="block config: SYN-C segments whose pre-state is their predecessor's post-state (claim continuity), through the native session executor")
     ap.add_argument("--recompute-code", action="store_true", help="block / succinct: re-commit the code group for every segment (upstream's SegmentProver) instead of keeping it resident")
+    ap.add_argument("--no-join3", action="store_true", help="recursion: leave the join3 program out (three nodes above the bottom level then cost two joins instead of one proof; same tree, same root claim)")
     ap.add_argument("--no-fused-lift", action="store_true", help="recursion: lift every segment on its own and join (three proofs per pair at the bottom level) instead of lift2")
     ap.add_argument("--no-preflight-leg", action="store_true", help="segment config: skip the block leg with the host-preflight witness pipeline")
     ap.add_argument("--preflight-producers", type=int, default=2, help="host preflight threads per sealing lane")
@@ -498,6 +499,14 @@ def main() -> None:
         device_sync(lanes)
         return receipts, t0, wit_s, seal_s
 
+    def top_proofs(tops, kinds):
+        """proofs rank 0 spends on folding the ranks' local roots (zeth_amd/recursion.py fold_plan: pairs, then three at a time)"""
+        from zeth_amd.recursion import fold_plan
+        if not tops or len(tops) < 2:
+            return 0
+        po2 = tops[0].po2
+        return sum((1 if len(g) == 2 or ("join3", po2, po2, po2) in kinds else 2) for groups in fold_plan(len(tops)) for g in groups if len(g) > 1)
+
     def fold_lanes(lanes):
         """the lanes of the fold: the sealing lanes plus extra contexts up to --fold-inflight"""
         return list(lanes) + [Lane() for _ in range(max(0, args.fold_inflight - len(lanes)))]
@@ -507,7 +516,7 @@ def main() -> None:
         lift + join per lane: before any clock, as upstream ships lift / join as precompiled .zkr programs"""
         from zeth_amd import recursion as zrec
         t_b = time.perf_counter()
-        programs = zrec.build_programs(desc, leaf_roots)
+        programs = zrec.build_programs(desc, leaf_roots, ternary=not args.no_join3)
         build_s = time.perf_counter() - t_b
         t_b = time.perf_counter()
         for ln in lanes:
@@ -558,12 +567,10 @@ def main() -> None:
         device_sync(lanes)
         lift_s = time.perf_counter() - t0
         n_joins = 0
-        while len(level) > 1:
-            nxt = spread([(lambda ln, a=level[2 * k], b=level[2 * k + 1]: ln.rec.join(a, b, BENCH_NOISE)) for k in range(len(level) // 2)])
-            n_joins += len(nxt)
-            if len(level) % 2:
-                nxt.append(level[-1])
-            level = nxt
+        from zeth_amd.recursion import fold_plan
+        for groups in fold_plan(len(leaves))[1:]:           # above the bottom level: three nodes per proof (join3), zeth_amd/recursion.py fold_plan
+            n_joins += sum((1 if len(g) == 2 or ("join3",) + tuple(level[k].po2 for k in g) in rx0.kinds else 2) for g in groups if len(g) > 1)
+            level = spread([(lambda ln, nodes=[level[k] for k in g]: ln.rec.join_group(nodes, BENCH_NOISE)) for g in groups])
         device_sync(lanes)
         total_s = time.perf_counter() - t0
         rx = lanes[0].rec
@@ -1127,7 +1134,7 @@ def main() -> None:
             probe.prover.prove_segment(Segment(index=0, po2=args.po2, seed=1, noise_seed=BENCH_NOISE))
             roots = {p: probe.prover.control_root(p) for p in sorted({s.po2 for s in segs})}
             t_b = time.perf_counter()
-            programs = zrec.build_programs(desc, roots, fused_pairs=not args.no_fused_lift)
+            programs = zrec.build_programs(desc, roots, fused_pairs=not args.no_fused_lift, ternary=not args.no_join3)
             build_s = time.perf_counter() - t_b
             t_b = time.perf_counter()
             sess = Session(desc, devices=(device,), lanes_per_device=inflight)
@@ -1197,7 +1204,7 @@ def main() -> None:
                     root_verify_s = time.perf_counter() - t_rv
                     verified += 1
                     allc = {k: v for part in parts for k, v in part.items()}
-                    follows = bool(np.array_equal(root.seal[:8], zrec.fold_leaf_claims([allc[i] for i in range(S)])))
+                    follows = bool(np.array_equal(root.seal[:8], zrec.fold_leaf_claims([allc[i] for i in range(S)], ranks=world)))
                     if not follows:
                         raise SystemExit("bench: the root receipt's output is not the claim tree of the leaves")
                 else:
@@ -1211,8 +1218,8 @@ def main() -> None:
                           "pcie_bytes_per_segment": float(tt[8]) / max(1.0, float(tt[6])) if args.witness == "preflight" else None,
                           "fold": args.fold, "streamed_fold": st["streamed_fold"], "code_group": "recomputed per segment" if args.recompute_code else "resident per lane and size",
                           "bottom_level_proofs": st["n_lifts"] * world, "fused_lift2": (len(mine) // 2) * world if all_fused else 0,
-                          "joins": st["n_joins"] * world + (world - 1), "proofs": (st["n_lifts"] + st["n_joins"]) * world + (world - 1),
-                          "leaves_s": t_leaves, "fold_tail_s": fold_tail, "fold_busy_lane_s": float(tt[3]), "top_joins": world - 1, "top_joins_s": top_s,
+                          "joins": st["n_joins"] * world + top_proofs(tops, kinds), "proofs": (st["n_lifts"] + st["n_joins"]) * world + top_proofs(tops, kinds),
+                          "leaves_s": t_leaves, "fold_tail_s": fold_tail, "fold_busy_lane_s": float(tt[3]), "top_joins": top_proofs(tops, kinds), "top_joins_s": top_s,
                           "segment_retries": int(tt[4]), "program_build_s": build_s, "program_load_s_all_lanes": load_s,
                           "in_flight": {"sealing_lanes": inflight, "fold_lanes": max(args.fold_inflight, inflight)},
                           "root_verify_s": root_verify_s,
@@ -1277,7 +1284,7 @@ def main() -> None:
                     t_top = time.perf_counter()
                     root = lanes[0].rec.fold(tops, BENCH_NOISE)
                     lanes[0].hal.sync()
-                    rstats["top_joins"] = len(tops) - 1
+                    rstats["top_joins"] = top_proofs(tops, lanes[0].rec.kinds)
                     rstats["top_joins_s"] = time.perf_counter() - t_top
             elif succinct:
                 # join tree: tasks of one level are independent -> spread over the lanes of this rank
@@ -1375,7 +1382,7 @@ def main() -> None:
                     allc = {k: v for part in parts for k, v in part.items()}
                     if recursive:
                         from zeth_amd.recursion import fold_leaf_claims
-                        follows = bool(np.array_equal(root.seal[:8], fold_leaf_claims([allc[i] for i in range(S)])))
+                        follows = bool(np.array_equal(root.seal[:8], fold_leaf_claims([allc[i] for i in range(S)], ranks=world)))
                     else:
                         follows = bool(np.array_equal(root.seal[:8], fold_claims([allc[i] for i in range(S)])))
                     if not follows:

@@ -8,7 +8,7 @@
 // written out against the low-level entry points.)
 //
 //   prove_session --desc syn_a.desc [--join-desc p2_join.desc | --recursion-dir DIR] [--po2 20] [--tail-po2 18] [--segments 64]
-//                 [--devices 1] [--inflight 3] [--join-po2 18] [--noise-seed N] [--two-phase] [--recompute-code]
+//                 [--devices 1] [--inflight 3] [--join-po2 18] [--noise-seed N] [--two-phase] [--recompute-code] [--no-join3]
 // --recursion-dir: the directory `python -m zeth_amd.circuits.rec_verify DIR` and `python -m zeth_amd.circuits.recursion
 // DIR/recursion.desc` wrote (lift-<po2>.zkr1, lift2-<l>-<r>.zkr1, join-<l>-<r>.zkr1): lift the receipts (in pairs: lift2) and join them to one root receipt whose
 // every node verified its child seal(s) IN-CIRCUIT (BASELINE.json config 5).
@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
     std::string desc_path, join_path, rec_dir;
     size_t po2 = 20, tail_po2 = 18, n = 64, devices = 1, inflight = 3, join_po2 = 18;
     uint64_t noise = 0;
-    bool two_phase = false, recompute_code = false;
+    bool two_phase = false, recompute_code = false, no_join3 = false;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto num = [&](size_t& d) { if (i + 1 < argc) d = strtoull(argv[++i], nullptr, 10); };
@@ -50,6 +50,7 @@ int main(int argc, char** argv) {
         else if (a == "--inflight") num(inflight);
         else if (a == "--join-po2") num(join_po2);
         else if (a == "--noise-seed" && i + 1 < argc) noise = strtoull(argv[++i], nullptr, 0);
+        else if (a == "--no-join3") no_join3 = true;            // leave the join3 program out: three nodes cost two proofs
         else if (a == "--two-phase") two_phase = true;          // seal everything, then fold (default: one pipeline)
         else if (a == "--recompute-code") recompute_code = true; // re-commit the code group per segment, like upstream's SegmentProver
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
@@ -76,10 +77,15 @@ int main(int argc, char** argv) {
         while (dirent* e = readdir(d)) names.push_back(e->d_name);
         closedir(d);
         for (const std::string& name : names) {
-            unsigned a = 0, b = 0;
+            unsigned a = 0, b = 0, c3 = 0;
             uint32_t kind;
             if (name.find(".zkr1") == std::string::npos) continue;
-            if (sscanf(name.c_str(), "lift2-%u-%u.zkr1", &a, &b) == 2) kind = 2;
+            if (sscanf(name.c_str(), "join3-%u-%u-%u.zkr1", &a, &b, &c3) == 3) {
+                if (no_join3) continue;                   // --no-join3: groups of three are proven as join(join(a, b), c)
+                if (a != b) { fprintf(stderr, "%s: a join3 whose first two children differ in size\n", name.c_str()); return 2; }
+                kind = 3; b = c3;
+            }
+            else if (sscanf(name.c_str(), "lift2-%u-%u.zkr1", &a, &b) == 2) kind = 2;
             else if (sscanf(name.c_str(), "lift-%u.zkr1", &a) == 1) { kind = 0; b = 0; }
             else if (sscanf(name.c_str(), "join-%u-%u.zkr1", &a, &b) == 2) kind = 1;
             else continue;

@@ -338,7 +338,7 @@ const char* zkh_rec_program_info(const zkh_rec_program*, uint32_t root[8], uint3
  * number of steps of its launch plan (runs of narrow levels in one persistent workgroup + single wide levels).  0: the plan is
  * launched kernel by kernel (the default: measured equal, and profilers cope with it). */
 int zkh_rec_program_has_graph(const zkh_rec_program*);
-const char* zkh_rec_code(const zkh_rec_program*, zkh_buf* code /* 57 x 2^po2 */);
+const char* zkh_rec_code(const zkh_rec_program*, zkh_buf* code /* 58 x 2^po2 */);
 const char* zkh_rec_witgen(const zkh_rec_program*, const uint32_t* inputs, size_t n_inputs, uint64_t noise_seed,
                            zkh_buf* data /* 72 x 2^po2 */, uint32_t out_global[16]);
 const char* zkh_rec_accum(const zkh_rec_program*, uint64_t noise_seed, const zkh_buf* data, const uint32_t* mix_global /* 20 */,
@@ -406,7 +406,9 @@ void zkh_session_set_resident_code(zkh_session*, int on);
  * rec_desc = the RECURSION description; program i is blobs[i] (words[i] words) of kind kinds[3 i .. 3 i + 3) = {0, segment po2,
  * circuit family (0 = the session's)} for a lift, {1, left po2, right po2} for a join of two recursion seals, {2, left po2,
  * right po2} for a lift2 (two SEGMENT seals verified by one program: lift + lift + join fused; used for the bottom level when
- * every pair of the session has one).  Every lane loads every program (code groups resident). */
+ * every pair of the session has one), {3, po2 of the first two children, po2 of the third} for a join3 (three recursion seals,
+ * out = what join(join(a, b), c) publishes: used above the bottom level wherever three neighbours have these sizes).
+ * Every lane loads every program (code groups resident). */
 const char* zkh_session_set_recursion(zkh_session*, const uint32_t* rec_desc, size_t rec_desc_words, const uint32_t* const* blobs,
                                       const size_t* words, const uint32_t* kinds, size_t n_programs);
 /* join_tree == 2 runs as ONE pipeline by default: a lift2 / join is proven the moment both children exist, on the fold lanes while
@@ -425,7 +427,9 @@ const char* zkh_session_set_chained(zkh_session*, int on, uint32_t initial_state
 const char* zkh_session_set_witness_source(zkh_session*, int source, size_t producers_per_lane);
 /* join_tree == 1: fold the receipts through the P2-JOIN tree (joins at 2^join_po2; join_noise_seed 0 = OS randomness);
  * join_tree == 2: lift every receipt and join level by level with the RECURSION programs - every node verifies its child
- * seal(s) in-circuit; the root receipt is a RECURSION seal with out = claim tree root ‖ allowed-programs root */
+ * seal(s) in-circuit; the root receipt is a RECURSION seal with out = claim tree root ‖ allowed-programs root.  The tree: the
+ * first level pairs the segments, every level above takes three nodes at a time (a remainder of two is a join, of one moves up);
+ * a group of three is ONE proof where the session has a join3 program for its sizes, else join(join(a, b), c) - the same node. */
 const char* zkh_session_prove(zkh_session*, const zkh_segment* segs, size_t n, int join_tree, size_t join_po2,
                               uint64_t join_noise_seed, zkh_prove_info* info);
 void zkh_prove_info_free(zkh_prove_info*);

@@ -19,11 +19,12 @@ static inline fp4 ld4(const uint32_t* p) { fp4 r; memcpy(&r, p, 16); return r; }
 #define RC_NW 6
 #define RC_WD 72
 #define RC_WA 12
-#define RC_WC 57
+#define RC_WC 58
 #define RC_ROW_WORDS 13
 #define RC_MAGIC 0x5a4b5231u
+#define RC_VERSION 2u
 enum { RO_INPUT = 1, RO_GEN, RO_MUX, RO_PACK, RO_UNPACK, RO_INV, RO_BITS, RO_P2, RO_EQ, RO_ISZ };
-enum { RG_MUX = 1, RG_BOOL = 2, RG_EMB = 4, RG_PACK0 = 8, RG_PUB = 128 };
+enum { RG_MUX = 1, RG_BOOL = 2, RG_EMB = 4, RG_PACK0 = 8, RG_PUB = 128, RG_SWAP = 256 };
 
 typedef struct {
     uint32_t po2, zk, A, n_vars, n_consts, n_ops, n_inputs, n_p2, n_gates;
@@ -31,7 +32,7 @@ typedef struct {
 } rec_prog;
 
 static const char* rec_parse(const uint32_t* b, size_t words, rec_prog* p) {
-    if (words < 16 || b[0] != RC_MAGIC || b[1] != 1) return "recursion program: bad header";
+    if (words < 16 || b[0] != RC_MAGIC || b[1] != RC_VERSION) return "recursion program: bad header";
     p->po2 = b[2]; p->zk = b[3]; p->A = b[4]; p->n_vars = b[5]; p->n_consts = b[6]; p->n_ops = b[7]; p->n_inputs = b[8];
     p->n_p2 = b[9]; p->n_gates = b[10];
     if (p->po2 < 1 || p->po2 > 24 || (size_t)p->A + p->zk != (size_t)1 << p->po2) return "recursion program: bad shape";
@@ -94,6 +95,16 @@ void zko_rec_p2_rows(const uint32_t in[RC_T], uint32_t rows[RC_BLOCK][2 * RC_T])
     memcpy(rows[RC_BLOCK - 1], s, sizeof s);
 }
 
+/* the input state of a conditional-swap block (recursion.py swap_state): cell 16 is the bit t (Montgomery 0 / 1); t set: the
+ * first two digests change places; cell 16 itself enters the permutation as zero.  -> 0 if t is not a bit */
+static int rc_swap_state(uint32_t cells[RC_T]) {
+    const fp t = cells[16];
+    if (t != 0 && t != fp_from_u32(1)) return 0;
+    if (t) for (int j = 0; j < 8; j++) { uint32_t x = cells[j]; cells[j] = cells[j + 8]; cells[j + 8] = x; }
+    cells[16] = 0;
+    return 1;
+}
+
 /* the code group: a function of the program alone (its Merkle root is the program's control root) */
 const char* zko_rec_code(const uint32_t* blob, size_t words, uint32_t* code) {
     rec_prog p;
@@ -122,7 +133,9 @@ const char* zko_rec_code(const uint32_t* blob, size_t words, uint32_t* code) {
         const unsigned k = (unsigned)(r % RC_BLOCK);
         const int full = (k >= 1 && k <= 4) || (k >= 7 && k <= 10);
         const unsigned rnd = k <= 4 ? k - 1 : k == 5 ? 4 : k == 6 ? 16 : k + 18;      /* first round this row performs (k = 7: 25) */
-        code[24 * n + r] = (k == 0 || k == RC_BLOCK - 1) ? one : 0;
+        const int swap = k == 0 && (fl & RG_SWAP);
+        code[24 * n + r] = ((k == 0 && !swap) || k == RC_BLOCK - 1) ? one : 0;
+        code[57 * n + r] = swap ? one : 0;
         code[26 * n + r] = k == 1 ? one : 0;
         code[27 * n + r] = full ? one : 0;
         code[28 * n + r] = k == 5 ? one : 0;
@@ -138,7 +151,7 @@ const char* zko_rec_code(const uint32_t* blob, size_t words, uint32_t* code) {
 
 static char rec_err[256];
 
-/* Executes the witness schedule on `inputs` (raw Montgomery words, e.g. child seals) and fills code (55 x n), data (72 x n)
+/* Executes the witness schedule on `inputs` (raw Montgomery words, e.g. child seals) and fills code (58 x n), data (72 x n)
  * and out_global (16 words = the wires of the PUB row).  NULL on success; a message when the witness does not exist (an
  * assertion of the program fails: the child seal is not valid). */
 const char* zko_rec_witgen(const uint32_t* blob, size_t words, const uint32_t* inputs, size_t n_inputs, uint64_t noise_seed,
@@ -206,6 +219,7 @@ const char* zko_rec_witgen(const uint32_t* blob, size_t words, const uint32_t* i
         case RO_P2: {
             uint32_t cells[RC_T];
             for (int w = 0; w < RC_NW; w++) for (int t = 0; t < 4; t++) cells[4 * w + t] = val[in[w]].c[t];
+            if ((aux & 1) && !rc_swap_state(cells)) { BAD("the selector of a conditional swap is not a bit"); break; }
             zko_poseidon2_mix(cells);
             for (int w = 0; w < RC_NW; w++) for (int t = 0; t < 4; t++) val[out + w].c[t] = cells[4 * w + t];
             break;
@@ -233,6 +247,7 @@ const char* zko_rec_witgen(const uint32_t* blob, size_t words, const uint32_t* i
                 fp in[RC_T];
                 const size_t r0 = RC_BLOCK * b;
                 for (int j = 0; j < RC_T; j++) in[j] = data[(size_t)j * n + r0];
+                if (p.table[r0 * RC_ROW_WORDS + 6] & RG_SWAP) (void)rc_swap_state(in);
                 zko_rec_p2_rows(in, rows);
                 for (size_t k = 0; k < RC_BLOCK; k++)
                     for (size_t col = 0; col < 2 * RC_T; col++) data[(RC_T + col) * n + r0 + k] = rows[k][col];

@@ -28,6 +28,12 @@ def small_program():
     sel = pr.mux(bits[0], s, m)
     h = pr.p2([x, y, s, m, pr.zero(), pr.zero()])
     h2 = pr.p2([h[0], h[1], sel, iv, h[4], h[5]])
+    # conditional-swap blocks (one Merkle level each): bit 0 of a = 5 is set, bit 1 is clear
+    z = pr.zero()
+    sw1 = pr.p2([h2[0], h2[1], x, y, bits[0], z], swap=True)
+    sw0 = pr.p2([h2[0], h2[1], x, y, bits[1], z], swap=True)
+    pr.eq(sw1[0], pr.p2([x, y, h2[0], h2[1], z, z])[0])
+    pr.eq(sw0[1], pr.p2([h2[0], h2[1], x, y, z, z])[1])
     pr.eq(pr.is_zero(b), pr.zero())
     pk = pr.pack(2, x, y, s, m)
     k = pr.const(3, 1, 4, 1)
@@ -42,7 +48,7 @@ def rec(oracle):
 
 def test_circuit_shape():
     c = Circuit.parse(R.recursion_circuit())
-    assert c.kind == 4 and c.group_sizes == (R.WA, R.WC, R.WD) == (12, 57, 72) and c.global_sizes == (16, 20)
+    assert c.kind == 4 and c.group_sizes == (R.WA, R.WC, R.WD) == (12, 58, 72) and c.global_sizes == (16, 20)
     assert max(b for _, _, b in c.taps) == 1                       # only the previous row is ever read
 
 
@@ -217,6 +223,18 @@ def test_join_verifies_two_lifts_in_circuit(oracle, rec):
     code, data, out = rec.rec_witgen(jblob, np.concatenate([left, path, opening(100), right, path, opening(101)]))
     assert np.array_equal(out[:8], host_rec.wrap_claim(host_rec.hash_pair(left[:8], right[:8]), 0, 0)) and np.array_equal(out[8:], A)
     assert np.array_equal(out[:8], host_rec.fold_leaf_claims([leaf_claim(100), leaf_claim(101)]))
+    # join3: THREE children in one program, out = what join(join(a, b), c) would publish (the inner claim' is computed in-circuit)
+    j3 = V.build_join(R.recursion_circuit(), lpo2, lpo2, lpo2)
+    j3po2 = j3.min_po2()
+    third = lifted(102, A)
+    c3, d3, o3 = rec.rec_witgen(j3.finish(j3po2), np.concatenate([left, path, opening(100), right, path, opening(101), third, path, opening(102)]))
+    inner = host_rec.wrap_claim(host_rec.hash_pair(left[:8], right[:8]), 0, 0)
+    assert np.array_equal(o3[:8], host_rec.wrap_claim(host_rec.hash_pair(inner, third[:8]), 0, 0)) and np.array_equal(o3[8:], A)
+    nested = host_rec._parent_node(host_rec._parent_node((leaf_claim(100), 0, 0), (leaf_claim(101), 0, 0)), (leaf_claim(102), 0, 0))
+    assert np.array_equal(o3[:8], host_rec.wrap_claim(*nested))
+    assert rec.check_rows(j3po2, rec.rec_accum(j3po2, c3, d3, MIX), c3, d3, o3, MIX) == -1
+    with pytest.raises(RuntimeError, match="tie"):                              # the third child's opening must be ITS claim'
+        rec.rec_witgen(j3.finish(j3po2), np.concatenate([left, path, opening(100), right, path, opening(101), third, path, opening(100)]))
     with pytest.raises(RuntimeError, match="tie"):                              # an opening that is not the child's claim': no witness
         rec.rec_witgen(jblob, np.concatenate([left, path, opening(101), right, path, opening(101)]))
     with pytest.raises(RuntimeError, match="tie"):                              # a state range the child's claim' does not commit to
@@ -284,15 +302,19 @@ def test_random_programs_python_semantics_c_interpreter_and_constraints_agree(re
 
 
 def test_program_set_of_a_block_closes_at_po2_18():
-    """build_programs (host only): a SYN-A block with po2-20 segments and a po2-18 tail needs 2 lifts, 3 fused lift2 and 4 joins;
-    lifts fit po2 17, everything above po2 18, and the set fits the allowed tree"""
+    """build_programs (host only): a SYN-A block with po2-20 segments and a po2-18 tail needs 2 lifts, 3 fused lift2, 4 joins and the
+    join3 of the largest size (three po2-18 children in one po2-18 proof: conditional-swap blocks made the room); lifts fit po2 17,
+    everything above po2 18, and the set fits the allowed tree"""
     from zeth_amd import recursion as host_rec
     r = np.arange(8, dtype=np.uint32)
     programs = host_rec.build_programs(syn_air.syn_a(), {20: r, 18: r + 1})
     kinds = [k for k, _ in programs]
     assert kinds == [("lift", 20, 0), ("lift", 18, 0), ("lift2", 20, 20), ("lift2", 20, 18), ("lift2", 18, 18),
-                     ("join", 17, 17), ("join", 17, 18), ("join", 18, 17), ("join", 18, 18)]
-    assert [int(b[2]) for _, b in programs] == [17, 17, 18, 18, 18, 18, 18, 18, 18] and len(programs) <= host_rec.N_ALLOWED
+                     ("join", 17, 17), ("join", 17, 18), ("join", 18, 17), ("join", 18, 18), ("join3", 18, 18, 18)]
+    assert [int(b[2]) for _, b in programs] == [17, 17, 18, 18, 18, 18, 18, 18, 18, 18] and len(programs) <= host_rec.N_ALLOWED
+    assert [k for k, _ in host_rec.build_programs(syn_air.syn_a(), {20: r, 18: r + 1}, ternary=False)] == kinds[:-1]
+    j3 = programs[-1][1]
+    assert int(j3[9]) <= ((1 << 18) - R.ZK_CYCLES) // R.BLOCK and int(j3[10]) <= ((1 << 18) - R.ZK_CYCLES) - 2 * (((1 << 18) - R.ZK_CYCLES) // R.BLOCK)
     levels = host_rec.allowed_tree([np.full(8, i + 1, np.uint32) for i in range(len(programs))])
     assert [len(lv) for lv in levels] == [16, 8, 4, 2, 1]
     w = host_rec.membership_words(levels, 5)
@@ -317,8 +339,45 @@ def test_shipped_program_manifest_is_what_the_builder_emits():
     assert {p: [int(w) for w in r] for p, r in roots.items()} == {int(k): v for k, v in man["segment_control_roots"].items()}
     built = {}
     for kind, blob in host_rec.build_programs(desc, roots):
-        name = "-".join(str(x) for x in kind[:2 if kind[0] == "lift" else 3]) + ".zkr1"
+        name = "-".join(str(x) for x in kind[:2 if kind[0] == "lift" else 4 if kind[0] == "join3" else 3]) + ".zkr1"
         built[name] = {"words": int(blob.size), "po2": int(blob[2]), "sha256": hashlib.sha256(np.asarray(blob, dtype="<u4").tobytes()).hexdigest()}
     rdesc = np.asarray(R.recursion_circuit(), dtype="<u4")
     built["recursion.desc"] = {"words": int(rdesc.size), "sha256": hashlib.sha256(rdesc.tobytes()).hexdigest()}
     assert built == man["files"]
+
+
+def test_fold_plan_pairs_first_then_three_at_a_time():
+    """zeth_amd/recursion.py fold_plan: THE shape every fold follows (Recursion.fold / fold_segments, csrc/session.hip, the claim
+    tree): every node of a level is consumed exactly once, the first level pairs, the levels above take three (remainder two: a
+    join, one: moves up); a group of three is join(join(a, b), c) claim-wise."""
+    from zeth_amd import recursion as host_rec
+    for n in (1, 2, 3, 4, 5, 7, 8, 9, 64, 513, 1024):
+        width = n
+        for lv, groups in enumerate(host_rec.fold_plan(n)):
+            assert [k for g in groups for k in g] == list(range(width))
+            assert all(len(g) == (2 if lv == 0 else 3) for g in groups[:-1]) and 1 <= len(groups[-1]) <= (2 if lv == 0 else 3)
+            width = len(groups)
+        assert width == 1
+    plan = host_rec.fold_plan(1024)
+    assert [len(g) for g in plan] == [512, 171, 57, 19, 7, 3, 1]
+    assert sum(1 for lv in plan for g in lv if len(g) > 1) == 768                    # 512 lift2 + 256 joins / join3s (binary: 1023)
+    rng = np.random.default_rng(5)
+    leaves = [rng.integers(0, P, 8, dtype=np.uint32) for _ in range(8)]
+    node = lambda c: (c, 0, 0)
+    par = host_rec._parent_node
+    pairs = [par(node(leaves[2 * k]), node(leaves[2 * k + 1])) for k in range(4)]
+    want = par(par(par(pairs[0], pairs[1]), pairs[2]), pairs[3])                        # level 2: (p0 p1 p2) + p3 carried; level 3: a join
+    assert np.array_equal(host_rec.fold_leaf_claims(leaves), host_rec.wrap_claim(*want))
+    # folded in two ranges of four (one per rank), whose roots rank 0 then joins
+    half = lambda ps: par(ps[0], ps[1])
+    want2 = par(half(pairs[:2]), half(pairs[2:]))
+    assert np.array_equal(host_rec.fold_leaf_claims(leaves, ranks=2), host_rec.wrap_claim(*want2))
+    # states must chain through every group
+    chained = [(leaves[i], 10 + i, 11 + i) for i in range(8)]
+    core, pre, post = host_rec._fold_nodes(chained)
+    assert (pre, post) == (10, 18)
+    broken = list(chained)
+    broken[5] = (leaves[5], 99, 16)
+    from zeth_amd.hal import HalError
+    with pytest.raises(HalError, match="do not chain"):
+        host_rec.fold_leaf_claims(broken)

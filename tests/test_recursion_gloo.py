@@ -74,7 +74,7 @@ def _worker(rank, world, port, q):
         mix = np.array([(i * 7919 + 13) % P for i in range(20)], dtype=np.uint32)
         bad = rec.check_rows(jpo2, rec.rec_accum(jpo2, code, data, mix), code, data, out, mix)
         allc = {k: v for _, part in gathered for k, v in part.items()}
-        want = host_rec.fold_leaf_claims([allc[i] for i in range(N_LEAVES)])
+        want = host_rec.fold_leaf_claims([allc[i] for i in range(N_LEAVES)], ranks=world)
         q.put({"bad_row": bad, "claim_ok": bool(np.array_equal(out[:8], want)), "allowed_ok": bool(np.array_equal(out[8:], A)),
                "ranges": [list(host_rec.aligned_range(N_LEAVES, world, r)) for r in range(world)]})
     dist.barrier()

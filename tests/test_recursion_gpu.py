@@ -165,7 +165,7 @@ def test_block_of_segments_folds_to_one_receipt_that_verified_every_child_in_cir
     programs = rec.build_programs(desc, roots)
     rx = rec.Recursion(hal, programs)
     t_load = time.time() - t0
-    assert [k[0] for k in rx.kinds] == ["lift", "lift", "lift2", "lift2", "lift2", "join", "join", "join", "join"]
+    assert [k[0] for k in rx.kinds] == ["lift", "lift", "lift2", "lift2", "lift2", "join", "join", "join", "join", "join3"]
     assert {p.po2 for p in rx.programs[:2]} == {17} and {p.po2 for p in rx.programs[2:]} == {18}
     hal.sync()
     t0 = time.time()
@@ -194,6 +194,23 @@ def test_block_of_segments_folds_to_one_receipt_that_verified_every_child_in_cir
     bad.seal[bad.seal.size // 3] ^= 1
     with pytest.raises(HalError, match="assertion of the program fails"):
         rx.lift2(leaves[0], bad)
+    # above the bottom level a proof takes THREE nodes: join3(a, b, c) publishes exactly what join(join(a, b), c) does (the inner
+    # claim' is computed in-circuit), verifies all three child seals, and refuses a forged one
+    a3, b3, c3 = two, rx.lift2(leaves[2], leaves[3], 9), rx.lift2(leaves[0], leaves[1], 11)
+    t0 = time.time()
+    j3 = rx.join3(a3, b3, c3, 9)
+    hal.sync()
+    t_join3 = time.time() - t0
+    nested = rx.join(rx.join(a3, b3, 9), c3, 9)
+    assert j3.po2 == 18 and j3.n_leaves == 6 and np.array_equal(j3.claim, nested.claim) and np.array_equal(j3.core, nested.core)
+    assert rx.kinds[j3.program] == ("join3", 18, 18, 18) and np.array_equal(rx.join_group([a3, b3, c3], 9).seal, j3.seal)
+    j3.verify(rx.allowed_roots(), [claims[0], claims[1], claims[2], claims[3], claims[0], claims[1]])
+    forged3 = rec.RecReceipt(c3.seal.copy(), c3.po2, c3.program, c3.control_root, 2, c3.core, 0, 0)
+    forged3.seal[c3.seal.size // 2] ^= 1
+    with pytest.raises(HalError, match="assertion of the program fails"):
+        rx.join3(a3, b3, forged3)
+    with pytest.raises(HalError, match="assertion of the program fails"):          # the third child opened with another node's core
+        rx.join3(a3, b3, rec.RecReceipt(c3.seal, c3.po2, c3.program, c3.control_root, 2, b3.core, 0, 0))
     with pytest.raises(HalError, match="claim tree"):
         root.verify(rx.allowed_roots(), claims[::-1])
     with pytest.raises(HalError, match="allowed set"):
@@ -235,7 +252,7 @@ def test_block_of_segments_folds_to_one_receipt_that_verified_every_child_in_cir
     assert np.array_equal(lifted[0].seal, oc.prove_traces(p20.po2, ocode, odata, oout, ZK, 7))
     line = {"config": "succinct, recursive", "segments": 5, "segment_s": round(t_seg, 3), "program_load_s": round(t_load, 2),
             "lift_s_each": round(t_lift / 5, 4), "join_s_each": round(t_join / 4, 4), "fold_s_9_proofs": round(t_lift + t_join, 4),
-            "fold_s_fused_5_proofs": round(t_fused, 4),
+            "fold_s_fused_5_proofs": round(t_fused, 4), "join3_s": round(t_join3, 4),
             "programs": [{"kind": list(k), "po2": p.po2, "permutations": p.n_p2, "gates": p.n_gates, "levels": p.n_levels,
                           "input_words": p.n_inputs} for k, p in zip(rx.kinds, rx.programs)]}
     print("RECURSION " + json.dumps(line))
@@ -281,7 +298,7 @@ def test_native_session_executor_lifts_and_joins_like_the_python_driver(hal, tmp
     d.mkdir()
     np.asarray(R.recursion_circuit(), dtype="<u4").tofile(d / "recursion.desc")
     for kind, blob in programs:
-        np.asarray(blob, dtype="<u4").tofile(d / ("-".join(str(x) for x in kind[:2 if kind[0] == "lift" else 3]) + ".zkr1"))
+        np.asarray(blob, dtype="<u4").tofile(d / ("-".join(str(x) for x in kind[:2 if kind[0] == "lift" else 4 if kind[0] == "join3" else 3]) + ".zkr1"))
     dpath = tmp_path / "syn_small.desc"
     np.asarray(desc, dtype="<u4").tofile(dpath)
     exe = os.path.join(os.path.dirname(build.build_examples()), "prove_session")
@@ -289,7 +306,9 @@ def test_native_session_executor_lifts_and_joins_like_the_python_driver(hal, tmp
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert out["verified"] is True and out["lifts"] == 3 and out["joins"] == 2 and out["in_circuit_verification"] is True   # 3 lift2
+    m = int(dict(programs)[("lift2", 13, 13)][2])                 # three lift2 nodes of size m: one join3 where the set has it, else two joins
+    has3 = ("join3", m, m, m) in [k for k, _ in programs]
+    assert out["verified"] is True and out["lifts"] == 3 and out["joins"] == (1 if has3 else 2) and out["in_circuit_verification"] is True   # 3 lift2
 
 
 def SegmentReceipt_like(r):

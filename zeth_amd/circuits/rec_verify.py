@@ -116,6 +116,11 @@ class Verifier:
         z = self.pr.zero()
         return self.pr.p2([a[0], a[1], b[0], b[1], z, z])[:2]
 
+    def pair_at(self, bit: int, cur: Sequence[int], sib: Sequence[int]) -> List[int]:
+        """one Merkle level: hash_pair(cur, sib) if the index bit is clear, hash_pair(sib, cur) if it is set — a conditional-swap
+        block (recursion.py `pios`), no gate"""
+        return self.pr.p2([cur[0], cur[1], sib[0], sib[1], bit, self.pr.zero()], swap=True)[:2]
+
     # ---- MerkleTreeVerifier (csrc/verifier.hip:81-117 = risc0-zkp verify/merkle.rs)
     def tree_init(self, rows: int, cols: int) -> dict:
         layers = log2_ceil(rows)
@@ -143,10 +148,7 @@ class Verifier:
         low = t["layers"] - t["top_layer"]
         for lvl in range(low):
             sib = self.read(8)
-            b = idx_bits[lvl]
-            left = [pr.mux(b, cur[k], sib[k]) for k in range(2)]
-            right = [pr.mux(b, sib[k], cur[k]) for k in range(2)]
-            cur = self.pair(left, right)
+            cur = self.pair_at(idx_bits[lvl], cur, sib)
         cand = t["top"][1 << t["top_layer"]:]
         for b in idx_bits[low:]:
             cand = [[pr.mux(b, cand[2 * i][k], cand[2 * i + 1][k]) for k in range(2)] for i in range(len(cand) // 2)]
@@ -407,9 +409,7 @@ class Verifier:
             b = pr.unpack(self.read(1)[0])[0]
             pr.boolean(b)
             sib = self.read(8)
-            left = [pr.mux(b, cur[k], sib[k]) for k in range(2)]
-            right = [pr.mux(b, sib[k], cur[k]) for k in range(2)]
-            cur = self.pair(left, right)
+            cur = self.pair_at(b, cur, sib)
         pr.eq(cur[0], allowed[0])
         pr.eq(cur[1], allowed[1])
 
@@ -470,16 +470,20 @@ def build_lift2(circuit_desc: np.ndarray, po2_left: int, root_left: Sequence[int
     return pr
 
 
-def build_join(recursion_desc: np.ndarray, po2_left: int, po2_right: int) -> Program:
-    """Inputs per child: its seal, its membership path (ALLOWED_DEPTH x (bit, 8 sibling words)), then the OPENING of its claim':
-    core (8 words) and (pre, post).  Each child's out is claim' ‖ A; both A must be this program's A (= its own public output);
-    hash_pair(core, (pre, post, 0..)) must BE the child's claim'; and post(left) = pre(right) — upstream's join asserts the same
-    continuity between the two `ReceiptClaim`s it merges.  out = hash_pair(hash_pair(claim'_l, claim'_r), (pre_l, post_r, 0..)) ‖ A."""
+def build_join(recursion_desc: np.ndarray, *po2s: int) -> Program:
+    """join of two — or THREE — recursion seals.  Inputs per child: its seal, its membership path (ALLOWED_DEPTH x (bit, 8 sibling
+    words)), then the OPENING of its claim': core (8 words) and (pre, post).  Each child's out is claim' ‖ A; every A must be this
+    program's A (= its own public output); hash_pair(core, (pre, post, 0..)) must BE the child's claim'; and post(k) = pre(k + 1)
+    for neighbours — upstream's join asserts the same continuity between the `ReceiptClaim`s it merges.
+    Two children: out = wrap(hash_pair(claim'_l, claim'_r), pre_l, post_r) ‖ A.
+    Three children (a, b, c): out = what join(join(a, b), c) would publish — the inner node's claim' is computed in-circuit (two
+    permutations) instead of proven on its own: one proof where the binary tree needs two."""
+    assert len(po2s) in (2, 3)
     c = Circuit.parse(recursion_desc)
     pr = Program()
     v = Verifier(pr)
     claims, states, allowed = [], [], None
-    for po2 in (po2_left, po2_right):
+    for po2 in po2s:
         v.io = Sponge(pr)
         s = v.verify_seal(c, po2)
         out_packed = s["head"][:4]                               # out = 16 words: claim' (2 wires) ‖ A (2 wires)
@@ -496,10 +500,12 @@ def build_join(recursion_desc: np.ndarray, po2_left: int, po2_right: int) -> Pro
         pr.eq(opened[1], out_packed[1])
         claims.append(out_packed[:2])
         states.append((st[0], st[1]))
-    pr.eq(states[0][1], states[1][0])                             # continuity
-    parent = v.pair(claims[0], claims[1])
-    wrapped = _wrap(v, parent, states[0][0], states[1][1])
-    pr.public(wrapped[0], wrapped[1], allowed[0], allowed[1])
+    node, pre, post = claims[0], states[0][0], states[0][1]
+    for k in range(1, len(po2s)):
+        pr.eq(post, states[k][0])                                 # continuity: child k starts where the node so far ended
+        node = _wrap(v, v.pair(node, claims[k]), pre, states[k][1])
+        post = states[k][1]
+    pr.public(node[0], node[1], allowed[0], allowed[1])
     return pr
 
 
@@ -521,7 +527,7 @@ if __name__ == "__main__":      # python -m zeth_amd.circuits.rec_verify out_dir
     import json
     manifest = {}
     for kind, blob in host_rec.build_programs(desc, roots):
-        name = "-".join(str(x) for x in kind[:2 if kind[0] == "lift" else 3]) + ".zkr1"
+        name = "-".join(str(x) for x in kind[:2 if kind[0] == "lift" else 4 if kind[0] == "join3" else 3]) + ".zkr1"
         path = os.path.join(out_dir, name)
         np.asarray(blob, dtype="<u4").tofile(path)
         manifest[name] = {"words": int(blob.size), "po2": int(blob[2]), "sha256": hashlib.sha256(np.asarray(blob, dtype="<u4").tobytes()).hexdigest()}

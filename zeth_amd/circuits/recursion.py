@@ -19,6 +19,10 @@ and `join` are programs that run the STARK verifier on one / two child seals.  T
     later state cell is a LINEAR form of (S, X_1 .. X_i) with constant coefficients (the powers of the internal matrix);
     row 11 holds the output (bound to the wires).  All constraints have degree <= 3 (+ selector).  The gates of the 10 rows
     between input and output are free for arithmetic, so hashing and arithmetic run side by side;
+  * a block may take its first two digests CONDITIONALLY SWAPPED (`pios` instead of `pio` on its input row): with the bit
+    t = e_0 of the row's fifth wire, S[0..8) = (a b) + t ((c d) - (a b)), S[8..16) = (c d) + t ((a b) - (c d)), S[16] = 0 —
+    one Merkle level (hash_pair(cur, sibling) or hash_pair(sibling, cur), chosen by the index bit, which sits where hash_pair's
+    capacity is zero) costs one block and no gate; as four MUX gates per level it was 19 % of a verifier program's rows;
   * equal wires are tied by a PLONK-style COPY argument in the accum group: position (row, wire) has the id 6 row + wire,
     the code columns sigma_w hold the id of the next position of the same variable, and three running products
         Z_k(row) = Z_k(row - 1) * prod_{w in {2k, 2k+1}} F(id_w, W_w) / F(sigma_w, W_w),
@@ -27,9 +31,10 @@ and `join` are programs that run the STARK verifier on one / two child seals.  T
 The program (gate coefficients, sigma) is the code group, hence the control root identifies the program, as upstream.
 rec_verify.py compiles this repository's verifier (csrc/verifier.hip = risc0-zkp src/verify/mod.rs) into such programs.
 
-Columns:  data 72 = W[6][4] | S[24] | Q[24];  accum 12 = Z[3][4];  code 57:
+Columns:  data 72 = W[6][4] | S[24] | Q[24];  accum 12 = Z[3][4];  code 58:
    0 active 1 first 2 body 3 last   4 rowid   5..10 sigma[6]   11 qM 12 qA 13 qB 14 qC 15 qD 16 qK
    17 qMux 18 qBool 19 qEmb 20..23 qP[4]   24 pio 25 pub   26 lin 27 fullr 28 partA 29 partB 30 lf 31 lpA 32 lpB   33..56 rc[24]
+   57 pios
 Globals: out = 16 words (program-defined: rec_verify puts claim (8) ‖ allowed-programs root (8));  mix = 20 words.
 """
 from __future__ import annotations
@@ -44,12 +49,13 @@ from .desc import GLOBAL_MIX, GLOBAL_OUT, GROUP_ACCUM, GROUP_CODE, GROUP_DATA, P
 
 KIND_RECURSION = 4
 T, BLOCK, NW = 24, 12, 6
-WD, WA, WC, OUT_WORDS, MIX_WORDS = 72, 12, 57, 16, 20
+WD, WA, WC, OUT_WORDS, MIX_WORDS = 72, 12, 58, 16, 20
 PART_A, PART_B = 12, 9                 # partial rounds held by rows 5 and 6 of a block (rounds 4..15, 16..24)
 C_ACTIVE, C_FIRST, C_BODY, C_LAST, C_ROWID, C_SIGMA = 0, 1, 2, 3, 4, 5
 C_QM, C_QA, C_QB, C_QC, C_QD, C_QK = 11, 12, 13, 14, 15, 16
 C_MUX, C_BOOL, C_EMB, C_PACK, C_PIO, C_PUB = 17, 18, 19, 20, 24, 25
 C_LIN, C_FULLR, C_PARTA, C_PARTB, C_LF, C_LPA, C_LPB, C_RC = 26, 27, 28, 29, 30, 31, 32, 33
+C_PIOS = 57
 D_S, D_Q = 24, 48
 NBETA = P - 11
 M4, DIAG, RC = p2_join.M4, p2_join.DIAG, p2_join.RC
@@ -152,6 +158,15 @@ def build_recursion() -> np.ndarray:
     chain = gated(chain, code(C_PUB), [b.sub(W(i // 4, i % 4), out(i)) for i in range(OUT_WORDS)])
     # Poseidon2 blocks (p2_join.py): wires <-> state on the input / output rows, the rounds in between
     chain = gated(chain, code(C_PIO), [b.sub(W(j // 4, j % 4), S(j)) for j in range(T)])
+    # ... or, on an input row, with the first two digests swapped when the bit t = e_0 is set (t sits in the capacity cell that
+    # hash_pair leaves at zero, so S[16] = 0 either way); t is a bit here too, whatever gate produced the wire
+    flat = lambda j: W(j // 4, j % 4)
+    t_bit = we[0]
+    swap = [b.sub(S(j), b.add(flat(j), b.mul(t_bit, b.sub(flat(j + 8), flat(j))))) for j in range(8)]
+    swap += [b.sub(S(j + 8), b.add(flat(j + 8), b.mul(t_bit, b.sub(flat(j), flat(j + 8))))) for j in range(8)]
+    swap += [S(16)] + [b.sub(flat(j), S(j)) for j in range(17, T)]
+    swap += [b.mul(t_bit, b.sub(t_bit, one))]
+    chain = gated(chain, code(C_PIOS), swap)
 
     def times(c, x):
         return x if c == 1 else b.mul(cst[c], x)
@@ -251,9 +266,10 @@ def recursion_circuit() -> np.ndarray:
 # witness ops (executed in order by oracle/recursion.c and csrc/recursion.hip): [op | aux << 8, out, i0 .. i5]
 OP_INPUT, OP_GEN, OP_MUX, OP_PACK, OP_UNPACK, OP_INV, OP_BITS, OP_P2, OP_EQ, OP_ISZ = range(1, 11)
 OP_WORDS = 8
-G_MUX, G_BOOL, G_EMB, G_PACK0, G_PUB = 1, 2, 4, 8, 128          # gate flag bits (G_PACK0 << j)
+G_MUX, G_BOOL, G_EMB, G_PACK0, G_PUB, G_SWAP = 1, 2, 4, 8, 128, 256   # gate flag bits (G_PACK0 << j); G_SWAP marks a block's input row
 PROG_MAGIC = 0x5a4b5231                                             # 'ZKR1'
 PROG_HEADER = 16
+PROG_VERSION = 2                                                    # 2: conditional-swap blocks (OP_P2 aux bit 0, G_SWAP rows, 58 code columns)
 
 
 @dataclass
@@ -271,7 +287,7 @@ class Program:
         self.n_vars = 0
         self.ops: List[Tuple[int, ...]] = []
         self.gates: List[Gate] = []
-        self.p2s: List[Tuple[List[int], int]] = []          # (6 input vars, first of 6 output vars)
+        self.p2s: List[Tuple[List[int], int, bool]] = []    # (6 input vars, first of 6 output vars, conditional swap)
         self.consts: List[int] = []                         # pool of canonical residues (GEN coefficients)
         self._const_at: Dict[Tuple[int, ...], int] = {}
         self._const_var: Dict[Tuple[int, ...], int] = {}
@@ -435,11 +451,13 @@ class Program:
         out = [base + i for i in range(want)]
         return out + ([partial] if want < 31 else [])
 
-    def p2(self, ins: Sequence[int]) -> List[int]:
+    def p2(self, ins: Sequence[int], swap: bool = False) -> List[int]:
+        """one permutation of the six wires; swap: wire 4 is a bit t (a BOOL wire) and the state is (t ? ins[2:4] ‖ ins[0:2] :
+        ins[0:4]) ‖ (0, ins[4]_1..3) ‖ ins[5] — hash_pair with its two digests in the order an index bit says"""
         assert len(ins) == NW
         out = self.var(NW)
-        self.p2s.append((list(ins), out))
-        self._op(OP_P2, out, *ins)
+        self.p2s.append((list(ins), out, bool(swap)))
+        self._op(OP_P2, out, *ins, aux=1 if swap else 0)
         return list(range(out, out + NW))
 
     def public(self, a: int, b: int, c: int, d: int) -> None:
@@ -480,9 +498,11 @@ class Program:
             gq = np.array([list(g.q) + [g.flags] for g in self.gates], dtype=np.int64)
             pos[free_rows] = gp
             gate[free_rows] = gq
-        for p, (ins, out) in enumerate(self.p2s):
+        for p, (ins, out, swap) in enumerate(self.p2s):
             pos[BLOCK * p] = ins
             pos[BLOCK * p + BLOCK - 1] = np.arange(out, out + NW)
+            if swap:
+                gate[BLOCK * p, 6] = G_SWAP
         # copy classes -> sigma
         roots = np.array(self.parent, dtype=np.int64)                  # union-find resolved by pointer jumping (parents point downwards)
         while True:
@@ -505,7 +525,7 @@ class Program:
         posr[used] = cls                                               # the trace is filled from the class representative
         ops = np.array(self.ops, dtype=np.int64).reshape(-1, OP_WORDS) if self.ops else np.zeros((0, OP_WORDS), dtype=np.int64)
         head = np.zeros(PROG_HEADER, dtype=np.int64)
-        head[:9] = [PROG_MAGIC, 1, po2, zk, A, self.n_vars, len(self.consts), len(ops), self.n_inputs]
+        head[:9] = [PROG_MAGIC, PROG_VERSION, po2, zk, A, self.n_vars, len(self.consts), len(ops), self.n_inputs]
         head[9] = len(self.p2s)
         head[10] = len(self.gates)
         table = np.concatenate([gate, sigma.reshape(A, NW)], axis=1)           # 13 words per row
@@ -533,6 +553,16 @@ def f4inv(x):
         b = f4mul(b, b)
         e >>= 1
     return r
+
+
+def swap_state(st: Sequence[int]) -> List[int]:
+    """the input state of a conditional-swap block from the row's 24 wire cells: cell 16 is the bit"""
+    st = list(st)
+    assert st[16] in (0, 1), "conditional swap: the selector is not a bit"
+    if st[16]:
+        st[0:8], st[8:16] = st[8:16], st[0:8]
+    st[16] = 0
+    return st
 
 
 def run_program(prog: Program, inputs: Sequence[int]) -> List[Tuple[int, int, int, int]]:
@@ -567,7 +597,8 @@ def run_program(prog: Program, inputs: Sequence[int]) -> List[Tuple[int, int, in
             for t in range(31):
                 val[out + t] = ((val[i0][0] >> t) & 1, 0, 0, 0)
         elif op == OP_P2:
-            st = [val[v][t] for v in (i0, i1, i2, i3, i4, i5) for t in range(4)]
+            st = swap_state([val[v][t] for v in (i0, i1, i2, i3, i4, i5) for t in range(4)]) if aux & 1 else \
+                [val[v][t] for v in (i0, i1, i2, i3, i4, i5) for t in range(4)]
             o = p2_join.permute(st)
             for w in range(NW):
                 val[out + w] = tuple(o[4 * w:4 * w + 4])

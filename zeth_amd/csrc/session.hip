@@ -393,12 +393,13 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
 
     // ---- the fold plan (join_tree 2), fixed before anything runs: the bottom level turns segment receipts into recursion
     // receipts — a pair of segments is ONE proof where the program set has lift2(po2_l, po2_r) for EVERY pair (lift + lift + join
-    // fused), else every segment is lifted on its own — and every level above pairs nodes (2k, 2k+1), an unpaired last node moves
-    // up unchanged (the tree of host.fold_claims).  A node's program follows from its children's sizes, so a missing program is
-    // reported here, not after the leaves are sealed. ----
+    // fused), else every segment is lifted on its own and the first level above pairs the lifts — and every level above THAT takes
+    // three nodes at a time (zeth_amd/recursion.py fold_plan: one join3 where the program set has it for their sizes, else
+    // join(join(a, b), c), the same node either way), a remainder of two is a join, of one moves up unchanged.  A node's program
+    // follows from its children's sizes, so a missing program is reported here, not after the leaves are sealed. ----
     struct PNode {
-        uint32_t kind = 0;                 // 0 lift(a), 2 lift2(a, b): a, b segment indices; 1 join(a, b): node ids
-        size_t a = 0, b = 0, parent = (size_t)-1;
+        uint32_t kind = 0;                 // 0 lift(a), 2 lift2(a, b): a, b segment indices; 1 join(a, b), 3 join3(a, b, c): node ids
+        size_t a = 0, b = 0, c = 0, parent = (size_t)-1;
         uint32_t program = 0, po2 = 0;
         int pending = 0;                   // children not yet available
         uint32_t* seal = nullptr;
@@ -439,18 +440,39 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
         n_bottom = plan.size();
         std::vector<size_t> cur(n_bottom);
         for (size_t k = 0; k < n_bottom; k++) cur[k] = k;
+        auto add_join = [&](size_t a, size_t b) -> size_t {                 // -> node id, or NONE (perr set)
+            PNode nd; nd.kind = 1; nd.a = a; nd.b = b; nd.pending = 2;
+            const int p = program_of(1, plan[a].po2, plan[b].po2);
+            if (p < 0) { perr = make_err("session_prove: no join program for children of po2 %u and %u", plan[a].po2, plan[b].po2); return NONE; }
+            nd.program = (uint32_t)p; nd.po2 = po2_of(nd.program);
+            plan[a].parent = plan[b].parent = plan.size();
+            plan.push_back(nd);
+            return plan.size() - 1;
+        };
+        // the bottom nodes are the first level's pairs when they are lift2s (and a lone lift); when every segment was lifted on its
+        // own, the first level above still pairs
+        size_t group = all_fused || n < 2 ? 3 : 2;
         while (cur.size() > 1 && !perr) {
             std::vector<size_t> nxt;
-            for (size_t k = 0; k + 1 < cur.size(); k += 2) {
-                PNode nd; nd.kind = 1; nd.a = cur[k]; nd.b = cur[k + 1]; nd.pending = 2;
-                const int p = program_of(1, plan[nd.a].po2, plan[nd.b].po2);
-                if (p < 0) { perr = make_err("session_prove: no join program for children of po2 %u and %u", plan[nd.a].po2, plan[nd.b].po2); break; }
-                nd.program = (uint32_t)p; nd.po2 = po2_of(nd.program);
-                plan[nd.a].parent = plan[nd.b].parent = plan.size();
-                nxt.push_back(plan.size()); plan.push_back(nd);
+            size_t k = 0;
+            for (; k + group <= cur.size() && !perr; k += group) {
+                if (group == 2) { nxt.push_back(add_join(cur[k], cur[k + 1])); continue; }
+                const size_t a = cur[k], b = cur[k + 1], c = cur[k + 2];
+                const int p3 = plan[a].po2 == plan[b].po2 ? program_of(3, plan[a].po2, plan[c].po2) : -1;
+                if (p3 >= 0) {
+                    PNode nd; nd.kind = 3; nd.a = a; nd.b = b; nd.c = c; nd.pending = 3;
+                    nd.program = (uint32_t)p3; nd.po2 = po2_of(nd.program);
+                    plan[a].parent = plan[b].parent = plan[c].parent = plan.size();
+                    nxt.push_back(plan.size()); plan.push_back(nd);
+                } else {                                                        // the same node as two proofs
+                    const size_t ab = add_join(a, b);
+                    nxt.push_back(perr ? NONE : add_join(ab, c));
+                }
             }
-            if (cur.size() % 2) nxt.push_back(cur.back());
+            if (!perr && cur.size() - k == 2) nxt.push_back(add_join(cur[k], cur[k + 1]));
+            else if (!perr && cur.size() - k == 1) nxt.push_back(cur[k]);
             cur.swap(nxt);
+            group = 3;
         }
         if (perr) { zkh_prove_info_free(info); return perr; }
         root_node = cur[0];
@@ -510,16 +532,18 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
         PNode& nd = plan[id];
         in.clear();
         const std::vector<uint32_t>& A = s->allowed.back()[0];
-        if (nd.kind == 1) {
+        if (nd.kind == 1 || nd.kind == 3) {
             // per child: seal, membership path, then the opening of its claim' (core, pre, post) — all checked in-circuit
-            const PNode &a = plan[nd.a], &b = plan[nd.b];
-            for (const PNode* ch : {&a, &b}) {
+            const PNode* ch3[3] = {&plan[nd.a], &plan[nd.b], nd.kind == 3 ? &plan[nd.c] : nullptr};
+            for (const PNode* ch : ch3) {
+                if (!ch) continue;
                 in.insert(in.end(), ch->seal, ch->seal + ch->words);
                 path_of(ch->program, in);
                 in.insert(in.end(), ch->claim.core, ch->claim.core + 8);
                 in.push_back(ch->claim.pre); in.push_back(ch->claim.post);
             }
-            ZKH_TRY(parent_claim(a.claim, b.claim, &nd.claim));
+            ZKH_TRY(parent_claim(ch3[0]->claim, ch3[1]->claim, &nd.claim));
+            if (ch3[2]) { const NodeClaim ab = nd.claim; ZKH_TRY(parent_claim(ab, ch3[2]->claim, &nd.claim)); }     // join3 = join(join(a, b), c)
         } else {
             const zkh_circuit* lc = s->lanes[0].circuit;
             in.assign(info->seals[nd.a], info->seals[nd.a] + info->seal_words[nd.a]);
@@ -538,9 +562,10 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
         uint64_t noise = join_noise_seed;
         if (!noise) ZKH_TRY(os_random64(&noise));
         ZKH_TRY(zkh_rec_prove(l->programs[nd.program], in.data(), in.size(), noise, nullptr, &nd.seal, &nd.words));
-        if (nd.kind == 1) {                                    // children are not kept: the verifier needs the root only
+        if (nd.kind == 1 || nd.kind == 3) {                    // children are not kept: the verifier needs the root only
             zkh_free_seal(plan[nd.a].seal); zkh_free_seal(plan[nd.b].seal);
             plan[nd.a].seal = plan[nd.b].seal = nullptr;
+            if (nd.kind == 3) { zkh_free_seal(plan[nd.c].seal); plan[nd.c].seal = nullptr; }
         }
         return nullptr;
     };
@@ -676,7 +701,7 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
                 const double te = now_s();
                 lk.lock();
                 fold_t += te - ts;
-                if (err) { errs.set(err, plan[id].kind == 1 ? "join" : plan[id].kind == 2 ? "lift2" : "lift"); cv.notify_all(); break; }
+                if (err) { errs.set(err, plan[id].kind == 1 ? "join" : plan[id].kind == 3 ? "join3" : plan[id].kind == 2 ? "lift2" : "lift"); cv.notify_all(); break; }
                 if (id < n_bottom && ++bottom_done == n_bottom) t_bottom_done = now_s();
                 if (id == root_node) { root_done = true; cv.notify_all(); }
                 else if (plan[id].parent != NONE) child_done(plan[id].parent);
@@ -853,10 +878,19 @@ extern "C" const char* zkh_session_verify(zkh_session* s, const zkh_segment* seg
             const bool chained = hc->kind == 1 && hc->global_size[GLOBAL_OUT] == 5;
             nodes[i].pre = chained ? info->seals[i][4] : 0; nodes[i].post = chained ? info->seals[i][0] : 0;
         }
-        while (nodes.size() > 1) {
-            std::vector<NodeClaim> up(nodes.size() / 2);
-            for (size_t k = 0; k < up.size(); k++) ZKH_TRY(parent_claim(nodes[2 * k], nodes[2 * k + 1], &up[k]));
-            if (nodes.size() % 2) up.push_back(nodes.back());
+        // ... in the shape of the fold plan: the first level pairs, every level above takes three at a time (join3 = join(join(a, b),
+        // c)), a remainder of two is a join, of one moves up
+        for (size_t group = 2; nodes.size() > 1; group = 3) {
+            std::vector<NodeClaim> up;
+            size_t k = 0;
+            for (; k + group <= nodes.size(); k += group) {
+                NodeClaim nd;
+                ZKH_TRY(parent_claim(nodes[k], nodes[k + 1], &nd));
+                if (group == 3) { const NodeClaim ab = nd; ZKH_TRY(parent_claim(ab, nodes[k + 2], &nd)); }
+                up.push_back(nd);
+            }
+            if (nodes.size() - k == 2) { NodeClaim nd; ZKH_TRY(parent_claim(nodes[k], nodes[k + 1], &nd)); up.push_back(nd); }
+            else if (nodes.size() - k == 1) up.push_back(nodes[k]);
             nodes.swap(up);
         }
         uint32_t want[8];

@@ -303,8 +303,10 @@ class Session:
         u32p = C.POINTER(C.c_uint32)
         ptrs = (u32p * len(blobs))(*[b.ctypes.data_as(u32p) for b in blobs])
         words = (C.c_size_t * len(blobs))(*[b.size for b in blobs])
-        code = {"lift": 0, "join": 1, "lift2": 2}
-        kinds = np.array([[code[k[0]], k[1], k[2]] for k, _ in programs], dtype=np.uint32).reshape(-1)
+        code = {"lift": 0, "join": 1, "lift2": 2, "join3": 3}
+        for k, _ in programs:
+            assert k[0] != "join3" or k[1] == k[2], "join3: the first two children have one size"
+        kinds = np.array([[code[k[0]], k[1], k[3] if k[0] == "join3" else k[2]] for k, _ in programs], dtype=np.uint32).reshape(-1)
         self._hal._check(self._hal._lib.zkh_session_set_recursion(self.h, self._hal._ptr(rdesc), rdesc.size, ptrs, words, self._hal._ptr(kinds), len(blobs)))
 
     def set_streamed_fold(self, on: bool) -> None:

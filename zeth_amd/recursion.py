@@ -71,25 +71,58 @@ def segment_state(desc, seal) -> Tuple[int, int]:
     return (int(seal[cw[0]]), int(seal[cw[1]])) if cw else (0, 0)
 
 
-def fold_leaf_claims(leaves) -> np.ndarray:
-    """The claim' a lift / lift2 / join tree ends in, recomputed on the host from the LEAVES: [(receipt claim, pre, post)] (a bare
-    8-word claim counts as state (0, 0)).  Node = (core, pre, post): a leaf's core is its receipt claim; a parent's core is
-    hash_pair(claim'_l, claim'_r) and its state range runs from the left child's pre to the right child's post; pairs left to
-    right, an unpaired last node moves up unchanged (the tree of host.join_schedule).  Raises if two neighbours do not chain —
-    the joins could not have been proven: every join asserts post(l) = pre(r) in-circuit."""
+def _parent_node(l, r):
+    """the node a join of l and r publishes, as (core, pre, post): core = hash_pair(claim'_l, claim'_r), range = pre(l) .. post(r);
+    raises if they do not chain — the join could not have been proven: it asserts post(l) = pre(r) in-circuit"""
+    (cl, pl, ql), (cr, pr_, qr) = l, r
+    if ql != pr_:
+        raise _hal.HalError("claim tree: two neighbouring nodes do not chain (post(l) != pre(r)): no join has a witness for them")
+    return hash_pair(wrap_claim(cl, pl, ql), wrap_claim(cr, pr_, qr)), pl, qr
+
+
+def fold_plan(n: int) -> List[List[Tuple[int, ...]]]:
+    """THE shape of a fold over n nodes, level by level: groups of node indices of the level below (a group of one moves up
+    unchanged).  The first level PAIRS (a pair of segments is one lift2; a pair of anything else one join), every level above takes
+    THREE at a time (one join3 where the program set has it for their sizes, else join(join(a, b), c) — the same node either way),
+    a remainder of two is a join, of one moves up.  Everything that folds — Recursion.fold / fold_segments, csrc/session.hip, the
+    claim tree the verifiers recompute — follows this one rule."""
+    levels, width, first = [], n, True
+    while width > 1:
+        g = 2 if first else 3
+        groups = [tuple(range(k, k + g)) for k in range(0, width - width % g, g)]
+        rest = tuple(range(width - width % g, width))
+        if rest:
+            groups.append(rest)
+        levels.append(groups)
+        width, first = len(groups), False
+    return levels
+
+
+def _fold_nodes(level):
+    for groups in fold_plan(len(level)):
+        nxt = []
+        for g in groups:
+            node = level[g[0]]
+            for k in g[1:]:
+                node = _parent_node(node, level[k])
+            nxt.append(node)
+        level = nxt
+    return level[0]
+
+
+def fold_leaf_claims(leaves, ranks: int = 1) -> np.ndarray:
+    """The claim' a lift / lift2 / join / join3 tree ends in, recomputed on the host from the LEAVES: [(receipt claim, pre, post)] (a
+    bare 8-word claim counts as state (0, 0)).  Node = (core, pre, post): a leaf's core is its receipt claim; a parent's core is
+    hash_pair(claim'_l, claim'_r) and its state range runs from the left child's pre to the right child's post; a group of three is
+    join(join(a, b), c).  The shape is `fold_plan`'s; ranks > 1: the leaves were folded in `ranks` contiguous equal ranges (one per
+    GPU, `aligned_range`) whose roots were then folded by the same rule.  Raises if two neighbours do not chain."""
     level = [(np.asarray(l[0], dtype=np.uint32), int(l[1]), int(l[2])) if isinstance(l, (tuple, list)) and len(l) == 3 and not np.isscalar(l[0])
              else (np.asarray(l, dtype=np.uint32), 0, 0) for l in leaves]
-    while len(level) > 1:
-        nxt = []
-        for k in range(len(level) // 2):
-            (cl, pl, ql), (cr, pr_, qr) = level[2 * k], level[2 * k + 1]
-            if ql != pr_:
-                raise _hal.HalError("claim tree: two neighbouring nodes do not chain (post(l) != pre(r)): no join has a witness for them")
-            nxt.append((hash_pair(wrap_claim(cl, pl, ql), wrap_claim(cr, pr_, qr)), pl, qr))
-        if len(level) % 2:
-            nxt.append(level[-1])
-        level = nxt
-    return wrap_claim(*level[0])
+    if ranks > 1:
+        per = len(level) // ranks
+        assert per * ranks == len(level), "fold_leaf_claims: the leaves do not split into equal ranges"
+        level = [_fold_nodes(level[r * per:(r + 1) * per]) for r in range(ranks)]
+    return wrap_claim(*_fold_nodes(level))
 
 
 @dataclass
@@ -126,7 +159,7 @@ class RecReceipt:
             idx >>= 1
         return rc.succinct_receipt_bytes(self.seal, self.control_root, self.claim, journal, self.program, digests, verifier_parameters=allowed_levels[-1][0])
 
-    def verify(self, allowed_roots: Sequence[np.ndarray], leaf_claims: Optional[Sequence[np.ndarray]] = None) -> None:
+    def verify(self, allowed_roots: Sequence[np.ndarray], leaf_claims: Optional[Sequence[np.ndarray]] = None, ranks: int = 1) -> None:
         """Host check of the whole tree below this receipt: ONE seal verification, the program's membership in the allowed
         set, the allowed root the receipt carries, and (given the leaves: receipt claims, or (claim, pre, post) for circuits with a
         state) the claim tree — whose joins each asserted post(l) = pre(r) in-circuit.  Raises HalError."""
@@ -136,7 +169,7 @@ class RecReceipt:
         _hal.HostCircuit(rc.recursion_circuit()).verify_segment(self.seal, self.control_root)
         if not np.array_equal(self.allowed, allowed_tree(roots)[-1][0]):
             raise _hal.HalError("recursion receipt: it was produced under another allowed-programs root")
-        if leaf_claims is not None and not np.array_equal(self.claim, fold_leaf_claims(list(leaf_claims))):
+        if leaf_claims is not None and not np.array_equal(self.claim, fold_leaf_claims(list(leaf_claims), ranks)):
             raise _hal.HalError("recursion receipt: its claim is not the root of the leaves' claim tree")
 
 
@@ -146,14 +179,17 @@ class ProgramSet(list):
 
 
 def build_programs(segment_desc, segment_roots: Optional[Dict[int, np.ndarray]] = None, zk_cycles: int = _hal.ZK_CYCLES,
-                   assumptions: Sequence[Tuple[np.ndarray, Dict[int, np.ndarray]]] = (), fused_pairs: bool = True) -> List[Tuple[Tuple, np.ndarray]]:
+                   assumptions: Sequence[Tuple[np.ndarray, Dict[int, np.ndarray]]] = (), fused_pairs: bool = True,
+                   ternary: bool = True) -> List[Tuple[Tuple, np.ndarray]]:
     """The program set of a block: one lift per segment size (`segment_roots`: {po2: control root of the segment circuit}) and
     per size of every assumption circuit (`assumptions`: [(circuit description, {po2: control root})], e.g. KECCAK-F batches:
     upstream lifts those receipts too and resolves them on the way to the succinct receipt), then joins for every pair of
     child sizes that can meet, until the set of sizes closes (po2-20 / po2-18 SYN-A segments: two lifts at po2 17,
     join(17,17) -> 18, join(17,18), join(18,17), join(18,18) -> 18).  Pure host work, no GPU: [(kind, blob)], kind =
     ("lift", segment po2, family) with family 0 = the segment circuit, 1.. = the assumption circuits, ("lift2", po2_l, po2_r) =
-    lift + lift + join fused for a pair of segment receipts (fused_pairs), or ("join", po2_l, po2_r)."""
+    lift + lift + join fused for a pair of segment receipts (fused_pairs), ("join", po2_l, po2_r), or (ternary) ("join3", m, m, m)
+    for the largest size m when three such children fit one proof of that size again — the levels above the bottom of a large
+    block are all of that size, and take three nodes per proof instead of two."""
     rdesc = rc.recursion_circuit()
     out: List[Tuple[Tuple, np.ndarray]] = []
     sizes = set()
@@ -183,6 +219,11 @@ def build_programs(segment_desc, segment_roots: Optional[Dict[int, np.ndarray]] 
         for a, b in todo:
             done.add((a, b))
             add(("join", a, b), rec_verify.build_join(rdesc, a, b))
+    if ternary and sizes and len(out) < N_ALLOWED:
+        m = max(sizes)
+        pr3 = rec_verify.build_join(rdesc, m, m, m)
+        if pr3.min_po2(zk_cycles) == m:
+            out.append((("join3", m, m, m), pr3.finish(m, zk_cycles)))
     assert len(out) <= N_ALLOWED, f"{len(out)} programs do not fit the allowed set"
     ps = ProgramSet(out)
     ps.families = [(np.asarray(d, dtype=np.uint32), dict(r)) for d, r in families]
@@ -262,25 +303,50 @@ class Recursion:
         core = hash_pair(left.claim, right.claim)
         return RecReceipt(seal, self.programs[i].po2, i, self.programs[i].root, left.n_leaves + right.n_leaves, core, left.pre, right.post)
 
+    def join3(self, a: RecReceipt, b: RecReceipt, c: RecReceipt, noise_seed: Optional[int] = None) -> RecReceipt:
+        """the node join(join(a, b), c) would produce, as ONE proof (the inner node's claim' is computed in-circuit)"""
+        i = self.kinds.index(("join3", a.po2, b.po2, c.po2))
+        parts = []
+        for ch in (a, b, c):
+            if ch.core is None:
+                raise _hal.HalError("join: a child receipt without the opening of its claim (core, pre, post)")
+            parts += [ch.seal, membership_words(self.levels, ch.program), np.asarray(ch.core, dtype=np.uint32), np.array([ch.pre, ch.post], dtype=np.uint32)]
+        seal, _ = self.programs[i].prove(np.concatenate(parts), _seed(noise_seed))
+        inner = wrap_claim(hash_pair(a.claim, b.claim), a.pre, b.post)
+        return RecReceipt(seal, self.programs[i].po2, i, self.programs[i].root, a.n_leaves + b.n_leaves + c.n_leaves,
+                          hash_pair(inner, c.claim), a.pre, c.post)
+
+    def join_group(self, nodes: Sequence[RecReceipt], noise_seed: Optional[int] = None) -> RecReceipt:
+        """one group of `fold_plan`: a single node moves up, two are a join, three a join3 — or join(join(a, b), c) where the
+        program set has no join3 for their sizes (the same node: same claim, one proof more)"""
+        if len(nodes) == 1:
+            return nodes[0]
+        if len(nodes) == 2:
+            return self.join(nodes[0], nodes[1], noise_seed)
+        a, b, c = nodes
+        if ("join3", a.po2, b.po2, c.po2) in self.kinds:
+            return self.join3(a, b, c, noise_seed)
+        return self.join(self.join(a, b, noise_seed), c, noise_seed)
+
     def fold_segments(self, receipts: Sequence[SegmentReceipt], noise_seed: Optional[int] = None) -> RecReceipt:
         """segment receipts -> one receipt: the bottom level pairs them with lift2 where the program set has it (else lift, lift,
-        join), an unpaired last receipt is lifted; the tree above is `fold`.  Same tree, same claims as lifting everything."""
+        join), an unpaired last receipt is lifted; the levels above are `fold_plan`'s (three nodes per proof).  Same tree, same
+        claims as lifting everything and calling `fold`."""
         level: List[RecReceipt] = []
         for k in range(len(receipts) // 2):
             a, b = receipts[2 * k], receipts[2 * k + 1]
             level.append(self.lift2(a, b, noise_seed) if self.has_lift2(a, b) else self.join(self.lift(a, noise_seed), self.lift(b, noise_seed), noise_seed))
         if len(receipts) % 2:
             level.append(self.lift(receipts[-1], noise_seed))
-        return self.fold(level, noise_seed)
+        for groups in fold_plan(len(receipts))[1:]:
+            level = [self.join_group([level[k] for k in g], noise_seed) for g in groups]
+        return level[0]
 
     def fold(self, leaves: Sequence[RecReceipt], noise_seed: Optional[int] = None) -> RecReceipt:
-        """the join tree of host.join_schedule / fold_claims: pairs left to right, an unpaired last node moves up unchanged"""
+        """the tree of `fold_plan` over recursion receipts: the first level pairs, every level above takes three at a time"""
         level = list(leaves)
-        while len(level) > 1:
-            nxt = [self.join(level[2 * k], level[2 * k + 1], noise_seed) for k in range(len(level) // 2)]
-            if len(level) % 2:
-                nxt.append(level[-1])
-            level = nxt
+        for groups in fold_plan(len(level)):
+            level = [self.join_group([level[k] for k in g], noise_seed) for g in groups]
         return level[0]
 
 
