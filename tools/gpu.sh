@@ -91,6 +91,16 @@ foldlanes)
     LD_LIBRARY_PATH=$PWD/zeth_amd ZKH_FOLD_LANES=$k timeout 600 examples/prove_session --desc /tmp/syn_a.desc --recursion-dir $D --segments 1024 --noise-seed 11904 > $O/fold_lanes_$k.json 2>> $O/err.txt
     echo -n "fold lanes $k: "; cut -c150-420 $O/fold_lanes_$k.json
   done ;;
+join3)
+  O=gpurun_out/${1:-join3}; mkdir -p $O          # config 5 with three children per proof above the bottom level (join3) against the same tree proven with joins only
+  D=/tmp/zkr; mkdir -p $D; python -m zeth_amd.circuits.rec_verify $D > /dev/null; python -m zeth_amd.circuits.recursion $D/recursion.desc > /dev/null
+  python -m zeth_amd.circuits.syn_air syn_a /tmp/syn_a.desc > /dev/null
+  for rep in 1 2; do for tag in join3 no-join3; do
+    f=""; [ $tag = no-join3 ] && f="--no-join3"
+    LD_LIBRARY_PATH=$PWD/zeth_amd timeout 600 examples/prove_session --desc /tmp/syn_a.desc --recursion-dir $D --segments 1024 --noise-seed 11904 $f > $O/prove_session_1024_${tag}_$rep.json 2>> $O/err.txt
+    echo -n "$tag $rep: "; cut -c1-600 $O/prove_session_1024_${tag}_$rep.json
+  done; done
+  timeout 900 python bench.py --config succinct --no-cpu-baseline > $O/bench_succinct.json 2>> $O/err.txt; line $O/bench_succinct.json ;;
 inflight)
   O=gpurun_out/${1:-inflight}; mkdir -p $O       # seals in flight per GPU: the headline at 2 / 3 / 4 / 5 / 6 lanes, twice each, interleaved
   for rep in 1 2; do for k in 3 2 4 5 6; do
