@@ -346,3 +346,43 @@ def test_session_over_a_device_list_with_streamed_fold(hal):
         sess.close()
     assert np.array_equal(roots[(0,)][0], roots[(0, 0)][0])
     assert all(np.array_equal(a, b) for a, b in zip(roots[(0,)][1], roots[(0, 0)][1]))
+
+
+def test_gathered_power_tables_travel_inside_the_code_objects(hal, oracle, tmp_path, monkeypatch):
+    """Round 4's eval_check generator gives every kernel its own mix-power table in emission order and exports the exponent list
+    as `<kernel>_exps` inside the code object: a host that attaches the parts needs to know nothing about it.  Kernels generated
+    WITH the table and WITHOUT it give the interpreter's words; a set that mixes the two is refused, not launched."""
+    from zeth_amd.circuits import codegen, jit, syn_heavy
+    from zeth_amd.hal import HalError
+    from zeth_amd.prover import Segment, SegmentProver
+    from test_round2_gpu import _evaluated_groups
+    import zko
+    monkeypatch.setenv("ZKH_JIT_CACHE", str(tmp_path))
+    monkeypatch.setenv("ZKH_CODEGEN_PART", "1600")
+    desc = syn_heavy.syn_heavy_small()
+    prover = SegmentProver(hal, desc)
+    circ = prover.circuit
+    oc = zko.OracleCircuit(oracle, desc)
+    seg = Segment(index=0, po2=10, seed=31, noise_seed=32, zk_cycles=300)
+    ev, _, out, mix = _evaluated_groups(hal, oracle, prover, oc, seg)
+    dom = 4 << seg.po2
+    poly_mix = np.random.default_rng(4).integers(1, 2013265921, size=4, dtype=np.uint64).astype(np.uint32)
+    g_out, g_mix = hal.copy_from("out", out), hal.copy_from("mix", mix)
+    want = hal.alloc_elem("want", 4 * dom)
+    circ.eval_check(want, ev, [g_out, g_mix], poly_mix, seg.po2, use_interpreter=True)
+    want = want.to_vec()
+    objs = {}
+    for gather in (1, 0):
+        monkeypatch.setattr(codegen, "GATHER", gather)
+        objs[gather] = jit.compile_code_objects(desc, use_cache=False)
+        assert len(objs[gather]) >= 2
+    for gather in (1, 0, 1):                                   # gathered, plain, gathered again: a new set replaces the old one whole
+        for i, (img, name) in enumerate(objs[gather]):
+            circ.attach_code_object(img, name, i, len(objs[gather]))
+        assert circ.kernel_kind() == "attached"
+        got = hal.alloc_elem("check", 4 * dom)
+        circ.eval_check(got, ev, [g_out, g_mix], poly_mix, seg.po2)
+        assert np.array_equal(got.to_vec(), want), f"gather={gather}"
+    img, name = objs[0][1]                                     # one plain part among gathered ones: refused when the set completes
+    with pytest.raises(HalError, match="gathered power table"):
+        circ.attach_code_object(img, name, 1, len(objs[1]))
