@@ -199,7 +199,7 @@ const char* zkh_circuit_attach_code_object(zkh_circuit*, const void* image, size
  * zkh_eval_check uses them once all n_parts are attached: part 0 writes `check`, the others add their share.
  * A code object may export `<kernel_name>_exps` (device data: {count, e_0, e_1, ...}): the kernel then reads slot k of
  * EvalCheckArgs::mix_pows as poly_mix^e_k — its powers gathered into the order its code touches them — and zkh_eval_check
- * builds that table per call (all parts of a circuit export it, or none: a mixed set is refused). */
+ * builds that table per call (all parts of a circuit export it, or none: zkh_eval_check refuses a mixed set). */
 const char* zkh_circuit_attach_code_object_part(zkh_circuit*, const void* image, size_t len, const char* kernel_name,
                                                 size_t part, size_t n_parts);
 /* number of kernels zkh_eval_check will launch for this circuit (0: step interpreter) */

@@ -383,6 +383,11 @@ def test_gathered_power_tables_travel_inside_the_code_objects(hal, oracle, tmp_p
         got = hal.alloc_elem("check", 4 * dom)
         circ.eval_check(got, ev, [g_out, g_mix], poly_mix, seg.po2)
         assert np.array_equal(got.to_vec(), want), f"gather={gather}"
-    img, name = objs[0][1]                                     # one plain part among gathered ones: refused when the set completes
+    img, name = objs[0][1]                                     # one plain part among gathered ones: such a set is not launched ...
+    circ.attach_code_object(img, name, 1, len(objs[1]))
     with pytest.raises(HalError, match="gathered power table"):
-        circ.attach_code_object(img, name, 1, len(objs[1]))
+        circ.eval_check(got, ev, [g_out, g_mix], poly_mix, seg.po2)
+    img, name = objs[1][1]                                     # ... and the right part repairs it
+    circ.attach_code_object(img, name, 1, len(objs[1]))
+    circ.eval_check(got, ev, [g_out, g_mix], poly_mix, seg.po2)
+    assert np.array_equal(got.to_vec(), want)

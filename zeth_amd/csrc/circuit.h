@@ -103,6 +103,7 @@ struct zkh_circuit {
     uint32_t* d_gather[2];
     std::vector<uint32_t> gather_off[2];
     std::vector<std::vector<uint32_t>> jit_exps;   // per attached part: its exponent list ({} = none exported)
+    bool jit_mixed;       // the attached parts disagree about the table (a set half replaced): not launched until repaired
     bool interp_ok;       // the step interpreter's live values fit its LDS
     // interpreter program
     std::vector<zkh::InterpInsn> prog;

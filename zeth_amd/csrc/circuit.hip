@@ -683,10 +683,18 @@ extern "C" const char* zkh_circuit_attach_code_object_part(zkh_circuit* c, const
     }
     if (c->jit_modules[part]) (void)hipModuleUnload(c->jit_modules[part]);
     c->jit_modules[part] = mod; c->jit_kernels[part] = fn; c->jit_exps[part] = std::move(exps);
+    c->jit_mixed = false;
     if (jit_complete(c)) {
         std::vector<const uint32_t*> lists;
-        for (const auto& l : c->jit_exps) lists.push_back(l.empty() ? nullptr : l.data());
-        if (const char* err = set_gather(c, 1, lists)) {      // a set that disagrees with itself is not launched
+        size_t exported = 0;
+        for (const auto& l : c->jit_exps) { lists.push_back(l.empty() ? nullptr : l.data()); exported += !l.empty(); }
+        // a set being replaced part by part passes through states where some parts carry a table and some do not: such a set
+        // is never launched (zkh_eval_check refuses it), but attaching the remaining parts repairs it
+        if (exported && exported != lists.size()) {
+            c->jit_mixed = true;
+            std::vector<const uint32_t*> none(lists.size(), nullptr);
+            (void)set_gather(c, 1, none);
+        } else if (const char* err = set_gather(c, 1, lists)) {
             c->jit_kernels[part] = nullptr;
             return err;
         }
@@ -723,6 +731,7 @@ extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_bu
     // the mix powers: the plain table mix^0, mix^1, ... — or, for kernels generated that way, every part's own table, gathered
     // into the order its code reads them (one launch either way)
     const int which = jit_complete(c) ? 1 : 0;
+    ZKH_REQUIRE(use_interpreter || which == 0 || !c->jit_mixed, "eval_check: the attached kernels disagree — some export a gathered power table, some do not (attach every part of ONE generated set)");
     const std::vector<uint32_t>* goff = (!use_interpreter && (which == 1 || c->compiled) && !c->gather_off[which].empty()) ? &c->gather_off[which] : nullptr;
     Tmp pows;
     if (goff) {
