@@ -34,7 +34,7 @@ def test_default_line_has_every_contract_field():
     assert l["timed_seals_verified"] == 60 and l["seal_matches_golden"] is True
     b = l["block"]
     assert b["verified_after_clock"] == b["segments"] == 64 and b["succinct"]["compact_receipt_verified"] is True
-    assert b["recursive"]["root_verified_against_leaf_claims"] is True and b["recursive"]["proofs"] == 63
+    assert b["recursive"]["root_verified_against_leaf_claims"] is True and b["recursive"]["proofs"] == 49        # 32 lift2 + 17 join3 / joins (binary: 63)
     assert "resident" in b["code_group"] and b["recompute_code_group"]["segments_per_s"] > 0
     assert l["block_wall_clock_s"] == b["wall_clock_s"] and l["block_segments_per_s"] == b["segments_per_s"]
     # row f1: the host-preflight pipeline, with the Amdahl term and the PCIe bytes in the line
@@ -70,6 +70,14 @@ def test_config5_line_is_the_streamed_in_circuit_fold():
     assert l["block_wall_clock_s"] < two["block_wall_clock_s"] < 27.8                   # round 3: 27.8 s
     host = _line("r04_prove_session_recursion_1024_streamed.json")                       # the g++ host, no Python in the process
     assert host["wall_s"] <= 26.5 and host["streamed_fold"] is True and host["verified"] is True and host["joins"] == 511      # 25.7-26.3 s over boxes
+    # ... and with three children per proof above the bottom level (conditional-swap blocks made the room): 768 proofs, not 1 023
+    j3, no3 = _line("r04_prove_session_recursion_1024_join3.json"), _line("r04_prove_session_recursion_1024_no_join3.json")
+    assert j3["lifts"] == no3["lifts"] == 512 and j3["joins"] == 256 and no3["joins"] == 511 and j3["verified"] is no3["verified"] is True
+    assert j3["wall_s"] < no3["wall_s"] and j3["wall_s"] <= 25.5 and j3["fold_busy_lane_s"] < 0.85 * no3["fold_busy_lane_s"]
+    ph = _line("r04_prove_session_recursion_1024_join3_two_phase.json")                  # the fold on its own: round 3's 4.2 s -> 3.1 s
+    assert ph["streamed_fold"] is False and ph["lift_s"] + ph["join_tree_s"] <= 3.3 and ph["verified"] is True
+    b3 = _line("r04_bench_succinct_join3.json")
+    assert b3["recursion"]["proofs"] == 768 and b3["succinct_root_follows_from_leaf_claims"] is True and b3["block_wall_clock_s"] < l["block_wall_clock_s"]
 
 
 def test_bench_accepts_the_drivers_flags():
