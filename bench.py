@@ -1058,8 +1058,8 @@ def main() -> None:
         segs = block_segments(S)
         mine = partition_round_robin(S, world, rank)
         if recursive and world > 1:
-            # every rank folds a contiguous, aligned power-of-two range of leaves: its local root is a node of the global join
-            # tree, and rank 0 joins the `world` local roots (the top log2(world) levels)
+            # every rank folds a contiguous, equal range of leaves (zeth_amd/recursion.py fold_plan), and rank 0 folds the `world`
+            # local roots by the same rule: N range trees under one top tree (the verifier: fold_leaf_claims(leaves, ranks = N))
             from zeth_amd.recursion import aligned_range
             try:
                 mine = list(aligned_range(S, world, rank))
@@ -1237,9 +1237,9 @@ def main() -> None:
                                             f"witness generation inside the clock; {rstats['proofs']} proofs of the RECURSION circuit, every node runs the STARK "
                                             f"verifier on its child seal(s) in-circuit; fold {args.fold}"),
                                "po2": args.po2, "circuit": args.circuit, "segments": S,
-                               "parallelism": (f"{world} GPU(s): every rank seals AND folds its own contiguous, aligned power-of-two range of segments "
-                                               f"(a deviation from round-robin, so that a rank's local root is a node of the global join tree), rank 0 joins "
-                                               f"the {world} local roots gathered over gloo; no data-path collective; {inflight} sealing + "
+                               "parallelism": (f"{world} GPU(s): every rank seals AND folds its own contiguous, equal range of segments "
+                                               f"(a deviation from round-robin: a rank folds what it sealed), rank 0 folds "
+                                               f"the {world} local roots gathered over gloo by the same plan; no data-path collective; {inflight} sealing + "
                                                f"{max(args.fold_inflight, inflight) - inflight} fold-only lanes per GPU"),
                                "inflight_per_gpu": inflight, "library": HipHal.version(), "host_placement_rank0": placement,
                                "join_circuit": "recursion (lift2 + join programs, in-circuit verification of every child seal)",

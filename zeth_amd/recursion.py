@@ -231,10 +231,11 @@ def build_programs(segment_desc, segment_roots: Optional[Dict[int, np.ndarray]] 
 
 
 def aligned_range(n_leaves: int, world_size: int, rank: int) -> range:
-    """The leaves rank `rank` folds when a block is spread over `world_size` GPUs: contiguous, aligned power-of-two ranges, so
-    that every rank's local root is a node of the global join tree (the tree of host.fold_claims) and rank 0 only joins the
-    `world_size` local roots - the one exchange of the path: world_size - 1 receipts (~210 KB each) gathered over the control
-    plane.  Needs world_size and n_leaves / world_size to be powers of two."""
+    """The leaves rank `rank` folds when a block is spread over `world_size` GPUs: contiguous, equal ranges; every rank folds its
+    range to a local root (`fold_plan`), rank 0 folds the `world_size` local roots by the same rule - the one exchange of the
+    path: world_size - 1 receipts (~210 KB each) gathered over the control plane - and the verifier recomputes that shape
+    (`fold_leaf_claims(leaves, ranks=world_size)`).  world_size and n_leaves / world_size are kept powers of two (every range
+    then has the same shape, and a block's short tail segment lands in the last range)."""
     per = n_leaves // world_size
     if n_leaves % world_size or per & (per - 1) or world_size & (world_size - 1) or per == 0:
         raise ValueError("the recursive fold on N ranks needs N and S / N to be powers of two")
