@@ -305,7 +305,8 @@ class Session:
         words = (C.c_size_t * len(blobs))(*[b.size for b in blobs])
         code = {"lift": 0, "join": 1, "lift2": 2, "join3": 3}
         for k, _ in programs:
-            assert k[0] != "join3" or k[1] == k[2], "join3: the first two children have one size"
+            if k[0] == "join3" and k[1] != k[2]:
+                raise ValueError("set_recursion: a join3 whose first two children differ in size has no kind code")
         kinds = np.array([[code[k[0]], k[1], k[3] if k[0] == "join3" else k[2]] for k, _ in programs], dtype=np.uint32).reshape(-1)
         self._hal._check(self._hal._lib.zkh_session_set_recursion(self.h, self._hal._ptr(rdesc), rdesc.size, ptrs, words, self._hal._ptr(kinds), len(blobs)))
 
