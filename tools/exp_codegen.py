@@ -64,9 +64,9 @@ def main():
         for k in knobs:
             os.environ.pop("ZKH_CODEGEN_" + k, None)
         for kv in var.split(","):
-            k, v = kv.split("=")
+            k, v = kv.split("=", 1)
             assert k in knobs, k
-            os.environ["ZKH_CODEGEN_" + k] = v
+            os.environ["ZKH_CODEGEN_" + k] = v.replace(";", " ")          # FLAGS=-mllvm;-enable-misched=0
         importlib.reload(codegen)
         importlib.reload(jit)
         t0 = time.perf_counter()
