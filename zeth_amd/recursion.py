@@ -120,7 +120,8 @@ def fold_leaf_claims(leaves, ranks: int = 1) -> np.ndarray:
              else (np.asarray(l, dtype=np.uint32), 0, 0) for l in leaves]
     if ranks > 1:
         per = len(level) // ranks
-        assert per * ranks == len(level), "fold_leaf_claims: the leaves do not split into equal ranges"
+        if per * ranks != len(level):
+            raise ValueError("fold_leaf_claims: the leaves do not split into `ranks` equal ranges")
         level = [_fold_nodes(level[r * per:(r + 1) * per]) for r in range(ranks)]
     return wrap_claim(*_fold_nodes(level))
 
