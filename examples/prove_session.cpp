@@ -7,13 +7,20 @@
 // library; this file only builds the segment list and prints what came back.  (examples/seal_segments.cpp is the same session
 // written out against the low-level entry points.)
 //
-//   prove_session --desc syn_a.desc [--join-desc p2_join.desc | --recursion-dir DIR] [--po2 20] [--tail-po2 18] [--segments 64]
+//   prove_session (--desc syn_a.desc | --circuit syn_a) [--join-desc p2_join.desc | --recursion-dir DIR | --build-recursion]
+//                 [--po2 20] [--tail-po2 18] [--segments 64]
 //                 [--devices 1] [--inflight 3] [--join-po2 18] [--noise-seed N] [--two-phase] [--recompute-code] [--no-join3]
+// --circuit NAME: a circuit description compiled into the library (zkh_shipped_circuit_desc) instead of a file.
+// --build-recursion: no files at all — the lift / lift2 / join / join3 programs of this block are BUILT here, in-process, by the
+// library's C++ builder (zkh_rec_build_program: this library's STARK verifier restated for the RECURSION circuit) from the segment
+// circuit's control roots (computed on the GPU) and the built-in RECURSION description: nothing in the run needs Python.
 // --recursion-dir: the directory `python -m zeth_amd.circuits.rec_verify DIR` and `python -m zeth_amd.circuits.recursion
 // DIR/recursion.desc` wrote (lift-<po2>.zkr1, lift2-<l>-<r>.zkr1, join-<l>-<r>.zkr1, join3-<a>-<b>-<c>.zkr1): lift the receipts (in pairs: lift2) and join them to one root receipt whose
 // every node verified its child seal(s) IN-CIRCUIT (BASELINE.json config 5).
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -33,7 +40,8 @@ static bool read_words(const std::string& path, std::vector<uint32_t>& out) {
 }
 
 int main(int argc, char** argv) {
-    std::string desc_path, join_path, rec_dir;
+    std::string desc_path, join_path, rec_dir, circuit_name;
+    bool build_recursion = false;
     size_t po2 = 20, tail_po2 = 18, n = 64, devices = 1, inflight = 3, join_po2 = 18;
     uint64_t noise = 0;
     bool two_phase = false, recompute_code = false, no_join3 = false;
@@ -41,6 +49,8 @@ int main(int argc, char** argv) {
         const std::string a = argv[i];
         auto num = [&](size_t& d) { if (i + 1 < argc) d = strtoull(argv[++i], nullptr, 10); };
         if (a == "--desc" && i + 1 < argc) desc_path = argv[++i];
+        else if (a == "--circuit" && i + 1 < argc) circuit_name = argv[++i];
+        else if (a == "--build-recursion") build_recursion = true;
         else if (a == "--join-desc" && i + 1 < argc) join_path = argv[++i];
         else if (a == "--recursion-dir" && i + 1 < argc) rec_dir = argv[++i];
         else if (a == "--po2") num(po2);
@@ -56,8 +66,14 @@ int main(int argc, char** argv) {
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     std::vector<uint32_t> desc, jdesc;
-    if (desc_path.empty() || !read_words(desc_path, desc) || (!join_path.empty() && !read_words(join_path, jdesc))) {
-        fprintf(stderr, "usage: %s --desc FILE [--join-desc FILE] [--po2 N] [--tail-po2 N] [--segments S] [--devices G] [--inflight K] [--join-po2 N] [--noise-seed N]\n", argv[0]);
+    if (!circuit_name.empty()) {
+        const uint32_t* w = nullptr;
+        size_t nw = 0;
+        if (const char* e = zkh_shipped_circuit_desc(circuit_name.c_str(), &w, &nw)) { fprintf(stderr, "%s\n", e); zkh_free_error(e); return 2; }
+        desc.assign(w, w + nw);
+    }
+    if ((desc.empty() && (desc_path.empty() || !read_words(desc_path, desc))) || (!join_path.empty() && !read_words(join_path, jdesc))) {
+        fprintf(stderr, "usage: %s (--desc FILE | --circuit NAME) [--join-desc FILE | --recursion-dir DIR | --build-recursion] [--po2 N] [--tail-po2 N] [--segments S] [--devices G] [--inflight K] [--join-po2 N] [--noise-seed N]\n", argv[0]);
         return 2;
     }
     std::vector<int> devs(devices);
@@ -99,6 +115,88 @@ int main(int argc, char** argv) {
         err = zkh_session_set_recursion(session, rdesc.data(), rdesc.size(), ptrs.data(), words.data(), kinds.data(), blobs.size());
         if (err) { fprintf(stderr, "zkh_session_set_recursion: %s\n", err); zkh_free_error(err); return 1; }
     }
+    double build_s = 0;
+    size_t n_built = 0;
+    if (build_recursion) {
+        // 1) the segment circuit's control roots at the block's sizes (one context of our own: code group generated and committed on the GPU)
+        const uint32_t tail = (uint32_t)(tail_po2 < po2 ? tail_po2 : po2);
+        std::vector<uint32_t> sizes = {(uint32_t)po2};
+        if (tail != po2 && n > 1) sizes.push_back(tail);
+        std::vector<std::vector<uint32_t>> roots(sizes.size(), std::vector<uint32_t>(8));
+        {
+            zkh_ctx* ctx = nullptr;
+            zkh_circuit* circ = nullptr;
+            zkh_prover* prover = nullptr;
+            err = zkh_ctx_create(devs[0], "poseidon2", &ctx);
+            if (!err) err = zkh_circuit_load(ctx, desc.data(), desc.size(), &circ);
+            if (!err) err = zkh_prover_create(ctx, circ, &prover);
+            for (size_t k = 0; k < sizes.size() && !err; k++) err = zkh_syn_control_root(prover, sizes[k], ZKH_ZK_CYCLES, roots[k].data());
+            if (prover) zkh_prover_destroy(prover);
+            if (circ) zkh_circuit_destroy(circ);
+            if (ctx) zkh_ctx_destroy(ctx);
+            if (err) { fprintf(stderr, "control roots: %s\n", err); zkh_free_error(err); return 1; }
+        }
+        // 2) the program set of the block (zeth_amd/recursion.py build_programs): a lift per size, a lift2 per pair (a >= b), joins for
+        //    every pair of program sizes until the set closes, and the join3 of the largest size if it fits that size again
+        const uint32_t* rdesc = nullptr;
+        size_t rdesc_words = 0;
+        if ((err = zkh_shipped_circuit_desc("recursion", &rdesc, &rdesc_words))) { fprintf(stderr, "%s\n", err); zkh_free_error(err); return 1; }
+        struct Built { uint32_t kind, a, b; uint32_t* blob; size_t words; };
+        std::vector<Built> built;
+        std::vector<uint32_t> prog_sizes;
+        const auto t_b = std::chrono::steady_clock::now();
+        auto add = [&](uint32_t kind, const uint32_t* d, size_t dw, std::vector<uint32_t> ps, const uint32_t* rts, uint32_t ka, uint32_t kb, bool only_if_po2 = false, uint32_t want = 0) -> bool {
+            ps.resize(3, 0);
+            uint32_t* blob = nullptr;
+            size_t words = 0;
+            if ((err = zkh_rec_build_program(kind, d, dw, ps.data(), rts, ZKH_ZK_CYCLES, &blob, &words))) return false;
+            if (only_if_po2 && blob[2] != want) { zkh_free_seal(blob); return true; }
+            built.push_back({kind, ka, kb, blob, words});
+            bool seen = false;
+            for (uint32_t s : prog_sizes) seen |= s == blob[2];
+            if (!seen) prog_sizes.push_back(blob[2]);
+            return true;
+        };
+        bool ok = true;
+        for (size_t k = 0; k < sizes.size() && ok; k++) ok = add(0, desc.data(), desc.size(), {sizes[k]}, roots[k].data(), sizes[k], 0);
+        for (size_t i = 0; i < sizes.size() && ok; i++)
+            for (size_t j = i; j < sizes.size() && ok; j++) {
+                std::vector<uint32_t> two(roots[i]);
+                two.insert(two.end(), roots[j].begin(), roots[j].end());
+                ok = add(2, desc.data(), desc.size(), {sizes[i], sizes[j]}, two.data(), sizes[i], sizes[j]);
+            }
+        std::vector<std::pair<uint32_t, uint32_t>> done;
+        for (bool more = true; more && ok;) {
+            more = false;
+            std::vector<uint32_t> cur(prog_sizes);
+            std::sort(cur.begin(), cur.end());                 // the order of zeth_amd/recursion.py build_programs: the same allowed-programs root
+            for (uint32_t a : cur)
+                for (uint32_t b : cur) {
+                    bool have = false;
+                    for (auto& p : done) have |= p.first == a && p.second == b;
+                    if (have || !ok) continue;
+                    done.push_back({a, b});
+                    ok = add(1, rdesc, rdesc_words, {a, b}, nullptr, a, b);
+                    more = true;
+                }
+        }
+        if (ok && !no_join3 && !prog_sizes.empty()) {
+            uint32_t m = 0;
+            for (uint32_t s : prog_sizes) m = s > m ? s : m;
+            ok = add(3, rdesc, rdesc_words, {m, m, m}, nullptr, m, m, true, m);
+        }
+        if (!ok) { fprintf(stderr, "zkh_rec_build_program: %s\n", err); zkh_free_error(err); return 1; }
+        build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_b).count();
+        n_built = built.size();
+        std::vector<const uint32_t*> ptrs;
+        std::vector<size_t> words;
+        std::vector<uint32_t> kinds;
+        for (auto& b : built) { ptrs.push_back(b.blob); words.push_back(b.words); kinds.insert(kinds.end(), {b.kind, b.a, b.b}); }
+        err = zkh_session_set_recursion(session, rdesc, rdesc_words, ptrs.data(), words.data(), kinds.data(), built.size());
+        for (auto& b : built) zkh_free_seal(b.blob);
+        if (err) { fprintf(stderr, "zkh_session_set_recursion: %s\n", err); zkh_free_error(err); return 1; }
+    }
+    const bool recursive = !rec_dir.empty() || build_recursion;
     if (two_phase) zkh_session_set_streamed_fold(session, 0);
     if (recompute_code) zkh_session_set_resident_code(session, 0);
     // the session's segment list: S distinct segments, the last one the short tail
@@ -110,19 +208,22 @@ int main(int argc, char** argv) {
         segs[i].noise_seed = noise;                       // 0: fresh OS randomness per segment, like upstream
     }
     zkh_prove_info info;
-    err = zkh_session_prove(session, segs.data(), n, !rec_dir.empty() ? 2 : !jdesc.empty(), join_po2, noise, &info);
+    err = zkh_session_prove(session, segs.data(), n, recursive ? 2 : !jdesc.empty(), join_po2, noise, &info);
     if (err) { fprintf(stderr, "zkh_session_prove: %s\n", err); zkh_free_error(err); return 1; }
     err = zkh_session_verify(session, segs.data(), &info, join_po2);
     if (err) { fprintf(stderr, "REJECTED: %s\n", err); zkh_free_error(err); return 1; }
     size_t words = 0;
     for (size_t i = 0; i < info.n_segments; i++) words += info.seal_words[i];
+    std::string root_out;                                  // the root receipt's public output (claim ‖ allowed-programs root), hex words
+    for (size_t i = 0; i < 16 && i < info.root_seal_words; i++) { char h[12]; snprintf(h, sizeof h, "%08x", info.root_seal[i]); root_out += h; }
     printf("{\"driver\": \"prove_session\", \"library\": \"%s\", \"segments\": %zu, \"po2\": %zu, \"tail_po2\": %u, \"lanes\": %zu, "
            "\"wall_s\": %.4f, \"leaves_s\": %.4f, \"segments_per_s\": %.3f, \"witgen_ms_per_segment\": %.3f, \"lifts\": %zu, \"lift_s\": %.4f, "
            "\"joins\": %zu, \"join_tree_s\": %.4f, \"in_circuit_verification\": %s, \"root_receipt_words\": %zu, \"seal_words_total\": %zu, "
-           "\"streamed_fold\": %s, \"fold_tail_s\": %.4f, \"fold_busy_lane_s\": %.3f, \"segment_retries\": %zu, \"verified\": true}\n",
+           "\"streamed_fold\": %s, \"fold_tail_s\": %.4f, \"fold_busy_lane_s\": %.3f, \"segment_retries\": %zu, "
+           "\"programs_built_in_process\": %zu, \"program_build_s\": %.3f, \"root_out\": \"%s\", \"verified\": true}\n",
            zkh_version(), n, po2, segs[n - 1].po2, zkh_session_lanes(session), info.wall_s, info.leaves_s, n / info.leaves_s,
            1e3 * info.witgen_s_sum / n, info.n_lifts, info.lift_s, info.n_joins, info.join_s, info.n_lifts ? "true" : "false",
-           info.root_seal_words, words, info.streamed ? "true" : "false", info.fold_tail_s, info.fold_busy_s_sum, info.n_retries);
+           info.root_seal_words, words, info.streamed ? "true" : "false", info.fold_tail_s, info.fold_busy_s_sum, info.n_retries, n_built, build_s, root_out.c_str());
     zkh_prove_info_free(&info);
     zkh_session_destroy(session);
     return 0;

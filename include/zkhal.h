@@ -329,6 +329,20 @@ const char* zkh_receipt_decode(const zkh_circuit*, const uint32_t* blob, size_t 
  * A program handle owns its witness buffers and the hipGraph of its schedule: one zkh_rec_witgen / zkh_rec_prove at a time per
  * handle (every lane loads its own). */
 typedef struct zkh_rec_program zkh_rec_program;
+/* The circuit DESCRIPTIONS compiled into the library (the shipped circuits of zeth_amd/circuits/: syn_a, syn_small, syn_tiny, syn_join,
+ * syn_chain, syn_heavy, keccak_f, p2_join, recursion), for hosts without Python; the words are static data (do not free). */
+size_t zkh_shipped_circuit_count(void);
+const char* zkh_shipped_circuit_name(size_t i);                       /* NULL past the end */
+const char* zkh_shipped_circuit_desc(const char* name, const uint32_t** words, size_t* n_words);
+/* The program BUILDER on the host, in C++ (csrc/rec_builder.hip; no GPU, no Python): what zeth_amd/circuits/rec_verify.py +
+ * recursion.py Program.finish produce, word for word (upstream ships its lift / join programs as precompiled .zkr files; a host
+ * without Python builds them here).  kind 0 lift: child_desc = the SEGMENT circuit, po2s[0], control_roots = the 8 words of
+ * its control root at that size as the library hands them out (zkh_syn_control_root: Montgomery form); kind 2 lift2: po2s[0..2),
+ * control_roots = 16 words (left, right); kind 1 join /
+ * kind 3 join3: child_desc = the RECURSION circuit, po2s[0..2) / [0..3), control_roots = NULL.  The program is placed at the
+ * smallest po2 that holds it (blob[2]); *blob is malloc'd: release with zkh_free_seal. */
+const char* zkh_rec_build_program(uint32_t kind, const uint32_t* child_desc, size_t child_desc_words, const uint32_t* po2s,
+                                  const uint32_t* control_roots, uint32_t zk_cycles, uint32_t** blob, size_t* words);
 const char* zkh_rec_program_load(zkh_ctx*, const zkh_circuit* circuit, const uint32_t* blob, size_t words, zkh_rec_program** out);
 void zkh_rec_program_destroy(zkh_rec_program*);
 /* root: the program's control root (Merkle root of its code group); info: po2, zk_cycles, input words, permutations, gates,

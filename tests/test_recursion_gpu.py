@@ -311,6 +311,33 @@ def test_native_session_executor_lifts_and_joins_like_the_python_driver(hal, tmp
     assert out["verified"] is True and out["lifts"] == 3 and out["joins"] == (1 if has3 else 2) and out["in_circuit_verification"] is True   # 3 lift2
 
 
+def test_cpp_host_builds_the_recursion_programs_itself_and_gets_the_python_root(hal, tmp_path):
+    """examples/prove_session --circuit syn_small --build-recursion: NO files — the circuit description comes out of the library, the
+    control roots from the GPU, the lift / lift2 / join / join3 programs from the library's C++ builder (csrc/rec_builder.hip), in the
+    order zeth_amd/recursion.py build_programs uses: the root receipt's public output (claim tree root ‖ allowed-programs root) is
+    the one the Python-built program set gives for the same segments and noise."""
+    import subprocess
+    from zeth_amd import build, recursion as rec
+    from zeth_amd.host import Session
+    from zeth_amd.prover import Segment, SegmentProver
+    desc = syn_air.syn_small()
+    sp = SegmentProver(hal, desc)
+    programs = rec.build_programs(desc, {13: sp.control_root(13), 12: sp.control_root(12)})
+    segs = [Segment(index=i, po2=13 if i < 6 else 12, seed=0x5EED0000 + i, noise_seed=0x51) for i in range(7)]
+    sess = Session(desc, devices=(0,), lanes_per_device=2)
+    sess.set_recursion(programs)
+    _, root, st = sess.prove(segs, join_tree=2, join_noise_seed=0x51, verify=True)
+    sess.close()
+    exe = os.path.join(os.path.dirname(build.build_examples()), "prove_session")
+    r = subprocess.run([exe, "--circuit", "syn_small", "--build-recursion", "--po2", "13", "--tail-po2", "12", "--segments", "7", "--inflight", "2",
+                        "--noise-seed", str(0x51)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["verified"] is True and out["programs_built_in_process"] == len(programs) and out["in_circuit_verification"] is True
+    assert out["lifts"] == st["n_lifts"] and out["joins"] == st["n_joins"]
+    assert out["root_out"] == "".join(f"{int(w):08x}" for w in root.seal[:16])
+
+
 def SegmentReceipt_like(r):
     from zeth_amd.prover import SegmentReceipt
     return SegmentReceipt(seal=r.seal.copy(), index=r.index, po2=r.po2)

@@ -138,6 +138,10 @@ ABI = {
     "zkh_receipt_claim": (_err, [_vp, _u32p, _sz, _u32p, _u32p, _u32p, _u32p]),
     "zkh_receipt_encode": (_err, [_vp, _u32p, _sz, _u32, _u32p, C.POINTER(_u32p), C.POINTER(_sz)]),
     "zkh_receipt_decode": (_err, [_vp, _u32p, _sz, _u32p, C.POINTER(_sz)]),
+    "zkh_shipped_circuit_count": (_sz, []),
+    "zkh_shipped_circuit_name": (C.c_char_p, [_sz]),
+    "zkh_shipped_circuit_desc": (_err, [C.c_char_p, C.POINTER(_u32p), C.POINTER(_sz)]),
+    "zkh_rec_build_program": (_err, [_u32, _u32p, _sz, _u32p, _u32p, _u32, C.POINTER(_u32p), C.POINTER(_sz)]),
     "zkh_rec_program_load": (_err, [_vp, _vp, _u32p, _sz, C.POINTER(_vp)]),
     "zkh_rec_program_destroy": (None, [_vp]),
     "zkh_rec_program_info": (_err, [_vp, _u32p, _u32p]),
