@@ -12,14 +12,13 @@
 //                 [--devices 1] [--inflight 3] [--join-po2 18] [--noise-seed N] [--two-phase] [--recompute-code] [--no-join3]
 // --circuit NAME: a circuit description compiled into the library (zkh_shipped_circuit_desc) instead of a file.
 // --build-recursion: no files at all — the lift / lift2 / join / join3 programs of this block are BUILT here, in-process, by the
-// library's C++ builder (zkh_rec_build_program: this library's STARK verifier restated for the RECURSION circuit) from the segment
-// circuit's control roots (computed on the GPU) and the built-in RECURSION description: nothing in the run needs Python.
+// library (zkh_session_build_recursion -> zkh_rec_build_program: this library's STARK verifier restated for the RECURSION circuit) from the
+// segment circuit's control roots (computed on the GPU) and the built-in RECURSION description: nothing in the run needs Python.
 // --recursion-dir: the directory `python -m zeth_amd.circuits.rec_verify DIR` and `python -m zeth_amd.circuits.recursion
 // DIR/recursion.desc` wrote (lift-<po2>.zkr1, lift2-<l>-<r>.zkr1, join-<l>-<r>.zkr1, join3-<a>-<b>-<c>.zkr1): lift the receipts (in pairs: lift2) and join them to one root receipt whose
 // every node verified its child seal(s) IN-CIRCUIT (BASELINE.json config 5).
 #include <cstdint>
 #include <cstdio>
-#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -118,83 +117,15 @@ int main(int argc, char** argv) {
     double build_s = 0;
     size_t n_built = 0;
     if (build_recursion) {
-        // 1) the segment circuit's control roots at the block's sizes (one context of our own: code group generated and committed on the GPU)
+        // the program set of this block, built and loaded by the library (csrc/rec_builder.hip + the compiled-in RECURSION description)
         const uint32_t tail = (uint32_t)(tail_po2 < po2 ? tail_po2 : po2);
         std::vector<uint32_t> sizes = {(uint32_t)po2};
         if (tail != po2 && n > 1) sizes.push_back(tail);
-        std::vector<std::vector<uint32_t>> roots(sizes.size(), std::vector<uint32_t>(8));
-        {
-            zkh_ctx* ctx = nullptr;
-            zkh_circuit* circ = nullptr;
-            zkh_prover* prover = nullptr;
-            err = zkh_ctx_create(devs[0], "poseidon2", &ctx);
-            if (!err) err = zkh_circuit_load(ctx, desc.data(), desc.size(), &circ);
-            if (!err) err = zkh_prover_create(ctx, circ, &prover);
-            for (size_t k = 0; k < sizes.size() && !err; k++) err = zkh_syn_control_root(prover, sizes[k], ZKH_ZK_CYCLES, roots[k].data());
-            if (prover) zkh_prover_destroy(prover);
-            if (circ) zkh_circuit_destroy(circ);
-            if (ctx) zkh_ctx_destroy(ctx);
-            if (err) { fprintf(stderr, "control roots: %s\n", err); zkh_free_error(err); return 1; }
-        }
-        // 2) the program set of the block (zeth_amd/recursion.py build_programs): a lift per size, a lift2 per pair (a >= b), joins for
-        //    every pair of program sizes until the set closes, and the join3 of the largest size if it fits that size again
-        const uint32_t* rdesc = nullptr;
-        size_t rdesc_words = 0;
-        if ((err = zkh_shipped_circuit_desc("recursion", &rdesc, &rdesc_words))) { fprintf(stderr, "%s\n", err); zkh_free_error(err); return 1; }
-        struct Built { uint32_t kind, a, b; uint32_t* blob; size_t words; };
-        std::vector<Built> built;
-        std::vector<uint32_t> prog_sizes;
         const auto t_b = std::chrono::steady_clock::now();
-        auto add = [&](uint32_t kind, const uint32_t* d, size_t dw, std::vector<uint32_t> ps, const uint32_t* rts, uint32_t ka, uint32_t kb, bool only_if_po2 = false, uint32_t want = 0) -> bool {
-            ps.resize(3, 0);
-            uint32_t* blob = nullptr;
-            size_t words = 0;
-            if ((err = zkh_rec_build_program(kind, d, dw, ps.data(), rts, ZKH_ZK_CYCLES, &blob, &words))) return false;
-            if (only_if_po2 && blob[2] != want) { zkh_free_seal(blob); return true; }
-            built.push_back({kind, ka, kb, blob, words});
-            bool seen = false;
-            for (uint32_t s : prog_sizes) seen |= s == blob[2];
-            if (!seen) prog_sizes.push_back(blob[2]);
-            return true;
-        };
-        bool ok = true;
-        for (size_t k = 0; k < sizes.size() && ok; k++) ok = add(0, desc.data(), desc.size(), {sizes[k]}, roots[k].data(), sizes[k], 0);
-        for (size_t i = 0; i < sizes.size() && ok; i++)
-            for (size_t j = i; j < sizes.size() && ok; j++) {
-                std::vector<uint32_t> two(roots[i]);
-                two.insert(two.end(), roots[j].begin(), roots[j].end());
-                ok = add(2, desc.data(), desc.size(), {sizes[i], sizes[j]}, two.data(), sizes[i], sizes[j]);
-            }
-        std::vector<std::pair<uint32_t, uint32_t>> done;
-        for (bool more = true; more && ok;) {
-            more = false;
-            std::vector<uint32_t> cur(prog_sizes);
-            std::sort(cur.begin(), cur.end());                 // the order of zeth_amd/recursion.py build_programs: the same allowed-programs root
-            for (uint32_t a : cur)
-                for (uint32_t b : cur) {
-                    bool have = false;
-                    for (auto& p : done) have |= p.first == a && p.second == b;
-                    if (have || !ok) continue;
-                    done.push_back({a, b});
-                    ok = add(1, rdesc, rdesc_words, {a, b}, nullptr, a, b);
-                    more = true;
-                }
-        }
-        if (ok && !no_join3 && !prog_sizes.empty()) {
-            uint32_t m = 0;
-            for (uint32_t s : prog_sizes) m = s > m ? s : m;
-            ok = add(3, rdesc, rdesc_words, {m, m, m}, nullptr, m, m, true, m);
-        }
-        if (!ok) { fprintf(stderr, "zkh_rec_build_program: %s\n", err); zkh_free_error(err); return 1; }
-        build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_b).count();
-        n_built = built.size();
-        std::vector<const uint32_t*> ptrs;
-        std::vector<size_t> words;
-        std::vector<uint32_t> kinds;
-        for (auto& b : built) { ptrs.push_back(b.blob); words.push_back(b.words); kinds.insert(kinds.end(), {b.kind, b.a, b.b}); }
-        err = zkh_session_set_recursion(session, rdesc, rdesc_words, ptrs.data(), words.data(), kinds.data(), built.size());
-        for (auto& b : built) zkh_free_seal(b.blob);
-        if (err) { fprintf(stderr, "zkh_session_set_recursion: %s\n", err); zkh_free_error(err); return 1; }
+        err = zkh_session_build_recursion(session, sizes.data(), sizes.size(), no_join3 ? 0 : 1);
+        if (err) { fprintf(stderr, "zkh_session_build_recursion: %s\n", err); zkh_free_error(err); return 1; }
+        build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_b).count();     // control roots + build + load on every lane
+        n_built = 1;
     }
     const bool recursive = !rec_dir.empty() || build_recursion;
     if (two_phase) zkh_session_set_streamed_fold(session, 0);
@@ -220,10 +151,10 @@ int main(int argc, char** argv) {
            "\"wall_s\": %.4f, \"leaves_s\": %.4f, \"segments_per_s\": %.3f, \"witgen_ms_per_segment\": %.3f, \"lifts\": %zu, \"lift_s\": %.4f, "
            "\"joins\": %zu, \"join_tree_s\": %.4f, \"in_circuit_verification\": %s, \"root_receipt_words\": %zu, \"seal_words_total\": %zu, "
            "\"streamed_fold\": %s, \"fold_tail_s\": %.4f, \"fold_busy_lane_s\": %.3f, \"segment_retries\": %zu, "
-           "\"programs_built_in_process\": %zu, \"program_build_s\": %.3f, \"root_out\": \"%s\", \"verified\": true}\n",
+           "\"programs_built_by_library\": %s, \"program_build_and_load_s\": %.3f, \"root_out\": \"%s\", \"verified\": true}\n",
            zkh_version(), n, po2, segs[n - 1].po2, zkh_session_lanes(session), info.wall_s, info.leaves_s, n / info.leaves_s,
            1e3 * info.witgen_s_sum / n, info.n_lifts, info.lift_s, info.n_joins, info.join_s, info.n_lifts ? "true" : "false",
-           info.root_seal_words, words, info.streamed ? "true" : "false", info.fold_tail_s, info.fold_busy_s_sum, info.n_retries, n_built, build_s, root_out.c_str());
+           info.root_seal_words, words, info.streamed ? "true" : "false", info.fold_tail_s, info.fold_busy_s_sum, info.n_retries, n_built ? "true" : "false", build_s, root_out.c_str());
     zkh_prove_info_free(&info);
     zkh_session_destroy(session);
     return 0;

@@ -425,6 +425,11 @@ void zkh_session_set_resident_code(zkh_session*, int on);
  * Every lane loads every program (code groups resident). */
 const char* zkh_session_set_recursion(zkh_session*, const uint32_t* rec_desc, size_t rec_desc_words, const uint32_t* const* blobs,
                                       const size_t* words, const uint32_t* kinds, size_t n_programs);
+/* The same, with the programs BUILT by the library (zkh_rec_build_program; the RECURSION description is compiled in): for a block
+ * whose segments have the sizes po2s[0] > po2s[1] > .. (built-in circuits, kinds 1..3: the control roots come from their own code
+ * generators) — a lift per size, a lift2 per pair, joins until the set of program sizes closes, and (with_join3) the join3 of the
+ * largest size if it fits that size again: the set and the order of zeth_amd/recursion.py build_programs.  No Python, no files. */
+const char* zkh_session_build_recursion(zkh_session*, const uint32_t* po2s, size_t n_po2s, int with_join3);
 /* join_tree == 2 runs as ONE pipeline by default: a lift2 / join is proven the moment both children exist, on the fold lanes while
  * the sealing lanes are still busy with segments, on every lane afterwards (upstream joins as receipts arrive too).  on = 0: two
  * phases (seal everything, then fold).  Same tree, same receipts either way. */

@@ -328,12 +328,17 @@ def test_cpp_host_builds_the_recursion_programs_itself_and_gets_the_python_root(
     sess.set_recursion(programs)
     _, root, st = sess.prove(segs, join_tree=2, join_noise_seed=0x51, verify=True)
     sess.close()
+    sess2 = Session(desc, devices=(0,), lanes_per_device=2)      # the same through the ctypes mirror: zkh_session_build_recursion
+    sess2.build_recursion([s.po2 for s in segs])
+    _, root2, st2 = sess2.prove(segs, join_tree=2, join_noise_seed=0x51, verify=True)
+    sess2.close()
+    assert np.array_equal(root2.seal, root.seal) and st2["root_program"] == st["root_program"]
     exe = os.path.join(os.path.dirname(build.build_examples()), "prove_session")
     r = subprocess.run([exe, "--circuit", "syn_small", "--build-recursion", "--po2", "13", "--tail-po2", "12", "--segments", "7", "--inflight", "2",
                         "--noise-seed", str(0x51)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert out["verified"] is True and out["programs_built_in_process"] == len(programs) and out["in_circuit_verification"] is True
+    assert out["verified"] is True and out["programs_built_by_library"] is True and out["in_circuit_verification"] is True
     assert out["lifts"] == st["n_lifts"] and out["joins"] == st["n_joins"]
     assert out["root_out"] == "".join(f"{int(w):08x}" for w in root.seal[:16])
 

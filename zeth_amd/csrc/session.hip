@@ -282,6 +282,73 @@ static const char* leaf_control_root(zkh_session* s, const zkh_segment& seg, uin
     return zkh_code_root(l.prover, code, seg.po2, root);
 }
 
+// The program set of a block whose segments have the sizes `po2s` (largest first), built HERE (rec_builder.hip: no Python, no
+// files) and loaded on every lane: a lift per size, a lift2 per pair (a >= b), joins for every pair of program sizes until the set
+// closes, the join3 of the largest size if three such children fit that size again (with_join3) — the set and the ORDER of
+// zeth_amd/recursion.py build_programs, hence the same allowed-programs root.  Built-in circuits (kinds 1..3): the control roots
+// come from their own code generators.
+extern "C" const char* zkh_session_build_recursion(zkh_session* s, const uint32_t* po2s, size_t n_po2s, int with_join3) {
+    ZKH_REQUIRE(s && po2s && n_po2s >= 1 && n_po2s <= 4, "session_build_recursion: 1..4 segment sizes");
+    ZKH_REQUIRE(s->lanes[0].circuit->kind >= 1 && s->lanes[0].circuit->kind <= 3, "session_build_recursion: the segment circuit has no built-in code generator "
+                "(build the programs with zkh_rec_build_program from its control roots and use zkh_session_set_recursion)");
+    for (size_t k = 1; k < n_po2s; k++) ZKH_REQUIRE(po2s[k] < po2s[k - 1], "session_build_recursion: sizes go largest first, each once");
+    std::vector<std::vector<uint32_t>> roots(n_po2s, std::vector<uint32_t>(8));
+    for (size_t k = 0; k < n_po2s; k++) {
+        zkh_segment seg;
+        memset(&seg, 0, sizeof seg);
+        seg.po2 = po2s[k];
+        ZKH_TRY(leaf_control_root(s, seg, roots[k].data()));
+    }
+    const uint32_t* rdesc = nullptr;
+    size_t rdesc_words = 0;
+    ZKH_TRY(zkh_shipped_circuit_desc("recursion", &rdesc, &rdesc_words));
+    struct Built { uint32_t kind, a, b; uint32_t* blob; size_t words; };
+    std::vector<Built> built;
+    struct Free { std::vector<Built>& b; ~Free() { for (auto& x : b) zkh_free_seal(x.blob); } } free_blobs{built};
+    std::vector<uint32_t> sizes;
+    auto add = [&](uint32_t kind, const uint32_t* d, size_t dw, std::vector<uint32_t> ps, const uint32_t* rts, uint32_t ka, uint32_t kb, uint32_t only_po2 = 0) -> const char* {
+        ps.resize(3, 0);
+        uint32_t* blob = nullptr;
+        size_t words = 0;
+        ZKH_TRY(zkh_rec_build_program(kind, d, dw, ps.data(), rts, ZKH_ZK_CYCLES, &blob, &words));
+        if (only_po2 && blob[2] != only_po2) { zkh_free_seal(blob); return nullptr; }
+        built.push_back({kind, ka, kb, blob, words});
+        if (std::find(sizes.begin(), sizes.end(), blob[2]) == sizes.end()) sizes.push_back(blob[2]);
+        return nullptr;
+    };
+    const std::vector<uint32_t>& desc = s->desc;
+    for (size_t k = 0; k < n_po2s; k++) ZKH_TRY(add(0, desc.data(), desc.size(), {po2s[k]}, roots[k].data(), po2s[k], 0));
+    for (size_t i = 0; i < n_po2s; i++)
+        for (size_t j = i; j < n_po2s; j++) {
+            std::vector<uint32_t> two(roots[i]);
+            two.insert(two.end(), roots[j].begin(), roots[j].end());
+            ZKH_TRY(add(2, desc.data(), desc.size(), {po2s[i], po2s[j]}, two.data(), po2s[i], po2s[j]));
+        }
+    std::vector<std::pair<uint32_t, uint32_t>> done;
+    for (bool more = true; more;) {
+        more = false;
+        std::vector<uint32_t> cur(sizes);
+        std::sort(cur.begin(), cur.end());
+        for (uint32_t a : cur)
+            for (uint32_t b : cur) {
+                if (std::find(done.begin(), done.end(), std::make_pair(a, b)) != done.end()) continue;
+                done.push_back({a, b});
+                ZKH_TRY(add(1, rdesc, rdesc_words, {a, b}, nullptr, a, b));
+                more = true;
+            }
+    }
+    if (with_join3 && built.size() < REC_ALLOWED) {
+        const uint32_t m = *std::max_element(sizes.begin(), sizes.end());
+        ZKH_TRY(add(3, rdesc, rdesc_words, {m, m, m}, nullptr, m, m, m));
+    }
+    ZKH_REQUIRE(built.size() <= REC_ALLOWED, "session_build_recursion: %zu programs do not fit the allowed set", built.size());
+    std::vector<const uint32_t*> ptrs;
+    std::vector<size_t> words;
+    std::vector<uint32_t> kinds;
+    for (auto& b : built) { ptrs.push_back(b.blob); words.push_back(b.words); kinds.insert(kinds.end(), {b.kind, b.a, b.b}); }
+    return zkh_session_set_recursion(s, rdesc, rdesc_words, ptrs.data(), words.data(), kinds.data(), built.size());
+}
+
 // one segment on one lane: built-in witness generator, or the caller's traces through prove_begin / accumulate / prove_finish
 // records / ram: this segment's preflight output in pinned memory (witness source 1), or NULL: run the preflight here (a retry)
 static const char* seal_one(zkh_session* s, Lane& l, const zkh_segment& seg, uint32_t** seal, size_t* words, double* witgen_s,

@@ -310,6 +310,13 @@ class Session:
         kinds = np.array([[code[k[0]], k[1], k[3] if k[0] == "join3" else k[2]] for k, _ in programs], dtype=np.uint32).reshape(-1)
         self._hal._check(self._hal._lib.zkh_session_set_recursion(self.h, self._hal._ptr(rdesc), rdesc.size, ptrs, words, self._hal._ptr(kinds), len(blobs)))
 
+    def build_recursion(self, po2s, join3: bool = True) -> None:
+        """the program set of a block with segments of the sizes `po2s`, built by the LIBRARY (csrc/rec_builder.hip: the C++ twin of
+        zeth_amd.recursion.build_programs — same programs, same order, same allowed-programs root) and loaded on every lane"""
+        np = self._np
+        sizes = np.array(sorted({int(p) for p in po2s}, reverse=True), dtype=np.uint32)
+        self._hal._check(self._hal._lib.zkh_session_build_recursion(self.h, self._hal._ptr(sizes), sizes.size, int(join3)))
+
     def set_streamed_fold(self, on: bool) -> None:
         """join_tree=2: prove a lift2 / join the moment its children exist, concurrently with the sealing lanes (default), or hold
         the fold back until the last segment is sealed (two phases).  Same tree, same receipts."""
