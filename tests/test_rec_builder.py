@@ -99,5 +99,9 @@ def test_cpp_builder_refuses_what_it_cannot_build():
         cpp_build(0, syn_air.syn_a(), [20])
     with pytest.raises(hal.HalError, match="bad circuit description"):
         cpp_build(0, np.arange(64, dtype=np.uint32), [12], [[1] * 8])
+    bad = np.asarray(syn_air.syn_tiny(), dtype=np.uint32).copy()
+    bad[-5 * 3 + 1] = 0xFFFF                                          # a step whose first operand names no value
+    with pytest.raises(hal.HalError, match="operand out of range|result is not"):
+        cpp_build(0, bad, [8], [[1] * 8], 50)
     with pytest.raises(hal.HalError, match="child po2"):
         cpp_build(0, syn_air.syn_a(), [40], [[1] * 8])

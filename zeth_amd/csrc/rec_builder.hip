@@ -64,6 +64,25 @@ const char* parse_desc(const u32* d, size_t n, Desc& c) {
     }
     ZKH_REQUIRE(pos + 5 * (size_t)n_steps <= n, "rec_build: circuit description is truncated (steps)");
     for (u32 i = 0; i < n_steps; i++, pos += 5) c.steps.push_back({d[pos], d[pos + 1], d[pos + 2], d[pos + 3], d[pos + 4]});
+    // operands name earlier values only (what zkh_circuit_load checks before a circuit reaches the GPU): the builder indexes by them
+    u32 cf = 0, cm = 0;
+    for (const Step& st : c.steps) {
+        bool ok = true;
+        switch (st.op) {
+        case S_CONST: case S_CONST_EXT: break;
+        case S_GET: ok = st.a < n_taps; break;
+        case S_GET_GLOBAL: ok = st.a <= 1 && st.b < c.global_size[st.a]; break;
+        case S_ADD: case S_SUB: case S_MUL: ok = st.a < cf && st.b < cf; break;
+        case S_TRUE: break;
+        case S_AND_EQZ: ok = st.a < cm && st.b < cf; break;
+        case S_AND_COND: ok = st.a < cm && st.b < cf && st.c < cm; break;
+        default: ok = false;
+        }
+        ZKH_REQUIRE(ok, "rec_build: the circuit description has a step with an operand out of range");
+        if (st.op >= S_TRUE) cm++; else cf++;
+    }
+    ZKH_REQUIRE(c.ret < cm, "rec_build: the circuit description's result is not a mix value");
+    for (const auto& t : c.taps) ZKH_REQUIRE(t[0] < 3 && t[1] < c.group_size[t[0]], "rec_build: a tap names a column outside its group");
     for (const auto& t : c.taps) {                                   // registers in tap order, each with its back-set's combo
         if (!c.regs.empty() && c.regs.back().group == t[0] && c.regs.back().offset == t[1]) c.regs.back().backs.push_back(t[2]);
         else c.regs.push_back({t[0], t[1], {t[2]}, 0});
