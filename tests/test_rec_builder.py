@@ -80,6 +80,10 @@ def test_cpp_builder_equals_python_on_other_circuit_shapes():
                                 ("syn_chain_small", syn_air.syn_chain_small(), 9, R.ZK_CYCLES)):
         py = V.build_lift(desc, po2, root)
         assert np.array_equal(cpp_build(0, desc, [po2], [root], zk), py.finish(py.min_po2(zk), zk)), name
+    from zeth_amd.circuits import keccak_f, p2_join
+    for name, desc in (("keccak_f", keccak_f.keccak_f_circuit()), ("p2_join", p2_join.p2_join_circuit())):       # 3 840 columns, 43.8 k steps: a po2-19 lift
+        py = V.build_lift(desc, 13, root)
+        assert np.array_equal(cpp_build(0, desc, [13], [root]), py.finish(py.min_po2())), name
     chain = syn_air.syn_chain_small()                                # lift2 of a CHAINED circuit: the continuity assertion and the state words
     py = V.build_lift2(chain, 9, root, 8, other)
     assert np.array_equal(cpp_build(2, chain, [9, 8], [root, other]), py.finish(py.min_po2()))
