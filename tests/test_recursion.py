@@ -17,6 +17,12 @@ def enc(vals):
     return np.array([int(v) * RM % P for v in vals], dtype=np.uint32)
 
 
+def dec(vals):
+    """Montgomery words -> canonical residues"""
+    rinv = pow((1 << 32) % P, -1, P)
+    return [int(v) * rinv % P for v in vals]
+
+
 def small_program():
     pr = R.Program()
     x, y = pr.input(0, 4), pr.input(4, 4)
@@ -102,6 +108,28 @@ def test_every_kind_of_gate_and_the_copy_argument_bind_the_trace(rec):
     # the copy argument alone: a wire nobody's gate reads, but which shares a variable with another position
     r_in = R.BLOCK                                                  # input row of the second permutation: its wire a is h[0]
     assert broken(0, r_in) >= 0 and broken(R.D_S + 5, 3) >= 0 and broken(R.D_Q + 2, R.BLOCK + 2) >= 0 and broken(R.D_Q + 5, 5) >= 0 and broken(R.D_Q + 17, R.BLOCK + 6) >= 0
+    # conditional-swap blocks: the input state is the wires' digests in the order the bit says, and nothing else - a block whose S
+    # cells hold the OTHER order (with its permutation rows recomputed, so that only the `pios` binding can object), a swap bit that
+    # is not a bit, and a stray capacity cell are all found
+    swaps = np.nonzero(cg[R.C_PIOS])[0]
+    assert swaps.size == 2 and all(int(r) % R.BLOCK == 0 for r in swaps) and not cg[R.C_PIO][swaps].any()
+    dm = data.reshape(R.WD, n)
+    for r0 in (int(r) for r in swaps):
+        wires = [int(dm[j, r0]) for j in range(R.T)]
+        bit = wires[16]
+        assert bit in (0, int(enc([1])[0]))
+        want = wires[8:16] + wires[0:8] if bit else wires[0:16]
+        assert [int(dm[R.D_S + j, r0]) for j in range(16)] == want and int(dm[R.D_S + 16, r0]) == 0
+        d = data.copy().reshape(R.WD, n)
+        other = wires[0:16] if bit else wires[8:16] + wires[0:8]                   # the order the bit does NOT say
+        rows = R.block_rows([int(x) for x in dec(other)] + [0] + [int(x) for x in dec(wires[17:])])
+        for k, (S_, Q_) in enumerate(rows):
+            d[R.D_S:R.D_S + R.T, r0 + k] = enc(S_)
+            d[R.D_Q:R.D_Q + R.T, r0 + k] = enc(Q_)
+        d = d.reshape(-1)
+        bad = rec.check_rows(po2, rec.rec_accum(po2, code, d, MIX, zk), code, d, out, MIX)
+        assert bad == r0, (bad, r0)                                                 # exactly the input row objects
+        assert broken(R.D_S + 16, r0) >= 0                                          # S[16] must be zero
     # the out globals are bound to the PUB row
     o2 = out.copy()
     o2[3] = (int(o2[3]) + 1) % P
