@@ -456,6 +456,15 @@ void zkh_prove_info_free(zkh_prove_info*);
  * (hash_pair over the leaf claims, recomputed on the host) against the root's public output */
 const char* zkh_session_verify(zkh_session*, const zkh_segment* segs, const zkh_prove_info* info, size_t join_po2);
 
+/* `receipt.verify` for a SUCCINCT receipt on the host alone — no GPU, no session (upstream: SuccinctReceipt::verify_integrity, reached
+ * from /root/reference/crates/host/src/bin/cli.rs:103): ONE seal of the RECURSION circuit (description compiled in) under the control
+ * root of program `root_program` of the allowed set (allowed_roots: n_allowed x 8 words, in the order the prover loaded its
+ * programs), the allowed-programs root the receipt carries, and its claim = the root of the leaves' claim tree.  leaves: n_leaves x
+ * 10 words = (receipt claim digest [8], pre, post) per segment, taken from VERIFIED segment receipts or from the statement being
+ * checked; ranks = 1, or N when the block was folded as N contiguous equal ranges whose roots were folded again (§7). */
+const char* zkh_succinct_verify(const uint32_t* root_seal, size_t root_words, const uint32_t* allowed_roots, size_t n_allowed,
+                                size_t root_program, const uint32_t* leaves, size_t n_leaves, size_t ranks);
+
 /* ---- host placement (topology.hip): one process per GPU / one lane thread per context should run on the cores of the NUMA node
  * the GPU's root port hangs off, and allocate its pinned witness blocks there (upstream leaves placement to the operator:
  * /root/reference/run-parallel.sh:15 starts one prover per GPU and pins nothing).  Host only; sysfs + sched_setaffinity. ---- */

@@ -283,6 +283,15 @@ def test_join_verifies_two_lifts_in_circuit(oracle, rec):
     forged.seal[left.size // 2] ^= 1
     with pytest.raises(HalError):
         forged.verify(roots, [claim])
+    # the same checks as ONE host-only library call (zkh_succinct_verify: what a non-Python verifier runs; no GPU, no session)
+    host_rec.succinct_verify(left, roots, 0, [claim])
+    host_rec.succinct_verify(left, roots, 0, [(claim, 0, 0)])
+    for args, what in (((left, roots[::-1], 1, [claim]), "allowed-programs root"), ((left, roots, 1, [claim]), "root receipt"),
+                       ((left, roots, 0, [claim[::-1].copy()]), "claim tree"), ((left, roots, 0, [(claim, 0, 7)]), "claim tree"),
+                       ((forged.seal, roots, 0, [claim]), "root receipt"), ((left, roots, 0, [claim, claim]), "claim tree"),
+                       ((left, roots, 2, [claim]), "not in the allowed set"), ((left, roots, 0, [claim, claim, claim], 2), "equal ranges")):
+        with pytest.raises(HalError, match=what):
+            host_rec.succinct_verify(*args)
     stranger = lifted(101, np.arange(8, dtype=np.uint32))                       # a valid lift, handed another allowed root
     with pytest.raises(RuntimeError, match="tie"):
         rec.rec_witgen(jblob, np.concatenate([left, path, opening(100), stranger, path, opening(101)]))

@@ -181,6 +181,9 @@ def test_block_of_segments_folds_to_one_receipt_that_verified_every_child_in_cir
         assert np.array_equal(l.claim, rec.wrap_claim(c, 0, 0)) and np.array_equal(l.core, c) and np.array_equal(l.allowed, rx.allowed_root())
     assert root.n_leaves == 5 and root.po2 == 18
     root.verify(rx.allowed_roots(), claims)                         # ONE seal + the claim tree: nothing else is needed
+    rec.succinct_verify(root.seal, rx.allowed_roots(), root.program, claims)       # the same as one host-only library call (zkh_succinct_verify)
+    with pytest.raises(HalError, match="claim tree"):
+        rec.succinct_verify(root.seal, rx.allowed_roots(), root.program, claims[::-1])
     # the same tree with the bottom level fused: lift2 = lift + lift + join as one proof per pair of segments (5 proofs, not 9)
     t0 = time.time()
     fused = rx.fold_segments(leaves, noise_seed=9)
@@ -205,6 +208,7 @@ def test_block_of_segments_folds_to_one_receipt_that_verified_every_child_in_cir
     assert j3.po2 == 18 and j3.n_leaves == 6 and np.array_equal(j3.claim, nested.claim) and np.array_equal(j3.core, nested.core)
     assert rx.kinds[j3.program] == ("join3", 18, 18, 18) and np.array_equal(rx.join_group([a3, b3, c3], 9).seal, j3.seal)
     j3.verify(rx.allowed_roots(), [claims[0], claims[1], claims[2], claims[3], claims[0], claims[1]])
+    rec.succinct_verify(j3.seal, rx.allowed_roots(), j3.program, [claims[0], claims[1], claims[2], claims[3], claims[0], claims[1]])
     forged3 = rec.RecReceipt(c3.seal.copy(), c3.po2, c3.program, c3.control_root, 2, c3.core, 0, 0)
     forged3.seal[c3.seal.size // 2] ^= 1
     with pytest.raises(HalError, match="assertion of the program fails"):

@@ -176,6 +176,72 @@ static const char* parent_claim(const NodeClaim& l, const NodeClaim& r, NodeClai
     return nullptr;
 }
 
+// the fold plan's shape over claim nodes (zeth_amd/recursion.py fold_plan): the first level pairs, every level above takes three at
+// a time (a group of three is join(join(a, b), c)), a remainder of two is a join, of one moves up
+static const char* fold_claim_nodes(std::vector<NodeClaim> nodes, NodeClaim* root) {
+    ZKH_REQUIRE(!nodes.empty(), "claim tree: no leaves");
+    for (size_t group = 2; nodes.size() > 1; group = 3) {
+        std::vector<NodeClaim> up;
+        size_t k = 0;
+        for (; k + group <= nodes.size(); k += group) {
+            NodeClaim nd;
+            ZKH_TRY(parent_claim(nodes[k], nodes[k + 1], &nd));
+            if (group == 3) { const NodeClaim ab = nd; ZKH_TRY(parent_claim(ab, nodes[k + 2], &nd)); }
+            up.push_back(nd);
+        }
+        if (nodes.size() - k == 2) { NodeClaim nd; ZKH_TRY(parent_claim(nodes[k], nodes[k + 1], &nd)); up.push_back(nd); }
+        else if (nodes.size() - k == 1) up.push_back(nodes[k]);
+        nodes.swap(up);
+    }
+    *root = nodes[0];
+    return nullptr;
+}
+
+// `receipt.verify` for a SUCCINCT receipt, on the host alone (no GPU, no session): what zeth_amd/recursion.py RecReceipt.verify does.
+extern "C" const char* zkh_succinct_verify(const uint32_t* root_seal, size_t root_words, const uint32_t* allowed_roots, size_t n_allowed,
+                                           size_t root_program, const uint32_t* leaves, size_t n_leaves, size_t ranks) {
+    ZKH_REQUIRE(root_seal && allowed_roots && leaves, "succinct_verify: null argument");
+    ZKH_REQUIRE(n_allowed >= 1 && n_allowed <= REC_ALLOWED && root_program < n_allowed, "succinct_verify: the receipt's program is not in the allowed set");
+    ZKH_REQUIRE(n_leaves >= 1 && ranks >= 1 && n_leaves % ranks == 0, "succinct_verify: %zu leaves do not split into %zu equal ranges", n_leaves, ranks);
+    ZKH_REQUIRE(root_words > 16, "succinct_verify: not a recursion seal");
+    // 1) ONE seal, under the control root of an allowed program
+    const uint32_t* rdesc = nullptr;
+    size_t rdesc_words = 0;
+    ZKH_TRY(zkh_shipped_circuit_desc("recursion", &rdesc, &rdesc_words));
+    zkh_circuit* rc = nullptr;
+    ZKH_TRY(zkh_circuit_load(nullptr, rdesc, rdesc_words, &rc));
+    std::unique_ptr<zkh_circuit, void (*)(zkh_circuit*)> hold(rc, zkh_circuit_destroy);
+    if (const char* e = zkh_verify_segment(rc, root_seal, root_words, allowed_roots + 8 * root_program, nullptr, nullptr)) {
+        const char* out = make_err("succinct_verify: root receipt: %s", e);
+        zkh_free_error(e);
+        return out;
+    }
+    // 2) the allowed-programs root the receipt carries is the root of THIS set (16 leaves, zero padded)
+    std::vector<std::vector<uint32_t>> level(REC_ALLOWED, std::vector<uint32_t>(8, 0));
+    for (size_t i = 0; i < n_allowed; i++) level[i].assign(allowed_roots + 8 * i, allowed_roots + 8 * i + 8);
+    while (level.size() > 1) {
+        std::vector<std::vector<uint32_t>> up(level.size() / 2, std::vector<uint32_t>(8));
+        for (size_t k = 0; k < up.size(); k++) ZKH_TRY(hash_pair_host(level[2 * k].data(), level[2 * k + 1].data(), up[k].data()));
+        level.swap(up);
+    }
+    ZKH_REQUIRE(memcmp(root_seal + 8, level[0].data(), 32) == 0, "succinct_verify: the receipt was produced under another allowed-programs root");
+    // 3) its claim is the root of the leaves' claim tree: `ranks` contiguous equal ranges folded on their own, their roots folded again
+    std::vector<NodeClaim> nodes(n_leaves);
+    for (size_t i = 0; i < n_leaves; i++) { memcpy(nodes[i].core, leaves + 10 * i, 32); nodes[i].pre = leaves[10 * i + 8]; nodes[i].post = leaves[10 * i + 9]; }
+    if (ranks > 1) {
+        const size_t per = n_leaves / ranks;
+        std::vector<NodeClaim> tops(ranks);
+        for (size_t r = 0; r < ranks; r++) ZKH_TRY(fold_claim_nodes(std::vector<NodeClaim>(nodes.begin() + r * per, nodes.begin() + (r + 1) * per), &tops[r]));
+        nodes.swap(tops);
+    }
+    NodeClaim top;
+    ZKH_TRY(fold_claim_nodes(nodes, &top));
+    uint32_t want[8];
+    ZKH_TRY(wrap_claim(top, want));
+    ZKH_REQUIRE(memcmp(root_seal, want, 32) == 0, "succinct_verify: the receipt's claim is not the root of the leaves' claim tree");
+    return nullptr;
+}
+
 extern "C" const char* zkh_session_set_recursion(zkh_session* s, const uint32_t* rec_desc, size_t rec_desc_words, const uint32_t* const* blobs,
                                                  const size_t* words, const uint32_t* kinds, size_t n_programs) {
     ZKH_REQUIRE(s && rec_desc && rec_desc_words >= 16 && blobs && words && kinds && n_programs && n_programs <= REC_ALLOWED, "session_set_recursion: bad argument");

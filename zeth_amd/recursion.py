@@ -126,6 +126,24 @@ def fold_leaf_claims(leaves, ranks: int = 1) -> np.ndarray:
     return wrap_claim(*_fold_nodes(level))
 
 
+def succinct_verify(root_seal, allowed_roots: Sequence[np.ndarray], root_program: int, leaves, ranks: int = 1) -> None:
+    """zkh_succinct_verify: `RecReceipt.verify` as ONE host-only library call (no GPU, no session) — the seal under an allowed
+    program's control root, the allowed-programs root, the claim tree of the leaves ([(receipt claim, pre, post)] or bare claims).
+    Raises HalError."""
+    import ctypes as C
+    lib = _hal.load_library()
+    u32p = C.POINTER(C.c_uint32)
+    seal = np.ascontiguousarray(root_seal, dtype=np.uint32)
+    roots = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=np.uint32) for r in allowed_roots]))
+    rows = []
+    for l in leaves:
+        core, pre, post = (l if isinstance(l, (tuple, list)) and len(l) == 3 and not np.isscalar(l[0]) else (l, 0, 0))
+        rows.append(np.concatenate([np.asarray(core, dtype=np.uint32), np.array([pre, post], dtype=np.uint32)]))
+    lv = np.ascontiguousarray(np.concatenate(rows))
+    _hal._check(lib.zkh_succinct_verify(seal.ctypes.data_as(u32p), seal.size, roots.ctypes.data_as(u32p), len(allowed_roots), int(root_program),
+                                        lv.ctypes.data_as(u32p), len(rows), int(ranks)))
+
+
 @dataclass
 class RecReceipt:
     """`SuccinctReceipt` analogue: one seal of the RECURSION circuit under program `program` (index into the allowed set).
