@@ -84,7 +84,7 @@ def test_bench_accepts_the_drivers_flags():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup", "--config", "--join-circuit", "--fold-inflight", "--no-fused-lift", "--fold", "--executor",
-                 "--recompute-code", "--no-preflight-leg"):
+                 "--recompute-code", "--no-preflight-leg", "--no-join3", "--witness"):
         assert flag in out.stdout, flag
 
 
