@@ -1011,23 +1011,11 @@ extern "C" const char* zkh_session_verify(zkh_session* s, const zkh_segment* seg
             const bool chained = hc->kind == 1 && hc->global_size[GLOBAL_OUT] == 5;
             nodes[i].pre = chained ? info->seals[i][4] : 0; nodes[i].post = chained ? info->seals[i][0] : 0;
         }
-        // ... in the shape of the fold plan: the first level pairs, every level above takes three at a time (join3 = join(join(a, b),
-        // c)), a remainder of two is a join, of one moves up
-        for (size_t group = 2; nodes.size() > 1; group = 3) {
-            std::vector<NodeClaim> up;
-            size_t k = 0;
-            for (; k + group <= nodes.size(); k += group) {
-                NodeClaim nd;
-                ZKH_TRY(parent_claim(nodes[k], nodes[k + 1], &nd));
-                if (group == 3) { const NodeClaim ab = nd; ZKH_TRY(parent_claim(ab, nodes[k + 2], &nd)); }
-                up.push_back(nd);
-            }
-            if (nodes.size() - k == 2) { NodeClaim nd; ZKH_TRY(parent_claim(nodes[k], nodes[k + 1], &nd)); up.push_back(nd); }
-            else if (nodes.size() - k == 1) up.push_back(nodes[k]);
-            nodes.swap(up);
-        }
+        // ... in the shape of the fold plan (fold_claim_nodes: pairs, then three at a time)
+        NodeClaim top;
+        ZKH_TRY(fold_claim_nodes(nodes, &top));
         uint32_t want[8];
-        ZKH_TRY(wrap_claim(nodes[0], want));
+        ZKH_TRY(wrap_claim(top, want));
         ZKH_REQUIRE(info->root_seal_words > 16 && memcmp(info->root_seal, want, 32) == 0,
                     "session_verify: the root receipt does not commit to the claim tree of these segments");
         ZKH_REQUIRE(memcmp(info->root_seal + 8, s->allowed.back()[0].data(), 32) == 0, "session_verify: the root receipt was produced under another allowed-programs root");
