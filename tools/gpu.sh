@@ -91,6 +91,10 @@ foldlanes)
     LD_LIBRARY_PATH=$PWD/zeth_amd ZKH_FOLD_LANES=$k timeout 600 examples/prove_session --desc /tmp/syn_a.desc --recursion-dir $D --segments 1024 --noise-seed 11904 > $O/fold_lanes_$k.json 2>> $O/err.txt
     echo -n "fold lanes $k: "; cut -c150-420 $O/fold_lanes_$k.json
   done ;;
+overlap)
+  O=gpurun_out/${1:-overlap}; mkdir -p $O        # can a VALU-bound and an HBM-bound kernel be paired deliberately (stream priorities, occupancy share)?
+  [ -x tools/ubench_overlap ] || hipcc --offload-arch=gfx950 -O3 tools/ubench_overlap.hip -o tools/ubench_overlap
+  timeout 120 tools/ubench_overlap | tee $O/ubench_overlap.jsonl ;;
 join3)
   O=gpurun_out/${1:-join3}; mkdir -p $O          # config 5 with three children per proof above the bottom level (join3) against the same tree proven with joins only
   D=/tmp/zkr; mkdir -p $D; python -m zeth_amd.circuits.rec_verify $D > /dev/null; python -m zeth_amd.circuits.recursion $D/recursion.desc > /dev/null
