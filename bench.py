@@ -323,6 +323,12 @@ def main() -> None:
     ap.add_argument("--no-certify", action="store_true", help="segment config: do not verify the timed seals / compare with the golden digest after the clock")
     args = ap.parse_args()
 
+    # a source-only snapshot (the GPU box) has no built library: build it before anything else — once, under a file lock, so the
+    # ranks of a launcher-started run serialise on it and all but the first find it done (a current tree costs milliseconds)
+    from zeth_amd import build as _build
+    t_build = time.perf_counter()
+    _build.ensure_built(oracle=not args.no_cpu_baseline)
+    build_s = time.perf_counter() - t_build
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args, sys.argv[1:]))
 

@@ -17,11 +17,10 @@ P = 2013265921
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # a fresh checkout has no built artefacts: build them once (hipcc cross-compiles gfx950 without a GPU)
+    # a fresh checkout / the GPU box's source-only snapshot has no built artefacts: build them (incremental; a current tree
+    # costs milliseconds; hipcc cross-compiles gfx950 without a GPU); xdist workers serialise on the build lock
     from zeth_amd import build as _build
-    if not os.path.exists(_build.LIB) or not os.path.exists(os.path.join(ROOT, "oracle", "libzkoracle.so")):
-        _build.build()
-        _build.build_oracle()
+    _build.ensure_built(oracle=True)
 
 
 @pytest.fixture(scope="session")
