@@ -2,1561 +2,221 @@
 """bench.py — segments/sec for sealing 2^20-cycle zkVM segments on N MI355X (BASELINE.json metric).
 
 One "step" = one segment seal (commit code/data, accum, eval_check, DEEP, FRI, queries).
-Configs (SURVEY.md §8d restatements of BASELINE.json's configs):
+Configs (SURVEY.md §8d restatements of BASELINE.json's configs; one module each under benchlib/):
 
   --config segment  (default; BASELINE config 2)  every step seals one 2^po2-cycle segment whose witness is already
                     resident in HBM when the clock starts; N GPUs = N ranks each doing K steps ("scaling": "weak").
+                    The same run then measures, as guarded secondary legs: the SYN-HEAVY constraint system, the resident
+                    code group, a short block (S distinct segments, witgen in the clock, all verified), the host-preflight
+                    witness pipeline and the block's fold to one receipt; then roofline{} (live HBM traffic and VALU issue
+                    from rocprofv3 --pmc child runs) and cpu_baseline{}.
   --config block    (configs 3/4)  one block = S DISTINCT segments (seeds base+i, the last one a po2-18 tail), handed out
                     round-robin over the ranks and through a shared work index inside a rank; witness generation runs
-                    inside the clock (reported separately), every seal is verified on the host after the clock stops;
-                    value = S / wall ("scaling": "strong").
-  --config succinct (config 5)  S leaf segments + the binary P2-JOIN join tree (Poseidon2 in-circuit) down to one root receipt; joins run on the
-                    rank that holds the left child, right children cross the gloo control plane.
+                    inside the clock, every seal is verified on the host after the clock stops; value = S / wall ("strong").
+  --config succinct (config 5)  S leaf segments sealed and folded to ONE root receipt (lift2 / join3 / join programs of the
+                    RECURSION circuit: every node verifies its child seals in-circuit), one native call per rank.
+  --config dev      (config 1)  RISC0_DEV_MODE plumbing: fake receipts, no GPU — the partition, control plane and assembly only.
 
-  --circuit syn_heavy  seals with the realistically heavy constraint system instead of SYN-A.
-  --ingress host       additionally times the PCIe-inclusive path: traces uploaded from pinned host memory every step.
+    python bench.py                         # N=1, K=60, W=2 (about a minute)
+    python bench.py --gpus 8                # self-launching: spawns 8 ranks (one GPU each), kills siblings if one dies
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W          # the driver's launch shape
 
-The default line also carries two secondary measurements of the same step, neither of which is `value`: `syn_heavy` (the
-heavy constraint system) and `code_group_resident` (the per-size code group kept in HBM instead of re-committed per
-segment: DESIGN.md §3); --no-heavy / --no-resident skip them.
-
-    python bench.py                         # N=1, K=60, W=2
-    python bench.py --gpus 8                # self-launching: spawns 8 ranks (gloo control plane, one GPU each)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W          # the driver's launch shape works too
+N > 1: one process per GPU, NO data-path collective (segments are independent); the control plane (barriers, MAX over ranks,
+gathers) is a key/value store that survives a dead rank (benchlib/control.py): rank 0 still prints the line, with `failed_ranks`.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
-import socket
-import subprocess
 import sys
-import threading
 import time
+from datetime import timedelta
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
-PO2 = 20
-TAIL_PO2 = 18                   # the short last segment of a block (SURVEY.md §8d config 3)
-CPU_SAMPLE_PO2 = 17             # thread-count probe runs at 2^15 cycles; the timed sample is the largest po2 <= 20 that fits the budget
-CPU_SAMPLE_BUDGET_S = 30.0
-BASE_SEED = 0x5EED0000
-BENCH_NOISE = 0x2E80            # fixed blinding seed: bench seals must be reproducible run to run (product default: OS RNG)
+from benchlib.common import PO2, Run                                          # noqa: E402
+from benchlib.control import TIMEOUT_S, ControlPlane, RankFailed, launch_ranks  # noqa: E402
+from benchlib.roofline import add_roofline, by_op                              # noqa: E402,F401  (re-exported: tests/test_bench_contract.py)
 
 
-def seal_algorithmic_bytes(wa: int, wc: int, wd: int, n_taps: int, n_combos: int, n: int) -> float:
-    """SURVEY.md §8d per-op read-once + write-once bytes for ONE seal, parametric in the column counts."""
-    groups = [wc, wd, wa]
-    commit = sum(60 * w + 512 for w in groups) * n                 # iNTT, shift, expand-NTT, bitrev, hash_rows, hash_fold
-    sigma = wa + wc + wd
-    eval_check = (16 * sigma + 64) * n
-    check_group = (128 + 44 * 16 + 512) * n
-    deep = 4 * (sigma + 16) * n * 1                                 # each column streamed once per evaluation pass
-    mix = (4 * (sigma + 16) + 4 * 2 * 16 * (n_combos + 1)) * n
-    combos = (2 * 32 * (n_combos + 1) + 16 * (n_combos + 1) + 16 + 32) * n
-    fri = 208 * n
-    return float(commit + eval_check + check_group + deep + mix + combos + fri)
-
-
-_CPU_WORKER = r"""
-import os, sys, time, json
-cpus = [int(c) for c in sys.argv[3].split(",")] if sys.argv[3] else []
-if cpus:
-    try:
-        os.sched_setaffinity(0, cpus)
-    except OSError:
-        pass
-try:                                          # memory follows the worker's own cores (first touch), not the bench rank's GPU node
-    import ctypes
-    ctypes.CDLL(None, use_errno=True).syscall(238, 0, None, 0)      # x86-64 set_mempolicy(MPOL_DEFAULT)
-except Exception:
-    pass
-sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
-import zko                                   # test infrastructure; here ONLY as the reported CPU baseline
-from zeth_amd.circuits import syn_air, syn_heavy
-desc = syn_heavy.syn_heavy() if sys.argv[2] == "syn_heavy" else syn_air.syn_a()
-lib = zko.load()
-oc = zko.OracleCircuit(lib, desc)
-po2, seed, noise = int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
-sys.stdout.write("ready\n"); sys.stdout.flush()
-sys.stdin.readline()                          # all workers start their seal together
-t0 = time.perf_counter()
-seal = oc.prove(po2, 1994, seed, noise)
-print(json.dumps({"s": time.perf_counter() - t0, "words": int(seal.size)})); sys.stdout.flush()
-"""
-
-
-def cpu_baseline(desc, circuit_name: str, cpus=None) -> dict:
-    """The CPU oracle (a from-spec port of the reference CPU prover's algorithm) on this host's cores, two figures:
-    (1) ONE seal alone at the thread count where the oracle's OpenMP loops stop scaling (latency), and
-    (2) the WHOLE host: floor(cores / threads) independent seals at once, one process each, pinned to disjoint core blocks
-        (the reference proves segments independently, so a CPU-only deployment would fill its cores exactly like this) ->
-        aggregate segments/s = `value`, `cores` = all cores those processes used.
-    About 10-30 s of CPU work each.  On a host where the whole unit fits that budget (the GPU box: one po2-20 seal in ~20 s)
-    the unit itself is timed; otherwise the largest power-of-two fraction of it that does, scaled linearly (work ~ n)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import zko                                     # test infrastructure; used here ONLY as the reported CPU baseline
-    lib = zko.load()
-    oc = zko.OracleCircuit(lib, desc)
-    # the oracle's OpenMP loops stop scaling long before a two-socket host is full (fork/join + memory bound): scan a
-    # few thread counts on a small segment and run every seal at the fastest one
-    # `cpus`: the CPUs this process could use BEFORE it bound itself next to its GPU (host placement) — the baseline is the whole host's
-    try:
-        usable = sorted(cpus) if cpus else sorted(os.sched_getaffinity(0))
-        os.sched_setaffinity(0, usable)
-    except (AttributeError, OSError):
-        usable = list(range(os.cpu_count() or 1))
-    avail = len(usable)
-    probe_po2 = CPU_SAMPLE_PO2 - 2
-    best, best_dt = avail, None
-    for t in sorted({c for c in (8, 16, 32, 64, avail) if c <= avail}):
-        lib.zko_set_num_threads(t)
-        t0 = time.perf_counter()
-        oc.prove(probe_po2, 1994, BASE_SEED, BENCH_NOISE)
-        d = time.perf_counter() - t0
-        if best_dt is None or d < best_dt:
-            best, best_dt = t, d
-    if os.environ.get("ZKH_CPU_BASELINE_THREADS"):             # tests: force the per-process thread count
-        best = max(1, min(avail, int(os.environ["ZKH_CPU_BASELINE_THREADS"])))
-    lib.zko_set_num_threads(best)
-    sample_po2 = probe_po2
-    while sample_po2 < PO2 and best_dt * (1 << (sample_po2 + 1 - probe_po2)) <= CPU_SAMPLE_BUDGET_S:
-        sample_po2 += 1
-    t0 = time.perf_counter()
-    seal = oc.prove(sample_po2, 1994, BASE_SEED, BENCH_NOISE)
-    dt = time.perf_counter() - t0
-    scale = 1 << (PO2 - sample_po2)
-    how = "the unit itself, no extrapolation" if scale == 1 else f"scaled x1/{scale} to the po2={PO2} unit (work is ~linear in n)"
-    single = {"value": 1.0 / (dt * scale), "seal_s": dt * scale, "cores": best,
-              "sample": f"one {circuit_name} segment seal at po2={sample_po2} alone on the host ({dt:.2f} s wall, OpenMP oracle incl. witgen, at the "
-                        f"fastest of 8/16/32/64/{avail} threads = {best}); {how}"}
-    out = {"value": single["value"], "unit": "segments/s", "cores": best, "cores_available": avail, "kind": "port",
-           "sample": single["sample"], "single_seal": single,
-           "note": "a literal, untuned port (the reference CPU prover cannot be built here); reported as the contract asks, "
-                   "never a target and never a quotable speed-up",
-           "seal_words": int(seal.size)}
-    # ---- the whole host: P = floor(cores / best) processes, `best` threads each, disjoint core blocks, distinct segments ----
-    # (a bounded sample: the seals of this leg are 1/16 of the unit each — with every core busy the memory-bound oracle runs ~20 x
-    # slower per seal than alone, and the whole command has to stay within minutes)
-    procs_n = max(1, avail // best)
-    full_po2 = max(probe_po2, sample_po2 - 4)              # measured on the GPU box: 16 seals at once run ~20 x slower each than one alone
-    full_scale = 1 << (PO2 - full_po2)
-    try:
-        mem_avail = next(int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable:")) * 1024
-        per_proc = 10e9 * (1 << full_po2) / (1 << 20)            # measured: 0.49 GB of RSS per 2^16 cycles (SYN-A), 8 GB at po2 20
-        procs_n = max(1, min(procs_n, int(0.8 * mem_avail / per_proc)))
-    except (OSError, StopIteration, ValueError):
-        pass
-    workers = []
-    if procs_n > 1:
-        try:
-            for k in range(procs_n):
-                block = usable[k * best:(k + 1) * best]
-                env = dict(os.environ, OMP_NUM_THREADS=str(best), OMP_PROC_BIND="false")
-                for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
-                    env.pop(var, None)
-                workers.append(subprocess.Popen([sys.executable, "-c", _CPU_WORKER, ROOT, circuit_name, ",".join(map(str, block)), str(full_po2),
-                                                 str(BASE_SEED + k), str(BENCH_NOISE)], env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True))
-            for w in workers:
-                if w.stdout.readline().strip() != "ready":
-                    raise RuntimeError("a CPU baseline worker did not start")
-            t0 = time.perf_counter()
-            for w in workers:
-                w.stdin.write("go\n"); w.stdin.flush()
-            import select
-            times, deadline = [], time.perf_counter() + 3.0 * CPU_SAMPLE_BUDGET_S
-            for w in workers:
-                left = deadline - time.perf_counter()
-                if left <= 0 or not select.select([w.stdout], [], [], left)[0]:
-                    raise TimeoutError(f"the full-host leg did not finish within {3.0 * CPU_SAMPLE_BUDGET_S:.0f} s")
-                times.append(json.loads(w.stdout.readline())["s"])
-            wall = time.perf_counter() - t0
-            for w in workers:
-                w.wait(timeout=60)
-            agg = procs_n / (wall * full_scale)
-            fhow = "the unit itself" if full_scale == 1 else f"scaled x1/{full_scale} to the po2={PO2} unit (work is ~linear in n)"
-            full = {"value": agg, "cores": procs_n * best, "processes": procs_n, "threads_each": best, "sample_po2": full_po2, "wall_s": wall,
-                    "seal_s_under_load": times,
-                    "sample": f"{procs_n} independent {circuit_name} segment seals at po2={full_po2} at once, one process x {best} OpenMP threads each on "
-                              f"disjoint core blocks of the whole host, memory local to each block ({wall:.2f} s wall for all, {min(times):.1f}-{max(times):.1f} s "
-                              f"per seal under load; OpenMP oracle incl. witgen): {procs_n * best} of {avail} cores; {fhow}"}
-            out["full_host"] = full
-            if agg >= single["value"]:       # the host's best: every core busy
-                out.update(value=agg, cores=full["cores"], sample=full["sample"] + f"; one po2-{sample_po2} seal alone: {dt:.2f} s at {best} threads")
-            else:                            # the oracle is memory-bound: filling every core yields LESS than one seal at a time
-                out["sample"] += (f"; with every core busy ({procs_n} seals at once x {best} threads = {procs_n * best} of {avail} cores) the host does "
-                                  f"{agg:.4f} segments/s - less than one seal at a time, so the single-seal figure is the host's best and is the one quoted")
-        except Exception as e:           # the single-seal figure stands
-            out["full_host_error"] = repr(e)
-        for w in workers:
-            if w.poll() is None:
-                w.kill()
-    return out
-
-
-def live_traffic(kernels, circuit: str, po2: int, budget_s: float = 150.0, device: int = 0):
-    """HBM bytes per launch of the kernels whose names start with one of `kernels`, measured NOW: two child runs of this script
-    (one serial seal each, no extra legs, on `device` only) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` — separate
-    passes, kernel trace only, as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes; FETCH_SIZE doubled per that guide's
-    gfx950 correction.  -> (bytes per launch, launches, description) or None when rocprofv3 is unavailable / a pass fails / the
-    budget runs out."""
-    import csv
-    import glob
-    import re
-    import shutil
-    import tempfile
-    if shutil.which("rocprofv3") is None:
-        return None
-    if isinstance(kernels, str):
-        kernels = (kernels,)
-    env = dict(os.environ, TMPDIR="/tmp")
-    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "ZKH_BENCH_CHILD", "ZKH_SHARE_GPUS", "GROUP_RANK", "ROLE_RANK",
-                "LOCAL_WORLD_SIZE", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
-        env.pop(var, None)
-    visible = [v for v in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if v != ""]
-    env["HIP_VISIBLE_DEVICES"] = visible[device] if device < len(visible) else str(device)      # the child sees this rank's GPU as device 0
-    t0 = time.perf_counter()
-    sums = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        left = budget_s - (time.perf_counter() - t0)
-        if left < 20:
-            return None
-        d = tempfile.mkdtemp(prefix="zkh_pmc_", dir="/tmp")
-        cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "bench", "--",
-               sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--inflight", "1", "--po2", str(po2),
-               "--circuit", circuit, "--no-cpu-baseline", "--no-prof", "--no-heavy", "--no-resident", "--no-block", "--no-certify",
-               "--no-live-traffic"]
-        try:
-            subprocess.run(cmd, cwd="/tmp", env=env, timeout=left, stdout=subprocess.DEVNULL,
-                           stderr=subprocess.DEVNULL, check=True)
-            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            vals = []
-            for r in csv.DictReader(open(files[0])):
-                m = re.search(r"(k_[A-Za-z0-9_]+)", r["Kernel_Name"])
-                if m and any(m.group(1) == k or (k.endswith("_") and m.group(1).startswith(k)) for k in kernels) and r.get("Counter_Name", counter) == counter:
-                    vals.append(float(r["Counter_Value"]) * 1024.0)           # rocprofv3 reports KB
-            if not vals:
-                return None
-            sums[counter] = vals
-        except Exception:
-            return None
-        finally:
-            shutil.rmtree(d, ignore_errors=True)
-    n = len(sums["FETCH_SIZE"])
-    per_launch = (2.0 * sum(sums["FETCH_SIZE"]) + sum(sums["WRITE_SIZE"])) / n
-    return per_launch, n, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, kernel trace only) around "
-                           f"two child runs of this command with one serial seal each; FETCH x2 per the gfx950 correction; mean over {n} launches "
-                           f"({time.perf_counter() - t0:.0f} s)")
-
-
-def self_launch(args, argv) -> int:
-    """`python bench.py --gpus N` without a launcher: spawn the N ranks ourselves (one process per GPU, gloo control
-    plane over 127.0.0.1), pass rank 0's stdout (the ONE JSON line) through, fail if any rank fails."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), ZKH_BENCH_CHILD="1")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    return rc
-
-
-def main() -> None:
-    ap = argparse.ArgumentParser()
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60, help="timed seals per GPU (60 x ~23.5 ms: 1.4 s of GPU time; run-to-run spread +-0.2 %%)")
     ap.add_argument("--warmup", type=int, default=2, help="untimed seals per lane before the clock starts (also ramps the clocks)")
     ap.add_argument("--po2", type=int, default=PO2)
-    ap.add_argument("--config", choices=("segment", "block", "succinct"), default="segment")
+    ap.add_argument("--config", choices=("segment", "block", "succinct", "dev"),
+                    default="dev" if os.environ.get("RISC0_DEV_MODE", "").lower() in ("1", "true", "yes") else "segment")
     ap.add_argument("--circuit", choices=("syn_a", "syn_heavy"), default="syn_a")
-    ap.add_argument("--segments", type=int, default=None, help="block / succinct: number of segments S (default 256 / 1024)")
-    ap.add_argument("--join-po2", type=int, default=18)
-    ap.add_argument("--ingress", choices=("device", "host"), default="device")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("ZKH_INFLIGHT", "3")),
                     help="segments sealed concurrently per GPU (one host thread + HIP stream each); 1 = strictly serial")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events (no roofline object)")
-    ap.add_argument("--no-verify", action="store_true", help="block / succinct: skip the host verification after the clock stops")
-    ap.add_argument("--no-heavy", action="store_true", help="segment config with SYN-A: skip the extra SYN-HEAVY measurement")
-    ap.add_argument("--heavy-steps", type=int, default=9)
-    ap.add_argument("--no-resident", action="store_true", help="segment config: skip the extra measurement with the code group kept resident")
-    ap.add_argument("--no-block", action="store_true", help="segment config: skip the short block leg (S distinct segments, witgen in the clock, all verified)")
-    ap.add_argument("--block-segments", type=int, default=None,
-                    help="segment config: segments of the block leg (the last one a po2-18 tail); default 64 on one GPU, 256 on N > 1 "
-                         "(the strong-scaling figure next to the weak-scaling `value`: BASELINE's metric is a block's wall-clock)")
-    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from the committed PMC file instead of two rocprofv3 --pmc child runs")
-    ap.add_argument("--join-circuit", choices=("recursion", "p2_join"), default="recursion",
-                    help="succinct config: joins that verify both child seals in-circuit (lift + join programs of the RECURSION circuit), "
-                         "or round 3's P2-JOIN joins (claims hashed in-circuit, child seals checked by the host verifier)")
-    ap.add_argument("--fold-inflight", type=int, default=int(os.environ.get("ZKH_FOLD_INFLIGHT", "6")),
-                    help="lifts / joins in flight per GPU: a lift's witness schedule is a chain of ~300 small launches (latency), so the fold "
-                         "packs the GPU with more lanes than the seals need (measured: 3 -> 6 lanes, 5.1 -> 4.4 ms per join)")
-    ap.add_argument("--executor", choices=("native", "python"), default="native",
-                    help="succinct config with --join-circuit recursion: the native session executor (zkh_session_prove: one pipeline) or round 3's "
-                         "Python-orchestrated two-phase fold")
-    ap.add_argument("--fold", choices=("streamed", "phased"), default="streamed",
-                    help="native executor: prove a lift2 / join the moment its children exist, concurrently with the sealing lanes (one pipeline), "
-                         "or seal everything first and fold afterwards (two phases)")
-    ap.add_argument("--witness", choices=("device", "preflight"), default="device",
-                    help="succinct config (native executor): where a segment's witness comes from - the closed-form generator on the device, or upstream's "
-                         "shape: a sequential host preflight per segment (producer threads), its compact records uploaded and row-filled on the GPU")
-    ap.add_argument("--chained", action="store_true", help="block config: SYN-C segments whose pre-state is their predecessor's post-state (claim continuity), through the native session executor")
-    ap.add_argument("--recompute-code", action="store_true", help="block / succinct: re-commit the code group for every segment (upstream's SegmentProver) instead of keeping it resident")
-    ap.add_argument("--no-join3", action="store_true", help="recursion: leave the join3 program out (three nodes above the bottom level then cost two joins instead of one proof; same tree, same root claim)")
-    ap.add_argument("--no-fused-lift", action="store_true", help="recursion: lift every segment on its own and join (three proofs per pair at the bottom level) instead of lift2")
-    ap.add_argument("--no-preflight-leg", action="store_true", help="segment config: skip the block leg with the host-preflight witness pipeline")
-    ap.add_argument("--preflight-producers", type=int, default=2, help="host preflight threads per sealing lane")
-    ap.add_argument("--no-recursive", action="store_true", help="segment config: skip the lift / join fold of the block leg's receipts")
-    ap.add_argument("--no-succinct", action="store_true", help="segment config: skip the join tree over the block leg's receipts")
-    ap.add_argument("--no-certify", action="store_true", help="segment config: do not verify the timed seals / compare with the golden digest after the clock")
-    args = ap.parse_args()
+    g = ap.add_argument_group("segment config: what else the default run measures")
+    g.add_argument("--no-cpu-baseline", action="store_true")
+    g.add_argument("--cpu-full-host", action="store_true",
+                   help="cpu_baseline: also fill EVERY core (floor(cores / threads) seals at once) and time the po2-20 unit itself: +~45 s")
+    g.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events (no roofline object)")
+    g.add_argument("--no-live-traffic", action="store_true",
+                   help="roofline.traffic from the committed PMC file, no rocprofv3 --pmc child runs (no live VALU figures)")
+    g.add_argument("--no-certify", action="store_true", help="do not verify the timed seals / compare with the golden digest after the clock")
+    g.add_argument("--no-heavy", action="store_true", help="skip the SYN-HEAVY measurement")
+    g.add_argument("--heavy-steps", type=int, default=9)
+    g.add_argument("--no-resident", action="store_true", help="skip the measurement with the code group kept resident")
+    g.add_argument("--no-block", action="store_true", help="skip the short block leg (S distinct segments, witgen in the clock, all verified)")
+    g.add_argument("--block-segments", type=int, default=None,
+                   help="segments of the block leg (the last one a po2-18 tail); default 64 on one GPU, 256 on N > 1 "
+                        "(the strong-scaling figure next to the weak-scaling `value`: BASELINE's metric is a block's wall-clock)")
+    g.add_argument("--no-preflight-leg", action="store_true", help="skip the block leg with the host-preflight witness pipeline")
+    g.add_argument("--preflight-producers", type=int, default=2, help="host preflight threads per sealing lane")
+    g.add_argument("--no-recursive", action="store_true", help="skip the lift2 / join fold of the block leg's receipts")
+    g.add_argument("--with-p2-join", action="store_true", help="also fold the block leg's receipts through round 3's P2-JOIN tree")
+    g.add_argument("--ingress", choices=("device", "host"), default="device", help="host: additionally time the PCIe-inclusive path")
+    g = ap.add_argument_group("block / succinct configs")
+    g.add_argument("--segments", type=int, default=None, help="number of segments S (default 256 / 1024)")
+    g.add_argument("--no-verify", action="store_true", help="skip the host verification after the clock stops")
+    g.add_argument("--chained", action="store_true",
+                   help="block: SYN-C segments whose pre-state is their predecessor's post-state (claim continuity), native session executor")
+    g.add_argument("--recompute-code", action="store_true",
+                   help="re-commit the code group for every segment (upstream's SegmentProver) instead of keeping it resident")
+    g.add_argument("--join-circuit", choices=("recursion", "p2_join"), default="recursion",
+                   help="succinct: joins that verify both child seals in-circuit (RECURSION programs), or round 3's P2-JOIN joins")
+    g.add_argument("--join-po2", type=int, default=18)
+    g.add_argument("--fold-inflight", type=int, default=int(os.environ.get("ZKH_FOLD_INFLIGHT", "6")),
+                   help="lifts / joins in flight per GPU (a lift's witness schedule is a latency chain: more lanes pack the GPU)")
+    g.add_argument("--executor", choices=("native", "python"), default="native",
+                   help="succinct + recursion: the native session executor (zkh_session_prove: one pipeline) or round 3's Python-orchestrated fold")
+    g.add_argument("--fold", choices=("streamed", "phased"), default="streamed",
+                   help="native executor: prove a lift2 / join the moment its children exist, or seal everything first and fold afterwards")
+    g.add_argument("--witness", choices=("device", "preflight"), default="device",
+                   help="succinct (native): the closed-form generator on the device, or a sequential host preflight per segment + row fill on the GPU")
+    g.add_argument("--no-join3", action="store_true", help="recursion: leave the join3 program out (same tree, same root claim, more proofs)")
+    g.add_argument("--no-fused-lift", action="store_true", help="recursion: lift every segment on its own and join instead of lift2")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)       # benchlib/roofline.py's rocprofv3 child runs
+    return ap.parse_args(argv)
 
+
+def main() -> int:
+    args = parse_args()
+    t_start = time.perf_counter()
+    dev = args.config == "dev"
     # a source-only snapshot (the GPU box) has no built library: build it before anything else — once, under a file lock, so the
     # ranks of a launcher-started run serialise on it and all but the first find it done (a current tree costs milliseconds)
-    from zeth_amd import build as _build
-    t_build = time.perf_counter()
-    _build.ensure_built(oracle=not args.no_cpu_baseline)
-    build_s = time.perf_counter() - t_build
+    build_s = 0.0
+    if not dev:
+        from zeth_amd import build as _build
+        t_build = time.perf_counter()
+        _build.ensure_built(oracle=not args.no_cpu_baseline and not args.pmc_child)
+        build_s = time.perf_counter() - t_build
+    if args.pmc_child:
+        from benchlib.segment import run_pmc_child
+        run = Run(args, ControlPlane(0, 1), 0, 0, 1)
+        run.load_circuit()
+        run_pmc_child(run)
+        return 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(self_launch(args, sys.argv[1:]))
+        return launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])
 
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    distributed = world > 1
-    backend = "gloo"
-    if distributed:
+    rccl = None
+    if world > 1:
+        import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # Control plane only — the path has no exchange step (segments are independent), so there is no collective on
-        # the data path and none is invented: barrier and MAX-of-elapsed go over gloo on CPU tensors, which keeps the
-        # timing protocol independent of torch's own HIP state.  ZKH_DIST_BACKEND=cpu:gloo,cuda:nccl additionally
-        # brings RCCL up next to it and runs one all_reduce over xGMI before the timed region (health probe only).
+        # Rendezvous through torch.distributed (gloo on CPU tensors; a rank that never shows up fails the group within the timeout
+        # instead of gloo's 30 minutes).  The path has no exchange step, so no collective is invented for it; the control plane
+        # proper is the store (benchlib/control.py).  ZKH_DIST_BACKEND=cpu:gloo,cuda:nccl additionally brings RCCL up and runs
+        # one all_reduce over xGMI before the timed region (health probe only).
         backend = os.environ.get("ZKH_DIST_BACKEND", "gloo")
-        if "nccl" in backend:
-            try:
-                torch.cuda.set_device(local_rank)
-            except (RuntimeError, AssertionError):
-                backend = "gloo"
-        ctrl_dev = "cpu" if "gloo" in backend else f"cuda:{local_rank}"
-
-        def barrier():
-            dist.all_reduce(torch.zeros(1, device=ctrl_dev))
-
-        # gloo announces its connections on stdout; keep stdout for the ONE JSON line
         sys.stdout.flush()
-        saved_stdout = os.dup(1)
+        saved_stdout = os.dup(1)                  # gloo announces its connections on stdout; keep stdout for the ONE JSON line
         os.dup2(2, 1)
         try:
-            dist.init_process_group(backend)
-            barrier()
+            if "nccl" in backend:
+                try:
+                    torch.cuda.set_device(local_rank)
+                except (RuntimeError, AssertionError):
+                    backend = "gloo"
+            dist.init_process_group(backend, timeout=timedelta(seconds=TIMEOUT_S))
+            if "nccl" in backend:
+                try:
+                    probe = torch.ones(1, device=f"cuda:{local_rank}")
+                    dist.all_reduce(probe)
+                    torch.cuda.synchronize()
+                    rccl = "ok" if int(probe.item()) == world else "wrong sum"
+                except Exception as e:               # the seals never needed RCCL
+                    rccl = f"unavailable ({type(e).__name__})"
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
-    else:
-        ctrl_dev = "cpu"
-
-        def barrier():
-            pass
-
-    from zeth_amd.circuits import syn_air
-    from zeth_amd.circuits.desc import Circuit
-    from zeth_amd.hal import HipHal
-    from zeth_amd.host import JoinExecutor, fold_claims, node_claim, partition_round_robin, receipt_claim
-    from zeth_amd.prover import Segment, SegmentProver
-
-    # one GPU per rank; ZKH_SHARE_GPUS=1 lets ranks wrap around the visible devices (dry runs on a 1-GPU box)
-    device = local_rank
+    ctl = ControlPlane.connect(rank, world)
+    run = Run(args, ctl, rank, local_rank, world)
+    run.rccl = rccl
+    run.failed_ranks, run.failed_in = {}, None
+    line, after = None, []
     try:
-        visible = int(torch.cuda.device_count())
-    except (RuntimeError, AssertionError):
-        visible = 0
-    if os.environ.get("ZKH_SHARE_GPUS"):
-        device = local_rank % max(1, visible)
-    elif 0 < visible <= local_rank:
-        # a launcher that narrows HIP_VISIBLE_DEVICES per rank (every rank sees ITS GPU as device 0): follow it instead of failing
-        device = local_rank % visible
-    # host placement: this rank's threads (and the pinned blocks they allocate) next to its GPU's root port; the ranks whose
-    # GPUs share a NUMA node split that node's cores (csrc/topology.hip; ZKH_AFFINITY=off leaves the process alone)
-    try:
-        cpus_before = sorted(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        cpus_before = None
-    placement = {"numa_node": -1, "cpus": 0, "cpus_before": len(cpus_before or [])}
-    try:
-        from zeth_amd import hal as _zhal
-        slot, share = (0, 1) if os.environ.get("ZKH_SHARE_GPUS") or visible < world else _zhal.placement_slot(device, list(range(world)))
-        placement = _zhal.bind_to_device(device, slot, share)
-        placement.update(slot=slot, share=share, pci_bus_id=_zhal.device_numa_node(device)[1])
-    except Exception as e:                               # placement is an optimisation, never a dependency
-        placement["error"] = repr(e)
-    if args.circuit == "syn_heavy":
-        from zeth_amd.circuits import syn_heavy
-        desc = syn_heavy.syn_heavy()
-    else:
-        desc = syn_air.syn_a()
-    from zeth_amd.circuits import p2_join
-    join_desc = p2_join.p2_join_circuit()     # joins hash their children's claims in-circuit (Poseidon2 unrolled over trace rows)
-    circ = Circuit.parse(desc)
-    wa, wc, wd = circ.group_sizes
-    n = 1 << args.po2
-    inflight = max(1, min(args.inflight, args.steps))
-    workload = (f"{args.circuit.upper().replace('_', '-')} circuit (W_code {wc}, W_data {wd}, W_accum {wa}, check 16; {len(circ.taps)} taps, "
-                f"{len(circ.steps)} constraint steps), poseidon2")
-
-    def device_sync(workers):
-        """Both sides of the timed region: every library stream, then torch's device-wide synchronize (torch is only
-        plumbing here; if its own HIP initialisation is unavailable the library's syncs already cover all our work)."""
-        for wk in workers:
-            wk.hal.sync()
-        try:
-            if torch.cuda.is_available():
-                torch.cuda.synchronize(device)       # this rank's GPU only (never touch another rank's device)
-        except (RuntimeError, AssertionError):
-            pass
-
-    class Lane:
-        """One seal in flight: a context (HIP stream) + circuit + prover, driven by one host thread."""
-
-        def __init__(self, with_join=False, resident=False):
-            self.hal = HipHal(device)                # raises if the HIP library / GPU is missing: no fallback
-            self.prover = SegmentProver(self.hal, desc, resident_code_group=resident)
-            self.join_prover = SegmentProver(self.hal, join_desc) if with_join else None
-            self.seal_s, self.witgen_s, self.err = [], [], None
-            self.last, self.sealed = None, []
-
-    def run_lanes(lanes, fn):
-        threads = [threading.Thread(target=fn, args=(ln,)) for ln in lanes]
-        for th in threads:
-            th.start()
-        for th in threads:
-            th.join()
-        for ln in lanes:
-            if ln.err is not None:
-                raise ln.err
-
-    def merged_prof(lanes):
-        merged = {}
-        for ln in lanes:
-            for p in ln.hal.prof_get():
-                m = merged.setdefault(p["name"], {"name": p["name"], "calls": 0, "total_ms": 0.0, "alg_bytes": 0.0})
-                m["calls"] += p["calls"]; m["total_ms"] += p["total_ms"]; m["alg_bytes"] += p["alg_bytes"]
-        return list(merged.values())
-
-    def block_segments(S):
-        """S distinct segments of one block: seeds base + i, the last one the short po2-18 tail."""
-        return [Segment(index=i, po2=args.po2 if i + 1 < S or S == 1 else min(args.po2, TAIL_PO2), seed=BASE_SEED + i,
-                        noise_seed=BENCH_NOISE) for i in range(S)]
-
-    def seal_block(lanes, segs, mine, prover_of=lambda ln: ln.prover):
-        """Seal this rank's share `mine` of the block `segs` on the lanes (shared work index), witness generation inside the
-        clock -> ({index: receipt}, wall seconds incl. both device syncs, witgen seconds[], seal-call seconds[])."""
-        receipts, wit_s, seal_s = {}, [], []
-        lock, nxt = threading.Lock(), [0]
-
-        def take():
-            with lock:
-                k = nxt[0]
-                if k >= len(mine):
-                    return None
-                nxt[0] = k + 1
-                return mine[k]
-
-        def seal_leaves(ln):
-            try:
-                while True:
-                    i = take()
-                    if i is None:
-                        break
-                    t_w = time.perf_counter()
-                    pv = prover_of(ln)
-                    code, data, out = pv.witgen(segs[i])             # inside the clock, reported separately
-                    ln.hal.sync()                                    # so that t_s - t_w is the witness generator alone
-                    t_s = time.perf_counter()
-                    rec = pv.seal(segs[i], code, data, out)
-                    t_e = time.perf_counter()
-                    with lock:
-                        receipts[i] = rec
-                        wit_s.append(t_s - t_w); seal_s.append(t_e - t_s)
-                ln.hal.sync()
-            except Exception as e:
-                ln.err = e
-
-        device_sync(lanes)
-        barrier()
-        t0 = time.perf_counter()
-        run_lanes(lanes, seal_leaves)
-        device_sync(lanes)
-        return receipts, t0, wit_s, seal_s
-
-    def top_proofs(tops, kinds):
-        """proofs rank 0 spends on folding the ranks' local roots (zeth_amd/recursion.py fold_plan: pairs, then three at a time)"""
-        from zeth_amd.recursion import fold_plan
-        if not tops or len(tops) < 2:
-            return 0
-        po2 = tops[0].po2
-        return sum((1 if len(g) == 2 or ("join3", po2, po2, po2) in kinds else 2) for groups in fold_plan(len(tops)) for g in groups if len(g) > 1)
-
-    def fold_lanes(lanes):
-        """the lanes of the fold: the sealing lanes plus extra contexts up to --fold-inflight"""
-        return list(lanes) + [Lane() for _ in range(max(0, args.fold_inflight - len(lanes)))]
-
-    def recursive_prepare(lanes, leaf_roots, warm):
-        """build the lift / join programs (host) and load them on every lane (code groups committed, resident), one warm
-        lift + join per lane: before any clock, as upstream ships lift / join as precompiled .zkr programs"""
-        from zeth_amd import recursion as zrec
-        t_b = time.perf_counter()
-        programs = zrec.build_programs(desc, leaf_roots, ternary=not args.no_join3)
-        build_s = time.perf_counter() - t_b
-        t_b = time.perf_counter()
-        for ln in lanes:
-            ln.rec = zrec.Recursion(ln.hal, programs)
-            w = ln.rec.lift(warm, BENCH_NOISE)
-            ln.rec.join(w, w, BENCH_NOISE)
-            ln.hal.sync()
-        return {"program_build_s": build_s, "program_load_s_all_lanes": time.perf_counter() - t_b}
-
-    def recursive_fold(lanes, leaves):
-        """lift every segment receipt of `leaves` (in order), then join level by level down to ONE receipt - each join runs the
-        STARK verifier on both children INSIDE its circuit (zeth_amd/recursion.py).  Lifts and the joins of a level are
-        independent: a shared work index spreads them over the lanes.  -> (root receipt, stats)"""
-        lock = threading.Lock()
-
-        def spread(jobs):
-            """jobs: callables taking a lane -> results in order"""
-            out, pos = [None] * len(jobs), [0]
-
-            def work(ln):
-                try:
-                    while True:
-                        with lock:
-                            k = pos[0]
-                            if k >= len(jobs):
-                                return
-                            pos[0] = k + 1
-                        out[k] = jobs[k](ln)
-                except Exception as e:
-                    ln.err = e
-            run_lanes(lanes, work)
-            return out
-        device_sync(lanes)
-        t0 = time.perf_counter()
-        # bottom level: lift + lift + join fused into one proof per pair of segments (lift2) where the program set has it
-        rx0 = lanes[0].rec
-        jobs, n_fused = [], 0
-        for k in range(len(leaves) // 2):
-            a, b = leaves[2 * k], leaves[2 * k + 1]
-            if not args.no_fused_lift and rx0.has_lift2(a, b):
-                jobs.append(lambda ln, a=a, b=b: ln.rec.lift2(a, b, BENCH_NOISE))
-                n_fused += 1
-            else:
-                jobs.append(lambda ln, a=a, b=b: ln.rec.join(ln.rec.lift(a, BENCH_NOISE), ln.rec.lift(b, BENCH_NOISE), BENCH_NOISE))
-        if len(leaves) % 2:
-            jobs.append(lambda ln, r=leaves[-1]: ln.rec.lift(r, BENCH_NOISE))
-        level = spread(jobs)
-        device_sync(lanes)
-        lift_s = time.perf_counter() - t0
-        n_joins = 0
-        from zeth_amd.recursion import fold_plan
-        for groups in fold_plan(len(leaves))[1:]:           # above the bottom level: three nodes per proof (join3), zeth_amd/recursion.py fold_plan
-            n_joins += sum((1 if len(g) == 2 or ("join3",) + tuple(level[k].po2 for k in g) in rx0.kinds else 2) for g in groups if len(g) > 1)
-            level = spread([(lambda ln, nodes=[level[k] for k in g]: ln.rec.join_group(nodes, BENCH_NOISE)) for g in groups])
-        device_sync(lanes)
-        total_s = time.perf_counter() - t0
-        rx = lanes[0].rec
-        n_unfused = len(leaves) // 2 - n_fused
-        stats = {"segments_lifted": len(leaves), "fused_lift2": n_fused, "lifts": 2 * n_unfused + len(leaves) % 2, "joins": n_joins + n_unfused,
-                 "proofs": n_fused + 3 * n_unfused + len(leaves) % 2 + n_joins,
-                 "bottom_level_s": lift_s, "join_phase_s": total_s - lift_s, "fold_s": total_s,
-                 "bottom_ms_per_segment": 1e3 * lift_s / max(1, len(leaves)), "join_ms_each": 1e3 * (total_s - lift_s) / max(1, n_joins),
-                 "programs": [{"kind": "-".join(str(x) for x in k), "po2": p.po2, "permutations": p.n_p2, "gates": p.n_gates,
-                               "levels": p.n_levels, "witness_words": p.n_inputs} for k, p in zip(rx.kinds, rx.programs)],
-                 "root_receipt_words": int(level[0].seal.size),
-                 "note": "every lift runs the STARK verifier on its segment seal and every join on both child seals INSIDE the RECURSION "
-                         "circuit (Fiat-Shamir sponge, all Merkle openings, constraint check at z, DEEP, FRI of 50 queries); the root "
-                         "receipt is checked below with ONE seal verification + the claim tree of the leaves"}
-        return level[0], stats
-
-    line = None
-    after_group = []                  # rank 0: work for the line that runs once the process group is destroyed
-    # =====================================================================================================
-    if args.config == "segment":
-        # segment list of the "block": (warmup + steps) * world segments, partitioned round-robin over ranks; inside a
-        # rank, `inflight` host threads (one HipHal context = one HIP stream each) seal different segments concurrently so
-        # that the latency-bound phases of one seal (Merkle tree tops, scans, Fiat-Shamir round trips) overlap another's
-        # throughput-bound phases.  Segments stay independent: no data is shared between the threads.
-        total = (args.warmup + args.steps) * world
-        mine = partition_round_robin(total, world, rank)
-        lanes = [Lane() for _ in range(inflight)]
-        for w, ln in enumerate(lanes):
-            ring = max(1, min(-(-args.steps // inflight) + args.warmup, 2))
-            ln.wit = []
-            for j in range(ring):                    # witnesses resident in HBM before the clock starts
-                idx = mine[(w + j * inflight) % len(mine)]
-                seg = Segment(index=idx, po2=args.po2, seed=BASE_SEED + idx, noise_seed=BENCH_NOISE)
-                t_w = time.perf_counter()
-                ln.wit.append((seg, *ln.prover.witgen(seg)))
-                ln.hal.sync()
-                ln.witgen_s.append(time.perf_counter() - t_w)
-
-        def seal_one(ln, i):
-            seg, code, data, out = ln.wit[i % len(ln.wit)]
-            t_s = time.perf_counter()
-            ln.last = ln.prover.seal(seg, code, data, out)   # returns with the seal words on the host
-            ln.seal_s.append(time.perf_counter() - t_s)
-            ln.sealed.append((seg, ln.last))                 # kept: every timed seal is verified after the clock
-
-        work_lock, work_next = threading.Lock(), [0]
-
-        def next_step(limit):
-            with work_lock:
-                k = work_next[0]
-                if k >= limit:
-                    return None
-                work_next[0] = k + 1
-                return k
-
-        def timed(ln):
-            # the K timed steps are handed out through a shared work index (SURVEY.md §8e: work stealing), so K need
-            # not be a multiple of the number of seals in flight
-            try:
-                done = 0
-                while next_step(args.steps) is not None:
-                    seal_one(ln, args.warmup + done)
-                    done += 1
-                ln.hal.sync()
-            except Exception as e:                   # surfaced after join
-                ln.err = e
-
-        for ln in lanes:
-            for i in range(args.warmup):
-                seal_one(ln, i)
-            ln.hal.sync()
-        if not args.no_prof:
-            for ln in lanes:
-                ln.hal.prof_reset()
-                ln.hal.prof_enable(True)
-        rccl = None
-        if distributed and "nccl" in backend:
-            try:
-                probe = torch.ones(1, device=f"cuda:{device}")
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-                rccl = "ok" if int(probe.item()) == world else "wrong sum"
-            except Exception as e:                       # control plane stays on gloo; the seals never needed RCCL
-                rccl = f"unavailable ({type(e).__name__})"
-        device_sync(lanes)
-        barrier()
-        for ln in lanes:
-            ln.seal_s.clear()
-            ln.sealed.clear()
-        t0 = time.perf_counter()
-        run_lanes(lanes, timed)
-        device_sync(lanes)
-        barrier()
-        dt = time.perf_counter() - t0
-        if distributed:
-            t = torch.tensor([dt], dtype=torch.float64, device=ctrl_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        prof = []
-        if not args.no_prof:
-            prof = merged_prof(lanes)
-            for ln in lanes:
-                ln.hal.prof_enable(False)
-        # ---- after the clock: the timed work certifies itself.  EVERY seal produced inside the timed region goes through
-        # the host verifier (`receipt.verify`, /root/reference/crates/host/src/bin/cli.rs:103) against the control root
-        # of its size, and the seal of segment index 0 — whose seeds are exactly the CPU oracle's golden case
-        # (tests/golden/large_digests.json, made by tests/golden/make_golden_large.py) — is compared with the oracle's
-        # seal by SHA-256.  No oracle code runs here: the digest is a committed fixture.
-        certify = None
-        if not args.no_certify:
-            import hashlib
-            t_v = time.perf_counter()
-            sealed = [x for ln in lanes for x in ln.sealed]
-            croot = lanes[0].prover.control_root(args.po2)
-            for seg, rec in sealed:
-                rec.verify(desc, croot)                      # raises HalError if a timed seal is rejected
-            golden, matches = None, None
-            try:
-                cases = json.load(open(os.path.join(ROOT, "tests", "golden", "large_digests.json")))["cases"]
-                golden = next((c for c in cases if c["shape"] == args.circuit and c["po2"] == args.po2 and c["seed"] == BASE_SEED
-                               and c["noise_seed"] == BENCH_NOISE and c["zk_cycles"] == 1994), None)
-            except (OSError, ValueError, KeyError):
-                pass
-            zero = [rec for seg, rec in sealed if seg.index == 0]
-            if golden is not None and zero:
-                matches = all(hashlib.sha256(rec.seal_bytes()).hexdigest() == golden["seal_sha256"] for rec in zero)
-                if not matches:
-                    raise SystemExit("bench: the timed seal of segment 0 differs from the CPU oracle's golden seal (tests/golden/large_digests.json)")
-            cnt = torch.tensor([float(len(sealed))], dtype=torch.float64, device=ctrl_dev)
-            if distributed:
-                dist.all_reduce(cnt)
-            certify = {"timed_seals_verified": int(cnt.item()), "seal_matches_golden": matches,
-                       "golden_is": "the SHA-256 of THIS repository's CPU oracle seal for the same seeds (tests/golden/large_digests.json): a regression pin "
-                                    "that ties the timed GPU seal to the oracle, not a vector held by the reference (it holds none for this path)",
-                       "golden_seals_compared": len(zero) if golden is not None else 0,
-                       "verify_ms_per_seal_host": 1e3 * (time.perf_counter() - t_v) / max(1, len(sealed))}
-        # With several seals in flight the HIP-event brackets of one stream include time its kernels spent sharing the GPU
-        # with the other streams.  One more seal, alone on the GPU and outside the timed region, gives the unshared
-        # per-kernel durations next to them (and names the kernel that really dominates the work).
-        seal_times = [t for ln in lanes for t in ln.seal_s]
-        unloaded_seal_s = None
-        ref = []
-        if prof:
-            barrier()                                    # every rank is past its certification: nothing else runs while rank 0 takes its reference seal
-            if rank == 0:
-                w0 = lanes[0]
-                w0.hal.prof_reset(); w0.hal.prof_enable(True)
-                seal_one(w0, args.warmup)
-                w0.hal.sync()
-                ref = w0.hal.prof_get()
-                w0.hal.prof_enable(False)
-                unloaded_seal_s = w0.seal_s[-1]          # one seal alone on the GPU: the single-segment latency
-            barrier()
-        # PCIe-inclusive variant: the same K steps, but every step uploads its code + data traces from pinned host memory
-        pcie = None
-        if args.ingress == "host":
-            for ln in lanes:
-                seg, code, data, out = ln.wit[0]
-                ln.host = (ln.hal.host_alloc(code.size()), ln.hal.host_alloc(data.size()))
-                ln.host[0][:] = code.to_vec()
-                ln.host[1][:] = data.to_vec()
-
-            def host_step(ln):
-                seg, _, _, out = ln.wit[0]
-                ln.last = ln.prover.seal_host_witness(seg, ln.host[0], ln.host[1], out)
-
-            def timed_host(ln):
-                try:
-                    while next_step(args.steps) is not None:
-                        host_step(ln)
-                    ln.hal.sync()
-                except Exception as e:
-                    ln.err = e
-
-            for ln in lanes:
-                host_step(ln)
-            device_sync(lanes)
-            barrier()
-            work_next[0] = 0
-            t1 = time.perf_counter()
-            run_lanes(lanes, timed_host)
-            device_sync(lanes)
-            barrier()
-            dth = time.perf_counter() - t1
-            if distributed:
-                t = torch.tensor([dth], dtype=torch.float64, device=ctrl_dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dth = float(t.item())
-            up_bytes = 4.0 * (lanes[0].host[0].size + lanes[0].host[1].size)
-            pcie = {"segments_per_s": world * args.steps / dth, "ms_per_step": 1e3 * dth / args.steps,
-                    "upload_bytes_per_segment": up_bytes, "upload_GBps_sustained": up_bytes * args.steps / dth / 1e9,
-                    "note": "code + data traces uploaded from pinned host memory (zkh_write_async) inside every step, "
-                            "sealed through zkh_prove_begin / zkh_prove_finish; uploads of one lane overlap the kernels of the others"}
-            for ln in lanes:
-                for h in ln.host:
-                    ln.hal.host_free(h)
-        # The same step under the realistically heavy constraint system (SYN-HEAVY: same trace shape and witness, ~54 k
-        # constraint steps instead of ~1 k): SYN-A's eval_check is 4 % of a seal, upstream's is the largest kernel, so the
-        # headline number above flatters the real workload and this one is reported next to it (same lanes, same resident
-        # witnesses, a few steps).
-        def timed_extra(make_prover, steps, with_prof):
-            """A few more timed steps of the same resident witnesses under another prover per lane -> (seconds, per-kernel times)."""
-            for ln in lanes:
-                ln.extra = make_prover(ln)
-
-            def one(ln):
-                seg, code, data, out = ln.wit[0]
-                ln.last_extra = ln.extra.seal(seg, code, data, out)
-
-            def timed(ln):
-                try:
-                    while next_step(steps) is not None:
-                        one(ln)
-                    ln.hal.sync()
-                except Exception as e:
-                    ln.err = e
-
-            for ln in lanes:
-                one(ln)
-            kprof = {}
-            if with_prof and rank == 0 and not args.no_prof:
-                lanes[0].hal.prof_reset(); lanes[0].hal.prof_enable(True)
-                one(lanes[0]); lanes[0].hal.sync()
-                kprof = {p["name"]: p for p in lanes[0].hal.prof_get()}
-                lanes[0].hal.prof_enable(False)
-            device_sync(lanes)
-            barrier()
-            work_next[0] = 0
-            t2 = time.perf_counter()
-            run_lanes(lanes, timed)
-            device_sync(lanes)
-            barrier()
-            dte = time.perf_counter() - t2
-            if distributed:
-                t = torch.tensor([dte], dtype=torch.float64, device=ctrl_dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dte = float(t.item())
-            return dte, kprof
-
-        heavy = None
-        if args.circuit == "syn_a" and not args.no_heavy and args.po2 >= 13:
-            from zeth_amd.circuits import syn_heavy
-            hdesc = syn_heavy.syn_heavy()
-            hsteps = max(inflight, min(args.heavy_steps, args.steps))
-            dth, hprof = timed_extra(lambda ln: SegmentProver(ln.hal, hdesc), hsteps, True)
-            hc = Circuit.parse(hdesc)
-            heavy = {"segments_per_s": world * hsteps / dth, "ms_per_step": 1e3 * dth / hsteps, "steps": hsteps,
-                     "workload": f"same step with the SYN-HEAVY constraint system ({len(hc.steps)} steps, {len(hc.taps)} taps, "
-                                 f"{len(hc.combos)} tap combos, degree 5, ConstExt, nested AndCond; {lanes[0].extra.circuit.compiled_parts()} generated kernels)",
-                     "kernels_ms_per_seal_unshared": {k: round(v["total_ms"], 3) for k, v in sorted(hprof.items(), key=lambda kv: -kv[1]["total_ms"])[:6]}}
-        # The same step with the committed code (control) group of this segment size kept resident in HBM instead of being
-        # re-committed for every segment (zkh_prover_cache_code; the group is a function of (circuit, po2) alone, 0.6 GB at
-        # po2 20).  Upstream's SegmentProver recomputes it and so does `value`; this is what a deployment that keeps it gets.
-        resident = None
-        if not args.no_resident and args.po2 >= 13:
-            rsteps = max(inflight, min(args.heavy_steps, args.steps))
-            dtr, _ = timed_extra(lambda ln: SegmentProver(ln.hal, desc, resident_code_group=True), rsteps, False)
-            import numpy as np
-            same = all(np.array_equal(ln.last_extra.seal, ln.prover.seal(*ln.wit[0]).seal) for ln in lanes)   # same witness, recomputing prover
-            resident = {"segments_per_s": world * rsteps / dtr, "ms_per_step": 1e3 * dtr / rsteps, "steps": rsteps,
-                        "seals_identical_to_recomputing_prover": bool(same),
-                        "note": "NOT the headline: the code group's iNTT / expand-NTT / leaf hashing / Merkle fold are skipped because "
-                                "its committed form is resident (opt-in: SegmentProver(resident_code_group=True))"}
-        # A short block in the same run (BASELINE's metric is "segments/sec + seal wall-clock" of a block: configs 3/4):
-        # S DISTINCT segments, the last one a po2-18 tail, round-robin over the ranks, witness generation INSIDE the clock,
-        # every seal verified on the host after the clock.  `--config block` is the full-size version (S = 256).
-        block = None
-        if args.block_segments is None:
-            args.block_segments = 64 if world == 1 else 256
-        if not args.no_block and args.po2 >= 13 and args.block_segments > 0:
-            S = args.block_segments
-            bsegs = block_segments(S)
-            bmine = partition_round_robin(S, world, rank)
-            # The block leg keeps the committed code (control) group of each segment size RESIDENT per lane (DESIGN.md §3: it is a
-            # function of (circuit, po2) alone; seals are byte-identical) — what the session executor does by default.  Upstream's
-            # SegmentProver re-commits it per segment: that figure is reported next to it (`recompute_code_group`), and `value`
-            # above is measured that way too.
-            for ln in lanes:                                  # every size once, outside the clock (pool blocks, code objects, the resident groups)
-                ln.block_prover = ln.prover if args.recompute_code else SegmentProver(ln.hal, desc, resident_code_group=True)
-                for p2 in sorted({sg.po2 for sg in bsegs}):
-                    ln.block_prover.prove_segment(Segment(index=0, po2=p2, seed=1, noise_seed=BENCH_NOISE))
-                    ln.prover.prove_segment(Segment(index=0, po2=p2, seed=1, noise_seed=BENCH_NOISE))
-                ln.hal.sync()
-            broots = {p: lanes[0].prover.control_root(p) for p in sorted({sg.po2 for sg in bsegs})}
-            recompute = None
-            if not args.recompute_code:
-                _, tr0, _, _ = seal_block(lanes, bsegs, bmine)
-                barrier()
-                trc = torch.tensor([time.perf_counter() - tr0], dtype=torch.float64, device=ctrl_dev)
-                if distributed:
-                    dist.all_reduce(trc, op=dist.ReduceOp.MAX)
-                recompute = {"wall_clock_s": float(trc.item()), "segments_per_s": S / float(trc.item()),
-                             "note": "the same block with the code group re-committed for every segment, as upstream's SegmentProver does"}
-            brec, tb0, bwit, bseal = seal_block(lanes, bsegs, bmine, prover_of=lambda ln: ln.block_prover)
-            barrier()
-            dtb = time.perf_counter() - tb0
-            t_v = time.perf_counter()
-            for i in bmine:
-                brec[i].verify(desc, broots[bsegs[i].po2])
-            verify_s = time.perf_counter() - t_v
-            tb = torch.tensor([dtb, float(len(bmine)), sum(bwit), float(len(bwit))], dtype=torch.float64, device=ctrl_dev)
-            if distributed:
-                mx = tb[:1].clone()
-                dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-                dist.all_reduce(tb)
-                tb[0] = mx[0]
-            block = {"segments": S, "wall_clock_s": float(tb[0].item()), "segments_per_s": S / float(tb[0].item()),
-                     "tail_po2": bsegs[-1].po2, "witgen_in_clock": True, "verified_after_clock": int(tb[1].item()),
-                     "code_group": "recomputed per segment" if args.recompute_code else "resident per lane and size (byte-identical seals)",
-                     "recompute_code_group": recompute,
-                     "witgen_ms_per_segment": 1e3 * float(tb[2].item()) / max(1.0, float(tb[3].item())),
-                     "verify_s_rank0": verify_s,
-                     "workload": f"{S} distinct 2^{args.po2}-cycle segments (last one 2^{bsegs[-1].po2}), round-robin over {world} GPU(s), "
-                                 f"{inflight} in flight per GPU; `--config block` runs S = 256"}
-            # The same block with upstream's witness SHAPE (SURVEY.md §8f row f1): a sequential host preflight per segment replays the
-            # cycles on host threads that run AHEAD of the seals (2 per sealing lane), 16 bytes per cycle cross PCIe from pinned
-            # memory, the GPU row-fill kernel expands them (csrc/preflight.hip), and the preload is a zkh_scatter — through the native
-            # session executor (zkh_session_set_witness_source(1)).  The host CPU seconds per segment are the Amdahl term of the
-            # pipeline: with T producer threads it sustains min(GPU rate, T / preflight seconds).
-            if not args.no_preflight_leg and args.circuit == "syn_a":
-                from zeth_amd.hal import HalError
-                from zeth_amd.host import Session
-                for ln in lanes:                       # the session brings its own lanes: hand the cached pool blocks of this rank's back first
-                    ln.hal.trim()
-                psess, perr = None, None
-                try:
-                    psess = Session(desc, devices=(device,), lanes_per_device=inflight)
-                    psess.set_witness_source(1, args.preflight_producers)
-                    psess.set_resident_code(not args.recompute_code)
-                    psess.prove([bsegs[0]] * inflight + [bsegs[-1]])          # warm-up: every size once per lane
-                except HalError as e:                  # (ranks sharing ONE GPU in a dry run can run out of HBM here)
-                    perr = str(e)
-                okf = torch.tensor([0.0 if perr else 1.0], dtype=torch.float64, device=ctrl_dev)
-                if distributed:
-                    dist.all_reduce(okf, op=dist.ReduceOp.MIN)
-                if okf.item() < 1.0:                   # every rank skips the leg together
-                    block["host_preflight_pipeline"] = {"error": perr or "another rank could not set the leg up"}
-                    if psess is not None:
-                        psess.close()
-                    psess = None
-            if not args.no_preflight_leg and args.circuit == "syn_a" and psess is not None:
-                device_sync(lanes)
-                barrier()
-                tp0 = time.perf_counter()
-                pcomp, _, pst = psess.prove([bsegs[i] for i in bmine])
-                barrier()
-                dtp = time.perf_counter() - tp0
-                for r in pcomp.segments:
-                    r.verify(desc, broots[r.po2])
-                tpv = torch.tensor([dtp, pst["preflight_cpu_s_sum"], pst["trace_bytes"], float(len(bmine)), pst["witgen_s_sum"]], dtype=torch.float64, device=ctrl_dev)
-                if distributed:
-                    mx = tpv[:1].clone()
-                    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-                    dist.all_reduce(tpv)
-                    tpv[0] = mx[0]
-                block["host_preflight_pipeline"] = {
-                    "segments": S, "wall_clock_s": float(tpv[0]), "segments_per_s": S / float(tpv[0]),
-                    "host_preflight_cpu_ms_per_segment": 1e3 * float(tpv[1]) / max(1.0, float(tpv[3])),
-                    "pcie_bytes_per_segment": float(tpv[2]) / max(1.0, float(tpv[3])),
-                    "full_trace_bytes_per_segment": 4.0 * (wc + wd) * n,
-                    "upload_and_row_fill_ms_per_segment": 1e3 * float(tpv[4]) / max(1.0, float(tpv[3])),
-                    "producer_threads_per_gpu": inflight * (args.preflight_producers or 2), "sealing_lanes_per_gpu": inflight,
-                    "verified_after_clock": int(tpv[3]),
-                    "note": "the preflight is a sequential per-cycle machine (SYN-VM: 8 registers, 64 instructions, 1 KiB words of RAM) on host "
-                            "threads; its 16-byte-per-cycle records are the ONLY witness input that crosses PCIe; the GPU expands them (one lane per "
-                            "cycle), scans the running sum and scatters the preloaded RAM image; a DIFFERENT witness than the closed-form "
-                            "generator's, same circuit, seals byte-identical to the CPU oracle's (tests/test_round4_gpu.py)"}
-                psess.close()
-                del psess
-            # ... and, on one GPU, the join tree over that block's receipts down to ONE root receipt (BASELINE config 5 in
-            # small: P2-JOIN joins at po2 18 hash their children's claims in-circuit).  Per level the joins are independent and
-            # spread over the lanes.  Afterwards the compact receipt (root + leaves, joins dropped) is verified the way a
-            # holder would: root seal, then the claim tree recomputed on the host from the leaf claims.
-            if world == 1 and not args.no_succinct and S > 1:
-                from zeth_amd.host import SuccinctReceipt, join_schedule, join_segment
-                for ln in lanes:
-                    ln.join_prover = SegmentProver(ln.hal, join_desc)
-                    ln.join_prover.prove_segment(Segment(index=0, po2=args.join_po2, seed=1, noise_seed=BENCH_NOISE, pub=tuple([1] * 16)))
-                    ln.hal.sync()
-                jroot = lanes[0].join_prover.control_root(args.join_po2)
-                nodes = [(brec[i], receipt_claim(brec[i], desc, broots[bsegs[i].po2])) for i in range(S)]
-                n_joins = 0
-                device_sync(lanes)
-                t_j = time.perf_counter()
-                for tasks in join_schedule(S, 1):
-                    jsegs = [join_segment(t, nodes[t.left][1], nodes[t.right][1], args.join_po2, BENCH_NOISE) for t in tasks]
-                    out_recs = [None] * len(jsegs)
-                    pos, plock = [0], threading.Lock()
-
-                    def jwork(ln):
-                        try:
-                            while True:
-                                with plock:
-                                    k = pos[0]
-                                    if k >= len(jsegs):
-                                        return
-                                    pos[0] = k + 1
-                                out_recs[k] = ln.join_prover.prove_segment(jsegs[k])
-                        except Exception as e:
-                            ln.err = e
-                    run_lanes(lanes, jwork)
-                    nxt = [(r, node_claim(r, join_desc, jroot, False)) for r in out_recs]
-                    if len(nodes) % 2:
-                        nxt.append(nodes[-1])
-                    nodes, n_joins = nxt, n_joins + len(jsegs)
-                device_sync(lanes)
-                join_s = time.perf_counter() - t_j
-                SuccinctReceipt(root=nodes[0][0], joins=[], leaves=[brec[i] for i in range(S)]).verify(desc, join_desc, broots, jroot)
-                block["succinct"] = {"leaves": S, "joins": n_joins, "join_po2": args.join_po2, "join_tree_s": join_s,
-                                     "block_plus_joins_s": block["wall_clock_s"] + join_s,
-                                     "root_receipt_words": int(nodes[0][0].seal.size), "compact_receipt_verified": True,
-                                     "note": "P2-JOIN: parent claim = Poseidon2 hash_pair(children's claims) constrained in-circuit; the verifier "
-                                             "needs the root receipt + the leaves only (`--config succinct` runs S = 1024)"}
-            if world == 1 and not args.no_recursive and S > 1:
-                rlanes = fold_lanes(lanes)
-                prep = recursive_prepare(rlanes, broots, brec[0])
-                rroot, rstats = recursive_fold(rlanes, [brec[i] for i in range(S)])
-                rstats.update(prep)
-                rstats["in_flight"] = len(rlanes)
-                t_v = time.perf_counter()
-                rroot.verify(lanes[0].rec.allowed_roots(), [receipt_claim(brec[i], desc, broots[bsegs[i].po2]) for i in range(S)])
-                rstats["root_verify_s"] = time.perf_counter() - t_v
-                rstats["root_verified_against_leaf_claims"] = True
-                rstats["block_plus_fold_s"] = block["wall_clock_s"] + rstats["fold_s"]
-                block["recursive"] = rstats
-        last = next((ln.last for ln in lanes if ln.last is not None), None)
-        if rank == 0:
-            value = world * args.steps / dt
-            line = {
-                "metric": "segments/sec", "value": value, "unit": "segments/s", "n_gpus": world, "steps": args.steps,
-                "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-                "config": {"workload": f"single 2^{args.po2}-cycle segment seal per step per GPU, {workload}, witness resident in HBM",
-                           "po2": args.po2, "circuit": args.circuit,
-                           "parallelism": f"segments round-robin over {world} GPU(s), no collectives; {inflight} segment(s) in flight per GPU",
-                           "rccl_probe": rccl, "inflight_per_gpu": inflight, "host_placement_rank0": placement,
-                           "seal_words": int(last.seal.size) if last is not None else 0,
-                           "library": HipHal.version(),
-                           "poseidon2_consts": HipHal.version().split("poseidon2_consts=")[-1].rstrip(")")},
-                # wall-clock of one seal call (enqueue .. seal words on the host), mean over the timed seals of this rank;
-                # with several seals in flight each one shares the GPU, so this is latency under load, not 1/value
-                "seal_wall_clock_s": sum(seal_times) / max(1, len(seal_times)),
-                # ... and of one seal with the GPU to itself (inflight 1: the same thing as seal_wall_clock_s)
-                "seal_wall_clock_unloaded_s": unloaded_seal_s if unloaded_seal_s is not None else sum(seal_times) / max(1, len(seal_times)),
-            }
-            # witness generation (synthetic, on the device) is reported separately (SURVEY.md §8d).  ONE meaning in every
-            # config: the MEAN per segment measured INSIDE a clock with the other lanes sealing (here: the block leg's).
-            if block is not None:
-                line["witgen_ms_per_segment"] = block["witgen_ms_per_segment"]
-            else:
-                line["witgen_ms_per_segment_idle_gpu"] = 1e3 * sum(t for ln in lanes for t in ln.witgen_s) / max(1, sum(len(ln.witgen_s) for ln in lanes))
-            if certify is not None:
-                line.update(timed_seals_verified=certify["timed_seals_verified"], seal_matches_golden=certify["seal_matches_golden"])
-                line["certify"] = certify
-            if block is not None:
-                line["block"] = block
-                # the strong-scaling figure (BASELINE's metric is a block's seal wall-clock): total work fixed at S segments
-                line["block_wall_clock_s"] = block["wall_clock_s"]
-                line["block_segments_per_s"] = block["segments_per_s"]
-            if pcie is not None:
-                line["pcie_inclusive"] = pcie
-            if heavy is not None:
-                line["syn_heavy"] = heavy
-            if resident is not None:
-                line["code_group_resident"] = resident
-            alg = seal_algorithmic_bytes(wa, wc, wd, len(circ.taps), len(circ.combos), n)
-            line["seal_roofline"] = {"alg_bytes": alg, "achieved": alg / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBPS,
-                                     "unit": "GB/s", "frac": alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS}
-            # roofline{} (its HBM traffic is measured by child runs under rocprofv3) and the CPU baseline are taken by rank 0 AFTER
-            # the process group is gone: the other ranks have nothing left to do, the host's cores and rank 0's GPU are idle
-            if prof:
-                after_group.append(lambda: add_roofline(line, prof, ref, args, inflight, (wa, wc, wd), n, device))
-            if not args.no_cpu_baseline:
-                def _cpu():
-                    try:
-                        line["cpu_baseline"] = cpu_baseline(desc, args.circuit, cpus_before)
-                    except Exception as e:       # the baseline is a reported number, never a dependency of the product path
-                        line["cpu_baseline"] = {"error": repr(e)}
-                after_group.append(_cpu)
-    # =====================================================================================================
-    else:
-        S = args.segments or (256 if args.config == "block" else 1024)
-        succinct = args.config == "succinct"
-        recursive = succinct and args.join_circuit == "recursion"
-        segs = block_segments(S)
-        mine = partition_round_robin(S, world, rank)
-        if recursive and world > 1:
-            # every rank folds a contiguous, equal range of leaves (zeth_amd/recursion.py fold_plan), and rank 0 folds the `world`
-            # local roots by the same rule: N range trees under one top tree (the verifier: fold_leaf_claims(leaves, ranks = N))
-            from zeth_amd.recursion import aligned_range
-            try:
-                mine = list(aligned_range(S, world, rank))
-            except ValueError as e:
-                raise SystemExit(f"bench: --join-circuit recursion: {e}")
-        if args.config == "block" and args.chained:
-            # ---- a CHAINED block (claim continuity, DESIGN.md §2g): SYN-C segments — SYN-A with the pre-state as public input, out =
-            # (post, 0, 0, 0, pre) — through the native session executor.  Rank 0 runs the executor's pass for the WHOLE block (one
-            # launch: every segment's contribution to the running state; before the clock, as upstream's executor runs before any
-            # proving), the pre-states travel with the segment list, every rank proves its round-robin share independently, and
-            # after the clock the gathered composite must pass pre == prev.post (`CompositeReceipt::verify_integrity`). ----
-            from zeth_amd.circuits import syn_air as _sa
-            from zeth_amd.host import CompositeReceipt, Session, chain_segments
-            cdesc = _sa.syn_chain()
-            cprobe = SegmentProver(HipHal(device), cdesc)
-            croots = {p: cprobe.control_root(p) for p in sorted({sg.po2 for sg in segs})}
-            box = [None]
-            t_e = time.perf_counter()
-            if rank == 0:
-                box[0] = chain_segments(segs, cprobe.chain_contribution, initial_state=1)
-            executor_s = time.perf_counter() - t_e
-            if distributed:
-                dist.broadcast_object_list(box, src=0)
-            csegs = box[0]
-            sess = Session(cdesc, devices=(device,), lanes_per_device=inflight)
-            sess.set_resident_code(not args.recompute_code)
-            sess.prove([csegs[0]] * inflight + [csegs[-1]])            # warm-up (the library treats `pub` as given: not chained mode)
-            device_sync([cprobe])
-            barrier()
-            t0 = time.perf_counter()
-            comp, _, st = sess.prove([csegs[i] for i in mine])
-            barrier()
-            dt = time.perf_counter() - t0
-            t_v = time.perf_counter()
-            for r in comp.segments:
-                r.verify(cdesc, croots[r.po2])
-            verify_s = time.perf_counter() - t_v
-            for r, i in zip(comp.segments, mine):
-                r.index = i
-            parts = [comp.segments]
-            if distributed:
-                parts = [None] * world if rank == 0 else None
-                dist.gather_object(comp.segments, parts, dst=0)
-                tm = torch.tensor([dt], dtype=torch.float64, device=ctrl_dev)
-                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-                dt = float(tm.item())
-            if rank == 0:
-                whole = CompositeReceipt(sorted((r for part in parts for r in part), key=lambda r: r.index))
-                whole.verify_integrity(chained=True, initial_state=1)           # raises if the session is not continuous
-                line = {
-                    "metric": "segments/sec", "value": S / dt, "unit": "segments/s", "n_gpus": world, "steps": S, "warmup": 1,
-                    "ms_per_step": 1e3 * dt / S, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-                    "config": {"workload": f"one CHAINED block: {S} distinct 2^{args.po2}-cycle SYN-C segments (last one 2^{segs[-1].po2}); every segment's "
-                                           f"pre-state is its predecessor's post-state (out = post, 0, 0, 0, pre), fixed by the executor's pass before the clock; "
-                                           f"witness generation inside the clock", "po2": args.po2, "circuit": "syn_chain", "segments": S,
-                               "parallelism": f"segments round-robin over {world} GPU(s), native session executor per rank, no data-path collective; {inflight} seal(s) in flight per GPU",
-                               "inflight_per_gpu": inflight, "library": HipHal.version(), "host_placement_rank0": placement},
-                    "block_wall_clock_s": dt, "verified_after_clock": len(whole.segments), "verify_s_rank0": verify_s,
-                    "continuity": {"checked": "pre == prev.post over all segments (CompositeReceipt.verify_integrity), first pre == the initial state",
-                                   "executor_pass_s": executor_s, "initial_state": 1, "final_state_word": whole.final_state()},
-                }
-        elif recursive and args.executor == "native":
-            # ---- config 5 as ONE native call per rank: zkh_session_prove(join_tree = 2) seals this rank's segments and folds them —
-            # by default as one pipeline (a lift2 / join is proven the moment its children exist, on the fold lanes while the sealing
-            # lanes are busy), with --fold phased as two phases.  No Python in the loop; this is what a Rust shim's Prover::prove
-            # would call once per session (/root/reference/crates/host/src/lib.rs:137). ----
-            import numpy as np
-            from zeth_amd import recursion as zrec
-            from zeth_amd.host import Session
-            os.environ["ZKH_FOLD_LANES"] = str(max(args.fold_inflight, inflight))
-            probe = Lane()                                     # control roots + (rank 0, N > 1) the top joins
-            probe.prover.prove_segment(Segment(index=0, po2=args.po2, seed=1, noise_seed=BENCH_NOISE))
-            roots = {p: probe.prover.control_root(p) for p in sorted({s.po2 for s in segs})}
-            t_b = time.perf_counter()
-            programs = zrec.build_programs(desc, roots, fused_pairs=not args.no_fused_lift, ternary=not args.no_join3)
-            build_s = time.perf_counter() - t_b
-            t_b = time.perf_counter()
-            sess = Session(desc, devices=(device,), lanes_per_device=inflight)
-            sess.set_recursion(programs)
-            sess.set_streamed_fold(args.fold == "streamed")
-            sess.set_resident_code(not args.recompute_code)
-            if args.witness == "preflight":                    # upstream's whole shape: host preflight -> row fill -> seal -> join-as-you-go
-                sess.set_witness_source(1, args.preflight_producers)
-            load_s = time.perf_counter() - t_b
-            # warm-up: a short session of the same shape (every segment size, every program kind, pools, clocks)
-            wsegs = [segs[0]] * (2 * max(args.fold_inflight, inflight)) + [segs[0], segs[-1]]
-            for _ in range(max(1, args.warmup)):
-                sess.prove(wsegs, join_tree=2, join_noise_seed=BENCH_NOISE)
-            if distributed and rank == 0:
-                probe.rec = zrec.Recursion(probe.hal, programs)
-            device_sync([probe])
-            barrier()
-            t0 = time.perf_counter()
-            comp, local_root, st = sess.prove([segs[i] for i in mine], join_tree=2, join_noise_seed=BENCH_NOISE)
-            t_local = time.perf_counter() - t0
-            kinds = [k for k, _ in programs]
-            rp = st["root_program"]
-            local = zrec.RecReceipt(local_root.seal, local_root.po2, rp, None, len(mine), st["root_core"], st["root_pre"], st["root_post"])
-            tops, root = [local], local
-            top_s = 0.0
-            if distributed:
-                tops = [None] * world if rank == 0 else None
-                dist.gather_object(local, tops, dst=0)
-                if rank == 0:
-                    t_top = time.perf_counter()
-                    for t in tops:
-                        t.control_root = probe.rec.programs[t.program].root
-                    root = probe.rec.fold(tops, BENCH_NOISE)
-                    probe.hal.sync()
-                    top_s = time.perf_counter() - t_top
-            barrier()
-            dt = time.perf_counter() - t0
-            tt = torch.tensor([dt, st["leaves_s"], st["fold_tail_s"], st["fold_busy_s_sum"], float(st["n_retries"]), st["witgen_s_sum"], float(len(mine)),
-                               st["preflight_cpu_s_sum"], st["trace_bytes"]], dtype=torch.float64, device=ctrl_dev)
-            if distributed:
-                mx = tt[:3].clone()
-                dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-                dist.all_reduce(tt)
-                tt[:3] = mx
-            dt, t_leaves, fold_tail = float(tt[0]), float(tt[1]), float(tt[2])
-            # ---- after the clock: every leaf seal through the host verifier, the root seal, and the claim tree ----
-            verified, follows = 0, None
-            t_v = time.perf_counter()
-            if not args.no_verify:
-                for r in comp.segments:
-                    r.verify(desc, roots[r.po2])
-                    verified += 1
-            verify_s = time.perf_counter() - t_v
-            mine_claims = {i: receipt_claim(r, desc, roots[r.po2]) for i, r in zip(mine, comp.segments)} if not args.no_verify else {}
-            parts = [mine_claims]
-            if distributed:
-                parts = [None] * world if rank == 0 else None
-                dist.gather_object(mine_claims, parts, dst=0)
-            rstats = None
-            if rank == 0:
-                if not args.no_verify:
-                    if not distributed:
-                        probe.rec = zrec.Recursion(probe.hal, programs)       # only for the allowed set (host data), after the clock
-                        root.control_root = probe.rec.programs[root.program].root
-                    t_rv = time.perf_counter()
-                    root.verify(probe.rec.allowed_roots())                    # ONE seal; the claim tree is checked against the leaves below
-                    root_verify_s = time.perf_counter() - t_rv
-                    verified += 1
-                    allc = {k: v for part in parts for k, v in part.items()}
-                    follows = bool(np.array_equal(root.seal[:8], zrec.fold_leaf_claims([allc[i] for i in range(S)], ranks=world)))
-                    if not follows:
-                        raise SystemExit("bench: the root receipt's output is not the claim tree of the leaves")
-                else:
-                    root_verify_s = None
-                n_fused = sum(1 for k in range(len(mine) // 2) if ("lift2", segs[mine[2 * k]].po2, segs[mine[2 * k + 1]].po2) in kinds)
-                all_fused = n_fused == len(mine) // 2 and len(mine) > 1
-                rstats = {"executor": "native: one zkh_session_prove(join_tree = 2) call per rank (csrc/session.hip), no Python in the loop",
-                          "witness": ("host preflight: a sequential per-cycle machine on producer threads ahead of the seals, 16 bytes per cycle over PCIe, row fill "
-                                      "on the GPU" if args.witness == "preflight" else "closed-form generator on the device"),
-                          "host_preflight_cpu_ms_per_segment": 1e3 * float(tt[7]) / max(1.0, float(tt[6])) if args.witness == "preflight" else None,
-                          "pcie_bytes_per_segment": float(tt[8]) / max(1.0, float(tt[6])) if args.witness == "preflight" else None,
-                          "fold": args.fold, "streamed_fold": st["streamed_fold"], "code_group": "recomputed per segment" if args.recompute_code else "resident per lane and size",
-                          "bottom_level_proofs": st["n_lifts"] * world, "fused_lift2": (len(mine) // 2) * world if all_fused else 0,
-                          "joins": st["n_joins"] * world + top_proofs(tops, kinds), "proofs": (st["n_lifts"] + st["n_joins"]) * world + top_proofs(tops, kinds),
-                          "leaves_s": t_leaves, "fold_tail_s": fold_tail, "fold_busy_lane_s": float(tt[3]), "top_joins": top_proofs(tops, kinds), "top_joins_s": top_s,
-                          "segment_retries": int(tt[4]), "program_build_s": build_s, "program_load_s_all_lanes": load_s,
-                          "in_flight": {"sealing_lanes": inflight, "fold_lanes": max(args.fold_inflight, inflight)},
-                          "root_verify_s": root_verify_s,
-                          "note": "every lift2 runs the STARK verifier on two segment seals and every join on both child seals INSIDE the RECURSION "
-                                  "circuit; fold_tail_s = last segment sealed -> root receipt (the part of the fold the leaves did not hide)"}
-            cnt = torch.tensor([float(verified)], dtype=torch.float64, device=ctrl_dev)
-            if distributed:
-                dist.all_reduce(cnt)
-            if rank == 0:
-                line = {
-                    "metric": "segments/sec", "value": S / dt, "unit": "segments/s", "n_gpus": world, "steps": S,
-                    "warmup": max(1, args.warmup), "ms_per_step": 1e3 * dt / S, "higher_is_better": True, "scaling": "strong",
-                    "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-                    "config": {"workload": (f"block + fold to ONE succinct receipt: {S} distinct 2^{args.po2}-cycle segments (last one 2^{segs[-1].po2}), {workload}; "
-                                            f"witness generation inside the clock; {rstats['proofs']} proofs of the RECURSION circuit, every node runs the STARK "
-                                            f"verifier on its child seal(s) in-circuit; fold {args.fold}"),
-                               "po2": args.po2, "circuit": args.circuit, "segments": S,
-                               "parallelism": (f"{world} GPU(s): every rank seals AND folds its own contiguous, equal range of segments "
-                                               f"(a deviation from round-robin: a rank folds what it sealed), rank 0 folds "
-                                               f"the {world} local roots gathered over gloo by the same plan; no data-path collective; {inflight} sealing + "
-                                               f"{max(args.fold_inflight, inflight) - inflight} fold-only lanes per GPU"),
-                               "inflight_per_gpu": inflight, "library": HipHal.version(), "host_placement_rank0": placement,
-                               "join_circuit": "recursion (lift2 + join programs, in-circuit verification of every child seal)",
-                               "poseidon2_consts": HipHal.version().split("poseidon2_consts=")[-1].rstrip(")")},
-                    "block_wall_clock_s": dt, "leaf_phase_s": t_leaves, "join_phase_s": dt - t_leaves,
-                    "witgen_ms_per_segment": 1e3 * float(tt[5]) / max(1.0, float(tt[6])),
-                    "verified_after_clock": int(cnt.item()), "verify_s_rank0": verify_s,
-                    "root_receipt_words": int(root.seal.size), "succinct_root_follows_from_leaf_claims": follows,
-                    "recursion": rstats,
-                }
+        ctl.barrier()
+        if dev:
+            from benchlib.dev import run_dev
+            line, after = run_dev(run)
         else:
-            # block / succinct: the committed code group of each segment size stays resident per lane (what the session executor does
-            # by default; byte-identical seals); --recompute-code re-commits it per segment like upstream's SegmentProver
-            lanes = [Lane(with_join=succinct and not recursive, resident=not args.recompute_code) for _ in range(inflight)]
-            # warm-up: one seal of every size per lane (clocks, pools, code objects, resident groups), plus the control roots the verifier needs
-            for ln in lanes:
-                for _ in range(max(1, args.warmup)):
-                    for p2 in sorted({sg.po2 for sg in segs}, reverse=True):
-                        ln.prover.prove_segment(Segment(index=0, po2=p2, seed=1, noise_seed=BENCH_NOISE))
-                if succinct and not recursive:
-                    ln.join_prover.prove_segment(Segment(index=0, po2=args.join_po2, seed=1, noise_seed=BENCH_NOISE,
-                                                         pub=tuple([1] * 16)))
-                ln.hal.sync()
-            roots = {p: lanes[0].prover.control_root(p) for p in sorted({s.po2 for s in segs})}
-            join_root = lanes[0].join_prover.control_root(args.join_po2) if succinct and not recursive else None
-            rstats, rlanes = None, None
-            if recursive:
-                rlanes = fold_lanes(lanes)
-                rstats = recursive_prepare(rlanes, roots, lanes[0].prover.prove_segment(Segment(index=0, po2=args.po2, seed=1, noise_seed=BENCH_NOISE)))
-                rstats["in_flight"] = len(rlanes)
-            receipts, t0, wit_s, seal_s = seal_block(lanes, segs, mine)
-            t_leaves = time.perf_counter() - t0
-            joins_done, root = {}, None
-            if recursive:
-                local_root, st = recursive_fold(rlanes, [receipts[i] for i in mine])
-                rstats.update(st)
-                tops = [local_root]
-                if distributed:
-                    tops = [None] * world if rank == 0 else None
-                    dist.gather_object(local_root, tops, dst=0)
-                if rank == 0:
-                    t_top = time.perf_counter()
-                    root = lanes[0].rec.fold(tops, BENCH_NOISE)
-                    lanes[0].hal.sync()
-                    rstats["top_joins"] = top_proofs(tops, lanes[0].rec.kinds)
-                    rstats["top_joins_s"] = time.perf_counter() - t_top
-            elif succinct:
-                # join tree: tasks of one level are independent -> spread over the lanes of this rank
-                def claim_of(r, is_leaf):
-                    return node_claim(r, desc if is_leaf else join_desc, roots[r.po2] if is_leaf else join_root, is_leaf)
-
-                jlock = threading.Lock()
-
-                def prove_joins_parallel(tasks_segs):
-                    """prove a list of join Segments on this rank's lanes concurrently -> receipts in the same order"""
-                    out = [None] * len(tasks_segs)
-                    pos = [0]
-
-                    def work(ln):
-                        try:
-                            while True:
-                                with jlock:
-                                    k = pos[0]
-                                    if k >= len(tasks_segs):
-                                        return
-                                    pos[0] = k + 1
-                                out[k] = ln.join_prover.prove_segment(tasks_segs[k])
-                        except Exception as e:
-                            ln.err = e
-                    run_lanes(lanes, work)
-                    return out
-
-                class BatchedExecutor(JoinExecutor):
-                    """JoinExecutor whose per-level local joins run concurrently on the lanes (same schedule, same results)."""
-                    def run(self, n_leaves, local_leaves):
-                        from zeth_amd.host import join_schedule, join_segment
-                        nodes = {i: (r, True) for i, r in local_leaves.items()}
-                        n_nodes, done = n_leaves, {}
-                        for tasks in join_schedule(n_leaves, self.world_size):
-                            right = {}
-                            for t in tasks:
-                                if t.right_owner == t.device:
-                                    continue
-                                if self.rank == t.right_owner:
-                                    self._send(nodes[t.right], t.device)
-                                elif self.rank == t.device:
-                                    right[t.index] = self._recv(t.right_owner)
-                            local = [t for t in tasks if t.device == self.rank]
-                            jsegs = []
-                            for t in local:
-                                l_rec, l_leaf = nodes[t.left]
-                                r_rec, r_leaf = right[t.index] if t.index in right else nodes[t.right]
-                                jsegs.append(join_segment(t, self.claim_of(l_rec, l_leaf), self.claim_of(r_rec, r_leaf), self.join_po2, self.noise_seed))
-                            recs = prove_joins_parallel(jsegs)
-                            nxt2 = {}
-                            for t, j in zip(local, recs):
-                                done[(t.level, t.index)] = j
-                                nxt2[t.index] = (j, False)
-                            if n_nodes % 2 and (n_nodes - 1) in nodes:
-                                nxt2[n_nodes // 2] = nodes[n_nodes - 1]
-                            nodes, n_nodes = nxt2, (n_nodes + 1) // 2
-                        return done, (nodes.get(0, (None, False))[0] if n_nodes == 1 else None)
-
-                ex = BatchedExecutor(None, claim_of, rank, world, join_po2=args.join_po2, noise_seed=BENCH_NOISE)
-                joins_done, root = ex.run(S, {i: receipts[i] for i in mine})
-                device_sync(lanes)
-            barrier()
-            dt = time.perf_counter() - t0
-            if distributed:
-                t = torch.tensor([dt, t_leaves], dtype=torch.float64, device=ctrl_dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt, t_leaves = float(t[0].item()), float(t[1].item())
-            # ---- after the clock: verify every seal this rank produced (cli.rs:103 analogue) ----
-            verified = 0
-            t_v = time.perf_counter()
-            if not args.no_verify:
-                for i in mine:
-                    receipts[i].verify(desc, roots[segs[i].po2])
-                    verified += 1
-                for j in joins_done.values():
-                    j.verify(join_desc, join_root)
-                    verified += 1
-            verify_s = time.perf_counter() - t_v
-            # succinct: what a holder of the COMPACT receipt (root + leaves, joins dropped) checks — the claim tree over the leaf
-            # claims, recomputed on the host with hash_pair, must end in the root receipt's public output
-            follows = None
-            if recursive and not args.no_verify and rank == 0:
-                t_rv = time.perf_counter()
-                root.verify(lanes[0].rec.allowed_roots())            # ONE seal; the claim tree is checked against the leaves below
-                rstats["root_verify_s"] = time.perf_counter() - t_rv
-                verified += 1
-            if succinct and not args.no_verify:
-                mine_claims = {i: receipt_claim(receipts[i], desc, roots[segs[i].po2]) for i in mine}
-                parts = [mine_claims]
-                if distributed:
-                    parts = [None] * world if rank == 0 else None
-                    dist.gather_object(mine_claims, parts, dst=0)
-                if rank == 0 and root is not None and (S > 1 or recursive):
-                    import numpy as np
-                    allc = {k: v for part in parts for k, v in part.items()}
-                    if recursive:
-                        from zeth_amd.recursion import fold_leaf_claims
-                        follows = bool(np.array_equal(root.seal[:8], fold_leaf_claims([allc[i] for i in range(S)], ranks=world)))
-                    else:
-                        follows = bool(np.array_equal(root.seal[:8], fold_claims([allc[i] for i in range(S)])))
-                    if not follows:
-                        raise SystemExit("bench: the root receipt's output is not the claim tree of the leaves")
-            counts = torch.tensor([float(verified), float(len(joins_done))], dtype=torch.float64, device=ctrl_dev)
-            if distributed:
-                dist.all_reduce(counts)
-            if rank == 0:
-                n_joins = int(counts[1].item())
-                line = {
-                    "metric": "segments/sec", "value": S / dt, "unit": "segments/s", "n_gpus": world, "steps": S,
-                    "warmup": max(1, args.warmup), "ms_per_step": 1e3 * dt / S, "higher_is_better": True, "scaling": "strong",
-                    "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-                    "config": {"workload": (f"{'block + join tree to one succinct receipt' if succinct else 'one block'}: {S} distinct "
-                                            f"2^{args.po2}-cycle segments (last one 2^{segs[-1].po2}), {workload}; witness generation inside the clock"
-                                            + (f"; {rstats['proofs']} proofs of the RECURSION circuit ({rstats['fused_lift2']} lift2 = lift + lift + join fused, {rstats['lifts']} lifts, {rstats['joins']} joins): every node runs the STARK verifier on its child seal(s) in-circuit" if recursive else
-                                               f"; {n_joins} P2-JOIN joins at po2 {args.join_po2} (parent claim = Poseidon2 hash_pair of the children's, proven in-circuit)" if succinct else "")),
-                               "po2": args.po2, "circuit": args.circuit, "segments": S,
-                               "parallelism": f"segments round-robin over {world} GPU(s) + shared work index inside a rank, no data-path collective; "
-                                              f"{inflight} seal(s) in flight per GPU" + ("; every rank folds its own aligned range of leaves, rank 0 joins the local roots (gathered over gloo)" if recursive else
-                                                                                         "; joins on the rank of their left child, right child over gloo" if succinct else ""),
-                               "inflight_per_gpu": inflight, "library": HipHal.version(), "host_placement_rank0": placement,
-                               "code_group": "recomputed per segment" if args.recompute_code else "resident per lane and size (byte-identical seals)",
-                               "poseidon2_consts": HipHal.version().split("poseidon2_consts=")[-1].rstrip(")")},
-                    "block_wall_clock_s": dt, "leaf_phase_s": t_leaves, "join_phase_s": dt - t_leaves if succinct else None,
-                    "witgen_ms_per_segment": 1e3 * sum(wit_s) / max(1, len(wit_s)),      # mean, in-clock (rank 0's segments)
-                    "seal_call_ms_mean": 1e3 * sum(seal_s) / max(1, len(seal_s)),
-                    "verified_after_clock": int(counts[0].item()), "verify_s_rank0": verify_s,
-                    "root_receipt_words": int(root.seal.size) if root is not None else None,
-                    "succinct_root_follows_from_leaf_claims": follows,
-                }
-                if recursive:
-                    line["recursion"] = rstats
-                    line["config"]["join_circuit"] = "recursion (lift + join programs, in-circuit verification of every child seal)"
-                elif succinct:
-                    line["config"]["join_circuit"] = "p2_join"
-    if distributed:
-        barrier()
-        dist.destroy_process_group()
-    if rank == 0 and line is not None:
-        for fn in after_group:
-            fn()
-        # the secondary measurements of this run once more, INSIDE `config` (a record that keeps only the contract's keys then still
-        # holds them): nothing here is `value`
-        also = {}
-        if isinstance(line.get("syn_heavy"), dict):
-            also["syn_heavy_segments_per_s"] = round(line["syn_heavy"]["segments_per_s"], 3)
-        if isinstance(line.get("code_group_resident"), dict):
-            also["code_group_resident_segments_per_s"] = round(line["code_group_resident"]["segments_per_s"], 3)
-        blk = line.get("block")
-        if isinstance(blk, dict):
-            also["block"] = {"segments": blk["segments"], "wall_clock_s": round(blk["wall_clock_s"], 4), "segments_per_s": round(blk["segments_per_s"], 3),
-                             "recompute_code_group_segments_per_s": round((blk.get("recompute_code_group") or {}).get("segments_per_s", 0.0), 3) or None}
-            pre = blk.get("host_preflight_pipeline")
-            if isinstance(pre, dict) and "segments_per_s" in pre:
-                also["host_preflight_pipeline"] = {"segments_per_s": round(pre["segments_per_s"], 3),
-                                                   "host_cpu_ms_per_segment": round(pre["host_preflight_cpu_ms_per_segment"], 2),
-                                                   "pcie_MB_per_segment": round(pre["pcie_bytes_per_segment"] / 1e6, 2)}
-            if isinstance(blk.get("recursive"), dict):
-                also["block_fold_to_one_receipt_s"] = round(blk["recursive"]["fold_s"], 4)
-        if isinstance(line.get("recursion"), dict):
-            also["fold"] = {k: line["recursion"].get(k) for k in ("fold", "proofs", "fold_tail_s", "leaves_s")}
-        if "seal_wall_clock_unloaded_s" in line:
-            also["seal_wall_clock_unloaded_s"] = round(line["seal_wall_clock_unloaded_s"], 5)
-        if also:
-            line["config"]["also_measured"] = also
-        print(json.dumps(line))
-
-
-# kernels (rocprofv3 names) behind the ops whose HBM traffic bench.py can measure on itself
-TRAFFIC_KERNELS = {"hash_rows": ("k_hash_rows", "k_hash_rows_pair"), "hash_fold": ("k_hash_fold",), "eval_check": ("k_eval_check_",)}
-
-
-def by_op(records):
-    """HIP-event records -> per Hal op.  NTT records are "<op>:<kernel>" per pass and the op's §8d bytes are charged to exactly ONE
-    pass of every invocation, so: op time = sum over its passes, op bytes = sum, op invocations = calls of the passes that carry
-    bytes.  A sub-kernel bracket is never a roofline candidate on its own (its bytes live with the parent op)."""
-    ops = {}
-    for p in records:
-        o = ops.setdefault(p["name"].split(":")[0], {"name": p["name"].split(":")[0], "total_ms": 0.0, "alg_bytes": 0.0, "calls": 0, "launches": 0})
-        o["total_ms"] += p["total_ms"]; o["alg_bytes"] += p["alg_bytes"]; o["launches"] += p["calls"]
-        if p["alg_bytes"] > 0 or ":" not in p["name"]:
-            o["calls"] += p["calls"]
-    for o in ops.values():
-        o["calls"] = max(1, o["calls"])
-    return ops
-
-
-def add_roofline(line, prof, ref, args, inflight, widths, n, device=0):
-    """roofline{} for the dominant op + the per-kernel table, from the HIP-event brackets of the timed region (prof)
-    and of one extra seal that ran alone on the GPU (ref)."""
-    wa, wc, wd = widths
-    unshared = {p["name"]: p for p in (ref or prof)}
-    ops_unshared, ops_timed = by_op(unshared.values()), by_op(prof)
-    # the dominant OP among those with algorithmic bytes (every Hal op has them; witness-generator brackets may not)
-    cands = [o for o in ops_unshared.values() if o["alg_bytes"] > 0 and o["name"] in ops_timed] or list(ops_unshared.values())
-    dom_u = max(cands, key=lambda o: o["total_ms"])
-    dom_name = dom_u["name"]
-    dom = ops_timed.get(dom_name, dom_u)
-    per_launch_ms = dom["total_ms"] / dom["calls"]
-    per_launch_ms_unshared = dom_u["total_ms"] / dom_u["calls"]
-    per_launch_bytes = dom_u["alg_bytes"] / dom_u["calls"]
-    ach = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
-    # HBM bytes per launch: measured now (two child runs under rocprofv3 --pmc, separate passes) on this rank's GPU, else
-    # from the committed PMC passes of an earlier run of this command (tools/pmc_summary.py)
-    traffic, traffic_source = None, None
-    knames = TRAFFIC_KERNELS.get(dom_name)
-    if knames and not args.no_live_traffic:
-        got = live_traffic(knames, args.circuit, args.po2, device=device)
-        if got is not None:
-            per_kernel_launch, n_launch, traffic_source = got
-            # an op invocation = dom_u["launches"] / dom_u["calls"] kernel launches (eval_check of a split circuit: one per part)
-            traffic = per_kernel_launch * dom_u["launches"] / dom_u["calls"]
-    for fn in () if traffic is not None else ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
-            kname = (knames or ("",))[0]
-            if kname == "k_eval_check_":
-                kname = "k_eval_check_" + args.circuit
-            if kname in tj and args.po2 == PO2 and args.circuit == "syn_a":
-                traffic = (tj[kname]["fetch_x2_bytes"] + tj[kname]["write_bytes"]) / tj[kname]["launches"]
-                traffic_source = f"profiles/{fn} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, not measured in this run)"
-                break
+            run.bind_device()
+            run.load_circuit()
+            if args.config == "segment":
+                from benchlib.segment import run_segment
+                line, after = run_segment(run)
+            elif args.config == "block":
+                from benchlib.block import run_block
+                line, after = run_block(run)
+            else:
+                from benchlib.succinct import run_succinct
+                line, after = run_succinct(run)
+    except RankFailed as e:
+        # this rank is out (its own leg failed, or its peers gave up on it): say so, stay until rank 0 has printed, exit non-zero
+        sys.stderr.write(f"bench: {e}\n")
+        if ctl.i_failed is None:
+            ctl.fail("the control plane", e)
+        ctl.wait_done()
+        return 3
+    except BaseException as e:
+        if world > 1 and ctl.i_failed is None:
+            try:
+                ctl.fail(args.config, e)
+            except Exception:
+                pass
+        raise
+    if world > 1 and not run.failed_ranks:
+        try:                                      # (with a dead rank the group is left alone: tearing it down can wait for the dead)
+            import torch.distributed as dist
+            t_d = time.perf_counter()
+            dist.destroy_process_group()
+            if os.environ.get("ZKH_BENCH_TRACE_EXIT"):
+                sys.stderr.write(f"rank {rank}: destroy_process_group {time.perf_counter() - t_d:.2f} s\n")
         except Exception:
-            continue
-    # Primary figures = the kernel's own launch duration (HIP-event brackets of one seal that ran ALONE right after the timed
-    # region: what `rocprofv3 --kernel-trace --stats` reports per dispatch, profiles/r0N_kernel_stats*.csv).  With several
-    # seals in flight the brackets of the timed region also contain the time a launch spent queued behind the other streams'
-    # kernels; those are kept as *_timed_region.
-    ach_unshared = per_launch_bytes / (per_launch_ms_unshared * 1e-3) / 1e9
-    line["roofline"] = {"bound": "hbm", "kernel": dom_name, "achieved": ach_unshared, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                        "frac": ach_unshared / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                        "avg_launch_ms": per_launch_ms_unshared,
-                        "avg_launch_ms_timed_region": per_launch_ms, "achieved_timed_region": ach,
-                        "alg_bytes_per_launch": per_launch_bytes,
-                        "share_of_kernel_time": dom_u["total_ms"] / sum(p["total_ms"] for p in unshared.values()),
-                        "launches_overlap": inflight > 1,
-                        "measured_on": f"rank 0's GPU (device {device}), one seal alone after the timed region" if ref else "the timed region",
-                        "note": "dominant kernel is integer-VALU-bound by construction (Poseidon2: ~21 Montgomery "
-                                "products per absorbed byte); HBM fraction is reported as the contract asks; avg_launch_ms is the "
-                                "kernel's own duration (one seal alone on the GPU, measured live after the timed region); with "
-                                "inflight_per_gpu > 1 the HIP-event brackets of the timed region (*_timed_region) also include time "
-                                "queued behind other streams' kernels"}
-    if dom_name == "hash_rows":
-        # VALU view of the same kernel: permutations per launch x modelled issue cycles per 64-lane permutation
-        # (DESIGN.md §4c: 8 full rounds x 1990 + 7 partial groups x 1259 + first M_ext 711 + scale fixes 480 cycles;
-        # 4 cycles per multiply / fp64 / select-class instruction, 2.46 per plain add-class one: tools/ubench_valu.hip) against 1024 SIMDs at 2.4 GHz
-        perms = sum(-(-w // 16) for w in (wc, wd, wa, 16)) * 4 * n          # leaves of the 3 trace trees + check tree
-        deg = n
-        while deg > 256:                                                   # FRI rounds: 4*deg/16 rows of 64 words
-            perms += 4 * (4 * deg // 16)
-            deg //= 16
-        cyc = 8 * 1990 + 7 * 1259 + 711 + 480
-        per_seal_ms = dom_u["total_ms"] / (1 if ref else args.steps)
-        line["roofline"]["valu"] = {"permutations_per_seal": perms, "model_cycles_per_wave_permutation": cyc,
-                                    "issue_utilisation_at_2p4GHz": (perms / 64.0) * cyc / (1024 * 2.4e9 * per_seal_ms * 1e-3)}
-    div = 1 if ref else args.steps
-    line["kernels"] = [{"name": p["name"], "calls_per_seal": p["calls"] / div,
-                        "ms_per_seal": p["total_ms"] / div,          # unshared (one seal alone on the GPU)
-                        "ms_per_seal_timed_region": next((q["total_ms"] / args.steps for q in prof if q["name"] == p["name"]), None),
-                        # §8d algorithmic bytes (operands once in, once out) / time; 0 for the later passes of a multi-pass op
-                        "alg_GBps": (p["alg_bytes"] / (p["total_ms"] * 1e-3) / 1e9) if p["total_ms"] > 0 else 0.0}
-                       for p in sorted(unshared.values(), key=lambda p: -p["total_ms"])]
-    # per Hal op (NTT records are "<op>:<kernel>" per pass): op totals with §8d bytes over the sum of the passes
-    line["ops"] = [{"op": o["name"], "ms_per_seal": o["total_ms"] / div,
-                    "alg_GBps": o["alg_bytes"] / (o["total_ms"] * 1e-3) / 1e9 if o["total_ms"] > 0 else 0.0}
-                   for o in sorted(ops_unshared.values(), key=lambda o: -o["total_ms"])]
+            pass
+    rc = 0
+    if rank == 0 and line is not None:
+        for fn in after:
+            fn()
+        line["build_s"] = round(build_s, 2)
+        line["command_wall_s"] = round(time.perf_counter() - t_start, 1)
+        if run.failed_ranks:
+            line["failed_in"] = run.failed_in
+            rc = 4 if run.failed_in == "headline" else 0      # a secondary leg's failure is in the line; `value` is whole
+        print(json.dumps(line))
+        sys.stdout.flush()
+        ctl.finish()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    _rc = main()
+    if os.environ.get("ZKH_BENCH_TRACE_EXIT"):
+        sys.stderr.write(f"rank {os.environ.get('RANK')}: main returned {_rc} at {time.time():.2f}\n")
+    raise SystemExit(_rc)

@@ -1,0 +1,164 @@
+"""The CPU oracle timed on this host's cores — the reported CPU baseline (bench.py's `cpu_baseline` object).
+
+The ONLY place outside tests/ and __graft_entry__.smoke() that touches oracle/: here it is the thing measured beside the GPU, never
+part of the GPU path (the product fails loudly without the HIP library).  kind "port": the reference CPU prover (risc0-zkp's CpuHal
+in r0vm) cannot be built here (no Rust toolchain, crates un-vendored: SURVEY.md §8c), so the figure is this repository's from-spec
+restatement of the same algorithm."""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+import time
+
+from .common import BASE_SEED, BENCH_NOISE, PO2, ROOT
+
+CPU_PROBE_PO2 = 14              # thread-count probe; the timed sample is the largest po2 <= 20 that fits the budget
+CPU_SAMPLE_BUDGET_S = 12.0      # default run: one sample of ~10 s (the whole default command stays near a minute)
+CPU_SAMPLE_BUDGET_FULL_S = 30.0 # --cpu-full-host: the unit itself (one po2-20 seal, ~21 s on the GPU box) + the all-cores leg
+
+
+_CPU_WORKER = r"""
+import os, sys, time, json
+cpus = [int(c) for c in sys.argv[3].split(",")] if sys.argv[3] else []
+if cpus:
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        pass
+try:                                          # memory follows the worker's own cores (first touch), not the bench rank's GPU node
+    import ctypes
+    ctypes.CDLL(None, use_errno=True).syscall(238, 0, None, 0)      # x86-64 set_mempolicy(MPOL_DEFAULT)
+except Exception:
+    pass
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import zko                                   # test infrastructure; here ONLY as the reported CPU baseline
+from zeth_amd.circuits import syn_air, syn_heavy
+desc = syn_heavy.syn_heavy() if sys.argv[2] == "syn_heavy" else syn_air.syn_a()
+lib = zko.load()
+oc = zko.OracleCircuit(lib, desc)
+po2, seed, noise = int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+sys.stdout.write("ready\n"); sys.stdout.flush()
+sys.stdin.readline()                          # all workers start their seal together
+t0 = time.perf_counter()
+seal = oc.prove(po2, 1994, seed, noise)
+print(json.dumps({"s": time.perf_counter() - t0, "words": int(seal.size)})); sys.stdout.flush()
+"""
+
+
+def cpu_baseline(desc, circuit_name: str, cpus=None, full_host: bool = False) -> dict:
+    """The CPU oracle (a from-spec port of the reference CPU prover's algorithm) on this host's cores, two figures:
+    (1) ONE seal alone at the thread count where the oracle's OpenMP loops stop scaling (latency), and
+    (2) the WHOLE host: floor(cores / threads) independent seals at once, one process each, pinned to disjoint core blocks
+        (the reference proves segments independently, so a CPU-only deployment would fill its cores exactly like this) ->
+        aggregate segments/s = `value`, `cores` = all cores those processes used.
+    Leg (2) runs only with `full_host` (bench.py --cpu-full-host): it doubles the CPU time of the command, and on the GPU box it
+    has never beaten leg (1) (the memory-bound oracle gets slower per seal when every core is busy: profiles/README.md).
+    A bounded sample: the largest power-of-two fraction of the unit that fits the budget (12 s by default, 30 s with `full_host`:
+    then the po2-20 unit itself on the GPU box), scaled linearly (work ~ n)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import zko                                     # test infrastructure; used here ONLY as the reported CPU baseline
+    lib = zko.load()
+    oc = zko.OracleCircuit(lib, desc)
+    # the oracle's OpenMP loops stop scaling long before a two-socket host is full (fork/join + memory bound): scan a
+    # few thread counts on a small segment and run every seal at the fastest one
+    # `cpus`: the CPUs this process could use BEFORE it bound itself next to its GPU (host placement) — the baseline is the whole host's
+    try:
+        usable = sorted(cpus) if cpus else sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, usable)
+    except (AttributeError, OSError):
+        usable = list(range(os.cpu_count() or 1))
+    avail = len(usable)
+    budget = CPU_SAMPLE_BUDGET_FULL_S if full_host else CPU_SAMPLE_BUDGET_S
+    probe_po2 = CPU_PROBE_PO2
+    best, best_dt = avail, None
+    for t in sorted({c for c in (8, 16, 32, 64) if c <= avail} or {avail}):
+        lib.zko_set_num_threads(t)
+        t0 = time.perf_counter()
+        oc.prove(probe_po2, 1994, BASE_SEED, BENCH_NOISE)
+        d = time.perf_counter() - t0
+        if best_dt is None or d < best_dt:
+            best, best_dt = t, d
+    if os.environ.get("ZKH_CPU_BASELINE_THREADS"):             # tests: force the per-process thread count
+        best = max(1, min(avail, int(os.environ["ZKH_CPU_BASELINE_THREADS"])))
+    lib.zko_set_num_threads(best)
+    sample_po2 = probe_po2
+    while sample_po2 < PO2 and best_dt * (1 << (sample_po2 + 1 - probe_po2)) <= budget:
+        sample_po2 += 1
+    t0 = time.perf_counter()
+    seal = oc.prove(sample_po2, 1994, BASE_SEED, BENCH_NOISE)
+    dt = time.perf_counter() - t0
+    scale = 1 << (PO2 - sample_po2)
+    how = "the unit itself, no extrapolation" if scale == 1 else f"scaled x1/{scale} to the po2={PO2} unit (work is ~linear in n)"
+    single = {"value": 1.0 / (dt * scale), "seal_s": dt * scale, "cores": best,
+              "sample": f"one {circuit_name} segment seal at po2={sample_po2} alone on the host ({dt:.2f} s wall, OpenMP oracle incl. witgen, at the "
+                        f"fastest of 8/16/32/64 threads = {best}; {avail} hardware threads available); {how}"}
+    out = {"value": single["value"], "unit": "segments/s", "cores": best, "cores_available": avail, "kind": "port",
+           "sample": single["sample"], "single_seal": single,
+           "note": "a literal, untuned port (the reference CPU prover cannot be built here); reported as the contract asks, "
+                   "never a target and never a quotable speed-up",
+           "seal_words": int(seal.size)}
+    # ---- the whole host: P = floor(cores / best) processes, `best` threads each, disjoint core blocks, distinct segments ----
+    # (a bounded sample: the seals of this leg are 1/16 of the unit each — with every core busy the memory-bound oracle runs ~20 x
+    # slower per seal than alone, and the whole command has to stay within minutes)
+    if not full_host:
+        out["full_host"] = None
+        out["sample"] += "; the all-cores leg (floor(cores / threads) seals at once) runs with --cpu-full-host"
+        return out
+    procs_n = max(1, avail // best)
+    full_po2 = max(probe_po2, sample_po2 - 4)              # measured on the GPU box: 16 seals at once run ~20 x slower each than one alone
+    full_scale = 1 << (PO2 - full_po2)
+    try:
+        mem_avail = next(int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable:")) * 1024
+        per_proc = 10e9 * (1 << full_po2) / (1 << 20)            # measured: 0.49 GB of RSS per 2^16 cycles (SYN-A), 8 GB at po2 20
+        procs_n = max(1, min(procs_n, int(0.8 * mem_avail / per_proc)))
+    except (OSError, StopIteration, ValueError):
+        pass
+    workers = []
+    if procs_n > 1:
+        try:
+            for k in range(procs_n):
+                block = usable[k * best:(k + 1) * best]
+                env = dict(os.environ, OMP_NUM_THREADS=str(best), OMP_PROC_BIND="false")
+                for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                    env.pop(var, None)
+                workers.append(subprocess.Popen([sys.executable, "-c", _CPU_WORKER, ROOT, circuit_name, ",".join(map(str, block)), str(full_po2),
+                                                 str(BASE_SEED + k), str(BENCH_NOISE)], env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True))
+            for w in workers:
+                if w.stdout.readline().strip() != "ready":
+                    raise RuntimeError("a CPU baseline worker did not start")
+            t0 = time.perf_counter()
+            for w in workers:
+                w.stdin.write("go\n"); w.stdin.flush()
+            import select
+            times, deadline = [], time.perf_counter() + 3.0 * budget
+            for w in workers:
+                left = deadline - time.perf_counter()
+                if left <= 0 or not select.select([w.stdout], [], [], left)[0]:
+                    raise TimeoutError(f"the full-host leg did not finish within {3.0 * budget:.0f} s")
+                times.append(json.loads(w.stdout.readline())["s"])
+            wall = time.perf_counter() - t0
+            for w in workers:
+                w.wait(timeout=60)
+            agg = procs_n / (wall * full_scale)
+            fhow = "the unit itself" if full_scale == 1 else f"scaled x1/{full_scale} to the po2={PO2} unit (work is ~linear in n)"
+            full = {"value": agg, "cores": procs_n * best, "processes": procs_n, "threads_each": best, "sample_po2": full_po2, "wall_s": wall,
+                    "seal_s_under_load": times,
+                    "sample": f"{procs_n} independent {circuit_name} segment seals at po2={full_po2} at once, one process x {best} OpenMP threads each on "
+                              f"disjoint core blocks of the whole host, memory local to each block ({wall:.2f} s wall for all, {min(times):.1f}-{max(times):.1f} s "
+                              f"per seal under load; OpenMP oracle incl. witgen): {procs_n * best} of {avail} cores; {fhow}"}
+            out["full_host"] = full
+            if agg >= single["value"]:       # the host's best: every core busy
+                out.update(value=agg, cores=full["cores"], sample=full["sample"] + f"; one po2-{sample_po2} seal alone: {dt:.2f} s at {best} threads")
+            else:                            # the oracle is memory-bound: filling every core yields LESS than one seal at a time
+                out["sample"] += (f"; with every core busy ({procs_n} seals at once x {best} threads = {procs_n * best} of {avail} cores) the host does "
+                                  f"{agg:.4f} segments/s - less than one seal at a time, so the single-seal figure is the host's best and is the one quoted")
+        except Exception as e:           # the single-seal figure stands
+            out["full_host_error"] = repr(e)
+        for w in workers:
+            if w.poll() is None:
+                w.kill()
+    return out
+
+

@@ -51,6 +51,12 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not bad.search(txt), f"{f} references the oracle"
+    # bench.py and its parts: ONLY the cpu_baseline leg may touch it (as the thing measured beside the GPU, never on the GPU path)
+    for f in ["bench.py"] + [os.path.join("benchlib", g) for g in sorted(os.listdir(os.path.join(ROOT, "benchlib"))) if g.endswith(".py")]:
+        if f.endswith("cpu_baseline.py"):
+            continue
+        code = "\n".join(l for l in open(os.path.join(ROOT, f), errors="replace").read().split("\n") if not l.lstrip().startswith("#"))
+        assert not re.search(r"import\s+zko|libzkoracle|\bzko\.", code), f"{f} references the oracle"
 
 
 def test_syn_air_desc_roundtrip_and_shapes():
