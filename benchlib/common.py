@@ -65,7 +65,7 @@ class Run:
         self.widths = (0, 0, 0)
         self.n = 1 << args.po2
         self.inflight = max(1, args.inflight)
-        self.line_extra = {}
+        self.ranks_per_gpu = 1
 
     # ---- device + host placement ----
     def bind_device(self) -> None:
@@ -79,6 +79,7 @@ class Run:
             visible = 0
         if os.environ.get("ZKH_SHARE_GPUS"):
             self.device = self.local_rank % max(1, visible)
+            self.ranks_per_gpu = -(-self.world // max(1, visible))
         elif 0 < visible <= self.local_rank:
             # a launcher that narrows HIP_VISIBLE_DEVICES per rank (every rank sees ITS GPU as device 0): follow it instead of failing
             self.device = self.local_rank % visible
@@ -223,7 +224,7 @@ def seal_block(run: Run, lanes, segs, mine, prover_of=lambda ln: ln.prover):
 def config_common(run: Run) -> dict:
     from zeth_amd.hal import HipHal
     v = HipHal.version()
-    return {"po2": run.args.po2, "circuit": run.args.circuit, "inflight_per_gpu": run.inflight, "library": v,
+    return {"po2": run.args.po2, "circuit": run.args.circuit, "inflight_per_gpu": run.inflight, "ranks_per_gpu": run.ranks_per_gpu, "library": v,
             "poseidon2_consts": v.split("poseidon2_consts=")[-1].rstrip(")"), "host_placement_rank0": run.placement}
 
 

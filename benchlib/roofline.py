@@ -209,7 +209,8 @@ def add_roofline(line, prof, ref, args, inflight, widths, n, device=0, live=True
     if counters and counters.get("seal_valu"):
         s = counters["seal_valu"]
         clock = s["clock_GHz"] or 0.0
-        step_s = line["ms_per_step"] * 1e-3
+        # (ranks that SHARE one GPU in a dry run each see 1 / ranks_per_gpu of it: the chip's rate is what counts)
+        step_s = line["ms_per_step"] * 1e-3 / max(1, int((line.get("config") or {}).get("ranks_per_gpu", 1)))
         r["seal_valu_wave_instr"] = s["wave_instr"]
         r["seal_valu_issue_frac"] = s["wave_instr"] / (step_s * clock * 1e9 * N_SIMDS) if clock else None
         r["seal_valu_issue_frac_serial"] = s["issue_frac_serial"]
