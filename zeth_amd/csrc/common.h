@@ -41,9 +41,13 @@ inline const char* make_err(const char* fmt, ...) {
     } while (0)
 
 constexpr int ZKH_P2_PTAB = 414;            // partial-round table, layout in poseidon2.h (P2_TAB_WORDS)
-constexpr int TW_BITS = 12;                 // two-level twiddle tables: w_{2^24}^(hi*4096 + lo)
+constexpr int TW_BITS = 12;                 // two-level twiddle tables: w_{2^26}^(hi*4096 + lo), lo < 2^12, hi < 2^14
 constexpr int TW_SIZE = 1 << TW_BITS;
-constexpr int MAX_LOG_N = 2 * TW_BITS;      // largest NTT / coset-shift domain supported (2^24)
+constexpr int TW_HI_BITS = 14;              // (64 KiB per hi table: L2-resident; the index arithmetic of every kernel is unchanged)
+constexpr int TW_HI_SIZE = 1 << TW_HI_BITS;
+// largest NTT / coset-shift domain: 2^26 = the evaluation domain (INV_RATE 4) of a po2-24 segment, upstream's MAX_CYCLES_PO2
+// (--segment-po2 at /root/reference/crates/host/src/bin/cli.rs:61-66 accepts it); BabyBear's 2-adicity is 27
+constexpr int MAX_LOG_N = TW_BITS + TW_HI_BITS;
 constexpr int LDS_TW_LOG = 12;              // in-tile twiddles: w_{2^12}^j, j < 2^11
 
 struct DeviceTables {
@@ -51,12 +55,12 @@ struct DeviceTables {
     uint32_t* rc;        // 24*29
     uint32_t* diag;      // ZKH_P2_PTAB words: partial-round table
     // twiddles, Montgomery form
-    uint32_t* tw_fwd_lo; uint32_t* tw_fwd_hi;   // w^lo, w^(hi*4096), w = ROU_FWD[24]
-    uint32_t* tw_rev_lo; uint32_t* tw_rev_hi;   // same for ROU_REV[24]
+    uint32_t* tw_fwd_lo; uint32_t* tw_fwd_hi;   // w^lo, w^(hi*4096), w = ROU_FWD[MAX_LOG_N]
+    uint32_t* tw_rev_lo; uint32_t* tw_rev_hi;   // same for ROU_REV[MAX_LOG_N]
     uint32_t* tile_fwd;  uint32_t* tile_rev;    // ROU_FWD[12]^j / ROU_REV[12]^j, j < 2048
     uint32_t* layer_fwd; uint32_t* layer_rev;   // per-layer: [2^(j-1) + e] = ROU[j]^e, e < 2^(j-1), j <= 12 (4096 words)
     uint32_t* layer_fwd_plain;                  // layer_fwd out of Montgomery form (plain residues): lazy butterflies (ntt.hip)
-    uint32_t* shift_lo;  uint32_t* shift_hi;    // 3^lo, 3^(hi*4096)
+    uint32_t* shift_lo;  uint32_t* shift_hi;    // 3^lo, 3^(hi*4096), hi < 2^14
 };
 
 struct ProfAgg { uint64_t calls = 0; double ms = 0; double bytes = 0; };

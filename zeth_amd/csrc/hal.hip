@@ -157,9 +157,9 @@ static const char* ctx_init_tables(zkh_ctx* c) {
     }
     Fp wf = Fp::raw(c->rou_fwd[MAX_LOG_N]), wr = Fp::raw(c->rou_rev[MAX_LOG_N]);
     ZKH_TRY(upload(&c->tab.tw_fwd_lo, powers(wf, TW_SIZE)));
-    ZKH_TRY(upload(&c->tab.tw_fwd_hi, powers(fp_pow(wf, TW_SIZE), TW_SIZE)));
+    ZKH_TRY(upload(&c->tab.tw_fwd_hi, powers(fp_pow(wf, TW_SIZE), TW_HI_SIZE)));
     ZKH_TRY(upload(&c->tab.tw_rev_lo, powers(wr, TW_SIZE)));
-    ZKH_TRY(upload(&c->tab.tw_rev_hi, powers(fp_pow(wr, TW_SIZE), TW_SIZE)));
+    ZKH_TRY(upload(&c->tab.tw_rev_hi, powers(fp_pow(wr, TW_SIZE), TW_HI_SIZE)));
     ZKH_TRY(upload(&c->tab.tile_fwd, powers(Fp::raw(c->rou_fwd[LDS_TW_LOG]), 1 << (LDS_TW_LOG - 1))));
     ZKH_TRY(upload(&c->tab.tile_rev, powers(Fp::raw(c->rou_rev[LDS_TW_LOG]), 1 << (LDS_TW_LOG - 1))));
     {
@@ -175,7 +175,7 @@ static const char* ctx_init_tables(zkh_ctx* c) {
     }
     Fp three = fp_encode(3);
     ZKH_TRY(upload(&c->tab.shift_lo, powers(three, TW_SIZE)));
-    ZKH_TRY(upload(&c->tab.shift_hi, powers(fp_pow(three, TW_SIZE), TW_SIZE)));
+    ZKH_TRY(upload(&c->tab.shift_hi, powers(fp_pow(three, TW_SIZE), TW_HI_SIZE)));
     ZKH_TRY(upload(&c->tab.rc, std::vector<uint32_t>(24 * 29)));
     ZKH_TRY(upload(&c->tab.diag, std::vector<uint32_t>(ZKH_P2_PTAB)));
     ZKH_TRY(zkh_poseidon2_set_constants(c, ZKH_P2_ROUND_CONSTANTS, ZKH_P2_M_INT_DIAG));

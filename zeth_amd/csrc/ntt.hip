@@ -9,7 +9,7 @@
 // (forward, DIT) or out (inverse, DIF).  expand (x4 replication, first two layers skipped), n^-1 scaling and
 // the zk coset shift 3^bitrev(i) are fused into the first/last pass, so neither the zero-padded input nor the
 // unshifted coefficients ever touch HBM.
-//   HBM traffic: 8 B per element per pass (one read + one write), i.e. 16 B/elem for k <= 24.
+//   HBM traffic: 8 B per element per pass (one read + one write), i.e. 16 B/elem for k <= 22, 24 B/elem up to 2^26.
 #include "common.h"
 
 using namespace zkh;
@@ -33,8 +33,8 @@ struct PassParams {
     uint32_t zk_shift;       // ... and by 3^bitrev(i)
     const uint32_t* tile_tw; // w_{2^12}^j
     const uint32_t* layer_tw; // per-layer tables: [2^(j-1) + e] = w_j^e
-    const uint32_t* tw_lo;   // w_{2^24}^lo
-    const uint32_t* tw_hi;   // w_{2^24}^(4096 hi)
+    const uint32_t* tw_lo;   // w_{2^26}^lo
+    const uint32_t* tw_hi;   // w_{2^26}^(4096 hi), hi < 2^14
     const uint32_t* sh_lo;
     const uint32_t* sh_hi;
     uint32_t tiles_per_col;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassParams p) {
     const uint32_t l0 = lt << p.log_t;
     const uint32_t* in = p.in + (size_t)col * p.in_col_stride;
     uint32_t* out = p.out + (size_t)col * p.out_col_stride;
-    const uint32_t tw_shift = MAX_LOG_N - (p.L + p.R);   // w_{L+R}^e = w_24^(e << tw_shift)
+    const uint32_t tw_shift = MAX_LOG_N - (p.L + p.R);   // w_{L+R}^e = w_26^(e << tw_shift)
 
     // ---- load (+ expand, + DIT pre-twiddle) ----
     for (uint32_t e = tid; e < elems; e += NTT_THREADS) {
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassParams p) {
         uint32_t v = in[gi >> p.expand_bits];
         if (!INVERSE && p.twiddle) {
             const uint32_t r = __brev(m) >> (32 - p.R);
-            const uint32_t ex = ((l0 + t) * r) << tw_shift;          // < 2^24
+            const uint32_t ex = ((l0 + t) * r) << tw_shift;          // < 2^26
             const uint32_t w = mul_mod(p.tw_lo[ex & (TW_SIZE - 1)], p.tw_hi[ex >> TW_BITS]);
             v = mul_mod(v, w);
         }
@@ -569,7 +569,7 @@ std::vector<Pass> plan_passes(uint32_t log_n) {
         return v;
     }
     // >= 2^18: the contiguous 4096-word register-radix pass, then strided passes.  2^8 and 2^10 rows have
-    // register-radix kernels; what is left over (1..3 bits at 2^21, 2^23, 2^24) goes to a last light pass of the
+    // register-radix kernels; what is left over (1..4 bits at 2^21, 2^23 .. 2^26: po2 19, 21 .. 24) goes to a last light pass of the
     // generic kernel over wide tiles instead of a 9..12-layer LDS sweep (2^21: 0.94 ms vs 1.40 for 64 columns).
     const uint32_t rem = log_n - 12;
     v.push_back({0, 12});
