@@ -136,10 +136,12 @@ int main(int argc, char** argv) {
         memset(&segs[i], 0, sizeof segs[i]);
         segs[i].po2 = (uint32_t)((i + 1 == n && n > 1) ? (tail_po2 < po2 ? tail_po2 : po2) : po2);
         segs[i].seed = 0x5EED0000ull + i;
-        segs[i].noise_seed = noise;                       // 0: fresh OS randomness per segment, like upstream
+        segs[i].noise_key[0] = (uint32_t)noise;           // all-zero: a fresh 256-bit OS key per segment, like upstream; --noise-seed N: (N lo, N hi, 0, ..)
+        segs[i].noise_key[1] = (uint32_t)(noise >> 32);
     }
     zkh_prove_info info;
-    err = zkh_session_prove(session, segs.data(), n, recursive ? 2 : !jdesc.empty(), join_po2, noise, &info);
+    const uint32_t join_key[8] = {(uint32_t)noise, (uint32_t)(noise >> 32), 0, 0, 0, 0, 0, 0};
+    err = zkh_session_prove(session, segs.data(), n, recursive ? 2 : !jdesc.empty(), join_po2, noise ? join_key : nullptr, &info);
     if (err) { fprintf(stderr, "zkh_session_prove: %s\n", err); zkh_free_error(err); return 1; }
     err = zkh_session_verify(session, segs.data(), &info, join_po2);
     if (err) { fprintf(stderr, "REJECTED: %s\n", err); zkh_free_error(err); return 1; }

@@ -50,12 +50,13 @@ struct Options {
     size_t join_po2 = 18;
 };
 
-// The zero-knowledge blinding rows must be unpredictable: upstream fills them from an OS RNG.
-uint64_t fresh_noise_seed() {
-    uint64_t v = 0;
-    if (getrandom(&v, sizeof v, 0) != (ssize_t)sizeof v) { perror("getrandom"); abort(); }
-    return v;
-}
+// The zero-knowledge blinding rows must be unpredictable: upstream fills them from an OS RNG.  Here a NULL key tells the library to
+// draw a fresh 256-bit ChaCha12 key from getrandom() for the call (include/zkhal.h, BLINDING ROWS); --noise-seed N fixes the key to
+// (N lo, N hi, 0, ..) for reproducible seals (tests).
+struct NoiseKey {
+    uint32_t k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    explicit NoiseKey(uint64_t seed) { k[0] = (uint32_t)seed; k[1] = (uint32_t)(seed >> 32); }
+};
 
 struct Receipt {
     std::vector<uint32_t> seal;
@@ -134,7 +135,8 @@ void lane(int device, const std::vector<uint32_t>& desc, const Options& opt, std
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= opt.segments) break;
-            const uint64_t noise = opt.fixed_noise ? opt.noise_seed : fresh_noise_seed();
+            const NoiseKey fixed(opt.noise_seed);
+            const uint32_t* noise = opt.fixed_noise ? fixed.k : nullptr;
             if (failed(zkh_syn_witgen(ctx, circuit, opt.po2, ZKH_ZK_CYCLES, 0x5EED0000ull + i, noise, pub.empty() ? nullptr : pub.data(),
                                       code, data, out_global.data()),
                        "zkh_syn_witgen"))
@@ -221,7 +223,8 @@ bool join_tree(const Options& opt, const std::vector<uint32_t>& jdesc, std::vect
                     if (k >= pairs) return;
                     memcpy(pub.data(), claims[2 * k].data(), 32);
                     memcpy(pub.data() + 8, claims[2 * k + 1].data(), 32);
-                    const uint64_t noise = opt.fixed_noise ? opt.noise_seed : fresh_noise_seed();
+                    const NoiseKey fixed(opt.noise_seed);
+                    const uint32_t* noise = opt.fixed_noise ? fixed.k : nullptr;
                     uint32_t* seal = nullptr;
                     size_t words = 0;
                     if (failed(zkh_syn_witgen(lane->ctx, lane->circuit, opt.join_po2, ZKH_ZK_CYCLES, 0, noise, pub.data(), lane->code, lane->data, out.data()),

@@ -7,11 +7,15 @@
 //   segment order (index i at position i),
 //   every seal against the control root THE VERIFIER expects for its size (zkh_verify_segment, host arithmetic only) — never the
 //   root a container carries,
-//   and with --chained the continuity of the session (SYN-C circuits: the first segment starts from --initial-state, every
-//   segment's pre-state is its predecessor's post-state: CompositeReceipt::verify_integrity).
+//   with --chained the continuity of the session (SYN-C / SYN-S circuits: the first segment starts from --initial-state, every
+//   segment's pre-state is its predecessor's post-state: CompositeReceipt::verify_integrity),
+//   and that the session is WHOLE: a SYN-S circuit ("syn_session") binds an exit code and the journal's digest in every seal —
+//   SystemSplit .. SystemSplit, Halted(0) + SHA-256(journal) — so trailing segments cannot be dropped and the journal cannot be
+//   rewritten (zkh_session_check_termination; --journal HEX gives the journal bytes, default: the final state word); a SYN-C circuit
+//   binds none of that, so --chained then REQUIRES --segments N, the number of segments the verifier expects.
 //
 //   verify_receipts (--desc FILE | --circuit NAME) --receipts-dir DIR --control-root PO2:HEX64 [--control-root PO2:HEX64 ...]
-//                   [--chained [--initial-state N]]
+//                   [--chained [--initial-state N]] [--segments N] [--journal HEX]
 // PO2:HEX64 = the segment size and the 8 words of the expected control root as 64 hex digits (word 0 first, as
 // `python -m zeth_amd.prover` / circuits/control_roots.json print them and zkh_syn_control_root returns them).
 // Exit code 0 and {"verified": N} on success; 1 and the reason on the first receipt that does not verify.
@@ -37,8 +41,10 @@ static bool read_words(const std::string& path, std::vector<uint32_t>& out) {
 int main(int argc, char** argv) {
     std::string desc_path, circuit_name, dir;
     std::map<uint32_t, std::vector<uint32_t>> roots;
-    bool chained = false;
+    bool chained = false, have_journal = false;
     uint32_t initial_state = 0;
+    long expect_segments = -1;
+    std::vector<uint8_t> journal;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "--desc" && i + 1 < argc) desc_path = argv[++i];
@@ -46,6 +52,13 @@ int main(int argc, char** argv) {
         else if (a == "--receipts-dir" && i + 1 < argc) dir = argv[++i];
         else if (a == "--chained") chained = true;
         else if (a == "--initial-state" && i + 1 < argc) initial_state = (uint32_t)strtoul(argv[++i], nullptr, 0);
+        else if (a == "--segments" && i + 1 < argc) expect_segments = strtol(argv[++i], nullptr, 0);
+        else if (a == "--journal" && i + 1 < argc) {
+            const std::string hex = argv[++i];
+            if (hex.size() % 2) { fprintf(stderr, "--journal wants an even number of hex digits\n"); return 2; }
+            for (size_t k = 0; k < hex.size(); k += 2) journal.push_back((uint8_t)strtoul(hex.substr(k, 2).c_str(), nullptr, 16));
+            have_journal = true;
+        }
         else if (a == "--control-root" && i + 1 < argc) {
             unsigned po2 = 0;
             char hex[65] = {0};
@@ -63,12 +76,19 @@ int main(int argc, char** argv) {
         desc.assign(w, w + nw);
     } else if (!desc_path.empty()) read_words(desc_path, desc);
     if (desc.empty() || dir.empty() || roots.empty()) {
-        fprintf(stderr, "usage: %s (--desc FILE | --circuit NAME) --receipts-dir DIR --control-root PO2:HEX64 [...] [--chained [--initial-state N]]\n", argv[0]);
+        fprintf(stderr, "usage: %s (--desc FILE | --circuit NAME) --receipts-dir DIR --control-root PO2:HEX64 [...] [--chained [--initial-state N]] [--segments N] [--journal HEX]\n", argv[0]);
         return 2;
     }
     zkh_circuit* circuit = nullptr;                        // ctx == NULL: a host-only circuit, enough for everything a verifier does
     const char* err = zkh_circuit_load(nullptr, desc.data(), desc.size(), &circuit);
     if (err) { fprintf(stderr, "zkh_circuit_load: %s\n", err); zkh_free_error(err); return 1; }
+    const bool session = desc.size() > 13 && desc[13] == 1 && desc[7] == 23;      // SYN-S: exit code + journal digest bound in every seal
+    if (chained && !session && expect_segments < 0) {
+        fprintf(stderr, "REJECTED: --chained on a circuit that binds no exit code (SYN-C) needs --segments N: without it a session with its trailing "
+                        "segments cut off would verify (use the syn_session circuit to bind termination in the seals)\n");
+        return 1;
+    }
+    std::vector<std::vector<uint32_t>> kept;                                     // SYN-S: the verified seals, for the termination check
     size_t verified = 0;
     uint32_t prev_post = 0;
     bool have_prev = false;
@@ -91,7 +111,7 @@ int main(int argc, char** argv) {
         if (chained) {
             // SYN-C: out = (post, 0, 0, 0, pre) as the first words of the seal (Montgomery form); the initial state is a canonical residue
             const uint32_t* seal = blob.data() + off;
-            if (info[8] != 5) return reject(i, "--chained: the circuit's segments carry no state words", nullptr);
+            if (info[8] != 5 && info[8] != 23) return reject(i, "--chained: the circuit's segments carry no state words", nullptr);
             uint32_t want = prev_post;
             if (!have_prev) {
                 const uint64_t R = ((uint64_t)1 << 32) % 2013265921ull;
@@ -101,10 +121,25 @@ int main(int argc, char** argv) {
             prev_post = seal[0];
             have_prev = true;
         }
+        if (session) kept.emplace_back(blob.begin() + off, blob.begin() + off + info[9]);
         verified++;
     }
-    zkh_circuit_destroy(circuit);
     if (!verified) { fprintf(stderr, "no segment_<i>.zkr under %s\n", dir.c_str()); return 1; }
+    if (expect_segments >= 0 && (long)verified != expect_segments) {
+        fprintf(stderr, "REJECTED: %zu segment receipts found, the session has %ld\n", verified, expect_segments);
+        return 1;
+    }
+    if (session) {          // the session must END here: SystemSplit .. SystemSplit, Halted(0), and the journal's digest in the last seal
+        std::vector<const uint32_t*> ptrs;
+        std::vector<size_t> words;
+        for (auto& s : kept) { ptrs.push_back(s.data()); words.push_back(s.size()); }
+        if ((err = zkh_session_check_termination(circuit, ptrs.data(), words.data(), ptrs.size(), have_journal ? journal.data() : nullptr, journal.size()))) {
+            fprintf(stderr, "REJECTED: %s\n", err);
+            zkh_free_error(err);
+            return 1;
+        }
+    }
+    zkh_circuit_destroy(circuit);
     printf("{\"driver\": \"verify_receipts\", \"library\": \"%s\", \"verified\": %zu, \"chained\": %s, \"gpu\": false}\n", zkh_version(), verified, chained ? "true" : "false");
     return 0;
 }

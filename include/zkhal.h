@@ -220,13 +220,23 @@ const char* zkh_eval_check(zkh_ctx*, const zkh_circuit*, zkh_buf* check, const z
  *   kind 3 P2-JOIN   every 31 active rows are one Poseidon2 permutation; block 0 = hash_pair(left, right) (zeth_amd/circuits/
  *                    p2_join.py; stands in for the in-circuit hashing of risc0-circuit-recursion 4.0.2, Cargo.lock:5305).
  *                    `pub` = the two child claims (16 words, required); out_global = parent (8) ‖ left (8) ‖ right (8). */
+/* BLINDING ROWS.  The last zk_cycles rows of every data / accum column are zero-knowledge blinding noise.  Upstream draws each
+ * cell from the OS RNG (`Elem::random(&mut rng)`); here the randomness enters once per call as a 256-bit key — `noise_key`, 8
+ * words — and every cell is ChaCha12(key; counter = (row, column), nonce = (group, "ZKN1")) folded mod P the way upstream's
+ * Elem::random folds six u32 draws (csrc/noise.h; CPU twin oracle/noise.h).  noise_key == NULL or all-zero: 256 fresh bits from
+ * getrandom() for this call — the product default; the call FAILS if the OS cannot deliver.  A fixed key makes seals reproducible
+ * (tests, bench.py, golden fixtures).
+ * The two host functions below expose the generator itself (no GPU): one blinding cell, and the underlying RFC 8439 block function
+ * with `double_rounds` double rounds (10 = ChaCha20: what the RFC's test vector pins; the stream uses 6). */
+uint32_t zkh_noise_cell_host(const uint32_t noise_key[8], uint32_t group, uint32_t column, uint32_t row);
+void zkh_chacha_block_host(const uint32_t key[8], const uint32_t counter_nonce[4], int double_rounds, uint32_t out[16]);
 /* code group only: a function of (circuit, po2, zk_cycles) — what the control root commits to */
 const char* zkh_syn_code(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cycles, zkh_buf* code);
 /* pub: OUTPUT_SIZE - 4 public input words (Montgomery; NULL if the circuit has none); out_global: OUTPUT_SIZE words;
  * code may be NULL for kinds 1 and 2 (the caller already holds this size's code group, e.g. resident in its prover) */
 const char* zkh_syn_witgen(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cycles, uint64_t seed,
-                           uint64_t noise_seed, const uint32_t* pub, zkh_buf* code, zkh_buf* data, uint32_t* out_global);
-const char* zkh_syn_accum(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cycles, uint64_t noise_seed,
+                           const uint32_t noise_key[8], const uint32_t* pub, zkh_buf* code, zkh_buf* data, uint32_t* out_global);
+const char* zkh_syn_accum(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cycles, const uint32_t noise_key[8],
                           const zkh_buf* data, const uint32_t* mix_global, zkh_buf* accum);
 /* Chained sessions (SYN-C: a kind-1 circuit with ONE public input = the segment's pre-state; out = (post, 0, 0, 0, pre)): what each
  * of n segments (seed, po2) adds to the running state — its post-state when started from state 0 — in one launch.  The executor's
@@ -247,7 +257,7 @@ const char* zkh_syn_chain_contributions(zkh_ctx*, const zkh_circuit*, const uint
 size_t zkh_syn_preflight_ram_words(void);
 const char* zkh_syn_preflight(uint64_t seed, size_t po2, size_t zk_cycles, uint32_t* records, uint32_t* ram_image,
                               double* cpu_seconds);
-const char* zkh_syn_witgen_trace(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cycles, uint64_t noise_seed,
+const char* zkh_syn_witgen_trace(zkh_ctx*, const zkh_circuit*, size_t po2, size_t zk_cycles, const uint32_t noise_key[8],
                                  const zkh_buf* records, const uint32_t* ram_image, zkh_buf* code, zkh_buf* data,
                                  uint32_t* out_global);
 
@@ -257,7 +267,7 @@ void zkh_prover_destroy(zkh_prover*);   /* before zkh_ctx_destroy: a prover may 
 /* Seal one segment of a SYN-AIR-family circuit (kind 1: the accum witness generator is zkh_syn_accum) whose code/data
  * traces are already resident in HBM (W x 2^po2 each); out_global has OUTPUT_SIZE words.  On success *seal is a
  * malloc'd word array (release with zkh_free_seal). */
-const char* zkh_prove_segment(zkh_prover*, size_t po2, size_t zk_cycles, uint64_t noise_seed, const zkh_buf* code,
+const char* zkh_prove_segment(zkh_prover*, size_t po2, size_t zk_cycles, const uint32_t noise_key[8], const zkh_buf* code,
                               const zkh_buf* data, const uint32_t* out_global, uint32_t** seal,
                               size_t* seal_words);
 void zkh_free_seal(uint32_t* seal);
@@ -353,11 +363,11 @@ const char* zkh_rec_program_info(const zkh_rec_program*, uint32_t root[8], uint3
  * launched kernel by kernel (the default: measured equal, and profilers cope with it). */
 int zkh_rec_program_has_graph(const zkh_rec_program*);
 const char* zkh_rec_code(const zkh_rec_program*, zkh_buf* code /* 58 x 2^po2 */);
-const char* zkh_rec_witgen(const zkh_rec_program*, const uint32_t* inputs, size_t n_inputs, uint64_t noise_seed,
+const char* zkh_rec_witgen(const zkh_rec_program*, const uint32_t* inputs, size_t n_inputs, const uint32_t noise_key[8],
                            zkh_buf* data /* 72 x 2^po2 */, uint32_t out_global[16]);
-const char* zkh_rec_accum(const zkh_rec_program*, uint64_t noise_seed, const zkh_buf* data, const uint32_t* mix_global /* 20 */,
+const char* zkh_rec_accum(const zkh_rec_program*, const uint32_t noise_key[8], const zkh_buf* data, const uint32_t* mix_global /* 20 */,
                           zkh_buf* accum /* 12 x 2^po2 */);
-const char* zkh_rec_prove(const zkh_rec_program*, const uint32_t* inputs, size_t n_inputs, uint64_t noise_seed,
+const char* zkh_rec_prove(const zkh_rec_program*, const uint32_t* inputs, size_t n_inputs, const uint32_t noise_key[8],
                           uint32_t out_global[16] /* may be NULL */, uint32_t** seal, size_t* seal_words);
 
 /* ---- session executor: ProverServer::prove_session / ProverImpl::{prove_segment, join} (risc0-zkvm 3.0.3, un-vendored:
@@ -370,7 +380,7 @@ typedef struct zkh_session zkh_session;
 typedef struct {
     uint32_t po2;                 /* segment size 2^po2 cycles */
     uint64_t seed;                /* built-in witness generators (circuit kind 1..3): witness seed */
-    uint64_t noise_seed;          /* blinding rows; 0 = fresh OS randomness per segment (the product default, like upstream) */
+    uint32_t noise_key[8];        /* blinding rows: 256-bit ChaCha12 key; all-zero = fresh OS randomness per segment (the product default, like upstream) */
     const uint32_t* pub;          /* public inputs of the built-in generators (see zkh_syn_witgen), may be NULL */
     size_t n_pub;
     /* caller-produced traces instead (CPU preflight + witgen, upstream's flow): W_code x 2^po2, W_data x 2^po2 words and
@@ -437,24 +447,37 @@ void zkh_session_set_streamed_fold(zkh_session*, int on);
 /* Chained session (SYN-C circuits): zkh_session_prove runs the executor's pass first (zkh_syn_chain_contributions), gives segment i
  * the pre-state initial + sum of the contributions of segments 0 .. i-1 as its public input (any `pub` of the caller is replaced),
  * and zkh_session_verify additionally checks CONTINUITY on the seals: the first segment starts from initial_state (canonical
- * residue), every segment's pre-state (out[4]) is its predecessor's post-state (out[0]) — `CompositeReceipt::verify_integrity`. */
+ * residue), every segment's pre-state (out[4]) is its predecessor's post-state (out[0]) — `CompositeReceipt::verify_integrity`.
+ * SYN-S circuits additionally get their exit-code pair and journal-digest limbs here and have them checked (see below). */
 const char* zkh_session_set_chained(zkh_session*, int on, uint32_t initial_state);
 /* Where a segment's witness comes from (SYN-AIR circuits without public inputs).  0 (default): the closed-form generator on the
  * device (zkh_syn_witgen).  1: upstream's shape — a SEQUENTIAL host preflight per segment (zkh_syn_preflight) running ahead of the
  * seals on `producers_per_lane` host threads per sealing lane (0 = 2), its compact records (16 bytes per cycle) uploaded from pinned
  * memory and expanded on the GPU (zkh_syn_witgen_trace).  zkh_prove_info reports the host CPU seconds and the PCIe bytes. */
 const char* zkh_session_set_witness_source(zkh_session*, int source, size_t producers_per_lane);
-/* join_tree == 1: fold the receipts through the P2-JOIN tree (joins at 2^join_po2; join_noise_seed 0 = OS randomness);
+/* join_tree == 1: fold the receipts through the P2-JOIN tree (joins at 2^join_po2; join_noise_key NULL = a fresh OS key per proof);
  * join_tree == 2: lift every receipt and join level by level with the RECURSION programs - every node verifies its child
  * seal(s) in-circuit; the root receipt is a RECURSION seal with out = claim tree root ‖ allowed-programs root.  The tree: the
  * first level pairs the segments, every level above takes three nodes at a time (a remainder of two is a join, of one moves up);
  * a group of three is ONE proof where the session has a join3 program for its sizes, else join(join(a, b), c) - the same node. */
 const char* zkh_session_prove(zkh_session*, const zkh_segment* segs, size_t n, int join_tree, size_t join_po2,
-                              uint64_t join_noise_seed, zkh_prove_info* info);
+                              const uint32_t join_noise_key[8], zkh_prove_info* info);
 void zkh_prove_info_free(zkh_prove_info*);
 /* every leaf seal against the control root of its size; with a root receipt also the root seal and the claim tree
  * (hash_pair over the leaf claims, recomputed on the host) against the root's public output */
 const char* zkh_session_verify(zkh_session*, const zkh_segment* segs, const zkh_prove_info* info, size_t join_po2);
+
+/* Sessions that TERMINATE (SYN-S circuits: zeth_amd/circuits/syn_air.py syn_session; shipped as "syn_session").  Upstream's ReceiptClaim
+ * carries an exit code and an output (journal) digest per segment, and `receipt.verify(image_id)` + the journal comparison
+ * (/root/reference/crates/host/src/bin/cli.rs:103-107) rely on them: every segment but the last ends in SystemSplit, the last in
+ * Halted(0) with the digest of the journal (risc0-zkvm 3.0.3 receipt/composite.rs verify_integrity, recalled).  A SYN-S segment
+ * publishes out = (post, 0, 0, 0, pre, exit_sys, exit_user, j_0 .. j_15) — j = SHA-256(journal) as sixteen 16-bit limbs — every word
+ * a bound public input; zkh_session_set_chained fills them (the journal of a session = its final state word, 4 bytes LE) and
+ * zkh_session_verify checks them.  zkh_session_check_termination is that check for a verifier that holds VERIFIED seals: a receipt
+ * whose trailing segments were cut off ends in a SystemSplit and is refused; journal == NULL: the final state word.  Host only. */
+void zkh_sha256(const uint8_t* data, size_t len, uint8_t out[32]);
+const char* zkh_session_check_termination(const zkh_circuit*, const uint32_t* const* seals, const size_t* seal_words, size_t n,
+                                          const uint8_t* journal, size_t journal_len);
 
 /* `receipt.verify` for a SUCCINCT receipt on the host alone — no GPU, no session (upstream: SuccinctReceipt::verify_integrity, reached
  * from /root/reference/crates/host/src/bin/cli.rs:103): ONE seal of the RECURSION circuit (description compiled in) under the control

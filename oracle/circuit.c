@@ -14,6 +14,7 @@
 #include <string.h>
 #include "field.h"
 #include "circuit.h"
+#include "noise.h"
 
 static inline fp4 ld4(const uint32_t* p) { fp4 r; memcpy(&r, p, 16); return r; }
 static inline void st4(uint32_t* p, fp4 v) { memcpy(p, &v, 16); }
@@ -143,6 +144,10 @@ void zko_eval_check(const zko_circuit* c, uint32_t* check, const uint32_t* const
     }
 }
 
+/* ---- blinding rows (noise.h) ---- */
+uint32_t zko_noise_cell(const uint32_t* noise_key, uint32_t group, uint32_t col, uint32_t row) { return zko_noise_cell_inline(noise_key, group, col, row); }
+void zko_chacha_block(const uint32_t* key, const uint32_t* tail, int double_rounds, uint32_t* out) { zko_chacha_block_inline(key, tail, double_rounds, out); }
+
 /* ---- SYN-AIR witness ---- */
 uint32_t zko_syn_cell(uint64_t seed, uint32_t group, uint32_t col, uint32_t row) {
     uint64_t z = seed ^ ((uint64_t)(group + 1) * 0x9E3779B97F4A7C15ull);
@@ -177,10 +182,10 @@ void zko_syn_code(const zko_circuit* c, unsigned po2, unsigned zk, uint32_t* cod
         }
 }
 
-void zko_syn_witgen(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t seed, uint64_t noise_seed,
+void zko_syn_witgen(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t seed, const uint32_t* noise_key,
                     const uint32_t* pub, uint32_t* code, uint32_t* data, uint32_t* out_global) {
-    if (c->kind == 2) { zko_keccak_witgen(c, po2, zk, seed, noise_seed, pub, code, data, out_global); return; }
-    if (c->kind == 3) { zko_p2join_witgen(c, po2, zk, noise_seed, pub, code, data, out_global); return; }
+    if (c->kind == 2) { zko_keccak_witgen(c, po2, zk, seed, noise_key, pub, code, data, out_global); return; }
+    if (c->kind == 3) { zko_p2join_witgen(c, po2, zk, noise_key, pub, code, data, out_global); return; }
     size_t n = (size_t)1 << po2, A = n - zk;
     size_t wd = c->group_size[ZKC_GROUP_DATA];
     size_t n_pub = c->global_size[ZKC_GLOBAL_OUT] - 4;
@@ -188,7 +193,7 @@ void zko_syn_witgen(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t se
     size_t T = (wd - 2) / 3;
     for (size_t col = 0; col < wd; col++)
         for (size_t r = 0; r < n; r++)
-            data[col * n + r] = zko_syn_cell(r < A ? seed : noise_seed, ZKC_GROUP_DATA, (uint32_t)col, (uint32_t)r);
+            data[col * n + r] = (r < A ? zko_syn_cell(seed, ZKC_GROUP_DATA, (uint32_t)col, (uint32_t)r) : zko_noise_cell(noise_key, ZKC_GROUP_DATA, (uint32_t)col, (uint32_t)r));
     /* public inputs: word k sits in row 0 of data column 3k (the x cell of triple k) and is bound to out[4 + k] */
     for (size_t k = 0; k < n_pub; k++) data[(3 * k) * n] = pub[k];
     fp s = 0;
@@ -204,7 +209,7 @@ void zko_syn_witgen(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t se
     for (size_t k = 0; k < n_pub; k++) out_global[4 + k] = pub[k];
 }
 
-void zko_syn_accum(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t noise_seed, const uint32_t* data,
+void zko_syn_accum(const zko_circuit* c, unsigned po2, unsigned zk, const uint32_t* noise_key, const uint32_t* data,
                    const uint32_t* mix_global, uint32_t* accum) {
     size_t n = (size_t)1 << po2, A = n - zk;
     size_t wa = c->group_size[ZKC_GROUP_ACCUM], wd = c->group_size[ZKC_GROUP_DATA];
@@ -219,5 +224,5 @@ void zko_syn_accum(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t noi
     }
     for (size_t col = 0; col < wa; col++)
         for (size_t r = A; r < n; r++)
-            accum[col * n + r] = zko_syn_cell(noise_seed, ZKC_GROUP_ACCUM, (uint32_t)col, (uint32_t)r);
+            accum[col * n + r] = zko_noise_cell(noise_key, ZKC_GROUP_ACCUM, (uint32_t)col, (uint32_t)r);
 }

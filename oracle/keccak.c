@@ -97,7 +97,7 @@ void zko_keccak_code(const zko_circuit* c, unsigned po2, unsigned zk, uint32_t* 
 /* last_input: 50 words (25 lanes, low word first) = the input state of the LAST permutation, or NULL (seeded like the
  * others).  out_global: 200 words — the output state of the last permutation as 16-bit limbs (lane l, limb j at 4 l + j), then its
  * input state at 100 + 4 l + j (the claim binds the PAIR: an output alone always has a preimage). */
-void zko_keccak_witgen(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t seed, uint64_t noise_seed,
+void zko_keccak_witgen(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t seed, const uint32_t* noise_key,
                        const uint32_t* last_input, uint32_t* code, uint32_t* data, uint32_t* out_global) {
     size_t n = (size_t)1 << po2, A = n - zk, K = A / KF_BLOCK;
     size_t wd = c->group_size[ZKC_GROUP_DATA];
@@ -127,5 +127,5 @@ void zko_keccak_witgen(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t
     free(rows);
     for (size_t col = 0; col < wd; col++)
         for (size_t r = A; r < n; r++)
-            data[col * n + r] = zko_syn_cell(noise_seed, ZKC_GROUP_DATA, (uint32_t)col, (uint32_t)r);
+            data[col * n + r] = zko_noise_cell(noise_key, ZKC_GROUP_DATA, (uint32_t)col, (uint32_t)r);
 }

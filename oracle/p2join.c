@@ -88,7 +88,7 @@ void zko_p2join_code(const zko_circuit* c, unsigned po2, unsigned zk, uint32_t* 
 }
 
 /* children: 16 words = left claim ‖ right claim (Montgomery words).  out_global: parent (8) ‖ left (8) ‖ right (8). */
-void zko_p2join_witgen(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t noise_seed, const uint32_t* children,
+void zko_p2join_witgen(const zko_circuit* c, unsigned po2, unsigned zk, const uint32_t* noise_key, const uint32_t* children,
                        uint32_t* code, uint32_t* data, uint32_t* out_global) {
     size_t n = (size_t)1 << po2, A = n - zk, K = A / PJ_BLOCK;
     size_t wd = c->group_size[ZKC_GROUP_DATA];
@@ -113,5 +113,5 @@ void zko_p2join_witgen(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t
     memcpy(out_global + 8, children, 64);
     for (size_t col = 0; col < wd; col++)
         for (size_t r = A; r < n; r++)
-            data[col * n + r] = zko_syn_cell(noise_seed, ZKC_GROUP_DATA, (uint32_t)col, (uint32_t)r);
+            data[col * n + r] = zko_noise_cell(noise_key, ZKC_GROUP_DATA, (uint32_t)col, (uint32_t)r);
 }

@@ -80,14 +80,14 @@ static uint64_t pf_rowseed(const uint32_t* rec) {
  * the execution — every other free cell is hashed from the record; products, the degree-4 product and s as in zko_syn_witgen;
  * rows >= A are blinding noise; then the preload: the first unconstrained column (3 T, where the shape has one) gets the RAM
  * image in rows [0, min(1024, A)) — a scatter upstream's witgen does with Hal::scatter. */
-void zko_syn_witgen_trace(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t noise_seed, const uint32_t* records,
+void zko_syn_witgen_trace(const zko_circuit* c, unsigned po2, unsigned zk, const uint32_t* noise_key, const uint32_t* records,
                           const uint32_t* ram_image, uint32_t* code, uint32_t* data, uint32_t* out_global) {
     const size_t n = (size_t)1 << po2, A = n - zk, wd = c->group_size[ZKC_GROUP_DATA], T = (wd - 2) / 3;
     if (code) zko_syn_code(c, po2, zk, code);
     fp s = 0;
     for (size_t r = 0; r < n; r++) {
         if (r >= A) {
-            for (size_t col = 0; col < wd; col++) data[col * n + r] = zko_syn_cell(noise_seed, ZKC_GROUP_DATA, (uint32_t)col, (uint32_t)r);
+            for (size_t col = 0; col < wd; col++) data[col * n + r] = zko_noise_cell(noise_key, ZKC_GROUP_DATA, (uint32_t)col, (uint32_t)r);
             continue;
         }
         const uint32_t* rec = records + 4 * r;

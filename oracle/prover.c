@@ -129,7 +129,7 @@ void zko_root_of_code(const zko_circuit* c, unsigned po2, const uint32_t* code, 
     polygroup_free(&pg); free(io.w);
 }
 
-uint32_t* zko_prove_segment(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t seed, uint64_t noise_seed,
+uint32_t* zko_prove_segment(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t seed, const uint32_t* noise_key,
                             const uint32_t* pub, size_t* seal_words, const char** err) {
     *err = NULL;
     size_t n = (size_t)1 << po2;
@@ -141,14 +141,14 @@ uint32_t* zko_prove_segment(const zko_circuit* c, unsigned po2, unsigned zk, uin
     uint32_t* data = (uint32_t*)malloc(4 * wd * n);
     size_t out_size = c->global_size[ZKC_GLOBAL_OUT];
     uint32_t* out_global = (uint32_t*)malloc(4 * (out_size + 1));
-    zko_syn_witgen(c, po2, zk, seed, noise_seed, pub, code, data, out_global);
-    uint32_t* seal = zko_prove_traces(c, po2, zk, noise_seed, code, data, out_global, seal_words, err);
+    zko_syn_witgen(c, po2, zk, seed, noise_key, pub, code, data, out_global);
+    uint32_t* seal = zko_prove_traces(c, po2, zk, noise_key, code, data, out_global, seal_words, err);
     free(code); free(data); free(out_global);
     return seal;
 }
 
 /* the seal of given code / data traces and out globals (the accum group is generated here, after the mix challenge) */
-uint32_t* zko_prove_traces(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t noise_seed, const uint32_t* code,
+uint32_t* zko_prove_traces(const zko_circuit* c, unsigned po2, unsigned zk, const uint32_t* noise_key, const uint32_t* code,
                            const uint32_t* data, const uint32_t* out_words, size_t* seal_words, const char** err) {
     *err = NULL;
     size_t n = (size_t)1 << po2, dom = n * ZKO_INV_RATE;
@@ -177,8 +177,8 @@ uint32_t* zko_prove_traces(const zko_circuit* c, unsigned po2, unsigned zk, uint
     uint32_t* mix_global = (uint32_t*)malloc(4 * (wa + c->global_size[ZKC_GLOBAL_MIX] + 1));
     for (size_t i = 0; i < c->global_size[ZKC_GLOBAL_MIX]; i++) mix_global[i] = zko_rng_random_elem(&io.rng);
     uint32_t* accum = (uint32_t*)malloc(4 * wa * n);
-    if (c->kind == 4) zko_rec_accum(c, po2, zk, noise_seed, code, data, mix_global, accum);
-    else zko_syn_accum(c, po2, zk, noise_seed, data, mix_global, accum);
+    if (c->kind == 4) zko_rec_accum(c, po2, zk, noise_key, code, data, mix_global, accum);
+    else zko_syn_accum(c, po2, zk, noise_key, data, mix_global, accum);
     stage("global.mix", mix_global, c->global_size[ZKC_GLOBAL_MIX]);
     stage("trace.accum", accum, wa * n);
     commit_group(&groups[ZKC_GROUP_ACCUM], &io, accum, wa, n);

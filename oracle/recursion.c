@@ -154,7 +154,7 @@ static char rec_err[256];
 /* Executes the witness schedule on `inputs` (raw Montgomery words, e.g. child seals) and fills code (58 x n), data (72 x n)
  * and out_global (16 words = the wires of the PUB row).  NULL on success; a message when the witness does not exist (an
  * assertion of the program fails: the child seal is not valid). */
-const char* zko_rec_witgen(const uint32_t* blob, size_t words, const uint32_t* inputs, size_t n_inputs, uint64_t noise_seed,
+const char* zko_rec_witgen(const uint32_t* blob, size_t words, const uint32_t* inputs, size_t n_inputs, const uint32_t* noise_key,
                            uint32_t* code, uint32_t* data, uint32_t* out_global) {
     rec_prog p;
     const char* e = rec_parse(blob, words, &p);
@@ -256,7 +256,7 @@ const char* zko_rec_witgen(const uint32_t* blob, size_t words, const uint32_t* i
             free(rows);
         }
         for (size_t col = 0; col < RC_WD; col++)
-            for (size_t r = A; r < n; r++) data[col * n + r] = zko_syn_cell(noise_seed, ZKC_GROUP_DATA, (uint32_t)col, (uint32_t)r);
+            for (size_t r = A; r < n; r++) data[col * n + r] = zko_noise_cell(noise_key, ZKC_GROUP_DATA, (uint32_t)col, (uint32_t)r);
         memset(out_global, 0, 64);
         for (size_t r = 0; r < A; r++)
             if (p.table[r * RC_ROW_WORDS + 6] & RG_PUB) { for (int i = 0; i < 16; i++) out_global[i] = data[(size_t)i * n + r]; break; }
@@ -266,7 +266,7 @@ const char* zko_rec_witgen(const uint32_t* blob, size_t words, const uint32_t* i
 }
 
 /* the copy argument: Z_k(r) = Z_k(r - 1) * prod_{w in {2k, 2k+1}} F(id) / F(sigma); mix = beta_1..4, gamma (20 words) */
-void zko_rec_accum(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t noise_seed, const uint32_t* code, const uint32_t* data,
+void zko_rec_accum(const zko_circuit* c, unsigned po2, unsigned zk, const uint32_t* noise_key, const uint32_t* code, const uint32_t* data,
                    const uint32_t* mix, uint32_t* accum) {
     (void)c;
     size_t n = (size_t)1 << po2, A = n - zk;
@@ -296,7 +296,7 @@ void zko_rec_accum(const zko_circuit* c, unsigned po2, unsigned zk, uint64_t noi
     }
     free(ratio);
     for (size_t col = 0; col < RC_WA; col++)
-        for (size_t r = A; r < n; r++) accum[col * n + r] = zko_syn_cell(noise_seed, ZKC_GROUP_ACCUM, (uint32_t)col, (uint32_t)r);
+        for (size_t r = A; r < n; r++) accum[col * n + r] = zko_noise_cell(noise_key, ZKC_GROUP_ACCUM, (uint32_t)col, (uint32_t)r);
 }
 
 /* Row-by-row check of a trace against the circuit's own step list: every constraint must vanish on every row of the trace

@@ -106,15 +106,20 @@ void zko_eval_check(const zko_circuit*, uint32_t* check, const uint32_t* const* 
 
 /* ---- SYN-AIR witness (definition in DESIGN.md §SYN-AIR; mirrored by the HIP witgen kernels) ---- */
 uint32_t zko_syn_cell(uint64_t seed, uint32_t group, uint32_t col, uint32_t row);
+/* blinding rows (noise.h): cell = fold mod P of six words of ChaCha12(key; counter = (row, col), nonce = (group, "ZKN1")); every
+ * noise_key below is 8 words and REQUIRED (the oracle is deterministic: it never draws from the OS) */
+uint32_t zko_noise_cell(const uint32_t* noise_key, uint32_t group, uint32_t col, uint32_t row);
+/* RFC 8439 section 2.3 block function with `double_rounds` double rounds (10 = ChaCha20); tail = state words 12..15 */
+void zko_chacha_block(const uint32_t* key, const uint32_t* tail, int double_rounds, uint32_t* out);
 #define ZKO_SYN_CODE_SEED 0xC0DEC0DE5EEDull
 /* code group (wc x n): a function of (circuit, po2, zk_cycles) only — its Merkle root is the control root */
 void zko_syn_code(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint32_t* code);
 /* fills code (wc x n) and data (wd x n), out global (OUTPUT_SIZE = 4 + n_pub words: s,0,0,0, pub...);
  * pub = n_pub public input words (Montgomery), may be NULL when n_pub == 0 */
-void zko_syn_witgen(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t seed, uint64_t noise_seed,
+void zko_syn_witgen(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t seed, const uint32_t* noise_key,
                     const uint32_t* pub, uint32_t* code, uint32_t* data, uint32_t* out_global);
 /* fills accum (wa x n) given data and the mix global (wa words) */
-void zko_syn_accum(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t noise_seed,
+void zko_syn_accum(const zko_circuit*, unsigned po2, unsigned zk_cycles, const uint32_t* noise_key,
                    const uint32_t* data, const uint32_t* mix_global, uint32_t* accum);
 
 /* ---- KECCAK-F witness (zeth_amd/circuits/keccak_f.py; circuit kind 2): every 25 active rows = one keccak-f[1600] ----
@@ -122,28 +127,28 @@ void zko_syn_accum(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_
  * (50 words = 25 lanes, low word first; NULL = seeded like the others) and out_global its output state (100 16-bit limbs). */
 uint64_t zko_keccak_lane(uint64_t seed, uint64_t perm, uint32_t lane);
 void zko_keccak_code(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint32_t* code);
-void zko_keccak_witgen(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t seed, uint64_t noise_seed,
+void zko_keccak_witgen(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t seed, const uint32_t* noise_key,
                        const uint32_t* last_input, uint32_t* code, uint32_t* data, uint32_t* out_global);
 
 /* ---- P2-JOIN witness (zeth_amd/circuits/p2_join.py; circuit kind 3): every 31 active rows = one Poseidon2 permutation,
  * block 0 = hash_pair(left, right).  zko_syn_code / zko_syn_witgen dispatch here for kind 3; `pub` = the two child claims
  * (16 Montgomery words, required), out_global = parent (8) ‖ left (8) ‖ right (8); the seed is unused. */
 void zko_p2join_code(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint32_t* code);
-void zko_p2join_witgen(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t noise_seed, const uint32_t* children,
+void zko_p2join_witgen(const zko_circuit*, unsigned po2, unsigned zk_cycles, const uint32_t* noise_key, const uint32_t* children,
                        uint32_t* code, uint32_t* data, uint32_t* out_global);
 
 /* ---- whole seal: restates SegmentProver::prove + risc0_zkp::prove::Prover ---- */
 /* returns malloc'd seal words (caller frees with zko_free); NULL + *err on failure */
 uint32_t* zko_prove_segment(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t seed,
-                            uint64_t noise_seed, const uint32_t* pub, size_t* seal_words, const char** err);
+                            const uint32_t* noise_key, const uint32_t* pub, size_t* seal_words, const char** err);
 /* the same from given code (wc x n) and data (wd x n) traces and the out globals (OUTPUT_SIZE words) */
 /* ---- trace-driven witness (preflight.c): the sequential per-cycle machine and the row fill ----
  * records: 4 words per ACTIVE row (2^po2 - zk_cycles rows); ram_image: zko_syn_preflight_ram_words() words (may be NULL) */
 size_t zko_syn_preflight_ram_words(void);
 void zko_syn_preflight(uint64_t seed, unsigned po2, unsigned zk_cycles, uint32_t* records, uint32_t* ram_image);
-void zko_syn_witgen_trace(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t noise_seed, const uint32_t* records,
+void zko_syn_witgen_trace(const zko_circuit*, unsigned po2, unsigned zk_cycles, const uint32_t* noise_key, const uint32_t* records,
                           const uint32_t* ram_image, uint32_t* code, uint32_t* data, uint32_t* out_global);
-uint32_t* zko_prove_traces(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t noise_seed, const uint32_t* code,
+uint32_t* zko_prove_traces(const zko_circuit*, unsigned po2, unsigned zk_cycles, const uint32_t* noise_key, const uint32_t* code,
                            const uint32_t* data, const uint32_t* out_words, size_t* seal_words, const char** err);
 void zko_root_of_code(const zko_circuit*, unsigned po2, const uint32_t* code, uint32_t root[8]);
 
@@ -152,10 +157,10 @@ void zko_root_of_code(const zko_circuit*, unsigned po2, const uint32_t* code, ui
 const char* zko_rec_code(const uint32_t* prog, size_t prog_words, uint32_t* code);
 /* runs the program's witness schedule on `inputs` (raw Montgomery words: child seals ...), fills code (55 x n), data (72 x n)
  * and out_global (16 words); a message if an assertion of the program fails (the inputs are not what the program verifies) */
-const char* zko_rec_witgen(const uint32_t* prog, size_t prog_words, const uint32_t* inputs, size_t n_inputs, uint64_t noise_seed,
+const char* zko_rec_witgen(const uint32_t* prog, size_t prog_words, const uint32_t* inputs, size_t n_inputs, const uint32_t* noise_key,
                            uint32_t* code, uint32_t* data, uint32_t* out_global);
 /* the copy argument's running products (12 x n) from code, data and the 20 mix words */
-void zko_rec_accum(const zko_circuit*, unsigned po2, unsigned zk_cycles, uint64_t noise_seed, const uint32_t* code,
+void zko_rec_accum(const zko_circuit*, unsigned po2, unsigned zk_cycles, const uint32_t* noise_key, const uint32_t* code,
                    const uint32_t* data, const uint32_t* mix_global, uint32_t* accum);
 /* every constraint of the circuit's step list on rows [row_lo, row_hi) of a trace (groups[g]: W_g x n): first failing row or -1 */
 long zko_check_rows(const zko_circuit*, unsigned po2, const uint32_t* const* groups, const uint32_t* const* globals, size_t row_lo,

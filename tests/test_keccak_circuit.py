@@ -108,7 +108,7 @@ def test_an_output_alone_no_longer_has_a_witness(oracle):
     n = 1 << PO2
     mix = np.array([5, 6, 7, 8], dtype=np.uint32)
     accum = np.zeros(4 * n, dtype=np.uint32)
-    oracle.zko_syn_accum(oc.h, PO2, ZK, 2, data, mix, accum)
+    oracle.zko_syn_accum(oc.h, PO2, ZK, zko.key_words(2), data, mix, accum)
     claimed = out.copy()
     claimed[100:200] = [int(oracle.zko_fp_encode(v)) for v in K.out_words(other_in)]      # same output, a different claimed input
     assert oc.check_rows(PO2, accum, code, data, out, mix) == -1                          # the honest (input, output) pair: every row holds

@@ -80,7 +80,7 @@ def test_merkle_tree_of_2_25_rows(hal, oracle):
     hal.merkle_build(nodes, hal.copy_from("m", m), rows)
     want = np.zeros(2 * rows * 8, dtype=np.uint32)
     leaves = want[rows * 8:]
-    oracle.zko_hash_rows(leaves, rows, m, cols)
+    oracle.zko_hash_rows(leaves, rows, m, rows * cols)
     layer = rows
     while layer >= 2:
         oracle.zko_hash_fold(want, layer, layer // 2)

@@ -30,7 +30,7 @@ def _witness_parity(hal, oracle, desc, po2, zk):
     accum = hal.alloc_elem("accum", wa * n)
     hal.syn_accum(circ, po2, zk, 99, data, mix, accum)
     oacc = np.zeros(wa * n, np.uint32)
-    oracle.zko_syn_accum(oc.h, po2, zk, 99, odata, mix, oacc)
+    oracle.zko_syn_accum(oc.h, po2, zk, zko.key_words(99), odata, mix, oacc)
     assert np.array_equal(accum.to_vec(), oacc)
     return circ, oc, (code, data, accum), (ocode, odata, oacc), (out, mix)
 

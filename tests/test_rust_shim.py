@@ -14,7 +14,7 @@ HEADER = os.path.join(ROOT, "include", "zkhal.h")
 LIB_RS = os.path.join(ROOT, "rust", "risc0-sys-hip", "src", "lib.rs")
 HAL_RS = os.path.join(ROOT, "rust", "hal_hip.rs")
 
-C_BASE = {"size_t": "usize", "int": "c_int", "uint32_t": "u32", "uint64_t": "u64", "double": "f64", "char": "c_char", "void": "c_void"}
+C_BASE = {"size_t": "usize", "int": "c_int", "uint32_t": "u32", "uint64_t": "u64", "double": "f64", "char": "c_char", "void": "c_void", "uint8_t": "u8"}
 
 
 def _camel(c_name: str) -> str:

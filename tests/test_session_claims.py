@@ -1,0 +1,165 @@
+"""A session that TERMINATES (SYN-S, circuits/syn_air.py syn_session): every segment's seal binds its exit code and the digest of
+its output, as upstream's `ReceiptClaim` does, so that `receipt.verify(image_id)` + the journal comparison
+(/root/reference/crates/host/src/bin/cli.rs:103-107) cannot be satisfied by a session with its trailing segments cut off or its
+journal rewritten (round-4 advisor finding).  Seals by the CPU oracle; everything checked is host code: zeth_amd.host, the C ABI's
+zkh_session_check_termination / zkh_sha256, the bincode container, examples/verify_receipts."""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+from dataclasses import replace
+
+import numpy as np
+import pytest
+
+import zko
+from zeth_amd import build, hal
+from zeth_amd.circuits import syn_air
+from zeth_amd.hal import HalError, fp_decode, fp_encode
+from zeth_amd.host import (EXIT_HALTED, EXIT_SYSTEM_SPLIT, CompositeReceipt, Receipt, ReceiptClaim, chain_session, exit_code_from_pair,
+                           exit_code_pair, image_id, journal_limbs, prove_chained_block, segment_claim, sha256_words, tagged_struct,
+                           verify_session_integrity)
+from zeth_amd.prover import Segment, SegmentReceipt
+
+PO2, ZK, INIT = 10, 300, 11
+
+
+@pytest.fixture(scope="module")
+def session(oracle):
+    desc = syn_air.syn_session_small()
+    oc = zko.OracleCircuit(oracle, desc)
+    root = oc.control_root(PO2, ZK)
+
+    def contribution(seg):
+        return int(oc.witgen(seg.po2, ZK, seg.seed, seg.noise_seed, pub=np.zeros(syn_air.SESSION_PUB_WORDS, np.uint32))[2][0])
+
+    def prove(seg):
+        seal = oc.prove(seg.po2, ZK, seg.seed, seg.noise_seed, pub=np.asarray(seg.pub, dtype=np.uint32))
+        assert oc.verify(seal, root, zk_cycles=ZK) is None
+        return SegmentReceipt(seal=seal, index=seg.index, po2=seg.po2, output=seal[:syn_air.SESSION_OUT_WORDS].copy())
+    base = [Segment(index=i, po2=PO2, seed=900 + i, noise_seed=0x77, zk_cycles=ZK) for i in range(3)]
+    receipt, iid = prove_chained_block(prove, contribution, desc, base, initial_state=INIT)
+    return desc, oc, root, base, contribution, prove, receipt, iid
+
+
+def test_exit_codes_and_tagged_structs_as_recalled():
+    assert [exit_code_pair(c) for c in ((EXIT_HALTED, 0), (EXIT_HALTED, 3), ("Paused", 1), (EXIT_SYSTEM_SPLIT, None), ("SessionLimit", None))] == [(0, 0), (0, 3), (1, 1), (2, 0), (2, 2)]
+    for c in ((EXIT_HALTED, 5), ("Paused", 0), (EXIT_SYSTEM_SPLIT, None), ("SessionLimit", None)):
+        assert exit_code_from_pair(*exit_code_pair(c)) == c
+    # tagged_struct(tag, down, data) = SHA-256(SHA-256(tag) ‖ down ‖ data u32 LE ‖ len(down) u16 LE), as a Digest of LE words
+    down, data = [list(range(8)), list(range(8, 16))], [7, 9]
+    body = hashlib.sha256(b"risc0.Test").digest() + np.array(down, dtype="<u4").tobytes() + np.array(data, dtype="<u4").tobytes() + (2).to_bytes(2, "little")
+    assert tagged_struct("risc0.Test", down, data) == [int(x) for x in np.frombuffer(hashlib.sha256(body).digest(), dtype="<u4")]
+    a, b = ReceiptClaim(1, 2, (EXIT_HALTED, 0), sha256_words(b"j")), ReceiptClaim(1, 2, (EXIT_SYSTEM_SPLIT, None), None)
+    assert a.digest() != b.digest() and a.digest() != replace(a, post=3).digest() and a.digest() != replace(a, journal_digest=sha256_words(b"k")).digest()
+    assert ReceiptClaim.from_codec_value(a.to_codec_value()) == a and ReceiptClaim.from_codec_value(b.to_codec_value()) == b
+
+
+def test_a_session_binds_its_exit_codes_and_its_journal(session):
+    desc, oc, root, base, contribution, prove, receipt, iid = session
+    receipt.verify(iid, desc, initial_state=INIT, control_root={PO2: root})
+    claims = [segment_claim(r) for r in receipt.inner.segments]
+    assert [c.exit_code for c in claims] == [(EXIT_SYSTEM_SPLIT, None), (EXIT_SYSTEM_SPLIT, None), (EXIT_HALTED, 0)]
+    assert claims[0].pre == INIT and all(a.post == b.pre for a, b in zip(claims, claims[1:])) and claims[-1].journal_digest == sha256_words(receipt.journal)
+    assert receipt.journal == int(claims[-1].post).to_bytes(4, "little") and receipt.claim().digest() == ReceiptClaim(INIT, claims[-1].post, (EXIT_HALTED, 0), sha256_words(receipt.journal)).digest()
+    # the round-4 finding: drop the trailing segment and rewrite the journal to the new final state — every remaining seal is valid,
+    # the chain is continuous, and the receipt is REFUSED because its last segment says SystemSplit
+    cut = Receipt(CompositeReceipt(receipt.inner.segments[:2]), int(claims[1].post).to_bytes(4, "little"))
+    with pytest.raises(HalError, match="not Halted"):
+        cut.verify(iid, desc, initial_state=INIT, control_root={PO2: root})
+    with pytest.raises(HalError, match="journal does not hash"):
+        Receipt(receipt.inner, b"\x01\x02\x03\x04").verify(iid, desc, initial_state=INIT, control_root={PO2: root})
+    with pytest.raises(HalError, match="image id"):
+        receipt.verify(image_id(desc, INIT + 1), desc, initial_state=INIT, control_root={PO2: root})
+    with pytest.raises(HalError, match="starts from state"):
+        verify_session_integrity([receipt.inner.segments[0], replace(receipt.inner.segments[2], index=1)], INIT, None)
+    # a session whose LAST segment is placed in the middle: it halts too early
+    with pytest.raises(HalError):
+        verify_session_integrity([receipt.inner.segments[0], replace(receipt.inner.segments[2], index=1), replace(receipt.inner.segments[1], index=2)], INIT, None)
+    # the words are BOUND: an exit code or a digest limb edited inside a seal breaks the seal
+    for pos in (syn_air.SESSION_EXIT_SYS, syn_air.SESSION_EXIT_USER, syn_air.SESSION_JOURNAL + 3):
+        forged = receipt.inner.segments[1].seal.copy()
+        forged[pos] = fp_encode({syn_air.SESSION_EXIT_SYS: 0, syn_air.SESSION_EXIT_USER: 1}.get(pos, 77))
+        assert oc.verify(forged, root, zk_cycles=ZK) is not None
+        with pytest.raises(HalError):
+            SegmentReceipt(seal=forged, index=1, po2=PO2).verify(desc, root)
+
+
+def test_the_library_checks_termination_too(session):
+    desc, oc, root, base, contribution, prove, receipt, iid = session
+    lib = hal.load_library()
+    out = (C.c_uint8 * 32)()
+    lib.zkh_sha256(b"abc", 3, out)
+    assert bytes(out) == hashlib.sha256(b"abc").digest()
+    lib.zkh_sha256(b"x" * 119, 119, out)
+    assert bytes(out) == hashlib.sha256(b"x" * 119).digest()
+    hc = hal.HostCircuit(desc)
+    u32p = C.POINTER(C.c_uint32)
+
+    def check(recs, journal=None):
+        seals = [np.ascontiguousarray(r.seal, dtype=np.uint32) for r in recs]
+        ptrs = (u32p * len(seals))(*[s.ctypes.data_as(u32p) for s in seals])
+        words = (C.c_size_t * len(seals))(*[s.size for s in seals])
+        hal._check(lib.zkh_session_check_termination(hc.h, ptrs, words, len(seals), journal, 0 if journal is None else len(journal)))
+    check(receipt.inner.segments)
+    check(receipt.inner.segments, receipt.journal)
+    with pytest.raises(HalError, match="does not say Halted"):
+        check(receipt.inner.segments[:2])
+    with pytest.raises(HalError, match="does not end in SystemSplit"):
+        check([receipt.inner.segments[2], receipt.inner.segments[2]])
+    with pytest.raises(HalError, match="journal does not hash"):
+        check(receipt.inner.segments, b"\x00\x00\x00\x00")
+    with pytest.raises(HalError, match="not a SYN-S circuit"):
+        hal._check(lib.zkh_session_check_termination(hal.HostCircuit(syn_air.syn_chain_small()).h, None, None, 1, None, 0) if False else
+                   lib.zkh_session_check_termination(hal.HostCircuit(syn_air.syn_chain_small()).h, (u32p * 1)(), (C.c_size_t * 1)(30), 1, None, 0))
+
+
+def test_the_bincode_container_carries_the_real_claims(session):
+    desc, oc, root, base, contribution, prove, receipt, iid = session
+    from zeth_amd import receipt_codec as rc
+    data = receipt.to_upstream_bytes(desc, {PO2: root})
+    val = rc.decode(rc.Receipt, data)
+    segs = val["inner"][1]["segments"]
+    assert [s["claim"]["exit_code"] for s in segs] == [("SystemSplit", None), ("SystemSplit", None), ("Halted", 0)]
+    assert segs[0]["claim"]["pre"] == ("Value", {"pc": 0, "merkle_root": [INIT, 0, 0, 0, 0, 0, 0, 0]}) and segs[0]["claim"]["output"] == ("Value", None)
+    assert segs[2]["claim"]["output"][1]["journal"] == ("Pruned", sha256_words(receipt.journal)) and val["journal"]["bytes"] == receipt.journal
+    assert rc.encode(rc.Receipt, val) == data
+    back = Receipt.from_upstream_bytes(data, desc)
+    back.verify(iid, desc, initial_state=INIT, control_root={PO2: root})
+    # a container whose claim FIELDS were edited (exit code of the middle segment -> Halted) no longer matches what its seal binds
+    segs[1]["claim"]["exit_code"] = ("Halted", 0)
+    with pytest.raises(HalError, match="its seal binds"):
+        Receipt.from_upstream_bytes(rc.encode(rc.Receipt, val), desc)
+
+
+def test_the_cpp_verifier_refuses_a_truncated_session_and_a_rewritten_journal(session, tmp_path):
+    desc, oc, root, base, contribution, prove, receipt, iid = session
+    exe = os.path.join(os.path.dirname(build.build_examples()), "verify_receipts")
+    dpath = tmp_path / "s.desc"
+    np.asarray(desc, dtype="<u4").tofile(dpath)
+    hexroot = "".join(f"{int(w):08x}" for w in root)
+
+    def write(recs):
+        for f in tmp_path.glob("segment_*.zkr"):
+            f.unlink()
+        for i, r in enumerate(recs):
+            SegmentReceipt(seal=r.seal, index=i, po2=PO2).to_words(desc, root).astype("<u4").tofile(tmp_path / f"segment_{i}.zkr")
+
+    def run(*extra):
+        return subprocess.run([exe, "--desc", str(dpath), "--receipts-dir", str(tmp_path), "--control-root", f"{PO2}:{hexroot}", "--chained",
+                               "--initial-state", str(INIT), *extra], capture_output=True, text=True, timeout=300)
+    write(receipt.inner.segments)
+    r = run()
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["verified"] == 3, r.stderr
+    assert run("--journal", receipt.journal.hex()).returncode == 0 and run("--segments", "3").returncode == 0
+    r = run("--journal", "01020304")
+    assert r.returncode == 1 and "journal does not hash" in r.stderr
+    write(receipt.inner.segments[:2])                                  # trailing segment dropped: every remaining receipt verifies, the session does not
+    r = run()
+    assert r.returncode == 1 and "does not say Halted(0)" in r.stderr
+    forged = receipt.inner.segments[1].seal.copy()
+    forged[syn_air.SESSION_EXIT_SYS] = fp_encode(0)                    # a middle segment edited to say "Halted": the seal no longer verifies
+    write([receipt.inner.segments[0], SegmentReceipt(seal=forged, index=1, po2=PO2)])
+    r = run()
+    assert r.returncode == 1 and "segment 1" in r.stderr

@@ -1,53 +1,159 @@
-"""Round 4 on the GPU: the fused Merkle build (leaves + their parents in one pass), the session executor as one pipeline
-(streamed fold, resident code groups, per-segment retry), host placement, and the compact-trace witness ingress."""
+"""The session executor on the GPU (csrc/session.hip: zkh_session_prove / _verify): native vs Python orchestration, streamed fold, resident code groups,
+per-segment retry, the host-preflight pipeline, chained sessions (claim continuity), several devices / contexts per process, host placement, the g++ hosts."""
+import hashlib
+import json
 import os
+import threading
 
 import numpy as np
 import pytest
 
+import zko
 from conftest import rand_fp
 from zeth_amd.circuits import syn_air
+from zeth_amd.circuits.desc import Circuit
+from zeth_amd.circuits.desc import Circuit as Desc
+from zeth_amd.hal import HalError, HipHal
+from zeth_amd.prover import Segment, SegmentProver, shipped_control_root
 
 pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+P = 2013265921
 
 
-@pytest.mark.parametrize("log_rows,cols", [(17, 0), (17, 5), (17, 16), (17, 17), (18, 33), (17, 208), (12, 40)])
-@pytest.mark.parametrize("fused", [False, True])
-def test_merkle_build_equals_hash_rows_plus_fold_all(oracle, log_rows, cols, fused, monkeypatch):
-    """zkh_merkle_build — the default path and the opt-in fused first pass (ZKH_MERKLE_FUSED=1: k_hash_rows_pair = two adjacent rows
-    per lane + their parent) — gives the nodes zkh_hash_rows + zkh_merkle_fold_all give, and the oracle's whole tree."""
-    import subprocess, sys
-    if fused:
-        # the switch is read once per process: run this case in a child interpreter
-        env = dict(os.environ, ZKH_MERKLE_FUSED="1")
-        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
-                            f"{__file__}::test_merkle_build_equals_hash_rows_plus_fold_all[False-{log_rows}-{cols}]"], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-        return
-    from zeth_amd.hal import HipHal
-    hal = HipHal(0)
-    rng = np.random.default_rng(400 + cols + log_rows)
-    rows = 1 << log_rows
-    mat = rand_fp(rng, cols * rows) if cols else np.zeros(0, np.uint32)
-    m = hal.copy_from("m", mat) if cols else hal.alloc("m", 0)
-    fused = hal.alloc_digest("nodes", 2 * rows)
-    hal.merkle_build(fused, m, rows)
-    plain = hal.alloc_digest("nodes2", 2 * rows)
-    hal.hash_rows(plain.slice(rows * 8, rows * 8), m)
-    hal.merkle_fold_all(plain, rows)
-    a, b = fused.to_vec(), plain.to_vec()
-    assert np.array_equal(a[8:], b[8:])                      # nodes[1 .. 2 rows): node 0 is unused
-    # oracle: a few leaves, their parent, and the whole tree's root
-    want = np.zeros(rows * 8, dtype=np.uint32)
-    oracle.zko_hash_rows(want, rows, np.ascontiguousarray(mat) if cols else np.zeros(1, np.uint32), rows * cols)
-    assert np.array_equal(a[rows * 8:], want)
-    nodes = np.zeros(2 * rows * 8, dtype=np.uint32)
-    nodes[rows * 8:] = want
-    size = rows
-    while size > 1:
-        oracle.zko_hash_fold(nodes, size, size // 2)
-        size //= 2
-    assert np.array_equal(a[8:], nodes[8:])
+
+def test_contexts_on_every_visible_device_from_threads(oracle):
+    """One context + prover per visible device, each driven by its own host thread, all sealing the same segments:
+    identical seals everywhere (per-device kernel attributes, per-thread device binding, atomic handle refcounts)."""
+    import ctypes as C
+    from zeth_amd import hal as zhal
+    zhal.load_library()
+    n_dev = 0
+    while True:
+        try:
+            h = HipHal(n_dev)
+        except HalError:
+            break
+        h.close()
+        n_dev += 1
+        if n_dev >= 8:
+            break
+    assert n_dev >= 1
+    desc = syn_air.syn_small()
+    lanes = [(d, k) for d in range(n_dev) for k in range(2)]
+    out, errs = {}, []
+
+    def work(dev, k):
+        try:
+            h = HipHal(dev)
+            prover = SegmentProver(h, desc)
+            out[(dev, k)] = [prover.prove_segment(Segment(index=i, po2=12, seed=70 + i, noise_seed=5)).seal for i in range(3)]
+            del prover
+            h.close()
+        except Exception as e:          # surfaced below
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=l) for l in lanes]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    oc = zko.OracleCircuit(oracle, desc)
+    want = [oc.prove(12, 1994, 70 + i, 5) for i in range(3)]
+    for l in lanes:
+        for i in range(3):
+            assert np.array_equal(out[l][i], want[i]), f"device {l[0]} lane {l[1]} segment {i}"
+
+
+def test_cpp_host_attaches_code_objects_and_writes_receipts(tmp_path, monkeypatch):
+    """A non-Python host with a circuit that is NOT built into the library: the generated eval_check kernels arrive as code
+    objects (`python -m zeth_amd.circuits.jit` wrote them + a manifest ahead of time), examples/seal_segments attaches them
+    through zkh_circuit_attach_code_object_part, seals, verifies against the control root and writes receipt containers,
+    which the Python side parses back and verifies again."""
+    import subprocess
+    from zeth_amd import build
+    from zeth_amd.circuits import jit, syn_heavy
+    from zeth_amd.prover import SegmentReceipt
+    monkeypatch.setenv("ZKH_CODEGEN_PART", "1600")
+    desc = syn_heavy.syn_heavy_small()                      # two kernels, no built-in match
+    desc_path = tmp_path / "c.desc"
+    np.asarray(desc, dtype="<u4").tofile(desc_path)
+    objs = tmp_path / "objs"
+    assert jit.main(["jit", str(desc_path), str(objs)]) == 0
+    assert (objs / "manifest.txt").read_text().count("\n") >= 2
+    rdir = tmp_path / "receipts"
+    rdir.mkdir()
+    exe = build.build_examples()
+    r = subprocess.run([exe, "--desc", str(desc_path), "--po2", "13", "--segments", "3", "--inflight", "2", "--noise-seed", "7",
+                        "--code-objects", str(objs), "--receipts-dir", str(rdir)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["verified"] == 3
+    blobs = []
+    for i in range(3):
+        blobs.append(np.fromfile(rdir / f"segment_{i}.zkr", dtype="<u4"))
+        rec = SegmentReceipt.from_words(desc, blobs[-1])
+        assert rec.index == i and rec.po2 == 13
+        rec.verify(desc, rec.control_root)                  # the driver computed the root on the GPU; same circuit, same po2
+    # without the code objects the same host still works (step interpreter), and gives the same seal for the same noise
+    r2 = subprocess.run([exe, "--desc", str(desc_path), "--po2", "13", "--segments", "1", "--inflight", "1", "--noise-seed", "7",
+                         "--receipts-dir", str(rdir)], capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr
+    assert np.array_equal(np.fromfile(rdir / "segment_0.zkr", dtype="<u4"), blobs[0])
+
+
+def test_native_session_executor_equals_the_python_orchestration(hal):
+    """zkh_session_prove (csrc/session.hip: C++ threads over lanes, one call per session) against the Python mirrors: the same
+    seals (fixed noise), the same root receipt as prove_succinct with the same join noise, zkh_session_verify accepts, and a
+    swapped leaf is rejected by the compact verification."""
+    from zeth_amd.circuits import p2_join
+    from zeth_amd.hal import HalError
+    from zeth_amd.host import Session, SuccinctReceipt, node_claim, prove_succinct
+    ldesc, jdesc = syn_air.syn_small(), p2_join.p2_join_circuit()
+    segs = [Segment(index=i, po2=12 if i < 4 else 13, seed=700 + i, noise_seed=0x51) for i in range(5)]
+    sess = Session(ldesc, devices=(0,), lanes_per_device=2, join_desc=jdesc)
+    comp, root, stats = sess.prove(segs, join_tree=True, join_po2=13, join_noise_seed=0x77, verify=True)
+    assert stats["n_joins"] == 4 and stats["verified"] and root is not None and stats["wall_s"] > 0
+    lp, jp = SegmentProver(hal, ldesc), SegmentProver(hal, jdesc)
+    want = [lp.prove_segment(s) for s in segs]
+    for a, b in zip(comp.segments, want):
+        assert np.array_equal(a.seal, b.seal)
+    roots = {p: lp.control_root(p) for p in (12, 13)}
+    jroot = jp.control_root(13)
+
+    def claim_of(r, is_leaf):
+        return node_claim(r, ldesc if is_leaf else jdesc, roots[r.po2] if is_leaf else jroot, is_leaf)
+    ref = prove_succinct(want, jp.prove_segment, claim_of, join_po2=13, noise_seed=0x77)
+    assert np.array_equal(root.seal, ref.root.seal)
+    SuccinctReceipt(root, [], comp.segments).verify(ldesc, jdesc, roots, jroot)
+    # a session without a join circuit refuses the join tree; a one-segment session has no root
+    plain = Session(ldesc, lanes_per_device=1)
+    with pytest.raises(HalError, match="without a join circuit"):
+        plain.prove(segs[:2], join_tree=True)
+    comp1, root1, _ = plain.prove(segs[:1], verify=True)
+    assert root1 is None and np.array_equal(comp1.segments[0].seal, want[0].seal)
+    sess.close(); plain.close()
+
+
+def test_session_executor_seals_caller_produced_traces(hal):
+    """The session's other input: traces the CALLER produced (upstream's flow — CPU preflight + witgen — here read back from the
+    device generator), uploaded and sealed through prove_begin / accumulate / prove_finish inside the library.  Same traces, same
+    noise: the same seals as the built-in path."""
+    from zeth_amd.host import Session
+    desc = syn_air.syn_small()
+    prover = SegmentProver(hal, desc)
+    segs = [Segment(index=i, po2=12, seed=40 + i, noise_seed=0x99) for i in range(3)]
+    traces, want = [], []
+    for seg in segs:
+        code, data, out = prover.witgen(seg)
+        traces.append((code.to_vec(), data.to_vec(), out))
+        want.append(prover.seal(seg, code, data, out).seal)
+    sess = Session(desc, lanes_per_device=2)
+    comp, root, _ = sess.prove(segs, host_traces=[traces[0], None, traces[2]], verify=True)      # mixed: two uploaded, one generated
+    for got, w in zip(comp.segments, want):
+        assert np.array_equal(got.seal, w)
+    sess.close()
 
 
 def test_session_streamed_fold_equals_two_phases_and_keeps_code_resident(hal):
@@ -96,6 +202,7 @@ def test_session_retries_a_failed_segment_on_another_lane(hal, monkeypatch):
     sess = Session(desc, devices=(0,), lanes_per_device=3)
     comp0, _, st0 = sess.prove(segs, verify=True)
     assert st0["n_retries"] == 0
+    monkeypatch.setenv("ZKH_TEST_HOOKS", "1")          # the fault hooks are inert without it (and without a strictly numeric index)
     monkeypatch.setenv("ZKH_FAULT_SEGMENT", "2")
     comp1, _, st1 = sess.prove(segs, verify=True)
     assert st1["n_retries"] == 1
@@ -132,42 +239,6 @@ def test_host_placement_of_this_device():
     assert H.placement_slot(0, [0]) == (0, 1)
 
 
-@pytest.mark.parametrize("shape,po2", [("syn_a", 13), ("wd21", 12), ("syn_small", 12)])
-def test_trace_driven_witness_equals_the_oracles(hal, oracle, shape, po2):
-    """Row f1: host preflight (sequential machine, 16 bytes per cycle) -> upload -> k_syn_rowfill + scan + the preload through
-    zkh_scatter gives the oracle's data group word for word (oracle/preflight.c), and the seal of those traces is the oracle's."""
-    import zko
-    from zeth_amd import hal as H
-    from zeth_amd.prover import Segment, SegmentProver
-    desc = {"syn_a": syn_air.syn_a, "syn_small": syn_air.syn_small, "wd21": lambda: syn_air.build_syn_air(8, 21, 8)}[shape]()
-    oc = zko.OracleCircuit(oracle, desc)
-    seed, noise = 0x5EED0000 + po2, 0x2E80
-    rec, ram, secs = H.syn_preflight(seed, po2)
-    orec, oram = oc.preflight(seed, po2)
-    assert np.array_equal(rec, orec) and np.array_equal(ram, oram) and secs > 0 and (rec < 2013265921).all()
-    sp = SegmentProver(hal, desc)
-    wa, wc, wd = sp.group_sizes()
-    n = 1 << po2
-    pinned = hal.host_alloc(rec.size)                        # the ingress path proper: pinned memory + an enqueued upload
-    pinned[:] = rec
-    drec = hal.alloc("records", rec.size)
-    hal.write_async(drec, pinned)
-    code, data = hal.alloc_elem("code", wc * n), hal.alloc_elem("data", wd * n)
-    out = hal.syn_witgen_trace(sp.circuit, po2, 1994, noise, drec, ram, code, data)
-    ocode, odata, oout = oc.witgen_trace(po2, rec, ram, noise)
-    assert np.array_equal(data.to_vec(), odata) and np.array_equal(code.to_vec(), ocode) and np.array_equal(out, oout)
-    T = (wd - 2) // 3
-    if wd - 2 > 3 * T:                                        # the preload landed: the first unconstrained column holds the RAM image
-        assert np.array_equal(odata[3 * T * n: 3 * T * n + 1024], ram)
-    seg = Segment(index=0, po2=po2, seed=seed, noise_seed=noise)
-    got = sp.seal(seg, code, data, out)
-    want = oc.prove_traces(po2, ocode, odata, oout, noise_seed=noise)
-    assert np.array_equal(got.seal, want)
-    got.verify(desc, sp.control_root(po2))
-    hal.sync()
-    hal.host_free(pinned)
-
-
 def test_session_with_host_preflight_pipeline(hal, oracle, monkeypatch):
     """zkh_session_set_witness_source(1): producer threads replay every segment's cycles on the host ahead of the seals; receipts
     equal the op-by-op path's and the oracle's, the host CPU time and the PCIe bytes are reported, a faulted segment is retried."""
@@ -188,6 +259,7 @@ def test_session_with_host_preflight_pipeline(hal, oracle, monkeypatch):
         rec, ram, _ = H.syn_preflight(s.seed, s.po2)
         ocode, odata, oout = oc.witgen_trace(s.po2, rec, ram, s.noise_seed)
         assert np.array_equal(r.seal, oc.prove_traces(s.po2, ocode, odata, oout, noise_seed=s.noise_seed))
+    monkeypatch.setenv("ZKH_TEST_HOOKS", "1")
     monkeypatch.setenv("ZKH_FAULT_SEGMENT", "3")
     comp2, _, st2 = sess.prove(segs, verify=True)
     assert st2["n_retries"] == 1 and all(np.array_equal(a.seal, b.seal) for a, b in zip(comp.segments, comp2.segments))
@@ -197,52 +269,6 @@ def test_session_with_host_preflight_pipeline(hal, oracle, monkeypatch):
     comp3, _, st3 = sess.prove(segs, verify=True)
     assert st3["trace_bytes"] == 0 and not np.array_equal(comp3.segments[0].seal, comp.segments[0].seal)
     sess.close()
-
-
-def test_combos_prepare_regs_takes_any_register_size_and_refuses_inconsistent_lists(hal):
-    """Round-3 advisor finding: registers larger than 32 silently lost their terms and the sizes were never checked against coeff_u.
-    Now: any size up to `cycles` (against the host aggregation), and an inconsistent register list is an ERROR before the launch."""
-    import hal_only_prover as hop
-    from zeth_amd.hal import HalError
-    P = 2013265921
-    rng = np.random.default_rng(11)
-    cycles, combo_count = 128, 3
-    sizes = np.array([1, 40, 3, 97, 32, 33, 128, 2], dtype=np.uint32)
-    ids = rng.integers(0, combo_count, size=sizes.size).astype(np.uint32)
-    n_u = int(sizes.sum()) + hop.CHECK_SIZE
-    coeff_u = rng.integers(0, P, size=4 * n_u, dtype=np.uint64).astype(np.uint32)
-    start = rng.integers(0, P, size=4 * cycles * (combo_count + 1), dtype=np.uint64).astype(np.uint32)
-    mix = tuple(int(x) for x in rng.integers(1, P, size=4))
-    a = hal.copy_from("combos", start)
-    hal.combos_prepare_regs(a, hal.copy_from("cu", coeff_u), combo_count, cycles, hal.copy_from("s", sizes), hal.copy_from("i", ids), hop.e_words(mix))
-    sub, cur, pos = {}, (1, 0, 0, 0), 0
-    cu = [tuple(hop.dec(coeff_u[4 * k + i]) for i in range(4)) for k in range(n_u)]
-    for sz, cid in zip(sizes, ids):
-        for i in range(int(sz)):
-            key = cycles * int(cid) + i
-            sub[key] = hop.e_add(sub.get(key, (0, 0, 0, 0)), hop.e_mul(cur, cu[pos + i]))
-        cur = hop.e_mul(cur, mix)
-        pos += int(sz)
-    for _ in range(hop.CHECK_SIZE):
-        key = cycles * combo_count
-        sub[key] = hop.e_add(sub.get(key, (0, 0, 0, 0)), hop.e_mul(cur, cu[pos]))
-        pos += 1
-        cur = hop.e_mul(cur, mix)
-    b = hal.copy_from("combos", start)
-    hal.combos_prepare(b, np.asarray(list(sub), dtype=np.uint32), np.asarray([w for v in sub.values() for w in hop.e_words(v)], dtype=np.uint32))
-    assert np.array_equal(a.to_vec(), b.to_vec())
-
-    def call(sz, idv, cu_words):
-        hal.combos_prepare_regs(hal.copy_from("combos", start), hal.copy_from("cu", coeff_u[:cu_words]), combo_count, cycles,
-                                hal.copy_from("s", np.asarray(sz, dtype=np.uint32)), hal.copy_from("i", np.asarray(idv, dtype=np.uint32)), hop.e_words(mix))
-    with pytest.raises(HalError, match="add up to"):                  # sizes claim more U coefficients than coeff_u holds
-        call(sizes, ids, 4 * (n_u - 5))
-    with pytest.raises(HalError, match="has size"):                   # a register larger than the polynomial
-        call([cycles + 1] + list(sizes[1:]), ids, coeff_u.size)
-    with pytest.raises(HalError, match="has size"):
-        call([0] + list(sizes[1:]), ids, coeff_u.size)
-    with pytest.raises(HalError, match="names combo"):
-        call(sizes, [combo_count] + list(ids[1:]), coeff_u.size)
 
 
 def test_chained_session_on_the_gpu(hal, oracle):
@@ -280,6 +306,55 @@ def test_chained_session_on_the_gpu(hal, oracle):
     comp0.verify(desc, roots, chained=True, initial_state=0)
     assert comp0.final_state() == sum(contrib) % P and not np.array_equal(comp0.segments[0].seal, comp.segments[0].seal)
     sess.close()
+
+
+def test_a_session_that_terminates_on_the_gpu(hal, oracle):
+    """SYN-S through the native executor: zkh_session_set_chained gives every segment its pre-state, its exit code (SystemSplit ..
+    SystemSplit, Halted(0)) and — the last one — the limbs of SHA-256(journal) as bound public inputs; zkh_session_verify refuses a
+    session whose trailing segment is missing.  Seals equal the oracle's for the same public words; the Python host and the g++-level
+    check (zkh_session_check_termination) agree; a po2-20 SYN-S segment seals with the generated kernel of its own circuit."""
+    import ctypes as C
+    import zko
+    from zeth_amd import hal as zhal
+    from zeth_amd.circuits import syn_air
+    from zeth_amd.host import (EXIT_HALTED, EXIT_SYSTEM_SPLIT, CompositeReceipt, Receipt, Session, chain_session, image_id, segment_claim,
+                               verify_session_integrity)
+    from zeth_amd.prover import Segment, SegmentProver
+    desc = syn_air.syn_session_small()
+    oc = zko.OracleCircuit(oracle, desc)
+    sp = SegmentProver(hal, desc)
+    segs = [Segment(index=i, po2=13 if i != 1 else 12, seed=2500 + i, noise_seed=0x58) for i in range(4)]
+    contrib = [sp.chain_contribution(s) for s in segs]
+    want, journal = chain_session(segs, lambda s: contrib[s.index], initial_state=5)
+    sess = Session(desc, devices=(0,), lanes_per_device=2)
+    sess.set_chained(True, 5)
+    comp, _, _ = sess.prove(segs, verify=True)
+    for s, r in zip(want, comp.segments):
+        assert np.array_equal(r.seal, oc.prove(s.po2, 1994, s.seed, s.noise_seed, pub=np.asarray(s.pub, dtype=np.uint32))), f"segment {s.index}"
+    claims = [segment_claim(r) for r in comp.segments]
+    assert [c.exit_code for c in claims] == [(EXIT_SYSTEM_SPLIT, None)] * 3 + [(EXIT_HALTED, 0)] and journal == int(claims[-1].post).to_bytes(4, "little")
+    roots = {p: sp.control_root(p) for p in (12, 13)}
+    rec = Receipt(comp, journal)
+    rec.verify(image_id(desc, 5), desc, initial_state=5, control_root=roots)
+    with pytest.raises(HalError, match="not Halted"):           # the advisor's attack: cut the tail, rewrite the journal
+        Receipt(CompositeReceipt(comp.segments[:3]), int(claims[2].post).to_bytes(4, "little")).verify(image_id(desc, 5), desc, initial_state=5, control_root=roots)
+    # the library's own verifier refuses the truncated session too (the seals are its own: zkh_session_verify re-checks them)
+    lib = zhal.load_library()
+    u32p = C.POINTER(C.c_uint32)
+    seals = [np.ascontiguousarray(r.seal) for r in comp.segments[:3]]
+    ptrs, words = (u32p * 3)(*[x.ctypes.data_as(u32p) for x in seals]), (C.c_size_t * 3)(*[x.size for x in seals])
+    with pytest.raises(HalError, match="does not say Halted"):
+        zhal._check(lib.zkh_session_check_termination(zhal.HostCircuit(desc).h, ptrs, words, 3, None, 0))
+    sess.close()
+    # full width at the BASELINE size: one SYN-S segment (23 output words, 19 bound) seals and verifies; its exit words are the ones asked for
+    big = syn_air.syn_session()
+    bp = SegmentProver(hal, big)
+    one, j1 = chain_session([Segment(index=0, po2=20, seed=0x5EED0000, noise_seed=0x2E80)], bp.chain_contribution, initial_state=3)
+    r = bp.prove_segment(one[0])
+    r.verify(big, bp.control_root(20))
+    assert bp.circuit.compiled_parts() >= 1 and segment_claim(r).exit_code == (EXIT_HALTED, 0)
+    verify_session_integrity([r], 3, j1)
+    assert np.array_equal(bp.control_root(20), SegmentProver(hal, syn_air.syn_a()).control_root(20))      # the code group does not depend on the public words
 
 
 def test_chained_session_folds_to_one_receipt_whose_joins_asserted_continuity(hal):
@@ -346,48 +421,3 @@ def test_session_over_a_device_list_with_streamed_fold(hal):
         sess.close()
     assert np.array_equal(roots[(0,)][0], roots[(0, 0)][0])
     assert all(np.array_equal(a, b) for a, b in zip(roots[(0,)][1], roots[(0, 0)][1]))
-
-
-def test_gathered_power_tables_travel_inside_the_code_objects(hal, oracle, tmp_path, monkeypatch):
-    """Round 4's eval_check generator gives every kernel its own mix-power table in emission order and exports the exponent list
-    as `<kernel>_exps` inside the code object: a host that attaches the parts needs to know nothing about it.  Kernels generated
-    WITH the table and WITHOUT it give the interpreter's words; a set that mixes the two is refused, not launched."""
-    from zeth_amd.circuits import codegen, jit, syn_heavy
-    from zeth_amd.hal import HalError
-    from zeth_amd.prover import Segment, SegmentProver
-    from test_round2_gpu import _evaluated_groups
-    import zko
-    monkeypatch.setenv("ZKH_JIT_CACHE", str(tmp_path))
-    monkeypatch.setenv("ZKH_CODEGEN_PART", "1600")
-    desc = syn_heavy.syn_heavy_small()
-    prover = SegmentProver(hal, desc)
-    circ = prover.circuit
-    oc = zko.OracleCircuit(oracle, desc)
-    seg = Segment(index=0, po2=10, seed=31, noise_seed=32, zk_cycles=300)
-    ev, _, out, mix = _evaluated_groups(hal, oracle, prover, oc, seg)
-    dom = 4 << seg.po2
-    poly_mix = np.random.default_rng(4).integers(1, 2013265921, size=4, dtype=np.uint64).astype(np.uint32)
-    g_out, g_mix = hal.copy_from("out", out), hal.copy_from("mix", mix)
-    want = hal.alloc_elem("want", 4 * dom)
-    circ.eval_check(want, ev, [g_out, g_mix], poly_mix, seg.po2, use_interpreter=True)
-    want = want.to_vec()
-    objs = {}
-    for gather in (1, 0):
-        monkeypatch.setattr(codegen, "GATHER", gather)
-        objs[gather] = jit.compile_code_objects(desc, use_cache=False)
-        assert len(objs[gather]) >= 2
-    for gather in (1, 0, 1):                                   # gathered, plain, gathered again: a new set replaces the old one whole
-        for i, (img, name) in enumerate(objs[gather]):
-            circ.attach_code_object(img, name, i, len(objs[gather]))
-        assert circ.kernel_kind() == "attached"
-        got = hal.alloc_elem("check", 4 * dom)
-        circ.eval_check(got, ev, [g_out, g_mix], poly_mix, seg.po2)
-        assert np.array_equal(got.to_vec(), want), f"gather={gather}"
-    img, name = objs[0][1]                                     # one plain part among gathered ones: such a set is not launched ...
-    circ.attach_code_object(img, name, 1, len(objs[1]))
-    with pytest.raises(HalError, match="gathered power table"):
-        circ.eval_check(got, ev, [g_out, g_mix], poly_mix, seg.po2)
-    img, name = objs[1][1]                                     # ... and the right part repairs it
-    circ.attach_code_object(img, name, 1, len(objs[1]))
-    circ.eval_check(got, ev, [g_out, g_mix], poly_mix, seg.po2)
-    assert np.array_equal(got.to_vec(), want)

@@ -164,14 +164,20 @@ def test_chained_session_is_continuous_and_tampering_breaks_the_chain(oracle):
     from zeth_amd.hal import HalError, fp_decode
     from zeth_amd.host import Receipt, image_id, prove_chained_block
     receipt, iid = prove_chained_block(prove, contribution, desc, base, initial_state=7)
-    receipt.verify(iid, desc, initial_state=7, control_root=root)
+    receipt.verify(iid, desc, initial_state=7, control_root=root, n_segments=4)
+    with pytest.raises(HalError, match="does not bind its termination"):       # SYN-C seals carry no exit code: the verifier must say how long the session is
+        receipt.verify(iid, desc, initial_state=7, control_root=root)
+    # ... because a holder can cut the session short and rewrite the 4-byte journal: only the expected segment count refuses that
+    cut = Receipt(CompositeReceipt(recs[:3]), int(fp_decode(int(recs[2].seal[0]))).to_bytes(4, "little"))
+    with pytest.raises(HalError, match="holds 3 segments, the session has 4"):
+        cut.verify(iid, desc, initial_state=7, control_root=root, n_segments=4)
     assert receipt.journal == int(fp_decode(comp.final_state())).to_bytes(4, "little") and np.array_equal(iid, image_id(desc, 7))
     with pytest.raises(HalError, match="image id"):
-        receipt.verify(image_id(desc, 8), desc, initial_state=7, control_root=root)           # another program / initial state
+        receipt.verify(image_id(desc, 8), desc, initial_state=7, control_root=root, n_segments=4)           # another program / initial state
     with pytest.raises(HalError, match="journal"):
-        Receipt(receipt.inner, b"\x00\x00\x00\x01").verify(iid, desc, initial_state=7, control_root=root)
+        Receipt(receipt.inner, b"\x00\x00\x00\x01").verify(iid, desc, initial_state=7, control_root=root, n_segments=4)
     with pytest.raises(ValueError, match="not continuous"):
-        Receipt(CompositeReceipt(swapped), receipt.journal).verify(iid, desc, initial_state=7, control_root=root)
+        Receipt(CompositeReceipt(swapped), receipt.journal).verify(iid, desc, initial_state=7, control_root=root, n_segments=4)
     # without the chain check the same receipts are individually valid: continuity is a property of the SESSION
     CompositeReceipt(swapped).verify(desc, root)
     # and a forged pre-state inside a seal is refused by the seal verification itself (the state words are bound public inputs)

@@ -92,8 +92,13 @@ def test_verifier_cli_checks_the_continuity_of_a_chained_session(oracle, exe, tm
     def write(order):
         for i, k in enumerate(order):
             SegmentReceipt(seal=seals[k], index=i, po2=po2).to_words(desc, root).astype("<u4").tofile(tmp_path / f"segment_{i}.zkr")
-    args = ["--desc", str(dpath), "--receipts-dir", str(tmp_path), "--control-root", f"{po2}:{_hex(root)}", "--chained"]
+    args = ["--desc", str(dpath), "--receipts-dir", str(tmp_path), "--control-root", f"{po2}:{_hex(root)}", "--segments", "3", "--chained"]
     write([0, 1, 2])
+    # SYN-C seals bind no exit code: --chained without the expected segment count is refused outright (a truncated session would pass)
+    r = _run(exe, *[a for a in args if a not in ("--segments", "3")], "--initial-state", "9")
+    assert r.returncode == 1 and "needs --segments" in r.stderr
+    r = _run(exe, *args[:-3], "--segments", "4", "--chained", "--initial-state", "9")
+    assert r.returncode == 1 and "3 segment receipts found, the session has 4" in r.stderr
     r = _run(exe, *args, "--initial-state", "9")
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["chained"] is True, r.stderr
     r = _run(exe, *args, "--initial-state", "8")                    # another starting state

@@ -47,21 +47,22 @@ def load():
         "zko_eval_check": (None, [vp, u32p, C.POINTER(vp), C.POINTER(vp), u32p, C.c_uint]),
         "zko_syn_cell": (u32, [u64, u32, u32, u32]),
         "zko_syn_code": (None, [vp, C.c_uint, C.c_uint, u32p]),
-        "zko_syn_witgen": (None, [vp, C.c_uint, C.c_uint, u64, u64, C.c_void_p, u32p, u32p, u32p]),
-        "zko_syn_accum": (None, [vp, C.c_uint, C.c_uint, u64, u32p, u32p, u32p]),
-        "zko_prove_segment": (C.POINTER(u32), [vp, C.c_uint, C.c_uint, u64, u64, C.c_void_p, C.POINTER(sz), C.POINTER(C.c_char_p)]),
+        "zko_syn_witgen": (None, [vp, C.c_uint, C.c_uint, u64, u32p, C.c_void_p, u32p, u32p, u32p]),
+        "zko_syn_accum": (None, [vp, C.c_uint, C.c_uint, u32p, u32p, u32p, u32p]),
+        "zko_noise_cell": (u32, [u32p, u32, u32, u32]), "zko_chacha_block": (None, [u32p, u32p, C.c_int, u32p]),
+        "zko_prove_segment": (C.POINTER(u32), [vp, C.c_uint, C.c_uint, u64, u32p, C.c_void_p, C.POINTER(sz), C.POINTER(C.c_char_p)]),
         "zko_control_root": (None, [vp, C.c_uint, C.c_uint, u32p]),
         "zko_verify_segment": (C.c_char_p, [vp, u32p, sz, C.c_void_p]),
         "zko_free": (None, [vp]),
-        "zko_prove_traces": (C.POINTER(u32), [vp, C.c_uint, C.c_uint, u64, u32p, u32p, u32p, C.POINTER(sz), C.POINTER(C.c_char_p)]),
+        "zko_prove_traces": (C.POINTER(u32), [vp, C.c_uint, C.c_uint, u32p, u32p, u32p, u32p, C.POINTER(sz), C.POINTER(C.c_char_p)]),
         "zko_root_of_code": (None, [vp, C.c_uint, u32p, u32p]),
         "zko_rec_code": (C.c_char_p, [u32p, sz, u32p]),
-        "zko_rec_witgen": (C.c_char_p, [u32p, sz, u32p, sz, u64, u32p, u32p, u32p]),
-        "zko_rec_accum": (None, [vp, C.c_uint, C.c_uint, u64, u32p, u32p, u32p, u32p]),
+        "zko_rec_witgen": (C.c_char_p, [u32p, sz, u32p, sz, u32p, u32p, u32p, u32p]),
+        "zko_rec_accum": (None, [vp, C.c_uint, C.c_uint, u32p, u32p, u32p, u32p, u32p]),
         "zko_check_rows": (C.c_long, [vp, C.c_uint, C.POINTER(vp), C.POINTER(vp), sz, sz]),
         "zko_syn_preflight_ram_words": (sz, []),
         "zko_syn_preflight": (None, [u64, C.c_uint, C.c_uint, u32p, u32p]),
-        "zko_syn_witgen_trace": (None, [vp, C.c_uint, C.c_uint, u64, u32p, u32p, C.c_void_p, u32p, u32p]),
+        "zko_syn_witgen_trace": (None, [vp, C.c_uint, C.c_uint, u32p, u32p, u32p, C.c_void_p, u32p, u32p]),
         "zko_num_threads": (C.c_int, []),
         "zko_set_num_threads": (None, [C.c_int]),
     }
@@ -69,6 +70,18 @@ def load():
         f = getattr(lib, name)
         f.restype, f.argtypes = res, args
     return lib
+
+
+def key_words(noise_seed) -> np.ndarray:
+    """the 8-word blinding key of an integer noise seed (little-endian words: the convention of zeth_amd.hal.noise_key); the oracle
+    is deterministic, so 0 / None is not "draw from the OS" here but an error"""
+    if isinstance(noise_seed, np.ndarray):
+        k = np.ascontiguousarray(noise_seed, dtype=np.uint32)
+        assert k.shape == (8,)
+        return k
+    v = int(noise_seed)
+    assert 0 < v < (1 << 256), "the oracle needs an explicit noise key"
+    return np.array([(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)], dtype=np.uint32)
 
 
 class OracleCircuit:
@@ -95,7 +108,7 @@ class OracleCircuit:
         wa, wc, wd = (int(x) for x in self.desc[3:6])
         n = 1 << po2
         code, data, out = np.zeros(wc * n, np.uint32), np.zeros(wd * n, np.uint32), np.zeros(self.out_size, np.uint32)
-        self.lib.zko_syn_witgen(self.h, po2, zk_cycles, seed, noise_seed, self._pub(pub), code, data, out)
+        self.lib.zko_syn_witgen(self.h, po2, zk_cycles, seed, key_words(noise_seed), self._pub(pub), code, data, out)
         return code, data, out
 
     def preflight(self, seed, po2, zk_cycles=1994):
@@ -110,7 +123,7 @@ class OracleCircuit:
         wa, wc, wd = (int(x) for x in self.desc[3:6])
         n = 1 << po2
         code, data, out = np.zeros(wc * n, np.uint32), np.zeros(wd * n, np.uint32), np.zeros(self.out_size, np.uint32)
-        self.lib.zko_syn_witgen_trace(self.h, po2, zk_cycles, noise_seed, np.ascontiguousarray(records, dtype=np.uint32),
+        self.lib.zko_syn_witgen_trace(self.h, po2, zk_cycles, key_words(noise_seed), np.ascontiguousarray(records, dtype=np.uint32),
                                       np.ascontiguousarray(ram, dtype=np.uint32), code.ctypes.data_as(C.c_void_p), data, out)
         return code, data, out
 
@@ -140,7 +153,7 @@ class OracleCircuit:
     def prove(self, po2, zk_cycles=1994, seed=0x5EED0000, noise_seed=0x2E80, pub=None):
         n = C.c_size_t()
         err = C.c_char_p()
-        p = self.lib.zko_prove_segment(self.h, po2, zk_cycles, seed, noise_seed, self._pub(pub), C.byref(n), C.byref(err))
+        p = self.lib.zko_prove_segment(self.h, po2, zk_cycles, seed, key_words(noise_seed), self._pub(pub), C.byref(n), C.byref(err))
         if not p:
             raise RuntimeError((err.value or b"?").decode())
         seal = np.ctypeslib.as_array(p, shape=(n.value,)).copy()
@@ -157,14 +170,14 @@ class OracleCircuit:
         wa, wc, wd = (int(x) for x in self.desc[3:6])
         n = 1 << int(prog[2])
         code, data, out = np.zeros(wc * n, np.uint32), np.zeros(wd * n, np.uint32), np.zeros(self.out_size, np.uint32)
-        err = self.lib.zko_rec_witgen(prog, prog.size, inputs, inputs.size, noise_seed, code, data, out)
+        err = self.lib.zko_rec_witgen(prog, prog.size, inputs, inputs.size, key_words(noise_seed), code, data, out)
         if err:
             raise RuntimeError(err.decode())
         return code, data, out
 
     def rec_accum(self, po2, code, data, mix, zk_cycles=1994, noise_seed=0x2E80):
         accum = np.zeros(int(self.desc[3]) << po2, np.uint32)
-        self.lib.zko_rec_accum(self.h, po2, zk_cycles, noise_seed, code, data, np.ascontiguousarray(mix, dtype=np.uint32), accum)
+        self.lib.zko_rec_accum(self.h, po2, zk_cycles, key_words(noise_seed), code, data, np.ascontiguousarray(mix, dtype=np.uint32), accum)
         return accum
 
     def check_rows(self, po2, accum, code, data, out, mix, lo=0, hi=None):
@@ -182,7 +195,7 @@ class OracleCircuit:
     def prove_traces(self, po2, code, data, out, zk_cycles=1994, noise_seed=0x2E80):
         n = C.c_size_t()
         err = C.c_char_p()
-        p = self.lib.zko_prove_traces(self.h, po2, zk_cycles, noise_seed, np.ascontiguousarray(code, dtype=np.uint32),
+        p = self.lib.zko_prove_traces(self.h, po2, zk_cycles, key_words(noise_seed), np.ascontiguousarray(code, dtype=np.uint32),
                                       np.ascontiguousarray(data, dtype=np.uint32), np.ascontiguousarray(out, dtype=np.uint32),
                                       C.byref(n), C.byref(err))
         if not p:

@@ -954,6 +954,7 @@ def shipped() -> Dict[str, np.ndarray]:
         SHIPPED["syn_tiny"] = syn_air.syn_tiny()
         SHIPPED["syn_join"] = syn_air.syn_join()
         SHIPPED["syn_chain"] = syn_air.syn_chain()
+        SHIPPED["syn_session"] = syn_air.syn_session()
         SHIPPED["syn_heavy"] = syn_heavy.syn_heavy()
         from . import keccak_f
         SHIPPED["keccak_f"] = keccak_f.keccak_f_circuit()

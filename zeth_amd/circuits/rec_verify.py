@@ -417,7 +417,7 @@ class Verifier:
 def chain_words(c: Circuit):
     """(index of the pre-state, index of the post-state) in the `out` globals of a circuit whose segments chain (SYN-C: kind 1 with
     one public input, out = (post, 0, 0, 0, pre)), or None for circuits without a state"""
-    return (4, 0) if c.kind == 1 and c.global_sizes[0] == 5 else None
+    return (4, 0) if c.kind == 1 and c.global_sizes[0] in (5, 23) else None      # SYN-C, SYN-S (syn_air.py syn_session)
 
 
 def _wrap(v: Verifier, core: Sequence[int], pre: int, post: int) -> List[int]:

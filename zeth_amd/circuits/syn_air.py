@@ -124,6 +124,30 @@ def syn_chain_small() -> np.ndarray:
 
 
 CHAIN_PRE, CHAIN_POST = 4, 0      # positions of the pre / post state words in a SYN-C seal's `out` header
+
+# SYN-S: what a segment of a SESSION publishes, bound word for word by the public-input constraints — what upstream's
+# `ReceiptClaim` holds per segment (risc0-zkvm 3.0.3 receipt_claim.rs, recalled): pre / post state, the exit code as its
+# (system, user) pair, and the digest of the output (journal) as sixteen 16-bit limbs (a SHA-256 word is not a field element).
+SESSION_EXIT_SYS, SESSION_EXIT_USER, SESSION_JOURNAL, SESSION_JOURNAL_LIMBS = 5, 6, 7, 16
+SESSION_PUB_WORDS = 1 + 2 + SESSION_JOURNAL_LIMBS                  # pre, exit (sys, user), journal digest limbs
+SESSION_OUT_WORDS = 4 + SESSION_PUB_WORDS
+
+
+def syn_session() -> np.ndarray:
+    """SYN-S: SYN-C whose segments also publish their EXIT CODE and OUTPUT DIGEST: out = (post, 0, 0, 0, pre, exit_sys, exit_user,
+    j_0 .. j_15).  Every word after the first four is a public input bound to a witness cell by a `first`-gated constraint, so a
+    holder of the receipt cannot change it without breaking the seal: a session cut short ends in a segment that says SystemSplit
+    (2, 0), not Halted(0) (0, 0), and a rewritten journal no longer hashes to the limbs the last seal carries.  What
+    `receipt.verify(image_id)` + the journal comparison check (/root/reference/crates/host/src/bin/cli.rs:103-107) through
+    upstream's `CompositeReceipt::verify_integrity` + exit-code check.  The executor fixes these words before any segment is proven
+    (as upstream's does); the circuit has no notion of halting of its own (declared: SYN-AIR's computation is a stand-in).  Same
+    code group as SYN-A, hence the same control roots."""
+    return build_syn_air(16, 208, 32, n_pub=SESSION_PUB_WORDS)
+
+
+def syn_session_small() -> np.ndarray:
+    """the same at small widths (tests): 20 triples hold the 19 public words"""
+    return build_syn_air(8, 62, 8, n_pub=SESSION_PUB_WORDS)
 JOIN_PUB_WORDS = 16      # two child claim digests (8 words each)
 
 
@@ -137,6 +161,6 @@ def syn_join() -> np.ndarray:
 if __name__ == "__main__":      # python -m zeth_amd.circuits.syn_air syn_a out.desc  (blob for non-Python hosts)
     import sys
     shape, path = sys.argv[1], sys.argv[2]
-    blob = {"syn_a": syn_a, "syn_tiny": syn_tiny, "syn_small": syn_small, "syn_join": syn_join, "syn_chain": syn_chain}[shape]()
+    blob = {"syn_a": syn_a, "syn_tiny": syn_tiny, "syn_small": syn_small, "syn_join": syn_join, "syn_chain": syn_chain, "syn_session": syn_session}[shape]()
     np.asarray(blob, dtype="<u4").tofile(path)
     print(f"{path}: {blob.size} words")

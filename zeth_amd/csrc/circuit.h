@@ -111,3 +111,15 @@ struct zkh_circuit {
     uint32_t* d_prog;     // device copy of prog
     uint32_t* d_taps;     // device copy of taps (group, offset, back)
 };
+
+// Circuits whose segments chain: SYN-C (kind 1, out = (post, 0, 0, 0, pre): 5 words) and SYN-S (zeth_amd/circuits/syn_air.py
+// syn_session: the same plus the exit code pair and the 16 limbs of the output digest: 23 words).  Every word past the first four
+// is a public input bound by a `first`-gated constraint.
+constexpr uint32_t SESSION_OUT_WORDS = 23, SESSION_EXIT_SYS = 5, SESSION_EXIT_USER = 6, SESSION_JOURNAL = 7, SESSION_JOURNAL_LIMBS = 16;
+constexpr uint32_t EXIT_SYS_HALTED = 0, EXIT_SYS_PAUSED = 1, EXIT_SYS_SPLIT = 2;        // ExitCode::into_pair (risc0-binfmt, recalled)
+inline bool circuit_is_session(const zkh_circuit* c) { return c->kind == 1 && c->global_size[0] == SESSION_OUT_WORDS; }
+inline bool circuit_has_state(const zkh_circuit* c) { return c->kind == 1 && (c->global_size[0] == 5 || c->global_size[0] == SESSION_OUT_WORDS); }
+namespace zkh {
+void session_journal_limbs(uint32_t final_state_mont, uint32_t limbs[16]);                                       // verifier.hip
+const char* check_session_termination(const uint32_t* const* seals, size_t n, const uint8_t* journal, size_t journal_len);
+}

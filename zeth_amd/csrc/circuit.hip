@@ -135,13 +135,13 @@ __global__ void k_syn_code(uint32_t* code, uint32_t wc, uint32_t n, uint32_t A, 
 }
 // one lane per row: free cells, products, and the running-sum increment (scanned afterwards)
 // pub: n_pub public input words; word k replaces the x cell of triple k in row 0 (bound to out[4 + k] by a constraint)
-__global__ void k_syn_data(uint32_t* data, uint32_t wd, uint32_t n, uint32_t A, uint64_t seed, uint64_t noise_seed,
+__global__ void k_syn_data(uint32_t* data, uint32_t wd, uint32_t n, uint32_t A, uint64_t seed, NoiseKey nk,
                            const uint32_t* __restrict__ pub, uint32_t n_pub) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     const uint32_t T = (wd - 2) / 3;
     if (r >= A) {
-        for (uint32_t c = 0; c < wd; c++) data[(size_t)c * n + r] = syn_cell(noise_seed, GROUP_DATA, c, r);
+        for (uint32_t c = 0; c < wd; c++) data[(size_t)c * n + r] = noise_cell(nk, GROUP_DATA, c, r);      // blinding rows: noise.h
         return;
     }
     uint32_t d0 = 0, d1 = 0, d3 = 0, d4 = 0;
@@ -244,7 +244,7 @@ __global__ void k_syn_accum_terms(uint32_t* terms, const uint32_t* data, const u
     }
     ((uint4*)terms)[(size_t)e * n + r] = v;
 }
-__global__ void k_syn_accum_store(uint32_t* accum, const uint32_t* prods, uint32_t n, uint32_t A, uint64_t noise_seed) {
+__global__ void k_syn_accum_store(uint32_t* accum, const uint32_t* prods, uint32_t n, uint32_t A, NoiseKey nk) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, e = blockIdx.y;
     if (r >= n) return;
     uint32_t v[4];
@@ -252,7 +252,7 @@ __global__ void k_syn_accum_store(uint32_t* accum, const uint32_t* prods, uint32
         const uint4 p = ((const uint4*)prods)[(size_t)e * n + r];
         v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w;
     } else {
-        for (int i = 0; i < 4; i++) v[i] = syn_cell(noise_seed, GROUP_ACCUM, 4 * e + i, r);
+        for (int i = 0; i < 4; i++) v[i] = noise_cell(nk, GROUP_ACCUM, 4 * e + i, r);
     }
     for (int i = 0; i < 4; i++) accum[(size_t)(4 * e + i) * n + r] = v[i];
 }
@@ -323,11 +323,11 @@ __global__ void k_keccak_perm(uint64_t* rows, uint32_t K, uint64_t seed, const u
     }
     for (uint32_t i = 0; i < KF_LANES; i++) row[i] = i < 25 ? a[i] : 0;         // row 24: the output state
 }
-__global__ void k_keccak_expand(uint32_t* data, const uint64_t* __restrict__ rows, uint32_t n, uint32_t A, uint32_t K, uint64_t noise_seed) {
+__global__ void k_keccak_expand(uint32_t* data, const uint64_t* __restrict__ rows, uint32_t n, uint32_t A, uint32_t K, NoiseKey nk) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y;
     if (r >= n) return;
     uint32_t v = 0;
-    if (r >= A) v = syn_cell(noise_seed, GROUP_DATA, col, r);
+    if (r >= A) v = noise_cell(nk, GROUP_DATA, col, r);
     else if (r < KF_BLOCK * K) v = ((rows[(size_t)r * KF_LANES + (col >> 6)] >> (col & 63)) & 1) ? R1 : 0;
     data[(size_t)col * n + r] = v;
 }
@@ -436,10 +436,10 @@ __global__ void k_p2join_blocks(uint32_t* data, const uint32_t* __restrict__ cod
     if (p == 0) for (uint32_t j = 0; j < 8; j++) parent[j] = s[j];
 }
 // rows past the last block: zero while active, blinding noise after
-__global__ void k_p2join_tail(uint32_t* data, uint32_t n, uint32_t A, uint32_t first_row, uint64_t noise_seed) {
+__global__ void k_p2join_tail(uint32_t* data, uint32_t n, uint32_t A, uint32_t first_row, NoiseKey nk) {
     const uint32_t r = first_row + blockIdx.x * blockDim.x + threadIdx.x, col = blockIdx.y;
     if (r >= n) return;
-    data[(size_t)col * n + r] = r < A ? 0u : syn_cell(noise_seed, GROUP_DATA, col, r);
+    data[(size_t)col * n + r] = r < A ? 0u : noise_cell(nk, GROUP_DATA, col, r);
 }
 
 }  // namespace
@@ -831,8 +831,10 @@ extern "C" const char* zkh_syn_code(zkh_ctx* ctx, const zkh_circuit* c, size_t p
     return last_launch_error("syn_code");
 }
 extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t po2, size_t zk_cycles, uint64_t seed,
-                                      uint64_t noise_seed, const uint32_t* pub, zkh_buf* code, zkh_buf* data, uint32_t* out_global) {
+                                      const uint32_t* noise_key, const uint32_t* pub, zkh_buf* code, zkh_buf* data, uint32_t* out_global) {
     ZKH_REQUIRE(c->kind >= 1 && c->kind <= 3, "syn_witgen: no built-in witness generator for circuit kind %u", c->kind);
+    NoiseKey nk;
+    ZKH_TRY(resolve_noise_key(noise_key, &nk));
     const size_t n = (size_t)1 << po2;
     ZKH_REQUIRE(n > zk_cycles + 1, "syn_witgen: po2 too small for zk_cycles");
     const uint32_t wc = c->group_size[GROUP_CODE], wd = c->group_size[GROUP_DATA], A = (uint32_t)(n - zk_cycles);
@@ -854,7 +856,7 @@ extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t
             k_p2join_blocks<<<1, 64, 0, ctx->stream>>>(data->ptr(), code->ptr(), (uint32_t)n, 0, 1, kids->ptr(), parent->ptr(), tab->ptr());
             if (K > 1) k_p2join_blocks<<<(K - 1 + 63) / 64, 64, 0, ctx->stream>>>(data->ptr(), code->ptr(), (uint32_t)n, 1, K - 1, kids->ptr(), parent->ptr(), tab->ptr());
             const uint32_t first = PJ_BLOCK * K;
-            if (first < n) k_p2join_tail<<<dim3((unsigned)((n - first + 255) / 256), wd), 256, 0, ctx->stream>>>(data->ptr(), (uint32_t)n, A, first, noise_seed);
+            if (first < n) k_p2join_tail<<<dim3((unsigned)((n - first + 255) / 256), wd), 256, 0, ctx->stream>>>(data->ptr(), (uint32_t)n, A, first, nk);
         }
         ZKH_TRY(last_launch_error("p2join_witgen"));
         memcpy(out_global + 8, pub, 64);
@@ -878,7 +880,7 @@ extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t
         }
         {
             ProfScope prof(ctx, "keccak_expand", 4.0 * wd * n);
-            k_keccak_expand<<<dim3((unsigned)((n + 255) / 256), wd), 256, 0, ctx->stream>>>(data->ptr(), (const uint64_t*)rows->ptr(), (uint32_t)n, A, K, noise_seed);
+            k_keccak_expand<<<dim3((unsigned)((n + 255) / 256), wd), 256, 0, ctx->stream>>>(data->ptr(), (const uint64_t*)rows->ptr(), (uint32_t)n, A, K, nk);
         }
         ZKH_TRY(last_launch_error("keccak_witgen"));
         // out = the last permutation's OUTPUT state, then its INPUT state (row 0 of the last block), as 16-bit limbs: the claim binds the pair
@@ -901,7 +903,7 @@ extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t
     ZKH_TRY(new_buf(ctx, 1, false, last.out()));
     if (n_pub) ZKH_TRY(zkh_copy_from(ctx, "pub", pub, n_pub, dpub.out()));
     const unsigned bx = (unsigned)((n + 255) / 256);
-    k_syn_data<<<bx, 256, 0, ctx->stream>>>(data->ptr(), wd, (uint32_t)n, A, seed, noise_seed, dpub ? dpub->ptr() : nullptr, n_pub);
+    k_syn_data<<<bx, 256, 0, ctx->stream>>>(data->ptr(), wd, (uint32_t)n, A, seed, nk, dpub ? dpub->ptr() : nullptr, n_pub);
     ZKH_TRY(prefix_sum_column(ctx, data->ptr() + (size_t)(wd - 1) * n, A, last->ptr()));
     ZKH_TRY(last_launch_error("syn_witgen"));
     out_global[1] = out_global[2] = out_global[3] = 0;
@@ -911,7 +913,7 @@ extern "C" const char* zkh_syn_witgen(zkh_ctx* ctx, const zkh_circuit* c, size_t
 extern "C" const char* zkh_syn_chain_contributions(zkh_ctx* ctx, const zkh_circuit* c, const uint64_t* seeds, const uint32_t* po2s, size_t n,
                                                    size_t zk_cycles, uint32_t* contributions) {
     ZKH_REQUIRE(ctx && c && seeds && po2s && contributions, "syn_chain_contributions: null argument");
-    ZKH_REQUIRE(c->kind == 1 && c->global_size[GLOBAL_OUT] == 5, "syn_chain_contributions: the circuit is not a SYN-C circuit (kind 1 with one public input)");
+    ZKH_REQUIRE(circuit_has_state(c), "syn_chain_contributions: the circuit is not a SYN-C / SYN-S circuit (kind 1 whose first public input is the pre-state)");
     if (!n) return nullptr;
     for (size_t i = 0; i < n; i++) ZKH_REQUIRE(po2s[i] >= 1 && po2s[i] <= 24 && ((size_t)1 << po2s[i]) > zk_cycles + 1, "syn_chain_contributions: segment %zu: po2 out of range", i);
     Tmp dseeds, dpo2, dout;
@@ -922,9 +924,11 @@ extern "C" const char* zkh_syn_chain_contributions(zkh_ctx* ctx, const zkh_circu
     ZKH_TRY(last_launch_error("syn_chain_contrib"));
     return zkh_read(ctx, dout, contributions, 0, n);
 }
-extern "C" const char* zkh_syn_accum(zkh_ctx* ctx, const zkh_circuit* c, size_t po2, size_t zk_cycles, uint64_t noise_seed,
+extern "C" const char* zkh_syn_accum(zkh_ctx* ctx, const zkh_circuit* c, size_t po2, size_t zk_cycles, const uint32_t* noise_key,
                                      const zkh_buf* data, const uint32_t* mix_global, zkh_buf* accum) {
     ZKH_REQUIRE(c->kind >= 1 && c->kind <= 3, "syn_accum: no built-in accum witness generator for circuit kind %u", c->kind);
+    NoiseKey nk;
+    ZKH_TRY(resolve_noise_key(noise_key, &nk));
     const size_t n = (size_t)1 << po2;
     const uint32_t wa = c->group_size[GROUP_ACCUM], wd = c->group_size[GROUP_DATA], A = (uint32_t)(n - zk_cycles), k = wa / 4;
     ZKH_REQUIRE(accum->len == (size_t)wa * n && data->len == (size_t)wd * n, "syn_accum: buffer shape mismatch");
@@ -939,7 +943,7 @@ extern "C" const char* zkh_syn_accum(zkh_ctx* ctx, const zkh_circuit* c, size_t 
     ZKH_TRY(prefix_products_batched(ctx, terms->ptr(), n, k, 4 * n));      // all k running products in one set of launches
     {
         ProfScope prof(ctx, "syn_accum_store", (16.0 + 16.0) * k * n);
-        k_syn_accum_store<<<dim3(bx, k), 256, 0, ctx->stream>>>(accum->ptr(), terms->ptr(), (uint32_t)n, A, noise_seed);
+        k_syn_accum_store<<<dim3(bx, k), 256, 0, ctx->stream>>>(accum->ptr(), terms->ptr(), (uint32_t)n, A, nk);
     }
 
     return last_launch_error("syn_accum");

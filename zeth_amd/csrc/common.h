@@ -13,6 +13,7 @@
 
 #include "../../include/zkhal.h"
 #include "fp.h"
+#include "noise.h"
 
 namespace zkh {
 
@@ -116,6 +117,9 @@ const char* new_buf(zkh_ctx* c, size_t n_words, bool zero, zkh_buf** out);
 void prof_begin(zkh_ctx* c, const char* name, double bytes);
 void prof_end(zkh_ctx* c);
 const char* ensure_pinned(zkh_ctx* c, size_t words);
+// The blinding key of one seal / witness: the caller's 8 words, or — NULL or all-zero — 256 fresh bits from the OS (getrandom).  If
+// the OS cannot deliver, the call FAILS: predictable blinding rows would silently lose zero-knowledge.  (hal.hip)
+const char* resolve_noise_key(const uint32_t* key_or_null, NoiseKey* out);
 
 // The HIP "current device" is per host thread: every entry point binds the calling thread to the context's GPU
 // (several host threads may each drive their own context on the same or on different GPUs).  No caching: other code

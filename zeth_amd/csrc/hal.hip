@@ -4,6 +4,8 @@
 #include <algorithm>
 
 #include "common.h"
+
+#include <sys/random.h>
 #include "poseidon2.h"
 #include "../../include/zkh_poseidon2_consts.h"
 
@@ -103,6 +105,28 @@ static const char* upload(uint32_t** dst, const std::vector<uint32_t>& v) {
     ZKH_HIP(hipMalloc((void**)dst, v.size() * 4));
     ZKH_HIP(hipMemcpy(*dst, v.data(), v.size() * 4, hipMemcpyHostToDevice));
     return nullptr;
+}
+const char* zkh::resolve_noise_key(const uint32_t* key, NoiseKey* out) {
+    bool given = false;
+    if (key) for (int i = 0; i < 8; i++) given = given || key[i] != 0;
+    if (given) { memcpy(out->k, key, sizeof out->k); return nullptr; }
+    bool ok = false;
+    for (int tries = 0; tries < 4 && !ok; tries++) {
+        ok = getrandom(out->k, sizeof out->k, 0) == (ssize_t)sizeof out->k;
+        bool nonzero = false;
+        for (int i = 0; i < 8; i++) nonzero = nonzero || out->k[i] != 0;
+        ok = ok && nonzero;
+    }
+    ZKH_REQUIRE(ok, "OS randomness (getrandom) is unavailable: refusing to seal with a predictable blinding key");
+    return nullptr;
+}
+extern "C" uint32_t zkh_noise_cell_host(const uint32_t noise_key[8], uint32_t group, uint32_t column, uint32_t row) {
+    NoiseKey k;
+    memcpy(k.k, noise_key, sizeof k.k);
+    return noise_cell(k, group, column, row);
+}
+extern "C" void zkh_chacha_block_host(const uint32_t key[8], const uint32_t counter_nonce[4], int double_rounds, uint32_t out[16]) {
+    chacha_block(key, counter_nonce[0], counter_nonce[1], counter_nonce[2], counter_nonce[3], double_rounds, out, 16);
 }
 static std::vector<uint32_t> powers(Fp base, size_t n) {
     std::vector<uint32_t> v(n);

@@ -43,11 +43,11 @@ __device__ __forceinline__ uint32_t pf_cell(uint64_t seed, uint32_t group, uint3
 // consecutive words of every column).  Triple 0 = (w0, w1) and triple 1 = (w3, w2) are the machine's own values, every other
 // free cell is hashed from the record; products, the degree-4 product and the running-sum increment as in k_syn_data.
 __global__ __launch_bounds__(256) void k_syn_rowfill(uint32_t* __restrict__ data, const uint4* __restrict__ records, uint32_t wd, uint32_t n,
-                                                     uint32_t A, uint64_t noise_seed) {
+                                                     uint32_t A, NoiseKey nk) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     if (r >= A) {
-        for (uint32_t c = 0; c < wd; c++) data[(size_t)c * n + r] = pf_cell(noise_seed, GROUP_DATA, c, r);
+        for (uint32_t c = 0; c < wd; c++) data[(size_t)c * n + r] = noise_cell(nk, GROUP_DATA, c, r);      // blinding rows: noise.h
         return;
     }
     const uint4 rec = records[r];                      // (w0, w1, w2, w3)
@@ -121,7 +121,7 @@ extern "C" const char* zkh_syn_preflight(uint64_t seed, size_t po2, size_t zk_cy
 // records (DEVICE buffer, 4 x A words, e.g. uploaded with zkh_write_async) + the RAM image (host, or NULL) -> code (NULL: the
 // caller holds this size's code group), data, out_global.  One row-fill launch, the running-sum scan, and the preload through
 // Hal::scatter: the first unconstrained data column (3 T, where the shape has one) gets the RAM image in rows [0, 1024).
-extern "C" const char* zkh_syn_witgen_trace(zkh_ctx* ctx, const zkh_circuit* c, size_t po2, size_t zk_cycles, uint64_t noise_seed,
+extern "C" const char* zkh_syn_witgen_trace(zkh_ctx* ctx, const zkh_circuit* c, size_t po2, size_t zk_cycles, const uint32_t* noise_key,
                                             const zkh_buf* records, const uint32_t* ram_image, zkh_buf* code, zkh_buf* data, uint32_t* out_global) {
     ZKH_REQUIRE(ctx && c && records && data && out_global, "syn_witgen_trace: null argument");
     ZKH_REQUIRE(c->kind == 1 && c->global_size[GLOBAL_OUT] == 4, "syn_witgen_trace: only SYN-AIR circuits (kind 1) without public inputs are trace-driven");
@@ -132,9 +132,11 @@ extern "C" const char* zkh_syn_witgen_trace(zkh_ctx* ctx, const zkh_circuit* c, 
     ZKH_REQUIRE(data->len == (size_t)wd * n && (!code || code->len == (size_t)wc * n), "syn_witgen_trace: buffer shape mismatch");
     ZKH_REQUIRE(((uintptr_t)records->ptr() & 15) == 0, "syn_witgen_trace: the record buffer must be 16-byte aligned");
     if (code) ZKH_TRY(zkh_syn_code(ctx, c, po2, zk_cycles, code));
+    NoiseKey nk;
+    ZKH_TRY(resolve_noise_key(noise_key, &nk));
     {
         ProfScope prof(ctx, "syn_rowfill", 16.0 * A + 4.0 * wd * n);
-        k_syn_rowfill<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(data->ptr(), (const uint4*)records->ptr(), wd, (uint32_t)n, A, noise_seed);
+        k_syn_rowfill<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(data->ptr(), (const uint4*)records->ptr(), wd, (uint32_t)n, A, nk);
         ZKH_TRY(last_launch_error("syn_rowfill"));
     }
     Tmp last;

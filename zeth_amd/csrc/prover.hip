@@ -310,7 +310,7 @@ extern "C" const char* zkh_prove_finish(zkh_seal_job* job_raw, const zkh_buf* ac
 }
 
 // SegmentProver::prove for the SYN-AIR family (kind 1), whose accum witness generator lives in this library.
-extern "C" const char* zkh_prove_segment(zkh_prover* pr, size_t po2, size_t zk_cycles, uint64_t noise_seed, const zkh_buf* code,
+extern "C" const char* zkh_prove_segment(zkh_prover* pr, size_t po2, size_t zk_cycles, const uint32_t* noise_key, const zkh_buf* code,
                                          const zkh_buf* data, const uint32_t* out_global, uint32_t** seal, size_t* seal_words) {
     ZKH_REQUIRE(pr && data && out_global && seal && seal_words, "prove_segment: null argument");
     zkh_ctx* c = pr->ctx;
@@ -324,7 +324,7 @@ extern "C" const char* zkh_prove_segment(zkh_prover* pr, size_t po2, size_t zk_c
     std::unique_ptr<zkh_seal_job> job(job_raw);
     Buf accum;
     ZKH_TRY(zkh_alloc(c, "accum", (size_t)cir->group_size[GROUP_ACCUM] * n, 0, accum.out()));
-    ZKH_TRY(zkh_syn_accum(c, cir, po2, zk_cycles, noise_seed, data, job->mix_global.data(), accum));
+    ZKH_TRY(zkh_syn_accum(c, cir, po2, zk_cycles, noise_key, data, job->mix_global.data(), accum));
     return prove_finish_impl(job.get(), accum, seal, seal_words);
 }
 

@@ -729,7 +729,7 @@ struct Verifier {
         ZKH_TRY(verify_seal(c, po2, s));
         const auto root_words = digest_words(s.code_root);
         for (size_t i = 0; i < 8; i++) { const int k = pr.constant(control_root[i]); pr.eq(root_words[i], k); }
-        const bool chained = c.kind == 1 && c.global_size[0] == 5;              // SYN-C: out = (post, 0, 0, 0, pre)
+        const bool chained = c.kind == 1 && (c.global_size[0] == 5 || c.global_size[0] == 23);   // SYN-C / SYN-S: out = (post, 0, 0, 0, pre, ..)
         if (chained) { pre = s.out[4]; post = s.out[0]; } else { pre = pr.zero(); post = pr.zero(); }
         std::vector<int> words = s.out;
         words.push_back(pr.constant(po2));

@@ -209,20 +209,11 @@ __global__ __launch_bounds__(256) void k_rec_p2_wide(const uint32_t* __restrict_
     if (live && j < 6) val[o[1] + j] = make_uint4(c[0], c[1], c[2], c[3]);
 }
 
-__device__ __forceinline__ uint32_t rc_cell(uint64_t seed, uint32_t group, uint32_t col, uint32_t row) {   // = syn_cell of circuit.hip
-    uint64_t z = seed ^ ((uint64_t)(group + 1) * 0x9E3779B97F4A7C15ull);
-    z += (uint64_t)col * 0xBF58476D1CE4E5B9ull;
-    z += (uint64_t)row * 0x94D049BB133111EBull;
-    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
-    z ^= z >> 27; z *= 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return mul_mod(R2, (uint32_t)(z >> 32) % P);
-}
 __device__ __forceinline__ bool rc_is_full(uint32_t rnd) { return rnd < 4 || rnd >= 25; }
 
 // wires: one lane per (row, wire); rows past A are blinding noise (all 72 data columns: blockIdx.y < 6 covers W, the rest below)
 __global__ void k_rec_fill_wires(uint32_t* data, const uint32_t* __restrict__ pos, const uint4* __restrict__ val, uint32_t n, uint32_t A,
-                                 uint64_t noise_seed) {
+                                 NoiseKey nk) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
     if (r >= n) return;
     uint4 x = make_uint4(0, 0, 0, 0);
@@ -230,17 +221,17 @@ __global__ void k_rec_fill_wires(uint32_t* data, const uint32_t* __restrict__ po
         const uint32_t v = pos[(size_t)r * RC_NW + w];
         if (v) x = val[v - 1];
     } else {
-        x = make_uint4(rc_cell(noise_seed, GROUP_DATA, 4 * w, r), rc_cell(noise_seed, GROUP_DATA, 4 * w + 1, r),
-                       rc_cell(noise_seed, GROUP_DATA, 4 * w + 2, r), rc_cell(noise_seed, GROUP_DATA, 4 * w + 3, r));
+        x = make_uint4(noise_cell(nk, GROUP_DATA, 4 * w, r), noise_cell(nk, GROUP_DATA, 4 * w + 1, r),
+                       noise_cell(nk, GROUP_DATA, 4 * w + 2, r), noise_cell(nk, GROUP_DATA, 4 * w + 3, r));
     }
     data[(size_t)(4 * w) * n + r] = x.x; data[(size_t)(4 * w + 1) * n + r] = x.y;
     data[(size_t)(4 * w + 2) * n + r] = x.z; data[(size_t)(4 * w + 3) * n + r] = x.w;
 }
 // S / Q columns outside the blocks: zero while active, noise after
-__global__ void k_rec_fill_tail(uint32_t* data, uint32_t n, uint32_t A, uint32_t first_row, uint64_t noise_seed) {
+__global__ void k_rec_fill_tail(uint32_t* data, uint32_t n, uint32_t A, uint32_t first_row, NoiseKey nk) {
     const uint32_t r = first_row + blockIdx.x * blockDim.x + threadIdx.x, col = RC_T + blockIdx.y;
     if (r >= n) return;
-    data[(size_t)col * n + r] = r < A ? 0u : rc_cell(noise_seed, GROUP_DATA, col, r);
+    data[(size_t)col * n + r] = r < A ? 0u : noise_cell(nk, GROUP_DATA, col, r);
 }
 __device__ void rc_m_ext(uint32_t (&c)[RC_T]) {
     uint32_t sums[4] = {0, 0, 0, 0};
@@ -359,7 +350,7 @@ __global__ void k_rec_accum_terms(uint32_t* terms, const uint32_t* __restrict__ 
     }
     ((uint4*)terms)[(size_t)k * n + r] = make_uint4(t.c[0].v, t.c[1].v, t.c[2].v, t.c[3].v);
 }
-__global__ void k_rec_accum_store(uint32_t* accum, const uint32_t* prods, uint32_t n, uint32_t A, uint64_t noise_seed) {
+__global__ void k_rec_accum_store(uint32_t* accum, const uint32_t* prods, uint32_t n, uint32_t A, NoiseKey nk) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, e = blockIdx.y;
     if (r >= n) return;
     uint32_t v[4];
@@ -367,7 +358,7 @@ __global__ void k_rec_accum_store(uint32_t* accum, const uint32_t* prods, uint32
         const uint4 p = ((const uint4*)prods)[(size_t)e * n + r];
         v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w;
     } else {
-        for (int i = 0; i < 4; i++) v[i] = rc_cell(noise_seed, GROUP_ACCUM, 4 * e + i, r);
+        for (int i = 0; i < 4; i++) v[i] = noise_cell(nk, GROUP_ACCUM, 4 * e + i, r);
     }
     for (int i = 0; i < 4; i++) accum[(size_t)(4 * e + i) * n + r] = v[i];
 }
@@ -593,13 +584,15 @@ extern "C" const char* zkh_rec_program_info(const zkh_rec_program* p, uint32_t r
 // The witness: runs the program on `inputs` (raw Montgomery words: the child seals and what else the program reads), fills
 // data (72 x n) and out_global (16 words).  An assertion of the program that fails - the inputs are not what the program
 // verifies - is an error naming the op, not a trace.
-extern "C" const char* zkh_rec_witgen(const zkh_rec_program* p, const uint32_t* inputs, size_t n_inputs, uint64_t noise_seed, zkh_buf* data,
+extern "C" const char* zkh_rec_witgen(const zkh_rec_program* p, const uint32_t* inputs, size_t n_inputs, const uint32_t* noise_key, zkh_buf* data,
                                       uint32_t out_global[16]) {
     ZKH_REQUIRE(p && data && out_global && (inputs || !p->n_inputs), "rec_witgen: null argument");
     ZKH_REQUIRE(n_inputs == p->n_inputs, "rec_witgen: the program reads %u input words, %zu were given", p->n_inputs, n_inputs);
     zkh_ctx* c = p->ctx;
     const size_t n = (size_t)1 << p->po2;
     ZKH_REQUIRE(data->len == (size_t)RC_WD * n, "rec_witgen: buffer shape mismatch");
+    NoiseKey nk;
+    ZKH_TRY(resolve_noise_key(noise_key, &nk));
     Tmp pub;
     zkh_buf *val = p->d_val, *fail = p->d_fail;
     const uint32_t none = 0xffffffffu;
@@ -620,10 +613,10 @@ extern "C" const char* zkh_rec_witgen(const zkh_rec_program* p, const uint32_t* 
     {
         ProfScope prof(c, "rec_fill", 4.0 * RC_WD * n);
         const unsigned bx = (unsigned)((n + 255) / 256);
-        k_rec_fill_wires<<<dim3(bx, RC_NW), 256, 0, c->stream>>>(data->ptr(), p->d_pos->ptr(), (const uint4*)val->ptr(), (uint32_t)n, A, noise_seed);
+        k_rec_fill_wires<<<dim3(bx, RC_NW), 256, 0, c->stream>>>(data->ptr(), p->d_pos->ptr(), (const uint4*)val->ptr(), (uint32_t)n, A, nk);
         k_rec_blocks<<<(K + 63) / 64, 64, 0, c->stream>>>(data->ptr(), (uint32_t)n, K, p->d_tab->ptr(), p->d_table->ptr());
         const uint32_t first = RC_BLOCK * K;
-        if (first < n) k_rec_fill_tail<<<dim3((unsigned)((n - first + 255) / 256), 2 * RC_T), 256, 0, c->stream>>>(data->ptr(), (uint32_t)n, A, first, noise_seed);
+        if (first < n) k_rec_fill_tail<<<dim3((unsigned)((n - first + 255) / 256), 2 * RC_T), 256, 0, c->stream>>>(data->ptr(), (uint32_t)n, A, first, nk);
     }
     ZKH_TRY(last_launch_error("rec_fill"));
     ZKH_TRY(new_buf(c, 16, true, pub.out()));
@@ -636,8 +629,10 @@ extern "C" const char* zkh_rec_witgen(const zkh_rec_program* p, const uint32_t* 
     return nullptr;
 }
 
-extern "C" const char* zkh_rec_accum(const zkh_rec_program* p, uint64_t noise_seed, const zkh_buf* data, const uint32_t* mix_global, zkh_buf* accum) {
+extern "C" const char* zkh_rec_accum(const zkh_rec_program* p, const uint32_t* noise_key, const zkh_buf* data, const uint32_t* mix_global, zkh_buf* accum) {
     ZKH_REQUIRE(p && data && mix_global && accum, "rec_accum: null argument");
+    NoiseKey nk;
+    ZKH_TRY(resolve_noise_key(noise_key, &nk));
     zkh_ctx* c = p->ctx;
     const size_t n = (size_t)1 << p->po2;
     ZKH_REQUIRE(accum->len == (size_t)RC_WA * n && data->len == (size_t)RC_WD * n, "rec_accum: buffer shape mismatch");
@@ -652,27 +647,29 @@ extern "C" const char* zkh_rec_accum(const zkh_rec_program* p, uint64_t noise_se
     ZKH_TRY(prefix_products_batched(c, terms->ptr(), n, 3, 4 * n));
     {
         ProfScope prof(c, "rec_accum_store", 32.0 * 3 * n);
-        k_rec_accum_store<<<dim3(bx, 3), 256, 0, c->stream>>>(accum->ptr(), terms->ptr(), (uint32_t)n, p->A, noise_seed);
+        k_rec_accum_store<<<dim3(bx, 3), 256, 0, c->stream>>>(accum->ptr(), terms->ptr(), (uint32_t)n, p->A, nk);
     }
     return last_launch_error("rec_accum");
 }
 
 // One lift / join: witness, seal.  The code group is the resident one committed at load.
-extern "C" const char* zkh_rec_prove(const zkh_rec_program* p, const uint32_t* inputs, size_t n_inputs, uint64_t noise_seed,
+extern "C" const char* zkh_rec_prove(const zkh_rec_program* p, const uint32_t* inputs, size_t n_inputs, const uint32_t* noise_key,
                                      uint32_t out_global[16], uint32_t** seal, size_t* seal_words) {
     ZKH_REQUIRE(p && seal && seal_words, "rec_prove: null argument");
     zkh_ctx* c = p->ctx;
     const size_t n = (size_t)1 << p->po2;
     Tmp data, accum;
     uint32_t out[16];
+    NoiseKey nk;                                       // one key per proof (NULL / all-zero: fresh from the OS), shared by its two generators
+    ZKH_TRY(resolve_noise_key(noise_key, &nk));
     ZKH_TRY(new_buf(c, (size_t)RC_WD * n, false, data.out()));
-    ZKH_TRY(zkh_rec_witgen(p, inputs, n_inputs, noise_seed, data.b, out));
+    ZKH_TRY(zkh_rec_witgen(p, inputs, n_inputs, nk.k, data.b, out));
     if (out_global) memcpy(out_global, out, sizeof out);
     zkh_seal_job* job = nullptr;
     uint32_t mix[20];
     ZKH_TRY(zkh_prove_begin(p->prover, p->po2, nullptr, data.b, out, &job, mix));
     const char* e = new_buf(c, (size_t)RC_WA * n, false, accum.out());
-    if (!e) e = zkh_rec_accum(p, noise_seed, data.b, mix, accum.b);
+    if (!e) e = zkh_rec_accum(p, nk.k, data.b, mix, accum.b);
     if (e) { zkh_prove_abort(job); return e; }
     return zkh_prove_finish(job, accum.b, seal, seal_words);
 }

@@ -29,17 +29,6 @@ namespace {
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// Blinding seeds come from the OS; if it cannot deliver, the seal must FAIL rather than run with a guessable seed
-// (predictable blinding rows would silently lose zero-knowledge).
-const char* os_random64(uint64_t* out) {
-    uint64_t v = 0;
-    for (int tries = 0; tries < 4 && !v; tries++)
-        if (getrandom(&v, sizeof v, 0) != (ssize_t)sizeof v) v = 0;
-    ZKH_REQUIRE(v != 0, "OS randomness (getrandom) is unavailable: refusing to seal with a predictable blinding seed");
-    *out = v;
-    return nullptr;
-}
-
 struct Lane {
     int device = 0;
     zkh_ctx* ctx = nullptr;
@@ -162,7 +151,7 @@ static const char* wrap_claim(const NodeClaim& c, uint32_t out[8]) {
 // (receipt claim, pre, post) of a segment seal: SYN-C circuits (kind 1, five outputs) carry their state in out[4] / out[0]
 static const char* leaf_claim(const zkh_circuit* c, const uint32_t* seal, size_t words, const uint32_t* control_root, NodeClaim* out) {
     ZKH_TRY(zkh_receipt_claim(c, seal, words, control_root, nullptr, nullptr, out->core));
-    const bool chained = c->kind == 1 && c->global_size[GLOBAL_OUT] == 5;
+    const bool chained = circuit_has_state(c);
     out->pre = chained ? seal[4] : 0; out->post = chained ? seal[0] : 0;
     return nullptr;
 }
@@ -314,8 +303,8 @@ extern "C" const char* zkh_session_set_recursion(zkh_session* s, const uint32_t*
 extern "C" void zkh_session_set_streamed_fold(zkh_session* s, int on) { if (s) s->streamed_fold = on != 0; }
 extern "C" const char* zkh_session_set_chained(zkh_session* s, int on, uint32_t initial_state) {
     ZKH_REQUIRE(s, "session_set_chained: null session");
-    ZKH_REQUIRE(!on || (s->lanes[0].circuit->kind == 1 && s->lanes[0].circuit->global_size[GLOBAL_OUT] == 5),
-                "session_set_chained: continuity needs a SYN-C circuit (kind 1 with one public input: the pre-state)");
+    ZKH_REQUIRE(!on || circuit_has_state(s->lanes[0].circuit),
+                "session_set_chained: continuity needs a SYN-C or SYN-S circuit (kind 1 whose first public input is the pre-state)");
     ZKH_REQUIRE(initial_state < P, "session_set_chained: the initial state is not a reduced element");
     s->chained = on != 0; s->initial_state = initial_state;
     return nullptr;
@@ -421,8 +410,9 @@ static const char* seal_one(zkh_session* s, Lane& l, const zkh_segment& seg, uin
                             const uint32_t* records = nullptr, const uint32_t* ram = nullptr, double* preflight_cpu_s = nullptr, double* trace_bytes = nullptr) {
     const zkh_circuit* cir = l.circuit;
     const size_t n = (size_t)1 << seg.po2;
-    uint64_t noise = seg.noise_seed;
-    if (!noise) ZKH_TRY(os_random64(&noise));
+    NoiseKey nk;                                   // this segment's blinding key: the caller's, or (all-zero) 256 fresh bits from the OS
+    ZKH_TRY(resolve_noise_key(seg.noise_key, &nk));
+    const uint32_t* noise = nk.k;
     Tmp code, data;
     ZKH_TRY(zkh_alloc(l.ctx, "code", (size_t)cir->group_size[GROUP_CODE] * n, 0, code.out()));
     ZKH_TRY(zkh_alloc(l.ctx, "data", (size_t)cir->group_size[GROUP_DATA] * n, 0, data.out()));
@@ -483,7 +473,7 @@ static const char* seal_one(zkh_session* s, Lane& l, const zkh_segment& seg, uin
     return zkh_prove_segment(l.prover, seg.po2, ZKH_ZK_CYCLES, noise, code_arg, data, out_global.data(), seal, words);
 }
 
-extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs, size_t n, int join_tree, size_t join_po2, uint64_t join_noise_seed,
+extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs, size_t n, int join_tree, size_t join_po2, const uint32_t* join_noise_key,
                                          zkh_prove_info* info) {
     ZKH_REQUIRE(s && segs && n && info, "session_prove: bad argument");
     ZKH_REQUIRE(join_tree != 1 || !s->join_desc.empty(), "session_prove: the session was created without a join circuit");
@@ -516,11 +506,25 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
             zkh_prove_info_free(info);
             return e;
         }
-        pre_states.resize(n);
+        // SYN-C: one public word per segment (the pre-state).  SYN-S: 19 — pre-state, the exit code pair (SystemSplit (2, 0) for
+        // every segment but the last, Halted(0) (0, 0) for the last) and the 16 limbs of SHA-256(journal), zero except in the last
+        // segment; the journal of a session is its final state word (canonical residue, 4 bytes little-endian).
+        const bool sess = circuit_is_session(s->lanes[0].circuit);
+        const size_t pw = sess ? SESSION_OUT_WORDS - 4 : 1;
+        pre_states.assign(n * pw, 0);
         uint32_t state = fp_encode(s->initial_state).v;
-        for (size_t i = 0; i < n; i++) { pre_states[i] = state; state = add_mod(state, contrib[i]); }
+        for (size_t i = 0; i < n; i++) { pre_states[i * pw] = state; state = add_mod(state, contrib[i]); }
+        if (sess) {
+            uint32_t limbs[SESSION_JOURNAL_LIMBS];
+            session_journal_limbs(state, limbs);
+            for (size_t i = 0; i < n; i++) {
+                const bool is_last = i + 1 == n;
+                pre_states[i * pw + 1] = fp_encode(is_last ? EXIT_SYS_HALTED : EXIT_SYS_SPLIT).v;
+                if (is_last) memcpy(&pre_states[i * pw + 3], limbs, sizeof limbs);
+            }
+        }
         chained_segs.assign(segs, segs + n);
-        for (size_t i = 0; i < n; i++) { chained_segs[i].pub = &pre_states[i]; chained_segs[i].n_pub = 1; }
+        for (size_t i = 0; i < n; i++) { chained_segs[i].pub = &pre_states[i * pw]; chained_segs[i].n_pub = pw; }
         segs = chained_segs.data();
     }
 
@@ -651,10 +655,18 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
     size_t bottom_done = 0;
     const char* renv = getenv("ZKH_SEGMENT_RETRIES");
     const int max_retries = renv ? atoi(renv) : 1;
-    const char* fenv = getenv("ZKH_FAULT_SEGMENT");            // fault injection (tests): the FIRST attempt at this segment fails
-    const long fault_seg = fenv ? atol(fenv) : -1;
-    const char* faenv = getenv("ZKH_FAULT_SEGMENT_ALWAYS");    // ... every attempt at this segment fails
-    const long fault_always = faenv ? atol(faenv) : -1;
+    // Fault injection (tests of the retry path): ZKH_FAULT_SEGMENT=<i> fails the FIRST attempt at segment i, ZKH_FAULT_SEGMENT_ALWAYS=<i>
+    // every attempt.  Armed only by a value that parses STRICTLY as a decimal index (an empty or stray variable arms nothing: atol("")
+    // was 0 = segment 0) and only together with ZKH_TEST_HOOKS=1, which no deployment sets.
+    auto fault_index = [](const char* name) -> long {
+        const char* v = getenv(name);
+        const char* armed = getenv("ZKH_TEST_HOOKS");
+        if (!v || !*v || !armed || strcmp(armed, "1") != 0) return -1;
+        char* end = nullptr;
+        const long k = strtol(v, &end, 10);
+        return (end && *end == 0 && k >= 0) ? k : -1;
+    };
+    const long fault_seg = fault_index("ZKH_FAULT_SEGMENT"), fault_always = fault_index("ZKH_FAULT_SEGMENT_ALWAYS");
     const double t0 = now_s();
 
     auto finished = [&] { return errs.any() || (seals_done == n && root_done); };            // call with m held
@@ -692,9 +704,7 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
             }
             in.insert(in.end(), A.begin(), A.end());
         }
-        uint64_t noise = join_noise_seed;
-        if (!noise) ZKH_TRY(os_random64(&noise));
-        ZKH_TRY(zkh_rec_prove(l->programs[nd.program], in.data(), in.size(), noise, nullptr, &nd.seal, &nd.words));
+        ZKH_TRY(zkh_rec_prove(l->programs[nd.program], in.data(), in.size(), join_noise_key, nullptr, &nd.seal, &nd.words));    // NULL: a fresh OS key per proof
         if (nd.kind == 1 || nd.kind == 3) {                    // children are not kept: the verifier needs the root only
             zkh_free_seal(plan[nd.a].seal); zkh_free_seal(plan[nd.b].seal);
             plan[nd.a].seal = plan[nd.b].seal = nullptr;
@@ -717,7 +727,10 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
     if (use_pre) {
         uint32_t max_po2 = 0;
         for (size_t i = 0; i < n; i++) {
-            ZKH_REQUIRE(!segs[i].host_code && !segs[i].host_data && !segs[i].n_pub, "session_prove: witness source 1 takes segments described by their seed only");
+            if (segs[i].host_code || segs[i].host_data || segs[i].n_pub) {       // (info's arrays are allocated: every early return frees them)
+                zkh_prove_info_free(info);
+                return make_err("session_prove: witness source 1 takes segments described by their seed only");
+            }
             max_po2 = std::max(max_po2, segs[i].po2);
         }
         const size_t slot_words = ((size_t)4 << max_po2) + ram_words;          // records, then the RAM image
@@ -793,7 +806,12 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
                 const double te = now_s();
                 lk.lock();
                 pre_cpu_sum += pcpu; trace_bytes_sum += tbytes;
-                if (slot) { laneq[lane_idx].free_slots.push_back(slot); cv.notify_all(); }      // the upload is done: the seal ended with a host sync
+                if (slot) {
+                    // a successful seal ended with a host sync, so the upload from this pinned slot is done; a FAILED one may have returned
+                    // with the async H2D still in flight: drain the lane's stream before a producer may overwrite the slot
+                    if (err) { lk.unlock(); if (const char* se = zkh_sync(l->ctx)) zkh_free_error(se); lk.lock(); }
+                    laneq[lane_idx].free_slots.push_back(slot); cv.notify_all();
+                }
                 if (err) {
                     if (attempts[seg]++ < max_retries) {       // hand it to another lane / device
                         zkh_free_error(err);
@@ -915,8 +933,9 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
                         if (k >= pairs || errs.any()) break;
                         memcpy(pub, claims[2 * k].data(), 32);
                         memcpy(pub + 8, claims[2 * k + 1].data(), 32);
-                        uint64_t noise = join_noise_seed;
-                        if (!noise && errs.set(os_random64(&noise), "join noise")) break;
+                        NoiseKey jk;
+                        if (errs.set(resolve_noise_key(join_noise_key, &jk), "join noise")) break;
+                        const uint32_t* noise = jk.k;
                         if (errs.set(zkh_syn_witgen(l->ctx, jc, join_po2, ZKH_ZK_CYCLES, 0, noise, pub, code, data, outg), "join witgen") ||
                             errs.set(zkh_prove_segment(l->join_prover, join_po2, ZKH_ZK_CYCLES, noise, code, data, outg, &seals[k], &words[k]), "join seal")) break;
                         memcpy(up[k].data(), seals[k], 32);
@@ -990,6 +1009,16 @@ extern "C" const char* zkh_session_verify(zkh_session* s, const zkh_segment* seg
             ZKH_REQUIRE(info->seal_words[i] > 5 && info->seals[i][4] == prev, "session_verify: the session is not continuous: segment %zu does not start from its predecessor's post-state", i);
             prev = info->seals[i][0];
         }
+        // SYN-S: the session TERMINATES here — every segment but the last says SystemSplit, the last Halted(0) and carries the digest
+        // of the journal (= the final state word): a receipt with trailing segments cut off ends in a SystemSplit and is refused
+        if (circuit_is_session(s->lanes[0].circuit)) {
+            std::vector<const uint32_t*> seals(info->n_segments);
+            for (size_t i = 0; i < info->n_segments; i++) {
+                ZKH_REQUIRE(info->seal_words[i] > SESSION_OUT_WORDS, "session_verify: segment %zu: seal too short", i);
+                seals[i] = info->seals[i];
+            }
+            ZKH_TRY(check_session_termination(seals.data(), info->n_segments, nullptr, 0));
+        }
     }
     if (!info->root_seal) return nullptr;
     if (info->n_lifts) {
@@ -1008,7 +1037,7 @@ extern "C" const char* zkh_session_verify(zkh_session* s, const zkh_segment* seg
         std::vector<NodeClaim> nodes(info->n_segments);
         for (size_t i = 0; i < info->n_segments; i++) {
             memcpy(nodes[i].core, claims[i].data(), 32);
-            const bool chained = hc->kind == 1 && hc->global_size[GLOBAL_OUT] == 5;
+            const bool chained = circuit_has_state(hc);
             nodes[i].pre = chained ? info->seals[i][4] : 0; nodes[i].post = chained ? info->seals[i][0] : 0;
         }
         // ... in the shape of the fold plan (fold_claim_nodes: pairs, then three at a time)

@@ -7,6 +7,7 @@
 
 #include "../../include/zkh_poseidon2_consts.h"
 #include "circuit.h"
+#include "sha256.h"
 #include "poseidon2.h"
 
 using namespace zkh;
@@ -420,4 +421,51 @@ extern "C" const char* zkh_receipt_decode(const zkh_circuit* c, const uint32_t* 
     memcpy(info, blob, 4 * RECEIPT_HEADER);
     *seal_offset = RECEIPT_HEADER;
     return nullptr;
+}
+
+// ---- sessions that terminate (SYN-S, zeth_amd/circuits/syn_air.py syn_session): the words a segment's seal binds beside its state ----
+// limbs of SHA-256(journal) for the journal of a session = its final state word as 4 little-endian bytes of the canonical residue
+void zkh::session_journal_limbs(uint32_t final_state_mont, uint32_t limbs[16]) {
+    const uint32_t v = fp_decode(Fp::raw(final_state_mont));
+    const uint8_t j[4] = {(uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16), (uint8_t)(v >> 24)};
+    uint8_t d[32];
+    sha256(j, 4, d);
+    for (int k = 0; k < 16; k++) limbs[k] = fp_encode((uint32_t)d[2 * k] | (uint32_t)d[2 * k + 1] << 8).v;
+}
+// `CompositeReceipt::verify_integrity` + the exit-code / journal checks behind `receipt.verify(image_id)` and the journal
+// comparison (/root/reference/crates/host/src/bin/cli.rs:103-107) on seals that have ALREADY been verified: every segment but the
+// last carries SystemSplit, the last Halted(0) and the digest of the journal.  journal == NULL: the journal is the session's final
+// state word (what zkh_session_prove binds); otherwise the caller's journal bytes must hash to the limbs the last seal carries.
+const char* zkh::check_session_termination(const uint32_t* const* seals, size_t n, const uint8_t* journal, size_t journal_len) {
+    ZKH_REQUIRE(seals && n, "session termination: no segments");
+    const uint32_t split = fp_encode(EXIT_SYS_SPLIT).v;
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t sys = seals[i][SESSION_EXIT_SYS], user = seals[i][SESSION_EXIT_USER];
+        if (i + 1 < n) {
+            ZKH_REQUIRE(sys == split && user == 0, "session: segment %zu of %zu does not end in SystemSplit (exit code pair %u, %u): the segments are not those of one session",
+                        i, n, fp_decode(Fp::raw(sys)), fp_decode(Fp::raw(user)));
+            for (uint32_t k = 0; k < SESSION_JOURNAL_LIMBS; k++) ZKH_REQUIRE(seals[i][SESSION_JOURNAL + k] == 0, "session: segment %zu carries an output although it did not halt", i);
+        } else {
+            ZKH_REQUIRE(sys == fp_encode(EXIT_SYS_HALTED).v && user == 0, "session: the last segment (%zu) does not say Halted(0) (exit code pair %u, %u): the session was cut short or did not succeed",
+                        i, fp_decode(Fp::raw(sys)), fp_decode(Fp::raw(user)));
+            uint32_t want[16];
+            if (journal) {
+                uint8_t d[32];
+                sha256(journal, journal_len, d);
+                for (int k = 0; k < 16; k++) want[k] = fp_encode((uint32_t)d[2 * k] | (uint32_t)d[2 * k + 1] << 8).v;
+            } else {
+                session_journal_limbs(seals[i][0], want);
+            }
+            ZKH_REQUIRE(memcmp(seals[i] + SESSION_JOURNAL, want, sizeof want) == 0, "session: the journal does not hash to the output digest the last segment's seal binds");
+        }
+    }
+    return nullptr;
+}
+extern "C" void zkh_sha256(const uint8_t* data, size_t len, uint8_t out[32]) { sha256(data, len, out); }
+extern "C" const char* zkh_session_check_termination(const zkh_circuit* c, const uint32_t* const* seals, const size_t* seal_words, size_t n,
+                                                     const uint8_t* journal, size_t journal_len) {
+    ZKH_REQUIRE(c && seals && seal_words && n, "session_check_termination: null argument");
+    ZKH_REQUIRE(circuit_is_session(c), "session_check_termination: the circuit's segments carry no exit code (not a SYN-S circuit)");
+    for (size_t i = 0; i < n; i++) ZKH_REQUIRE(seals[i] && seal_words[i] > SESSION_OUT_WORDS, "session_check_termination: segment %zu: seal too short", i);
+    return check_session_termination(seals, n, journal, journal_len);
 }

@@ -26,12 +26,39 @@ def fp_decode(word: int) -> int:
     return (int(word) * _RINV) % P
 
 
+def noise_key(noise_seed) -> Optional[np.ndarray]:
+    """The 8-word blinding key of include/zkhal.h (BLINDING ROWS) from the `noise_seed` this package's API takes: an integer below
+    2^256 (little-endian words; 0x2E80 -> (0x2E80, 0, ..)), 32 bytes, or 8 words; None / 0 -> None = NULL at the ABI = a fresh 256-bit
+    key from the OS for that call (the product default)."""
+    if noise_seed is None:
+        return None
+    if isinstance(noise_seed, (bytes, bytearray)):
+        noise_seed = int.from_bytes(noise_seed, "little")
+    if isinstance(noise_seed, (int, np.integer)):
+        v = int(noise_seed)
+        if v == 0:
+            return None
+        if not 0 < v < (1 << 256):
+            raise ValueError("noise seed out of range (256 bits)")
+        return np.array([(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)], dtype=np.uint32)
+    k = np.ascontiguousarray(noise_seed, dtype=np.uint32)
+    if k.shape != (8,):
+        raise ValueError("a noise key is 8 words")
+    return k if k.any() else None
+
+
+def _key_ptr(noise_seed):
+    """-> (keep-alive array or None, ctypes pointer or None)"""
+    k = noise_key(noise_seed)
+    return k, (None if k is None else k.ctypes.data_as(C.POINTER(C.c_uint32)))
+
+
 def fp_encode(x: int) -> int:
     return ((int(x) % P) << 32) % P
 
 class SegmentSpec(C.Structure):
     """`zkh_segment` (include/zkhal.h): one segment of a session."""
-    _fields_ = [("po2", C.c_uint32), ("seed", C.c_uint64), ("noise_seed", C.c_uint64), ("pub", C.POINTER(C.c_uint32)), ("n_pub", C.c_size_t),
+    _fields_ = [("po2", C.c_uint32), ("seed", C.c_uint64), ("noise_key", C.c_uint32 * 8), ("pub", C.POINTER(C.c_uint32)), ("n_pub", C.c_size_t),
                 ("host_code", C.POINTER(C.c_uint32)), ("host_data", C.POINTER(C.c_uint32)), ("out_global", C.POINTER(C.c_uint32))]
 
 
@@ -114,12 +141,16 @@ ABI = {
     "zkh_circuit_compiled_parts": (_sz, [_vp]),
     "zkh_eval_check": (_err, [_vp, _vp, _vp, C.POINTER(_vp), _sz, C.POINTER(_vp), _sz, _u32p, _sz, _sz, _i]),
     "zkh_syn_code": (_err, [_vp, _vp, _sz, _sz, _vp]),
-    "zkh_syn_witgen": (_err, [_vp, _vp, _sz, _sz, _u64, _u64, _u32p, _vp, _vp, _u32p]),
-    "zkh_syn_accum": (_err, [_vp, _vp, _sz, _sz, _u64, _vp, _u32p, _vp]),
+    "zkh_sha256": (None, [C.c_char_p, _sz, C.POINTER(C.c_uint8)]),
+    "zkh_session_check_termination": (_err, [_vp, C.POINTER(_u32p), C.POINTER(_sz), _sz, C.c_char_p, _sz]),
+    "zkh_noise_cell_host": (_u32, [_u32p, _u32, _u32, _u32]),
+    "zkh_chacha_block_host": (None, [_u32p, _u32p, _i, _u32p]),
+    "zkh_syn_witgen": (_err, [_vp, _vp, _sz, _sz, _u64, _u32p, _u32p, _vp, _vp, _u32p]),
+    "zkh_syn_accum": (_err, [_vp, _vp, _sz, _sz, _u32p, _vp, _u32p, _vp]),
     "zkh_syn_chain_contributions": (_err, [_vp, _vp, C.POINTER(_u64), _u32p, _sz, _sz, _u32p]),
     "zkh_syn_preflight_ram_words": (_sz, []),
     "zkh_syn_preflight": (_err, [_u64, _sz, _sz, _u32p, _u32p, C.POINTER(C.c_double)]),
-    "zkh_syn_witgen_trace": (_err, [_vp, _vp, _sz, _sz, _u64, _vp, _u32p, _vp, _vp, _u32p]),
+    "zkh_syn_witgen_trace": (_err, [_vp, _vp, _sz, _sz, _u32p, _vp, _u32p, _vp, _vp, _u32p]),
     "zkh_poseidon2_mix": (_err, [_vp, _vp, _sz]),
     "zkh_poseidon2_mix_host": (_err, [_u32p, _u32p, _u32p, _sz]),
     "zkh_prover_create": (_err, [_vp, _vp, C.POINTER(_vp)]),
@@ -127,7 +158,7 @@ ABI = {
     "zkh_prover_cache_code": (_err, [_vp, _sz, _vp]),
     "zkh_prover_drop_code_cache": (None, [_vp]),
     "zkh_prover_cached_code_root": (_err, [_vp, _sz, _u32p]),
-    "zkh_prove_segment": (_err, [_vp, _sz, _sz, _u64, _vp, _vp, _u32p, C.POINTER(_u32p), C.POINTER(_sz)]),
+    "zkh_prove_segment": (_err, [_vp, _sz, _sz, _u32p, _vp, _vp, _u32p, C.POINTER(_u32p), C.POINTER(_sz)]),
     "zkh_free_seal": (None, [_u32p]),
     "zkh_prove_begin": (_err, [_vp, _sz, _vp, _vp, _u32p, C.POINTER(_vp), _u32p]),
     "zkh_prove_finish": (_err, [_vp, _vp, C.POINTER(_u32p), C.POINTER(_sz)]),
@@ -147,9 +178,9 @@ ABI = {
     "zkh_rec_program_info": (_err, [_vp, _u32p, _u32p]),
     "zkh_rec_program_has_graph": (_i, [_vp]),
     "zkh_rec_code": (_err, [_vp, _vp]),
-    "zkh_rec_witgen": (_err, [_vp, _u32p, _sz, _u64, _vp, _u32p]),
-    "zkh_rec_accum": (_err, [_vp, _u64, _vp, _u32p, _vp]),
-    "zkh_rec_prove": (_err, [_vp, _u32p, _sz, _u64, _u32p, C.POINTER(_u32p), C.POINTER(_sz)]),
+    "zkh_rec_witgen": (_err, [_vp, _u32p, _sz, _u32p, _vp, _u32p]),
+    "zkh_rec_accum": (_err, [_vp, _u32p, _vp, _u32p, _vp]),
+    "zkh_rec_prove": (_err, [_vp, _u32p, _sz, _u32p, _u32p, C.POINTER(_u32p), C.POINTER(_sz)]),
     "zkh_session_create": (_err, [C.POINTER(_i), _sz, _sz, _u32p, _sz, _u32p, _sz, C.POINTER(_vp)]),
     "zkh_session_destroy": (None, [_vp]),
     "zkh_session_lanes": (_sz, [_vp]),
@@ -162,7 +193,7 @@ ABI = {
     "zkh_session_set_recursion": (_err, [_vp, _u32p, _sz, C.POINTER(_u32p), C.POINTER(_sz), _u32p, _sz]),
     "zkh_succinct_verify": (_err, [_u32p, _sz, _u32p, _sz, _sz, _u32p, _sz, _sz]),
     "zkh_session_build_recursion": (_err, [_vp, _u32p, _sz, _i]),
-    "zkh_session_prove": (_err, [_vp, C.POINTER(SegmentSpec), _sz, _i, _sz, _u64, C.POINTER(ProveInfo)]),
+    "zkh_session_prove": (_err, [_vp, C.POINTER(SegmentSpec), _sz, _i, _sz, _u32p, C.POINTER(ProveInfo)]),
     "zkh_prove_info_free": (None, [C.POINTER(ProveInfo)]),
     "zkh_session_verify": (_err, [_vp, C.POINTER(SegmentSpec), C.POINTER(ProveInfo), _sz]),
     "zkh_parse_cpulist": (_err, [C.c_char_p, C.POINTER(_i), _sz, C.POINTER(_sz)]),
@@ -383,20 +414,23 @@ class RecProgram:
     def witgen(self, inputs, data: Buffer, noise_seed: int = 0x2E80) -> np.ndarray:
         i = _u32(inputs)
         out = np.zeros(16, np.uint32)
-        _check(_lib.zkh_rec_witgen(self.h, _ptr(i), i.size, noise_seed, data.h, _ptr(out)))
+        _k, kp = _key_ptr(noise_seed)
+        _check(_lib.zkh_rec_witgen(self.h, _ptr(i), i.size, kp, data.h, _ptr(out)))
         return out
 
     def accum(self, data: Buffer, mix_global, accum: Buffer, noise_seed: int = 0x2E80) -> None:
         m = _u32(mix_global)
         assert m.size == 20
-        _check(_lib.zkh_rec_accum(self.h, noise_seed, data.h, _ptr(m), accum.h))
+        _k, kp = _key_ptr(noise_seed)
+        _check(_lib.zkh_rec_accum(self.h, kp, data.h, _ptr(m), accum.h))
 
     def prove(self, inputs, noise_seed: int = 0x2E80):
         """-> (seal words, out globals): the witness exists only if the program's in-circuit verifier accepts `inputs`"""
         i = _u32(inputs)
         out = np.zeros(16, np.uint32)
         seal, n = _u32p(), _sz()
-        _check(_lib.zkh_rec_prove(self.h, _ptr(i), i.size, noise_seed, _ptr(out), C.byref(seal), C.byref(n)))
+        _k, kp = _key_ptr(noise_seed)
+        _check(_lib.zkh_rec_prove(self.h, _ptr(i), i.size, kp, _ptr(out), C.byref(seal), C.byref(n)))
         words = np.ctypeslib.as_array(seal, shape=(n.value,)).copy()
         _lib.zkh_free_seal(seal)
         return words, out
@@ -675,7 +709,8 @@ class HipHal:
                 raise HalError(f"syn_witgen: P2-JOIN takes the two child claims (16 words), got {p.size}")
         elif p.size != out_size - 4:
             raise HalError(f"syn_witgen: circuit takes {out_size - 4} public input words, got {p.size}")
-        _check(_lib.zkh_syn_witgen(self.ctx, circuit.h, po2, zk_cycles, seed & (2**64 - 1), noise_seed & (2**64 - 1),
+        _k, kp = _key_ptr(noise_seed)
+        _check(_lib.zkh_syn_witgen(self.ctx, circuit.h, po2, zk_cycles, seed & (2**64 - 1), kp,
                                    _ptr(p) if p.size else None, code.h if code is not None else None, data.h, _ptr(out)))
         return out
 
@@ -684,13 +719,15 @@ class HipHal:
         """records (device, 4 words per active cycle) + the RAM image -> code (None: already held), data; returns the out globals"""
         out = np.zeros(int(circuit.desc[7]), dtype=np.uint32)
         ram = _u32(ram_image) if ram_image is not None else None
-        _check(_lib.zkh_syn_witgen_trace(self.ctx, circuit.h, po2, zk_cycles, noise_seed & (2**64 - 1), records.h, _ptr(ram) if ram is not None else None,
+        _k, kp = _key_ptr(noise_seed)
+        _check(_lib.zkh_syn_witgen_trace(self.ctx, circuit.h, po2, zk_cycles, kp, records.h, _ptr(ram) if ram is not None else None,
                                          code.h if code is not None else None, data.h, _ptr(out)))
         return out
 
     def syn_accum(self, circuit: Circuit, po2: int, zk_cycles: int, noise_seed: int, data: Buffer, mix_global, accum: Buffer) -> None:
         m = _u32(mix_global)
-        _check(_lib.zkh_syn_accum(self.ctx, circuit.h, po2, zk_cycles, noise_seed, data.h, _ptr(m), accum.h))
+        _k, kp = _key_ptr(noise_seed)
+        _check(_lib.zkh_syn_accum(self.ctx, circuit.h, po2, zk_cycles, kp, data.h, _ptr(m), accum.h))
 
     # ---- profiling ----
     def prof_enable(self, on: bool = True) -> None:

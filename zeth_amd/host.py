@@ -142,6 +142,8 @@ class CompositeReceipt:
         from . import receipt_codec as rc
         from .prover import shipped_control_root
         root_of = lambda s: _root_for(control_root, s.po2) if control_root is not None else shipped_control_root(circuit_desc, s.po2)
+        if _is_session_circuit(circuit_desc):       # SYN-S: the REAL claim values (states, exit code, output digest) in upstream's layout
+            return rc.composite_receipt_bytes([(s.seal, s.index, segment_claim(s).to_codec_value()) for s in self.segments], journal=journal)
         segs = [(s.seal, s.index, receipt_claim(s, circuit_desc, root_of(s))) for s in self.segments]
         return rc.composite_receipt_bytes(segs, journal=journal)
 
@@ -219,46 +221,273 @@ def chain_segments(segments: Sequence[Segment], contribution: Callable[[Segment]
     return out
 
 
-def image_id(circuit_desc, initial_state: int = 0) -> "np.ndarray":
-    """The 8-word identifier a verifier is handed for a chained session — the analogue of zeth's Image ID
-    (`compute_image_id(elf)`, /root/reference/crates/host/src/lib.rs:74-84: a digest of the guest program's initial memory image).
-    Here the "program" is the circuit description and the state every session starts from:
-    hash_pair(description hash ‖ 0.., initial state ‖ 0..) with the prover's own Poseidon2."""
-    import numpy as np
-    from .circuits.codegen import desc_hash64
+# ---------------------------------------------------------------------------------------------------------------
+# ReceiptClaim: what `receipt.verify(image_id)` + the journal comparison (/root/reference/crates/host/src/bin/cli.rs:103-107) are
+# about.  Upstream (risc0-zkvm 3.0.3 receipt_claim.rs, risc0-binfmt {exit_code.rs, tagged_struct}; un-vendored, RECALLED):
+#     ReceiptClaim { pre: SystemState, post: SystemState, exit_code: ExitCode, input: Option<Input>, output: Option<Output> }
+#     digest = tagged_struct("risc0.ReceiptClaim", [input, pre, post, output], [sys_exit, user_exit])
+#     tagged_struct(tag, down, data) = SHA-256( SHA-256(tag) ‖ down digests ‖ data as u32 LE ‖ len(down) as u16 LE )
+#     SystemState digest = tagged_struct("risc0.SystemState", [merkle_root], [pc]);  Output = ("risc0.Output", [journal, assumptions], [])
+#     ExitCode::into_pair: Halted(u) -> (0, u), Paused(u) -> (1, u), SystemSplit -> (2, 0), SessionLimit -> (2, 2)
+# A SYN-S segment (circuits/syn_air.py syn_session) binds the pieces in its seal: pre / post state words, the exit pair, the 16 limbs
+# of SHA-256(journal).  The SHA-256 claim digests below are computed on the host BESIDE the Poseidon2 claim the recursion circuit
+# uses (zkh_receipt_claim); tools/check_upstream_receipt.py is the one-command check of the recalled layouts against a real receipt.
+# ---------------------------------------------------------------------------------------------------------------
+EXIT_HALTED, EXIT_PAUSED, EXIT_SYSTEM_SPLIT, EXIT_SESSION_LIMIT = "Halted", "Paused", "SystemSplit", "SessionLimit"
+
+
+def exit_code_pair(exit_code) -> tuple:
+    """ExitCode -> (system, user) as upstream's `into_pair`; exit_code = ("Halted", u) / ("Paused", u) / ("SystemSplit", None) / .."""
+    name, user = exit_code
+    if name == EXIT_HALTED:
+        return (0, int(user or 0))
+    if name == EXIT_PAUSED:
+        return (1, int(user or 0))
+    if name == EXIT_SYSTEM_SPLIT:
+        return (2, 0)
+    if name == EXIT_SESSION_LIMIT:
+        return (2, 2)
+    raise ValueError(f"unknown exit code {exit_code!r}")
+
+
+def exit_code_from_pair(sys: int, user: int):
+    table = {(2, 0): (EXIT_SYSTEM_SPLIT, None), (2, 2): (EXIT_SESSION_LIMIT, None)}
+    if (sys, user) in table:
+        return table[(sys, user)]
+    if sys == 0:
+        return (EXIT_HALTED, user)
+    if sys == 1:
+        return (EXIT_PAUSED, user)
+    raise ValueError(f"({sys}, {user}) is not an exit code pair")
+
+
+def sha256_words(data: bytes) -> List[int]:
+    """SHA-256 as a risc0 `Digest`: eight u32 words, each the little-endian read of four digest bytes"""
+    import hashlib
+    d = hashlib.sha256(data).digest()
+    return [int.from_bytes(d[4 * i:4 * i + 4], "little") for i in range(8)]
+
+
+def tagged_struct(tag: str, down: Sequence[Sequence[int]], data: Sequence[int] = ()) -> List[int]:
+    import hashlib
+    import struct
+    body = hashlib.sha256(tag.encode()).digest()
+    for d in down:
+        body += struct.pack("<8I", *[int(w) for w in d])
+    body += struct.pack(f"<{len(data)}I", *[int(w) for w in data]) + struct.pack("<H", len(down))
+    return sha256_words(body)
+
+
+def journal_limbs(journal: bytes) -> List[int]:
+    """SHA-256(journal) as the sixteen 16-bit limbs a SYN-S seal binds (Montgomery words; limb k = digest bytes 2k, 2k + 1 LE)"""
+    import hashlib
     from .hal import fp_encode
-    h = desc_hash64(np.asarray(circuit_desc, dtype=np.uint32))
-    left = np.array([fp_encode(h & 0x3FFFFFFF), fp_encode((h >> 30) & 0x3FFFFFFF), fp_encode(h >> 60), 0, 0, 0, 0, 0], dtype=np.uint32)
-    right = np.array([fp_encode(initial_state), 0, 0, 0, 0, 0, 0, 0], dtype=np.uint32)
-    return hash_pair(left, right)
+    d = hashlib.sha256(bytes(journal)).digest()
+    return [fp_encode(d[2 * k] | d[2 * k + 1] << 8) for k in range(16)]
+
+
+ZERO_DIGEST = [0] * 8
+
+
+@dataclass
+class ReceiptClaim:
+    """`risc0_zkvm::ReceiptClaim` for a segment (or a whole session) of a SYN-S circuit: the state words stand where upstream has
+    `SystemState{pc, merkle_root}` (pc 0, merkle_root = (state word, 0, ..)), `input` is None as in every zkVM-2 receipt, and the
+    output is `Output{journal: digest, assumptions: zero}` for a halted segment, None otherwise."""
+    pre: int                                   # canonical residues of the state words
+    post: int
+    exit_code: tuple = (EXIT_HALTED, 0)
+    journal_digest: Optional[List[int]] = None  # 8 words, None = no output (the segment did not halt)
+
+    def state_digest(self, word: int) -> List[int]:
+        return tagged_struct("risc0.SystemState", [[int(word)] + [0] * 7], [0])
+
+    def output_digest(self) -> List[int]:
+        if self.journal_digest is None:
+            return ZERO_DIGEST
+        return tagged_struct("risc0.Output", [self.journal_digest, ZERO_DIGEST], [])
+
+    def digest(self) -> List[int]:
+        sys, user = exit_code_pair(self.exit_code)
+        return tagged_struct("risc0.ReceiptClaim", [ZERO_DIGEST, self.state_digest(self.pre), self.state_digest(self.post), self.output_digest()], [sys, user])
+
+    def to_codec_value(self) -> dict:
+        """this claim as a value of receipt_codec.ReceiptClaim (upstream's bincode layout, recalled)"""
+        st = lambda w: ("Value", {"pc": 0, "merkle_root": [int(w)] + [0] * 7})
+        out = ("Value", None) if self.journal_digest is None else ("Value", {"journal": ("Pruned", [int(w) for w in self.journal_digest]), "assumptions": ("Pruned", ZERO_DIGEST)})
+        return {"pre": st(self.pre), "post": st(self.post), "exit_code": self.exit_code, "input": ("Value", None), "output": out}
+
+    @staticmethod
+    def from_codec_value(v: dict) -> "ReceiptClaim":
+        word = lambda s: int(s[1]["merkle_root"][0])
+        out = v["output"][1] if v["output"][0] == "Value" else None
+        jd = None if out is None else [int(w) for w in out["journal"][1]]
+        return ReceiptClaim(pre=word(v["pre"]), post=word(v["post"]), exit_code=tuple(v["exit_code"]), journal_digest=jd)
+
+
+def segment_claim(receipt: SegmentReceipt) -> ReceiptClaim:
+    """The claim a SYN-S segment's seal binds, read from its `out` words (trust it only after the seal has been verified)."""
+    from .circuits.syn_air import CHAIN_POST, CHAIN_PRE, SESSION_EXIT_SYS, SESSION_EXIT_USER, SESSION_JOURNAL, SESSION_JOURNAL_LIMBS, SESSION_OUT_WORDS
+    from .hal import HalError, fp_decode
+    seal = receipt.seal
+    if len(seal) <= SESSION_OUT_WORDS:
+        raise HalError("segment_claim: not a SYN-S seal")
+    sys, user = fp_decode(int(seal[SESSION_EXIT_SYS])), fp_decode(int(seal[SESSION_EXIT_USER]))
+    try:
+        code = exit_code_from_pair(sys, user)
+    except ValueError as e:
+        raise HalError(f"segment_claim: {e}")
+    limbs = [fp_decode(int(w)) for w in seal[SESSION_JOURNAL:SESSION_JOURNAL + SESSION_JOURNAL_LIMBS]]
+    if any(l >> 16 for l in limbs):
+        raise HalError("segment_claim: an output-digest limb does not fit 16 bits")
+    jd = None
+    if code[0] == EXIT_HALTED or any(limbs):
+        raw = b"".join(int(l).to_bytes(2, "little") for l in limbs)
+        jd = [int.from_bytes(raw[4 * i:4 * i + 4], "little") for i in range(8)]
+    return ReceiptClaim(pre=fp_decode(int(seal[CHAIN_PRE])), post=fp_decode(int(seal[CHAIN_POST])), exit_code=code, journal_digest=jd)
+
+
+def session_pub_words(pre_state_mont: int, is_last: bool, journal: bytes) -> tuple:
+    """the 19 public words of a SYN-S segment: pre-state, exit pair, output-digest limbs (Montgomery words)"""
+    from .hal import fp_encode
+    sys, user = exit_code_pair((EXIT_HALTED, 0) if is_last else (EXIT_SYSTEM_SPLIT, None))
+    return (int(pre_state_mont), fp_encode(sys), fp_encode(user)) + tuple(journal_limbs(journal) if is_last else [0] * 16)
+
+
+def chain_session(segments: Sequence[Segment], contribution: Callable[[Segment], int], initial_state: int = 0):
+    """The executor's part of a SYN-S session: pre-states (as `chain_segments`), exit codes (SystemSplit .. SystemSplit, Halted(0)) and
+    the journal — the session's final state word, canonical, 4 bytes little-endian — whose digest the LAST segment binds.
+    -> (segments with their 19 public words, journal bytes)"""
+    from dataclasses import replace
+    from .hal import P, fp_decode, fp_encode
+    pres, state = [], fp_encode(initial_state)
+    for seg in segments:
+        pres.append(state)
+        state = (state + contribution(seg)) % P
+    journal = int(fp_decode(state)).to_bytes(4, "little")
+    out = [replace(seg, pub=session_pub_words(pre, i + 1 == len(segments), journal)) for i, (seg, pre) in enumerate(zip(segments, pres))]
+    return out, journal
+
+
+def verify_session_integrity(receipts: Sequence[SegmentReceipt], initial_state: int, journal: Optional[bytes]) -> ReceiptClaim:
+    """`CompositeReceipt::verify_integrity` + the exit-code and journal checks on VERIFIED SYN-S seals: indices 0 .. n-1 in order, the
+    first segment starts from `initial_state`, every pre-state is the predecessor's post-state, every segment but the last ends in
+    SystemSplit with no output, the last in Halted(0) with the digest of `journal` (None: the final state word).  A session with
+    trailing segments cut off ends in a SystemSplit: refused.  -> the session's claim (pre of the first, post / exit / output of the last)."""
+    from .hal import HalError
+    if [r.index for r in receipts] != list(range(len(receipts))) or not receipts:
+        raise HalError(f"session: missing or unordered segments: {[r.index for r in receipts]}")
+    claims = [segment_claim(r) for r in receipts]
+    prev = int(initial_state)
+    for i, c in enumerate(claims):
+        if c.pre != prev:
+            raise HalError(f"session: segment {i} starts from state {c.pre}, its predecessor ended in {prev}")
+        prev = c.post
+        last = i + 1 == len(claims)
+        if not last and (c.exit_code != (EXIT_SYSTEM_SPLIT, None) or c.journal_digest is not None):
+            raise HalError(f"session: segment {i} of {len(claims)} does not end in SystemSplit ({c.exit_code}): the segments are not those of one session")
+        if last and c.exit_code != (EXIT_HALTED, 0):
+            raise HalError(f"session: the last segment says {c.exit_code}, not Halted(0): the session was cut short or did not succeed")
+    j = journal if journal is not None else int(claims[-1].post).to_bytes(4, "little")
+    if claims[-1].journal_digest != sha256_words(bytes(j)):
+        raise HalError("session: the journal does not hash to the output digest the last segment's seal binds")
+    return ReceiptClaim(pre=claims[0].pre, post=claims[-1].post, exit_code=claims[-1].exit_code, journal_digest=claims[-1].journal_digest)
+
+
+
+def image_id(circuit_desc, initial_state: int = 0) -> "np.ndarray":
+    """The 8-word identifier a verifier is handed for a session — the analogue of zeth's Image ID (`compute_image_id(elf)`,
+    /root/reference/crates/host/src/lib.rs:74-84: a SHA-256 Merkle digest of the guest program's initial memory image).  Here the
+    "program" is the circuit and the state every session starts from:
+        tagged_struct("zeth_amd.ImageId", [SHA-256(description words), SHA-256(shipped control roots of the circuit, by size)], [initial state])
+    — collision resistant over the WHOLE description and the per-size control roots (round 4 hashed a 64-bit FNV of the description)."""
+    import numpy as np
+    from .prover import _CONTROL_ROOTS_JSON, desc_key, shipped_control_root      # noqa: F401
+    d = np.ascontiguousarray(circuit_desc, dtype="<u4")
+    roots = b""
+    for po2 in range(1, 25):
+        r = shipped_control_root(d, po2)
+        if r is not None:
+            roots += int(po2).to_bytes(4, "little") + np.asarray(r, dtype="<u4").tobytes()
+    return np.array(tagged_struct("zeth_amd.ImageId", [sha256_words(d.tobytes()), sha256_words(roots)], [int(initial_state) & 0xFFFFFFFF]), dtype=np.uint32)
+
+
+def _is_session_circuit(circuit_desc) -> bool:
+    from .circuits.syn_air import SESSION_OUT_WORDS
+    return int(circuit_desc[13]) == 1 and int(circuit_desc[7]) == SESSION_OUT_WORDS
 
 
 @dataclass
 class Receipt:
-    """`risc0_zkvm::Receipt{inner, journal}` analogue for a chained session: what `BlockProcessor::prove` returns next to the image
-    id (/root/reference/crates/host/src/lib.rs:123-143) and what the CLI then checks
-    (/root/reference/crates/host/src/bin/cli.rs:103-107): `receipt.verify(image_id)`, then the journal against the expected value.
-    The journal is the session's final state word (canonical, 4 bytes little-endian) — the public output the last segment binds."""
+    """`risc0_zkvm::Receipt{inner, journal}` analogue for a session: what `BlockProcessor::prove` returns next to the image id
+    (/root/reference/crates/host/src/lib.rs:123-143) and what the CLI then checks (/root/reference/crates/host/src/bin/cli.rs:103-107):
+    `receipt.verify(image_id)`, then the journal against the expected value.  The journal is the session's final state word
+    (canonical, 4 bytes little-endian) — the output whose digest the LAST segment's seal binds (SYN-S)."""
     inner: CompositeReceipt
     journal: bytes
 
-    def verify(self, expected_image_id, circuit_desc, initial_state: int = 0, control_root=None) -> None:
-        """Every segment seal against its control root, the session continuous from `initial_state`, the image id the caller
-        expected = the one (circuit, initial state) hash to, and the journal = the final state the last seal binds.  Raises."""
+    def claim(self) -> ReceiptClaim:
+        """the session's claim (SYN-S): pre of the first segment, post / exit code / output of the last (upstream: `Receipt::claim`)"""
+        first, last = segment_claim(self.inner.segments[0]), segment_claim(self.inner.segments[-1])
+        return ReceiptClaim(pre=first.pre, post=last.post, exit_code=last.exit_code, journal_digest=last.journal_digest)
+
+    def verify(self, expected_image_id, circuit_desc, initial_state: int = 0, control_root=None, n_segments: Optional[int] = None) -> None:
+        """Every segment seal against its control root; the image id the caller expected = the one (circuit, control roots, initial
+        state) hash to; and the session is WHOLE:
+          SYN-S circuits — continuity from `initial_state`, SystemSplit .. SystemSplit, Halted(0), SHA-256(journal) = the output digest the
+          last seal binds (`verify_session_integrity`): trailing segments cannot be cut off, the journal cannot be rewritten;
+          SYN-C circuits bind no exit code: continuity + journal == the last seal's post-state, and the caller MUST say how many segments
+          the session has (`n_segments`) — without it a holder could drop trailing segments and rewrite the 4-byte journal.  Raises."""
         import numpy as np
         from .hal import HalError, fp_decode
-        if not np.array_equal(np.asarray(expected_image_id, dtype=np.uint32), image_id(circuit_desc, initial_state)):
+        d = np.asarray(circuit_desc, dtype=np.uint32)
+        if not np.array_equal(np.asarray(expected_image_id, dtype=np.uint32), image_id(d, initial_state)):
             raise HalError("receipt.verify: the image id does not match this circuit and initial state")
-        self.inner.verify(circuit_desc, control_root, chained=True, initial_state=initial_state)
+        if n_segments is not None and len(self.inner.segments) != n_segments:
+            raise HalError(f"receipt.verify: the receipt holds {len(self.inner.segments)} segments, the session has {n_segments}")
+        if _is_session_circuit(d):
+            self.inner.verify(d, control_root)                       # order + every seal
+            verify_session_integrity(self.inner.segments, initial_state, self.journal)
+            return
+        if n_segments is None:
+            raise HalError("receipt.verify: a SYN-C session does not bind its termination (no exit code in its seals): pass the expected "
+                           "segment count, or prove the session with a SYN-S circuit (circuits/syn_air.py syn_session)")
+        self.inner.verify(d, control_root, chained=True, initial_state=initial_state)
         if self.journal != int(fp_decode(self.inner.final_state())).to_bytes(4, "little"):
             raise HalError("receipt.verify: the journal is not the final state the last segment's seal binds")
+
+    def to_upstream_bytes(self, circuit_desc, control_root=None) -> bytes:
+        """upstream's bincode `Receipt{inner: Composite{..}, journal, metadata}`; SYN-S segments carry their REAL claim values"""
+        return self.inner.to_upstream_bytes(circuit_desc, control_root, journal=self.journal)
+
+    @staticmethod
+    def from_upstream_bytes(data: bytes, circuit_desc) -> "Receipt":
+        """Decode the bincode container.  For a SYN-S circuit the `ReceiptClaim` each segment CARRIES must be the one its seal BINDS
+        (states, exit code, output digest read from the seal's `out` words): a container whose claim fields were edited is refused here,
+        before any seal is verified (the seal itself is what `verify` trusts)."""
+        from . import receipt_codec as rc
+        from .hal import HalError
+        val = rc.decode(rc.Receipt, data)
+        comp = CompositeReceipt.from_upstream_bytes(data, int(circuit_desc[7]))
+        if _is_session_circuit(circuit_desc):
+            for seg, v in zip(comp.segments, val["inner"][1]["segments"]):
+                carried, bound = ReceiptClaim.from_codec_value(v["claim"]), segment_claim(seg)
+                if carried != bound:
+                    raise HalError(f"receipt: segment {seg.index} carries the claim {carried}, its seal binds {bound}")
+        return Receipt(comp, bytes(val["journal"]["bytes"]))
 
 
 def prove_chained_block(prove_segment: Callable[[Segment], SegmentReceipt], contribution: Callable[[Segment], int], circuit_desc,
                         segments: Sequence[Segment], initial_state: int = 0):
     """`BlockProcessor::prove(input, po2) -> (Receipt, image id)` (/root/reference/crates/host/src/lib.rs:123-143) for a chained
-    session on this rank: the executor's pass (pre-states), the segment seals, the composite with its journal."""
+    session on this rank: the executor's pass (pre-states; SYN-S: exit codes and the journal digest too), the segment seals, the
+    composite with its journal."""
     from .hal import fp_decode
+    if _is_session_circuit(circuit_desc):
+        chained, journal = chain_session(segments, contribution, initial_state)
+        comp = CompositeReceipt([prove_segment(s) for s in chained])
+        verify_session_integrity(comp.segments, initial_state, journal)
+        return Receipt(comp, journal), image_id(circuit_desc, initial_state)
     chained = chain_segments(segments, contribution, initial_state)
     comp = CompositeReceipt([prove_segment(s) for s in chained])
     comp.verify_integrity(chained=True, initial_state=initial_state)
@@ -345,7 +574,10 @@ class Session:
         keep = []
         u32p = C.POINTER(C.c_uint32)
         for i, (s, seg) in enumerate(zip(arr, segments)):
-            s.po2, s.seed, s.noise_seed = seg.po2, seg.seed & (2**64 - 1), seg.noise_seed & (2**64 - 1)
+            s.po2, s.seed = seg.po2, seg.seed & (2**64 - 1)
+            k = self._hal.noise_key(seg.noise_seed)          # None / 0: all-zero = a fresh OS key inside the library
+            if k is not None:
+                s.noise_key[:] = [int(w) for w in k]
             if seg.pub:
                 p = np.asarray(seg.pub, dtype=np.uint32)
                 keep.append(p)
@@ -367,7 +599,8 @@ class Session:
         C, np = self._C, self._np
         specs, keep = self._specs(segments, host_traces)
         info = self._hal.ProveInfo()
-        self._hal._check(self._hal._lib.zkh_session_prove(self.h, specs, len(segments), int(join_tree), join_po2, join_noise_seed, C.byref(info)))
+        _jk, jkp = self._hal._key_ptr(join_noise_seed)
+        self._hal._check(self._hal._lib.zkh_session_prove(self.h, specs, len(segments), int(join_tree), join_po2, jkp, C.byref(info)))
         try:
             if verify:
                 self._hal._check(self._hal._lib.zkh_session_verify(self.h, specs, C.byref(info), join_po2))

@@ -34,7 +34,7 @@ _CONTROL_ROOTS_JSON = os.path.join(os.path.dirname(os.path.abspath(__file__)), "
 def fresh_noise_seed() -> int:
     """Seed of the zero-knowledge blinding rows: OS randomness, like upstream (which fills the last ZK_CYCLES rows of
     every trace column from an OS RNG).  Tests, benchmarks and golden fixtures pass an explicit seed instead."""
-    return int.from_bytes(os.urandom(8), "little")
+    return int.from_bytes(os.urandom(32), "little") | 1          # 256 bits: the ChaCha12 key of the blinding stream (csrc/noise.h); never 0
 
 
 @dataclass(frozen=True)
@@ -199,7 +199,8 @@ class SegmentProver:
         out = np.ascontiguousarray(out_global, dtype=np.uint32)
         seal_p = C.POINTER(C.c_uint32)()
         n = C.c_size_t()
-        _hal._check(_hal._lib.zkh_prove_segment(self.h, seg.po2, seg.zk_cycles, seg.noise_seed & (2**64 - 1), self._code_handle(seg, code), data.h,
+        _k, kp = _hal._key_ptr(seg.noise_seed)
+        _hal._check(_hal._lib.zkh_prove_segment(self.h, seg.po2, seg.zk_cycles, kp, self._code_handle(seg, code), data.h,
                                                 out.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(seal_p), C.byref(n)))
         return SegmentReceipt(seal=self._take_seal(seal_p, n), index=seg.index, po2=seg.po2, output=out.copy())
 
@@ -231,7 +232,7 @@ class SegmentProver:
 
         def acc(mix_global):
             accum = self.hal.alloc_elem("accum", wa << seg.po2)
-            self.hal.syn_accum(self.circuit, seg.po2, seg.zk_cycles, seg.noise_seed & (2**64 - 1), data, mix_global, accum)
+            self.hal.syn_accum(self.circuit, seg.po2, seg.zk_cycles, seg.noise_seed, data, mix_global, accum)
             return accum
         return acc
 
@@ -249,7 +250,7 @@ class SegmentProver:
         return self.seal(seg, code, data, out)
 
 
-def _generate_control_roots(po2s=range(13, 23)) -> None:
+def _generate_control_roots(po2s=range(13, 25)) -> None:
     """`python -m zeth_amd.prover` on a GPU box: (re)generate circuits/control_roots.json for the shipped circuits."""
     from .circuits import codegen
     hal = _hal.HipHal(0)

@@ -273,9 +273,11 @@ def claim_placeholder(claim_digest, exit_code=("Halted", 0)) -> dict:
 
 
 def segment_receipt_value(seal, index: int, claim_digest, verifier_parameters=None, hashfn: str = "poseidon2") -> dict:
+    """claim_digest: 8 words (a circuit without ReceiptClaim semantics: the placeholder above), or a dict — a full `ReceiptClaim` value
+    (zeth_amd.host.ReceiptClaim.to_codec_value: SYN-S segments carry real states, exit code and output digest)"""
     return {"seal": [int(w) for w in seal], "index": int(index), "hashfn": hashfn,
             "verifier_parameters": [int(w) for w in (verifier_parameters if verifier_parameters is not None else ZERO_DIGEST)],
-            "claim": claim_placeholder(claim_digest)}
+            "claim": claim_digest if isinstance(claim_digest, dict) else claim_placeholder(claim_digest)}
 
 
 def composite_receipt_bytes(segments, journal: bytes = b"", verifier_parameters=None) -> bytes:
