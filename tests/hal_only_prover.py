@@ -12,7 +12,7 @@ library is used —
   fri_prove    : per round batch_expand_into_evaluate_ntt, hash_rows / hash_fold, fri_fold
   queries      : per query and per tree gather_sample + the sibling digests read one by one (MerkleTreeProver::prove)
 
-while the library's own prover (csrc/prover.hip) fuses, batches and reorders.  tests/test_round3_gpu.py requires the two
+while the library's own prover (csrc/prover.hip) fuses, batches and reorders.  tests/test_seal_stages_gpu.py requires the two
 seals to be byte-identical.  Host-side arithmetic (Fiat-Shamir sponge, poly_interpolate, challenge powers) is plain Python
 over canonical residues; the Poseidon2 permutation is the library's HOST entry point zkh_poseidon2_mix_host.  The oracle is
 not imported here.

@@ -111,7 +111,6 @@ def test_gathered_power_tables_travel_inside_the_code_objects(hal, oracle, tmp_p
     from zeth_amd.circuits import codegen, jit, syn_heavy
     from zeth_amd.hal import HalError
     from zeth_amd.prover import Segment, SegmentProver
-    from test_round2_gpu import _evaluated_groups
     import zko
     monkeypatch.setenv("ZKH_JIT_CACHE", str(tmp_path))
     monkeypatch.setenv("ZKH_CODEGEN_PART", "1600")

@@ -3,7 +3,7 @@
 #     gpurun --timeout 900 -- 'bash tools/gpu.sh <recipe> [name]'        -> gpurun_out/<name>/...
 # Recipes (each step under its own `timeout`; counter passes never share a run with tracing domains):
 #   tests        the whole -m gpu suite + smoke()
-#   new [FILE]   one test file (default tests/test_round4_gpu.py), fail fast
+#   new [FILE]   one test file (default tests/test_session_gpu.py), fail fast
 #   bench        the driver's command (python bench.py) + its 8-rank form on ONE GPU (ZKH_SHARE_GPUS=1)
 #   foldlanes    config 5 (g++ host, streamed) at 4 / 5 / 6 / 8 fold lanes per GPU
 #   inflight     the headline at 2 .. 6 seals in flight per GPU
@@ -40,7 +40,7 @@ tests)
   tail -5 $O/pytest.log; tail -2 $O/smoke.log ;;
 new)
   O=gpurun_out/new; mkdir -p $O
-  ( time timeout 900 python -m pytest ${1:-tests/test_round4_gpu.py} -m gpu -q -x ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+  ( time timeout 900 python -m pytest ${1:-tests/test_session_gpu.py} -m gpu -q -x ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
   tail -30 $O/pytest.log ;;
 gather)
   O=gpurun_out/${1:-gather}; mkdir -p $O         # eval_check: the shipped generator (gathered power tables + locality order + 6400-step parts) against the round-3 generator, bit-exact
