@@ -159,7 +159,7 @@ def test_profiling_records(hal):
 
 def test_size_limits(hal):
     with pytest.raises(HalError, match="exceeds"):
-        hal.batch_interpolate_ntt(hal.alloc_elem("big", 1 << 25), 1)
+        hal.batch_interpolate_ntt(hal.alloc_elem("big", 1 << 27), 1)        # the largest domain is 2^26 (a po2-24 segment x INV_RATE 4)
     a = hal.alloc_elem("z", 0)
     assert a.size() == 0
 

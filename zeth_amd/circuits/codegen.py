@@ -62,9 +62,20 @@ LOCALITY_WINDOW = int(os.environ.get("ZKH_CODEGEN_LOCWIN", "0")) or max(16, REG_
 # 1 464 -> 0).  The kernel exports its exponent list (`exps_<kernel>` / `<kernel>_exps`, first word = count); circuit.hip computes
 # the per-call power table through it (mix^exps[i], ONE small launch, as before) and hands every part its own slice.
 GATHER = int(os.environ.get("ZKH_CODEGEN_GATHER", "1"))
+# FACTOR (round 5): constraints of one chain that are products with a COMMON factor,  mix^e_i * (f * q_i),  are accumulated as
+# f * sum_i mix^e_i * q_i  (distributivity: the same field element, hence the same canonical words in `check`).  A component of a
+# real circuit multiplies every one of its constraints by the same selector / vanishing term (SYN-HEAVY: 44 constraints per triple
+# share Z_j); the per-constraint product f * q_i (a multiply + Montgomery step) disappears and the factor is applied once per group
+# as four 64-bit multiply-adds into the outer sums.  Groups of at least FACTOR_MIN members; 0 disables.
+FACTOR_MIN = int(os.environ.get("ZKH_CODEGEN_FACTOR", "3"))
+# DISTRIBUTE (round 5): a product term  o * (x +- y)  of a sum of products, with o a single-use arithmetic value and x, y values
+# that are canonical anyway (taps, constants, globals, values with other consumers), is emitted as  o*x +- o*y: one more 64-bit
+# multiply-add, but the addition disappears and o may stay in [0, 2P) — its conditional subtraction (v_subrev_co + v_cndmask, and
+# the s_nop between them) is what the lazy sum x +- y used to force.
+DISTRIBUTE = int(os.environ.get("ZKH_CODEGEN_DISTRIBUTE", "0"))    # measured on the static opcode table and REJECTED as the default (profiles/r05_eval_check_static.txt)
 # compile flags of the generated translation units (build.py and jit.py use the same list)
 KERNEL_FLAGS = [f for f in os.environ.get("ZKH_CODEGEN_FLAGS", "").split() if f]
-GENERATOR_VERSION = 9
+GENERATOR_VERSION = 10
 
 
 def desc_hash64(desc: np.ndarray) -> int:
@@ -306,7 +317,23 @@ class Plan:
                         if cop in (OP_ADD, OP_SUB):
                             inner.append(child); stack.append((child, csg)); continue
                         if cop == OP_MUL:
-                            inner.append(child); terms.append((csg, "p", self.fp[child][1], self.fp[child][2])); continue
+                            fa, fb = self.fp[child][1], self.fp[child][2]
+                            split = None
+                            if DISTRIBUTE:
+                                for o, g in ((fa, fb), (fb, fa)):
+                                    if (self.fp[g][0] in (OP_ADD, OP_SUB) and not self.ext[g] and uses.get(g, 0) == 1 and g not in self.absorbed
+                                            and not self.ext[o] and uses.get(o, 0) == 1 and self.fp[o][0] in (OP_ADD, OP_SUB, OP_MUL)
+                                            and all(self.fp[t][0] in (OP_GET, OP_CONST, OP_GET_GLOBAL) or uses.get(t, 0) > 1 for t in self.fp[g][1:3])
+                                            and not any(self.ext[t] for t in self.fp[g][1:3])):
+                                        split = (o, g)
+                                        break
+                            if split:
+                                o, g = split
+                                inner.extend((child, g))
+                                terms.append((csg, "p", o, self.fp[g][1]))
+                                terms.append((csg if self.fp[g][0] == OP_ADD else -csg, "p", o, self.fp[g][2]))
+                                continue
+                            inner.append(child); terms.append((csg, "p", fa, fb)); continue
                     terms.append((csg, "v", child))
             n_prod = sum(1 for t in terms if t[1] == "p")
             n_plain = len(terms) - n_prod
@@ -355,10 +382,53 @@ class Plan:
                 items.append(("c", node[2], node[3], self.mix_exp[node[1]]))
             k = node[1]
         items.reverse()
+        if FACTOR_MIN:
+            items = self.group_by_factor(items)
         if LOCALITY and len(items) > 2:
             items = self.order_by_locality(items)
         self._chains[m] = items
         return items
+
+    def group_by_factor(self, items: List[Tuple]) -> List[Tuple]:
+        """('e', v, e) items whose value is a plain product v = f * q with a factor f shared by >= FACTOR_MIN items of this chain
+        become ONE item ('g', f, ((q, e), ...)) at the position of the group's first member: contribution f * sum mix^e q."""
+        cand: Dict[int, List[int]] = {}
+        ops: Dict[int, Tuple[int, int]] = {}
+        for i, it in enumerate(items):
+            if it[0] != "e":
+                continue
+            v = it[1]
+            if v in self.sop or self.fp[v][0] != OP_MUL:
+                continue
+            a, b = self.fp[v][1], self.fp[v][2]
+            if self.ext[a] and self.ext[b]:
+                continue                                   # Fp4 * Fp4: no scalar factor to pull out
+            ops[i] = (a, b)
+            for f in {a, b}:
+                if not self.ext[f] and self.fp[f][0] not in (OP_CONST,):
+                    cand.setdefault(f, []).append(i)
+        taken: Dict[int, int] = {}                         # item index -> factor
+        for f in sorted(cand, key=lambda f: (-len(cand[f]), f)):
+            free = [i for i in cand[f] if i not in taken]
+            if len(free) >= FACTOR_MIN:
+                for i in free:
+                    taken[i] = f
+        if not taken:
+            return items
+        groups: Dict[int, List[Tuple[int, int]]] = {}
+        for i in sorted(taken):
+            f = taken[i]
+            a, b = ops[i]
+            groups.setdefault(f, []).append((b if a == f else a, items[i][2]))
+        out, done = [], set()
+        for i, it in enumerate(items):
+            f = taken.get(i)
+            if f is None:
+                out.append(it)
+            elif f not in done:
+                done.add(f)
+                out.append(("g", f, tuple(groups[f])))
+        return out
 
     def tapset(self, v: int) -> frozenset:
         """taps (canonical OP_GET values) below value v"""
@@ -371,6 +441,11 @@ class Plan:
     def item_taps(self, it) -> frozenset:
         if it[0] == "e":
             return self.tapset(it[1])
+        if it[0] == "g":
+            acc = set(self.tapset(it[1]))
+            for q, _ in it[2]:
+                acc |= self.tapset(q)
+            return frozenset(acc)
         acc = set(self.tapset(it[1]))
         for sub in self.chain(it[2]):
             acc |= self.item_taps(sub)
@@ -453,6 +528,9 @@ class Plan:
             for it in self.chain(m):
                 if it[0] == "e":
                     w.append(4 + sum(1 for x in self.cone(it[1], set()) if self.fp[x][0] in (OP_ADD, OP_SUB, OP_MUL)))
+                elif it[0] == "g":
+                    for q, _ in it[2]:
+                        w.append(4 + sum(1 for x in self.cone(q, set()) if self.fp[x][0] in (OP_ADD, OP_SUB, OP_MUL)))
                 else:
                     walk(it[2])
         walk(self.c.ret)
@@ -781,6 +859,28 @@ class _Emitter:
         self.w("    }")
         self.tzero[d] = False
 
+    def acc_leaf(self, d: int, v: int, e: int) -> None:
+        """depth d += mix^e * v for one constraint value"""
+        self.need([v])
+        if self.p.ext[v]:
+            # tot += mix^e * x for an Fp4 x: sixteen products straight into the unreduced sums (four units of room)
+            if self.pend.get(d, 0) > 0:
+                self.fold(d)
+            self.w(f"    ext_accumulate(s{d}_0, s{d}_1, s{d}_2, s{d}_3, pwp[{self.pw(e)}], {self.ext_ref(v)});")
+            self.release()
+            self.pend[d] = 4
+            return
+        # tot += mix^e * v: four 64-bit multiply-adds (scalar-loaded power words); the sums are folded (not reduced)
+        # when four units of products are pending and reduced once where the total is needed
+        r = self.ref(v)
+        wgt = 2 if v in self.p.lazy else 1      # a lazy value (< 2P) makes a product below 2 P^2
+        if self.pend.get(d, 0) + wgt > 4:
+            self.fold(d)
+        self.w(f"    {{ const uint4 p_ = pwp[{self.pw(e)}]; s{d}_0 += (uint64_t)p_.x * {r}; s{d}_1 += (uint64_t)p_.y * {r}; "
+               f"s{d}_2 += (uint64_t)p_.z * {r}; s{d}_3 += (uint64_t)p_.w * {r}; }}")
+        self.release()
+        self.pend[d] = self.pend.get(d, 0) + wgt
+
     # ---- the mix tree ----
     def emit_chain(self, m: int, d: int) -> bool:
         """Accumulate into depth d the leaves of chain m that fall into [lo, hi).  Returns whether anything was emitted."""
@@ -792,24 +892,35 @@ class _Emitter:
                 if not (self.lo <= idx < self.hi):
                     continue
                 _, v, e = it
-                self.need([v])
                 any_emitted = True
-                if self.p.ext[v]:
-                    # tot += mix^e * x for an Fp4 x: sixteen products straight into the unreduced sums (four units of room)
-                    if self.pend.get(d, 0) > 0:
-                        self.fold(d)
-                    self.w(f"    ext_accumulate(s{d}_0, s{d}_1, s{d}_2, s{d}_3, pwp[{self.pw(e)}], {self.ext_ref(v)});")
-                    self.release()
-                    self.pend[d] = 4
+                self.acc_leaf(d, v, e)
+            elif it[0] == "g":
+                # f * sum_i mix^e_i q_i (Plan.group_by_factor): the members accumulate one level down with their OWN exponents, the
+                # factor multiplies the reduced level total straight into this level's unreduced sums (four multiply-adds)
+                _, f, members = it
+                first = self.leaf
+                if first + len(members) <= self.lo or first >= self.hi:
+                    self.leaf += len(members)
                     continue
-                # tot += mix^e * v: four 64-bit multiply-adds (scalar-loaded power words); the sums are folded (not reduced)
-                # when four units of products are pending and reduced once where the total is needed
-                r = self.ref(v)
-                wgt = 2 if v in self.p.lazy else 1      # a lazy value (< 2P) makes a product below 2 P^2
+                self.reset(d + 1)
+                got = False
+                for q, e in members:
+                    idx = self.leaf
+                    self.leaf += 1
+                    if self.lo <= idx < self.hi:
+                        self.acc_leaf(d + 1, q, e)
+                        got = True
+                if not got:
+                    continue
+                self.flush(d + 1)
+                self.need([f])
+                any_emitted = True
+                r = self.ref(f)
+                wgt = 2 if f in self.p.lazy else 1
                 if self.pend.get(d, 0) + wgt > 4:
                     self.fold(d)
-                self.w(f"    {{ const uint4 p_ = pwp[{self.pw(e)}]; s{d}_0 += (uint64_t)p_.x * {r}; s{d}_1 += (uint64_t)p_.y * {r}; "
-                       f"s{d}_2 += (uint64_t)p_.z * {r}; s{d}_3 += (uint64_t)p_.w * {r}; }}")
+                self.w(f"    s{d}_0 += (uint64_t)t{d + 1}_0 * {r}; s{d}_1 += (uint64_t)t{d + 1}_1 * {r}; "
+                       f"s{d}_2 += (uint64_t)t{d + 1}_2 * {r}; s{d}_3 += (uint64_t)t{d + 1}_3 * {r};")
                 self.release()
                 self.pend[d] = self.pend.get(d, 0) + wgt
             else:

@@ -4,7 +4,7 @@ vanish on a witness — `eval_check` is a pure function of (description, evaluat
 compared.  The shapes are chosen to reach the generator's corner cases: squares and repeated factors, long add/sub chains
 (sums of products with negative terms), values used both as factors and as addends (canonical vs lazy representatives),
 base-field values flowing into Fp4 expressions from either side, Fp4-valued constraints, nested AndCond with base and
-Fp4 conditions, constraints on bare taps / constants / globals."""
+Fp4 conditions, constraints on bare taps / constants / globals, runs of constraints sharing one factor."""
 from __future__ import annotations
 
 import numpy as np
@@ -83,7 +83,14 @@ def random_circuit(seed: int, groups=(4, 6, 12), n_values: int = 220, n_constrai
     def chain(n: int, depth: int):
         m = b.true()
         for _ in range(n):
-            if depth < 3 and rng.integers(0, 5) == 0:
+            if rng.integers(0, 7) == 0 and base:
+                # a COMPONENT: several constraints that share one factor (a selector / vanishing term), sometimes with an Fp4 member —
+                # what the generator's factor grouping (codegen.py Plan.group_by_factor) pulls out of the sum
+                f = pick(base)
+                for _ in range(int(rng.integers(3, 7))):
+                    q = ext[int(rng.integers(0, len(ext)))] if (ext and rng.integers(0, 5) == 0) else pick(base)
+                    m = b.and_eqz(m, b.mul(f, q) if rng.integers(0, 2) else b.mul(q, f))
+            elif depth < 3 and rng.integers(0, 5) == 0:
                 inner = chain(int(rng.integers(0, 5)), depth + 1)      # may be empty
                 cond = ext[int(rng.integers(0, len(ext)))] if (ext and rng.integers(0, 4) == 0) else pick(base)
                 m = b.and_cond(m, cond, inner)
