@@ -220,8 +220,27 @@ class Plan:
         p.n_unique = sum(1 for v in seen if p.fp[v][0] in (OP_ADD, OP_SUB, OP_MUL))
         if USE_SOP:
             p.find_sums_of_products(seen, roots)
+        # The values the emitter will actually ask for: with FACTOR a grouped constraint f * q_i is never computed — its members q_i
+        # and the factor f are — so the lazy analysis must see THOSE as the consumers' operands (an Fp4 member goes into the sums
+        # whole: canonical components; a base member and the factor are only ever multiplied).
+        eff: List[int] = []
+
+        def walk(m: int):
+            for it in p.chain(m):
+                if it[0] == "e":
+                    eff.append(it[1])
+                elif it[0] == "g":
+                    eff.append(it[1])
+                    eff.extend(q for q, _ in it[2])
+                else:
+                    eff.append(it[1])
+                    walk(it[2])
+        walk(c.ret)
         if USE_LAZY:
-            p.find_lazy(seen, roots)
+            reach = set()
+            for r in eff:
+                reach.update(p.cone(r, reach))
+            p.find_lazy(reach, eff)
         return p
 
     def find_lazy(self, reachable, mix_ext=()) -> None:

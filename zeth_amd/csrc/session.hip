@@ -22,6 +22,7 @@
 #include <sys/random.h>
 
 #include "circuit.h"
+#include "scheduler.h"
 
 using namespace zkh;
 
@@ -534,86 +535,29 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
     // three nodes at a time (zeth_amd/recursion.py fold_plan: one join3 where the program set has it for their sizes, else
     // join(join(a, b), c), the same node either way), a remainder of two is a join, of one moves up unchanged.  A node's program
     // follows from its children's sizes, so a missing program is reported here, not after the leaves are sealed. ----
-    struct PNode {
-        uint32_t kind = 0;                 // 0 lift(a), 2 lift2(a, b): a, b segment indices; 1 join(a, b), 3 join3(a, b, c): node ids
-        size_t a = 0, b = 0, c = 0, parent = (size_t)-1;
-        uint32_t program = 0, po2 = 0;
-        int pending = 0;                   // children not yet available
-        uint32_t* seal = nullptr;
-        size_t words = 0;
-        NodeClaim claim;                   // the opening of the claim' its seal publishes (set when the node is proven)
-    };
-    std::vector<PNode> plan;
-    std::vector<size_t> owner(fold ? n : 0, NONE);         // the bottom node that consumes segment i
-    size_t root_node = NONE, n_bottom = 0;
-    auto program_of = [&](uint32_t join, uint32_t a, uint32_t b) -> int {
-        for (size_t i = 0; i < s->rec_kinds.size(); i++)
-            if (s->rec_kinds[i].join == join && s->rec_kinds[i].a == a && s->rec_kinds[i].b == b) return (int)i;     // lifts: b = circuit family, 0 = the session's
-        return -1;
-    };
-    auto po2_of = [&](uint32_t program) { uint32_t inf[8] = {0}; (void)zkh_rec_program_info(s->lanes[0].programs[program], nullptr, inf); return inf[0]; };
+    // (the plan itself and the scheduling state machine: scheduler.h — plain C++, unit-tested without a GPU)
+
+    sched::FoldPlan fplan;
+    std::vector<sched::PlanNode>& plan = fplan.nodes;
+    std::vector<size_t>& owner = fplan.owner;
+    struct NodeData { uint32_t* seal = nullptr; size_t words = 0; NodeClaim claim; };     // what a proven node leaves for its parent
+    std::vector<NodeData> ndata;
     if (fold) {
-        const size_t n_pairs = n / 2;
-        bool all_fused = n > 1;
-        for (size_t k = 0; k < n_pairs && all_fused; k++) all_fused = program_of(2, segs[2 * k].po2, segs[2 * k + 1].po2) >= 0;
-        auto add_lift = [&](size_t i) -> const char* {
-            const int p = program_of(0, segs[i].po2, 0);
-            ZKH_REQUIRE(p >= 0, "session_prove: no lift program for po2-%u segments", segs[i].po2);
-            PNode nd; nd.kind = 0; nd.a = i; nd.program = (uint32_t)p; nd.po2 = po2_of((uint32_t)p); nd.pending = 1;
-            owner[i] = plan.size(); plan.push_back(nd);
-            return nullptr;
-        };
-        const char* perr = nullptr;
-        if (all_fused) {
-            for (size_t k = 0; k < n_pairs; k++) {
-                PNode nd; nd.kind = 2; nd.a = 2 * k; nd.b = 2 * k + 1; nd.pending = 2;
-                nd.program = (uint32_t)program_of(2, segs[2 * k].po2, segs[2 * k + 1].po2); nd.po2 = po2_of(nd.program);
-                owner[2 * k] = owner[2 * k + 1] = plan.size(); plan.push_back(nd);
-            }
-            if (n % 2) perr = add_lift(n - 1);
-        } else {
-            for (size_t i = 0; i < n && !perr; i++) perr = add_lift(i);
-        }
-        n_bottom = plan.size();
-        std::vector<size_t> cur(n_bottom);
-        for (size_t k = 0; k < n_bottom; k++) cur[k] = k;
-        auto add_join = [&](size_t a, size_t b) -> size_t {                 // -> node id, or NONE (perr set)
-            PNode nd; nd.kind = 1; nd.a = a; nd.b = b; nd.pending = 2;
-            const int p = program_of(1, plan[a].po2, plan[b].po2);
-            if (p < 0) { perr = make_err("session_prove: no join program for children of po2 %u and %u", plan[a].po2, plan[b].po2); return NONE; }
-            nd.program = (uint32_t)p; nd.po2 = po2_of(nd.program);
-            plan[a].parent = plan[b].parent = plan.size();
-            plan.push_back(nd);
-            return plan.size() - 1;
-        };
-        // the bottom nodes are the first level's pairs when they are lift2s (and a lone lift); when every segment was lifted on its
-        // own, the first level above still pairs
-        size_t group = all_fused || n < 2 ? 3 : 2;
-        while (cur.size() > 1 && !perr) {
-            std::vector<size_t> nxt;
-            size_t k = 0;
-            for (; k + group <= cur.size() && !perr; k += group) {
-                if (group == 2) { nxt.push_back(add_join(cur[k], cur[k + 1])); continue; }
-                const size_t a = cur[k], b = cur[k + 1], c = cur[k + 2];
-                const int p3 = plan[a].po2 == plan[b].po2 ? program_of(3, plan[a].po2, plan[c].po2) : -1;
-                if (p3 >= 0) {
-                    PNode nd; nd.kind = 3; nd.a = a; nd.b = b; nd.c = c; nd.pending = 3;
-                    nd.program = (uint32_t)p3; nd.po2 = po2_of(nd.program);
-                    plan[a].parent = plan[b].parent = plan[c].parent = plan.size();
-                    nxt.push_back(plan.size()); plan.push_back(nd);
-                } else {                                                        // the same node as two proofs
-                    const size_t ab = add_join(a, b);
-                    nxt.push_back(perr ? NONE : add_join(ab, c));
-                }
-            }
-            if (!perr && cur.size() - k == 2) nxt.push_back(add_join(cur[k], cur[k + 1]));
-            else if (!perr && cur.size() - k == 1) nxt.push_back(cur[k]);
-            cur.swap(nxt);
-            group = 3;
-        }
-        if (perr) { zkh_prove_info_free(info); return perr; }
-        root_node = cur[0];
+        std::vector<uint32_t> seg_po2(n);
+        for (size_t i = 0; i < n; i++) seg_po2[i] = segs[i].po2;
+        const std::string perr = sched::build_fold_plan(
+            seg_po2,
+            [&](uint32_t join, uint32_t a, uint32_t b) -> int {
+                for (size_t i = 0; i < s->rec_kinds.size(); i++)
+                    if (s->rec_kinds[i].join == join && s->rec_kinds[i].a == a && s->rec_kinds[i].b == b) return (int)i;     // lifts: b = circuit family, 0 = the session's
+                return -1;
+            },
+            [&](uint32_t program) { uint32_t inf[8] = {0}; (void)zkh_rec_program_info(s->lanes[0].programs[program], nullptr, inf); return inf[0]; },
+            &fplan);
+        if (!perr.empty()) { zkh_prove_info_free(info); return make_err("session_prove: %s", perr.c_str()); }
+        ndata.resize(plan.size());
     }
+    const size_t n_bottom = fplan.n_bottom, root_node = fplan.root;
     // control root of the leaf circuit per segment size (the lifts' claims are computed against it): before any thread starts
     std::vector<std::pair<uint32_t, std::vector<uint32_t>>> fold_leaf_roots;
     auto leaf_root_of = [&](uint32_t po2) -> const uint32_t* {
@@ -645,16 +589,8 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
     ErrorSlot errs;
     std::mutex m;
     std::condition_variable cv;
-    std::deque<size_t> ready;                                  // fold nodes whose children exist
-    struct Retry { size_t seg; const Lane* failed_on; double since; };
-    std::deque<Retry> retry;
-    std::vector<int> attempts(n, 0);
-    size_t next_seal = 0, seals_done = 0, seal_lanes_active = s->lanes.size();
-    bool root_done = !fold;
-    double t_leaves_done = 0, t_bottom_done = 0;
-    size_t bottom_done = 0;
     const char* renv = getenv("ZKH_SEGMENT_RETRIES");
-    const int max_retries = renv ? atoi(renv) : 1;
+    sched::Scheduler sc(n, s->lanes.size(), fold ? &fplan : nullptr, streamed, renv ? atoi(renv) : 1);
     // Fault injection (tests of the retry path): ZKH_FAULT_SEGMENT=<i> fails the FIRST attempt at segment i, ZKH_FAULT_SEGMENT_ALWAYS=<i>
     // every attempt.  Armed only by a value that parses STRICTLY as a decimal index (an empty or stray variable arms nothing: atol("")
     // was 0 = segment 0) and only together with ZKH_TEST_HOOKS=1, which no deployment sets.
@@ -669,26 +605,24 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
     const long fault_seg = fault_index("ZKH_FAULT_SEGMENT"), fault_always = fault_index("ZKH_FAULT_SEGMENT_ALWAYS");
     const double t0 = now_s();
 
-    auto finished = [&] { return errs.any() || (seals_done == n && root_done); };            // call with m held
-    auto child_done = [&](size_t node) {                                                       // call with m held
-        if (--plan[node].pending == 0) { ready.push_back(node); cv.notify_all(); }
-    };
+    auto finished = [&] { return errs.any() || sc.finished(); };                              // call with m held
     auto run_node = [&](Lane* l, size_t id, std::vector<uint32_t>& in) -> const char* {
-        PNode& nd = plan[id];
+        const sched::PlanNode& nd = plan[id];
+        NodeData& me = ndata[id];
         in.clear();
         const std::vector<uint32_t>& A = s->allowed.back()[0];
         if (nd.kind == 1 || nd.kind == 3) {
             // per child: seal, membership path, then the opening of its claim' (core, pre, post) — all checked in-circuit
-            const PNode* ch3[3] = {&plan[nd.a], &plan[nd.b], nd.kind == 3 ? &plan[nd.c] : nullptr};
-            for (const PNode* ch : ch3) {
-                if (!ch) continue;
-                in.insert(in.end(), ch->seal, ch->seal + ch->words);
-                path_of(ch->program, in);
-                in.insert(in.end(), ch->claim.core, ch->claim.core + 8);
-                in.push_back(ch->claim.pre); in.push_back(ch->claim.post);
+            const size_t ch3[3] = {nd.a, nd.b, nd.kind == 3 ? nd.c : NONE};
+            for (size_t ch : ch3) {
+                if (ch == NONE) continue;
+                in.insert(in.end(), ndata[ch].seal, ndata[ch].seal + ndata[ch].words);
+                path_of(plan[ch].program, in);
+                in.insert(in.end(), ndata[ch].claim.core, ndata[ch].claim.core + 8);
+                in.push_back(ndata[ch].claim.pre); in.push_back(ndata[ch].claim.post);
             }
-            ZKH_TRY(parent_claim(ch3[0]->claim, ch3[1]->claim, &nd.claim));
-            if (ch3[2]) { const NodeClaim ab = nd.claim; ZKH_TRY(parent_claim(ab, ch3[2]->claim, &nd.claim)); }     // join3 = join(join(a, b), c)
+            ZKH_TRY(parent_claim(ndata[nd.a].claim, ndata[nd.b].claim, &me.claim));
+            if (nd.kind == 3) { const NodeClaim ab = me.claim; ZKH_TRY(parent_claim(ab, ndata[nd.c].claim, &me.claim)); }     // join3 = join(join(a, b), c)
         } else {
             const zkh_circuit* lc = s->lanes[0].circuit;
             in.assign(info->seals[nd.a], info->seals[nd.a] + info->seal_words[nd.a]);
@@ -698,22 +632,20 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
                 in.insert(in.end(), info->seals[nd.b], info->seals[nd.b] + info->seal_words[nd.b]);
                 NodeClaim cb;
                 ZKH_TRY(leaf_claim(lc, info->seals[nd.b], info->seal_words[nd.b], leaf_root_of(segs[nd.b].po2), &cb));
-                ZKH_TRY(parent_claim(ca, cb, &nd.claim));
+                ZKH_TRY(parent_claim(ca, cb, &me.claim));
             } else {
-                nd.claim = ca;
+                me.claim = ca;
             }
             in.insert(in.end(), A.begin(), A.end());
         }
-        ZKH_TRY(zkh_rec_prove(l->programs[nd.program], in.data(), in.size(), join_noise_key, nullptr, &nd.seal, &nd.words));    // NULL: a fresh OS key per proof
+        ZKH_TRY(zkh_rec_prove(l->programs[nd.program], in.data(), in.size(), join_noise_key, nullptr, &me.seal, &me.words));    // NULL: a fresh OS key per proof
         if (nd.kind == 1 || nd.kind == 3) {                    // children are not kept: the verifier needs the root only
-            zkh_free_seal(plan[nd.a].seal); zkh_free_seal(plan[nd.b].seal);
-            plan[nd.a].seal = plan[nd.b].seal = nullptr;
-            if (nd.kind == 3) { zkh_free_seal(plan[nd.c].seal); plan[nd.c].seal = nullptr; }
+            for (size_t ch : {nd.a, nd.b, nd.kind == 3 ? nd.c : NONE})
+                if (ch != NONE) { zkh_free_seal(ndata[ch].seal); ndata[ch].seal = nullptr; }
         }
         return nullptr;
     };
     double wit_sum = 0, seal_sum = 0, fold_busy = 0, pre_cpu_sum = 0, trace_bytes_sum = 0;
-    size_t n_retries = 0;
     // ---- witness source 1: the sequential host preflight runs AHEAD of the seals.  Every sealing lane has its own producer threads
     // (zkh_session_set_witness_source: default 2 — one preflight of a po2-20 segment is ~70 ms of one core, a lane seals one every
     // ~70 ms) and a pool of pinned record slots (producers + 1): a producer takes the next segment index, replays its cycles into a
@@ -756,9 +688,9 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
         if (!getenv("ZKH_SESSION_NO_AFFINITY")) { const char* e = zkh_bind_thread_to_device(l.device, 0, 1, nullptr, nullptr); if (e) zkh_free_error(e); }
         std::unique_lock<std::mutex> lk(m);
         for (;;) {
-            cv.wait(lk, [&] { return errs.any() || !q.accepting || next_seal >= n || !q.free_slots.empty(); });
-            if (errs.any() || !q.accepting || next_seal >= n) break;
-            const size_t i = next_seal++;
+            cv.wait(lk, [&] { return errs.any() || !q.accepting || !sc.indices_left() || !q.free_slots.empty(); });
+            if (errs.any() || !q.accepting || !sc.indices_left()) break;
+            const size_t i = sc.claim_index();
             uint32_t* slot = q.free_slots.back();
             q.free_slots.pop_back();
             lk.unlock();
@@ -768,7 +700,7 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
             pre_cpu_sum += cpu;
             if (err) { errs.set(err, "preflight"); q.free_slots.push_back(slot); break; }
             if (q.accepting) q.ready.push_back(Ready{i, slot});
-            else { q.free_slots.push_back(slot); retry.push_back(Retry{i, nullptr, 0}); }     // the lane stopped sealing meanwhile: anyone may take it
+            else { q.free_slots.push_back(slot); sc.requeue(i); }     // the lane stopped sealing meanwhile: anyone may take it
             cv.notify_all();
         }
         q.producers_active--;
@@ -776,32 +708,30 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
         cv.notify_all();
     };
     auto worker = [&](Lane* l, bool can_seal) {
-        const size_t lane_idx = can_seal ? (size_t)(l - s->lanes.data()) : 0;
+        const size_t lane_idx = can_seal ? (size_t)(l - s->lanes.data()) : sched::NONE;
         if (!getenv("ZKH_SESSION_NO_AFFINITY")) { const char* e = zkh_bind_thread_to_device(l->device, 0, 1, nullptr, nullptr); if (e) zkh_free_error(e); }
         std::vector<uint32_t> in;
         double wit = 0, seal_t = 0, fold_t = 0;
-        int consecutive_failures = 0;
         std::unique_lock<std::mutex> lk(m);
         for (;;) {
             if (finished()) break;
-            // 1) a segment: retries first (never on the lane that just failed it, unless no other sealing lane is left or
-            //    nobody else picked it up within 50 ms), then the next index
+            // 1) a segment (scheduler.h take_segment: retries first, then the next index — or, with the host-preflight pipeline, what
+            //    this lane's producers have prepared)
             size_t seg = NONE;
             uint32_t* slot = nullptr;
             if (can_seal) {
-                for (auto it = retry.begin(); it != retry.end(); ++it)
-                    if (it->failed_on != l || seal_lanes_active <= 1 || now_s() - it->since > 0.05) { seg = it->seg; retry.erase(it); break; }
+                seg = sc.take_segment(lane_idx, now_s(), !use_pre).index;
                 if (seg == NONE && use_pre) {
                     LaneQ& q = laneq[lane_idx];
                     if (!q.ready.empty()) { seg = q.ready.front().seg; slot = q.ready.front().slot; q.ready.pop_front(); }
-                } else if (seg == NONE && next_seal < n) seg = next_seal++;
+                }
             }
             if (seg != NONE) {
                 lk.unlock();
                 double w = 0, pcpu = 0, tbytes = 0;
                 const double ts = now_s();
                 const char* err = nullptr;
-                if ((long)seg == fault_always || ((long)seg == fault_seg && attempts[seg] == 0)) err = make_err("injected fault (ZKH_FAULT_SEGMENT)");
+                if ((long)seg == fault_always || ((long)seg == fault_seg && sc.attempts(seg) == 0)) err = make_err("injected fault (ZKH_FAULT_SEGMENT)");
                 else err = seal_one(s, *l, segs[seg], &info->seals[seg], &info->seal_words[seg], &w, slot, slot ? slot + ((size_t)4 << segs[seg].po2) : nullptr, &pcpu, &tbytes);
                 const double te = now_s();
                 lk.lock();
@@ -813,39 +743,37 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
                     laneq[lane_idx].free_slots.push_back(slot); cv.notify_all();
                 }
                 if (err) {
-                    if (attempts[seg]++ < max_retries) {       // hand it to another lane / device
+                    const sched::Scheduler::Failure f = sc.on_seal_failed(seg, lane_idx, now_s());      // hand it to another lane / device, or give up
+                    if (f != sched::Scheduler::Failure::Fatal) {
                         zkh_free_error(err);
                         zkh_free_seal(info->seals[seg]); info->seals[seg] = nullptr; info->seal_words[seg] = 0;
-                        retry.push_back(Retry{seg, l, now_s()});
-                        n_retries++;
-                        cv.notify_all();
-                        if (++consecutive_failures >= 2 && seal_lanes_active > 1) {      // this lane stops taking segments
-                            can_seal = false; seal_lanes_active--;
+                        if (f == sched::Scheduler::Failure::RetryAndRetireLane) {        // two failures in a row: this lane stops taking segments
+                            can_seal = false;
                             if (use_pre) {                            // what its producers already prepared goes to the other lanes
                                 LaneQ& q = laneq[lane_idx];
                                 q.accepting = false;
-                                for (auto& r : q.ready) { q.free_slots.push_back(r.slot); retry.push_back(Retry{r.seg, nullptr, 0}); }
+                                for (auto& r : q.ready) { q.free_slots.push_back(r.slot); sc.requeue(r.seg); }
                                 q.ready.clear();
                             }
                         }
+                        cv.notify_all();
                         continue;
                     }
                     char what[64];
-                    snprintf(what, sizeof what, "segment %zu (after %d attempt(s))", seg, attempts[seg]);
+                    snprintf(what, sizeof what, "segment %zu (after %d attempt(s))", seg, sc.attempts(seg));
                     errs.set(err, what);
                     cv.notify_all();
                     break;
                 }
-                consecutive_failures = 0;
                 wit += w; seal_t += te - ts - w;
-                if (++seals_done == n) { t_leaves_done = now_s(); cv.notify_all(); }
-                if (fold) child_done(owner[seg]);
+                sc.on_seal_done(seg, lane_idx, now_s());
+                cv.notify_all();
                 continue;
             }
             // 2) a fold node (streamed: any time; two phases: once every segment is sealed)
-            if (fold && !ready.empty() && (streamed || seals_done == n)) {
-                const size_t id = ready.front();
-                ready.pop_front();
+            const sched::Scheduler::Work nw = sc.take_node();
+            if (nw.kind == sched::Scheduler::Kind::Node) {
+                const size_t id = nw.index;
                 lk.unlock();
                 const double ts = now_s();
                 const char* err = run_node(l, id, in);
@@ -853,17 +781,16 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
                 lk.lock();
                 fold_t += te - ts;
                 if (err) { errs.set(err, plan[id].kind == 1 ? "join" : plan[id].kind == 3 ? "join3" : plan[id].kind == 2 ? "lift2" : "lift"); cv.notify_all(); break; }
-                if (id < n_bottom && ++bottom_done == n_bottom) t_bottom_done = now_s();
-                if (id == root_node) { root_done = true; cv.notify_all(); }
-                else if (plan[id].parent != NONE) child_done(plan[id].parent);
+                sc.on_node_done(id, now_s());
+                cv.notify_all();
                 continue;
             }
             // 3) nothing to do right now (a retry entry held back for another lane wakes us after 20 ms; producers, finished seals and
             //    finished fold nodes notify)
-            if (can_seal && !retry.empty()) cv.wait_for(lk, std::chrono::milliseconds(20));
+            if (can_seal && sc.retries_waiting()) cv.wait_for(lk, std::chrono::milliseconds(20));
             else cv.wait(lk);
         }
-        if (can_seal) seal_lanes_active = seal_lanes_active ? seal_lanes_active - 1 : 0;
+        sc.lane_leaves(can_seal);
         wit_sum += wit; seal_sum += seal_t; fold_busy += fold_t;
         lk.unlock();
         cv.notify_all();
@@ -877,25 +804,25 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
         for (auto& t : th) t.join();
     }
     const double t_end = now_s();
-    info->witgen_s_sum = wit_sum; info->seal_s_sum = seal_sum; info->fold_busy_s_sum = fold_busy; info->n_retries = n_retries;
+    info->witgen_s_sum = wit_sum; info->seal_s_sum = seal_sum; info->fold_busy_s_sum = fold_busy; info->n_retries = sc.n_retries;
     info->preflight_cpu_s_sum = pre_cpu_sum; info->trace_bytes = trace_bytes_sum;
-    info->leaves_s = (t_leaves_done ? t_leaves_done : t_end) - t0;
+    info->leaves_s = (sc.t_leaves_done ? sc.t_leaves_done : t_end) - t0;
     if (fold) {
         // bottom level = lifts (or lift2 per pair); with the streamed fold these overlap the leaf phase: lift_s / join_s are what the
         // fold still took AFTER the last segment was sealed (bottom level, then joins); two phases: the two phases' durations
-        const double tb = std::max(t_bottom_done ? t_bottom_done : t_end, t0 + info->leaves_s);
+        const double tb = std::max(sc.t_bottom_done ? sc.t_bottom_done : t_end, t0 + info->leaves_s);
         info->n_lifts = n_bottom;
         info->n_joins = plan.size() - n_bottom;
         info->lift_s = tb - (t0 + info->leaves_s);
         info->join_s = t_end - tb;
         info->fold_tail_s = t_end - (t0 + info->leaves_s);
         if (!errs.any()) {
-            PNode& r = plan[root_node];
-            info->root_seal = r.seal; info->root_seal_words = r.words; info->root_program = r.program;
+            NodeData& r = ndata[root_node];
+            info->root_seal = r.seal; info->root_seal_words = r.words; info->root_program = plan[root_node].program;
             memcpy(info->root_core, r.claim.core, 32); info->root_pre = r.claim.pre; info->root_post = r.claim.post;
             r.seal = nullptr;
         }
-        for (auto& nd : plan) zkh_free_seal(nd.seal);
+        for (auto& nd : ndata) zkh_free_seal(nd.seal);
     }
     if (join_tree == 1 && n > 1 && !errs.any()) {
         const double tj = now_s();
