@@ -10,6 +10,11 @@
 //   prove_session (--desc syn_a.desc | --circuit syn_a) [--join-desc p2_join.desc | --recursion-dir DIR | --build-recursion]
 //                 [--po2 20] [--tail-po2 18] [--segments 64]
 //                 [--devices 1] [--inflight 3] [--join-po2 18] [--noise-seed N] [--two-phase] [--recompute-code] [--no-join3]
+//                 [--csv FILE [--block-number N] [--gas-used N]]
+// --csv appends one row in the reference's stats vocabulary (/root/reference/run-parallel.sh:15 writes the header
+// "block_number,execution_time,total_cycles,user_cycles,paging_cycles,keccak_calls,gas_used" and :53-70 scrape the columns out of a
+// dev-mode prove): execution_time = this session's wall-clock, total_cycles = sum of 2^po2 over the segments, user_cycles = their
+// active rows (2^po2 - ZK_CYCLES), paging_cycles and keccak_calls 0 (these circuits page nothing and call no accelerator).
 // --circuit NAME: a circuit description compiled into the library (zkh_shipped_circuit_desc) instead of a file.
 // --build-recursion: no files at all — the lift / lift2 / join / join3 programs of this block are BUILT here, in-process, by the
 // library (zkh_session_build_recursion -> zkh_rec_build_program: this library's STARK verifier restated for the RECURSION circuit) from the
@@ -39,7 +44,8 @@ static bool read_words(const std::string& path, std::vector<uint32_t>& out) {
 }
 
 int main(int argc, char** argv) {
-    std::string desc_path, join_path, rec_dir, circuit_name;
+    std::string desc_path, join_path, rec_dir, circuit_name, csv_path, gas_used = "N/A";
+    unsigned long long block_number = 0;
     bool build_recursion = false;
     size_t po2 = 20, tail_po2 = 18, n = 64, devices = 1, inflight = 3, join_po2 = 18;
     uint64_t noise = 0;
@@ -56,6 +62,9 @@ int main(int argc, char** argv) {
         else if (a == "--tail-po2") num(tail_po2);
         else if (a == "--segments") num(n);
         else if (a == "--devices") num(devices);
+        else if (a == "--csv" && i + 1 < argc) csv_path = argv[++i];
+        else if (a == "--block-number" && i + 1 < argc) block_number = strtoull(argv[++i], nullptr, 0);
+        else if (a == "--gas-used" && i + 1 < argc) gas_used = argv[++i];
         else if (a == "--inflight") num(inflight);
         else if (a == "--join-po2") num(join_po2);
         else if (a == "--noise-seed" && i + 1 < argc) noise = strtoull(argv[++i], nullptr, 0);
@@ -157,6 +166,20 @@ int main(int argc, char** argv) {
            zkh_version(), n, po2, segs[n - 1].po2, zkh_session_lanes(session), info.wall_s, info.leaves_s, n / info.leaves_s,
            1e3 * info.witgen_s_sum / n, info.n_lifts, info.lift_s, info.n_joins, info.join_s, info.n_lifts ? "true" : "false",
            info.root_seal_words, words, info.streamed ? "true" : "false", info.fold_tail_s, info.fold_busy_s_sum, info.n_retries, n_built ? "true" : "false", build_s, root_out.c_str());
+    if (!csv_path.empty()) {
+        unsigned long long total = 0, user = 0;
+        for (size_t i = 0; i < n; i++) { total += 1ull << segs[i].po2; user += (1ull << segs[i].po2) - ZKH_ZK_CYCLES; }
+        FILE* probe = fopen(csv_path.c_str(), "r");
+        const bool fresh = probe == nullptr;
+        if (probe) fclose(probe);
+        if (FILE* f = fopen(csv_path.c_str(), "a")) {
+            if (fresh) fprintf(f, "block_number,execution_time,total_cycles,user_cycles,paging_cycles,keccak_calls,gas_used\n");
+            fprintf(f, "%llu,%.6f,%llu,%llu,0,0,%s\n", block_number, info.wall_s, total, user, gas_used.c_str());
+            fclose(f);
+        } else {
+            fprintf(stderr, "cannot write %s\n", csv_path.c_str());
+        }
+    }
     zkh_prove_info_free(&info);
     zkh_session_destroy(session);
     return 0;

@@ -146,9 +146,10 @@ const char* zkh_combos_prepare(zkh_ctx*, zkh_buf* combos, const uint32_t* pos, c
  * reg_combo_ids, mix), all operands device buffers as in `impl Hal`:
  *   cur = 1; for r < regs_count: combos[cycles*reg_combo_ids[r] + i] -= cur * coeff_u[pos + i] (i < reg_sizes[r]); cur *= mix; pos += reg_sizes[r];
  *   then ZKH_CHECK_SIZE times: combos[cycles*combo_count] -= cur * coeff_u[pos]; pos += 1; cur *= mix.
- * combos: (combo_count + 1) x cycles ExtElems; registers of any size 1 .. cycles.  The register list is read back once and VALIDATED
- * before the launch (sizes, combo ids, and that coeff_u holds sum(sizes) + ZKH_CHECK_SIZE coefficients): an inconsistent list is an
- * error, never an out-of-bounds read.  (zkh_combos_prepare above is the host-flattened form the in-library prover uses.) */
+ * combos: (combo_count + 1) x cycles ExtElems; registers of any size 1 .. cycles.  Nothing is read back: the register list is
+ * VALIDATED ON THE DEVICE before it is used (sizes, combo ids, and that coeff_u holds sum(sizes) + ZKH_CHECK_SIZE coefficients); an
+ * inconsistent list leaves combos untouched — never an out-of-bounds read — and is REPORTED BY THE NEXT zkh_sync / zkh_read of the
+ * context (the error names the register).  (zkh_combos_prepare above is the host-flattened form the in-library prover uses.) */
 const char* zkh_combos_prepare_regs(zkh_ctx*, zkh_buf* combos, const zkh_buf* coeff_u, size_t combo_count, size_t cycles,
                                     size_t regs_count, const zkh_buf* reg_sizes, const zkh_buf* reg_combo_ids,
                                     const uint32_t mix[4]);

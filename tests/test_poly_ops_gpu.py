@@ -139,13 +139,20 @@ def test_combos_prepare_regs_takes_any_register_size_and_refuses_inconsistent_li
     assert np.array_equal(a.to_vec(), b.to_vec())
 
     def call(sz, idv, cu_words):
-        hal.combos_prepare_regs(hal.copy_from("combos", start), hal.copy_from("cu", coeff_u[:cu_words]), combo_count, cycles,
+        # the list is checked ON THE DEVICE (no read-back inside the call); the refusal arrives with the next host-visible sync, and the
+        # combos are untouched
+        target = hal.copy_from("combos", start)
+        hal.combos_prepare_regs(target, hal.copy_from("cu", coeff_u[:cu_words]), combo_count, cycles,
                                 hal.copy_from("s", np.asarray(sz, dtype=np.uint32)), hal.copy_from("i", np.asarray(idv, dtype=np.uint32)), hop.e_words(mix))
+        try:
+            hal.sync()
+        finally:
+            assert np.array_equal(target.to_vec(), start)
     with pytest.raises(HalError, match="add up to"):                  # sizes claim more U coefficients than coeff_u holds
         call(sizes, ids, 4 * (n_u - 5))
-    with pytest.raises(HalError, match="has size"):                   # a register larger than the polynomial
+    with pytest.raises(HalError, match="has size 0 or more"):         # a register larger than the polynomial
         call([cycles + 1] + list(sizes[1:]), ids, coeff_u.size)
-    with pytest.raises(HalError, match="has size"):
+    with pytest.raises(HalError, match="has size 0 or more"):
         call([0] + list(sizes[1:]), ids, coeff_u.size)
-    with pytest.raises(HalError, match="names combo"):
+    with pytest.raises(HalError, match="names a combo beyond"):
         call(sizes, [combo_count] + list(ids[1:]), coeff_u.size)

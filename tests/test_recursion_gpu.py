@@ -338,10 +338,19 @@ def test_cpp_host_builds_the_recursion_programs_itself_and_gets_the_python_root(
     sess2.close()
     assert np.array_equal(root2.seal, root.seal) and st2["root_program"] == st["root_program"]
     exe = os.path.join(os.path.dirname(build.build_examples()), "prove_session")
+    csv = os.path.join(os.path.dirname(exe), "..", "gpurun_out", "prove_session_stats.csv")
+    os.makedirs(os.path.dirname(csv), exist_ok=True)
+    if os.path.exists(csv):
+        os.remove(csv)
     r = subprocess.run([exe, "--circuit", "syn_small", "--build-recursion", "--po2", "13", "--tail-po2", "12", "--segments", "7", "--inflight", "2",
-                        "--noise-seed", str(0x51)], capture_output=True, text=True, timeout=600)
+                        "--noise-seed", str(0x51), "--csv", csv, "--block-number", "19000000", "--gas-used", "15000000"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
+    # the reference's stats vocabulary (/root/reference/run-parallel.sh:15): header once, one row per session
+    rows = open(csv).read().strip().splitlines()
+    assert rows[0] == "block_number,execution_time,total_cycles,user_cycles,paging_cycles,keccak_calls,gas_used" and len(rows) == 2
+    cols = rows[1].split(",")
+    assert cols[0] == "19000000" and float(cols[1]) > 0 and int(cols[2]) == 6 * 8192 + 4096 and int(cols[3]) == int(cols[2]) - 7 * 1994 and cols[4:] == ["0", "0", "15000000"]
     assert out["verified"] is True and out["programs_built_by_library"] is True and out["in_circuit_verification"] is True
     assert out["lifts"] == st["n_lifts"] and out["joins"] == st["n_joins"]
     assert out["root_out"] == "".join(f"{int(w):08x}" for w in root.seal[:16])

@@ -103,6 +103,12 @@ struct zkh_ctx {
     uint32_t* pinned = nullptr;                  // host staging
     size_t pinned_words = 0;
     size_t stage_next = 0, stage_used = 0;       // pinned staging ring for small uploads (hal.hip h2d)
+    // Device-side argument checks that must not cost a host round trip (zkh_combos_prepare_regs: the register list is DEVICE data):
+    // the kernel refuses to index out of bounds and raises this sticky word instead; the next host-visible sync point of the context
+    // (zkh_sync / zkh_read — one per commit) reads it back with the data it was reading anyway and reports the failure there.
+    uint32_t* d_fail = nullptr;                  // 2 words: code, detail
+    uint32_t* h_fail = nullptr;                  // pinned mirror
+    bool fail_armed = false;                     // an op that may raise it was enqueued since the last check
     std::map<void*, size_t> host_blocks;         // pinned host memory handed to the caller (zkh_host_alloc): ptr -> bytes
     // four-step twiddle matrices of the lazy forward NTT (ntt.hip): key (log_n << 8 | expand_bits) -> 2^log_n words,
     // built on first use by a kernel on this context's stream, shared by every column of every transform of that shape

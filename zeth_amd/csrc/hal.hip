@@ -71,6 +71,8 @@ const char* new_buf(zkh_ctx* c, size_t n_words, bool zero, zkh_buf** out) {
 const char* ensure_pinned(zkh_ctx* c, size_t words) {
     if (c->pinned_words >= words) return nullptr;
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->d_fail) (void)hipFree(c->d_fail);
+    if (c->h_fail) (void)hipHostFree(c->h_fail);
     size_t w = words < 65536 ? 65536 : words;
     ZKH_HIP(hipHostMalloc((void**)&c->pinned, w * 4, hipHostMallocDefault));
     c->pinned_words = w;
@@ -204,6 +206,10 @@ static const char* ctx_init_tables(zkh_ctx* c) {
     ZKH_TRY(upload(&c->tab.diag, std::vector<uint32_t>(ZKH_P2_PTAB)));
     ZKH_TRY(zkh_poseidon2_set_constants(c, ZKH_P2_ROUND_CONSTANTS, ZKH_P2_M_INT_DIAG));
     ZKH_TRY(ntt_device_init(c));
+    ZKH_HIP(hipMalloc((void**)&c->d_fail, 8));
+    ZKH_HIP(hipMemsetAsync(c->d_fail, 0, 8, c->stream));
+    ZKH_HIP(hipHostMalloc((void**)&c->h_fail, 8, hipHostMallocDefault));
+    c->h_fail[0] = c->h_fail[1] = 0;
     return nullptr;
 }
 extern "C" const char* zkh_ctx_trim(zkh_ctx* c) {
@@ -234,7 +240,27 @@ extern "C" void zkh_ctx_destroy(zkh_ctx* c) {
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
-extern "C" const char* zkh_sync(zkh_ctx* c) { bind_thread(c); ZKH_HIP(hipStreamSynchronize(c->stream)); c->stage_used = 0; return nullptr; }
+// the sticky device-side failure word (common.h): fetched with the sync the caller asked for anyway
+static const char* check_device_fail(zkh_ctx* c) {
+    if (!c->fail_armed) return nullptr;
+    c->fail_armed = false;
+    const uint32_t code = c->h_fail[0], detail = c->h_fail[1];
+    if (!code) return nullptr;
+    (void)hipMemsetAsync(c->d_fail, 0, 8, c->stream);
+    switch (code) {
+    case 1: return make_err("combos_prepare_regs: register %u has size 0 or more than `cycles` words (found on the device; the call's combos are unchanged)", detail);
+    case 2: return make_err("combos_prepare_regs: register %u names a combo beyond combo_count (found on the device; the call's combos are unchanged)", detail);
+    case 3: return make_err("combos_prepare_regs: the register sizes add up to %u U coefficients (+ %d of the check polynomial), more than coeff_u holds (found on the device; the call's combos are unchanged)", detail, ZKH_CHECK_SIZE);
+    default: return make_err("a kernel reported failure code %u (%u)", code, detail);
+    }
+}
+extern "C" const char* zkh_sync(zkh_ctx* c) {
+    bind_thread(c);
+    if (c->fail_armed) ZKH_HIP(hipMemcpyAsync(c->h_fail, c->d_fail, 8, hipMemcpyDeviceToHost, c->stream));
+    ZKH_HIP(hipStreamSynchronize(c->stream));
+    c->stage_used = 0;
+    return check_device_fail(c);
+}
 extern "C" void* zkh_ctx_stream(zkh_ctx* c) { return (void*)c->stream; }
 
 // ---- buffers ----
@@ -296,9 +322,10 @@ extern "C" const char* zkh_read(zkh_ctx* c, const zkh_buf* b, uint32_t* host, si
     bind_thread(c);
     ZKH_REQUIRE(n <= b->len && off <= b->len - n, "read [%zu, +%zu) out of range (size %zu)", off, n, b->len);   // no wrap-around
     if (n) ZKH_HIP(hipMemcpyAsync(host, b->ptr() + off, n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (c->fail_armed) ZKH_HIP(hipMemcpyAsync(c->h_fail, c->d_fail, 8, hipMemcpyDeviceToHost, c->stream));
     ZKH_HIP(hipStreamSynchronize(c->stream));
     c->stage_used = 0;
-    return nullptr;
+    return check_device_fail(c);
 }
 extern "C" const char* zkh_write(zkh_ctx* c, zkh_buf* b, const uint32_t* host, size_t off, size_t n) {
     bind_thread(c);
@@ -434,8 +461,42 @@ __global__ void k_combos_prepare(uint4* combos, const uint32_t* pos, const uint4
 // Lane (c, i) owns the target offsets i, i + 32, i + 64, ... of combo c (registers of any size: `max_size` is the largest one, from the
 // host's validation of the register list, which also bounds every coeff_u index this kernel forms).
 constexpr uint32_t PREP_LANES_PER_COMBO = 32;
+// The register list is the CALLER'S device data.  One wave walks it before the main kernel: every size in 1 .. cycles, every combo id
+// below combo_count, the sizes (+ CHECK_SIZE) within coeff_u — meta[0] = the largest register (0: the list is inconsistent and the
+// main kernel does nothing), and on an inconsistency the context's sticky failure word is raised (reported by the next zkh_sync /
+// zkh_read: no host round trip here, one host-visible sync per commit stays one).
+__global__ void k_combos_regs_check(uint32_t* meta, uint32_t* fail, const uint32_t* reg_sizes, const uint32_t* reg_combo_ids, uint32_t regs_count,
+                                    uint32_t combo_count, size_t cycles, size_t coeff_ext) {
+    __shared__ uint32_t s_max, s_bad, s_bad_at;
+    __shared__ unsigned long long s_total;
+    if (threadIdx.x == 0) { s_max = 1; s_bad = 0; s_bad_at = 0xffffffffu; s_total = 0; }
+    __syncthreads();
+    unsigned long long part = 0;
+    for (uint32_t r = threadIdx.x; r < regs_count; r += blockDim.x) {
+        const uint32_t sz = reg_sizes[r], id = reg_combo_ids[r];
+        const uint32_t bad = (sz < 1 || sz > cycles) ? 1u : (id >= combo_count ? 2u : 0u);
+        if (bad && atomicMin(&s_bad_at, r) > r) atomicExch(&s_bad, bad);       // (the code of SOME bad register; the index is the lowest)
+        atomicMax(&s_max, sz);
+        part += sz;
+    }
+    atomicAdd(&s_total, part);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t code = 0, detail = 0;
+        if (s_bad_at != 0xffffffffu) {
+            const uint32_t sz = reg_sizes[s_bad_at];
+            code = (sz < 1 || sz > cycles) ? 1u : 2u; detail = s_bad_at;
+        } else if (cycles < (size_t)ZKH_CHECK_SIZE || s_total + ZKH_CHECK_SIZE > coeff_ext) {
+            code = 3; detail = (uint32_t)s_total;
+        }
+        meta[0] = code ? 0u : s_max;
+        if (code && atomicCAS(&fail[0], 0u, code) == 0u) fail[1] = detail;
+    }
+}
 __global__ void k_combos_prepare_regs(uint4* combos, size_t combos_ext, const uint4* coeff_u, uint32_t combo_count, size_t cycles,
-                                      uint32_t regs_count, const uint32_t* reg_sizes, const uint32_t* reg_combo_ids, Fp4 mix, uint32_t max_size) {
+                                      uint32_t regs_count, const uint32_t* reg_sizes, const uint32_t* reg_combo_ids, Fp4 mix, const uint32_t* meta) {
+    const uint32_t max_size = meta[0];
+    if (max_size == 0) return;                               // the check kernel refused the list: nothing is read, nothing is written
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t c = tid / PREP_LANES_PER_COMBO, i0 = tid % PREP_LANES_PER_COMBO;
     if (c > combo_count || (c == combo_count && i0 != 0)) return;
@@ -565,31 +626,21 @@ extern "C" const char* zkh_combos_prepare_regs(zkh_ctx* c, zkh_buf* combos, cons
     ZKH_REQUIRE(reg_sizes->len == regs_count && reg_combo_ids->len == regs_count, "combos_prepare_regs: reg_sizes / reg_combo_ids must hold regs_count words");
     ZKH_REQUIRE(coeff_u->len % 4 == 0 && coeff_u->len >= 4 * (regs_count + ZKH_CHECK_SIZE), "combos_prepare_regs: coeff_u too short");
     for (int i = 0; i < 4; i++) ZKH_REQUIRE(mix[i] < P, "combos_prepare_regs: mix is not a reduced element");
-    // The register list is the caller's device data and this is a public entry point: read it back once (a few KB; the call is in
-    // the latency-bound DEEP phase anyway) and check everything the kernel will index with — every size, every combo id, and that
-    // the U coefficients the sizes add up to (plus the CHECK_SIZE of the check polynomial) are really there.
-    std::vector<uint32_t> h_sizes(regs_count), h_ids(regs_count);
-    if (regs_count) {
-        ZKH_TRY(zkh_read(c, reg_sizes, h_sizes.data(), 0, regs_count));
-        ZKH_TRY(zkh_read(c, reg_combo_ids, h_ids.data(), 0, regs_count));
-    }
-    size_t total = 0;
-    uint32_t max_size = 1;
-    for (size_t r = 0; r < regs_count; r++) {
-        ZKH_REQUIRE(h_sizes[r] >= 1 && h_sizes[r] <= cycles, "combos_prepare_regs: register %zu has size %u (must be 1 .. cycles = %zu)", r, h_sizes[r], cycles);
-        ZKH_REQUIRE(h_ids[r] < combo_count, "combos_prepare_regs: register %zu names combo %u of %zu", r, h_ids[r], combo_count);
-        total += h_sizes[r];
-        max_size = std::max(max_size, h_sizes[r]);
-    }
-    ZKH_REQUIRE(cycles >= ZKH_CHECK_SIZE && (total + ZKH_CHECK_SIZE) * 4 <= coeff_u->len,
-                "combos_prepare_regs: the register sizes add up to %zu U coefficients (+ %d of the check polynomial) but coeff_u holds %zu", total,
-                ZKH_CHECK_SIZE, coeff_u->len / 4);
+    // The register list is the caller's device data and this is a public entry point — and the Rust shim's per-seal call: NOTHING is
+    // read back here.  k_combos_regs_check validates the list on the device (sizes, combo ids, that coeff_u holds what the sizes add up
+    // to); an inconsistent list makes the main kernel a no-op and raises the context's sticky failure word, which the next zkh_sync /
+    // zkh_read reports.  Never an out-of-bounds read, never a host round trip of its own.
     const Fp4 m(Fp::raw(mix[0]), Fp::raw(mix[1]), Fp::raw(mix[2]), Fp::raw(mix[3]));
     const size_t lanes = (combo_count + 1) * PREP_LANES_PER_COMBO;
+    Tmp meta;
+    ZKH_TRY(new_buf(c, 1, false, meta.out()));
     ProfScope ps(c, "combos_prepare", 36.0 * (double)(coeff_u->len / 4));
+    k_combos_regs_check<<<1, 256, 0, c->stream>>>(meta->ptr(), c->d_fail, reg_sizes->ptr(), reg_combo_ids->ptr(), (uint32_t)regs_count,
+                                                 (uint32_t)combo_count, cycles, coeff_u->len / 4);
+    c->fail_armed = true;
     k_combos_prepare_regs<<<(unsigned)((lanes + 63) / 64), 64, 0, c->stream>>>((uint4*)combos->ptr(), combos->len / 4, (const uint4*)coeff_u->ptr(),
                                                                                (uint32_t)combo_count, cycles, (uint32_t)regs_count, reg_sizes->ptr(),
-                                                                               reg_combo_ids->ptr(), m, max_size);
+                                                                               reg_combo_ids->ptr(), m, meta->ptr());
     return last_launch_error("combos_prepare_regs");
 }
 extern "C" const char* zkh_merkle_open(zkh_ctx* c, const zkh_buf* matrix, const zkh_buf* nodes, size_t rows, size_t cols,
