@@ -350,7 +350,9 @@ const char* zkh_shipped_circuit_desc(const char* name, const uint32_t** words, s
  * without Python builds them here).  kind 0 lift: child_desc = the SEGMENT circuit, po2s[0], control_roots = the 8 words of
  * its control root at that size as the library hands them out (zkh_syn_control_root: Montgomery form); kind 2 lift2: po2s[0..2),
  * control_roots = 16 words (left, right); kind 1 join /
- * kind 3 join3: child_desc = the RECURSION circuit, po2s[0..2) / [0..3), control_roots = NULL.  The program is placed at the
+ * kind 3 join3: child_desc = the RECURSION circuit, po2s[0..2) / [0..3), control_roots = NULL; kind 4 union (two receipts of any
+ * claims -> the digest of the sorted pair; inputs: seal, membership path per child, then the swap bit) / kind 5 resolve (the
+ * conditional receipt, opened, bound to its assumption receipt): child_desc = the RECURSION circuit, po2s[0..2).  The program is placed at the
  * smallest po2 that holds it (blob[2]); *blob is malloc'd: release with zkh_free_seal. */
 const char* zkh_rec_build_program(uint32_t kind, const uint32_t* child_desc, size_t child_desc_words, const uint32_t* po2s,
                                   const uint32_t* control_roots, uint32_t zk_cycles, uint32_t** blob, size_t* words);
@@ -488,6 +490,15 @@ const char* zkh_session_check_termination(const zkh_circuit*, const uint32_t* co
  * checked; ranks = 1, or N when the block was folded as N contiguous equal ranges whose roots were folded again (§7). */
 const char* zkh_succinct_verify(const uint32_t* root_seal, size_t root_words, const uint32_t* allowed_roots, size_t n_allowed,
                                 size_t root_program, const uint32_t* leaves, size_t n_leaves, size_t ranks);
+/* The same for a RESOLVED receipt (upstream: ProverServer::{union, resolve}, risc0-zkvm 3.0.3, /root/reference/Cargo.lock:5418 — the
+ * session's assumption receipts, e.g. keccak batches, are lifted, united pairwise into one receipt whose claim is the digest of the
+ * SORTED pair at every node, and the session's root is resolved against it; recursion programs of kinds 4 / 5, zkh_rec_build_program):
+ * assumption_claims = n_assumptions x 8 words, the receipt claim digests of the assumption receipts (any order within a pair: the
+ * union sorts).  The claim must be wrap(hash_pair(claim' of the leaves' join tree, claim' of the union tree), pre, post of the
+ * session).  n_leaves == 0 (leaves may be NULL): the receipt is the union-tree root alone. */
+const char* zkh_succinct_verify_resolved(const uint32_t* root_seal, size_t root_words, const uint32_t* allowed_roots, size_t n_allowed,
+                                         size_t root_program, const uint32_t* leaves, size_t n_leaves, size_t ranks,
+                                         const uint32_t* assumption_claims, size_t n_assumptions);
 
 /* ---- host placement (topology.hip): one process per GPU / one lane thread per context should run on the cores of the NUMA node
  * the GPU's root port hangs off, and allocate its pinned witness blocks there (upstream leaves placement to the operator:

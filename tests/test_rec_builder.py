@@ -91,6 +91,10 @@ def test_cpp_builder_equals_python_on_other_circuit_shapes():
     for po2s in ([lift_po2, lift_po2], [lift_po2, lift_po2, lift_po2]):
         py = V.build_join(R.recursion_circuit(), *po2s)
         assert np.array_equal(cpp_build(1 if len(po2s) == 2 else 3, R.recursion_circuit(), po2s), py.finish(py.min_po2()))
+    # union (kind 4: the sorted pair, a swap bit) and resolve (kind 5: the conditional receipt opened, bound to its assumption receipt)
+    for kind, build in ((4, V.build_union), (5, V.build_resolve)):
+        py = build(R.recursion_circuit(), lift_po2, lift_po2 + 1)
+        assert np.array_equal(cpp_build(kind, R.recursion_circuit(), [lift_po2, lift_po2 + 1]), py.finish(py.min_po2())), kind
 
 
 def test_cpp_builder_refuses_what_it_cannot_build():

@@ -299,6 +299,92 @@ def test_join_verifies_two_lifts_in_circuit(oracle, rec):
         rec.rec_witgen(jblob, np.concatenate([left, path, opening(100), right, host_rec.membership_words(levels, 1), opening(101)]))
 
 
+def test_union_sorts_the_pair_and_resolve_binds_the_assumption_receipt(oracle, rec):
+    """`union` and `resolve` on the CPU (SURVEY.md §8 row f2; ProverServer::{union, resolve}, risc0-zkvm 3.0.3, un-vendored): three
+    SYN-tiny seals lifted by the oracle; union(a, b) publishes wrap(hash_pair of the SORTED pair, 0, 0) whichever way round the two
+    are handed over; resolve binds an assumption receipt (here a lift: any receipt of the allowed set will do) to a conditional
+    receipt whose claim' it opens.  No witness for a swap word that is not a bit, a membership path of another program, an opening
+    that is not the conditional's, a forged assumption receipt.  (Sealed union / resolve receipts, verified: test_recursion_gpu.py.)"""
+    from zeth_amd import recursion as host_rec
+    desc = syn_air.syn_tiny()
+    child = zko.OracleCircuit(oracle, desc)
+    cpo2, czk = 8, 50
+    croot = child.control_root(cpo2, czk)
+    rdesc = R.recursion_circuit()
+    lift = V.build_lift(desc, cpo2, [int(w) * RINV % P for w in croot])
+    lpo2 = lift.min_po2()
+    union = V.build_union(rdesc, lpo2, lpo2)
+    upo2 = union.min_po2()
+    resolve = V.build_resolve(rdesc, lpo2, lpo2)
+    rpo2 = resolve.min_po2()
+    blobs = [lift.finish(lpo2), union.finish(upo2), resolve.finish(rpo2)]
+    roots = []
+    for blob, po2 in zip(blobs, (lpo2, upo2, rpo2)):
+        code = np.zeros(R.WC << po2, np.uint32)
+        assert oracle.zko_rec_code(blob, blob.size, code) is None
+        roots.append(rec.root_of_code(po2, code))
+    levels = host_rec.allowed_tree(roots)
+    A = levels[-1][0]
+
+    def lifted(seed, allowed=A):
+        code, data, out = rec.rec_witgen(blobs[0], np.concatenate([child.prove(cpo2, czk, seed=seed), allowed]))
+        return rec.prove_traces(lpo2, code, data, out)
+
+    def leaf_claim(seed):
+        claim_in = np.concatenate([child.prove(cpo2, czk, seed=seed)[:5], croot])
+        c = np.zeros(8, np.uint32)
+        oracle.zko_hash_elem_slice(np.ascontiguousarray(claim_in), claim_in.size, 1, c)
+        return c
+    a, b, sess = lifted(100), lifted(101), lifted(102)
+    path0, other_path = host_rec.membership_words(levels, 0), host_rec.membership_words(levels, 1)
+    bit = lambda on: np.array([RM if on else 0], dtype=np.uint32)
+    want, swap = host_rec.union_node(a[:8], b[:8])
+    lo, hi = (b, a) if swap else (a, b)
+    assert tuple(dec(lo[:8])) <= tuple(dec(hi[:8])) and np.array_equal(want, host_rec.wrap_claim(host_rec.hash_pair(lo[:8], hi[:8]), 0, 0))
+    code, data, out = rec.rec_witgen(blobs[1], np.concatenate([a, path0, b, path0, bit(swap)]))
+    assert np.array_equal(out[:8], want) and np.array_equal(out[8:], A)
+    assert rec.check_rows(upo2, rec.rec_accum(upo2, code, data, MIX), code, data, out, MIX) == -1
+    # the other way round, the other bit: the SAME claim - and the host's tree does not depend on the order either
+    _, _, out_ba = rec.rec_witgen(blobs[1], np.concatenate([b, path0, a, path0, bit(not swap)]))
+    assert np.array_equal(out_ba[:8], want)
+    assert np.array_equal(host_rec.union_claims([a[:8], b[:8]]), want) and np.array_equal(host_rec.union_claims([b[:8], a[:8]]), want)
+    # the wrong bit has a witness too - for a claim no verifier recomputes
+    _, _, out_wrong = rec.rec_witgen(blobs[1], np.concatenate([a, path0, b, path0, bit(not swap)]))
+    assert not np.array_equal(out_wrong[:8], want)
+    with pytest.raises(RuntimeError, match="tie|boolean|bit"):                      # a swap word that is not a bit
+        rec.rec_witgen(blobs[1], np.concatenate([a, path0, b, path0, np.array([2 * RM % P], dtype=np.uint32)]))
+    with pytest.raises(RuntimeError, match="tie"):                                  # a membership path for another program
+        rec.rec_witgen(blobs[1], np.concatenate([a, path0, b, other_path, bit(swap)]))
+    # three assumptions: (a u b) u c - an odd one moves up
+    c3 = host_rec.wrap_claim(leaf_claim(103), 0, 0)
+    assert np.array_equal(host_rec.union_claims([a[:8], b[:8], c3]), host_rec.union_node(want, c3)[0])
+    # resolve: the conditional receipt (the third lift: core = its segment's claim, state (0, 0)) bound to an assumption receipt
+    opening = np.concatenate([leaf_claim(102), np.zeros(2, np.uint32)])
+    useal, path1 = a, path0
+    rcode, rdata, rout = rec.rec_witgen(blobs[2], np.concatenate([sess, path0, opening, useal, path1]))
+    assert np.array_equal(rout[:8], host_rec.resolved_claim(sess[:8], 0, 0, a[:8])) and np.array_equal(rout[8:], A)
+    assert rec.check_rows(rpo2, rec.rec_accum(rpo2, rcode, rdata, MIX), rcode, rdata, rout, MIX) == -1
+    with pytest.raises(RuntimeError, match="tie"):                                  # an opening that is not the conditional's claim'
+        rec.rec_witgen(blobs[2], np.concatenate([sess, path0, leaf_claim(100), np.zeros(2, np.uint32), useal, path1]))
+    with pytest.raises(RuntimeError, match="tie"):                                  # a state range the conditional does not commit to
+        rec.rec_witgen(blobs[2], np.concatenate([sess, path0, leaf_claim(102), np.array([0, 9], np.uint32), useal, path1]))
+    forged = useal.copy()
+    forged[useal.size // 2] ^= 1
+    with pytest.raises(RuntimeError):                                               # a forged assumption receipt: no witness
+        rec.rec_witgen(blobs[2], np.concatenate([sess, path0, opening, forged, path1]))
+    # the library's host-only check (zkh_succinct_verify_resolved): a union tree over ONE assumption is that receipt's lift itself
+    from zeth_amd.hal import HalError
+    host_rec.succinct_verify(a, roots, 0, [], assumption_claims=[leaf_claim(100)])
+    with pytest.raises(HalError, match="union tree"):
+        host_rec.succinct_verify(a, roots, 0, [], assumption_claims=[leaf_claim(100), leaf_claim(101)])
+    with pytest.raises(HalError, match="resolved root"):                             # a lift is not a RESOLVED receipt
+        host_rec.succinct_verify(sess, roots, 0, [leaf_claim(102)], assumption_claims=[leaf_claim(100)])
+    # what the host recomputes for a resolved receipt: the join tree over the session's leaves AND the union tree over the assumptions
+    core, pre, post = host_rec._fold_root([leaf_claim(102)])
+    assert np.array_equal(host_rec.wrap_claim(core, pre, post), sess[:8])
+    assert np.array_equal(rout[:8], host_rec.resolved_claim(sess[:8], pre, post, host_rec.union_claims([host_rec.wrap_claim(leaf_claim(100), 0, 0)])))
+
+
 def test_committed_digests_of_circuit_programs_and_oracle_witnesses():
     """tests/golden/recursion_digests.json (make_golden_recursion.py): the circuit description, the assembler's blobs and the
     oracle's witnesses / seal have not moved since the fixture was committed"""

@@ -419,3 +419,68 @@ def test_segments_and_a_keccak_assumption_fold_into_one_receipt(hal):
     root.verify(rx.allowed_roots(), claims)
     assert root.n_leaves == 4
     print("RESOLVE", {"programs": len(programs), "sizes": sizes})
+
+
+def test_keccak_assumptions_are_united_and_the_session_resolved_against_them(hal):
+    """upstream's full shape (ProverServer::{lift, join, union, resolve}): the segment receipts fold into the session's root through the
+    join tree; the keccak batch receipts are lifted and UNITED (each node the digest of the sorted pair: no order among assumptions);
+    `resolve` binds the two.  The verifier recomputes the resolved claim from the segment leaves and the assumption leaves — in
+    Python and as one host-only library call — and refuses another assumption set, a missing assumption, a plain join-tree reading."""
+    import hashlib
+    from zeth_amd import recursion as rec
+    from zeth_amd.circuits import keccak_f
+    from zeth_amd.hal import HalError, HostCircuit
+    from zeth_amd.prover import Segment, SegmentProver
+    sdesc, kdesc = syn_air.syn_small(), keccak_f.keccak_f_circuit()
+    sp, kp = SegmentProver(hal, sdesc), SegmentProver(hal, kdesc)
+    segs = [sp.prove_segment(Segment(index=i, po2=13, seed=80 + i, noise_seed=9)) for i in range(3)]
+    msgs = [b"assumption %d: one accelerator batch" % i for i in range(3)]
+    kpubs = [tuple(w for lane in keccak_f.sha3_256_block(m) for w in (lane & 0xFFFFFFFF, lane >> 32)) for m in msgs]
+    krecs = [kp.prove_segment(Segment(index=i, po2=13, seed=0xCECC + i, noise_seed=3, pub=kpubs[i])) for i in range(3)]
+    sroot, kroot = sp.control_root(13), kp.control_root(13)
+    t0 = time.time()
+    programs = rec.build_programs(sdesc, {13: sroot}, assumptions=[(kdesc, {13: kroot})], fused_pairs=False, resolve=True)
+    kinds = [k for k, _ in programs]
+    assert len(programs) <= 16 and {k[0] for k in kinds} == {"lift", "join", "join3", "union", "resolve"}
+    rx = rec.Recursion(hal, programs)
+    t_build = time.time() - t0
+    session_root = rx.fold([rx.lift(r, 5) for r in segs], 7)
+    lifted = [rx.lift(k, 5, family=1) for k in krecs]
+    # union(a, b) == union(b, a): the same claim' whichever way round (two proofs, one statement)
+    ab, ba = rx.union(lifted[0], lifted[1], 11), rx.union(lifted[1], lifted[0], 12)
+    assert np.array_equal(ab.claim, ba.claim) and np.array_equal(ab.claim, rec.union_node(lifted[0].claim, lifted[1].claim)[0])
+    t0 = time.time()
+    assumed = rx.union_fold(lifted, 13)
+    resolved = rx.resolve(session_root, assumed, 17)
+    t_fold = time.time() - t0
+    sclaims = [HostCircuit(sdesc).receipt_claim(r.seal, sroot) for r in segs]
+    kclaims = [HostCircuit(kdesc).receipt_claim(r.seal, kroot) for r in krecs]
+    roots = rx.allowed_roots()
+    assumed.verify(roots, assumption_claims=kclaims)
+    resolved.verify(roots, sclaims, assumption_claims=kclaims)
+    resolved.verify(roots, sclaims, assumption_claims=[kclaims[1], kclaims[0], kclaims[2]])        # within a pair the order is the union's
+    rec.succinct_verify(resolved.seal, roots, resolved.program, sclaims, assumption_claims=kclaims)
+    rec.succinct_verify(assumed.seal, roots, assumed.program, [], assumption_claims=kclaims)
+    assert resolved.n_leaves == 6 and (resolved.pre, resolved.post) == (session_root.pre, session_root.post)
+    for leaves, assumptions, what in ((sclaims, kclaims[:2], "resolved root"), (sclaims, [kclaims[0], kclaims[2], kclaims[1]], "resolved root"),
+                                      (sclaims[:2], kclaims, "resolved root"), (sclaims, None, "claim tree")):
+        with pytest.raises(HalError, match=what):
+            resolved.verify(roots, leaves, assumption_claims=assumptions)
+        with pytest.raises(HalError, match=what):
+            rec.succinct_verify(resolved.seal, roots, resolved.program, leaves, assumption_claims=assumptions)
+    with pytest.raises(HalError, match="root receipt"):                                 # the union root is not the resolved receipt
+        rec.succinct_verify(assumed.seal, roots, resolved.program, sclaims, assumption_claims=kclaims)
+    # a keccak receipt whose proven state was altered has no lift, so nothing to unite
+    from zeth_amd.prover import SegmentReceipt
+    forged = krecs[0].seal.copy()
+    forged[7] = (int(forged[7]) + 1) % P
+    with pytest.raises(HalError, match="assertion of the program fails"):
+        rx.lift(SegmentReceipt(seal=forged, index=0, po2=13), family=1)
+    # a resolve against a receipt that is NOT what the verifier is told was assumed: proves, but verifies only as what it is
+    other = rx.resolve(session_root, lifted[2], 19)
+    other.verify(roots, sclaims, assumption_claims=[kclaims[2]])
+    with pytest.raises(HalError, match="resolved root"):
+        other.verify(roots, sclaims, assumption_claims=kclaims)
+    assert hashlib.sha3_256(msgs[0]).digest()                                          # (the batches are real SHA-3 blocks: test above)
+    print("UNION/RESOLVE", {"programs": len(programs), "kinds": sorted({k[0] for k in kinds}), "sizes": sorted({p.po2 for p in rx.programs}),
+                             "build_s": round(t_build, 2), "union_fold_and_resolve_s": round(t_fold, 3)})

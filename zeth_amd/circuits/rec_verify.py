@@ -509,6 +509,62 @@ def build_join(recursion_desc: np.ndarray, *po2s: int) -> Program:
     return pr
 
 
+def _child(v: Verifier, c: Circuit, po2: int, allowed):
+    """verify one child RECURSION seal (fresh transcript) and its program's membership in the allowed set -> (claim' wires, A wires)"""
+    pr = v.pr
+    v.io = Sponge(pr)
+    s = v.verify_seal(c, po2)
+    out_packed = s["head"][:4]
+    if allowed is None:
+        allowed = out_packed[2:4]
+    else:
+        pr.eq(out_packed[2], allowed[0])
+        pr.eq(out_packed[3], allowed[1])
+    v.allowed_member(s["code_root"], allowed)
+    return out_packed[:2], allowed
+
+
+def build_union(recursion_desc: np.ndarray, po2_left: int, po2_right: int) -> Program:
+    """`union` (risc0-zkvm 3.0.3 ProverServer::union -> risc0-circuit-recursion's union program: two receipts of ANY claims merged
+    into one whose claim is the digest of the SORTED pair, /root/reference/Cargo.lock:5418, :5305): how a session's assumption
+    receipts (keccak batches) become one receipt before `resolve`.  Inputs per child: its seal, its membership path; then ONE word,
+    the swap bit.  No state is opened and nothing chains: out = wrap(hash_pair(lo, hi), 0, 0) ‖ A with (lo, hi) = (claim'_l, claim'_r),
+    or the two swapped when the bit is set.  The ORDER is the host's rule (zeth_amd/recursion.py union_node: canonical words,
+    lexicographic): a verifier recomputes the sorted tree from the leaves, so a prover that swaps the wrong way proves a claim nobody
+    asks for."""
+    c = Circuit.parse(recursion_desc)
+    pr = Program()
+    v = Verifier(pr)
+    left, allowed = _child(v, c, po2_left, None)
+    right, allowed = _child(v, c, po2_right, allowed)
+    b = pr.unpack(v.read(1)[0])[0]
+    pr.boolean(b)
+    node = _wrap(v, v.pair_at(b, left, right), pr.zero(), pr.zero())
+    pr.public(node[0], node[1], allowed[0], allowed[1])
+    return pr
+
+
+def build_resolve(recursion_desc: np.ndarray, po2_cond: int, po2_assum: int) -> Program:
+    """`resolve` (ProverServer::resolve, same crates): the CONDITIONAL receipt (a session's join-tree root) bound to the receipt of
+    what it assumed (the union-tree root of its assumption receipts).  Inputs: the conditional seal, its membership path, the
+    OPENING of its claim' (core, (pre, post)); the assumption seal, its membership path.  out = wrap(hash_pair(claim'_cond,
+    claim'_assum), pre, post) ‖ A: the session's state range, unchanged, over a core that commits to both — the verifier recomputes
+    it from the segment leaves AND the assumption leaves, so a session resolved against another assumption set has another claim."""
+    c = Circuit.parse(recursion_desc)
+    pr = Program()
+    v = Verifier(pr)
+    cond, allowed = _child(v, c, po2_cond, None)
+    core = v.read(8)
+    st = pr.unpack(v.read(2)[0])
+    opened = _wrap(v, core, st[0], st[1])
+    pr.eq(opened[0], cond[0])
+    pr.eq(opened[1], cond[1])
+    assum, allowed = _child(v, c, po2_assum, allowed)
+    node = _wrap(v, v.pair(cond, assum), st[0], st[1])
+    pr.public(node[0], node[1], allowed[0], allowed[1])
+    return pr
+
+
 if __name__ == "__main__":      # python -m zeth_amd.circuits.rec_verify out_dir [segment.desc po2:root_hex8 ...]
     # writes the program set of a block (zeth_amd/recursion.py build_programs) as u32 blobs for non-Python hosts; without a
     # segment description: SYN-A at po2 20 and 18 with the control roots shipped in circuits/control_roots.json

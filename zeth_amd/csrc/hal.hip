@@ -71,8 +71,6 @@ const char* new_buf(zkh_ctx* c, size_t n_words, bool zero, zkh_buf** out) {
 const char* ensure_pinned(zkh_ctx* c, size_t words) {
     if (c->pinned_words >= words) return nullptr;
     if (c->pinned) (void)hipHostFree(c->pinned);
-    if (c->d_fail) (void)hipFree(c->d_fail);
-    if (c->h_fail) (void)hipHostFree(c->h_fail);
     size_t w = words < 65536 ? 65536 : words;
     ZKH_HIP(hipHostMalloc((void**)&c->pinned, w * 4, hipHostMallocDefault));
     c->pinned_words = w;
@@ -236,6 +234,8 @@ extern "C" void zkh_ctx_destroy(zkh_ctx* c) {
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->d_fail) (void)hipFree(c->d_fail);
+    if (c->h_fail) (void)hipHostFree(c->h_fail);
     for (auto& kv : c->host_blocks) (void)hipHostFree(kv.first);
     (void)hipStreamDestroy(c->stream);
     delete c;

@@ -1,4 +1,4 @@
-// rec_builder.hip — the lift / lift2 / join / join3 PROGRAMS of the RECURSION circuit, built on the host in C++ (no GPU, no Python).
+// rec_builder.hip — the lift / lift2 / join / join3 / union / resolve PROGRAMS of the RECURSION circuit, built on the host in C++ (no GPU, no Python).
 //
 // Upstream ships its recursion programs as precompiled `.zkr` files (risc0-circuit-recursion 4.0.2, un-vendored:
 // /root/reference/Cargo.lock:5305) that its Zirgen toolchain emits offline; ProverServer::{lift, join} (risc0-zkvm 3.0.3
@@ -796,12 +796,54 @@ const char* build_join(Program& pr, const Desc& c, const u32* po2s, size_t n_chi
     return nullptr;
 }
 
+// one child RECURSION seal: verified under a fresh transcript, its allowed root tied to the program's, its program a member of the set
+const char* rec_child(Verifier& v, Program& pr, const Desc& c, u32 po2, bool first, W2& allowed, W2& claim) {
+    v.io.reset(new Sponge(pr));
+    SealOut s;
+    ZKH_TRY(v.verify_seal(c, po2, s));
+    ZKH_REQUIRE(s.head.size() >= 4, "rec_build: the children of a union / resolve must be recursion seals (16 outputs)");
+    if (first) allowed = {s.head[2], s.head[3]};
+    else { pr.eq(s.head[2], allowed[0]); pr.eq(s.head[3], allowed[1]); }
+    v.allowed_member(s.code_root, allowed);
+    claim = {s.head[0], s.head[1]};
+    return nullptr;
+}
+// union: two receipts of any claims -> wrap(hash_pair of the pair, swapped when the witness bit is set, 0, 0) (rec_verify.py build_union)
+const char* build_union(Program& pr, const Desc& c, const u32* po2s) {
+    Verifier v(pr);
+    W2 allowed{-1, -1}, left, right;
+    ZKH_TRY(rec_child(v, pr, c, po2s[0], true, allowed, left));
+    ZKH_TRY(rec_child(v, pr, c, po2s[1], false, allowed, right));
+    const auto w = v.read(1);
+    const int b = pr.unpack(w[0])[0];
+    pr.boolean(b);
+    const W2 node = v.wrap(v.pair_at(b, left, right), pr.zero(), pr.zero());
+    pr.publish(node[0], node[1], allowed[0], allowed[1]);
+    return nullptr;
+}
+// resolve: the conditional receipt (claim' opened: core, pre, post) bound to its assumption receipt; the state range is the conditional's
+const char* build_resolve(Program& pr, const Desc& c, const u32* po2s) {
+    Verifier v(pr);
+    W2 allowed{-1, -1}, cond, assum;
+    ZKH_TRY(rec_child(v, pr, c, po2s[0], true, allowed, cond));
+    const auto core = v.read(8);
+    const auto stw = v.read(2);
+    const auto st = pr.unpack(stw[0]);
+    const W2 opened = v.wrap({core[0], core[1]}, st[0], st[1]);
+    pr.eq(opened[0], cond[0]);
+    pr.eq(opened[1], cond[1]);
+    ZKH_TRY(rec_child(v, pr, c, po2s[1], false, allowed, assum));
+    const W2 node = v.wrap(v.pair(cond, assum), st[0], st[1]);
+    pr.publish(node[0], node[1], allowed[0], allowed[1]);
+    return nullptr;
+}
+
 }  // namespace
 
 extern "C" const char* zkh_rec_build_program(uint32_t kind, const uint32_t* child_desc, size_t child_desc_words, const uint32_t* po2s,
                                              const uint32_t* control_roots, uint32_t zk_cycles, uint32_t** blob, size_t* words) {
     ZKH_REQUIRE(child_desc && po2s && blob && words, "rec_build_program: null argument");
-    ZKH_REQUIRE(kind <= 3, "rec_build_program: kind %u (0 lift, 1 join, 2 lift2, 3 join3)", kind);
+    ZKH_REQUIRE(kind <= 5, "rec_build_program: kind %u (0 lift, 1 join, 2 lift2, 3 join3, 4 union, 5 resolve)", kind);
     const size_t n_children = kind == 0 ? 1 : kind == 3 ? 3 : 2;
     for (size_t k = 0; k < n_children; k++) ZKH_REQUIRE(po2s[k] >= 4 && po2s[k] <= 24, "rec_build_program: child po2 %u", po2s[k]);
     ZKH_REQUIRE((kind == 0 || kind == 2) == (control_roots != nullptr), "rec_build_program: lifts take the segment circuit's control roots, joins take none");
@@ -818,10 +860,12 @@ extern "C" const char* zkh_rec_build_program(uint32_t kind, const uint32_t* chil
     }
     Desc c;
     ZKH_TRY(parse_desc(child_desc, child_desc_words, c));
-    if (kind == 1 || kind == 3) ZKH_REQUIRE(c.kind == 4 && c.global_size[0] == 16, "rec_build_program: a join verifies seals of the RECURSION circuit");
+    if (kind == 1 || kind >= 3) ZKH_REQUIRE(c.kind == 4 && c.global_size[0] == 16, "rec_build_program: a join / union / resolve verifies seals of the RECURSION circuit");
     Program pr;
     if (kind == 0) ZKH_TRY(build_lift(pr, c, po2s[0], control_roots));
     else if (kind == 2) ZKH_TRY(build_lift2(pr, c, po2s[0], control_roots, po2s[1], control_roots + 8));
+    else if (kind == 4) ZKH_TRY(build_union(pr, c, po2s));
+    else if (kind == 5) ZKH_TRY(build_resolve(pr, c, po2s));
     else ZKH_TRY(build_join(pr, c, po2s, n_children));
     const u32 po2 = pr.min_po2(zk_cycles);
     ZKH_REQUIRE(po2, "rec_build_program: the program is too large");

@@ -9,6 +9,7 @@
 // index over all lanes of all devices: round-robin with work stealing for the short tail), with NO exchange between devices.
 // Host code only (threads + the C ABI of this library); one lane = one zkh_ctx (device + stream) + circuit + prover.
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -188,11 +189,42 @@ static const char* fold_claim_nodes(std::vector<NodeClaim> nodes, NodeClaim* roo
 }
 
 // `receipt.verify` for a SUCCINCT receipt, on the host alone (no GPU, no session): what zeth_amd/recursion.py RecReceipt.verify does.
-extern "C" const char* zkh_succinct_verify(const uint32_t* root_seal, size_t root_words, const uint32_t* allowed_roots, size_t n_allowed,
-                                           size_t root_program, const uint32_t* leaves, size_t n_leaves, size_t ranks) {
-    ZKH_REQUIRE(root_seal && allowed_roots && leaves, "succinct_verify: null argument");
+// union(l, r): wrap(hash_pair(lo, hi), 0, 0) with (lo, hi) the two claim' sorted by their canonical words, lexicographically
+// (zeth_amd/recursion.py union_node; ProverServer::union, risc0-zkvm 3.0.3: the UnionClaim keeps left <= right)
+static const char* union_claim(const uint32_t* l, const uint32_t* r, uint32_t out[8]) {
+    bool swap = false;
+    for (int i = 0; i < 8; i++) {
+        const uint32_t a = fp_decode(Fp::raw(l[i])), b = fp_decode(Fp::raw(r[i]));
+        if (a != b) { swap = b < a; break; }
+    }
+    NodeClaim nd;
+    ZKH_TRY(hash_pair_host(swap ? r : l, swap ? l : r, nd.core));
+    return wrap_claim(nd, out);
+}
+// the union tree over assumption claim' (zeth_amd/recursion.py union_claims): neighbours pairwise, level by level, an odd one moves up
+static const char* union_tree(std::vector<std::array<uint32_t, 8>> level, uint32_t out[8]) {
+    ZKH_REQUIRE(!level.empty(), "union tree: no assumption claims");
+    while (level.size() > 1) {
+        std::vector<std::array<uint32_t, 8>> up;
+        for (size_t k = 0; k + 1 < level.size(); k += 2) {
+            std::array<uint32_t, 8> u;
+            ZKH_TRY(union_claim(level[k].data(), level[k + 1].data(), u.data()));
+            up.push_back(u);
+        }
+        if (level.size() % 2) up.push_back(level.back());
+        level.swap(up);
+    }
+    memcpy(out, level[0].data(), 32);
+    return nullptr;
+}
+
+static const char* succinct_verify_impl(const uint32_t* root_seal, size_t root_words, const uint32_t* allowed_roots, size_t n_allowed,
+                                        size_t root_program, const uint32_t* leaves, size_t n_leaves, size_t ranks,
+                                        const uint32_t* assumptions, size_t n_assumptions) {
+    ZKH_REQUIRE(root_seal && allowed_roots && (leaves || !n_leaves) && (assumptions || !n_assumptions), "succinct_verify: null argument");
     ZKH_REQUIRE(n_allowed >= 1 && n_allowed <= REC_ALLOWED && root_program < n_allowed, "succinct_verify: the receipt's program is not in the allowed set");
-    ZKH_REQUIRE(n_leaves >= 1 && ranks >= 1 && n_leaves % ranks == 0, "succinct_verify: %zu leaves do not split into %zu equal ranges", n_leaves, ranks);
+    ZKH_REQUIRE(n_leaves + n_assumptions >= 1, "succinct_verify: neither leaves nor assumptions");
+    ZKH_REQUIRE(ranks >= 1 && n_leaves % ranks == 0 && (n_leaves || ranks == 1), "succinct_verify: %zu leaves do not split into %zu equal ranges", n_leaves, ranks);
     ZKH_REQUIRE(root_words > 16, "succinct_verify: not a recursion seal");
     // 1) ONE seal, under the control root of an allowed program
     const uint32_t* rdesc = nullptr;
@@ -224,12 +256,43 @@ extern "C" const char* zkh_succinct_verify(const uint32_t* root_seal, size_t roo
         for (size_t r = 0; r < ranks; r++) ZKH_TRY(fold_claim_nodes(std::vector<NodeClaim>(nodes.begin() + r * per, nodes.begin() + (r + 1) * per), &tops[r]));
         nodes.swap(tops);
     }
-    NodeClaim top;
-    ZKH_TRY(fold_claim_nodes(nodes, &top));
-    uint32_t want[8];
-    ZKH_TRY(wrap_claim(top, want));
-    ZKH_REQUIRE(memcmp(root_seal, want, 32) == 0, "succinct_verify: the receipt's claim is not the root of the leaves' claim tree");
+    uint32_t want[8], assumed[8];
+    if (n_assumptions) {                  // a lifted assumption receipt publishes wrap(receipt claim, 0, 0)
+        std::vector<std::array<uint32_t, 8>> lifted(n_assumptions);
+        for (size_t i = 0; i < n_assumptions; i++) {
+            NodeClaim nd;
+            memcpy(nd.core, assumptions + 8 * i, 32);
+            ZKH_TRY(wrap_claim(nd, lifted[i].data()));
+        }
+        ZKH_TRY(union_tree(lifted, assumed));
+    }
+    if (n_leaves) {
+        NodeClaim top;
+        ZKH_TRY(fold_claim_nodes(nodes, &top));
+        ZKH_TRY(wrap_claim(top, want));
+        if (n_assumptions) {              // resolve(cond, assum): the session's state range over hash_pair(claim'_cond, claim'_assum)
+            NodeClaim res;
+            ZKH_TRY(hash_pair_host(want, assumed, res.core));
+            res.pre = top.pre; res.post = top.post;
+            ZKH_TRY(wrap_claim(res, want));
+        }
+    } else {
+        memcpy(want, assumed, 32);
+    }
+    ZKH_REQUIRE(memcmp(root_seal, want, 32) == 0, n_assumptions ? "succinct_verify: the receipt's claim is not the resolved root of the leaves' claim tree and the assumptions' union tree"
+                                                                : "succinct_verify: the receipt's claim is not the root of the leaves' claim tree");
     return nullptr;
+}
+extern "C" const char* zkh_succinct_verify(const uint32_t* root_seal, size_t root_words, const uint32_t* allowed_roots, size_t n_allowed,
+                                           size_t root_program, const uint32_t* leaves, size_t n_leaves, size_t ranks) {
+    ZKH_REQUIRE(leaves && n_leaves >= 1, "succinct_verify: null argument");
+    return succinct_verify_impl(root_seal, root_words, allowed_roots, n_allowed, root_program, leaves, n_leaves, ranks, nullptr, 0);
+}
+extern "C" const char* zkh_succinct_verify_resolved(const uint32_t* root_seal, size_t root_words, const uint32_t* allowed_roots, size_t n_allowed,
+                                                    size_t root_program, const uint32_t* leaves, size_t n_leaves, size_t ranks,
+                                                    const uint32_t* assumption_claims, size_t n_assumptions) {
+    ZKH_REQUIRE(n_assumptions >= 1, "succinct_verify_resolved: no assumption claims (zkh_succinct_verify checks a receipt without assumptions)");
+    return succinct_verify_impl(root_seal, root_words, allowed_roots, n_allowed, root_program, leaves, n_leaves, ranks, assumption_claims, n_assumptions);
 }
 
 extern "C" const char* zkh_session_set_recursion(zkh_session* s, const uint32_t* rec_desc, size_t rec_desc_words, const uint32_t* const* blobs,

@@ -116,6 +116,11 @@ def fold_leaf_claims(leaves, ranks: int = 1) -> np.ndarray:
     hash_pair(claim'_l, claim'_r) and its state range runs from the left child's pre to the right child's post; a group of three is
     join(join(a, b), c).  The shape is `fold_plan`'s; ranks > 1: the leaves were folded in `ranks` contiguous equal ranges (one per
     GPU, `aligned_range`) whose roots were then folded by the same rule.  Raises if two neighbours do not chain."""
+    return wrap_claim(*_fold_root(leaves, ranks))
+
+
+def _fold_root(leaves, ranks: int = 1):
+    """(core, pre, post) of the root node of `fold_leaf_claims`' tree"""
     level = [(np.asarray(l[0], dtype=np.uint32), int(l[1]), int(l[2])) if isinstance(l, (tuple, list)) and len(l) == 3 and not np.isscalar(l[0])
              else (np.asarray(l, dtype=np.uint32), 0, 0) for l in leaves]
     if ranks > 1:
@@ -123,25 +128,66 @@ def fold_leaf_claims(leaves, ranks: int = 1) -> np.ndarray:
         if per * ranks != len(level):
             raise ValueError("fold_leaf_claims: the leaves do not split into `ranks` equal ranges")
         level = [_fold_nodes(level[r * per:(r + 1) * per]) for r in range(ranks)]
-    return wrap_claim(*_fold_nodes(level))
+    return _fold_nodes(level)
 
 
-def succinct_verify(root_seal, allowed_roots: Sequence[np.ndarray], root_program: int, leaves, ranks: int = 1) -> None:
+def _canonical(claim) -> Tuple[int, ...]:
+    """a digest as canonical residues: what `union` orders by"""
+    return tuple(int(w) * RINV % P for w in np.asarray(claim, dtype=np.uint32))
+
+
+def union_node(left, right) -> Tuple[np.ndarray, bool]:
+    """(claim' of union(left, right), swapped?): wrap(hash_pair(lo, hi), 0, 0) with (lo, hi) the two claim' SORTED by their canonical
+    words, lexicographically (upstream's UnionClaim keeps left <= right the same way: risc0-zkvm 3.0.3, recalled)"""
+    l, r = np.asarray(left, dtype=np.uint32), np.asarray(right, dtype=np.uint32)
+    swap = _canonical(r) < _canonical(l)
+    lo, hi = (r, l) if swap else (l, r)
+    return wrap_claim(hash_pair(lo, hi), 0, 0), swap
+
+
+def union_claims(claims: Sequence[np.ndarray]) -> np.ndarray:
+    """The claim' a union tree over assumption receipts ends in, from their claim' (a lifted keccak receipt publishes
+    wrap_claim(receipt claim, 0, 0)): neighbours are united pairwise, level by level (an odd one moves up).  The SET decides the
+    pairs' order, not the caller: union(a, b) = union(b, a)."""
+    level = [np.asarray(c, dtype=np.uint32) for c in claims]
+    if not level:
+        raise _hal.HalError("union: no assumption claims")
+    while len(level) > 1:
+        nxt = [union_node(level[k], level[k + 1])[0] for k in range(0, len(level) - 1, 2)]
+        if len(level) % 2:
+            nxt.append(level[-1])
+        level = nxt
+    return level[0]
+
+
+def resolved_claim(cond_claim, cond_pre: int, cond_post: int, assumption_claim) -> np.ndarray:
+    """claim' of resolve(cond, assum): the conditional's state range over hash_pair(claim'_cond, claim'_assum)"""
+    return wrap_claim(hash_pair(np.asarray(cond_claim, dtype=np.uint32), np.asarray(assumption_claim, dtype=np.uint32)), cond_pre, cond_post)
+
+
+def succinct_verify(root_seal, allowed_roots: Sequence[np.ndarray], root_program: int, leaves, ranks: int = 1,
+                    assumption_claims: Optional[Sequence[np.ndarray]] = None) -> None:
     """zkh_succinct_verify: `RecReceipt.verify` as ONE host-only library call (no GPU, no session) — the seal under an allowed
     program's control root, the allowed-programs root, the claim tree of the leaves ([(receipt claim, pre, post)] or bare claims).
-    Raises HalError."""
+    assumption_claims (zkh_succinct_verify_resolved): the receipt claims of the assumption receipts a RESOLVED receipt was bound to;
+    leaves empty: a union-tree root alone.  Raises HalError."""
     import ctypes as C
     lib = _hal.load_library()
     u32p = C.POINTER(C.c_uint32)
     seal = np.ascontiguousarray(root_seal, dtype=np.uint32)
     roots = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=np.uint32) for r in allowed_roots]))
     rows = []
-    for l in leaves:
+    for l in leaves or ():
         core, pre, post = (l if isinstance(l, (tuple, list)) and len(l) == 3 and not np.isscalar(l[0]) else (l, 0, 0))
         rows.append(np.concatenate([np.asarray(core, dtype=np.uint32), np.array([pre, post], dtype=np.uint32)]))
-    lv = np.ascontiguousarray(np.concatenate(rows))
-    _hal._check(lib.zkh_succinct_verify(seal.ctypes.data_as(u32p), seal.size, roots.ctypes.data_as(u32p), len(allowed_roots), int(root_program),
-                                        lv.ctypes.data_as(u32p), len(rows), int(ranks)))
+    lv = np.ascontiguousarray(np.concatenate(rows)) if rows else np.zeros(1, np.uint32)
+    if assumption_claims is None:
+        _hal._check(lib.zkh_succinct_verify(seal.ctypes.data_as(u32p), seal.size, roots.ctypes.data_as(u32p), len(allowed_roots), int(root_program),
+                                            lv.ctypes.data_as(u32p), len(rows), int(ranks)))
+        return
+    ac = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.uint32) for c in assumption_claims])) if len(assumption_claims) else np.zeros(1, np.uint32)
+    _hal._check(lib.zkh_succinct_verify_resolved(seal.ctypes.data_as(u32p), seal.size, roots.ctypes.data_as(u32p), len(allowed_roots), int(root_program),
+                                                 lv.ctypes.data_as(u32p), len(rows), int(ranks), ac.ctypes.data_as(u32p), len(assumption_claims)))
 
 
 @dataclass
@@ -178,17 +224,29 @@ class RecReceipt:
             idx >>= 1
         return rc.succinct_receipt_bytes(self.seal, self.control_root, self.claim, journal, self.program, digests, verifier_parameters=allowed_levels[-1][0])
 
-    def verify(self, allowed_roots: Sequence[np.ndarray], leaf_claims: Optional[Sequence[np.ndarray]] = None, ranks: int = 1) -> None:
+    def verify(self, allowed_roots: Sequence[np.ndarray], leaf_claims: Optional[Sequence[np.ndarray]] = None, ranks: int = 1,
+               assumption_claims: Optional[Sequence[np.ndarray]] = None) -> None:
         """Host check of the whole tree below this receipt: ONE seal verification, the program's membership in the allowed
         set, the allowed root the receipt carries, and (given the leaves: receipt claims, or (claim, pre, post) for circuits with a
-        state) the claim tree — whose joins each asserted post(l) = pre(r) in-circuit.  Raises HalError."""
+        state) the claim tree — whose joins each asserted post(l) = pre(r) in-circuit.  assumption_claims (receipt claims of the
+        assumption receipts, e.g. keccak batches): the receipt is a RESOLVED one — resolve(join tree over the leaves, union tree
+        over the lifted assumptions); without leaf_claims: a union-tree root over them alone.  Raises HalError."""
         roots = [np.asarray(r, dtype=np.uint32) for r in allowed_roots]
         if not any(np.array_equal(self.control_root, r) for r in roots):
             raise _hal.HalError("recursion receipt: its program is not in the allowed set")
         _hal.HostCircuit(rc.recursion_circuit()).verify_segment(self.seal, self.control_root)
         if not np.array_equal(self.allowed, allowed_tree(roots)[-1][0]):
             raise _hal.HalError("recursion receipt: it was produced under another allowed-programs root")
-        if leaf_claims is not None and not np.array_equal(self.claim, fold_leaf_claims(list(leaf_claims), ranks)):
+        if assumption_claims is not None:
+            assumed = union_claims([wrap_claim(c, 0, 0) for c in assumption_claims])
+            if leaf_claims is None:
+                expect = assumed
+            else:
+                core, pre, post = _fold_root(list(leaf_claims), ranks)
+                expect = resolved_claim(wrap_claim(core, pre, post), pre, post, assumed)
+            if not np.array_equal(self.claim, expect):
+                raise _hal.HalError("recursion receipt: its claim is not the resolved root of the leaves' claim tree and the assumptions' union tree")
+        elif leaf_claims is not None and not np.array_equal(self.claim, fold_leaf_claims(list(leaf_claims), ranks)):
             raise _hal.HalError("recursion receipt: its claim is not the root of the leaves' claim tree")
 
 
@@ -199,7 +257,7 @@ class ProgramSet(list):
 
 def build_programs(segment_desc, segment_roots: Optional[Dict[int, np.ndarray]] = None, zk_cycles: int = _hal.ZK_CYCLES,
                    assumptions: Sequence[Tuple[np.ndarray, Dict[int, np.ndarray]]] = (), fused_pairs: bool = True,
-                   ternary: bool = True) -> List[Tuple[Tuple, np.ndarray]]:
+                   ternary: bool = True, resolve: bool = False) -> List[Tuple[Tuple, np.ndarray]]:
     """The program set of a block: one lift per segment size (`segment_roots`: {po2: control root of the segment circuit}) and
     per size of every assumption circuit (`assumptions`: [(circuit description, {po2: control root})], e.g. KECCAK-F batches:
     upstream lifts those receipts too and resolves them on the way to the succinct receipt), then joins for every pair of
@@ -208,21 +266,26 @@ def build_programs(segment_desc, segment_roots: Optional[Dict[int, np.ndarray]] 
     ("lift", segment po2, family) with family 0 = the segment circuit, 1.. = the assumption circuits, ("lift2", po2_l, po2_r) =
     lift + lift + join fused for a pair of segment receipts (fused_pairs), ("join", po2_l, po2_r), or (ternary) ("join3", m, m, m)
     for the largest size m when three such children fit one proof of that size again — the levels above the bottom of a large
-    block are all of that size, and take three nodes per proof instead of two."""
+    block are all of that size, and take three nodes per proof instead of two.
+    resolve: upstream's shape for assumptions — their lifts do NOT join the segments' tree: ("union", a, b) programs close over THEIR
+    sizes (the union tree of `Recursion.union_fold`), and ("resolve", s, u) binds a session root of size s to a union root of size u
+    (`Recursion.resolve`).  Without it (the default) assumption lifts are leaves of the one join tree."""
     rdesc = rc.recursion_circuit()
     out: List[Tuple[Tuple, np.ndarray]] = []
     sizes = set()
 
-    def add(kind, pr):
+    asizes = set()                        # resolve: the sizes on the assumptions' side (their lifts, the unions)
+
+    def add(kind, pr, into=None):
         po2 = pr.min_po2(zk_cycles)
         out.append((kind, pr.finish(po2, zk_cycles)))
-        sizes.add(po2)
+        (sizes if into is None else into).add(po2)
     families = [(segment_desc, segment_roots or {})] + list(assumptions)
     canon = lambda root: [int(w) * RINV % P for w in np.asarray(root, dtype=np.uint32)]
     for fam, (desc, roots) in enumerate(families):
         desc = np.asarray(desc, dtype=np.uint32)
         for po2, root in sorted(roots.items(), reverse=True):
-            add(("lift", po2, fam), rec_verify.build_lift(desc, po2, canon(root)))
+            add(("lift", po2, fam), rec_verify.build_lift(desc, po2, canon(root)), asizes if resolve and fam else None)
     if fused_pairs:
         # lift + lift + join as one program for pairs of SEGMENT receipts (a block's segments come largest first, the short
         # tail last: pairs (a, b) with a >= b)
@@ -243,6 +306,23 @@ def build_programs(segment_desc, segment_roots: Optional[Dict[int, np.ndarray]] 
         pr3 = rec_verify.build_join(rdesc, m, m, m)
         if pr3.min_po2(zk_cycles) == m:
             out.append((("join3", m, m, m), pr3.finish(m, zk_cycles)))
+    if resolve and asizes:
+        # the pairs `union_fold` can meet: two leaves, or a union result on the LEFT of anything (an odd node moves up at the END of its
+        # level, so the right operand is never newer than the left one)
+        leaf_sizes, usizes, done = set(asizes), set(), set()
+        while True:
+            todo = [(a, b) for a in sorted(leaf_sizes | usizes) for b in sorted(leaf_sizes | usizes)
+                    if (a, b) not in done and (a in usizes or (a in leaf_sizes and b in leaf_sizes))]
+            if not todo:
+                break
+            for a, b in todo:
+                done.add((a, b))
+                add(("union", a, b), rec_verify.build_union(rdesc, a, b), usizes)
+        # a session root of size s against a union root of size u: the largest session sizes first, as far as the allowed set has room
+        for a in sorted(sizes, reverse=True):
+            for b in sorted(leaf_sizes | usizes):
+                if len(out) < N_ALLOWED:
+                    add(("resolve", a, b), rec_verify.build_resolve(rdesc, a, b), set())
     assert len(out) <= N_ALLOWED, f"{len(out)} programs do not fit the allowed set"
     ps = ProgramSet(out)
     ps.families = [(np.asarray(d, dtype=np.uint32), dict(r)) for d, r in families]
@@ -347,6 +427,41 @@ class Recursion:
         if ("join3", a.po2, b.po2, c.po2) in self.kinds:
             return self.join3(a, b, c, noise_seed)
         return self.join(self.join(a, b, noise_seed), c, noise_seed)
+
+    def union(self, a: RecReceipt, b: RecReceipt, noise_seed: Optional[int] = None) -> RecReceipt:
+        """`ProverServer::union`: two receipts of ANY claims -> one whose claim' is wrap(hash_pair of the SORTED pair, 0, 0); the swap
+        bit the program reads is decided here (union_node); union(a, b) and union(b, a) publish the same claim'"""
+        i = self.kinds.index(("union", a.po2, b.po2))
+        claim, swap = union_node(a.claim, b.claim)
+        parts = [a.seal, membership_words(self.levels, a.program), b.seal, membership_words(self.levels, b.program),
+                 np.array([R if swap else 0], dtype=np.uint32)]
+        seal, _ = self.programs[i].prove(np.concatenate(parts), _seed(noise_seed))
+        lo, hi = (b, a) if swap else (a, b)
+        return RecReceipt(seal, self.programs[i].po2, i, self.programs[i].root, a.n_leaves + b.n_leaves, hash_pair(lo.claim, hi.claim), 0, 0)
+
+    def union_fold(self, leaves: Sequence[RecReceipt], noise_seed: Optional[int] = None) -> RecReceipt:
+        """the union tree over assumption receipts (lifted keccak batches): neighbours pairwise, level by level (`union_claims`)"""
+        level = list(leaves)
+        if not level:
+            raise _hal.HalError("union: no assumption receipts")
+        while len(level) > 1:
+            nxt = [self.union(level[k], level[k + 1], noise_seed) for k in range(0, len(level) - 1, 2)]
+            if len(level) % 2:
+                nxt.append(level[-1])
+            level = nxt
+        return level[0]
+
+    def resolve(self, cond: RecReceipt, assum: RecReceipt, noise_seed: Optional[int] = None) -> RecReceipt:
+        """`ProverServer::resolve`: the conditional receipt (a session's join-tree root; its claim' is opened in-circuit) bound to the
+        receipt of what it assumed (a union-tree root): claim' = wrap(hash_pair(claim'_cond, claim'_assum), pre, post) of the session"""
+        i = self.kinds.index(("resolve", cond.po2, assum.po2))
+        if cond.core is None:
+            raise _hal.HalError("resolve: a conditional receipt without the opening of its claim (core, pre, post)")
+        parts = [cond.seal, membership_words(self.levels, cond.program), np.asarray(cond.core, dtype=np.uint32), np.array([cond.pre, cond.post], dtype=np.uint32),
+                 assum.seal, membership_words(self.levels, assum.program)]
+        seal, _ = self.programs[i].prove(np.concatenate(parts), _seed(noise_seed))
+        return RecReceipt(seal, self.programs[i].po2, i, self.programs[i].root, cond.n_leaves + assum.n_leaves,
+                          hash_pair(cond.claim, assum.claim), cond.pre, cond.post)
 
     def fold_segments(self, receipts: Sequence[SegmentReceipt], noise_seed: Optional[int] = None) -> RecReceipt:
         """segment receipts -> one receipt: the bottom level pairs them with lift2 where the program set has it (else lift, lift,
