@@ -10,13 +10,16 @@
 //   prove_session (--desc syn_a.desc | --circuit syn_a) [--join-desc p2_join.desc | --recursion-dir DIR | --build-recursion]
 //                 [--po2 20] [--tail-po2 18] [--segments 64]
 //                 [--devices 1] [--inflight 3] [--join-po2 18] [--noise-seed N] [--two-phase] [--recompute-code] [--no-join3]
-//                 [--csv FILE [--block-number N] [--gas-used N]]
+//                 [--csv FILE [--block-number N] [--gas-used N]] [--keccak-batches N [--keccak-po2 P]]
+// --keccak-batches N (with --build-recursion): the session ASSUMES N keccak batch receipts (KECCAK-F seals proven first, the shape
+// upstream's prove_keccak leaves behind): zkh_session_set_assumptions -> they are lifted, united pairwise (sorted pairs) and the
+// session's root is RESOLVED against the union root; the CSV's keccak_calls column counts their permutations.
 // --csv appends one row in the reference's stats vocabulary (/root/reference/run-parallel.sh:15 writes the header
 // "block_number,execution_time,total_cycles,user_cycles,paging_cycles,keccak_calls,gas_used" and :53-70 scrape the columns out of a
 // dev-mode prove): execution_time = this session's wall-clock, total_cycles = sum of 2^po2 over the segments, user_cycles = their
 // active rows (2^po2 - ZK_CYCLES), paging_cycles and keccak_calls 0 (these circuits page nothing and call no accelerator).
 // --circuit NAME: a circuit description compiled into the library (zkh_shipped_circuit_desc) instead of a file.
-// --build-recursion: no files at all — the lift / lift2 / join / join3 programs of this block are BUILT here, in-process, by the
+// --build-recursion: no files at all — the lift / lift2 / join / join3 (and union / resolve) programs of this block are BUILT here, in-process, by the
 // library (zkh_session_build_recursion -> zkh_rec_build_program: this library's STARK verifier restated for the RECURSION circuit) from the
 // segment circuit's control roots (computed on the GPU) and the built-in RECURSION description: nothing in the run needs Python.
 // --recursion-dir: the directory `python -m zeth_amd.circuits.rec_verify DIR` and `python -m zeth_amd.circuits.recursion
@@ -50,6 +53,7 @@ int main(int argc, char** argv) {
     size_t po2 = 20, tail_po2 = 18, n = 64, devices = 1, inflight = 3, join_po2 = 18;
     uint64_t noise = 0;
     bool two_phase = false, recompute_code = false, no_join3 = false;
+    size_t keccak_batches = 0, keccak_po2 = 13;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto num = [&](size_t& d) { if (i + 1 < argc) d = strtoull(argv[++i], nullptr, 10); };
@@ -68,6 +72,8 @@ int main(int argc, char** argv) {
         else if (a == "--inflight") num(inflight);
         else if (a == "--join-po2") num(join_po2);
         else if (a == "--noise-seed" && i + 1 < argc) noise = strtoull(argv[++i], nullptr, 0);
+        else if (a == "--keccak-batches") num(keccak_batches);
+        else if (a == "--keccak-po2") num(keccak_po2);
         else if (a == "--no-join3") no_join3 = true;            // leave the join3 program out: three nodes cost two proofs
         else if (a == "--two-phase") two_phase = true;          // seal everything, then fold (default: one pipeline)
         else if (a == "--recompute-code") recompute_code = true; // re-commit the code group per segment, like upstream's SegmentProver
@@ -123,6 +129,38 @@ int main(int argc, char** argv) {
         err = zkh_session_set_recursion(session, rdesc.data(), rdesc.size(), ptrs.data(), words.data(), kinds.data(), blobs.size());
         if (err) { fprintf(stderr, "zkh_session_set_recursion: %s\n", err); zkh_free_error(err); return 1; }
     }
+    // ---- assumption receipts: N keccak batches sealed by a session of their own, handed to the block's session (verified there) ----
+    zkh_prove_info kinfo;
+    memset(&kinfo, 0, sizeof kinfo);
+    if (keccak_batches) {
+        if (!build_recursion) { fprintf(stderr, "--keccak-batches needs --build-recursion (the union / resolve programs are built for the session)\n"); return 2; }
+        const uint32_t* kw = nullptr;
+        size_t knw = 0;
+        if (const char* e = zkh_shipped_circuit_desc("keccak_f", &kw, &knw)) { fprintf(stderr, "%s\n", e); zkh_free_error(e); return 2; }
+        zkh_session* ks = nullptr;
+        err = zkh_session_create(devs.data(), 1, 1, kw, knw, nullptr, 0, &ks);
+        if (err) { fprintf(stderr, "zkh_session_create (keccak): %s\n", err); zkh_free_error(err); return 1; }
+        std::vector<zkh_segment> ksegs(keccak_batches);
+        for (size_t i = 0; i < keccak_batches; i++) {
+            memset(&ksegs[i], 0, sizeof ksegs[i]);
+            ksegs[i].po2 = (uint32_t)keccak_po2;
+            ksegs[i].seed = 0xCECCull + i;
+            ksegs[i].noise_key[0] = (uint32_t)noise; ksegs[i].noise_key[1] = (uint32_t)(noise >> 32);
+        }
+        err = zkh_session_prove(ks, ksegs.data(), keccak_batches, 0, 0, nullptr, &kinfo);
+        if (err) { fprintf(stderr, "zkh_session_prove (keccak): %s\n", err); zkh_free_error(err); return 1; }
+        zkh_session_destroy(ks);
+        // the keccak circuit's control root at that size (a deployment ships it: upstream's control IDs)
+        zkh_ctx* kc = nullptr; zkh_circuit* kcir = nullptr; zkh_prover* kp = nullptr;
+        uint32_t kroot[8];
+        if ((err = zkh_ctx_create(devs[0], "poseidon2", &kc)) || (err = zkh_circuit_load(kc, kw, knw, &kcir)) || (err = zkh_prover_create(kc, kcir, &kp)) ||
+            (err = zkh_syn_control_root(kp, keccak_po2, ZKH_ZK_CYCLES, kroot))) { fprintf(stderr, "keccak control root: %s\n", err); zkh_free_error(err); return 1; }
+        zkh_prover_destroy(kp); zkh_circuit_destroy(kcir); zkh_ctx_destroy(kc);
+        std::vector<uint32_t> kroots, kpo2s(keccak_batches, (uint32_t)keccak_po2);
+        for (size_t i = 0; i < keccak_batches; i++) kroots.insert(kroots.end(), kroot, kroot + 8);
+        err = zkh_session_set_assumptions(session, kw, knw, kinfo.seals, kinfo.seal_words, kpo2s.data(), kroots.data(), keccak_batches);
+        if (err) { fprintf(stderr, "zkh_session_set_assumptions: %s\n", err); zkh_free_error(err); return 1; }
+    }
     double build_s = 0;
     size_t n_built = 0;
     if (build_recursion) {
@@ -162,10 +200,10 @@ int main(int argc, char** argv) {
            "\"wall_s\": %.4f, \"leaves_s\": %.4f, \"segments_per_s\": %.3f, \"witgen_ms_per_segment\": %.3f, \"lifts\": %zu, \"lift_s\": %.4f, "
            "\"joins\": %zu, \"join_tree_s\": %.4f, \"in_circuit_verification\": %s, \"root_receipt_words\": %zu, \"seal_words_total\": %zu, "
            "\"streamed_fold\": %s, \"fold_tail_s\": %.4f, \"fold_busy_lane_s\": %.3f, \"segment_retries\": %zu, "
-           "\"programs_built_by_library\": %s, \"program_build_and_load_s\": %.3f, \"root_out\": \"%s\", \"verified\": true}\n",
+           "\"programs_built_by_library\": %s, \"program_build_and_load_s\": %.3f, \"assumption_receipts\": %zu, \"resolved\": %s, \"root_out\": \"%s\", \"verified\": true}\n",
            zkh_version(), n, po2, segs[n - 1].po2, zkh_session_lanes(session), info.wall_s, info.leaves_s, n / info.leaves_s,
            1e3 * info.witgen_s_sum / n, info.n_lifts, info.lift_s, info.n_joins, info.join_s, info.n_lifts ? "true" : "false",
-           info.root_seal_words, words, info.streamed ? "true" : "false", info.fold_tail_s, info.fold_busy_s_sum, info.n_retries, n_built ? "true" : "false", build_s, root_out.c_str());
+           info.root_seal_words, words, info.streamed ? "true" : "false", info.fold_tail_s, info.fold_busy_s_sum, info.n_retries, n_built ? "true" : "false", build_s, keccak_batches, keccak_batches ? "true" : "false", root_out.c_str());
     if (!csv_path.empty()) {
         unsigned long long total = 0, user = 0;
         for (size_t i = 0; i < n; i++) { total += 1ull << segs[i].po2; user += (1ull << segs[i].po2) - ZKH_ZK_CYCLES; }
@@ -174,13 +212,16 @@ int main(int argc, char** argv) {
         if (probe) fclose(probe);
         if (FILE* f = fopen(csv_path.c_str(), "a")) {
             if (fresh) fprintf(f, "block_number,execution_time,total_cycles,user_cycles,paging_cycles,keccak_calls,gas_used\n");
-            fprintf(f, "%llu,%.6f,%llu,%llu,0,0,%s\n", block_number, info.wall_s, total, user, gas_used.c_str());
+            // keccak_calls: the permutations the assumed batches prove (25 rows each; upstream counts the guest's accelerator calls)
+            const unsigned long long kcalls = keccak_batches * (((1ull << keccak_po2) - ZKH_ZK_CYCLES) / 25);
+            fprintf(f, "%llu,%.6f,%llu,%llu,0,%llu,%s\n", block_number, info.wall_s, total, user, kcalls, gas_used.c_str());
             fclose(f);
         } else {
             fprintf(stderr, "cannot write %s\n", csv_path.c_str());
         }
     }
     zkh_prove_info_free(&info);
+    zkh_prove_info_free(&kinfo);
     zkh_session_destroy(session);
     return 0;
 }

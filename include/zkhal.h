@@ -443,6 +443,17 @@ const char* zkh_session_set_recursion(zkh_session*, const uint32_t* rec_desc, si
  * generators) — a lift per size, a lift2 per pair, joins until the set of program sizes closes, and (with_join3) the join3 of the
  * largest size if it fits that size again: the set and the order of zeth_amd/recursion.py build_programs.  No Python, no files. */
 const char* zkh_session_build_recursion(zkh_session*, const uint32_t* po2s, size_t n_po2s, int with_join3);
+/* ASSUMPTION receipts of the session (upstream: the keccak batch receipts a guest's accelerator calls leave behind; ProverServer::
+ * {prove_keccak, lift, union, resolve}, risc0-zkvm 3.0.3, /root/reference/Cargo.lock:5418): n seals of the circuit `desc` (no state
+ * words; KECCAK-F), sizes po2s[i], proven beforehand (zkh_prove_segment), control_roots = n x 8 words (that circuit's control root at
+ * each size).  Every receipt is VERIFIED here on the host; the session keeps copies.  With join_tree == 2 they are lifted (lift
+ * programs of family 1), united pairwise into one receipt (kind 4: every node the digest of the SORTED pair; an odd one moves up) and
+ * the session's join-tree root is resolved against the union root (kind 5): the root receipt of zkh_session_prove is the RESOLVED
+ * one, zkh_session_verify recomputes its claim from the segments AND these receipts (zkh_succinct_verify_resolved: the same from
+ * claims alone).  Call BEFORE zkh_session_build_recursion, which then also builds those programs (zkh_session_set_recursion: kinds
+ * {0, po2, 1}, {4, a, b}, {5, session size, union size}).  n = 0 clears. */
+const char* zkh_session_set_assumptions(zkh_session*, const uint32_t* desc, size_t desc_words, const uint32_t* const* seals,
+                                        const size_t* seal_words, const uint32_t* po2s, const uint32_t* control_roots, size_t n);
 /* join_tree == 2 runs as ONE pipeline by default: a lift2 / join is proven the moment both children exist, on the fold lanes while
  * the sealing lanes are still busy with segments, on every lane afterwards (upstream joins as receipts arrive too).  on = 0: two
  * phases (seal everything, then fold).  Same tree, same receipts either way. */

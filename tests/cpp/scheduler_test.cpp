@@ -2,7 +2,8 @@
 //   g++ -std=c++17 -O1 -I zeth_amd/csrc tests/cpp/scheduler_test.cpp -o scheduler_test && ./scheduler_test
 // Checks: the fold plan's shape against the counts of zeth_amd/recursion.py fold_plan (pairs, then three at a time; join3 or two joins);
 // every node proven exactly once and only after its children under random completion orders, streamed and two-phase; a failed segment
-// retried on ANOTHER lane; a lane retired after two failures in a row; a segment that keeps failing ends the run; producers' indices.
+// retried on ANOTHER lane; a lane retired after two failures in a row; a segment that keeps failing ends the run; producers' indices;
+// sessions with assumption receipts: their lifts ready from the start, the union tree, one resolve as the root.
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -23,21 +24,26 @@ static int failures = 0;
 struct Programs {
     bool lift2 = true, join3 = true;
     uint32_t lift_po2 = 18;
+    bool unions = true;
     int program_of(uint32_t kind, uint32_t a, uint32_t b) const {
+        if (kind == 0 && b == 1) return a == 13 ? 4 : -1;                 // the lift of an assumption receipt (family 1): runs at po2 19
+        if (kind == 4) return (unions && a >= 18 && a <= 19 && b >= 18 && b <= 19) ? 5 : -1;
+        if (kind == 5) return (a >= 17 && a <= 18 && b >= 18 && b <= 19) ? 6 : -1;
         if (kind == 0) return (a == 20 || a == 18) ? 0 : -1;
         if (kind == 2) return lift2 ? 1 : -1;
         if (kind == 1) return (a >= 17 && a <= 18 && b >= 17 && b <= 18) ? 2 : -1;
         if (kind == 3) return (join3 && a == 18 && b == 18) ? 3 : -1;
         return -1;
     }
-    uint32_t po2_of(uint32_t program) const { return program == 0 ? lift_po2 : 18; }
+    uint32_t po2_of(uint32_t program) const { return program == 0 ? lift_po2 : program == 4 ? 19 : 18; }
 };
 
-static FoldPlan plan_for(size_t n, const Programs& pr, std::string* err = nullptr) {
+static FoldPlan plan_for(size_t n, const Programs& pr, std::string* err = nullptr, size_t n_assumptions = 0) {
     std::vector<uint32_t> po2(n, 20);
     if (n > 1) po2[n - 1] = 18;
     FoldPlan p;
-    const std::string e = build_fold_plan(po2, [&](uint32_t k, uint32_t a, uint32_t b) { return pr.program_of(k, a, b); }, [&](uint32_t g) { return pr.po2_of(g); }, &p);
+    const std::string e = build_fold_plan(po2, [&](uint32_t k, uint32_t a, uint32_t b) { return pr.program_of(k, a, b); }, [&](uint32_t g) { return pr.po2_of(g); }, &p,
+                                          std::vector<uint32_t>(n_assumptions, 13));
     if (err) *err = e;
     else CHECK(e.empty());
     return p;
@@ -85,6 +91,36 @@ static void test_plan_shapes() {
     pr.join3 = false; pr.lift2 = false;                               // every segment lifted on its own, the first level above pairs
     const FoldPlan p = plan_for(8, pr);
     CHECK(p.n_bottom == 8 && p.nodes.size() == 8 + 4 + 2 + 1);
+    // assumptions: a lift each (ready from the start), the union tree (neighbours pairwise, an odd one moves up), one resolve = the root
+    pr = Programs();
+    for (size_t na : {1, 2, 3, 4, 5, 8, 9}) {
+        const FoldPlan base = plan_for(10, pr), q = plan_for(10, pr, nullptr, na);
+        CHECK(q.n_assumptions == na && q.session_root == base.root && q.n_bottom == base.n_bottom);
+        CHECK(q.nodes.size() == base.nodes.size() + na + (na - 1) + 1);                 // lifts, unions, the resolve
+        const PlanNode& top = q.nodes[q.root];
+        CHECK(top.kind == 5 && top.a == q.session_root && top.parent == NONE && q.nodes[q.session_root].parent == q.root);
+        size_t lifts = 0, unions = 0, ready = 0;
+        for (size_t k = base.nodes.size(); k < q.nodes.size(); k++) {
+            const PlanNode& nd = q.nodes[k];
+            lifts += nd.kind == 0 && nd.family == 1; unions += nd.kind == 4; ready += nd.pending == 0;
+            if (nd.kind == 0) CHECK(nd.family == 1 && nd.pending == 0 && nd.po2 == 19 && nd.a < na);
+            if (nd.kind == 4) CHECK(nd.pending == 2 && nd.a < k && nd.b < k && q.nodes[nd.a].parent == k && q.nodes[nd.b].parent == k);
+        }
+        CHECK(lifts == na && unions == na - 1 && ready == na);
+        for (size_t k = 0; k < base.nodes.size(); k++) CHECK(q.nodes[k].kind == base.nodes[k].kind && q.nodes[k].a == base.nodes[k].a && q.nodes[k].family == 0);
+        // the union tree's shape: level 0 pairs (0, 1), (2, 3), ..; the union root hangs under the resolve
+        CHECK(q.nodes[top.b].parent == q.root && (na == 1 ? q.nodes[top.b].kind == 0 : q.nodes[top.b].kind == 4));
+    }
+    {
+        std::string e2;
+        pr.unions = false;
+        plan_for(4, pr, &e2, 2);
+        CHECK(e2.find("no union program") != std::string::npos);
+        pr.unions = true;
+        FoldPlan q;
+        const std::string e3 = build_fold_plan({20, 20}, [&](uint32_t k, uint32_t a, uint32_t b) { return pr.program_of(k, a, b); }, [&](uint32_t g) { return pr.po2_of(g); }, &q, {12});
+        CHECK(e3.find("no lift program for po2-12 assumption") != std::string::npos);
+    }
     std::string err;
     std::vector<uint32_t> odd(3, 21);
     FoldPlan q;
@@ -92,9 +128,9 @@ static void test_plan_shapes() {
 }
 
 // drive a scheduler with `lanes` sealing lanes + `fold_lanes` fold-only lanes under a random completion order; returns proofs done
-static void simulate(size_t n, size_t lanes, size_t fold_lanes, bool streamed, unsigned seed) {
+static void simulate(size_t n, size_t lanes, size_t fold_lanes, bool streamed, unsigned seed, size_t n_assumptions = 0) {
     Programs pr;
-    FoldPlan plan = plan_for(n, pr);
+    FoldPlan plan = plan_for(n, pr, nullptr, n_assumptions);
     Scheduler sc(n, lanes, &plan, streamed, 1);
     std::mt19937 rng(seed);
     struct Busy { bool is_node; size_t index; size_t lane; };
@@ -113,7 +149,8 @@ static void simulate(size_t n, size_t lanes, size_t fold_lanes, bool streamed, u
             if (w.kind == Scheduler::Kind::Node) {
                 const PlanNode& nd = plan.nodes[w.index];
                 if (!streamed) CHECK(sealed.size() == n);                           // two phases: no fold node before the last seal
-                if (nd.kind == 0) CHECK(sealed.count(nd.a));
+                if (nd.kind == 0 && nd.family == 1) CHECK(nd.a < n_assumptions);               // an assumption's lift waits for nothing
+                else if (nd.kind == 0) CHECK(sealed.count(nd.a));
                 else if (nd.kind == 2) CHECK(sealed.count(nd.a) && sealed.count(nd.b));
                 else { CHECK(proven.count(nd.a) && proven.count(nd.b)); if (nd.kind == 3) CHECK(proven.count(nd.c)); }
                 CHECK(!proven.count(w.index));
@@ -182,6 +219,10 @@ int main() {
         simulate(1 + seed % 23, 1 + seed % 3, seed % 4, false, seed);
     }
     simulate(1024, 3, 3, true, 7);
+    for (unsigned seed = 0; seed < 24; seed++) {                                      // sessions with assumption receipts: union tree + resolve
+        simulate(1 + seed % 11, 1 + seed % 3, seed % 3, true, seed, 1 + seed % 6);
+        simulate(1 + seed % 11, 1 + seed % 3, seed % 3, false, seed, 1 + seed % 6);
+    }
     test_failure_paths();
     if (failures) { printf("%d check(s) failed\n", failures); return 1; }
     printf("scheduler ok\n");

@@ -484,3 +484,70 @@ def test_keccak_assumptions_are_united_and_the_session_resolved_against_them(hal
     assert hashlib.sha3_256(msgs[0]).digest()                                          # (the batches are real SHA-3 blocks: test above)
     print("UNION/RESOLVE", {"programs": len(programs), "kinds": sorted({k[0] for k in kinds}), "sizes": sorted({p.po2 for p in rx.programs}),
                              "build_s": round(t_build, 2), "union_fold_and_resolve_s": round(t_fold, 3)})
+
+
+def test_native_session_unites_its_assumption_receipts_and_resolves_the_root(hal):
+    """zkh_session_set_assumptions + zkh_session_prove(join_tree = 2): the native executor's plan (csrc/scheduler.h) gets a lift per
+    keccak receipt, the union tree and ONE resolve; programs built by the library (zkh_session_build_recursion) in build_programs'
+    order.  The root receipt equals the Python driver's resolve(fold_segments(..), union_fold(..)) word for word (fixed noise),
+    zkh_session_verify recomputes the resolved claim, a forged assumption receipt is refused when it is handed over."""
+    from zeth_amd import recursion as rec
+    from zeth_amd.circuits import keccak_f
+    from zeth_amd.hal import HalError, HostCircuit
+    from zeth_amd.host import Session
+    from zeth_amd.prover import Segment, SegmentProver, SegmentReceipt
+    sdesc, kdesc = syn_air.syn_small(), keccak_f.keccak_f_circuit()
+    sp, kp = SegmentProver(hal, sdesc), SegmentProver(hal, kdesc)
+    segs = [Segment(index=i, po2=13, seed=700 + i, noise_seed=0x51) for i in range(5)]
+    krecs = [kp.prove_segment(Segment(index=i, po2=13, seed=0xCECC + i, noise_seed=3)) for i in range(3)]
+    sroot, kroot = sp.control_root(13), kp.control_root(13)
+    programs = rec.build_programs(sdesc, {13: sroot}, assumptions=[(kdesc, {13: kroot})], resolve=True)
+    sess = Session(sdesc, devices=(0,), lanes_per_device=2)
+    forged = krecs[1].seal.copy()
+    forged[7] = (int(forged[7]) + 1) % P
+    with pytest.raises(HalError, match="assumption receipt 1"):
+        sess.set_assumptions(kdesc, [krecs[0], SegmentReceipt(seal=forged, index=1, po2=13), krecs[2]], {13: kroot})
+    sess.set_assumptions(kdesc, krecs, {13: kroot})
+    t0 = time.time()
+    sess.build_recursion([13])
+    t_build = time.time() - t0
+    comp, root, stats = sess.prove(segs, join_tree=2, join_noise_seed=0x77, verify=True)
+    sess.close()
+    # plan: 2 lift2 + 1 lift at the bottom; above: 1 join3 or 2 joins; 3 assumption lifts + 2 unions + 1 resolve
+    m = int(dict(programs)[("lift2", 13, 13)][2])
+    has3 = ("join3", m, m, m) in [k for k, _ in programs]
+    assert stats["n_lifts"] == 3 and stats["n_joins"] == (1 if has3 else 2) + 3 + 2 + 1 and stats["verified"]
+    rx = rec.Recursion(hal, programs)
+    assert np.array_equal(root.seal[8:16], rx.allowed_root())                        # the library built build_programs' set, in its order
+    leaves = [sp.prove_segment(s) for s in segs]
+    want = rx.resolve(rx.fold_segments(leaves, 0x77), rx.union_fold([rx.lift(k, 0x77, family=1) for k in krecs], 0x77), 0x77)
+    assert np.array_equal(root.seal, want.seal) and stats["root_program"] == want.program
+    assert np.array_equal(stats["root_core"], want.core) and (stats["root_pre"], stats["root_post"]) == (want.pre, want.post)
+    sclaims = [HostCircuit(sdesc).receipt_claim(r.seal, sroot) for r in comp.segments]
+    kclaims = [HostCircuit(kdesc).receipt_claim(r.seal, kroot) for r in krecs]
+    rec.succinct_verify(root.seal, rx.allowed_roots(), stats["root_program"], sclaims, assumption_claims=kclaims)
+    with pytest.raises(HalError, match="resolved root"):
+        rec.succinct_verify(root.seal, rx.allowed_roots(), stats["root_program"], sclaims, assumption_claims=kclaims[:2])
+    # the same session WITHOUT assumptions is another statement: the plain join-tree root
+    sess2 = Session(sdesc, devices=(0,), lanes_per_device=2)
+    sess2.set_recursion(programs)
+    _, plain, st2 = sess2.prove(segs, join_tree=2, join_noise_seed=0x77, verify=True)
+    sess2.close()
+    assert not np.array_equal(plain.seal[:8], root.seal[:8]) and st2["n_joins"] == (1 if has3 else 2)
+    # the g++ host: examples/prove_session --keccak-batches (no Python, no files): keccak batches sealed, handed over, united, resolved
+    import subprocess
+    from zeth_amd import build
+    exe = os.path.join(os.path.dirname(build.build_examples()), "prove_session")
+    csv = os.path.join(os.path.dirname(exe), "..", "gpurun_out", "prove_session_keccak.csv")
+    os.makedirs(os.path.dirname(csv), exist_ok=True)
+    if os.path.exists(csv):
+        os.remove(csv)
+    r = subprocess.run([exe, "--circuit", "syn_small", "--build-recursion", "--po2", "13", "--segments", "5", "--inflight", "2", "--keccak-batches", "3",
+                        "--noise-seed", str(0x51), "--csv", csv, "--block-number", "19000001"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["verified"] is True and out["resolved"] is True and out["assumption_receipts"] == 3 and out["lifts"] == 3 and out["joins"] == stats["n_joins"]
+    assert out["root_out"][64:] == "".join(f"{int(w):08x}" for w in rx.allowed_root())        # the same program set: the same allowed-programs root
+    cols = open(csv).read().strip().splitlines()[1].split(",")
+    assert cols[0] == "19000001" and int(cols[5]) == 3 * ((8192 - 1994) // 25)                # keccak_calls: the permutations the batches prove
+    print("NATIVE UNION/RESOLVE", {"programs": len(programs), "library_build_s": round(t_build, 2), "wall_s": round(stats["wall_s"], 3), "nodes": stats["n_lifts"] + stats["n_joins"]})

@@ -6,7 +6,10 @@
 //   * FoldPlan — which recursion program proves which node, fixed before anything runs (zeth_amd/recursion.py fold_plan: the first
 //     level pairs the segments — one lift2 per pair where the program set has it for EVERY pair, else a lift per segment and joins —
 //     every level above takes three nodes per proof: join3 where a program exists for their sizes, else join(join(a, b), c); a
-//     remainder of two is a join, of one moves up);
+//     remainder of two is a join, of one moves up).  A session with ASSUMPTION receipts (keccak batches; ProverServer::{union,
+//     resolve}) gets three more kinds of nodes: a lift per assumption receipt (ready from the start: nothing is sealed for it), a
+//     union tree over those (neighbours pairwise, an odd one moves up: zeth_amd/recursion.py union_claims), and ONE resolve of the
+//     session's root against the union root — the plan's root;
 //   * Scheduler — segments handed out through one index (work stealing over all lanes), a failed segment retried on ANOTHER lane,
 //     a lane that fails twice in a row retired from sealing, a fold node ready the moment its children exist (streamed) or once the
 //     last segment is sealed (two phases), the run finished when every segment is sealed and the root exists.
@@ -27,9 +30,11 @@ namespace sched {
 constexpr size_t NONE = (size_t)-1;
 
 struct PlanNode {
-    uint32_t kind = 0;                 // 0 lift(a), 2 lift2(a, b): a, b segment indices; 1 join(a, b), 3 join3(a, b, c): node ids
+    uint32_t kind = 0;                 // 0 lift(a), 2 lift2(a, b): a, b segment indices; 1 join(a, b), 3 join3(a, b, c): node ids;
+                                       // 4 union(a, b), 5 resolve(a = the session's root, b = the union root): node ids
     size_t a = 0, b = 0, c = 0, parent = NONE;
     uint32_t program = 0, po2 = 0;
+    uint32_t family = 0;               // lifts: 0 = a segment of the session, 1 = an ASSUMPTION receipt (a = its index; pending 0)
     int pending = 0;                   // children not yet available
 };
 
@@ -37,16 +42,18 @@ struct FoldPlan {
     std::vector<PlanNode> nodes;
     std::vector<size_t> owner;         // the bottom node that consumes segment i
     size_t n_bottom = 0, root = NONE;
+    size_t session_root = NONE;        // the join tree's root (== root without assumptions)
+    size_t n_assumptions = 0;
 };
 
 // program_of(kind, a, b) -> index or -1: kind 0 lift (a = segment po2, b = circuit family), 1 join (child sizes), 2 lift2 (segment
-// sizes), 3 join3 (size of the first two children, size of the third); po2_of(program) -> the size the program runs at.
-// -> "" or what is missing.
+// sizes), 3 join3 (size of the first two children, size of the third), 4 union / 5 resolve (child sizes); po2_of(program) -> the size
+// the program runs at.  assum_po2: the sizes of the session's assumption receipts (lift family 1).  -> "" or what is missing.
 inline std::string build_fold_plan(const std::vector<uint32_t>& seg_po2, const std::function<int(uint32_t, uint32_t, uint32_t)>& program_of,
-                                   const std::function<uint32_t(uint32_t)>& po2_of, FoldPlan* out) {
+                                   const std::function<uint32_t(uint32_t)>& po2_of, FoldPlan* out, const std::vector<uint32_t>& assum_po2 = {}) {
     FoldPlan& p = *out;
     const size_t n = seg_po2.size();
-    p.nodes.clear(); p.owner.assign(n, NONE); p.n_bottom = 0; p.root = NONE;
+    p.nodes.clear(); p.owner.assign(n, NONE); p.n_bottom = 0; p.root = NONE; p.session_root = NONE; p.n_assumptions = assum_po2.size();
     if (!n) return "no segments";
     std::string err;
     const size_t n_pairs = n / 2;
@@ -107,8 +114,36 @@ inline std::string build_fold_plan(const std::vector<uint32_t>& seg_po2, const s
         group = 3;
     }
     if (!err.empty()) return err;
-    p.root = cur[0];
-    return "";
+    p.root = p.session_root = cur[0];
+    if (assum_po2.empty()) return "";
+    // ---- assumptions: a lift each, the union tree, one resolve ----
+    std::vector<size_t> lvl;
+    for (size_t i = 0; i < assum_po2.size(); i++) {
+        const int pr = program_of(0, assum_po2[i], 1);
+        if (pr < 0) return "no lift program for po2-" + std::to_string(assum_po2[i]) + " assumption receipts";
+        PlanNode nd; nd.kind = 0; nd.family = 1; nd.a = i; nd.program = (uint32_t)pr; nd.po2 = po2_of((uint32_t)pr); nd.pending = 0;
+        lvl.push_back(p.nodes.size()); p.nodes.push_back(nd);
+    }
+    auto add_pair = [&](uint32_t kind, size_t a, size_t b) -> size_t {
+        const int pr = program_of(kind, p.nodes[a].po2, p.nodes[b].po2);
+        if (pr < 0) {
+            err = std::string("no ") + (kind == 4 ? "union" : "resolve") + " program for children of po2 " + std::to_string(p.nodes[a].po2) + " and " + std::to_string(p.nodes[b].po2);
+            return NONE;
+        }
+        PlanNode nd; nd.kind = kind; nd.a = a; nd.b = b; nd.pending = 2; nd.program = (uint32_t)pr; nd.po2 = po2_of(nd.program);
+        p.nodes[a].parent = p.nodes[b].parent = p.nodes.size();
+        p.nodes.push_back(nd);
+        return p.nodes.size() - 1;
+    };
+    while (lvl.size() > 1 && err.empty()) {
+        std::vector<size_t> nxt;
+        for (size_t k = 0; k + 1 < lvl.size() && err.empty(); k += 2) nxt.push_back(add_pair(4, lvl[k], lvl[k + 1]));
+        if (lvl.size() % 2) nxt.push_back(lvl.back());
+        lvl.swap(nxt);
+    }
+    if (!err.empty()) return err;
+    p.root = add_pair(5, p.session_root, lvl[0]);
+    return err;
 }
 
 class Scheduler {
@@ -123,6 +158,9 @@ class Scheduler {
           consecutive_(n_seal_lanes, 0) {
         seal_lanes_active = n_seal_lanes;
         root_done = plan == nullptr;
+        if (plan)
+            for (size_t k = 0; k < plan->nodes.size(); k++)
+                if (plan->nodes[k].pending == 0) ready_.push_back(k);      // lifts of assumption receipts: nothing to wait for
     }
 
     // ---- what a lane does next ----

@@ -92,6 +92,12 @@ struct zkh_session {
     uint32_t initial_state = 0;          // ... as a canonical residue
     int witness_source = 0;              // 0: closed-form generators on the device; 1: sequential host preflight -> compact records -> row fill
     size_t producers_per_lane = 2;       // ... host threads per sealing lane that run the preflight ahead of the seals
+    // assumption receipts of the session (zkh_session_set_assumptions): seals of ANOTHER circuit (keccak batches) proven beforehand;
+    // join_tree 2 lifts them (family 1), unites them pairwise and resolves the session's root against the union root
+    std::vector<uint32_t> assum_desc;
+    std::vector<std::vector<uint32_t>> assum_seals;
+    std::vector<uint32_t> assum_po2;
+    std::vector<std::vector<uint32_t>> assum_roots;    // the assumption circuit's control root at assum_po2[i]
     ~zkh_session() { for (auto& l : fold_lanes) l.close(); for (auto& l : lanes) l.close(); }
 };
 
@@ -364,6 +370,32 @@ extern "C" const char* zkh_session_set_recursion(zkh_session* s, const uint32_t*
     s->allowed = std::move(allowed);
     return nullptr;
 }
+extern "C" const char* zkh_session_set_assumptions(zkh_session* s, const uint32_t* desc, size_t desc_words, const uint32_t* const* seals,
+                                                   const size_t* seal_words, const uint32_t* po2s, const uint32_t* control_roots, size_t n) {
+    ZKH_REQUIRE(s, "session_set_assumptions: null session");
+    if (!n) { s->assum_desc.clear(); s->assum_seals.clear(); s->assum_po2.clear(); s->assum_roots.clear(); return nullptr; }
+    ZKH_REQUIRE(desc && desc_words >= 16 && seals && seal_words && po2s && control_roots, "session_set_assumptions: null argument");
+    // every receipt is verified HERE, on the host, against the control root it is handed with: what the lifts then prove in-circuit
+    zkh_circuit* hc = nullptr;
+    ZKH_TRY(zkh_circuit_load(nullptr, desc, desc_words, &hc));
+    std::unique_ptr<zkh_circuit, void (*)(zkh_circuit*)> hold(hc, zkh_circuit_destroy);
+    ZKH_REQUIRE(!circuit_has_state(hc), "session_set_assumptions: an assumption circuit has no state words (its claim' is wrap(claim, 0, 0))");
+    for (size_t i = 0; i < n; i++) {
+        ZKH_REQUIRE(seals[i] && po2s[i] >= 4 && po2s[i] <= 24, "session_set_assumptions: assumption %zu: bad seal / po2", i);
+        if (const char* e = zkh_verify_segment(hc, seals[i], seal_words[i], control_roots + 8 * i, nullptr, nullptr)) {
+            const char* out = make_err("session_set_assumptions: assumption receipt %zu: %s", i, e);
+            zkh_free_error(e);
+            return out;
+        }
+    }
+    s->assum_desc.assign(desc, desc + desc_words);
+    s->assum_seals.clear(); s->assum_po2.assign(po2s, po2s + n); s->assum_roots.clear();
+    for (size_t i = 0; i < n; i++) {
+        s->assum_seals.emplace_back(seals[i], seals[i] + seal_words[i]);
+        s->assum_roots.emplace_back(control_roots + 8 * i, control_roots + 8 * i + 8);
+    }
+    return nullptr;
+}
 extern "C" void zkh_session_set_streamed_fold(zkh_session* s, int on) { if (s) s->streamed_fold = on != 0; }
 extern "C" const char* zkh_session_set_chained(zkh_session* s, int on, uint32_t initial_state) {
     ZKH_REQUIRE(s, "session_set_chained: null session");
@@ -437,6 +469,28 @@ extern "C" const char* zkh_session_build_recursion(zkh_session* s, const uint32_
     };
     const std::vector<uint32_t>& desc = s->desc;
     for (size_t k = 0; k < n_po2s; k++) ZKH_TRY(add(0, desc.data(), desc.size(), {po2s[k]}, roots[k].data(), po2s[k], 0));
+    // the session's assumption receipts (zkh_session_set_assumptions before this call): a lift per size of THEIR circuit (family 1),
+    // kept out of the join closure: they meet the session's tree in one resolve
+    std::vector<uint32_t> leaf_sizes;                           // program sizes of the assumption lifts
+    {
+        std::vector<std::pair<uint32_t, const uint32_t*>> asz;  // distinct assumption po2s, largest first, with their control root
+        for (size_t i = 0; i < s->assum_po2.size(); i++) {
+            bool have = false;
+            for (auto& a : asz) {
+                if (a.first != s->assum_po2[i]) continue;
+                have = true;
+                ZKH_REQUIRE(memcmp(a.second, s->assum_roots[i].data(), 32) == 0, "session_build_recursion: two assumption receipts of po2 %u under different control roots", a.first);
+            }
+            if (!have) asz.emplace_back(s->assum_po2[i], s->assum_roots[i].data());
+        }
+        std::sort(asz.begin(), asz.end(), [](auto& x, auto& y) { return x.first > y.first; });
+        const std::vector<uint32_t> session_sizes(sizes);
+        for (auto& a : asz) {
+            ZKH_TRY(add(0, s->assum_desc.data(), s->assum_desc.size(), {a.first}, a.second, a.first, 1));
+            leaf_sizes.push_back(built.back().blob[2]);
+        }
+        sizes = session_sizes;                                  // (add() recorded the assumption lifts' sizes: not part of the join closure)
+    }
     for (size_t i = 0; i < n_po2s; i++)
         for (size_t j = i; j < n_po2s; j++) {
             std::vector<uint32_t> two(roots[i]);
@@ -459,6 +513,41 @@ extern "C" const char* zkh_session_build_recursion(zkh_session* s, const uint32_
     if (with_join3 && built.size() < REC_ALLOWED) {
         const uint32_t m = *std::max_element(sizes.begin(), sizes.end());
         ZKH_TRY(add(3, rdesc, rdesc_words, {m, m, m}, nullptr, m, m, m));
+    }
+    if (!leaf_sizes.empty()) {
+        // unions for the pairs the union tree can meet — two leaves, or a union result on the LEFT of anything (an odd node moves up at
+        // the END of its level) — until the sizes close; then resolves, the largest session sizes first, as far as the set has room
+        const std::vector<uint32_t> session_sizes(sizes);
+        std::sort(leaf_sizes.begin(), leaf_sizes.end());
+        leaf_sizes.erase(std::unique(leaf_sizes.begin(), leaf_sizes.end()), leaf_sizes.end());
+        std::vector<uint32_t> usizes;
+        std::vector<std::pair<uint32_t, uint32_t>> udone;
+        auto in = [](const std::vector<uint32_t>& v, uint32_t x) { return std::find(v.begin(), v.end(), x) != v.end(); };
+        for (bool more = true; more;) {
+            more = false;
+            std::vector<uint32_t> all(leaf_sizes);
+            for (uint32_t u : usizes) if (!in(all, u)) all.push_back(u);
+            std::sort(all.begin(), all.end());
+            std::vector<std::pair<uint32_t, uint32_t>> todo;      // (decided on the sizes known when the round starts: build_programs' order)
+            for (uint32_t a : all)
+                for (uint32_t b : all)
+                    if (std::find(udone.begin(), udone.end(), std::make_pair(a, b)) == udone.end() && (in(usizes, a) || (in(leaf_sizes, a) && in(leaf_sizes, b))))
+                        todo.push_back({a, b});
+            for (auto& ab : todo) {
+                udone.push_back(ab);
+                ZKH_TRY(add(4, rdesc, rdesc_words, {ab.first, ab.second}, nullptr, ab.first, ab.second));
+                if (!in(usizes, built.back().blob[2])) usizes.push_back(built.back().blob[2]);
+                more = true;
+            }
+        }
+        std::vector<uint32_t> all(leaf_sizes);
+        for (uint32_t u : usizes) if (!in(all, u)) all.push_back(u);
+        std::sort(all.begin(), all.end());
+        std::vector<uint32_t> ss(session_sizes);
+        std::sort(ss.begin(), ss.end(), std::greater<uint32_t>());
+        for (uint32_t a : ss)
+            for (uint32_t b : all)
+                if (built.size() < REC_ALLOWED) ZKH_TRY(add(5, rdesc, rdesc_words, {a, b}, nullptr, a, b));
     }
     ZKH_REQUIRE(built.size() <= REC_ALLOWED, "session_build_recursion: %zu programs do not fit the allowed set", built.size());
     std::vector<const uint32_t*> ptrs;
@@ -616,11 +705,17 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
                 return -1;
             },
             [&](uint32_t program) { uint32_t inf[8] = {0}; (void)zkh_rec_program_info(s->lanes[0].programs[program], nullptr, inf); return inf[0]; },
-            &fplan);
+            &fplan, s->assum_po2);
         if (!perr.empty()) { zkh_prove_info_free(info); return make_err("session_prove: %s", perr.c_str()); }
         ndata.resize(plan.size());
     }
     const size_t n_bottom = fplan.n_bottom, root_node = fplan.root;
+    std::unique_ptr<zkh_circuit, void (*)(zkh_circuit*)> assum_circuit(nullptr, zkh_circuit_destroy);      // host-only: the assumption receipts' claims
+    if (fold && !s->assum_po2.empty()) {
+        zkh_circuit* ac = nullptr;
+        if (const char* e = zkh_circuit_load(nullptr, s->assum_desc.data(), s->assum_desc.size(), &ac)) { zkh_prove_info_free(info); return e; }
+        assum_circuit.reset(ac);
+    }
     // control root of the leaf circuit per segment size (the lifts' claims are computed against it): before any thread starts
     std::vector<std::pair<uint32_t, std::vector<uint32_t>>> fold_leaf_roots;
     auto leaf_root_of = [&](uint32_t po2) -> const uint32_t* {
@@ -686,6 +781,43 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
             }
             ZKH_TRY(parent_claim(ndata[nd.a].claim, ndata[nd.b].claim, &me.claim));
             if (nd.kind == 3) { const NodeClaim ab = me.claim; ZKH_TRY(parent_claim(ab, ndata[nd.c].claim, &me.claim)); }     // join3 = join(join(a, b), c)
+        } else if (nd.kind == 4) {
+            // union: per child its seal and membership path, then the swap bit — (lo, hi) = the two claim' sorted by canonical words
+            uint32_t ca[8], cb[8];
+            ZKH_TRY(wrap_claim(ndata[nd.a].claim, ca)); ZKH_TRY(wrap_claim(ndata[nd.b].claim, cb));
+            bool swap = false;
+            for (int i = 0; i < 8; i++) {
+                const uint32_t x = fp_decode(Fp::raw(ca[i])), y = fp_decode(Fp::raw(cb[i]));
+                if (x != y) { swap = y < x; break; }
+            }
+            for (size_t ch : {nd.a, nd.b}) {
+                in.insert(in.end(), ndata[ch].seal, ndata[ch].seal + ndata[ch].words);
+                path_of(plan[ch].program, in);
+            }
+            in.push_back(fp_encode(swap ? 1u : 0u).v);
+            ZKH_TRY(hash_pair_host(swap ? cb : ca, swap ? ca : cb, me.claim.core));
+            me.claim.pre = me.claim.post = 0;
+        } else if (nd.kind == 5) {
+            // resolve: the conditional receipt (the session's root: seal, path, the opening of its claim'), then the assumption receipt
+            const NodeData& cond = ndata[nd.a];
+            const NodeData& assum = ndata[nd.b];
+            in.insert(in.end(), cond.seal, cond.seal + cond.words);
+            path_of(plan[nd.a].program, in);
+            in.insert(in.end(), cond.claim.core, cond.claim.core + 8);
+            in.push_back(cond.claim.pre); in.push_back(cond.claim.post);
+            in.insert(in.end(), assum.seal, assum.seal + assum.words);
+            path_of(plan[nd.b].program, in);
+            uint32_t cc[8], ca[8];
+            ZKH_TRY(wrap_claim(cond.claim, cc)); ZKH_TRY(wrap_claim(assum.claim, ca));
+            ZKH_TRY(hash_pair_host(cc, ca, me.claim.core));
+            me.claim.pre = cond.claim.pre; me.claim.post = cond.claim.post;
+        } else if (nd.kind == 0 && nd.family == 1) {
+            // the lift of an assumption receipt: its seal, then A; claim = its receipt claim, no state
+            const std::vector<uint32_t>& seal = s->assum_seals[nd.a];
+            in.assign(seal.begin(), seal.end());
+            ZKH_TRY(zkh_receipt_claim(assum_circuit.get(), seal.data(), seal.size(), s->assum_roots[nd.a].data(), nullptr, nullptr, me.claim.core));
+            me.claim.pre = me.claim.post = 0;
+            in.insert(in.end(), A.begin(), A.end());
         } else {
             const zkh_circuit* lc = s->lanes[0].circuit;
             in.assign(info->seals[nd.a], info->seals[nd.a] + info->seal_words[nd.a]);
@@ -702,7 +834,7 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
             in.insert(in.end(), A.begin(), A.end());
         }
         ZKH_TRY(zkh_rec_prove(l->programs[nd.program], in.data(), in.size(), join_noise_key, nullptr, &me.seal, &me.words));    // NULL: a fresh OS key per proof
-        if (nd.kind == 1 || nd.kind == 3) {                    // children are not kept: the verifier needs the root only
+        if (nd.kind == 1 || nd.kind >= 3) {                    // children are not kept: the verifier needs the root only
             for (size_t ch : {nd.a, nd.b, nd.kind == 3 ? nd.c : NONE})
                 if (ch != NONE) { zkh_free_seal(ndata[ch].seal); ndata[ch].seal = nullptr; }
         }
@@ -1035,8 +1167,28 @@ extern "C" const char* zkh_session_verify(zkh_session* s, const zkh_segment* seg
         ZKH_TRY(fold_claim_nodes(nodes, &top));
         uint32_t want[8];
         ZKH_TRY(wrap_claim(top, want));
+        if (!s->assum_seals.empty()) {
+            // the session was RESOLVED against its assumption receipts (verified when they were handed over): the union tree over their
+            // lifted claims, then claim' = wrap(hash_pair(claim' of the join tree, claim' of the union tree), pre, post of the session)
+            zkh_circuit* ac = nullptr;
+            ZKH_TRY(zkh_circuit_load(nullptr, s->assum_desc.data(), s->assum_desc.size(), &ac));
+            std::unique_ptr<zkh_circuit, void (*)(zkh_circuit*)> ahold(ac, zkh_circuit_destroy);
+            std::vector<std::array<uint32_t, 8>> lifted(s->assum_seals.size());
+            for (size_t i = 0; i < lifted.size(); i++) {
+                NodeClaim nd;
+                ZKH_TRY(zkh_receipt_claim(ac, s->assum_seals[i].data(), s->assum_seals[i].size(), s->assum_roots[i].data(), nullptr, nullptr, nd.core));
+                ZKH_TRY(wrap_claim(nd, lifted[i].data()));
+            }
+            uint32_t assumed[8];
+            ZKH_TRY(union_tree(lifted, assumed));
+            NodeClaim res;
+            ZKH_TRY(hash_pair_host(want, assumed, res.core));
+            res.pre = top.pre; res.post = top.post;
+            ZKH_TRY(wrap_claim(res, want));
+        }
         ZKH_REQUIRE(info->root_seal_words > 16 && memcmp(info->root_seal, want, 32) == 0,
-                    "session_verify: the root receipt does not commit to the claim tree of these segments");
+                    s->assum_seals.empty() ? "session_verify: the root receipt does not commit to the claim tree of these segments"
+                                           : "session_verify: the root receipt does not commit to the claim tree of these segments resolved against the session's assumption receipts");
         ZKH_REQUIRE(memcmp(info->root_seal + 8, s->allowed.back()[0].data(), 32) == 0, "session_verify: the root receipt was produced under another allowed-programs root");
         return nullptr;
     }

@@ -194,6 +194,7 @@ ABI = {
     "zkh_succinct_verify": (_err, [_u32p, _sz, _u32p, _sz, _sz, _u32p, _sz, _sz]),
     "zkh_succinct_verify_resolved": (_err, [_u32p, _sz, _u32p, _sz, _sz, _u32p, _sz, _sz, _u32p, _sz]),
     "zkh_session_build_recursion": (_err, [_vp, _u32p, _sz, _i]),
+    "zkh_session_set_assumptions": (_err, [_vp, _u32p, _sz, C.POINTER(_u32p), C.POINTER(_sz), _u32p, _u32p, _sz]),
     "zkh_session_prove": (_err, [_vp, C.POINTER(SegmentSpec), _sz, _i, _sz, _u32p, C.POINTER(ProveInfo)]),
     "zkh_prove_info_free": (None, [C.POINTER(ProveInfo)]),
     "zkh_session_verify": (_err, [_vp, C.POINTER(SegmentSpec), C.POINTER(ProveInfo), _sz]),

@@ -532,12 +532,31 @@ class Session:
         u32p = C.POINTER(C.c_uint32)
         ptrs = (u32p * len(blobs))(*[b.ctypes.data_as(u32p) for b in blobs])
         words = (C.c_size_t * len(blobs))(*[b.size for b in blobs])
-        code = {"lift": 0, "join": 1, "lift2": 2, "join3": 3}
+        code = {"lift": 0, "join": 1, "lift2": 2, "join3": 3, "union": 4, "resolve": 5}
         for k, _ in programs:
             if k[0] == "join3" and k[1] != k[2]:
                 raise ValueError("set_recursion: a join3 whose first two children differ in size has no kind code")
         kinds = np.array([[code[k[0]], k[1], k[3] if k[0] == "join3" else k[2]] for k, _ in programs], dtype=np.uint32).reshape(-1)
         self._hal._check(self._hal._lib.zkh_session_set_recursion(self.h, self._hal._ptr(rdesc), rdesc.size, ptrs, words, self._hal._ptr(kinds), len(blobs)))
+
+    def set_assumptions(self, circuit_desc, receipts: Sequence[SegmentReceipt], control_roots) -> None:
+        """the session's assumption receipts (keccak batches: seals of `circuit_desc`, proven beforehand): verified on the host here;
+        `prove(..., join_tree=2)` then lifts them, unites them pairwise (sorted pairs) and resolves the session's root against the
+        union root — ProverServer::{lift, union, resolve}.  control_roots: {po2: control root} of that circuit.  Before
+        build_recursion / set_recursion(build_programs(..., assumptions=[...], resolve=True)).  No receipts: cleared."""
+        C, np = self._C, self._np
+        u32p = C.POINTER(C.c_uint32)
+        if not receipts:
+            self._hal._check(self._hal._lib.zkh_session_set_assumptions(self.h, None, 0, None, None, None, None, 0))
+            return
+        desc = np.ascontiguousarray(circuit_desc, dtype=np.uint32)
+        seals = [np.ascontiguousarray(r.seal, dtype=np.uint32) for r in receipts]
+        ptrs = (u32p * len(seals))(*[x.ctypes.data_as(u32p) for x in seals])
+        words = (C.c_size_t * len(seals))(*[x.size for x in seals])
+        po2s = np.array([r.po2 for r in receipts], dtype=np.uint32)
+        roots = np.ascontiguousarray(np.concatenate([np.asarray(control_roots[r.po2], dtype=np.uint32) for r in receipts]))
+        self._hal._check(self._hal._lib.zkh_session_set_assumptions(self.h, self._hal._ptr(desc), desc.size, ptrs, words, self._hal._ptr(po2s),
+                                                                    self._hal._ptr(roots), len(seals)))
 
     def build_recursion(self, po2s, join3: bool = True) -> None:
         """the program set of a block with segments of the sizes `po2s`, built by the LIBRARY (csrc/rec_builder.hip: the C++ twin of
