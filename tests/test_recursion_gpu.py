@@ -496,9 +496,9 @@ def test_native_session_unites_its_assumption_receipts_and_resolves_the_root(hal
     from zeth_amd.hal import HalError, HostCircuit
     from zeth_amd.host import Session
     from zeth_amd.prover import Segment, SegmentProver, SegmentReceipt
-    sdesc, kdesc = syn_air.syn_small(), keccak_f.keccak_f_circuit()
+    sdesc, kdesc = syn_air.syn_a(), keccak_f.keccak_f_circuit()      # (po2-13 SYN-A: program sizes {17, 18} - the set with unions and resolves fits 16)
     sp, kp = SegmentProver(hal, sdesc), SegmentProver(hal, kdesc)
-    segs = [Segment(index=i, po2=13, seed=700 + i, noise_seed=0x51) for i in range(5)]
+    segs = [Segment(index=i, po2=13, seed=700 + i, noise_seed=0x51) for i in range(6)]
     krecs = [kp.prove_segment(Segment(index=i, po2=13, seed=0xCECC + i, noise_seed=3)) for i in range(3)]
     sroot, kroot = sp.control_root(13), kp.control_root(13)
     programs = rec.build_programs(sdesc, {13: sroot}, assumptions=[(kdesc, {13: kroot})], resolve=True)
@@ -508,12 +508,15 @@ def test_native_session_unites_its_assumption_receipts_and_resolves_the_root(hal
     with pytest.raises(HalError, match="assumption receipt 1"):
         sess.set_assumptions(kdesc, [krecs[0], SegmentReceipt(seal=forged, index=1, po2=13), krecs[2]], {13: kroot})
     sess.set_assumptions(kdesc, krecs, {13: kroot})
+    assert len(programs) <= 16 and {"union", "resolve"} <= {k[0] for k, _ in programs}
+    with pytest.raises(ValueError, match="no room for resolve"):                    # SYN-small's three program sizes (16, 17, 18) need 9 joins
+        rec.build_programs(syn_air.syn_small(), {13: sroot}, assumptions=[(kdesc, {13: kroot})], resolve=True)
     t0 = time.time()
     sess.build_recursion([13])
     t_build = time.time() - t0
     comp, root, stats = sess.prove(segs, join_tree=2, join_noise_seed=0x77, verify=True)
     sess.close()
-    # plan: 2 lift2 + 1 lift at the bottom; above: 1 join3 or 2 joins; 3 assumption lifts + 2 unions + 1 resolve
+    # plan: 3 lift2 at the bottom; above: 1 join3 or 2 joins; 3 assumption lifts + 2 unions + 1 resolve
     m = int(dict(programs)[("lift2", 13, 13)][2])
     has3 = ("join3", m, m, m) in [k for k, _ in programs]
     assert stats["n_lifts"] == 3 and stats["n_joins"] == (1 if has3 else 2) + 3 + 2 + 1 and stats["verified"]
@@ -542,7 +545,7 @@ def test_native_session_unites_its_assumption_receipts_and_resolves_the_root(hal
     os.makedirs(os.path.dirname(csv), exist_ok=True)
     if os.path.exists(csv):
         os.remove(csv)
-    r = subprocess.run([exe, "--circuit", "syn_small", "--build-recursion", "--po2", "13", "--segments", "5", "--inflight", "2", "--keccak-batches", "3",
+    r = subprocess.run([exe, "--circuit", "syn_a", "--build-recursion", "--po2", "13", "--segments", "6", "--inflight", "2", "--keccak-batches", "3",
                         "--noise-seed", str(0x51), "--csv", csv, "--block-number", "19000001"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])

@@ -323,6 +323,9 @@ def build_programs(segment_desc, segment_roots: Optional[Dict[int, np.ndarray]] 
             for b in sorted(leaf_sizes | usizes):
                 if len(out) < N_ALLOWED:
                     add(("resolve", a, b), rec_verify.build_resolve(rdesc, a, b), set())
+                elif a == max(sizes):
+                    raise ValueError(f"build_programs: the allowed set ({N_ALLOWED} programs) has no room for resolve({a}, {b}): this block's segment sizes give "
+                                     f"{len(sizes)} program sizes (their join closure alone is {len(sizes) ** 2} programs); drop join3 / the fused pairs")
     assert len(out) <= N_ALLOWED, f"{len(out)} programs do not fit the allowed set"
     ps = ProgramSet(out)
     ps.families = [(np.asarray(d, dtype=np.uint32), dict(r)) for d, r in families]
