@@ -43,7 +43,7 @@ def test_batch_interpolate_ntt(hal, oracle, log_n, count):
 
 
 @pytest.mark.parametrize("log_n,count,bits", [(4, 2, 2), (10, 3, 2), (14, 4, 2), (15, 2, 0), (18, 3, 2), (20, 2, 2), (22, 1, 2), (12, 2, 1), (24, 1, 2), (13, 1, 3),
-                                              (20, 2, 0), (20, 1, 3), (22, 1, 4), (22, 1, 1), (21, 1, 2), (19, 2, 2)])
+                                              (20, 2, 0), (20, 1, 3), (22, 1, 4), (22, 1, 1), (21, 1, 2), (19, 2, 2), (23, 2, 2), (21, 3, 0), (24, 1, 0), (23, 1, 4)])
 def test_batch_expand_into_evaluate_ntt(hal, oracle, log_n, count, bits):
     rng = np.random.default_rng(log_n * 7 + count)
     n_out = 1 << log_n

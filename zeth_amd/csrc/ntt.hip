@@ -133,6 +133,88 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassParams p) {
     }
 }
 
+// Top pass, index bits [L, L + R) with L + R = log_n, L >= 12 and R in 1..4 — what is left above the register-radix passes at 2^21 and
+// 2^23 .. 2^26 (po2 19, 21 .. 24).  One lane = 4 consecutive low indices x ALL 2^R rows, in registers: rows are 2^L words apart, so every
+// load and store is a 16-byte piece of a contiguous run (the pass streams the columns once, at HBM speed), the R butterfly layers use
+// wave-uniform twiddles (w_{2^j}^low: scalar loads), and the four-step twiddle of row m at low index j is (w^j)^bitrev(m): ONE two-level
+// table root per lane, the neighbours and the powers by products.  Same arithmetic as k_ntt_pass on the same tile (canonical words in,
+// canonical words out): results are identical.  (round 5: the generic LDS kernel spent 8.8 ms per po2-21 seal here, 15.3 at po2 22.)
+template <int R, bool INVERSE>
+__global__ __launch_bounds__(256) void k_ntt_top(PassParams p) {
+    constexpr int N = 1 << R;
+    const uint32_t j0 = (blockIdx.x * 256u + threadIdx.x) << 2;             // first of this lane's 4 low indices, < 2^L
+    const uint32_t* in = p.in + (size_t)blockIdx.y * p.in_col_stride + j0;
+    uint32_t* out = p.out + (size_t)blockIdx.y * p.out_col_stride + j0;
+    const uint32_t tw_shift = MAX_LOG_N - p.log_n;
+    uint32_t v[N][4];
+#pragma unroll
+    for (int m = 0; m < N; m++) {
+        const uint4 w = *(const uint4*)(in + ((size_t)m << p.L));
+        v[m][0] = w.x; v[m][1] = w.y; v[m][2] = w.z; v[m][3] = w.w;
+    }
+    auto root = [&](uint32_t e) -> uint32_t {                                // w_{log_n}^e, e < 2^log_n
+        const uint32_t ex = e << tw_shift;
+        return mul_mod(p.tw_lo[ex & (TW_SIZE - 1)], p.tw_hi[ex >> TW_BITS]);
+    };
+    // v[m][c] *= (w^(j0 + c))^bitrev_R(m): forward before the layers (DIT pre-twiddle), inverse after them (DIF post-twiddle)
+    auto four_step = [&]() {
+        const uint32_t step = root(1u);                                      // (wave-uniform)
+        uint32_t g = root(j0);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            uint32_t pw[N];
+            pw[1] = g;
+#pragma unroll
+            for (int r = 2; r < N; r++) pw[r] = mul_mod(pw[r - 1], g);
+#pragma unroll
+            for (int m = 1; m < N; m++) {
+                const int r = (int)(__builtin_bitreverse32((uint32_t)m) >> (32 - R));
+                v[m][c] = mul_mod(v[m][c], pw[r]);
+            }
+            if (c < 3) g = mul_mod(g, step);
+        }
+    };
+    if (!INVERSE) {
+        four_step();
+#pragma unroll
+        for (int j = 1; j <= R; j++) {
+            const int hb = j - 1;
+#pragma unroll
+            for (int i0 = 0; i0 < N; i0++) {
+                if (i0 & (1 << hb)) continue;
+                const int low = i0 & ((1 << hb) - 1), i1 = i0 + (1 << hb);
+                const uint32_t w = low ? p.tile_tw[(uint32_t)low << (LDS_TW_LOG - j)] : 0u;     // low == 0: the unit twiddle, no product
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t x = v[i0][c], y = low ? mul_mod(v[i1][c], w) : v[i1][c];
+                    v[i0][c] = add_mod(x, y);
+                    v[i1][c] = sub_mod(x, y);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = R; j >= 1; j--) {
+            const int hb = j - 1;
+#pragma unroll
+            for (int i0 = 0; i0 < N; i0++) {
+                if (i0 & (1 << hb)) continue;
+                const int low = i0 & ((1 << hb) - 1), i1 = i0 + (1 << hb);
+                const uint32_t w = low ? p.tile_tw[(uint32_t)low << (LDS_TW_LOG - j)] : 0u;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t x = v[i0][c], y = v[i1][c];
+                    v[i0][c] = add_mod(x, y);
+                    v[i1][c] = low ? mul_mod(x - y + P, w) : sub_mod(x, y);    // lazy difference in (0, 2P): a valid Montgomery operand
+                }
+            }
+        }
+        four_step();
+    }
+#pragma unroll
+    for (int m = 0; m < N; m++) *(uint4*)(out + ((size_t)m << p.L)) = make_uint4(v[m][0], v[m][1], v[m][2], v[m][3]);
+}
+
 // zk_shift alone (Hal::zk_shift): io[c][i] *= 3^bitrev(i)
 __global__ void k_zk_shift(uint32_t* io, size_t total, uint32_t log_n, const uint32_t* sh_lo, const uint32_t* sh_hi) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -569,13 +651,13 @@ std::vector<Pass> plan_passes(uint32_t log_n) {
         return v;
     }
     // >= 2^18: the contiguous 4096-word register-radix pass, then strided passes.  2^8 and 2^10 rows have
-    // register-radix kernels; what is left over (1..4 bits at 2^21, 2^23 .. 2^26: po2 19, 21 .. 24) goes to a last light pass of the
-    // generic kernel over wide tiles instead of a 9..12-layer LDS sweep (2^21: 0.94 ms vs 1.40 for 64 columns).
+    // register-radix kernels; what is left over (1..4 bits at 2^21, 2^23 .. 2^26: po2 19, 21 .. 24) goes to a last streaming pass in
+    // registers (k_ntt_top) instead of a 9..12-layer LDS sweep.
     const uint32_t rem = log_n - 12;
     v.push_back({0, 12});
     if (rem == 8 || rem == 10 || rem <= 7) v.push_back({12, rem});
     else if (rem == 9) { v.push_back({12, 8}); v.push_back({20, 1}); }
-    else if (rem == 11) { v.push_back({12, 8}); v.push_back({20, 3}); }
+    else if (rem == 11 || rem == 12) { v.push_back({12, 8}); v.push_back({20, rem - 8}); }     // the top pass streams 1..4 bits at the same cost: the cheaper strided pass below it
     else { v.push_back({12, 10}); v.push_back({22, rem - 10}); }
     return v;
 }
@@ -685,7 +767,10 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
         const bool k_low = ps.L == 0 && ps.R == 12 && p.expand_bits <= 4;
         const bool k_h10 = !k_low && ps.L >= 4 && (p.log_t == 4 || narrow_here) && ps.R == 10 && !(scale_here && p.zk_shift);
         const bool k_h8 = !k_low && !k_h10 && ps.L >= 4 && p.log_t == 4 && ps.R == 8 && !(scale_here && p.zk_shift);
-        const std::string pname = std::string(name) + (k_low ? ":k_ntt_low12" : k_h10 ? ":k_ntt_high10" : k_h8 ? ":k_ntt_high8" : ":k_ntt_pass");
+        static const bool no_top = getenv("ZKH_NTT_NO_TOP") != nullptr;      // A/B switch: the generic LDS kernel on the top pass
+        const bool k_top = !no_top && !k_low && !k_h10 && !k_h8 && ps.L >= 12 && ps.L + ps.R == log_n && ps.R >= 1 && ps.R <= 4 && p.twiddle &&
+                           p.expand_bits == 0 && p.first_layer == 1 && !scale_here && !p.zk_shift;
+        const std::string pname = std::string(name) + (k_low ? ":k_ntt_low12" : k_h10 ? ":k_ntt_high10" : k_h8 ? ":k_ntt_high8" : k_top ? ":k_ntt_top" : ":k_ntt_pass");
         ProfScope prof(c, pname.c_str(), alg_bytes);
         if (ps.L == 0 && ps.R == 12 && p.expand_bits <= 4) {
             if (inverse) k_ntt_low12<true><<<grid, 256, 0, c->stream>>>(p);
@@ -706,6 +791,18 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
 #endif
             else if (lazy) k_ntt_high<8, false, true><<<grid, 256, lds, c->stream>>>(p);
             else k_ntt_high<8, false><<<grid, 256, lds, c->stream>>>(p);
+        } else if (k_top) {
+            const dim3 tg((unsigned)(((size_t)1 << ps.L) >> 10), (unsigned)count);          // 256 lanes x 4 low indices per workgroup
+            switch (ps.R * 2 + (inverse ? 1 : 0)) {
+            case 2: k_ntt_top<1, false><<<tg, 256, 0, c->stream>>>(p); break;
+            case 3: k_ntt_top<1, true><<<tg, 256, 0, c->stream>>>(p); break;
+            case 4: k_ntt_top<2, false><<<tg, 256, 0, c->stream>>>(p); break;
+            case 5: k_ntt_top<2, true><<<tg, 256, 0, c->stream>>>(p); break;
+            case 6: k_ntt_top<3, false><<<tg, 256, 0, c->stream>>>(p); break;
+            case 7: k_ntt_top<3, true><<<tg, 256, 0, c->stream>>>(p); break;
+            case 8: k_ntt_top<4, false><<<tg, 256, 0, c->stream>>>(p); break;
+            default: k_ntt_top<4, true><<<tg, 256, 0, c->stream>>>(p); break;
+            }
         } else if (inverse) k_ntt_pass<true><<<grid, NTT_THREADS, lds, c->stream>>>(p);
         else k_ntt_pass<false><<<grid, NTT_THREADS, lds, c->stream>>>(p);
         ZKH_TRY(last_launch_error(name));
