@@ -401,7 +401,7 @@ typedef struct {
     size_t n_joins;
     double wall_s, leaves_s, join_s;            /* whole call, leaf phase, join tree */
     double witgen_s_sum, seal_s_sum;            /* summed over segments (lane seconds) */
-    size_t n_lifts;                             /* join_tree == 2: proofs of the bottom level (lifts, or lift2 per pair); the root is a RECURSION seal */
+    size_t n_lifts;                             /* join_tree == 2: proofs of the bottom level (lifts, or lift2 per pair) + one lift per assumption receipt; the root is a RECURSION seal (n_joins then counts joins, join3s, unions and the resolve) */
     size_t root_program;                        /* ... and the index of the program the root was sealed under */
     double lift_s;                              /* ... the bottom level (join_s is then the joins alone) — with the streamed fold: what
                                                  * each still took AFTER the last segment was sealed (most of it overlapped the leaves) */

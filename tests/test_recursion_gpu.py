@@ -519,7 +519,7 @@ def test_native_session_unites_its_assumption_receipts_and_resolves_the_root(hal
     # plan: 3 lift2 at the bottom; above: 1 join3 or 2 joins; 3 assumption lifts + 2 unions + 1 resolve
     m = int(dict(programs)[("lift2", 13, 13)][2])
     has3 = ("join3", m, m, m) in [k for k, _ in programs]
-    assert stats["n_lifts"] == 3 and stats["n_joins"] == (1 if has3 else 2) + 3 + 2 + 1 and stats["verified"]
+    assert stats["n_lifts"] == 3 + 3 and stats["n_joins"] == (1 if has3 else 2) + 2 + 1 and stats["verified"]
     rx = rec.Recursion(hal, programs)
     assert np.array_equal(root.seal[8:16], rx.allowed_root())                        # the library built build_programs' set, in its order
     leaves = [sp.prove_segment(s) for s in segs]
@@ -536,7 +536,7 @@ def test_native_session_unites_its_assumption_receipts_and_resolves_the_root(hal
     sess2.set_recursion(programs)
     _, plain, st2 = sess2.prove(segs, join_tree=2, join_noise_seed=0x77, verify=True)
     sess2.close()
-    assert not np.array_equal(plain.seal[:8], root.seal[:8]) and st2["n_joins"] == (1 if has3 else 2)
+    assert not np.array_equal(plain.seal[:8], root.seal[:8]) and st2["n_joins"] == (1 if has3 else 2) and st2["n_lifts"] == 3
     # the g++ host: examples/prove_session --keccak-batches (no Python, no files): keccak batches sealed, handed over, united, resolved
     import subprocess
     from zeth_amd import build
@@ -549,7 +549,7 @@ def test_native_session_unites_its_assumption_receipts_and_resolves_the_root(hal
                         "--noise-seed", str(0x51), "--csv", csv, "--block-number", "19000001"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert out["verified"] is True and out["resolved"] is True and out["assumption_receipts"] == 3 and out["lifts"] == 3 and out["joins"] == stats["n_joins"]
+    assert out["verified"] is True and out["resolved"] is True and out["assumption_receipts"] == 3 and out["lifts"] == stats["n_lifts"] and out["joins"] == stats["n_joins"]
     assert out["root_out"][64:] == "".join(f"{int(w):08x}" for w in rx.allowed_root())        # the same program set: the same allowed-programs root
     cols = open(csv).read().strip().splitlines()[1].split(",")
     assert cols[0] == "19000001" and int(cols[5]) == 3 * ((8192 - 1994) // 25)                # keccak_calls: the permutations the batches prove

@@ -644,6 +644,10 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
         return make_err("session_prove: out of host memory for %zu receipts", n);
     }
     const bool fold = join_tree == 2;
+    if (join_tree == 1 && !s->assum_po2.empty()) {
+        zkh_prove_info_free(info);
+        return make_err("session_prove: the session has assumption receipts: they are united and resolved by the RECURSION programs (join_tree 2), the P2-JOIN tree has no such node");
+    }
     const bool streamed = fold && s->streamed_fold;
     info->streamed = streamed;
     constexpr size_t NONE = (size_t)-1;
@@ -1009,8 +1013,8 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
         // bottom level = lifts (or lift2 per pair); with the streamed fold these overlap the leaf phase: lift_s / join_s are what the
         // fold still took AFTER the last segment was sealed (bottom level, then joins); two phases: the two phases' durations
         const double tb = std::max(sc.t_bottom_done ? sc.t_bottom_done : t_end, t0 + info->leaves_s);
-        info->n_lifts = n_bottom;
-        info->n_joins = plan.size() - n_bottom;
+        info->n_lifts = n_bottom + fplan.n_assumptions;          // the bottom level + a lift per assumption receipt
+        info->n_joins = plan.size() - info->n_lifts;             // joins / join3s, unions, the resolve
         info->lift_s = tb - (t0 + info->leaves_s);
         info->join_s = t_end - tb;
         info->fold_tail_s = t_end - (t0 + info->leaves_s);
