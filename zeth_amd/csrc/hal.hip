@@ -106,7 +106,7 @@ static const char* upload(uint32_t** dst, const std::vector<uint32_t>& v) {
     ZKH_HIP(hipMemcpy(*dst, v.data(), v.size() * 4, hipMemcpyHostToDevice));
     return nullptr;
 }
-const char* zkh::resolve_noise_key(const uint32_t* key, NoiseKey* out) {
+const char* resolve_noise_key(const uint32_t* key, NoiseKey* out) {
     bool given = false;
     if (key) for (int i = 0; i < 8; i++) given = given || key[i] != 0;
     if (given) { memcpy(out->k, key, sizeof out->k); return nullptr; }

@@ -698,7 +698,6 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
 
     sched::FoldPlan fplan;
     std::vector<sched::PlanNode>& plan = fplan.nodes;
-    std::vector<size_t>& owner = fplan.owner;
     struct NodeData { uint32_t* seal = nullptr; size_t words = 0; NodeClaim claim; };     // what a proven node leaves for its parent
     std::vector<NodeData> ndata;
     if (fold) {
