@@ -209,8 +209,6 @@ __global__ __launch_bounds__(256) void k_rec_p2_wide(const uint32_t* __restrict_
     if (live && j < 6) val[o[1] + j] = make_uint4(c[0], c[1], c[2], c[3]);
 }
 
-__device__ __forceinline__ bool rc_is_full(uint32_t rnd) { return rnd < 4 || rnd >= 25; }
-
 // wires: one lane per (row, wire); rows past A are blinding noise (all 72 data columns: blockIdx.y < 6 covers W, the rest below)
 __global__ void k_rec_fill_wires(uint32_t* data, const uint32_t* __restrict__ pos, const uint4* __restrict__ val, uint32_t n, uint32_t A,
                                  NoiseKey nk) {
