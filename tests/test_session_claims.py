@@ -163,3 +163,24 @@ def test_the_cpp_verifier_refuses_a_truncated_session_and_a_rewritten_journal(se
     write([receipt.inner.segments[0], SegmentReceipt(seal=forged, index=1, po2=PO2)])
     r = run()
     assert r.returncode == 1 and "segment 1" in r.stderr
+
+
+def test_union_claim_and_assumption_list_digests():
+    """the SHA-256 statements next to the union / resolve programs' Poseidon2 claims (recalled layouts, zeth_amd/host.py): the union
+    digest does not depend on the order of its two claims; the assumptions list is a cons list over the zero digest"""
+    import hashlib
+    import struct
+    from zeth_amd import host
+    a, b = host.sha256_words(b"claim a"), host.sha256_words(b"claim b")
+    u = host.union_claim_digest(a, b)
+    assert u == host.union_claim_digest(b, a) and u != host.union_claim_digest(a, a)
+    lo, hi = sorted([a, b])
+    body = hashlib.sha256(b"risc0.UnionClaim").digest() + struct.pack("<8I", *lo) + struct.pack("<8I", *hi) + struct.pack("<H", 2)
+    assert u == host.sha256_words(body)
+    assert host.assumptions_digest([]) == host.ZERO_DIGEST
+    one = host.assumptions_digest([(a, host.ZERO_DIGEST)])
+    head = host.tagged_struct("risc0.Assumption", [a, host.ZERO_DIGEST])
+    assert one == host.tagged_struct("risc0.Assumptions", [head, host.ZERO_DIGEST])
+    two = host.assumptions_digest([(b, host.ZERO_DIGEST), (a, host.ZERO_DIGEST)])
+    assert two == host.tagged_struct("risc0.Assumptions", [host.tagged_struct("risc0.Assumption", [b, host.ZERO_DIGEST]), one])
+    assert two != host.assumptions_digest([(a, host.ZERO_DIGEST), (b, host.ZERO_DIGEST)])       # a LIST: the order is the guest's

@@ -10,7 +10,7 @@ receipts (~0.25 MB each) are gathered on rank 0 over the control plane (gloo / R
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Callable, List, Optional, Sequence
+from typing import Callable, List, Optional, Sequence, Tuple
 
 from .prover import Segment, SegmentReceipt
 
@@ -287,6 +287,26 @@ def journal_limbs(journal: bytes) -> List[int]:
 
 
 ZERO_DIGEST = [0] * 8
+
+
+def union_claim_digest(a: Sequence[int], b: Sequence[int]) -> List[int]:
+    """`UnionClaim{left, right}.digest()` (risc0-zkvm 3.0.3, RECALLED): the two claim digests SORTED (left <= right, compared word by
+    word), then tagged_struct("risc0.UnionClaim", [left, right], []) — the SHA-256 statement beside the Poseidon2 claim' a `union`
+    program publishes (zeth_amd/recursion.py union_node): union(a, b) and union(b, a) are the same claim."""
+    a, b = [int(w) for w in a], [int(w) for w in b]
+    left, right = (a, b) if a <= b else (b, a)
+    return tagged_struct("risc0.UnionClaim", [left, right])
+
+
+def assumptions_digest(assumptions: Sequence[Tuple[Sequence[int], Sequence[int]]]) -> List[int]:
+    """`Assumptions(Vec<Assumption{claim, control_root}>).digest()` (RECALLED): a cons list folded from the END over the zero digest,
+    every element tagged_struct("risc0.Assumption", [claim, control_root], []) and every cons cell tagged_struct("risc0.Assumptions",
+    [head, tail], []) — what `Output{journal, assumptions}` commits to for a session that assumed receipts (keccak batches)."""
+    acc = list(ZERO_DIGEST)
+    for claim, control_root in reversed(list(assumptions)):
+        head = tagged_struct("risc0.Assumption", [list(claim), list(control_root)])
+        acc = tagged_struct("risc0.Assumptions", [head, acc])
+    return acc
 
 
 @dataclass
