@@ -10,6 +10,7 @@ OUT=$(realpath -m "${1:-gpurun_out/prof}"); mkdir -p "$OUT"
 ROOT=$PWD; export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 12 --warmup 2 --no-live-traffic"
 SHORT="python $ROOT/bench.py --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-prof --no-heavy --no-resident --no-block --no-certify --no-live-traffic"
+python -c "from zeth_amd import build; build.ensure_built(); build.build_examples()" > /dev/null 2>&1 || echo "collect_profiles: build failed"   # the box gets source only
 cd /tmp
 # ---- BASELINE config 2 (SYN-A): default (3 seals in flight), serial, PCIe-inclusive ----
 want syn_a && timeout 300 $BENCH --ingress host > "$OUT/bench.json" 2> "$OUT/bench.err"
@@ -41,7 +42,7 @@ for d in stats stats_serial stats_heavy_serial; do f=$(ls "$OUT/$d"/*kernel_stat
 want micro && timeout 300 python tools/microbench.py > "$OUT/microbench.jsonl" 2> "$OUT/microbench.err"
 # ---- the g++-only host driver over the C ABI ----
 want cpp && python -m zeth_amd.circuits.syn_air syn_a /tmp/syn_a.desc > /dev/null
-want cpp && timeout 300 examples/seal_segments --desc /tmp/syn_a.desc --po2 20 --segments 48 --inflight 3 > "$OUT/cpp_driver.json" 2> "$OUT/cpp_driver.err"
+want cpp && LD_LIBRARY_PATH=$ROOT/zeth_amd timeout 300 examples/seal_segments --desc /tmp/syn_a.desc --po2 20 --segments 48 --inflight 3 > "$OUT/cpp_driver.json" 2> "$OUT/cpp_driver.err"
 # raw rocprof directories are large: keep the summaries only
 rm -rf "$OUT"/stats "$OUT"/stats_serial "$OUT"/stats_heavy_serial "$OUT"/fetch "$OUT"/write "$OUT"/sq "$OUT"/fetch_heavy "$OUT"/write_heavy "$OUT"/sq_heavy
 ls -la "$OUT"

@@ -32,6 +32,8 @@ except Exception as e:
     print(sys.argv[1], "no line:", e)
 PY
 }
+# the box receives SOURCE only (.gpurunignore): the library and the g++ example hosts are built here, once
+python -c "from zeth_amd import build; build.ensure_built(); build.build_examples()" > /dev/null 2>&1 || echo "gpu.sh: build failed"
 case $R in
 tests)
   O=gpurun_out/${1:-tests}; mkdir -p $O
