@@ -44,9 +44,6 @@ new)
   O=gpurun_out/new; mkdir -p $O
   ( time timeout 900 python -m pytest ${1:-tests/test_session_gpu.py} -m gpu -q -x ) > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
   tail -30 $O/pytest.log ;;
-gather)
-  O=gpurun_out/${1:-gather}; mkdir -p $O         # eval_check: the shipped generator (gathered power tables + locality order + 6400-step parts) against the round-3 generator, bit-exact
-  EXP_PO2=20 timeout 600 python tools/exp_gather.py default .variants/libzkhal_oldgen.so > $O/exp_gather.jsonl 2> $O/err.txt; cut -c1-700 $O/exp_gather.jsonl ;;
 knobs)
   O=gpurun_out/${1:-knobs}; mkdir -p $O          # generator knobs on SYN-HEAVY around the gathered + locality default (every variant compiled on the box, bit-exact vs built-in)
   timeout 1200 python tools/exp_codegen.py syn_heavy ${KNOB_VARIANTS:-GATHER=0,LOCALITY=0 PART=4800 PART=6400 PART=2400 REGS=80 REGS=112 REGS=128 PREFETCH=2 PREFETCH=8 EPOCH=32 EPOCH=96 LOCWIN=32 LOCWIN=96 REGS=112,PART=4800} > $O/exp_codegen.jsonl 2> $O/err.txt; cat $O/exp_codegen.jsonl ;;
