@@ -1,4 +1,4 @@
-"""The driver's contract for bench.py, checked on the committed lines of the last GPU runs (profiles/r05_*.json; config 5: r04_*): the
+"""The driver's contract for bench.py, checked on the committed lines of the last GPU runs (profiles/r05_*.json; config 5: r04_* and r05_config5_*): the
 one JSON line carries BASELINE.json's metric with every field the contract names, a roofline object for the dominant kernel and
 a CPU baseline; and the command line still parses the driver's flags.  (No GPU: the line is a committed measurement.)"""
 import json
@@ -105,6 +105,21 @@ def test_config5_line_is_the_streamed_in_circuit_fold():
     assert ph["streamed_fold"] is False and ph["lift_s"] + ph["join_tree_s"] <= 3.3 and ph["verified"] is True
     b3 = _line("r04_bench_succinct_join3.json")
     assert b3["recursion"]["proofs"] == 768 and b3["succinct_root_follows_from_leaf_claims"] is True and b3["block_wall_clock_s"] < l["block_wall_clock_s"]
+
+
+def test_config5_on_the_final_tree_of_round5_incl_assumption_receipts():
+    """profiles/r05_config5_*.json: the same 1024-segment block through the round-5 executor (csrc/scheduler.h), programs built by the
+    library; and the same session ASSUMING 8 keccak receipts - 8 more lifts, 7 unions, one resolve - for 0.1 s more"""
+    host = _line("r05_config5_prove_session_1024.json")
+    assert host["segments"] == 1024 and host["lifts"] == 512 and host["joins"] == 256 and host["verified"] is True and host["programs_built_by_library"] is True
+    assert host["wall_s"] <= 26.5 and host["fold_tail_s"] < 0.5 and host["resolved"] is False
+    k8 = _line("r05_config5_prove_session_1024_keccak8.json")
+    assert k8["assumption_receipts"] == 8 and k8["resolved"] is True and k8["verified"] is True
+    assert k8["lifts"] == 512 + 8 and k8["joins"] == 256 + 7 + 1 and k8["wall_s"] < host["wall_s"] + 0.5 and k8["root_out"] != host["root_out"]
+    assert k8["root_out"][64:] != host["root_out"][64:]                                   # another program set: another allowed-programs root
+    b = _line("r05_config5_bench_succinct.json")
+    assert b["steps"] == 1024 and b["recursion"]["proofs"] == 768 and b["succinct_root_follows_from_leaf_claims"] is True and b["verified_after_clock"] >= 1025
+    assert b["block_wall_clock_s"] < 27.8 and b["recursion"]["fold_tail_s"] < 0.5
 
 
 def test_bench_accepts_the_drivers_flags():
