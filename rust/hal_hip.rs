@@ -346,23 +346,50 @@ pub fn prove_segment_from_host_traces(hal: &HipHal, prover: *mut sys::ZkhProver,
 
 /// `ProverServer::prove_session` + lift / join to ONE succinct receipt (risc0-zkvm 3.0.3 host/server/prove/prover_impl.rs), as the
 /// library's session executor: `zkh_session_create` (G devices x K lanes), `zkh_session_build_recursion` (the lift / lift2 / join /
-/// join3 programs of a block with these segment sizes, BUILT by the library: no `.zkr` files), `zkh_session_prove(join_tree = 2)`
+/// join3 — and, with assumptions, union / resolve — programs of a block with these segment sizes, BUILT by the library: no `.zkr` files), `zkh_session_prove(join_tree = 2)`
 /// (seals and fold as one pipeline), and the root receipt's seal back.  `desc` = the segment circuit (`zkh_shipped_circuit_desc`
 /// or the imported upstream tables), `segments` = (po2, seed) per segment, largest sizes first.
-pub fn prove_session_succinct(devices: &[i32], lanes_per_device: usize, desc: &[u32], segments: &[(u32, u64)]) -> Vec<u32> {
+pub fn prove_session_succinct(devices: &[i32], lanes_per_device: usize, desc: &[u32], segments: &[(u32, u64)],
+                              assumptions: Option<(&[u32], &[AssumptionReceipt])>) -> Vec<u32> {
     let mut session: *mut sys::ZkhSession = std::ptr::null_mut();
     ffi(|| unsafe { sys::zkh_session_create(devices.as_ptr(), devices.len(), lanes_per_device, desc.as_ptr(), desc.len(), std::ptr::null(), 0, &mut session) });
+    // `ProverServer::{union, resolve}`: the session's assumption receipts (keccak batches proven by `prove_keccak`) are handed over
+    // BEFORE the programs are built; the executor lifts them, unites them pairwise and resolves the session's root against the union
+    if let Some((adesc, receipts)) = assumptions {
+        let seals: Vec<*const u32> = receipts.iter().map(|r| r.seal.as_ptr()).collect();
+        let words: Vec<usize> = receipts.iter().map(|r| r.seal.len()).collect();
+        let po2s: Vec<u32> = receipts.iter().map(|r| r.po2).collect();
+        let roots: Vec<u32> = receipts.iter().flat_map(|r| r.control_root.iter().copied()).collect();
+        ffi(|| unsafe { sys::zkh_session_set_assumptions(session, adesc.as_ptr(), adesc.len(), seals.as_ptr(), words.as_ptr(), po2s.as_ptr(), roots.as_ptr(), receipts.len()) });
+    }
     let mut sizes: Vec<u32> = segments.iter().map(|s| s.0).collect();
     sizes.sort_unstable_by(|a, b| b.cmp(a));
     sizes.dedup();
     ffi(|| unsafe { sys::zkh_session_build_recursion(session, sizes.as_ptr(), sizes.len(), 1) });
     let segs: Vec<sys::ZkhSegment> = segments.iter().map(|&(po2, seed)| sys::ZkhSegment { po2, seed, ..unsafe { std::mem::zeroed() } }).collect();
     let mut info: sys::ZkhProveInfo = unsafe { std::mem::zeroed() };
-    ffi(|| unsafe { sys::zkh_session_prove(session, segs.as_ptr(), segs.len(), 2, 0, 0, &mut info) });
+    ffi(|| unsafe { sys::zkh_session_prove(session, segs.as_ptr(), segs.len(), 2, 0, std::ptr::null() /* a fresh OS key per fold proof */, &mut info) });
     ffi(|| unsafe { sys::zkh_session_verify(session, segs.as_ptr(), &info, 0) });
     let root = unsafe { std::slice::from_raw_parts(info.root_seal, info.root_seal_words) }.to_vec();
     unsafe { sys::zkh_prove_info_free(&mut info); sys::zkh_session_destroy(session) };
     root
+}
+
+/// One assumption receipt of a session: a seal of another circuit (KECCAK-F), its size, that circuit's control root at the size.
+pub struct AssumptionReceipt { pub seal: Vec<u32>, pub po2: u32, pub control_root: [u32; 8] }
+
+/// `verify_succinct` for a RESOLVED receipt: the claim is recomputed from the segment leaves AND the assumption receipts' claim digests
+/// (the union tree sorts every pair; `leaves` empty: the receipt is the union-tree root alone).
+pub fn verify_succinct_resolved(root_seal: &[u32], allowed_roots: &[[u32; 8]], root_program: usize, leaves: &[([u32; 8], u32, u32)], ranks: usize,
+                                assumption_claims: &[[u32; 8]]) -> Result<(), String> {
+    let flat_roots: Vec<u32> = allowed_roots.iter().flatten().copied().collect();
+    let mut flat_leaves: Vec<u32> = Vec::with_capacity(10 * leaves.len());
+    for (core, pre, post) in leaves { flat_leaves.extend_from_slice(core); flat_leaves.push(*pre); flat_leaves.push(*post); }
+    let flat_claims: Vec<u32> = assumption_claims.iter().flatten().copied().collect();
+    sys::ffi_wrap(|| unsafe {
+        sys::zkh_succinct_verify_resolved(root_seal.as_ptr(), root_seal.len(), flat_roots.as_ptr(), allowed_roots.len(), root_program,
+                                          flat_leaves.as_ptr(), leaves.len(), ranks, flat_claims.as_ptr(), assumption_claims.len())
+    })
 }
 
 /// `SuccinctReceipt::verify_integrity` on the verifier's host (no GPU): one RECURSION seal under an allowed program's control
