@@ -673,9 +673,11 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
     // forward transforms whose two passes are both register-radix kernels (2^20 and 2^22: what po2-18/20 seals
     // expand into) run the lazy signed butterflies; the constant R^(layers run) rides on the four-step twiddle
     static const bool no_lazy = getenv("ZKH_NTT_NO_LAZY") != nullptr;     // A/B switch for debugging
-    // (measured: letting the lazy pair also run under a third, generic top pass - 2^21 / 2^23 / 2^24 - is bit-exact and buys nothing:
-    // po2 21 / 22 seals 18.4 / 9.58 vs 18.7 / 9.59 segments/s)
-    const bool lazy = !no_lazy && !inverse && npass == 2 && passes[0].R == 12 && (passes[1].R == 8 || passes[1].R == 10) && expand_bits <= 4;
+    // (measured twice: letting the lazy pair also run under a third pass - 2^21 / 2^23 / 2^24 - is bit-exact and buys nothing: under the
+    // generic top pass po2 21 / 22 seals 18.4 / 9.58 vs 18.7 / 9.59 segments/s; under k_ntt_top 20.35 / 10.30 vs 20.45 / 10.20, round 5.
+    // ZKH_NTT_LAZY3=1 re-runs the A/B)
+    static const bool lazy3 = getenv("ZKH_NTT_LAZY3") != nullptr;         // A/B switch: the lazy pair under a third (top) pass
+    const bool lazy = !no_lazy && !inverse && (npass == 2 || (lazy3 && npass == 3)) && passes[0].R == 12 && (passes[1].R == 8 || passes[1].R == 10) && expand_bits <= 4;
     const uint32_t lazy_comp = lazy ? fp_pow(Fp::raw(R2), passes[0].R - expand_bits + passes[1].R).v : 0;
     // the strided pass of a lazy transform reads its four-step twiddles from a per-shape matrix (built once per context)
     // MEASURED AND REJECTED as the default (profiles/r03_ntt_matrix.txt): the matrix removes 15 % of the pass's VALU
