@@ -56,13 +56,16 @@ def parse_args(argv=None):
     g = ap.add_argument_group("segment config: what else the default run measures")
     g.add_argument("--no-cpu-baseline", action="store_true")
     g.add_argument("--cpu-full-host", action="store_true",
-                   help="cpu_baseline: also fill EVERY core (floor(cores / threads) seals at once) and time the po2-20 unit itself: +~45 s")
+                   help="cpu_baseline: a larger sample for both legs (the po2-20 unit itself alone, 1/16-unit seals on every core): +~45 s")
+    g.add_argument("--no-cpu-all-cores", action="store_true",
+                   help="cpu_baseline: skip the all-cores leg (floor(cores / threads) seals at once on disjoint core blocks; default on, ~10-15 s)")
     g.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events (no roofline object)")
     g.add_argument("--no-live-traffic", action="store_true",
                    help="roofline.traffic from the committed PMC file, no rocprofv3 --pmc child runs (no live VALU figures)")
     g.add_argument("--no-certify", action="store_true", help="do not verify the timed seals / compare with the golden digest after the clock")
     g.add_argument("--no-heavy", action="store_true", help="skip the SYN-HEAVY measurement")
-    g.add_argument("--heavy-steps", type=int, default=9)
+    g.add_argument("--heavy-steps", type=int, default=18,
+                   help="timed steps of each repetition of the SYN-HEAVY and resident-code legs (two repetitions after three warm-up seals per lane)")
     g.add_argument("--no-resident", action="store_true", help="skip the measurement with the code group kept resident")
     g.add_argument("--no-block", action="store_true", help="skip the short block leg (S distinct segments, witgen in the clock, all verified)")
     g.add_argument("--block-segments", type=int, default=None,
@@ -93,6 +96,13 @@ def parse_args(argv=None):
                    help="succinct (native): the closed-form generator on the device, or a sequential host preflight per segment + row fill on the GPU")
     g.add_argument("--no-join3", action="store_true", help="recursion: leave the join3 program out (same tree, same root claim, more proofs)")
     g.add_argument("--no-fused-lift", action="store_true", help="recursion: lift every segment on its own and join instead of lift2")
+    g = ap.add_argument_group("N > 1")
+    g.add_argument("--allow-shared-gpu", action="store_true", default=bool(os.environ.get("ZKH_SHARE_GPUS")),
+                   help="let several ranks (or session devices) drive the SAME GPU: a dry run of the N-rank shape on a box with fewer GPUs.  "
+                        "Without it an N > 1 run refuses to start unless its ranks hold N distinct devices (config.devices lists them)")
+    g.add_argument("--launcher", choices=("ranks", "session"), default="ranks",
+                   help="ranks: one process per GPU (the driver's shape).  session: ONE process, zkh_session_create with N devices x "
+                        "--inflight lanes (the library's own executor: C++ threads, one work index)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)       # benchlib/roofline.py's rocprofv3 child runs
     return ap.parse_args(argv)
 
@@ -115,6 +125,11 @@ def main() -> int:
         run.load_circuit()
         run_pmc_child(run)
         return 0
+    if args.allow_shared_gpu:
+        os.environ["ZKH_SHARE_GPUS"] = "1"        # (the ranks and the pmc child runs read the environment)
+    if args.launcher == "session" and not dev:
+        from benchlib.session_launcher import run_session_launcher
+        return run_session_launcher(args, t_start, build_s)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])
 
@@ -123,50 +138,40 @@ def main() -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    rccl = None
     if world > 1:
-        import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # Rendezvous through torch.distributed (gloo on CPU tensors; a rank that never shows up fails the group within the timeout
         # instead of gloo's 30 minutes).  The path has no exchange step, so no collective is invented for it; the control plane
-        # proper is the store (benchlib/control.py).  ZKH_DIST_BACKEND=cpu:gloo,cuda:nccl additionally brings RCCL up and runs
-        # one all_reduce over xGMI before the timed region (health probe only).
-        backend = os.environ.get("ZKH_DIST_BACKEND", "gloo")
+        # proper is the store (benchlib/control.py).  RCCL is brought up AFTER the ranks have exchanged their device identities
+        # (below): a health probe on a group of its own, by default whenever the ranks hold N distinct GPUs.
         sys.stdout.flush()
         saved_stdout = os.dup(1)                  # gloo announces its connections on stdout; keep stdout for the ONE JSON line
         os.dup2(2, 1)
         try:
-            if "nccl" in backend:
-                try:
-                    torch.cuda.set_device(local_rank)
-                except (RuntimeError, AssertionError):
-                    backend = "gloo"
-            dist.init_process_group(backend, timeout=timedelta(seconds=TIMEOUT_S))
-            if "nccl" in backend:
-                try:
-                    probe = torch.ones(1, device=f"cuda:{local_rank}")
-                    dist.all_reduce(probe)
-                    torch.cuda.synchronize()
-                    rccl = "ok" if int(probe.item()) == world else "wrong sum"
-                except Exception as e:               # the seals never needed RCCL
-                    rccl = f"unavailable ({type(e).__name__})"
+            dist.init_process_group("gloo", timeout=timedelta(seconds=TIMEOUT_S))
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
     ctl = ControlPlane.connect(rank, world)
     run = Run(args, ctl, rank, local_rank, world)
-    run.rccl = rccl
     run.failed_ranks, run.failed_in = {}, None
     line, after = None, []
     try:
         ctl.barrier()
+        if not dev:
+            run.bind_device()
+        # who holds which GPU: every rank's {pci_bus_id, uuid, numa_node} goes into config.devices, and an N > 1 run refuses to
+        # start unless they are N distinct devices (--allow-shared-gpu: a dry run).  Then RCCL comes up (probe only).
+        run.exchange_devices()
+        if world > 1 and not dev:
+            from benchlib.control import rccl_probe
+            run.rccl = rccl_probe(run)
         if dev:
             from benchlib.dev import run_dev
             line, after = run_dev(run)
         else:
-            run.bind_device()
             run.load_circuit()
             if args.config == "segment":
                 from benchlib.segment import run_segment
@@ -191,7 +196,7 @@ def main() -> int:
             except Exception:
                 pass
         raise
-    if world > 1 and not run.failed_ranks:
+    if world > 1 and not run.failed_ranks and not run.rccl_hung:
         try:                                      # (with a dead rank the group is left alone: tearing it down can wait for the dead)
             import torch.distributed as dist
             t_d = time.perf_counter()
@@ -212,6 +217,9 @@ def main() -> int:
         print(json.dumps(line))
         sys.stdout.flush()
         ctl.finish()
+    if run.rccl_hung:                             # an RCCL probe that never returned: its communicator's teardown could block the exit
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(rc)
     return rc
 
 

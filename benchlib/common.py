@@ -60,7 +60,9 @@ class Run:
         self.torch = None
         self.placement = {"numa_node": -1, "cpus": 0}
         self.cpus_before = None
-        self.rccl = None
+        self.rccl, self.rccl_hung = None, False
+        self.devices, self.devices_distinct = None, None
+        self.identity = {"rank": rank, "pci_bus_id": None, "uuid": None, "numa_node": -1}
         self.desc = self.circ = self.workload = None
         self.widths = (0, 0, 0)
         self.n = 1 << args.po2
@@ -77,7 +79,7 @@ class Run:
             visible = int(torch.cuda.device_count())
         except Exception:
             visible = 0
-        if os.environ.get("ZKH_SHARE_GPUS"):
+        if os.environ.get("ZKH_SHARE_GPUS") or getattr(self.args, "allow_shared_gpu", False):
             self.device = self.local_rank % max(1, visible)
             self.ranks_per_gpu = -(-self.world // max(1, visible))
         elif 0 < visible <= self.local_rank:
@@ -95,6 +97,31 @@ class Run:
             self.placement.update(slot=slot, share=share, pci_bus_id=_zhal.device_numa_node(self.device)[1])
         except Exception as e:                               # placement is an optimisation, never a dependency
             self.placement["error"] = repr(e)
+        from zeth_amd import hal as _zhal
+        ident = _zhal.device_identity(self.device)           # (raises without the HIP library / a GPU: there is no fallback)
+        self.identity.update(ident, hip_device=self.device, hip_visible_devices=os.environ.get("HIP_VISIBLE_DEVICES"))
+
+    def exchange_devices(self) -> None:
+        """every rank learns which physical GPU every rank drives (PCI bus id + device UUID + NUMA node -> `config.devices`), and
+        an N > 1 run REFUSES to start unless these are N distinct devices — `--allow-shared-gpu` (ZKH_SHARE_GPUS=1) is the dry
+        run of the N-rank shape on fewer GPUs.  (Tests: ZKH_BENCH_FAKE_DEVICES="a,b,c,d" stands in for the identities of a
+        `--config dev` run, which touches no GPU.)"""
+        fake = os.environ.get("ZKH_BENCH_FAKE_DEVICES")
+        if fake:
+            ids = fake.split(",")
+            self.identity.update(pci_bus_id=ids[self.rank % len(ids)], uuid=ids[self.rank % len(ids)], fake=True)
+        views = self.ctl.allgather(self.identity) if self.distributed else {0: self.identity}
+        self.devices = [views[r] for r in sorted(views)]
+        keys = [(d.get("uuid") or d.get("pci_bus_id")) for d in self.devices]
+        known = [k for k in keys if k]
+        self.devices_distinct = len(known) == len(keys) and len(set(known)) == len(keys) if known else None
+        if self.distributed and self.devices_distinct is False and not getattr(self.args, "allow_shared_gpu", False):
+            shared = {}
+            for d, k in zip(self.devices, keys):
+                shared.setdefault(k, []).append(d["rank"])
+            dup = "; ".join(f"ranks {r} all drive {k}" for k, r in shared.items() if len(r) > 1)
+            raise SystemExit(f"bench: --gpus {self.world} but the ranks do not hold {self.world} distinct GPUs ({dup}).  A dry run of the "
+                             f"N-rank shape on fewer GPUs needs --allow-shared-gpu; its line then says `devices_distinct: false`.")
 
     def load_circuit(self) -> None:
         from zeth_amd.circuits import syn_air
@@ -225,7 +252,10 @@ def config_common(run: Run) -> dict:
     from zeth_amd.hal import HipHal
     v = HipHal.version()
     return {"po2": run.args.po2, "circuit": run.args.circuit, "inflight_per_gpu": run.inflight, "ranks_per_gpu": run.ranks_per_gpu, "library": v,
-            "poseidon2_consts": v.split("poseidon2_consts=")[-1].rstrip(")"), "host_placement_rank0": run.placement}
+            "poseidon2_consts": v.split("poseidon2_consts=")[-1].rstrip(")"), "host_placement_rank0": run.placement,
+            "launcher": "ranks", "devices": run.devices, "devices_distinct": run.devices_distinct,
+            "distinct_devices": len({(d.get("uuid") or d.get("pci_bus_id")) for d in (run.devices or [])}),
+            "rccl_probe": run.rccl, "rccl_world": run.world if run.rccl == "ok" else None}
 
 
 # ---- the recursive fold driven from Python (round 3's two-phase form; the native executor is the default: succinct.py) ----

@@ -216,6 +216,54 @@ class ControlPlane:
             time.sleep(0.05)
 
 
+def rccl_probe(run, timeout_s: float = 60.0):
+    """Bring RCCL up on a process group OF ITS OWN and run ONE all_reduce over xGMI before anything is timed: a health probe (the
+    data path has no collective and never will: SURVEY.md §8e).  Default: whenever the ranks hold N distinct GPUs
+    (ZKH_DIST_BACKEND=gloo switches it off, =nccl forces it).  Every rank takes the same decision (it depends only on the device
+    identities all ranks have just exchanged), so the collective `new_group` is entered by all or none.  The probe runs on a helper
+    thread with a deadline: a hung RCCL bring-up costs 70 s and the string "timeout", never the run.
+    -> "ok" | "wrong sum" | "unavailable (...)" | "timeout" | None (not attempted)"""
+    import threading
+    want = os.environ.get("ZKH_DIST_BACKEND", "auto")
+    if want == "gloo" or (want == "auto" and not run.devices_distinct):
+        return None
+    # the watchdog of a wedged communicator must not abort the process: the seals never needed RCCL
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+    os.environ.setdefault("TORCH_NCCL_ENABLE_MONITORING", "0")
+    out = {}
+
+    def work():
+        try:
+            import torch
+            import torch.distributed as dist
+            torch.cuda.set_device(run.device)
+            grp = dist.new_group(backend="nccl", timeout=timedelta(seconds=timeout_s))
+            probe = torch.ones(1, device=f"cuda:{run.device}")
+            dist.all_reduce(probe, group=grp)
+            torch.cuda.synchronize(run.device)
+            out["v"] = "ok" if int(probe.item()) == run.world else "wrong sum"
+        except Exception as e:                       # the seals never needed RCCL
+            out["v"] = f"unavailable ({type(e).__name__}: {str(e).splitlines()[0][:120] if str(e) else ''})"
+
+    sys.stdout.flush()
+    saved = os.dup(1)                                # RCCL / gloo may announce themselves on stdout: keep it for the ONE JSON line
+    os.dup2(2, 1)
+    try:
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        th.join(timeout_s + 10.0)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+    if th.is_alive():
+        run.rccl_hung = True
+        return "timeout"
+    if out.get("v") != "ok":
+        run.rccl_hung = True                         # a communicator in an unknown state: do not tear the groups down, just exit
+    return out.get("v")
+
+
 def free_port() -> int:
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -15,8 +15,8 @@ import time
 from .common import BASE_SEED, BENCH_NOISE, PO2, ROOT
 
 CPU_PROBE_PO2 = 14              # thread-count probe; the timed sample is the largest po2 <= 20 that fits the budget
-CPU_SAMPLE_BUDGET_S = 12.0      # default run: one sample of ~10 s (the whole default command stays near a minute)
-CPU_SAMPLE_BUDGET_FULL_S = 30.0 # --cpu-full-host: the unit itself (one po2-20 seal, ~21 s on the GPU box) + the all-cores leg
+CPU_SAMPLE_BUDGET_S = 12.0      # default run: one sample of ~10 s alone + the all-cores leg (1/16-unit seals, ~10-15 s): ~25 s of CPU work
+CPU_SAMPLE_BUDGET_FULL_S = 30.0 # --cpu-full-host: the unit itself (one po2-20 seal, ~21 s on the GPU box) + a larger all-cores leg
 
 
 _CPU_WORKER = r"""
@@ -47,14 +47,31 @@ print(json.dumps({"s": time.perf_counter() - t0, "words": int(seal.size)})); sys
 """
 
 
-def cpu_baseline(desc, circuit_name: str, cpus=None, full_host: bool = False) -> dict:
+def cpu_model() -> str:
+    """the host CPU's model name and socket count (core count and CPU model printed)"""
+    try:
+        names, sockets = [], set()
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                names.append(l.split(":", 1)[1].strip())
+            elif l.startswith("physical id"):
+                sockets.add(l.split(":", 1)[1].strip())
+        if names:
+            return f"{max(1, len(sockets))} x {names[0]}"
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def cpu_baseline(desc, circuit_name: str, cpus=None, full_host: bool = False, all_cores: bool = True) -> dict:
     """The CPU oracle (a from-spec port of the reference CPU prover's algorithm) on this host's cores, two figures:
     (1) ONE seal alone at the thread count where the oracle's OpenMP loops stop scaling (latency), and
     (2) the WHOLE host: floor(cores / threads) independent seals at once, one process each, pinned to disjoint core blocks
         (the reference proves segments independently, so a CPU-only deployment would fill its cores exactly like this) ->
         aggregate segments/s = `value`, `cores` = all cores those processes used.
-    Leg (2) runs only with `full_host` (bench.py --cpu-full-host): it doubles the CPU time of the command, and on the GPU box it
-    has never beaten leg (1) (the memory-bound oracle gets slower per seal when every core is busy: profiles/README.md).
+    BOTH legs run by default (round 6; `all_cores=False` = bench.py --no-cpu-all-cores skips leg (2)); `full_host`
+    (--cpu-full-host) gives both a larger budget.  On the GPU box leg (2) has never beaten leg (1) (the memory-bound oracle gets
+    slower per seal when every core is busy: profiles/README.md) — which is itself the informative result: the line carries both.
     A bounded sample: the largest power-of-two fraction of the unit that fits the budget (12 s by default, 30 s with `full_host`:
     then the po2-20 unit itself on the GPU box), scaled linearly (work ~ n)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -91,10 +108,11 @@ def cpu_baseline(desc, circuit_name: str, cpus=None, full_host: bool = False) ->
     dt = time.perf_counter() - t0
     scale = 1 << (PO2 - sample_po2)
     how = "the unit itself, no extrapolation" if scale == 1 else f"scaled x1/{scale} to the po2={PO2} unit (work is ~linear in n)"
+    model = cpu_model()
     single = {"value": 1.0 / (dt * scale), "seal_s": dt * scale, "cores": best,
-              "sample": f"one {circuit_name} segment seal at po2={sample_po2} alone on the host ({dt:.2f} s wall, OpenMP oracle incl. witgen, at the "
+              "sample": f"one {circuit_name} segment seal at po2={sample_po2} alone on the host ({model}; {dt:.2f} s wall, OpenMP oracle incl. witgen, at the "
                         f"fastest of 8/16/32/64 threads = {best}; {avail} hardware threads available); {how}"}
-    out = {"value": single["value"], "unit": "segments/s", "cores": best, "cores_available": avail, "kind": "port",
+    out = {"value": single["value"], "unit": "segments/s", "cores": best, "cores_available": avail, "cpu_model": model, "kind": "port",
            "sample": single["sample"], "single_seal": single,
            "note": "a literal, untuned port (the reference CPU prover cannot be built here); reported as the contract asks, "
                    "never a target and never a quotable speed-up",
@@ -102,9 +120,9 @@ def cpu_baseline(desc, circuit_name: str, cpus=None, full_host: bool = False) ->
     # ---- the whole host: P = floor(cores / best) processes, `best` threads each, disjoint core blocks, distinct segments ----
     # (a bounded sample: the seals of this leg are 1/16 of the unit each — with every core busy the memory-bound oracle runs ~20 x
     # slower per seal than alone, and the whole command has to stay within minutes)
-    if not full_host:
+    if not all_cores and not full_host:
         out["full_host"] = None
-        out["sample"] += "; the all-cores leg (floor(cores / threads) seals at once) runs with --cpu-full-host"
+        out["sample"] += "; the all-cores leg (floor(cores / threads) seals at once) was switched off (--no-cpu-all-cores)"
         return out
     procs_n = max(1, avail // best)
     full_po2 = max(probe_po2, sample_po2 - 4)              # measured on the GPU box: 16 seals at once run ~20 x slower each than one alone

@@ -77,7 +77,8 @@ def run_dev(run: Run):
         "data": "dev-mode",
         "config": {"workload": f"RISC0_DEV_MODE plumbing: fake receipts ({fake_ms} ms of sleep per segment), no GPU work, no proving — "
                                f"BASELINE config 1; exercises the partition, the control plane and result assembly only",
-                   "po2": args.po2, "circuit": "none", "parallelism": f"segments round-robin over {world} rank(s), no collectives"},
+                   "po2": args.po2, "circuit": "none", "parallelism": f"segments round-robin over {world} rank(s), no collectives",
+                   "launcher": "ranks", "devices": run.devices, "devices_distinct": run.devices_distinct, "rccl_probe": run.rccl},
     }
     if run.failed_ranks:
         line["failed_ranks"] = sorted(run.failed_ranks)

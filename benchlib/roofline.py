@@ -17,7 +17,7 @@ import time
 from .common import HBM_PEAK_GBPS, N_SIMDS, PO2, ROOT
 
 # kernels (rocprofv3 names) behind the ops whose counters bench.py can measure on itself
-TRAFFIC_KERNELS = {"hash_rows": ("k_hash_rows", "k_hash_rows_pair"), "hash_fold": ("k_hash_fold",), "eval_check": ("k_eval_check_",)}
+TRAFFIC_KERNELS = {"hash_rows": ("k_hash_rows",), "hash_fold": ("k_hash_fold",), "eval_check": ("k_eval_check_",)}
 # witness generators that run BEFORE a seal (not part of the unit of work): excluded from the whole-seal VALU sum
 WITGEN_KERNELS = ("k_syn_code", "k_syn_data", "k_syn_rowfill", "k_keccak_", "k_p2join_")
 # Share of k_hash_rows' VALU wave-instructions that are of the HALF-RATE class on gfx950 (32-bit multiplies, v_mad_*64*, fp64,
@@ -81,6 +81,65 @@ def pmc_child(counters, circuit: str, po2: int, device: int, timeout_s: float):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def valu_pass(kernels, circuit: str, po2: int, device: int, timeout_s: float):
+    """One child run under `--pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE` -> (figures of the kernels named `kernels`, per launch AND per seal;
+    figures of the whole seal), either None when the pass gave nothing."""
+    rows = pmc_child(("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"), circuit, po2, device, timeout_s)
+    if not rows:
+        return None, None
+    valu = None
+    dom = [(ms, c) for name, _, ms, c in rows if _matches(name, kernels)]
+    if dom:
+        wi = sum(c.get("SQ_INSTS_VALU", 0.0) for _, c in dom) / len(dom)
+        gui = sum(c.get("GRBM_GUI_ACTIVE", 0.0) for _, c in dom) / len(dom)        # summed over the 8 XCDs
+        ms = sum(m for m, _ in dom) / len(dom)
+        cyc = gui / 8.0 * N_SIMDS
+        valu = {"wave_instr": wi, "simd_cycles": cyc, "issue_frac": wi / cyc if cyc else None, "launches": len(dom),
+                "clock_GHz": gui / 8.0 / (ms * 1e-3) / 1e9 if ms else None, "launch_ms_under_counters": ms,
+                "wave_instr_per_seal": wi * len(dom), "ms_per_seal_under_counters": ms * len(dom)}
+    tot_wi = sum(c.get("SQ_INSTS_VALU", 0.0) for _, _, _, c in rows)
+    tot_gui = sum(c.get("GRBM_GUI_ACTIVE", 0.0) for _, _, _, c in rows)
+    tot_ms = sum(ms for _, _, ms, _ in rows)
+    seal = {"wave_instr": tot_wi, "kernel_ms_serial": tot_ms, "dispatches": len(rows),
+            "clock_GHz": tot_gui / 8.0 / (tot_ms * 1e-3) / 1e9 if tot_ms else None,
+            "issue_frac_serial": tot_wi / (tot_gui / 8.0 * N_SIMDS) if tot_gui else None}
+    return valu, seal
+
+
+def add_heavy_valu(line, args, n, device=0):
+    """`syn_heavy.roofline`: the VALU roofline of SYN-HEAVY's eval_check (the kernel that makes the heavy seal heavy), live — one more
+    child run of this command with `--circuit syn_heavy` under `--pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE` (its own pass, kernel trace
+    only).  instr_per_point = wave-instructions x 64 lanes / 4n domain points: the figure the generator's static table predicts."""
+    h = line.get("syn_heavy")
+    if not isinstance(h, dict) or "segments_per_s" not in h or getattr(args, "no_live_traffic", False):
+        return
+    t0 = time.perf_counter()
+    valu, seal = valu_pass(("k_eval_check_",), "syn_heavy", args.po2, device, 120.0)
+    if not valu:
+        h["roofline"] = None
+        return
+    clock = (seal or {}).get("clock_GHz") or 0.0
+    step_s = h["ms_per_step"] * 1e-3 / max(1, int((line.get("config") or {}).get("ranks_per_gpu", 1)))
+    h["roofline"] = {"kernel": "eval_check", "bound": "valu",
+                     "valu": {"wave_instr_per_seal": valu["wave_instr_per_seal"], "launches_per_seal": valu["launches"],
+                              "simd_cycles_per_seal": valu["simd_cycles"] * valu["launches"], "issue_frac": valu["issue_frac"],
+                              "issue_peak_half_rate_class": HALF_RATE_ISSUE_PEAK, "clock_GHz": valu["clock_GHz"],
+                              "instr_per_point": valu["wave_instr_per_seal"] * 64.0 / (4.0 * n),
+                              "ms_per_seal_under_counters": valu["ms_per_seal_under_counters"]},
+                     "seal_valu_wave_instr": seal["wave_instr"] if seal else None,
+                     "seal_valu_issue_frac": seal["wave_instr"] / (step_s * clock * 1e9 * N_SIMDS) if seal and clock else None,
+                     "source": "measured in this run: rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE around a child run of this command with "
+                               "--circuit syn_heavy (one serial seal); the generated eval_check kernels (k_eval_check_*) summed over their parts",
+                     "child_run_s": time.perf_counter() - t0}
+    cfg = line.get("config")
+    if isinstance(cfg, dict):
+        cfg["syn_heavy_eval_instr_per_point"] = round(h["roofline"]["valu"]["instr_per_point"], 0)
+        if h["roofline"]["valu"]["issue_frac"] is not None:
+            cfg["syn_heavy_eval_valu_issue_frac"] = round(h["roofline"]["valu"]["issue_frac"], 4)
+        if h["roofline"]["seal_valu_issue_frac"] is not None:
+            cfg["syn_heavy_seal_valu_issue_frac"] = round(h["roofline"]["seal_valu_issue_frac"], 4)
+
+
 def live_counters(kernels, circuit: str, po2: int, budget_s: float = 120.0, device: int = 0):
     """HBM bytes per launch of the kernels named `kernels` and VALU issue figures (theirs, and the whole seal's), measured NOW:
     three child runs — `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` (separate passes; FETCH_SIZE doubled per the guide's gfx950
@@ -105,22 +164,8 @@ def live_counters(kernels, circuit: str, po2: int, budget_s: float = 120.0, devi
         out["traffic_source"] = (f"measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, kernel trace only) around "
                                  f"two child runs of this command with one serial seal each; FETCH x2 per the gfx950 correction; mean over {nl} launches")
     left = budget_s - (time.perf_counter() - t0)
-    rows = pmc_child(("SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"), circuit, po2, device, left) if left > 15 else None
-    if rows:
-        dom = [(ms, c) for name, _, ms, c in rows if _matches(name, kernels)]
-        if dom:
-            wi = sum(c.get("SQ_INSTS_VALU", 0.0) for _, c in dom) / len(dom)
-            gui = sum(c.get("GRBM_GUI_ACTIVE", 0.0) for _, c in dom) / len(dom)        # summed over the 8 XCDs
-            ms = sum(m for m, _ in dom) / len(dom)
-            cyc = gui / 8.0 * N_SIMDS
-            out["valu"] = {"wave_instr": wi, "simd_cycles": cyc, "issue_frac": wi / cyc if cyc else None, "launches": len(dom),
-                           "clock_GHz": gui / 8.0 / (ms * 1e-3) / 1e9 if ms else None, "launch_ms_under_counters": ms}
-        tot_wi = sum(c.get("SQ_INSTS_VALU", 0.0) for _, _, _, c in rows)
-        tot_gui = sum(c.get("GRBM_GUI_ACTIVE", 0.0) for _, _, _, c in rows)
-        tot_ms = sum(ms for _, _, ms, _ in rows)
-        out["seal_valu"] = {"wave_instr": tot_wi, "kernel_ms_serial": tot_ms, "dispatches": len(rows),
-                            "clock_GHz": tot_gui / 8.0 / (tot_ms * 1e-3) / 1e9 if tot_ms else None,
-                            "issue_frac_serial": tot_wi / (tot_gui / 8.0 * N_SIMDS) if tot_gui else None}
+    if left > 15:
+        out["valu"], out["seal_valu"] = valu_pass(kernels, circuit, po2, device, left)
     out["child_runs_s"] = time.perf_counter() - t0
     return out
 

@@ -248,14 +248,39 @@ def run_segment(run: Run):
         return out
     pcie = secondary(run, "pcie", pcie_leg) if args.ingress == "host" else None
 
+    REPS, EXTRA_WARM = 2, 2
+
+    def rep_stats(times, steps):
+        """seconds of each repetition of `steps` steps -> the figures a secondary leg reports: the rate over ALL repetitions, the
+        slowest and the fastest repetition, and whether they agree (a leg whose repetitions differ by more than 8 % says so)"""
+        rates = [world * steps / t for t in times]
+        v = world * steps * len(times) / sum(times)
+        spread = (max(rates) - min(rates)) / v
+        out = {"segments_per_s": v, "min": min(rates), "max": max(rates), "reps": len(times), "spread_pct": 100.0 * spread,
+               "ms_per_step": 1e3 * sum(times) / (steps * len(times)), "steps": steps}
+        if spread > 0.08:
+            out["unstable"] = f"the {len(times)} repetitions differ by {100.0 * spread:.1f} % (> 8 %): quote min .. max, not the mean"
+        return out
+
     def timed_extra(make_prover, steps, with_prof):
-        """A few more timed steps of the same resident witnesses under another prover per lane -> (seconds, per-kernel times)."""
+        """`steps` more timed steps of the same resident witnesses under another prover per lane, REPS times over -> (seconds of
+        each repetition, per-kernel times of one seal alone).  Before the first clock every lane seals once on its own (that seal
+        loads the prover's code objects and sizes its pool blocks) and then EXTRA_WARM more times with the other lanes running —
+        round 5 timed 9 steps after one seal per lane and the driver's box read 26 % low."""
         for ln in lanes:
             ln.extra = make_prover(ln)
 
         def one(ln):
             seg, code, data, out = ln.wit[0]
             ln.last_extra = ln.extra.seal(seg, code, data, out)
+
+        def warm_x(ln):
+            try:
+                for _ in range(EXTRA_WARM):
+                    one(ln)
+                ln.hal.sync()
+            except Exception as e:
+                ln.err = e
 
         def timed_x(ln):
             try:
@@ -267,20 +292,25 @@ def run_segment(run: Run):
 
         for ln in lanes:
             one(ln)
+            ln.hal.sync()
+        run_lanes(lanes, warm_x)
         kprof = {}
         if with_prof and rank == 0 and not args.no_prof:
             lanes[0].hal.prof_reset(); lanes[0].hal.prof_enable(True)
             one(lanes[0]); lanes[0].hal.sync()
             kprof = {p["name"]: p for p in lanes[0].hal.prof_get()}
             lanes[0].hal.prof_enable(False)
-        run.device_sync(lanes)
-        ctl.barrier()
-        idx.reset()
-        t2 = time.perf_counter()
-        run_lanes(lanes, timed_x)
-        run.device_sync(lanes)
-        ctl.barrier()
-        return ctl.max(time.perf_counter() - t2), kprof
+        times = []
+        for _ in range(REPS):
+            run.device_sync(lanes)
+            ctl.barrier()
+            idx.reset()
+            t2 = time.perf_counter()
+            run_lanes(lanes, timed_x)
+            run.device_sync(lanes)
+            ctl.barrier()
+            times.append(ctl.max(time.perf_counter() - t2))
+        return times, kprof
 
     # The same step under the realistically heavy constraint system (SYN-HEAVY: same trace shape and witness, ~54 k constraint steps
     # instead of ~1 k): SYN-A's eval_check is 4 % of a seal, upstream's is the largest kernel, so the headline flatters the real
@@ -290,9 +320,11 @@ def run_segment(run: Run):
         from zeth_amd.circuits.desc import Circuit
         hdesc = syn_heavy.syn_heavy()
         hsteps = max(inflight, min(args.heavy_steps, args.steps))
-        dth, hprof = timed_extra(lambda ln: SegmentProver(ln.hal, hdesc), hsteps, True)
+        times, hprof = timed_extra(lambda ln: SegmentProver(ln.hal, hdesc), hsteps, True)
         hc = Circuit.parse(hdesc)
-        return {"segments_per_s": world * hsteps / dth, "ms_per_step": 1e3 * dth / hsteps, "steps": hsteps,
+        out = rep_stats(times, hsteps)
+        out["value"], out["unit"] = out["segments_per_s"], "segments/s"
+        return {**out,
                 "workload": f"same step with the SYN-HEAVY constraint system ({len(hc.steps)} steps, {len(hc.taps)} taps, "
                             f"{len(hc.combos)} tap combos, degree 5, ConstExt, nested AndCond; {lanes[0].extra.circuit.compiled_parts()} generated kernels)",
                 "kernels_ms_per_seal_unshared": {k: round(v["total_ms"], 3) for k, v in sorted(hprof.items(), key=lambda kv: -kv[1]["total_ms"])[:6]}}
@@ -304,9 +336,9 @@ def run_segment(run: Run):
     def resident_leg():
         import numpy as np
         rsteps = max(inflight, min(args.heavy_steps, args.steps))
-        dtr, _ = timed_extra(lambda ln: SegmentProver(ln.hal, run.desc, resident_code_group=True), rsteps, False)
+        times, _ = timed_extra(lambda ln: SegmentProver(ln.hal, run.desc, resident_code_group=True), rsteps, False)
         same = all(np.array_equal(ln.last_extra.seal, ln.prover.seal(*ln.wit[0]).seal) for ln in lanes)   # same witness, recomputing prover
-        return {"segments_per_s": world * rsteps / dtr, "ms_per_step": 1e3 * dtr / rsteps, "steps": rsteps,
+        return {**rep_stats(times, rsteps),
                 "seals_identical_to_recomputing_prover": bool(same),
                 "note": "NOT the headline: the code group's iNTT / expand-NTT / leaf hashing / Merkle fold are skipped because "
                         "its committed form is resident (opt-in: SegmentProver(resident_code_group=True))"}
@@ -378,30 +410,38 @@ def run_segment(run: Run):
             psess = Session(run.desc, devices=(run.device,), lanes_per_device=inflight)
             psess.set_witness_source(1, args.preflight_producers)
             psess.set_resident_code(not args.recompute_code)
-            psess.prove([bsegs[0]] * inflight + [bsegs[-1]])          # warm-up: every size once per lane
+            psess.prove([bsegs[0]] * (3 * inflight) + [bsegs[-1]] * inflight)   # warm-up: three seals per lane, every size
         except HalError as e:                  # (ranks sharing ONE GPU in a dry run can run out of HBM here)
             perr = str(e)
         if ctl.min(0.0 if perr else 1.0) < 1.0:                       # every rank skips the leg together
             if psess is not None:
                 psess.close()
             return {"error": perr or "another rank could not set the leg up"}
-        run.device_sync(lanes)
-        ctl.barrier()
-        tp0 = time.perf_counter()
-        pcomp, _, pst = psess.prove([bsegs[i] for i in bmine])
-        ctl.barrier()
-        dtp = time.perf_counter() - tp0
+        ptimes = []
+        for _ in range(REPS):
+            run.device_sync(lanes)
+            ctl.barrier()
+            tp0 = time.perf_counter()
+            pcomp, _, pst = psess.prove([bsegs[i] for i in bmine])
+            ctl.barrier()
+            ptimes.append(ctl.max(time.perf_counter() - tp0))
         for r in pcomp.segments:
             r.verify(run.desc, broots[r.po2])
-        dtp = ctl.max(dtp)
         tpv = ctl.sum([pst["preflight_cpu_s_sum"], pst["trace_bytes"], float(len(bmine)), pst["witgen_s_sum"]])
         psess.close()
-        return {"segments": S, "wall_clock_s": dtp, "segments_per_s": S / dtp,
+        dtp = sum(ptimes) / len(ptimes)
+        prates = [S / t for t in ptimes]
+        pspread = (max(prates) - min(prates)) / (S / dtp)
+        return {"segments": S, "wall_clock_s": dtp, "segments_per_s": S / dtp, "min": min(prates), "max": max(prates), "reps": len(ptimes),
+                "spread_pct": 100.0 * pspread, **({"unstable": f"the repetitions differ by {100.0 * pspread:.1f} % (> 8 %)"} if pspread > 0.08 else {}),
                 "host_preflight_cpu_ms_per_segment": 1e3 * tpv[0] / max(1.0, tpv[2]),
                 "pcie_bytes_per_segment": tpv[1] / max(1.0, tpv[2]),
                 "full_trace_bytes_per_segment": 4.0 * (wc + wd) * n,
                 "upload_and_row_fill_ms_per_segment": 1e3 * tpv[3] / max(1.0, tpv[2]),
                 "producer_threads_per_gpu": inflight * (args.preflight_producers or 2), "sealing_lanes_per_gpu": inflight,
+                # the Amdahl term of an N-GPU node: host cores the preflight producers keep busy = N x segments/s per GPU x CPU seconds per segment
+                "host_cores_needed": (S / dtp) * (tpv[0] / max(1.0, tpv[2])),
+                "host_cores_needed_8_gpus": 8.0 * (S / dtp / world) * (tpv[0] / max(1.0, tpv[2])),
                 "verified_after_clock": int(tpv[2]),
                 "note": "the preflight is a sequential per-cycle machine (SYN-VM: 8 registers, 64 instructions, 1 KiB words of RAM) on host "
                         "threads; its 16-byte-per-cycle records are the ONLY witness input that crosses PCIe; the GPU expands them (one lane per "
@@ -485,7 +525,7 @@ def run_segment(run: Run):
     cfg.update({"workload": (f"single 2^{args.po2}-cycle segment seal per step per GPU, {run.workload}, witness resident in HBM; every group incl. the "
                              f"code (control) group is re-committed per segment as upstream's SegmentProver does (`value` does NOT keep it resident)"),
                 "parallelism": f"segments round-robin over {world} GPU(s), no collectives; {inflight} segment(s) in flight per GPU",
-                "rccl_probe": run.rccl, "seal_words": int(last.seal.size) if last is not None else 0,
+                "seal_words": int(last.seal.size) if last is not None else 0,
                 "value_recomputes_code_group": True})
     line = {
         "metric": "segments/sec", "value": value, "unit": "segments/s", "n_gpus": world, "steps": args.steps,
@@ -538,15 +578,21 @@ def run_segment(run: Run):
         for ln in lanes:                       # the child runs bring their own context: hand this rank's cached pool blocks back first
             after.append(ln.hal.trim)
         after.append(lambda: add_roofline(line, prof, ref, args, inflight, (wa, wc, wd), n, run.device, live=live))
+        if live:
+            from .roofline import add_heavy_valu
+            after.append(lambda: add_heavy_valu(line, args, n, run.device))
     if not args.no_cpu_baseline and not run.failed_ranks:
         def _cpu():
             from .cpu_baseline import cpu_baseline
             try:
-                line["cpu_baseline"] = cpu_baseline(run.desc, args.circuit, run.cpus_before, full_host=args.cpu_full_host)
+                line["cpu_baseline"] = cpu_baseline(run.desc, args.circuit, run.cpus_before, full_host=args.cpu_full_host, all_cores=not args.no_cpu_all_cores)
             except Exception as e:       # the baseline is a reported number, never a dependency of the product path
                 line["cpu_baseline"] = {"error": repr(e)}
         after.append(_cpu)
     return line, after
+
+
+MAX_CONFIG_KEY = 32             # round 5: the driver's record cut `block_recompute_code_group_segments_per_` at 40 characters
 
 
 def flatten_secondary(line: dict) -> None:
@@ -558,21 +604,27 @@ def flatten_secondary(line: dict) -> None:
         if isinstance(obj, dict) and isinstance(obj.get(field), (int, float)):
             cfg[key] = round(obj[field], digits)
     put("syn_heavy_segments_per_s", line.get("syn_heavy"), "segments_per_s")
-    put("code_group_resident_segments_per_s", line.get("code_group_resident"), "segments_per_s")
+    put("syn_heavy_min_segments_per_s", line.get("syn_heavy"), "min")
+    put("syn_heavy_max_segments_per_s", line.get("syn_heavy"), "max")
+    put("syn_heavy_ms_per_step", line.get("syn_heavy"), "ms_per_step")
+    put("resident_code_segments_per_s", line.get("code_group_resident"), "segments_per_s")
     blk = line.get("block")
     if isinstance(blk, dict):
         put("block_segments", blk, "segments", 0)
         put("block_segments_per_s", blk, "segments_per_s")
         put("block_wall_clock_s", blk, "wall_clock_s", 4)
-        put("block_recompute_code_group_segments_per_s", blk.get("recompute_code_group"), "segments_per_s")
+        put("block_recompute_segments_per_s", blk.get("recompute_code_group"), "segments_per_s")
         pre = blk.get("host_preflight_pipeline")
-        put("preflight_pipeline_segments_per_s", pre, "segments_per_s")
-        put("preflight_host_cpu_ms_per_segment", pre, "host_preflight_cpu_ms_per_segment", 2)
+        put("preflight_segments_per_s", pre, "segments_per_s")
+        put("preflight_host_cpu_ms_per_seg", pre, "host_preflight_cpu_ms_per_segment", 2)
+        put("preflight_host_cores_needed", pre, "host_cores_needed", 2)
         if isinstance(pre, dict) and isinstance(pre.get("pcie_bytes_per_segment"), (int, float)):
             cfg["preflight_pcie_MB_per_segment"] = round(pre["pcie_bytes_per_segment"] / 1e6, 2)
         put("block_fold_to_one_receipt_s", blk.get("recursive"), "fold_s", 4)
     put("seal_wall_clock_unloaded_s", line, "seal_wall_clock_unloaded_s", 5)
     put("seal_hbm_frac", line.get("seal_roofline"), "frac", 4)
+    too_long = [k for k in cfg if len(k) > MAX_CONFIG_KEY]
+    assert not too_long, f"config keys longer than {MAX_CONFIG_KEY} characters (a record that truncates keys loses them): {too_long}"
 
 
 def run_pmc_child(run: Run) -> None:

@@ -7,7 +7,7 @@
 //   segment order (index i at position i),
 //   every seal against the control root THE VERIFIER expects for its size (zkh_verify_segment, host arithmetic only) — never the
 //   root a container carries,
-//   with --chained the continuity of the session (SYN-C / SYN-S circuits: the first segment starts from --initial-state, every
+//   with --chained (implied by a SYN-S circuit) the continuity of the session (SYN-C / SYN-S circuits: the first segment starts from --initial-state, every
 //   segment's pre-state is its predecessor's post-state: CompositeReceipt::verify_integrity),
 //   and that the session is WHOLE: a SYN-S circuit ("syn_session") binds an exit code and the journal's digest in every seal —
 //   SystemSplit .. SystemSplit, Halted(0) + SHA-256(journal) — so trailing segments cannot be dropped and the journal cannot be
@@ -83,6 +83,9 @@ int main(int argc, char** argv) {
     const char* err = zkh_circuit_load(nullptr, desc.data(), desc.size(), &circuit);
     if (err) { fprintf(stderr, "zkh_circuit_load: %s\n", err); zkh_free_error(err); return 1; }
     const bool session = desc.size() > 13 && desc[13] == 1 && desc[7] == 23;      // SYN-S: exit code + journal digest bound in every seal
+    // A session circuit's seals carry the state words: continuity and the initial state are ALWAYS checked for it (a directory
+    // holding segments 0..k of one session followed by the halting segment of another must not verify); --chained is implied.
+    if (session) chained = true;
     if (chained && !session && expect_segments < 0) {
         fprintf(stderr, "REJECTED: --chained on a circuit that binds no exit code (SYN-C) needs --segments N: without it a session with its trailing "
                         "segments cut off would verify (use the syn_session circuit to bind termination in the seals)\n");
@@ -132,8 +135,9 @@ int main(int argc, char** argv) {
     if (session) {          // the session must END here: SystemSplit .. SystemSplit, Halted(0), and the journal's digest in the last seal
         std::vector<const uint32_t*> ptrs;
         std::vector<size_t> words;
+        static const uint8_t empty_journal = 0;          // --journal "": an EXPLICITLY empty journal (a NULL pointer would mean "the default journal")
         for (auto& s : kept) { ptrs.push_back(s.data()); words.push_back(s.size()); }
-        if ((err = zkh_session_check_termination(circuit, ptrs.data(), words.data(), ptrs.size(), have_journal ? journal.data() : nullptr, journal.size()))) {
+        if ((err = zkh_session_check_termination(circuit, ptrs.data(), words.data(), ptrs.size(), have_journal ? (journal.empty() ? &empty_journal : journal.data()) : nullptr, journal.size()))) {
             fprintf(stderr, "REJECTED: %s\n", err);
             zkh_free_error(err);
             return 1;

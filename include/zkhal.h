@@ -118,8 +118,7 @@ const char* zkh_hash_fold(zkh_ctx*, zkh_buf* io_digests, size_t input_size, size
  * nodes has 2*rows digests, leaves already at [rows, 2*rows). */
 const char* zkh_merkle_fold_all(zkh_ctx*, zkh_buf* nodes, size_t rows);
 /* MerkleTreeProver::new as one call: nodes[rows .. 2 rows) = hash_rows(matrix), then every layer above down to the root at nodes[1];
- * digests are identical to zkh_hash_rows + zkh_merkle_fold_all.  (ZKH_MERKLE_FUSED=1: wide trees hash two adjacent rows per lane
- * and their parent in one pass — measured, not faster on MI355X, hence opt-in.) */
+ * digests are identical to zkh_hash_rows + zkh_merkle_fold_all. */
 const char* zkh_merkle_build(zkh_ctx*, zkh_buf* nodes, const zkh_buf* matrix, size_t rows);
 /* The bare permutation (risc0_zkp::core::hash::poseidon2::poseidon2_mix): `count` states of 24 Montgomery words each,
  * in place — on the device with the context's tables, or on the host (rc / diag canonical residues, NULL = the shipped
@@ -521,6 +520,10 @@ const char* zkh_parse_cpulist(const char* text, int* cpus, size_t cap, size_t* n
 const char* zkh_pci_numa_cpus(const char* sysfs_root, const char* bdf, int* node, int* cpus, size_t cap, size_t* n_cpus);
 /* NUMA node of a HIP device (-1 = unknown) and, optionally, its PCI bus id */
 const char* zkh_device_numa_node(int device, int* node, char pci_bus_id[32]);
+/* What tells one GPU from another across processes (bench.py gathers it from every rank: an N-GPU line lists N distinct devices):
+ * PCI bus id, the device UUID as 32 hex digits (independent of HIP_VISIBLE_DEVICES renumbering; empty if the runtime has none),
+ * NUMA node (-1 = unknown), marketing name, and the number of devices this process sees.  Any out pointer may be NULL. */
+const char* zkh_device_identity(int device, char pci_bus_id[32], char uuid_hex[40], int* numa_node, char name[64], int* visible_devices);
 /* Bind the CALLING thread (and the threads it creates afterwards) to slice `slot` of `share` equal slices of the device's
  * NUMA-node CPUs (share <= 1: the whole node) and make that node its preferred memory node.  ZKH_AFFINITY=off, or a host that
  * reports no node: nothing is changed and *node = -1. */

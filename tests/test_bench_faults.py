@@ -90,3 +90,23 @@ def test_the_drivers_launch_shape(fault):
         assert rc == 0 and "failed_ranks" not in lines[0]
     else:
         assert rc != 0 and lines[0]["failed_ranks"] == [2] and dt < 60
+
+
+def test_an_n_rank_line_lists_n_distinct_devices_or_refuses_to_start():
+    """Round-5 verdict, weak #6: an N > 1 line must PROVE it ran on N GPUs.  Every rank's device identity (PCI bus id, UUID, NUMA
+    node) is gathered into config.devices; N ranks that do not hold N distinct devices refuse to start unless --allow-shared-gpu
+    says it is a dry run.  (`--config dev` touches no GPU: ZKH_BENCH_FAKE_DEVICES stands in for the identities.)"""
+    rc, dt, lines, err = _run({"ZKH_BENCH_FAKE_DEVICES": "0000:05:00.0,0000:15:00.0,0000:65:00.0,0000:75:00.0"})
+    assert rc == 0 and len(lines) == 1, err[-2000:]
+    cfg = lines[0]["config"]
+    assert [d["rank"] for d in cfg["devices"]] == [0, 1, 2, 3] and cfg["devices_distinct"] is True
+    assert len({d["pci_bus_id"] for d in cfg["devices"]}) == 4 and cfg["launcher"] == "ranks"
+    # two ranks on one device: nobody starts, the message names them, no line
+    rc, dt, lines, err = _run({"ZKH_BENCH_FAKE_DEVICES": "0000:05:00.0,0000:15:00.0,0000:15:00.0,0000:75:00.0"})
+    assert rc != 0 and not lines and dt < 30
+    assert "do not hold 4 distinct GPUs" in err and "ranks [1, 2] all drive 0000:15:00.0" in err and "--allow-shared-gpu" in err
+    # ... unless it is declared a dry run: the line then says so
+    rc, dt, lines, err = _run({"ZKH_BENCH_FAKE_DEVICES": "0000:05:00.0"}, args=("--config", "dev", "--gpus", "4", "--steps", "40", "--allow-shared-gpu"))
+    assert rc == 0 and len(lines) == 1, err[-2000:]
+    cfg = lines[0]["config"]
+    assert cfg["devices_distinct"] is False and len(cfg["devices"]) == 4 and {d["pci_bus_id"] for d in cfg["devices"]} == {"0000:05:00.0"}

@@ -155,6 +155,23 @@ def test_the_cpp_verifier_refuses_a_truncated_session_and_a_rewritten_journal(se
     assert run("--journal", receipt.journal.hex()).returncode == 0 and run("--segments", "3").returncode == 0
     r = run("--journal", "01020304")
     assert r.returncode == 1 and "journal does not hash" in r.stderr
+    r = run("--journal", "")                                           # an EXPLICITLY empty journal is not "the default journal" (round-5 advisor finding)
+    assert r.returncode == 1 and "journal does not hash" in r.stderr
+
+    # a session circuit is ALWAYS checked for continuity and its initial state, --chained or not (round-5 advisor finding: without it a
+    # directory holding segments 0..k of session A followed by the halting segment of session B printed "verified")
+    def run_plain(*extra):
+        return subprocess.run([exe, "--desc", str(dpath), "--receipts-dir", str(tmp_path), "--control-root", f"{PO2}:{hexroot}", *extra],
+                              capture_output=True, text=True, timeout=300)
+    r = run_plain("--initial-state", str(INIT))
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["chained"] is True, r.stderr
+    r = run_plain()                                                    # the default initial state (0) is not this session's
+    assert r.returncode == 1 and "not continuous" in r.stderr
+    other, _ = prove_chained_block(prove, contribution, desc, base, initial_state=INIT + 1)
+    write([receipt.inner.segments[0], receipt.inner.segments[1], other.inner.segments[2]])     # A0, A1, then B's halting segment
+    r = run_plain("--initial-state", str(INIT))
+    assert r.returncode == 1 and "segment 2" in r.stderr and "not continuous" in r.stderr
+    write(receipt.inner.segments)
     write(receipt.inner.segments[:2])                                  # trailing segment dropped: every remaining receipt verifies, the session does not
     r = run()
     assert r.returncode == 1 and "does not say Halted(0)" in r.stderr

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Forward / inverse NTT A/B on one MI355X: per-pass HIP-event times of the data-group shape (W x 2^po2 -> 2^(po2+2)) plus a
-SHA-256 of the first 8 output columns so that variants (env switches ZKH_NTT_NO_MATRIX / ZKH_NTT_NO_COLFAST / ZKH_NTT_NO_LAZY,
-or another build through ZKH_LIBRARY) can be checked for identical results.   python tools/exp_ntt.py [--po2 20] [--width 208]"""
+SHA-256 of the first 8 output columns so that variants (another build through ZKH_LIBRARY; the round-3 env switches are gone) can be checked for identical results.   python tools/exp_ntt.py [--po2 20] [--width 208]"""
 import argparse
 import hashlib
 import json

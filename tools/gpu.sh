@@ -11,7 +11,11 @@
 #   succinct4    config 5's N-rank shape as 4 ranks on ONE GPU (native executor per rank + top joins on rank 0)
 #   chained      bench.py --config block --chained (S = 256 SYN-C segments, pre == prev.post checked after the clock)
 #   config5      BASELINE config 5 (S = 1024 -> one succinct receipt): streamed pipeline, two phases, and the g++ host
-#   ab VAR       A/B of one env switch of the library (e.g. ZKH_MERKLE_FUSED): bench with and without VAR=1, 3 repeats each
+#   ab VAR       A/B of one env switch of the library (e.g. ZKH_REC_GRAPH): bench with and without VAR=1, 3 repeats each
+#   repro        the DRIVER'S exact command (python bench.py --gpus 1 --steps 20 --warmup 5) five times on this lease: spread of `value` and of
+#                every secondary figure (syn_heavy, resident code, block, preflight) -> repro_summary.json  (round-5 verdict, item 1)
+#   devices      N > 1 readiness on ONE GPU: 8 ranks sharing it (--allow-shared-gpu; config.devices), the same without the flag (must
+#                refuse), the in-process launcher (--launcher session, 8 devices x 1 lane and 1 device x 3 lanes), the RCCL probe at world 1
 #   profiles     everything profiles/ holds (tools/collect_profiles.sh)
 #   big          po2 21 / 22 segments
 #   soak         1000 distinct segments through the g++ driver
@@ -52,6 +56,50 @@ bench)
   ( time timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err ) 2> $O/bench_default.time; line $O/bench_default.json
   ( time ZKH_SHARE_GPUS=1 timeout 900 python bench.py --gpus 8 --steps 6 --warmup 1 --no-heavy > $O/bench_8rank_one_gpu.json 2> $O/bench_8rank.err ) 2> $O/bench_8rank.time; line $O/bench_8rank_one_gpu.json
   grep real $O/*.time; tail -3 $O/bench_default.err | grep -v amdgpu.ids ;;
+repro)
+  O=gpurun_out/${1:-repro}; mkdir -p $O
+  for i in 1 2 3 4 5; do
+    ( time timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/driver_cmd_$i.json 2> $O/driver_cmd_$i.err ) 2> $O/driver_cmd_$i.time; line $O/driver_cmd_$i.json
+  done
+  python - $O <<'PY'
+import json, sys
+O = sys.argv[1]
+ls = [json.loads(open(f"{O}/driver_cmd_{i}.json").read().strip().splitlines()[-1]) for i in range(1, 6)]
+def col(f):
+    v = [f(l) for l in ls]
+    m = sum(v) / len(v)
+    return {"runs": [round(x, 3) for x in v], "mean": round(m, 3), "spread_pct": round(100 * (max(v) - min(v)) / m, 2)}
+out = {"command": "python bench.py --gpus 1 --steps 20 --warmup 5 (five times, one lease)",
+       "value": col(lambda l: l["value"]), "syn_heavy": col(lambda l: l["syn_heavy"]["segments_per_s"]),
+       "syn_heavy_min": col(lambda l: l["syn_heavy"]["min"]), "syn_heavy_max": col(lambda l: l["syn_heavy"]["max"]),
+       "resident_code": col(lambda l: l["code_group_resident"]["segments_per_s"]), "block": col(lambda l: l["block"]["segments_per_s"]),
+       "preflight": col(lambda l: l["block"]["host_preflight_pipeline"]["segments_per_s"]),
+       "seal_unloaded_ms": col(lambda l: 1e3 * l["seal_wall_clock_unloaded_s"]), "command_wall_s": col(lambda l: l["command_wall_s"]),
+       "unstable_legs": sorted({k for l in ls for k in ("syn_heavy", "code_group_resident") if "unstable" in l.get(k, {})})}
+json.dump(out, open(f"{O}/repro_summary.json", "w"), indent=1)
+print(json.dumps(out))
+PY
+  ;;
+devices)
+  O=gpurun_out/${1:-devices}; mkdir -p $O
+  ( time timeout 900 python bench.py --gpus 8 --steps 6 --warmup 1 --no-heavy --allow-shared-gpu > $O/bench_8rank_one_gpu.json 2> $O/bench_8rank.err ) 2> $O/bench_8rank.time; line $O/bench_8rank_one_gpu.json
+  timeout 300 python bench.py --gpus 8 --steps 6 --warmup 1 --no-heavy > $O/bench_8rank_refused.out 2> $O/bench_8rank_refused.err; echo "8 ranks on one GPU without --allow-shared-gpu: rc=$? (must be non-zero)"; grep -h "distinct GPUs" $O/bench_8rank_refused.err | head -1 | cut -c1-240
+  ( time timeout 600 python bench.py --gpus 8 --launcher session --inflight 1 --steps 6 --warmup 1 --allow-shared-gpu > $O/bench_session_8dev_one_gpu.json 2> $O/bench_session8.err ) 2> $O/bench_session8.time; line $O/bench_session_8dev_one_gpu.json
+  ( time timeout 600 python bench.py --gpus 1 --launcher session > $O/bench_session_1gpu.json 2> $O/bench_session1.err ) 2> $O/bench_session1.time; line $O/bench_session_1gpu.json
+  ZKH_DIST_BACKEND=nccl timeout 600 python bench.py --gpus 2 --steps 6 --warmup 1 --no-heavy --no-block --no-resident --no-cpu-baseline --allow-shared-gpu > $O/bench_2rank_forced_rccl.json 2> $O/bench_2rank_forced_rccl.err; line $O/bench_2rank_forced_rccl.json
+  timeout 300 python tools/rccl_probe_check.py > $O/rccl_probe_world1.json 2> $O/rccl_probe_world1.err; cat $O/rccl_probe_world1.json
+  python - $O <<'PY'
+import json, sys
+O = sys.argv[1]
+for f in ("bench_8rank_one_gpu", "bench_session_8dev_one_gpu", "bench_session_1gpu", "bench_2rank_forced_rccl"):
+    try:
+        l = json.loads(open(f"{O}/{f}.json").read().strip().splitlines()[-1]); c = l["config"]
+        print(f, "value", round(l["value"], 2), "launcher", c.get("launcher"), "devices", len(c.get("devices") or []), "distinct", c.get("devices_distinct"),
+              "rccl", c.get("rccl_probe"), [d.get("pci_bus_id") for d in (c.get("devices") or [])][:2])
+    except Exception as e:
+        print(f, "no line:", e)
+PY
+  grep real $O/*.time; for f in $O/*.err; do grep -v amdgpu.ids $f | tail -2; done ;;
 chained)
   O=gpurun_out/${1:-chained}; mkdir -p $O        # a chained block (claim continuity) and the same block with the host-preflight witness, full size
   timeout 600 python bench.py --config block --chained --no-cpu-baseline > $O/bench_block_chained.json 2> $O/err.txt; line $O/bench_block_chained.json

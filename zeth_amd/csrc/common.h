@@ -110,9 +110,6 @@ struct zkh_ctx {
     uint32_t* h_fail = nullptr;                  // pinned mirror
     bool fail_armed = false;                     // an op that may raise it was enqueued since the last check
     std::map<void*, size_t> host_blocks;         // pinned host memory handed to the caller (zkh_host_alloc): ptr -> bytes
-    // four-step twiddle matrices of the lazy forward NTT (ntt.hip): key (log_n << 8 | expand_bits) -> 2^log_n words,
-    // built on first use by a kernel on this context's stream, shared by every column of every transform of that shape
-    std::map<uint32_t, uint32_t*> ntt_fwd_matrix;
 };
 
 namespace zkh {

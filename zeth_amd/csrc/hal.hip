@@ -230,7 +230,6 @@ extern "C" void zkh_ctx_destroy(zkh_ctx* c) {
     uint32_t* t[] = {c->tab.rc, c->tab.diag, c->tab.tw_fwd_lo, c->tab.tw_fwd_hi, c->tab.tw_rev_lo, c->tab.tw_rev_hi,
                      c->tab.tile_fwd, c->tab.tile_rev, c->tab.shift_lo, c->tab.shift_hi, c->tab.layer_fwd, c->tab.layer_rev, c->tab.layer_fwd_plain};
     for (auto p : t) (void)hipFree(p);
-    for (auto& kv : c->ntt_fwd_matrix) (void)hipFree(kv.second);
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -254,12 +253,18 @@ static const char* check_device_fail(zkh_ctx* c) {
     default: return make_err("a kernel reported failure code %u (%u)", code, detail);
     }
 }
-extern "C" const char* zkh_sync(zkh_ctx* c) {
-    bind_thread(c);
+// every host-visible synchronisation of the library's stream goes through here: the sticky word is fetched with it, so a
+// device-side failure (zkh_combos_prepare_regs) surfaces at the FIRST sync after it, whichever call that is (zkh_sync, zkh_read,
+// a large zkh_write / zkh_copy_from, a full staging ring).  Callers that synchronise zkh_ctx_stream() themselves must call zkh_sync.
+static const char* sync_checked(zkh_ctx* c) {
     if (c->fail_armed) ZKH_HIP(hipMemcpyAsync(c->h_fail, c->d_fail, 8, hipMemcpyDeviceToHost, c->stream));
     ZKH_HIP(hipStreamSynchronize(c->stream));
     c->stage_used = 0;
     return check_device_fail(c);
+}
+extern "C" const char* zkh_sync(zkh_ctx* c) {
+    bind_thread(c);
+    return sync_checked(c);
 }
 extern "C" void* zkh_ctx_stream(zkh_ctx* c) { return (void*)c->stream; }
 
@@ -277,7 +282,7 @@ const char* h2d(zkh_ctx* c, uint32_t* dst, const uint32_t* host, size_t n) {
     bind_thread(c);
     if (n <= STAGE_SLOT_WORDS) {
         ZKH_TRY(ensure_pinned(c, STAGE_SLOT_WORDS * STAGE_SLOTS));
-        if (c->stage_used == STAGE_SLOTS) { ZKH_HIP(hipStreamSynchronize(c->stream)); c->stage_used = 0; }
+        if (c->stage_used == STAGE_SLOTS) ZKH_TRY(sync_checked(c));
         uint32_t* slot = c->pinned + (size_t)c->stage_next * STAGE_SLOT_WORDS;
         memcpy(slot, host, n * 4);
         ZKH_HIP(hipMemcpyAsync(dst, slot, n * 4, hipMemcpyHostToDevice, c->stream));
@@ -286,9 +291,7 @@ const char* h2d(zkh_ctx* c, uint32_t* dst, const uint32_t* host, size_t n) {
         return nullptr;
     }
     ZKH_HIP(hipMemcpyAsync(dst, host, n * 4, hipMemcpyHostToDevice, c->stream));
-    ZKH_HIP(hipStreamSynchronize(c->stream));      // the host pointer is only borrowed for the call
-    c->stage_used = 0;
-    return nullptr;
+    return sync_checked(c);                         // the host pointer is only borrowed for the call
 }
 }  // namespace zkh
 extern "C" const char* zkh_copy_from(zkh_ctx* c, const char*, const uint32_t* host, size_t n, zkh_buf** out) {
@@ -322,10 +325,7 @@ extern "C" const char* zkh_read(zkh_ctx* c, const zkh_buf* b, uint32_t* host, si
     bind_thread(c);
     ZKH_REQUIRE(n <= b->len && off <= b->len - n, "read [%zu, +%zu) out of range (size %zu)", off, n, b->len);   // no wrap-around
     if (n) ZKH_HIP(hipMemcpyAsync(host, b->ptr() + off, n * 4, hipMemcpyDeviceToHost, c->stream));
-    if (c->fail_armed) ZKH_HIP(hipMemcpyAsync(c->h_fail, c->d_fail, 8, hipMemcpyDeviceToHost, c->stream));
-    ZKH_HIP(hipStreamSynchronize(c->stream));
-    c->stage_used = 0;
-    return check_device_fail(c);
+    return sync_checked(c);
 }
 extern "C" const char* zkh_write(zkh_ctx* c, zkh_buf* b, const uint32_t* host, size_t off, size_t n) {
     bind_thread(c);

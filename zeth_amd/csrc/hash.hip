@@ -59,68 +59,6 @@ __global__ __launch_bounds__(256, 4) void k_hash_rows(uint32_t* __restrict__ out
     o[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
-// (opt-in, see zkh_merkle_build) MerkleTreeProver::new for a wide tree: hash_rows AND the first hash_fold layer in one pass.  A lane owns the ADJACENT rows 2p and
-// 2p + 1 (column loads are 8 bytes per lane: a wave still reads 512 contiguous bytes per column) and runs their two sponges block
-// by block in alternation, then — with both digests in registers — their parent's permutation: the largest layer of every tree
-// (rows / 2 permutations) runs in the steady state of this kernel (constants hot, no launch, no 64-byte re-read of the two digests).
-// One call site of the permutation (the turns of a pair are a runtime loop), so the code stays the size of k_hash_rows.
-__global__ __launch_bounds__(256, 4) void k_hash_rows_pair(uint32_t* __restrict__ nodes, const uint32_t* __restrict__ matrix, size_t rows,
-                                                        uint32_t cols, const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
-    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // parent index = pair of rows
-    if (p >= rows / 2) return;
-    // mine / other: the capacity (after a row's last block: the digest) of the row whose turn it is / of the other row.  They trade
-    // places after every turn — plain register moves; indexing two arrays by the turn's parity would put them in scratch.
-    uint32_t s[CELLS], hold[RATE], mine[OUT], other[OUT];
-#pragma unroll
-    for (int i = 0; i < OUT; i++) mine[i] = other[i] = 0;
-    const uint2* src = (const uint2*)(matrix + 2 * p);
-    const size_t rows2 = rows / 2;                                            // column stride in uint2 units
-    const uint32_t blocks = cols ? (cols + RATE - 1) / RATE : 1;
-    // turn t: block t / 2 of row 2p (t even) or 2p + 1 (t odd); the last turn hashes the two digests into the parent
-#pragma unroll 1
-    for (uint32_t t = 0; t <= 2 * blocks; t++) {
-        const bool parent = t == 2 * blocks, odd = t & 1, last = (t >> 1) + 1 == blocks;
-        if (parent) {                                                         // mine = digest of row 2p, other = digest of row 2p + 1
-#pragma unroll
-            for (int i = 0; i < OUT; i++) { s[i] = mine[i]; s[OUT + i] = other[i]; s[RATE + i] = 0; }
-        } else {
-            if (!odd) {
-                const uint32_t b = t >> 1, left = cols - b * RATE;            // columns of this block (>= 16: a full one; cols == 0: none)
-                const uint2* bsrc = src + (size_t)b * RATE * rows2;
-#pragma unroll
-                for (int i = 0; i < RATE; i++) {
-                    uint2 v = make_uint2(0u, 0u);
-                    if (cols && (uint32_t)i < left) v = bsrc[(size_t)i * rows2];
-                    s[i] = v.x; hold[i] = v.y;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < RATE; i++) s[i] = hold[i];
-            }
-#pragma unroll
-            for (int i = 0; i < OUT; i++) s[RATE + i] = mine[i];
-        }
-        poseidon2_mix_raw(s, rc, diag);
-        // what the next turn of this row keeps: the capacity, or — after the row's last block, and for the parent — the digest
-        const bool digest = last || parent;
-#pragma unroll
-        for (int i = 0; i < OUT; i++) {
-            const uint32_t keep = p2_finish(digest ? s[i] : s[RATE + i], diag);
-            mine[i] = other[i]; other[i] = keep;                              // trade places: the other row is next
-        }
-        if (last && odd) {                                                    // both leaf digests are final: 64 contiguous bytes per lane
-            uint4* o = (uint4*)(nodes + (rows + 2 * p) * 8);                  // (after the swap: mine = row 2p's, other = row 2p + 1's)
-            o[0] = make_uint4(mine[0], mine[1], mine[2], mine[3]);
-            o[1] = make_uint4(mine[4], mine[5], mine[6], mine[7]);
-            o[2] = make_uint4(other[0], other[1], other[2], other[3]);
-            o[3] = make_uint4(other[4], other[5], other[6], other[7]);
-        }
-    }
-    uint4* o = (uint4*)(nodes + (rows2 + p) * 8);                             // the parent's digest was the last thing kept
-    o[0] = make_uint4(other[0], other[1], other[2], other[3]);
-    o[1] = make_uint4(other[4], other[5], other[6], other[7]);
-}
-
 // Hal::hash_fold — one lane per parent: io[out+i] = H(io[in+2i] || io[in+2i+1])
 __global__ __launch_bounds__(256, 4) void k_hash_fold(uint32_t* __restrict__ io, size_t input_size, size_t output_size,
                                                    const uint32_t* __restrict__ rc, const uint32_t* __restrict__ diag) {
@@ -251,25 +189,11 @@ extern "C" const char* zkh_merkle_fold_all(zkh_ctx* c, zkh_buf* nodes, size_t ro
     ZKH_REQUIRE(nodes->len == rows * 16 && rows && (rows & (rows - 1)) == 0, "merkle_fold_all: nodes must hold 2*rows digests");
     return merkle_fold_from(c, nodes, rows);
 }
-// MerkleTreeProver::new: leaves = hash_rows(matrix), then every layer above.  ZKH_MERKLE_FUSED=1 gives wide trees the fused
-// first pass (k_hash_rows_pair: leaves + their parents) — built for the round-3 verdict's item 6, measured, and NOT the default:
-// the 2^21-parent layers of a po2-20 seal cost 1.73 ms inside the fused kernel against 1.60 ms as k_hash_fold launches
-// (profiles/r04_merkle_fused_ab.txt: 17.81 vs 17.68 ms of Poseidon2 per seal, 42.3 vs 42.4 segments/s).  Per permutation
-// k_hash_fold (190 ps) was never slower than k_hash_rows (197 ps); the pair kernel's 127 VGPRs cost it one wave per SIMD.
+// MerkleTreeProver::new: leaves = hash_rows(matrix), then every layer above.  (A fused leaves + first-layer pass was built in
+// round 4, measured slower — 17.81 vs 17.68 ms of Poseidon2 per seal, profiles/r04_merkle_fused_ab.txt — and removed in round 6.)
 extern "C" const char* zkh_merkle_build(zkh_ctx* c, zkh_buf* nodes, const zkh_buf* matrix, size_t rows) {
     ZKH_REQUIRE(nodes && matrix && nodes->len == rows * 16 && rows && (rows & (rows - 1)) == 0, "merkle_build: nodes must hold 2*rows digests");
     ZKH_REQUIRE(matrix->len % rows == 0, "merkle_build: matrix size %zu not a multiple of rows %zu", matrix->len, rows);
-    static const bool fused = getenv("ZKH_MERKLE_FUSED") != nullptr;
-    if (rows / 2 > ((size_t)1 << 15) && fused) {
-        const size_t cols = matrix->len / rows;
-        {
-            // §8d bytes, no credit for the fusion: hash_rows (matrix in, leaves out) + the first hash_fold layer (leaves in, parents out)
-            ProfScope prof(c, "hash_rows", 4.0 * matrix->len + 32.0 * rows + 96.0 * (rows / 2));
-            k_hash_rows_pair<<<(unsigned)((rows / 2 + 255) / 256), 256, 0, c->stream>>>(nodes->ptr(), matrix->ptr(), rows, (uint32_t)cols, c->tab.rc, c->tab.diag);
-            ZKH_TRY(last_launch_error("hash_rows_pair"));
-        }
-        return merkle_fold_from(c, nodes, rows / 2);
-    }
     zkh_buf* leaves = nullptr;
     ZKH_TRY(zkh_slice(nodes, rows * 8, rows * 8, &leaves));
     const char* err = zkh_hash_rows(c, leaves, matrix);

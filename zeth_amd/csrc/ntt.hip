@@ -41,9 +41,6 @@ struct PassParams {
     uint32_t lazy;           // forward register-radix pair (low12 + high<8|10>): see radix_layers<..., LAZY>
     uint32_t lazy_comp;      // R^(number of lazy layers) as a Montgomery word: folded into the four-step twiddle
     uint32_t shift16[16];    // inverse last pass: n^-1 * 3^(bitrev4(k) << (log_n - 4)), k < 16 (Montgomery; 0 = unused)
-    const int32_t* tw_matrix; // lazy forward strided pass: the whole four-step twiddle matrix (k_fwd_twiddle_matrix), or NULL
-    uint32_t col_fast;       // 1-D grid, columns fastest within an XCD: the twiddle tile of an XCD stays hot in its L2
-    uint32_t ncols;
 };
 
 // global index of tile element (m, t):  a*2^(L+R) + m*2^L + l0 + t
@@ -427,22 +424,13 @@ __global__ __launch_bounds__(256) void k_ntt_low12(PassParams p) {
 // Strided pass, index bits [L, L+RH) with RH in {8, 10}: tile = 2^RH rows x 16 consecutive words, one lane per
 // (row group, column), 16 rows per lane.  Inverse: first pass (reads the witness, DIF, post-twiddle).  Forward:
 // last pass (pre-twiddle, DIT, in place).
-template <int RH, bool INVERSE, bool LAZY = false, bool MATRIX = false, int LT = 4>
-__global__ __launch_bounds__(1 << (RH - 4 + LT)) void k_ntt_high(PassParams p) {
-    // LT = log2 of the tile width in words: 4 (64-byte runs, 2^RH lanes) or 3 (32-byte runs, half the lanes and half the LDS per
-    // workgroup: twice as many independent workgroups per CU for the same waves)
+template <int RH, bool INVERSE, bool LAZY = false>
+__global__ __launch_bounds__(1 << RH) void k_ntt_high(PassParams p) {
+    constexpr int LT = 4;                 // tile width 2^LT words: 64-byte runs, 2^RH lanes
     constexpr uint32_t TW = 1u << LT;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];     // [2^RH][16]
     const uint32_t tid = threadIdx.x, t = tid & (TW - 1), g = tid >> LT;
-    uint32_t tile_id, col;
-    if (p.col_fast) {        // block b runs on XCD b % 8: that XCD owns a contiguous slice of tiles and walks the COLUMNS of a tile first
-        const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, tl = slot / p.ncols;
-        col = slot - tl * p.ncols;
-        tile_id = xcd * (p.tiles_per_col >> 3) + tl;
-    } else {
-        tile_id = xcd_remap(blockIdx.x, p.tiles_per_col);
-        col = blockIdx.y;
-    }
+    const uint32_t tile_id = xcd_remap(blockIdx.x, p.tiles_per_col), col = blockIdx.y;
     const uint32_t lt_bits = p.L - LT;
     const uint32_t a = tile_id >> lt_bits, lt = tile_id & ((1u << lt_bits) - 1);
     const size_t base = ((size_t)a << (p.L + RH)) + ((size_t)lt << LT);      // wave-uniform: first word of the tile
@@ -453,9 +441,7 @@ __global__ __launch_bounds__(1 << (RH - 4 + LT)) void k_ntt_high(PassParams p) {
     // (row < 2^RH, L <= 14: the offset stays below 2^RH+L+2 <= 2^26 bytes.)
     const char* in = (const char*)(p.in + (size_t)col * p.in_col_stride + base);
     char* out = (char*)(p.out + (size_t)col * p.out_col_stride + base);
-    const char* twm = (const char*)(p.tw_matrix + base);
     const uint32_t tb = t * 4u;
-#define TILE_TW(row) (*(const int32_t*)(twm + ((((uint32_t)(row)) << (p.L + 2)) + tb)))
 #define TILE_IN(row) (*(const uint32_t*)(in + ((((uint32_t)(row)) << (p.L + 2)) + tb)))
 #define TILE_OUT(row) (*(uint32_t*)(out + ((((uint32_t)(row)) << (p.L + 2)) + tb)))
     const uint32_t* __restrict__ ltab = p.layer_tw;
@@ -471,9 +457,7 @@ __global__ __launch_bounds__(1 << (RH - 4 + LT)) void k_ntt_high(PassParams p) {
     // Four-step twiddles w^(lcol * bitrev(m)) of this lane's 16 rows, factored so that only 3 (RH = 10) or 2 (RH = 8)
     // table gathers are needed instead of 16: bitrev splits over the bit fields of m.
     uint32_t tw[16];
-    constexpr bool use_matrix = LAZY && !INVERSE && MATRIX;
-    if (use_matrix) {
-    } else if (RH == 10) {         // m = g*16 + i*4 + k: bitrev10(m) = br2(k)*256 + br2(i)*64 + br6(g);  slot = 4*i + k
+    if (RH == 10) {         // m = g*16 + i*4 + k: bitrev10(m) = br2(k)*256 + br2(i)*64 + br6(g);  slot = 4*i + k
         uint32_t w0 = root(lcol * (__brev(g) >> 26));
         if (LAZY) w0 = tmul(w0, p.lazy_comp);                // cancels the R^-layers of both lazy passes
         const uint32_t u1 = root(lcol * 64u), v1 = root(lcol * 256u);
@@ -529,26 +513,12 @@ __global__ __launch_bounds__(1 << (RH - 4 + LT)) void k_ntt_high(PassParams p) {
             for (int i = 0; i < 4; i++) {
                 uint32_t u[4];
                 const uint32_t m0 = (g * 4 + i) * 4;
-                if (LAZY && use_matrix) {
-                    // twiddle products folded into the unit-twiddle first layer: (x0 t0 +- x1 t1) / R, |T| <= P^2
-                    int32_t x[4], tq[4];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) { x[k] = (int32_t)TILE_IN(m0 + k); tq[k] = TILE_TW(m0 + k); }
-#pragma unroll
-                    for (int k = 0; k < 4; k += 2) {
-                        const int64_t t0 = mul_i64(x[k], tq[k]);
-                        u[k] = (uint32_t)smont_reduce(mad_i64(x[k + 1], tq[k + 1], t0));
-                        u[k + 1] = (uint32_t)smont_reduce(mad_i64(x[k + 1], -tq[k + 1], t0));
-                    }
-                    radix_layers<2, false, true, 1, LAZY>(u, ltab, 0, 1);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint32_t x = TILE_IN(m0 + k);
-                        u[k] = LAZY ? (uint32_t)smont((int32_t)x, (int32_t)tw[4 * i + k]) : mul_mod(x, tw[4 * i + k]);
-                    }
-                    radix_layers<2, false, true, 1, LAZY>(u, ltab, 0, 0);
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t x = TILE_IN(m0 + k);
+                    u[k] = LAZY ? (uint32_t)smont((int32_t)x, (int32_t)tw[4 * i + k]) : mul_mod(x, tw[4 * i + k]);
                 }
+                radix_layers<2, false, true, 1, LAZY>(u, ltab, 0, 0);
 #pragma unroll
                 for (int k = 0; k < 4; k++) lds[(m0 + k) * TW + t] = u[k];
             }
@@ -582,25 +552,6 @@ __global__ __launch_bounds__(1 << (RH - 4 + LT)) void k_ntt_high(PassParams p) {
                 if (p.scale) x = mul_mod(x, p.scale);
                 TILE_OUT(g * 16 + k) = x;
             }
-        } else if (LAZY && use_matrix) {
-            int32_t x[16], tq[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) { x[k] = (int32_t)TILE_IN(g * 16 + k); tq[k] = TILE_TW(g * 16 + k); }
-#pragma unroll
-            for (int k = 0; k < 16; k += 2) {
-                const int64_t t0 = mul_i64(x[k], tq[k]);
-                v[k] = (uint32_t)smont_reduce(mad_i64(x[k + 1], tq[k + 1], t0));
-                v[k + 1] = (uint32_t)smont_reduce(mad_i64(x[k + 1], -tq[k + 1], t0));
-            }
-            radix_layers<4, false, true, 1, LAZY>(v, ltab, 0, 1);
-#pragma unroll
-            for (int k = 0; k < 16; k++) lds[(g * 16 + k) * TW + t] = v[k];
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = lds[(k * 16 + g) * TW + t];
-            radix_layers<4, false, false, 5, LAZY>(v, ltab, g, 0);
-#pragma unroll
-            for (int k = 0; k < 16; k++) TILE_OUT(k * 16 + g) = canon((int32_t)v[k]);
         } else {
 #pragma unroll
             for (int k = 0; k < 16; k++) {
@@ -621,22 +572,6 @@ __global__ __launch_bounds__(1 << (RH - 4 + LT)) void k_ntt_high(PassParams p) {
 }
 #undef TILE_IN
 #undef TILE_OUT
-#undef TILE_TW
-
-// The four-step twiddle matrix of a lazy forward transform, laid out exactly like one column of the data the strided pass
-// reads (row m, low index l at m * 2^L + l):  center( w_{L+RH}^(l * bitrev_RH(m)) * R^K ), K = lazy layers run by both
-// passes, as a PLAIN signed residue in [-(P-1)/2, (P-1)/2].  It is the same for every column (208 of them in the data
-// group) and every transform of this shape, so the strided pass reads it through L2 instead of rebuilding 16 entries per
-// lane from three table gathers and ~23 modular products (round 2: ~13 % of that kernel's VALU instructions); and
-// because the entries are centred, in0*t0 +- in1*t1 fits the signed reduction's domain (|T| <= P^2 < P 2^31), which lets
-// the twiddle products be folded into the first (unit-twiddle) butterfly layer.
-__global__ void k_fwd_twiddle_matrix(int32_t* out, uint32_t L, uint32_t RH, uint32_t scale_word, const uint32_t* tw_lo, const uint32_t* tw_hi) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t m = i >> L, l = i & ((1u << L) - 1);
-    const uint32_t ex = (l * (__brev(m) >> (32 - RH))) << (MAX_LOG_N - (L + RH));
-    const uint32_t w = mul_mod(tw_lo[ex & (TW_SIZE - 1)], tw_hi[ex >> TW_BITS]);       // Montgomery word of the root
-    out[i] = center(mul_mod(w, scale_word));                                          // w * R^K, plain, centred
-}
 
 struct Pass { uint32_t L, R; };
 // Cut log_n index bits into HBM passes of <= 12 bits.  The lowest pass works on contiguous runs (cheapest), the
@@ -672,43 +607,11 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
     const size_t npass = passes.size();
     // forward transforms whose two passes are both register-radix kernels (2^20 and 2^22: what po2-18/20 seals
     // expand into) run the lazy signed butterflies; the constant R^(layers run) rides on the four-step twiddle
-    static const bool no_lazy = getenv("ZKH_NTT_NO_LAZY") != nullptr;     // A/B switch for debugging
-    // (measured twice: letting the lazy pair also run under a third pass - 2^21 / 2^23 / 2^24 - is bit-exact and buys nothing: under the
-    // generic top pass po2 21 / 22 seals 18.4 / 9.58 vs 18.7 / 9.59 segments/s; under k_ntt_top 20.35 / 10.30 vs 20.45 / 10.20, round 5.
-    // ZKH_NTT_LAZY3=1 re-runs the A/B)
-    static const bool lazy3 = getenv("ZKH_NTT_LAZY3") != nullptr;         // A/B switch: the lazy pair under a third (top) pass
-    const bool lazy = !no_lazy && !inverse && (npass == 2 || (lazy3 && npass == 3)) && passes[0].R == 12 && (passes[1].R == 8 || passes[1].R == 10) && expand_bits <= 4;
+    // (letting the lazy pair also run under a third pass - 2^21 / 2^23 / 2^24 - is bit-exact and was measured flat twice; the
+    // per-shape twiddle matrix, 32-byte tiles and the column-fast grid were measured slower: profiles/README.md, r03_ntt_matrix.txt,
+    // r03_ntt_ab*.jsonl.  None of those variants is in the library any more.)
+    const bool lazy = !inverse && npass == 2 && passes[0].R == 12 && (passes[1].R == 8 || passes[1].R == 10) && expand_bits <= 4;
     const uint32_t lazy_comp = lazy ? fp_pow(Fp::raw(R2), passes[0].R - expand_bits + passes[1].R).v : 0;
-    // the strided pass of a lazy transform reads its four-step twiddles from a per-shape matrix (built once per context)
-    // MEASURED AND REJECTED as the default (profiles/r03_ntt_matrix.txt): the matrix removes 15 % of the pass's VALU
-    // instructions (934 -> 796 per wave) but doubles its loads, and the pass is as much memory- as VALU-limited (2.16 -> 2.31 ms
-    // for 208 x 2^22; walking the columns of a tile first so that the matrix tile stays in L2 makes every concurrent block
-    // hit the same in-column offsets: 3.11 ms).  Kept behind ZKH_NTT_MATRIX=1 / ZKH_NTT_COLFAST=1 so the A/B can be re-run.
-    // The rejected variants are compiled only into experiment builds (ZKH_BUILD_FLAGS=-DZKH_NTT_EXPERIMENTS): the shipped library
-    // carries neither their template instantiations nor their switches; profiles/r03_ntt_matrix.txt and r03_ntt_ab*.jsonl are the record.
-#ifdef ZKH_NTT_EXPERIMENTS
-    static const bool use_matrix = getenv("ZKH_NTT_MATRIX") != nullptr;
-    static const bool no_colfast = getenv("ZKH_NTT_COLFAST") == nullptr;
-#else
-    constexpr bool use_matrix = false, no_colfast = true;
-#endif
-    const int32_t* fwd_matrix = nullptr;
-    if (lazy && use_matrix && (n >> (passes[1].R + 4)) % 8 == 0) {
-        const uint32_t key = (log_n << 8) | expand_bits;
-        auto it = c->ntt_fwd_matrix.find(key);
-        if (it == c->ntt_fwd_matrix.end()) {
-            bind_thread(c);
-            uint32_t* m = nullptr;
-            ZKH_HIP(hipMalloc((void**)&m, (size_t)4 << log_n));
-            // entry = w * R^K as a plain residue, K = 12 - expand_bits + R lazy layers: Montgomery word of the root times the word R^K
-            const uint32_t scale_word = fp_pow(Fp::raw(R2), passes[0].R - expand_bits + passes[1].R - 1).v;
-            k_fwd_twiddle_matrix<<<(unsigned)(n / 256), 256, 0, c->stream>>>((int32_t*)m, passes[1].L, passes[1].R, scale_word,
-                                                                             c->tab.tw_fwd_lo, c->tab.tw_fwd_hi);
-            if (const char* e = last_launch_error("fwd_twiddle_matrix")) { (void)hipFree(m); return e; }
-            it = c->ntt_fwd_matrix.emplace(key, m).first;
-        }
-        fwd_matrix = (const int32_t*)it->second;
-    }
     for (size_t pi = 0; pi < npass; pi++) {
         // inverse: high bits first; forward: low bits first
         const Pass ps = inverse ? passes[npass - 1 - pi] : passes[pi];
@@ -725,13 +628,6 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
         // the generic kernel on a strided pass: 4096-element tiles, i.e. runs of 2^(12 - R) consecutive words (a 1..3-bit top pass
         // at 2^21 / 2^23 / 2^24 then streams 2..8 KiB runs; with 16-word runs it moved 64 elements per workgroup: 0.6 TB/s)
         if (ps.L != 0 && !reg_high && ps.R < 12) p.log_t = std::max<uint32_t>(p.log_t, std::min<uint32_t>(ps.L, 12 - ps.R));
-#ifdef ZKH_NTT_EXPERIMENTS
-        static const bool narrow = getenv("ZKH_NTT_NARROW") != nullptr;        // A/B: 32-byte runs, 512-lane workgroups (profiles/r03_ntt_matrix.txt)
-#else
-        constexpr bool narrow = false;
-#endif
-        const bool narrow_here = narrow && lazy && reg_high && ps.R == 10 && !fwd_matrix;
-        if (narrow_here) p.log_t = 3;
         // keep the tile <= 64 KiB
         while (p.R + p.log_t > 14 && p.log_t > 0) p.log_t--;
         p.expand_bits = (!inverse && first) ? expand_bits : 0;
@@ -753,24 +649,15 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
         p.tiles_per_col = (uint32_t)(n >> (p.R + p.log_t));
         const size_t lds = ((size_t)4 << (p.R + p.log_t));
         dim3 grid(p.tiles_per_col, (unsigned)count);
-        p.ncols = (uint32_t)count;
-        if (lazy && reg_high && fwd_matrix) {
-            p.tw_matrix = fwd_matrix;
-            if (!no_colfast && (size_t)p.tiles_per_col * count < ((size_t)1 << 31)) {
-                p.col_fast = 1;
-                grid = dim3((unsigned)(p.tiles_per_col * count), 1);
-            }
-        }
         // algorithmic bytes in SURVEY.md §8d's sense (operands read once + written once, whatever the number of HBM passes):
         // charged to the first pass, the other passes of the same transform add time only
         const double alg_bytes = pi == 0 ? 4.0 * count * (double)(((size_t)1 << log_n) >> expand_bits) + 4.0 * count * (double)n : 0.0;
         const bool scale_here = p.scale != 0;
         // profiler record = "<Hal op>:<kernel>", so both the op totals and the per-kernel (per-pass) times can be read off
         const bool k_low = ps.L == 0 && ps.R == 12 && p.expand_bits <= 4;
-        const bool k_h10 = !k_low && ps.L >= 4 && (p.log_t == 4 || narrow_here) && ps.R == 10 && !(scale_here && p.zk_shift);
+        const bool k_h10 = !k_low && ps.L >= 4 && p.log_t == 4 && ps.R == 10 && !(scale_here && p.zk_shift);
         const bool k_h8 = !k_low && !k_h10 && ps.L >= 4 && p.log_t == 4 && ps.R == 8 && !(scale_here && p.zk_shift);
-        static const bool no_top = getenv("ZKH_NTT_NO_TOP") != nullptr;      // A/B switch: the generic LDS kernel on the top pass
-        const bool k_top = !no_top && !k_low && !k_h10 && !k_h8 && ps.L >= 12 && ps.L + ps.R == log_n && ps.R >= 1 && ps.R <= 4 && p.twiddle &&
+        const bool k_top = !k_low && !k_h10 && !k_h8 && ps.L >= 12 && ps.L + ps.R == log_n && ps.R >= 1 && ps.R <= 4 && p.twiddle &&
                            p.expand_bits == 0 && p.first_layer == 1 && !scale_here && !p.zk_shift;
         const std::string pname = std::string(name) + (k_low ? ":k_ntt_low12" : k_h10 ? ":k_ntt_high10" : k_h8 ? ":k_ntt_high8" : k_top ? ":k_ntt_top" : ":k_ntt_pass");
         ProfScope prof(c, pname.c_str(), alg_bytes);
@@ -778,19 +665,12 @@ const char* run_transform(zkh_ctx* c, bool inverse, const uint32_t* in, size_t i
             if (inverse) k_ntt_low12<true><<<grid, 256, 0, c->stream>>>(p);
             else if (lazy) k_ntt_low12<false, true><<<grid, 256, 0, c->stream>>>(p);
             else k_ntt_low12<false><<<grid, 256, 0, c->stream>>>(p);
-        } else if (ps.L >= 4 && (p.log_t == 4 || narrow_here) && ps.R == 10 && !(scale_here && p.zk_shift)) {
+        } else if (ps.L >= 4 && p.log_t == 4 && ps.R == 10 && !(scale_here && p.zk_shift)) {
             if (inverse) k_ntt_high<10, true><<<grid, 1024, lds, c->stream>>>(p);
-#ifdef ZKH_NTT_EXPERIMENTS
-            else if (lazy && p.tw_matrix) k_ntt_high<10, false, true, true><<<grid, 1024, lds, c->stream>>>(p);
-            else if (narrow_here) k_ntt_high<10, false, true, false, 3><<<grid, 512, lds, c->stream>>>(p);
-#endif
             else if (lazy) k_ntt_high<10, false, true><<<grid, 1024, lds, c->stream>>>(p);
             else k_ntt_high<10, false><<<grid, 1024, lds, c->stream>>>(p);
         } else if (ps.L >= 4 && p.log_t == 4 && ps.R == 8 && !(scale_here && p.zk_shift)) {
             if (inverse) k_ntt_high<8, true><<<grid, 256, lds, c->stream>>>(p);
-#ifdef ZKH_NTT_EXPERIMENTS
-            else if (lazy && p.tw_matrix) k_ntt_high<8, false, true, true><<<grid, 256, lds, c->stream>>>(p);
-#endif
             else if (lazy) k_ntt_high<8, false, true><<<grid, 256, lds, c->stream>>>(p);
             else k_ntt_high<8, false><<<grid, 256, lds, c->stream>>>(p);
         } else if (k_top) {
@@ -821,9 +701,6 @@ const char* zkh::ntt_device_init(zkh_ctx* c) {
     ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high<10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high<10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high<10, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-#ifdef ZKH_NTT_EXPERIMENTS
-    ZKH_HIP(hipFuncSetAttribute((const void*)k_ntt_high<10, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-#endif
     return nullptr;
 }
 

@@ -387,7 +387,7 @@ struct zkh_rec_program {
 };
 
 // the launches of one witness schedule on the context's stream (directly, or while the stream is being captured into a graph)
-static void rec_enqueue_schedule(const zkh_rec_program* p, uint4* v, const uint32_t* din, uint32_t* fail, bool per_level);
+static void rec_enqueue_schedule(const zkh_rec_program* p, uint4* v, const uint32_t* din, uint32_t* fail);
 
 extern "C" void zkh_rec_program_destroy(zkh_rec_program* p) {
     if (!p) return;
@@ -405,20 +405,16 @@ static const char* rec_check_shape(const zkh_circuit* c) {
     return nullptr;
 }
 
-static void rec_enqueue_schedule(const zkh_rec_program* p, uint4* v, const uint32_t* din, uint32_t* fail, bool per_level) {
+static void rec_enqueue_schedule(const zkh_rec_program* p, uint4* v, const uint32_t* din, uint32_t* fail) {
     zkh_ctx* c = p->ctx;
     for (const auto& st : p->plan) {
-        if (st.run && !per_level) {
+        if (st.run) {
             k_rec_run<<<1, 1024, 0, c->stream>>>(p->d_ops->ptr(), (const uint4*)p->d_lv->ptr(), st.l0, st.l1, v, p->d_consts->ptr(), din, fail,
                                                  c->tab.rc, c->tab.diag);
             continue;
         }
         for (uint32_t l = st.l0; l < st.l1; l++) {
             const uint32_t lo = p->lv[4 * l], a = p->lv[4 * l + 1], b = p->lv[4 * l + 2], hi = p->lv[4 * l + 3];
-            if (per_level) {
-                if (hi > lo) k_rec_level<<<(hi - lo + 63) / 64, 64, 0, c->stream>>>(p->d_ops->ptr(), lo, hi, v, p->d_consts->ptr(), din, fail, c->tab.rc, c->tab.diag);
-                continue;
-            }
             if (a > lo) k_rec_level<<<(a - lo + 63) / 64, 64, 0, c->stream>>>(p->d_ops->ptr(), lo, a, v, p->d_consts->ptr(), din, fail, c->tab.rc, c->tab.diag);
             if (hi > b) k_rec_level<<<(hi - b + 63) / 64, 64, 0, c->stream>>>(p->d_ops->ptr(), b, hi, v, p->d_consts->ptr(), din, fail, c->tab.rc, c->tab.diag);
             if (b > a) k_rec_p2_wide<<<(8 * (b - a) + 255) / 256, 256, 0, c->stream>>>(p->d_ops->ptr(), a, b, v, c->tab.rc, c->tab.diag);
@@ -545,7 +541,7 @@ extern "C" const char* zkh_rec_program_load(zkh_ctx* ctx, const zkh_circuit* cir
         ZKH_HIP(hipStreamSynchronize(ctx->stream));
         hipGraph_t g = nullptr;
         if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            rec_enqueue_schedule(p.get(), (uint4*)p->d_val->ptr(), p->d_in->ptr(), p->d_fail->ptr(), false);
+            rec_enqueue_schedule(p.get(), (uint4*)p->d_val->ptr(), p->d_in->ptr(), p->d_fail->ptr());
             if (hipStreamEndCapture(ctx->stream, &g) == hipSuccess && g) {
                 if (hipGraphInstantiate(&p->graph, g, nullptr, nullptr, 0) != hipSuccess) p->graph = nullptr;
                 (void)hipGraphDestroy(g);
@@ -598,12 +594,11 @@ extern "C" const char* zkh_rec_witgen(const zkh_rec_program* p, const uint32_t* 
     ZKH_TRY(zkh_write(c, p->d_fail, &none, 0, 1));
     {
         ProfScope prof(c, "rec_exec", 16.0 * p->n_vars);
-        static const bool per_level = getenv("ZKH_REC_PER_LEVEL") != nullptr;       // A/B: one launch per level, one lane per op
-        if (p->graph && !per_level) {
+        if (p->graph) {
             const hipError_t e = hipGraphLaunch(p->graph, c->stream);
             if (e != hipSuccess) return make_err("rec_witgen: hipGraphLaunch: %s", hipGetErrorString(e));
         } else {
-            rec_enqueue_schedule(p, (uint4*)p->d_val->ptr(), p->d_in->ptr(), p->d_fail->ptr(), per_level);
+            rec_enqueue_schedule(p, (uint4*)p->d_val->ptr(), p->d_in->ptr(), p->d_fail->ptr());
         }
     }
     ZKH_TRY(last_launch_error("rec_exec"));

@@ -886,7 +886,7 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
     auto producer = [&](size_t lane_idx) {
         LaneQ& q = laneq[lane_idx];
         const Lane& l = s->lanes[lane_idx];
-        if (!getenv("ZKH_SESSION_NO_AFFINITY")) { const char* e = zkh_bind_thread_to_device(l.device, 0, 1, nullptr, nullptr); if (e) zkh_free_error(e); }
+        { const char* e = zkh_bind_thread_to_device(l.device, 0, 1, nullptr, nullptr); if (e) zkh_free_error(e); }      // (ZKH_AFFINITY=off: a no-op)
         std::unique_lock<std::mutex> lk(m);
         for (;;) {
             cv.wait(lk, [&] { return errs.any() || !q.accepting || !sc.indices_left() || !q.free_slots.empty(); });
@@ -910,7 +910,7 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
     };
     auto worker = [&](Lane* l, bool can_seal) {
         const size_t lane_idx = can_seal ? (size_t)(l - s->lanes.data()) : sched::NONE;
-        if (!getenv("ZKH_SESSION_NO_AFFINITY")) { const char* e = zkh_bind_thread_to_device(l->device, 0, 1, nullptr, nullptr); if (e) zkh_free_error(e); }
+        { const char* e = zkh_bind_thread_to_device(l->device, 0, 1, nullptr, nullptr); if (e) zkh_free_error(e); }
         std::vector<uint32_t> in;
         double wit = 0, seal_t = 0, fold_t = 0;
         std::unique_lock<std::mutex> lk(m);

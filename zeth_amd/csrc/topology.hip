@@ -87,6 +87,40 @@ extern "C" const char* zkh_device_numa_node(int device, int* node, char pci_bus_
     return zkh_pci_numa_cpus("/sys", bdf, node, nullptr, 0, &n);
 }
 
+// What tells one GPU from another across processes: the PCI bus id, the device's UUID (16 bytes as 32 hex digits; the same for
+// every process whatever HIP_VISIBLE_DEVICES renumbering it runs under), its NUMA node and marketing name.  bench.py gathers these
+// from every rank so that an N-GPU line can prove it ran on N distinct devices.
+extern "C" const char* zkh_device_identity(int device, char pci_bus_id[32], char uuid_hex[40], int* numa_node, char name[64], int* visible_devices) {
+    int count = 0;
+    ZKH_HIP(hipGetDeviceCount(&count));
+    if (visible_devices) *visible_devices = count;
+    ZKH_REQUIRE(device >= 0 && device < count, "device_identity: device %d of %d visible", device, count);
+    char bdf[32] = {0};
+    ZKH_HIP(hipDeviceGetPCIBusId(bdf, sizeof bdf, device));
+    if (pci_bus_id) memcpy(pci_bus_id, bdf, 32);
+    if (uuid_hex) {
+        hipUUID u;
+        memset(&u, 0, sizeof u);
+        memset(uuid_hex, 0, 40);
+        if (hipDeviceGetUuid(&u, device) == hipSuccess)
+            for (int i = 0; i < 16; i++) snprintf(uuid_hex + 2 * i, 3, "%02x", (unsigned)(unsigned char)u.bytes[i]);
+        else (void)hipGetLastError();
+    }
+    if (name) {
+        hipDeviceProp_t prop;
+        memset(name, 0, 64);
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) snprintf(name, 64, "%s", prop.name);
+        else (void)hipGetLastError();
+    }
+    if (numa_node) {
+        *numa_node = -1;
+        size_t n = 0;
+        const char* e = zkh_pci_numa_cpus("/sys", bdf, numa_node, nullptr, 0, &n);
+        if (e) zkh_free_error(e);
+    }
+    return nullptr;
+}
+
 // Bind the CALLING thread to the cores of `device`'s NUMA node, sliced when several devices share the node: with `share` > 1
 // the thread gets slice `slot` of `share` equal slices of the node's CPU list (bench.py: the ranks of the GPUs on one socket
 // split its cores; share = 1: the whole node).  Memory policy of the thread becomes "prefer that node" (pinned witness blocks

@@ -201,6 +201,7 @@ ABI = {
     "zkh_parse_cpulist": (_err, [C.c_char_p, C.POINTER(_i), _sz, C.POINTER(_sz)]),
     "zkh_pci_numa_cpus": (_err, [C.c_char_p, C.c_char_p, C.POINTER(_i), C.POINTER(_i), _sz, C.POINTER(_sz)]),
     "zkh_device_numa_node": (_err, [_i, C.POINTER(_i), C.c_char_p]),
+    "zkh_device_identity": (_err, [_i, C.c_char_p, C.c_char_p, C.POINTER(_i), C.c_char_p, C.POINTER(_i)]),
     "zkh_bind_thread_to_device": (_err, [_i, _sz, _sz, C.POINTER(_i), C.POINTER(_sz)]),
     "zkh_prof_enable": (_err, [_vp, _i]),
     "zkh_prof_get": (_err, [_vp, C.POINTER(ProfRec), _sz, C.POINTER(_sz)]),
@@ -477,6 +478,17 @@ def device_numa_node(device: int):
     bdf = C.create_string_buffer(32)
     _check(_lib.zkh_device_numa_node(device, C.byref(node), bdf))
     return node.value, bdf.value.decode()
+
+
+def device_identity(device: int) -> dict:
+    """-> {"pci_bus_id", "uuid", "numa_node", "name", "visible_devices"} of a HIP device: what tells one GPU from another across
+    processes (bench.py gathers it from every rank)"""
+    load_library()
+    bdf, uuid, name = C.create_string_buffer(32), C.create_string_buffer(40), C.create_string_buffer(64)
+    node, count = _i(-1), _i(0)
+    _check(_lib.zkh_device_identity(device, bdf, uuid, C.byref(node), name, C.byref(count)))
+    return {"pci_bus_id": bdf.value.decode(), "uuid": uuid.value.decode(), "numa_node": node.value, "name": name.value.decode(),
+            "visible_devices": count.value}
 
 
 def bind_to_device(device: int, slot: int = 0, share: int = 1) -> dict:
