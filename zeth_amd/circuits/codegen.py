@@ -75,7 +75,7 @@ FACTOR_MIN = int(os.environ.get("ZKH_CODEGEN_FACTOR", "3"))
 DISTRIBUTE = int(os.environ.get("ZKH_CODEGEN_DISTRIBUTE", "0"))    # measured on the static opcode table and REJECTED as the default (profiles/r05_eval_check_static.txt)
 # compile flags of the generated translation units (build.py and jit.py use the same list)
 KERNEL_FLAGS = [f for f in os.environ.get("ZKH_CODEGEN_FLAGS", "").split() if f]
-GENERATOR_VERSION = 10
+GENERATOR_VERSION = 11
 
 
 def desc_hash64(desc: np.ndarray) -> int:
@@ -611,9 +611,24 @@ class _Emitter:
         self.epoch_backs: List[set] = []
         self.n_loads = 0
         self.n_arith = 0
+        # BOUNDS TRACE (round 6): the generator's own worst cases in exact Python integers, emitted as `// BOUND name <= N` comments
+        # next to the statements they describe — every lazy value (< 2P), every 64-bit sum of products before its reduction, the four
+        # running constraint sums of a level after every accumulation.  tools/check_bounds.py re-derives each from the emitted text
+        # alone (it shares no code with this file) and fails if the text allows more than is claimed here, or than a word holds.
+        self.sb: Dict[int, int] = {}        # depth -> worst case of s{d}_k
 
     def w(self, s: str) -> None:
         self.lines.append(s)
+
+    def claim(self, name: str, hi: int) -> None:
+        if not self.dry:
+            self.lines.append(f"    // BOUND {name} <= {hi}")
+
+    def hi_of(self, v: int) -> int:
+        """worst case of the word that holds value v: a constant is itself, a lazy value is below 2P, anything else canonical"""
+        if self.p.fp[v][0] == OP_CONST:
+            return mont(self.p.fp[v][1])
+        return 2 * P - 1 if v in self.p.lazy else P - 1
 
     # ---- offset epochs ----
     def new_epoch(self) -> None:
@@ -756,6 +771,7 @@ class _Emitter:
             if op == OP_MUL and not self.p.ext[b]:
                 if v in self.p.lazy:                   # every consumer multiplies the components by a canonical factor
                     self.w(f"    const Fp4 {name} = ext_mul_base_lazy({self.cache[a]}, {self.ref(b)});")
+                    self.claim(name, 2 * P - 1)
                 else:
                     self.w(f"    const Fp4 {name} = {self.cache[a]} * Fp::raw({self.ref(b)});")
             elif op in (OP_ADD, OP_SUB) and not self.p.ext[b]:
@@ -771,6 +787,7 @@ class _Emitter:
                 expr = {OP_ADD: f"{self.ref(a)} + {self.ref(b)}", OP_SUB: f"{self.ref(a)} - {self.ref(b)} + {P}u",
                         OP_MUL: f"mul_lazy({self.ref(a)}, {self.ref(b)})"}[op]
                 self.w(f"    const uint32_t {name} = {expr};")
+                self.claim(name, 2 * P - 1)
             else:
                 fn = {OP_ADD: "add_mod", OP_SUB: "sub_mod", OP_MUL: "mul_mod"}[op]
                 self.w(f"    const uint32_t {name} = {fn}({self.ref(a)}, {self.ref(b)});")
@@ -784,10 +801,13 @@ class _Emitter:
         name = f"v{v}" + (f"_{g}" if g else "")
         lz = self.p.lazy
         const_sum = 0                                  # constant plain terms fold into the accumulator's initial value
-        dyn: List[Tuple[float, str]] = []
+        dyn: List[Tuple[float, str, int]] = []      # (float weight the decisions use, expression, exact worst case of the term)
 
         def neg(x: int) -> str:
             return f"({2 * P if x in lz else P}u - {self.ref(x)})"
+
+        def nhi(x: int, sg: int) -> int:               # worst case of the factor as it is written: x, or (2P | P) - x
+            return self.hi_of(x) if sg > 0 else (2 * P if x in lz else P)
 
         for t in self.p.sop[v]:
             sg = t[0]
@@ -797,7 +817,7 @@ class _Emitter:
                     c = mont(self.p.fp[x][1])
                     const_sum += (c if sg > 0 else (P - c) % P) * R1
                 else:
-                    dyn.append((PLAIN * (2 if x in lz else 1), f"(uint64_t){self.ref(x) if sg > 0 else neg(x)} * {R1}u"))
+                    dyn.append((PLAIN * (2 if x in lz else 1), f"(uint64_t){self.ref(x) if sg > 0 else neg(x)} * {R1}u", nhi(x, sg) * R1))
             else:
                 a, b = t[2], t[3]
                 if self.p.fp[a][0] == OP_CONST:
@@ -805,26 +825,36 @@ class _Emitter:
                 wgt = PROD * (2 if (a in lz or b in lz) else 1)
                 if self.p.fp[b][0] == OP_CONST:
                     c = mont(self.p.fp[b][1])
-                    dyn.append((wgt, f"(uint64_t){self.ref(a)} * {c if sg > 0 else (P - c) % P}u"))
+                    dyn.append((wgt, f"(uint64_t){self.ref(a)} * {c if sg > 0 else (P - c) % P}u", self.hi_of(a) * (c if sg > 0 else (P - c) % P)))
                 else:
-                    dyn.append((wgt, f"(uint64_t){self.ref(a) if sg > 0 else neg(a)} * {self.ref(b)}"))
+                    dyn.append((wgt, f"(uint64_t){self.ref(a) if sg > 0 else neg(a)} * {self.ref(b)}", nhi(a, sg) * self.hi_of(b)))
         tmp = f"u{v}" + (f"_{g}" if g else "")
         const_sum %= P                                 # only the residue matters to the Montgomery step
         acc = float(const_sum)
+        exact = const_sum                               # the same sum in exact integers: the bounds trace
+
+        def folded(x: int) -> int:
+            return x if x < (1 << 32) else (x >> 32) * R1 + (1 << 32) - 1
         self.w(f"    uint64_t {tmp} = {const_sum}ull;")
-        for wgt, expr in dyn:
+        for wgt, expr, hi in dyn:
             if acc + wgt > LIMIT:                       # out of room: hi 2^32 + lo = hi R + lo (mod P), below 2^60 + 2^32
                 self.w(f"    {tmp} = fold_acc({tmp});")
                 acc = 4294967296.0 * R1 + 4294967296.0
+                exact = folded(exact)
             self.w(f"    {tmp} += {expr};")
             acc += wgt
+            exact += hi
         # below P 2^32 the plain reduction is enough (one correction instead of two); a lazy root skips the last correction
         wide = acc >= float(P) * 4294967296.0
         if wide and acc >= 2.0 * float(P) * 4294967296.0:
             self.w(f"    {tmp} = fold_acc({tmp});")
+            exact = folded(exact)
             wide = False
+        self.claim(tmp, exact)
         fn = ("mont_reduce_wide" if wide else "mont_reduce") + ("_lazy" if v in lz else "")
         self.w(f"    const uint32_t {name} = {fn}({tmp});")
+        if v in lz:
+            self.claim(name, 2 * P - 1)
         self.n_arith += 1
         self.cache[v] = name
 
@@ -843,6 +873,7 @@ class _Emitter:
         self.use_depth(d)
         self.w(f"    t{d}_0 = t{d}_1 = t{d}_2 = t{d}_3 = 0; s{d}_0 = s{d}_1 = s{d}_2 = s{d}_3 = 0;")
         self.pend[d], self.tzero[d], self.folded[d] = 0, True, False
+        self.sb[d] = 0
 
     def fold(self, d: int) -> None:
         """Make room in the 64-bit constraint sums without reducing them: s = hi 2^32 + lo = hi R + lo (mod P), which is
@@ -851,6 +882,8 @@ class _Emitter:
             self.w(f"    s{d}_{k} = fold_acc(s{d}_{k});")
         self.pend[d] = 0
         self.folded[d] = True
+        x = self.sb.get(d, 0)
+        self.sb[d] = x if x < (1 << 32) else (x >> 32) * R1 + (1 << 32) - 1
 
     def flush(self, d: int) -> None:
         """t{d} = everything accumulated at depth d so far, as canonical words (needed before an Fp4 contribution is
@@ -868,6 +901,7 @@ class _Emitter:
             else:
                 self.w(f"    t{d}_{k} = mont_reduce(s{d}_{k} + (uint64_t)t{d}_{k} * {R1}u); s{d}_{k} = 0;")
         self.pend[d], self.tzero[d], self.folded[d] = 0, False, False
+        self.sb[d] = 0
 
     def add_fp4(self, d: int, expr: str) -> None:
         """t{d} += Fp4 expression (non-lazy path: ConstExt-valued constraints and AndCond contributions)."""
@@ -888,6 +922,9 @@ class _Emitter:
             self.w(f"    ext_accumulate(s{d}_0, s{d}_1, s{d}_2, s{d}_3, pwp[{self.pw(e)}], {self.ext_ref(v)});")
             self.release()
             self.pend[d] = 4
+            self.sb[d] = self.sb.get(d, 0) + 4 * (P - 1) * (P - 1)      # at most three products + (-11) x one reduced word per component
+            for k in range(4):
+                self.claim(f"s{d}_{k}", self.sb[d])
             return
         # tot += mix^e * v: four 64-bit multiply-adds (scalar-loaded power words); the sums are folded (not reduced)
         # when four units of products are pending and reduced once where the total is needed
@@ -899,6 +936,8 @@ class _Emitter:
                f"s{d}_2 += (uint64_t)p_.z * {r}; s{d}_3 += (uint64_t)p_.w * {r}; }}")
         self.release()
         self.pend[d] = self.pend.get(d, 0) + wgt
+        self.sb[d] = self.sb.get(d, 0) + (P - 1) * self.hi_of(v)
+        self.claim(f"s{d}_0", self.sb[d])
 
     # ---- the mix tree ----
     def emit_chain(self, m: int, d: int) -> bool:
@@ -942,6 +981,8 @@ class _Emitter:
                        f"s{d}_2 += (uint64_t)t{d + 1}_2 * {r}; s{d}_3 += (uint64_t)t{d + 1}_3 * {r};")
                 self.release()
                 self.pend[d] = self.pend.get(d, 0) + wgt
+                self.sb[d] = self.sb.get(d, 0) + (P - 1) * self.hi_of(f)
+                self.claim(f"s{d}_0", self.sb[d])
             else:
                 _, cond, inner, e = it
                 first = self.leaf
@@ -985,6 +1026,7 @@ def emit_part(kernel: str, plan: Plan, lo: int, hi: int, standalone: bool, heade
     em.upcoming = dry.requests
     em.use_depth(0)
     em.pend[0], em.tzero[0] = 0, True
+    em.sb[0] = 0
     em.emit_chain(plan.c.ret, 0)
     em.flush(0)
     body = []

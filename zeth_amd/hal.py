@@ -616,8 +616,7 @@ class HipHal:
         _check(_lib.zkh_merkle_fold_all(self.ctx, nodes.h, rows))
 
     def merkle_build(self, nodes: Buffer, matrix: Buffer, rows: int) -> None:
-        """`MerkleTreeProver::new`: leaves = hash_rows(matrix) at nodes[rows..2 rows), then every layer above (wide trees hash two
-        adjacent rows and their parent per lane in one pass)."""
+        """`MerkleTreeProver::new`: leaves = hash_rows(matrix) at nodes[rows..2 rows), then every layer above."""
         _check(_lib.zkh_merkle_build(self.ctx, nodes.h, matrix.h, rows))
 
     def batch_evaluate_any(self, coeffs: Buffer, poly_count: int, which: Buffer, xs: Buffer, out: Buffer) -> None:
