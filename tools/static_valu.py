@@ -76,7 +76,7 @@ def main():
     desc = codegen.shipped()[name] if name in codegen.shipped() else None
     if desc is None:
         from zeth_amd.circuits import syn_heavy
-        desc = {"syn_heavy_small": syn_heavy.syn_heavy_small}[name]()
+        desc = {"syn_heavy_small": syn_heavy.syn_heavy_small, "syn_huge": syn_heavy.syn_huge}[name]()
     srcs = jit.eval_check_sources(desc)
     tmp = tempfile.mkdtemp(prefix="zkh_static_")
 
@@ -87,8 +87,11 @@ def main():
         out = os.path.join(tmp, kname + ".s")
         subprocess.run([jit.hipcc_path(), *jit.FLAGS, "--cuda-device-only", "-S", "-I", jit.CSRC, "-I", jit.INCLUDE, p, "-o", out], check=True, capture_output=True)
         return kname, count(open(out).read(), kname)
-    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+    import time
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 8, len(srcs))) as ex:
         rows = list(ex.map(one, srcs))
+    compile_s = time.perf_counter() - t0
     tot = collections.Counter()
     keys = ["valu", "mad64", "mul32", "add_sub", "min_select", "mov_logic", "other_valu", "global_load", "s_load", "s_nop", "s_waitcnt", "salu"]
     print(f"# {name}: {len(rows)} parts; knobs " + " ".join(sys.argv[2:]))
@@ -99,7 +102,8 @@ def main():
             tot[k] += c[k]
         tot["vgprs"] = max(tot["vgprs"], c["vgprs"])
     print(" total " + " ".join(f"{tot[k]:10d}" for k in keys) + f"   {tot['vgprs']:5d}")
-    print(json.dumps({"circuit": name, "parts": len(rows), **{k: tot[k] for k in keys}, "vgprs_max": tot["vgprs"]}))
+    print(json.dumps({"circuit": name, "parts": len(rows), **{k: tot[k] for k in keys}, "vgprs_max": tot["vgprs"],
+                      "scratch_max": max(c["scratch"] for _, c in rows), "hipcc_S_wall_s": round(compile_s, 1), "jobs": min(os.cpu_count() or 8, len(srcs))}))
 
 
 if __name__ == "__main__":

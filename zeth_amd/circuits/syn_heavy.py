@@ -43,9 +43,18 @@ def _rng(seed: int):
     return nxt
 
 
-def build_syn_heavy(wc: int = 16, wd: int = 208, wa: int = 32, per_triple: int = 44, seed: int = 0x48454156) -> np.ndarray:
+# SYN-HUGE (round 6): the same generator at a real circuit's SCALE — backs 0 .. 7 on every column, ~2 k taps, ~14 k constraints,
+# > 250 k PolyExtSteps — so that the code generator, hipcc and the code-object loader meet the size upstream's rv32im `eval_check`
+# has (tens of generated translation units) before the real tables are ever supplied.
+_FULL8 = (0, 1, 2, 3, 4, 5, 6, 7)
+DATA_BACKS_HUGE = [_FULL8, _FULL8, _FULL8, _FULL8, _FULL8, (0, 2, 3, 4, 5, 6, 7), _FULL8, _FULL8, (0, 1, 2, 3, 4, 5, 6), _FULL8, _FULL8, _FULL8]
+
+
+def build_syn_heavy(wc: int = 16, wd: int = 208, wa: int = 32, per_triple: int = 44, seed: int = 0x48454156, huge: bool = False) -> np.ndarray:
     """per_triple heavy constraints for each of the T = (wd-2)//3 multiplicative triples (68 x 44 ~ 3 k constraints)."""
     assert wc >= 5 and wd >= 8 and wa >= 4 and wa % 4 == 0
+    data_backs = DATA_BACKS_HUGE if huge else DATA_BACKS
+    code_backs, accum_backs = ((0, 1, 2, 3, 4, 5, 6, 7), (0, 1, 2, 3, 4, 5, 6, 7)) if huge else ((0, 1, 2, 3), (0, 1, 2))
     b = CircuitBuilder((wa, wc, wd), (4, wa))
     rnd = _rng(seed)
     code = lambda c, back=0: b.get(GROUP_CODE, c, back)
@@ -58,9 +67,11 @@ def build_syn_heavy(wc: int = 16, wd: int = 208, wa: int = 32, per_triple: int =
     s_col = wd - 1
 
     # every (column, back) pair the circuit is allowed to read; handed out round-robin so that each becomes a tap
-    tap_pool = [(GROUP_DATA, c, bk) for c in range(wd - 1) for bk in DATA_BACKS[c % len(DATA_BACKS)]]
-    tap_pool += [(GROUP_CODE, c, bk) for c in range(5, wc) for bk in (0, 1, 2, 3)]
-    tap_pool += [(GROUP_ACCUM, c, bk) for c in range(wa) for bk in (0, 1, 2)]
+    tap_pool = [(GROUP_DATA, c, bk) for c in range(wd - 1) for bk in data_backs[c % len(data_backs)]]
+    tap_pool += [(GROUP_CODE, c, bk) for c in range(5, wc) for bk in code_backs]
+    if huge:                                             # the selector columns at earlier rows too
+        tap_pool += [(GROUP_CODE, c, bk) for c in range(5) for bk in code_backs[1:]]
+    tap_pool += [(GROUP_ACCUM, c, bk) for c in range(wa) for bk in accum_backs]
     pool_pos = [0]
 
     # Locality, as in a real circuit: the constraints of one component (here: one triple) read a small set of related
@@ -68,7 +79,7 @@ def build_syn_heavy(wc: int = 16, wd: int = 208, wa: int = 32, per_triple: int =
     # tap — and only now and then something from elsewhere in the trace.
     local: list = []
 
-    def new_local_pool(size: int = 28):
+    def new_local_pool(size: int = 32 if huge else 28):
         local.clear()
         for _ in range(size):
             local.append(tap_pool[pool_pos[0] % len(tap_pool)])
@@ -181,6 +192,15 @@ def syn_heavy() -> np.ndarray:
     return _CACHE["heavy"]
 
 
+def syn_huge() -> np.ndarray:
+    """SYN-HUGE: SYN-A's trace under a constraint system of a real circuit's size (> 250 k steps, > 2 k taps at backs 0 .. 7,
+    > 14 k degree-5 constraints).  Not compiled into the library: it is DATA, loaded like any circuit the library has never seen
+    (generated + compiled at load time, parts in parallel: circuits/jit.py) — `tools/syn_huge_report.py` measures that path."""
+    if "huge" not in _CACHE:
+        _CACHE["huge"] = build_syn_heavy(per_triple=218, seed=0x48554745, huge=True)
+    return _CACHE["huge"]
+
+
 def syn_heavy_small() -> np.ndarray:
     """A small instance for byte-exact tests against the oracle (same generator, fewer columns and constraints)."""
     if "small" not in _CACHE:
@@ -191,7 +211,7 @@ def syn_heavy_small() -> np.ndarray:
 if __name__ == "__main__":
     import sys
     from .desc import Circuit
-    for name, d in (("syn_heavy", syn_heavy()), ("syn_heavy_small", syn_heavy_small())):
+    for name, d in (("syn_heavy", syn_heavy()), ("syn_heavy_small", syn_heavy_small()), ("syn_huge", syn_huge())):
         c = Circuit.parse(d)
         print(name, "groups", c.group_sizes, "taps", len(c.taps), "combos", c.combos, "steps", len(c.steps))
     if len(sys.argv) > 1:

@@ -15,6 +15,8 @@
 #include <fstream>
 #include <sstream>
 
+#include <cctype>
+
 #include "common.h"
 
 using namespace zkh;
@@ -102,9 +104,14 @@ extern "C" const char* zkh_device_identity(int device, char pci_bus_id[32], char
         hipUUID u;
         memset(&u, 0, sizeof u);
         memset(uuid_hex, 0, 40);
-        if (hipDeviceGetUuid(&u, device) == hipSuccess)
-            for (int i = 0; i < 16; i++) snprintf(uuid_hex + 2 * i, 3, "%02x", (unsigned)(unsigned char)u.bytes[i]);
-        else (void)hipGetLastError();
+        if (hipDeviceGetUuid(&u, device) == hipSuccess) {
+            // ROCm reports the 16 bytes as ASCII hex digits of the 64-bit unique id (what rocm-smi --showuniqueid prints): kept as
+            // text when every byte is a printable hex digit, hex-encoded otherwise
+            bool text = true;
+            for (int i = 0; i < 16; i++) text = text && isxdigit((unsigned char)u.bytes[i]);
+            if (text) memcpy(uuid_hex, u.bytes, 16);
+            else for (int i = 0; i < 16; i++) snprintf(uuid_hex + 2 * i, 3, "%02x", (unsigned)(unsigned char)u.bytes[i]);
+        } else (void)hipGetLastError();
     }
     if (name) {
         hipDeviceProp_t prop;
