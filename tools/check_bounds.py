@@ -80,6 +80,23 @@ class U4:
 
 
 CANON = lambda: S(0, P - 1, 32)          # noqa: E731
+NEG_PINV = (-pow(P, -1, W32)) % W32
+M32 = W32 - 1
+
+
+def exact(*vals) -> bool:
+    """all operands are single values (concrete execution: tools/check_bounds.py execute_source), not intervals"""
+    return all(v.lo == v.hi for v in vals)
+
+
+def pt(v: int, w: int = 32) -> S:
+    return S(v, v, w)
+
+
+def _mont(t: int, correct: bool) -> int:
+    m = ((t & M32) * NEG_PINV) & M32
+    r = (t + m * P) >> 32
+    return r - P if correct and r >= P else r
 
 
 def fits(s: S, what: str) -> S:
@@ -95,6 +112,8 @@ def fits(s: S, what: str) -> S:
 def reduce_once(s: S, what: str) -> S:
     if s.hi >= 2 * P:
         raise Violation(f"{what}: reduce_once needs s < 2P, worst case {s.hi}")
+    if exact(s):
+        return pt(s.hi - P if s.hi >= P else s.hi)
     return CANON()
 
 
@@ -102,6 +121,8 @@ def mont_reduce(t: S, what="mont_reduce") -> S:
     fits(t, what)
     if t.hi >= P << 32:
         raise Violation(f"{what}: needs t < P 2^32 = {P << 32}, worst case {t.hi} ({t.hi / (P << 32):.3f} x)")
+    if exact(t):
+        return pt(_mont(t.hi, True))
     return CANON()
 
 
@@ -109,6 +130,8 @@ def mont_reduce_lazy(t: S, what="mont_reduce_lazy") -> S:
     fits(t, what)
     if t.hi >= P << 32:
         raise Violation(f"{what}: needs t < P 2^32 = {P << 32}, worst case {t.hi} ({t.hi / (P << 32):.3f} x)")
+    if exact(t):
+        return pt(_mont(t.hi, False))
     return S(0, (t.hi + (W32 - 1) * P) >> 32, 32)
 
 
@@ -116,6 +139,10 @@ def mont_reduce_wide(t: S, what="mont_reduce_wide", lazy=False) -> S:
     fits(t, what)
     if t.hi >= (2 * P) << 32:
         raise Violation(f"{what}: needs t < 2 P 2^32 = {(2 * P) << 32}, worst case {t.hi} ({t.hi / ((2 * P) << 32):.3f} x)")
+    if exact(t):
+        hi = t.hi >> 32
+        hi = hi - P if hi >= P else hi
+        return pt(_mont((hi << 32) | (t.hi & M32), not lazy))
     if not lazy:
         return CANON()
     return S(0, ((min(t.hi, (P << 32) - 1)) + (W32 - 1) * P) >> 32, 32)
@@ -123,6 +150,8 @@ def mont_reduce_wide(t: S, what="mont_reduce_wide", lazy=False) -> S:
 
 def fold_acc(s: S, what="fold_acc") -> S:
     fits(s, what)
+    if exact(s):
+        return pt((s.hi >> 32) * R1 + (s.hi & M32), 64)
     return S(0, s.hi if s.hi < W32 else (s.hi >> 32) * R1 + W32 - 1, 64)
 
 
@@ -135,6 +164,8 @@ def sub_mod(a: S, b: S, what="sub_mod") -> S:
     fits(a, what); fits(b, what)
     if a.hi > P - 1 or b.hi > P - 1:
         raise Violation(f"{what}: needs canonical operands (< P), worst cases {a.hi}, {b.hi}")
+    if exact(a, b):
+        return pt(a.hi - b.hi if a.hi >= b.hi else a.hi - b.hi + P)
     return CANON()
 
 
@@ -206,6 +237,7 @@ def tokenize(text: str) -> List[Tuple[str, str]]:
 class Parser:
     def __init__(self, toks, env: Dict[str, object], ctx: str):
         self.t, self.i, self.env, self.ctx = toks, 0, env, ctx
+        self.conc = env.get("__concrete__")             # concrete execution: the inputs of ONE domain point (execute_source)
 
     def peek(self, k=0):
         return self.t[self.i + k] if self.i + k < len(self.t) else ("end", "")
@@ -290,9 +322,9 @@ class Parser:
                     raise Violation(f"unsupported member .{name} in `{self.ctx}`")
             elif tok == ("op", "[") and isinstance(v, str) and v == "pwp":
                 self.eat()
-                self.expr()
+                k = self.expr()
                 self.eat("]")
-                v = U4([CANON() for _ in range(4)])
+                v = U4([pt(int(x)) for x in self.conc["pwp"][k.hi]]) if self.conc is not None else U4([CANON() for _ in range(4)])
             else:
                 return v
 
@@ -326,6 +358,7 @@ class Parser:
         if val == "pwp":
             return "pwp"
         if val == "a":                                   # a.globals[x][y], a.zinv[idx & 3], a.check[...]: canonical input words
+            text = "".join(v for _, v in self.t[self.i:])
             depth = 0
             while not self.done():
                 k, v = self.peek()
@@ -338,6 +371,13 @@ class Parser:
                 elif depth == 0 and v in (",", "+", "-", "*", "=") and k == "op":
                     break
                 self.eat()
+            if self.conc is not None:
+                m = re.match(r"^\.globals\[(\d+)\]\[(\d+)\]", text)
+                if m:
+                    return pt(int(self.conc["globals"][int(m.group(1))][int(m.group(2))]))
+                if text.startswith(".zinv["):
+                    return pt(int(self.conc["zinv"]))
+                raise Violation(f"concrete execution: unsupported input `a{text[:30]}`")
             return CANON()
         if val == "Fp::raw":
             (x,) = self.args()
@@ -353,13 +393,19 @@ class Parser:
             raise Violation(f"unsupported Fp4 constructor in `{self.ctx}`")
         if self.peek() == ("op", "("):
             if val == "tap_load":                        # address arithmetic inside: a canonical trace word comes back
-                depth = 0
+                depth, inner = 0, []
                 while True:
                     v = self.eat()[1]
+                    inner.append(v)
                     depth += v == "("
                     depth -= v == ")"
                     if depth == 0:
                         break
+                if self.conc is not None:                 # tap_load(g<group>, (size_t)<offset> * dw<k>, o<back>_<k>)
+                    m = re.match(r"^\(g(\d)\,\(size_t\)(\d+)\*dw\d+\,o(\d+)_\d+\)$", "".join(inner))
+                    if not m:
+                        raise Violation(f"concrete execution: tap_load form not understood in `{self.ctx}`")
+                    return pt(int(self.conc["tap"](int(m.group(1)), int(m.group(2)), int(m.group(3)))))
                 return CANON()
             a = self.args()
             fn = {"mont_reduce": mont_reduce, "mont_reduce_lazy": mont_reduce_lazy, "mont_reduce_wide": mont_reduce_wide,
@@ -570,6 +616,91 @@ def check_source(src: str, label: str = "") -> Tuple[List[str], dict]:
             stats["max_acc_bits"] = max(stats["max_acc_bits"], round(kc.max_acc.bit_length() - 1 + (kc.max_acc / (1 << (kc.max_acc.bit_length() - 1)) - 1), 3))
         i = j + 1
     return violations, stats
+
+
+# ---- concrete execution: the emitted kernels run on the CPU for ONE domain point (the same parser, single values instead of intervals) ----
+def fp4_mul_canon(a, b):
+    r = [0] * 7
+    for i in range(4):
+        for j in range(4):
+            r[i + j] += a[i] * b[j]
+    return tuple((r[k] - 11 * (r[k + 4] if k + 4 < 7 else 0)) % P for k in range(4))
+
+
+def fp4_pow_canon(a, e: int):
+    r = (1, 0, 0, 0)
+    while e:
+        if e & 1:
+            r = fp4_mul_canon(r, a)
+        a = fp4_mul_canon(a, a)
+        e >>= 1
+    return r
+
+
+def kernel_tables(src: str) -> Tuple[List[int], List[Tuple[int, Tuple[int, int, int, int]]]]:
+    """the gathered-table description a kernel exports: exponent per slot, and (slot, Fp4 constant as Montgomery words) records"""
+    m = re.search(r"const uint32_t (?:exps_\w+|\w+_exps)\[\] = \{([^}]*)\}", src)
+    exps = [int(x) for x in m.group(1).split(",")] if m else None
+    m = re.search(r"const uint32_t (?:pwc_\w+|\w+_pwc)\[\] = \{([^}]*)\}", src)
+    recs = [int(x) for x in m.group(1).split(",")] if m else [0]
+    consts = [(recs[1 + 5 * i], tuple(recs[2 + 5 * i: 6 + 5 * i])) for i in range(recs[0])]
+    return (exps[1:] if exps else None), consts
+
+
+def execute_source(src: str, groups, globals_, poly_mix, po2: int, idx: int) -> List[int]:
+    """Run every `__global__` kernel of a generated translation unit for domain point `idx` in exact integer arithmetic, the way the
+    device does (Montgomery words, the library's gathered power table incl. slot constants, zinv), and return the four words this
+    unit contributes to check[k * dom + idx] (parts of a split circuit: add them mod P).  groups: three W x dom arrays of raw words;
+    globals_: (out, mix) raw words; poly_mix: four raw words.  Every precondition the bound checker knows is ALSO checked on the
+    concrete values, so a wrapped accumulator raises instead of silently computing garbage."""
+    n, dom = 1 << po2, 4 << po2
+    RINV = pow(W32, -1, P)
+    canon = lambda w: (int(w) * RINV) % P            # noqa: E731
+    montw = lambda x: (x * W32) % P                  # noqa: E731
+    mixc = tuple(canon(w) for w in poly_mix)
+    exps, consts = kernel_tables(src)
+    if exps is None:
+        raise Violation("concrete execution needs the kernel's exported exponent list (GATHER)")
+    cmap = {slot: tuple(canon(w) for w in C) for slot, C in consts}
+    cache: Dict[int, tuple] = {}
+    pwp = []
+    for slot, e in enumerate(exps):
+        if e not in cache:
+            cache[e] = fp4_pow_canon(mixc, e)
+        v = cache[e]
+        if slot in cmap:
+            v = fp4_mul_canon(v, cmap[slot])
+        pwp.append(tuple(montw(x) for x in v))
+    w = pow(137, 1 << (27 - (po2 + 2)), P)
+    y = pow(3 * pow(w, idx, P) % P, n, P)
+    zinv = montw(pow((y - 1) % P, P - 2, P))
+    conc = {"pwp": pwp, "globals": globals_, "zinv": zinv,
+            "tap": lambda g, off, back: groups[g][off * dom + ((idx - 4 * back) & (dom - 1))]}
+    lines = src.split("\n")
+    out = [0, 0, 0, 0]
+    i = 0
+    while i < len(lines):
+        m = re.search(r"__global__ .* void (k_eval_check_\w+)\(EvalCheckArgs a\) \{", lines[i])
+        if not m:
+            i += 1
+            continue
+        j = i + 1
+        body = []
+        while j < len(lines) and lines[j] != "}":
+            if not re.match(r"^\s*(if \(a\.accumulate\)|\} else \{|a\.check\[|\}$)", lines[j]) and "a.check[" not in lines[j]:
+                body.append((j + 1, lines[j]))
+            j += 1
+        kc = KernelCheck(m.group(1))
+        kc.env["__concrete__"] = conc
+        kc.run(body)
+        if kc.violations:
+            raise Violation(kc.violations[0])
+        zi = kc.env["zi"]
+        for k in range(4):
+            r = mul_mod(kc.env[f"t0_{k}"], zi)
+            out[k] = (out[k] + r.hi) % P
+        i = j + 1
+    return out
 
 
 def check_desc(name: str, desc) -> Tuple[List[str], dict]:

@@ -16,6 +16,8 @@
 #                every secondary figure (syn_heavy, resident code, block, preflight) -> repro_summary.json  (round-5 verdict, item 1)
 #   devices      N > 1 readiness on ONE GPU: 8 ranks sharing it (--allow-shared-gpu; config.devices), the same without the flag (must
 #                refuse), the in-process launcher (--launcher session, 8 devices x 1 lane and 1 device x 3 lanes), the RCCL probe at world 1
+#   huge         SYN-HUGE (> 250 k steps, > 2 k taps, ~15 k constraints) loaded as data: generator / hipcc / code-object figures, eval_check and
+#                seal ms at po2 20, three evaluators + extreme vectors (tools/syn_huge_report.py); the same report for SYN-HEAVY beside it
 #   profiles     everything profiles/ holds (tools/collect_profiles.sh)
 #   big          po2 21 / 22 segments
 #   soak         1000 distinct segments through the g++ driver
@@ -100,6 +102,24 @@ for f in ("bench_8rank_one_gpu", "bench_session_8dev_one_gpu", "bench_session_1g
         print(f, "no line:", e)
 PY
   grep real $O/*.time; for f in $O/*.err; do grep -v amdgpu.ids $f | tail -2; done ;;
+huge)
+  O=gpurun_out/${1:-huge}; mkdir -p $O
+  ( time timeout 1500 python tools/syn_huge_report.py --circuit syn_huge > $O/syn_huge_report.json 2> $O/syn_huge.err ) 2> $O/syn_huge.time
+  ( time timeout 900 python tools/syn_huge_report.py --circuit syn_heavy > $O/syn_heavy_report.json 2> $O/syn_heavy.err ) 2> $O/syn_heavy.time
+  python - $O <<'PY'
+import json, sys
+for n in ("syn_huge", "syn_heavy"):
+    try:
+        r = json.load(open(f"{sys.argv[1]}/{n}_report.json"))
+        g = r.get("gpu", {})
+        print(n, "steps", r["steps"], "taps", r["taps"], "constraints", r["constraints"], "kernels", r["kernels"], "generator_s", r["generator_s"], "hipcc", r["hipcc"],
+              "static", r.get("static"), "bounds", r["bounds"]["violations"])
+        print("   gpu:", {k: v for k, v in g.items() if k not in ("equals_oracle_po2_6", "kernels_ms")}, g.get("kernels_ms"))
+        print("   agree:", g.get("equals_oracle_po2_6"))
+    except Exception as e:
+        print(n, "no report:", e)
+PY
+  grep real $O/*.time; tail -3 $O/syn_huge.err | grep -v amdgpu.ids ;;
 chained)
   O=gpurun_out/${1:-chained}; mkdir -p $O        # a chained block (claim continuity) and the same block with the host-preflight witness, full size
   timeout 600 python bench.py --config block --chained --no-cpu-baseline > $O/bench_block_chained.json 2> $O/err.txt; line $O/bench_block_chained.json

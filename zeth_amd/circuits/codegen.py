@@ -72,10 +72,19 @@ FACTOR_MIN = int(os.environ.get("ZKH_CODEGEN_FACTOR", "3"))
 # that are canonical anyway (taps, constants, globals, values with other consumers), is emitted as  o*x +- o*y: one more 64-bit
 # multiply-add, but the addition disappears and o may stay in [0, 2P) — its conditional subtraction (v_subrev_co + v_cndmask, and
 # the s_nop between them) is what the lazy sum x +- y used to force.
+# LINFORM (round 6): an Fp4-valued constraint whose value is LINEAR over Fp4 CONSTANTS —  x = sum_j C_j * b_j  with C_j constants
+# (ConstExt operands, products of them, the unit) and b_j base-field values — contributes  mix^e * x = sum_j (mix^e * C_j) * b_j:
+# every term is an ordinary BASE leaf (four 64-bit multiply-adds) against a table slot that holds mix^e * C_j instead of mix^e.  The
+# slot's constant travels with the kernel (`<kernel>_pwc` / `pwc_<kernel>`), the library multiplies it in when it builds the gathered
+# table (one small launch more per call).  The Fp4 value itself — its four component products, the sixteen products + three
+# reductions of ext_accumulate — is never computed.  Same field element, same canonical words in `check`.  SYN-HEAVY: the 371
+# constraints (c + L) * s cost ~58 VALU instructions each before, ~12 after.  Needs GATHER; at most LIN_MAX terms, else the Fp4 path.
+LINFORM = int(os.environ.get("ZKH_CODEGEN_LINFORM", "1"))
+LIN_MAX = 4
 DISTRIBUTE = int(os.environ.get("ZKH_CODEGEN_DISTRIBUTE", "0"))    # measured on the static opcode table and REJECTED as the default (profiles/r05_eval_check_static.txt)
 # compile flags of the generated translation units (build.py and jit.py use the same list)
 KERNEL_FLAGS = [f for f in os.environ.get("ZKH_CODEGEN_FLAGS", "").split() if f]
-GENERATOR_VERSION = 11
+GENERATOR_VERSION = 12
 
 
 def desc_hash64(desc: np.ndarray) -> int:
@@ -89,6 +98,18 @@ def desc_hash64(desc: np.ndarray) -> int:
 
 def mont(x: int) -> int:
     return (x % P) * pow(2, 32, P) % P
+
+
+def fp4_const_mul(a: Tuple[int, int, int, int], b: Tuple[int, int, int, int]) -> Tuple[int, int, int, int]:
+    """product of two Fp4 constants (canonical residues), x^4 = -11"""
+    r = [0] * 7
+    for i in range(4):
+        for j in range(4):
+            r[i + j] += a[i] * b[j]
+    return tuple((r[k] - 11 * (r[k + 4] if k + 4 < 7 else 0)) % P for k in range(4))
+
+
+UNIT = (1, 0, 0, 0)
 
 
 def analyse(c: Circuit):
@@ -156,11 +177,14 @@ class Plan:
     lazy: set = field(default_factory=set)                                     # values kept in [0, 2P): every consumer multiplies
     _chains: Dict[int, List[Tuple]] = field(default_factory=dict)
     _tapsets: Dict[int, frozenset] = field(default_factory=dict)
+    _vn: Dict[Tuple, int] = field(default_factory=dict)                        # the value-numbering table (kept: LINFORM adds products)
+    _lin: Dict[int, Optional[List[Tuple]]] = field(default_factory=dict)       # Fp4 value -> [(Fp4 constant, base value)] or None
+    n_synth: int = 0                                                           # values LINFORM added to the step list's own
 
     @staticmethod
     def build(c: Circuit) -> "Plan":
         p = Plan(c)
-        table: Dict[Tuple, int] = {}
+        table = p._vn
         for op, a, b, cc, d in c.steps:
             if op >= OP_TRUE:
                 if op == OP_TRUE:
@@ -218,30 +242,112 @@ class Plan:
             if op in (OP_ADD, OP_SUB, OP_MUL):
                 work.append(x); work.append(y)
         p.n_unique = sum(1 for v in seen if p.fp[v][0] in (OP_ADD, OP_SUB, OP_MUL))
-        if USE_SOP:
-            p.find_sums_of_products(seen, roots)
-        # The values the emitter will actually ask for: with FACTOR a grouped constraint f * q_i is never computed — its members q_i
-        # and the factor f are — so the lazy analysis must see THOSE as the consumers' operands (an Fp4 member goes into the sums
-        # whole: canonical components; a base member and the factor are only ever multiplied).
+        # The values the emitter will actually ask for.  With FACTOR a grouped constraint f * q_i is never computed — its members q_i
+        # and the factor f are; with LINFORM an Fp4 leaf that is linear over constants is never computed — the base values b_j of its
+        # terms are.  Both analyses below (sums of products, lazy representatives) must see THOSE as the consumers' operands (round 5
+        # shipped the lazy analysis on the old roots once: tools/check_bounds.py is the net under that).
         eff: List[int] = []
+
+        def leaf(v: int):
+            terms = p.linform(v)
+            if terms is None:
+                eff.append(v)
+            else:
+                eff.extend(b for _, b in terms)
 
         def walk(m: int):
             for it in p.chain(m):
                 if it[0] == "e":
-                    eff.append(it[1])
+                    leaf(it[1])
                 elif it[0] == "g":
                     eff.append(it[1])
-                    eff.extend(q for q, _ in it[2])
+                    for q, _ in it[2]:
+                        leaf(q)
                 else:
                     eff.append(it[1])
                     walk(it[2])
         walk(c.ret)
+        reach0 = set()
+        for r in eff:
+            reach0.update(p.cone(r, reach0))
+        if USE_SOP:
+            p.find_sums_of_products(reach0, eff)
         if USE_LAZY:
             reach = set()
             for r in eff:
                 reach.update(p.cone(r, reach))
             p.find_lazy(reach, eff)
         return p
+
+    def value(self, op: int, x: int, y: int) -> int:
+        """the canonical value  x op y  of two BASE values: the step list's own if it has one, else a new one (LINFORM's products)"""
+        if op != OP_SUB and x > y:
+            x, y = y, x
+        key = (op, x, y)
+        v = self._vn.get(key)
+        if v is None:
+            v = len(self.fp)
+            self._vn[key] = v
+            self.fp.append((op, x, y, 0, 0)); self.canon.append(v); self.ext.append(False)
+            self.n_synth += 1
+        return v
+
+    def one(self) -> int:
+        v = self._vn.get((OP_CONST, 1))
+        if v is None:
+            v = len(self.fp)
+            self._vn[(OP_CONST, 1)] = v
+            self.fp.append((OP_CONST, 1, 0, 0, 0)); self.canon.append(v); self.ext.append(False)
+        return v
+
+    def linform(self, v: int) -> Optional[List[Tuple]]:
+        """An Fp4 value as  sum_j C_j * b_j  (C_j Fp4 constants as canonical residues, b_j base values; b_j = the constant 1 for a
+        pure constant term), or None: not Fp4, not linear over constants (a product of two non-constant Fp4 values), more than
+        LIN_MAX terms, or LINFORM off."""
+        if not (LINFORM and GATHER) or not self.ext[v]:
+            return None
+        if v in self._lin:
+            return self._lin[v]
+
+        def form(x: int):
+            if not self.ext[x]:
+                return [(UNIT, x)]
+            if x in self._lin and self._lin[x] is not None:
+                return self._lin[x]
+            op, a, b, cc, d = self.fp[x]
+            if op == OP_CONST_EXT:
+                return [((a, b, cc, d), self.one())]
+            if op in (OP_ADD, OP_SUB):
+                fa, fb = form(a), form(b)
+                if fa is None or fb is None:
+                    return None
+                if op == OP_SUB:
+                    fb = [(tuple((P - k) % P for k in C), t) for C, t in fb]
+                acc: Dict[int, Tuple] = {}
+                for C, t in fa + fb:
+                    acc[t] = tuple((p_ + q_) % P for p_, q_ in zip(acc[t], C)) if t in acc else C
+                out = [(C, t) for t, C in acc.items() if any(C)]
+                return out if len(out) <= LIN_MAX else None
+            if op == OP_MUL:
+                if self.ext[a] and self.ext[b]:
+                    fa, fb = form(a), form(b)
+                    if fa is None or fb is None:
+                        return None
+                    one = self.one()
+                    for k, o in ((fa, fb), (fb, fa)):
+                        if len(k) == 1 and k[0][1] == one:                    # an Fp4 constant times a linear form
+                            return [(fp4_const_mul(k[0][0], C), t) for C, t in o]
+                    return None
+                e_, s_ = (a, b) if self.ext[a] else (b, a)
+                fe = form(e_)
+                if fe is None:
+                    return None
+                one = self.one()
+                return [(C, s_ if t == one else self.value(OP_MUL, t, s_)) for C, t in fe]
+            return None
+        out = form(v)
+        self._lin[v] = out
+        return out
 
     def find_lazy(self, reachable, mix_ext=()) -> None:
         """Which arithmetic values may skip their final conditional subtraction and live in [0, 2P).
@@ -543,13 +649,18 @@ class Plan:
         """Cost estimate per AndEqz leaf in depth-first order (arithmetic steps in its cone, no cross-leaf sharing)."""
         w: List[int] = []
 
+        def cost(v: int) -> int:
+            terms = self.linform(v)
+            vals = [v] if terms is None else [b for _, b in terms]
+            return 4 * len(vals) + sum(1 for r in vals for x in self.cone(r, set()) if self.fp[x][0] in (OP_ADD, OP_SUB, OP_MUL))
+
         def walk(m: int):
             for it in self.chain(m):
                 if it[0] == "e":
-                    w.append(4 + sum(1 for x in self.cone(it[1], set()) if self.fp[x][0] in (OP_ADD, OP_SUB, OP_MUL)))
+                    w.append(cost(it[1]))
                 elif it[0] == "g":
                     for q, _ in it[2]:
-                        w.append(4 + sum(1 for x in self.cone(q, set()) if self.fp[x][0] in (OP_ADD, OP_SUB, OP_MUL)))
+                        w.append(cost(q))
                 else:
                     walk(it[2])
         walk(self.c.ret)
@@ -606,6 +717,7 @@ class _Emitter:
         self.globals_used: set = set()
         self.leaf = 0                       # depth-first index of the next leaf
         self.pw_exps: List[int] = []        # GATHER: the exponent behind every slot of this part's power table, in emission order
+        self.pw_consts: List[Tuple[int, Tuple[int, int, int, int]]] = []    # LINFORM: (slot, Fp4 constant the slot's power is multiplied by)
         self.epoch = -1
         self.epoch_loads = EPOCH_LOADS      # forces an epoch before the first load
         self.epoch_backs: List[set] = []
@@ -858,11 +970,15 @@ class _Emitter:
         self.n_arith += 1
         self.cache[v] = name
 
-    def pw(self, e: int) -> int:
-        """Index of mix^e in the table this kernel reads: e itself, or (GATHER) the next slot of the part's own table."""
+    def pw(self, e: int, const: Optional[Tuple[int, int, int, int]] = None) -> int:
+        """Index of mix^e in the table this kernel reads: e itself, or (GATHER) the next slot of the part's own table — which may
+        hold mix^e times an Fp4 constant (LINFORM)."""
         if not GATHER:
+            assert const is None or const == UNIT
             return e
         self.pw_exps.append(e)
+        if const is not None and const != UNIT:
+            self.pw_consts.append((len(self.pw_exps) - 1, const))
         return len(self.pw_exps) - 1
 
     # ---- accumulators ----
@@ -912,8 +1028,13 @@ class _Emitter:
         self.w("    }")
         self.tzero[d] = False
 
-    def acc_leaf(self, d: int, v: int, e: int) -> None:
-        """depth d += mix^e * v for one constraint value"""
+    def acc_leaf(self, d: int, v: int, e: int, const: Optional[Tuple[int, int, int, int]] = None) -> None:
+        """depth d += mix^e * v for one constraint value (`const`: the slot holds mix^e * const — a term of an Fp4 leaf's linear form)"""
+        terms = self.p.linform(v) if const is None else None
+        if terms is not None:                   # mix^e * sum_j C_j b_j = sum_j (mix^e C_j) b_j: base leaves against constant-scaled slots
+            for C, b in terms:
+                self.acc_leaf(d, b, e, C)
+            return
         self.need([v])
         if self.p.ext[v]:
             # tot += mix^e * x for an Fp4 x: sixteen products straight into the unreduced sums (four units of room)
@@ -932,7 +1053,7 @@ class _Emitter:
         wgt = 2 if v in self.p.lazy else 1      # a lazy value (< 2P) makes a product below 2 P^2
         if self.pend.get(d, 0) + wgt > 4:
             self.fold(d)
-        self.w(f"    {{ const uint4 p_ = pwp[{self.pw(e)}]; s{d}_0 += (uint64_t)p_.x * {r}; s{d}_1 += (uint64_t)p_.y * {r}; "
+        self.w(f"    {{ const uint4 p_ = pwp[{self.pw(e, const)}]; s{d}_0 += (uint64_t)p_.x * {r}; s{d}_1 += (uint64_t)p_.y * {r}; "
                f"s{d}_2 += (uint64_t)p_.z * {r}; s{d}_3 += (uint64_t)p_.w * {r}; }}")
         self.release()
         self.pend[d] = self.pend.get(d, 0) + wgt
@@ -1080,10 +1201,17 @@ def emit_part(kernel: str, plan: Plan, lo: int, hi: int, standalone: bool, heade
         w("}")
     if GATHER:          # the exponent behind every slot of this part's power table (first word: how many)
         words = ", ".join(str(x) for x in [len(em.pw_exps)] + em.pw_exps)
+        # ... and the slots whose power is multiplied by an Fp4 constant (LINFORM): {count, then (slot, c0, c1, c2, c3) each, Montgomery words}
+        cw = [len(em.pw_consts)]
+        for slot, C in em.pw_consts:
+            cw += [slot] + [mont(k) for k in C]
+        cwords = ", ".join(str(x) for x in cw)
         if standalone:
             w(f'extern "C" __device__ __attribute__((used)) const uint32_t {kernel}_exps[] = {{{words}}};')
+            w(f'extern "C" __device__ __attribute__((used)) const uint32_t {kernel}_pwc[] = {{{cwords}}};')
         else:
             w(f"extern const uint32_t exps_{kernel}[] = {{{words}}};")
+            w(f"extern const uint32_t pwc_{kernel}[] = {{{cwords}}};")
     return "\n".join(L)
 
 
@@ -1160,12 +1288,15 @@ def generate_sources() -> Dict[str, str]:
                 externs.append(f"void launch_{k}(const EvalCheckArgs&, hipStream_t);")
                 launchers.append(f"launch_{k}")
         main.append(f"static const eval_check_launch_fn parts_{name}[] = {{{', '.join(launchers)}}};")
-        gather = "nullptr"
         if GATHER:
             if len(parts) > 1:
                 externs.extend(f"extern const uint32_t exps_{k}[];" for k, _ in parts)
+                externs.extend(f"extern const uint32_t pwc_{k}[];" for k, _ in parts)
             main.append(f"static const uint32_t* const gexps_{name}[] = {{{', '.join('exps_' + k for k, _ in parts)}}};")
-            gather = f"gexps_{name}"
+            main.append(f"static const uint32_t* const gpwc_{name}[] = {{{', '.join('pwc_' + k for k, _ in parts)}}};")
+            gather = f"gexps_{name}, gpwc_{name}"
+        else:
+            gather = "nullptr, nullptr"
         table.append(f'    {{0x{h:016x}ull, "{name}", parts_{name}, {len(launchers)}u, {n_pows}u, {gather}}},')
     # the extern declarations must precede the arrays that reference them
     src = "\n".join(PREAMBLE + externs + [""] + main[len(PREAMBLE):] + ["", "static const CompiledEvalCheck k_table[] = {", *table, "};", "",

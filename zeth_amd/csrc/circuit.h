@@ -65,8 +65,10 @@ typedef void (*eval_check_launch_fn)(const EvalCheckArgs&, hipStream_t);
 // part 0 writes `check`, the others add their share (circuits/codegen.py).
 // gather_exps (optional): per part, {count, exponent of slot 0, 1, ...} — the part reads its mix powers from a table of its own,
 // gathered into the order its code touches them (codegen.py GATHER); NULL: every part indexes the plain table mix^0, mix^1, ...
+// gather_consts (optional, with gather_exps): per part, {count, then (slot, c0, c1, c2, c3) each} — slots whose power is multiplied by an
+// Fp4 constant (Montgomery words) when the table is built (codegen.py LINFORM: an Fp4 constraint linear over constants becomes base leaves).
 struct CompiledEvalCheck { uint64_t desc_hash; const char* name; const eval_check_launch_fn* parts; uint32_t n_parts; uint32_t n_mix_pows;
-                           const uint32_t* const* gather_exps; };
+                           const uint32_t* const* gather_exps; const uint32_t* const* gather_consts; };
 // registry filled by the generated translation unit (eval_check_gen.hip)
 const CompiledEvalCheck* find_compiled_eval_check(uint64_t desc_hash);
 
@@ -102,7 +104,10 @@ struct zkh_circuit {
     // and where each part's slots start (n_parts + 1 entries); empty = the parts index the plain table
     uint32_t* d_gather[2];
     std::vector<uint32_t> gather_off[2];
+    uint32_t* d_gconst[2];                         // (slot, c0..c3) records of all parts, slots rebased to the concatenated table
+    uint32_t n_gconst[2];
     std::vector<std::vector<uint32_t>> jit_exps;   // per attached part: its exponent list ({} = none exported)
+    std::vector<std::vector<uint32_t>> jit_pwc;    // per attached part: its slot-constant list ({} = none exported)
     bool jit_mixed;       // the attached parts disagree about the table (a set half replaced): not launched until repaired
     bool interp_ok;       // the step interpreter's live values fit its LDS
     // interpreter program

@@ -22,8 +22,9 @@ uint64_t desc_hash64(const uint32_t* w, size_t n) {   // FNV-1a over the words
 }
 const char* launch_ext_powers(zkh_ctx* c, uint32_t* out, const uint32_t start[4], const uint32_t base[4], uint32_t n);
 const char* launch_ext_powers_at(zkh_ctx* c, uint32_t* out, const uint32_t base[4], const uint32_t* d_exps, uint32_t n);
+const char* launch_ext_scale_at(zkh_ctx* c, uint32_t* out, const uint32_t* d_recs, uint32_t n);
 }
-static const char* set_gather(zkh_circuit* c, int which, const std::vector<const uint32_t*>& lists);
+static const char* set_gather(zkh_circuit* c, int which, const std::vector<const uint32_t*>& lists, const std::vector<const uint32_t*>& consts);
 namespace zkh {
 const char* prefix_products_batched(zkh_ctx* c, uint32_t* io, size_t n0, size_t count, size_t col_stride);
 }  // namespace zkh
@@ -593,30 +594,48 @@ extern "C" const char* zkh_circuit_load(zkh_ctx* ctx, const uint32_t* d, size_t 
         if (e != hipSuccess) { const char* m = hipGetErrorString(e); return fail(m); }
         if (c->compiled && c->compiled->gather_exps) {
             std::vector<const uint32_t*> lists(c->compiled->gather_exps, c->compiled->gather_exps + c->compiled->n_parts);
-            if (const char* err = set_gather(c, 0, lists)) { std::string m(err); zkh_free_error(err); return fail(m.c_str()); }
+            std::vector<const uint32_t*> consts(c->compiled->n_parts, nullptr);
+            if (c->compiled->gather_consts) consts.assign(c->compiled->gather_consts, c->compiled->gather_consts + c->compiled->n_parts);
+            if (const char* err = set_gather(c, 0, lists, consts)) { std::string m(err); zkh_free_error(err); return fail(m.c_str()); }
         }
     }
     *out = c;
     return nullptr;
 }
 // The parts' exported exponent lists ({count, e0, e1, ...} each) -> one device list + the parts' slot offsets.  All parts or none.
-static const char* set_gather(zkh_circuit* c, int which, const std::vector<const uint32_t*>& lists) {
+// consts: per part NULL or {count, (slot, c0, c1, c2, c3) x count}: slots whose power is multiplied by an Fp4 constant (Montgomery words).
+static const char* set_gather(zkh_circuit* c, int which, const std::vector<const uint32_t*>& lists, const std::vector<const uint32_t*>& consts) {
     if (c->d_gather[which]) { (void)hipFree(c->d_gather[which]); c->d_gather[which] = nullptr; }
+    if (c->d_gconst[which]) { (void)hipFree(c->d_gconst[which]); c->d_gconst[which] = nullptr; }
+    c->n_gconst[which] = 0;
     c->gather_off[which].clear();
     size_t exported = 0;
     for (const uint32_t* l : lists) exported += l != nullptr;
     if (!exported) return nullptr;
     ZKH_REQUIRE(exported == lists.size(), "eval_check kernels: %zu of %zu parts export a gathered power table", exported, lists.size());
-    std::vector<uint32_t> all, off(1, 0);
-    for (const uint32_t* l : lists) {
+    std::vector<uint32_t> all, off(1, 0), recs;
+    for (size_t part = 0; part < lists.size(); part++) {
+        const uint32_t* l = lists[part];
         for (uint32_t i = 0; i < l[0]; i++) {
             ZKH_REQUIRE(l[1 + i] < c->n_mix_pows, "eval_check kernels: gathered mix power %u, the step list has %u", l[1 + i], c->n_mix_pows);
             all.push_back(l[1 + i]);
+        }
+        const uint32_t* k = part < consts.size() ? consts[part] : nullptr;
+        for (uint32_t i = 0; k && i < k[0]; i++) {
+            const uint32_t* r = k + 1 + 5 * (size_t)i;
+            ZKH_REQUIRE(r[0] < l[0], "eval_check kernels: a slot constant names slot %u of a part with %u slots", r[0], l[0]);
+            recs.push_back(off.back() + r[0]);
+            for (int j = 1; j <= 4; j++) { ZKH_REQUIRE(r[j] < P, "eval_check kernels: a slot constant is not a reduced word"); recs.push_back(r[j]); }
         }
         off.push_back((uint32_t)all.size());
     }
     hipError_t e = hipMalloc((void**)&c->d_gather[which], all.size() * 4 + 4);
     if (e == hipSuccess) e = hipMemcpy(c->d_gather[which], all.data(), all.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !recs.empty()) {
+        e = hipMalloc((void**)&c->d_gconst[which], recs.size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(c->d_gconst[which], recs.data(), recs.size() * 4, hipMemcpyHostToDevice);
+        c->n_gconst[which] = (uint32_t)(recs.size() / 5);
+    }
     if (e != hipSuccess) return make_err("eval_check kernels: gathered power table: %s", hipGetErrorString(e));
     c->gather_off[which] = std::move(off);
     return nullptr;
@@ -625,6 +644,7 @@ extern "C" void zkh_circuit_destroy(zkh_circuit* c) {
     if (!c) return;
     if (c->ctx) bind_thread(c->ctx);
     for (int w = 0; w < 2; w++) if (c->d_gather[w]) (void)hipFree(c->d_gather[w]);
+    for (int w = 0; w < 2; w++) if (c->d_gconst[w]) (void)hipFree(c->d_gconst[w]);
     if (c->d_prog) (void)hipFree(c->d_prog);
     if (c->d_taps) (void)hipFree(c->d_taps);
     for (hipModule_t m : c->jit_modules) if (m) (void)hipModuleUnload(m);
@@ -658,8 +678,24 @@ extern "C" const char* zkh_circuit_attach_code_object_part(zkh_circuit* c, const
     if (e != hipSuccess) { (void)hipGetLastError(); return make_err("attach_code_object: hipModuleLoadData: %s", hipGetErrorString(e)); }
     e = hipModuleGetFunction(&fn, mod, kernel_name);
     if (e != hipSuccess) { (void)hipGetLastError(); (void)hipModuleUnload(mod); return make_err("attach_code_object: no kernel '%s': %s", kernel_name, hipGetErrorString(e)); }
-    // a kernel generated with a gathered power table exports `<kernel>_exps` = {count, exponent of slot 0, 1, ...}
-    std::vector<uint32_t> exps;
+    // a kernel generated with a gathered power table exports `<kernel>_exps` = {count, exponent of slot 0, 1, ...} and, when some
+    // slots hold a power times an Fp4 constant, `<kernel>_pwc` = {count, (slot, c0, c1, c2, c3) x count}
+    std::vector<uint32_t> exps, pwc;
+    {
+        hipDeviceptr_t dptr = nullptr;
+        size_t bytes = 0;
+        const std::string sym = std::string(kernel_name) + "_pwc";
+        if (hipModuleGetGlobal(&dptr, &bytes, mod, sym.c_str()) == hipSuccess && bytes >= 4 && bytes % 4 == 0) {
+            pwc.resize(bytes / 4);
+            e = hipMemcpy(pwc.data(), dptr, bytes, hipMemcpyDeviceToHost);
+            if (e != hipSuccess || (size_t)pwc[0] * 5 != pwc.size() - 1) {
+                (void)hipGetLastError(); (void)hipModuleUnload(mod);
+                return make_err("attach_code_object: '%s' is malformed", sym.c_str());
+            }
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     {
         hipDeviceptr_t dptr = nullptr;
         size_t bytes = 0;
@@ -680,21 +716,23 @@ extern "C" const char* zkh_circuit_attach_code_object_part(zkh_circuit* c, const
         c->jit_modules.assign(n_parts, nullptr);
         c->jit_kernels.assign(n_parts, nullptr);
         c->jit_exps.assign(n_parts, {});
+        c->jit_pwc.assign(n_parts, {});
     }
     if (c->jit_modules[part]) (void)hipModuleUnload(c->jit_modules[part]);
-    c->jit_modules[part] = mod; c->jit_kernels[part] = fn; c->jit_exps[part] = std::move(exps);
+    c->jit_modules[part] = mod; c->jit_kernels[part] = fn; c->jit_exps[part] = std::move(exps); c->jit_pwc[part] = std::move(pwc);
     c->jit_mixed = false;
     if (jit_complete(c)) {
-        std::vector<const uint32_t*> lists;
+        std::vector<const uint32_t*> lists, consts;
         size_t exported = 0;
         for (const auto& l : c->jit_exps) { lists.push_back(l.empty() ? nullptr : l.data()); exported += !l.empty(); }
+        for (const auto& l : c->jit_pwc) consts.push_back(l.empty() ? nullptr : l.data());
         // a set being replaced part by part passes through states where some parts carry a table and some do not: such a set
         // is never launched (zkh_eval_check refuses it), but attaching the remaining parts repairs it
         if (exported && exported != lists.size()) {
             c->jit_mixed = true;
             std::vector<const uint32_t*> none(lists.size(), nullptr);
-            (void)set_gather(c, 1, none);
-        } else if (const char* err = set_gather(c, 1, lists)) {
+            (void)set_gather(c, 1, none, none);
+        } else if (const char* err = set_gather(c, 1, lists, consts)) {
             c->jit_kernels[part] = nullptr;
             return err;
         }
@@ -737,6 +775,7 @@ extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_bu
     if (goff) {
         ZKH_TRY(new_buf(ctx, 4 * (size_t)goff->back() + 4, false, pows.out()));
         ZKH_TRY(launch_ext_powers_at(ctx, pows->ptr(), poly_mix, c->d_gather[which], goff->back()));
+        ZKH_TRY(launch_ext_scale_at(ctx, pows->ptr(), c->d_gconst[which], c->n_gconst[which]));
     } else {
         ZKH_TRY(new_buf(ctx, 4 * (size_t)c->n_mix_pows, false, pows.out()));
         const uint32_t one[4] = {R1, 0, 0, 0};

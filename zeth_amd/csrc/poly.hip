@@ -34,6 +34,16 @@ __global__ void k_ext_powers_at(uint32_t* out, Fp4 base, const uint32_t* __restr
     if (i < n) st_ext(out + 4 * i, fp4_pow(base, exps[i]));
 }
 
+// out[slot] *= C for the slots a generated kernel wants scaled by an Fp4 constant: recs = (slot, c0, c1, c2, c3) x n
+__global__ void k_ext_scale_at(uint32_t* out, const uint32_t* __restrict__ recs, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* r = recs + 5 * (size_t)i;
+    const Fp4 c(Fp::raw(r[1]), Fp::raw(r[2]), Fp::raw(r[3]), Fp::raw(r[4]));
+    uint32_t* o = out + 4 * (size_t)r[0];
+    st_ext(o, ld_ext(o) * c);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // batch_evaluate_any.  Block (chunk, k): partial[k][chunk] = sum_{j in chunk} coeffs[which[k]][j] * x_k^j.
 // Lane t owns coefficients j = chunk*CH + i*256 + t (coalesced); term = c * X^i (X = x^256, table in LDS),
@@ -452,6 +462,11 @@ const char* launch_ext_powers_at(zkh_ctx* c, uint32_t* out, const uint32_t base[
     if (!n) return nullptr;
     k_ext_powers_at<<<(unsigned)ceil_div(n, TB), TB, 0, c->stream>>>(out, to_fp4(base), d_exps, n);
     return last_launch_error("ext_powers_at");
+}
+const char* launch_ext_scale_at(zkh_ctx* c, uint32_t* out, const uint32_t* d_recs, uint32_t n) {
+    if (!n) return nullptr;
+    k_ext_scale_at<<<(unsigned)ceil_div(n, TB), TB, 0, c->stream>>>(out, d_recs, n);
+    return last_launch_error("ext_scale_at");
 }
 }  // namespace zkh
 
