@@ -248,6 +248,18 @@ def seal_block(run: Run, lanes, segs, mine, prover_of=lambda ln: ln.prover):
     return receipts, t0, wit_s, seal_s
 
 
+def parity_pins():
+    """tests/upstream/parity_pins.json (written by tests/test_upstream_dropbox.py when upstream artefacts have been dropped into
+    tests/upstream/): which recalled details have been pinned against the real reference.  None: nothing has been dropped yet —
+    parity against the crates is unpinned."""
+    import json
+    try:
+        pins = json.load(open(os.path.join(ROOT, "tests", "upstream", "parity_pins.json")))
+        return {k: {"ok": v.get("ok"), "checked_at": v.get("checked_at")} for k, v in pins.items()}
+    except (OSError, ValueError):
+        return None
+
+
 def config_common(run: Run) -> dict:
     from zeth_amd.hal import HipHal
     v = HipHal.version()
@@ -255,7 +267,7 @@ def config_common(run: Run) -> dict:
             "poseidon2_consts": v.split("poseidon2_consts=")[-1].rstrip(")"), "host_placement_rank0": run.placement,
             "launcher": "ranks", "devices": run.devices, "devices_distinct": run.devices_distinct,
             "distinct_devices": len({(d.get("uuid") or d.get("pci_bus_id")) for d in (run.devices or [])}),
-            "rccl_probe": run.rccl, "rccl_world": run.world if run.rccl == "ok" else None}
+            "rccl_probe": run.rccl, "rccl_world": run.world if run.rccl == "ok" else None, "parity_pins": parity_pins()}
 
 
 # ---- the recursive fold driven from Python (round 3's two-phase form; the native executor is the default: succinct.py) ----
