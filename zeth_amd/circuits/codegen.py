@@ -48,6 +48,8 @@ REG_BUDGET = int(os.environ.get("ZKH_CODEGEN_REGS", "96"))      # values (taps +
 EPOCH_LOADS = int(os.environ.get("ZKH_CODEGEN_EPOCH", "48"))    # tap loads per offset epoch
 PART_WEIGHT = int(os.environ.get("ZKH_CODEGEN_PART", "6400"))   # value steps per generated kernel (~ one translation unit / code object)
 USE_LAZY = int(os.environ.get("ZKH_CODEGEN_LAZY", "1"))
+SOP_MIN = int(os.environ.get("ZKH_CODEGEN_SOPMIN", "3"))       # fewest terms an ADD/SUB tree needs to become a sum of products
+SOP_SLACK = int(os.environ.get("ZKH_CODEGEN_SOPSLACK", "4"))   # cost-model margin a sum of products must win by
 PREFETCH = int(os.environ.get("ZKH_CODEGEN_PREFETCH", "8"))    # tap loads issued this many constraints ahead of their first use
 # Order the constraints of a chain by tap-set locality (Plan.order_by_locality): 23 % (SYN-HEAVY) / 37 % (KECCAK-F) fewer tap
 # loads per point.  On its own it LOST (round 3, profiles/r03_eval_check_locality.txt: 12.41 -> 12.87 ms): it scatters the
@@ -474,7 +476,7 @@ class Plan:
             neg = sum(1 for t in terms if t[0] < 0 and not (t[1] == "v" and self.fp[t[2]][0] == OP_CONST)
                       and not (t[1] == "p" and OP_CONST in (self.fp[t[2]][0], self.fp[t[3]][0])))
             sop_cost = 4 * len(terms) + 2 * neg + 20 * n_red
-            if n_prod + n_plain >= 3 and sop_cost + 4 <= plain_cost:
+            if n_prod + n_plain >= SOP_MIN and sop_cost + SOP_SLACK <= plain_cost:
                 self.sop[r] = terms
                 self.absorbed.update(inner)
                 self.n_sop_terms += len(terms)
