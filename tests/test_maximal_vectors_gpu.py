@@ -151,3 +151,20 @@ def test_poseidon2_mix_on_extreme_states(hal, oracle):
     d = hal.copy_from("states", flat)
     hal.poseidon2_mix(d)
     assert np.array_equal(d.to_vec(), want)
+
+
+def test_syn_huge_loads_as_data_and_three_evaluators_agree(hal, oracle, tmp_path, monkeypatch):
+    """SYN-HUGE (circuits/syn_heavy.py syn_huge: > 250 k steps, > 2 k taps, ~15 k constraints) is not compiled into the library: it
+    arrives as data, its ~26 kernels are generated and compiled at load time (parts in parallel) and attached; generated == interpreter
+    == oracle on random and extreme vectors, and a whole small seal is byte-identical to the oracle's."""
+    from zeth_amd.circuits import syn_heavy
+    from zeth_amd.prover import Segment, SegmentProver
+    monkeypatch.setenv("ZKH_JIT_CACHE", str(tmp_path))
+    desc = syn_heavy.syn_huge()
+    prover = SegmentProver(hal, desc)
+    circ = prover.circuit
+    assert circ.kernel_kind() == "attached" and circ.compiled_parts() >= 16
+    _three_evaluators(hal, oracle, circ, desc, 5, patterns=("max", "half_hi", "rows_alternate"))
+    rec = prover.prove_segment(Segment(index=0, po2=9, seed=21, noise_seed=22, zk_cycles=200))
+    want = zko.OracleCircuit(oracle, desc).prove(9, 200, 21, 22)
+    assert np.array_equal(rec.seal, want)

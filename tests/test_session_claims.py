@@ -43,6 +43,28 @@ def session(oracle):
     return desc, oc, root, base, contribution, prove, receipt, iid
 
 
+def test_the_image_id_is_pinned_and_binds_the_program_only():
+    """Round-5 advisor finding: the id used to hash every control root control_roots.json held, so widening that file changed every
+    circuit's id.  Scheme v2 binds the description (a control root is a function of it) and the initial state; these values are the
+    pin — a change here breaks every issued Receipt.verify(expected_image_id) and must be a deliberate new scheme."""
+    from zeth_amd import prover
+    want = {"syn_session": "8fc994f3a1b9294d52d9de3a85152594ff9466981ecdac0a618bf79bb05e3b05",
+            "syn_chain": "15922210e2a743a2dc2f588bc567e17aad02c5807bb18d37d07df8f1932ef7e9"}
+    for name, fn in (("syn_session", syn_air.syn_session), ("syn_chain", syn_air.syn_chain)):
+        assert "".join(f"{int(w):08x}" for w in image_id(fn(), 11)) == want[name]
+    a = image_id(syn_air.syn_session(), 11)
+    assert not np.array_equal(a, image_id(syn_air.syn_session(), 12)) and not np.array_equal(a, image_id(syn_air.syn_chain(), 11))
+    # the verifier's table of control roots is not part of the id: emptying it changes nothing
+    saved = dict(prover._CONTROL_ROOTS_JSON) if isinstance(getattr(prover, "_CONTROL_ROOTS_JSON", None), dict) else None
+    try:
+        if saved is not None:
+            prover._CONTROL_ROOTS_JSON.clear()
+        assert np.array_equal(a, image_id(syn_air.syn_session(), 11))
+    finally:
+        if saved is not None:
+            prover._CONTROL_ROOTS_JSON.update(saved)
+
+
 def test_exit_codes_and_tagged_structs_as_recalled():
     assert [exit_code_pair(c) for c in ((EXIT_HALTED, 0), (EXIT_HALTED, 3), ("Paused", 1), (EXIT_SYSTEM_SPLIT, None), ("SessionLimit", None))] == [(0, 0), (0, 3), (1, 1), (2, 0), (2, 2)]
     for c in ((EXIT_HALTED, 5), ("Paused", 0), (EXIT_SYSTEM_SPLIT, None), ("SessionLimit", None)):

@@ -981,7 +981,13 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
                 const double te = now_s();
                 lk.lock();
                 fold_t += te - ts;
-                if (err) { errs.set(err, plan[id].kind == 1 ? "join" : plan[id].kind == 3 ? "join3" : plan[id].kind == 2 ? "lift2" : "lift"); cv.notify_all(); break; }
+                if (err) {
+                    const uint32_t k = plan[id].kind;
+                    errs.set(err, k == 1 ? "join" : k == 3 ? "join3" : k == 2 ? "lift2" : k == 4 ? "union (of two assumption receipts)" : k == 5 ? "resolve (the session's root against its assumptions)"
+                             : plan[id].family == 1 ? "lift (of an assumption receipt)" : "lift");
+                    cv.notify_all();
+                    break;
+                }
                 sc.on_node_done(id, now_s());
                 cv.notify_all();
                 continue;

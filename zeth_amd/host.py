@@ -415,21 +415,23 @@ def verify_session_integrity(receipts: Sequence[SegmentReceipt], initial_state: 
 
 
 
+IMAGE_ID_SCHEME = "zeth_amd.ImageId.v2"
+
+
 def image_id(circuit_desc, initial_state: int = 0) -> "np.ndarray":
     """The 8-word identifier a verifier is handed for a session — the analogue of zeth's Image ID (`compute_image_id(elf)`,
     /root/reference/crates/host/src/lib.rs:74-84: a SHA-256 Merkle digest of the guest program's initial memory image).  Here the
     "program" is the circuit and the state every session starts from:
-        tagged_struct("zeth_amd.ImageId", [SHA-256(description words), SHA-256(shipped control roots of the circuit, by size)], [initial state])
-    — collision resistant over the WHOLE description and the per-size control roots (round 4 hashed a 64-bit FNV of the description)."""
+        tagged_struct("zeth_amd.ImageId.v2", [SHA-256(description words)], [initial state])
+    Collision resistant over the WHOLE description.  Scheme v2 (round 6): the id binds the program ONLY.  v1 also hashed every
+    control root zeth_amd/circuits/control_roots.json happened to hold for po2 1 .. 24, so regenerating or widening that file (round 5
+    did: 13 .. 22 -> 13 .. 24) silently changed the id of every circuit and broke every issued `Receipt.verify(expected_image_id)`
+    (round-5 advisor finding).  A control root is a FUNCTION of (description, po2, zk cycles) — the Merkle root of the code group the
+    description generates — so binding the description binds them all; which root a seal is checked against is the verifier's own
+    table (`shipped_control_root`), not something the id has to carry.  tests/test_session_claims.py pins the value."""
     import numpy as np
-    from .prover import _CONTROL_ROOTS_JSON, desc_key, shipped_control_root      # noqa: F401
     d = np.ascontiguousarray(circuit_desc, dtype="<u4")
-    roots = b""
-    for po2 in range(1, 25):
-        r = shipped_control_root(d, po2)
-        if r is not None:
-            roots += int(po2).to_bytes(4, "little") + np.asarray(r, dtype="<u4").tobytes()
-    return np.array(tagged_struct("zeth_amd.ImageId", [sha256_words(d.tobytes()), sha256_words(roots)], [int(initial_state) & 0xFFFFFFFF]), dtype=np.uint32)
+    return np.array(tagged_struct(IMAGE_ID_SCHEME, [sha256_words(d.tobytes())], [int(initial_state) & 0xFFFFFFFF]), dtype=np.uint32)
 
 
 def _is_session_circuit(circuit_desc) -> bool:
