@@ -122,7 +122,7 @@ def test_the_session_launcher_and_the_rccl_probe_on_one_gpu():
         assert "INSIDE the clock" in cfg["workload"] and max(len(k) for k in cfg) <= 32
     assert s8["config"]["devices_distinct"] is False and s1["config"]["devices_distinct"] is True
     assert s8["value"] > 41.0 and s1["value"] > 41.0                              # one process, no launcher: the GPU's rate
-    p = json.load(open(os.path.join(ROOT, "profiles", "r06_rccl_probe_world1.json")))
+    p = json.loads(open(os.path.join(ROOT, "profiles", "r06_rccl_probe_world1.json")).read().splitlines()[0])     # (RCCL prints its version banner after it)
     assert p["rccl_probe"] == "ok" and p["rccl_world"] == 1 and p["hung"] is False
     f = _line("r06_2rank_forced_rccl_one_gpu.json")
     assert f["n_gpus"] == 2 and f["config"]["rccl_probe"].startswith("unavailable (") and f["config"]["rccl_world"] is None and f["value"] > 0
