@@ -54,9 +54,6 @@ def parse_args(argv=None):
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("ZKH_INFLIGHT", "3")),
                     help="segments sealed concurrently per GPU (one host thread + HIP stream each); 1 = strictly serial")
     g = ap.add_argument_group("segment config: what else the default run measures")
-    g.add_argument("--overlap-code-commit", action="store_true",
-                   help="every lane's prover commits the code group on a second stream beside the data group (zkh_prover_set_overlap): "
-                        "the single-seal latency lever of DESIGN.md §9; byte-identical seals")
     g.add_argument("--no-cpu-baseline", action="store_true")
     g.add_argument("--cpu-full-host", action="store_true",
                    help="cpu_baseline: a larger sample for both legs (the po2-20 unit itself alone, 1/16-unit seals on every core): +~45 s")

@@ -160,7 +160,7 @@ class Lane:
         from zeth_amd.hal import HipHal
         from zeth_amd.prover import SegmentProver
         self.hal = HipHal(run.device)                # raises if the HIP library / GPU is missing: no fallback
-        self.prover = SegmentProver(self.hal, run.desc, resident_code_group=resident, overlap_code_commit=bool(getattr(run.args, "overlap_code_commit", False)))
+        self.prover = SegmentProver(self.hal, run.desc, resident_code_group=resident)
         self.join_prover = SegmentProver(self.hal, join_desc) if with_join else None
         self.seal_s, self.witgen_s, self.err = [], [], None
         self.last, self.sealed = None, []
@@ -265,7 +265,6 @@ def config_common(run: Run) -> dict:
     v = HipHal.version()
     return {"po2": run.args.po2, "circuit": run.args.circuit, "inflight_per_gpu": run.inflight, "ranks_per_gpu": run.ranks_per_gpu, "library": v,
             "poseidon2_consts": v.split("poseidon2_consts=")[-1].rstrip(")"), "host_placement_rank0": run.placement,
-            "overlap_code_commit": bool(getattr(run.args, "overlap_code_commit", False)),
             "launcher": "ranks", "devices": run.devices, "devices_distinct": run.devices_distinct,
             "distinct_devices": len({(d.get("uuid") or d.get("pci_bus_id")) for d in (run.devices or [])}),
             "rccl_probe": run.rccl, "rccl_world": run.world if run.rccl == "ok" else None, "parity_pins": parity_pins()}

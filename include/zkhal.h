@@ -263,11 +263,6 @@ const char* zkh_syn_witgen_trace(zkh_ctx*, const zkh_circuit*, size_t po2, size_
 
 /* ---- segment prover: SegmentProver::prove_segment + risc0_zkp::prove::Prover ---- */
 const char* zkh_prover_create(zkh_ctx*, const zkh_circuit*, zkh_prover** out);
-/* on != 0: the code group's commitment of every later seal runs on a second stream of the same device beside the data group's (the
- * two depend on no challenge and not on each other); seals are byte-identical.  Helps ONE seal alone (latency); with several seals in
- * flight per GPU the other seals already fill the same holes.  Default off.  Costs a second context (tables, a pool that caches the
- * code group's blocks: ~0.6 GB at po2 20). */
-const char* zkh_prover_set_overlap(zkh_prover*, int on);
 void zkh_prover_destroy(zkh_prover*);   /* before zkh_ctx_destroy: a prover may hold device buffers (zkh_prover_cache_code) */
 /* Seal one segment of a SYN-AIR-family circuit (kind 1: the accum witness generator is zkh_syn_accum) whose code/data
  * traces are already resident in HBM (W x 2^po2 each); out_global has OUTPUT_SIZE words.  On success *seal is a

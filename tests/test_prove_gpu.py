@@ -228,19 +228,3 @@ def test_wide_circuit_seal_bit_exact(hal, oracle, tmp_path, monkeypatch):
     want = oc.prove(11, 700, seg.seed, seg.noise_seed)
     assert np.array_equal(receipt.seal, want)
     receipt.verify(desc, prover.control_root(11, 700))
-
-
-@pytest.mark.parametrize("po2", [13, 16, 20])
-def test_code_commit_on_a_second_stream_gives_the_same_seal(hal, po2):
-    """zkh_prover_set_overlap: the code group's commitment runs on a second stream (a context of its own) beside the data group's;
-    the transcript still absorbs code, then data — seals are byte-identical, many times over (the side pool recycles its blocks), and
-    also after the Poseidon2 tables of the main context were replaced and restored (the side context follows them)."""
-    from zeth_amd.circuits import syn_air
-    from zeth_amd.prover import Segment, SegmentProver
-    desc = syn_air.syn_a() if po2 == 20 else syn_air.syn_small()
-    plain, both = SegmentProver(hal, desc), SegmentProver(hal, desc, overlap_code_commit=True)
-    for k in range(4 if po2 < 20 else 2):
-        seg = Segment(index=k, po2=po2, seed=40 + k, noise_seed=7 + k)
-        a, b = plain.prove_segment(seg), both.prove_segment(seg)
-        assert np.array_equal(a.seal, b.seal), (po2, k)
-    b.verify(desc, plain.control_root(po2))

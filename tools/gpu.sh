@@ -18,7 +18,6 @@
 #                refuse), the in-process launcher (--launcher session, 8 devices x 1 lane and 1 device x 3 lanes), the RCCL probe at world 1
 #   huge         SYN-HUGE (> 250 k steps, > 2 k taps, ~15 k constraints) loaded as data: generator / hipcc / code-object figures, eval_check and
 #                seal ms at po2 20, three evaluators + extreme vectors (tools/syn_huge_report.py); the same report for SYN-HEAVY beside it
-#   overlap      A/B of the code-group commit on a second stream (bench.py --overlap-code-commit): one seal alone and three in flight, 3 repeats each
 #   profiles     everything profiles/ holds (tools/collect_profiles.sh)
 #   big          po2 21 / 22 segments
 #   soak         1000 distinct segments through the g++ driver
@@ -121,28 +120,6 @@ for n in ("syn_huge", "syn_heavy"):
         print(n, "no report:", e)
 PY
   grep real $O/*.time; tail -3 $O/syn_huge.err | grep -v amdgpu.ids ;;
-overlap)
-  O=gpurun_out/${1:-overlap}; mkdir -p $O
-  F="--no-cpu-baseline --no-heavy --no-resident --no-block --no-live-traffic --no-certify"
-  for i in 1 2 3; do for tag in off on; do
-    x=""; [ $tag = on ] && x="--overlap-code-commit"
-    timeout 300 python bench.py --inflight 1 --steps 30 $F $x > $O/serial_${tag}_$i.json 2>> $O/err.txt
-    timeout 300 python bench.py $F $x > $O/depth3_${tag}_$i.json 2>> $O/err.txt
-  done; done
-  python - $O <<'PY'
-import json, sys
-O = sys.argv[1]
-out = {}
-for shape in ("serial", "depth3"):
-    for tag in ("off", "on"):
-        ls = [json.loads(open(f"{O}/{shape}_{tag}_{i}.json").read().strip().splitlines()[-1]) for i in (1, 2, 3)]
-        out[f"{shape}_{tag}"] = {"segments_per_s": [round(l["value"], 3) for l in ls], "ms_per_step": [round(l["ms_per_step"], 3) for l in ls],
-                                 "seal_wall_clock_unloaded_ms": [round(1e3 * l["seal_wall_clock_unloaded_s"], 3) for l in ls],
-                                 "seals_verified": [l.get("timed_seals_verified") for l in ls]}
-json.dump(out, open(f"{O}/overlap_ab.json", "w"), indent=1)
-print(json.dumps(out))
-PY
-  grep -v amdgpu.ids $O/err.txt | tail -3 ;;
 chained)
   O=gpurun_out/${1:-chained}; mkdir -p $O        # a chained block (claim continuity) and the same block with the host-preflight witness, full size
   timeout 600 python bench.py --config block --chained --no-cpu-baseline > $O/bench_block_chained.json 2> $O/err.txt; line $O/bench_block_chained.json

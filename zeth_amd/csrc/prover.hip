@@ -198,11 +198,6 @@ struct zkh_prover {
     const zkh_circuit* circuit;
     HostHash hash;
     std::map<size_t, std::unique_ptr<PolyGroup>> code_cache;   // po2 -> the committed code group, resident (zkh_prover_cache_code)
-    // zkh_prover_set_overlap: the code group's commit runs on a second stream of the same device (a context of its own: stream, pool,
-    // tables) beside the data group's — the two commitments depend on no challenge and on each other not at all
-    bool overlap = false;
-    zkh_ctx* side = nullptr;
-    hipEvent_t ev_main = nullptr, ev_side = nullptr;
 };
 
 extern "C" const char* zkh_prover_create(zkh_ctx* ctx, const zkh_circuit* circuit, zkh_prover** out) {
@@ -210,42 +205,7 @@ extern "C" const char* zkh_prover_create(zkh_ctx* ctx, const zkh_circuit* circui
     *out = new zkh_prover{ctx, circuit, HostHash{ctx->h_rc, ctx->h_diag}, {}};
     return nullptr;
 }
-extern "C" void zkh_prover_destroy(zkh_prover* p) {
-    if (!p) return;
-    p->code_cache.clear();
-    if (p->side) {
-        (void)hipStreamSynchronize(p->ctx->stream);
-        if (p->ev_main) (void)hipEventDestroy(p->ev_main);
-        if (p->ev_side) (void)hipEventDestroy(p->ev_side);
-        zkh_ctx_destroy(p->side);
-    }
-    delete p;
-}
-// One seal alone leaves the GPU partly idle wherever a kernel is latency-bound (the narrow layers of a Merkle tree, a 16-column NTT pass
-// that does not fill 256 CUs).  The code and data commitments of a seal are independent, so the code group's kernels can fill those
-// holes of the data group's — on a second stream.  Seals are byte-identical (the transcript absorbs code, then data, as before).
-// Off by default: with three seals in flight the other seals already fill the holes (DESIGN.md §9 has the A/B).
-extern "C" const char* zkh_prover_set_overlap(zkh_prover* pr, int on) {
-    ZKH_REQUIRE(pr, "prover_set_overlap: null prover");
-    pr->overlap = on != 0;
-    if (pr->overlap && !pr->side) {
-        ZKH_TRY(zkh_ctx_create(pr->ctx->device, "poseidon2", &pr->side));
-        ZKH_HIP(hipEventCreateWithFlags(&pr->ev_main, hipEventDisableTiming));
-        ZKH_HIP(hipEventCreateWithFlags(&pr->ev_side, hipEventDisableTiming));
-    }
-    return nullptr;
-}
-// the side context hashes with the tables of the main one (a caller may have replaced them: zkh_poseidon2_set_constants)
-static const char* side_sync_tables(zkh_prover* pr) {
-    zkh_ctx *m = pr->ctx, *s = pr->side;
-    if (memcmp(m->h_rc, s->h_rc, sizeof m->h_rc) == 0 && memcmp(m->h_diag, s->h_diag, sizeof m->h_diag) == 0) return nullptr;
-    memcpy(s->h_rc, m->h_rc, sizeof m->h_rc);
-    memcpy(s->h_diag, m->h_diag, sizeof m->h_diag);
-    ZKH_HIP(hipStreamSynchronize(s->stream));
-    ZKH_HIP(hipMemcpy(s->tab.rc, m->h_rc, sizeof m->h_rc, hipMemcpyHostToDevice));
-    ZKH_HIP(hipMemcpy(s->tab.diag, m->h_diag, sizeof m->h_diag, hipMemcpyHostToDevice));
-    return nullptr;
-}
+extern "C" void zkh_prover_destroy(zkh_prover* p) { delete p; }
 extern "C" void zkh_free_seal(uint32_t* s) { free(s); }
 
 static const char* commit_group_enqueue(zkh_ctx* c, PolyGroup& pg, const zkh_buf* trace, size_t count, size_t n) {
@@ -274,10 +234,6 @@ struct zkh_seal_job {
     Iop iop;
     PolyGroup groups[3];
     std::vector<uint32_t> out_global, mix_global;
-    bool side_used = false;
-    // the code group's buffers came from the side context's pool: they go back to it only when nothing on the main stream can still
-    // read them (the normal end of a seal has just synchronised; an aborted one has not)
-    ~zkh_seal_job() { if (side_used && pr) (void)hipStreamSynchronize(pr->ctx->stream); }
 };
 
 extern "C" void zkh_prove_abort(zkh_seal_job* job) { delete job; }
@@ -331,21 +287,9 @@ extern "C" const char* zkh_prove_begin(zkh_prover* pr, size_t po2, const zkh_buf
     }
     // ---- commit code, data: neither commitment depends on a challenge, so both groups are queued before the first
     // root is read back; the transcript still absorbs them in upstream's order (code, then data)
-    // (zkh_prover_set_overlap: the code group on the side stream, which first waits for everything queued on the main one — the code
-    // trace may still be being written — and which the main stream waits for before it goes on: whatever the caller frees or
-    // overwrites after this call is ordered behind the side stream's reads.  Not while the profiler brackets this context's kernels.)
-    const bool side = code && pr->overlap && pr->side && !c->prof;
-    if (side) {
-        ZKH_TRY(side_sync_tables(pr));
-        job->side_used = true;
-        ZKH_HIP(hipEventRecord(pr->ev_main, c->stream));
-        ZKH_HIP(hipStreamWaitEvent(pr->side->stream, pr->ev_main, 0));
-        ZKH_TRY(commit_group_enqueue(pr->side, job->groups[GROUP_CODE], code, wc, n));
-        ZKH_HIP(hipEventRecord(pr->ev_side, pr->side->stream));
-    } else if (code) ZKH_TRY(commit_group_enqueue(c, job->groups[GROUP_CODE], code, wc, n));
+    if (code) ZKH_TRY(commit_group_enqueue(c, job->groups[GROUP_CODE], code, wc, n));
     else ZKH_TRY(job->groups[GROUP_CODE].share_from(*pr->code_cache[po2]));      // resident: nothing to compute
     ZKH_TRY(commit_group_enqueue(c, job->groups[GROUP_DATA], data, wd, n));
-    if (side) ZKH_HIP(hipStreamWaitEvent(c->stream, pr->ev_side, 0));
     if (code) ZKH_TRY(commit_group_finish(c, iop, job->groups[GROUP_CODE]));
     else job->groups[GROUP_CODE].merkle.commit(iop);
     ZKH_TRY(commit_group_finish(c, iop, job->groups[GROUP_DATA]));

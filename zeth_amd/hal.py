@@ -201,7 +201,6 @@ ABI = {
     "zkh_parse_cpulist": (_err, [C.c_char_p, C.POINTER(_i), _sz, C.POINTER(_sz)]),
     "zkh_pci_numa_cpus": (_err, [C.c_char_p, C.c_char_p, C.POINTER(_i), C.POINTER(_i), _sz, C.POINTER(_sz)]),
     "zkh_device_numa_node": (_err, [_i, C.POINTER(_i), C.c_char_p]),
-    "zkh_prover_set_overlap": (_err, [_vp, _i]),
     "zkh_device_identity": (_err, [_i, C.c_char_p, C.c_char_p, C.POINTER(_i), C.c_char_p, C.POINTER(_i)]),
     "zkh_bind_thread_to_device": (_err, [_i, _sz, _sz, C.POINTER(_i), C.POINTER(_sz)]),
     "zkh_prof_enable": (_err, [_vp, _i]),

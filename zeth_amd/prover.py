@@ -116,19 +116,15 @@ class SegmentReceipt:
 class SegmentProver:
     """`SegmentProverImpl<H, C>` analogue bound to one HipHal (one GPU)."""
 
-    def __init__(self, hal: "_hal.HipHal", circuit_desc=None, resident_code_group: bool = False, overlap_code_commit: bool = False):
+    def __init__(self, hal: "_hal.HipHal", circuit_desc=None, resident_code_group: bool = False):
         """resident_code_group: keep the committed code (control) group of each segment size in HBM instead of re-committing
         it for every segment (zkh_prover_cache_code): the group is a function of (circuit, po2, zk_cycles) alone.  Off by
-        default — upstream's SegmentProver recomputes it, and so does the benchmark's headline number.
-        overlap_code_commit: the code group's commitment on a second stream beside the data group's (zkh_prover_set_overlap): one
-        seal alone gets shorter, seals stay byte-identical."""
+        default — upstream's SegmentProver recomputes it, and so does the benchmark's headline number."""
         self.hal = hal
         self.circuit = hal.load_circuit(syn_air.syn_a() if circuit_desc is None else circuit_desc)
         h = C.c_void_p()
         _hal._check(_hal._lib.zkh_prover_create(hal.ctx, self.circuit.h, C.byref(h)))
         self.h = h
-        if overlap_code_commit:
-            _hal._check(_hal._lib.zkh_prover_set_overlap(self.h, 1))
         self.resident_code_group = resident_code_group
         self._resident: Dict[int, int] = {}                 # po2 -> zk_cycles of the resident code group
         self._roots: Dict[Tuple[int, int], np.ndarray] = {}
