@@ -110,13 +110,6 @@ struct zkh_ctx {
     uint32_t* h_fail = nullptr;                  // pinned mirror
     bool fail_armed = false;                     // an op that may raise it was enqueued since the last check
     std::map<void*, size_t> host_blocks;         // pinned host memory handed to the caller (zkh_host_alloc): ptr -> bytes
-    // batched read-backs (hal.hip d2h_async / d2h_flush): several device-to-host copies, ONE synchronisation — a Fiat-Shamir round
-    // trip that fetches k things (the tree tops of two groups, the tap evaluations of four groups, the openings of seven trees) costs
-    // one host turnaround instead of k (each 30 - 60 us on an idle stream: profiles/r06_seal_gaps.json)
-    uint32_t* readback = nullptr;                // pinned
-    size_t readback_words = 0, readback_used = 0;
-    struct Readback { uint32_t* host; size_t at, n; };
-    std::vector<Readback> readback_pending;
 };
 
 namespace zkh {
@@ -124,12 +117,6 @@ namespace zkh {
 const char* pool_alloc(zkh_ctx* c, size_t bytes, void** out);
 void pool_free(zkh_ctx* c, void* p, size_t bytes);
 const char* new_buf(zkh_ctx* c, size_t n_words, bool zero, zkh_buf** out);
-const char* d2h_async(zkh_ctx* c, const zkh_buf* b, uint32_t* host, size_t off, size_t n);   // `host` is filled by the next d2h_flush
-const char* d2h_flush(zkh_ctx* c);                                                             // one sync (+ the sticky failure word)
-// forget the read-backs that have not been delivered (their host destinations are about to go out of scope: an error path);
-// the copies themselves land in the context's pinned staging area and harm nothing
-inline void d2h_cancel(zkh_ctx* c) { c->readback_pending.clear(); c->readback_used = 0; }
-struct ReadbackScope { zkh_ctx* c; explicit ReadbackScope(zkh_ctx* ctx) : c(ctx) {} ~ReadbackScope() { d2h_cancel(c); } };
 void prof_begin(zkh_ctx* c, const char* name, double bytes);
 void prof_end(zkh_ctx* c);
 const char* ensure_pinned(zkh_ctx* c, size_t words);

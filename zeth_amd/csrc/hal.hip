@@ -233,7 +233,6 @@ extern "C" void zkh_ctx_destroy(zkh_ctx* c) {
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
     if (c->pinned) (void)hipHostFree(c->pinned);
-    if (c->readback) (void)hipHostFree(c->readback);
     if (c->d_fail) (void)hipFree(c->d_fail);
     if (c->h_fail) (void)hipHostFree(c->h_fail);
     for (auto& kv : c->host_blocks) (void)hipHostFree(kv.first);
@@ -261,10 +260,6 @@ static const char* sync_checked(zkh_ctx* c) {
     if (c->fail_armed) ZKH_HIP(hipMemcpyAsync(c->h_fail, c->d_fail, 8, hipMemcpyDeviceToHost, c->stream));
     ZKH_HIP(hipStreamSynchronize(c->stream));
     c->stage_used = 0;
-    // batched read-backs (d2h_async) are delivered by WHICHEVER sync comes first
-    for (const auto& r : c->readback_pending) memcpy(r.host, c->readback + r.at, r.n * 4);
-    c->readback_pending.clear();
-    c->readback_used = 0;
     return check_device_fail(c);
 }
 extern "C" const char* zkh_sync(zkh_ctx* c) {
@@ -332,28 +327,6 @@ extern "C" const char* zkh_read(zkh_ctx* c, const zkh_buf* b, uint32_t* host, si
     if (n) ZKH_HIP(hipMemcpyAsync(host, b->ptr() + off, n * 4, hipMemcpyDeviceToHost, c->stream));
     return sync_checked(c);
 }
-namespace zkh {
-constexpr size_t READBACK_WORDS = (size_t)1 << 20;          // 4 MiB pinned: a po2-24 seal's openings are 0.4 M words
-const char* d2h_async(zkh_ctx* c, const zkh_buf* b, uint32_t* host, size_t off, size_t n) {
-    bind_thread(c);
-    ZKH_REQUIRE(n <= b->len && off <= b->len - n, "read [%zu, +%zu) out of range (size %zu)", off, n, b->len);
-    if (!n) return nullptr;
-    if (!c->readback) {
-        ZKH_HIP(hipHostMalloc((void**)&c->readback, READBACK_WORDS * 4, hipHostMallocDefault));
-        c->readback_words = READBACK_WORDS;
-    }
-    if (n > c->readback_words) { ZKH_TRY(d2h_flush(c)); return zkh_read(c, b, host, off, n); }     // larger than the staging area: on its own
-    if (c->readback_used + n > c->readback_words) ZKH_TRY(d2h_flush(c));
-    ZKH_HIP(hipMemcpyAsync(c->readback + c->readback_used, b->ptr() + off, n * 4, hipMemcpyDeviceToHost, c->stream));
-    c->readback_pending.push_back({host, c->readback_used, n});
-    c->readback_used += n;
-    return nullptr;
-}
-const char* d2h_flush(zkh_ctx* c) {
-    bind_thread(c);
-    return sync_checked(c);
-}
-}  // namespace zkh
 extern "C" const char* zkh_write(zkh_ctx* c, zkh_buf* b, const uint32_t* host, size_t off, size_t n) {
     bind_thread(c);
     ZKH_REQUIRE(n <= b->len && off <= b->len - n, "write [%zu, +%zu) out of range (size %zu)", off, n, b->len);   // no wrap-around

@@ -106,11 +106,6 @@ struct Merkle {
         top.resize((2 * top_size - 1) * 8);
         return zkh_read(c, nodes, top.data(), 8, top.size());
     }
-    // the same without the synchronisation: `top` is valid after the next d2h_flush / zkh_read / zkh_sync of the context
-    const char* fetch_top_async(zkh_ctx* c) {
-        top.resize((2 * top_size - 1) * 8);
-        return d2h_async(c, nodes, top.data(), 8, top.size());
-    }
     const uint32_t* root() const { return top.data(); }
     void commit(Iop& iop) const {
         iop.write(top.data() + (top_size - 1) * 8, top_size * 8);  // nodes[top_size .. 2*top_size)
@@ -123,9 +118,9 @@ struct Merkle {
         ZKH_TRY(zkh_alloc(c, "open", words_per_query() * idx.size(), 0, out.out()));
         return zkh_merkle_open(c, matrix, nodes, rows, cols, idx.data(), idx.size(), out);
     }
-    const char* open_fetch(zkh_ctx* c, const Buf& out, size_t n_idx, std::vector<uint32_t>& result) const {      // (delivered by the next d2h_flush)
+    const char* open_fetch(zkh_ctx* c, const Buf& out, size_t n_idx, std::vector<uint32_t>& result) const {
         result.resize(words_per_query() * n_idx);
-        return d2h_async(c, out, result.data(), 0, result.size());
+        return zkh_read(c, out, result.data(), 0, result.size());
     }
 };
 
@@ -277,7 +272,6 @@ extern "C" const char* zkh_prove_begin(zkh_prover* pr, size_t po2, const zkh_buf
     const size_t out_size = cir->global_size[GLOBAL_OUT];
     std::unique_ptr<zkh_seal_job> job(new zkh_seal_job());
     job->pr = pr; job->po2 = po2;
-    ReadbackScope readbacks(c);             // a batched read-back never outlives the buffers it fills (error paths)
     Iop& iop = job->iop;
     iop.rng.h = &pr->hash;
     // ---- header: out globals + po2, both as field elements (write_field_elem_slice), bound into the transcript ----
@@ -296,12 +290,9 @@ extern "C" const char* zkh_prove_begin(zkh_prover* pr, size_t po2, const zkh_buf
     if (code) ZKH_TRY(commit_group_enqueue(c, job->groups[GROUP_CODE], code, wc, n));
     else ZKH_TRY(job->groups[GROUP_CODE].share_from(*pr->code_cache[po2]));      // resident: nothing to compute
     ZKH_TRY(commit_group_enqueue(c, job->groups[GROUP_DATA], data, wd, n));
-    // ONE host round trip for both tops (two synchronous reads cost two host turnarounds on an idle stream)
-    if (code) ZKH_TRY(job->groups[GROUP_CODE].merkle.fetch_top_async(c));
-    ZKH_TRY(job->groups[GROUP_DATA].merkle.fetch_top_async(c));
-    ZKH_TRY(d2h_flush(c));
-    job->groups[GROUP_CODE].merkle.commit(iop);
-    job->groups[GROUP_DATA].merkle.commit(iop);
+    if (code) ZKH_TRY(commit_group_finish(c, iop, job->groups[GROUP_CODE]));
+    else job->groups[GROUP_CODE].merkle.commit(iop);
+    ZKH_TRY(commit_group_finish(c, iop, job->groups[GROUP_DATA]));
     // ---- accum mix challenges ----
     job->mix_global.resize(cir->global_size[GLOBAL_MIX] ? cir->global_size[GLOBAL_MIX] : 1);
     for (size_t i = 0; i < cir->global_size[GLOBAL_MIX]; i++) job->mix_global[i] = iop.rng.random_elem();
@@ -365,7 +356,6 @@ static const char* prove_finish_impl(zkh_seal_job* job, const zkh_buf* accum_tra
     const size_t n = (size_t)1 << po2, dom = n * ZKH_INV_RATE;
     const size_t wa = cir->group_size[GROUP_ACCUM];
     Iop& iop = job->iop;
-    ReadbackScope readbacks(c);             // a batched read-back never outlives the buffers it fills (error paths)
     PolyGroup* groups = job->groups;
     const std::vector<uint32_t>& mix_global = job->mix_global;
     const uint32_t* out_global = job->out_global.data();
@@ -429,11 +419,10 @@ static const char* prove_finish_impl(zkh_seal_job* job, const zkh_buf* accum_tra
         }
         pos = 0;
         for (uint32_t g = 0; g < 3; g++) {
-            if (counts[g]) ZKH_TRY(d2h_async(c, dout[g], (uint32_t*)&eval_u[pos], 0, 4 * counts[g]));
+            if (counts[g]) ZKH_TRY(zkh_read(c, dout[g], (uint32_t*)&eval_u[pos], 0, 4 * counts[g]));
             pos += counts[g];
         }
-        ZKH_TRY(d2h_async(c, dout[3], (uint32_t*)&coeff_u[n_taps], 0, 4 * ZKH_CHECK_SIZE));
-        ZKH_TRY(d2h_flush(c));                     // one round trip for the four evaluations
+        ZKH_TRY(zkh_read(c, dout[3], (uint32_t*)&coeff_u[n_taps], 0, 4 * ZKH_CHECK_SIZE));
         pos = 0;
         for (const Reg& r : cir->regs) {
             poly_interpolate(&coeff_u[pos], &all_xs[pos], &eval_u[pos], r.size);
@@ -491,17 +480,7 @@ static const char* prove_finish_impl(zkh_seal_job* job, const zkh_buf* accum_tra
         ZKH_TRY(zkh_combos_prepare(c, combos, pos.data(), (const uint32_t*)vals.data(), pos.size()));
     }
     // combos_divide: by prod (x - z w^-back) per combo, the check combo by (x - z^4); remainders must vanish.  One call:
-    // the r-th divisions of all combos share their launches.  The remainders ride back with the NEXT round trip (the first FRI
-    // commitment's top, or the final coefficients): the check costs no host turnaround of its own.
-    Buf rems;
-    std::vector<uint32_t> rem_words;
-    bool rems_checked = false;
-    auto check_rems = [&]() -> const char* {
-        if (rems_checked) return nullptr;
-        rems_checked = true;
-        for (uint32_t w : rem_words) ZKH_REQUIRE(w == 0, "prove_segment: DEEP quotient has a non-zero remainder (witness does not satisfy the constraints)");
-        return nullptr;
-    };
+    // the r-th divisions of all combos share their launches.
     {
         std::vector<Fp4> pts;
         std::vector<uint32_t> begin(1, 0);
@@ -510,10 +489,12 @@ static const char* prove_finish_impl(zkh_seal_job* job, const zkh_buf* accum_tra
             else for (uint32_t b : cir->combos[i]) pts.push_back(z * fp_pow(back_one, b));
             begin.push_back((uint32_t)pts.size());
         }
+        Buf rems;
         ZKH_TRY(zkh_alloc(c, "rems", 4 * pts.size(), 1, rems.out()));
         ZKH_TRY(zkh_combos_divide_all(c, combos, n, combo_count + 1, (const uint32_t*)pts.data(), begin.data(), rems));
-        rem_words.resize(4 * pts.size());
-        ZKH_TRY(d2h_async(c, rems, rem_words.data(), 0, rem_words.size()));
+        std::vector<uint32_t> r(4 * pts.size());
+        ZKH_TRY(zkh_read(c, rems, r.data(), 0, r.size()));
+        for (uint32_t w : r) ZKH_REQUIRE(w == 0, "prove_segment: DEEP quotient has a non-zero remainder (witness does not satisfy the constraints)");
     }
     Buf final_coeffs;
     ZKH_TRY(zkh_alloc(c, "final_poly_coeffs", n * ZKH_EXT_SIZE, 0, final_coeffs.out()));
@@ -533,7 +514,6 @@ static const char* prove_finish_impl(zkh_seal_job* job, const zkh_buf* accum_tra
             ZKH_TRY(zkh_batch_expand_into_evaluate_ntt(c, r->evaluated, cur, ZKH_EXT_SIZE, 2));
             ZKH_TRY(r->merkle.enqueue(c, r->evaluated, r->domain / ZKH_FRI_FOLD, ZKH_FRI_FOLD * ZKH_EXT_SIZE));
             ZKH_TRY(r->merkle.fetch_top(c));
-            ZKH_TRY(check_rems());
             r->merkle.commit(iop);
             const Fp4 fold_mix = iop.rng.random_ext();
             ZKH_TRY(zkh_alloc(c, "out_coeffs", size / ZKH_FRI_FOLD * ZKH_EXT_SIZE, 0, r->coeffs.out()));
@@ -547,7 +527,6 @@ static const char* prove_finish_impl(zkh_seal_job* job, const zkh_buf* accum_tra
         ZKH_TRY(zkh_batch_bit_reverse(c, fin, ZKH_EXT_SIZE));
         std::vector<uint32_t> fw(cur->len);
         ZKH_TRY(zkh_read(c, fin, fw.data(), 0, fw.size()));
-        ZKH_TRY(check_rems());
         iop.write(fw.data(), fw.size());
         uint32_t dg[8];
         pr->hash.hash_elems(fw.data(), fw.size(), dg);
@@ -569,7 +548,6 @@ static const char* prove_finish_impl(zkh_seal_job* job, const zkh_buf* accum_tra
         }
         for (int t = 0; t < 4; t++) ZKH_TRY(trees[t]->open_fetch(c, dev[t], ZKH_QUERIES, opened[t]));
         for (size_t r = 0; r < rounds.size(); r++) ZKH_TRY(rounds[r]->merkle.open_fetch(c, dev[4 + r], ZKH_QUERIES, opened[4 + r]));
-        ZKH_TRY(d2h_flush(c));                     // one round trip for every tree's openings
         for (int q = 0; q < ZKH_QUERIES; q++) {
             for (int t = 0; t < 4; t++) {
                 const size_t w = trees[t]->words_per_query();
