@@ -251,6 +251,21 @@ def add_roofline(line, prof, ref, args, inflight, widths, n, device=0, live=True
                      "source": "measured in this run: rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE (its own pass, kernel trace only) around a child run "
                                "with one serial seal; wave_instr and simd_cycles (= GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) are per launch; "
                                "half_rate_share is static (the kernel's opcode table: profiles/r03_hash_rows_isa_histogram.txt)"}
+        if dom_name == "hash_rows" and v.get("simd_cycles") and v.get("launches"):
+            # ... and against the ALGORITHMIC work of SURVEY.md §8d: a Poseidon2 permutation of width 24 is 1 356 Montgomery products
+            # (8 full rounds x 24 x 4 for x^7, 21 partial rounds x (4 + 24 diagonal), M_ext in f64 counted as its multiplies) = 3
+            # half-rate instructions each (4 issue cycles per wave64) + ~3 k full-rate additions (2 cycles): 22.3 k SIMD-cycles per
+            # 64 permutations.  What the launches of one seal really spent per wave-permutation says how close the kernel is to THAT.
+            perms = sum(-(-w // 16) for w in (wc, wd, wa, 16)) * 4 * n
+            deg = n
+            while deg > 256:
+                perms += 4 * (4 * deg // 16)
+                deg //= 16
+            floor = 1356 * 3 * 4 + 3000 * 2
+            cpw = v["simd_cycles"] * v["launches"] / (perms / 64.0)
+            r["valu"].update(permutations_per_seal=perms, cycles_per_wave_permutation=cpw, algorithmic_floor_cycles=floor,
+                             frac_of_algorithmic_floor=floor / cpw,
+                             frac_of_algorithmic_floor_at_2p4GHz=(floor / cpw) * (v["clock_GHz"] / 2.4) if v.get("clock_GHz") else None)
     if counters and counters.get("seal_valu"):
         s = counters["seal_valu"]
         clock = s["clock_GHz"] or 0.0
@@ -284,6 +299,8 @@ def add_roofline(line, prof, ref, args, inflight, widths, n, device=0, live=True
             cfg["dominant_kernel_valu_issue_frac"] = round(r["valu"]["issue_frac"], 4)
         if r.get("seal_valu_issue_frac") is not None:
             cfg["seal_valu_issue_frac"] = round(r["seal_valu_issue_frac"], 4)
+        if isinstance(r.get("valu"), dict) and r["valu"].get("frac_of_algorithmic_floor") is not None:
+            cfg["dominant_valu_algorithmic_frac"] = round(r["valu"]["frac_of_algorithmic_floor"], 4)
         cfg["valu_issue_peak_half_rate_class"] = HALF_RATE_ISSUE_PEAK
     div = 1 if ref else args.steps
     line["kernels"] = [{"name": p["name"], "calls_per_seal": p["calls"] / div,
