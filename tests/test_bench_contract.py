@@ -30,6 +30,10 @@ def test_default_line_has_every_contract_field():
     v = r["valu"]
     assert abs(v["issue_frac"] - v["wave_instr"] / v["simd_cycles"]) < 1e-9 and 0.2 < v["issue_frac"] <= 0.25 and v["half_rate_share"] == 0.85
     assert "SQ_INSTS_VALU" in v["source"] and 0.15 < r["seal_valu_issue_frac"] <= 0.26 and r["seal_valu_wave_instr"] > 1e10
+    # ... and against the ALGORITHMIC VALU work of a Poseidon2 permutation (22.3 k SIMD-cycles per 64 permutations): ~0.83 at the sustained clock
+    assert v["algorithmic_floor_cycles"] == 1356 * 12 + 6000 and abs(v["frac_of_algorithmic_floor"] - v["algorithmic_floor_cycles"] / v["cycles_per_wave_permutation"]) < 1e-9
+    assert 0.75 < v["frac_of_algorithmic_floor"] < 0.95 and 0.6 < v["frac_of_algorithmic_floor_at_2p4GHz"] < v["frac_of_algorithmic_floor"]
+    assert abs(l["config"]["dominant_valu_algorithmic_frac"] - v["frac_of_algorithmic_floor"]) < 1e-3
     # the CPU baseline: one seal alone AND every core busy, the CPU named (round 6)
     c = l["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "segments/s" and c["sample"]
