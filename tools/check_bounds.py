@@ -32,12 +32,12 @@ import argparse
 import os
 import re
 import sys
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Tuple
 
 P = 2013265921
 R1 = (1 << 32) % P
 NBETA_M = P - (11 << 32) % P
-W32, W64 = 1 << 32, 1 << 64
+W32 = 1 << 32
 
 
 class Violation(Exception):
