@@ -168,3 +168,81 @@ def test_syn_huge_loads_as_data_and_three_evaluators_agree(hal, oracle, tmp_path
     rec = prover.prove_segment(Segment(index=0, po2=9, seed=21, noise_seed=22, zk_cycles=200))
     want = zko.OracleCircuit(oracle, desc).prove(9, 200, 21, 22)
     assert np.array_equal(rec.seal, want)
+
+
+EXTREME_WORDS = (P - 1, (P - 1) // 2, (P + 1) // 2, 1)
+
+
+@pytest.mark.parametrize("word", EXTREME_WORDS)
+def test_hand_written_lazy_sums_on_extreme_inputs(hal, oracle, word):
+    """The hand-written kernels that sum unreduced products — batch_evaluate_any (four Fp x Fp4 products per 64-bit accumulator, also
+    the bit-reversed form the prover uses from po2 14 on), mix_poly_coeffs (a running mix power times every coefficient), fri_fold
+    (sixteen Fp4 x Fp4 products), eltwise_sum_extelem, the combos scans — with EVERY operand the same extreme word: coefficients,
+    evaluation points, mix values.  Bit-exact against the oracle."""
+    rng = np.random.default_rng(word % 1000)
+    full = lambda k: np.full(k, word, np.uint32)                     # noqa: E731
+    # batch_evaluate_any: natural and bit-reversed coefficient order
+    for po, polys, evals in ((1 << 12, 3, 5), (70000, 2, 3), (1 << 16, 2, 4)):
+        coeffs, which, xs = full(po * polys), rng.integers(0, polys, size=evals).astype(np.uint32), full(4 * evals)
+        want = np.zeros(4 * evals, np.uint32)
+        oracle.zko_batch_evaluate_any(coeffs, coeffs.size, polys, which, xs, evals, want)
+        out = hal.alloc_extelem("out", evals)
+        hal.batch_evaluate_any(hal.copy_from("c", coeffs), polys, hal.copy_from("w", which), hal.copy_from("x", xs), out)
+        assert np.array_equal(out.to_vec(), want), ("batch_evaluate_any", po)
+        if po == 1 << 16:
+            br = coeffs.copy()
+            oracle.zko_batch_bit_reverse(br, br.size, polys)
+            out2 = hal.alloc_extelem("out", evals)
+            hal.batch_evaluate_any_bitrev(hal.copy_from("c", br), polys, hal.copy_from("w", np.sort(which)), hal.copy_from("x", xs), out2)
+            want2 = np.zeros(4 * evals, np.uint32)
+            oracle.zko_batch_evaluate_any(coeffs, coeffs.size, polys, np.sort(which), xs, evals, want2)
+            assert np.array_equal(out2.to_vec(), want2), "batch_evaluate_any_bitrev"
+    # mix_poly_coeffs
+    count, input_size, ncombo = 4096, 17, 3
+    inp, combos = full(input_size * count), np.sort(rng.integers(0, ncombo, size=input_size)).astype(np.uint32)
+    out0, mix_start, mix = full(4 * ncombo * count), full(4), full(4)
+    want = out0.copy()
+    oracle.zko_mix_poly_coeffs(want, mix_start, mix, inp, combos, input_size, count)
+    out = hal.copy_from("out", out0)
+    hal.mix_poly_coeffs(out, mix_start, mix, hal.copy_from("in", inp), hal.copy_from("cb", combos), input_size, count)
+    assert np.array_equal(out.to_vec(), want), "mix_poly_coeffs"
+    # fri_fold
+    count = 4096
+    inp, mix = full(4 * 16 * count), full(4)
+    want = np.zeros(4 * count, np.uint32)
+    oracle.zko_fri_fold(want, want.size, inp, mix)
+    out = hal.alloc_elem("o", 4 * count)
+    hal.fri_fold(out, hal.copy_from("i", inp), mix)
+    assert np.array_equal(out.to_vec(), want), "fri_fold"
+    # eltwise_sum_extelem
+    count, k = 777, 5
+    inp = full(4 * count * k)
+    want = np.zeros(4 * count, np.uint32)
+    oracle.zko_eltwise_sum_extelem(want, want.size, inp, count * k)
+    out = hal.alloc_elem("s", 4 * count)
+    hal.eltwise_sum_extelem(out, hal.copy_from("i", inp))
+    assert np.array_equal(out.to_vec(), want), "eltwise_sum_extelem"
+
+
+@pytest.mark.parametrize("log_n,bits", [(20, 2), (22, 2), (18, 2), (16, 0)])
+def test_ntt_round_trip_on_extreme_columns(hal, oracle, log_n, bits):
+    """expand-NTT (the lazy signed butterflies at 2^20 / 2^22) and the inverse transform with the fused zk shift on columns that hold
+    one extreme word or alternate: the forward result equals the oracle's, and interpolating it back returns the input"""
+    n_out, n_in = 1 << log_n, (1 << log_n) >> bits
+    cols = [np.full(n_in, w, np.uint32) for w in EXTREME_WORDS] + [np.where(np.arange(n_in) % 2 == 0, P - 1, 0).astype(np.uint32)]
+    x = np.concatenate(cols)
+    want = np.zeros(len(cols) * n_out, np.uint32)
+    oracle.zko_batch_expand_into_evaluate_ntt(want, want.size, x, x.size, len(cols), bits)
+    out = hal.alloc_elem("out", len(cols) * n_out)
+    hal.batch_expand_into_evaluate_ntt(out, hal.copy_from("in", x), len(cols), bits)
+    assert np.array_equal(out.to_vec(), want)
+    if bits == 0:
+        hal.batch_interpolate_ntt(out, len(cols))
+        back = x.copy()
+        assert np.array_equal(out.to_vec(), back)
+    inv = x.copy()
+    oracle.zko_batch_interpolate_ntt(inv, inv.size, len(cols))
+    oracle.zko_zk_shift(inv, inv.size, len(cols))
+    buf = hal.copy_from("io", x)
+    hal.batch_interpolate_ntt_zk_shift(buf, len(cols))
+    assert np.array_equal(buf.to_vec(), inv)
