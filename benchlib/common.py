@@ -120,6 +120,8 @@ class Run:
             for d, k in zip(self.devices, keys):
                 shared.setdefault(k, []).append(d["rank"])
             dup = "; ".join(f"ranks {r} all drive {k}" for k, r in shared.items() if len(r) > 1)
+            if self.rank != 0:                 # every rank reaches the same verdict from the same exchanged view: one message is enough
+                raise SystemExit(2)
             raise SystemExit(f"bench: --gpus {self.world} but the ranks do not hold {self.world} distinct GPUs ({dup}).  A dry run of the "
                              f"N-rank shape on fewer GPUs needs --allow-shared-gpu; its line then says `devices_distinct: false`.")
 
