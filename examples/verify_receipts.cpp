@@ -15,7 +15,10 @@
 //   binds none of that, so --chained then REQUIRES --segments N, the number of segments the verifier expects.
 //
 //   verify_receipts (--desc FILE | --circuit NAME) --receipts-dir DIR --control-root PO2:HEX64 [--control-root PO2:HEX64 ...]
-//                   [--chained [--initial-state N]] [--segments N] [--journal HEX]
+//                   [--chained [--initial-state N]] [--segments N] [--journal HEX] [--assumption CLAIMHEX64:ROOTHEX64 ...]
+// --assumption (repeatable, in the session's order): claim digest and control root (64 hex digits each, word 0 first) of a receipt the
+// session ASSUMED (a keccak batch).  A SYN-S session's last seal binds Output{journal, assumptions}: the list given here must be the one
+// the session names, or the session is refused — it cannot be resolved against other receipts.
 // PO2:HEX64 = the segment size and the 8 words of the expected control root as 64 hex digits (word 0 first, as
 // `python -m zeth_amd.prover` / circuits/control_roots.json print them and zkh_syn_control_root returns them).
 // Exit code 0 and {"verified": N} on success; 1 and the reason on the first receipt that does not verify.
@@ -45,6 +48,12 @@ int main(int argc, char** argv) {
     uint32_t initial_state = 0;
     long expect_segments = -1;
     std::vector<uint8_t> journal;
+    std::vector<uint32_t> assum_claims, assum_roots;
+    auto hex8 = [](const std::string& h, std::vector<uint32_t>& out) {
+        if (h.size() != 64) return false;
+        for (int k = 0; k < 8; k++) out.push_back((uint32_t)strtoul(h.substr(8 * k, 8).c_str(), nullptr, 16));
+        return true;
+    };
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "--desc" && i + 1 < argc) desc_path = argv[++i];
@@ -53,6 +62,14 @@ int main(int argc, char** argv) {
         else if (a == "--chained") chained = true;
         else if (a == "--initial-state" && i + 1 < argc) initial_state = (uint32_t)strtoul(argv[++i], nullptr, 0);
         else if (a == "--segments" && i + 1 < argc) expect_segments = strtol(argv[++i], nullptr, 0);
+        else if (a == "--assumption" && i + 1 < argc) {
+            const std::string v = argv[++i];
+            const size_t colon = v.find(':');
+            if (colon == std::string::npos || !hex8(v.substr(0, colon), assum_claims) || !hex8(v.substr(colon + 1), assum_roots)) {
+                fprintf(stderr, "--assumption wants CLAIMHEX64:ROOTHEX64\n");
+                return 2;
+            }
+        }
         else if (a == "--journal" && i + 1 < argc) {
             const std::string hex = argv[++i];
             if (hex.size() % 2) { fprintf(stderr, "--journal wants an even number of hex digits\n"); return 2; }
@@ -137,7 +154,11 @@ int main(int argc, char** argv) {
         std::vector<size_t> words;
         static const uint8_t empty_journal = 0;          // --journal "": an EXPLICITLY empty journal (a NULL pointer would mean "the default journal")
         for (auto& s : kept) { ptrs.push_back(s.data()); words.push_back(s.size()); }
-        if ((err = zkh_session_check_termination(circuit, ptrs.data(), words.data(), ptrs.size(), have_journal ? (journal.empty() ? &empty_journal : journal.data()) : nullptr, journal.size()))) {
+        uint32_t ad[8];
+        const bool assumes = !assum_claims.empty();
+        if (assumes) zkh_assumptions_digest(assum_claims.data(), assum_roots.data(), assum_claims.size() / 8, ad);
+        if ((err = zkh_session_check_output(circuit, ptrs.data(), words.data(), ptrs.size(), have_journal ? (journal.empty() ? &empty_journal : journal.data()) : nullptr, journal.size(),
+                                            assumes ? ad : nullptr))) {
             fprintf(stderr, "REJECTED: %s\n", err);
             zkh_free_error(err);
             return 1;

@@ -484,13 +484,22 @@ const char* zkh_session_verify(zkh_session*, const zkh_segment* segs, const zkh_
  * carries an exit code and an output (journal) digest per segment, and `receipt.verify(image_id)` + the journal comparison
  * (/root/reference/crates/host/src/bin/cli.rs:103-107) rely on them: every segment but the last ends in SystemSplit, the last in
  * Halted(0) with the digest of the journal (risc0-zkvm 3.0.3 receipt/composite.rs verify_integrity, recalled).  A SYN-S segment
- * publishes out = (post, 0, 0, 0, pre, exit_sys, exit_user, j_0 .. j_15) — j = SHA-256(journal) as sixteen 16-bit limbs — every word
- * a bound public input; zkh_session_set_chained fills them (the journal of a session = its final state word, 4 bytes LE) and
- * zkh_session_verify checks them.  zkh_session_check_termination is that check for a verifier that holds VERIFIED seals: a receipt
- * whose trailing segments were cut off ends in a SystemSplit and is refused; journal == NULL: the final state word.  Host only. */
+ * publishes out = (post, 0, 0, 0, pre, exit_sys, exit_user, j_0 .. j_15) — j = the session's OUTPUT digest
+ * tagged_struct("risc0.Output", [SHA-256(journal), Assumptions digest]) as sixteen 16-bit limbs (round 6; until then SHA-256(journal)
+ * alone) — every word a bound public input; zkh_session_set_chained fills them (the journal of a session = its final state word, 4 bytes
+ * LE; the assumptions = the receipts handed to zkh_session_set_assumptions, in that order) and zkh_session_verify checks them.
+ * zkh_session_check_output is that check for a verifier that holds VERIFIED seals: a receipt whose trailing segments were cut off ends in
+ * a SystemSplit and is refused; journal == NULL: the final state word; assumptions_digest == NULL: the session assumed nothing —
+ * otherwise zkh_assumptions_digest over (claim digest = zkh_receipt_claim, control root) of the assumption receipts THE VERIFIER holds:
+ * a session cannot be resolved against other receipts than the ones its own seal names.  zkh_session_check_termination = the same with
+ * no assumptions.  Host only. */
 void zkh_sha256(const uint8_t* data, size_t len, uint8_t out[32]);
 const char* zkh_session_check_termination(const zkh_circuit*, const uint32_t* const* seals, const size_t* seal_words, size_t n,
                                           const uint8_t* journal, size_t journal_len);
+const char* zkh_session_check_output(const zkh_circuit*, const uint32_t* const* seals, const size_t* seal_words, size_t n,
+                                     const uint8_t* journal, size_t journal_len, const uint32_t assumptions_digest[8]);
+/* Assumptions([Assumption{claim, control_root}, ..]).digest() (recalled layout): claims / control_roots = n x 8 words; n == 0: zero digest */
+void zkh_assumptions_digest(const uint32_t* claims, const uint32_t* control_roots, size_t n, uint32_t out[8]);
 
 /* `receipt.verify` for a SUCCINCT receipt on the host alone — no GPU, no session (upstream: SuccinctReceipt::verify_integrity, reached
  * from /root/reference/crates/host/src/bin/cli.rs:103): ONE seal of the RECURSION circuit (description compiled in) under the control

@@ -446,3 +446,50 @@ def test_bench_launchers_on_one_gpu(tmp_path):
     assert r.returncode != 0 and "--allow-shared-gpu" in r.stderr and not r.stdout.strip()
     r = subprocess.run([sys.executable, bench, "--gpus", "2", *quick, "--no-heavy", "--no-block", "--no-resident"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "do not hold 2 distinct GPUs" in r.stderr and not [x for x in r.stdout.splitlines() if x.startswith("{")]
+
+
+def test_the_native_executor_binds_the_assumptions_in_the_last_seal(hal, oracle):
+    """zkh_session_set_assumptions + zkh_session_set_chained: the LAST seal of the session binds Output{journal, assumptions} with the
+    assumption list of the receipts the session was handed (claim digest = zkh_receipt_claim, control root), in that order — the same
+    words the Python host computes; the library's verifier, the Python verifier and zkh_session_check_output accept exactly that list."""
+    import ctypes as C
+    from zeth_amd import hal as zhal
+    from zeth_amd.circuits import syn_air
+    from zeth_amd.host import Receipt, Session, assumption_of, assumptions_digest, image_id, output_digest, segment_claim
+    from zeth_amd.prover import Segment, SegmentProver
+    desc, adesc = syn_air.syn_session_small(), syn_air.syn_small()
+    ap = SegmentProver(hal, adesc)
+    arecs = [ap.prove_segment(Segment(index=k, po2=12, seed=900 + k, noise_seed=0x31 + k)) for k in range(3)]
+    aroot = ap.control_root(12)
+    assumed = [assumption_of(r, adesc, aroot) for r in arecs]
+    segs = [Segment(index=i, po2=13, seed=2600 + i, noise_seed=0x59) for i in range(3)]
+    sess = Session(desc, devices=(0,), lanes_per_device=2)
+    sess.set_assumptions(adesc, arecs, {12: aroot})
+    sess.set_chained(True, 9)
+    comp, _, _ = sess.prove(segs, verify=True)                      # zkh_session_verify: its own list
+    claims = [segment_claim(r) for r in comp.segments]
+    journal = int(claims[-1].post).to_bytes(4, "little")
+    assert claims[-1].output == output_digest(journal, assumed) != output_digest(journal)
+    sp = SegmentProver(hal, desc)
+    roots = {13: sp.control_root(13)}
+    rec = Receipt(comp, journal, tuple(assumed))
+    rec.verify(image_id(desc, 9), desc, initial_state=9, control_root=roots)
+    rec.verify_assumptions(adesc, arecs, {12: aroot})
+    with pytest.raises(HalError, match="do not hash"):
+        Receipt(comp, journal, tuple(assumed[::-1])).verify(image_id(desc, 9), desc, initial_state=9, control_root=roots)
+    with pytest.raises(HalError, match="journal does not hash"):
+        Receipt(comp, journal).verify(image_id(desc, 9), desc, initial_state=9, control_root=roots)
+    lib = zhal.load_library()
+    u32p = C.POINTER(C.c_uint32)
+    seals = [np.ascontiguousarray(r.seal) for r in comp.segments]
+    ptrs, words = (u32p * 3)(*[x.ctypes.data_as(u32p) for x in seals]), (C.c_size_t * 3)(*[x.size for x in seals])
+    ok = np.asarray(assumptions_digest(assumed), dtype=np.uint32)
+    zhal._check(lib.zkh_session_check_output(zhal.HostCircuit(desc).h, ptrs, words, 3, None, 0, ok.ctypes.data_as(u32p)))
+    with pytest.raises(HalError, match="journal does not hash"):
+        zhal._check(lib.zkh_session_check_output(zhal.HostCircuit(desc).h, ptrs, words, 3, None, 0, None))
+    # the same session WITHOUT assumptions seals other public words in its last segment, and only there
+    sess.set_assumptions(adesc, [], {})
+    comp0, _, _ = sess.prove(segs, verify=True)
+    assert segment_claim(comp0.segments[-1]).output == output_digest(journal)
+    assert all(np.array_equal(a.seal, b.seal) for a, b in zip(comp.segments[:2], comp0.segments[:2])) and not np.array_equal(comp.segments[2].seal, comp0.segments[2].seal)
+    sess.close()

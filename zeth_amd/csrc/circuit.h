@@ -125,6 +125,10 @@ constexpr uint32_t EXIT_SYS_HALTED = 0, EXIT_SYS_PAUSED = 1, EXIT_SYS_SPLIT = 2;
 inline bool circuit_is_session(const zkh_circuit* c) { return c->kind == 1 && c->global_size[0] == SESSION_OUT_WORDS; }
 inline bool circuit_has_state(const zkh_circuit* c) { return c->kind == 1 && (c->global_size[0] == 5 || c->global_size[0] == SESSION_OUT_WORDS); }
 namespace zkh {
-void session_journal_limbs(uint32_t final_state_mont, uint32_t limbs[16]);                                       // verifier.hip
-const char* check_session_termination(const uint32_t* const* seals, size_t n, const uint8_t* journal, size_t journal_len);
+// the OUTPUT digest a session's last seal binds = tagged_struct("risc0.Output", [SHA-256(journal), Assumptions digest]) as sixteen
+// 16-bit limbs (assumptions == NULL: the session assumed nothing, the zero digest) — verifier.hip
+void session_output_limbs(const uint8_t* journal, size_t journal_len, const uint32_t assumptions[8], uint32_t limbs[16]);
+void session_journal_limbs(uint32_t final_state_mont, const uint32_t assumptions[8], uint32_t limbs[16]);         // journal = the final state word
+void assumptions_digest(const uint32_t* claims, const uint32_t* control_roots, size_t n, uint32_t out[8]);
+const char* check_session_termination(const uint32_t* const* seals, size_t n, const uint8_t* journal, size_t journal_len, const uint32_t assumptions[8]);
 }

@@ -98,6 +98,16 @@ struct zkh_session {
     std::vector<std::vector<uint32_t>> assum_seals;
     std::vector<uint32_t> assum_po2;
     std::vector<std::vector<uint32_t>> assum_roots;    // the assumption circuit's control root at assum_po2[i]
+    std::vector<uint32_t> assum_claims;                // 8 words each: the receipts' claim digests (zkh_receipt_claim), in the caller's order
+    // the digest a chained SYN-S session's last seal binds beside its journal: Assumptions([Assumption{claim, control root}, ..]) of the
+    // receipts above, NULL when the session assumes nothing (verifier.hip assumptions_digest)
+    const uint32_t* assumptions_digest(uint32_t out[8]) const {
+        if (assum_seals.empty()) return nullptr;
+        std::vector<uint32_t> roots;
+        for (const auto& r : assum_roots) roots.insert(roots.end(), r.begin(), r.end());
+        zkh::assumptions_digest(assum_claims.data(), roots.data(), assum_seals.size(), out);
+        return out;
+    }
     ~zkh_session() { for (auto& l : fold_lanes) l.close(); for (auto& l : lanes) l.close(); }
 };
 
@@ -373,13 +383,14 @@ extern "C" const char* zkh_session_set_recursion(zkh_session* s, const uint32_t*
 extern "C" const char* zkh_session_set_assumptions(zkh_session* s, const uint32_t* desc, size_t desc_words, const uint32_t* const* seals,
                                                    const size_t* seal_words, const uint32_t* po2s, const uint32_t* control_roots, size_t n) {
     ZKH_REQUIRE(s, "session_set_assumptions: null session");
-    if (!n) { s->assum_desc.clear(); s->assum_seals.clear(); s->assum_po2.clear(); s->assum_roots.clear(); return nullptr; }
+    if (!n) { s->assum_desc.clear(); s->assum_seals.clear(); s->assum_po2.clear(); s->assum_roots.clear(); s->assum_claims.clear(); return nullptr; }
     ZKH_REQUIRE(desc && desc_words >= 16 && seals && seal_words && po2s && control_roots, "session_set_assumptions: null argument");
     // every receipt is verified HERE, on the host, against the control root it is handed with: what the lifts then prove in-circuit
     zkh_circuit* hc = nullptr;
     ZKH_TRY(zkh_circuit_load(nullptr, desc, desc_words, &hc));
     std::unique_ptr<zkh_circuit, void (*)(zkh_circuit*)> hold(hc, zkh_circuit_destroy);
     ZKH_REQUIRE(!circuit_has_state(hc), "session_set_assumptions: an assumption circuit has no state words (its claim' is wrap(claim, 0, 0))");
+    std::vector<uint32_t> claims(8 * n);
     for (size_t i = 0; i < n; i++) {
         ZKH_REQUIRE(seals[i] && po2s[i] >= 4 && po2s[i] <= 24, "session_set_assumptions: assumption %zu: bad seal / po2", i);
         if (const char* e = zkh_verify_segment(hc, seals[i], seal_words[i], control_roots + 8 * i, nullptr, nullptr)) {
@@ -387,7 +398,9 @@ extern "C" const char* zkh_session_set_assumptions(zkh_session* s, const uint32_
             zkh_free_error(e);
             return out;
         }
+        ZKH_TRY(zkh_receipt_claim(hc, seals[i], seal_words[i], control_roots + 8 * i, nullptr, nullptr, &claims[8 * i]));
     }
+    s->assum_claims = std::move(claims);
     s->assum_desc.assign(desc, desc + desc_words);
     s->assum_seals.clear(); s->assum_po2.assign(po2s, po2s + n); s->assum_roots.clear();
     for (size_t i = 0; i < n; i++) {
@@ -675,8 +688,9 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
         uint32_t state = fp_encode(s->initial_state).v;
         for (size_t i = 0; i < n; i++) { pre_states[i * pw] = state; state = add_mod(state, contrib[i]); }
         if (sess) {
-            uint32_t limbs[SESSION_JOURNAL_LIMBS];
-            session_journal_limbs(state, limbs);
+            // ... and WHICH receipts the session assumes: the last seal binds Output{journal, assumptions} (zkh_session_set_assumptions first)
+            uint32_t limbs[SESSION_JOURNAL_LIMBS], ad[8];
+            session_journal_limbs(state, s->assumptions_digest(ad), limbs);
             for (size_t i = 0; i < n; i++) {
                 const bool is_last = i + 1 == n;
                 pre_states[i * pw + 1] = fp_encode(is_last ? EXIT_SYS_HALTED : EXIT_SYS_SPLIT).v;
@@ -1151,7 +1165,8 @@ extern "C" const char* zkh_session_verify(zkh_session* s, const zkh_segment* seg
                 ZKH_REQUIRE(info->seal_words[i] > SESSION_OUT_WORDS, "session_verify: segment %zu: seal too short", i);
                 seals[i] = info->seals[i];
             }
-            ZKH_TRY(check_session_termination(seals.data(), info->n_segments, nullptr, 0));
+            uint32_t ad[8];
+            ZKH_TRY(check_session_termination(seals.data(), info->n_segments, nullptr, 0, s->assumptions_digest(ad)));
         }
     }
     if (!info->root_seal) return nullptr;

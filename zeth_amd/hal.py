@@ -143,6 +143,8 @@ ABI = {
     "zkh_syn_code": (_err, [_vp, _vp, _sz, _sz, _vp]),
     "zkh_sha256": (None, [C.c_char_p, _sz, C.POINTER(C.c_uint8)]),
     "zkh_session_check_termination": (_err, [_vp, C.POINTER(_u32p), C.POINTER(_sz), _sz, C.c_char_p, _sz]),
+    "zkh_session_check_output": (_err, [_vp, C.POINTER(_u32p), C.POINTER(_sz), _sz, C.c_char_p, _sz, _u32p]),
+    "zkh_assumptions_digest": (None, [_u32p, _u32p, _sz, _u32p]),
     "zkh_noise_cell_host": (_u32, [_u32p, _u32, _u32, _u32]),
     "zkh_chacha_block_host": (None, [_u32p, _u32p, _i, _u32p]),
     "zkh_syn_witgen": (_err, [_vp, _vp, _sz, _sz, _u64, _u32p, _u32p, _vp, _vp, _u32p]),

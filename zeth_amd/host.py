@@ -230,7 +230,8 @@ def chain_segments(segments: Sequence[Segment], contribution: Callable[[Segment]
 #     SystemState digest = tagged_struct("risc0.SystemState", [merkle_root], [pc]);  Output = ("risc0.Output", [journal, assumptions], [])
 #     ExitCode::into_pair: Halted(u) -> (0, u), Paused(u) -> (1, u), SystemSplit -> (2, 0), SessionLimit -> (2, 2)
 # A SYN-S segment (circuits/syn_air.py syn_session) binds the pieces in its seal: pre / post state words, the exit pair, the 16 limbs
-# of SHA-256(journal).  The SHA-256 claim digests below are computed on the host BESIDE the Poseidon2 claim the recursion circuit
+# of the OUTPUT digest tagged_struct("risc0.Output", [SHA-256(journal), Assumptions digest]) (round 6; until then SHA-256(journal) alone:
+# which receipts a session had assumed was then whatever list the verifier was handed).  The SHA-256 claim digests below are computed on the host BESIDE the Poseidon2 claim the recursion circuit
 # uses (zkh_receipt_claim); tools/check_upstream_receipt.py is the one-command check of the recalled layouts against a real receipt.
 # ---------------------------------------------------------------------------------------------------------------
 EXIT_HALTED, EXIT_PAUSED, EXIT_SYSTEM_SPLIT, EXIT_SESSION_LIMIT = "Halted", "Paused", "SystemSplit", "SessionLimit"
@@ -278,14 +279,6 @@ def tagged_struct(tag: str, down: Sequence[Sequence[int]], data: Sequence[int] =
     return sha256_words(body)
 
 
-def journal_limbs(journal: bytes) -> List[int]:
-    """SHA-256(journal) as the sixteen 16-bit limbs a SYN-S seal binds (Montgomery words; limb k = digest bytes 2k, 2k + 1 LE)"""
-    import hashlib
-    from .hal import fp_encode
-    d = hashlib.sha256(bytes(journal)).digest()
-    return [fp_encode(d[2 * k] | d[2 * k + 1] << 8) for k in range(16)]
-
-
 ZERO_DIGEST = [0] * 8
 
 
@@ -309,23 +302,43 @@ def assumptions_digest(assumptions: Sequence[Tuple[Sequence[int], Sequence[int]]
     return acc
 
 
+def output_digest(journal: bytes, assumptions: Sequence[Tuple[Sequence[int], Sequence[int]]] = ()) -> List[int]:
+    """`Output{journal, assumptions}.digest()` (RECALLED) = tagged_struct("risc0.Output", [SHA-256(journal), Assumptions digest], []) —
+    what the LAST segment of a session binds: the journal AND which receipts the session assumed ([(claim digest, control root)] of
+    its keccak batches, in order; none: the zero digest).  Twin of csrc/verifier.hip session_output_limbs."""
+    return tagged_struct("risc0.Output", [sha256_words(bytes(journal)), assumptions_digest(assumptions)], [])
+
+
+def output_limbs(journal: bytes, assumptions=()) -> List[int]:
+    """the output digest as the sixteen 16-bit limbs a SYN-S seal binds (Montgomery words; limb k = digest bytes 2k, 2k + 1 LE)"""
+    from .hal import fp_encode
+    out = []
+    for w in output_digest(journal, assumptions):
+        out += [fp_encode(w & 0xFFFF), fp_encode(w >> 16)]
+    return out
+
+
+def assumption_of(receipt: "SegmentReceipt", circuit_desc, control_root) -> Tuple[List[int], List[int]]:
+    """`Assumption{claim, control_root}` of a receipt a session assumes: its claim digest (the 8 words zkh_receipt_claim gives: Poseidon2
+    over its public output, size and control root) and the control root of ITS circuit"""
+    return [int(w) for w in receipt_claim(receipt, circuit_desc, control_root)], [int(w) for w in control_root]
+
+
 @dataclass
 class ReceiptClaim:
     """`risc0_zkvm::ReceiptClaim` for a segment (or a whole session) of a SYN-S circuit: the state words stand where upstream has
     `SystemState{pc, merkle_root}` (pc 0, merkle_root = (state word, 0, ..)), `input` is None as in every zkVM-2 receipt, and the
-    output is `Output{journal: digest, assumptions: zero}` for a halted segment, None otherwise."""
+    output is the digest of `Output{journal, assumptions}` for a halted segment (what the seal binds: `output_digest`), None otherwise."""
     pre: int                                   # canonical residues of the state words
     post: int
     exit_code: tuple = (EXIT_HALTED, 0)
-    journal_digest: Optional[List[int]] = None  # 8 words, None = no output (the segment did not halt)
+    output: Optional[List[int]] = None          # 8 words: Output{journal, assumptions}.digest(); None = no output (the segment did not halt)
 
     def state_digest(self, word: int) -> List[int]:
         return tagged_struct("risc0.SystemState", [[int(word)] + [0] * 7], [0])
 
     def output_digest(self) -> List[int]:
-        if self.journal_digest is None:
-            return ZERO_DIGEST
-        return tagged_struct("risc0.Output", [self.journal_digest, ZERO_DIGEST], [])
+        return ZERO_DIGEST if self.output is None else [int(w) for w in self.output]
 
     def digest(self) -> List[int]:
         sys, user = exit_code_pair(self.exit_code)
@@ -334,15 +347,20 @@ class ReceiptClaim:
     def to_codec_value(self) -> dict:
         """this claim as a value of receipt_codec.ReceiptClaim (upstream's bincode layout, recalled)"""
         st = lambda w: ("Value", {"pc": 0, "merkle_root": [int(w)] + [0] * 7})
-        out = ("Value", None) if self.journal_digest is None else ("Value", {"journal": ("Pruned", [int(w) for w in self.journal_digest]), "assumptions": ("Pruned", ZERO_DIGEST)})
+        # the output travels PRUNED (MaybePruned::Pruned(digest)): the seal binds the digest of Output{journal, assumptions}, not its parts
+        out = ("Value", None) if self.output is None else ("Pruned", [int(w) for w in self.output])
         return {"pre": st(self.pre), "post": st(self.post), "exit_code": self.exit_code, "input": ("Value", None), "output": out}
 
     @staticmethod
     def from_codec_value(v: dict) -> "ReceiptClaim":
         word = lambda s: int(s[1]["merkle_root"][0])
-        out = v["output"][1] if v["output"][0] == "Value" else None
-        jd = None if out is None else [int(w) for w in out["journal"][1]]
-        return ReceiptClaim(pre=word(v["pre"]), post=word(v["post"]), exit_code=tuple(v["exit_code"]), journal_digest=jd)
+        if v["output"][0] == "Pruned":
+            od = [int(w) for w in v["output"][1]]
+        elif v["output"][1] is None:
+            od = None
+        else:                                  # Value{journal: Pruned(d), assumptions: Pruned(d)}: the digest of the pair
+            od = tagged_struct("risc0.Output", [[int(w) for w in v["output"][1]["journal"][1]], [int(w) for w in v["output"][1]["assumptions"][1]]], [])
+        return ReceiptClaim(pre=word(v["pre"]), post=word(v["post"]), exit_code=tuple(v["exit_code"]), output=od)
 
 
 def segment_claim(receipt: SegmentReceipt) -> ReceiptClaim:
@@ -360,23 +378,24 @@ def segment_claim(receipt: SegmentReceipt) -> ReceiptClaim:
     limbs = [fp_decode(int(w)) for w in seal[SESSION_JOURNAL:SESSION_JOURNAL + SESSION_JOURNAL_LIMBS]]
     if any(l >> 16 for l in limbs):
         raise HalError("segment_claim: an output-digest limb does not fit 16 bits")
-    jd = None
+    od = None
     if code[0] == EXIT_HALTED or any(limbs):
         raw = b"".join(int(l).to_bytes(2, "little") for l in limbs)
-        jd = [int.from_bytes(raw[4 * i:4 * i + 4], "little") for i in range(8)]
-    return ReceiptClaim(pre=fp_decode(int(seal[CHAIN_PRE])), post=fp_decode(int(seal[CHAIN_POST])), exit_code=code, journal_digest=jd)
+        od = [int.from_bytes(raw[4 * i:4 * i + 4], "little") for i in range(8)]
+    return ReceiptClaim(pre=fp_decode(int(seal[CHAIN_PRE])), post=fp_decode(int(seal[CHAIN_POST])), exit_code=code, output=od)
 
 
-def session_pub_words(pre_state_mont: int, is_last: bool, journal: bytes) -> tuple:
+def session_pub_words(pre_state_mont: int, is_last: bool, journal: bytes, assumptions=()) -> tuple:
     """the 19 public words of a SYN-S segment: pre-state, exit pair, output-digest limbs (Montgomery words)"""
     from .hal import fp_encode
     sys, user = exit_code_pair((EXIT_HALTED, 0) if is_last else (EXIT_SYSTEM_SPLIT, None))
-    return (int(pre_state_mont), fp_encode(sys), fp_encode(user)) + tuple(journal_limbs(journal) if is_last else [0] * 16)
+    return (int(pre_state_mont), fp_encode(sys), fp_encode(user)) + tuple(output_limbs(journal, assumptions) if is_last else [0] * 16)
 
 
-def chain_session(segments: Sequence[Segment], contribution: Callable[[Segment], int], initial_state: int = 0):
+def chain_session(segments: Sequence[Segment], contribution: Callable[[Segment], int], initial_state: int = 0, assumptions=()):
     """The executor's part of a SYN-S session: pre-states (as `chain_segments`), exit codes (SystemSplit .. SystemSplit, Halted(0)) and
-    the journal — the session's final state word, canonical, 4 bytes little-endian — whose digest the LAST segment binds.
+    the journal — the session's final state word, canonical, 4 bytes little-endian — whose OUTPUT digest Output{journal, assumptions}
+    the LAST segment binds; `assumptions` = [(claim digest, control root)] of the receipts the session assumes (`assumption_of`).
     -> (segments with their 19 public words, journal bytes)"""
     from dataclasses import replace
     from .hal import P, fp_decode, fp_encode
@@ -385,11 +404,11 @@ def chain_session(segments: Sequence[Segment], contribution: Callable[[Segment],
         pres.append(state)
         state = (state + contribution(seg)) % P
     journal = int(fp_decode(state)).to_bytes(4, "little")
-    out = [replace(seg, pub=session_pub_words(pre, i + 1 == len(segments), journal)) for i, (seg, pre) in enumerate(zip(segments, pres))]
+    out = [replace(seg, pub=session_pub_words(pre, i + 1 == len(segments), journal, assumptions)) for i, (seg, pre) in enumerate(zip(segments, pres))]
     return out, journal
 
 
-def verify_session_integrity(receipts: Sequence[SegmentReceipt], initial_state: int, journal: Optional[bytes]) -> ReceiptClaim:
+def verify_session_integrity(receipts: Sequence[SegmentReceipt], initial_state: int, journal: Optional[bytes], assumptions=()) -> ReceiptClaim:
     """`CompositeReceipt::verify_integrity` + the exit-code and journal checks on VERIFIED SYN-S seals: indices 0 .. n-1 in order, the
     first segment starts from `initial_state`, every pre-state is the predecessor's post-state, every segment but the last ends in
     SystemSplit with no output, the last in Halted(0) with the digest of `journal` (None: the final state word).  A session with
@@ -404,14 +423,16 @@ def verify_session_integrity(receipts: Sequence[SegmentReceipt], initial_state: 
             raise HalError(f"session: segment {i} starts from state {c.pre}, its predecessor ended in {prev}")
         prev = c.post
         last = i + 1 == len(claims)
-        if not last and (c.exit_code != (EXIT_SYSTEM_SPLIT, None) or c.journal_digest is not None):
+        if not last and (c.exit_code != (EXIT_SYSTEM_SPLIT, None) or c.output is not None):
             raise HalError(f"session: segment {i} of {len(claims)} does not end in SystemSplit ({c.exit_code}): the segments are not those of one session")
         if last and c.exit_code != (EXIT_HALTED, 0):
             raise HalError(f"session: the last segment says {c.exit_code}, not Halted(0): the session was cut short or did not succeed")
     j = journal if journal is not None else int(claims[-1].post).to_bytes(4, "little")
-    if claims[-1].journal_digest != sha256_words(bytes(j)):
-        raise HalError("session: the journal does not hash to the output digest the last segment's seal binds")
-    return ReceiptClaim(pre=claims[0].pre, post=claims[-1].post, exit_code=claims[-1].exit_code, journal_digest=claims[-1].journal_digest)
+    if claims[-1].output != output_digest(bytes(j), assumptions):
+        raise HalError("session: the journal and these assumption receipts do not hash to the output digest the last segment's seal binds "
+                       "(another journal, or the session assumed other receipts / in another order)" if assumptions else
+                       "session: the journal does not hash to the output digest the last segment's seal binds")
+    return ReceiptClaim(pre=claims[0].pre, post=claims[-1].post, exit_code=claims[-1].exit_code, output=claims[-1].output)
 
 
 
@@ -444,20 +465,38 @@ class Receipt:
     """`risc0_zkvm::Receipt{inner, journal}` analogue for a session: what `BlockProcessor::prove` returns next to the image id
     (/root/reference/crates/host/src/lib.rs:123-143) and what the CLI then checks (/root/reference/crates/host/src/bin/cli.rs:103-107):
     `receipt.verify(image_id)`, then the journal against the expected value.  The journal is the session's final state word
-    (canonical, 4 bytes little-endian) — the output whose digest the LAST segment's seal binds (SYN-S)."""
+    (canonical, 4 bytes little-endian); the LAST segment's seal binds Output{journal, assumptions} (SYN-S), `assumptions` being the
+    [(claim digest, control root)] of the receipts the session assumed (its keccak batches) — a conditional receipt names them, it does
+    not carry them: `verify_assumptions` checks the receipts a holder presents against that list."""
     inner: CompositeReceipt
     journal: bytes
+    assumptions: tuple = ()
 
     def claim(self) -> ReceiptClaim:
         """the session's claim (SYN-S): pre of the first segment, post / exit code / output of the last (upstream: `Receipt::claim`)"""
         first, last = segment_claim(self.inner.segments[0]), segment_claim(self.inner.segments[-1])
-        return ReceiptClaim(pre=first.pre, post=last.post, exit_code=last.exit_code, journal_digest=last.journal_digest)
+        return ReceiptClaim(pre=first.pre, post=last.post, exit_code=last.exit_code, output=last.output)
+
+    def verify_assumptions(self, circuit_desc, receipts: Sequence[SegmentReceipt], control_roots) -> None:
+        """The receipts a holder presents for the session's assumptions (seals of `circuit_desc`, e.g. KECCAK-F batches): every one is
+        verified against its control root, and their (claim digest, control root) list must be EXACTLY the one the session names — which
+        `verify` has tied to the output digest the last seal binds.  A session cannot be resolved against other receipts.  Raises."""
+        from .hal import HalError
+        got = []
+        for r in receipts:
+            root = control_roots[r.po2]
+            r.verify(circuit_desc, root)
+            got.append(assumption_of(r, circuit_desc, root))
+        want = [([int(w) for w in c], [int(w) for w in k]) for c, k in self.assumptions]
+        if got != want:
+            raise HalError(f"receipt.verify_assumptions: the session names {len(want)} assumption(s); the {len(got)} receipt(s) presented are not those (or not in that order)")
 
     def verify(self, expected_image_id, circuit_desc, initial_state: int = 0, control_root=None, n_segments: Optional[int] = None) -> None:
         """Every segment seal against its control root; the image id the caller expected = the one (circuit, control roots, initial
         state) hash to; and the session is WHOLE:
-          SYN-S circuits — continuity from `initial_state`, SystemSplit .. SystemSplit, Halted(0), SHA-256(journal) = the output digest the
-          last seal binds (`verify_session_integrity`): trailing segments cannot be cut off, the journal cannot be rewritten;
+          SYN-S circuits — continuity from `initial_state`, SystemSplit .. SystemSplit, Halted(0), Output{SHA-256(journal), assumptions} = the
+          output digest the last seal binds (`verify_session_integrity`): trailing segments cannot be cut off, the journal cannot be
+          rewritten, the assumption list cannot be swapped;
           SYN-C circuits bind no exit code: continuity + journal == the last seal's post-state, and the caller MUST say how many segments
           the session has (`n_segments`) — without it a holder could drop trailing segments and rewrite the 4-byte journal.  Raises."""
         import numpy as np
@@ -469,7 +508,7 @@ class Receipt:
             raise HalError(f"receipt.verify: the receipt holds {len(self.inner.segments)} segments, the session has {n_segments}")
         if _is_session_circuit(d):
             self.inner.verify(d, control_root)                       # order + every seal
-            verify_session_integrity(self.inner.segments, initial_state, self.journal)
+            verify_session_integrity(self.inner.segments, initial_state, self.journal, self.assumptions)
             return
         if n_segments is None:
             raise HalError("receipt.verify: a SYN-C session does not bind its termination (no exit code in its seals): pass the expected "
@@ -500,16 +539,16 @@ class Receipt:
 
 
 def prove_chained_block(prove_segment: Callable[[Segment], SegmentReceipt], contribution: Callable[[Segment], int], circuit_desc,
-                        segments: Sequence[Segment], initial_state: int = 0):
+                        segments: Sequence[Segment], initial_state: int = 0, assumptions=()):
     """`BlockProcessor::prove(input, po2) -> (Receipt, image id)` (/root/reference/crates/host/src/lib.rs:123-143) for a chained
     session on this rank: the executor's pass (pre-states; SYN-S: exit codes and the journal digest too), the segment seals, the
     composite with its journal."""
     from .hal import fp_decode
     if _is_session_circuit(circuit_desc):
-        chained, journal = chain_session(segments, contribution, initial_state)
+        chained, journal = chain_session(segments, contribution, initial_state, assumptions)
         comp = CompositeReceipt([prove_segment(s) for s in chained])
-        verify_session_integrity(comp.segments, initial_state, journal)
-        return Receipt(comp, journal), image_id(circuit_desc, initial_state)
+        verify_session_integrity(comp.segments, initial_state, journal, assumptions)
+        return Receipt(comp, journal, tuple(assumptions)), image_id(circuit_desc, initial_state)
     chained = chain_segments(segments, contribution, initial_state)
     comp = CompositeReceipt([prove_segment(s) for s in chained])
     comp.verify_integrity(chained=True, initial_state=initial_state)
