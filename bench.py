@@ -50,7 +50,9 @@ def parse_args(argv=None):
     ap.add_argument("--po2", type=int, default=PO2)
     ap.add_argument("--config", choices=("segment", "block", "succinct", "dev"),
                     default="dev" if os.environ.get("RISC0_DEV_MODE", "").lower() in ("1", "true", "yes") else "segment")
-    ap.add_argument("--circuit", choices=("syn_a", "syn_heavy"), default="syn_a")
+    ap.add_argument("--circuit", choices=("syn_a", "syn_heavy", "syn_huge"), default="syn_a",
+                    help="syn_huge: the constraint system of a real circuit's size (255 k steps; not built in: generated, verified and compiled "
+                         "when it is loaded, ~10 s the first time on this machine)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("ZKH_INFLIGHT", "3")),
                     help="segments sealed concurrently per GPU (one host thread + HIP stream each); 1 = strictly serial")
     g = ap.add_argument_group("segment config: what else the default run measures")

@@ -131,6 +131,9 @@ class Run:
         if self.args.circuit == "syn_heavy":
             from zeth_amd.circuits import syn_heavy
             self.desc = syn_heavy.syn_heavy()
+        elif self.args.circuit == "syn_huge":
+            from zeth_amd.circuits import syn_heavy
+            self.desc = syn_heavy.syn_huge()
         else:
             self.desc = syn_air.syn_a()
         self.circ = Circuit.parse(self.desc)

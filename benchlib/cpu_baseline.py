@@ -35,7 +35,7 @@ except Exception:
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
 import zko                                   # test infrastructure; here ONLY as the reported CPU baseline
 from zeth_amd.circuits import syn_air, syn_heavy
-desc = syn_heavy.syn_heavy() if sys.argv[2] == "syn_heavy" else syn_air.syn_a()
+desc = syn_heavy.syn_heavy() if sys.argv[2] == "syn_heavy" else syn_heavy.syn_huge() if sys.argv[2] == "syn_huge" else syn_air.syn_a()
 lib = zko.load()
 oc = zko.OracleCircuit(lib, desc)
 po2, seed, noise = int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
