@@ -554,3 +554,35 @@ def test_native_session_unites_its_assumption_receipts_and_resolves_the_root(hal
     cols = open(csv).read().strip().splitlines()[1].split(",")
     assert cols[0] == "19000001" and int(cols[5]) == 3 * ((8192 - 1994) // 25)                # keccak_calls: the permutations the batches prove
     print("NATIVE UNION/RESOLVE", {"programs": len(programs), "library_build_s": round(t_build, 2), "wall_s": round(stats["wall_s"], 3), "nodes": stats["n_lifts"] + stats["n_joins"]})
+
+
+def test_a_chained_session_that_assumes_receipts_folds_resolves_and_names_them(hal):
+    """Everything at once, natively: a CHAINED SYN-S session (exit codes, journal, continuity) that ASSUMES three keccak receipts is
+    sealed, folded (lift2 / joins that assert continuity), its assumption receipts lifted and united, the root resolved — and the last
+    segment's seal binds Output{journal, assumptions} over exactly those receipts: the Python verifier accepts the composite with that
+    list and refuses it reordered (round-5 verdict, missing #5)."""
+    from zeth_amd.circuits import keccak_f
+    from zeth_amd.hal import HalError
+    from zeth_amd.host import Receipt, Session, assumption_of, image_id, output_digest, segment_claim
+    from zeth_amd.prover import Segment, SegmentProver
+    sdesc, kdesc = syn_air.syn_session(), keccak_f.keccak_f_circuit()
+    sp, kp = SegmentProver(hal, sdesc), SegmentProver(hal, kdesc)
+    krecs = [kp.prove_segment(Segment(index=i, po2=13, seed=0xCECC + i, noise_seed=3)) for i in range(3)]
+    kroot, sroot = kp.control_root(13), sp.control_root(13)
+    assumed = [assumption_of(r, kdesc, kroot) for r in krecs]
+    segs = [Segment(index=i, po2=13, seed=4700 + i, noise_seed=0x51) for i in range(6)]
+    sess = Session(sdesc, devices=(0,), lanes_per_device=2)
+    sess.set_assumptions(kdesc, krecs, {13: kroot})
+    sess.set_chained(True, 4)
+    sess.build_recursion([13])
+    comp, root, st = sess.prove(segs, join_tree=2, join_noise_seed=0x77, verify=True)
+    sess.close()
+    assert st["n_lifts"] == 3 + 3 and st["verified"] and root is not None
+    claims = [segment_claim(r) for r in comp.segments]
+    journal = int(claims[-1].post).to_bytes(4, "little")
+    assert claims[-1].output == output_digest(journal, assumed) and all(c.output is None for c in claims[:-1])
+    rec_ = Receipt(comp, journal, tuple(assumed))
+    rec_.verify(image_id(sdesc, 4), sdesc, initial_state=4, control_root={13: sroot})
+    rec_.verify_assumptions(kdesc, krecs, {13: kroot})
+    with pytest.raises(HalError, match="do not hash"):
+        Receipt(comp, journal, tuple(assumed[::-1])).verify(image_id(sdesc, 4), sdesc, initial_state=4, control_root={13: sroot})
