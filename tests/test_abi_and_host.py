@@ -248,6 +248,15 @@ def test_multi_part_jit_cross_compiles_with_verified_cache(tmp_path, monkeypatch
     files = sorted(f.name for f in tmp_path.iterdir())
     assert sum(f.endswith(".hsaco") for f in files) == len(objs) == sum(f.endswith(".sha256") for f in files)
     assert (os.stat(tmp_path).st_mode & 0o022) == 0
+    # a repeated load is served by the circuit-level manifest: the generator does not even run (round 6: SYN-HUGE's second load 3.0 -> 0.25 s)
+    assert sum(f.endswith(".manifest.json") for f in files) == 1
+    with monkeypatch.context() as m:
+        m.setattr(jit, "eval_check_sources", lambda d: (_ for _ in ()).throw(AssertionError("the generator ran on a cache hit")))
+        again = jit.compile_code_objects(desc)
+        assert [n for _, n in again] == [n for _, n in objs] and all(a == b for (a, _), (b, _) in zip(again, objs))
+        with pytest.raises(AssertionError, match="generator ran"):          # another knob = another set of kernels = another manifest
+            m.setenv("ZKH_CODEGEN_PART", "1500")
+            jit.compile_code_objects(desc)
     # a tampered cache entry is not used: it is recompiled (and with no compiler available, that fails loudly)
     victim = next(f for f in tmp_path.iterdir() if f.name.endswith(".hsaco"))
     victim.write_bytes(victim.read_bytes()[:-8] + b"tampered")
