@@ -29,14 +29,14 @@ class Violation(Exception):
 
 
 class S:
-    """an integer scalar: true-value interval [lo, hi] and the C type's width"""
-    __slots__ = ("lo", "hi", "w")
+    """an integer scalar: true-value interval [lo, hi], the C type's width and signedness"""
+    __slots__ = ("lo", "hi", "w", "sg")
 
-    def __init__(self, lo: int, hi: int, w: int = 32):
-        self.lo, self.hi, self.w = lo, hi, w
+    def __init__(self, lo: int, hi: int, w: int = 32, sg: bool = False):
+        self.lo, self.hi, self.w, self.sg = lo, hi, w, sg
 
     def __repr__(self):
-        return f"S[{self.lo}, {self.hi}]u{self.w}"
+        return f"S[{self.lo}, {self.hi}]{'i' if self.sg else 'u'}{self.w}"
 
 
 class FP:
@@ -85,6 +85,10 @@ def _mont(t: int, correct: bool) -> int:
 
 def fits(s: S, what: str) -> S:
     """the value is stored / cast / multiplied / passed on: it must be what the machine word holds"""
+    if s.sg:
+        if s.lo < -(1 << (s.w - 1)) or s.hi >= (1 << (s.w - 1)):
+            raise Violation(f"{what}: [{s.lo}, {s.hi}] does not fit i{s.w} (|.| up to 2^{max(abs(s.lo), abs(s.hi)).bit_length() - 1}.., limit 2^{s.w - 1})")
+        return s
     if s.lo < 0:
         raise Violation(f"{what}: may be negative (lowest true value {s.lo}): the u{s.w} word wraps")
     if s.hi >= (1 << s.w):
@@ -137,6 +141,41 @@ def fold_acc(s: S, what="fold_acc") -> S:
     if exact(s):
         return pt((s.hi >> 32) * R1 + (s.hi & M32), 64)
     return S(0, s.hi if s.hi < W32 else (s.hi >> 32) * R1 + W32 - 1, 64)
+
+
+def as_i32(x: S, what: str) -> S:
+    """an operand of a signed multiply-add: the 32-bit word read as int32 must BE the value (no wrap)"""
+    if x.lo < -(1 << 31) or x.hi >= (1 << 31):
+        raise Violation(f"{what}: operand [{x.lo}, {x.hi}] does not fit int32")
+    return x
+
+
+def mad_i64(a: S, b: S, acc: S, what="mad_i64") -> S:
+    """v_mad_i64_i32: acc + a * b, exact in signed 64 bits"""
+    as_i32(a, what); as_i32(b, what)
+    prods = [a.lo * b.lo, a.lo * b.hi, a.hi * b.lo, a.hi * b.hi]
+    return fits(S(acc.lo + min(prods), acc.hi + max(prods), 64, True), what)
+
+
+def fold_acc_s(s: S, what="fold_acc_s") -> S:
+    """hi R + lo with hi = s >> 32 signed, lo = the low word unsigned"""
+    fits(S(s.lo, s.hi, 64, True), what)
+    if exact(s):
+        return S((s.hi >> 32) * R1 + (s.hi & M32), (s.hi >> 32) * R1 + (s.hi & M32), 64, True)
+    return S((s.lo >> 32) * R1, (s.hi >> 32) * R1 + W32 - 1, 64, True)
+
+
+def smont_canon(t: S, what="smont_canon") -> S:
+    """signed Montgomery step (|t| < P 2^31 -> (-P, P)) and one conditional + P -> [0, P)"""
+    fits(S(t.lo, t.hi, 64, True), what)
+    if t.lo <= -(P << 31) or t.hi >= (P << 31):
+        raise Violation(f"{what}: needs |t| < P 2^31 = {P << 31}, worst case [{t.lo}, {t.hi}] ({max(abs(t.lo), abs(t.hi)) / (P << 31):.3f} x)")
+    if exact(t):
+        m = ((t.hi & M32) * NEG_PINV) & M32
+        m = m - W32 if m >= (1 << 31) else m
+        r = (t.hi + m * P) >> 32
+        return pt(r + P if r < 0 else r)
+    return CANON()
 
 
 def add_mod(a: S, b: S, what="add_mod") -> S:
@@ -277,6 +316,21 @@ class Parser:
 
     def unary(self):
         # a cast: `(uint64_t)` / `(size_t)` followed by a unary expression
+        if self.peek() == ("op", "(") and self.peek(1) == ("id", "int32_t") and self.peek(2) == ("op", ")"):
+            # (int32_t)x and (int32_t)(x - Pu): the 32-bit word REINTERPRETED as signed — the u32 expression may wrap (that is the point:
+            # x - P for x in [0, 2P)), the true value must fit int32
+            self.eat(); self.eat(); self.eat()
+            if self.peek() == ("op", "("):
+                self.eat()
+                v = self.expr()
+                self.eat(")")
+            else:
+                v = self.unary()
+            if not isinstance(v, S):
+                raise Violation(f"cast of a non-scalar in `{self.ctx}`")
+            if v.w != 32:
+                raise Violation(f"(int32_t) of a {v.w}-bit value in `{self.ctx}`")
+            return as_i32(S(v.lo, v.hi, 32, True), "(int32_t)")
         if self.peek() == ("op", "(") and self.peek(1) == ("id", "uint64_t") and self.peek(2) == ("op", ")"):
             self.eat(); self.eat(); self.eat()
             v = self.unary()
@@ -308,7 +362,13 @@ class Parser:
                 self.eat()
                 k = self.expr()
                 self.eat("]")
-                v = U4([pt(int(x)) for x in self.conc["pwp"][k.hi]]) if self.conc is not None else U4([CANON() for _ in range(4)])
+                centred = bool(self.env.get("__centred__", {}).get(k.hi)) if exact(k) else False
+                if self.conc is not None:
+                    v = U4([pt(int(x)) for x in self.conc["pwp"][k.hi]])          # (centred slots: negative values)
+                elif centred:                                                     # |p| <= (P - 1) / 2, read as int32 by its consumer
+                    v = U4([S(-((P - 1) // 2), (P - 1) // 2, 32) for _ in range(4)])
+                else:
+                    v = U4([CANON() for _ in range(4)])
             else:
                 return v
 
@@ -392,6 +452,14 @@ class Parser:
                     return pt(int(self.conc["tap"](int(m.group(1)), int(m.group(2)), int(m.group(3)))))
                 return CANON()
             a = self.args()
+            if val in ("mad_i64", "mad_i64_k"):
+                if len(a) != 3 or not all(isinstance(x, S) for x in a):
+                    raise Violation(f"{val} wants three scalars in `{self.ctx}`")
+                return mad_i64(a[0], a[1], a[2], val)
+            if val == "fold_acc_s":
+                return fold_acc_s(a[0])
+            if val == "smont_canon":
+                return smont_canon(a[0])
             fn = {"mont_reduce": mont_reduce, "mont_reduce_lazy": mont_reduce_lazy, "mont_reduce_wide": mont_reduce_wide,
                   "mont_reduce_wide_lazy": lambda t, what="mont_reduce_wide_lazy": mont_reduce_wide(t, what, lazy=True),
                   "fold_acc": fold_acc, "add_mod": add_mod, "sub_mod": sub_mod, "mul_mod": mul_mod, "mul_lazy": mul_lazy}.get(val)
@@ -436,7 +504,7 @@ class KernelCheck:
         if isinstance(v, S):
             fits(v, f"{what} {name}")
             if v.w == 64:
-                self.max_acc = max(self.max_acc, v.hi)
+                self.max_acc = max(self.max_acc, 2 * max(abs(v.lo), abs(v.hi)) if v.sg else v.hi)      # (a signed sum uses one bit for the sign)
         elif isinstance(v, E):
             for x in v.c:
                 fits(x, f"{what} {name}")
@@ -456,7 +524,7 @@ class KernelCheck:
             for n, v in zip(names, new):
                 self.store(n, v, "accumulator")
             return
-        m = re.match(r"^(?:const\s+)?(uint32_t|uint64_t|Fp4|uint4)\s+(.*)$", st)
+        m = re.match(r"^(?:const\s+)?(uint32_t|uint64_t|int32_t|int64_t|Fp4|uint4)\s+(.*)$", st)
         if m:
             typ, rest = m.group(1), m.group(2)
             if typ == "Fp4" and re.match(r"^[A-Za-z_0-9]+\(", rest):           # const Fp4 x7(Fp::raw(..), ...)
@@ -466,14 +534,14 @@ class KernelCheck:
                 return
             # `uint32_t t0_0 = 0, t0_1 = 0, ...` (several declarators) or one `NAME = EXPR`
             for decl in _split_top(rest, ","):
-                decl = re.sub(r"^(uint32_t|uint64_t)\s+", "", decl.strip())
+                decl = re.sub(r"^(uint32_t|uint64_t|int32_t|int64_t)\s+", "", decl.strip())
                 name, expr = [x.strip() for x in decl.split("=", 1)]
                 p = Parser(tokenize(expr), env, st)
                 v = p.expr()
                 if not p.done():
                     raise Violation(f"parse: trailing tokens in `{st}`")
                 if isinstance(v, S):
-                    v = S(v.lo, v.hi, 64 if typ == "uint64_t" else 32)
+                    v = S(v.lo, v.hi, 64 if typ in ("uint64_t", "int64_t") else 32, typ in ("int32_t", "int64_t"))
                 self.store(name, v, "value")
             return
         m = re.match(r"^([A-Za-z_0-9]+)\s*\+=\s*(.*)$", st)
@@ -482,7 +550,7 @@ class KernelCheck:
             p = Parser(tokenize(expr), env, st)
             v = p.expr()
             cur = env[name]
-            self.store(name, S(cur.lo + v.lo, cur.hi + v.hi, cur.w), "accumulator")
+            self.store(name, S(cur.lo + v.lo, cur.hi + v.hi, cur.w, cur.sg), "accumulator")
             return
         m = re.match(r"^a\.check\[[^\]]*\]\s*=\s*(.*)$", st)
         if m:
@@ -500,7 +568,7 @@ class KernelCheck:
                 if name not in env:
                     raise Violation(f"assignment to an undeclared name {name} in `{st}`")
                 cur = env[name]
-                self.store(name, S(v.lo, v.hi, cur.w) if isinstance(v, S) else v, "value")
+                self.store(name, S(v.lo, v.hi, cur.w, cur.sg) if isinstance(v, S) else v, "value")
             return
         raise Violation(f"statement form not understood: `{st}`")
 
@@ -566,6 +634,11 @@ def check_source(src: str, label: str = "") -> Tuple[List[str], dict]:
             body.append((j + 1, lines[j]))
             j += 1
         kc = KernelCheck((label + ":" if label else "") + name)
+        # which slots of its power table this kernel reads CENTRED (bit 31 of the exported exponent word): |p| <= (P - 1) / 2 there
+        mm = re.search(r"const uint32_t (?:exps_%s|%s_exps)\[\] = \{([^}]*)\}" % (name, name), src)
+        if mm:
+            words = [int(x) for x in mm.group(1).split(",")]
+            kc.env["__centred__"] = {k: True for k, w in enumerate(words[1:]) if w >> 31}
         # the generator's claims are checked where they stand: a `// BOUND x <= N` line follows the statement that completes x
         claims_inline: List[Tuple[int, str, int]] = []
         kc_lines: List[Tuple[int, str]] = []
@@ -585,7 +658,7 @@ def check_source(src: str, label: str = "") -> Tuple[List[str], dict]:
                 continue
             stats["claims"] += 1
             v = kc.env.get(cname)
-            got = max(x.hi for x in v.c) if isinstance(v, E) else (v.hi if isinstance(v, S) else None)
+            got = max(x.hi for x in v.c) if isinstance(v, E) else (max(abs(v.lo), abs(v.hi)) if isinstance(v, S) else None)      # (a signed sum: its magnitude)
             if got is None:
                 kc.violations.append(f"{kc.name}: the bounds trace names {cname}, which the code has not defined at that point")
                 break
@@ -648,13 +721,17 @@ def execute_source(src: str, groups, globals_, poly_mix, po2: int, idx: int) -> 
     cmap = {slot: tuple(canon(w) for w in C) for slot, C in consts}
     cache: Dict[int, tuple] = {}
     pwp = []
-    for slot, e in enumerate(exps):
+    for slot, word in enumerate(exps):
+        e, centred = word & 0x7FFFFFFF, word >> 31
         if e not in cache:
             cache[e] = fp4_pow_canon(mixc, e)
         v = cache[e]
         if slot in cmap:
             v = fp4_mul_canon(v, cmap[slot])
-        pwp.append(tuple(montw(x) for x in v))
+        ws = tuple(montw(x) for x in v)
+        if centred:                                  # the library's last table step: x or x - P in [-(P-1)/2, (P-1)/2] (k_ext_center_at)
+            ws = tuple(x - P if x > (P - 1) // 2 else x for x in ws)
+        pwp.append(ws)
     w = pow(137, 1 << (27 - (po2 + 2)), P)
     y = pow(3 * pow(w, idx, P) % P, n, P)
     zinv = montw(pow((y - 1) % P, P - 2, P))

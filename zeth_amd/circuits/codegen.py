@@ -83,10 +83,17 @@ FACTOR_MIN = int(os.environ.get("ZKH_CODEGEN_FACTOR", "3"))
 # constraints (c + L) * s cost ~58 VALU instructions each before, ~12 after.  Needs GATHER; at most LIN_MAX terms, else the Fp4 path.
 LINFORM = int(os.environ.get("ZKH_CODEGEN_LINFORM", "1"))
 LIN_MAX = 4
+# SIGNED (round 6): the running constraint sums are SIGNED 64-bit.  A base leaf multiplies the CENTRED mix power (|p| <= (P-1)/2: the
+# slot is flagged in bit 31 of its exponent word, the library centres it when it builds the table) by its operand as an int32 — a
+# canonical word as it is, a lazy one ([0, 2P)) as x - P in [-P, P), the same residue, one subtraction — so EVERY leaf is at most
+# (P-1)/2 * P ~ P^2 / 2: four leaves between folds whether their operands were reduced or not (2^63 = 2.27 P^2), where the unsigned
+# sums held two lazy ones.  Folding was 17 % of a kernel; SYN-HEAVY 84.1 k -> 77 k VALU instructions per point.  A non-linear Fp4 leaf
+# (a product of two non-constant Fp4 values: none in the shipped circuits) goes through the reduced total instead of ext_accumulate.
+SIGNED = int(os.environ.get("ZKH_CODEGEN_SIGNED", "1")) and GATHER
 DISTRIBUTE = int(os.environ.get("ZKH_CODEGEN_DISTRIBUTE", "0"))    # measured on the static opcode table and REJECTED as the default (profiles/r05_eval_check_static.txt)
 # compile flags of the generated translation units (build.py and jit.py use the same list)
 KERNEL_FLAGS = [f for f in os.environ.get("ZKH_CODEGEN_FLAGS", "").split() if f]
-GENERATOR_VERSION = 12
+GENERATOR_VERSION = 13
 
 
 def desc_hash64(desc: np.ndarray) -> int:
@@ -972,13 +979,13 @@ class _Emitter:
         self.n_arith += 1
         self.cache[v] = name
 
-    def pw(self, e: int, const: Optional[Tuple[int, int, int, int]] = None) -> int:
+    def pw(self, e: int, const: Optional[Tuple[int, int, int, int]] = None, centered: bool = False) -> int:
         """Index of mix^e in the table this kernel reads: e itself, or (GATHER) the next slot of the part's own table — which may
         hold mix^e times an Fp4 constant (LINFORM)."""
         if not GATHER:
             assert const is None or const == UNIT
             return e
-        self.pw_exps.append(e)
+        self.pw_exps.append(e | (1 << 31) if centered else e)
         if const is not None and const != UNIT:
             self.pw_consts.append((len(self.pw_exps) - 1, const))
         return len(self.pw_exps) - 1
@@ -997,11 +1004,14 @@ class _Emitter:
         """Make room in the 64-bit constraint sums without reducing them: s = hi 2^32 + lo = hi R + lo (mod P), which is
         below 2^60 + 2^32 and leaves room for four more products (4 P^2 + 2^60 + 2^32 < 2^64)."""
         for k in range(4):
-            self.w(f"    s{d}_{k} = fold_acc(s{d}_{k});")
+            self.w(f"    s{d}_{k} = fold_acc{'_s' if SIGNED else ''}(s{d}_{k});")
         self.pend[d] = 0
         self.folded[d] = True
         x = self.sb.get(d, 0)
-        self.sb[d] = x if x < (1 << 32) else (x >> 32) * R1 + (1 << 32) - 1
+        if SIGNED:                          # |hi| R + lo with |hi| <= (|s| >> 32) + 1
+            self.sb[d] = ((x >> 32) + 1) * R1 + (1 << 32) - 1
+        else:
+            self.sb[d] = x if x < (1 << 32) else (x >> 32) * R1 + (1 << 32) - 1
 
     def flush(self, d: int) -> None:
         """t{d} = everything accumulated at depth d so far, as canonical words (needed before an Fp4 contribution is
@@ -1011,6 +1021,18 @@ class _Emitter:
         # The running total re-enters as t * R and the plain reduction wants the sum below P 2^32.  Two units of pending
         # products alone qualify: (P-1)(2P-1) + (P-1) R = (P-1)(2^32 - 1); so does a folded part (< 2^60 + 2^32) with one
         # unit on top; anything more is folded first.
+        if SIGNED:
+            # the signed Montgomery step wants |s + t R| < P 2^31 = 1.07 P^2: one unit (P^2 / 2) + a folded part (0.14 P^2) + t R (0.13 P^2)
+            if self.pend.get(d, 0) > 1:
+                self.fold(d)
+            for k in range(4):
+                if self.tzero[d]:
+                    self.w(f"    t{d}_{k} = smont_canon(s{d}_{k}); s{d}_{k} = 0;")
+                else:
+                    self.w(f"    t{d}_{k} = smont_canon(mad_i64_k((int32_t)t{d}_{k}, (int32_t){R1}u, s{d}_{k})); s{d}_{k} = 0;")
+            self.pend[d], self.tzero[d], self.folded[d] = 0, False, False
+            self.sb[d] = 0
+            return
         if self.pend.get(d, 0) > 2 or (self.pend.get(d, 0) > 1 and self.folded.get(d, False)):
             self.fold(d)
         for k in range(4):
@@ -1038,6 +1060,13 @@ class _Emitter:
                 self.acc_leaf(d, b, e, C)
             return
         self.need([v])
+        if self.p.ext[v] and SIGNED:
+            # an Fp4 leaf that is not linear over constants: mix^e * x as an Fp4 product into the REDUCED total (the signed sums read centred
+            # powers; this slot is a canonical one)
+            k = self.pw(e)
+            self.add_fp4(d, f"Fp4(Fp::raw(pwp[{k}].x), Fp::raw(pwp[{k}].y), Fp::raw(pwp[{k}].z), Fp::raw(pwp[{k}].w)) * {self.ext_ref(v)}")
+            self.release()
+            return
         if self.p.ext[v]:
             # tot += mix^e * x for an Fp4 x: sixteen products straight into the unreduced sums (four units of room)
             if self.pend.get(d, 0) > 0:
@@ -1052,6 +1081,19 @@ class _Emitter:
         # tot += mix^e * v: four 64-bit multiply-adds (scalar-loaded power words); the sums are folded (not reduced)
         # when four units of products are pending and reduced once where the total is needed
         r = self.ref(v)
+        if SIGNED:
+            # tot += centred(mix^e) * (v as int32): one unit whether v is lazy (v - P in [-P, P)) or canonical
+            if self.pend.get(d, 0) + 1 > 4:
+                self.fold(d)
+            rs = f"(int32_t)({r} - {P}u)" if (v in self.p.lazy and self.p.fp[v][0] != OP_CONST) else f"(int32_t){r}"
+            self.w(f"    {{ const uint4 p_ = pwp[{self.pw(e, const, centered=True)}]; const int32_t r_ = {rs}; "
+                   f"s{d}_0 = mad_i64_k(r_, (int32_t)p_.x, s{d}_0); s{d}_1 = mad_i64_k(r_, (int32_t)p_.y, s{d}_1); "
+                   f"s{d}_2 = mad_i64_k(r_, (int32_t)p_.z, s{d}_2); s{d}_3 = mad_i64_k(r_, (int32_t)p_.w, s{d}_3); }}")
+            self.release()
+            self.pend[d] = self.pend.get(d, 0) + 1
+            self.sb[d] = self.sb.get(d, 0) + ((P - 1) // 2) * (P if v in self.p.lazy else self.hi_of(v))
+            self.claim(f"s{d}_0", self.sb[d])
+            return
         wgt = 2 if v in self.p.lazy else 1      # a lazy value (< 2P) makes a product below 2 P^2
         if self.pend.get(d, 0) + wgt > 4:
             self.fold(d)
@@ -1097,6 +1139,18 @@ class _Emitter:
                 self.need([f])
                 any_emitted = True
                 r = self.ref(f)
+                if SIGNED:
+                    # the level total is a canonical word (< P: a positive int32), the factor enters like a leaf operand: |t f| <= (P-1) P, two units
+                    if self.pend.get(d, 0) + 2 > 4:
+                        self.fold(d)
+                    rs = f"(int32_t)({r} - {P}u)" if (f in self.p.lazy and self.p.fp[f][0] != OP_CONST) else f"(int32_t){r}"
+                    self.w(f"    {{ const int32_t f_ = {rs}; s{d}_0 = mad_i64((int32_t)t{d + 1}_0, f_, s{d}_0); s{d}_1 = mad_i64((int32_t)t{d + 1}_1, f_, s{d}_1); "
+                           f"s{d}_2 = mad_i64((int32_t)t{d + 1}_2, f_, s{d}_2); s{d}_3 = mad_i64((int32_t)t{d + 1}_3, f_, s{d}_3); }}")
+                    self.release()
+                    self.pend[d] = self.pend.get(d, 0) + 2
+                    self.sb[d] = self.sb.get(d, 0) + (P - 1) * (P if f in self.p.lazy else self.hi_of(f))
+                    self.claim(f"s{d}_0", self.sb[d])
+                    continue
                 wgt = 2 if f in self.p.lazy else 1
                 if self.pend.get(d, 0) + wgt > 4:
                     self.fold(d)
@@ -1184,7 +1238,7 @@ def emit_part(kernel: str, plan: Plan, lo: int, hi: int, standalone: bool, heade
     for (x, y) in sorted(em.globals_used):
         w(f"    const uint32_t q{x}_{y} = a.globals[{x}][{y}];")
     for d in range(em.depth_used):
-        w(f"    uint32_t t{d}_0 = 0, t{d}_1 = 0, t{d}_2 = 0, t{d}_3 = 0; uint64_t s{d}_0 = 0, s{d}_1 = 0, s{d}_2 = 0, s{d}_3 = 0;")
+        w(f"    uint32_t t{d}_0 = 0, t{d}_1 = 0, t{d}_2 = 0, t{d}_3 = 0; {'int64_t' if SIGNED else 'uint64_t'} s{d}_0 = 0, s{d}_1 = 0, s{d}_2 = 0, s{d}_3 = 0;")
     L.extend(body)
     w("    const uint32_t zi = a.zinv[idx & 3];")
     w("    if (a.accumulate) {")

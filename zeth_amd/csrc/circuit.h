@@ -106,6 +106,7 @@ struct zkh_circuit {
     std::vector<uint32_t> gather_off[2];
     uint32_t* d_gconst[2];                         // (slot, c0..c3) records of all parts, slots rebased to the concatenated table
     uint32_t n_gconst[2];
+    bool gather_centered[2];                       // some slot is read centred (bit 31 of its exponent word): the table build ends with k_ext_center_at
     std::vector<std::vector<uint32_t>> jit_exps;   // per attached part: its exponent list ({} = none exported)
     std::vector<std::vector<uint32_t>> jit_pwc;    // per attached part: its slot-constant list ({} = none exported)
     bool jit_mixed;       // the attached parts disagree about the table (a set half replaced): not launched until repaired

@@ -23,6 +23,7 @@ uint64_t desc_hash64(const uint32_t* w, size_t n) {   // FNV-1a over the words
 const char* launch_ext_powers(zkh_ctx* c, uint32_t* out, const uint32_t start[4], const uint32_t base[4], uint32_t n);
 const char* launch_ext_powers_at(zkh_ctx* c, uint32_t* out, const uint32_t base[4], const uint32_t* d_exps, uint32_t n);
 const char* launch_ext_scale_at(zkh_ctx* c, uint32_t* out, const uint32_t* d_recs, uint32_t n);
+const char* launch_ext_center_at(zkh_ctx* c, uint32_t* out, const uint32_t* d_exps, uint32_t n);
 }
 static const char* set_gather(zkh_circuit* c, int which, const std::vector<const uint32_t*>& lists, const std::vector<const uint32_t*>& consts);
 namespace zkh {
@@ -608,6 +609,7 @@ static const char* set_gather(zkh_circuit* c, int which, const std::vector<const
     if (c->d_gather[which]) { (void)hipFree(c->d_gather[which]); c->d_gather[which] = nullptr; }
     if (c->d_gconst[which]) { (void)hipFree(c->d_gconst[which]); c->d_gconst[which] = nullptr; }
     c->n_gconst[which] = 0;
+    c->gather_centered[which] = false;
     c->gather_off[which].clear();
     size_t exported = 0;
     for (const uint32_t* l : lists) exported += l != nullptr;
@@ -616,9 +618,10 @@ static const char* set_gather(zkh_circuit* c, int which, const std::vector<const
     std::vector<uint32_t> all, off(1, 0), recs;
     for (size_t part = 0; part < lists.size(); part++) {
         const uint32_t* l = lists[part];
-        for (uint32_t i = 0; i < l[0]; i++) {
-            ZKH_REQUIRE(l[1 + i] < c->n_mix_pows, "eval_check kernels: gathered mix power %u, the step list has %u", l[1 + i], c->n_mix_pows);
+        for (uint32_t i = 0; i < l[0]; i++) {            // (bit 31: the kernel reads this slot centred)
+            ZKH_REQUIRE((l[1 + i] & 0x7fffffffu) < c->n_mix_pows, "eval_check kernels: gathered mix power %u, the step list has %u", l[1 + i] & 0x7fffffffu, c->n_mix_pows);
             all.push_back(l[1 + i]);
+            if (l[1 + i] >> 31) c->gather_centered[which] = true;
         }
         const uint32_t* k = part < consts.size() ? consts[part] : nullptr;
         for (uint32_t i = 0; k && i < k[0]; i++) {
@@ -776,6 +779,7 @@ extern "C" const char* zkh_eval_check(zkh_ctx* ctx, const zkh_circuit* c, zkh_bu
         ZKH_TRY(new_buf(ctx, 4 * (size_t)goff->back() + 4, false, pows.out()));
         ZKH_TRY(launch_ext_powers_at(ctx, pows->ptr(), poly_mix, c->d_gather[which], goff->back()));
         ZKH_TRY(launch_ext_scale_at(ctx, pows->ptr(), c->d_gconst[which], c->n_gconst[which]));
+        if (c->gather_centered[which]) ZKH_TRY(launch_ext_center_at(ctx, pows->ptr(), c->d_gather[which], goff->back()));
     } else {
         ZKH_TRY(new_buf(ctx, 4 * (size_t)c->n_mix_pows, false, pows.out()));
         const uint32_t one[4] = {R1, 0, 0, 0};

@@ -174,6 +174,15 @@ ZKH_HD uint32_t mul_lazy(uint32_t a, uint32_t b) { return mont_reduce_lazy((uint
 // Room in a 64-bit sum of products without reducing it: hi 2^32 + lo = hi R + lo (mod P), below 2^60 + 2^32.
 ZKH_HD uint64_t fold_acc(uint64_t s) { return (s >> 32) * R1 + (uint32_t)s; }
 
+// SIGNED twins for the generated eval_check kernels' running constraint sums (circuits/codegen.py SIGNED): the mix powers are read
+// CENTRED (|p| <= (P-1)/2, as int32) and a lazy operand x in [0, 2P) enters as x - P in [-P, P) (the same residue), so every leaf
+// is |p r| <= (P-1)/2 * P ~ P^2 / 2 whether its operand was reduced or not — four leaves fit the signed 64-bit sum (2^63 = 2.27 P^2)
+// between folds, where the unsigned sums (4.55 P^2) held only two lazy ones (2 P^2 each).
+// fold: s = hi 2^32 + lo with hi SIGNED and lo unsigned = hi R + lo (mod P); |result| < 2^31 R + 2^32 < 2^59.1
+ZKH_HD int64_t fold_acc_s(int64_t s) { return mad_i64_k((int32_t)(s >> 32), (int32_t)R1, (int64_t)(uint32_t)s); }
+// the canonical word of a signed sum |t| < P 2^31: the signed Montgomery step (uncorrected, in (-P, P)) and one conditional + P
+ZKH_HD uint32_t smont_canon(int64_t t) { return canon(smont_reduce(t)); }
+
 ZKH_HD Fp4 operator*(Fp4 a, Fp4 b) {
     const uint64_t a0 = a.c[0].v, a1 = a.c[1].v, a2 = a.c[2].v, a3 = a.c[3].v;
     const uint64_t b0 = b.c[0].v, b1 = b.c[1].v, b2 = b.c[2].v, b3 = b.c[3].v;

@@ -29,9 +29,20 @@ __global__ void k_ext_powers(uint32_t* out, Fp4 start, Fp4 base, uint32_t n) {
 }
 
 // out[i] = base^exps[i], i < n   (eval_check's mix powers gathered into the order a generated kernel reads them)
+// (bit 31 of an exponent word = the slot is read CENTRED by its kernel: see k_ext_center_at)
 __global__ void k_ext_powers_at(uint32_t* out, Fp4 base, const uint32_t* __restrict__ exps, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) st_ext(out + 4 * i, fp4_pow(base, exps[i]));
+    if (i < n) st_ext(out + 4 * i, fp4_pow(base, exps[i] & 0x7fffffffu));
+}
+// slots flagged in bit 31 of their exponent word hold the CENTRED representative of every component, x or x - P in
+// [-(P-1)/2, (P-1)/2] as a two's-complement word (the signed constraint sums of the generated kernels: fp.h fold_acc_s); last step of
+// the table build, after the constants of k_ext_scale_at
+__global__ void k_ext_center_at(uint32_t* out, const uint32_t* __restrict__ exps, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !(exps[i] >> 31)) return;
+    uint4 v = *(uint4*)(out + 4 * (size_t)i);
+    v.x = (uint32_t)center(v.x); v.y = (uint32_t)center(v.y); v.z = (uint32_t)center(v.z); v.w = (uint32_t)center(v.w);
+    *(uint4*)(out + 4 * (size_t)i) = v;
 }
 
 // out[slot] *= C for the slots a generated kernel wants scaled by an Fp4 constant: recs = (slot, c0, c1, c2, c3) x n
@@ -462,6 +473,11 @@ const char* launch_ext_powers_at(zkh_ctx* c, uint32_t* out, const uint32_t base[
     if (!n) return nullptr;
     k_ext_powers_at<<<(unsigned)ceil_div(n, TB), TB, 0, c->stream>>>(out, to_fp4(base), d_exps, n);
     return last_launch_error("ext_powers_at");
+}
+const char* launch_ext_center_at(zkh_ctx* c, uint32_t* out, const uint32_t* d_exps, uint32_t n) {
+    if (!n) return nullptr;
+    k_ext_center_at<<<(unsigned)ceil_div(n, TB), TB, 0, c->stream>>>(out, d_exps, n);
+    return last_launch_error("ext_center_at");
 }
 const char* launch_ext_scale_at(zkh_ctx* c, uint32_t* out, const uint32_t* d_recs, uint32_t n) {
     if (!n) return nullptr;
