@@ -311,6 +311,11 @@ class Parser:
         if isinstance(a, S) and isinstance(b, S):
             w = max(a.w, b.w)
             fits(a, "multiplicand"); fits(b, "multiplicand")
+            if a.sg or b.sg:
+                if not (a.sg and b.sg and a.w == b.w):
+                    raise Violation(f"a product of a signed and an unsigned (or differently wide) operand in `{self.ctx}`")
+                prods = [a.lo * b.lo, a.lo * b.hi, a.hi * b.lo, a.hi * b.hi]
+                return S(min(prods), max(prods), w, True)
             return S(a.lo * b.lo, a.hi * b.hi, w)
         raise Violation(f"unsupported operands of * in `{self.ctx}`")
 
@@ -331,6 +336,13 @@ class Parser:
             if v.w != 32:
                 raise Violation(f"(int32_t) of a {v.w}-bit value in `{self.ctx}`")
             return as_i32(S(v.lo, v.hi, 32, True), "(int32_t)")
+        if self.peek() == ("op", "(") and self.peek(1) == ("id", "int64_t") and self.peek(2) == ("op", ")"):
+            self.eat(); self.eat(); self.eat()
+            v = self.unary()
+            if not isinstance(v, S) or not v.sg:
+                raise Violation(f"(int64_t) of something that is not a signed scalar in `{self.ctx}`")
+            fits(v, "(int64_t) operand")
+            return S(v.lo, v.hi, 64, True)
         if self.peek() == ("op", "(") and self.peek(1) == ("id", "uint64_t") and self.peek(2) == ("op", ")"):
             self.eat(); self.eat(); self.eat()
             v = self.unary()

@@ -89,7 +89,13 @@ LIN_MAX = 4
 # (P-1)/2 * P ~ P^2 / 2: four leaves between folds whether their operands were reduced or not (2^63 = 2.27 P^2), where the unsigned
 # sums held two lazy ones.  Folding was 17 % of a kernel; SYN-HEAVY 84.1 k -> 77 k VALU instructions per point.  A non-linear Fp4 leaf
 # (a product of two non-constant Fp4 values: none in the shipped circuits) goes through the reduced total instead of ext_accumulate.
-SIGNED = int(os.environ.get("ZKH_CODEGEN_SIGNED", "1")) and GATHER
+SIGNED = int(os.environ.get("ZKH_CODEGEN_SIGNED", "1"))
+
+
+def signed_sums() -> bool:
+    """the signed running sums need the gathered tables (a centred slot is a slot of a kernel's OWN table): read when code is emitted"""
+    return bool(SIGNED and GATHER)
+
 DISTRIBUTE = int(os.environ.get("ZKH_CODEGEN_DISTRIBUTE", "0"))    # measured on the static opcode table and REJECTED as the default (profiles/r05_eval_check_static.txt)
 # compile flags of the generated translation units (build.py and jit.py use the same list)
 KERNEL_FLAGS = [f for f in os.environ.get("ZKH_CODEGEN_FLAGS", "").split() if f]
@@ -1004,11 +1010,11 @@ class _Emitter:
         """Make room in the 64-bit constraint sums without reducing them: s = hi 2^32 + lo = hi R + lo (mod P), which is
         below 2^60 + 2^32 and leaves room for four more products (4 P^2 + 2^60 + 2^32 < 2^64)."""
         for k in range(4):
-            self.w(f"    s{d}_{k} = fold_acc{'_s' if SIGNED else ''}(s{d}_{k});")
+            self.w(f"    s{d}_{k} = fold_acc{'_s' if signed_sums() else ''}(s{d}_{k});")
         self.pend[d] = 0
         self.folded[d] = True
         x = self.sb.get(d, 0)
-        if SIGNED:                          # |hi| R + lo with |hi| <= (|s| >> 32) + 1
+        if signed_sums():                   # |hi| R + lo with |hi| <= (|s| >> 32) + 1
             self.sb[d] = ((x >> 32) + 1) * R1 + (1 << 32) - 1
         else:
             self.sb[d] = x if x < (1 << 32) else (x >> 32) * R1 + (1 << 32) - 1
@@ -1021,7 +1027,7 @@ class _Emitter:
         # The running total re-enters as t * R and the plain reduction wants the sum below P 2^32.  Two units of pending
         # products alone qualify: (P-1)(2P-1) + (P-1) R = (P-1)(2^32 - 1); so does a folded part (< 2^60 + 2^32) with one
         # unit on top; anything more is folded first.
-        if SIGNED:
+        if signed_sums():
             # the signed Montgomery step wants |s + t R| < P 2^31 = 1.07 P^2: one unit (P^2 / 2) + a folded part (0.14 P^2) + t R (0.13 P^2)
             if self.pend.get(d, 0) > 1:
                 self.fold(d)
@@ -1060,7 +1066,7 @@ class _Emitter:
                 self.acc_leaf(d, b, e, C)
             return
         self.need([v])
-        if self.p.ext[v] and SIGNED:
+        if self.p.ext[v] and signed_sums():
             # an Fp4 leaf that is not linear over constants: mix^e * x as an Fp4 product into the REDUCED total (the signed sums read centred
             # powers; this slot is a canonical one)
             k = self.pw(e)
@@ -1081,14 +1087,16 @@ class _Emitter:
         # tot += mix^e * v: four 64-bit multiply-adds (scalar-loaded power words); the sums are folded (not reduced)
         # when four units of products are pending and reduced once where the total is needed
         r = self.ref(v)
-        if SIGNED:
+        if signed_sums():
             # tot += centred(mix^e) * (v as int32): one unit whether v is lazy (v - P in [-P, P)) or canonical
             if self.pend.get(d, 0) + 1 > 4:
                 self.fold(d)
             rs = f"(int32_t)({r} - {P}u)" if (v in self.p.lazy and self.p.fp[v][0] != OP_CONST) else f"(int32_t){r}"
+            # (plain C, not the pinned v_mad_i64_i32 of fp.h: hipcc picks that instruction here by itself, and an asm operand tied to an
+            # SGPR keeps it from merging the scalar loads of the powers — s_load 313 -> 188 per part, 12 VGPRs fewer)
             self.w(f"    {{ const uint4 p_ = pwp[{self.pw(e, const, centered=True)}]; const int32_t r_ = {rs}; "
-                   f"s{d}_0 = mad_i64_k(r_, (int32_t)p_.x, s{d}_0); s{d}_1 = mad_i64_k(r_, (int32_t)p_.y, s{d}_1); "
-                   f"s{d}_2 = mad_i64_k(r_, (int32_t)p_.z, s{d}_2); s{d}_3 = mad_i64_k(r_, (int32_t)p_.w, s{d}_3); }}")
+                   f"s{d}_0 += (int64_t)r_ * (int64_t)(int32_t)p_.x; s{d}_1 += (int64_t)r_ * (int64_t)(int32_t)p_.y; "
+                   f"s{d}_2 += (int64_t)r_ * (int64_t)(int32_t)p_.z; s{d}_3 += (int64_t)r_ * (int64_t)(int32_t)p_.w; }}")
             self.release()
             self.pend[d] = self.pend.get(d, 0) + 1
             self.sb[d] = self.sb.get(d, 0) + ((P - 1) // 2) * (P if v in self.p.lazy else self.hi_of(v))
@@ -1139,13 +1147,13 @@ class _Emitter:
                 self.need([f])
                 any_emitted = True
                 r = self.ref(f)
-                if SIGNED:
+                if signed_sums():
                     # the level total is a canonical word (< P: a positive int32), the factor enters like a leaf operand: |t f| <= (P-1) P, two units
                     if self.pend.get(d, 0) + 2 > 4:
                         self.fold(d)
                     rs = f"(int32_t)({r} - {P}u)" if (f in self.p.lazy and self.p.fp[f][0] != OP_CONST) else f"(int32_t){r}"
-                    self.w(f"    {{ const int32_t f_ = {rs}; s{d}_0 = mad_i64((int32_t)t{d + 1}_0, f_, s{d}_0); s{d}_1 = mad_i64((int32_t)t{d + 1}_1, f_, s{d}_1); "
-                           f"s{d}_2 = mad_i64((int32_t)t{d + 1}_2, f_, s{d}_2); s{d}_3 = mad_i64((int32_t)t{d + 1}_3, f_, s{d}_3); }}")
+                    self.w(f"    {{ const int32_t f_ = {rs}; s{d}_0 += (int64_t)(int32_t)t{d + 1}_0 * (int64_t)f_; s{d}_1 += (int64_t)(int32_t)t{d + 1}_1 * (int64_t)f_; "
+                           f"s{d}_2 += (int64_t)(int32_t)t{d + 1}_2 * (int64_t)f_; s{d}_3 += (int64_t)(int32_t)t{d + 1}_3 * (int64_t)f_; }}")
                     self.release()
                     self.pend[d] = self.pend.get(d, 0) + 2
                     self.sb[d] = self.sb.get(d, 0) + (P - 1) * (P if f in self.p.lazy else self.hi_of(f))
@@ -1238,7 +1246,7 @@ def emit_part(kernel: str, plan: Plan, lo: int, hi: int, standalone: bool, heade
     for (x, y) in sorted(em.globals_used):
         w(f"    const uint32_t q{x}_{y} = a.globals[{x}][{y}];")
     for d in range(em.depth_used):
-        w(f"    uint32_t t{d}_0 = 0, t{d}_1 = 0, t{d}_2 = 0, t{d}_3 = 0; {'int64_t' if SIGNED else 'uint64_t'} s{d}_0 = 0, s{d}_1 = 0, s{d}_2 = 0, s{d}_3 = 0;")
+        w(f"    uint32_t t{d}_0 = 0, t{d}_1 = 0, t{d}_2 = 0, t{d}_3 = 0; {'int64_t' if signed_sums() else 'uint64_t'} s{d}_0 = 0, s{d}_1 = 0, s{d}_2 = 0, s{d}_3 = 0;")
     L.extend(body)
     w("    const uint32_t zi = a.zinv[idx & 3];")
     w("    if (a.accumulate) {")
