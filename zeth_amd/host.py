@@ -45,7 +45,8 @@ def session_segments(total_cycles: int, segment_po2: int = 20, base_seed: int = 
 # `cache/input_<blockhash>.json` per block = serde_json of `StatelessInput{block, witness}`; run-parallel.sh:93 iterates
 # over exactly those files.  The segment count of a block comes from EXECUTING the guest on that input (the "N total
 # cycles" line run-parallel.sh:67 scrapes), which needs the rv32im executor + guest ELF (not available offline), so this
-# reader is a stub: it validates the file shape, takes the cycle count from a sidecar written by a previous dev-mode run
+# reader validates the file shape and, as cli.rs:141 does (`ensure!(input.block.hash_slow() == header.hash)`), that the block
+# header hashes to the hash in the file name (zeth_amd/eth_header.py); the CYCLES stay a stub: taken from a sidecar written by a previous dev-mode run
 # (`input_<hash>.cycles.json`: the run-parallel.sh columns) when there is one, and otherwise falls back to a declared
 # estimate from the block's gas — enough to drive `session_segments` / the block bench with realistic segment counts.
 # ---------------------------------------------------------------------------------------------------------------
@@ -61,6 +62,8 @@ class CachedInput:
     total_cycles: int
     cycles_source: str              # "sidecar" (measured by a dev-mode run) | "gas-estimate" | "size-estimate"
     keccak_calls: Optional[int] = None
+    hash_checked: bool = False      # the header was complete and keccak256(rlp(header)) == block_hash (cli.rs:141)
+    block_number: Optional[int] = None
 
     def segments(self, segment_po2: int = 20, base_seed: int = 0x5EED0000) -> List[Segment]:
         return session_segments(self.total_cycles, segment_po2, base_seed)
@@ -79,6 +82,15 @@ def read_cached_input(cache_dir: str, block_hash: str) -> CachedInput:
     gas = header.get("gasUsed", header.get("gas_used"))
     if isinstance(gas, str):
         gas = int(gas, 16) if gas.startswith("0x") else int(gas)
+    from .eth_header import header_hash, header_is_complete
+    checked, number = False, None
+    if header_is_complete(header):
+        got = header_hash(header)
+        if got != block_hash.lower():
+            raise ValueError(f"{path}: the block header hashes to {got}, not to the hash the file is named after")
+        checked = True
+        number = header["number"]
+        number = int(number, 16) if isinstance(number, str) and number.startswith("0x") else int(number)
     size = os.path.getsize(path)
     side = os.path.join(cache_dir, f"input_{block_hash}.cycles.json")
     keccak = None
@@ -90,7 +102,7 @@ def read_cached_input(cache_dir: str, block_hash: str) -> CachedInput:
         cycles, source = int(gas * CYCLES_PER_GAS_ESTIMATE), "gas-estimate"
     else:
         cycles, source = max(1 << 20, size * 64), "size-estimate"
-    return CachedInput(block_hash, path, size, gas, cycles, source, keccak)
+    return CachedInput(block_hash, path, size, gas, cycles, source, keccak, checked, number)
 
 
 def list_cached_inputs(cache_dir: str) -> List[str]:
