@@ -111,6 +111,10 @@ class Run:
             ids = fake.split(",")
             self.identity.update(pci_bus_id=ids[self.rank % len(ids)], uuid=ids[self.rank % len(ids)], fake=True)
         views = self.ctl.allgather(self.identity) if self.distributed else {0: self.identity}
+        if self.distributed:
+            # nobody acts on the view before everybody HAS it: a rank that refuses below declares itself failed on its way out, and a
+            # peer still polling inside the allgather would then drop that rank's entry, count one device fewer and start the run
+            self.ctl.barrier()
         self.devices = [views[r] for r in sorted(views)]
         keys = [(d.get("uuid") or d.get("pci_bus_id")) for d in self.devices]
         known = [k for k in keys if k]

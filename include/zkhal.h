@@ -463,6 +463,12 @@ void zkh_session_set_streamed_fold(zkh_session*, int on);
  * residue), every segment's pre-state (out[4]) is its predecessor's post-state (out[0]) — `CompositeReceipt::verify_integrity`.
  * SYN-S circuits additionally get their exit-code pair and journal-digest limbs here and have them checked (see below). */
 const char* zkh_session_set_chained(zkh_session*, int on, uint32_t initial_state);
+/* The journal of a chained SYN-S session: the bytes the guest commits — zeth's guest commits the 32-byte block hash
+ * (/root/reference/guests/stateless-client/src/lib.rs:33 `env::commit_slice(block_hash)`), which the CLI then compares with the hash
+ * it computed itself (/root/reference/crates/host/src/bin/cli.rs:103-107).  The last seal binds Output{SHA-256(journal), assumptions};
+ * zkh_session_verify checks the seals against THESE bytes.  journal == NULL (default): the session's final state word, 4 bytes LE.
+ * journal != NULL with journal_len == 0: an empty journal.  Call before zkh_session_prove. */
+const char* zkh_session_set_journal(zkh_session*, const uint8_t* journal, size_t journal_len);
 /* Where a segment's witness comes from (SYN-AIR circuits without public inputs).  0 (default): the closed-form generator on the
  * device (zkh_syn_witgen).  1: upstream's shape — a SEQUENTIAL host preflight per segment (zkh_syn_preflight) running ahead of the
  * seals on `producers_per_lane` host threads per sealing lane (0 = 2), its compact records (16 bytes per cycle) uploaded from pinned

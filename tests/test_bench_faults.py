@@ -110,3 +110,47 @@ def test_an_n_rank_line_lists_n_distinct_devices_or_refuses_to_start():
     assert rc == 0 and len(lines) == 1, err[-2000:]
     cfg = lines[0]["config"]
     assert cfg["devices_distinct"] is False and len(cfg["devices"]) == 4 and {d["pci_bus_id"] for d in cfg["devices"]} == {"0000:05:00.0"}
+
+
+def test_a_slow_rank_still_sees_every_device_before_anyone_refuses(monkeypatch):
+    """The refusal is a verdict every rank reaches from the SAME view.  A rank that got the view first used to declare itself failed
+    on its way out while a slower peer was still polling inside the exchange; the peer then dropped that rank's entry, counted one
+    device fewer, found them distinct and started the run (seen once on the GPU box: no message, the launcher killed rank 0 after its
+    grace period).  Two ranks in threads over one store, rank 0 made slow inside the exchange: both must refuse."""
+    import threading
+    import types
+    import torch.distributed as dist
+    from benchlib.common import Run
+    from benchlib.control import ControlPlane, RankFailed
+    monkeypatch.setenv("ZKH_BENCH_FAKE_DEVICES", "0000:05:00.0")
+    store = dist.HashStore()
+    args = types.SimpleNamespace(po2=16, inflight=1, allow_shared_gpu=False)
+    ctls = [ControlPlane(r, 2, dist.PrefixStore("t", store), 20.0) for r in range(2)]
+    slow = {"first": True}
+    plain = ControlPlane._refresh_failed
+
+    def dawdle(self):
+        if self.rank == 0 and slow["first"]:
+            slow["first"] = False
+            time.sleep(1.0)                      # rank 1 has everything it needs long before rank 0 looks at the store again
+        return plain(self)
+    monkeypatch.setattr(ControlPlane, "_refresh_failed", dawdle)
+    got = {}
+
+    def rank_main(r):
+        run = Run(args, ctls[r], r, r, 2)
+        try:
+            run.exchange_devices()
+            got[r] = ("started", len(run.devices))
+        except SystemExit as e:
+            ctls[r].fail("segment", e)           # what bench.py's handler does with it
+            got[r] = ("refused", e.code)
+        except RankFailed as e:                  # rank 0 said its verdict while this rank was still in the barrier: out, non-zero
+            got[r] = ("released", str(e))
+    ths = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(30)
+    assert got[1] == ("refused", 2) or (got[1][0] == "released" and "rank 0 is gone" in got[1][1])
+    assert got[0][0] == "refused" and "do not hold 2 distinct GPUs" in str(got[0][1]) and "ranks [0, 1] all drive 0000:05:00.0" in str(got[0][1])

@@ -312,3 +312,25 @@ def test_a_session_names_the_receipts_it_assumes(oracle, session, tmp_path):
     assert r.returncode == 1 and "journal does not hash" in r.stderr
     r = run(*flags[2:], *flags[:2])
     assert r.returncode == 1 and "assumption receipts do not hash" in r.stderr
+
+
+def test_a_journal_the_guest_commits_and_the_cli_check():
+    """chain_session(journal=...) binds the bytes the guest commits (zeth: the block hash) instead of the final state word, in the
+    last segment only; Receipt.check_block_hash is cli.rs:103-107 (`B256::try_from(journal)`, then equality)."""
+    from zeth_amd.hal import HalError
+    from zeth_amd.host import CompositeReceipt, Receipt, chain_session, output_limbs
+    from zeth_amd.prover import Segment
+    segs = [Segment(index=i, po2=13, seed=40 + i) for i in range(3)]
+    h = bytes(range(32))
+    a, ja = chain_session(segs, lambda s: 7 + s.index, initial_state=2)
+    b, jb = chain_session(segs, lambda s: 7 + s.index, initial_state=2, journal=h)
+    assert len(ja) == 4 and jb == h
+    assert [x.pub for x in a[:2]] == [x.pub for x in b[:2]] and a[2].pub[:3] == b[2].pub[:3]
+    assert list(b[2].pub[3:]) == output_limbs(h) != list(a[2].pub[3:])
+    rec = Receipt(CompositeReceipt([]), h)
+    rec.check_block_hash(h)
+    rec.check_block_hash("0x" + h.hex())
+    with pytest.raises(HalError, match="journal output mismatch"):
+        rec.check_block_hash(bytes(32))
+    with pytest.raises(HalError, match="failed to decode journal: 4 bytes"):
+        Receipt(CompositeReceipt([]), ja).check_block_hash(h)

@@ -493,3 +493,82 @@ def test_the_native_executor_binds_the_assumptions_in_the_last_seal(hal, oracle)
     assert segment_claim(comp0.segments[-1]).output == output_digest(journal)
     assert all(np.array_equal(a.seal, b.seal) for a, b in zip(comp.segments[:2], comp0.segments[:2])) and not np.array_equal(comp.segments[2].seal, comp0.segments[2].seal)
     sess.close()
+
+
+@pytest.mark.gpu
+def test_a_session_whose_journal_is_a_block_hash(hal, oracle, tmp_path):
+    """The CLI's flow end to end (/root/reference/crates/host/src/bin/cli.rs:88-107): read the cached input (its header must hash to the
+    name it is stored under), prove the session with the journal the guest commits — the 32-byte block hash
+    (guests/stateless-client/src/lib.rs:33) — `receipt.verify(image_id)`, then `journal == block_hash`.  zkh_session_set_journal makes
+    the native executor bind those bytes (Output{SHA-256(journal), ..} in the last seal); seals equal the Python orchestration's and the
+    oracle's; another journal — or the default one — is refused by all three verifiers."""
+    import ctypes as C
+    import json
+    import zko
+    from test_eth_header import BLOCK1, BLOCK1_HASH, GENESIS_HASH
+    from zeth_amd import hal as zhal
+    from zeth_amd.circuits import syn_air
+    from zeth_amd.host import Receipt, Session, chain_session, image_id, output_digest, read_cached_input, segment_claim
+    from zeth_amd.prover import Segment, SegmentProver
+    (tmp_path / f"input_{BLOCK1_HASH}.json").write_text(json.dumps({"block": {"header": BLOCK1, "body": {}}, "witness": {}}))
+    cached = read_cached_input(str(tmp_path), BLOCK1_HASH)
+    assert cached.hash_checked
+    block_hash = bytes.fromhex(cached.block_hash[2:])
+    desc = syn_air.syn_session_small()
+    sp = SegmentProver(hal, desc)
+    segs = [Segment(index=i, po2=13 if i else 12, seed=2700 + i, noise_seed=0x5A) for i in range(3)]
+    contrib = [sp.chain_contribution(s) for s in segs]
+    want, journal = chain_session(segs, lambda s: contrib[s.index], initial_state=4, journal=block_hash)
+    assert journal == block_hash
+    sess = Session(desc, devices=(0,), lanes_per_device=2)
+    sess.set_chained(True, 4)
+    sess.set_journal(block_hash)
+    comp, _, _ = sess.prove(segs, verify=True)
+    oc = zko.OracleCircuit(oracle, desc)
+    for s, r in zip(want, comp.segments):
+        assert np.array_equal(r.seal, oc.prove(s.po2, 1994, s.seed, s.noise_seed, pub=np.asarray(s.pub, dtype=np.uint32))), f"segment {s.index}"
+    assert segment_claim(comp.segments[-1]).output == output_digest(block_hash)
+    roots = {p: sp.control_root(p) for p in (12, 13)}
+    rec = Receipt(comp, block_hash)
+    rec.verify(image_id(desc, 4), desc, initial_state=4, control_root=roots)
+    rec.check_block_hash(BLOCK1_HASH)
+    with pytest.raises(HalError, match="journal output mismatch"):
+        rec.check_block_hash(GENESIS_HASH)
+    with pytest.raises(HalError, match="journal does not hash"):
+        Receipt(comp, bytes.fromhex(GENESIS_HASH[2:])).verify(image_id(desc, 4), desc, initial_state=4, control_root=roots)
+    state_journal = int(segment_claim(comp.segments[-1]).post).to_bytes(4, "little")
+    with pytest.raises(HalError, match="journal does not hash"):
+        Receipt(comp, state_journal).verify(image_id(desc, 4), desc, initial_state=4, control_root=roots)
+    with pytest.raises(HalError, match="failed to decode journal"):
+        Receipt(comp, state_journal).check_block_hash(BLOCK1_HASH)
+    lib = zhal.load_library()
+    u32p = C.POINTER(C.c_uint32)
+    seals = [np.ascontiguousarray(r.seal) for r in comp.segments]
+    ptrs, words = (u32p * 3)(*[x.ctypes.data_as(u32p) for x in seals]), (C.c_size_t * 3)(*[x.size for x in seals])
+    hc = zhal.HostCircuit(desc).h
+    zhal._check(lib.zkh_session_check_termination(hc, ptrs, words, 3, block_hash, 32))
+    with pytest.raises(HalError, match="journal does not hash"):
+        zhal._check(lib.zkh_session_check_termination(hc, ptrs, words, 3, None, 0))
+    # the library's verifier holds the journal it was given: told another one afterwards, it refuses its own seals
+    specs, keep = sess._specs(segs)
+    info = zhal.ProveInfo()
+    zhal._check(lib.zkh_session_prove(sess.h, specs, 3, 0, 18, None, C.byref(info)))
+    try:
+        zhal._check(lib.zkh_session_verify(sess.h, specs, C.byref(info), 18))
+        sess.set_journal(b"")                                                   # an EMPTY journal is a journal, not "the default"
+        with pytest.raises(HalError, match="journal does not hash"):
+            zhal._check(lib.zkh_session_verify(sess.h, specs, C.byref(info), 18))
+        sess.set_journal(None)
+        with pytest.raises(HalError, match="journal does not hash"):
+            zhal._check(lib.zkh_session_verify(sess.h, specs, C.byref(info), 18))
+    finally:
+        lib.zkh_prove_info_free(C.byref(info))
+    # back on the default journal the session binds its final state word again; an empty journal binds SHA-256("")
+    comp0, _, _ = sess.prove(segs, verify=True)
+    assert segment_claim(comp0.segments[-1]).output == output_digest(state_journal)
+    sess.set_journal(b"")
+    comp1, _, _ = sess.prove(segs, verify=True)
+    assert segment_claim(comp1.segments[-1]).output == output_digest(b"")
+    with pytest.raises(HalError, match="only a SYN-S circuit"):
+        Session(syn_air.syn_small(), devices=(0,), lanes_per_device=1).set_journal(block_hash)
+    sess.close()

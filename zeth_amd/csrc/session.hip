@@ -90,6 +90,12 @@ struct zkh_session {
     bool streamed_fold = true;           // join_tree 2: lift2 / join a node the moment its children exist, concurrently with the sealing lanes
     bool chained = false;                // SYN-C sessions: segment i's pre-state = initial + contributions of segments 0 .. i-1 (continuity)
     uint32_t initial_state = 0;          // ... as a canonical residue
+    bool has_journal = false;            // SYN-S: the bytes the guest commits (zkh_session_set_journal); unset: the final state word
+    std::vector<uint8_t> journal;
+    const uint8_t* journal_ptr() const {     // non-NULL also for an EMPTY journal (NULL means "the final state word" downstream)
+        static const uint8_t none = 0;
+        return !has_journal ? nullptr : journal.empty() ? &none : journal.data();
+    }
     int witness_source = 0;              // 0: closed-form generators on the device; 1: sequential host preflight -> compact records -> row fill
     size_t producers_per_lane = 2;       // ... host threads per sealing lane that run the preflight ahead of the seals
     // assumption receipts of the session (zkh_session_set_assumptions): seals of ANOTHER circuit (keccak batches) proven beforehand;
@@ -418,6 +424,14 @@ extern "C" const char* zkh_session_set_chained(zkh_session* s, int on, uint32_t 
     s->chained = on != 0; s->initial_state = initial_state;
     return nullptr;
 }
+extern "C" const char* zkh_session_set_journal(zkh_session* s, const uint8_t* journal, size_t journal_len) {
+    ZKH_REQUIRE(s, "session_set_journal: null session");
+    ZKH_REQUIRE(!journal || circuit_is_session(s->lanes[0].circuit), "session_set_journal: only a SYN-S circuit binds an output digest");
+    ZKH_REQUIRE(journal || !journal_len, "session_set_journal: a length without bytes");
+    s->has_journal = journal != nullptr;
+    s->journal.assign(journal, journal + (journal ? journal_len : 0));
+    return nullptr;
+}
 extern "C" const char* zkh_session_set_witness_source(zkh_session* s, int source, size_t producers_per_lane) {
     ZKH_REQUIRE(s && (source == 0 || source == 1), "session_set_witness_source: source must be 0 (closed form on the device) or 1 (host preflight)");
     ZKH_REQUIRE(source == 0 || (s->lanes[0].circuit->kind == 1 && s->lanes[0].circuit->global_size[GLOBAL_OUT] == 4),
@@ -690,7 +704,8 @@ extern "C" const char* zkh_session_prove(zkh_session* s, const zkh_segment* segs
         if (sess) {
             // ... and WHICH receipts the session assumes: the last seal binds Output{journal, assumptions} (zkh_session_set_assumptions first)
             uint32_t limbs[SESSION_JOURNAL_LIMBS], ad[8];
-            session_journal_limbs(state, s->assumptions_digest(ad), limbs);
+            if (s->has_journal) session_output_limbs(s->journal_ptr(), s->journal.size(), s->assumptions_digest(ad), limbs);
+            else session_journal_limbs(state, s->assumptions_digest(ad), limbs);
             for (size_t i = 0; i < n; i++) {
                 const bool is_last = i + 1 == n;
                 pre_states[i * pw + 1] = fp_encode(is_last ? EXIT_SYS_HALTED : EXIT_SYS_SPLIT).v;
@@ -1166,7 +1181,7 @@ extern "C" const char* zkh_session_verify(zkh_session* s, const zkh_segment* seg
                 seals[i] = info->seals[i];
             }
             uint32_t ad[8];
-            ZKH_TRY(check_session_termination(seals.data(), info->n_segments, nullptr, 0, s->assumptions_digest(ad)));
+            ZKH_TRY(check_session_termination(seals.data(), info->n_segments, s->journal_ptr(), s->journal.size(), s->assumptions_digest(ad)));
         }
     }
     if (!info->root_seal) return nullptr;

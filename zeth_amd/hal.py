@@ -192,6 +192,7 @@ ABI = {
     "zkh_session_set_streamed_fold": (None, [_vp, _i]),
     "zkh_session_set_witness_source": (_err, [_vp, _i, _sz]),
     "zkh_session_set_chained": (_err, [_vp, _i, _u32]),
+    "zkh_session_set_journal": (_err, [_vp, C.c_char_p, _sz]),
     "zkh_session_set_recursion": (_err, [_vp, _u32p, _sz, C.POINTER(_u32p), C.POINTER(_sz), _u32p, _sz]),
     "zkh_succinct_verify": (_err, [_u32p, _sz, _u32p, _sz, _sz, _u32p, _sz, _sz]),
     "zkh_succinct_verify_resolved": (_err, [_u32p, _sz, _u32p, _sz, _sz, _u32p, _sz, _sz, _u32p, _sz]),

@@ -404,9 +404,11 @@ def session_pub_words(pre_state_mont: int, is_last: bool, journal: bytes, assump
     return (int(pre_state_mont), fp_encode(sys), fp_encode(user)) + tuple(output_limbs(journal, assumptions) if is_last else [0] * 16)
 
 
-def chain_session(segments: Sequence[Segment], contribution: Callable[[Segment], int], initial_state: int = 0, assumptions=()):
+def chain_session(segments: Sequence[Segment], contribution: Callable[[Segment], int], initial_state: int = 0, assumptions=(),
+                  journal: Optional[bytes] = None):
     """The executor's part of a SYN-S session: pre-states (as `chain_segments`), exit codes (SystemSplit .. SystemSplit, Halted(0)) and
-    the journal — the session's final state word, canonical, 4 bytes little-endian — whose OUTPUT digest Output{journal, assumptions}
+    the journal — the bytes the guest commits (zeth: the 32-byte block hash, guests/stateless-client/src/lib.rs:33); None: the session's
+    final state word, canonical, 4 bytes little-endian — whose OUTPUT digest Output{journal, assumptions}
     the LAST segment binds; `assumptions` = [(claim digest, control root)] of the receipts the session assumes (`assumption_of`).
     -> (segments with their 19 public words, journal bytes)"""
     from dataclasses import replace
@@ -415,7 +417,7 @@ def chain_session(segments: Sequence[Segment], contribution: Callable[[Segment],
     for seg in segments:
         pres.append(state)
         state = (state + contribution(seg)) % P
-    journal = int(fp_decode(state)).to_bytes(4, "little")
+    journal = int(fp_decode(state)).to_bytes(4, "little") if journal is None else bytes(journal)
     out = [replace(seg, pub=session_pub_words(pre, i + 1 == len(segments), journal, assumptions)) for i, (seg, pre) in enumerate(zip(segments, pres))]
     return out, journal
 
@@ -529,6 +531,16 @@ class Receipt:
         if self.journal != int(fp_decode(self.inner.final_state())).to_bytes(4, "little"):
             raise HalError("receipt.verify: the journal is not the final state the last segment's seal binds")
 
+    def check_block_hash(self, block_hash) -> None:
+        """The CLI's last step after `receipt.verify(image_id)` (/root/reference/crates/host/src/bin/cli.rs:103-107): the journal decodes
+        as a 32-byte hash (`B256::try_from(journal)`) and is the hash of the block that was to be proven.  `block_hash`: bytes or 0x-hex.  Raises."""
+        from .hal import HalError
+        want = bytes.fromhex(block_hash[2:] if block_hash.startswith("0x") else block_hash) if isinstance(block_hash, str) else bytes(block_hash)
+        if len(self.journal) != 32:
+            raise HalError(f"failed to decode journal: {len(self.journal)} bytes, a block hash has 32")
+        if self.journal != want:
+            raise HalError("journal output mismatch")
+
     def to_upstream_bytes(self, circuit_desc, control_root=None) -> bytes:
         """upstream's bincode `Receipt{inner: Composite{..}, journal, metadata}`; SYN-S segments carry their REAL claim values"""
         return self.inner.to_upstream_bytes(circuit_desc, control_root, journal=self.journal)
@@ -551,13 +563,13 @@ class Receipt:
 
 
 def prove_chained_block(prove_segment: Callable[[Segment], SegmentReceipt], contribution: Callable[[Segment], int], circuit_desc,
-                        segments: Sequence[Segment], initial_state: int = 0, assumptions=()):
+                        segments: Sequence[Segment], initial_state: int = 0, assumptions=(), journal: Optional[bytes] = None):
     """`BlockProcessor::prove(input, po2) -> (Receipt, image id)` (/root/reference/crates/host/src/lib.rs:123-143) for a chained
     session on this rank: the executor's pass (pre-states; SYN-S: exit codes and the journal digest too), the segment seals, the
     composite with its journal."""
     from .hal import fp_decode
     if _is_session_circuit(circuit_desc):
-        chained, journal = chain_session(segments, contribution, initial_state, assumptions)
+        chained, journal = chain_session(segments, contribution, initial_state, assumptions, journal)
         comp = CompositeReceipt([prove_segment(s) for s in chained])
         verify_session_integrity(comp.segments, initial_state, journal, assumptions)
         return Receipt(comp, journal, tuple(assumptions)), image_id(circuit_desc, initial_state)
@@ -654,6 +666,11 @@ class Session:
         predecessors, one launch), proves the segments with those pre-states as public inputs, and `verify=True` additionally checks
         continuity (pre == prev.post) on the seals."""
         self._hal._check(self._hal._lib.zkh_session_set_chained(self.h, int(on), int(initial_state)))
+
+    def set_journal(self, journal: Optional[bytes]) -> None:
+        """SYN-S sessions: the bytes the guest commits (zeth: the block hash); the last seal binds their digest and `verify=True` checks
+        the seals against them.  None: the default, the session's final state word."""
+        self._hal._check(self._hal._lib.zkh_session_set_journal(self.h, None if journal is None else bytes(journal), 0 if journal is None else len(journal)))
 
     def set_resident_code(self, on: bool) -> None:
         """built-in circuits: keep the committed code group of each segment size resident per lane (default) or re-commit it per
