@@ -349,10 +349,18 @@ pub fn prove_segment_from_host_traces(hal: &HipHal, prover: *mut sys::ZkhProver,
 /// join3 — and, with assumptions, union / resolve — programs of a block with these segment sizes, BUILT by the library: no `.zkr` files), `zkh_session_prove(join_tree = 2)`
 /// (seals and fold as one pipeline), and the root receipt's seal back.  `desc` = the segment circuit (`zkh_shipped_circuit_desc`
 /// or the imported upstream tables), `segments` = (po2, seed) per segment, largest sizes first.
+///
+/// `chained` = Some((initial state, journal)) for a SYN-S circuit: the executor's pass gives every segment its pre-state and exit code, and the
+/// LAST seal binds Output{SHA-256(journal), assumptions} — `journal` = the bytes the guest commits, for zeth the 32-byte block hash
+/// (/root/reference/guests/stateless-client/src/lib.rs:33), which `cli.rs:103-107` then compares with `block.hash_slow()`.
 pub fn prove_session_succinct(devices: &[i32], lanes_per_device: usize, desc: &[u32], segments: &[(u32, u64)],
-                              assumptions: Option<(&[u32], &[AssumptionReceipt])>) -> Vec<u32> {
+                              assumptions: Option<(&[u32], &[AssumptionReceipt])>, chained: Option<(u32, &[u8])>) -> Vec<u32> {
     let mut session: *mut sys::ZkhSession = std::ptr::null_mut();
     ffi(|| unsafe { sys::zkh_session_create(devices.as_ptr(), devices.len(), lanes_per_device, desc.as_ptr(), desc.len(), std::ptr::null(), 0, &mut session) });
+    if let Some((initial_state, journal)) = chained {
+        ffi(|| unsafe { sys::zkh_session_set_chained(session, 1, initial_state) });
+        ffi(|| unsafe { sys::zkh_session_set_journal(session, journal.as_ptr(), journal.len()) });
+    }
     // `ProverServer::{union, resolve}`: the session's assumption receipts (keccak batches proven by `prove_keccak`) are handed over
     // BEFORE the programs are built; the executor lifts them, unites them pairwise and resolves the session's root against the union
     if let Some((adesc, receipts)) = assumptions {
