@@ -11,6 +11,13 @@
 //                 [--po2 20] [--tail-po2 18] [--segments 64]
 //                 [--devices 1] [--inflight 3] [--join-po2 18] [--noise-seed N] [--two-phase] [--recompute-code] [--no-join3]
 //                 [--csv FILE [--block-number N] [--gas-used N]] [--keccak-batches N [--keccak-po2 P]]
+//                 [--chained [--initial-state N] [--journal HEX]] [--receipts-dir DIR]
+// --chained (SYN-C / SYN-S circuits, e.g. --circuit syn_session): the library's executor pass gives every segment its pre-state (and, SYN-S, its
+// exit code; the last seal binds Output{SHA-256(journal), assumptions}) — zkh_session_set_chained; --journal HEX = the bytes the guest
+// commits, for zeth the 32-byte block hash (/root/reference/guests/stateless-client/src/lib.rs:33) — zkh_session_set_journal; default: the
+// session's final state word.  --receipts-dir DIR writes segment_<i>.zkr (zkh_receipt_encode) and prints the control roots, so that
+// `verify_receipts --circuit syn_session --receipts-dir DIR --control-root PO2:HEX .. --initial-state N --journal HEX` is the verifier's side
+// of /root/reference/crates/host/src/bin/cli.rs:103-107 with no GPU.
 // --keccak-batches N (with --build-recursion): the session ASSUMES N keccak batch receipts (KECCAK-F seals proven first, the shape
 // upstream's prove_keccak leaves behind): zkh_session_set_assumptions -> they are lifted, united pairwise (sorted pairs) and the
 // session's root is RESOLVED against the union root; the CSV's keccak_calls column counts their permutations.
@@ -54,6 +61,10 @@ int main(int argc, char** argv) {
     uint64_t noise = 0;
     bool two_phase = false, recompute_code = false, no_join3 = false;
     size_t keccak_batches = 0, keccak_po2 = 13;
+    bool chained = false, have_journal = false;
+    size_t initial_state = 0;
+    std::vector<uint8_t> journal;
+    std::string receipts_dir;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto num = [&](size_t& d) { if (i + 1 < argc) d = strtoull(argv[++i], nullptr, 10); };
@@ -74,6 +85,15 @@ int main(int argc, char** argv) {
         else if (a == "--noise-seed" && i + 1 < argc) noise = strtoull(argv[++i], nullptr, 0);
         else if (a == "--keccak-batches") num(keccak_batches);
         else if (a == "--keccak-po2") num(keccak_po2);
+        else if (a == "--chained") chained = true;
+        else if (a == "--initial-state") num(initial_state);
+        else if (a == "--receipts-dir" && i + 1 < argc) receipts_dir = argv[++i];
+        else if (a == "--journal" && i + 1 < argc) {
+            const std::string hex = argv[++i];
+            if (hex.size() % 2) { fprintf(stderr, "--journal wants an even number of hex digits\n"); return 2; }
+            for (size_t k = 0; k < hex.size(); k += 2) journal.push_back((uint8_t)strtoul(hex.substr(k, 2).c_str(), nullptr, 16));
+            have_journal = true;
+        }
         else if (a == "--no-join3") no_join3 = true;            // leave the join3 program out: three nodes cost two proofs
         else if (a == "--two-phase") two_phase = true;          // seal everything, then fold (default: one pipeline)
         else if (a == "--recompute-code") recompute_code = true; // re-commit the code group per segment, like upstream's SegmentProver
@@ -177,6 +197,16 @@ int main(int argc, char** argv) {
     const bool recursive = !rec_dir.empty() || build_recursion;
     if (two_phase) zkh_session_set_streamed_fold(session, 0);
     if (recompute_code) zkh_session_set_resident_code(session, 0);
+    if (chained) {
+        err = zkh_session_set_chained(session, 1, (uint32_t)initial_state);
+        if (err) { fprintf(stderr, "zkh_session_set_chained: %s\n", err); zkh_free_error(err); return 1; }
+    }
+    if (have_journal) {
+        if (!chained) { fprintf(stderr, "--journal needs --chained (the executor's pass is what writes the output digest into the last segment)\n"); return 2; }
+        static const uint8_t none = 0;                     // an empty journal is a journal: the pointer stays non-NULL
+        err = zkh_session_set_journal(session, journal.empty() ? &none : journal.data(), journal.size());
+        if (err) { fprintf(stderr, "zkh_session_set_journal: %s\n", err); zkh_free_error(err); return 1; }
+    }
     // the session's segment list: S distinct segments, the last one the short tail
     std::vector<zkh_segment> segs(n);
     for (size_t i = 0; i < n; i++) {
@@ -204,6 +234,37 @@ int main(int argc, char** argv) {
            zkh_version(), n, po2, segs[n - 1].po2, zkh_session_lanes(session), info.wall_s, info.leaves_s, n / info.leaves_s,
            1e3 * info.witgen_s_sum / n, info.n_lifts, info.lift_s, info.n_joins, info.join_s, info.n_lifts ? "true" : "false",
            info.root_seal_words, words, info.streamed ? "true" : "false", info.fold_tail_s, info.fold_busy_s_sum, info.n_retries, n_built ? "true" : "false", build_s, keccak_batches, keccak_batches ? "true" : "false", root_out.c_str());
+    if (!receipts_dir.empty()) {
+        // the receipts a verifier WITHOUT a GPU checks (examples/verify_receipts.cpp): one container per segment; the control root of each
+        // size comes from a prover of the circuit (a deployment ships them: upstream's control IDs)
+        zkh_ctx* c = nullptr; zkh_circuit* cir = nullptr; zkh_prover* p = nullptr;
+        if ((err = zkh_ctx_create(devs[0], "poseidon2", &c)) || (err = zkh_circuit_load(c, desc.data(), desc.size(), &cir)) || (err = zkh_prover_create(c, cir, &p))) {
+            fprintf(stderr, "receipts: %s\n", err); zkh_free_error(err); return 1;
+        }
+        uint32_t roots[32][8];
+        bool have[32] = {false};
+        for (size_t i = 0; i < info.n_segments; i++) {
+            const uint32_t q = segs[i].po2;
+            if (!have[q]) {
+                if ((err = zkh_syn_control_root(p, q, ZKH_ZK_CYCLES, roots[q]))) { fprintf(stderr, "control root: %s\n", err); zkh_free_error(err); return 1; }
+                have[q] = true;
+                fprintf(stderr, "control-root %u:", q);
+                for (int k = 0; k < 8; k++) fprintf(stderr, "%08x", roots[q][k]);
+                fprintf(stderr, "\n");
+            }
+            uint32_t* blob = nullptr;
+            size_t bw = 0;
+            if ((err = zkh_receipt_encode(cir, info.seals[i], info.seal_words[i], (uint32_t)i, roots[q], &blob, &bw))) {
+                fprintf(stderr, "zkh_receipt_encode: %s\n", err); zkh_free_error(err); return 1;
+            }
+            const std::string path = receipts_dir + "/segment_" + std::to_string(i) + ".zkr";
+            FILE* f = fopen(path.c_str(), "wb");
+            if (!f || fwrite(blob, 4, bw, f) != bw) { perror(path.c_str()); return 1; }
+            fclose(f);
+            zkh_free_seal(blob);
+        }
+        zkh_prover_destroy(p); zkh_circuit_destroy(cir); zkh_ctx_destroy(c);
+    }
     if (!csv_path.empty()) {
         unsigned long long total = 0, user = 0;
         for (size_t i = 0; i < n; i++) { total += 1ull << segs[i].po2; user += (1ull << segs[i].po2) - ZKH_ZK_CYCLES; }

@@ -572,3 +572,46 @@ def test_a_session_whose_journal_is_a_block_hash(hal, oracle, tmp_path):
     with pytest.raises(HalError, match="only a SYN-S circuit"):
         Session(syn_air.syn_small(), devices=(0,), lanes_per_device=1).set_journal(block_hash)
     sess.close()
+
+
+@pytest.mark.gpu
+def test_cpp_hosts_prove_and_verify_a_session_whose_journal_is_a_block_hash(tmp_path):
+    """The same flow with no Python in it: examples/prove_session --chained --journal <block hash> seals a SYN-S session on the GPU
+    (zkh_session_set_chained + zkh_session_set_journal) and writes its receipts; examples/verify_receipts — a host WITHOUT a GPU — accepts
+    them only for that journal, that initial state and all of the segments (/root/reference/crates/host/src/bin/cli.rs:103-107)."""
+    import re
+    import subprocess
+    from test_eth_header import BLOCK1_HASH, GENESIS_HASH
+    from zeth_amd import build
+    desc_path = tmp_path / "syn_session_small.desc"
+    np.asarray(syn_air.syn_session_small(), dtype="<u4").tofile(desc_path)
+    rdir = tmp_path / "receipts"
+    rdir.mkdir()
+    exe_dir = os.path.dirname(build.build_examples())
+    prove, verify = os.path.join(exe_dir, "prove_session"), os.path.join(exe_dir, "verify_receipts")
+    r = subprocess.run([prove, "--desc", str(desc_path), "--po2", "13", "--tail-po2", "12", "--segments", "3", "--inflight", "2", "--noise-seed", "9",
+                        "--chained", "--initial-state", "4", "--journal", BLOCK1_HASH[2:], "--receipts-dir", str(rdir)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["verified"] is True
+    roots = re.findall(r"^control-root (\d+):([0-9a-f]{64})$", r.stderr, re.M)
+    assert sorted(int(p) for p, _ in roots) == [12, 13]
+    base = [verify, "--desc", str(desc_path), "--receipts-dir", str(rdir)] + [x for p, h in roots for x in ("--control-root", f"{p}:{h}")]
+
+    def run(*extra):
+        return subprocess.run([*base, *extra], capture_output=True, text=True, timeout=300)
+    ok = run("--initial-state", "4", "--journal", BLOCK1_HASH[2:])
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    out = json.loads(ok.stdout.strip().splitlines()[-1])
+    assert out["verified"] == 3 and out["chained"] is True and out["gpu"] is False
+    for extra, why in ((("--initial-state", "4", "--journal", GENESIS_HASH[2:]), "journal does not hash"),      # another block's hash
+                       (("--initial-state", "4"), "journal does not hash"),                                     # the default journal (final state word)
+                       (("--initial-state", "4", "--journal", ""), "journal does not hash"),                    # an empty journal
+                       (("--initial-state", "5", "--journal", BLOCK1_HASH[2:]), "REJECTED")):                   # another initial state
+        bad = run(*extra)
+        assert bad.returncode != 0 and why in bad.stderr, (extra, bad.stderr[-600:])
+    os.remove(rdir / "segment_2.zkr")                                                                            # the halting segment cut off
+    cut = run("--initial-state", "4", "--journal", BLOCK1_HASH[2:])
+    assert cut.returncode != 0 and "Halted" in cut.stderr
+    # --journal without --chained is a usage error of the prover, not a silently ignored flag
+    r = subprocess.run([prove, "--desc", str(desc_path), "--po2", "13", "--segments", "1", "--journal", "00"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "--journal needs --chained" in r.stderr
