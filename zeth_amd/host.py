@@ -69,8 +69,10 @@ class CachedInput:
         return session_segments(self.total_cycles, segment_po2, base_seed)
 
 
-def read_cached_input(cache_dir: str, block_hash: str) -> CachedInput:
-    """`cache/input_<hash>.json` -> CachedInput (see the banner above for what is real and what is estimated)."""
+def read_cached_input(cache_dir: str, block_hash: str, check_hash: bool = True) -> CachedInput:
+    """`cache/input_<hash>.json` -> CachedInput (see the banner above for what is real and what is estimated).  check_hash (default): the
+    header must be complete and hash to `block_hash`, as cli.rs:141 insists; False accepts a file whose header cannot be hashed (a stub
+    that only carries `gasUsed`) and says so in `hash_checked`."""
     import json
     import os
     path = os.path.join(cache_dir, f"input_{block_hash}.json")
@@ -91,6 +93,8 @@ def read_cached_input(cache_dir: str, block_hash: str) -> CachedInput:
         checked = True
         number = header["number"]
         number = int(number, 16) if isinstance(number, str) and number.startswith("0x") else int(number)
+    elif check_hash:
+        raise ValueError(f"{path}: the block header is incomplete: its hash cannot be re-derived (pass check_hash=False for a stub input)")
     size = os.path.getsize(path)
     side = os.path.join(cache_dir, f"input_{block_hash}.cycles.json")
     keccak = None
