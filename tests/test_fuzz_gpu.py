@@ -1,7 +1,10 @@
 """Seeded random shape sweep of the HAL ops against the CPU oracle (bit-exact), complementing the fixed shapes of
 test_hal_parity_gpu.py: ragged sizes, column counts around the sponge rate, sizes around the 256-wide scan blocks and
 the kernels' path switches (2^12 / 2^18 / 2^20 transforms, 2^7 / 2^15 Merkle layers).  Inputs mix uniform elements
-with runs of 0 and P-1.  The seeds are fixed, so a failure reproduces."""
+with runs of 0 and P-1.  The seeds are fixed, so a failure reproduces.  ZKH_FUZZ_SEED_OFFSET=N shifts every seed by N: a soak
+over fresh shapes on spare GPU time (`tools/gpu.sh fuzzsoak`); unset (the suite) = offset 0."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +12,7 @@ import zko
 from conftest import P, rand_fp
 
 pytestmark = pytest.mark.gpu
+OFF = int(os.environ.get("ZKH_FUZZ_SEED_OFFSET", "0"))
 
 
 def eq(a, b):
@@ -30,7 +34,7 @@ def spicy(rng, n):
 
 @pytest.mark.parametrize("seed", range(48))
 def test_fuzz_ntt(hal, oracle, seed):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + seed + OFF)
     log_n = int(rng.choice([1, 2, 3, 5, 7, 9, 11, 12, 13, 14, 16, 17, 18, 19, 20]))
     count = int(rng.integers(1, 4)) if log_n >= 18 else int(rng.integers(1, 7))
     n = 1 << log_n
@@ -51,7 +55,7 @@ def test_fuzz_ntt(hal, oracle, seed):
 
 @pytest.mark.parametrize("seed", range(48))
 def test_fuzz_hash_rows_and_tree(hal, oracle, seed):
-    rng = np.random.default_rng(2000 + seed)
+    rng = np.random.default_rng(2000 + seed + OFF)
     rows = 1 << int(rng.integers(1, 17))
     cols = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 64, 100, 208]))
     m = spicy(rng, rows * cols)
@@ -69,7 +73,7 @@ def test_fuzz_hash_rows_and_tree(hal, oracle, seed):
 
 @pytest.mark.parametrize("seed", range(40))
 def test_fuzz_evaluate_and_mix(hal, oracle, seed):
-    rng = np.random.default_rng(3000 + seed)
+    rng = np.random.default_rng(3000 + seed + OFF)
     po = int(rng.choice([1, 3, 255, 256, 257, 1000, 4096, 16383, 16384, 16385, 40000]))
     polys, evals = int(rng.integers(1, 6)), int(rng.integers(1, 9))
     coeffs = spicy(rng, po * polys)
@@ -95,7 +99,7 @@ def test_fuzz_evaluate_and_mix(hal, oracle, seed):
 
 @pytest.mark.parametrize("seed", range(40))
 def test_fuzz_scans_and_fold(hal, oracle, seed):
-    rng = np.random.default_rng(4000 + seed)
+    rng = np.random.default_rng(4000 + seed + OFF)
     n = int(rng.choice([1, 2, 3, 255, 256, 257, 511, 65535, 65536, 65537, 100000]))
     x = spicy(rng, 4 * n)
     want = x.copy()
@@ -136,7 +140,7 @@ def test_fuzz_whole_seals(hal, oracle, seed, tmp_path, monkeypatch):
     from zeth_amd.circuits import syn_air
     from zeth_amd.prover import Segment, SegmentProver
     monkeypatch.setenv("ZKH_JIT_CACHE", str(tmp_path))
-    rng = np.random.default_rng(5000 + seed)
+    rng = np.random.default_rng(5000 + seed + OFF)
     wc, wd, wa = int(rng.integers(5, 20)), int(rng.integers(8, 120)), 4 * int(rng.integers(1, 6))
     po2 = int(rng.integers(9, 14))
     zk = int(rng.integers(50, min(1994, (1 << po2) - 64)))
@@ -174,9 +178,9 @@ def test_fuzz_eval_check_random_circuits(hal, oracle, seed, tmp_path, monkeypatc
     import ctypes as C
     from zeth_amd.circuits import syn_random
     monkeypatch.setenv("ZKH_JIT_CACHE", str(tmp_path))
-    rng = np.random.default_rng(7000 + seed)
+    rng = np.random.default_rng(7000 + seed + OFF)
     groups = [(4, 6, 12), (8, 5, 20), (4, 16, 33)][seed % 3]
-    desc = syn_random.random_circuit(seed, groups=groups, n_values=160 + 40 * (seed % 4), n_constraints=30 + 15 * (seed % 3),
+    desc = syn_random.random_circuit(seed + OFF, groups=groups, n_values=160 + 40 * (seed % 4), n_constraints=30 + 15 * (seed % 3),
                                      max_back=1 + seed % 4)
     circ = hal.load_circuit(desc, jit=True)
     assert circ.kernel_kind() == "attached"

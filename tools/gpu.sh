@@ -18,6 +18,8 @@
 #                refuse), the in-process launcher (--launcher session, 8 devices x 1 lane and 1 device x 3 lanes), the RCCL probe at world 1
 #   huge         SYN-HUGE (> 250 k steps, > 2 k taps, ~15 k constraints) loaded as data: generator / hipcc / code-object figures, eval_check and
 #                seal ms at po2 20, three evaluators + extreme vectors (tools/syn_huge_report.py); the same report for SYN-HEAVY beside it
+#   fuzzsoak     tests/test_fuzz_gpu.py over FRESH seeds (ZKH_FUZZ_SEED_OFFSET = 10000, 20000, ...; args: name, rounds): spare GPU minutes spent
+#                on shapes the suite never saw; one summary line per round
 #   profiles     everything profiles/ holds (tools/collect_profiles.sh)
 #   big          po2 21 / 22 segments
 #   soak         1000 distinct segments through the g++ driver
@@ -82,6 +84,13 @@ json.dump(out, open(f"{O}/repro_summary.json", "w"), indent=1)
 print(json.dumps(out))
 PY
   ;;
+fuzzsoak)
+  O=gpurun_out/${1:-fuzzsoak}; mkdir -p $O
+  for k in $(seq 1 ${2:-6}); do
+    off=$((k * 10000))
+    ZKH_FUZZ_SEED_OFFSET=$off timeout 900 python -m pytest tests/test_fuzz_gpu.py -m gpu -q -p no:cacheprovider > $O/offset_$off.log 2>&1
+    echo "offset $off rc=$? $(tail -1 $O/offset_$off.log)"
+  done | tee $O/summary.txt ;;
 devices)
   O=gpurun_out/${1:-devices}; mkdir -p $O
   ( time timeout 900 python bench.py --gpus 8 --steps 6 --warmup 1 --no-heavy --allow-shared-gpu > $O/bench_8rank_one_gpu.json 2> $O/bench_8rank.err ) 2> $O/bench_8rank.time; line $O/bench_8rank_one_gpu.json
