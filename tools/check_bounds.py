@@ -54,11 +54,11 @@ def check_desc(name: str, desc) -> Tuple[List[str], dict]:
     return violations, total
 
 
-def fuzz_descs(count: int):
+def fuzz_descs(count: int, first: int = 0):
     """the random constraint systems tests/test_fuzz_gpu.py runs through three evaluators (same generator arguments), and more"""
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from zeth_amd.circuits import syn_random
-    for seed in range(count):
+    for seed in range(first, first + count):
         groups = [(4, 6, 12), (8, 5, 20), (4, 16, 33)][seed % 3]
         yield f"fuzz{seed}", syn_random.random_circuit(seed, groups=groups, n_values=160 + 40 * (seed % 4), n_constraints=30 + 15 * (seed % 3),
                                                        max_back=1 + seed % 4)
@@ -68,6 +68,7 @@ def main() -> int:
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("--circuit", action="append", help="a shipped circuit by name (default: all of codegen.shipped())")
     ap.add_argument("--fuzz", type=int, default=0, help="also the first N random constraint systems")
+    ap.add_argument("--fuzz-from", type=int, default=0, help="the first random seed of --fuzz (a soak over seeds the test suite does not use)")
     ap.add_argument("--files", nargs="*", help="generated translation units on disk instead of running the generator")
     a = ap.parse_args()
     bad: List[str] = []
@@ -81,7 +82,7 @@ def main() -> int:
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from zeth_amd.circuits import codegen
         todo = [(n, d) for n, d in codegen.shipped().items() if not a.circuit or n in a.circuit]
-        todo += list(fuzz_descs(a.fuzz))
+        todo += list(fuzz_descs(a.fuzz, a.fuzz_from))
         for name, desc in todo:
             v, st = check_desc(name, desc)
             print(f"{name:14s} kernels {st['kernels']:3d}  statements {st['statements']:7d}  reductions {st['reductions']:7d}  claims {st['claims']:6d}  "
