@@ -575,8 +575,9 @@ extern "C" const char* zkh_session_build_recursion(zkh_session* s, const uint32_
         for (uint32_t a : ss)
             for (uint32_t b : all) {
                 if (built.size() < REC_ALLOWED) ZKH_TRY(add(5, rdesc, rdesc_words, {a, b}, nullptr, a, b));
-                else ZKH_REQUIRE(a != ss[0], "session_build_recursion: the allowed set (%zu programs) has no room for resolve(%u, %u): this block's segment sizes give "
-                                 "%zu program sizes (their join closure alone is %zu programs); pass with_join3 = 0", REC_ALLOWED, a, b, ss.size(), ss.size() * ss.size());
+                else ZKH_REQUIRE(a != ss[0], "session_build_recursion: the allowed set (%zu programs) has no room for resolve(%u, %u): this circuit's lift / lift2 / join "
+                                 "programs come in %zu sizes (their join closure alone is %zu programs)%s", REC_ALLOWED, a, b, ss.size(), ss.size() * ss.size(),
+                                 with_join3 ? "; pass with_join3 = 0" : ": a circuit this narrow cannot resolve assumptions within one allowed set (the BASELINE widths give two sizes)");
             }
     }
     ZKH_REQUIRE(built.size() <= REC_ALLOWED, "session_build_recursion: %zu programs do not fit the allowed set", built.size());
