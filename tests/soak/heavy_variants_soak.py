@@ -8,8 +8,8 @@ factor grouping, LINFORM and the signed sums of DESIGN.md §4b act on).  The shi
   (GPU)   per variant: generated (hipcc, attached at load time) == on-device interpreter == oracle on five input families at po2 6,
           and one po2-9 seal byte for byte against the oracle's
 
-    python tools/heavy_variants_soak.py --cpu --first 0 --count 40
-    python tools/heavy_variants_soak.py --first 100 --count 25          # on an MI355X
+    python tests/soak/heavy_variants_soak.py --cpu --first 0 --count 40
+    python tests/soak/heavy_variants_soak.py --first 100 --count 25          # on an MI355X
 One JSON line at the end; a problem prints its variant's parameters (they reproduce it) and the exit code is 1.
 """
 import argparse
@@ -21,7 +21,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
     sys.path.insert(0, p)
 P = 2013265921

@@ -12,7 +12,7 @@ library has never seen is loaded: as DATA, generated + compiled at load time (ci
        instructions per point per ms, one whole po2-20 seal (ms, verified by the host verifier), and generated == interpreter ==
        oracle on a small segment + the extreme vectors (tests/test_maximal_vectors_gpu.py's patterns).
 
-    python tools/syn_huge_report.py [--circuit syn_huge|syn_heavy] [--no-gpu] [--po2 20] > report.json
+    python tests/soak/syn_huge_report.py [--circuit syn_huge|syn_heavy] [--no-gpu] [--po2 20] > report.json
 """
 import argparse
 import json
@@ -21,7 +21,7 @@ import sys
 import tempfile
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -17,7 +17,7 @@
 #   devices      N > 1 readiness on ONE GPU: 8 ranks sharing it (--allow-shared-gpu; config.devices), the same without the flag (must
 #                refuse), the in-process launcher (--launcher session, 8 devices x 1 lane and 1 device x 3 lanes), the RCCL probe at world 1
 #   huge         SYN-HUGE (> 250 k steps, > 2 k taps, ~15 k constraints) loaded as data: generator / hipcc / code-object figures, eval_check and
-#                seal ms at po2 20, three evaluators + extreme vectors (tools/syn_huge_report.py); the same report for SYN-HEAVY beside it
+#                seal ms at po2 20, three evaluators + extreme vectors (tests/soak/syn_huge_report.py); the same report for SYN-HEAVY beside it
 #   fuzzsoak     tests/test_fuzz_gpu.py over FRESH seeds (ZKH_FUZZ_SEED_OFFSET = 10000, 20000, ...; args: name, rounds): spare GPU minutes spent
 #                on shapes the suite never saw; one summary line per round
 #   profiles     everything profiles/ holds (tools/collect_profiles.sh)
@@ -113,8 +113,8 @@ PY
   grep real $O/*.time; for f in $O/*.err; do grep -v amdgpu.ids $f | tail -2; done ;;
 huge)
   O=gpurun_out/${1:-huge}; mkdir -p $O
-  ( time timeout 1500 python tools/syn_huge_report.py --circuit syn_huge > $O/syn_huge_report.json 2> $O/syn_huge.err ) 2> $O/syn_huge.time
-  ( time timeout 900 python tools/syn_huge_report.py --circuit syn_heavy > $O/syn_heavy_report.json 2> $O/syn_heavy.err ) 2> $O/syn_heavy.time
+  ( time timeout 1500 python tests/soak/syn_huge_report.py --circuit syn_huge > $O/syn_huge_report.json 2> $O/syn_huge.err ) 2> $O/syn_huge.time
+  ( time timeout 900 python tests/soak/syn_huge_report.py --circuit syn_heavy > $O/syn_heavy_report.json 2> $O/syn_heavy.err ) 2> $O/syn_heavy.time
   python - $O <<'PY'
 import json, sys
 for n in ("syn_huge", "syn_heavy"):

@@ -195,7 +195,7 @@ def syn_heavy() -> np.ndarray:
 def syn_huge() -> np.ndarray:
     """SYN-HUGE: SYN-A's trace under a constraint system of a real circuit's size (> 250 k steps, > 2 k taps at backs 0 .. 7,
     > 14 k degree-5 constraints).  Not compiled into the library: it is DATA, loaded like any circuit the library has never seen
-    (generated + compiled at load time, parts in parallel: circuits/jit.py) — `tools/syn_huge_report.py` measures that path."""
+    (generated + compiled at load time, parts in parallel: circuits/jit.py) — `tests/soak/syn_huge_report.py` measures that path."""
     if "huge" not in _CACHE:
         _CACHE["huge"] = build_syn_heavy(per_triple=218, seed=0x48554745, huge=True)
     return _CACHE["huge"]
