@@ -128,7 +128,7 @@ for n in ("syn_huge", "syn_heavy"):
     except Exception as e:
         print(n, "no report:", e)
 PY
-  grep real $O/*.time; tail -3 $O/syn_huge.err | grep -v amdgpu.ids ;;
+  grep real $O/*.time; tail -3 $O/syn_huge.err | grep -v amdgpu.ids || true ;;
 chained)
   O=gpurun_out/${1:-chained}; mkdir -p $O        # a chained block (claim continuity) and the same block with the host-preflight witness, full size
   timeout 600 python bench.py --config block --chained --no-cpu-baseline > $O/bench_block_chained.json 2> $O/err.txt; line $O/bench_block_chained.json
